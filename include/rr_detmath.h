@@ -1,0 +1,313 @@
+/* rr_detmath.h -- the deterministic arithmetic contract ("D-spec") of the engine.
+ *
+ * Every transcendental the hot path needs (exp, log, sin/cos, atan2) and the
+ * counter-based noise source (Philox4x32-10 -> Box-Muller) are written here as a
+ * fixed sequence of IEEE-754 binary64 operations: +, -, *, /, sqrt, fma,
+ * round-to-nearest-even and integer bit manipulation.  Those primitives are
+ * correctly rounded on both x86-64 and gfx950, so a translation unit compiled
+ * with floating-point contraction OFF (-ffp-contract=off) produces bit-identical
+ * results on the host CPU and on the MI355X.  The HIP kernels
+ * (rust_robotics_amd/csrc) and the deterministic CPU restatement
+ * (oracle/det_spec.c) both include this header; the literal restatement of the
+ * reference (oracle/ref_literal.c) does NOT -- it uses libm exactly like the
+ * reference uses Rust's std f64 methods, so a defect in this header shows up
+ * as a tolerance failure between the two oracles (tests/test_detmath.py).
+ *
+ * Reference call sites these replace (all under /root/reference/crates):
+ *   f64::exp   rust_robotics_localization/src/particle_filter.rs:476-479
+ *              rust_robotics_slam/src/fastslam1.rs:180
+ *   f64::sin/cos  particle_filter.rs:292-293, fastslam1.rs:73-74,146-147
+ *   f64::atan2    fastslam1.rs:97
+ *   rand_distr::Normal  particle_filter.rs:259-287, fastslam1.rs:124-131
+ *     (the reference RNG is the unseedable thread-local ChaCha12; the engine
+ *      owns its noise source)
+ *
+ * Accuracy (measured against mpmath in tests/test_detmath.py): <= 2.5 ulp for
+ * exp/sin/cos/atan2/log on the ranges the path uses.
+ */
+#ifndef RR_DETMATH_H
+#define RR_DETMATH_H
+
+#include <stdint.h>
+#include "rr_detmath_consts.h"
+
+#if defined(__HIPCC__)
+#define RR_HD __host__ __device__ static inline
+#else
+#define RR_HD static inline
+#endif
+
+RR_HD double rr_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+RR_HD double rr_rint(double x) { return __builtin_rint(x); }
+RR_HD double rr_sqrt(double x) { return __builtin_sqrt(x); }
+RR_HD double rr_fabs(double x) { return __builtin_fabs(x); }
+
+RR_HD uint64_t rr_d2u(double x) {
+  uint64_t u;
+  __builtin_memcpy(&u, &x, 8);
+  return u;
+}
+RR_HD double rr_u2d(uint64_t u) {
+  double x;
+  __builtin_memcpy(&x, &u, 8);
+  return x;
+}
+
+/* 2^k for k in [-1022, 1023] */
+RR_HD double rr_pow2i(int k) { return rr_u2d((uint64_t)(k + 1023) << 52); }
+
+/* p * 2^k, k in [-2098, 2046]; two exact-power multiplies, the second one may
+ * round (subnormal result) or overflow exactly as IEEE prescribes. */
+RR_HD double rr_scale2(double p, int k) {
+  int k1 = k / 2;
+  int k2 = k - k1;
+  return (p * rr_pow2i(k1)) * rr_pow2i(k2);
+}
+
+/* ------------------------------------------------------------------ exp */
+RR_HD double rr_exp(double x) {
+  if (x != x) return x;
+  if (x > 709.782712893384) return rr_u2d(0x7ff0000000000000ull);
+  if (x < -745.1332191019412) return 0.0;
+  double k = rr_rint(x * RR_LOG2E);
+  double r = rr_fma(-k, RR_LN2_HI, x);
+  r = rr_fma(-k, RR_LN2_LO, r);
+  double p = RR_EXP_C_12;
+  p = rr_fma(p, r, RR_EXP_C_11);
+  p = rr_fma(p, r, RR_EXP_C_10);
+  p = rr_fma(p, r, RR_EXP_C_9);
+  p = rr_fma(p, r, RR_EXP_C_8);
+  p = rr_fma(p, r, RR_EXP_C_7);
+  p = rr_fma(p, r, RR_EXP_C_6);
+  p = rr_fma(p, r, RR_EXP_C_5);
+  p = rr_fma(p, r, RR_EXP_C_4);
+  p = rr_fma(p, r, RR_EXP_C_3);
+  p = rr_fma(p, r, RR_EXP_C_2);
+  p = rr_fma(p, r, RR_EXP_C_1);
+  p = rr_fma(p, r, RR_EXP_C_0);
+  return rr_scale2(p, (int)k);
+}
+
+/* ------------------------------------------------------------------ log (x > 0) */
+RR_HD double rr_log(double x) {
+  if (x != x || x < 0.0) return rr_u2d(0x7ff8000000000000ull);
+  if (x == 0.0) return rr_u2d(0xfff0000000000000ull);
+  uint64_t u = rr_d2u(x);
+  if (u >= 0x7ff0000000000000ull) return x; /* +inf */
+  int e = 0;
+  if (u < 0x0010000000000000ull) { /* subnormal */
+    x = x * 0x1p54;
+    u = rr_d2u(x);
+    e = -54;
+  }
+  e += (int)(u >> 52) - 1023;
+  double m = rr_u2d((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull); /* [1,2) */
+  if (m > RR_SQRT2) {
+    m = m * 0.5;
+    e += 1;
+  }
+  double f = m - 1.0;
+  double s = f / (2.0 + f);
+  double z = s * s;
+  double p = RR_LOG_C_9;
+  p = rr_fma(p, z, RR_LOG_C_8);
+  p = rr_fma(p, z, RR_LOG_C_7);
+  p = rr_fma(p, z, RR_LOG_C_6);
+  p = rr_fma(p, z, RR_LOG_C_5);
+  p = rr_fma(p, z, RR_LOG_C_4);
+  p = rr_fma(p, z, RR_LOG_C_3);
+  p = rr_fma(p, z, RR_LOG_C_2);
+  p = rr_fma(p, z, RR_LOG_C_1);
+  p = rr_fma(p, z, RR_LOG_C_0);
+  /* atanh(s) = s + s*z*p ; log(m) = 2 atanh(s) */
+  double t = s * z;
+  double lm = 2.0 * rr_fma(t, p, s);
+  double de = (double)e;
+  return rr_fma(de, RR_LN2_HI, rr_fma(de, RR_LN2_LO, lm));
+}
+
+/* ------------------------------------------------------------------ sin/cos kernels, |r| <= pi/4 */
+RR_HD double rr_sin_kernel(double r) {
+  double s = r * r;
+  double p = RR_SIN_C_7;
+  p = rr_fma(p, s, RR_SIN_C_6);
+  p = rr_fma(p, s, RR_SIN_C_5);
+  p = rr_fma(p, s, RR_SIN_C_4);
+  p = rr_fma(p, s, RR_SIN_C_3);
+  p = rr_fma(p, s, RR_SIN_C_2);
+  p = rr_fma(p, s, RR_SIN_C_1);
+  p = rr_fma(p, s, RR_SIN_C_0);
+  return rr_fma(r * s, p, r);
+}
+RR_HD double rr_cos_kernel(double r) {
+  double s = r * r;
+  double p = RR_COS_C_7;
+  p = rr_fma(p, s, RR_COS_C_6);
+  p = rr_fma(p, s, RR_COS_C_5);
+  p = rr_fma(p, s, RR_COS_C_4);
+  p = rr_fma(p, s, RR_COS_C_3);
+  p = rr_fma(p, s, RR_COS_C_2);
+  p = rr_fma(p, s, RR_COS_C_1);
+  p = rr_fma(p, s, RR_COS_C_0);
+  return rr_fma(s * s, p, rr_fma(-0.5, s, 1.0));
+}
+
+RR_HD void rr_quadrant(int q, double sr, double cr, double* s, double* c) {
+  switch (q & 3) {
+    case 0: *s = sr;  *c = cr;  break;
+    case 1: *s = cr;  *c = -sr; break;
+    case 2: *s = -sr; *c = -cr; break;
+    default: *s = -cr; *c = sr; break;
+  }
+}
+
+/* sin and cos of x; 3-term fma Cody-Waite reduction, intended for |x| < ~1e6
+ * (yaw angles); beyond 2^30 the result is defined (deterministic) but loses
+ * accuracy.  Non-finite x -> NaN for both. */
+RR_HD void rr_sincos(double x, double* s, double* c) {
+  if (!(rr_fabs(x) < 0x1p30)) {
+    if (x != x || rr_fabs(x) == rr_u2d(0x7ff0000000000000ull)) {
+      *s = *c = rr_u2d(0x7ff8000000000000ull);
+      return;
+    }
+    /* deterministic fold of huge finite arguments (|x| >= 2^30 never occurs for
+     * yaw angles; the result is defined, not accurate): x -= 2pi*rint(x/2pi),
+     * each pass removes ~52 bits of magnitude */
+    for (int it = 0; it < 40 && !(rr_fabs(x) < 0x1p30); ++it) {
+      double n = rr_rint(x / RR_TWO_PI);
+      x = rr_fma(-n, RR_TWO_PI, x);
+    }
+  }
+  double k = rr_rint(x * RR_TWO_OVER_PI);
+  double r = rr_fma(-k, RR_PIO2_1, x);
+  r = rr_fma(-k, RR_PIO2_2, r);
+  r = rr_fma(-k, RR_PIO2_3, r);
+  int q = (int)((long long)k & 3);
+  rr_quadrant(q, rr_sin_kernel(r), rr_cos_kernel(r), s, c);
+}
+
+/* sin(2 pi u), cos(2 pi u) for u in [0,1): exact quadrant split of u. */
+RR_HD void rr_sincos2pi(double u, double* s, double* c) {
+  double q = rr_rint(4.0 * u);
+  double f = rr_fma(-0.25, q, u); /* exact, |f| <= 1/8 */
+  double r = f * RR_TWO_PI;
+  rr_quadrant((int)q, rr_sin_kernel(r), rr_cos_kernel(r), s, c);
+}
+
+/* ------------------------------------------------------------------ atan2 */
+/* atan of t in [0, +inf) (t == +inf allowed) */
+RR_HD double rr_atan_pos(double y, double x) {
+  /* returns atan(y/x) for y >= 0, x >= 0, not both zero/inf handled by caller */
+  int swap = y > x;
+  double num = swap ? x : y;
+  double den = swap ? y : x;
+  double t = num / den; /* in [0,1] */
+  double base_hi = 0.0, base_lo = 0.0;
+  if (t > RR_TAN_PIO8) {
+    t = (t - 1.0) / (t + 1.0); /* atan(t) = pi/4 + atan(t') */
+    base_hi = RR_PIO4_HI;
+    base_lo = RR_PIO4_LO;
+  }
+  double z = t * t;
+  double p = RR_ATAN_C_13;
+  p = rr_fma(p, z, RR_ATAN_C_12);
+  p = rr_fma(p, z, RR_ATAN_C_11);
+  p = rr_fma(p, z, RR_ATAN_C_10);
+  p = rr_fma(p, z, RR_ATAN_C_9);
+  p = rr_fma(p, z, RR_ATAN_C_8);
+  p = rr_fma(p, z, RR_ATAN_C_7);
+  p = rr_fma(p, z, RR_ATAN_C_6);
+  p = rr_fma(p, z, RR_ATAN_C_5);
+  p = rr_fma(p, z, RR_ATAN_C_4);
+  p = rr_fma(p, z, RR_ATAN_C_3);
+  p = rr_fma(p, z, RR_ATAN_C_2);
+  p = rr_fma(p, z, RR_ATAN_C_1);
+  p = rr_fma(p, z, RR_ATAN_C_0);
+  double a = base_hi + (rr_fma(t * z, p, t) + base_lo);
+  if (swap) a = RR_PIO2_1 - (a - RR_PIO2_2);
+  return a;
+}
+
+RR_HD double rr_atan2(double y, double x) {
+  if (x != x || y != y) return rr_u2d(0x7ff8000000000000ull);
+  const double inf = rr_u2d(0x7ff0000000000000ull);
+  uint64_t sy = rr_d2u(y) & 0x8000000000000000ull;
+  int xneg = (rr_d2u(x) >> 63) != 0;
+  double ay = rr_fabs(y), ax = rr_fabs(x);
+  double a;
+  if (ay == 0.0) {
+    a = xneg ? RR_PI_HI : 0.0;
+  } else if (ax == 0.0) {
+    a = RR_PIO2_1;
+  } else if (ax == inf || ay == inf) {
+    if (ax == inf && ay == inf) a = xneg ? 3.0 * RR_PIO4_HI : RR_PIO4_HI;
+    else if (ax == inf) a = xneg ? RR_PI_HI : 0.0;
+    else a = RR_PIO2_1;
+  } else {
+    a = rr_atan_pos(ay, ax);
+    if (xneg) a = RR_PI_HI - (a - RR_PI_LO);
+  }
+  return rr_u2d(rr_d2u(a) | sy);
+}
+
+/* ------------------------------------------------------------------ Philox4x32-10 */
+/* Salmon et al., "Parallel random numbers: as easy as 1, 2, 3" (SC'11);
+ * constants are the published ones. */
+#define RR_PHILOX_M0 0xD2511F53u
+#define RR_PHILOX_M1 0xCD9E8D57u
+#define RR_PHILOX_W0 0x9E3779B9u
+#define RR_PHILOX_W1 0xBB67AE85u
+
+typedef struct rr_philox4 {
+  uint32_t v[4];
+} rr_philox4;
+
+RR_HD rr_philox4 rr_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  for (int i = 0; i < 10; ++i) {
+    uint64_t p0 = (uint64_t)RR_PHILOX_M0 * c0;
+    uint64_t p1 = (uint64_t)RR_PHILOX_M1 * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += RR_PHILOX_W0;
+    k1 += RR_PHILOX_W1;
+  }
+  rr_philox4 r;
+  r.v[0] = c0; r.v[1] = c1; r.v[2] = c2; r.v[3] = c3;
+  return r;
+}
+
+/* Streams of the engine: what a (seed, stream, step, index) counter is used for. */
+enum {
+  RR_STREAM_INIT_XY = 1,   /* initial cloud jitter x,y      (particle_filter.rs:182-183) */
+  RR_STREAM_INIT_YV = 2,   /* initial cloud jitter yaw,v    (particle_filter.rs:184-185) */
+  RR_STREAM_MOTION = 3,    /* (n_v, n_w) per particle/step  (particle_filter.rs:280-287; fastslam1.rs:129-130) */
+  RR_STREAM_RESAMPLE = 4,  /* per-draw uniform / r0         (particle_filter.rs:456; fastslam1.rs:219-220) */
+  RR_STREAM_SIM = 5        /* observation simulator noise   (fastslam1.rs:291-292) */
+};
+
+/* two uniforms in [0,1) with 53 random bits each */
+RR_HD void rr_uniform2(uint64_t seed, uint32_t stream, uint32_t step, uint64_t index, double* u0, double* u1) {
+  rr_philox4 r = rr_philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), step, stream,
+                                  (uint32_t)seed, (uint32_t)(seed >> 32));
+  uint64_t a = ((uint64_t)r.v[1] << 32) | r.v[0];
+  uint64_t b = ((uint64_t)r.v[3] << 32) | r.v[2];
+  *u0 = (double)(a >> 11) * 0x1p-53;
+  *u1 = (double)(b >> 11) * 0x1p-53;
+}
+
+/* two independent N(0,1) draws (Box-Muller on the two uniforms above) */
+RR_HD void rr_normal2(uint64_t seed, uint32_t stream, uint32_t step, uint64_t index, double* z0, double* z1) {
+  double u0, u1;
+  rr_uniform2(seed, stream, step, index, &u0, &u1);
+  double v = 1.0 - u0; /* (0,1], exact */
+  double rad = rr_sqrt(-2.0 * rr_log(v));
+  double s, c;
+  rr_sincos2pi(u1, &s, &c);
+  *z0 = rad * c;
+  *z1 = rad * s;
+}
+
+#endif /* RR_DETMATH_H */

@@ -1,0 +1,336 @@
+/* rr_pf_spec.h -- per-element arithmetic of the deterministic spec ("D-spec").
+ *
+ * One particle (or one particle x landmark pair) at a time, as `static inline`
+ * functions that compile for the host (gcc/clang) and for gfx950 (hipcc).  The
+ * HIP kernels call these from device code; oracle/det_spec.c calls the very same
+ * functions from plain serial loops, so "GPU == D-spec" is a statement about the
+ * kernels' plumbing (indexing, LDS staging, reductions, scans, gathers), and
+ * "D-spec ~= reference" (tolerance 1e-6, the reference's own gate convention,
+ * scripts/check_benchmark_gate.py:34-35) is checked against oracle/ref_literal.c,
+ * which shares nothing with this file.
+ *
+ * All citations are /root/reference/crates/... file:line.
+ */
+#ifndef RR_PF_SPEC_H
+#define RR_PF_SPEC_H
+
+#include "rr_detmath.h"
+
+/* ===================================================================== PF / MCL */
+
+/* rust_robotics_localization/src/particle_filter.rs:279-296 (same arithmetic in
+ * monte_carlo_localization.rs:236-253).  nv, nw are the already scaled noise
+ * samples (sigma * z), exactly 0.0 when the sigma is 0 (Q5).  yaw is NOT wrapped
+ * (Q3).  Operation order (v*cos)*dt as the reference (Q4); the final add is fused. */
+RR_HD void rr_pf_propagate_one(double* x, double* y, double* yaw, double* v,
+                               double u0, double u1, double dt, double nv, double nw) {
+  double v_noisy = u0 + nv;
+  double w_noisy = u1 + nw;
+  double s, c;
+  rr_sincos(*yaw, &s, &c);
+  *x = rr_fma(v_noisy * c, dt, *x);
+  *y = rr_fma(v_noisy * s, dt, *y);
+  *yaw = rr_fma(w_noisy, dt, *yaw);
+  *v = v_noisy;
+}
+
+/* Scaled motion noise of particle `gid` at step `step` (replaces the unseedable
+ * rand::rng() draws of particle_filter.rs:280-287). */
+RR_HD void rr_pf_motion_noise(uint64_t seed, uint32_t step, uint64_t gid,
+                              double sigma_v, double sigma_w, double* nv, double* nw) {
+  double z0, z1;
+  rr_normal2(seed, RR_STREAM_MOTION, step, gid, &z0, &z1);
+  *nv = sigma_v > 0.0 ? sigma_v * z0 : 0.0;
+  *nw = sigma_w > 0.0 ? sigma_w * z1 : 0.0;
+}
+
+/* Initial cloud jitter, particle_filter.rs:181-185 (MCL: monte_carlo_localization.rs:190-194). */
+RR_HD void rr_pf_init_one(uint64_t seed, uint64_t gid, const double st[4],
+                          double* x, double* y, double* yaw, double* v) {
+  double a, b, c, d;
+  rr_uniform2(seed, RR_STREAM_INIT_XY, 0, gid, &a, &b);
+  rr_uniform2(seed, RR_STREAM_INIT_YV, 0, gid, &c, &d);
+  *x = st[0] + a * 2.0 - 1.0;
+  *y = st[1] + b * 2.0 - 1.0;
+  *yaw = st[2] + c * 0.5 - 0.25;
+  *v = st[3] + d * 1.0 - 0.5;
+}
+
+/* Constants of the range likelihood, particle_filter.rs:476-479:
+ *   coeff = 1/sqrt(2 pi sigma^2),  two_s2 = 2 sigma^2,  log_coeff = ln(coeff). */
+typedef struct rr_pf_lik {
+  double coeff;
+  double two_s2;
+  double inv_two_s2;
+  double log_coeff;
+} rr_pf_lik;
+
+RR_HD rr_pf_lik rr_pf_lik_make(double sigma) {
+  rr_pf_lik k;
+  k.two_s2 = 2.0 * (sigma * sigma);
+  k.coeff = 1.0 / rr_sqrt(RR_TWO_PI * (sigma * sigma));
+  k.inv_two_s2 = 1.0 / k.two_s2;
+  k.log_coeff = rr_log(k.coeff);
+  return k;
+}
+
+/* squared range residual of one (particle, observation) pair,
+ * particle_filter.rs:320-325: dx = particle - landmark (Q2). */
+RR_HD double rr_pf_residual(double x, double y, double d_obs, double lx, double ly) {
+  double dx = x - lx;
+  double dy = y - ly;
+  double d_pred = rr_sqrt(rr_fma(dy, dy, dx * dx));
+  return d_obs - d_pred;
+}
+
+/* RR_LIK_PRODUCT: the reference's per-pair form w *= coeff*exp(-diff^2/(2 sigma^2))
+ * (particle_filter.rs:317-328); obs = n_obs x (d, lx, ly). */
+RR_HD double rr_pf_weight_product(double x, double y, const double* obs, int n_obs, rr_pf_lik k) {
+  double w = 1.0;
+  for (int l = 0; l < n_obs; ++l) {
+    double diff = rr_pf_residual(x, y, obs[3 * l], obs[3 * l + 1], obs[3 * l + 2]);
+    w *= k.coeff * rr_exp(-(diff * diff) / k.two_s2);
+  }
+  return w;
+}
+
+/* RR_LIK_FUSED: the same product with the exponentials merged,
+ *   w = exp(L ln coeff - sum diff^2 / (2 sigma^2)),
+ * one exp per particle instead of one per pair (SURVEY.md section 7 "hard parts").
+ * Differs from the product form by ~1e-13 relative, and in the deep-underflow
+ * regime (w < 1e-290) where the running product loses bits first. */
+RR_HD double rr_pf_weight_fused(double x, double y, const double* obs, int n_obs, rr_pf_lik k) {
+  double ss = 0.0;
+  for (int l = 0; l < n_obs; ++l) {
+    double diff = rr_pf_residual(x, y, obs[3 * l], obs[3 * l + 1], obs[3 * l + 2]);
+    ss = rr_fma(diff, diff, ss);
+  }
+  return rr_exp(rr_fma(-ss, k.inv_two_s2, (double)n_obs * k.log_coeff));
+}
+
+/* ===================================================================== fixed-point CDF */
+/* The resampling CDF is built from integer weights so that its value does not
+ * depend on summation order (1 GPU, 8 GPUs and the CPU agree bit for bit):
+ *   shift = (62 - ceil_log2(N)) - floor(log2(w_max)),  q_i = floor(w_i * 2^shift),
+ * hence q_i < 2^(63-ceil_log2 N) and T = sum q_i < 2^63 exactly. */
+
+RR_HD int rr_ceil_log2_u64(uint64_t n) {
+  int b = 0;
+  while (b < 63 && ((uint64_t)1 << b) < n) ++b;
+  return b;
+}
+
+/* floor(log2(w)) for finite w > 0 (subnormals included) */
+RR_HD int rr_ilogb_pos(double w) {
+  uint64_t u = rr_d2u(w);
+  int e = (int)(u >> 52);
+  if (e == 0) { /* subnormal: w = m * 2^-1074 */
+    uint64_t m = u & 0x000fffffffffffffull;
+    int hb = 63 - __builtin_clzll(m);
+    return hb - 1074;
+  }
+  return e - 1023;
+}
+
+RR_HD int rr_fix_shift(double w_max, uint64_t n_global) {
+  return (62 - rr_ceil_log2_u64(n_global)) - rr_ilogb_pos(w_max);
+}
+
+/* floor(w * 2^shift) by mantissa shifting; w < 0, NaN -> 0; caller guarantees
+ * w <= w_max so the result fits. */
+RR_HD uint64_t rr_fix_quantize(double w, int shift) {
+  uint64_t u = rr_d2u(w);
+  if (u >= 0x7ff0000000000000ull) return 0; /* negative, inf or NaN */
+  int e = (int)(u >> 52);
+  uint64_t m = u & 0x000fffffffffffffull;
+  int sh;
+  if (e == 0) {
+    sh = -1074 + shift;
+  } else {
+    m |= 0x0010000000000000ull;
+    sh = e - 1075 + shift;
+  }
+  if (sh >= 0) return m << (sh > 10 ? 10 : sh); /* sh <= 10 by construction */
+  if (sh <= -64) return 0;
+  return m >> (-sh);
+}
+
+/* S = T * 2^-shift as a double: the order-independent weight sum used for
+ * normalisation in the D-spec (replaces the serial float sum of
+ * particle_filter.rs:427 / fastslam1.rs:197). */
+RR_HD double rr_fix_total_to_double(uint64_t total, int shift) {
+  return rr_scale2((double)total, -shift);
+}
+
+/* N_eff = (sum w)^2 / sum w^2 from the exact integer sums (particle_filter.rs:416-423,
+ * fastslam1.rs:186-193); q2 = sum q_i^2 as a 128-bit integer (hi, lo). */
+RR_HD double rr_fix_neff(uint64_t total, uint64_t q2_hi, uint64_t q2_lo) {
+  if (q2_hi == 0 && q2_lo == 0) return 0.0;
+  double t = (double)total;
+  double q2 = rr_fma((double)q2_hi, 0x1p64, (double)q2_lo);
+  return (t * t) / q2;
+}
+
+RR_HD void rr_mul64wide(uint64_t a, uint64_t b, uint64_t* hi, uint64_t* lo) {
+  unsigned __int128 p = (unsigned __int128)a * b;
+  *hi = (uint64_t)(p >> 64);
+  *lo = (uint64_t)p;
+}
+
+/* Multinomial draw r in [0,1) -> CDF target: smallest P with r*T <= P, i.e.
+ * index = first i with C_i >= P  <=>  first i with r <= C_i / T
+ * (particle_filter.rs:459-465 "r <= cum_w"). */
+RR_HD uint64_t rr_fix_target_multinomial(double r, uint64_t total) {
+  uint64_t R = (uint64_t)(r * 0x1p53); /* exact: r is a multiple of 2^-53 */
+  unsigned __int128 p = (unsigned __int128)R * total + (((unsigned __int128)1 << 53) - 1);
+  return (uint64_t)(p >> 53);
+}
+
+/* Systematic resampling (fastslam1.rs:219-231): output i sits at (i + rho)/n,
+ * rho = u0 in [0,1); offs = floor(rho*T); target_i = ceil((i*T + offs)/n). */
+typedef struct rr_sys_plan {
+  uint64_t q;    /* T / n */
+  uint64_t rem;  /* T % n */
+  uint64_t offs; /* floor(rho * T) */
+  uint64_t n;
+} rr_sys_plan;
+
+RR_HD rr_sys_plan rr_sys_plan_make(double rho, uint64_t total, uint64_t n) {
+  rr_sys_plan p;
+  uint64_t R = (uint64_t)(rho * 0x1p53);
+  p.offs = (uint64_t)(((unsigned __int128)R * total) >> 53);
+  p.q = total / n;
+  p.rem = total % n;
+  p.n = n;
+  return p;
+}
+
+RR_HD uint64_t rr_sys_target(rr_sys_plan p, uint64_t i) {
+  uint64_t t = i * p.rem + p.offs; /* < n^2 + 2^63 <= 2^64 for n < 2^31 */
+  return i * p.q + (t + p.n - 1) / p.n;
+}
+
+/* first i in [0,n) with c[i] >= target (c inclusive, non-decreasing); n-1 if none */
+RR_HD uint64_t rr_lower_bound_u64(const uint64_t* c, uint64_t n, uint64_t target) {
+  uint64_t lo = 0, hi = n;
+  while (lo < hi) {
+    uint64_t mid = lo + ((hi - lo) >> 1);
+    if (c[mid] >= target) hi = mid; else lo = mid + 1;
+  }
+  return lo < n ? lo : n - 1;
+}
+
+/* ===================================================================== FastSLAM 1.0 */
+
+/* model constants of rust_robotics_slam/src/fastslam1.rs:13-23 as run-time fields */
+typedef struct rr_fs1_model {
+  double dt;            /* DT = 0.1 */
+  double q_sqrt0;       /* sqrt(Q_SIM[0][0]) = sqrt(0.3) */
+  double q_sqrt1;       /* sqrt(Q_SIM[1][1]) = sqrt(0.0305) */
+  double r00, r11;      /* R_SIM diagonal 0.5, 0.0305 */
+  double init_threshold;/* 100.0: cov[(0,0)] > threshold => first observation (fastslam1.rs:143) */
+  double init_cov;      /* NaN => reference-faithful "leave cov untouched" (Q11); else cov := init_cov * I */
+} rr_fs1_model;
+
+/* fastslam1.rs:80-89 */
+RR_HD double rr_normalize_angle(double a) {
+  while (a > RR_PI_HI) a -= 2.0 * RR_PI_HI;
+  while (a < -RR_PI_HI) a += 2.0 * RR_PI_HI;
+  return a;
+}
+
+/* fastslam1.rs:123-137 + 70-77; z0,z1 unit normals.  (u0*DT)*cos(yaw) order (Q4). */
+RR_HD void rr_fs1_predict_one(double* x, double* y, double* yaw, double u0, double u1,
+                              double z0, double z1, rr_fs1_model m) {
+  double un0 = rr_fma(z0, m.q_sqrt0, u0);
+  double un1 = rr_fma(z1, m.q_sqrt1, u1);
+  double s, c;
+  rr_sincos(*yaw, &s, &c);
+  *x = rr_fma(un0 * m.dt, c, *x);
+  *y = rr_fma(un0 * m.dt, s, *y);
+  *yaw = rr_normalize_angle(rr_fma(un1, m.dt, *yaw));
+}
+
+/* One (particle, observation) EKF update, fastslam1.rs:140-183.
+ * lm = {x, y, c00, c10, c01, c11} (nalgebra Matrix2 is column-major).
+ * Returns the likelihood factor to multiply into the particle weight
+ * (1.0 on the first-observation branch and when det S <= 0, Q13). */
+RR_HD double rr_fs1_update_one(double px, double py, double pyaw, double zd, double za,
+                               double* lm, rr_fs1_model m) {
+  double lx = lm[0], ly = lm[1];
+  double p00 = lm[2], p10 = lm[3], p01 = lm[4], p11 = lm[5];
+  if (p00 > m.init_threshold) { /* :143-149 */
+    double s, c;
+    rr_sincos(pyaw + za, &s, &c);
+    lm[0] = rr_fma(zd, c, px);
+    lm[1] = rr_fma(zd, s, py);
+    if (m.init_cov == m.init_cov) {
+      lm[2] = m.init_cov; lm[3] = 0.0; lm[4] = 0.0; lm[5] = m.init_cov;
+    }
+    return 1.0;
+  }
+  /* observation model :92-99 (landmark - particle, Q2) and Jacobian :102-110 */
+  double dx = lx - px;
+  double dy = ly - py;
+  double d2 = rr_fma(dy, dy, dx * dx);
+  double d = rr_sqrt(d2);
+  double zp_a = rr_normalize_angle(rr_atan2(dy, dx) - pyaw);
+  double y0 = zd - d;
+  double y1 = rr_normalize_angle(za - zp_a);
+  double h00 = dx / d, h01 = dy / d, h10 = -dy / d2, h11 = dx / d2;
+  /* HP = H * P */
+  double hp00 = rr_fma(h01, p10, h00 * p00);
+  double hp01 = rr_fma(h01, p11, h00 * p01);
+  double hp10 = rr_fma(h11, p10, h10 * p00);
+  double hp11 = rr_fma(h11, p11, h10 * p01);
+  /* S = HP * H^T + R :161 */
+  double s00 = rr_fma(hp01, h01, hp00 * h00) + m.r00;
+  double s01 = rr_fma(hp01, h11, hp00 * h10);
+  double s10 = rr_fma(hp11, h01, hp10 * h00);
+  double s11 = rr_fma(hp11, h11, hp10 * h10) + m.r11;
+  /* S^-1 :164 -- nalgebra try_inverse for 2x2: det == 0 => None => identity */
+  double det = rr_fma(s00, s11, -(s10 * s01));
+  double i00, i01, i10, i11;
+  if (det == 0.0) {
+    i00 = 1.0; i01 = 0.0; i10 = 0.0; i11 = 1.0;
+  } else {
+    i00 = s11 / det; i01 = -s01 / det; i10 = -s10 / det; i11 = s00 / det;
+  }
+  /* K = P * H^T * S^-1 :165 */
+  double pht00 = rr_fma(p01, h01, p00 * h00);
+  double pht01 = rr_fma(p01, h11, p00 * h10);
+  double pht10 = rr_fma(p11, h01, p10 * h00);
+  double pht11 = rr_fma(p11, h11, p10 * h10);
+  double k00 = rr_fma(pht01, i10, pht00 * i00);
+  double k01 = rr_fma(pht01, i11, pht00 * i01);
+  double k10 = rr_fma(pht11, i10, pht10 * i00);
+  double k11 = rr_fma(pht11, i11, pht10 * i01);
+  /* landmark += K y :168-170 */
+  lm[0] = lx + rr_fma(k01, y1, k00 * y0);
+  lm[1] = ly + rr_fma(k11, y1, k10 * y0);
+  /* P = (I - K H) P :173-174, no symmetrisation (Q12) */
+  double a00 = 1.0 - rr_fma(k01, h10, k00 * h00);
+  double a01 = -rr_fma(k01, h11, k00 * h01);
+  double a10 = -rr_fma(k11, h10, k10 * h00);
+  double a11 = 1.0 - rr_fma(k11, h11, k10 * h01);
+  lm[2] = rr_fma(a01, p10, a00 * p00);
+  lm[3] = rr_fma(a11, p10, a10 * p00);
+  lm[4] = rr_fma(a01, p11, a00 * p01);
+  lm[5] = rr_fma(a11, p11, a10 * p01);
+  /* likelihood :177-182, uses s.determinant() = s00*s11 - s10*s01 */
+  if (det > 0.0) {
+    /* (y^T S^-1) y, row vector first as nalgebra evaluates it */
+    double t0 = rr_fma(y1, i10, y0 * i00);
+    double t1 = rr_fma(y1, i11, y0 * i01);
+    double mahal = rr_fma(t1, y1, t0 * y0);
+    return rr_exp(-0.5 * mahal) / (RR_TWO_PI * rr_sqrt(det));
+  }
+  return 1.0;
+}
+
+/* unit motion noise for FastSLAM particle gid at step (fastslam1.rs:129-130) */
+RR_HD void rr_fs1_motion_noise(uint64_t seed, uint32_t step, uint64_t gid, double* z0, double* z1) {
+  rr_normal2(seed, RR_STREAM_MOTION, step, gid, z0, z1);
+}
+
+#endif /* RR_PF_SPEC_H */

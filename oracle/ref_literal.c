@@ -1,0 +1,454 @@
+/* ref_literal.c -- TEST INFRASTRUCTURE, not product code.
+ *
+ * A plain-C, single-threaded restatement of the reference's CPU algorithm for
+ * the sampling-based localization hot path, following the reference line by
+ * line: same loop order, same operation order, serial left-to-right sums,
+ * libm transcendentals (Rust's f64::{sin,cos,exp,sqrt,atan2} are the platform
+ * libm on Linux), no fused multiply-add (rustc never contracts).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
+ *
+ * Reference files restated (all under /root/reference/crates):
+ *   rust_robotics_localization/src/particle_filter.rs
+ *   rust_robotics_localization/src/monte_carlo_localization.rs  (fixed-N resample variant)
+ *   rust_robotics_slam/src/fastslam1.rs
+ *
+ * PARITY PINNING: the reference cannot be compiled here (no rustc/cargo in the
+ * image) and its hot path is not seedable (rand::rng() at particle_filter.rs:258,443;
+ * fastslam1.rs:129-130,220), and its own tests pin invariants, never values
+ * (SURVEY.md section 4).  This restatement is therefore pinned by (a) every
+ * reference-owned invariant re-expressed in tests/test_reference_invariants.py and
+ * (b) the hand-derivable known answers KA1-KA7 of SURVEY.md Appendix B
+ * (tests/test_known_answers.py).  RNG-level parity with rand/rand_distr is
+ * UNPINNED by construction: all random draws enter as explicit arrays.
+ *
+ * Build: see oracle/Makefile (compiled with -ffp-contract=off).
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define REF_PI 3.14159265358979323846 /* std::f64::consts::PI */
+
+/* ------------------------------------------------------------------ PF */
+
+/* particle_filter.rs:476-479 */
+double ref_gauss_likelihood(double x, double sigma) {
+  double coeff = 1.0 / sqrt(2.0 * REF_PI * (sigma * sigma));
+  return coeff * exp(-(x * x) / (2.0 * (sigma * sigma)));
+}
+
+/* particle_filter.rs:279-296.  nv/nw: per-particle noise samples already scaled
+ * by sigma (Normal::new(0, sigma).sample), NULL => the `None` arm (exactly 0.0). */
+void ref_pf_predict(size_t n, double* x, double* y, double* yaw, double* v,
+                    double u0, double u1, double dt, const double* nv, const double* nw) {
+  for (size_t i = 0; i < n; ++i) {
+    double v_noise = nv ? nv[i] : 0.0;
+    double yaw_noise = nw ? nw[i] : 0.0;
+    double v_noisy = u0 + v_noise;
+    double yaw_rate_noisy = u1 + yaw_noise;
+    x[i] += v_noisy * cos(yaw[i]) * dt;
+    y[i] += v_noisy * sin(yaw[i]) * dt;
+    yaw[i] += yaw_rate_noisy * dt;
+    v[i] = v_noisy;
+  }
+}
+
+/* particle_filter.rs:316-329: weight overwritten with the product of likelihoods */
+void ref_pf_update_raw(size_t n, const double* x, const double* y, double* w,
+                       const double* obs, size_t n_obs, double sigma) {
+  for (size_t i = 0; i < n; ++i) {
+    double wi = 1.0;
+    for (size_t l = 0; l < n_obs; ++l) {
+      double d_obs = obs[3 * l], lx = obs[3 * l + 1], ly = obs[3 * l + 2];
+      double dx = x[i] - lx;
+      double dy = y[i] - ly;
+      double d_pred = sqrt(dx * dx + dy * dy);
+      double diff = d_obs - d_pred;
+      wi *= ref_gauss_likelihood(diff, sigma);
+    }
+    w[i] = wi;
+  }
+}
+
+/* particle_filter.rs:426-439; returns the serial sum it divided by */
+double ref_pf_normalize(size_t n, double* w) {
+  double sum_w = 0.0;
+  for (size_t i = 0; i < n; ++i) sum_w += w[i];
+  if (sum_w > 0.0) {
+    for (size_t i = 0; i < n; ++i) w[i] /= sum_w;
+  } else {
+    double uniform = 1.0 / (double)n;
+    for (size_t i = 0; i < n; ++i) w[i] = uniform;
+  }
+  return sum_w;
+}
+
+/* particle_filter.rs:416-423 */
+double ref_pf_neff(size_t n, const double* w) {
+  double s2 = 0.0;
+  for (size_t i = 0; i < n; ++i) s2 += w[i] * w[i];
+  return s2 > 0.0 ? 1.0 / s2 : 0.0;
+}
+
+/* particle_filter.rs:382-396 */
+void ref_pf_estimate(size_t n, const double* x, const double* y, const double* yaw,
+                     const double* v, const double* w, double out[4]) {
+  double xe = 0.0, ye = 0.0, yawe = 0.0, ve = 0.0;
+  for (size_t i = 0; i < n; ++i) {
+    xe += w[i] * x[i];
+    ye += w[i] * y[i];
+    yawe += w[i] * yaw[i];
+    ve += w[i] * v[i];
+  }
+  out[0] = xe; out[1] = ye; out[2] = yawe; out[3] = ve;
+}
+
+/* particle_filter.rs:398-413: cov += w * dx * dx^T (nalgebra evaluates (w*dx) * dx^T);
+ * out row-major 4x4 */
+void ref_pf_covariance(size_t n, const double* x, const double* y, const double* yaw,
+                       const double* v, const double* w, const double est[4], double out[16]) {
+  for (int k = 0; k < 16; ++k) out[k] = 0.0;
+  for (size_t i = 0; i < n; ++i) {
+    double d[4] = {x[i] - est[0], y[i] - est[1], yaw[i] - est[2], v[i] - est[3]};
+    double wd[4] = {w[i] * d[0], w[i] * d[1], w[i] * d[2], w[i] * d[3]};
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) out[4 * r + c] += wd[r] * d[c];
+  }
+}
+
+/* particle_filter.rs:441-473 -- multinomial despite its doc comment: serial
+ * inclusive cumsum, one uniform per output, first i with r <= c[i], DEFAULT 0.
+ * Writes the chosen source indices; the caller gathers and sets w = 1/n. */
+void ref_pf_resample_indices(size_t n, const double* w, const double* r, uint32_t* idx) {
+  double* cum = (double*)malloc(n * sizeof(double));
+  double cs = 0.0;
+  for (size_t i = 0; i < n; ++i) {
+    cs += w[i];
+    cum[i] = cs;
+  }
+  for (size_t k = 0; k < n; ++k) {
+    size_t index = 0;
+    for (size_t i = 0; i < n; ++i) {
+      if (r[k] <= cum[i]) {
+        index = i;
+        break;
+      }
+    }
+    idx[k] = (uint32_t)index;
+  }
+  free(cum);
+}
+
+/* The same selection rule found by binary search (identical indices: cum is
+ * non-decreasing) -- the "algorithmically equal" CPU variant timed at full N
+ * because the literal O(N^2) scan above is infeasible at 1e6. */
+void ref_pf_resample_indices_bsearch(size_t n, const double* w, const double* r, uint32_t* idx) {
+  double* cum = (double*)malloc(n * sizeof(double));
+  double cs = 0.0;
+  for (size_t i = 0; i < n; ++i) {
+    cs += w[i];
+    cum[i] = cs;
+  }
+  for (size_t k = 0; k < n; ++k) {
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+      size_t mid = lo + (hi - lo) / 2;
+      if (r[k] <= cum[mid]) hi = mid; else lo = mid + 1;
+    }
+    idx[k] = (uint32_t)(lo < n ? lo : 0); /* default 0 */
+  }
+  free(cum);
+}
+
+/* monte_carlo_localization.rs:328-336,387-392 with min_particles == max_particles == n:
+ * cumsum with the LAST entry forced to 1.0, first i with r <= c[i], fallback LAST. */
+void ref_mcl_resample_indices(size_t n, const double* w, const double* r, uint32_t* idx) {
+  double* cum = (double*)malloc(n * sizeof(double));
+  double cs = 0.0;
+  for (size_t i = 0; i < n; ++i) {
+    cs += w[i];
+    cum[i] = cs;
+  }
+  if (n) cum[n - 1] = 1.0;
+  for (size_t k = 0; k < n; ++k) {
+    size_t lo = 0, hi = n;
+    while (lo < hi) {
+      size_t mid = lo + (hi - lo) / 2;
+      if (r[k] <= cum[mid]) hi = mid; else lo = mid + 1;
+    }
+    idx[k] = (uint32_t)(lo < n ? lo : n - 1);
+  }
+  free(cum);
+}
+
+/* gather + uniform weights, particle_filter.rs:467-469 */
+void ref_pf_gather(size_t n, double* x, double* y, double* yaw, double* v, double* w,
+                   const uint32_t* idx) {
+  double* t = (double*)malloc(4 * n * sizeof(double));
+  for (size_t k = 0; k < n; ++k) {
+    t[k] = x[idx[k]];
+    t[n + k] = y[idx[k]];
+    t[2 * n + k] = yaw[idx[k]];
+    t[3 * n + k] = v[idx[k]];
+  }
+  memcpy(x, t, n * sizeof(double));
+  memcpy(y, t + n, n * sizeof(double));
+  memcpy(yaw, t + 2 * n, n * sizeof(double));
+  memcpy(v, t + 3 * n, n * sizeof(double));
+  for (size_t k = 0; k < n; ++k) w[k] = 1.0 / (double)n;
+  free(t);
+}
+
+/* One full PF step, particle_filter.rs:488-497: predict, update (+normalise),
+ * N_eff-gated resample (:337-345).  r_draws: n uniforms used iff the gate fires.
+ * scheme: 0 = PF (:441-473, gate n_eff < n*threshold, default index 0)
+ *         1 = fixed-N MCL (monte_carlo_localization.rs:298, every step, fallback last)
+ * Returns 1 if it resampled.  est_out (4) = estimate after the step (Q15). */
+int ref_pf_step(size_t n, double* x, double* y, double* yaw, double* v, double* w,
+                double u0, double u1, double dt, const double* nv, const double* nw,
+                const double* obs, size_t n_obs, double sigma, double resample_threshold,
+                int scheme, const double* r_draws, uint32_t* idx_scratch, double* est_out) {
+  ref_pf_predict(n, x, y, yaw, v, u0, u1, dt, nv, nw);
+  ref_pf_update_raw(n, x, y, w, obs, n_obs, sigma);
+  ref_pf_normalize(n, w);
+  int fired = 0;
+  if (scheme == 1) {
+    ref_mcl_resample_indices(n, w, r_draws, idx_scratch);
+    ref_pf_gather(n, x, y, yaw, v, w, idx_scratch);
+    fired = 1;
+  } else {
+    double n_eff = ref_pf_neff(n, w);
+    if (n_eff < (double)n * resample_threshold) {
+      ref_pf_resample_indices_bsearch(n, w, r_draws, idx_scratch);
+      ref_pf_gather(n, x, y, yaw, v, w, idx_scratch);
+      fired = 1;
+    }
+  }
+  if (est_out) ref_pf_estimate(n, x, y, yaw, v, w, est_out);
+  return fired;
+}
+
+/* ------------------------------------------------------------------ FastSLAM 1.0 */
+/* Particle poses px,py,pyaw and weights pw are arrays of n; the per-particle
+ * maps are particle-major AoS lm[(p*L + l)*6 + {x,y,c00,c10,c01,c11}], the memory
+ * order of the reference's Vec<Landmark> with a column-major nalgebra Matrix2
+ * (fastslam1.rs:26-31). */
+
+typedef struct ref_fs1_model {
+  double dt, q00, q11, r00, r11, init_threshold, init_cov;
+} ref_fs1_model;
+
+/* fastslam1.rs:13-23 */
+void ref_fs1_model_default(ref_fs1_model* m) {
+  m->dt = 0.1;
+  m->q00 = 0.3;
+  m->q11 = 0.0305;
+  m->r00 = 0.5;
+  m->r11 = 0.0305;
+  m->init_threshold = 100.0;
+  m->init_cov = NAN; /* reference leaves cov untouched on first observation (Q11) */
+}
+
+/* fastslam1.rs:80-89 */
+double ref_normalize_angle(double a) {
+  while (a > REF_PI) a -= 2.0 * REF_PI;
+  while (a < -REF_PI) a += 2.0 * REF_PI;
+  return a;
+}
+
+/* fastslam1.rs:302-306 with Particle::new :54-61 and Landmark::new :34-40 */
+void ref_fs1_create(size_t n, size_t L, double* px, double* py, double* pyaw, double* pw, double* lm) {
+  for (size_t p = 0; p < n; ++p) {
+    px[p] = py[p] = pyaw[p] = 0.0;
+    pw[p] = 1.0 / 100.0; /* 1/N_PARTICLE regardless of n (Q10) */
+    for (size_t l = 0; l < L; ++l) {
+      double* e = lm + (p * L + l) * 6;
+      e[0] = 0.0; e[1] = 0.0;
+      e[2] = 1000.0; e[3] = 0.0; e[4] = 0.0; e[5] = 1000.0;
+    }
+  }
+}
+
+/* fastslam1.rs:123-137 + 70-77; z0,z1 = unit normal draws per particle */
+void ref_fs1_predict(size_t n, double* px, double* py, double* pyaw, double u0, double u1,
+                     const double* z0, const double* z1, const ref_fs1_model* m) {
+  for (size_t p = 0; p < n; ++p) {
+    double un0 = u0 + z0[p] * sqrt(m->q00);
+    double un1 = u1 + z1[p] * sqrt(m->q11);
+    double yaw = pyaw[p];
+    px[p] = px[p] + un0 * m->dt * cos(yaw);
+    py[p] = py[p] + un0 * m->dt * sin(yaw);
+    pyaw[p] = ref_normalize_angle(yaw + un1 * m->dt);
+  }
+}
+
+/* fastslam1.rs:140-183 for one particle and one observation; returns nothing,
+ * multiplies *weight in place. */
+void ref_fs1_update_landmark(double px, double py, double pyaw, double* weight,
+                             double zd, double za, double* e, const ref_fs1_model* m) {
+  if (e[2] > m->init_threshold) { /* :143-149 */
+    e[0] = px + zd * cos(pyaw + za);
+    e[1] = py + zd * sin(pyaw + za);
+    if (!isnan(m->init_cov)) {
+      e[2] = m->init_cov; e[3] = 0.0; e[4] = 0.0; e[5] = m->init_cov;
+    }
+    return;
+  }
+  double p00 = e[2], p10 = e[3], p01 = e[4], p11 = e[5];
+  /* observation_model :92-99 */
+  double dx = e[0] - px;
+  double dy = e[1] - py;
+  double d = sqrt(dx * dx + dy * dy);
+  double zp_a = ref_normalize_angle(atan2(dy, dx) - pyaw);
+  /* innovation :155 */
+  double y0 = zd - d;
+  double y1 = ref_normalize_angle(za - zp_a);
+  /* compute_jacobian :102-110 */
+  double d2 = dx * dx + dy * dy;
+  double dd = sqrt(d2);
+  double h00 = dx / dd, h01 = dy / dd, h10 = -dy / d2, h11 = dx / d2;
+  /* s = h * cov * h^T + r :161, evaluated (h*cov)*h^T, entries summed in k order */
+  double hp00 = h00 * p00 + h01 * p10, hp01 = h00 * p01 + h01 * p11;
+  double hp10 = h10 * p00 + h11 * p10, hp11 = h10 * p01 + h11 * p11;
+  double s00 = hp00 * h00 + hp01 * h01 + m->r00;
+  double s01 = hp00 * h10 + hp01 * h11 + 0.0;
+  double s10 = hp10 * h00 + hp11 * h01 + 0.0;
+  double s11 = hp10 * h10 + hp11 * h11 + m->r11;
+  /* s.try_inverse().unwrap_or(identity) :164 -- nalgebra 0.33 2x2: det = m11*m22 - m21*m12;
+   * det == 0 => None */
+  double det_inv = s00 * s11 - s10 * s01;
+  double i00, i01, i10, i11;
+  if (det_inv == 0.0) {
+    i00 = 1.0; i01 = 0.0; i10 = 0.0; i11 = 1.0;
+  } else {
+    i00 = s11 / det_inv; i01 = -s01 / det_inv; i10 = -s10 / det_inv; i11 = s00 / det_inv;
+  }
+  /* k = cov * h^T * s_inv :165 */
+  double pht00 = p00 * h00 + p01 * h01, pht01 = p00 * h10 + p01 * h11;
+  double pht10 = p10 * h00 + p11 * h01, pht11 = p10 * h10 + p11 * h11;
+  double k00 = pht00 * i00 + pht01 * i10, k01 = pht00 * i01 + pht01 * i11;
+  double k10 = pht10 * i00 + pht11 * i10, k11 = pht10 * i01 + pht11 * i11;
+  /* :168-170 */
+  e[0] += k00 * y0 + k01 * y1;
+  e[1] += k10 * y0 + k11 * y1;
+  /* cov = (I - k*h) * cov :173-174 */
+  double kh00 = k00 * h00 + k01 * h10, kh01 = k00 * h01 + k01 * h11;
+  double kh10 = k10 * h00 + k11 * h10, kh11 = k10 * h01 + k11 * h11;
+  double a00 = 1.0 - kh00, a01 = 0.0 - kh01, a10 = 0.0 - kh10, a11 = 1.0 - kh11;
+  e[2] = a00 * p00 + a01 * p10;
+  e[3] = a10 * p00 + a11 * p10;
+  e[4] = a00 * p01 + a01 * p11;
+  e[5] = a10 * p01 + a11 * p11;
+  /* :177-182 */
+  double det_s = s00 * s11 - s10 * s01;
+  if (det_s > 0.0) {
+    double t0 = y0 * i00 + y1 * i10; /* y^T * s_inv */
+    double t1 = y0 * i01 + y1 * i11;
+    double mahal = t0 * y0 + t1 * y1;
+    double likelihood = exp(-0.5 * mahal) / (2.0 * REF_PI * sqrt(det_s));
+    *weight *= likelihood;
+  }
+}
+
+/* fastslam1.rs:196-203 (no fallback) */
+double ref_fs1_normalize(size_t n, double* pw) {
+  double s = 0.0;
+  for (size_t p = 0; p < n; ++p) s += pw[p];
+  if (s > 0.0)
+    for (size_t p = 0; p < n; ++p) pw[p] /= s;
+  return s;
+}
+
+/* fastslam1.rs:186-193 */
+double ref_fs1_neff(size_t n, const double* pw) {
+  double s2 = 0.0;
+  for (size_t p = 0; p < n; ++p) s2 += pw[p] * pw[p];
+  return s2 > 0.0 ? 1.0 / s2 : 0.0;
+}
+
+/* fastslam1.rs:205-234: indices of the systematic walk; r0 in [0, 1/n) */
+void ref_fs1_resample_indices(size_t n, double* pw, double r0, uint32_t* idx) {
+  ref_fs1_normalize(n, pw); /* :207 */
+  double* cum = (double*)malloc((n + 1) * sizeof(double));
+  cum[0] = 0.0;
+  for (size_t i = 0; i < n; ++i) cum[i + 1] = cum[i] + pw[i];
+  double r = r0;
+  size_t j = 0;
+  for (size_t k = 0; k < n; ++k) {
+    while (r > cum[j + 1] && j < n - 1) j += 1;
+    idx[k] = (uint32_t)j;
+    r += 1.0 / (double)n;
+  }
+  free(cum);
+}
+
+/* clone step of fastslam1.rs:227-229 */
+void ref_fs1_gather(size_t n, size_t L, double* px, double* py, double* pyaw, double* pw,
+                    double* lm, const uint32_t* idx) {
+  double* t = (double*)malloc((3 * n + n * L * 6) * sizeof(double));
+  double* tl = t + 3 * n;
+  for (size_t k = 0; k < n; ++k) {
+    size_t j = idx[k];
+    t[k] = px[j]; t[n + k] = py[j]; t[2 * n + k] = pyaw[j];
+    memcpy(tl + k * L * 6, lm + j * L * 6, L * 6 * sizeof(double));
+  }
+  memcpy(px, t, n * sizeof(double));
+  memcpy(py, t + n, n * sizeof(double));
+  memcpy(pyaw, t + 2 * n, n * sizeof(double));
+  memcpy(lm, tl, n * L * 6 * sizeof(double));
+  for (size_t k = 0; k < n; ++k) pw[k] = 1.0 / (double)n;
+  free(t);
+}
+
+/* fastslam1.rs:237-266.  z = n_z x (d, angle, id as double); nth = NTH (66.67 in the
+ * reference); r0 used iff the gate fires.  Returns 1 if it resampled. */
+int ref_fs1_update(size_t n, size_t L, double* px, double* py, double* pyaw, double* pw, double* lm,
+                   double u0, double u1, const double* z0, const double* z1,
+                   const double* z, size_t n_z, const ref_fs1_model* m, double nth, double r0,
+                   uint32_t* idx_scratch) {
+  ref_fs1_predict(n, px, py, pyaw, u0, u1, z0, z1, m);
+  for (size_t k = 0; k < n_z; ++k) { /* observation outer, particle inner :250-256 */
+    double zd = z[3 * k], za = z[3 * k + 1];
+    size_t id = (size_t)z[3 * k + 2];
+    for (size_t p = 0; p < n; ++p)
+      ref_fs1_update_landmark(px[p], py[p], pyaw[p], &pw[p], zd, za, lm + (p * L + id) * 6, m);
+  }
+  ref_fs1_normalize(n, pw);
+  double neff = ref_fs1_neff(n, pw);
+  if (neff < nth) {
+    ref_fs1_resample_indices(n, pw, r0, idx_scratch);
+    ref_fs1_gather(n, L, px, py, pyaw, pw, lm, idx_scratch);
+    return 1;
+  }
+  return 0;
+}
+
+/* fastslam1.rs:269-274: Iterator::max_by returns the LAST maximal element (Q14) */
+size_t ref_fs1_best_particle(size_t n, const double* pw) {
+  size_t best = 0;
+  for (size_t p = 1; p < n; ++p)
+    if (!(pw[p] < pw[best])) best = p; /* partial_cmp: >= keeps the later one */
+  return best;
+}
+
+/* fastslam1.rs:277-299: observation simulator; zn = 2 unit normals per landmark;
+ * out = (d, angle, id) rows; returns the count (range gate MAX_RANGE). */
+size_t ref_fs1_get_observations(const double xt[3], const double* lms, size_t L, double max_range,
+                                const double* zn, const ref_fs1_model* m, double* out) {
+  size_t cnt = 0;
+  for (size_t l = 0; l < L; ++l) {
+    double dx = lms[2 * l] - xt[0];
+    double dy = lms[2 * l + 1] - xt[1];
+    double d = sqrt(dx * dx + dy * dy);
+    if (d <= max_range) {
+      double angle = ref_normalize_angle(atan2(dy, dx) - xt[2]);
+      out[3 * cnt] = d + zn[2 * l] * sqrt(m->r00);
+      out[3 * cnt + 1] = angle + zn[2 * l + 1] * sqrt(m->r11);
+      out[3 * cnt + 2] = (double)l;
+      ++cnt;
+    }
+  }
+  return cnt;
+}

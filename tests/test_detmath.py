@@ -1,0 +1,161 @@
+"""include/rr_detmath.h against mpmath (the contract's accuracy claim) and its
+structural properties (Philox known-answer vectors, uniform ranges)."""
+import ctypes as C
+
+import mpmath as mp
+import numpy as np
+import pytest
+
+import oracle
+from oracle import dp
+
+mp.mp.dps = 40
+
+
+def ulp_err(got, exact_fn, xs):
+    worst = 0.0
+    for g, x in zip(got, xs):
+        e = exact_fn(x)
+        ef = float(e)
+        if ef == 0.0 or not np.isfinite(ef):
+            continue
+        u = np.spacing(abs(ef))
+        worst = max(worst, abs(float((mp.mpf(float(g)) - e) / mp.mpf(float(u)))))
+    return worst
+
+
+def test_exp_accuracy(det):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.uniform(-745, 709, 3000), rng.uniform(-2, 2, 3000), [0.0, -0.0, 1.0, -1.0]])
+    o = np.empty_like(x)
+    det.det_exp_v(x.size, dp(x), dp(o))
+    # skip the subnormal tail where one extra rounding is by design
+    keep = x > -708
+    assert ulp_err(o[keep], lambda v: mp.exp(mp.mpf(float(v))), x[keep]) <= 1.5
+    assert np.all(np.abs(o[~keep] - np.exp(x[~keep])) <= 2 * np.spacing(np.exp(x[~keep])) + 5e-324)
+
+
+def test_exp_edges(det):
+    x = np.array([710.0, 1e308, -746.0, -1e308, np.nan, np.inf, -np.inf])
+    o = np.empty_like(x)
+    det.det_exp_v(x.size, dp(x), dp(o))
+    assert o[0] == np.inf and o[1] == np.inf and o[2] == 0.0 and o[3] == 0.0
+    assert np.isnan(o[4]) and o[5] == np.inf and o[6] == 0.0
+
+
+def test_log_accuracy(det):
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(0, 1, 4000), 10.0 ** rng.uniform(-300, 300, 2000), [1.0, 0.5, 2.0, 5e-324]])
+    x = x[x > 0]
+    o = np.empty_like(x)
+    det.det_log_v(x.size, dp(x), dp(o))
+    assert ulp_err(o, lambda v: mp.log(mp.mpf(float(v))), x) <= 2.5
+    z = np.array([0.0, -1.0, np.inf])
+    oz = np.empty_like(z)
+    det.det_log_v(3, dp(z), dp(oz))
+    assert oz[0] == -np.inf and np.isnan(oz[1]) and oz[2] == np.inf
+
+
+def test_sincos_accuracy(det):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.uniform(-10, 10, 4000), rng.uniform(-1e4, 1e4, 3000), [0.0, 1e-300, -1e-20]])
+    s = np.empty_like(x)
+    c = np.empty_like(x)
+    det.det_sincos_v(x.size, dp(x), dp(s), dp(c))
+    # absolute error is what the pose update sees; <= 1 ulp of 1.0 everywhere,
+    # and <= 2 ulp relative away from the zeros
+    for got, fn in ((s, mp.sin), (c, mp.cos)):
+        ex = np.array([float(fn(mp.mpf(float(v)))) for v in x])
+        assert np.max(np.abs(got - ex)) <= 2.3e-16
+        far = np.abs(ex) > 1e-3
+        assert ulp_err(got[far], lambda v: fn(mp.mpf(float(v))), x[far]) <= 2.0
+
+
+def test_sincos_nonfinite_and_huge(det):
+    x = np.array([np.inf, -np.inf, np.nan, 1e300, 2.0**40 + 0.5])
+    s = np.empty_like(x)
+    c = np.empty_like(x)
+    det.det_sincos_v(x.size, dp(x), dp(s), dp(c))
+    assert np.all(np.isnan(s[:3])) and np.all(np.isnan(c[:3]))
+    assert np.all(np.abs(s[3:]) <= 1.0) and np.all(np.abs(c[3:]) <= 1.0)
+
+
+def test_sincos2pi(det):
+    rng = np.random.default_rng(4)
+    u = np.floor(rng.uniform(0, 1, 5000) * 2**53) / 2**53
+    u = np.concatenate([u, [0.0, 0.25, 0.5, 0.75, 1 - 2**-53, 0.125, 0.375]])
+    s = np.empty_like(u)
+    c = np.empty_like(u)
+    det.det_sincos2pi_v(u.size, dp(u), dp(s), dp(c))
+    es = np.array([float(mp.sin(2 * mp.pi * mp.mpf(float(v)))) for v in u])
+    ec = np.array([float(mp.cos(2 * mp.pi * mp.mpf(float(v)))) for v in u])
+    assert np.max(np.abs(s - es)) <= 5e-16 and np.max(np.abs(c - ec)) <= 5e-16
+    assert np.max(np.abs(s * s + c * c - 1)) <= 5e-16
+
+
+def test_atan2_accuracy(det):
+    rng = np.random.default_rng(5)
+    y = rng.normal(size=6000) * 10.0 ** rng.uniform(-3, 3, 6000)
+    x = rng.normal(size=6000) * 10.0 ** rng.uniform(-3, 3, 6000)
+    o = np.empty_like(x)
+    det.det_atan2_v(x.size, dp(y), dp(x), dp(o))
+    exact = lambda pair: mp.atan2(mp.mpf(float(pair[0])), mp.mpf(float(pair[1])))
+    assert ulp_err(o, exact, list(zip(y, x))) <= 2.5
+
+
+def test_atan2_special(det):
+    y = np.array([0.0, -0.0, 0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.inf, 1.0, 1.0, np.nan])
+    x = np.array([1.0, 1.0, -1.0, -1.0, 0.0, 0.0, np.inf, np.inf, -np.inf, np.inf, -np.inf, 1.0])
+    o = np.empty_like(x)
+    det.det_atan2_v(x.size, dp(y), dp(x), dp(o))
+    e = np.arctan2(y, x)
+    assert np.isnan(o[-1])
+    np.testing.assert_allclose(o[:-1], e[:-1], rtol=0, atol=4.5e-16)
+    assert np.array_equal(np.signbit(o[:-1]), np.signbit(e[:-1]))
+
+
+def test_sqrt_div_are_ieee(det):
+    rng = np.random.default_rng(6)
+    a = 10.0 ** rng.uniform(-200, 200, 20000)
+    b = 10.0 ** rng.uniform(-100, 100, 20000)
+    o = np.empty_like(a)
+    det.det_sqrt_v(a.size, dp(a), dp(o))
+    assert np.array_equal(o, np.sqrt(a))
+    det.det_div_v(a.size, dp(a), dp(b), dp(o))
+    assert np.array_equal(o, a / b)
+
+
+def test_philox_known_answers(det):
+    """Random123 kat_vectors for philox4x32-10."""
+    out = (C.c_uint32 * 4)()
+    det.det_philox_raw(0, 0, 0, 0, 0, 0, out)
+    assert [hex(v) for v in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    det.det_philox_raw(0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, 0xFFFFFFFF, out)
+    assert [hex(v) for v in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    det.det_philox_raw(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0, out)
+    assert [hex(v) for v in out] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_uniform_and_normal_streams(det):
+    n = 200000
+    u0 = np.empty(n)
+    u1 = np.empty(n)
+    det.det_uniform2_v(42, 4, 7, 0, n, dp(u0), dp(u1))
+    assert u0.min() >= 0 and u0.max() < 1 and u1.min() >= 0 and u1.max() < 1
+    assert abs(u0.mean() - 0.5) < 5e-3 and abs(u0.var() - 1 / 12) < 2e-3
+    assert np.all(u0 * 2**53 == np.floor(u0 * 2**53))
+    z0 = np.empty(n)
+    z1 = np.empty(n)
+    det.det_normal2_v(42, 3, 7, 0, n, dp(z0), dp(z1))
+    assert np.all(np.isfinite(z0)) and np.all(np.isfinite(z1))
+    for z in (z0, z1):
+        assert abs(z.mean()) < 1e-2 and abs(z.var() - 1) < 1.5e-2
+        assert abs(np.mean(z**4) - 3) < 0.1
+    assert abs(np.mean(z0 * z1)) < 1e-2
+    # counter-based: a sub-range reproduces the same values, another step does not
+    w0 = np.empty(10)
+    w1 = np.empty(10)
+    det.det_normal2_v(42, 3, 7, 1000, 10, dp(w0), dp(w1))
+    assert np.array_equal(w0, z0[1000:1010]) and np.array_equal(w1, z1[1000:1010])
+    det.det_normal2_v(42, 3, 8, 1000, 10, dp(w0), dp(w1))
+    assert not np.array_equal(w0, z0[1000:1010])
