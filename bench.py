@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-landmark updates/s of the MCL hot path on N MI355X.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched
+under torch.distributed.run with one rank per GPU.  One "step" = one full pass of the hot path
+(propagate + weight + resample) over the whole particle set; the workload at N = 1 is
+BASELINE.json configs[1]: fixed-N MCL, 1 000 000 particles x 32 landmarks, resampling every step
+(weak scaling: 1e6 particles per GPU).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+# algorithmic HBM bytes per particle of the dominant kernel k_propagate_weight:
+# read x,y,yaw (24 B) + write x,y,yaw,v,w (40 B)
+K1_BYTES_PER_PARTICLE = 64.0
+
+
+def make_scene(L, steps, seed):
+    from tests import helpers as H
+
+    lms = H.landmarks_grid(L, seed)
+    rng = np.random.default_rng(seed + 1)
+    return [H.observations(lms, H.true_pose(t + 1), 0.2, rng) for t in range(steps)]
+
+
+def cpu_baseline(n, L, obs_list, max_seconds=25.0):
+    """The literal C restatement of the reference (oracle/ref_literal.c), one host core,
+    same workload; runs whole steps until ~max_seconds have elapsed."""
+    import oracle
+    from oracle import dp, u32p
+
+    ref = oracle.ref()
+    det = oracle.det()
+    x, y, yaw, v = (np.zeros(n) for _ in range(4))
+    st = np.array([0.0, 0.0, 0.0, 1.0])
+    det.det_pf_init(n, 1, 0, dp(st), dp(x), dp(y), dp(yaw), dp(v))
+    w = np.full(n, 1.0 / n)
+    idx = np.empty(n, np.uint32)
+    est = np.empty(4)
+    sv, sw = 2.0, math.radians(40.0)
+    z0, z1, r, r2 = (np.empty(n) for _ in range(4))
+    steps = 0
+    t_total = 0.0
+    while steps < len(obs_list) and t_total < max_seconds:
+        obs = np.ascontiguousarray(obs_list[steps])
+        # noise generation is not part of the reference's timed arithmetic budget here: the
+        # reference draws from ChaCha12/ziggurat; we hand it ready samples
+        det.det_normal2_v(1, 3, steps, 0, n, dp(z0), dp(z1))
+        det.det_uniform2_v(1, 4, steps, 0, n, dp(r), dp(r2))
+        nv, nw = sv * z0, sw * z1
+        t0 = time.perf_counter()
+        ref.ref_pf_step(n, dp(x), dp(y), dp(yaw), dp(v), dp(w), 1.0, 0.1, 0.1, dp(nv), dp(nw), dp(obs), L, 0.2, 1.0, 1,
+                        dp(r), u32p(idx), dp(est))
+        t_total += time.perf_counter() - t0
+        steps += 1
+    return dict(value=n * L * steps / t_total, unit="particle-landmark updates/s", cores=1, kind="port",
+                sample=f"oracle/ref_literal.c ref_pf_step (literal reference arithmetic, binary-search multinomial "
+                       f"resample), {n} particles x {L} landmarks x {steps} steps, {t_total:.1f} s, noise samples pre-drawn")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--particles", type=int, default=1_000_000, help="particles PER GPU")
+    ap.add_argument("--landmarks", type=int, default=32)
+    ap.add_argument("--scheme", choices=["systematic", "multinomial"], default="systematic")
+    ap.add_argument("--likelihood", choices=["fused", "product"], default="fused")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    n, L, K, W = args.particles, args.landmarks, args.steps, args.warmup
+    obs_list = make_scene(L, K + W, seed=1)
+    scheme = 1 if args.scheme == "systematic" else 0
+    lik = 0 if args.likelihood == "fused" else 1
+
+    if world > 1:
+        from rust_robotics_amd import sharded
+
+        res = sharded.bench_sharded(rank, world, local_rank, n, L, K, W, obs_list, scheme, lik)
+    else:
+        import rust_robotics_amd.localization as loc
+
+        cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
+        pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=local_rank,
+                                                        resample_scheme=scheme, likelihood_mode=lik)
+        u = [1.0, 0.1]
+        for t in range(W):
+            pf.step_async(u, obs_list[t])
+        pf.synchronize()
+        t0 = time.perf_counter()
+        for t in range(W, W + K):
+            pf.step_async(u, obs_list[t])
+        pf.synchronize()
+        dt = time.perf_counter() - t0
+        est = pf.estimate()
+        # instrumented re-run of the same K steps: HIP events on the filter's own stream around
+        # every kernel launch (adds event overhead, so it is kept out of `value`)
+        pf.profile_enable(True)
+        pf.profile_reset()
+        t1 = time.perf_counter()
+        for t in range(W, W + K):
+            pf.step_async(u, obs_list[t])
+        pf.synchronize()
+        dt_instr = time.perf_counter() - t1
+        prof = pf.profile_read()
+        pf.profile_enable(False)
+        res = dict(seconds=dt, seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est])
+
+    if rank != 0:
+        return
+    total_updates = float(n) * world * L * K
+    value = total_updates / res["seconds"]
+    kern = res["kernels"]
+    k1_n, k1_ms = kern["k_propagate_weight"]
+    k1_avg_s = (k1_ms / max(k1_n, 1)) * 1e-3
+    achieved = K1_BYTES_PER_PARTICLE * n / k1_avg_s if k1_avg_s > 0 else 0.0
+    step_kernel_ms = {k: (v[1] / max(v[0], 1)) for k, v in kern.items() if v[0]}
+    out = {
+        "metric": "particle-landmark updates/sec",
+        "value": value,
+        "unit": "particle-landmark updates/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": res["seconds"] / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"fixed-N MCL (BASELINE.json configs[1]): {n} particles/GPU x {L} landmarks, "
+                        f"propagate+weight+{args.scheme} resample every step, likelihood={args.likelihood}",
+            "particles_per_gpu": n,
+            "landmarks": L,
+            "resample": args.scheme,
+            "sharding": "none" if world == 1 else f"particle blocks over {world} GPUs, RCCL all-gather of integer sums + segment exchange",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_propagate_weight",
+            "achieved": achieved / 1e9,
+            "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK,
+            "traffic": None,
+            "avg_kernel_ms": k1_avg_s * 1e3,
+            "algorithmic_bytes_per_launch": K1_BYTES_PER_PARTICLE * n,
+            "note": "FP64-VALU co-bound at L=32 (DESIGN.md): ~18 f64 ops per particle-landmark pair",
+        },
+        "kernel_ms_avg": step_kernel_ms,
+        "ms_per_step_instrumented": res.get("seconds_instrumented", 0.0) / K * 1e3,
+        "estimate": res.get("estimate"),
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(n, L, obs_list)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,241 @@
+/* rr_pf.h -- C ABI of the MI355X particle-filter localization engine.
+ *
+ * Drop-in boundary for the hot path of
+ *   rust_robotics_localization::particle_filter::ParticleFilterLocalizer
+ *     (/root/reference/crates/rust_robotics_localization/src/particle_filter.rs:121-573)
+ *   rust_robotics_localization::monte_carlo_localization::MonteCarloLocalizer in its
+ *     fixed-N mode, min_particles == max_particles
+ *     (/root/reference/crates/rust_robotics_localization/src/monte_carlo_localization.rs:136-462)
+ * The reference offers no FFI/plugin interface (it is `#![forbid(unsafe_code)]`
+ * Rust, lib.rs:1); the seam is its struct + trait surface.  Every entry point
+ * below names the reference method it stands in for; a Rust `-sys` crate binds
+ * them one to one (INTEGRATION.md shows the extern block and the safe wrapper
+ * implementing rust_robotics_core::StateEstimator, traits.rs:31-52).
+ *
+ * Conventions
+ *   - plain C, opaque handle, POD structs, no C++/torch types;
+ *   - every fallible call returns rr_status; rr_last_error() returns the message
+ *     of the calling thread's last failure.  RR_INVALID_PARAMETER corresponds to
+ *     RoboticsError::InvalidParameter (rust_robotics_core/src/error.rs:8-24) and
+ *     carries the reference's message text;
+ *   - one caller at a time per handle (the reference methods take &mut self);
+ *     distinct handles are independent (one HIP stream each);
+ *   - host pointers unless a parameter says "device";
+ *   - there is NO CPU fallback: creating a handle without a usable HIP device
+ *     fails with RR_RUNTIME_ERROR.
+ */
+#ifndef RR_PF_H
+#define RR_PF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rr_status {
+  RR_OK = 0,
+  RR_INVALID_PARAMETER = 1, /* RoboticsError::InvalidParameter */
+  RR_RUNTIME_ERROR = 2      /* HIP / allocation / device failure */
+} rr_status;
+
+/* message of the last failing call on this thread ("" if none) */
+const char* rr_last_error(void);
+/* library version string, e.g. "rust_robotics_amd 0.1.0 (gfx950)" */
+const char* rr_version(void);
+/* number of visible HIP devices (0 if none / runtime unusable) */
+int rr_device_count(void);
+
+/* ParticleFilterConfig, particle_filter.rs:51-65 (field for field) */
+typedef struct rr_pf_config {
+  uint64_t n_particles;
+  double resample_threshold;
+  double range_noise;
+  double velocity_noise;
+  double yaw_rate_noise;
+  double dt;
+} rr_pf_config;
+
+/* How the engine realises the parts of the step the reference leaves to its
+ * (unseedable) RNG and to its two resamplers. */
+typedef enum rr_resample_scheme {
+  RR_RESAMPLE_MULTINOMIAL = 0, /* particle_filter.rs:441-473, monte_carlo_localization.rs:343-355 */
+  RR_RESAMPLE_SYSTEMATIC = 1   /* fastslam1.rs:205-234 (low variance) */
+} rr_resample_scheme;
+typedef enum rr_resample_gate {
+  RR_GATE_NEFF = 0,  /* particle_filter.rs:337-345: iff N_eff < N * resample_threshold */
+  RR_GATE_ALWAYS = 1 /* monte_carlo_localization.rs:298: every step */
+} rr_resample_gate;
+typedef enum rr_likelihood_mode {
+  RR_LIK_FUSED = 0,  /* exp(L ln c - sum diff^2 / 2 sigma^2): one exp per particle */
+  RR_LIK_PRODUCT = 1 /* prod_l c * exp(-diff_l^2 / 2 sigma^2): the reference's literal form */
+} rr_likelihood_mode;
+
+typedef struct rr_pf_options {
+  int32_t device;          /* HIP device ordinal */
+  int32_t resample_scheme; /* rr_resample_scheme */
+  int32_t resample_gate;   /* rr_resample_gate */
+  int32_t likelihood_mode; /* rr_likelihood_mode */
+  uint64_t seed;           /* Philox key of this filter's noise streams */
+  /* sharding (rr_pf_shard_* below); a single-GPU filter uses 0 / 1 / 0 */
+  uint64_t first_global_index; /* global index of this shard's particle 0 */
+  uint64_t n_global;           /* particles over all shards; 0 => n_particles */
+  int32_t record_indices;      /* keep the last resample's source indices for rr_pf_last_resample_indices */
+  int32_t reserved;
+} rr_pf_options;
+
+typedef struct rr_pf rr_pf; /* opaque: device-resident particle set + stream */
+
+/* ParticleFilterConfig::default(), particle_filter.rs:67-78 */
+void rr_pf_config_default(rr_pf_config* cfg);
+/* ParticleFilterConfig::validate(), particle_filter.rs:81-117 (same messages) */
+rr_status rr_pf_config_validate(const rr_pf_config* cfg);
+/* PF defaults: device 0, multinomial, N_eff gate, fused likelihood, seed 0 */
+void rr_pf_options_default(rr_pf_options* opt);
+/* MonteCarloLocalizer fixed-N semantics: multinomial, resample every step */
+void rr_pf_options_mcl(rr_pf_options* opt);
+
+/* try_new, particle_filter.rs:139-156: all particles at the origin, w = 1/N */
+rr_status rr_pf_create(const rr_pf_config* cfg, const rr_pf_options* opt, rr_pf** out);
+/* try_with_initial_state, particle_filter.rs:170-199: uniform jitter
+ * (+-1, +-1, +-0.25, +-0.5) around state[4] = (x, y, yaw, v) */
+rr_status rr_pf_create_with_state(const rr_pf_config* cfg, const rr_pf_options* opt,
+                                  const double state[4], rr_pf** out);
+void rr_pf_destroy(rr_pf* h);
+
+/* try_set_landmarks :216-220 (stored only, never read by the update -- Q19);
+ * xy = n x (x, y) */
+rr_status rr_pf_set_landmarks(rr_pf* h, const double* xy, size_t n);
+size_t rr_pf_landmark_count(const rr_pf* h);
+/* get_landmarks :239-241; copies min(cap, count) points, returns count */
+size_t rr_pf_get_landmarks(const rr_pf* h, double* xy_out, size_t cap);
+/* set_range_noise :228-236 */
+rr_status rr_pf_set_range_noise(rr_pf* h, double range_noise);
+
+/* try_predict_with_control :255-301; control = (v, yaw_rate) */
+rr_status rr_pf_predict(rr_pf* h, const double control[2]);
+/* try_update_with_observations :310-334; obs = n_obs x (d, landmark_x, landmark_y) */
+rr_status rr_pf_update(rr_pf* h, const double* obs, size_t n_obs);
+/* resample :337-345 (gate per options) */
+rr_status rr_pf_resample(rr_pf* h);
+/* try_step :488-497 = predict + update + resample; writes the estimate */
+rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_t n_obs,
+                     double out_state[4]);
+/* the same step enqueued on the filter's stream without waiting for it: the
+ * form a node uses when it only publishes every k-th estimate, and what
+ * bench.py times.  Fused propagate+weight kernel, no host synchronisation. */
+rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs, size_t n_obs);
+/* wait for everything enqueued on the filter's stream */
+rr_status rr_pf_synchronize(rr_pf* h);
+
+/* estimate :348-350 -- weighted mean (x, y, yaw, v) of the current particle set */
+rr_status rr_pf_estimate(rr_pf* h, double out[4]);
+/* calc_covariance :363-365 -- 4x4 row-major */
+rr_status rr_pf_covariance(rr_pf* h, double out[16]);
+/* config.n_particles */
+uint64_t rr_pf_particle_count(const rr_pf* h);
+/* get_particles :244-246; out = N x (x, y, yaw, v, w) with normalised w */
+rr_status rr_pf_get_particles(rr_pf* h, double* out_aos);
+/* N_eff of the current weights, calc_n_eff :416-423 */
+rr_status rr_pf_n_eff(rr_pf* h, double* out);
+/* 1 if the most recent resample()/step() actually resampled */
+rr_status rr_pf_last_resample_fired(rr_pf* h, int32_t* out);
+
+/* ---- parity seams: what the reference keeps private, exposed so that the
+ * engine can be checked against the CPU oracles on identical inputs ---- */
+/* overwrite the particle set; aos = N x (x, y, yaw, v, w); w is taken as a raw weight */
+rr_status rr_pf_set_particles(rr_pf* h, const double* aos);
+/* predict with caller-supplied scaled noise samples instead of the Philox stream
+ * (n_v[i], n_w[i] are the values Normal(0, sigma).sample() would have returned) */
+rr_status rr_pf_predict_with_noise(rr_pf* h, const double control[2], const double* n_v,
+                                   const double* n_w);
+/* unconditional multinomial resample with caller-supplied uniforms r[N] in [0,1) */
+rr_status rr_pf_resample_with_uniforms(rr_pf* h, const double* r, size_t n);
+/* unconditional systematic resample with caller-supplied rho = r0 * N in [0,1) */
+rr_status rr_pf_resample_systematic(rr_pf* h, double rho);
+/* source index of every output slot of the last resample (needs record_indices) */
+rr_status rr_pf_last_resample_indices(rr_pf* h, uint32_t* out, size_t n);
+/* raw (unnormalised) weights as the weight kernel wrote them */
+rr_status rr_pf_get_raw_weights(rr_pf* h, double* out);
+/* integer image of the current weights: shift, T = sum q_i, sum q_i^2 (hi, lo), w_max */
+typedef struct rr_pf_fixed_sums {
+  int32_t usable; /* 0 => degenerate weights (uniform fallback, :433-438) */
+  int32_t shift;
+  uint64_t total;
+  uint64_t q2_hi, q2_lo;
+  double w_max;
+  double sum; /* total * 2^-shift */
+} rr_pf_fixed_sums;
+rr_status rr_pf_get_fixed_sums(rr_pf* h, rr_pf_fixed_sums* out);
+/* step / resample counters that key the Philox streams */
+rr_status rr_pf_get_counters(rr_pf* h, uint32_t* step, uint32_t* resample_step);
+
+/* ---- measurement hooks (bench.py): HIP-event timing of the engine's kernels on
+ * the filter's own stream ---- */
+typedef enum rr_pf_kernel_id {
+  RR_K_PROPAGATE_WEIGHT = 0,
+  RR_K_QUANTIZE_REDUCE = 1,
+  RR_K_SCAN_TILES = 2,
+  RR_K_CDF = 3,
+  RR_K_RESAMPLE_GATHER = 4,
+  RR_K_COMMIT = 5,
+  RR_K_MOMENTS = 6,
+  RR_K_COUNT = 7
+} rr_pf_kernel_id;
+/* enable != 0: bracket every kernel launch with hipEvents from now on */
+rr_status rr_pf_profile_enable(rr_pf* h, int32_t enable);
+/* accumulated since the last reset: launches and total milliseconds per kernel */
+rr_status rr_pf_profile_read(rr_pf* h, int32_t kernel_id, uint64_t* launches, double* total_ms);
+rr_status rr_pf_profile_reset(rr_pf* h);
+const char* rr_pf_kernel_name(int32_t kernel_id);
+
+/* ---- device self-test of the arithmetic contract (include/rr_detmath.h): evaluates one
+ * function of the contract ON THE GPU for n inputs so that tests can assert bit-identity
+ * with the host evaluation.  fn: 0 exp(a) 1 log(a) 2 sincos(a)->out0,out1 3 sincos2pi(a)
+ * 4 atan2(a,b) 5 sqrt(a) 6 a/b 7 normal2(seed=a[0] bits, stream 3, step b[0] bits, index i)
+ * 8 fma(a,b,a).  Host pointers; out1 may be NULL for single-output functions. */
+rr_status rr_selftest_math(int32_t device, int32_t fn, size_t n, const double* a, const double* b,
+                           double* out0, double* out1);
+
+/* ---- sharded (multi-GPU) operation: one shard per process/GPU, the host side
+ * (rust_robotics_amd/sharded.py) runs the RCCL collectives between the phases.
+ * All pointers here are DEVICE pointers on this shard's device; `stream` is the
+ * hipStream_t the caller's collectives are ordered on (NULL = the filter's own). */
+typedef struct rr_pf_shard_sums {
+  uint64_t total;        /* local T */
+  uint64_t q2_hi, q2_lo; /* local sum q^2 */
+} rr_pf_shard_sums;
+/* use `stream` (a hipStream_t) for all subsequent work of this handle */
+rr_status rr_pf_set_stream(rr_pf* h, void* stream);
+/* phase A: fused propagate + weight; writes the local max weight (as a double)
+ * to *d_wmax_out (device) */
+rr_status rr_pf_shard_propagate_weight(rr_pf* h, const double control[2], const double* obs,
+                                       size_t n_obs, double* d_wmax_out);
+/* phase B: quantise with the GLOBAL max *d_wmax_global (device), write local
+ * sums to *d_sums_out (device, rr_pf_shard_sums) */
+rr_status rr_pf_shard_quantize(rr_pf* h, const double* d_wmax_global, rr_pf_shard_sums* d_sums_out);
+/* phase C: given all shards' sums d_all_sums[n_shards] (device) and this shard's
+ * rank, build the local slice of the global CDF and decide the gate */
+rr_status rr_pf_shard_cdf(rr_pf* h, const rr_pf_shard_sums* d_all_sums, int32_t n_shards, int32_t rank);
+/* phase D (systematic only): gather the particles that output slots
+ * [first_slot, first_slot + n_slots) take from THIS shard into d_out
+ * (SoA, 4 planes of n_slots doubles: x | y | yaw | v) */
+rr_status rr_pf_shard_gather_slots(rr_pf* h, uint64_t first_slot, uint64_t n_slots, double* d_out);
+/* phase E: replace the particle set by d_in (SoA as above, N doubles per plane), w = 1/N_global */
+rr_status rr_pf_shard_adopt(rr_pf* h, const double* d_in);
+/* host copy of phase C's decision: fired flag, global total, this shard's CDF base, rho */
+typedef struct rr_pf_shard_plan {
+  int32_t fired;
+  int32_t usable;
+  uint64_t total_global;
+  uint64_t base;
+  uint64_t total_local;
+  double rho;
+} rr_pf_shard_plan;
+rr_status rr_pf_shard_get_plan(rr_pf* h, rr_pf_shard_plan* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RR_PF_H */

@@ -1,0 +1,147 @@
+"""ctypes binding of the engine's C ABI (include/rr_pf.h, include/rr_fastslam1.h).
+
+This is the Python twin of the Rust ``-sys`` crate shown in INTEGRATION.md: it
+declares exactly the entry points the headers declare and nothing else.  There is
+no fallback path: if ``librust_robotics_amd.so`` is missing the import fails
+loudly (build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C rust_robotics_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librust_robotics_amd.so")
+
+RR_OK, RR_INVALID_PARAMETER, RR_RUNTIME_ERROR = 0, 1, 2
+RR_RESAMPLE_MULTINOMIAL, RR_RESAMPLE_SYSTEMATIC = 0, 1
+RR_GATE_NEFF, RR_GATE_ALWAYS = 0, 1
+RR_LIK_FUSED, RR_LIK_PRODUCT = 0, 1
+RR_K_PROPAGATE_WEIGHT, RR_K_QUANTIZE_REDUCE, RR_K_SCAN_TILES, RR_K_CDF = 0, 1, 2, 3
+RR_K_RESAMPLE_GATHER, RR_K_COMMIT, RR_K_MOMENTS, RR_K_COUNT = 4, 5, 6, 7
+
+
+class PfConfig(C.Structure):
+    """rr_pf_config == ParticleFilterConfig (particle_filter.rs:51-65)"""
+
+    _fields_ = [
+        ("n_particles", C.c_uint64),
+        ("resample_threshold", C.c_double),
+        ("range_noise", C.c_double),
+        ("velocity_noise", C.c_double),
+        ("yaw_rate_noise", C.c_double),
+        ("dt", C.c_double),
+    ]
+
+
+class PfOptions(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32),
+        ("resample_scheme", C.c_int32),
+        ("resample_gate", C.c_int32),
+        ("likelihood_mode", C.c_int32),
+        ("seed", C.c_uint64),
+        ("first_global_index", C.c_uint64),
+        ("n_global", C.c_uint64),
+        ("record_indices", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class PfFixedSums(C.Structure):
+    _fields_ = [
+        ("usable", C.c_int32),
+        ("shift", C.c_int32),
+        ("total", C.c_uint64),
+        ("q2_hi", C.c_uint64),
+        ("q2_lo", C.c_uint64),
+        ("w_max", C.c_double),
+        ("sum", C.c_double),
+    ]
+
+
+class PfShardSums(C.Structure):
+    _fields_ = [("total", C.c_uint64), ("q2_hi", C.c_uint64), ("q2_lo", C.c_uint64)]
+
+
+class PfShardPlan(C.Structure):
+    _fields_ = [
+        ("fired", C.c_int32),
+        ("usable", C.c_int32),
+        ("total_global", C.c_uint64),
+        ("base", C.c_uint64),
+        ("total_local", C.c_uint64),
+        ("rho", C.c_double),
+    ]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load the shared library once and declare every prototype of include/rr_pf.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP engine has not been built and there is no CPU fallback. "
+            "Run `make -C rust_robotics_amd/csrc` (hipcc --offload-arch=gfx950)."
+        )
+    L = C.CDLL(LIB_PATH)
+    d, i32, u32, u64, sz = C.c_double, C.c_int32, C.c_uint32, C.c_uint64, C.c_size_t
+    P = C.POINTER(d)
+    H = C.c_void_p
+    st = C.c_int
+
+    def proto(name, res, args):
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+
+    proto("rr_last_error", C.c_char_p, [])
+    proto("rr_version", C.c_char_p, [])
+    proto("rr_device_count", C.c_int, [])
+    proto("rr_pf_config_default", None, [C.POINTER(PfConfig)])
+    proto("rr_pf_config_validate", st, [C.POINTER(PfConfig)])
+    proto("rr_pf_options_default", None, [C.POINTER(PfOptions)])
+    proto("rr_pf_options_mcl", None, [C.POINTER(PfOptions)])
+    proto("rr_pf_create", st, [C.POINTER(PfConfig), C.POINTER(PfOptions), C.POINTER(H)])
+    proto("rr_pf_create_with_state", st, [C.POINTER(PfConfig), C.POINTER(PfOptions), P, C.POINTER(H)])
+    proto("rr_pf_destroy", None, [H])
+    proto("rr_pf_set_landmarks", st, [H, P, sz])
+    proto("rr_pf_landmark_count", sz, [H])
+    proto("rr_pf_get_landmarks", sz, [H, P, sz])
+    proto("rr_pf_set_range_noise", st, [H, d])
+    proto("rr_pf_predict", st, [H, P])
+    proto("rr_pf_update", st, [H, P, sz])
+    proto("rr_pf_resample", st, [H])
+    proto("rr_pf_step", st, [H, P, P, sz, P])
+    proto("rr_pf_step_async", st, [H, P, P, sz])
+    proto("rr_pf_synchronize", st, [H])
+    proto("rr_pf_estimate", st, [H, P])
+    proto("rr_pf_covariance", st, [H, P])
+    proto("rr_pf_particle_count", u64, [H])
+    proto("rr_pf_get_particles", st, [H, P])
+    proto("rr_pf_n_eff", st, [H, P])
+    proto("rr_pf_last_resample_fired", st, [H, C.POINTER(i32)])
+    proto("rr_pf_set_particles", st, [H, P])
+    proto("rr_pf_predict_with_noise", st, [H, P, P, P])
+    proto("rr_pf_resample_with_uniforms", st, [H, P, sz])
+    proto("rr_pf_resample_systematic", st, [H, d])
+    proto("rr_pf_last_resample_indices", st, [H, C.POINTER(u32), sz])
+    proto("rr_pf_get_raw_weights", st, [H, P])
+    proto("rr_pf_get_fixed_sums", st, [H, C.POINTER(PfFixedSums)])
+    proto("rr_pf_get_counters", st, [H, C.POINTER(u32), C.POINTER(u32)])
+    proto("rr_pf_profile_enable", st, [H, i32])
+    proto("rr_pf_profile_read", st, [H, i32, C.POINTER(u64), P])
+    proto("rr_pf_profile_reset", st, [H])
+    proto("rr_pf_kernel_name", C.c_char_p, [i32])
+    proto("rr_selftest_math", st, [i32, i32, sz, P, P, P, P])
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().rr_last_error().decode()

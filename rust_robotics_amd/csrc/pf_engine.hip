@@ -1,0 +1,1235 @@
+// pf_engine.hip -- MI355X (gfx950) particle-filter / fixed-N MCL engine behind include/rr_pf.h.
+//
+// Replaces the CPU hot path of
+//   rust_robotics_localization/src/particle_filter.rs:255-301 (propagate), :310-334 (weight),
+//   :337-345,416-473 (N_eff gate + resample), :382-413 (mean / covariance)
+//   rust_robotics_localization/src/monte_carlo_localization.rs:209-288,322-365 (fixed-N mode)
+// (paths under /root/reference/crates).  Not a translation: the particle set lives in HBM as
+// structure-of-arrays, one thread per particle, the observation block is staged in LDS, weight
+// maxima/sums are wave64 shuffle reductions, and the resampling CDF is an integer
+// reduce-then-scan whose value is independent of summation order (include/rr_pf_spec.h).
+//
+// Kernels (one HIP stream per filter, no host synchronisation inside a step):
+//   k_propagate_weight   x,y,yaw -> x,y,yaw,v,w + atomic max(w)        64 B / particle
+//   k_quantize_reduce    w -> per-tile integer totals, sum q^2           8 B / particle
+//   k_scan_tiles         tile totals -> exclusive offsets, gate decision (single block)
+//   k_cdf                w -> inclusive integer CDF                     16 B / particle
+//   k_resample_gather    CDF search + SoA gather into the other buffer  ~72 B / particle
+//   k_commit             flip the live buffer
+//   k_moments(+final)    weighted first/second moments about particle 0 40 B / particle
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rr_common.hpp"
+#include "rr_pf.h"
+#include "rr_pf_spec.h"
+
+namespace rr {
+std::string& last_error_slot() {
+  static thread_local std::string s;
+  return s;
+}
+}  // namespace rr
+
+using rr::fail;
+using rr::u128;
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kItems = 8;
+constexpr int kTile = kBlock * kItems;  // 2048 particles per scan tile
+constexpr int kScanThreads = 1024;
+constexpr int kMaxObsKernarg = 96;      // observations that travel inside the launch packet
+constexpr int kMomentBlocks = 1024;
+constexpr int kNumMoments = 15;         // sum w, 4 first, 10 second moments
+
+// ---- device-resident control block: everything a later kernel needs to know about an
+// earlier one's data-dependent outcome, so the host never has to look.
+struct Ctl {
+  int cur;              // which of the two SoA buffer sets is live
+  int weights_uniform;  // 1 => every particle weighs 1/N (w[] is stale)
+  int usable;           // 0 => degenerate raw weights (uniform fallback, particle_filter.rs:433-438)
+  int shift;            // fixed-point shift of the current integer image
+  int fired;            // last gate decision
+  int pad0;
+  uint64_t wmax_bits;  // atomic max of the raw weights (bit pattern of a double >= 0)
+  uint64_t total;      // T (global in sharded mode)
+  uint64_t total_local;
+  uint64_t base;       // CDF base of this shard
+  uint64_t q2_hi, q2_lo;
+  double wmax;  // max used for the current integer image
+  double sum;   // T * 2^-shift
+  double neff;
+  double rho;
+  rr_sys_plan plan;
+  double moments[kNumMoments];
+  double shift_point[4];
+};
+
+struct Bufs {
+  double* x[2];
+  double* y[2];
+  double* yaw[2];
+  double* v[2];
+};
+
+struct ObsArg {
+  double v[3 * kMaxObsKernarg];
+};
+
+struct StepParams {
+  uint64_t n;          // particles in this shard
+  uint64_t n_global;
+  uint64_t first_gid;
+  uint64_t seed;
+  unsigned int step;
+  unsigned int rstep;
+  int n_obs;
+  int lik_mode;
+  double u0, u1, dt;
+  double sigma_v, sigma_w;
+  rr_pf_lik lik;
+};
+
+// ------------------------------------------------------------------------------------------
+// K1: propagate + weight.  One thread per particle; the observation block (d, lx, ly) x n_obs
+// is staged once per workgroup in LDS and read back with wave-uniform addresses (broadcast).
+// Reads x,y,yaw (24 B), writes x,y,yaw,v,w (40 B).  The per-particle maximum weight is reduced
+// across the wave with shuffles, across waves through LDS, and folded into Ctl with one
+// atomicMax per workgroup (bit pattern of a non-negative double is order preserving).
+template <bool PREDICT, bool WEIGHT, bool EXPLICIT_NOISE, bool OBS_KERNARG>
+__global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __restrict__ w,
+                                                            Ctl* __restrict__ ctl, StepParams p,
+                                                            ObsArg obs_arg,
+                                                            const double* __restrict__ obs_dev,
+                                                            const double* __restrict__ nv,
+                                                            const double* __restrict__ nw) {
+  extern __shared__ double s_obs[];
+  __shared__ double s_wmax[kBlock / rr::kWave];
+  const int tid = threadIdx.x;
+  if (WEIGHT) {
+    for (int i = tid; i < 3 * p.n_obs; i += kBlock) s_obs[i] = OBS_KERNARG ? obs_arg.v[i] : obs_dev[i];
+    __syncthreads();
+  }
+  const int cur = ctl->cur;
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + tid;
+  double wgt = 0.0;
+  if (i < p.n) {
+    double x = b.x[cur][i], y = b.y[cur][i];
+    if (PREDICT) {
+      double yaw = b.yaw[cur][i], v;
+      double a, c;
+      if (EXPLICIT_NOISE) {
+        a = nv[i];
+        c = nw[i];
+      } else {
+        rr_pf_motion_noise(p.seed, p.step, p.first_gid + i, p.sigma_v, p.sigma_w, &a, &c);
+      }
+      rr_pf_propagate_one(&x, &y, &yaw, &v, p.u0, p.u1, p.dt, a, c);
+      b.x[cur][i] = x;
+      b.y[cur][i] = y;
+      b.yaw[cur][i] = yaw;
+      b.v[cur][i] = v;
+    }
+    if (WEIGHT) {
+      wgt = p.lik_mode == RR_LIK_PRODUCT ? rr_pf_weight_product(x, y, s_obs, p.n_obs, p.lik)
+                                         : rr_pf_weight_fused(x, y, s_obs, p.n_obs, p.lik);
+      w[i] = wgt;
+    }
+  }
+  if (WEIGHT) {
+    double m = wgt > 0.0 ? wgt : 0.0;  // NaN and negatives drop out
+    m = rr::wave_max(m);
+    if ((tid & 63) == 0) s_wmax[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+      double bm = s_wmax[0];
+      for (int k = 1; k < kBlock / rr::kWave; ++k) bm = s_wmax[k] > bm ? s_wmax[k] : bm;
+      if (bm > 0.0) rr::atomic_max_u64(&ctl->wmax_bits, rr_d2u(bm));
+      if (blockIdx.x == 0) ctl->weights_uniform = 0;
+    }
+  }
+}
+
+// q_i of particle i under the current integer image
+__device__ inline uint64_t quantize_at(const double* __restrict__ w, uint64_t i,
+                                                 uint64_t n, bool uniform, int shift) {
+  if (i >= n) return 0ull;
+  return uniform ? 1ull : rr_fix_quantize(w[i], shift);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: per-tile integer totals and sum of squares.  Tile = 2048 particles; each wave owns 512
+// consecutive particles as 8 coalesced rows of 64.  wmax_src points at the maximum to scale by
+// (Ctl.wmax_bits on one GPU, the all-reduced maximum when sharded).
+__global__ __launch_bounds__(kBlock) void k_quantize_reduce(const double* __restrict__ w,
+                                                           Ctl* __restrict__ ctl,
+                                                           const double* __restrict__ wmax_src,
+                                                           uint64_t n,
+                                                           uint64_t n_global,
+                                                           uint64_t* __restrict__ tile_total,
+                                                           uint64_t* __restrict__ tile_q2) {
+  __shared__ uint64_t s_t[kBlock / rr::kWave];
+  __shared__ uint64_t s_qh[kBlock / rr::kWave];
+  __shared__ uint64_t s_ql[kBlock / rr::kWave];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const double wmax = *wmax_src;
+  const bool usable = !ctl->weights_uniform && wmax > 0.0 && wmax < INFINITY;
+  const int shift = usable ? rr_fix_shift(wmax, n_global) : 0;
+  const uint64_t base = (uint64_t)blockIdx.x * kTile + (uint64_t)wv * (kTile / 4);
+  uint64_t t = 0;
+  u128 q2 = {0, 0};
+#pragma unroll
+  for (int r = 0; r < kItems; ++r) {
+    uint64_t q = quantize_at(w, base + r * 64 + lane, n, !usable, shift);
+    t += q;
+    u128 sq;
+    rr_mul64wide(q, q, &sq.hi, &sq.lo);
+    q2 = rr::add128(q2, sq);
+  }
+  t = rr::wave_sum_u64(t);
+  q2 = rr::wave_sum_u128(q2);
+  if (lane == 0) {
+    s_t[wv] = t;
+    s_qh[wv] = q2.hi;
+    s_ql[wv] = q2.lo;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint64_t tt = 0;
+    u128 qq = {0, 0};
+    for (int k = 0; k < kBlock / rr::kWave; ++k) {
+      tt += s_t[k];
+      qq = rr::add128(qq, u128{s_qh[k], s_ql[k]});
+    }
+    tile_total[blockIdx.x] = tt;
+    tile_q2[2 * blockIdx.x] = qq.hi;
+    tile_q2[2 * blockIdx.x + 1] = qq.lo;
+    if (blockIdx.x == 0) {
+      ctl->usable = usable ? 1 : 0;
+      ctl->shift = shift;
+      ctl->wmax = wmax;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3: single workgroup.  Exclusive scan of the tile totals (in place), grand totals, the gate
+// decision (particle_filter.rs:337-345 / monte_carlo_localization.rs:298) and the systematic
+// plan.  mode: 0 = decide by gate, 1 = force fire, 2 = statistics only (never fire).
+struct ScanArgs {
+  uint64_t n_tiles;
+  uint64_t n_global;
+  double threshold;  // resample_threshold
+  int gate;          // rr_resample_gate
+  int mode;
+  int scheme;
+  double rho_override;  // NaN => Philox
+  uint64_t seed;
+  unsigned int rstep;
+};
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_tiles(uint64_t* __restrict__ tile_total,
+                                                            const uint64_t* __restrict__ tile_q2,
+                                                            Ctl* __restrict__ ctl, ScanArgs a) {
+  __shared__ uint64_t s_w[kScanThreads / rr::kWave];
+  __shared__ uint64_t s_h[kScanThreads / rr::kWave];
+  __shared__ uint64_t s_l[kScanThreads / rr::kWave];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint64_t per = (a.n_tiles + kScanThreads - 1) / kScanThreads;
+  const uint64_t lo = (uint64_t)tid * per;
+  const uint64_t hi = lo + per < a.n_tiles ? lo + per : a.n_tiles;
+  uint64_t local = 0;
+  u128 q2 = {0, 0};
+  for (uint64_t k = lo; k < hi; ++k) {
+    local += tile_total[k];
+    q2 = rr::add128(q2, u128{tile_q2[2 * k], tile_q2[2 * k + 1]});
+  }
+  uint64_t incl = rr::wave_scan_u64(local, lane);
+  u128 q2w = rr::wave_sum_u128(q2);
+  if (lane == 63) s_w[wv] = incl;
+  if (lane == 0) {
+    s_h[wv] = q2w.hi;
+    s_l[wv] = q2w.lo;
+  }
+  __syncthreads();
+  uint64_t wave_off = 0;
+  for (int k = 0; k < wv; ++k) wave_off += s_w[k];
+  uint64_t run = wave_off + incl - local;  // exclusive prefix of this thread's range
+  for (uint64_t k = lo; k < hi; ++k) {
+    uint64_t t = tile_total[k];
+    tile_total[k] = run;
+    run += t;
+  }
+  if (tid == 0) {
+    uint64_t total = 0;
+    u128 qq = {0, 0};
+    for (int k = 0; k < kScanThreads / rr::kWave; ++k) {
+      total += s_w[k];
+      qq = rr::add128(qq, u128{s_h[k], s_l[k]});
+    }
+    int usable = ctl->usable;
+    if (usable && total == 0) usable = 0;  // everything quantised to zero cannot happen (w_max > 0) but stay safe
+    ctl->total_local = total;
+    ctl->total = total;
+    ctl->base = 0;
+    ctl->q2_hi = qq.hi;
+    ctl->q2_lo = qq.lo;
+    double neff, sum;
+    if (usable) {
+      sum = rr_fix_total_to_double(total, ctl->shift);
+      neff = rr_fix_neff(total, qq.hi, qq.lo);
+    } else {  // uniform image q_i = 1: T = n, N_eff = n
+      sum = 1.0;
+      neff = (double)a.n_global;
+    }
+    ctl->sum = sum;
+    ctl->neff = neff;
+    if (a.mode == 2) return;  // statistics only: leave the last gate decision alone
+    int fire = 0;
+    if (a.mode == 1) fire = 1;
+    else fire = a.gate == RR_GATE_ALWAYS ? 1 : (neff < (double)a.n_global * a.threshold);
+    ctl->fired = fire;
+    if (fire && a.scheme == RR_RESAMPLE_SYSTEMATIC) {
+      double rho = a.rho_override;
+      if (rho != rho) {
+        double dummy;
+        rr_uniform2(a.seed, RR_STREAM_RESAMPLE, a.rstep, 0, &rho, &dummy);
+      }
+      ctl->rho = rho;
+      ctl->plan = rr_sys_plan_make(rho, total, a.n_global);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: inclusive integer CDF of this shard: cdf[i] = base + tile_offset + within-tile scan.
+// Reads w (8 B), writes cdf (8 B).  Skipped when the gate did not fire.
+__global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, const Ctl* __restrict__ ctl,
+                                               uint64_t n,
+                                               const uint64_t* __restrict__ tile_offset,
+                                               uint64_t* __restrict__ cdf) {
+  if (!ctl->fired) return;
+  __shared__ uint64_t s_w[kBlock / rr::kWave];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool uniform = !ctl->usable;
+  const int shift = ctl->shift;
+  const uint64_t base = (uint64_t)blockIdx.x * kTile + (uint64_t)wv * (kTile / 4);
+  uint64_t vals[kItems];
+  uint64_t carry = 0;
+#pragma unroll
+  for (int r = 0; r < kItems; ++r) {
+    uint64_t q = quantize_at(w, base + r * 64 + lane, n, uniform, shift);
+    uint64_t incl = rr::wave_scan_u64(q, lane);
+    vals[r] = incl + carry;
+    carry += rr::shfl_u64(incl, 63);
+  }
+  if (lane == 0) s_w[wv] = carry;
+  __syncthreads();
+  uint64_t off = ctl->base + tile_offset[blockIdx.x];
+  for (int k = 0; k < wv; ++k) off += s_w[k];
+#pragma unroll
+  for (int r = 0; r < kItems; ++r) {
+    uint64_t i = base + r * 64 + lane;
+    if (i < n) cdf[i] = vals[r] + off;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: one thread per output slot: CDF target (multinomial draw or systematic position), lower
+// bound in the integer CDF, SoA gather from the live buffer set into the other one.
+struct GatherArgs {
+  uint64_t n_src;       // CDF entries (particles of this shard)
+  uint64_t first_slot;  // global index of output slot 0 handled here
+  uint64_t n_slots;
+  uint64_t seed;
+  unsigned int rstep;
+  int scheme;
+  int to_staging;  // 1 => write the gathered particles to `staging` (sharded exchange) instead of the other buffer set
+};
+
+__global__ __launch_bounds__(kBlock) void k_resample_gather(Bufs b, const Ctl* __restrict__ ctl,
+                                                           const uint64_t* __restrict__ cdf,
+                                                           const double* __restrict__ r_explicit,
+                                                           unsigned int* __restrict__ idx_out,
+                                                           double* __restrict__ staging, GatherArgs a) {
+  if (!ctl->fired) return;
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= a.n_slots) return;
+  const int cur = ctl->cur;
+  const uint64_t slot = a.first_slot + k;
+  uint64_t target;
+  if (a.scheme == RR_RESAMPLE_SYSTEMATIC) {
+    target = rr_sys_target(ctl->plan, slot);
+  } else {
+    double r, dummy;
+    if (r_explicit) r = r_explicit[k];
+    else rr_uniform2(a.seed, RR_STREAM_RESAMPLE, a.rstep, slot, &r, &dummy);
+    target = rr_fix_target_multinomial(r, ctl->total);
+  }
+  const uint64_t j = rr_lower_bound_u64(cdf, a.n_src, target);
+  const double x = b.x[cur][j], y = b.y[cur][j], yaw = b.yaw[cur][j], v = b.v[cur][j];
+  if (a.to_staging) {
+    staging[k] = x;
+    staging[a.n_slots + k] = y;
+    staging[2 * a.n_slots + k] = yaw;
+    staging[3 * a.n_slots + k] = v;
+  } else {
+    const int nxt = cur ^ 1;
+    b.x[nxt][k] = x;
+    b.y[nxt][k] = y;
+    b.yaw[nxt][k] = yaw;
+    b.v[nxt][k] = v;
+  }
+  if (idx_out) idx_out[k] = (unsigned int)j;
+}
+
+// K6: publish the resampled set (particle_filter.rs:467-472: w = 1/N for every particle)
+__global__ void k_commit(Ctl* ctl) {
+  if (ctl->fired) {
+    ctl->cur ^= 1;
+    ctl->weights_uniform = 1;
+  }
+}
+
+// sharded adopt: copy a received SoA block into the other buffer set, then commit
+__global__ __launch_bounds__(kBlock) void k_adopt(Bufs b, const Ctl* __restrict__ ctl,
+                                                 const double* __restrict__ in, uint64_t n) {
+  if (!ctl->fired) return;
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n) return;
+  const int nxt = ctl->cur ^ 1;
+  b.x[nxt][k] = in[k];
+  b.y[nxt][k] = in[n + k];
+  b.yaw[nxt][k] = in[2 * n + k];
+  b.v[nxt][k] = in[3 * n + k];
+}
+
+// ------------------------------------------------------------------------------------------
+// K7: weighted moments about the shift point p0 = particle 0 of the live set (always inside
+// the cloud, so the one-pass covariance does not cancel): sum w, sum w d, sum w d d^T with
+// d = p - p0.  Grid-stride, 15 accumulators per thread, wave shuffle + LDS, per-block partials
+// combined by k_moments_final in block order.  force_uniform => w_i = 1.
+__global__ __launch_bounds__(kBlock) void k_moments(Bufs b, const double* __restrict__ w,
+                                                   const Ctl* __restrict__ ctl, uint64_t n,
+                                                   int force_uniform, double* __restrict__ partials) {
+  __shared__ double s_acc[kBlock / rr::kWave][kNumMoments];
+  const int cur = ctl->cur;
+  const bool uniform = force_uniform || ctl->weights_uniform;
+  const double p0x = b.x[cur][0], p0y = b.y[cur][0], p0a = b.yaw[cur][0], p0v = b.v[cur][0];
+  double acc[kNumMoments];
+#pragma unroll
+  for (int k = 0; k < kNumMoments; ++k) acc[k] = 0.0;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
+       i += (uint64_t)gridDim.x * kBlock) {
+    const double wi = uniform ? 1.0 : w[i];
+    const double d0 = b.x[cur][i] - p0x, d1 = b.y[cur][i] - p0y, d2 = b.yaw[cur][i] - p0a, d3 = b.v[cur][i] - p0v;
+    const double w0 = wi * d0, w1 = wi * d1, w2 = wi * d2, w3 = wi * d3;
+    acc[0] += wi;
+    acc[1] += w0; acc[2] += w1; acc[3] += w2; acc[4] += w3;
+    acc[5] += w0 * d0; acc[6] += w0 * d1; acc[7] += w0 * d2; acc[8] += w0 * d3;
+    acc[9] += w1 * d1; acc[10] += w1 * d2; acc[11] += w1 * d3;
+    acc[12] += w2 * d2; acc[13] += w2 * d3;
+    acc[14] += w3 * d3;
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < kNumMoments; ++k) {
+    double s = rr::wave_sum(acc[k]);
+    if (lane == 0) s_acc[wv][k] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < kNumMoments) {
+    double s = 0.0;
+    for (int k = 0; k < kBlock / rr::kWave; ++k) s += s_acc[k][threadIdx.x];
+    partials[(uint64_t)blockIdx.x * kNumMoments + threadIdx.x] = s;
+  }
+}
+
+__global__ void k_moments_final(Bufs b, Ctl* __restrict__ ctl, const double* __restrict__ partials, int n_blocks) {
+  const int k = threadIdx.x;
+  if (k < kNumMoments) {
+    double s = 0.0;
+    for (int j = 0; j < n_blocks; ++j) s += partials[j * kNumMoments + k];
+    ctl->moments[k] = s;
+  }
+  if (k == 0) {
+    const int cur = ctl->cur;
+    ctl->shift_point[0] = b.x[cur][0];
+    ctl->shift_point[1] = b.y[cur][0];
+    ctl->shift_point[2] = b.yaw[cur][0];
+    ctl->shift_point[3] = b.v[cur][0];
+  }
+}
+
+// initial clouds
+__global__ __launch_bounds__(kBlock) void k_init(Bufs b, double* __restrict__ w, uint64_t n,
+                                                uint64_t n_global, uint64_t first_gid,
+                                                uint64_t seed, int jitter, double s0, double s1,
+                                                double s2, double s3) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  double x = 0.0, y = 0.0, yaw = 0.0, v = 0.0;
+  if (jitter) {
+    const double st[4] = {s0, s1, s2, s3};
+    rr_pf_init_one(seed, first_gid + i, st, &x, &y, &yaw, &v);
+  }
+  b.x[0][i] = x;
+  b.y[0][i] = y;
+  b.yaw[0][i] = yaw;
+  b.v[0][i] = v;
+  w[i] = 1.0 / (double)n_global;
+}
+
+// AoS (x,y,yaw,v,w) <-> SoA
+__global__ __launch_bounds__(kBlock) void k_pack_aos(Bufs b, const double* __restrict__ w,
+                                                    const Ctl* __restrict__ ctl, uint64_t n,
+                                                    uint64_t n_global, double* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const int cur = ctl->cur;
+  double wi;
+  if (ctl->weights_uniform || !ctl->usable) wi = 1.0 / (double)n_global;
+  else wi = w[i] / ctl->sum;
+  out[5 * i] = b.x[cur][i];
+  out[5 * i + 1] = b.y[cur][i];
+  out[5 * i + 2] = b.yaw[cur][i];
+  out[5 * i + 3] = b.v[cur][i];
+  out[5 * i + 4] = wi;
+}
+
+__global__ __launch_bounds__(kBlock) void k_unpack_aos(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
+                                                      uint64_t n, const double* __restrict__ in) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int cur = ctl->cur;
+  double wi = 0.0;
+  if (i < n) {
+    b.x[cur][i] = in[5 * i];
+    b.y[cur][i] = in[5 * i + 1];
+    b.yaw[cur][i] = in[5 * i + 2];
+    b.v[cur][i] = in[5 * i + 3];
+    wi = in[5 * i + 4];
+    w[i] = wi;
+  }
+  double m = wi > 0.0 ? wi : 0.0;
+  m = rr::wave_max(m);
+  if ((threadIdx.x & 63) == 0 && m > 0.0) rr::atomic_max_u64(&ctl->wmax_bits, rr_d2u(m));
+  if (i == 0) ctl->weights_uniform = 0;
+}
+
+}  // namespace
+
+// =============================================================================================
+// host side
+// =============================================================================================
+
+struct rr_pf {
+  rr_pf_config cfg;
+  rr_pf_options opt;
+  uint64_t n = 0, n_global = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+  Bufs b{};
+  double* w = nullptr;
+  uint64_t* cdf = nullptr;
+  uint64_t* tile_total = nullptr;
+  uint64_t* tile_q2 = nullptr;
+  unsigned int* idx = nullptr;
+  double* partials = nullptr;
+  double* scratch_a = nullptr;  // n doubles: explicit noise v / uniforms / AoS staging (5n)
+  double* scratch_b = nullptr;  // n doubles: explicit noise w
+  double* obs_dev = nullptr;
+  size_t obs_cap = 0;
+  Ctl* ctl = nullptr;
+  Ctl* ctl_host = nullptr;  // pinned
+  uint64_t n_tiles = 0;
+  unsigned int step = 0, rstep = 0;
+  rr_pf_lik lik{};
+  std::vector<double> landmarks;
+  // profiling
+  bool profiling = false;
+  struct Ev { int id; hipEvent_t a, b; };
+  std::vector<Ev> events;
+  std::vector<hipEvent_t> event_pool;
+  uint64_t prof_launches[RR_K_COUNT] = {};
+  double prof_ms[RR_K_COUNT] = {};
+};
+
+namespace {
+
+const char* kKernelNames[RR_K_COUNT] = {"k_propagate_weight", "k_quantize_reduce", "k_scan_tiles", "k_cdf",
+                                        "k_resample_gather",  "k_commit",          "k_moments"};
+
+struct Timed {
+  rr_pf* h;
+  int id;
+  hipEvent_t a = nullptr, b = nullptr;
+  Timed(rr_pf* h_, int id_) : h(h_), id(id_) {
+    if (!h->profiling) return;
+    auto take = [&]() {
+      hipEvent_t e;
+      if (!h->event_pool.empty()) {
+        e = h->event_pool.back();
+        h->event_pool.pop_back();
+      } else {
+        (void)hipEventCreate(&e);
+      }
+      return e;
+    };
+    a = take();
+    b = take();
+    (void)hipEventRecord(a, h->stream);
+  }
+  ~Timed() {
+    if (!h->profiling) return;
+    (void)hipEventRecord(b, h->stream);
+    h->events.push_back({id, a, b});
+  }
+};
+
+inline unsigned grid_for(uint64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+rr_status validate_config(const rr_pf_config* c) {
+  // messages are the reference's (particle_filter.rs:81-117)
+  if (!c) return fail(RR_INVALID_PARAMETER, "null config");
+  if (c->n_particles == 0) return fail(RR_INVALID_PARAMETER, "particle filter requires at least one particle");
+  if (!std::isfinite(c->resample_threshold) || c->resample_threshold < 0.0 || c->resample_threshold > 1.0)
+    return fail(RR_INVALID_PARAMETER, "particle filter resample_threshold must be within [0.0, 1.0]");
+  if (!std::isfinite(c->range_noise) || c->range_noise <= 0.0)
+    return fail(RR_INVALID_PARAMETER, "particle filter range_noise must be positive and finite");
+  if (!std::isfinite(c->velocity_noise) || c->velocity_noise < 0.0)
+    return fail(RR_INVALID_PARAMETER, "particle filter velocity_noise must be non-negative and finite");
+  if (!std::isfinite(c->yaw_rate_noise) || c->yaw_rate_noise < 0.0)
+    return fail(RR_INVALID_PARAMETER, "particle filter yaw_rate_noise must be non-negative and finite");
+  if (!std::isfinite(c->dt) || c->dt <= 0.0)
+    return fail(RR_INVALID_PARAMETER, "particle filter dt must be positive and finite");
+  return RR_OK;
+}
+
+rr_status validate_control(const double u[2]) {  // particle_filter.rs:515-523
+  if (!u || !std::isfinite(u[0]) || !std::isfinite(u[1]))
+    return fail(RR_INVALID_PARAMETER, "particle filter control input must contain only finite values");
+  return RR_OK;
+}
+
+rr_status validate_obs(const double* obs, size_t n_obs) {  // particle_filter.rs:538-549
+  if (n_obs && !obs) return fail(RR_INVALID_PARAMETER, "null observations");
+  for (size_t k = 0; k < n_obs; ++k) {
+    const double d = obs[3 * k], x = obs[3 * k + 1], y = obs[3 * k + 2];
+    if (!std::isfinite(d) || !std::isfinite(x) || !std::isfinite(y) || d < 0.0)
+      return fail(RR_INVALID_PARAMETER, "particle filter observations must have finite, non-negative distances");
+  }
+  return RR_OK;
+}
+
+rr_status bind(rr_pf* h) {
+  if (!h) return fail(RR_INVALID_PARAMETER, "null handle");
+  RR_HIP_TRY(hipSetDevice(h->opt.device));
+  return RR_OK;
+}
+
+StepParams make_params(const rr_pf* h, const double u[2], int n_obs) {
+  StepParams p{};
+  p.n = h->n;
+  p.n_global = h->n_global;
+  p.first_gid = h->opt.first_global_index;
+  p.seed = h->opt.seed;
+  p.step = h->step;
+  p.rstep = h->rstep;
+  p.n_obs = n_obs;
+  p.lik_mode = h->opt.likelihood_mode;
+  p.u0 = u ? u[0] : 0.0;
+  p.u1 = u ? u[1] : 0.0;
+  p.dt = h->cfg.dt;
+  p.sigma_v = h->cfg.velocity_noise;
+  p.sigma_w = h->cfg.yaw_rate_noise;
+  p.lik = h->lik;
+  return p;
+}
+
+// stage the observation block: inside the launch packet when it fits, else a device buffer
+rr_status stage_obs(rr_pf* h, const double* obs, size_t n_obs, ObsArg* arg, bool* kernarg) {
+  *kernarg = n_obs <= (size_t)kMaxObsKernarg;
+  if (*kernarg) {
+    if (n_obs) std::memcpy(arg->v, obs, 3 * n_obs * sizeof(double));
+    return RR_OK;
+  }
+  if (n_obs > h->obs_cap) {
+    if (h->obs_dev) RR_HIP_TRY(hipFree(h->obs_dev));
+    h->obs_dev = nullptr;
+    h->obs_cap = 0;
+    RR_HIP_TRY(hipMalloc(&h->obs_dev, 3 * n_obs * sizeof(double)));
+    h->obs_cap = n_obs;
+  }
+  // pageable source: HIP stages it before returning, so the caller's buffer may be reused
+  RR_HIP_TRY(hipMemcpyAsync(h->obs_dev, obs, 3 * n_obs * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  return RR_OK;
+}
+
+template <bool PREDICT, bool WEIGHT, bool EXPLICIT>
+rr_status launch_pw(rr_pf* h, const StepParams& p, const ObsArg& arg, bool kernarg) {
+  const unsigned grid = grid_for(h->n, kBlock);
+  const size_t lds = WEIGHT ? 3 * (size_t)p.n_obs * sizeof(double) : 0;
+  if (lds > 150 * 1024) return fail(RR_INVALID_PARAMETER, "too many observations for one LDS block (max 6400)");
+  if (WEIGHT) RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+  {
+    Timed t(h, RR_K_PROPAGATE_WEIGHT);
+    if (kernarg)
+      hipLaunchKernelGGL((k_propagate_weight<PREDICT, WEIGHT, EXPLICIT, true>), dim3(grid), dim3(kBlock), lds,
+                         h->stream, h->b, h->w, h->ctl, p, arg, (const double*)nullptr, h->scratch_a, h->scratch_b);
+    else
+      hipLaunchKernelGGL((k_propagate_weight<PREDICT, WEIGHT, EXPLICIT, false>), dim3(grid), dim3(kBlock), lds,
+                         h->stream, h->b, h->w, h->ctl, p, arg, (const double*)h->obs_dev, h->scratch_a,
+                         h->scratch_b);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+// quantize-reduce + tile scan (+ gate).  mode as k_scan_tiles.
+rr_status launch_sums(rr_pf* h, int mode, int scheme, double rho_override) {
+  {
+    Timed t(h, RR_K_QUANTIZE_REDUCE);
+    hipLaunchKernelGGL(k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->w, h->ctl,
+                       (const double*)&h->ctl->wmax_bits, h->n, h->n_global, h->tile_total, h->tile_q2);
+  }
+  ScanArgs a{};
+  a.n_tiles = h->n_tiles;
+  a.n_global = h->n_global;
+  a.threshold = h->cfg.resample_threshold;
+  a.gate = h->opt.resample_gate;
+  a.mode = mode;
+  a.scheme = scheme;
+  a.rho_override = rho_override;
+  a.seed = h->opt.seed;
+  a.rstep = h->rstep;
+  {
+    Timed t(h, RR_K_SCAN_TILES);
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl, a);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+// the resample pipeline after the sums: CDF, gather, commit (all no-ops on the device if the
+// gate did not fire)
+rr_status launch_resample(rr_pf* h, int scheme, const double* r_explicit_dev) {
+  {
+    Timed t(h, RR_K_CDF);
+    hipLaunchKernelGGL(k_cdf, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->w, h->ctl, h->n,
+                       h->tile_total, h->cdf);
+  }
+  GatherArgs g{};
+  g.n_src = h->n;
+  g.first_slot = 0;
+  g.n_slots = h->n;
+  g.seed = h->opt.seed;
+  g.rstep = h->rstep;
+  g.scheme = scheme;
+  g.to_staging = 0;
+  {
+    Timed t(h, RR_K_RESAMPLE_GATHER);
+    hipLaunchKernelGGL(k_resample_gather, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl,
+                       h->cdf, r_explicit_dev, h->idx, (double*)nullptr, g);
+  }
+  {
+    Timed t(h, RR_K_COMMIT);
+    hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, h->stream, h->ctl);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  h->rstep += 1;
+  return RR_OK;
+}
+
+rr_status fetch_ctl(rr_pf* h) {
+  RR_HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return RR_OK;
+}
+
+rr_status compute_moments(rr_pf* h, double est[4], double cov[16]) {
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    const int blocks = (int)std::min<uint64_t>(kMomentBlocks, grid_for(h->n, kBlock));
+    {
+      Timed t(h, RR_K_MOMENTS);
+      hipLaunchKernelGGL(k_moments, dim3(blocks), dim3(kBlock), 0, h->stream, h->b, h->w, h->ctl, h->n, attempt,
+                         h->partials);
+      hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(64), 0, h->stream, h->b, h->ctl, h->partials, blocks);
+    }
+    RR_HIP_TRY(hipGetLastError());
+    rr_status s = fetch_ctl(h);
+    if (s != RR_OK) return s;
+    const double W = h->ctl_host->moments[0];
+    if (W > 0.0 && std::isfinite(W)) break;
+    // sum of weights <= 0: the reference's normalize_weights falls back to uniform weights
+    // (particle_filter.rs:433-438); redo with w_i = 1
+  }
+  const double* m = h->ctl_host->moments;
+  const double* p0 = h->ctl_host->shift_point;
+  const double W = m[0];
+  double d[4] = {m[1] / W, m[2] / W, m[3] / W, m[4] / W};
+  if (est)
+    for (int k = 0; k < 4; ++k) est[k] = p0[k] + d[k];
+  if (cov) {
+    const int idx[4][4] = {{5, 6, 7, 8}, {6, 9, 10, 11}, {7, 10, 12, 13}, {8, 11, 13, 14}};
+    for (int r = 0; r < 4; ++r)
+      for (int c = 0; c < 4; ++c) cov[4 * r + c] = m[idx[r][c]] / W - d[r] * d[c];
+  }
+  return RR_OK;
+}
+
+void drain_events(rr_pf* h) {
+  for (auto& e : h->events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      h->prof_ms[e.id] += ms;
+      h->prof_launches[e.id] += 1;
+    }
+    h->event_pool.push_back(e.a);
+    h->event_pool.push_back(e.b);
+  }
+  h->events.clear();
+}
+
+rr_status create_common(const rr_pf_config* cfg, const rr_pf_options* opt_in, const double* state, rr_pf** out) {
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output handle");
+  *out = nullptr;
+  rr_status s = validate_config(cfg);
+  if (s != RR_OK) return s;
+  rr_pf_options opt;
+  if (opt_in) opt = *opt_in; else rr_pf_options_default(&opt);
+  if (state)
+    for (int k = 0; k < 4; ++k)
+      if (!std::isfinite(state[k]))  // particle_filter.rs:505-513
+        return fail(RR_INVALID_PARAMETER, "particle filter state must contain only finite values");
+  if (cfg->n_particles >= (1ull << 31)) return fail(RR_INVALID_PARAMETER, "n_particles must be below 2^31 per shard");
+  const uint64_t n_global = opt.n_global ? opt.n_global : cfg->n_particles;
+  if (n_global >= (1ull << 31)) return fail(RR_INVALID_PARAMETER, "n_global must be below 2^31");
+  if (opt.first_global_index + cfg->n_particles > n_global)
+    return fail(RR_INVALID_PARAMETER, "shard range exceeds n_global");
+  if (opt.resample_scheme != RR_RESAMPLE_MULTINOMIAL && opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC)
+    return fail(RR_INVALID_PARAMETER, "unknown resample_scheme");
+  if (opt.resample_gate != RR_GATE_NEFF && opt.resample_gate != RR_GATE_ALWAYS)
+    return fail(RR_INVALID_PARAMETER, "unknown resample_gate");
+  if (opt.likelihood_mode != RR_LIK_FUSED && opt.likelihood_mode != RR_LIK_PRODUCT)
+    return fail(RR_INVALID_PARAMETER, "unknown likelihood_mode");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(RR_RUNTIME_ERROR, "no HIP device available: the engine has no CPU fallback");
+  if (opt.device < 0 || opt.device >= ndev) return fail(RR_INVALID_PARAMETER, "device ordinal out of range");
+  RR_HIP_TRY(hipSetDevice(opt.device));
+
+  rr_pf* h = new rr_pf();
+  h->cfg = *cfg;
+  h->opt = opt;
+  h->n = cfg->n_particles;
+  h->n_global = n_global;
+  h->n_tiles = (h->n + kTile - 1) / kTile;
+  h->lik = rr_pf_lik_make(cfg->range_noise);
+  auto cleanup = [&](rr_status st) {
+    rr_pf_destroy(h);
+    return st;
+  };
+#define RR_TRY_OR_CLEAN(expr)                                                                      \
+  do {                                                                                             \
+    hipError_t _e = (expr);                                                                        \
+    if (_e != hipSuccess) return cleanup(fail(RR_RUNTIME_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+  } while (0)
+  RR_TRY_OR_CLEAN(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  h->owns_stream = true;
+  const size_t nb = h->n * sizeof(double);
+  for (int k = 0; k < 2; ++k) {
+    RR_TRY_OR_CLEAN(hipMalloc(&h->b.x[k], nb));
+    RR_TRY_OR_CLEAN(hipMalloc(&h->b.y[k], nb));
+    RR_TRY_OR_CLEAN(hipMalloc(&h->b.yaw[k], nb));
+    RR_TRY_OR_CLEAN(hipMalloc(&h->b.v[k], nb));
+  }
+  RR_TRY_OR_CLEAN(hipMalloc(&h->w, nb));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->cdf, h->n * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->tile_total, h->n_tiles * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->tile_q2, 2 * h->n_tiles * sizeof(uint64_t)));
+  if (opt.record_indices) RR_TRY_OR_CLEAN(hipMalloc(&h->idx, h->n * sizeof(unsigned int)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->partials, (size_t)kMomentBlocks * kNumMoments * sizeof(double)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->ctl, sizeof(Ctl)));
+  RR_TRY_OR_CLEAN(hipHostMalloc(&h->ctl_host, sizeof(Ctl)));
+  RR_TRY_OR_CLEAN(hipMemsetAsync(h->ctl, 0, sizeof(Ctl), h->stream));
+  hipLaunchKernelGGL(k_init, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->w, h->n, h->n_global,
+                     h->opt.first_global_index, h->opt.seed, state ? 1 : 0, state ? state[0] : 0.0,
+                     state ? state[1] : 0.0, state ? state[2] : 0.0, state ? state[3] : 0.0);
+  RR_TRY_OR_CLEAN(hipGetLastError());
+  // Particle::new gives every particle w = 1/N (particle_filter.rs:35-43)
+  Ctl init{};
+  init.weights_uniform = 1;
+  init.usable = 1;
+  init.sum = 1.0;
+  init.neff = (double)n_global;
+  *h->ctl_host = init;
+  RR_TRY_OR_CLEAN(hipMemcpyAsync(h->ctl, h->ctl_host, sizeof(Ctl), hipMemcpyHostToDevice, h->stream));
+  RR_TRY_OR_CLEAN(hipStreamSynchronize(h->stream));
+#undef RR_TRY_OR_CLEAN
+  *out = h;
+  return RR_OK;
+}
+
+rr_status ensure_scratch(rr_pf* h, size_t doubles_a, size_t doubles_b) {
+  // scratch_a doubles as the AoS staging area (5n), scratch_b only ever needs n
+  static_assert(sizeof(double) == 8, "");
+  if (doubles_a) {
+    size_t want = std::max<size_t>(doubles_a, 5 * h->n);
+    if (!h->scratch_a) RR_HIP_TRY(hipMalloc(&h->scratch_a, want * sizeof(double)));
+  }
+  if (doubles_b && !h->scratch_b) RR_HIP_TRY(hipMalloc(&h->scratch_b, h->n * sizeof(double)));
+  return RR_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char* rr_last_error(void) { return rr::last_error_slot().c_str(); }
+const char* rr_version(void) { return "rust_robotics_amd 0.1.0 (gfx950)"; }
+int rr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+void rr_pf_config_default(rr_pf_config* c) {
+  if (!c) return;
+  c->n_particles = 100;
+  c->resample_threshold = 0.5;
+  c->range_noise = 0.2;
+  c->velocity_noise = 2.0;
+  c->yaw_rate_noise = 40.0 * (RR_PI_HI / 180.0);  // 40.0_f64.to_radians()
+  c->dt = 0.1;
+}
+
+rr_status rr_pf_config_validate(const rr_pf_config* c) { return validate_config(c); }
+
+void rr_pf_options_default(rr_pf_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+  o->device = 0;
+  o->resample_scheme = RR_RESAMPLE_MULTINOMIAL;
+  o->resample_gate = RR_GATE_NEFF;
+  o->likelihood_mode = RR_LIK_FUSED;
+}
+
+void rr_pf_options_mcl(rr_pf_options* o) {
+  rr_pf_options_default(o);
+  if (o) o->resample_gate = RR_GATE_ALWAYS;
+}
+
+rr_status rr_pf_create(const rr_pf_config* cfg, const rr_pf_options* opt, rr_pf** out) {
+  return create_common(cfg, opt, nullptr, out);
+}
+
+rr_status rr_pf_create_with_state(const rr_pf_config* cfg, const rr_pf_options* opt, const double state[4],
+                                  rr_pf** out) {
+  if (!state) return fail(RR_INVALID_PARAMETER, "null initial state");
+  return create_common(cfg, opt, state, out);
+}
+
+void rr_pf_destroy(rr_pf* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->opt.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (int k = 0; k < 2; ++k) {
+    (void)hipFree(h->b.x[k]);
+    (void)hipFree(h->b.y[k]);
+    (void)hipFree(h->b.yaw[k]);
+    (void)hipFree(h->b.v[k]);
+  }
+  (void)hipFree(h->w);
+  (void)hipFree(h->cdf);
+  (void)hipFree(h->tile_total);
+  (void)hipFree(h->tile_q2);
+  (void)hipFree(h->idx);
+  (void)hipFree(h->partials);
+  (void)hipFree(h->scratch_a);
+  (void)hipFree(h->scratch_b);
+  (void)hipFree(h->obs_dev);
+  (void)hipFree(h->ctl);
+  if (h->ctl_host) (void)hipHostFree(h->ctl_host);
+  for (auto& e : h->events) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  for (auto e : h->event_pool) (void)hipEventDestroy(e);
+  if (h->owns_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+rr_status rr_pf_set_landmarks(rr_pf* h, const double* xy, size_t n) {
+  if (!h) return fail(RR_INVALID_PARAMETER, "null handle");
+  if (n && !xy) return fail(RR_INVALID_PARAMETER, "null landmarks");
+  for (size_t k = 0; k < 2 * n; ++k)
+    if (!std::isfinite(xy[k]))  // particle_filter.rs:525-536
+      return fail(RR_INVALID_PARAMETER, "particle filter landmarks must contain only finite values");
+  h->landmarks.assign(xy, xy + 2 * n);
+  return RR_OK;
+}
+
+size_t rr_pf_landmark_count(const rr_pf* h) { return h ? h->landmarks.size() / 2 : 0; }
+
+size_t rr_pf_get_landmarks(const rr_pf* h, double* xy_out, size_t cap) {
+  if (!h) return 0;
+  const size_t cnt = h->landmarks.size() / 2;
+  const size_t m = cnt < cap ? cnt : cap;
+  if (xy_out && m) std::memcpy(xy_out, h->landmarks.data(), 2 * m * sizeof(double));
+  return cnt;
+}
+
+rr_status rr_pf_set_range_noise(rr_pf* h, double range_noise) {
+  if (!h) return fail(RR_INVALID_PARAMETER, "null handle");
+  if (!std::isfinite(range_noise) || range_noise <= 0.0)
+    return fail(RR_INVALID_PARAMETER, "particle filter range_noise must be positive and finite");
+  h->cfg.range_noise = range_noise;
+  h->lik = rr_pf_lik_make(range_noise);
+  return RR_OK;
+}
+
+rr_status rr_pf_predict(rr_pf* h, const double control[2]) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = validate_control(control)) != RR_OK) return s;
+  StepParams p = make_params(h, control, 0);
+  ObsArg arg;
+  s = launch_pw<true, false, false>(h, p, arg, true);
+  h->step += 1;
+  return s;
+}
+
+rr_status rr_pf_predict_with_noise(rr_pf* h, const double control[2], const double* n_v, const double* n_w) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = validate_control(control)) != RR_OK) return s;
+  if (!n_v || !n_w) return fail(RR_INVALID_PARAMETER, "null noise arrays");
+  if ((s = ensure_scratch(h, h->n, h->n)) != RR_OK) return s;
+  RR_HIP_TRY(hipMemcpyAsync(h->scratch_a, n_v, h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RR_HIP_TRY(hipMemcpyAsync(h->scratch_b, n_w, h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  StepParams p = make_params(h, control, 0);
+  ObsArg arg;
+  s = launch_pw<true, false, true>(h, p, arg, true);
+  h->step += 1;
+  return s;
+}
+
+rr_status rr_pf_update(rr_pf* h, const double* obs, size_t n_obs) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
+  ObsArg arg;
+  bool kernarg;
+  if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
+  StepParams p = make_params(h, nullptr, (int)n_obs);
+  return launch_pw<false, true, false>(h, p, arg, kernarg);
+}
+
+rr_status rr_pf_resample(rr_pf* h) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = launch_sums(h, 0, h->opt.resample_scheme, NAN)) != RR_OK) return s;
+  return launch_resample(h, h->opt.resample_scheme, nullptr);
+}
+
+rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = validate_control(control)) != RR_OK) return s;
+  if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
+  ObsArg arg;
+  bool kernarg;
+  if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
+  StepParams p = make_params(h, control, (int)n_obs);
+  if ((s = launch_pw<true, true, false>(h, p, arg, kernarg)) != RR_OK) return s;
+  h->step += 1;
+  if ((s = launch_sums(h, 0, h->opt.resample_scheme, NAN)) != RR_OK) return s;
+  return launch_resample(h, h->opt.resample_scheme, nullptr);
+}
+
+rr_status rr_pf_synchronize(rr_pf* h) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return RR_OK;
+}
+
+rr_status rr_pf_estimate(rr_pf* h, double out[4]) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  return compute_moments(h, out, nullptr);
+}
+
+rr_status rr_pf_covariance(rr_pf* h, double out[16]) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  return compute_moments(h, nullptr, out);
+}
+
+rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_t n_obs, double out_state[4]) {
+  rr_status s = rr_pf_step_async(h, control, obs, n_obs);
+  if (s != RR_OK) return s;
+  if (!out_state) return rr_pf_synchronize(h);
+  return compute_moments(h, out_state, nullptr);
+}
+
+uint64_t rr_pf_particle_count(const rr_pf* h) { return h ? h->n : 0; }
+
+rr_status rr_pf_get_fixed_sums(rr_pf* h, rr_pf_fixed_sums* out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  if ((s = launch_sums(h, 2, h->opt.resample_scheme, NAN)) != RR_OK) return s;
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  const Ctl& c = *h->ctl_host;
+  out->usable = c.usable;
+  out->shift = c.shift;
+  out->total = c.total;
+  out->q2_hi = c.q2_hi;
+  out->q2_lo = c.q2_lo;
+  out->w_max = c.wmax;
+  out->sum = c.sum;
+  return RR_OK;
+}
+
+rr_status rr_pf_n_eff(rr_pf* h, double* out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  if ((s = launch_sums(h, 2, h->opt.resample_scheme, NAN)) != RR_OK) return s;
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  *out = h->ctl_host->neff;
+  return RR_OK;
+}
+
+rr_status rr_pf_last_resample_fired(rr_pf* h, int32_t* out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  *out = h->ctl_host->fired;
+  return RR_OK;
+}
+
+rr_status rr_pf_get_particles(rr_pf* h, double* out_aos) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out_aos) return fail(RR_INVALID_PARAMETER, "null output");
+  if ((s = ensure_scratch(h, 5 * h->n, 0)) != RR_OK) return s;
+  if ((s = launch_sums(h, 2, h->opt.resample_scheme, NAN)) != RR_OK) return s;  // refresh Ctl.sum / usable
+  hipLaunchKernelGGL(k_pack_aos, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->w, h->ctl, h->n,
+                     h->n_global, h->scratch_a);
+  RR_HIP_TRY(hipGetLastError());
+  RR_HIP_TRY(hipMemcpyAsync(out_aos, h->scratch_a, 5 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return RR_OK;
+}
+
+rr_status rr_pf_set_particles(rr_pf* h, const double* aos) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!aos) return fail(RR_INVALID_PARAMETER, "null input");
+  if ((s = ensure_scratch(h, 5 * h->n, 0)) != RR_OK) return s;
+  RR_HIP_TRY(hipMemcpyAsync(h->scratch_a, aos, 5 * h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+  hipLaunchKernelGGL(k_unpack_aos, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->w, h->ctl, h->n,
+                     (const double*)h->scratch_a);
+  RR_HIP_TRY(hipGetLastError());
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return RR_OK;
+}
+
+rr_status rr_pf_resample_with_uniforms(rr_pf* h, const double* r, size_t n) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!r || n != h->n) return fail(RR_INVALID_PARAMETER, "need exactly one uniform per particle");
+  for (size_t k = 0; k < n; ++k)
+    if (!(r[k] >= 0.0 && r[k] < 1.0)) return fail(RR_INVALID_PARAMETER, "uniforms must lie in [0, 1)");
+  if ((s = ensure_scratch(h, h->n, 0)) != RR_OK) return s;
+  RR_HIP_TRY(hipMemcpyAsync(h->scratch_a, r, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if ((s = launch_sums(h, 1, RR_RESAMPLE_MULTINOMIAL, NAN)) != RR_OK) return s;
+  return launch_resample(h, RR_RESAMPLE_MULTINOMIAL, h->scratch_a);
+}
+
+rr_status rr_pf_resample_systematic(rr_pf* h, double rho) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!(rho >= 0.0 && rho < 1.0)) return fail(RR_INVALID_PARAMETER, "rho must lie in [0, 1)");
+  if ((s = launch_sums(h, 1, RR_RESAMPLE_SYSTEMATIC, rho)) != RR_OK) return s;
+  return launch_resample(h, RR_RESAMPLE_SYSTEMATIC, nullptr);
+}
+
+rr_status rr_pf_last_resample_indices(rr_pf* h, uint32_t* out, size_t n) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!h->idx) return fail(RR_INVALID_PARAMETER, "record_indices was not enabled for this filter");
+  if (!out || n != h->n) return fail(RR_INVALID_PARAMETER, "need room for one index per particle");
+  RR_HIP_TRY(hipMemcpyAsync(out, h->idx, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return RR_OK;
+}
+
+rr_status rr_pf_get_raw_weights(rr_pf* h, double* out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  RR_HIP_TRY(hipMemcpyAsync(out, h->w, h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return RR_OK;
+}
+
+rr_status rr_pf_get_counters(rr_pf* h, uint32_t* step, uint32_t* resample_step) {
+  if (!h) return fail(RR_INVALID_PARAMETER, "null handle");
+  if (step) *step = h->step;
+  if (resample_step) *resample_step = h->rstep;
+  return RR_OK;
+}
+
+rr_status rr_pf_profile_enable(rr_pf* h, int32_t enable) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  drain_events(h);
+  h->profiling = enable != 0;
+  return RR_OK;
+}
+
+rr_status rr_pf_profile_read(rr_pf* h, int32_t kernel_id, uint64_t* launches, double* total_ms) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (kernel_id < 0 || kernel_id >= RR_K_COUNT) return fail(RR_INVALID_PARAMETER, "kernel id out of range");
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  drain_events(h);
+  if (launches) *launches = h->prof_launches[kernel_id];
+  if (total_ms) *total_ms = h->prof_ms[kernel_id];
+  return RR_OK;
+}
+
+rr_status rr_pf_profile_reset(rr_pf* h) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  drain_events(h);
+  for (int k = 0; k < RR_K_COUNT; ++k) {
+    h->prof_launches[k] = 0;
+    h->prof_ms[k] = 0.0;
+  }
+  return RR_OK;
+}
+
+const char* rr_pf_kernel_name(int32_t kernel_id) {
+  return kernel_id >= 0 && kernel_id < RR_K_COUNT ? kKernelNames[kernel_id] : "";
+}
+
+}  // extern "C"

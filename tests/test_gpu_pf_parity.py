@@ -1,0 +1,461 @@
+"""GPU parity of the PF / fixed-N MCL engine (through the C ABI) against
+  * oracle/det_spec.c  -- BIT-EXACT (states, raw weights, integer sums, resample indices)
+  * oracle/ref_literal.c -- the reference arithmetic, rtol = atol = 1e-6 (the reference's own
+    gate convention, scripts/check_benchmark_gate.py:34-35); indices identical on these sizes.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import dp, u32p, u64p
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+TOL = dict(rtol=1e-6, atol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def loc():
+    import rust_robotics_amd.localization as l
+
+    return l
+
+
+@pytest.fixture(scope="module")
+def ffi():
+    from rust_robotics_amd import _ffi
+
+    L = _ffi.lib()
+    assert L.rr_device_count() >= 1, "no HIP device visible"
+    return _ffi
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def assert_bits_equal(a, b, what=""):
+    a, b = bits(a), bits(b)
+    bad = np.nonzero(a != b)[0]
+    assert bad.size == 0, f"{what}: {bad.size} of {a.size} differ, first at {bad[:5]}"
+
+
+# ------------------------------------------------------------------ arithmetic contract on the device
+@pytest.mark.parametrize("fn,name", [(0, "exp"), (1, "log"), (2, "sincos"), (3, "sincos2pi"), (4, "atan2"), (5, "sqrt"), (6, "div"), (8, "fma")])
+def test_device_math_bit_identical(ffi, det, fn, name):
+    rng = np.random.default_rng(100 + fn)
+    n = 1 << 16
+    if fn == 0:
+        a = rng.uniform(-745, 709, n)
+    elif fn == 1:
+        a = np.concatenate([rng.uniform(0, 1, n // 2), 10.0 ** rng.uniform(-300, 300, n // 2)])
+    elif fn == 2:
+        a = np.concatenate([rng.uniform(-10, 10, n // 2), rng.uniform(-1e5, 1e5, n // 2)])
+    elif fn == 3:
+        a = np.floor(rng.uniform(0, 1, n) * 2**53) / 2**53
+    elif fn in (5,):
+        a = 10.0 ** rng.uniform(-300, 300, n)
+    else:
+        a = rng.normal(size=n) * 10.0 ** rng.uniform(-5, 5, n)
+    b = rng.normal(size=n) * 10.0 ** rng.uniform(-5, 5, n)
+    o0, o1 = np.empty(n), np.empty(n)
+    L = ffi.lib()
+    assert L.rr_selftest_math(0, fn, n, dp(a), dp(b), dp(o0), dp(o1)) == 0, ffi.last_error()
+    e0, e1 = np.empty(n), np.empty(n)
+    if fn == 0:
+        det.det_exp_v(n, dp(a), dp(e0))
+    elif fn == 1:
+        det.det_log_v(n, dp(a), dp(e0))
+    elif fn == 2:
+        det.det_sincos_v(n, dp(a), dp(e0), dp(e1))
+    elif fn == 3:
+        det.det_sincos2pi_v(n, dp(a), dp(e0), dp(e1))
+    elif fn == 4:
+        det.det_atan2_v(n, dp(a), dp(b), dp(e0))
+    elif fn == 5:
+        det.det_sqrt_v(n, dp(a), dp(e0))
+    elif fn == 6:
+        det.det_div_v(n, dp(a), dp(b), dp(e0))
+    elif fn == 8:
+        e0 = np.array([math.fma(x, y, x) for x, y in zip(a[:2000], b[:2000])]) if hasattr(math, "fma") else None
+        if e0 is None:
+            pytest.skip("no host fma to compare with")
+        o0 = o0[:2000]
+    assert_bits_equal(o0, e0, name)
+    if fn in (2, 3):
+        assert_bits_equal(o1, e1, name + "/cos")
+
+
+def test_device_normal_stream_bit_identical(ffi, det):
+    n = 1 << 16
+    seed, step = 0x1234ABCD5678EF01, 17
+    a = np.array([seed], dtype=np.uint64).view(np.float64)
+    b = np.array([step], dtype=np.uint64).view(np.float64)
+    a = np.concatenate([a, np.zeros(n - 1)])
+    b = np.concatenate([b, np.zeros(n - 1)])
+    o0, o1 = np.empty(n), np.empty(n)
+    assert ffi.lib().rr_selftest_math(0, 7, n, dp(a), dp(b), dp(o0), dp(o1)) == 0
+    e0, e1 = np.empty(n), np.empty(n)
+    det.det_normal2_v(seed, 3, step, 0, n, dp(e0), dp(e1))
+    assert_bits_equal(o0, e0, "z0")
+    assert_bits_equal(o1, e1, "z1")
+
+
+# ------------------------------------------------------------------ kernel-level parity
+def make_pf(loc, n, *, seed=7, scheme=0, lik=0, gate_cls=None, record=True, **cfg):
+    c = loc.ParticleFilterConfig(n_particles=n, **cfg)
+    cls = gate_cls or loc.ParticleFilterLocalizer
+    return cls(c, seed=seed, resample_scheme=scheme, likelihood_mode=lik, record_indices=record)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 257, 1000, 4097])
+def test_predict_with_noise_matches_oracles(loc, det, ref, n):
+    x, y, yaw, v = H.cloud(n, 1)
+    rng = np.random.default_rng(2)
+    nv, nw = rng.normal(0, 2.0, n), rng.normal(0, 0.7, n)
+    pf = make_pf(loc, n)
+    pf.set_particles_array(H.aos(x, y, yaw, v, np.full(n, 1.0 / n)))
+    pf.predict_with_noise([1.0, 0.1], nv, nw)
+    got = pf.get_particles_array()
+    dx, dy, dyaw, dv = (a.copy() for a in (x, y, yaw, v))
+    det.det_pf_predict(n, dp(dx), dp(dy), dp(dyaw), dp(dv), 1.0, 0.1, 0.1, dp(nv), dp(nw), 0, 0, 0, 0.0, 0.0)
+    for k, e in enumerate((dx, dy, dyaw, dv)):
+        assert_bits_equal(got[:, k], e, f"col {k}")
+    rx, ry, ryaw, rv = (a.copy() for a in (x, y, yaw, v))
+    ref.ref_pf_predict(n, dp(rx), dp(ry), dp(ryaw), dp(rv), 1.0, 0.1, 0.1, dp(nv), dp(nw))
+    for k, e in enumerate((rx, ry, ryaw, rv)):
+        np.testing.assert_allclose(got[:, k], e, rtol=1e-13, atol=1e-15)
+
+
+def test_predict_philox_matches_det(loc, det):
+    n = 5000
+    x, y, yaw, v = H.cloud(n, 3)
+    pf = make_pf(loc, n, seed=99, velocity_noise=2.0, yaw_rate_noise=0.7)
+    pf.set_particles_array(H.aos(x, y, yaw, v, np.full(n, 1.0 / n)))
+    for step in range(3):
+        pf.predict_with_control([1.0, 0.1])
+        det.det_pf_predict(n, dp(x), dp(y), dp(yaw), dp(v), 1.0, 0.1, 0.1, None, None, 99, step, 0, 2.0, 0.7)
+    got = pf.get_particles_array()
+    for k, e in enumerate((x, y, yaw, v)):
+        assert_bits_equal(got[:, k], e, f"col {k}")
+    # zero sigmas take the reference's "None" arm: no noise at all (Q5)
+    pf0 = make_pf(loc, 8, velocity_noise=0.0, yaw_rate_noise=0.0)
+    pf0.predict_with_control([1.0, 0.1])
+    g = pf0.get_particles_array()
+    assert np.all(g[:, 0] == 0.1) and np.all(g[:, 1] == 0.0) and np.all(g[:, 2] == 0.1 * 0.1) and np.all(g[:, 3] == 1.0)
+
+
+@pytest.mark.parametrize("lik", [0, 1])
+@pytest.mark.parametrize("n,L", [(1000, 4), (4097, 32), (300, 64), (50, 130)])
+def test_update_weights_match_oracles(loc, det, ref, n, L, lik):
+    lms = H.landmarks_grid(L, 5)
+    pose = H.true_pose(3)
+    obs = H.observations(lms, pose, 0.2, np.random.default_rng(6))
+    x, y, yaw, v = H.cloud(n, 7, center=(pose[0], pose[1], pose[2], 1.0))
+    pf = make_pf(loc, n, lik=lik)
+    pf.set_particles_array(H.aos(x, y, yaw, v, np.full(n, 1.0 / n)))
+    pf.update_with_observations(obs)
+    raw = pf.raw_weights()
+    wd = np.empty(n)
+    det.det_pf_weights(n, dp(x), dp(y), dp(wd), dp(obs), L, 0.2, lik)
+    assert_bits_equal(raw, wd, "raw weights")
+    wr = np.empty(n)
+    ref.ref_pf_update_raw(n, dp(x), dp(y), dp(wr), dp(obs), L, 0.2)
+    big = wr > 1e-280
+    np.testing.assert_allclose(raw[big], wr[big], rtol=1e-9)
+    # integer image and normalised weights
+    fx = H.det_fixed(det, wd)
+    got = pf.fixed_sums()
+    assert (got.usable, got.shift, got.total, got.q2_hi, got.q2_lo) == (fx["usable"], fx["shift"], fx["total"], fx["q2_hi"], fx["q2_lo"])
+    assert got.w_max == fx["wmax"]
+    parts = pf.get_particles_array()
+    s = det.det_fix_total_to_double(fx["total"], fx["shift"])
+    assert_bits_equal(parts[:, 4], wd / s, "normalised weights")
+    ref.ref_pf_normalize(n, dp(wr))
+    np.testing.assert_allclose(parts[:, 4], wr, **TOL)
+    assert abs(parts[:, 4].sum() - 1.0) < 1e-3  # particle_filter.rs:611-623
+    np.testing.assert_allclose(pf.n_eff(), ref.ref_pf_neff(n, dp(wr)), rtol=1e-6)
+
+
+def test_estimate_and_covariance_match_reference(loc, ref):
+    n, L = 3000, 8
+    lms = H.landmarks_grid(L, 8)
+    pose = H.true_pose(10)
+    obs = H.observations(lms, pose, 0.2, np.random.default_rng(9))
+    x, y, yaw, v = H.cloud(n, 10, center=(pose[0], pose[1], pose[2] + 100.0, 1.0))  # large yaw offset: cancellation check
+    pf = make_pf(loc, n)
+    pf.set_particles_array(H.aos(x, y, yaw, v, np.full(n, 1.0 / n)))
+    pf.update_with_observations(obs)
+    w = np.empty(n)
+    ref.ref_pf_update_raw(n, dp(x), dp(y), dp(w), dp(obs), L, 0.2)
+    ref.ref_pf_normalize(n, dp(w))
+    est = np.empty(4)
+    cov = np.empty(16)
+    ref.ref_pf_estimate(n, dp(x), dp(y), dp(yaw), dp(v), dp(w), dp(est))
+    ref.ref_pf_covariance(n, dp(x), dp(y), dp(yaw), dp(v), dp(w), dp(est), dp(cov))
+    np.testing.assert_allclose(pf.estimate(), est, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(pf.calc_covariance(), cov.reshape(4, 4), rtol=1e-6, atol=1e-9)
+    c = pf.calc_covariance()
+    assert c[0, 0] >= 0 and c[1, 1] >= 0  # particle_filter.rs:639-646
+
+
+@pytest.mark.parametrize("n", [4, 100, 1000, 2049, 10000])
+def test_multinomial_indices_match_oracles(loc, det, ref, n):
+    rng = np.random.default_rng(20 + n)
+    w = rng.random(n) ** 8 * np.exp(-rng.random(n) * 30)
+    x, y, yaw, v = H.cloud(n, 21)
+    r = np.floor(rng.random(n) * 2**53) / 2**53
+    pf = make_pf(loc, n)
+    pf.set_particles_array(H.aos(x, y, yaw, v, w))
+    pf.resample_with_uniforms(r)
+    idx = pf.last_resample_indices()
+    fx = H.det_fixed(det, w)
+    cdf = H.det_cdf(det, w, fx)
+    e = np.empty(n, np.uint32)
+    det.det_indices_multinomial(n, u64p(cdf), fx["total"], 0, n, dp(r), 0, 0, u32p(e))
+    assert np.array_equal(idx, e)
+    wn = w.copy()
+    ref.ref_pf_normalize(n, dp(wn))
+    er = np.empty(n, np.uint32)
+    (ref.ref_pf_resample_indices if n <= 2049 else ref.ref_pf_resample_indices_bsearch)(n, dp(wn), dp(r), u32p(er))
+    assert np.array_equal(idx, er), f"{np.count_nonzero(idx != er)} draws differ from the literal float-cumsum walk"
+    em = np.empty(n, np.uint32)
+    ref.ref_mcl_resample_indices(n, dp(wn), dp(r), u32p(em))
+    assert np.array_equal(idx, em)
+    got = pf.get_particles_array()
+    assert_bits_equal(got[:, 0], x[idx], "gathered x")
+    assert_bits_equal(got[:, 3], v[idx], "gathered v")
+    assert np.all(got[:, 4] == 1.0 / n)  # particle_filter.rs:468
+    assert pf.last_resample_fired()
+
+
+@pytest.mark.parametrize("n", [4, 100, 1000, 2049, 10000])
+def test_systematic_indices_match_oracles(loc, det, ref, n):
+    rng = np.random.default_rng(40 + n)
+    w = rng.random(n) ** 6 * np.exp(-rng.random(n) * 20)
+    x, y, yaw, v = H.cloud(n, 41)
+    rho = float(np.floor(rng.random() * 2**53) / 2**53)
+    pf = make_pf(loc, n, scheme=1)
+    pf.set_particles_array(H.aos(x, y, yaw, v, w))
+    pf.resample_systematic(rho)
+    idx = pf.last_resample_indices()
+    fx = H.det_fixed(det, w)
+    cdf = H.det_cdf(det, w, fx)
+    e = np.empty(n, np.uint32)
+    det.det_indices_systematic(n, u64p(cdf), fx["total"], n, 0, n, rho, u32p(e))
+    assert np.array_equal(idx, e)
+    er = np.empty(n, np.uint32)
+    ref.ref_fs1_resample_indices(n, dp(w.copy()), rho / n, u32p(er))
+    assert np.array_equal(idx, er), f"{np.count_nonzero(idx != er)} slots differ from the literal systematic walk"
+    assert np.all(np.diff(idx.astype(np.int64)) >= 0)
+
+
+def test_degenerate_weights_fall_back_to_uniform(loc):
+    """particle_filter.rs:433-438: sum w <= 0 -> every weight 1/len"""
+    n = 500
+    x, y, yaw, v = H.cloud(n, 50)
+    pf = make_pf(loc, n)
+    pf.set_particles_array(H.aos(x, y, yaw, v, np.full(n, 1.0 / n)))
+    pf.update_with_observations([(500.0, 0.0, 0.0), (0.0, 300.0, 300.0)] * 8)  # hopeless: underflows to 0
+    assert np.all(pf.raw_weights() == 0.0)
+    p = pf.get_particles_array()
+    assert np.all(p[:, 4] == 1.0 / n)
+    np.testing.assert_allclose(pf.estimate(), [x.mean(), y.mean(), yaw.mean(), v.mean()], rtol=1e-12)
+    assert pf.n_eff() == n
+
+
+def test_empty_observations_are_valid(loc):
+    """Q18 / tests/proptest_filters.rs:42-54"""
+    pf = make_pf(loc, 200)
+    for _ in range(5):
+        e = pf.step([1.0, 0.3], [])
+        assert np.all(np.isfinite(e))
+    p = pf.get_particles_array()
+    assert np.all(p[:, 4] == 1.0 / 200)
+
+
+# ------------------------------------------------------------------ whole trajectories
+@pytest.mark.parametrize("scheme", [0, 1])
+@pytest.mark.parametrize("mcl", [False, True])
+def test_trajectory_bit_exact_vs_det(loc, det, scheme, mcl):
+    n, L, T = 3000, 4, 25
+    lms = H.REF_SCENE_LANDMARKS
+    cls = loc.MonteCarloLocalizer if mcl else loc.ParticleFilterLocalizer
+    kw = dict(seed=42, resample_scheme=scheme, record_indices=True)
+    if mcl:
+        cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.5, velocity_noise=0.3,
+                                               yaw_rate_noise=math.radians(5.0))
+        pf = cls(cfg, **kw)
+    else:
+        cfg = loc.ParticleFilterConfig(n_particles=n, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))
+        pf = cls(cfg, **kw)
+    z = np.zeros(n)
+    d = H.DetPF(det, z, z, z, z, dt=0.1, sigma=0.5, sigma_v=0.3, sigma_w=math.radians(5.0), threshold=1.0 if mcl else 0.5,
+                gate=1 if mcl else 0, scheme=scheme, lik=0, seed=42)
+    rng = np.random.default_rng(43)
+    fired_any = False
+    for t in range(T):
+        obs = H.observations(lms, H.true_pose(t + 1), 0.5, rng)
+        est = pf.step([1.0, 0.1], obs)
+        fired = d.step([1.0, 0.1], obs)
+        fired_any |= fired
+        assert pf.last_resample_fired() == fired, f"gate decision differs at step {t}"
+        if fired:
+            assert np.array_equal(pf.last_resample_indices(), d.idx), f"resample indices differ at step {t}"
+        got = pf.get_particles_array()
+        for k, e in enumerate((d.x, d.y, d.yaw, d.v)):
+            assert_bits_equal(got[:, k], e, f"step {t} col {k}")
+        assert_bits_equal(got[:, 4], d.normalized_weights(), f"step {t} weights")
+        e_est, e_cov = d.moments()
+        np.testing.assert_allclose(est, e_est, rtol=1e-9, atol=1e-9)
+    assert fired_any
+    assert np.hypot(*(pf.estimate()[:2] - H.true_pose(T)[:2])) < 1.0  # monte_carlo_localization.rs:489-516
+
+
+def test_trajectory_vs_literal_reference(loc, det, ref):
+    """Same noise and the same resample draws fed to the literal restatement: poses and
+    weights agree to 1e-6, resample indices agree exactly."""
+    n, T = 1500, 20
+    lms = H.REF_SCENE_LANDMARKS
+    sv, sw, sig = 0.3, math.radians(5.0), 0.5
+    cfg = loc.ParticleFilterConfig(n_particles=n, range_noise=sig, velocity_noise=sv, yaw_rate_noise=sw)
+    pf = loc.ParticleFilterLocalizer(cfg, seed=11, record_indices=True)
+    x, y, yaw, v = (np.zeros(n) for _ in range(4))
+    w = np.full(n, 1.0 / n)
+    rng = np.random.default_rng(12)
+    idx = np.empty(n, np.uint32)
+    est = np.empty(4)
+    mism = 0
+    for t in range(T):
+        obs = H.observations(lms, H.true_pose(t + 1), sig, rng)
+        z0, z1 = np.empty(n), np.empty(n)
+        det.det_normal2_v(11, 3, t, 0, n, dp(z0), dp(z1))
+        r, _ = np.empty(n), None
+        r2 = np.empty(n)
+        det.det_uniform2_v(11, 4, t, 0, n, dp(r), dp(r2))
+        nv, nw = sv * z0, sw * z1
+        fired = ref.ref_pf_step(n, dp(x), dp(y), dp(yaw), dp(v), dp(w), 1.0, 0.1, 0.1, dp(nv), dp(nw), dp(obs), len(obs), sig,
+                                0.5, 0, dp(r), u32p(idx), dp(est))
+        got_est = pf.step([1.0, 0.1], obs)
+        assert pf.last_resample_fired() == bool(fired)
+        if fired:
+            mism += int(np.count_nonzero(pf.last_resample_indices() != idx))
+        got = pf.get_particles_array()
+        if mism == 0:
+            np.testing.assert_allclose(got[:, :4], np.column_stack([x, y, yaw, v]), **TOL)
+            np.testing.assert_allclose(got[:, 4], w, **TOL)
+            np.testing.assert_allclose(got_est, est, **TOL)
+    assert mism == 0, f"{mism} resample indices differ from the literal reference walk"
+
+
+# ------------------------------------------------------------------ API surface / error behaviour
+def test_reference_unit_tests_reexpressed(loc):
+    """particle_filter.rs:575-707 against the engine"""
+    pf = loc.ParticleFilterLocalizer.with_defaults()
+    assert pf.particle_count() == 100 and len(pf.get_particles()) == 100
+    pf2 = loc.ParticleFilterLocalizer.with_initial_state([1.0, 2.0, 0.5, 1.0], loc.ParticleFilterConfig())
+    e = pf2.estimate()
+    assert abs(e[0] - 1.0) < 2.0 and abs(e[1] - 2.0) < 2.0
+    before = pf.estimate()
+    pf.predict_with_control([1.0, 0.0])
+    after = pf.estimate()
+    assert after[0] != before[0] or after[1] != before[1]
+    pf3 = loc.ParticleFilterLocalizer.with_initial_state([5.0, 5.0, 0.0, 0.0], loc.ParticleFilterConfig())
+    pf3.update_with_observations([(5.0, 0.0, 5.0)])
+    assert abs(sum(p.w for p in pf3.get_particles()) - 1.0) < 1e-3
+    s = loc.ParticleFilterLocalizer.with_defaults().try_step_state(loc.ControlInput(1.0, 0.1), [(10.0, 10.0, 0.0)])
+    assert math.isfinite(s.x) and math.isfinite(s.y)
+    with pytest.raises(loc.RoboticsError) as ei:
+        loc.ParticleFilterLocalizer.try_new(loc.ParticleFilterConfig(n_particles=0))
+    assert ei.value.kind == "InvalidParameter"
+    pf4 = loc.ParticleFilterLocalizer.with_initial_state_2d(loc.State2D(1.0, 2.0, 0.3, 0.4), loc.ParticleFilterConfig())
+    st = pf4.state_2d()
+    assert abs(st.x - 1.0) < 2.0 and abs(st.y - 2.0) < 2.0
+    pf.set_landmarks_from_obstacles(loc.Obstacles.from_points([loc.Point2D(1.0, 1.0), loc.Point2D(2.0, 2.0)]))
+    assert len(pf.get_landmarks()) == 2
+    pf5 = loc.ParticleFilterLocalizer.with_defaults()
+    pf5.predict([1.0, 0.0], 0.1)
+    pf5.update([(10.0, 0.0, 0.0)])
+    assert math.isfinite(pf5.get_state()[0]) and pf5.get_covariance().shape == (4, 4)
+
+
+def test_invalid_inputs_raise_invalid_parameter(loc):
+    pf = loc.ParticleFilterLocalizer.with_defaults()
+    for bad in ([float("nan"), 0.0], [0.0, float("inf")]):
+        with pytest.raises(loc.RoboticsError) as ei:
+            pf.predict_with_control(bad)
+        assert "control input must contain only finite values" in str(ei.value)
+    for bad in ([(-1.0, 0.0, 0.0)], [(1.0, float("nan"), 0.0)], [(float("inf"), 0.0, 0.0)]):
+        with pytest.raises(loc.RoboticsError) as ei:
+            pf.update_with_observations(bad)
+        assert "finite, non-negative distances" in str(ei.value)
+    with pytest.raises(loc.RoboticsError):
+        pf.set_range_noise(0.0)
+    with pytest.raises(loc.RoboticsError):
+        pf.set_landmarks([loc.Point2D(float("nan"), 0.0)])
+    with pytest.raises(loc.RoboticsError):
+        loc.ParticleFilterLocalizer.with_initial_state([0.0, float("nan"), 0.0, 0.0], loc.ParticleFilterConfig())
+    with pytest.raises(loc.RoboticsError):
+        loc.MonteCarloLocalizer(loc.MonteCarloLocalizationConfig(min_particles=10, max_particles=20))
+
+
+def test_mcl_reference_tests_reexpressed(loc):
+    """monte_carlo_localization.rs:489-516: error < 1.0 m after 60 steps"""
+    n = 1200
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.3, velocity_noise=0.5,
+                                           yaw_rate_noise=math.radians(10.0))
+    mcl = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=5)
+    lms = H.REF_SCENE_LANDMARKS
+    rng = np.random.default_rng(6)
+    for t in range(60):
+        est = mcl.try_step([1.0, 0.1], H.observations(lms, H.true_pose(t + 1), 0.3, rng))
+    assert mcl.particle_count() == n
+    assert np.hypot(*(est[:2] - H.true_pose(60)[:2])) < 1.0
+
+
+# ------------------------------------------------------------------ BASELINE sizes: size-independent properties
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_million_particle_properties(loc, det, scheme):
+    n, L = 1_000_000, 32
+    lms = H.landmarks_grid(L, 1)
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
+    pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, resample_scheme=scheme, record_indices=True)
+    rng = np.random.default_rng(2)
+    before = None
+    for t in range(3):
+        obs = H.observations(lms, H.true_pose(t + 1), 0.2, rng)
+        if t == 2:
+            pf.predict_with_control([1.0, 0.1])
+            pf.update_with_observations(obs)
+            before = pf.get_particles_array()
+            raw = pf.raw_weights()
+            pf.resample()
+        else:
+            pf.step([1.0, 0.1], obs)
+    after = pf.get_particles_array()
+    idx = pf.last_resample_indices()
+    # every survivor is an exact copy of its source
+    assert np.array_equal(after[:, :4].view(np.uint64), before[idx, :4].view(np.uint64))
+    assert np.all(after[:, 4] == 1.0 / n)
+    assert abs(before[:, 4].sum() - 1.0) < 1e-9
+    # the integer image is order independent: recompute it on the host
+    fx = H.det_fixed(det, raw)
+    got = pf.fixed_sums()  # weights are uniform now -> degenerate image
+    assert got.usable == 0
+    cdf = H.det_cdf(det, raw, fx)
+    e = np.empty(n, np.uint32)
+    if scheme == 1:
+        rho = det.det_resample_rho(1, 2)
+        det.det_indices_systematic(n, u64p(cdf), fx["total"], n, 0, n, rho, u32p(e))
+        assert np.all(np.diff(idx.astype(np.int64)) >= 0)
+        # offspring counts of systematic resampling are within 1 of n * w
+        cnt = np.bincount(idx, minlength=n)
+        assert np.max(np.abs(cnt - n * before[:, 4])) <= 1.0 + 1e-6
+    else:
+        det.det_indices_multinomial(n, u64p(cdf), fx["total"], 0, n, None, 1, 2, u32p(e))
+    assert np.array_equal(idx, e)
+    assert np.hypot(*(pf.estimate()[:2] - H.true_pose(3)[:2])) < 1.0
