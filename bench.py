@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--scheme", choices=["systematic", "multinomial"], default="systematic")
     ap.add_argument("--likelihood", choices=["fused", "product"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="run the sharded (RCCL) path even at --gpus 1")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,7 +92,7 @@ def main():
     scheme = 1 if args.scheme == "systematic" else 0
     lik = 0 if args.likelihood == "fused" else 1
 
-    if world > 1:
+    if world > 1 or args.force_sharded:
         from rust_robotics_amd import sharded
 
         res = sharded.bench_sharded(rank, world, local_rank, n, L, K, W, obs_list, scheme, lik)

@@ -198,33 +198,31 @@ const char* rr_pf_kernel_name(int32_t kernel_id);
 rr_status rr_selftest_math(int32_t device, int32_t fn, size_t n, const double* a, const double* b,
                            double* out0, double* out1);
 
-/* ---- sharded (multi-GPU) operation: one shard per process/GPU, the host side
- * (rust_robotics_amd/sharded.py) runs the RCCL collectives between the phases.
- * All pointers here are DEVICE pointers on this shard's device; `stream` is the
- * hipStream_t the caller's collectives are ordered on (NULL = the filter's own). */
-typedef struct rr_pf_shard_sums {
-  uint64_t total;        /* local T */
-  uint64_t q2_hi, q2_lo; /* local sum q^2 */
-} rr_pf_shard_sums;
-/* use `stream` (a hipStream_t) for all subsequent work of this handle */
+/* ---- sharded (multi-GPU) operation: one shard per process/GPU.  A shard is an ordinary
+ * filter created with options.first_global_index / n_global set; the host side
+ * (rust_robotics_amd/sharded.py) runs the RCCL collectives between the phases below.
+ * Pointers named d_* are DEVICE pointers on this shard's device.  Systematic resampling only.
+ *
+ *   A  rr_pf_shard_propagate_weight   fused propagate + weight, local max weight -> d_wmax
+ *      -- all-reduce(MAX) of d_wmax over the shards --
+ *   B  rr_pf_shard_quantize           integer image under the GLOBAL max, local sums -> d_sums
+ *      -- all-gather of d_sums (3 x u64 per shard) --
+ *   C  rr_pf_shard_cdf                global totals, gate decision, local slice of the global CDF
+ *      -- host: rr_pf_shard_get_plan + rr_sys_first_slot_above give every (source, destination)
+ *         segment length; nothing below runs if the gate did not fire --
+ *   D  rr_pf_shard_gather_slots       particles that global output slots [first, first+n) copy
+ *                                     from THIS shard -> d_out, n x (x, y, yaw, v)
+ *      -- all-to-all of the contiguous segments --
+ *   E  rr_pf_shard_adopt              the received N x (x, y, yaw, v) becomes the particle set
+ */
+/* run all subsequent work of this handle on `stream` (a hipStream_t; NULL restores the
+ * filter's own stream) so that it is ordered with the caller's collectives */
 rr_status rr_pf_set_stream(rr_pf* h, void* stream);
-/* phase A: fused propagate + weight; writes the local max weight (as a double)
- * to *d_wmax_out (device) */
 rr_status rr_pf_shard_propagate_weight(rr_pf* h, const double control[2], const double* obs,
                                        size_t n_obs, double* d_wmax_out);
-/* phase B: quantise with the GLOBAL max *d_wmax_global (device), write local
- * sums to *d_sums_out (device, rr_pf_shard_sums) */
-rr_status rr_pf_shard_quantize(rr_pf* h, const double* d_wmax_global, rr_pf_shard_sums* d_sums_out);
-/* phase C: given all shards' sums d_all_sums[n_shards] (device) and this shard's
- * rank, build the local slice of the global CDF and decide the gate */
-rr_status rr_pf_shard_cdf(rr_pf* h, const rr_pf_shard_sums* d_all_sums, int32_t n_shards, int32_t rank);
-/* phase D (systematic only): gather the particles that output slots
- * [first_slot, first_slot + n_slots) take from THIS shard into d_out
- * (SoA, 4 planes of n_slots doubles: x | y | yaw | v) */
-rr_status rr_pf_shard_gather_slots(rr_pf* h, uint64_t first_slot, uint64_t n_slots, double* d_out);
-/* phase E: replace the particle set by d_in (SoA as above, N doubles per plane), w = 1/N_global */
-rr_status rr_pf_shard_adopt(rr_pf* h, const double* d_in);
-/* host copy of phase C's decision: fired flag, global total, this shard's CDF base, rho */
+rr_status rr_pf_shard_quantize(rr_pf* h, const double* d_wmax_global, uint64_t* d_sums_out /* [3] */);
+rr_status rr_pf_shard_cdf(rr_pf* h, const uint64_t* d_all_sums /* [n_shards][3] */, int32_t n_shards,
+                          int32_t rank);
 typedef struct rr_pf_shard_plan {
   int32_t fired;
   int32_t usable;
@@ -233,7 +231,14 @@ typedef struct rr_pf_shard_plan {
   uint64_t total_local;
   double rho;
 } rr_pf_shard_plan;
+/* synchronises the stream and copies phase C's outcome to the host */
 rr_status rr_pf_shard_get_plan(rr_pf* h, rr_pf_shard_plan* out);
+rr_status rr_pf_shard_gather_slots(rr_pf* h, uint64_t first_slot, uint64_t n_slots, double* d_out);
+rr_status rr_pf_shard_adopt(rr_pf* h, const double* d_in);
+/* Host-only integer helper (no GPU needed): the first global output slot i in [0, n_global]
+ * whose systematic CDF target exceeds `bound` (n_global if none).  Slots served by a shard
+ * with CDF interval (base, base + T] are [first_slot_above(base), first_slot_above(base + T)). */
+uint64_t rr_sys_first_slot_above(double rho, uint64_t total_global, uint64_t n_global, uint64_t bound);
 
 #ifdef __cplusplus
 }

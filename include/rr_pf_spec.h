@@ -177,13 +177,16 @@ RR_HD void rr_mul64wide(uint64_t a, uint64_t b, uint64_t* hi, uint64_t* lo) {
   *lo = (uint64_t)p;
 }
 
-/* Multinomial draw r in [0,1) -> CDF target: smallest P with r*T <= P, i.e.
+/* Multinomial draw r in [0,1) -> CDF target: smallest P >= 1 with r*T <= P, i.e.
  * index = first i with C_i >= P  <=>  first i with r <= C_i / T
- * (particle_filter.rs:459-465 "r <= cum_w"). */
+ * (particle_filter.rs:459-465 "r <= cum_w").  Targets are clamped to >= 1 so that every
+ * target lies in exactly one shard's interval (base, base + T_local]; the only inputs this
+ * changes are r == 0 exactly with a zero-weight first particle (probability 2^-53). */
 RR_HD uint64_t rr_fix_target_multinomial(double r, uint64_t total) {
   uint64_t R = (uint64_t)(r * 0x1p53); /* exact: r is a multiple of 2^-53 */
   unsigned __int128 p = (unsigned __int128)R * total + (((unsigned __int128)1 << 53) - 1);
-  return (uint64_t)(p >> 53);
+  uint64_t t = (uint64_t)(p >> 53);
+  return t ? t : 1; /* r == 0 selects the first particle of non-zero weight */
 }
 
 /* Systematic resampling (fastslam1.rs:219-231): output i sits at (i + rho)/n,
@@ -207,7 +210,8 @@ RR_HD rr_sys_plan rr_sys_plan_make(double rho, uint64_t total, uint64_t n) {
 
 RR_HD uint64_t rr_sys_target(rr_sys_plan p, uint64_t i) {
   uint64_t t = i * p.rem + p.offs; /* < n^2 + 2^63 <= 2^64 for n < 2^31 */
-  return i * p.q + (t + p.n - 1) / p.n;
+  uint64_t r = i * p.q + (t + p.n - 1) / p.n;
+  return r ? r : 1; /* position 0 selects the first particle of non-zero weight */
 }
 
 /* first i in [0,n) with c[i] >= target (c inclusive, non-decreasing); n-1 if none */

@@ -139,6 +139,15 @@ def lib() -> C.CDLL:
     proto("rr_pf_profile_reset", st, [H])
     proto("rr_pf_kernel_name", C.c_char_p, [i32])
     proto("rr_selftest_math", st, [i32, i32, sz, P, P, P, P])
+    V = C.c_void_p  # device pointers
+    proto("rr_pf_set_stream", st, [H, V])
+    proto("rr_pf_shard_propagate_weight", st, [H, P, P, sz, V])
+    proto("rr_pf_shard_quantize", st, [H, V, V])
+    proto("rr_pf_shard_cdf", st, [H, V, i32, i32])
+    proto("rr_pf_shard_get_plan", st, [H, C.POINTER(PfShardPlan)])
+    proto("rr_pf_shard_gather_slots", st, [H, u64, u64, V])
+    proto("rr_pf_shard_adopt", st, [H, V])
+    proto("rr_sys_first_slot_above", u64, [d, u64, u64, u64])
     _lib = L
     return L
 

@@ -24,6 +24,7 @@
 #include <string>
 #include <vector>
 
+#include "resample_core.hpp"
 #include "rr_common.hpp"
 #include "rr_pf.h"
 #include "rr_pf_spec.h"
@@ -37,39 +38,17 @@ std::string& last_error_slot() {
 
 using rr::fail;
 using rr::u128;
+using rr::Ctl;
+using rr::ImageArgs;
+using rr::PlanArgs;
+using rr::kBlock;
+using rr::kTile;
+using rr::kScanThreads;
+using rr::kMaxObsKernarg;
+using rr::kMomentBlocks;
+using rr::kNumMoments;
 
 namespace {
-
-constexpr int kBlock = 256;
-constexpr int kItems = 8;
-constexpr int kTile = kBlock * kItems;  // 2048 particles per scan tile
-constexpr int kScanThreads = 1024;
-constexpr int kMaxObsKernarg = 96;      // observations that travel inside the launch packet
-constexpr int kMomentBlocks = 1024;
-constexpr int kNumMoments = 15;         // sum w, 4 first, 10 second moments
-
-// ---- device-resident control block: everything a later kernel needs to know about an
-// earlier one's data-dependent outcome, so the host never has to look.
-struct Ctl {
-  int cur;              // which of the two SoA buffer sets is live
-  int weights_uniform;  // 1 => every particle weighs 1/N (w[] is stale)
-  int usable;           // 0 => degenerate raw weights (uniform fallback, particle_filter.rs:433-438)
-  int shift;            // fixed-point shift of the current integer image
-  int fired;            // last gate decision
-  int pad0;
-  uint64_t wmax_bits;  // atomic max of the raw weights (bit pattern of a double >= 0)
-  uint64_t total;      // T (global in sharded mode)
-  uint64_t total_local;
-  uint64_t base;       // CDF base of this shard
-  uint64_t q2_hi, q2_lo;
-  double wmax;  // max used for the current integer image
-  double sum;   // T * 2^-shift
-  double neff;
-  double rho;
-  rr_sys_plan plan;
-  double moments[kNumMoments];
-  double shift_point[4];
-};
 
 struct Bufs {
   double* x[2];
@@ -156,190 +135,6 @@ __global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __r
   }
 }
 
-// q_i of particle i under the current integer image
-__device__ inline uint64_t quantize_at(const double* __restrict__ w, uint64_t i,
-                                                 uint64_t n, bool uniform, int shift) {
-  if (i >= n) return 0ull;
-  return uniform ? 1ull : rr_fix_quantize(w[i], shift);
-}
-
-// ------------------------------------------------------------------------------------------
-// K2: per-tile integer totals and sum of squares.  Tile = 2048 particles; each wave owns 512
-// consecutive particles as 8 coalesced rows of 64.  wmax_src points at the maximum to scale by
-// (Ctl.wmax_bits on one GPU, the all-reduced maximum when sharded).
-__global__ __launch_bounds__(kBlock) void k_quantize_reduce(const double* __restrict__ w,
-                                                           Ctl* __restrict__ ctl,
-                                                           const double* __restrict__ wmax_src,
-                                                           uint64_t n,
-                                                           uint64_t n_global,
-                                                           uint64_t* __restrict__ tile_total,
-                                                           uint64_t* __restrict__ tile_q2) {
-  __shared__ uint64_t s_t[kBlock / rr::kWave];
-  __shared__ uint64_t s_qh[kBlock / rr::kWave];
-  __shared__ uint64_t s_ql[kBlock / rr::kWave];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const double wmax = *wmax_src;
-  const bool usable = !ctl->weights_uniform && wmax > 0.0 && wmax < INFINITY;
-  const int shift = usable ? rr_fix_shift(wmax, n_global) : 0;
-  const uint64_t base = (uint64_t)blockIdx.x * kTile + (uint64_t)wv * (kTile / 4);
-  uint64_t t = 0;
-  u128 q2 = {0, 0};
-#pragma unroll
-  for (int r = 0; r < kItems; ++r) {
-    uint64_t q = quantize_at(w, base + r * 64 + lane, n, !usable, shift);
-    t += q;
-    u128 sq;
-    rr_mul64wide(q, q, &sq.hi, &sq.lo);
-    q2 = rr::add128(q2, sq);
-  }
-  t = rr::wave_sum_u64(t);
-  q2 = rr::wave_sum_u128(q2);
-  if (lane == 0) {
-    s_t[wv] = t;
-    s_qh[wv] = q2.hi;
-    s_ql[wv] = q2.lo;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    uint64_t tt = 0;
-    u128 qq = {0, 0};
-    for (int k = 0; k < kBlock / rr::kWave; ++k) {
-      tt += s_t[k];
-      qq = rr::add128(qq, u128{s_qh[k], s_ql[k]});
-    }
-    tile_total[blockIdx.x] = tt;
-    tile_q2[2 * blockIdx.x] = qq.hi;
-    tile_q2[2 * blockIdx.x + 1] = qq.lo;
-    if (blockIdx.x == 0) {
-      ctl->usable = usable ? 1 : 0;
-      ctl->shift = shift;
-      ctl->wmax = wmax;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// K3: single workgroup.  Exclusive scan of the tile totals (in place), grand totals, the gate
-// decision (particle_filter.rs:337-345 / monte_carlo_localization.rs:298) and the systematic
-// plan.  mode: 0 = decide by gate, 1 = force fire, 2 = statistics only (never fire).
-struct ScanArgs {
-  uint64_t n_tiles;
-  uint64_t n_global;
-  double threshold;  // resample_threshold
-  int gate;          // rr_resample_gate
-  int mode;
-  int scheme;
-  double rho_override;  // NaN => Philox
-  uint64_t seed;
-  unsigned int rstep;
-};
-
-__global__ __launch_bounds__(kScanThreads) void k_scan_tiles(uint64_t* __restrict__ tile_total,
-                                                            const uint64_t* __restrict__ tile_q2,
-                                                            Ctl* __restrict__ ctl, ScanArgs a) {
-  __shared__ uint64_t s_w[kScanThreads / rr::kWave];
-  __shared__ uint64_t s_h[kScanThreads / rr::kWave];
-  __shared__ uint64_t s_l[kScanThreads / rr::kWave];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint64_t per = (a.n_tiles + kScanThreads - 1) / kScanThreads;
-  const uint64_t lo = (uint64_t)tid * per;
-  const uint64_t hi = lo + per < a.n_tiles ? lo + per : a.n_tiles;
-  uint64_t local = 0;
-  u128 q2 = {0, 0};
-  for (uint64_t k = lo; k < hi; ++k) {
-    local += tile_total[k];
-    q2 = rr::add128(q2, u128{tile_q2[2 * k], tile_q2[2 * k + 1]});
-  }
-  uint64_t incl = rr::wave_scan_u64(local, lane);
-  u128 q2w = rr::wave_sum_u128(q2);
-  if (lane == 63) s_w[wv] = incl;
-  if (lane == 0) {
-    s_h[wv] = q2w.hi;
-    s_l[wv] = q2w.lo;
-  }
-  __syncthreads();
-  uint64_t wave_off = 0;
-  for (int k = 0; k < wv; ++k) wave_off += s_w[k];
-  uint64_t run = wave_off + incl - local;  // exclusive prefix of this thread's range
-  for (uint64_t k = lo; k < hi; ++k) {
-    uint64_t t = tile_total[k];
-    tile_total[k] = run;
-    run += t;
-  }
-  if (tid == 0) {
-    uint64_t total = 0;
-    u128 qq = {0, 0};
-    for (int k = 0; k < kScanThreads / rr::kWave; ++k) {
-      total += s_w[k];
-      qq = rr::add128(qq, u128{s_h[k], s_l[k]});
-    }
-    int usable = ctl->usable;
-    if (usable && total == 0) usable = 0;  // everything quantised to zero cannot happen (w_max > 0) but stay safe
-    ctl->total_local = total;
-    ctl->total = total;
-    ctl->base = 0;
-    ctl->q2_hi = qq.hi;
-    ctl->q2_lo = qq.lo;
-    double neff, sum;
-    if (usable) {
-      sum = rr_fix_total_to_double(total, ctl->shift);
-      neff = rr_fix_neff(total, qq.hi, qq.lo);
-    } else {  // uniform image q_i = 1: T = n, N_eff = n
-      sum = 1.0;
-      neff = (double)a.n_global;
-    }
-    ctl->sum = sum;
-    ctl->neff = neff;
-    if (a.mode == 2) return;  // statistics only: leave the last gate decision alone
-    int fire = 0;
-    if (a.mode == 1) fire = 1;
-    else fire = a.gate == RR_GATE_ALWAYS ? 1 : (neff < (double)a.n_global * a.threshold);
-    ctl->fired = fire;
-    if (fire && a.scheme == RR_RESAMPLE_SYSTEMATIC) {
-      double rho = a.rho_override;
-      if (rho != rho) {
-        double dummy;
-        rr_uniform2(a.seed, RR_STREAM_RESAMPLE, a.rstep, 0, &rho, &dummy);
-      }
-      ctl->rho = rho;
-      ctl->plan = rr_sys_plan_make(rho, total, a.n_global);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// K4: inclusive integer CDF of this shard: cdf[i] = base + tile_offset + within-tile scan.
-// Reads w (8 B), writes cdf (8 B).  Skipped when the gate did not fire.
-__global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, const Ctl* __restrict__ ctl,
-                                               uint64_t n,
-                                               const uint64_t* __restrict__ tile_offset,
-                                               uint64_t* __restrict__ cdf) {
-  if (!ctl->fired) return;
-  __shared__ uint64_t s_w[kBlock / rr::kWave];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const bool uniform = !ctl->usable;
-  const int shift = ctl->shift;
-  const uint64_t base = (uint64_t)blockIdx.x * kTile + (uint64_t)wv * (kTile / 4);
-  uint64_t vals[kItems];
-  uint64_t carry = 0;
-#pragma unroll
-  for (int r = 0; r < kItems; ++r) {
-    uint64_t q = quantize_at(w, base + r * 64 + lane, n, uniform, shift);
-    uint64_t incl = rr::wave_scan_u64(q, lane);
-    vals[r] = incl + carry;
-    carry += rr::shfl_u64(incl, 63);
-  }
-  if (lane == 0) s_w[wv] = carry;
-  __syncthreads();
-  uint64_t off = ctl->base + tile_offset[blockIdx.x];
-  for (int k = 0; k < wv; ++k) off += s_w[k];
-#pragma unroll
-  for (int r = 0; r < kItems; ++r) {
-    uint64_t i = base + r * 64 + lane;
-    if (i < n) cdf[i] = vals[r] + off;
-  }
-}
-
 // ------------------------------------------------------------------------------------------
 // K5: one thread per output slot: CDF target (multinomial draw or systematic position), lower
 // bound in the integer CDF, SoA gather from the live buffer set into the other one.
@@ -363,22 +158,14 @@ __global__ __launch_bounds__(kBlock) void k_resample_gather(Bufs b, const Ctl* _
   if (k >= a.n_slots) return;
   const int cur = ctl->cur;
   const uint64_t slot = a.first_slot + k;
-  uint64_t target;
-  if (a.scheme == RR_RESAMPLE_SYSTEMATIC) {
-    target = rr_sys_target(ctl->plan, slot);
-  } else {
-    double r, dummy;
-    if (r_explicit) r = r_explicit[k];
-    else rr_uniform2(a.seed, RR_STREAM_RESAMPLE, a.rstep, slot, &r, &dummy);
-    target = rr_fix_target_multinomial(r, ctl->total);
-  }
+  const uint64_t target = rr::resample_target(ctl, a.scheme, slot, a.seed, a.rstep, r_explicit, k);
   const uint64_t j = rr_lower_bound_u64(cdf, a.n_src, target);
   const double x = b.x[cur][j], y = b.y[cur][j], yaw = b.yaw[cur][j], v = b.v[cur][j];
-  if (a.to_staging) {
-    staging[k] = x;
-    staging[a.n_slots + k] = y;
-    staging[2 * a.n_slots + k] = yaw;
-    staging[3 * a.n_slots + k] = v;
+  if (a.to_staging) {  // n_slots x (x, y, yaw, v): one contiguous 32-byte record per slot
+    staging[4 * k] = x;
+    staging[4 * k + 1] = y;
+    staging[4 * k + 2] = yaw;
+    staging[4 * k + 3] = v;
   } else {
     const int nxt = cur ^ 1;
     b.x[nxt][k] = x;
@@ -397,17 +184,17 @@ __global__ void k_commit(Ctl* ctl) {
   }
 }
 
-// sharded adopt: copy a received SoA block into the other buffer set, then commit
+// sharded adopt: unpack the received n x (x, y, yaw, v) records into the other buffer set; k_commit follows
 __global__ __launch_bounds__(kBlock) void k_adopt(Bufs b, const Ctl* __restrict__ ctl,
                                                  const double* __restrict__ in, uint64_t n) {
   if (!ctl->fired) return;
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= n) return;
   const int nxt = ctl->cur ^ 1;
-  b.x[nxt][k] = in[k];
-  b.y[nxt][k] = in[n + k];
-  b.yaw[nxt][k] = in[2 * n + k];
-  b.v[nxt][k] = in[3 * n + k];
+  b.x[nxt][k] = in[4 * k];
+  b.y[nxt][k] = in[4 * k + 1];
+  b.yaw[nxt][k] = in[4 * k + 2];
+  b.v[nxt][k] = in[4 * k + 3];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -451,14 +238,17 @@ __global__ __launch_bounds__(kBlock) void k_moments(Bufs b, const double* __rest
   }
 }
 
-__global__ void k_moments_final(Bufs b, Ctl* __restrict__ ctl, const double* __restrict__ partials, int n_blocks) {
-  const int k = threadIdx.x;
-  if (k < kNumMoments) {
-    double s = 0.0;
-    for (int j = 0; j < n_blocks; ++j) s += partials[j * kNumMoments + k];
-    ctl->moments[k] = s;
-  }
-  if (k == 0) {
+// one wave per moment: lanes stride over the per-block partials (fixed order per lane), then a
+// shuffle tree -- deterministic for a given grid
+__global__ __launch_bounds__(kNumMoments * 64) void k_moments_final(Bufs b, Ctl* __restrict__ ctl,
+                                                                   const double* __restrict__ partials,
+                                                                   int n_blocks) {
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double s = 0.0;
+  for (int j = lane; j < n_blocks; j += 64) s += partials[j * kNumMoments + k];
+  s = rr::wave_sum(s);
+  if (lane == 0) ctl->moments[k] = s;
+  if (threadIdx.x == 0) {
     const int cur = ctl->cur;
     ctl->shift_point[0] = b.x[cur][0];
     ctl->shift_point[1] = b.y[cur][0];
@@ -494,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_aos(Bufs b, const double* __res
   if (i >= n) return;
   const int cur = ctl->cur;
   double wi;
-  if (ctl->weights_uniform || !ctl->usable) wi = 1.0 / (double)n_global;
+  if (ctl->weights_uniform || ctl->image_mode != rr::kImageWeights) wi = 1.0 / (double)n_global;
   else wi = w[i] / ctl->sum;
   out[5 * i] = b.x[cur][i];
   out[5 * i + 1] = b.y[cur][i];
@@ -532,8 +322,10 @@ struct rr_pf {
   rr_pf_config cfg;
   rr_pf_options opt;
   uint64_t n = 0, n_global = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // the stream all work is enqueued on
+  hipStream_t own_stream = nullptr;  // created with the handle
   bool owns_stream = false;
+  bool using_external_stream = false;
   Bufs b{};
   double* w = nullptr;
   uint64_t* cdf = nullptr;
@@ -691,26 +483,40 @@ rr_status launch_pw(rr_pf* h, const StepParams& p, const ObsArg& arg, bool kerna
   return RR_OK;
 }
 
-// quantize-reduce + tile scan (+ gate).  mode as k_scan_tiles.
-rr_status launch_sums(rr_pf* h, int mode, int scheme, double rho_override) {
-  {
-    Timed t(h, RR_K_QUANTIZE_REDUCE);
-    hipLaunchKernelGGL(k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->w, h->ctl,
-                       (const double*)&h->ctl->wmax_bits, h->n, h->n_global, h->tile_total, h->tile_q2);
-  }
-  ScanArgs a{};
-  a.n_tiles = h->n_tiles;
+ImageArgs image_args(const rr_pf* h) {
+  ImageArgs a{};
+  a.n = h->n;
   a.n_global = h->n_global;
-  a.threshold = h->cfg.resample_threshold;
+  a.gid0 = h->opt.first_global_index;
+  a.degenerate = rr::kDegenerateUniform;
+  a.honour_uniform_flag = 1;
+  return a;
+}
+
+PlanArgs plan_args(const rr_pf* h, int mode, int scheme, double rho_override) {
+  PlanArgs a{};
+  a.n_global = h->n_global;
+  a.neff_threshold = (double)h->n_global * h->cfg.resample_threshold;  // particle_filter.rs:339
   a.gate = h->opt.resample_gate;
   a.mode = mode;
   a.scheme = scheme;
   a.rho_override = rho_override;
   a.seed = h->opt.seed;
   a.rstep = h->rstep;
+  return a;
+}
+
+// quantize-reduce + tile scan (+ gate).  mode as rr::finalize_plan.
+rr_status launch_sums(rr_pf* h, int mode, int scheme, double rho_override) {
+  {
+    Timed t(h, RR_K_QUANTIZE_REDUCE);
+    hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->w, h->ctl,
+                       (const double*)&h->ctl->wmax_bits, image_args(h), h->tile_total, h->tile_q2);
+  }
   {
     Timed t(h, RR_K_SCAN_TILES);
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl, a);
+    hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl,
+                       h->n_tiles, 1, plan_args(h, mode, scheme, rho_override), (uint64_t*)nullptr);
   }
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
@@ -721,7 +527,7 @@ rr_status launch_sums(rr_pf* h, int mode, int scheme, double rho_override) {
 rr_status launch_resample(rr_pf* h, int scheme, const double* r_explicit_dev) {
   {
     Timed t(h, RR_K_CDF);
-    hipLaunchKernelGGL(k_cdf, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->w, h->ctl, h->n,
+    hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->w, h->ctl, image_args(h),
                        h->tile_total, h->cdf);
   }
   GatherArgs g{};
@@ -759,7 +565,7 @@ rr_status compute_moments(rr_pf* h, double est[4], double cov[16]) {
       Timed t(h, RR_K_MOMENTS);
       hipLaunchKernelGGL(k_moments, dim3(blocks), dim3(kBlock), 0, h->stream, h->b, h->w, h->ctl, h->n, attempt,
                          h->partials);
-      hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(64), 0, h->stream, h->b, h->ctl, h->partials, blocks);
+      hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(kNumMoments * 64), 0, h->stream, h->b, h->ctl, h->partials, blocks);
     }
     RR_HIP_TRY(hipGetLastError());
     rr_status s = fetch_ctl(h);
@@ -840,7 +646,8 @@ rr_status create_common(const rr_pf_config* cfg, const rr_pf_options* opt_in, co
     hipError_t _e = (expr);                                                                        \
     if (_e != hipSuccess) return cleanup(fail(RR_RUNTIME_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e))); \
   } while (0)
-  RR_TRY_OR_CLEAN(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  RR_TRY_OR_CLEAN(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+  h->stream = h->own_stream;
   h->owns_stream = true;
   const size_t nb = h->n * sizeof(double);
   for (int k = 0; k < 2; ++k) {
@@ -865,7 +672,8 @@ rr_status create_common(const rr_pf_config* cfg, const rr_pf_options* opt_in, co
   // Particle::new gives every particle w = 1/N (particle_filter.rs:35-43)
   Ctl init{};
   init.weights_uniform = 1;
-  init.usable = 1;
+  init.usable = 0;
+  init.image_mode = rr::kImageUniform;
   init.sum = 1.0;
   init.neff = (double)n_global;
   *h->ctl_host = init;
@@ -964,7 +772,7 @@ void rr_pf_destroy(rr_pf* h) {
     (void)hipEventDestroy(e.b);
   }
   for (auto e : h->event_pool) (void)hipEventDestroy(e);
-  if (h->owns_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->owns_stream && h->own_stream) (void)hipStreamDestroy(h->own_stream);
   delete h;
 }
 
@@ -1194,6 +1002,141 @@ rr_status rr_pf_get_counters(rr_pf* h, uint32_t* step, uint32_t* resample_step) 
   if (step) *step = h->step;
   if (resample_step) *resample_step = h->rstep;
   return RR_OK;
+}
+
+rr_status rr_pf_set_stream(rr_pf* h, void* stream) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (stream) {
+    h->stream = (hipStream_t)stream;
+    h->using_external_stream = true;
+  } else {
+    h->stream = h->own_stream;
+    h->using_external_stream = false;
+  }
+  return RR_OK;
+}
+
+static rr_status require_systematic_shard(const rr_pf* h) {
+  if (h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC)
+    return fail(RR_INVALID_PARAMETER, "sharded resampling is systematic only: create the shard with RR_RESAMPLE_SYSTEMATIC");
+  return RR_OK;
+}
+
+rr_status rr_pf_shard_propagate_weight(rr_pf* h, const double control[2], const double* obs, size_t n_obs,
+                                       double* d_wmax_out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = require_systematic_shard(h)) != RR_OK) return s;
+  if (!d_wmax_out) return fail(RR_INVALID_PARAMETER, "null d_wmax_out");
+  if ((s = validate_control(control)) != RR_OK) return s;
+  if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
+  ObsArg arg;
+  bool kernarg;
+  if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
+  StepParams p = make_params(h, control, (int)n_obs);
+  if ((s = launch_pw<true, true, false>(h, p, arg, kernarg)) != RR_OK) return s;
+  h->step += 1;
+  RR_HIP_TRY(hipMemcpyAsync(d_wmax_out, &h->ctl->wmax_bits, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  return RR_OK;
+}
+
+rr_status rr_pf_shard_quantize(rr_pf* h, const double* d_wmax_global, uint64_t* d_sums_out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!d_wmax_global || !d_sums_out) return fail(RR_INVALID_PARAMETER, "null device pointer");
+  {
+    Timed t(h, RR_K_QUANTIZE_REDUCE);
+    hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->w, h->ctl,
+                       d_wmax_global, image_args(h), h->tile_total, h->tile_q2);
+  }
+  {
+    Timed t(h, RR_K_SCAN_TILES);
+    hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl,
+                       h->n_tiles, 0, plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN), d_sums_out);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+rr_status rr_pf_shard_cdf(rr_pf* h, const uint64_t* d_all_sums, int32_t n_shards, int32_t rank) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!d_all_sums || n_shards <= 0 || rank < 0 || rank >= n_shards)
+    return fail(RR_INVALID_PARAMETER, "bad shard sums / rank");
+  hipLaunchKernelGGL(rr::k_shard_plan, dim3(1), dim3(1), 0, h->stream, h->ctl, d_all_sums, (int)n_shards, (int)rank,
+                     plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN));
+  {
+    Timed t(h, RR_K_CDF);
+    hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->w, h->ctl, image_args(h),
+                       h->tile_total, h->cdf);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  h->rstep += 1;
+  return RR_OK;
+}
+
+rr_status rr_pf_shard_get_plan(rr_pf* h, rr_pf_shard_plan* out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  const Ctl& c = *h->ctl_host;
+  out->fired = c.fired;
+  out->usable = c.usable;
+  out->total_global = c.total;
+  out->base = c.base;
+  out->total_local = c.total_local;
+  out->rho = c.rho;
+  return RR_OK;
+}
+
+rr_status rr_pf_shard_gather_slots(rr_pf* h, uint64_t first_slot, uint64_t n_slots, double* d_out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (n_slots == 0) return RR_OK;
+  if (!d_out) return fail(RR_INVALID_PARAMETER, "null d_out");
+  if (first_slot + n_slots > h->n_global) return fail(RR_INVALID_PARAMETER, "slot range exceeds n_global");
+  GatherArgs g{};
+  g.n_src = h->n;
+  g.first_slot = first_slot;
+  g.n_slots = n_slots;
+  g.seed = h->opt.seed;
+  g.rstep = h->rstep;
+  g.scheme = RR_RESAMPLE_SYSTEMATIC;
+  g.to_staging = 1;
+  {
+    Timed t(h, RR_K_RESAMPLE_GATHER);
+    hipLaunchKernelGGL(k_resample_gather, dim3(grid_for(n_slots, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl,
+                       h->cdf, (const double*)nullptr, (unsigned int*)nullptr, d_out, g);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+rr_status rr_pf_shard_adopt(rr_pf* h, const double* d_in) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!d_in) return fail(RR_INVALID_PARAMETER, "null d_in");
+  hipLaunchKernelGGL(k_adopt, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, d_in, h->n);
+  {
+    Timed t(h, RR_K_COMMIT);
+    hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, h->stream, h->ctl);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+uint64_t rr_sys_first_slot_above(double rho, uint64_t total_global, uint64_t n_global, uint64_t bound) {
+  if (n_global == 0) return 0;
+  const rr_sys_plan p = rr_sys_plan_make(rho, total_global, n_global);
+  uint64_t lo = 0, hi = n_global;  // target is non-decreasing in the slot index
+  while (lo < hi) {
+    const uint64_t mid = lo + ((hi - lo) >> 1);
+    if (rr_sys_target(p, mid) > bound) hi = mid; else lo = mid + 1;
+  }
+  return lo;
 }
 
 rr_status rr_pf_profile_enable(rr_pf* h, int32_t enable) {

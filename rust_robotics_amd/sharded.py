@@ -1,0 +1,294 @@
+"""Particle set sharded over the GPUs of one node: one process per GPU, RCCL between the phases.
+
+SURVEY.md section 8(e): particles are independent in propagate / weight; the coupling is (i) the
+global weight maximum and integer sums and (ii) the resample permutation.  Rank g owns the
+contiguous global index block [g*N/G, (g+1)*N/G).  Per step (systematic resampling,
+fastslam1.rs:205-234 semantics on the MCL step of monte_carlo_localization.rs:291-300):
+
+  A  propagate + weight (local kernel)               -> local max weight
+     all-reduce(MAX) of one double                   -- RCCL, 8 B
+  B  integer image under the GLOBAL max (local)      -> local (T, sum q^2)
+     all-gather of 3 x u64 per rank                  -- RCCL, 24 B * G
+  C  global totals, gate, local slice of the global CDF (local kernels)
+     host reads the G totals (one small D2H) and derives, with integer arithmetic only, which
+     contiguous run of global output slots every rank serves
+  D  every rank gathers the particles its slots' owners need into one contiguous send buffer
+     all-to-all of contiguous 32-byte-per-particle segments -- RCCL; in steady state only
+     neighbouring ranks exchange the few particles by which the cumulative weights drift
+  E  the received block becomes the new particle set (w = 1/N)
+
+Because every quantity that feeds back into the particle state is an exact integer sum, the
+sharded filter produces bit-identical particles for any G (tests/test_sharded_gloo.py checks
+G = 2 against G = 1 on CPU with the oracle standing in for the kernels).
+
+The orchestration below is backend-agnostic: ``HipShard`` drives the C ABI (include/rr_pf.h
+"sharded operation"); tests inject a CPU stand-in built on the oracle to cover the N > 1 logic
+with the gloo backend.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+import time
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from .core import RoboticsError
+
+
+@dataclass
+class ShardPlan:
+    fired: bool
+    usable: bool
+    total_global: int
+    base: int
+    total_local: int
+    rho: float
+
+
+def first_slot_above(rho: float, total_global: int, n_global: int, bound: int) -> int:
+    """Host-only integer helper of the C ABI (no GPU needed)."""
+    return int(_ffi.lib().rr_sys_first_slot_above(rho, total_global, n_global, bound))
+
+
+def segment_matrix(rho: float, totals: Sequence[int], n_global: int, n_local: int) -> np.ndarray:
+    """M[src][dst] = number of global output slots owned by rank dst whose source particle lives
+    on rank src, for systematic positions (i + rho) / N over the integer CDF with per-rank totals
+    ``totals``.  Pure integer arithmetic; every rank computes the same matrix."""
+    G = len(totals)
+    total = int(sum(totals))
+    M = np.zeros((G, G), dtype=np.int64)
+    base = 0
+    for src in range(G):
+        lo = first_slot_above(rho, total, n_global, base)
+        hi = first_slot_above(rho, total, n_global, base + int(totals[src]))
+        base += int(totals[src])
+        for dst in range(G):
+            a, b = max(lo, dst * n_local), min(hi, (dst + 1) * n_local)
+            if b > a:
+                M[src, dst] = b - a
+    return M
+
+
+class HipShard:
+    """One shard of the MCL engine on one GPU, driven through the C ABI with torch tensors as
+    the device buffers the collectives operate on (torch is plumbing here: memory + streams)."""
+
+    def __init__(self, rank: int, world: int, device: int, n_local: int, *, seed: int, range_noise=0.2,
+                 velocity_noise=2.0, yaw_rate_noise=math.radians(40.0), dt=0.1, gate=_ffi.RR_GATE_ALWAYS,
+                 resample_threshold=1.0, likelihood_mode=_ffi.RR_LIK_FUSED, initial_state=None):
+        import torch
+
+        self.torch = torch
+        self.rank, self.world, self.n_local = rank, world, n_local
+        self.n_global = n_local * world
+        self.device = torch.device("cuda", device)
+        L = _ffi.lib()
+        self.L = L
+        cfg = _ffi.PfConfig(n_local, resample_threshold, range_noise, velocity_noise, yaw_rate_noise, dt)
+        opt = _ffi.PfOptions()
+        L.rr_pf_options_default(C.byref(opt))
+        opt.device = device
+        opt.seed = seed
+        opt.resample_scheme = _ffi.RR_RESAMPLE_SYSTEMATIC
+        opt.resample_gate = gate
+        opt.likelihood_mode = likelihood_mode
+        opt.first_global_index = rank * n_local
+        opt.n_global = self.n_global
+        self.h = C.c_void_p()
+        if initial_state is None:
+            self._check(L.rr_pf_create(C.byref(cfg), C.byref(opt), C.byref(self.h)))
+        else:
+            st = np.ascontiguousarray(initial_state, dtype=np.float64)
+            self._check(L.rr_pf_create_with_state(C.byref(cfg), C.byref(opt), st.ctypes.data_as(C.POINTER(C.c_double)),
+                                                  C.byref(self.h)))
+        with torch.cuda.device(self.device):
+            self.wmax = torch.zeros(1, dtype=torch.float64, device=self.device)
+            self.sums = torch.zeros(3, dtype=torch.int64, device=self.device)
+            self.all_sums = torch.zeros(world * 3, dtype=torch.int64, device=self.device)
+            self.all_sums_host = torch.zeros(world * 3, dtype=torch.int64).pin_memory()
+            self.send_buf = torch.empty((n_local * 2, 4), dtype=torch.float64, device=self.device)
+            self.recv_buf = torch.empty((n_local, 4), dtype=torch.float64, device=self.device)
+            stream = torch.cuda.current_stream(self.device)
+        self._check(L.rr_pf_set_stream(self.h, C.c_void_p(stream.cuda_stream)))
+
+    def _check(self, status: int) -> None:
+        if status != _ffi.RR_OK:
+            kind = RoboticsError.invalid_parameter if status == _ffi.RR_INVALID_PARAMETER else RoboticsError.runtime
+            raise kind(_ffi.last_error())
+
+    def close(self) -> None:
+        if self.h:
+            self.L.rr_pf_destroy(self.h)
+            self.h = None
+
+    # ---- phases
+    def propagate_weight(self, u, obs: np.ndarray) -> None:
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, 3)
+        dp = C.POINTER(C.c_double)
+        self._check(self.L.rr_pf_shard_propagate_weight(self.h, u.ctypes.data_as(dp),
+                                                        obs.ctypes.data_as(dp) if obs.size else None, obs.shape[0],
+                                                        C.c_void_p(self.wmax.data_ptr())))
+
+    def quantize(self) -> None:
+        self._check(self.L.rr_pf_shard_quantize(self.h, C.c_void_p(self.wmax.data_ptr()), C.c_void_p(self.sums.data_ptr())))
+
+    def cdf(self) -> None:
+        self._check(self.L.rr_pf_shard_cdf(self.h, C.c_void_p(self.all_sums.data_ptr()), self.world, self.rank))
+        self.all_sums_host.copy_(self.all_sums, non_blocking=True)
+
+    def plan(self) -> ShardPlan:
+        p = _ffi.PfShardPlan()
+        self._check(self.L.rr_pf_shard_get_plan(self.h, C.byref(p)))  # synchronises the stream
+        return ShardPlan(bool(p.fired), bool(p.usable), int(p.total_global), int(p.base), int(p.total_local), float(p.rho))
+
+    def totals(self) -> List[int]:
+        a = self.all_sums_host.numpy().view(np.uint64).reshape(self.world, 3)
+        return [int(v) for v in a[:, 0]]
+
+    def gather_slots(self, first_slot: int, n_slots: int):
+        if n_slots > self.send_buf.shape[0]:
+            self.send_buf = self.torch.empty((n_slots, 4), dtype=self.torch.float64, device=self.device)
+        out = self.send_buf[:n_slots]
+        if n_slots:
+            self._check(self.L.rr_pf_shard_gather_slots(self.h, first_slot, n_slots, C.c_void_p(out.data_ptr())))
+        return out
+
+    def adopt(self, recv) -> None:
+        self._check(self.L.rr_pf_shard_adopt(self.h, C.c_void_p(recv.data_ptr())))
+
+    # ---- read-out (local)
+    def particles(self) -> np.ndarray:
+        out = np.empty((self.n_local, 5))
+        self._check(self.L.rr_pf_get_particles(self.h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def local_moments(self):
+        e = np.empty(4)
+        c = np.empty(16)
+        dp = C.POINTER(C.c_double)
+        self._check(self.L.rr_pf_estimate(self.h, e.ctypes.data_as(dp)))
+        self._check(self.L.rr_pf_covariance(self.h, c.ctypes.data_as(dp)))
+        return e, c.reshape(4, 4)
+
+    def synchronize(self) -> None:
+        self._check(self.L.rr_pf_synchronize(self.h))
+
+    def profile(self, on: bool) -> None:
+        self._check(self.L.rr_pf_profile_enable(self.h, 1 if on else 0))
+        if on:
+            self._check(self.L.rr_pf_profile_reset(self.h))
+
+    def profile_read(self) -> dict:
+        out = {}
+        for k in range(_ffi.RR_K_COUNT):
+            n, ms = C.c_uint64(), C.c_double()
+            self._check(self.L.rr_pf_profile_read(self.h, k, C.byref(n), C.byref(ms)))
+            out[self.L.rr_pf_kernel_name(k).decode()] = (n.value, ms.value)
+        return out
+
+
+class ShardedLocalizer:
+    """The step of one rank; ``backend`` is a HipShard (or a stand-in with the same phase methods
+    and ``wmax`` / ``sums`` / ``all_sums`` tensors); ``dist`` is torch.distributed."""
+
+    def __init__(self, backend, dist, group=None):
+        self.b = backend
+        self.dist = dist
+        self.group = group
+        self.last_matrix: Optional[np.ndarray] = None
+        self.weight_share = 1.0 / backend.world  # this rank's share of the total weight
+
+    def step(self, u, obs) -> bool:
+        b, dist = self.b, self.dist
+        b.propagate_weight(u, obs)
+        dist.all_reduce(b.wmax, op=dist.ReduceOp.MAX, group=self.group)
+        b.quantize()
+        dist.all_gather_into_tensor(b.all_sums, b.sums, group=self.group)
+        b.cdf()
+        plan = b.plan()
+        if not plan.fired:
+            self.weight_share = plan.total_local / plan.total_global if plan.total_global else 1.0 / b.world
+            return False
+        totals = b.totals()
+        M = segment_matrix(plan.rho, totals, b.n_global, b.n_local)
+        self.last_matrix = M
+        r = b.rank
+        n_send = int(M[r].sum())
+        first = first_slot_above(plan.rho, plan.total_global, b.n_global, plan.base)
+        send = b.gather_slots(first, n_send)
+        recv = b.recv_buf
+        assert int(M[:, r].sum()) == b.n_local, "every output slot of this rank must have exactly one source"
+        dist.all_to_all_single(recv, send, output_split_sizes=[int(v) for v in M[:, r]],
+                               input_split_sizes=[int(v) for v in M[r]], group=self.group)
+        b.adopt(recv)
+        self.weight_share = 1.0 / b.world
+        return True
+
+    def estimate(self):
+        """Global weighted mean / covariance (particle_filter.rs:382-413) from per-rank moments:
+        all-gather of (W_g, mean_g, cov_g), combined in rank order on every rank."""
+        torch = self.b.torch
+        e, c = self.b.local_moments()
+        rec = np.concatenate([[self.weight_share], e, c.reshape(-1)])
+        t = torch.from_numpy(rec).to(self.b.wmax.device)
+        allr = torch.empty(self.b.world * rec.size, dtype=torch.float64, device=t.device)
+        self.dist.all_gather_into_tensor(allr, t, group=self.group)
+        a = allr.cpu().numpy().reshape(self.b.world, -1)
+        W = a[:, 0].sum()
+        mean = (a[:, 0:1] * a[:, 1:5]).sum(0) / W
+        cov = np.zeros((4, 4))
+        for g in range(self.b.world):
+            d = a[g, 1:5] - mean
+            cov += a[g, 0] * (a[g, 5:].reshape(4, 4) + np.outer(d, d))
+        return mean, cov / W
+
+
+def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, lik):
+    """bench.py's N > 1 leg: weak scaling, n_local particles per GPU, barrier + synchronize on
+    both sides of the K timed steps, MAX over ranks."""
+    import torch
+    import torch.distributed as dist
+
+    if scheme != _ffi.RR_RESAMPLE_SYSTEMATIC:
+        raise SystemExit("the sharded path resamples systematically (use --scheme systematic)")
+    torch.cuda.set_device(local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    shard = HipShard(rank, world, local_rank, n_local, seed=1, likelihood_mode=lik, initial_state=[0.0, 0.0, 0.0, 1.0])
+    loc = ShardedLocalizer(shard, dist)
+    u = [1.0, 0.1]
+    for t in range(W):
+        loc.step(u, obs_list[t])
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        loc.step(u, obs_list[t])
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    est, _ = loc.estimate()
+    shard.profile(True)
+    t1 = time.perf_counter()
+    for t in range(W, W + K):
+        loc.step(u, obs_list[t])
+    torch.cuda.synchronize()
+    dt_instr = time.perf_counter() - t1
+    prof = shard.profile_read()
+    shard.profile(False)
+    moved = int(loc.last_matrix.sum() - np.trace(loc.last_matrix)) if loc.last_matrix is not None else 0
+    dist.barrier()
+    shard.close()
+    dist.destroy_process_group()
+    return dict(seconds=float(tmax.item()), seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est],
+                migrated_particles_last_step=moved)
