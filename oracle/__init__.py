@@ -174,9 +174,11 @@ def det() -> C.CDLL:
     L.det_fs1_model_default.restype = None
     L.det_fs1_predict.argtypes = [sz, P, P, P, d, d, P, P, u64, u32v, u64, MP]
     L.det_fs1_predict.restype = None
-    L.det_fs1_observe.argtypes = [sz, P, P, P, P, P, P, sz, MP]
+    L.det_fs1_observe.argtypes = [sz, P, P, P, P, P, P, sz, MP, i]
     L.det_fs1_observe.restype = None
-    L.det_fs1_update.argtypes = [sz, sz, P, P, P, P, P, d, d, P, sz, MP, d, u64, u32v, u32v, u32]
+    L.det_fs1_update.argtypes = [sz, sz, P, P, P, P, P, d, d, P, sz, MP, d, u64, u32v, u32v, i, u32]
+    L.det_fs1_get_observations.argtypes = [P, P, sz, d, d, d, u64, u32v, P]
+    L.det_fs1_get_observations.restype = sz
     L.det_fs1_update.restype = i
     L.det_fs1_best_particle.argtypes = [sz, P]
     L.det_fs1_best_particle.restype = sz

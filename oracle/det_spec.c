@@ -236,17 +236,29 @@ void det_fs1_predict(size_t n, double* px, double* py, double* pyaw, double u0, 
   }
 }
 
-/* per particle, observations in order (the per-particle order of fastslam1.rs:250-256) */
+/* per particle, observations in order (the per-particle order of fastslam1.rs:250-256).
+ * n_chunks > 1 mirrors the engine's observation chunking: chunk c covers observations
+ * [c*len, (c+1)*len), len = ceil(n_z / n_chunks); its partial product starts from the old weight
+ * (c == 0) or from 1.0, and the partials are multiplied together in chunk order.  With one chunk
+ * this is exactly the reference's left-to-right weight *= likelihood. */
 void det_fs1_observe(size_t n, const double* px, const double* py, const double* pyaw, double* pw,
-                     double* maps, const double* z, size_t n_z, const rr_fs1_model* m) {
+                     double* maps, const double* z, size_t n_z, const rr_fs1_model* m, int n_chunks) {
+  if (n_z == 0) return;
+  if (n_chunks < 1) n_chunks = 1;
+  size_t len = (n_z + (size_t)n_chunks - 1) / (size_t)n_chunks;
   for (size_t p = 0; p < n; ++p) {
-    double w = pw[p];
-    for (size_t k = 0; k < n_z; ++k) {
-      size_t id = (size_t)z[3 * k + 2];
-      double e[6];
-      for (int f = 0; f < 6; ++f) e[f] = maps[(id * 6 + f) * n + p];
-      w *= rr_fs1_update_one(px[p], py[p], pyaw[p], z[3 * k], z[3 * k + 1], e, *m);
-      for (int f = 0; f < 6; ++f) maps[(id * 6 + f) * n + p] = e[f];
+    double w = 0.0;
+    for (size_t c = 0; c * len < n_z; ++c) {
+      double acc = c == 0 ? pw[p] : 1.0;
+      size_t k1 = (c + 1) * len < n_z ? (c + 1) * len : n_z;
+      for (size_t k = c * len; k < k1; ++k) {
+        size_t id = (size_t)z[3 * k + 2];
+        double e[6];
+        for (int f = 0; f < 6; ++f) e[f] = maps[(id * 6 + f) * n + p];
+        acc *= rr_fs1_update_one(px[p], py[p], pyaw[p], z[3 * k], z[3 * k + 1], e, *m);
+        for (int f = 0; f < 6; ++f) maps[(id * 6 + f) * n + p] = e[f];
+      }
+      w = c == 0 ? acc : w * acc;
     }
     pw[p] = w;
   }
@@ -274,9 +286,9 @@ static void fs1_gather(size_t n, size_t L, double* px, double* py, double* pyaw,
  * weights; the normalised weight is w / (T * 2^-shift). */
 int det_fs1_update(size_t n, size_t L, double* px, double* py, double* pyaw, double* pw, double* maps,
                    double u0, double u1, const double* z, size_t n_z, const rr_fs1_model* m,
-                   double nth, uint64_t seed, uint32_t step, uint32_t rstep, uint32_t* idx_out) {
+                   double nth, uint64_t seed, uint32_t step, uint32_t rstep, int n_chunks, uint32_t* idx_out) {
   det_fs1_predict(n, px, py, pyaw, u0, u1, NULL, NULL, seed, step, 0, m);
-  det_fs1_observe(n, px, py, pyaw, pw, maps, z, n_z, m);
+  det_fs1_observe(n, px, py, pyaw, pw, maps, z, n_z, m, n_chunks);
   double wmax = det_wmax(n, pw);
   int shift;
   uint64_t total, q2h, q2l;
@@ -302,6 +314,28 @@ int det_fs1_update(size_t n, size_t L, double* px, double* py, double* pyaw, dou
     for (size_t p = 0; p < n; ++p) pw[p] = pw[p] / s;
   }
   return 0;
+}
+
+/* observation simulator of the engine (rr_fs1_get_observations): fastslam1.rs:277-299 with the
+ * Philox SIM stream; out rows (d, angle, id); returns the count */
+size_t det_fs1_get_observations(const double xt[3], const double* lms, size_t L, double max_range, double r00,
+                                double r11, uint64_t seed, uint32_t step, double* out) {
+  size_t cnt = 0;
+  double sr0 = rr_sqrt(r00), sr1 = rr_sqrt(r11);
+  for (size_t l = 0; l < L; ++l) {
+    double dx = lms[2 * l] - xt[0], dy = lms[2 * l + 1] - xt[1];
+    double d = rr_sqrt(rr_fma(dy, dy, dx * dx));
+    if (d <= max_range) {
+      double angle = rr_normalize_angle(rr_atan2(dy, dx) - xt[2]);
+      double z0, z1;
+      rr_normal2(seed, RR_STREAM_SIM, step, l, &z0, &z1);
+      out[3 * cnt] = rr_fma(z0, sr0, d);
+      out[3 * cnt + 1] = rr_fma(z1, sr1, angle);
+      out[3 * cnt + 2] = (double)l;
+      ++cnt;
+    }
+  }
+  return cnt;
 }
 
 /* fastslam1.rs:269-274: arg max of the weight, ties -> last */

@@ -61,6 +61,21 @@ class PfFixedSums(C.Structure):
     ]
 
 
+class Fs1Params(C.Structure):
+    """rr_fs1_params: the constants of fastslam1.rs:13-23 as fields"""
+
+    _fields_ = [(k, C.c_double) for k in ("dt", "q00", "q11", "r00", "r11", "max_range", "nth", "initial_weight",
+                                          "init_cov", "init_threshold", "first_obs_cov")]
+
+
+class Fs1Options(C.Structure):
+    _fields_ = [("device", C.c_int32), ("record_indices", C.c_int32), ("seed", C.c_uint64), ("obs_chunks", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+RR_FK_COUNT = 10
+
+
 class PfShardSums(C.Structure):
     _fields_ = [("total", C.c_uint64), ("q2_hi", C.c_uint64), ("q2_lo", C.c_uint64)]
 
@@ -148,6 +163,37 @@ def lib() -> C.CDLL:
     proto("rr_pf_shard_gather_slots", st, [H, u64, u64, V])
     proto("rr_pf_shard_adopt", st, [H, V])
     proto("rr_sys_first_slot_above", u64, [d, u64, u64, u64])
+    FP, FO = C.POINTER(Fs1Params), C.POINTER(Fs1Options)
+    proto("rr_fs1_params_default", None, [FP])
+    proto("rr_fs1_options_default", None, [FO])
+    proto("rr_fs1_create", st, [u64, u64, FP, FO, C.POINTER(H)])
+    proto("rr_fs1_destroy", None, [H])
+    proto("rr_fs1_particle_count", u64, [H])
+    proto("rr_fs1_landmark_count", u64, [H])
+    proto("rr_fs1_update", st, [H, P, P, sz])
+    proto("rr_fs1_update_async", st, [H, P, P, sz])
+    proto("rr_fs1_synchronize", st, [H])
+    proto("rr_fs1_best_particle", st, [H, P, P, C.POINTER(u64)])
+    proto("rr_fs1_get_landmarks", st, [H, u64, P])
+    proto("rr_fs1_get_poses", st, [H, P])
+    proto("rr_fs1_get_state", st, [H, P, P])
+    proto("rr_fs1_set_state", st, [H, P, P])
+    proto("rr_fs1_update_host", st, [H, P, P, P, P, sz])
+    proto("rr_fs1_get_observations", sz, [P, P, sz, FP, u64, u32, P, sz])
+    proto("rr_fs1_predict_with_noise", st, [H, P, P, P])
+    proto("rr_fs1_predict", st, [H, P])
+    proto("rr_fs1_observe", st, [H, P, sz])
+    proto("rr_fs1_normalize_resample", st, [H])
+    proto("rr_fs1_resample_systematic", st, [H, d])
+    proto("rr_fs1_last_resample_fired", st, [H, C.POINTER(i32)])
+    proto("rr_fs1_last_resample_indices", st, [H, C.POINTER(u32), sz])
+    proto("rr_fs1_n_eff", st, [H, P])
+    proto("rr_fs1_get_fixed_sums", st, [H, C.POINTER(PfFixedSums)])
+    proto("rr_fs1_get_counters", st, [H, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32)])
+    proto("rr_fs1_profile_enable", st, [H, i32])
+    proto("rr_fs1_profile_read", st, [H, i32, C.POINTER(u64), P])
+    proto("rr_fs1_profile_reset", st, [H])
+    proto("rr_fs1_kernel_name", C.c_char_p, [i32])
     _lib = L
     return L
 

@@ -1,0 +1,911 @@
+// fs1_engine.hip -- MI355X (gfx950) FastSLAM 1.0 engine behind include/rr_fastslam1.h.
+//
+// Replaces the CPU hot path of /root/reference/crates/rust_robotics_slam/src/fastslam1.rs:
+//   predict_particle :123-137, update_landmark :140-183 (the N x K double loop of :250-256),
+//   normalize_weights / compute_neff :186-203, resample :205-234, get_best_particle :269-274.
+// Not a translation of the reference's Vec<Particle>{Vec<Landmark>} layout: every particle's map
+// lives in HBM as landmark-major planes plane[(l*6+f)*N + p] (+3 pose planes), so one wavefront
+// touching 64 consecutive particles of one landmark field is one coalesced 512-byte access, the
+// observation list is wave-uniform (LDS), and the systematic resample is a monotone plane gather.
+//
+// Kernels
+//   k_fs1_predict      pose planes in place                               48 B / particle
+//   k_fs1_observe      (particle, observation chunk): 2x2 EKF per observed landmark,
+//                      R 48 B + W <= 48 B per (particle, landmark) update  <- dominant
+//   k_fs1_combine      partial weight products -> weight, atomic max
+//   rr::k_quantize_reduce / k_scan_tiles / k_cdf   integer CDF (resample_core.hpp)
+//   k_fs1_normalize    w /= sum when the gate did not fire
+//   k_fs1_indices      CDF search per output slot
+//   k_fs1_gather       out[plane][k] = in[plane][idx[k]] over 3 + 6L planes  16 B / element
+//   k_commit           flip the live buffer
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "resample_core.hpp"
+#include "rr_common.hpp"
+#include "rr_fastslam1.h"
+#include "rr_pf_spec.h"
+
+using rr::Ctl;
+using rr::fail;
+using rr::ImageArgs;
+using rr::kBlock;
+using rr::kScanThreads;
+using rr::kTile;
+using rr::PlanArgs;
+
+namespace {
+
+constexpr int kMaxChunks = 32;
+constexpr int kPlanesPerThread = 8;  // planes one gather thread copies for its output slot
+
+struct Planes {
+  double* s[2];  // [(3 + 6L) * N]: planes 0..2 = x, y, yaw; plane 3 + l*6 + f = landmark l field f
+};
+
+template <bool EXPLICIT>
+__global__ __launch_bounds__(kBlock) void k_fs1_predict(Planes pl, const Ctl* __restrict__ ctl, uint64_t n,
+                                                       double u0, double u1, rr_fs1_model m, uint64_t seed,
+                                                       unsigned int step, const double* __restrict__ z0,
+                                                       const double* __restrict__ z1) {
+  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  double* s = pl.s[ctl->cur];
+  double x = s[p], y = s[n + p], yaw = s[2 * n + p];
+  double a, b;
+  if (EXPLICIT) {
+    a = z0[p];
+    b = z1[p];
+  } else {
+    rr_fs1_motion_noise(seed, step, p, &a, &b);
+  }
+  rr_fs1_predict_one(&x, &y, &yaw, u0, u1, a, b, m);
+  s[p] = x;
+  s[n + p] = y;
+  s[2 * n + p] = yaw;
+}
+
+// (particle, observation chunk).  blockIdx.y = chunk.  The chunk's observations are staged in
+// LDS and read back with wave-uniform addresses; each update loads the 6 planes of the observed
+// landmark for 64 consecutive particles (coalesced), runs the 2x2 EKF of rr_fs1_update_one and
+// stores only the fields that changed.
+__global__ __launch_bounds__(kBlock) void k_fs1_observe(Planes pl, double* __restrict__ pw, Ctl* __restrict__ ctl,
+                                                       uint64_t n, const double* __restrict__ z, int n_z,
+                                                       int chunk_len, int n_chunks, rr_fs1_model m,
+                                                       double* __restrict__ partial) {
+  extern __shared__ double s_z[];
+  __shared__ double s_wmax[kBlock / rr::kWave];
+  const int chunk = blockIdx.y;
+  const int k0 = chunk * chunk_len;
+  const int k1 = min(k0 + chunk_len, n_z);
+  for (int i = threadIdx.x; i < 3 * (k1 - k0); i += kBlock) s_z[i] = z[3 * k0 + i];
+  __syncthreads();
+  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  double acc = 0.0;
+  if (p < n) {
+    double* s = pl.s[ctl->cur];
+    const double px = s[p], py = s[n + p], pyaw = s[2 * n + p];
+    acc = chunk == 0 ? pw[p] : 1.0;
+    for (int k = 0; k < k1 - k0; ++k) {
+      const double zd = s_z[3 * k], za = s_z[3 * k + 1];
+      const uint64_t id = (uint64_t)s_z[3 * k + 2];
+      double* e0 = s + (3 + id * 6) * n + p;
+      double e[6], o[6];
+#pragma unroll
+      for (int f = 0; f < 6; ++f) o[f] = e[f] = e0[f * n];
+      acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
+#pragma unroll
+      for (int f = 0; f < 6; ++f)
+        if (rr_d2u(e[f]) != rr_d2u(o[f])) e0[f * n] = e[f];
+    }
+    if (n_chunks == 1) pw[p] = acc;
+    else partial[(uint64_t)chunk * n + p] = acc;
+  }
+  if (n_chunks == 1) {
+    double mx = acc > 0.0 ? acc : 0.0;
+    mx = rr::wave_max(mx);
+    if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double bm = s_wmax[0];
+      for (int k = 1; k < kBlock / rr::kWave; ++k) bm = s_wmax[k] > bm ? s_wmax[k] : bm;
+      if (bm > 0.0) rr::atomic_max_u64(&ctl->wmax_bits, rr_d2u(bm));
+    }
+  }
+}
+
+// weight = partial[0] * partial[1] * ... (chunk order), max into Ctl
+__global__ __launch_bounds__(kBlock) void k_fs1_combine(double* __restrict__ pw, Ctl* __restrict__ ctl, uint64_t n,
+                                                       const double* __restrict__ partial, int n_chunks) {
+  __shared__ double s_wmax[kBlock / rr::kWave];
+  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  double w = 0.0;
+  if (p < n) {
+    w = partial[p];
+    for (int c = 1; c < n_chunks; ++c) w *= partial[(uint64_t)c * n + p];
+    pw[p] = w;
+  }
+  double mx = w > 0.0 ? w : 0.0;
+  mx = rr::wave_max(mx);
+  if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double bm = s_wmax[0];
+    for (int k = 1; k < kBlock / rr::kWave; ++k) bm = s_wmax[k] > bm ? s_wmax[k] : bm;
+    if (bm > 0.0) rr::atomic_max_u64(&ctl->wmax_bits, rr_d2u(bm));
+  }
+}
+
+// max only (after set_state)
+__global__ __launch_bounds__(kBlock) void k_fs1_wmax(const double* __restrict__ pw, Ctl* __restrict__ ctl, uint64_t n) {
+  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  double w = p < n ? pw[p] : 0.0;
+  double mx = w > 0.0 ? w : 0.0;
+  mx = rr::wave_max(mx);
+  if ((threadIdx.x & 63) == 0 && mx > 0.0) rr::atomic_max_u64(&ctl->wmax_bits, rr_d2u(mx));
+}
+
+// fastslam1.rs:196-203 when no resample follows: w /= sum iff the sum is positive
+__global__ __launch_bounds__(kBlock) void k_fs1_normalize(double* __restrict__ pw, const Ctl* __restrict__ ctl, uint64_t n) {
+  if (ctl->fired || ctl->image_mode != rr::kImageWeights) return;
+  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p < n) pw[p] = pw[p] / ctl->sum;
+}
+
+__global__ __launch_bounds__(kBlock) void k_fs1_indices(const Ctl* __restrict__ ctl, const uint64_t* __restrict__ cdf,
+                                                       uint64_t n, unsigned int* __restrict__ idx,
+                                                       double* __restrict__ pw) {
+  if (!ctl->fired) return;
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n) return;
+  const uint64_t target = rr_sys_target(ctl->plan, k);
+  idx[k] = (unsigned int)rr_lower_bound_u64(cdf, n, target);
+  pw[k] = 1.0 / (double)n;  // fastslam1.rs:228
+}
+
+// blockIdx.y selects a group of kPlanesPerThread planes; indices are non-decreasing, so each
+// plane is read almost sequentially
+__global__ __launch_bounds__(kBlock) void k_fs1_gather(Planes pl, const Ctl* __restrict__ ctl,
+                                                      const unsigned int* __restrict__ idx, uint64_t n,
+                                                      uint64_t n_planes) {
+  if (!ctl->fired) return;
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n) return;
+  const int cur = ctl->cur;
+  const double* __restrict__ in = pl.s[cur];
+  double* __restrict__ out = pl.s[cur ^ 1];
+  const uint64_t j = idx[k];
+  const uint64_t p0 = (uint64_t)blockIdx.y * kPlanesPerThread;
+  double v[kPlanesPerThread];
+#pragma unroll
+  for (int q = 0; q < kPlanesPerThread; ++q)
+    if (p0 + q < n_planes) v[q] = in[(p0 + q) * n + j];
+#pragma unroll
+  for (int q = 0; q < kPlanesPerThread; ++q)
+    if (p0 + q < n_planes) out[(p0 + q) * n + k] = v[q];
+}
+
+__global__ void k_fs1_commit(Ctl* ctl) {
+  if (ctl->fired) ctl->cur ^= 1;
+}
+
+// arg max of the weight with ties -> highest index (fastslam1.rs:269-274, Q14): the key
+// (weight bits, index) is order preserving for non-negative doubles
+__global__ __launch_bounds__(kBlock) void k_fs1_argmax(const double* __restrict__ pw, uint64_t n,
+                                                      uint64_t* __restrict__ part_bits, uint64_t* __restrict__ part_idx) {
+  __shared__ uint64_t s_b[kBlock / rr::kWave], s_i[kBlock / rr::kWave];
+  uint64_t bb = 0, bi = 0;
+  bool have = false;
+  for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (uint64_t)gridDim.x * kBlock) {
+    const double w = pw[p];
+    const uint64_t b = w > 0.0 ? rr_d2u(w) : 0ull;  // NaN / negative weights rank lowest
+    if (!have || b > bb || (b == bb && p > bi)) {
+      bb = b;
+      bi = p;
+      have = true;
+    }
+  }
+  if (!have) {
+    bb = 0;
+    bi = 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint64_t ob = rr::shfl_xor_u64(bb, o), oi = rr::shfl_xor_u64(bi, o);
+    if (ob > bb || (ob == bb && oi > bi)) {
+      bb = ob;
+      bi = oi;
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_b[threadIdx.x >> 6] = bb;
+    s_i[threadIdx.x >> 6] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < kBlock / rr::kWave; ++k)
+      if (s_b[k] > bb || (s_b[k] == bb && s_i[k] > bi)) {
+        bb = s_b[k];
+        bi = s_i[k];
+      }
+    part_bits[blockIdx.x] = bb;
+    part_idx[blockIdx.x] = bi;
+  }
+}
+
+__global__ void k_fs1_argmax_final(Ctl* __restrict__ ctl, const uint64_t* __restrict__ part_bits,
+                                   const uint64_t* __restrict__ part_idx, int n_blocks) {
+  if (threadIdx.x != 0) return;
+  uint64_t bb = part_bits[0], bi = part_idx[0];
+  for (int k = 1; k < n_blocks; ++k)
+    if (part_bits[k] > bb || (part_bits[k] == bb && part_idx[k] > bi)) {
+      bb = part_bits[k];
+      bi = part_idx[k];
+    }
+  ctl->best_bits = bb;
+  ctl->best_index = bi;
+}
+
+// host layouts <-> planes.  tmp holds the AoS image on the device.
+__global__ __launch_bounds__(kBlock) void k_fs1_init(Planes pl, double* __restrict__ pw, uint64_t n, uint64_t L,
+                                                    double w0, double cov0) {
+  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t n_planes = 3 + 6 * L;
+  if (t >= n_planes * n) return;
+  const uint64_t plane = t / n, p = t % n;
+  double v = 0.0;
+  if (plane >= 3) {
+    const int f = (int)((plane - 3) % 6);
+    if (f == 2 || f == 5) v = cov0;
+  }
+  pl.s[0][t] = v;
+  if (plane == 0) pw[p] = w0;
+}
+
+// maps AoS [p][l][6] -> planes (dir = 0) or back (dir = 1); one thread per (p, l)
+__global__ __launch_bounds__(kBlock) void k_fs1_maps_transpose(double* __restrict__ planes, double* __restrict__ aos,
+                                                              uint64_t n, uint64_t L, int dir) {
+  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (t >= n * L) return;
+  const uint64_t l = t / n, p = t % n;  // consecutive threads -> consecutive particles: plane side coalesced
+  double* a = aos + (p * L + l) * 6;
+  double* b = planes + (3 + l * 6) * n + p;
+#pragma unroll
+  for (int f = 0; f < 6; ++f) {
+    if (dir == 0) b[f * n] = a[f];
+    else a[f] = b[f * n];
+  }
+}
+
+// poses N x (w, x, y, yaw) <-> weight array + pose planes
+__global__ __launch_bounds__(kBlock) void k_fs1_poses(double* __restrict__ planes, double* __restrict__ pw,
+                                                     double* __restrict__ aos, uint64_t n, int dir) {
+  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  if (dir == 0) {
+    pw[p] = aos[4 * p];
+    planes[p] = aos[4 * p + 1];
+    planes[n + p] = aos[4 * p + 2];
+    planes[2 * n + p] = aos[4 * p + 3];
+  } else {
+    aos[4 * p] = pw[p];
+    aos[4 * p + 1] = planes[p];
+    aos[4 * p + 2] = planes[n + p];
+    aos[4 * p + 3] = planes[2 * n + p];
+  }
+}
+
+__global__ void k_fs1_one_landmarks(const double* __restrict__ planes, uint64_t n, uint64_t L, uint64_t p,
+                                    double* __restrict__ out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 6 * L) return;
+  out[t] = planes[(3 + t) * n + p];  // t = l*6 + f
+}
+
+}  // namespace
+
+// =============================================================================================
+struct rr_fs1 {
+  rr_fs1_params prm;
+  rr_fs1_options opt;
+  uint64_t n = 0, L = 0, n_planes = 0, n_tiles = 0;
+  hipStream_t stream = nullptr;
+  Planes pl{};
+  double* pw = nullptr;
+  uint64_t* cdf = nullptr;
+  uint64_t* tile_total = nullptr;
+  uint64_t* tile_q2 = nullptr;
+  unsigned int* idx = nullptr;
+  double* partial = nullptr;  // kMaxChunks * n
+  double* z_dev = nullptr;
+  size_t z_cap = 0;
+  double* noise = nullptr;  // 2n
+  uint64_t* part_bits = nullptr;
+  uint64_t* part_idx = nullptr;
+  Ctl* ctl = nullptr;
+  Ctl* ctl_host = nullptr;
+  unsigned int step = 0, rstep = 0;
+  int last_chunks = 1;
+  rr::Profiler prof{RR_FK_COUNT};
+};
+
+namespace {
+
+const char* kFkNames[RR_FK_COUNT] = {"k_fs1_predict", "k_fs1_observe", "k_fs1_combine", "k_quantize_reduce",
+                                     "k_scan_tiles",  "k_fs1_normalize", "k_cdf",        "k_fs1_indices",
+                                     "k_fs1_gather",  "k_fs1_commit"};
+
+inline unsigned grid_for(uint64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+rr_status bind(rr_fs1* h) {
+  if (!h) return fail(RR_INVALID_PARAMETER, "null handle");
+  RR_HIP_TRY(hipSetDevice(h->opt.device));
+  return RR_OK;
+}
+
+rr_fs1_model host_model(const rr_fs1_params& p) {
+  rr_fs1_model m;
+  m.dt = p.dt;
+  m.q_sqrt0 = rr_sqrt(p.q00);
+  m.q_sqrt1 = rr_sqrt(p.q11);
+  m.r00 = p.r00;
+  m.r11 = p.r11;
+  m.init_threshold = p.init_threshold;
+  m.init_cov = p.first_obs_cov;
+  return m;
+}
+
+rr_status validate_u(const double u[2]) {
+  if (!u || !std::isfinite(u[0]) || !std::isfinite(u[1]))
+    return fail(RR_INVALID_PARAMETER, "fastslam control input must contain only finite values");
+  return RR_OK;
+}
+
+// z rows are (d, angle, id); ids must be integral and inside the map; duplicates force one chunk
+rr_status validate_z(const rr_fs1* h, const double* z, size_t n_z, bool* has_duplicates) {
+  if (n_z && !z) return fail(RR_INVALID_PARAMETER, "null observations");
+  std::vector<char> seen(h->L, 0);
+  *has_duplicates = false;
+  for (size_t k = 0; k < n_z; ++k) {
+    const double d = z[3 * k], a = z[3 * k + 1], id = z[3 * k + 2];
+    if (!std::isfinite(d) || !std::isfinite(a) || !std::isfinite(id))
+      return fail(RR_INVALID_PARAMETER, "fastslam observations must be finite");
+    if (id < 0.0 || id >= (double)h->L || id != std::floor(id))
+      return fail(RR_INVALID_PARAMETER, "fastslam observation landmark id out of range");  // the reference would panic on the index
+    if (seen[(size_t)id]) *has_duplicates = true;
+    seen[(size_t)id] = 1;
+  }
+  return RR_OK;
+}
+
+ImageArgs image_args(const rr_fs1* h) {
+  ImageArgs a{};
+  a.n = h->n;
+  a.n_global = h->n;
+  a.gid0 = 0;
+  a.degenerate = rr::kDegenerateLast;
+  a.honour_uniform_flag = 0;
+  return a;
+}
+
+PlanArgs plan_args(const rr_fs1* h, int mode, double rho_override) {
+  PlanArgs a{};
+  a.n_global = h->n;
+  a.neff_threshold = h->prm.nth;  // fastslam1.rs:262-265
+  a.gate = RR_GATE_NEFF;
+  a.mode = mode;
+  a.scheme = RR_RESAMPLE_SYSTEMATIC;
+  a.rho_override = rho_override;
+  a.seed = h->opt.seed;
+  a.rstep = h->rstep;
+  return a;
+}
+
+template <bool EXPLICIT>
+rr_status launch_predict(rr_fs1* h, const double u[2]) {
+  rr::ScopedTimer t(h->prof, h->stream, RR_FK_PREDICT);
+  hipLaunchKernelGGL((k_fs1_predict<EXPLICIT>), dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl, h->ctl,
+                     h->n, u[0], u[1], host_model(h->prm), h->opt.seed, h->step, (const double*)h->noise,
+                     (const double*)(h->noise ? h->noise + h->n : nullptr));
+  RR_HIP_TRY(hipGetLastError());
+  h->step += 1;
+  return RR_OK;
+}
+
+int choose_chunks(const rr_fs1* h, size_t n_z, bool dup) {
+  if (dup || n_z <= 1) return 1;
+  int want = h->opt.obs_chunks;
+  if (want <= 0) {
+    // aim for >= ~8 waves per SIMD over the 256 CUs (1024 SIMDs) of an MI355X
+    const uint64_t waves = (h->n + 63) / 64;
+    want = (int)((8192 + waves - 1) / waves);
+  }
+  want = std::max(1, std::min<int>({want, kMaxChunks, (int)n_z}));
+  const int len = (int)((n_z + want - 1) / want);
+  return (int)((n_z + len - 1) / len);
+}
+
+rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup) {
+  if (n_z == 0) {  // no observation: weights untouched, but the max must still be known
+    RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+    hipLaunchKernelGGL(k_fs1_wmax, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
+    h->last_chunks = 1;
+    return RR_OK;
+  }
+  if (n_z > h->z_cap) {
+    if (h->z_dev) RR_HIP_TRY(hipFree(h->z_dev));
+    h->z_dev = nullptr;
+    h->z_cap = 0;
+    RR_HIP_TRY(hipMalloc(&h->z_dev, 3 * n_z * sizeof(double)));
+    h->z_cap = n_z;
+  }
+  RR_HIP_TRY(hipMemcpyAsync(h->z_dev, z, 3 * n_z * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+  const int chunks = choose_chunks(h, n_z, dup);
+  const int len = (int)((n_z + chunks - 1) / chunks);
+  h->last_chunks = chunks;
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_OBSERVE);
+    hipLaunchKernelGGL(k_fs1_observe, dim3(grid_for(h->n, kBlock), chunks), dim3(kBlock), 3 * (size_t)len * sizeof(double),
+                       h->stream, h->pl, h->pw, h->ctl, h->n, (const double*)h->z_dev, (int)n_z, len, chunks,
+                       host_model(h->prm), h->partial);
+  }
+  if (chunks > 1) {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_COMBINE);
+    hipLaunchKernelGGL(k_fs1_combine, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n,
+                       (const double*)h->partial, chunks);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+rr_status launch_sums(rr_fs1* h, int mode, double rho_override) {
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_QUANTIZE_REDUCE);
+    hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->pw, h->ctl,
+                       (const double*)&h->ctl->wmax_bits, image_args(h), h->tile_total, h->tile_q2);
+  }
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_SCAN_TILES);
+    hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl,
+                       h->n_tiles, 1, plan_args(h, mode, rho_override), (uint64_t*)nullptr);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+// normalise-or-resample after the sums (every kernel decides on the device whether it runs)
+rr_status launch_finish(rr_fs1* h) {
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_CDF);
+    hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->pw, h->ctl, image_args(h),
+                       h->tile_total, h->cdf);
+  }
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_NORMALIZE);
+    hipLaunchKernelGGL(k_fs1_normalize, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
+  }
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_INDICES);
+    hipLaunchKernelGGL(k_fs1_indices, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->ctl, h->cdf, h->n,
+                       h->idx, h->pw);
+  }
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_GATHER);
+    hipLaunchKernelGGL(k_fs1_gather, dim3(grid_for(h->n, kBlock), grid_for(h->n_planes, kPlanesPerThread)), dim3(kBlock), 0,
+                       h->stream, h->pl, h->ctl, h->idx, h->n, h->n_planes);
+  }
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_COMMIT);
+    hipLaunchKernelGGL(k_fs1_commit, dim3(1), dim3(1), 0, h->stream, h->ctl);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  h->rstep += 1;
+  return RR_OK;
+}
+
+rr_status fetch_ctl(rr_fs1* h) {
+  RR_HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return RR_OK;
+}
+
+rr_status ensure_noise(rr_fs1* h) {
+  if (!h->noise) RR_HIP_TRY(hipMalloc(&h->noise, 2 * h->n * sizeof(double)));
+  return RR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void rr_fs1_params_default(rr_fs1_params* p) {
+  if (!p) return;
+  p->dt = 0.1;
+  p->q00 = 0.3;
+  p->q11 = 0.0305;
+  p->r00 = 0.5;
+  p->r11 = 0.0305;
+  p->max_range = 20.0;
+  p->nth = 100.0 / 1.5;
+  p->initial_weight = 1.0 / 100.0;
+  p->init_cov = 1000.0;
+  p->init_threshold = 100.0;
+  p->first_obs_cov = NAN;
+}
+
+void rr_fs1_options_default(rr_fs1_options* o) {
+  if (!o) return;
+  std::memset(o, 0, sizeof(*o));
+}
+
+rr_status rr_fs1_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs1_params* params,
+                        const rr_fs1_options* opt_in, rr_fs1** out) {
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output handle");
+  *out = nullptr;
+  if (n_particles == 0) return fail(RR_INVALID_PARAMETER, "fastslam requires at least one particle");
+  if (n_particles >= (1ull << 31)) return fail(RR_INVALID_PARAMETER, "n_particles must be below 2^31");
+  rr_fs1_params prm;
+  if (params) prm = *params; else rr_fs1_params_default(&prm);
+  rr_fs1_options opt;
+  if (opt_in) opt = *opt_in; else rr_fs1_options_default(&opt);
+  if (!(prm.dt > 0.0) || !(prm.q00 >= 0.0) || !(prm.q11 >= 0.0) || !std::isfinite(prm.r00) || !std::isfinite(prm.r11) ||
+      !std::isfinite(prm.nth) || !std::isfinite(prm.initial_weight) || !std::isfinite(prm.init_cov))
+    return fail(RR_INVALID_PARAMETER, "fastslam parameters must be finite (dt > 0, Q >= 0)");
+  if (opt.obs_chunks < 0 || opt.obs_chunks > kMaxChunks) return fail(RR_INVALID_PARAMETER, "obs_chunks out of range");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(RR_RUNTIME_ERROR, "no HIP device available: the engine has no CPU fallback");
+  if (opt.device < 0 || opt.device >= ndev) return fail(RR_INVALID_PARAMETER, "device ordinal out of range");
+  RR_HIP_TRY(hipSetDevice(opt.device));
+  rr_fs1* h = new rr_fs1();
+  h->prm = prm;
+  h->opt = opt;
+  h->n = n_particles;
+  h->L = n_landmarks;
+  h->n_planes = 3 + 6 * n_landmarks;
+  h->n_tiles = (h->n + kTile - 1) / kTile;
+  auto cleanup = [&](rr_status st) {
+    rr_fs1_destroy(h);
+    return st;
+  };
+#define RR_TRY_OR_CLEAN(expr)                                                                                          \
+  do {                                                                                                                 \
+    hipError_t _e = (expr);                                                                                            \
+    if (_e != hipSuccess) return cleanup(fail(RR_RUNTIME_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e)));  \
+  } while (0)
+  RR_TRY_OR_CLEAN(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  const size_t state_bytes = h->n_planes * h->n * sizeof(double);
+  RR_TRY_OR_CLEAN(hipMalloc(&h->pl.s[0], state_bytes));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->pl.s[1], state_bytes));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->pw, h->n * sizeof(double)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->cdf, h->n * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->tile_total, h->n_tiles * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->tile_q2, 2 * h->n_tiles * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->idx, h->n * sizeof(unsigned int)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->partial, (size_t)kMaxChunks * h->n * sizeof(double)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->part_bits, 1024 * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->part_idx, 1024 * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->ctl, sizeof(Ctl)));
+  RR_TRY_OR_CLEAN(hipHostMalloc(&h->ctl_host, sizeof(Ctl)));
+  RR_TRY_OR_CLEAN(hipMemsetAsync(h->ctl, 0, sizeof(Ctl), h->stream));
+  hipLaunchKernelGGL(k_fs1_init, dim3(grid_for(h->n_planes * h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl, h->pw,
+                     h->n, h->L, prm.initial_weight, prm.init_cov);
+  RR_TRY_OR_CLEAN(hipGetLastError());
+  RR_TRY_OR_CLEAN(hipStreamSynchronize(h->stream));
+#undef RR_TRY_OR_CLEAN
+  *out = h;
+  return RR_OK;
+}
+
+void rr_fs1_destroy(rr_fs1* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->opt.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)hipFree(h->pl.s[0]);
+  (void)hipFree(h->pl.s[1]);
+  (void)hipFree(h->pw);
+  (void)hipFree(h->cdf);
+  (void)hipFree(h->tile_total);
+  (void)hipFree(h->tile_q2);
+  (void)hipFree(h->idx);
+  (void)hipFree(h->partial);
+  (void)hipFree(h->z_dev);
+  (void)hipFree(h->noise);
+  (void)hipFree(h->part_bits);
+  (void)hipFree(h->part_idx);
+  (void)hipFree(h->ctl);
+  if (h->ctl_host) (void)hipHostFree(h->ctl_host);
+  h->prof.destroy();
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+uint64_t rr_fs1_particle_count(const rr_fs1* h) { return h ? h->n : 0; }
+uint64_t rr_fs1_landmark_count(const rr_fs1* h) { return h ? h->L : 0; }
+
+rr_status rr_fs1_predict(rr_fs1* h, const double u[2]) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = validate_u(u)) != RR_OK) return s;
+  return launch_predict<false>(h, u);
+}
+
+rr_status rr_fs1_predict_with_noise(rr_fs1* h, const double u[2], const double* z0, const double* z1) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = validate_u(u)) != RR_OK) return s;
+  if (!z0 || !z1) return fail(RR_INVALID_PARAMETER, "null noise arrays");
+  if ((s = ensure_noise(h)) != RR_OK) return s;
+  RR_HIP_TRY(hipMemcpyAsync(h->noise, z0, h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RR_HIP_TRY(hipMemcpyAsync(h->noise + h->n, z1, h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  return launch_predict<true>(h, u);
+}
+
+rr_status rr_fs1_observe(rr_fs1* h, const double* z, size_t n_z) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  bool dup;
+  if ((s = validate_z(h, z, n_z, &dup)) != RR_OK) return s;
+  return launch_observe(h, z, n_z, dup);
+}
+
+rr_status rr_fs1_normalize_resample(rr_fs1* h) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = launch_sums(h, 0, NAN)) != RR_OK) return s;
+  return launch_finish(h);
+}
+
+rr_status rr_fs1_resample_systematic(rr_fs1* h, double rho) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!(rho >= 0.0 && rho < 1.0)) return fail(RR_INVALID_PARAMETER, "rho must lie in [0, 1)");
+  if ((s = launch_sums(h, 1, rho)) != RR_OK) return s;
+  return launch_finish(h);
+}
+
+rr_status rr_fs1_update_async(rr_fs1* h, const double u[2], const double* z, size_t n_z) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = validate_u(u)) != RR_OK) return s;
+  bool dup;
+  if ((s = validate_z(h, z, n_z, &dup)) != RR_OK) return s;
+  if ((s = launch_predict<false>(h, u)) != RR_OK) return s;
+  if ((s = launch_observe(h, z, n_z, dup)) != RR_OK) return s;
+  if ((s = launch_sums(h, 0, NAN)) != RR_OK) return s;
+  return launch_finish(h);
+}
+
+rr_status rr_fs1_synchronize(rr_fs1* h) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return RR_OK;
+}
+
+rr_status rr_fs1_update(rr_fs1* h, const double u[2], const double* z, size_t n_z) {
+  rr_status s = rr_fs1_update_async(h, u, z, n_z);
+  if (s != RR_OK) return s;
+  return rr_fs1_synchronize(h);
+}
+
+rr_status rr_fs1_best_particle(rr_fs1* h, double out_pose[3], double* out_weight, uint64_t* out_index) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  const int blocks = (int)std::min<uint64_t>(1024, grid_for(h->n, kBlock));
+  hipLaunchKernelGGL(k_fs1_argmax, dim3(blocks), dim3(kBlock), 0, h->stream, h->pw, h->n, h->part_bits, h->part_idx);
+  hipLaunchKernelGGL(k_fs1_argmax_final, dim3(1), dim3(64), 0, h->stream, h->ctl, h->part_bits, h->part_idx, blocks);
+  RR_HIP_TRY(hipGetLastError());
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  const uint64_t bi = h->ctl_host->best_index;
+  const int cur = h->ctl_host->cur;
+  double pose[3], w;
+  for (int k = 0; k < 3; ++k)
+    RR_HIP_TRY(hipMemcpyAsync(&pose[k], h->pl.s[cur] + k * h->n + bi, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RR_HIP_TRY(hipMemcpyAsync(&w, h->pw + bi, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (out_pose) std::memcpy(out_pose, pose, sizeof pose);
+  if (out_weight) *out_weight = w;
+  if (out_index) *out_index = bi;
+  return RR_OK;
+}
+
+rr_status rr_fs1_get_landmarks(rr_fs1* h, uint64_t particle_index, double* out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  if (particle_index >= h->n) return fail(RR_INVALID_PARAMETER, "particle index out of range");
+  if (h->L == 0) return RR_OK;
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  const int cur = h->ctl_host->cur;
+  double* tmp = h->pl.s[cur ^ 1];  // the inactive buffer set is free between steps
+  hipLaunchKernelGGL(k_fs1_one_landmarks, dim3(grid_for(6 * h->L, 256)), dim3(256), 0, h->stream,
+                     (const double*)h->pl.s[cur], h->n, h->L, particle_index, tmp);
+  RR_HIP_TRY(hipGetLastError());
+  RR_HIP_TRY(hipMemcpyAsync(out, tmp, 6 * h->L * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return RR_OK;
+}
+
+rr_status rr_fs1_get_state(rr_fs1* h, double* poses_out, double* maps_out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  const int cur = h->ctl_host->cur;
+  double* tmp = h->pl.s[cur ^ 1];
+  if (poses_out) {
+    hipLaunchKernelGGL(k_fs1_poses, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl.s[cur], h->pw, tmp,
+                       h->n, 1);
+    RR_HIP_TRY(hipGetLastError());
+    RR_HIP_TRY(hipMemcpyAsync(poses_out, tmp, 4 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  if (maps_out && h->L) {
+    hipLaunchKernelGGL(k_fs1_maps_transpose, dim3(grid_for(h->n * h->L, kBlock)), dim3(kBlock), 0, h->stream, h->pl.s[cur],
+                       tmp, h->n, h->L, 1);
+    RR_HIP_TRY(hipGetLastError());
+    RR_HIP_TRY(hipMemcpyAsync(maps_out, tmp, 6 * h->L * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  return RR_OK;
+}
+
+rr_status rr_fs1_get_poses(rr_fs1* h, double* out) {
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  return rr_fs1_get_state(h, out, nullptr);
+}
+
+rr_status rr_fs1_set_state(rr_fs1* h, const double* poses, const double* maps) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  const int cur = h->ctl_host->cur;
+  double* tmp = h->pl.s[cur ^ 1];
+  if (poses) {
+    RR_HIP_TRY(hipMemcpyAsync(tmp, poses, 4 * h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_fs1_poses, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl.s[cur], h->pw, tmp,
+                       h->n, 0);
+    RR_HIP_TRY(hipGetLastError());
+    RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  if (maps && h->L) {
+    RR_HIP_TRY(hipMemcpyAsync(tmp, maps, 6 * h->L * h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_fs1_maps_transpose, dim3(grid_for(h->n * h->L, kBlock)), dim3(kBlock), 0, h->stream, h->pl.s[cur],
+                       tmp, h->n, h->L, 0);
+    RR_HIP_TRY(hipGetLastError());
+    RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  }
+  // the weight maximum of the uploaded set (needed if normalize_resample is called next)
+  RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+  hipLaunchKernelGGL(k_fs1_wmax, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
+  RR_HIP_TRY(hipGetLastError());
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return RR_OK;
+}
+
+rr_status rr_fs1_update_host(rr_fs1* h, double* poses, double* maps, const double u[2], const double* z, size_t n_z) {
+  if (!poses || (!maps && h && h->L)) return fail(RR_INVALID_PARAMETER, "null state");
+  rr_status s = rr_fs1_set_state(h, poses, maps);
+  if (s != RR_OK) return s;
+  if ((s = rr_fs1_update(h, u, z, n_z)) != RR_OK) return s;
+  return rr_fs1_get_state(h, poses, maps);
+}
+
+size_t rr_fs1_get_observations(const double x_true[3], const double* landmarks_xy, size_t n_landmarks,
+                               const rr_fs1_params* params, uint64_t seed, uint32_t step, double* out, size_t cap) {
+  rr_fs1_params prm;
+  if (params) prm = *params; else rr_fs1_params_default(&prm);
+  if (!x_true || (!landmarks_xy && n_landmarks) || (!out && cap)) return 0;
+  const double sr0 = rr_sqrt(prm.r00), sr1 = rr_sqrt(prm.r11);
+  size_t cnt = 0;
+  for (size_t l = 0; l < n_landmarks; ++l) {
+    const double dx = landmarks_xy[2 * l] - x_true[0];
+    const double dy = landmarks_xy[2 * l + 1] - x_true[1];
+    const double d = rr_sqrt(rr_fma(dy, dy, dx * dx));
+    if (d <= prm.max_range) {  // fastslam1.rs:288
+      const double angle = rr_normalize_angle(rr_atan2(dy, dx) - x_true[2]);
+      double z0, z1;
+      rr_normal2(seed, RR_STREAM_SIM, step, l, &z0, &z1);
+      if (cnt < cap) {
+        out[3 * cnt] = rr_fma(z0, sr0, d);
+        out[3 * cnt + 1] = rr_fma(z1, sr1, angle);
+        out[3 * cnt + 2] = (double)l;
+      }
+      ++cnt;
+    }
+  }
+  return cnt;
+}
+
+rr_status rr_fs1_last_resample_fired(rr_fs1* h, int32_t* out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  *out = h->ctl_host->fired;
+  return RR_OK;
+}
+
+rr_status rr_fs1_last_resample_indices(rr_fs1* h, uint32_t* out, size_t n) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out || n != h->n) return fail(RR_INVALID_PARAMETER, "need room for one index per particle");
+  RR_HIP_TRY(hipMemcpyAsync(out, h->idx, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return RR_OK;
+}
+
+rr_status rr_fs1_n_eff(rr_fs1* h, double* out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  if ((s = launch_sums(h, 2, NAN)) != RR_OK) return s;
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  *out = h->ctl_host->neff;
+  return RR_OK;
+}
+
+rr_status rr_fs1_get_fixed_sums(rr_fs1* h, rr_pf_fixed_sums* out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  if ((s = launch_sums(h, 2, NAN)) != RR_OK) return s;
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  const Ctl& c = *h->ctl_host;
+  out->usable = c.usable;
+  out->shift = c.shift;
+  out->total = c.total;
+  out->q2_hi = c.q2_hi;
+  out->q2_lo = c.q2_lo;
+  out->w_max = c.wmax;
+  out->sum = c.sum;
+  return RR_OK;
+}
+
+rr_status rr_fs1_get_counters(rr_fs1* h, uint32_t* step, uint32_t* resample_step, int32_t* obs_chunks) {
+  if (!h) return fail(RR_INVALID_PARAMETER, "null handle");
+  if (step) *step = h->step;
+  if (resample_step) *resample_step = h->rstep;
+  if (obs_chunks) *obs_chunks = h->last_chunks;
+  return RR_OK;
+}
+
+rr_status rr_fs1_profile_enable(rr_fs1* h, int32_t enable) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  h->prof.drain();
+  h->prof.on = enable != 0;
+  return RR_OK;
+}
+
+rr_status rr_fs1_profile_read(rr_fs1* h, int32_t kernel_id, uint64_t* launches, double* total_ms) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (kernel_id < 0 || kernel_id >= RR_FK_COUNT) return fail(RR_INVALID_PARAMETER, "kernel id out of range");
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  h->prof.drain();
+  if (launches) *launches = h->prof.launches[kernel_id];
+  if (total_ms) *total_ms = h->prof.ms[kernel_id];
+  return RR_OK;
+}
+
+rr_status rr_fs1_profile_reset(rr_fs1* h) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  h->prof.reset();
+  return RR_OK;
+}
+
+const char* rr_fs1_kernel_name(int32_t kernel_id) {
+  return kernel_id >= 0 && kernel_id < RR_FK_COUNT ? kFkNames[kernel_id] : "";
+}
+
+}  // extern "C"

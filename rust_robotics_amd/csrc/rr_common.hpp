@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <string>
+#include <vector>
 
 #include "rr_pf.h"
 
@@ -26,6 +27,75 @@ inline rr_status fail(rr_status code, const std::string& msg) {
       return ::rr::fail(RR_RUNTIME_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     }                                                                                     \
   } while (0)
+
+// ---- HIP-event timing of kernel launches on one stream (measurement hooks of the C ABI)
+struct Profiler {
+  struct Ev {
+    int id;
+    hipEvent_t a, b;
+  };
+  bool on = false;
+  std::vector<Ev> events;
+  std::vector<hipEvent_t> pool;
+  std::vector<uint64_t> launches;
+  std::vector<double> ms;
+  explicit Profiler(int n_ids) : launches(n_ids, 0), ms(n_ids, 0.0) {}
+  hipEvent_t take() {
+    hipEvent_t e;
+    if (!pool.empty()) {
+      e = pool.back();
+      pool.pop_back();
+    } else {
+      (void)hipEventCreate(&e);
+    }
+    return e;
+  }
+  void drain() {
+    for (auto& e : events) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, e.a, e.b) == hipSuccess) {
+        ms[e.id] += t;
+        launches[e.id] += 1;
+      }
+      pool.push_back(e.a);
+      pool.push_back(e.b);
+    }
+    events.clear();
+  }
+  void reset() {
+    drain();
+    for (auto& v : launches) v = 0;
+    for (auto& v : ms) v = 0.0;
+  }
+  void destroy() {
+    for (auto& e : events) {
+      (void)hipEventDestroy(e.a);
+      (void)hipEventDestroy(e.b);
+    }
+    for (auto e : pool) (void)hipEventDestroy(e);
+    events.clear();
+    pool.clear();
+  }
+};
+
+// brackets the launches issued during its lifetime with two events on `stream`
+struct ScopedTimer {
+  Profiler& p;
+  hipStream_t stream;
+  int id;
+  hipEvent_t a = nullptr, b = nullptr;
+  ScopedTimer(Profiler& p_, hipStream_t s, int id_) : p(p_), stream(s), id(id_) {
+    if (!p.on) return;
+    a = p.take();
+    b = p.take();
+    (void)hipEventRecord(a, stream);
+  }
+  ~ScopedTimer() {
+    if (!p.on) return;
+    (void)hipEventRecord(b, stream);
+    p.events.push_back({id, a, b});
+  }
+};
 
 // ---- wave64 primitives (gfx950: a wavefront is 64 lanes) ------------------------------
 constexpr int kWave = 64;

@@ -1,0 +1,356 @@
+"""GPU parity of the FastSLAM 1.0 engine (through the C ABI) against
+  * oracle/det_spec.c   -- BIT-EXACT: poses, maps, weights, gate decision, resample indices
+  * oracle/ref_literal.c -- the reference arithmetic (fastslam1.rs), rtol = atol = 1e-6
+and the reference's own unit tests (fastslam1.rs:308-401) re-expressed against the engine.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import dp, u32p, u64p
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-6, atol=1e-6)
+
+
+@pytest.fixture(scope="module")
+def fs():
+    from rust_robotics_amd.slam import fastslam1
+
+    assert fastslam1._ffi.lib().rr_device_count() >= 1
+    return fastslam1
+
+
+def bits_equal(a, b):
+    return np.array_equal(np.ascontiguousarray(a, dtype=np.float64).view(np.uint64), np.ascontiguousarray(b, dtype=np.float64).view(np.uint64))
+
+
+def scene(L, seed, half=15.0):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(-half, half, size=(L, 2))
+
+
+def make_state(n, L, lms, seed, cov=0.5):
+    """maps pre-initialised so that every pair takes the EKF branch"""
+    rng = np.random.default_rng(seed)
+    poses = np.column_stack([np.full(n, 1.0 / n), rng.normal(0, 0.2, n), rng.normal(0, 0.2, n), rng.normal(0, 0.05, n)])
+    maps = np.zeros((n, L, 6))
+    maps[:, :, 0] = lms[None, :, 0] + rng.normal(0, 0.5, (n, L))
+    maps[:, :, 1] = lms[None, :, 1] + rng.normal(0, 0.5, (n, L))
+    maps[:, :, 2] = cov
+    maps[:, :, 5] = cov
+    maps[:, :, 3] = rng.normal(0, 0.01, (n, L))  # slightly asymmetric on purpose (Q12)
+    maps[:, :, 4] = rng.normal(0, 0.01, (n, L))
+    return poses, maps
+
+
+def observations_for(fs, pose, lms, seed, step):
+    return np.array(fs.get_observations(pose, [tuple(p) for p in lms], seed=seed, step=step)).reshape(-1, 3)
+
+
+def test_simulator_matches_det_and_reference_gate(fs, det, ref):
+    lms = np.array([[5.0, 0.0], [100.0, 100.0], [0.0, 19.9], [3.0, -4.0]])
+    xt = np.array([0.0, 0.0, 0.3])
+    z = observations_for(fs, xt, lms, seed=9, step=4)
+    out = np.empty((4, 3))
+    cnt = det.det_fs1_get_observations(dp(xt), dp(np.ascontiguousarray(lms)), 4, 20.0, 0.5, 0.0305, 9, 4, dp(out))
+    assert cnt == len(z) == 3 and bits_equal(z, out[:cnt])
+    # fastslam1.rs:325-341: only the landmark inside MAX_RANGE is observed
+    z2 = fs.get_observations([0.0, 0.0, 0.0], [(5.0, 0.0), (100.0, 100.0)], seed=1)
+    assert len(z2) == 1 and z2[0][2] == 0 and abs(z2[0][0] - 5.0) < 5.0
+    # literal reference with the same unit normals
+    zn = np.empty(8)
+    z0, z1 = np.empty(4), np.empty(4)
+    det.det_normal2_v(9, 5, 4, 0, 4, dp(z0), dp(z1))
+    zn[0::2], zn[1::2] = z0, z1
+    m = oracle.ref_fs1_model()
+    outr = np.empty((4, 3))
+    cr = ref.ref_fs1_get_observations(dp(xt), dp(np.ascontiguousarray(lms)), 4, 20.0, dp(zn), C.byref(m), dp(outr))
+    assert cr == cnt
+    np.testing.assert_allclose(z, outr[:cr], rtol=1e-13, atol=1e-13)
+
+
+def test_initial_state_matches_reference(fs):
+    """fastslam1.rs:382-400"""
+    f = fs.FastSlam1(10, 4)
+    poses, maps = f.get_state()
+    assert np.all(poses[:, 1:] == 0.0)
+    assert np.all(np.abs(poses[:, 0] - 1.0 / 100) < np.finfo(float).eps)
+    assert np.all(maps[:, :, 0] == 0) and np.all(maps[:, :, 1] == 0)
+    assert np.all(maps[:, :, 2] == 1000.0) and np.all(maps[:, :, 5] == 1000.0)
+    assert np.all(maps[:, :, 3] == 0) and np.all(maps[:, :, 4] == 0)
+    ps = fs.create_particles(50, 5)
+    assert len(ps) == 50 and all(len(p.landmarks) == 5 for p in ps)
+
+
+@pytest.mark.parametrize("n", [1, 64, 1000, 4097])
+def test_predict_with_noise(fs, det, ref, n):
+    rng = np.random.default_rng(3)
+    poses = np.column_stack([np.full(n, 1.0 / n), rng.normal(0, 1, n), rng.normal(0, 1, n), rng.uniform(-3.1, 3.1, n)])
+    z0, z1 = rng.normal(size=n), rng.normal(size=n)
+    f = fs.FastSlam1(n, 2)
+    f.set_state(poses, None)
+    f.predict_with_noise([1.0, 0.1], z0, z1)
+    got = f.poses()
+    px, py, pyaw = (np.ascontiguousarray(poses[:, k]) for k in (1, 2, 3))
+    md = oracle.det_fs1_model()
+    det.det_fs1_predict(n, dp(px), dp(py), dp(pyaw), 1.0, 0.1, dp(z0), dp(z1), 0, 0, 0, C.byref(md))
+    assert bits_equal(got[:, 1], px) and bits_equal(got[:, 2], py) and bits_equal(got[:, 3], pyaw)
+    rx, ry, ryaw = (np.ascontiguousarray(poses[:, k]) for k in (1, 2, 3))
+    mr = oracle.ref_fs1_model()
+    ref.ref_fs1_predict(n, dp(rx), dp(ry), dp(ryaw), 1.0, 0.1, dp(z0), dp(z1), C.byref(mr))
+    np.testing.assert_allclose(got[:, 1:], np.column_stack([rx, ry, ryaw]), rtol=1e-13, atol=1e-14)
+    assert np.all(np.abs(got[:, 3]) <= math.pi)
+
+
+@pytest.mark.parametrize("n,L,chunks", [(300, 6, 1), (1000, 50, 1), (1000, 50, 4), (2049, 33, 7), (500, 200, 0)])
+def test_observe_ekf_matches_oracles(fs, det, ref, n, L, chunks):
+    lms = scene(L, 11)
+    poses, maps = make_state(n, L, lms, 12)
+    truth = np.array([0.0, 0.0, 0.0])
+    z = observations_for(fs, truth, lms, seed=13, step=0)
+    assert len(z) == L
+    f = fs.FastSlam1(n, L, obs_chunks=chunks)
+    f.set_state(poses, maps)
+    f.observe(z)
+    used = f.counters()[2]
+    if chunks:
+        assert used == math.ceil(L / math.ceil(L / chunks))
+    gp, gm = f.get_state()
+    # D-spec (landmark-major planes), same chunking
+    px, py, pyaw, pw = (np.ascontiguousarray(poses[:, k]) for k in (1, 2, 3, 0))
+    planes = oracle.maps_aos_to_planes(maps, n, L)
+    md = oracle.det_fs1_model()
+    det.det_fs1_observe(n, dp(px), dp(py), dp(pyaw), dp(pw), dp(planes), dp(z), len(z), C.byref(md), used)
+    assert bits_equal(gp[:, 0], pw), "accumulated weights"
+    assert bits_equal(gm.reshape(-1), oracle.maps_planes_to_aos(planes, n, L)), "maps"
+    # literal reference: observation outer, particle inner (fastslam1.rs:250-256)
+    rw = np.ascontiguousarray(poses[:, 0])
+    rm = maps.copy().reshape(-1)
+    mr = oracle.ref_fs1_model()
+    for k in range(len(z)):
+        for p in range(n):
+            wv = C.c_double(rw[p])
+            e = rm[(p * L + int(z[k, 2])) * 6:(p * L + int(z[k, 2])) * 6 + 6]
+            ref.ref_fs1_update_landmark(poses[p, 1], poses[p, 2], poses[p, 3], C.byref(wv), z[k, 0], z[k, 1], dp(e), C.byref(mr))
+            rw[p] = wv.value
+        if n * L > 60000 and k >= 20:
+            break
+    if n * L <= 60000:
+        np.testing.assert_allclose(gm.reshape(-1), rm, **TOL)
+        big = rw > 1e-250
+        np.testing.assert_allclose(gp[big, 0], rw[big], rtol=1e-6)
+
+
+def test_first_observation_branch_reference_quirk(fs, det):
+    """Q11: with the reference's parameters the first observation sets x,y and leaves cov at 1000,
+    so the weights never change through fastslam_update alone; first_obs_cov switches that."""
+    n, L = 256, 5
+    lms = scene(L, 21)
+    f = fs.FastSlam1(n, L, seed=22)
+    for t in range(3):
+        f.update([1.0, 0.1], observations_for(fs, H.true_pose(t + 1), lms, seed=22, step=t))
+    poses, maps = f.get_state()
+    assert np.all(maps[:, :, 2] == 1000.0) and np.all(maps[:, :, 5] == 1000.0)
+    assert np.any(maps[:, :, 0] != 0.0)
+    assert np.allclose(poses[:, 0], 1.0 / n)  # normalised from 1/100 each, never reweighted
+    prm = fs.default_params()
+    prm.first_obs_cov = 10.0
+    g = fs.FastSlam1(n, L, params=prm, seed=22)
+    for t in range(3):
+        g.update([1.0, 0.1], observations_for(fs, H.true_pose(t + 1), lms, seed=22, step=t))
+    p2, m2 = g.get_state()
+    assert np.all(m2[:, :, 2] < 100.0) and np.ptp(p2[:, 0]) > 0.0
+
+
+def test_systematic_resample_and_gather(fs, det, ref):
+    n, L = 5000, 7
+    lms = scene(L, 31)
+    poses, maps = make_state(n, L, lms, 32)
+    rng = np.random.default_rng(33)
+    poses[:, 0] = rng.random(n) ** 6 * np.exp(-rng.random(n) * 15)
+    rho = float(np.floor(rng.random() * 2**53) / 2**53)
+    f = fs.FastSlam1(n, L)
+    f.set_state(poses, maps)
+    f.resample_systematic(rho)
+    idx = f.last_resample_indices()
+    w = np.ascontiguousarray(poses[:, 0])
+    fx = H.det_fixed(det, w)
+    cdf = H.det_cdf(det, w, fx)
+    e = np.empty(n, np.uint32)
+    det.det_indices_systematic(n, u64p(cdf), fx["total"], n, 0, n, rho, u32p(e))
+    assert np.array_equal(idx, e)
+    er = np.empty(n, np.uint32)
+    ref.ref_fs1_resample_indices(n, dp(w.copy()), rho / n, u32p(er))
+    assert np.array_equal(idx, er)
+    gp, gm = f.get_state()
+    assert bits_equal(gp[:, 1:], poses[idx, 1:]) and bits_equal(gm, maps[idx])
+    assert np.all(gp[:, 0] == 1.0 / n)
+    assert f.last_resample_fired()
+
+
+def test_all_zero_weights_walk_to_last_particle(fs):
+    """fastslam1.rs:196-203,224-226: sum w == 0 => no normalisation, N_eff = 0 < NTH, and the walk
+    ends on the last particle for every slot"""
+    n, L = 300, 3
+    poses = np.column_stack([np.zeros(n), np.arange(n, dtype=float), np.zeros(n), np.zeros(n)])
+    f = fs.FastSlam1(n, L)
+    f.set_state(poses, None)
+    assert f.n_eff() == 0.0
+    f.normalize_resample()
+    assert f.last_resample_fired()
+    assert np.all(f.last_resample_indices() == n - 1)
+    assert np.all(f.poses()[:, 1] == n - 1)
+
+
+def test_best_particle_ties_go_last(fs):
+    """fastslam1.rs:344-360 + Q14"""
+    f = fs.FastSlam1(5, 3)
+    poses = np.zeros((5, 4))
+    poses[:, 0] = [0.1, 0.5, 0.9, 0.3, 0.2]
+    poses[:, 1] = np.arange(5)
+    f.set_state(poses, None)
+    pose, w, i = f.best_particle()
+    assert i == 2 and abs(w - 0.9) < np.finfo(float).eps and pose[0] == 2.0
+    poses[:, 0] = [0.9, 0.5, 0.9, 0.3, 0.9]
+    f.set_state(poses, None)
+    assert f.best_particle()[2] == 4
+    n = 100_000
+    g = fs.FastSlam1(n, 1)
+    p = np.zeros((n, 4))
+    p[:, 0] = np.random.default_rng(1).random(n)
+    p[[17, 99_998], 0] = 2.0
+    g.set_state(p, None)
+    assert g.best_particle()[2] == 99_998
+
+
+@pytest.mark.parametrize("chunks", [1, 0])
+def test_trajectory_bit_exact_vs_det(fs, det, chunks):
+    n, L, T = 2000, 24, 12
+    lms = scene(L, 41)
+    prm = fs.default_params()
+    prm.first_obs_cov = 2.0   # reach the EKF branch through updates alone
+    prm.nth = n / 1.5         # the evident intent of fastslam1.rs:18
+    f = fs.FastSlam1(n, L, params=prm, seed=77, obs_chunks=chunks)
+    px, py, pyaw = (np.zeros(n) for _ in range(3))
+    pw = np.full(n, 0.01)
+    planes = oracle.maps_aos_to_planes(np.tile(np.array([0, 0, 1000.0, 0, 0, 1000.0]), (n, L, 1)), n, L)
+    md = oracle.det_fs1_model()
+    md.init_cov = 2.0
+    idx = np.empty(n, np.uint32)
+    fired_any = False
+    for t in range(T):
+        z = observations_for(fs, H.true_pose(t + 1), lms, seed=77, step=t)
+        f.update([1.0, 0.1], z)
+        used = f.counters()[2]
+        fired = det.det_fs1_update(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(planes), 1.0, 0.1, dp(z), len(z), C.byref(md),
+                                   n / 1.5, 77, t, t, used, u32p(idx))
+        assert f.last_resample_fired() == bool(fired), f"gate differs at step {t}"
+        fired_any |= bool(fired)
+        if fired:
+            assert np.array_equal(f.last_resample_indices(), idx), f"indices differ at step {t}"
+        gp, gm = f.get_state()
+        assert bits_equal(gp[:, 0], pw), f"weights step {t}"
+        assert bits_equal(gp[:, 1], px) and bits_equal(gp[:, 2], py) and bits_equal(gp[:, 3], pyaw), f"poses step {t}"
+        assert bits_equal(gm.reshape(-1), oracle.maps_planes_to_aos(planes, n, L)), f"maps step {t}"
+    assert fired_any
+    pose, w, i = f.best_particle()
+    assert i == det.det_fs1_best_particle(n, dp(pw))
+    assert np.hypot(*(pose[:2] - H.true_pose(T)[:2])) < 2.0
+
+
+def test_trajectory_vs_literal_reference(fs, det, ref):
+    n, L, T = 400, 6, 10
+    lms = scene(L, 51, half=8.0)
+    prm = fs.default_params()
+    prm.first_obs_cov = 2.0
+    prm.nth = n / 1.5
+    f = fs.FastSlam1(n, L, params=prm, seed=5, obs_chunks=1)
+    px, py, pyaw = (np.zeros(n) for _ in range(3))
+    pw = np.full(n, 0.01)
+    lm = np.tile(np.array([0, 0, 1000.0, 0, 0, 1000.0]), (n, L, 1)).reshape(-1).copy()
+    mr = oracle.ref_fs1_model()
+    mr.init_cov = 2.0
+    idx = np.empty(n, np.uint32)
+    mism = 0
+    for t in range(T):
+        z = observations_for(fs, H.true_pose(t + 1), lms, seed=5, step=t)
+        z0, z1 = np.empty(n), np.empty(n)
+        det.det_normal2_v(5, 3, t, 0, n, dp(z0), dp(z1))
+        rho = det.det_resample_rho(5, t)
+        fired = ref.ref_fs1_update(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(lm), 1.0, 0.1, dp(z0), dp(z1), dp(z), len(z),
+                                   C.byref(mr), n / 1.5, rho / n, u32p(idx))
+        f.update([1.0, 0.1], z)
+        assert f.last_resample_fired() == bool(fired)
+        if fired:
+            mism += int(np.count_nonzero(f.last_resample_indices() != idx))
+        if mism == 0:
+            gp, gm = f.get_state()
+            np.testing.assert_allclose(gp, np.column_stack([pw, px, py, pyaw]), **TOL)
+            np.testing.assert_allclose(gm.reshape(-1), lm, **TOL)
+    assert mism == 0
+
+
+def test_reference_shim_and_no_panic(fs):
+    """fastslam1.rs:363-379 through the caller-owned-vector shim"""
+    particles = fs.create_particles(20, 3)
+    landmarks = [(10.0, 0.0), (0.0, 10.0), (10.0, 10.0)]
+    for t in range(5):
+        z = fs.get_observations([0.0, 0.0, 0.0], landmarks, seed=3, step=t)
+        fs.fastslam_update(particles, [1.0, 0.1], z, seed=3)
+    assert len(particles) == 20
+    assert all(math.isfinite(p.x) and math.isfinite(p.weight) for p in particles)
+    best = fs.get_best_particle(particles)
+    assert best.weight == max(p.weight for p in particles)
+    ps = fs.create_particles(5, 3)
+    for p, w in zip(ps, [0.1, 0.5, 0.9, 0.3, 0.2]):
+        p.weight = w
+    assert abs(fs.get_best_particle(ps).weight - 0.9) < np.finfo(float).eps
+
+
+def test_invalid_observation_ids_are_rejected(fs):
+    from rust_robotics_amd.core import RoboticsError
+
+    f = fs.FastSlam1(16, 3)
+    for bad in ([(1.0, 0.0, 3)], [(1.0, 0.0, -1)], [(float("nan"), 0.0, 0)], [(1.0, 0.0, 0.5)]):
+        with pytest.raises(RoboticsError):
+            f.update([1.0, 0.1], bad)
+    f.update([1.0, 0.1], [(1.0, 0.0, 1), (2.0, 0.1, 1)])  # duplicate ids: processed sequentially
+    assert f.counters()[2] == 1
+
+
+def test_config3_size_properties(fs, det):
+    """BASELINE configs[2] shape (1e5 x 200) for a few steps: size-independent properties"""
+    n, L = 100_000, 200
+    lms = scene(L, 61)
+    prm = fs.default_params()
+    prm.first_obs_cov = 0.5
+    prm.nth = n / 1.5
+    f = fs.FastSlam1(n, L, params=prm, seed=8)
+    for t in range(4):
+        z = observations_for(fs, H.true_pose(t + 1, v=0.5), lms, seed=8, step=t)
+        assert len(z) == L
+        f.update([0.5, 0.1], z)
+    poses = f.poses()
+    assert np.all(np.isfinite(poses))
+    assert abs(poses[:, 0].sum() - 1.0) < 1e-9
+    pose, w, i = f.best_particle()
+    assert w == poses[:, 0].max() and i == int(np.nonzero(poses[:, 0] == w)[0][-1])
+    lm_best = f.landmarks_of(i)
+    assert np.all(lm_best[:, 2] < 100.0) and np.all(np.isfinite(lm_best))
+    assert np.median(np.hypot(lm_best[:, 0] - lms[:, 0], lm_best[:, 1] - lms[:, 1])) < 1.5
+    # resample: survivors are exact copies (checked on the pose planes and one landmark column)
+    before = f.poses()
+    lm_before = f.landmarks_of(12345)
+    f.resample_systematic(0.37)
+    idx = f.last_resample_indices()
+    after = f.poses()
+    assert np.all(np.diff(idx.astype(np.int64)) >= 0)
+    assert bits_equal(after[:, 1:], before[idx, 1:]) and np.all(after[:, 0] == 1.0 / n)
+    k = int(np.searchsorted(idx, 12345))
+    if k < n and idx[k] == 12345:
+        assert bits_equal(f.landmarks_of(k), lm_before)

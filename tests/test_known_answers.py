@@ -69,7 +69,7 @@ def test_KA4_fastslam_ekf(ref, det):
     pw = np.array([1.0])
     z = np.array([5.2, 0.05, 0.0])
     zero = np.zeros(1)
-    det.det_fs1_observe(1, dp(zero), dp(zero.copy()), dp(zero.copy()), dp(pw), dp(maps), dp(z), 1, C.byref(md))
+    det.det_fs1_observe(1, dp(zero), dp(zero.copy()), dp(zero.copy()), dp(pw), dp(maps), dp(z), 1, C.byref(md), 1)
     assert close(maps[0], 5.1) and close(maps[1], 0.09900990099009901)
     assert close(maps[2], 0.25) and close(maps[5], 0.30198019801980197)
     assert close(pw[0], 0.6772339004082811)
