@@ -68,13 +68,112 @@ def cpu_baseline(n, L, obs_list, max_seconds=25.0):
                        f"resample), {n} particles x {L} landmarks x {steps} steps, {t_total:.1f} s, noise samples pre-drawn")
 
 
+FS1_BYTES_PER_UPDATE = 96.0  # k_fs1_observe: read 48 B + write 48 B per (particle, observed landmark), EKF branch
+
+
+def fs1_scene(L, seed, half=13.0):
+    rng = np.random.default_rng(seed)
+    return rng.uniform(-half, half, size=(L, 2))
+
+
+def fs1_cpu_baseline(n, L, z_list, max_seconds=20.0):
+    """fastslam_update of the literal C restatement (oracle/ref_literal.c), one host core."""
+    import ctypes as C
+
+    import oracle
+    from oracle import dp, u32p
+
+    ref, det = oracle.ref(), oracle.det()
+    m = oracle.ref_fs1_model()
+    m.init_cov = 0.5
+    px, py, pyaw = (np.zeros(n) for _ in range(3))
+    pw = np.full(n, 0.01)
+    lm = np.tile(np.array([0, 0, 1000.0, 0, 0, 1000.0]), (n, L, 1)).reshape(-1).copy()
+    idx = np.empty(n, np.uint32)
+    z0, z1 = np.empty(n), np.empty(n)
+    steps, t_total, updates = 0, 0.0, 0
+    while steps < len(z_list) and t_total < max_seconds:
+        z = np.ascontiguousarray(z_list[steps])
+        det.det_normal2_v(2, 3, steps, 0, n, dp(z0), dp(z1))
+        t0 = time.perf_counter()
+        ref.ref_fs1_update(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(lm), 0.5, 0.1, dp(z0), dp(z1), dp(z), len(z), C.byref(m),
+                           n / 1.5, 0.3 / n, u32p(idx))
+        t_total += time.perf_counter() - t0
+        updates += n * len(z)
+        steps += 1
+    return dict(value=updates / t_total, unit="particle-landmark updates/s", cores=1, kind="port",
+                sample=f"oracle/ref_literal.c ref_fs1_update (literal fastslam1.rs arithmetic), {n} particles x {L} landmarks x "
+                       f"{steps} steps (first step takes the initialisation branch), {t_total:.1f} s")
+
+
+def run_fastslam(args):
+    """BASELINE.json configs[2]: FastSLAM 1.0, 100 000 particles x 200 landmarks, every landmark observed
+    every step, EKF branch (first_obs_cov = 0.5 initialises the maps on the first, untimed, step),
+    N_eff threshold N/1.5 so that resampling triggers data-dependently."""
+    from rust_robotics_amd.slam import fastslam1 as fs
+    from tests import helpers as H
+
+    n, L, K, W = args.particles, args.landmarks, args.steps, args.warmup
+    lms = fs1_scene(L, 2)
+    prm = fs.default_params()
+    prm.first_obs_cov = 0.5
+    prm.nth = n / 1.5
+    f = fs.FastSlam1(n, L, params=prm, seed=2)
+    zs = [np.array(fs.get_observations(H.true_pose(t + 1, v=0.5), [tuple(p) for p in lms], seed=2, step=t)).reshape(-1, 3)
+          for t in range(K + W)]
+    u = [0.5, 0.1]
+    for t in range(W):
+        f.update_async(u, zs[t])
+    f.synchronize()
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        f.update_async(u, zs[t])
+    f.synchronize()
+    dt = time.perf_counter() - t0
+    updates = float(sum(n * len(zs[t]) for t in range(W, W + K)))
+    f.profile_enable(True)
+    f.profile_reset()
+    fired = 0
+    t1 = time.perf_counter()
+    for t in range(W, W + K):
+        f.update_async(u, zs[t])
+    f.synchronize()
+    dt_i = time.perf_counter() - t1
+    prof = f.profile_read()
+    f.profile_enable(False)
+    pose, w, i = f.best_particle()
+    k_n, k_ms = prof["k_fs1_observe"]
+    avg_s = k_ms / max(k_n, 1) * 1e-3
+    per_launch = FS1_BYTES_PER_UPDATE * n * np.mean([len(zs[t]) for t in range(W, W + K)])
+    achieved = per_launch / avg_s
+    out = {
+        "metric": "particle-landmark updates/sec", "value": updates / dt, "unit": "particle-landmark updates/s", "n_gpus": 1,
+        "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"FastSLAM 1.0 (BASELINE.json configs[2]): {n} particles x {L} landmarks, all observed, 2x2 EKF "
+                               f"branch, N_eff-gated systematic resample", "particles_per_gpu": n, "landmarks": L},
+        "roofline": {"bound": "hbm", "kernel": "k_fs1_observe", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK, "traffic": None, "avg_kernel_ms": avg_s * 1e3,
+                     "algorithmic_bytes_per_launch": per_launch},
+        "kernel_ms_avg": {k: v[1] / max(v[0], 1) for k, v in prof.items() if v[0]},
+        "kernel_launches": {k: v[0] for k, v in prof.items() if v[0]},
+        "ms_per_step_instrumented": dt_i / K * 1e3,
+        "obs_chunks": f.counters()[2],
+        "best_particle": {"index": i, "weight": w, "pose": [float(a) for a in pose]},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = fs1_cpu_baseline(min(n, 2000), L, zs)
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--particles", type=int, default=1_000_000, help="particles PER GPU")
-    ap.add_argument("--landmarks", type=int, default=32)
+    ap.add_argument("--workload", choices=["mcl", "fastslam"], default="mcl")
+    ap.add_argument("--particles", type=int, default=None, help="particles PER GPU (default 1e6 for mcl, 1e5 for fastslam)")
+    ap.add_argument("--landmarks", type=int, default=None, help="default 32 for mcl, 200 for fastslam")
     ap.add_argument("--scheme", choices=["systematic", "multinomial"], default="systematic")
     ap.add_argument("--likelihood", choices=["fused", "product"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -87,6 +186,16 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
+    if args.particles is None:
+        args.particles = 1_000_000 if args.workload == "mcl" else 100_000
+    if args.landmarks is None:
+        args.landmarks = 32 if args.workload == "mcl" else 200
+    if args.workload == "fastslam":
+        if world != 1:
+            raise SystemExit("the FastSLAM leg runs on one GPU (sharded FastSLAM is a next-round row, DESIGN.md)")
+        if args.steps == 200 and args.warmup == 20:
+            args.steps, args.warmup = 50, 5
+        return run_fastslam(args)
     n, L, K, W = args.particles, args.landmarks, args.steps, args.warmup
     obs_list = make_scene(L, K + W, seed=1)
     scheme = 1 if args.scheme == "systematic" else 0

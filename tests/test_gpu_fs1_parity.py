@@ -29,7 +29,7 @@ def bits_equal(a, b):
     return np.array_equal(np.ascontiguousarray(a, dtype=np.float64).view(np.uint64), np.ascontiguousarray(b, dtype=np.float64).view(np.uint64))
 
 
-def scene(L, seed, half=15.0):
+def scene(L, seed, half=13.0):
     rng = np.random.default_rng(seed)
     return rng.uniform(-half, half, size=(L, 2))
 
@@ -96,11 +96,11 @@ def test_predict_with_noise(fs, det, ref, n):
     f.set_state(poses, None)
     f.predict_with_noise([1.0, 0.1], z0, z1)
     got = f.poses()
-    px, py, pyaw = (np.ascontiguousarray(poses[:, k]) for k in (1, 2, 3))
+    px, py, pyaw = (np.array(poses[:, k], dtype=np.float64, order='C', copy=True) for k in (1, 2, 3))
     md = oracle.det_fs1_model()
     det.det_fs1_predict(n, dp(px), dp(py), dp(pyaw), 1.0, 0.1, dp(z0), dp(z1), 0, 0, 0, C.byref(md))
     assert bits_equal(got[:, 1], px) and bits_equal(got[:, 2], py) and bits_equal(got[:, 3], pyaw)
-    rx, ry, ryaw = (np.ascontiguousarray(poses[:, k]) for k in (1, 2, 3))
+    rx, ry, ryaw = (np.array(poses[:, k], dtype=np.float64, order='C', copy=True) for k in (1, 2, 3))
     mr = oracle.ref_fs1_model()
     ref.ref_fs1_predict(n, dp(rx), dp(ry), dp(ryaw), 1.0, 0.1, dp(z0), dp(z1), C.byref(mr))
     np.testing.assert_allclose(got[:, 1:], np.column_stack([rx, ry, ryaw]), rtol=1e-13, atol=1e-14)
@@ -122,14 +122,14 @@ def test_observe_ekf_matches_oracles(fs, det, ref, n, L, chunks):
         assert used == math.ceil(L / math.ceil(L / chunks))
     gp, gm = f.get_state()
     # D-spec (landmark-major planes), same chunking
-    px, py, pyaw, pw = (np.ascontiguousarray(poses[:, k]) for k in (1, 2, 3, 0))
+    px, py, pyaw, pw = (np.array(poses[:, k], dtype=np.float64, order='C', copy=True) for k in (1, 2, 3, 0))
     planes = oracle.maps_aos_to_planes(maps, n, L)
     md = oracle.det_fs1_model()
     det.det_fs1_observe(n, dp(px), dp(py), dp(pyaw), dp(pw), dp(planes), dp(z), len(z), C.byref(md), used)
     assert bits_equal(gp[:, 0], pw), "accumulated weights"
     assert bits_equal(gm.reshape(-1), oracle.maps_planes_to_aos(planes, n, L)), "maps"
     # literal reference: observation outer, particle inner (fastslam1.rs:250-256)
-    rw = np.ascontiguousarray(poses[:, 0])
+    rw = np.array(poses[:, 0], copy=True)
     rm = maps.copy().reshape(-1)
     mr = oracle.ref_fs1_model()
     for k in range(len(z)):
@@ -178,7 +178,7 @@ def test_systematic_resample_and_gather(fs, det, ref):
     f.set_state(poses, maps)
     f.resample_systematic(rho)
     idx = f.last_resample_indices()
-    w = np.ascontiguousarray(poses[:, 0])
+    w = np.array(poses[:, 0], copy=True)
     fx = H.det_fixed(det, w)
     cdf = H.det_cdf(det, w, fx)
     e = np.empty(n, np.uint32)
