@@ -40,6 +40,27 @@
 RR_HD double rr_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 RR_HD double rr_rint(double x) { return __builtin_rint(x); }
 RR_HD double rr_sqrt(double x) { return __builtin_sqrt(x); }
+#if defined(__HIP_DEVICE_COMPILE__)
+/* The core of LLVM's own correctly rounded f64 sqrt lowering for gfx950 -- v_rsq_f64, two
+ * Goldschmidt refinements, two residual corrections -- WITHOUT the 2^256 rescale it wraps around
+ * inputs below 2^-767 and without the 0/inf select.  For 2^-767 <= x < inf the rescale is the
+ * identity, so this returns exactly __builtin_sqrt(x); for x == 0, inf or NaN it returns NaN.
+ * Callers (rr_pf_weight_fused) track the minimum argument and fall back to rr_sqrt when any
+ * argument was outside the range or the result is NaN.  6 fewer VALU instructions per call. */
+__device__ static inline double rr_sqrt_core(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  double g = x * y;
+  double h = 0.5 * y;
+  double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  double d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  d = __builtin_fma(-g, g, x);
+  g = __builtin_fma(d, h, g);
+  return g;
+}
+#endif
 RR_HD double rr_fabs(double x) { return __builtin_fabs(x); }
 
 RR_HD uint64_t rr_d2u(double x) {

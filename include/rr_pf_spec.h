@@ -101,10 +101,30 @@ RR_HD double rr_pf_weight_product(double x, double y, const double* obs, int n_o
  * regime (w < 1e-290) where the running product loses bits first. */
 RR_HD double rr_pf_weight_fused(double x, double y, const double* obs, int n_obs, rr_pf_lik k) {
   double ss = 0.0;
+#if defined(__HIP_DEVICE_COMPILE__)
+  /* branch-free inner loop on the sqrt core; one range check per particle afterwards */
+  double qmin = 0x1p+1000;
+  for (int l = 0; l < n_obs; ++l) {
+    double dx = x - obs[3 * l + 1];
+    double dy = y - obs[3 * l + 2];
+    double q = rr_fma(dy, dy, dx * dx);
+    qmin = q < qmin ? q : qmin;
+    double diff = obs[3 * l] - rr_sqrt_core(q);
+    ss = rr_fma(diff, diff, ss);
+  }
+  if (!(qmin >= 0x1p-767) || ss != ss) { /* some q was 0, tiny, inf or NaN: exact slow path */
+    ss = 0.0;
+    for (int l = 0; l < n_obs; ++l) {
+      double diff = rr_pf_residual(x, y, obs[3 * l], obs[3 * l + 1], obs[3 * l + 2]);
+      ss = rr_fma(diff, diff, ss);
+    }
+  }
+#else
   for (int l = 0; l < n_obs; ++l) {
     double diff = rr_pf_residual(x, y, obs[3 * l], obs[3 * l + 1], obs[3 * l + 2]);
     ss = rr_fma(diff, diff, ss);
   }
+#endif
   return rr_exp(rr_fma(-ss, k.inv_two_s2, (double)n_obs * k.log_coeff));
 }
 
@@ -212,6 +232,63 @@ RR_HD uint64_t rr_sys_target(rr_sys_plan p, uint64_t i) {
   uint64_t t = i * p.rem + p.offs; /* < n^2 + 2^63 <= 2^64 for n < 2^31 */
   uint64_t r = i * p.q + (t + p.n - 1) / p.n;
   return r ? r : 1; /* position 0 selects the first particle of non-zero weight */
+}
+
+/* Number of output slots i in [0, n) whose target rr_sys_target(p, i) is <= c, for a CDF value
+ * c <= T: the inverse of the target map, used to turn "which source does slot i copy" into
+ * "which slots does source j feed": source j with inclusive CDF C_j and predecessor C_{j-1}
+ * feeds exactly the slots [slots_upto(C_{j-1}), slots_upto(C_j)).
+ *   target_i <= c  <=>  i*T + offs <= c*n  (and c >= 1 because targets are clamped to >= 1)
+ *   count = floor((c*n - offs) / T) + 1, capped at n.
+ * The 128-by-64 division is done as a double estimate corrected with exact 128-bit products, so
+ * the same code runs on the host and on gfx950 (no __udivti3 on the device). */
+#if defined(__HIPCC__)
+#define RR_HD_NOINLINE __host__ __device__ __attribute__((noinline)) static
+#else
+#define RR_HD_NOINLINE static __attribute__((noinline, unused))
+#endif
+RR_HD_NOINLINE uint64_t rr_sys_slots_upto_exact(rr_sys_plan p, uint64_t total, uint64_t c) {
+  if (c == 0 || total == 0) return 0;
+  unsigned __int128 a = (unsigned __int128)c * p.n;
+  if (a < p.offs) return 0;
+  unsigned __int128 d = a - p.offs;
+  double dd = (double)(uint64_t)(d >> 64) * 0x1p64 + (double)(uint64_t)d;
+  double est = dd / (double)total;
+  uint64_t q = est >= 0x1p63 ? ~(uint64_t)0 >> 1 : (uint64_t)est;
+  if (q > p.n) q = p.n; /* the count is capped at n anyway; keeps q*total inside 128 bits */
+  while ((unsigned __int128)q * total > d) --q;
+  while (q < p.n && (unsigned __int128)(q + 1) * total <= d) ++q;
+  uint64_t cnt = q + 1;
+  return cnt < p.n ? cnt : p.n;
+}
+
+/* Fast path of the same integer function: x = (c*n - offs)/T evaluated in doubles is within
+ * 2^-50 * n of the exact quotient, so floor(x) is the exact integer whenever x is at least
+ * `guard` away from the neighbouring integers; only then is the cheap answer taken, otherwise
+ * the exact 128-bit evaluation decides.  Identical results by construction. */
+typedef struct rr_sys_inv {
+  double n, offs, inv_total, guard;
+} rr_sys_inv;
+
+RR_HD rr_sys_inv rr_sys_inv_make(rr_sys_plan p, uint64_t total) {
+  rr_sys_inv v;
+  v.n = (double)p.n;
+  v.offs = (double)p.offs;
+  v.inv_total = total ? 1.0 / (double)total : 0.0;
+  v.guard = 0x1p-48 * (double)p.n + 0x1p-30; /* >> accumulated rounding error of the 4 operations */
+  return v;
+}
+
+RR_HD uint64_t rr_sys_slots_upto(rr_sys_plan p, rr_sys_inv v, uint64_t total, uint64_t c) {
+  if (c == 0 || total == 0) return 0;
+  double x = rr_fma((double)c, v.n, -v.offs) * v.inv_total; /* ~ (c*n - offs)/T */
+  double f = __builtin_floor(x);
+  double frac = x - f;
+  if (x >= 0.0 && frac > v.guard && frac < 1.0 - v.guard && x < 0x1p52) {
+    uint64_t cnt = (uint64_t)f + 1;
+    return cnt < p.n ? cnt : p.n;
+  }
+  return rr_sys_slots_upto_exact(p, total, c);
 }
 
 /* first i in [0,n) with c[i] >= target (c inclusive, non-decreasing); n-1 if none */

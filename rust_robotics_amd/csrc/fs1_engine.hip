@@ -17,7 +17,6 @@
 //   k_fs1_normalize    w /= sum when the gate did not fire
 //   k_fs1_indices      CDF search per output slot
 //   k_fs1_gather       out[plane][k] = in[plane][idx[k]] over 3 + 6L planes  16 B / element
-//   k_commit           flip the live buffer
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -176,9 +175,9 @@ __global__ __launch_bounds__(kBlock) void k_fs1_gather(Planes pl, const Ctl* __r
   if (!ctl->fired) return;
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= n) return;
-  const int cur = ctl->cur;
-  const double* __restrict__ in = pl.s[cur];
-  double* __restrict__ out = pl.s[cur ^ 1];
+  const int cur = ctl->cur;  // the plan kernel already flipped it: read the old set, write the live one
+  const double* __restrict__ in = pl.s[cur ^ 1];
+  double* __restrict__ out = pl.s[cur];
   const uint64_t j = idx[k];
   const uint64_t p0 = (uint64_t)blockIdx.y * kPlanesPerThread;
   double v[kPlanesPerThread];
@@ -188,10 +187,6 @@ __global__ __launch_bounds__(kBlock) void k_fs1_gather(Planes pl, const Ctl* __r
 #pragma unroll
   for (int q = 0; q < kPlanesPerThread; ++q)
     if (p0 + q < n_planes) out[(p0 + q) * n + k] = v[q];
-}
-
-__global__ void k_fs1_commit(Ctl* ctl) {
-  if (ctl->fired) ctl->cur ^= 1;
 }
 
 // arg max of the weight with ties -> highest index (fastslam1.rs:269-274, Q14): the key
@@ -331,6 +326,7 @@ struct rr_fs1 {
   Ctl* ctl_host = nullptr;
   unsigned int step = 0, rstep = 0;
   int last_chunks = 1;
+  bool wmax_live = false;  // Ctl.wmax_bits holds the maximum of the current weights
   rr::Profiler prof{RR_FK_COUNT};
 };
 
@@ -338,7 +334,7 @@ namespace {
 
 const char* kFkNames[RR_FK_COUNT] = {"k_fs1_predict", "k_fs1_observe", "k_fs1_combine", "k_quantize_reduce",
                                      "k_scan_tiles",  "k_fs1_normalize", "k_cdf",        "k_fs1_indices",
-                                     "k_fs1_gather",  "k_fs1_commit"};
+                                     "k_fs1_gather",  "(unused)"};
 
 inline unsigned grid_for(uint64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
@@ -403,6 +399,8 @@ PlanArgs plan_args(const rr_fs1* h, int mode, double rho_override) {
   a.rho_override = rho_override;
   a.seed = h->opt.seed;
   a.rstep = h->rstep;
+  a.set_uniform_on_fire = 0;  // FastSLAM stores explicit weights (k_fs1_indices writes 1/n)
+  a.lazy_gather = 0;
   return a;
 }
 
@@ -435,6 +433,7 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup) {
     RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
     hipLaunchKernelGGL(k_fs1_wmax, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
     h->last_chunks = 1;
+    h->wmax_live = true;
     return RR_OK;
   }
   if (n_z > h->z_cap) {
@@ -446,6 +445,7 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup) {
   }
   RR_HIP_TRY(hipMemcpyAsync(h->z_dev, z, 3 * n_z * sizeof(double), hipMemcpyHostToDevice, h->stream));
   RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+  h->wmax_live = true;
   const int chunks = choose_chunks(h, n_z, dup);
   const int len = (int)((n_z + chunks - 1) / chunks);
   h->last_chunks = chunks;
@@ -465,10 +465,15 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup) {
 }
 
 rr_status launch_sums(rr_fs1* h, int mode, double rho_override) {
+  if (!h->wmax_live) {  // the last plan kernel consumed the maximum (or the weights were renormalised since)
+    RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+    hipLaunchKernelGGL(k_fs1_wmax, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
+  }
+  h->wmax_live = mode == 2;  // statistics leave everything in place; a real plan consumes it
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_QUANTIZE_REDUCE);
-    hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->pw, h->ctl,
-                       (const double*)&h->ctl->wmax_bits, image_args(h), h->tile_total, h->tile_q2);
+    hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
+                       (const double*)&h->ctl->wmax_bits, image_args(h), h->tile_total, h->tile_q2, 0);
   }
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_SCAN_TILES);
@@ -483,7 +488,7 @@ rr_status launch_sums(rr_fs1* h, int mode, double rho_override) {
 rr_status launch_finish(rr_fs1* h) {
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_CDF);
-    hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->pw, h->ctl, image_args(h),
+    hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl, image_args(h),
                        h->tile_total, h->cdf);
   }
   {
@@ -499,10 +504,6 @@ rr_status launch_finish(rr_fs1* h) {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_GATHER);
     hipLaunchKernelGGL(k_fs1_gather, dim3(grid_for(h->n, kBlock), grid_for(h->n_planes, kPlanesPerThread)), dim3(kBlock), 0,
                        h->stream, h->pl, h->ctl, h->idx, h->n, h->n_planes);
-  }
-  {
-    rr::ScopedTimer t(h->prof, h->stream, RR_FK_COMMIT);
-    hipLaunchKernelGGL(k_fs1_commit, dim3(1), dim3(1), 0, h->stream, h->ctl);
   }
   RR_HIP_TRY(hipGetLastError());
   h->rstep += 1;
@@ -786,6 +787,7 @@ rr_status rr_fs1_set_state(rr_fs1* h, const double* poses, const double* maps) {
   hipLaunchKernelGGL(k_fs1_wmax, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
   RR_HIP_TRY(hipGetLastError());
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  h->wmax_live = true;
   return RR_OK;
 }
 

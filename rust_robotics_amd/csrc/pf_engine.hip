@@ -15,11 +15,11 @@
 //   k_scan_tiles         tile totals -> exclusive offsets, gate decision (single block)
 //   k_cdf                w -> inclusive integer CDF                     16 B / particle
 //   k_resample_gather    CDF search + SoA gather into the other buffer  ~72 B / particle
-//   k_commit             flip the live buffer
 //   k_moments(+final)    weighted first/second moments about particle 0 40 B / particle
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -96,13 +96,32 @@ __global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __r
     __syncthreads();
   }
   const int cur = ctl->cur;
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + tid;
-  double wgt = 0.0;
+  double* __restrict__ bx = b.x[cur];
+  double* __restrict__ by = b.y[cur];
+  double* __restrict__ byaw = b.yaw[cur];
+  double* __restrict__ bv = b.v[cur];
+  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
+  uint64_t i = (uint64_t)blockIdx.x * kBlock + tid;
+  double wmax_local = 0.0;
+  // grid-stride over the particles with the next particle's state prefetched while the current
+  // one is being computed (the kernel is FP64-VALU bound; this keeps its HBM reads off the
+  // critical path)
+  double x = 0.0, y = 0.0, yaw = 0.0;
   if (i < p.n) {
-    double x = b.x[cur][i], y = b.y[cur][i];
+    x = bx[i];
+    y = by[i];
+    if (PREDICT) yaw = byaw[i];
+  }
+  while (i < p.n) {
+    const uint64_t inext = i + stride;
+    double nx = 0.0, ny = 0.0, nyaw = 0.0;
+    if (inext < p.n) {
+      nx = bx[inext];
+      ny = by[inext];
+      if (PREDICT) nyaw = byaw[inext];
+    }
     if (PREDICT) {
-      double yaw = b.yaw[cur][i], v;
-      double a, c;
+      double v, a, c;
       if (EXPLICIT_NOISE) {
         a = nv[i];
         c = nw[i];
@@ -110,20 +129,24 @@ __global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __r
         rr_pf_motion_noise(p.seed, p.step, p.first_gid + i, p.sigma_v, p.sigma_w, &a, &c);
       }
       rr_pf_propagate_one(&x, &y, &yaw, &v, p.u0, p.u1, p.dt, a, c);
-      b.x[cur][i] = x;
-      b.y[cur][i] = y;
-      b.yaw[cur][i] = yaw;
-      b.v[cur][i] = v;
+      bx[i] = x;
+      by[i] = y;
+      byaw[i] = yaw;
+      bv[i] = v;
     }
     if (WEIGHT) {
-      wgt = p.lik_mode == RR_LIK_PRODUCT ? rr_pf_weight_product(x, y, s_obs, p.n_obs, p.lik)
-                                         : rr_pf_weight_fused(x, y, s_obs, p.n_obs, p.lik);
+      const double wgt = p.lik_mode == RR_LIK_PRODUCT ? rr_pf_weight_product(x, y, s_obs, p.n_obs, p.lik)
+                                                      : rr_pf_weight_fused(x, y, s_obs, p.n_obs, p.lik);
       w[i] = wgt;
+      if (wgt > wmax_local) wmax_local = wgt;  // NaN and negatives drop out
     }
+    i = inext;
+    x = nx;
+    y = ny;
+    yaw = nyaw;
   }
   if (WEIGHT) {
-    double m = wgt > 0.0 ? wgt : 0.0;  // NaN and negatives drop out
-    m = rr::wave_max(m);
+    double m = rr::wave_max(wmax_local);
     if ((tid & 63) == 0) s_wmax[tid >> 6] = m;
     __syncthreads();
     if (tid == 0) {
@@ -136,8 +159,87 @@ __global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __r
 }
 
 // ------------------------------------------------------------------------------------------
-// K5: one thread per output slot: CDF target (multinomial draw or systematic position), lower
-// bound in the integer CDF, SoA gather from the live buffer set into the other one.
+// K1 of the fused step (rr_pf_step_async, systematic resampling): propagate + weight with the
+// previous step's resample gather folded into its loads.  If Ctl.pending is set the last plan
+// kernel left markers instead of moved particles: each workgroup resolves the markers of its
+// 512-slot tiles to source indices (running maximum, rr::resolve_tile) and reads x,y,yaw of slot k
+// from particle idx[k] of the live buffer set, writing the propagated particle to slot k of the
+// OTHER set; k_quantize_reduce (next in the stream) then flips Ctl.cur.  Without a pending
+// resample it runs in place.  This removes a whole 72 B/particle pass over HBM per step.
+template <bool OBS_KERNARG>
+__global__ __launch_bounds__(kBlock) void k_step_lazy(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
+                                                     StepParams p, ObsArg obs_arg,
+                                                     const double* __restrict__ obs_dev,
+                                                     unsigned int* __restrict__ markers,
+                                                     const unsigned int* __restrict__ carry,
+                                                     unsigned int* __restrict__ idx_out) {
+  extern __shared__ double s_obs[];
+  __shared__ double s_wmax[kBlock / rr::kWave];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 3 * p.n_obs; i += kBlock) s_obs[i] = OBS_KERNARG ? obs_arg.v[i] : obs_dev[i];
+  __syncthreads();
+  const int pending = ctl->pending;
+  const int src = ctl->cur, dst = pending ? src ^ 1 : src;
+  const double* __restrict__ sx = b.x[src];
+  const double* __restrict__ sy = b.y[src];
+  const double* __restrict__ syaw = b.yaw[src];
+  const uint64_t n_tiles = (p.n + rr::kResolveSlots - 1) / rr::kResolveSlots;
+  double wmax_local = 0.0;
+  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    unsigned int idx[rr::kResolveRows];
+    const uint64_t tile_base = tile * rr::kResolveSlots;
+    if (pending) {
+      rr::resolve_tile(markers, carry, p.n, tile, idx);
+    } else {
+#pragma unroll
+      for (int r = 0; r < rr::kResolveRows; ++r) idx[r] = (unsigned int)(tile_base + (uint64_t)r * kBlock + tid);
+    }
+    // issue every row's loads before the (long) arithmetic of the first row
+    double x[rr::kResolveRows], y[rr::kResolveRows], yaw[rr::kResolveRows];
+#pragma unroll
+    for (int r = 0; r < rr::kResolveRows; ++r) {
+      const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
+      x[r] = y[r] = yaw[r] = 0.0;
+      if (k < p.n) {
+        const uint64_t j = idx[r];
+        x[r] = sx[j];
+        y[r] = sy[j];
+        yaw[r] = syaw[j];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < rr::kResolveRows; ++r) {
+      const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
+      if (k < p.n) {
+        double v, a, c;
+        rr_pf_motion_noise(p.seed, p.step, p.first_gid + k, p.sigma_v, p.sigma_w, &a, &c);
+        rr_pf_propagate_one(&x[r], &y[r], &yaw[r], &v, p.u0, p.u1, p.dt, a, c);
+        b.x[dst][k] = x[r];
+        b.y[dst][k] = y[r];
+        b.yaw[dst][k] = yaw[r];
+        b.v[dst][k] = v;
+        const double wgt = p.lik_mode == RR_LIK_PRODUCT ? rr_pf_weight_product(x[r], y[r], s_obs, p.n_obs, p.lik)
+                                                        : rr_pf_weight_fused(x[r], y[r], s_obs, p.n_obs, p.lik);
+        w[k] = wgt;
+        if (wgt > wmax_local) wmax_local = wgt;
+        if (pending && idx_out) idx_out[k] = idx[r];
+      }
+    }
+  }
+  double m = rr::wave_max(wmax_local);
+  if ((tid & 63) == 0) s_wmax[tid >> 6] = m;
+  __syncthreads();
+  if (tid == 0) {
+    double bm = s_wmax[0];
+    for (int k = 1; k < kBlock / rr::kWave; ++k) bm = s_wmax[k] > bm ? s_wmax[k] : bm;
+    if (bm > 0.0) rr::atomic_max_u64(&ctl->wmax_bits, rr_d2u(bm));
+    if (blockIdx.x == 0) ctl->weights_uniform = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5: resample gather.  The plan kernel has already flipped Ctl.cur, so the particles are read
+// from buffer set cur^1 and written to set cur (or to `staging` for the sharded exchange).
 struct GatherArgs {
   uint64_t n_src;       // CDF entries (particles of this shard)
   uint64_t first_slot;  // global index of output slot 0 handled here
@@ -145,56 +247,87 @@ struct GatherArgs {
   uint64_t seed;
   unsigned int rstep;
   int scheme;
-  int to_staging;  // 1 => write the gathered particles to `staging` (sharded exchange) instead of the other buffer set
+  int to_staging;  // 1 => write n_slots x (x, y, yaw, v) records to `staging`
 };
 
-__global__ __launch_bounds__(kBlock) void k_resample_gather(Bufs b, const Ctl* __restrict__ ctl,
-                                                           const uint64_t* __restrict__ cdf,
-                                                           const double* __restrict__ r_explicit,
-                                                           unsigned int* __restrict__ idx_out,
-                                                           double* __restrict__ staging, GatherArgs a) {
-  if (!ctl->fired) return;
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= a.n_slots) return;
-  const int cur = ctl->cur;
-  const uint64_t slot = a.first_slot + k;
-  const uint64_t target = rr::resample_target(ctl, a.scheme, slot, a.seed, a.rstep, r_explicit, k);
-  const uint64_t j = rr_lower_bound_u64(cdf, a.n_src, target);
-  const double x = b.x[cur][j], y = b.y[cur][j], yaw = b.yaw[cur][j], v = b.v[cur][j];
-  if (a.to_staging) {  // n_slots x (x, y, yaw, v): one contiguous 32-byte record per slot
+__device__ inline void copy_particle(const Bufs& b, int src, int dst, uint64_t j, uint64_t k, bool to_staging,
+                                     double* __restrict__ staging) {
+  const double x = b.x[src][j], y = b.y[src][j], yaw = b.yaw[src][j], v = b.v[src][j];
+  if (to_staging) {  // one contiguous 32-byte record per slot
     staging[4 * k] = x;
     staging[4 * k + 1] = y;
     staging[4 * k + 2] = yaw;
     staging[4 * k + 3] = v;
   } else {
-    const int nxt = cur ^ 1;
-    b.x[nxt][k] = x;
-    b.y[nxt][k] = y;
-    b.yaw[nxt][k] = yaw;
-    b.v[nxt][k] = v;
+    b.x[dst][k] = x;
+    b.y[dst][k] = y;
+    b.yaw[dst][k] = yaw;
+    b.v[dst][k] = v;
   }
+}
+
+// Systematic (fastslam1.rs:219-231): the plan kernel left one marker per source with offspring
+// (resample_core.hpp "WITHOUT any search"); resolve them to source indices with a running maximum
+// per 1024-slot tile and move the particles in the same pass.  Reads 4 B marker + 32 B particle,
+// writes 32 B particle (+ 4 B marker clear) per slot; no CDF array, no binary search.
+__global__ __launch_bounds__(kBlock) void k_resolve_gather(Bufs b, const Ctl* __restrict__ ctl,
+                                                          unsigned int* __restrict__ markers,
+                                                          const unsigned int* __restrict__ carry,
+                                                          unsigned int* __restrict__ idx_out,
+                                                          double* __restrict__ staging, uint64_t n_slots,
+                                                          int to_staging, int lazy) {
+  // eager: the plan kernel flipped Ctl.cur already (read cur^1, write cur), runs iff fired;
+  // lazy (materialise a pending resample for an accessor): read cur, write cur^1, k_settle flips
+  if (lazy ? !ctl->pending : !ctl->fired) return;
+  unsigned int idx[rr::kResolveRows];
+  rr::resolve_tile(markers, carry, n_slots, blockIdx.x, idx);
+  const int dst = lazy ? ctl->cur ^ 1 : ctl->cur, src = dst ^ 1;
+  const uint64_t tile_base = (uint64_t)blockIdx.x * rr::kResolveSlots;
+#pragma unroll
+  for (int r = 0; r < rr::kResolveRows; ++r) {
+    const uint64_t k = tile_base + (uint64_t)r * kBlock + threadIdx.x;
+    if (k < n_slots) {
+      copy_particle(b, src, dst, idx[r], k, to_staging != 0, staging);
+      if (idx_out) idx_out[k] = idx[r];
+    }
+  }
+}
+
+__global__ void k_settle(Ctl* ctl) {
+  if (ctl->pending) {
+    ctl->cur ^= 1;
+    ctl->pending = 0;
+  }
+}
+
+// Multinomial (particle_filter.rs:455-470): independent draws, one thread per output slot,
+// lower bound over the whole CDF.
+__global__ __launch_bounds__(kBlock) void k_resample_gather_mn(Bufs b, const Ctl* __restrict__ ctl,
+                                                              const uint64_t* __restrict__ cdf,
+                                                              const double* __restrict__ r_explicit,
+                                                              unsigned int* __restrict__ idx_out, GatherArgs a) {
+  if (!ctl->fired) return;
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= a.n_slots) return;
+  const int dst = ctl->cur, src = dst ^ 1;
+  const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, a.first_slot + k, a.seed, a.rstep, r_explicit, k);
+  const uint64_t j = rr_lower_bound_u64(cdf, a.n_src, target);
+  copy_particle(b, src, dst, j, k, false, nullptr);
   if (idx_out) idx_out[k] = (unsigned int)j;
 }
 
-// K6: publish the resampled set (particle_filter.rs:467-472: w = 1/N for every particle)
-__global__ void k_commit(Ctl* ctl) {
-  if (ctl->fired) {
-    ctl->cur ^= 1;
-    ctl->weights_uniform = 1;
-  }
-}
-
-// sharded adopt: unpack the received n x (x, y, yaw, v) records into the other buffer set; k_commit follows
+// sharded adopt: unpack the received n x (x, y, yaw, v) records into the live buffer set (the
+// plan kernel already made it the other one)
 __global__ __launch_bounds__(kBlock) void k_adopt(Bufs b, const Ctl* __restrict__ ctl,
                                                  const double* __restrict__ in, uint64_t n) {
   if (!ctl->fired) return;
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= n) return;
-  const int nxt = ctl->cur ^ 1;
-  b.x[nxt][k] = in[4 * k];
-  b.y[nxt][k] = in[4 * k + 1];
-  b.yaw[nxt][k] = in[4 * k + 2];
-  b.v[nxt][k] = in[4 * k + 3];
+  const int dst = ctl->cur;
+  b.x[dst][k] = in[4 * k];
+  b.y[dst][k] = in[4 * k + 1];
+  b.yaw[dst][k] = in[4 * k + 2];
+  b.v[dst][k] = in[4 * k + 3];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -332,6 +465,8 @@ struct rr_pf {
   uint64_t* tile_total = nullptr;
   uint64_t* tile_q2 = nullptr;
   unsigned int* idx = nullptr;
+  unsigned int* markers = nullptr;  // n_global + kResolveSlots, zero between steps
+  unsigned int* carry = nullptr;    // one per kResolveSlots slots
   double* partials = nullptr;
   double* scratch_a = nullptr;  // n doubles: explicit noise v / uniforms / AoS staging (5n)
   double* scratch_b = nullptr;  // n doubles: explicit noise w
@@ -341,6 +476,10 @@ struct rr_pf {
   Ctl* ctl_host = nullptr;  // pinned
   uint64_t n_tiles = 0;
   unsigned int step = 0, rstep = 0;
+  int k1_blocks_per_cu = 8;
+  bool wmax_live = false;        // Ctl.wmax_bits holds the maximum of the current raw weights
+  bool wmax_bits_clean = false;  // Ctl.wmax_bits is known to be zero
+  bool maybe_pending = false;    // a lazy resample plan was launched and nothing has consumed its markers yet
   rr_pf_lik lik{};
   std::vector<double> landmarks;
   // profiling
@@ -465,10 +604,17 @@ rr_status stage_obs(rr_pf* h, const double* obs, size_t n_obs, ObsArg* arg, bool
 
 template <bool PREDICT, bool WEIGHT, bool EXPLICIT>
 rr_status launch_pw(rr_pf* h, const StepParams& p, const ObsArg& arg, bool kernarg) {
-  const unsigned grid = grid_for(h->n, kBlock);
+  // grid-stride kernel: at most k1_blocks_per_cu workgroups per CU (256 CUs)
+  const unsigned grid = std::min<unsigned>(grid_for(h->n, kBlock), (unsigned)(256 * h->k1_blocks_per_cu));
   const size_t lds = WEIGHT ? 3 * (size_t)p.n_obs * sizeof(double) : 0;
   if (lds > 150 * 1024) return fail(RR_INVALID_PARAMETER, "too many observations for one LDS block (max 6400)");
-  if (WEIGHT) RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+  if (WEIGHT) {
+    // Ctl.wmax_bits must be zero before the weights' maximum is accumulated; the plan kernel of
+    // the previous resample pipeline leaves it zeroed, anything else needs the memset
+    if (!h->wmax_bits_clean) RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+    h->wmax_bits_clean = false;
+    h->wmax_live = true;
+  }
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
     if (kernarg)
@@ -503,16 +649,40 @@ PlanArgs plan_args(const rr_pf* h, int mode, int scheme, double rho_override) {
   a.rho_override = rho_override;
   a.seed = h->opt.seed;
   a.rstep = h->rstep;
+  a.set_uniform_on_fire = 1;
+  a.lazy_gather = 0;
   return a;
 }
 
-// quantize-reduce + tile scan (+ gate).  mode as rr::finalize_plan.
-rr_status launch_sums(rr_pf* h, int mode, int scheme, double rho_override) {
+// where the maximum to scale by lives: the atomic accumulator after a weight kernel, the
+// plan kernel's saved copy once a resample pipeline has consumed (and zeroed) it
+const double* wmax_source(const rr_pf* h) {
+  return h->wmax_live ? (const double*)&h->ctl->wmax_bits : (const double*)&h->ctl->wmax;
+}
+
+void launch_quantize(rr_pf* h, const double* wmax_src, int settle = 0) {
+  Timed t(h, RR_K_QUANTIZE_REDUCE);
+  hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl,
+                     wmax_src, image_args(h), h->tile_total, h->tile_q2, settle);
+}
+
+// make a pending lazy resample real (accessors and the non-fused entry points call this first)
+rr_status materialise(rr_pf* h) {
+  if (!h->maybe_pending) return RR_OK;
   {
-    Timed t(h, RR_K_QUANTIZE_REDUCE);
-    hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->w, h->ctl,
-                       (const double*)&h->ctl->wmax_bits, image_args(h), h->tile_total, h->tile_q2);
+    Timed t(h, RR_K_RESAMPLE_GATHER);
+    hipLaunchKernelGGL(k_resolve_gather, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b,
+                       h->ctl, h->markers, h->carry, h->idx, (double*)nullptr, h->n, 0, 1);
+    hipLaunchKernelGGL(k_settle, dim3(1), dim3(1), 0, h->stream, h->ctl);
   }
+  RR_HIP_TRY(hipGetLastError());
+  h->maybe_pending = false;
+  return RR_OK;
+}
+
+// statistics only (accessors): integer sums into Ctl, no gate decision, nothing consumed
+rr_status launch_sums(rr_pf* h, int mode, int scheme, double rho_override) {
+  launch_quantize(h, wmax_source(h));
   {
     Timed t(h, RR_K_SCAN_TILES);
     hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl,
@@ -522,30 +692,57 @@ rr_status launch_sums(rr_pf* h, int mode, int scheme, double rho_override) {
   return RR_OK;
 }
 
-// the resample pipeline after the sums: CDF, gather, commit (all no-ops on the device if the
-// gate did not fire)
-rr_status launch_resample(rr_pf* h, int scheme, const double* r_explicit_dev) {
+// The resample pipeline: integer image -> plan (gate) + CDF -> gather.  Every kernel after the
+// plan decides on the device whether it has anything to do.  mode 0 = gate, 1 = forced.
+rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, const double* r_explicit_dev,
+                          bool lazy = false, int settle = 0) {
+  launch_quantize(h, wmax_source(h), settle);
+  PlanArgs pa = plan_args(h, mode, scheme, rho_override);
+  lazy = lazy && scheme == RR_RESAMPLE_SYSTEMATIC;
+  pa.lazy_gather = lazy ? 1 : 0;
+  const bool fused = h->n_tiles <= (uint64_t)rr::kFusedMaxTiles;
+  const bool sys = scheme == RR_RESAMPLE_SYSTEMATIC;
+  if (!fused) {
+    Timed t(h, RR_K_SCAN_TILES);
+    hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl,
+                       h->n_tiles, 1, pa, (uint64_t*)nullptr);
+  }
   {
     Timed t(h, RR_K_CDF);
-    hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->w, h->ctl, image_args(h),
-                       h->tile_total, h->cdf);
+    const dim3 grid((unsigned)h->n_tiles), block(rr::kTileBlock);
+    if (sys && fused)
+      hipLaunchKernelGGL(rr::k_plan_mark, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total,
+                         h->tile_q2, h->n_tiles, pa, h->markers, h->carry);
+    else if (sys)
+      hipLaunchKernelGGL(rr::k_mark, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total, h->markers,
+                         h->carry);
+    else if (fused)
+      hipLaunchKernelGGL(rr::k_plan_cdf, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total,
+                         h->tile_q2, h->n_tiles, pa, h->cdf);
+    else
+      hipLaunchKernelGGL(rr::k_cdf, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total, h->cdf);
   }
-  GatherArgs g{};
-  g.n_src = h->n;
-  g.first_slot = 0;
-  g.n_slots = h->n;
-  g.seed = h->opt.seed;
-  g.rstep = h->rstep;
-  g.scheme = scheme;
-  g.to_staging = 0;
-  {
+  h->wmax_live = false;       // consumed: Ctl.wmax holds the value from now on
+  h->wmax_bits_clean = true;  // the plan kernel zeroed the accumulator
+  if (lazy) {
+    h->maybe_pending = true;  // the next k_step_lazy (or materialise) moves the particles
+  } else {
     Timed t(h, RR_K_RESAMPLE_GATHER);
-    hipLaunchKernelGGL(k_resample_gather, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl,
-                       h->cdf, r_explicit_dev, h->idx, (double*)nullptr, g);
-  }
-  {
-    Timed t(h, RR_K_COMMIT);
-    hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, h->stream, h->ctl);
+    if (sys) {
+      hipLaunchKernelGGL(k_resolve_gather, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b,
+                         h->ctl, h->markers, h->carry, h->idx, (double*)nullptr, h->n, 0, 0);
+    } else {
+      GatherArgs g{};
+      g.n_src = h->n;
+      g.first_slot = 0;
+      g.n_slots = h->n;
+      g.seed = h->opt.seed;
+      g.rstep = h->rstep;
+      g.scheme = scheme;
+      g.to_staging = 0;
+      hipLaunchKernelGGL(k_resample_gather_mn, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl,
+                         h->cdf, r_explicit_dev, h->idx, g);
+    }
   }
   RR_HIP_TRY(hipGetLastError());
   h->rstep += 1;
@@ -637,6 +834,10 @@ rr_status create_common(const rr_pf_config* cfg, const rr_pf_options* opt_in, co
   h->n_global = n_global;
   h->n_tiles = (h->n + kTile - 1) / kTile;
   h->lik = rr_pf_lik_make(cfg->range_noise);
+  if (const char* e = std::getenv("RR_K1_BLOCKS_PER_CU")) {
+    const int v = std::atoi(e);
+    if (v >= 1 && v <= 64) h->k1_blocks_per_cu = v;
+  }
   auto cleanup = [&](rr_status st) {
     rr_pf_destroy(h);
     return st;
@@ -661,6 +862,12 @@ rr_status create_common(const rr_pf_config* cfg, const rr_pf_options* opt_in, co
   RR_TRY_OR_CLEAN(hipMalloc(&h->tile_total, h->n_tiles * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->tile_q2, 2 * h->n_tiles * sizeof(uint64_t)));
   if (opt.record_indices) RR_TRY_OR_CLEAN(hipMalloc(&h->idx, h->n * sizeof(unsigned int)));
+  {
+    const size_t nm = (size_t)n_global + rr::kResolveSlots;
+    RR_TRY_OR_CLEAN(hipMalloc(&h->markers, nm * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(hipMemset(h->markers, 0, nm * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(hipMalloc(&h->carry, (nm / rr::kResolveSlots + 2) * sizeof(unsigned int)));
+  }
   RR_TRY_OR_CLEAN(hipMalloc(&h->partials, (size_t)kMomentBlocks * kNumMoments * sizeof(double)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->ctl, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipHostMalloc(&h->ctl_host, sizeof(Ctl)));
@@ -761,6 +968,8 @@ void rr_pf_destroy(rr_pf* h) {
   (void)hipFree(h->tile_total);
   (void)hipFree(h->tile_q2);
   (void)hipFree(h->idx);
+  (void)hipFree(h->markers);
+  (void)hipFree(h->carry);
   (void)hipFree(h->partials);
   (void)hipFree(h->scratch_a);
   (void)hipFree(h->scratch_b);
@@ -808,6 +1017,7 @@ rr_status rr_pf_set_range_noise(rr_pf* h, double range_noise) {
 rr_status rr_pf_predict(rr_pf* h, const double control[2]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if ((s = validate_control(control)) != RR_OK) return s;
   StepParams p = make_params(h, control, 0);
   ObsArg arg;
@@ -819,6 +1029,7 @@ rr_status rr_pf_predict(rr_pf* h, const double control[2]) {
 rr_status rr_pf_predict_with_noise(rr_pf* h, const double control[2], const double* n_v, const double* n_w) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if ((s = validate_control(control)) != RR_OK) return s;
   if (!n_v || !n_w) return fail(RR_INVALID_PARAMETER, "null noise arrays");
   if ((s = ensure_scratch(h, h->n, h->n)) != RR_OK) return s;
@@ -834,6 +1045,7 @@ rr_status rr_pf_predict_with_noise(rr_pf* h, const double control[2], const doub
 rr_status rr_pf_update(rr_pf* h, const double* obs, size_t n_obs) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
   ObsArg arg;
   bool kernarg;
@@ -845,8 +1057,8 @@ rr_status rr_pf_update(rr_pf* h, const double* obs, size_t n_obs) {
 rr_status rr_pf_resample(rr_pf* h) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
-  if ((s = launch_sums(h, 0, h->opt.resample_scheme, NAN)) != RR_OK) return s;
-  return launch_resample(h, h->opt.resample_scheme, nullptr);
+  if ((s = materialise(h)) != RR_OK) return s;
+  return launch_resample(h, 0, h->opt.resample_scheme, NAN, nullptr);
 }
 
 rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
@@ -858,10 +1070,33 @@ rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs,
   bool kernarg;
   if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
   StepParams p = make_params(h, control, (int)n_obs);
-  if ((s = launch_pw<true, true, false>(h, p, arg, kernarg)) != RR_OK) return s;
+  if (h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC) {
+    if ((s = launch_pw<true, true, false>(h, p, arg, kernarg)) != RR_OK) return s;
+    h->step += 1;
+    return launch_resample(h, 0, h->opt.resample_scheme, NAN, nullptr);
+  }
+  // systematic: 3 launches per step -- k_step_lazy (propagate + weight, reading through the
+  // previous resample's indices), k_quantize_reduce, k_plan_mark
+  const size_t lds = 3 * n_obs * sizeof(double);
+  if (lds > 150 * 1024) return fail(RR_INVALID_PARAMETER, "too many observations for one LDS block (max 6400)");
+  if (!h->wmax_bits_clean) RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+  h->wmax_bits_clean = false;
+  h->wmax_live = true;
+  const uint64_t n_rtiles = (h->n + rr::kResolveSlots - 1) / rr::kResolveSlots;
+  const unsigned grid = (unsigned)std::min<uint64_t>(n_rtiles, (uint64_t)256 * h->k1_blocks_per_cu);
+  {
+    Timed t(h, RR_K_PROPAGATE_WEIGHT);
+    if (kernarg)
+      hipLaunchKernelGGL((k_step_lazy<true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
+                         (const double*)nullptr, h->markers, h->carry, h->idx);
+    else
+      hipLaunchKernelGGL((k_step_lazy<false>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
+                         (const double*)h->obs_dev, h->markers, h->carry, h->idx);
+  }
+  RR_HIP_TRY(hipGetLastError());
   h->step += 1;
-  if ((s = launch_sums(h, 0, h->opt.resample_scheme, NAN)) != RR_OK) return s;
-  return launch_resample(h, h->opt.resample_scheme, nullptr);
+  h->maybe_pending = false;  // consumed (k_quantize_reduce settles Ctl.cur)
+  return launch_resample(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN, nullptr, /*lazy=*/true, /*settle=*/1);
 }
 
 rr_status rr_pf_synchronize(rr_pf* h) {
@@ -874,6 +1109,7 @@ rr_status rr_pf_synchronize(rr_pf* h) {
 rr_status rr_pf_estimate(rr_pf* h, double out[4]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if (!out) return fail(RR_INVALID_PARAMETER, "null output");
   return compute_moments(h, out, nullptr);
 }
@@ -881,6 +1117,7 @@ rr_status rr_pf_estimate(rr_pf* h, double out[4]) {
 rr_status rr_pf_covariance(rr_pf* h, double out[16]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if (!out) return fail(RR_INVALID_PARAMETER, "null output");
   return compute_moments(h, nullptr, out);
 }
@@ -889,6 +1126,7 @@ rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_
   rr_status s = rr_pf_step_async(h, control, obs, n_obs);
   if (s != RR_OK) return s;
   if (!out_state) return rr_pf_synchronize(h);
+  if ((s = materialise(h)) != RR_OK) return s;  // the estimate is over the resampled set
   return compute_moments(h, out_state, nullptr);
 }
 
@@ -897,6 +1135,7 @@ uint64_t rr_pf_particle_count(const rr_pf* h) { return h ? h->n : 0; }
 rr_status rr_pf_get_fixed_sums(rr_pf* h, rr_pf_fixed_sums* out) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if (!out) return fail(RR_INVALID_PARAMETER, "null output");
   if ((s = launch_sums(h, 2, h->opt.resample_scheme, NAN)) != RR_OK) return s;
   if ((s = fetch_ctl(h)) != RR_OK) return s;
@@ -914,6 +1153,7 @@ rr_status rr_pf_get_fixed_sums(rr_pf* h, rr_pf_fixed_sums* out) {
 rr_status rr_pf_n_eff(rr_pf* h, double* out) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if (!out) return fail(RR_INVALID_PARAMETER, "null output");
   if ((s = launch_sums(h, 2, h->opt.resample_scheme, NAN)) != RR_OK) return s;
   if ((s = fetch_ctl(h)) != RR_OK) return s;
@@ -933,6 +1173,7 @@ rr_status rr_pf_last_resample_fired(rr_pf* h, int32_t* out) {
 rr_status rr_pf_get_particles(rr_pf* h, double* out_aos) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if (!out_aos) return fail(RR_INVALID_PARAMETER, "null output");
   if ((s = ensure_scratch(h, 5 * h->n, 0)) != RR_OK) return s;
   if ((s = launch_sums(h, 2, h->opt.resample_scheme, NAN)) != RR_OK) return s;  // refresh Ctl.sum / usable
@@ -947,10 +1188,13 @@ rr_status rr_pf_get_particles(rr_pf* h, double* out_aos) {
 rr_status rr_pf_set_particles(rr_pf* h, const double* aos) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if (!aos) return fail(RR_INVALID_PARAMETER, "null input");
   if ((s = ensure_scratch(h, 5 * h->n, 0)) != RR_OK) return s;
   RR_HIP_TRY(hipMemcpyAsync(h->scratch_a, aos, 5 * h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+  h->wmax_live = true;
+  h->wmax_bits_clean = false;
   hipLaunchKernelGGL(k_unpack_aos, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->w, h->ctl, h->n,
                      (const double*)h->scratch_a);
   RR_HIP_TRY(hipGetLastError());
@@ -961,26 +1205,27 @@ rr_status rr_pf_set_particles(rr_pf* h, const double* aos) {
 rr_status rr_pf_resample_with_uniforms(rr_pf* h, const double* r, size_t n) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if (!r || n != h->n) return fail(RR_INVALID_PARAMETER, "need exactly one uniform per particle");
   for (size_t k = 0; k < n; ++k)
     if (!(r[k] >= 0.0 && r[k] < 1.0)) return fail(RR_INVALID_PARAMETER, "uniforms must lie in [0, 1)");
   if ((s = ensure_scratch(h, h->n, 0)) != RR_OK) return s;
   RR_HIP_TRY(hipMemcpyAsync(h->scratch_a, r, n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  if ((s = launch_sums(h, 1, RR_RESAMPLE_MULTINOMIAL, NAN)) != RR_OK) return s;
-  return launch_resample(h, RR_RESAMPLE_MULTINOMIAL, h->scratch_a);
+  return launch_resample(h, 1, RR_RESAMPLE_MULTINOMIAL, NAN, h->scratch_a);
 }
 
 rr_status rr_pf_resample_systematic(rr_pf* h, double rho) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if (!(rho >= 0.0 && rho < 1.0)) return fail(RR_INVALID_PARAMETER, "rho must lie in [0, 1)");
-  if ((s = launch_sums(h, 1, RR_RESAMPLE_SYSTEMATIC, rho)) != RR_OK) return s;
-  return launch_resample(h, RR_RESAMPLE_SYSTEMATIC, nullptr);
+  return launch_resample(h, 1, RR_RESAMPLE_SYSTEMATIC, rho, nullptr);
 }
 
 rr_status rr_pf_last_resample_indices(rr_pf* h, uint32_t* out, size_t n) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if (!h->idx) return fail(RR_INVALID_PARAMETER, "record_indices was not enabled for this filter");
   if (!out || n != h->n) return fail(RR_INVALID_PARAMETER, "need room for one index per particle");
   RR_HIP_TRY(hipMemcpyAsync(out, h->idx, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
@@ -1007,6 +1252,7 @@ rr_status rr_pf_get_counters(rr_pf* h, uint32_t* step, uint32_t* resample_step) 
 rr_status rr_pf_set_stream(rr_pf* h, void* stream) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
   if (stream) {
     h->stream = (hipStream_t)stream;
@@ -1028,6 +1274,7 @@ rr_status rr_pf_shard_propagate_weight(rr_pf* h, const double control[2], const 
                                        double* d_wmax_out) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if ((s = require_systematic_shard(h)) != RR_OK) return s;
   if (!d_wmax_out) return fail(RR_INVALID_PARAMETER, "null d_wmax_out");
   if ((s = validate_control(control)) != RR_OK) return s;
@@ -1046,11 +1293,7 @@ rr_status rr_pf_shard_quantize(rr_pf* h, const double* d_wmax_global, uint64_t* 
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!d_wmax_global || !d_sums_out) return fail(RR_INVALID_PARAMETER, "null device pointer");
-  {
-    Timed t(h, RR_K_QUANTIZE_REDUCE);
-    hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->w, h->ctl,
-                       d_wmax_global, image_args(h), h->tile_total, h->tile_q2);
-  }
+  launch_quantize(h, d_wmax_global);
   {
     Timed t(h, RR_K_SCAN_TILES);
     hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl,
@@ -1069,10 +1312,12 @@ rr_status rr_pf_shard_cdf(rr_pf* h, const uint64_t* d_all_sums, int32_t n_shards
                      plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN));
   {
     Timed t(h, RR_K_CDF);
-    hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(kBlock), 0, h->stream, h->w, h->ctl, image_args(h),
-                       h->tile_total, h->cdf);
+    hipLaunchKernelGGL(rr::k_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl, image_args(h),
+                       h->tile_total, h->markers, h->carry);
   }
   RR_HIP_TRY(hipGetLastError());
+  h->wmax_live = false;
+  h->wmax_bits_clean = true;
   h->rstep += 1;
   return RR_OK;
 }
@@ -1098,18 +1343,11 @@ rr_status rr_pf_shard_gather_slots(rr_pf* h, uint64_t first_slot, uint64_t n_slo
   if (n_slots == 0) return RR_OK;
   if (!d_out) return fail(RR_INVALID_PARAMETER, "null d_out");
   if (first_slot + n_slots > h->n_global) return fail(RR_INVALID_PARAMETER, "slot range exceeds n_global");
-  GatherArgs g{};
-  g.n_src = h->n;
-  g.first_slot = first_slot;
-  g.n_slots = n_slots;
-  g.seed = h->opt.seed;
-  g.rstep = h->rstep;
-  g.scheme = RR_RESAMPLE_SYSTEMATIC;
-  g.to_staging = 1;
+  (void)first_slot;  // markers are relative to the first slot this shard serves, which is what the caller passes
   {
     Timed t(h, RR_K_RESAMPLE_GATHER);
-    hipLaunchKernelGGL(k_resample_gather, dim3(grid_for(n_slots, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl,
-                       h->cdf, (const double*)nullptr, (unsigned int*)nullptr, d_out, g);
+    hipLaunchKernelGGL(k_resolve_gather, dim3(grid_for(n_slots, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b,
+                       h->ctl, h->markers, h->carry, (unsigned int*)nullptr, d_out, n_slots, 1, 0);
   }
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
@@ -1120,10 +1358,6 @@ rr_status rr_pf_shard_adopt(rr_pf* h, const double* d_in) {
   if (s != RR_OK) return s;
   if (!d_in) return fail(RR_INVALID_PARAMETER, "null d_in");
   hipLaunchKernelGGL(k_adopt, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, d_in, h->n);
-  {
-    Timed t(h, RR_K_COMMIT);
-    hipLaunchKernelGGL(k_commit, dim3(1), dim3(1), 0, h->stream, h->ctl);
-  }
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
 }

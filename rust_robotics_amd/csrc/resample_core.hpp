@@ -18,9 +18,12 @@
 
 namespace rr {
 
-constexpr int kBlock = 256;
-constexpr int kItems = 8;
-constexpr int kTile = kBlock * kItems;  // 2048 particles per scan tile
+constexpr int kBlock = 256;      // every kernel: 4 waves per workgroup
+constexpr int kTileBlock = kBlock;
+constexpr int kItems = 8;        // particles per thread in the tile kernels
+constexpr int kTile = kTileBlock * kItems;  // 2048 particles per scan tile
+constexpr int kTileWaves = kTileBlock / 64;
+constexpr int kWaveSpan = kTile / kTileWaves;  // consecutive particles owned by one wave in k_quantize_reduce
 constexpr int kScanThreads = 1024;
 constexpr int kMaxObsKernarg = 96;  // observations that travel inside the launch packet
 constexpr int kMomentBlocks = 1024;
@@ -46,6 +49,8 @@ struct Ctl {
   int image_mode;       // ImageMode of the current integer image
   int shift;            // fixed-point shift of the current integer image
   int fired;            // last gate decision
+  int pending;          // 1 => a fired resample is still only markers: particles not moved yet (lazy gather)
+  int pad_;
   uint64_t wmax_bits;   // atomic max of the raw weights (bit pattern of a double >= 0)
   uint64_t total;       // T over all shards
   uint64_t total_local;
@@ -83,22 +88,22 @@ struct ImageArgs {
 // K2: per-tile integer totals and sum of squares.  Tile = 2048 particles; each wave owns 512
 // consecutive particles as 8 coalesced rows of 64.  wmax_src points at the maximum to scale by
 // (Ctl.wmax_bits on one GPU, the all-reduced maximum when sharded).
-static __global__ __launch_bounds__(kBlock) void k_quantize_reduce(const double* __restrict__ w,
+static __global__ __launch_bounds__(kTileBlock) void k_quantize_reduce(const double* __restrict__ w,
                                                                   Ctl* __restrict__ ctl,
                                                                   const double* __restrict__ wmax_src,
                                                                   ImageArgs a,
                                                                   uint64_t* __restrict__ tile_total,
-                                                                  uint64_t* __restrict__ tile_q2) {
-  __shared__ uint64_t s_t[kBlock / kWave];
-  __shared__ uint64_t s_qh[kBlock / kWave];
-  __shared__ uint64_t s_ql[kBlock / kWave];
+                                                                  uint64_t* __restrict__ tile_q2, int settle) {
+  __shared__ uint64_t s_t[kTileWaves];
+  __shared__ uint64_t s_qh[kTileWaves];
+  __shared__ uint64_t s_ql[kTileWaves];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const double wmax = *wmax_src;
   const bool forced_uniform = a.honour_uniform_flag && ctl->weights_uniform;
   const bool usable = !forced_uniform && wmax > 0.0 && wmax < INFINITY;
   const int mode = usable ? (int)kImageWeights : (forced_uniform ? (int)kImageUniform : a.degenerate);
   const int shift = usable ? rr_fix_shift(wmax, a.n_global) : 0;
-  const uint64_t base = (uint64_t)blockIdx.x * kTile + (uint64_t)wv * (kTile / 4);
+  const uint64_t base = (uint64_t)blockIdx.x * kTile + (uint64_t)wv * kWaveSpan;
   uint64_t t = 0;
   u128 q2 = {0, 0};
 #pragma unroll
@@ -120,7 +125,7 @@ static __global__ __launch_bounds__(kBlock) void k_quantize_reduce(const double*
   if (tid == 0) {
     uint64_t tt = 0;
     u128 qq = {0, 0};
-    for (int k = 0; k < kBlock / kWave; ++k) {
+    for (int k = 0; k < kTileWaves; ++k) {
       tt += s_t[k];
       qq = add128(qq, u128{s_qh[k], s_ql[k]});
     }
@@ -128,6 +133,10 @@ static __global__ __launch_bounds__(kBlock) void k_quantize_reduce(const double*
     tile_q2[2 * blockIdx.x] = qq.hi;
     tile_q2[2 * blockIdx.x + 1] = qq.lo;
     if (blockIdx.x == 0) {
+      if (settle && ctl->pending) {  // the propagate kernel just before us consumed the lazy gather
+        ctl->cur ^= 1;
+        ctl->pending = 0;
+      }
       ctl->usable = usable ? 1 : 0;
       ctl->image_mode = mode;
       ctl->shift = shift;
@@ -150,6 +159,9 @@ struct PlanArgs {
   double rho_override;  // NaN => Philox
   uint64_t seed;
   unsigned int rstep;
+  int set_uniform_on_fire;  // PF/MCL: weights become 1/N when the resample fires
+  int lazy_gather;          // 1 => leave the particles where they are (Ctl.pending); the next propagate kernel
+                            // reads them through the resolved indices.  0 => a gather kernel follows: flip now
 };
 
 __device__ inline void finalize_plan(Ctl* ctl, uint64_t total_global, uint64_t base, uint64_t total_local, u128 q2,
@@ -177,6 +189,15 @@ __device__ inline void finalize_plan(Ctl* ctl, uint64_t total_global, uint64_t b
   if (a.mode == 1) fire = 1;
   else fire = a.gate == RR_GATE_ALWAYS ? 1 : (neff < a.neff_threshold);
   ctl->fired = fire;
+  ctl->wmax_bits = 0;  // consumed: the next weight kernel accumulates a fresh maximum
+  if (fire) {
+    // eager: publish the resampled set NOW -- the gather that follows reads buffer set cur^1 and
+    // writes set cur (no separate commit launch).  lazy: only mark it pending.
+    // PF/MCL weights become uniform either way (particle_filter.rs:468)
+    if (a.lazy_gather) ctl->pending = 1;
+    else ctl->cur ^= 1;
+    if (a.set_uniform_on_fire) ctl->weights_uniform = 1;
+  }
   if (fire && a.scheme == RR_RESAMPLE_SYSTEMATIC) {
     double rho = a.rho_override;
     if (rho != rho) {
@@ -260,34 +281,232 @@ static __global__ void k_shard_plan(Ctl* __restrict__ ctl, const uint64_t* __res
 }
 
 // ------------------------------------------------------------------------------------------
-// K4: inclusive integer CDF of this shard: cdf[i] = base + tile_offset + within-tile scan.
-// Reads w (8 B), writes cdf (8 B).  Skipped when the gate did not fire.
+// Tile-local scan, blocked layout: thread t of the workgroup owns the 8 CONSECUTIVE particles
+// [tile*2048 + 8t, +8).  Each thread prefix-sums its own 8 integer weights serially, one wave64
+// scan of the thread totals plus 4 wave totals through LDS gives every thread its exclusive
+// offset inside the tile.  (A row-per-wave layout needs one 6-step shuffle chain per row, and
+// those chains -- ds_bpermute latency -- were the whole critical path of the resample kernels.)
+struct TileScan {
+  uint64_t q[kItems];    // integer weights of this thread's particles
+  uint64_t c[kItems];    // inclusive prefix inside the thread
+  uint64_t thread_off;   // exclusive prefix of this thread inside the tile
+};
+
+__device__ inline TileScan tile_scan(const double* __restrict__ w, const ImageArgs& a, int mode, int shift,
+                                     uint64_t tile, uint64_t* s_w /* [kBlock / kWave] */) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  TileScan t;
+  const uint64_t i0 = tile * kTile + (uint64_t)tid * kItems;
+  uint64_t run = 0;
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    t.q[j] = quantize_at(w, i0 + j, a.n, mode, shift, a.gid0, a.n_global);
+    run += t.q[j];
+    t.c[j] = run;
+  }
+  const uint64_t incl = wave_scan_u64(run, lane);
+  if (lane == 63) s_w[wv] = incl;
+  __syncthreads();
+  uint64_t off = incl - run;
+  for (int k = 0; k < wv; ++k) off += s_w[k];
+  t.thread_off = off;
+  return t;
+}
+
+// the sums every workgroup of a fused plan kernel needs: its tile prefix, the grand total, sum q^2
+struct TileSums {
+  uint64_t pre, tot;
+  u128 q2;
+};
+
+__device__ inline TileSums tile_sums(const uint64_t* __restrict__ tile_total, const uint64_t* __restrict__ tile_q2,
+                                     uint64_t n_tiles, uint64_t* s4 /* [4][kBlock / kWave] */) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  constexpr int W = kBlock / kWave;
+  uint64_t pre = 0, tot = 0;
+  u128 q2 = {0, 0};
+  for (uint64_t k = tid; k < n_tiles; k += kBlock) {
+    const uint64_t t = tile_total[k];
+    tot += t;
+    if (k < blockIdx.x) pre += t;
+    q2 = add128(q2, u128{tile_q2[2 * k], tile_q2[2 * k + 1]});
+  }
+  pre = wave_sum_u64(pre);
+  tot = wave_sum_u64(tot);
+  q2 = wave_sum_u128(q2);
+  if (lane == 0) {
+    s4[wv] = pre;
+    s4[W + wv] = tot;
+    s4[2 * W + wv] = q2.hi;
+    s4[3 * W + wv] = q2.lo;
+  }
+  __syncthreads();
+  TileSums r{0, 0, {0, 0}};
+  for (int k = 0; k < W; ++k) {
+    r.pre += s4[k];
+    r.tot += s4[W + k];
+    r.q2 = add128(r.q2, u128{s4[2 * W + k], s4[3 * W + k]});
+  }
+  return r;
+}
+
+__device__ inline int gate_decision(int image_mode, const TileSums& ts, const PlanArgs& pa) {
+  double neff;
+  if (image_mode == kImageWeights && ts.tot > 0) neff = rr_fix_neff(ts.tot, ts.q2.hi, ts.q2.lo);
+  else if (image_mode == kImageUniform) neff = (double)pa.n_global;
+  else neff = 0.0;
+  return pa.mode == 1 ? 1 : (pa.mode == 2 ? 0 : (pa.gate == RR_GATE_ALWAYS ? 1 : (neff < pa.neff_threshold)));
+}
+
+// ------------------------------------------------------------------------------------------
+// K4: inclusive integer CDF of this shard (multinomial resampling and FastSLAM read it back):
+// cdf[i] = base + tile_offset + within-tile scan.  Reads w (8 B), writes cdf (8 B).
 static __global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, const Ctl* __restrict__ ctl,
                                                       ImageArgs a, const uint64_t* __restrict__ tile_offset,
                                                       uint64_t* __restrict__ cdf) {
   if (!ctl->fired) return;
   __shared__ uint64_t s_w[kBlock / kWave];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const TileScan t = tile_scan(w, a, ctl->image_mode, ctl->shift, blockIdx.x, s_w);
+  const uint64_t off = ctl->base + tile_offset[blockIdx.x] + t.thread_off;
+  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
+#pragma unroll
+  for (int j = 0; j < kItems; ++j)
+    if (i0 + j < a.n) cdf[i0 + j] = off + t.c[j];
+}
+
+// K3+K4 fused (single shard, n_tiles <= kFusedMaxTiles): every workgroup re-derives its tile
+// offset and the grand totals from the (L2-resident) tile totals -- integer sums, so every
+// workgroup gets the same bits -- takes the gate decision itself, and writes its slice of the
+// CDF.  Workgroup 0 publishes the plan.  Saves one launch and one dependent single-block kernel.
+constexpr int kFusedMaxTiles = 4096;
+
+static __global__ __launch_bounds__(kBlock) void k_plan_cdf(const double* __restrict__ w, Ctl* __restrict__ ctl,
+                                                           ImageArgs a, const uint64_t* __restrict__ tile_total,
+                                                           const uint64_t* __restrict__ tile_q2, uint64_t n_tiles,
+                                                           PlanArgs pa, uint64_t* __restrict__ cdf) {
+  __shared__ uint64_t s4[4 * (kBlock / kWave)];
+  __shared__ uint64_t s_w[kBlock / kWave];
+  const TileSums ts = tile_sums(tile_total, tile_q2, n_tiles, s4);
+  const int mode = ctl->image_mode;  // written by k_quantize_reduce; nothing below reads what block 0 writes
+  const int shift = ctl->shift;
+  const int fire = gate_decision(mode, ts, pa);
+  if (blockIdx.x == 0 && threadIdx.x == 0) finalize_plan(ctl, ts.tot, 0, ts.tot, ts.q2, pa);
+  if (!fire) return;
+  const TileScan t = tile_scan(w, a, mode, shift, blockIdx.x, s_w);
+  const uint64_t off = ts.pre + t.thread_off;
+  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
+#pragma unroll
+  for (int j = 0; j < kItems; ++j)
+    if (i0 + j < a.n) cdf[i0 + j] = off + t.c[j];
+}
+
+// ------------------------------------------------------------------------------------------
+// Systematic resampling WITHOUT any search.  Targets are monotone in the slot index, so source j
+// (inclusive CDF C_j) feeds the contiguous slot run [H_{j-1}, H_j), H_j = rr_sys_slots_upto(C_j).
+// The plan kernel therefore never materialises the CDF: it computes H per source in registers and
+//   * writes the marker  markers[H_{j-1} - slot_base] = j + 1   for every source with offspring,
+//   * writes             carry[b] = j + 1                        for every slot-tile boundary
+//     b * kResolveSlots that falls inside the run (the source of the first slot of slot-tile b).
+// The resolve step (engine specific: it also moves the particles) turns markers into indices with
+// a running maximum per slot tile seeded by carry[tile] -- markers are increasing in the slot
+// index -- and clears them for the next step.  Everything is O(N), balanced on the output side,
+// and free of dependent HBM probe chains (the old lower_bound cost 20 of them per slot).
+constexpr int kResolveRows = 2;
+constexpr int kResolveSlots = kResolveRows * kBlock;  // slots per resolve workgroup
+
+// this thread's 8 consecutive sources: exclusive CDF prefix `off`, inclusive prefixes off + c[j]
+__device__ inline void mark_sources(const TileScan& t, uint64_t off, uint64_t i0, uint64_t n, const rr_sys_plan plan,
+                                    uint64_t total, uint64_t slot_base, unsigned int* __restrict__ markers,
+                                    unsigned int* __restrict__ carry) {
+  const rr_sys_inv inv = rr_sys_inv_make(plan, total);
+  uint64_t h_run = rr_sys_slots_upto(plan, inv, total, off);  // H of the source just before this thread's first
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    if (t.q[j] == 0 || i0 + j >= n) continue;  // zero-weight sources feed no slot: H_j == H_{j-1}
+    const uint64_t h = rr_sys_slots_upto(plan, inv, total, off + t.c[j]);
+    if (h > h_run) {
+      const uint64_t lo = h_run - slot_base, hi = h - slot_base;
+      markers[lo] = (unsigned int)(i0 + j + 1);
+      for (uint64_t b = (lo + kResolveSlots - 1) / kResolveSlots; b * kResolveSlots < hi; ++b)
+        carry[b] = (unsigned int)(i0 + j + 1);
+      h_run = h;
+    }
+  }
+}
+
+// fused plan + mark (single shard, systematic, n_tiles <= kFusedMaxTiles)
+static __global__ __launch_bounds__(kBlock) void k_plan_mark(const double* __restrict__ w, Ctl* __restrict__ ctl,
+                                                            ImageArgs a, const uint64_t* __restrict__ tile_total,
+                                                            const uint64_t* __restrict__ tile_q2, uint64_t n_tiles,
+                                                            PlanArgs pa, unsigned int* __restrict__ markers,
+                                                            unsigned int* __restrict__ carry) {
+  __shared__ uint64_t s4[4 * (kBlock / kWave)];
+  __shared__ uint64_t s_w[kBlock / kWave];
+  const TileSums ts = tile_sums(tile_total, tile_q2, n_tiles, s4);
   const int mode = ctl->image_mode;
   const int shift = ctl->shift;
-  const uint64_t base = (uint64_t)blockIdx.x * kTile + (uint64_t)wv * (kTile / 4);
-  uint64_t vals[kItems];
-  uint64_t carry = 0;
-#pragma unroll
-  for (int r = 0; r < kItems; ++r) {
-    uint64_t q = quantize_at(w, base + r * 64 + lane, a.n, mode, shift, a.gid0, a.n_global);
-    uint64_t incl = wave_scan_u64(q, lane);
-    vals[r] = incl + carry;
-    carry += shfl_u64(incl, 63);
+  const int fire = gate_decision(mode, ts, pa);
+  // every workgroup derives the same plan (rho comes from the arguments or the Philox stream)
+  double rho = pa.rho_override;
+  if (rho != rho) {
+    double dummy;
+    rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
   }
-  if (lane == 0) s_w[wv] = carry;
-  __syncthreads();
-  uint64_t off = ctl->base + tile_offset[blockIdx.x];
-  for (int k = 0; k < wv; ++k) off += s_w[k];
+  if (blockIdx.x == 0 && threadIdx.x == 0) finalize_plan(ctl, ts.tot, 0, ts.tot, ts.q2, pa);
+  if (!fire) return;
+  const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
+  const TileScan t = tile_scan(w, a, mode, shift, blockIdx.x, s_w);
+  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
+  mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry);
+}
+
+// sharded: the plan is already in Ctl (k_shard_plan); mark this shard's sources.  tile_offset =
+// exclusive tile prefix written by k_scan_tiles.
+static __global__ __launch_bounds__(kBlock) void k_mark(const double* __restrict__ w, const Ctl* __restrict__ ctl,
+                                                       ImageArgs a, const uint64_t* __restrict__ tile_offset,
+                                                       unsigned int* __restrict__ markers,
+                                                       unsigned int* __restrict__ carry) {
+  if (!ctl->fired) return;
+  __shared__ uint64_t s_w[kBlock / kWave];
+  const TileScan t = tile_scan(w, a, ctl->image_mode, ctl->shift, blockIdx.x, s_w);
+  const rr_sys_plan plan = ctl->plan;
+  const uint64_t slot_base = rr_sys_slots_upto_exact(plan, ctl->total, ctl->base);
+  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
+  mark_sources(t, ctl->base + tile_offset[blockIdx.x] + t.thread_off, i0, a.n, plan, ctl->total, slot_base, markers, carry);
+}
+
+// markers -> source indices for the kResolveSlots slots of one workgroup; returns this thread's
+// indices (slot = tile_base + r*kBlock + tid), clears the markers it consumed
+__device__ inline void resolve_tile(unsigned int* __restrict__ markers, const unsigned int* __restrict__ carry,
+                                    uint64_t n_slots, uint64_t tile, unsigned int idx[kResolveRows]) {
+  __shared__ unsigned int s_m[kBlock / kWave];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint64_t tile_base = tile * kResolveSlots;
+  unsigned int run = carry[tile];  // source (+1) of the tile's first slot
+  // rows of kBlock consecutive slots: running maximum along the row, carried to the next row
 #pragma unroll
-  for (int r = 0; r < kItems; ++r) {
-    uint64_t i = base + r * 64 + lane;
-    if (i < a.n) cdf[i] = vals[r] + off;
+  for (int r = 0; r < kResolveRows; ++r) {
+    const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
+    unsigned int m = 0;
+    if (k < n_slots) {
+      m = markers[k];
+      if (m) markers[k] = 0;
+    }
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+      const unsigned int t = __shfl_up(m, o, kWave);
+      if (lane >= o && t > m) m = t;
+    }
+    if (lane == 63) s_m[wv] = m;
+    __syncthreads();
+    unsigned int pre = run;
+    for (int q = 0; q < wv; ++q) pre = s_m[q] > pre ? s_m[q] : pre;
+    if (pre > m) m = pre;
+    idx[r] = m - 1;
+    unsigned int row_max = run;
+    for (int q = 0; q < kBlock / kWave; ++q) row_max = s_m[q] > row_max ? s_m[q] : row_max;
+    run = row_max;
+    __syncthreads();
   }
 }
 
