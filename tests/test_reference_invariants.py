@@ -1,0 +1,111 @@
+"""The invariants the reference's OWN tests pin for this path, re-expressed
+against the literal restatement so that the restatement is held to what the reference holds itself
+to.  CPU only."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import dp, u32p
+from tests import helpers as H
+
+
+def run_pf(ref, n, steps, obs_fn, seed, v=1.0, w_=0.1, sig=0.2, sv=2.0, sw=math.radians(40.0), thr=0.5):
+    rng = np.random.default_rng(seed)
+    x, y, yaw, vv = (np.zeros(n) for _ in range(4))
+    w = np.full(n, 1.0 / n)
+    idx = np.empty(n, np.uint32)
+    est = np.empty(4)
+    for t in range(steps):
+        obs = np.ascontiguousarray(obs_fn(t, rng), dtype=np.float64).reshape(-1, 3)
+        nv, nw = rng.normal(0, sv, n), rng.normal(0, sw, n)
+        r = rng.random(n)
+        ref.ref_pf_step(n, dp(x), dp(y), dp(yaw), dp(vv), dp(w), v, w_, 0.1, dp(nv), dp(nw), dp(obs) if obs.size else None,
+                        obs.shape[0], sig, thr, 0, dp(r), u32p(idx), dp(est))
+    return x, y, yaw, vv, w, est
+
+
+def test_sum_of_weights_is_one_after_update(ref):
+    """particle_filter.rs:611-623"""
+    n = 100
+    x, y, yaw, v = H.cloud(n, 1, center=(5.0, 5.0, 0.0, 0.0))
+    w = np.empty(n)
+    obs = np.array([5.0, 0.0, 5.0])
+    ref.ref_pf_update_raw(n, dp(x), dp(y), dp(w), dp(obs), 1, 0.2)
+    ref.ref_pf_normalize(n, dp(w))
+    assert abs(w.sum() - 1.0) < 1e-3
+
+
+def test_step_outputs_are_finite_and_cov_diag_nonnegative(ref):
+    """particle_filter.rs:626-646, tests/unified_filter_comparison.rs:390-396"""
+    x, y, yaw, v, w, est = run_pf(ref, 100, 10, lambda t, rng: [(10.0, 10.0, 0.0)], 2)
+    assert np.all(np.isfinite(est))
+    cov = np.empty(16)
+    ref.ref_pf_covariance(100, dp(x), dp(y), dp(yaw), dp(v), dp(w), dp(est), dp(cov))
+    assert cov[0] >= 0 and cov[5] >= 0
+
+
+@pytest.mark.parametrize("steps,v,w_", [(1, -2.0, -1.0), (17, 0.3, 0.9), (49, 1.99, -0.5)])
+def test_empty_observations_keep_the_estimate_finite(ref, steps, v, w_):
+    """tests/proptest_filters.rs:42-54,79-88: steps in [1,50), v in [-2,2), omega in [-1,1)"""
+    *_, w, est = run_pf(ref, 64, steps, lambda t, rng: [], 3, v=v, w_=w_)
+    assert np.all(np.isfinite(est))
+    assert np.allclose(w, 1.0 / 64)
+
+
+def test_mcl_tracks_within_one_metre(ref):
+    """monte_carlo_localization.rs:489-516 with min == max particles"""
+    n = 600
+    rng = np.random.default_rng(4)
+    x, y, yaw, v = (np.zeros(n) for _ in range(4))
+    w = np.full(n, 1.0 / n)
+    idx = np.empty(n, np.uint32)
+    est = np.empty(4)
+    for t in range(60):
+        obs = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.3, rng)
+        nv, nw, r = rng.normal(0, 0.5, n), rng.normal(0, math.radians(10.0), n), rng.random(n)
+        ref.ref_pf_step(n, dp(x), dp(y), dp(yaw), dp(v), dp(w), 1.0, 0.1, 0.1, dp(nv), dp(nw), dp(obs), len(obs), 0.3, 1.0, 1,
+                        dp(r), u32p(idx), dp(est))
+    assert np.hypot(*(est[:2] - H.true_pose(60)[:2])) < 1.0
+
+
+def test_fastslam_initial_state_and_no_panic(ref):
+    """fastslam1.rs:363-400"""
+    n, L = 20, 3
+    px, py, pyaw, pw = (np.empty(n) for _ in range(4))
+    lm = np.empty(n * L * 6)
+    ref.ref_fs1_create(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(lm))
+    assert np.all(px == 0) and np.all(pyaw == 0) and np.all(np.abs(pw - 0.01) < np.finfo(float).eps)
+    e = lm.reshape(n, L, 6)
+    assert np.all(e[:, :, 2] == 1000.0) and np.all(e[:, :, 5] == 1000.0) and np.all(e[:, :, 0] == 0)
+    m = oracle.ref_fs1_model()
+    lms = np.array([[10.0, 0.0], [0.0, 10.0], [10.0, 10.0]])
+    rng = np.random.default_rng(5)
+    idx = np.empty(n, np.uint32)
+    xt = np.zeros(3)
+    for t in range(5):
+        z = np.empty((L, 3))
+        cnt = ref.ref_fs1_get_observations(dp(xt), dp(lms), L, 20.0, dp(rng.normal(size=2 * L)), C.byref(m), dp(z))
+        z = np.ascontiguousarray(z[:cnt])
+        z0, z1 = rng.normal(size=n), rng.normal(size=n)
+        ref.ref_fs1_update(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(lm), 1.0, 0.1, dp(z0), dp(z1), dp(z), cnt, C.byref(m),
+                           100 / 1.5, rng.random() / n, u32p(idx))
+    assert np.all(np.isfinite(px)) and np.all(np.isfinite(pw))
+    # Q11: through fastslam_update alone the covariance never leaves 1000, weights stay uniform
+    assert np.all(lm.reshape(n, L, 6)[:, :, 2] == 1000.0)
+    assert np.allclose(pw, 1.0 / n)
+
+
+def test_best_particle_and_range_gate(ref):
+    """fastslam1.rs:325-360"""
+    pw = np.array([0.1, 0.5, 0.9, 0.3, 0.2])
+    assert ref.ref_fs1_best_particle(5, dp(pw)) == 2
+    pw = np.array([0.9, 0.5, 0.9, 0.3, 0.9])
+    assert ref.ref_fs1_best_particle(5, dp(pw)) == 4  # ties -> last (Q14)
+    m = oracle.ref_fs1_model()
+    z = np.empty((2, 3))
+    cnt = ref.ref_fs1_get_observations(dp(np.zeros(3)), dp(np.array([[5.0, 0.0], [100.0, 100.0]])), 2, 20.0, dp(np.zeros(4)),
+                                       C.byref(m), dp(z))
+    assert cnt == 1 and z[0, 2] == 0 and z[0, 0] == 5.0
