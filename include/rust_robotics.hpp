@@ -1,0 +1,189 @@
+// rust_robotics.hpp -- header-only C++17 wrapper over the C ABI (include/rr_pf.h, include/rr_fastslam1.h)
+// with the reference's names: ParticleFilterLocalizer / MonteCarloLocalizer
+// (rust_robotics_localization/src/particle_filter.rs:121-573, monte_carlo_localization.rs:136-462) and
+// fastslam1 (rust_robotics_slam/src/fastslam1.rs).  try_* methods throw rr::RoboticsError where the
+// reference returns Err(RoboticsError::InvalidParameter(..)).  Link with -lrust_robotics_amd.
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "rr_fastslam1.h"
+#include "rr_pf.h"
+
+namespace rr {
+
+struct RoboticsError : std::runtime_error {
+  enum Kind { InvalidParameter, NumericalError } kind;
+  RoboticsError(Kind k, const std::string& m) : std::runtime_error(m), kind(k) {}
+};
+
+inline void check(rr_status s) {
+  if (s == RR_OK) return;
+  throw RoboticsError(s == RR_INVALID_PARAMETER ? RoboticsError::InvalidParameter : RoboticsError::NumericalError,
+                      rr_last_error());
+}
+
+struct Point2D { double x = 0, y = 0; };                       // core/src/types.rs:17-20
+struct State2D { double x = 0, y = 0, yaw = 0, v = 0; };       // core/src/types.rs:141-146
+struct ControlInput { double v = 0, omega = 0; };              // core/src/types.rs:189-192
+struct Particle { double x, y, yaw, v, w; };                   // particle_filter.rs:25-32
+using PFState = std::array<double, 4>;
+using PFControl = std::array<double, 2>;
+using PFMeasurement = std::vector<std::tuple<double, double, double>>;  // (d, landmark_x, landmark_y)
+
+struct ParticleFilterConfig : rr_pf_config {                   // particle_filter.rs:51-78
+  ParticleFilterConfig() { rr_pf_config_default(this); }
+  void validate() const { check(rr_pf_config_validate(this)); }
+};
+
+class ParticleFilterLocalizer {
+ public:
+  explicit ParticleFilterLocalizer(const ParticleFilterConfig& cfg = {}, uint64_t seed = 0, int device = 0) {
+    rr_pf_options o;
+    options(&o);
+    o.seed = seed;
+    o.device = device;
+    check(rr_pf_create(&cfg, &o, &h_));
+  }
+  ParticleFilterLocalizer(const PFState& initial, const ParticleFilterConfig& cfg, uint64_t seed = 0, int device = 0) {
+    rr_pf_options o;
+    options(&o);
+    o.seed = seed;
+    o.device = device;
+    check(rr_pf_create_with_state(&cfg, &o, initial.data(), &h_));
+  }
+  static ParticleFilterLocalizer with_defaults() { return ParticleFilterLocalizer(); }
+  ParticleFilterLocalizer(ParticleFilterLocalizer&& o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
+  ParticleFilterLocalizer(const ParticleFilterLocalizer&) = delete;
+  virtual ~ParticleFilterLocalizer() { rr_pf_destroy(h_); }
+
+  void try_set_landmarks(const std::vector<Point2D>& lm) {
+    check(rr_pf_set_landmarks(h_, lm.empty() ? nullptr : &lm[0].x, lm.size()));
+  }
+  std::vector<Point2D> get_landmarks() const {
+    std::vector<Point2D> out(rr_pf_landmark_count(h_));
+    if (!out.empty()) rr_pf_get_landmarks(h_, &out[0].x, out.size());
+    return out;
+  }
+  void set_range_noise(double s) { check(rr_pf_set_range_noise(h_, s)); }
+  void try_predict_with_control(const PFControl& u) { check(rr_pf_predict(h_, u.data())); }
+  void try_predict_input(const ControlInput& c) { try_predict_with_control({c.v, c.omega}); }
+  void try_update_with_observations(const PFMeasurement& obs) {
+    std::vector<double> flat = flatten(obs);
+    check(rr_pf_update(h_, flat.data(), obs.size()));
+  }
+  void resample() { check(rr_pf_resample(h_)); }
+  PFState try_step(const PFControl& u, const PFMeasurement& obs) {
+    std::vector<double> flat = flatten(obs);
+    PFState out;
+    check(rr_pf_step(h_, u.data(), flat.data(), obs.size(), out.data()));
+    return out;
+  }
+  State2D try_step_state(const ControlInput& c, const PFMeasurement& obs) {
+    PFState e = try_step({c.v, c.omega}, obs);
+    return {e[0], e[1], e[2], e[3]};
+  }
+  PFState estimate() {
+    PFState e;
+    check(rr_pf_estimate(h_, e.data()));
+    return e;
+  }
+  State2D state_2d() {
+    PFState e = estimate();
+    return {e[0], e[1], e[2], e[3]};
+  }
+  std::array<double, 16> calc_covariance() {
+    std::array<double, 16> c;
+    check(rr_pf_covariance(h_, c.data()));
+    return c;
+  }
+  std::vector<Particle> get_particles() {
+    std::vector<Particle> p(rr_pf_particle_count(h_));
+    check(rr_pf_get_particles(h_, &p[0].x));
+    return p;
+  }
+  // StateEstimator (core/src/traits.rs:31-52): dt is ignored as in particle_filter.rs:557-559
+  void predict(const PFControl& u, double /*dt*/) { try_predict_with_control(u); }
+  void update(const PFMeasurement& m) {
+    try_update_with_observations(m);
+    resample();
+  }
+  PFState get_state() { return estimate(); }
+  rr_pf* handle() { return h_; }
+
+ protected:
+  virtual void options(rr_pf_options* o) const { rr_pf_options_default(o); }
+  static std::vector<double> flatten(const PFMeasurement& obs) {
+    std::vector<double> f;
+    f.reserve(3 * obs.size());
+    for (auto& [d, x, y] : obs) {
+      f.push_back(d);
+      f.push_back(x);
+      f.push_back(y);
+    }
+    return f;
+  }
+  rr_pf* h_ = nullptr;
+};
+
+// fixed-N Monte Carlo localization: resample every step (monte_carlo_localization.rs:291-300)
+class MonteCarloLocalizer : public ParticleFilterLocalizer {
+ public:
+  using ParticleFilterLocalizer::ParticleFilterLocalizer;
+
+ protected:
+  void options(rr_pf_options* o) const override { rr_pf_options_mcl(o); }
+};
+
+namespace fastslam1 {
+struct Params : rr_fs1_params {
+  Params() { rr_fs1_params_default(this); }
+};
+
+class FastSlam1 {
+ public:
+  FastSlam1(uint64_t n_particles, uint64_t n_landmarks, const Params& p = {}, uint64_t seed = 0, int device = 0) {
+    rr_fs1_options o;
+    rr_fs1_options_default(&o);
+    o.seed = seed;
+    o.device = device;
+    check(rr_fs1_create(n_particles, n_landmarks, &p, &o, &h_));
+  }
+  FastSlam1(const FastSlam1&) = delete;
+  ~FastSlam1() { rr_fs1_destroy(h_); }
+  // fastslam_update, fastslam1.rs:237-266; z rows = (distance, angle, landmark id)
+  void update(const std::array<double, 2>& u, const std::vector<std::tuple<double, double, size_t>>& z) {
+    std::vector<double> f;
+    for (auto& [d, a, id] : z) {
+      f.push_back(d);
+      f.push_back(a);
+      f.push_back((double)id);
+    }
+    check(rr_fs1_update(h_, u.data(), f.data(), z.size()));
+  }
+  // get_best_particle, fastslam1.rs:269-274
+  std::tuple<std::array<double, 3>, double, uint64_t> best_particle() {
+    std::array<double, 3> pose;
+    double w;
+    uint64_t i;
+    check(rr_fs1_best_particle(h_, pose.data(), &w, &i));
+    return {pose, w, i};
+  }
+  std::vector<double> landmarks_of(uint64_t particle) {
+    std::vector<double> out(6 * rr_fs1_landmark_count(h_));
+    check(rr_fs1_get_landmarks(h_, particle, out.data()));
+    return out;
+  }
+
+ private:
+  rr_fs1* h_ = nullptr;
+};
+}  // namespace fastslam1
+}  // namespace rr
