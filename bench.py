@@ -20,9 +20,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
-# algorithmic HBM bytes per particle of the dominant kernel k_propagate_weight:
-# read x,y,yaw (24 B) + write x,y,yaw,v,w (40 B)
-K1_BYTES_PER_PARTICLE = 64.0
+# algorithmic HBM bytes per particle of the dominant kernel: read x,y,yaw (24 B) + write
+# x,y,yaw,v,w (40 B); the systematic path's k_step_lazy also reads and clears the 4-byte resample marker
+K1_BYTES = {"systematic": 72.0, "multinomial": 64.0}
 
 
 def make_scene(L, steps, seed):
@@ -241,7 +241,8 @@ def main():
     kern = res["kernels"]
     k1_n, k1_ms = kern["k_propagate_weight"]
     k1_avg_s = (k1_ms / max(k1_n, 1)) * 1e-3
-    achieved = K1_BYTES_PER_PARTICLE * n / k1_avg_s if k1_avg_s > 0 else 0.0
+    k1_bytes = K1_BYTES[args.scheme] if world == 1 and not args.force_sharded else 64.0
+    achieved = k1_bytes * n / k1_avg_s if k1_avg_s > 0 else 0.0
     step_kernel_ms = {k: (v[1] / max(v[0], 1)) for k, v in kern.items() if v[0]}
     out = {
         "metric": "particle-landmark updates/sec",
@@ -266,15 +267,16 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_propagate_weight",
+            "kernel": "k_step_lazy (propagate + weight + folded resample gather)" if k1_bytes == 72.0 else "k_propagate_weight",
             "achieved": achieved / 1e9,
             "peak": HBM_PEAK / 1e9,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK,
             "traffic": None,
             "avg_kernel_ms": k1_avg_s * 1e3,
-            "algorithmic_bytes_per_launch": K1_BYTES_PER_PARTICLE * n,
-            "note": "FP64-VALU co-bound at L=32 (DESIGN.md): ~18 f64 ops per particle-landmark pair",
+            "algorithmic_bytes_per_launch": k1_bytes * n,
+            "note": "this kernel is FP64-VALU bound at L=32 (~19 f64-rate instructions per particle-landmark pair, "
+                    "VALU ~96 % busy per rocprofv3 PMC); the HBM-bound workload is `--workload fastslam` (DESIGN.md section 4)",
         },
         "kernel_ms_avg": step_kernel_ms,
         "ms_per_step_instrumented": res.get("seconds_instrumented", 0.0) / K * 1e3,
