@@ -47,15 +47,22 @@ struct Planes {
   double* s[2];  // [(3 + 6L) * N]: planes 0..2 = x, y, yaw; plane 3 + l*6 + f = landmark l field f
 };
 
-template <bool EXPLICIT>
+// LAZY: consume a pending resample -- read the pose of slot p from particle idx[p] of the live
+// set and write the predicted pose to slot p of the OTHER set (k_quantize_reduce flips Ctl.cur
+// afterwards).  Otherwise in place.
+template <bool EXPLICIT, bool LAZY>
 __global__ __launch_bounds__(kBlock) void k_fs1_predict(Planes pl, const Ctl* __restrict__ ctl, uint64_t n,
                                                        double u0, double u1, rr_fs1_model m, uint64_t seed,
                                                        unsigned int step, const double* __restrict__ z0,
-                                                       const double* __restrict__ z1) {
+                                                       const double* __restrict__ z1,
+                                                       const unsigned int* __restrict__ idx) {
   const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
-  double* s = pl.s[ctl->cur];
-  double x = s[p], y = s[n + p], yaw = s[2 * n + p];
+  const bool pending = LAZY && ctl->pending;
+  const double* __restrict__ src = pl.s[ctl->cur];
+  double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
+  const uint64_t j = pending ? idx[p] : p;
+  double x = src[j], y = src[n + j], yaw = src[2 * n + j];
   double a, b;
   if (EXPLICIT) {
     a = z0[p];
@@ -64,19 +71,21 @@ __global__ __launch_bounds__(kBlock) void k_fs1_predict(Planes pl, const Ctl* __
     rr_fs1_motion_noise(seed, step, p, &a, &b);
   }
   rr_fs1_predict_one(&x, &y, &yaw, u0, u1, a, b, m);
-  s[p] = x;
-  s[n + p] = y;
-  s[2 * n + p] = yaw;
+  dst[p] = x;
+  dst[n + p] = y;
+  dst[2 * n + p] = yaw;
 }
 
 // (particle, observation chunk).  blockIdx.y = chunk.  The chunk's observations are staged in
 // LDS and read back with wave-uniform addresses; each update loads the 6 planes of the observed
 // landmark for 64 consecutive particles (coalesced), runs the 2x2 EKF of rr_fs1_update_one and
 // stores only the fields that changed.
+template <bool LAZY>
 __global__ __launch_bounds__(kBlock) void k_fs1_observe(Planes pl, double* __restrict__ pw, Ctl* __restrict__ ctl,
                                                        uint64_t n, const double* __restrict__ z, int n_z,
                                                        int chunk_len, int n_chunks, rr_fs1_model m,
-                                                       double* __restrict__ partial) {
+                                                       double* __restrict__ partial,
+                                                       const unsigned int* __restrict__ idx) {
   extern __shared__ double s_z[];
   __shared__ double s_wmax[kBlock / rr::kWave];
   const int chunk = blockIdx.y;
@@ -87,20 +96,28 @@ __global__ __launch_bounds__(kBlock) void k_fs1_observe(Planes pl, double* __res
   const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   double acc = 0.0;
   if (p < n) {
-    double* s = pl.s[ctl->cur];
-    const double px = s[p], py = s[n + p], pyaw = s[2 * n + p];
+    // LAZY + pending: the maps of slot p still sit at particle idx[p] of the live set; every observed
+    // landmark is read from there and written (all six fields) to slot p of the other set, which
+    // folds the resample gather of the observed landmarks into this kernel's own traffic.  The
+    // pose was already moved by k_fs1_predict<LAZY>.
+    const bool pending = LAZY && ctl->pending;
+    const double* __restrict__ src = pl.s[ctl->cur];
+    double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
+    const uint64_t j = pending ? idx[p] : p;
+    const double px = dst[p], py = dst[n + p], pyaw = dst[2 * n + p];
     acc = chunk == 0 ? pw[p] : 1.0;
     for (int k = 0; k < k1 - k0; ++k) {
       const double zd = s_z[3 * k], za = s_z[3 * k + 1];
       const uint64_t id = (uint64_t)s_z[3 * k + 2];
-      double* e0 = s + (3 + id * 6) * n + p;
+      const double* in0 = src + (3 + id * 6) * n + j;
+      double* out0 = dst + (3 + id * 6) * n + p;
       double e[6], o[6];
 #pragma unroll
-      for (int f = 0; f < 6; ++f) o[f] = e[f] = e0[f * n];
+      for (int f = 0; f < 6; ++f) o[f] = e[f] = in0[f * n];
       acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
 #pragma unroll
       for (int f = 0; f < 6; ++f)
-        if (rr_d2u(e[f]) != rr_d2u(o[f])) e0[f * n] = e[f];
+        if (pending || rr_d2u(e[f]) != rr_d2u(o[f])) out0[f * n] = e[f];
     }
     if (n_chunks == 1) pw[p] = acc;
     else partial[(uint64_t)chunk * n + p] = acc;
@@ -168,25 +185,40 @@ __global__ __launch_bounds__(kBlock) void k_fs1_indices(const Ctl* __restrict__ 
 }
 
 // blockIdx.y selects a group of kPlanesPerThread planes; indices are non-decreasing, so each
-// plane is read almost sequentially
+// plane is read almost sequentially.  mode 0 (eager): the plan kernel flipped Ctl.cur already --
+// read set cur^1, write set cur, runs iff fired.  mode 1 (lazy): a pending resample is being
+// consumed -- read set cur, write set cur^1, runs iff pending (a settle flips afterwards).
+// plane_list != nullptr restricts the copy to the listed planes (the landmarks a lazy observe
+// did not touch).
 __global__ __launch_bounds__(kBlock) void k_fs1_gather(Planes pl, const Ctl* __restrict__ ctl,
                                                       const unsigned int* __restrict__ idx, uint64_t n,
-                                                      uint64_t n_planes) {
-  if (!ctl->fired) return;
+                                                      uint64_t n_planes, int lazy,
+                                                      const unsigned int* __restrict__ plane_list) {
+  if (lazy ? !ctl->pending : !ctl->fired) return;
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= n) return;
-  const int cur = ctl->cur;  // the plan kernel already flipped it: read the old set, write the live one
-  const double* __restrict__ in = pl.s[cur ^ 1];
-  double* __restrict__ out = pl.s[cur];
+  const int cur = ctl->cur;
+  const double* __restrict__ in = pl.s[lazy ? cur : cur ^ 1];
+  double* __restrict__ out = pl.s[lazy ? cur ^ 1 : cur];
   const uint64_t j = idx[k];
   const uint64_t p0 = (uint64_t)blockIdx.y * kPlanesPerThread;
   double v[kPlanesPerThread];
+  uint64_t pid[kPlanesPerThread];
+#pragma unroll
+  for (int q = 0; q < kPlanesPerThread; ++q) {
+    pid[q] = p0 + q < n_planes ? (plane_list ? plane_list[p0 + q] : p0 + q) : 0;
+    if (p0 + q < n_planes) v[q] = in[pid[q] * n + j];
+  }
 #pragma unroll
   for (int q = 0; q < kPlanesPerThread; ++q)
-    if (p0 + q < n_planes) v[q] = in[(p0 + q) * n + j];
-#pragma unroll
-  for (int q = 0; q < kPlanesPerThread; ++q)
-    if (p0 + q < n_planes) out[(p0 + q) * n + k] = v[q];
+    if (p0 + q < n_planes) out[pid[q] * n + k] = v[q];
+}
+
+__global__ void k_fs1_settle(Ctl* ctl) {
+  if (ctl->pending) {
+    ctl->cur ^= 1;
+    ctl->pending = 0;
+  }
 }
 
 // arg max of the weight with ties -> highest index (fastslam1.rs:269-274, Q14): the key
@@ -327,6 +359,9 @@ struct rr_fs1 {
   unsigned int step = 0, rstep = 0;
   int last_chunks = 1;
   bool wmax_live = false;  // Ctl.wmax_bits holds the maximum of the current weights
+  bool maybe_pending = false;  // a lazy resample plan was launched; its gather has not been consumed yet
+  unsigned int* plane_list = nullptr;  // device: planes of the landmarks a lazy observe leaves untouched
+  std::vector<unsigned int> plane_list_host;
   rr::Profiler prof{RR_FK_COUNT};
 };
 
@@ -389,7 +424,7 @@ ImageArgs image_args(const rr_fs1* h) {
   return a;
 }
 
-PlanArgs plan_args(const rr_fs1* h, int mode, double rho_override) {
+PlanArgs plan_args(const rr_fs1* h, int mode, double rho_override, bool lazy = false) {
   PlanArgs a{};
   a.n_global = h->n;
   a.neff_threshold = h->prm.nth;  // fastslam1.rs:262-265
@@ -400,16 +435,30 @@ PlanArgs plan_args(const rr_fs1* h, int mode, double rho_override) {
   a.seed = h->opt.seed;
   a.rstep = h->rstep;
   a.set_uniform_on_fire = 0;  // FastSLAM stores explicit weights (k_fs1_indices writes 1/n)
-  a.lazy_gather = 0;
+  a.lazy_gather = lazy ? 1 : 0;
   return a;
 }
 
-template <bool EXPLICIT>
+// make a pending lazy resample real: gather every plane, flip the live set
+rr_status materialise(rr_fs1* h) {
+  if (!h->maybe_pending) return RR_OK;
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_GATHER);
+    hipLaunchKernelGGL(k_fs1_gather, dim3(grid_for(h->n, kBlock), grid_for(h->n_planes, kPlanesPerThread)), dim3(kBlock), 0,
+                       h->stream, h->pl, h->ctl, h->idx, h->n, h->n_planes, 1, (const unsigned int*)nullptr);
+    hipLaunchKernelGGL(k_fs1_settle, dim3(1), dim3(1), 0, h->stream, h->ctl);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  h->maybe_pending = false;
+  return RR_OK;
+}
+
+template <bool EXPLICIT, bool LAZY>
 rr_status launch_predict(rr_fs1* h, const double u[2]) {
   rr::ScopedTimer t(h->prof, h->stream, RR_FK_PREDICT);
-  hipLaunchKernelGGL((k_fs1_predict<EXPLICIT>), dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl, h->ctl,
-                     h->n, u[0], u[1], host_model(h->prm), h->opt.seed, h->step, (const double*)h->noise,
-                     (const double*)(h->noise ? h->noise + h->n : nullptr));
+  hipLaunchKernelGGL((k_fs1_predict<EXPLICIT, LAZY>), dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl,
+                     h->ctl, h->n, u[0], u[1], host_model(h->prm), h->opt.seed, h->step, (const double*)h->noise,
+                     (const double*)(h->noise ? h->noise + h->n : nullptr), (const unsigned int*)h->idx);
   RR_HIP_TRY(hipGetLastError());
   h->step += 1;
   return RR_OK;
@@ -428,7 +477,7 @@ int choose_chunks(const rr_fs1* h, size_t n_z, bool dup) {
   return (int)((n_z + len - 1) / len);
 }
 
-rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup) {
+rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool lazy = false) {
   if (n_z == 0) {  // no observation: weights untouched, but the max must still be known
     RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
     hipLaunchKernelGGL(k_fs1_wmax, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
@@ -451,9 +500,16 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup) {
   h->last_chunks = chunks;
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_OBSERVE);
-    hipLaunchKernelGGL(k_fs1_observe, dim3(grid_for(h->n, kBlock), chunks), dim3(kBlock), 3 * (size_t)len * sizeof(double),
-                       h->stream, h->pl, h->pw, h->ctl, h->n, (const double*)h->z_dev, (int)n_z, len, chunks,
-                       host_model(h->prm), h->partial);
+    const dim3 grid(grid_for(h->n, kBlock), chunks);
+    const size_t lds = 3 * (size_t)len * sizeof(double);
+    if (lazy)
+      hipLaunchKernelGGL(k_fs1_observe<true>, grid, dim3(kBlock), lds, h->stream, h->pl, h->pw, h->ctl, h->n,
+                         (const double*)h->z_dev, (int)n_z, len, chunks, host_model(h->prm), h->partial,
+                         (const unsigned int*)h->idx);
+    else
+      hipLaunchKernelGGL(k_fs1_observe<false>, grid, dim3(kBlock), lds, h->stream, h->pl, h->pw, h->ctl, h->n,
+                         (const double*)h->z_dev, (int)n_z, len, chunks, host_model(h->prm), h->partial,
+                         (const unsigned int*)h->idx);
   }
   if (chunks > 1) {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_COMBINE);
@@ -464,7 +520,7 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup) {
   return RR_OK;
 }
 
-rr_status launch_sums(rr_fs1* h, int mode, double rho_override) {
+rr_status launch_sums(rr_fs1* h, int mode, double rho_override, bool lazy = false, int settle = 0) {
   if (!h->wmax_live) {  // the last plan kernel consumed the maximum (or the weights were renormalised since)
     RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
     hipLaunchKernelGGL(k_fs1_wmax, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
@@ -473,19 +529,19 @@ rr_status launch_sums(rr_fs1* h, int mode, double rho_override) {
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_QUANTIZE_REDUCE);
     hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
-                       (const double*)&h->ctl->wmax_bits, image_args(h), h->tile_total, h->tile_q2, 0);
+                       (const double*)&h->ctl->wmax_bits, image_args(h), h->tile_total, h->tile_q2, settle);
   }
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_SCAN_TILES);
     hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl,
-                       h->n_tiles, 1, plan_args(h, mode, rho_override), (uint64_t*)nullptr);
+                       h->n_tiles, 1, plan_args(h, mode, rho_override, lazy), (uint64_t*)nullptr);
   }
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
 }
 
 // normalise-or-resample after the sums (every kernel decides on the device whether it runs)
-rr_status launch_finish(rr_fs1* h) {
+rr_status launch_finish(rr_fs1* h, bool lazy = false) {
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_CDF);
     hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl, image_args(h),
@@ -500,13 +556,34 @@ rr_status launch_finish(rr_fs1* h) {
     hipLaunchKernelGGL(k_fs1_indices, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->ctl, h->cdf, h->n,
                        h->idx, h->pw);
   }
-  {
+  if (lazy) {
+    h->maybe_pending = true;  // the next update reads through idx (or an accessor materialises)
+  } else {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_GATHER);
     hipLaunchKernelGGL(k_fs1_gather, dim3(grid_for(h->n, kBlock), grid_for(h->n_planes, kPlanesPerThread)), dim3(kBlock), 0,
-                       h->stream, h->pl, h->ctl, h->idx, h->n, h->n_planes);
+                       h->stream, h->pl, h->ctl, h->idx, h->n, h->n_planes, 0, (const unsigned int*)nullptr);
   }
   RR_HIP_TRY(hipGetLastError());
   h->rstep += 1;
+  return RR_OK;
+}
+
+// lazy consume, part 3: the landmarks this step does NOT observe still have to move with their
+// particle -- gather just their planes (list built on the host from the observation ids)
+rr_status launch_rest_gather(rr_fs1* h, const double* z, size_t n_z) {
+  std::vector<char> seen(h->L, 0);
+  for (size_t k = 0; k < n_z; ++k) seen[(size_t)z[3 * k + 2]] = 1;
+  auto& list = h->plane_list_host;
+  list.clear();
+  for (uint64_t l = 0; l < h->L; ++l)
+    if (!seen[l])
+      for (int f = 0; f < 6; ++f) list.push_back((unsigned int)(3 + l * 6 + f));
+  if (list.empty()) return RR_OK;
+  RR_HIP_TRY(hipMemcpyAsync(h->plane_list, list.data(), list.size() * sizeof(unsigned int), hipMemcpyHostToDevice, h->stream));
+  rr::ScopedTimer t(h->prof, h->stream, RR_FK_GATHER);
+  hipLaunchKernelGGL(k_fs1_gather, dim3(grid_for(h->n, kBlock), grid_for(list.size(), kPlanesPerThread)), dim3(kBlock), 0,
+                     h->stream, h->pl, h->ctl, h->idx, h->n, (uint64_t)list.size(), 1, (const unsigned int*)h->plane_list);
+  RR_HIP_TRY(hipGetLastError());
   return RR_OK;
 }
 
@@ -592,6 +669,7 @@ rr_status rr_fs1_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs1
   RR_TRY_OR_CLEAN(hipMalloc(&h->partial, (size_t)kMaxChunks * h->n * sizeof(double)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->part_bits, 1024 * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->part_idx, 1024 * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->plane_list, (h->n_planes + 1) * sizeof(unsigned int)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->ctl, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipHostMalloc(&h->ctl_host, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipMemsetAsync(h->ctl, 0, sizeof(Ctl), h->stream));
@@ -620,6 +698,7 @@ void rr_fs1_destroy(rr_fs1* h) {
   (void)hipFree(h->noise);
   (void)hipFree(h->part_bits);
   (void)hipFree(h->part_idx);
+  (void)hipFree(h->plane_list);
   (void)hipFree(h->ctl);
   if (h->ctl_host) (void)hipHostFree(h->ctl_host);
   h->prof.destroy();
@@ -634,7 +713,8 @@ rr_status rr_fs1_predict(rr_fs1* h, const double u[2]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if ((s = validate_u(u)) != RR_OK) return s;
-  return launch_predict<false>(h, u);
+  if ((s = materialise(h)) != RR_OK) return s;
+  return launch_predict<false, false>(h, u);
 }
 
 rr_status rr_fs1_predict_with_noise(rr_fs1* h, const double u[2], const double* z0, const double* z1) {
@@ -645,7 +725,8 @@ rr_status rr_fs1_predict_with_noise(rr_fs1* h, const double u[2], const double* 
   if ((s = ensure_noise(h)) != RR_OK) return s;
   RR_HIP_TRY(hipMemcpyAsync(h->noise, z0, h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
   RR_HIP_TRY(hipMemcpyAsync(h->noise + h->n, z1, h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  return launch_predict<true>(h, u);
+  if ((s = materialise(h)) != RR_OK) return s;
+  return launch_predict<true, false>(h, u);
 }
 
 rr_status rr_fs1_observe(rr_fs1* h, const double* z, size_t n_z) {
@@ -653,12 +734,14 @@ rr_status rr_fs1_observe(rr_fs1* h, const double* z, size_t n_z) {
   if (s != RR_OK) return s;
   bool dup;
   if ((s = validate_z(h, z, n_z, &dup)) != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   return launch_observe(h, z, n_z, dup);
 }
 
 rr_status rr_fs1_normalize_resample(rr_fs1* h) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if ((s = launch_sums(h, 0, NAN)) != RR_OK) return s;
   return launch_finish(h);
 }
@@ -667,6 +750,7 @@ rr_status rr_fs1_resample_systematic(rr_fs1* h, double rho) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!(rho >= 0.0 && rho < 1.0)) return fail(RR_INVALID_PARAMETER, "rho must lie in [0, 1)");
+  if ((s = materialise(h)) != RR_OK) return s;
   if ((s = launch_sums(h, 1, rho)) != RR_OK) return s;
   return launch_finish(h);
 }
@@ -677,10 +761,23 @@ rr_status rr_fs1_update_async(rr_fs1* h, const double u[2], const double* z, siz
   if ((s = validate_u(u)) != RR_OK) return s;
   bool dup;
   if ((s = validate_z(h, z, n_z, &dup)) != RR_OK) return s;
-  if ((s = launch_predict<false>(h, u)) != RR_OK) return s;
-  if ((s = launch_observe(h, z, n_z, dup)) != RR_OK) return s;
-  if ((s = launch_sums(h, 0, NAN)) != RR_OK) return s;
-  return launch_finish(h);
+  if (dup) {
+    // the same landmark twice in one step: the second update must see the first one's result,
+    // which the read-through-idx scheme cannot give -- settle first, then update in place
+    if ((s = materialise(h)) != RR_OK) return s;
+    if ((s = launch_predict<false, false>(h, u)) != RR_OK) return s;
+    if ((s = launch_observe(h, z, n_z, dup)) != RR_OK) return s;
+    if ((s = launch_sums(h, 0, NAN, /*lazy=*/true, /*settle=*/0)) != RR_OK) return s;
+    return launch_finish(h, /*lazy=*/true);
+  }
+  // lazy: predict and observe read the previous resample's survivors through idx and write the
+  // other buffer set; unobserved landmarks are gathered separately; k_quantize_reduce settles
+  if ((s = launch_predict<false, true>(h, u)) != RR_OK) return s;
+  if ((s = launch_observe(h, z, n_z, dup, /*lazy=*/true)) != RR_OK) return s;
+  if (h->maybe_pending && (s = launch_rest_gather(h, z, n_z)) != RR_OK) return s;
+  h->maybe_pending = false;
+  if ((s = launch_sums(h, 0, NAN, /*lazy=*/true, /*settle=*/1)) != RR_OK) return s;
+  return launch_finish(h, /*lazy=*/true);
 }
 
 rr_status rr_fs1_synchronize(rr_fs1* h) {
@@ -699,6 +796,7 @@ rr_status rr_fs1_update(rr_fs1* h, const double u[2], const double* z, size_t n_
 rr_status rr_fs1_best_particle(rr_fs1* h, double out_pose[3], double* out_weight, uint64_t* out_index) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   const int blocks = (int)std::min<uint64_t>(1024, grid_for(h->n, kBlock));
   hipLaunchKernelGGL(k_fs1_argmax, dim3(blocks), dim3(kBlock), 0, h->stream, h->pw, h->n, h->part_bits, h->part_idx);
   hipLaunchKernelGGL(k_fs1_argmax_final, dim3(1), dim3(64), 0, h->stream, h->ctl, h->part_bits, h->part_idx, blocks);
@@ -720,6 +818,7 @@ rr_status rr_fs1_best_particle(rr_fs1* h, double out_pose[3], double* out_weight
 rr_status rr_fs1_get_landmarks(rr_fs1* h, uint64_t particle_index, double* out) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if (!out) return fail(RR_INVALID_PARAMETER, "null output");
   if (particle_index >= h->n) return fail(RR_INVALID_PARAMETER, "particle index out of range");
   if (h->L == 0) return RR_OK;
@@ -737,6 +836,7 @@ rr_status rr_fs1_get_landmarks(rr_fs1* h, uint64_t particle_index, double* out) 
 rr_status rr_fs1_get_state(rr_fs1* h, double* poses_out, double* maps_out) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if ((s = fetch_ctl(h)) != RR_OK) return s;
   const int cur = h->ctl_host->cur;
   double* tmp = h->pl.s[cur ^ 1];
@@ -765,6 +865,7 @@ rr_status rr_fs1_get_poses(rr_fs1* h, double* out) {
 rr_status rr_fs1_set_state(rr_fs1* h, const double* poses, const double* maps) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
   if ((s = fetch_ctl(h)) != RR_OK) return s;
   const int cur = h->ctl_host->cur;
   double* tmp = h->pl.s[cur ^ 1];

@@ -228,8 +228,11 @@ def test_best_particle_ties_go_last(fs):
     assert g.best_particle()[2] == 99_998
 
 
-@pytest.mark.parametrize("chunks", [1, 0])
-def test_trajectory_bit_exact_vs_det(fs, det, chunks):
+@pytest.mark.parametrize("chunks,read_every,n_observed", [(1, 1, 24), (0, 1, 24), (0, 4, 24), (3, 5, 17), (0, 100, 9)])
+def test_trajectory_bit_exact_vs_det(fs, det, chunks, read_every, n_observed):
+    """read_every > 1 leaves several updates between accessor calls, so the resample gathers are
+    consumed lazily by the next update's own loads; n_observed < L exercises the separate gather of
+    the unobserved landmarks' planes."""
     n, L, T = 2000, 24, 12
     lms = scene(L, 41)
     prm = fs.default_params()
@@ -245,6 +248,7 @@ def test_trajectory_bit_exact_vs_det(fs, det, chunks):
     fired_any = False
     for t in range(T):
         z = observations_for(fs, H.true_pose(t + 1), lms, seed=77, step=t)
+        z = np.ascontiguousarray(z[(t % 3):][:n_observed])  # a varying subset of the landmarks
         f.update([1.0, 0.1], z)
         used = f.counters()[2]
         fired = det.det_fs1_update(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(planes), 1.0, 0.1, dp(z), len(z), C.byref(md),
@@ -253,6 +257,8 @@ def test_trajectory_bit_exact_vs_det(fs, det, chunks):
         fired_any |= bool(fired)
         if fired:
             assert np.array_equal(f.last_resample_indices(), idx), f"indices differ at step {t}"
+        if (t + 1) % read_every and t != T - 1:
+            continue
         gp, gm = f.get_state()
         assert bits_equal(gp[:, 0], pw), f"weights step {t}"
         assert bits_equal(gp[:, 1], px) and bits_equal(gp[:, 2], py) and bits_equal(gp[:, 3], pyaw), f"poses step {t}"
