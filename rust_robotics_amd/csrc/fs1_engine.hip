@@ -106,14 +106,28 @@ __global__ __launch_bounds__(kBlock) void k_fs1_observe(Planes pl, double* __res
     const uint64_t j = pending ? idx[p] : p;
     const double px = dst[p], py = dst[n + p], pyaw = dst[2 * n + p];
     acc = chunk == 0 ? pw[p] : 1.0;
-    for (int k = 0; k < k1 - k0; ++k) {
+    // software pipeline: the six plane loads of observation k+1 are issued before the ~300
+    // FP64 instructions of update k, so two updates' worth of HBM requests are in flight per wave
+    // (the kernel runs at 3 waves per SIMD; bytes in flight, not arithmetic, set its speed)
+    const int nk = k1 - k0;
+    double nxt[6];
+    if (nk > 0) {
+      const double* in0 = src + (3 + (uint64_t)s_z[2] * 6) * n + j;
+#pragma unroll
+      for (int f = 0; f < 6; ++f) nxt[f] = in0[f * n];
+    }
+    for (int k = 0; k < nk; ++k) {
       const double zd = s_z[3 * k], za = s_z[3 * k + 1];
       const uint64_t id = (uint64_t)s_z[3 * k + 2];
-      const double* in0 = src + (3 + id * 6) * n + j;
       double* out0 = dst + (3 + id * 6) * n + p;
       double e[6], o[6];
 #pragma unroll
-      for (int f = 0; f < 6; ++f) o[f] = e[f] = in0[f * n];
+      for (int f = 0; f < 6; ++f) o[f] = e[f] = nxt[f];
+      if (k + 1 < nk) {
+        const double* in1 = src + (3 + (uint64_t)s_z[3 * k + 5] * 6) * n + j;
+#pragma unroll
+        for (int f = 0; f < 6; ++f) nxt[f] = in1[f * n];
+      }
       acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
 #pragma unroll
       for (int f = 0; f < 6; ++f)
