@@ -239,6 +239,12 @@ rr_status rr_pf_shard_adopt(rr_pf* h, const double* d_in);
  * whose systematic CDF target exceeds `bound` (n_global if none).  Slots served by a shard
  * with CDF interval (base, base + T] are [first_slot_above(base), first_slot_above(base + T)). */
 uint64_t rr_sys_first_slot_above(double rho, uint64_t total_global, uint64_t n_global, uint64_t bound);
+/* Host-only: the whole exchange plan of one step.  totals[n_shards] = every shard's T (phase B);
+ * out[src * n_shards + dst] = number of global output slots owned by shard dst (equal blocks of
+ * n_local slots) whose source particle lives on shard src.  Row `rank` gives the all-to-all send
+ * splits, column `rank` the receive splits.  Returns the first global slot shard `rank` serves. */
+uint64_t rr_sys_segment_matrix(double rho, const uint64_t* totals, int32_t n_shards, uint64_t n_global,
+                               uint64_t n_local, int32_t rank, int64_t* out);
 
 #ifdef __cplusplus
 }

@@ -163,6 +163,7 @@ def lib() -> C.CDLL:
     proto("rr_pf_shard_gather_slots", st, [H, u64, u64, V])
     proto("rr_pf_shard_adopt", st, [H, V])
     proto("rr_sys_first_slot_above", u64, [d, u64, u64, u64])
+    proto("rr_sys_segment_matrix", u64, [d, C.POINTER(u64), i32, u64, u64, i32, C.POINTER(C.c_int64)])
     FP, FO = C.POINTER(Fs1Params), C.POINTER(Fs1Options)
     proto("rr_fs1_params_default", None, [FP])
     proto("rr_fs1_options_default", None, [FO])

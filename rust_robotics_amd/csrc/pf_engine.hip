@@ -18,6 +18,7 @@
 //   k_moments(+final)    weighted first/second moments about particle 0 40 B / particle
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -1371,6 +1372,27 @@ uint64_t rr_sys_first_slot_above(double rho, uint64_t total_global, uint64_t n_g
     if (rr_sys_target(p, mid) > bound) hi = mid; else lo = mid + 1;
   }
   return lo;
+}
+
+uint64_t rr_sys_segment_matrix(double rho, const uint64_t* totals, int32_t n_shards, uint64_t n_global,
+                               uint64_t n_local, int32_t rank, int64_t* out) {
+  if (!totals || !out || n_shards <= 0) return 0;
+  uint64_t total = 0;
+  for (int g = 0; g < n_shards; ++g) total += totals[g];
+  const rr_sys_plan p = rr_sys_plan_make(rho, total, n_global ? n_global : 1);
+  uint64_t base = 0, first_of_rank = 0;
+  for (int src = 0; src < n_shards; ++src) {
+    const uint64_t lo = rr_sys_slots_upto_exact(p, total, base);
+    const uint64_t hi = rr_sys_slots_upto_exact(p, total, base + totals[src]);
+    if (src == rank) first_of_rank = lo;
+    base += totals[src];
+    for (int dst = 0; dst < n_shards; ++dst) {
+      const uint64_t a = std::max<uint64_t>(lo, (uint64_t)dst * n_local);
+      const uint64_t b = std::min<uint64_t>(hi, (uint64_t)(dst + 1) * n_local);
+      out[(size_t)src * n_shards + dst] = b > a ? (int64_t)(b - a) : 0;
+    }
+  }
+  return first_of_rank;
 }
 
 rr_status rr_pf_profile_enable(rr_pf* h, int32_t enable) {

@@ -55,23 +55,17 @@ def first_slot_above(rho: float, total_global: int, n_global: int, bound: int) -
     return int(_ffi.lib().rr_sys_first_slot_above(rho, total_global, n_global, bound))
 
 
-def segment_matrix(rho: float, totals: Sequence[int], n_global: int, n_local: int) -> np.ndarray:
-    """M[src][dst] = number of global output slots owned by rank dst whose source particle lives
-    on rank src, for systematic positions (i + rho) / N over the integer CDF with per-rank totals
-    ``totals``.  Pure integer arithmetic; every rank computes the same matrix."""
+def segment_matrix(rho: float, totals: Sequence[int], n_global: int, n_local: int, rank: int = 0):
+    """(M, first): M[src][dst] = number of global output slots owned by rank dst whose source particle
+    lives on rank src, for systematic positions (i + rho) / N over the integer CDF with per-rank totals
+    ``totals``; first = first global slot ``rank`` serves.  Pure integer arithmetic in the C ABI
+    (``rr_sys_segment_matrix``); every rank computes the same matrix."""
     G = len(totals)
-    total = int(sum(totals))
+    t = np.ascontiguousarray(totals, dtype=np.uint64)
     M = np.zeros((G, G), dtype=np.int64)
-    base = 0
-    for src in range(G):
-        lo = first_slot_above(rho, total, n_global, base)
-        hi = first_slot_above(rho, total, n_global, base + int(totals[src]))
-        base += int(totals[src])
-        for dst in range(G):
-            a, b = max(lo, dst * n_local), min(hi, (dst + 1) * n_local)
-            if b > a:
-                M[src, dst] = b - a
-    return M
+    first = _ffi.lib().rr_sys_segment_matrix(rho, t.ctypes.data_as(C.POINTER(C.c_uint64)), G, n_global, n_local, rank,
+                                             M.ctypes.data_as(C.POINTER(C.c_int64)))
+    return M, int(first)
 
 
 class HipShard:
@@ -216,11 +210,10 @@ class ShardedLocalizer:
             self.weight_share = plan.total_local / plan.total_global if plan.total_global else 1.0 / b.world
             return False
         totals = b.totals()
-        M = segment_matrix(plan.rho, totals, b.n_global, b.n_local)
-        self.last_matrix = M
         r = b.rank
+        M, first = segment_matrix(plan.rho, totals, b.n_global, b.n_local, r)
+        self.last_matrix = M
         n_send = int(M[r].sum())
-        first = first_slot_above(plan.rho, plan.total_global, b.n_global, plan.base)
         send = b.gather_slots(first, n_send)
         recv = b.recv_buf
         assert int(M[:, r].sum()) == b.n_local, "every output slot of this rank must have exactly one source"

@@ -1,0 +1,115 @@
+"""Edge sizes and long runs of the GPU engine: particle counts around every tile boundary the
+kernels use (64, 256, 512, 2048), more observations than fit in the launch packet, no
+observations, BASELINE configs[4]'s per-GPU shape, and a 400-step run."""
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import dp, u32p, u64p
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def loc():
+    import rust_robotics_amd.localization as l
+
+    return l
+
+
+def bits_eq(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint64), np.ascontiguousarray(b).view(np.uint64))
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 65, 255, 257, 511, 513, 2047, 2049, 4097, 10_001])
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_odd_particle_counts_bit_exact(loc, det, n, scheme):
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.5, velocity_noise=0.3,
+                                           yaw_rate_noise=math.radians(5.0))
+    pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=9, resample_scheme=scheme, record_indices=True)
+    x, y, yaw, v = (np.empty(n) for _ in range(4))
+    st = np.array([0.0, 0.0, 0.0, 1.0])
+    det.det_pf_init(n, 9, 0, dp(st), dp(x), dp(y), dp(yaw), dp(v))
+    d = H.DetPF(det, x, y, yaw, v, dt=0.1, sigma=0.5, sigma_v=0.3, sigma_w=math.radians(5.0), threshold=1.0, gate=1, scheme=scheme,
+                lik=0, seed=9)
+    rng = np.random.default_rng(10)
+    for t in range(6):
+        obs = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng)
+        if t % 2:  # alternate the asynchronous (lazy) and the synchronous entry points
+            pf.step_async([1.0, 0.1], obs)
+        else:
+            pf.step([1.0, 0.1], obs)
+        d.step([1.0, 0.1], obs)
+    got = pf.get_particles_array()
+    assert np.array_equal(pf.last_resample_indices(), d.idx)
+    for k, e in enumerate((d.x, d.y, d.yaw, d.v)):
+        assert bits_eq(got[:, k], e), f"n={n} col {k}"
+    assert np.all(got[:, 4] == 1.0 / n)
+
+
+@pytest.mark.parametrize("L", [0, 1, 96, 97, 500])
+def test_observation_counts_around_the_kernarg_limit(loc, det, L):
+    n = 3000
+    lms = H.landmarks_grid(max(L, 1), 3)[:L]
+    pose = H.true_pose(5)
+    obs = H.observations(lms, pose, 0.5, np.random.default_rng(4)) if L else np.zeros((0, 3))
+    x, y, yaw, v = H.cloud(n, 5, center=(pose[0], pose[1], pose[2], 1.0))
+    cfg = loc.ParticleFilterConfig(n_particles=n, range_noise=0.5)
+    pf = loc.ParticleFilterLocalizer(cfg)
+    pf.set_particles_array(H.aos(x, y, yaw, v, np.full(n, 1.0 / n)))
+    pf.update_with_observations(obs)
+    w = np.empty(n)
+    det.det_pf_weights(n, dp(x), dp(y), dp(w), dp(np.ascontiguousarray(obs)), L, 0.5, 0)
+    assert bits_eq(pf.raw_weights(), w)
+    pf2 = loc.ParticleFilterLocalizer(cfg, seed=3, resample_scheme=1)
+    e = pf2.step([1.0, 0.1], obs)
+    assert np.all(np.isfinite(e))
+
+
+def test_long_run_stays_locked_and_finite(loc):
+    n = 20_000
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.3, velocity_noise=0.5,
+                                           yaw_rate_noise=math.radians(10.0))
+    pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=11, resample_scheme=1)
+    rng = np.random.default_rng(12)
+    for t in range(400):
+        pf.step_async([1.0, 0.1], H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.3, rng))
+    est = pf.estimate()
+    assert np.all(np.isfinite(est))
+    assert np.hypot(*(est[:2] - H.true_pose(400)[:2])) < 1.0
+    p = pf.get_particles_array()
+    assert np.all(np.isfinite(p)) and np.all(p[:, 4] == 1.0 / n)
+    cov = pf.calc_covariance()
+    assert np.all(np.diag(cov) >= 0)
+
+
+def test_config5_per_gpu_shape_properties(loc, det):
+    """BASELINE configs[4]: 1.6e7 particles x 64 landmarks over 8 GPUs = 2e6 x 64 per GPU"""
+    n, L = 2_000_000, 64
+    lms = H.landmarks_grid(L, 2)
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
+    pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=2, resample_scheme=1, record_indices=True)
+    rng = np.random.default_rng(3)
+    for t in range(4):
+        pf.step_async([1.0, 0.1], H.observations(lms, H.true_pose(t + 1), 0.2, rng))
+    pf.predict_with_control([1.0, 0.1])
+    pf.update_with_observations(H.observations(lms, H.true_pose(5), 0.2, rng))
+    before = pf.get_particles_array()
+    raw = pf.raw_weights()
+    assert abs(before[:, 4].sum() - 1.0) < 1e-9
+    pf.resample()
+    idx = pf.last_resample_indices()
+    after = pf.get_particles_array()
+    assert np.all(np.diff(idx.astype(np.int64)) >= 0)
+    assert np.array_equal(after[:, :4].view(np.uint64), before[idx, :4].view(np.uint64))
+    cnt = np.bincount(idx, minlength=n)
+    assert np.max(np.abs(cnt - n * before[:, 4])) <= 1.0 + 1e-6  # systematic: offspring within 1 of n*w
+    fx = H.det_fixed(det, raw)
+    cdf = H.det_cdf(det, raw, fx)
+    e = np.empty(n, np.uint32)
+    rstep = pf.counters()[1] - 1
+    det.det_indices_systematic(n, u64p(cdf), fx["total"], n, 0, n, det.det_resample_rho(2, rstep), u32p(e))
+    assert np.array_equal(idx, e)

@@ -67,7 +67,8 @@ def test_segment_matrix_properties():
         if sum(totals) == 0:
             totals[-1] = 1
         rho = float(np.floor(rng.random() * 2**53) / 2**53)
-        M = segment_matrix(rho, totals, n, n_local)
+        M, first = segment_matrix(rho, totals, n, n_local, 0)
+        assert first == 0
         assert M.sum() == n
         assert np.all(M.sum(axis=0) == n_local)  # every destination slot has exactly one source
         assert first_slot_above(rho, sum(totals), n, sum(totals)) == n
