@@ -25,6 +25,22 @@ HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 K1_BYTES = {"systematic": 72.0, "multinomial": 64.0}
 
 
+def measured_traffic(kernel_prefix, workload):
+    """HBM bytes per launch of `kernel_prefix` from the committed PMC passes (separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, read side doubled as MI355X_MICROARCH.md
+    prescribes for gfx950): profiles/r01c_pmc_hbm_traffic.csv.  None if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01c_pmc_hbm_traffic.csv")
+    try:
+        import csv
+
+        for r in csv.DictReader(open(path)):
+            if r["workload"] == workload and r["kernel"].startswith(kernel_prefix):
+                return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6
+    except Exception:
+        pass
+    return None
+
+
 def make_scene(L, steps, seed):
     from tests import helpers as H
 
@@ -153,7 +169,10 @@ def run_fastslam(args):
         "config": {"workload": f"FastSLAM 1.0 (BASELINE.json configs[2]): {n} particles x {L} landmarks, all observed, 2x2 EKF "
                                f"branch, N_eff-gated systematic resample", "particles_per_gpu": n, "landmarks": L},
         "roofline": {"bound": "hbm", "kernel": "k_fs1_observe", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK, "traffic": None, "avg_kernel_ms": avg_s * 1e3,
+                     "frac": achieved / HBM_PEAK,
+                     "traffic": measured_traffic("k_fs1_observe", "fs1") if (n, L) == (100_000, 200) else None,
+                     "traffic_source": "profiles/r01c_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
+                     "avg_kernel_ms": avg_s * 1e3,
                      "algorithmic_bytes_per_launch": per_launch},
         "kernel_ms_avg": {k: v[1] / max(v[0], 1) for k, v in prof.items() if v[0]},
         "kernel_launches": {k: v[0] for k, v in prof.items() if v[0]},
@@ -162,8 +181,8 @@ def run_fastslam(args):
         "best_particle": {"index": i, "weight": w, "pose": [float(a) for a in pose]},
     }
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = fs1_cpu_baseline(min(n, 2000), L, zs)
-    print(json.dumps(out))
+        out["cpu_baseline"] = fs1_cpu_baseline(min(n, 20000), L, zs)
+    emit(out)
 
 
 def main():
@@ -180,6 +199,8 @@ def main():
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (RCCL) path even at --gpus 1")
     args = ap.parse_args()
 
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's version banner off stdout
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -272,7 +293,8 @@ def main():
             "peak": HBM_PEAK / 1e9,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK,
-            "traffic": None,
+            "traffic": measured_traffic("k_step_lazy", "mcl") if k1_bytes == 72.0 and n == 1_000_000 else None,
+            "traffic_source": "profiles/r01c_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
             "avg_kernel_ms": k1_avg_s * 1e3,
             "algorithmic_bytes_per_launch": k1_bytes * n,
             "note": "this kernel is FP64-VALU bound at L=32 (~19 f64-rate instructions per particle-landmark pair, "
@@ -284,7 +306,20 @@ def main():
     }
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(n, L, obs_list)
-    print(json.dumps(out))
+    emit(out)
+
+
+def emit(out):
+    """ONE JSON line, last on stdout: native libraries (RCCL's version banner) write through C
+    stdio, so drain that buffer first."""
+    import ctypes
+
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
 
 
 if __name__ == "__main__":

@@ -246,6 +246,29 @@ uint64_t rr_sys_first_slot_above(double rho, uint64_t total_global, uint64_t n_g
 uint64_t rr_sys_segment_matrix(double rho, const uint64_t* totals, int32_t n_shards, uint64_t n_global,
                                uint64_t n_local, int32_t rank, int64_t* out);
 
+/* ---- native sharded step: the phases above driven from inside the library with RCCL called
+ * directly (librccl is dlopen'ed on first use, so single-GPU users never load it).  One
+ * communicator per process/GPU; the 128-byte unique id is created on one rank and handed to the
+ * others by whatever launcher the caller has (bench.py: torch.distributed/gloo broadcast). */
+typedef struct rr_comm rr_comm;
+#define RR_COMM_UNIQUE_ID_BYTES 128
+/* ncclGetUniqueId */
+rr_status rr_comm_unique_id(uint8_t out[RR_COMM_UNIQUE_ID_BYTES]);
+/* ncclCommInitRank on `device` */
+rr_status rr_comm_create(const uint8_t id[RR_COMM_UNIQUE_ID_BYTES], int32_t rank, int32_t n_ranks, int32_t device,
+                         rr_comm** out);
+void rr_comm_destroy(rr_comm* c);
+/* One whole sharded MCL/PF step (systematic resampling) of this rank: phases A-E with
+ * all-reduce(MAX) / all-gather / grouped send-recv in between, everything enqueued on the
+ * filter's stream; the only host wait is the D2H of the G totals that sizes the segments.
+ * Every rank of the communicator must call it with the same control and observations. */
+rr_status rr_pf_shard_step(rr_pf* h, rr_comm* c, const double control[2], const double* obs, size_t n_obs);
+/* global weighted mean (4) and covariance (16, row-major) over all shards (particle_filter.rs:382-413);
+ * collective: every rank must call it */
+rr_status rr_pf_shard_estimate(rr_pf* h, rr_comm* c, double est[4], double cov[16]);
+/* particles that crossed a shard boundary in the last resample (sum of off-diagonal segment sizes) */
+uint64_t rr_pf_shard_last_migrated(const rr_pf* h);
+
 #ifdef __cplusplus
 }
 #endif

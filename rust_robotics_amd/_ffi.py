@@ -163,6 +163,13 @@ def lib() -> C.CDLL:
     proto("rr_pf_shard_gather_slots", st, [H, u64, u64, V])
     proto("rr_pf_shard_adopt", st, [H, V])
     proto("rr_sys_first_slot_above", u64, [d, u64, u64, u64])
+    U8 = C.POINTER(C.c_uint8)
+    proto("rr_comm_unique_id", st, [U8])
+    proto("rr_comm_create", st, [U8, i32, i32, i32, C.POINTER(H)])
+    proto("rr_comm_destroy", None, [H])
+    proto("rr_pf_shard_step", st, [H, H, P, P, sz])
+    proto("rr_pf_shard_estimate", st, [H, H, P, P])
+    proto("rr_pf_shard_last_migrated", u64, [H])
     proto("rr_sys_segment_matrix", u64, [d, C.POINTER(u64), i32, u64, u64, i32, C.POINTER(C.c_int64)])
     FP, FO = C.POINTER(Fs1Params), C.POINTER(Fs1Options)
     proto("rr_fs1_params_default", None, [FP])

@@ -49,6 +49,11 @@ using rr::kMaxObsKernarg;
 using rr::kMomentBlocks;
 using rr::kNumMoments;
 
+// layout of ncclUniqueId (rccl.h:43): passed by value to ncclCommInitRank
+struct ncclUniqueIdPod {
+  char internal[128];
+};
+
 namespace {
 
 struct Bufs {
@@ -480,6 +485,7 @@ struct rr_pf {
   int k1_blocks_per_cu = 8;
   bool wmax_live = false;        // Ctl.wmax_bits holds the maximum of the current raw weights
   bool wmax_bits_clean = false;  // Ctl.wmax_bits is known to be zero
+  uint64_t last_migrated = 0;
   bool maybe_pending = false;    // a lazy resample plan was launched and nothing has consumed its markers yet
   rr_pf_lik lik{};
   std::vector<double> landmarks;
@@ -1393,6 +1399,254 @@ uint64_t rr_sys_segment_matrix(double rho, const uint64_t* totals, int32_t n_sha
     }
   }
   return first_of_rank;
+}
+
+// ---------------------------------------------------------------------------------------------
+// native sharded step: RCCL through dlopen
+}  // extern "C"
+
+#include <dlfcn.h>
+
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, ncclUniqueIdPod, int) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+// nccl.h enum values (stable ABI): ncclUint64 = 5, ncclFloat64 = 8; ncclSum = 0, ncclMax = 2
+constexpr int kNcclUint64 = 5, kNcclFloat64 = 8, kNcclMax = 2;
+
+Rccl& rccl() {
+  static Rccl r;
+  return r;
+}
+
+rr_status rccl_load() {
+  Rccl& r = rccl();
+  if (r.lib) return RR_OK;
+  // librccl.so.1 already mapped by the process (e.g. by torch) is reused; otherwise /opt/rocm/lib's
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  for (const char* n : names)
+    if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+  if (!r.lib) return fail(RR_RUNTIME_ERROR, std::string("cannot load librccl: ") + dlerror());
+  auto sym = [&](const char* n) { return dlsym(r.lib, n); };
+  r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
+  r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+  r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+  r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+  r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+  r.Send = (decltype(r.Send))sym("ncclSend");
+  r.Recv = (decltype(r.Recv))sym("ncclRecv");
+  r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+  r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
+  r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.AllGather || !r.Send || !r.Recv ||
+      !r.GroupStart || !r.GroupEnd) {
+    r.lib = nullptr;
+    return fail(RR_RUNTIME_ERROR, "librccl is missing a required symbol");
+  }
+  return RR_OK;
+}
+
+#define RR_NCCL_TRY(expr)                                                                                     \
+  do {                                                                                                        \
+    int _e = (expr);                                                                                          \
+    if (_e != 0)                                                                                              \
+      return fail(RR_RUNTIME_ERROR, std::string(#expr) + ": " +                                              \
+                                        (rccl().GetErrorString ? rccl().GetErrorString(_e) : "rccl error")); \
+  } while (0)
+}  // namespace
+
+struct rr_comm {
+  void* comm = nullptr;
+  int rank = 0, n_ranks = 1, device = 0;
+  // device scratch for the collectives
+  double* d_wmax = nullptr;      // [1]
+  uint64_t* d_sums = nullptr;    // [3]
+  uint64_t* d_all = nullptr;     // [n_ranks][3]
+  uint64_t* h_all = nullptr;     // pinned
+  double* d_send = nullptr;      // [cap_send][4]
+  double* d_recv = nullptr;      // [n_local][4]
+  size_t cap_send = 0, cap_recv = 0;
+  double* d_mom = nullptr;       // moments all-gather: [n_ranks][21]
+  double* h_mom = nullptr;       // pinned
+  std::vector<int64_t> matrix;
+};
+
+extern "C" {
+
+rr_status rr_comm_unique_id(uint8_t out[RR_COMM_UNIQUE_ID_BYTES]) {
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  rr_status s = rccl_load();
+  if (s != RR_OK) return s;
+  RR_NCCL_TRY(rccl().GetUniqueId(out));
+  return RR_OK;
+}
+
+rr_status rr_comm_create(const uint8_t id[RR_COMM_UNIQUE_ID_BYTES], int32_t rank, int32_t n_ranks, int32_t device,
+                         rr_comm** out) {
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  *out = nullptr;
+  if (!id || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(RR_INVALID_PARAMETER, "bad communicator arguments");
+  rr_status s = rccl_load();
+  if (s != RR_OK) return s;
+  RR_HIP_TRY(hipSetDevice(device));
+  rr_comm* c = new rr_comm();
+  c->rank = rank;
+  c->n_ranks = n_ranks;
+  c->device = device;
+  ncclUniqueIdPod uid;
+  std::memcpy(uid.internal, id, RR_COMM_UNIQUE_ID_BYTES);
+  int e = rccl().CommInitRank(&c->comm, n_ranks, uid, rank);
+  if (e != 0) {
+    delete c;
+    return fail(RR_RUNTIME_ERROR, std::string("ncclCommInitRank: ") + (rccl().GetErrorString ? rccl().GetErrorString(e) : "error"));
+  }
+  auto bad = [&](hipError_t err) {
+    rr_comm_destroy(c);
+    return fail(RR_RUNTIME_ERROR, std::string("communicator scratch: ") + hipGetErrorString(err));
+  };
+  hipError_t err;
+  if ((err = hipMalloc(&c->d_wmax, sizeof(double))) != hipSuccess) return bad(err);
+  if ((err = hipMalloc(&c->d_sums, 3 * sizeof(uint64_t))) != hipSuccess) return bad(err);
+  if ((err = hipMalloc(&c->d_all, 3 * n_ranks * sizeof(uint64_t))) != hipSuccess) return bad(err);
+  if ((err = hipHostMalloc(&c->h_all, 3 * n_ranks * sizeof(uint64_t))) != hipSuccess) return bad(err);
+  if ((err = hipMalloc(&c->d_mom, 21 * (n_ranks + 1) * sizeof(double))) != hipSuccess) return bad(err);
+  if ((err = hipHostMalloc(&c->h_mom, 21 * (n_ranks + 1) * sizeof(double))) != hipSuccess) return bad(err);
+  c->matrix.assign((size_t)n_ranks * n_ranks, 0);
+  *out = c;
+  return RR_OK;
+}
+
+void rr_comm_destroy(rr_comm* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
+  (void)hipFree(c->d_wmax);
+  (void)hipFree(c->d_sums);
+  (void)hipFree(c->d_all);
+  if (c->h_all) (void)hipHostFree(c->h_all);
+  (void)hipFree(c->d_send);
+  (void)hipFree(c->d_recv);
+  (void)hipFree(c->d_mom);
+  if (c->h_mom) (void)hipHostFree(c->h_mom);
+  delete c;
+}
+
+rr_status rr_pf_shard_step(rr_pf* h, rr_comm* c, const double control[2], const double* obs, size_t n_obs) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!c) return fail(RR_INVALID_PARAMETER, "null communicator");
+  if (h->n_global != h->n * (uint64_t)c->n_ranks || h->opt.first_global_index != h->n * (uint64_t)c->rank)
+    return fail(RR_INVALID_PARAMETER, "shard geometry does not match the communicator (equal blocks, rank * n_local)");
+  Rccl& R = rccl();
+  // A: propagate + weight, local maximum
+  if ((s = rr_pf_shard_propagate_weight(h, control, obs, n_obs, c->d_wmax)) != RR_OK) return s;
+  RR_NCCL_TRY(R.AllReduce(c->d_wmax, c->d_wmax, 1, kNcclFloat64, kNcclMax, c->comm, h->stream));
+  // B: integer image under the global maximum, local sums
+  if ((s = rr_pf_shard_quantize(h, c->d_wmax, c->d_sums)) != RR_OK) return s;
+  RR_NCCL_TRY(R.AllGather(c->d_sums, c->d_all, 3, kNcclUint64, c->comm, h->stream));
+  // C: plan + local marking; the G totals come back to the host to size the segments
+  if ((s = rr_pf_shard_cdf(h, c->d_all, c->n_ranks, c->rank)) != RR_OK) return s;
+  RR_HIP_TRY(hipMemcpyAsync(c->h_all, c->d_all, 3 * c->n_ranks * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  rr_pf_shard_plan plan;
+  if ((s = rr_pf_shard_get_plan(h, &plan)) != RR_OK) return s;  // synchronises the stream
+  if (!plan.fired) {
+    h->last_migrated = 0;
+    return RR_OK;
+  }
+  const int G = c->n_ranks, r = c->rank;
+  std::vector<uint64_t> totals(G);
+  for (int g = 0; g < G; ++g) totals[g] = c->h_all[3 * g];
+  const uint64_t first = rr_sys_segment_matrix(plan.rho, totals.data(), G, h->n_global, h->n, r, c->matrix.data());
+  const int64_t* M = c->matrix.data();
+  uint64_t n_send = 0, n_recv = 0, migrated = 0;
+  for (int g = 0; g < G; ++g) {
+    n_send += (uint64_t)M[(size_t)r * G + g];
+    n_recv += (uint64_t)M[(size_t)g * G + r];
+    for (int d = 0; d < G; ++d)
+      if (g != d) migrated += (uint64_t)M[(size_t)g * G + d];
+  }
+  h->last_migrated = migrated;
+  if (n_recv != h->n) return fail(RR_RUNTIME_ERROR, "segment plan does not cover this shard's slots exactly once");
+  if (n_send > c->cap_send) {
+    if (c->d_send) RR_HIP_TRY(hipFree(c->d_send));
+    c->d_send = nullptr;
+    c->cap_send = 0;
+    RR_HIP_TRY(hipMalloc(&c->d_send, (n_send + n_send / 4 + 1024) * 4 * sizeof(double)));
+    c->cap_send = n_send + n_send / 4 + 1024;
+  }
+  if (h->n > c->cap_recv) {
+    if (c->d_recv) RR_HIP_TRY(hipFree(c->d_recv));
+    c->d_recv = nullptr;
+    RR_HIP_TRY(hipMalloc(&c->d_recv, h->n * 4 * sizeof(double)));
+    c->cap_recv = h->n;
+  }
+  // D: gather what the served slots need into one contiguous buffer, exchange the segments
+  if ((s = rr_pf_shard_gather_slots(h, first, n_send, c->d_send)) != RR_OK) return s;
+  RR_NCCL_TRY(R.GroupStart());
+  uint64_t so = 0, ro = 0;
+  for (int g = 0; g < G; ++g) {
+    const uint64_t ns = (uint64_t)M[(size_t)r * G + g], nr = (uint64_t)M[(size_t)g * G + r];
+    if (ns) RR_NCCL_TRY(R.Send(c->d_send + 4 * so, 4 * ns, kNcclFloat64, g, c->comm, h->stream));
+    if (nr) RR_NCCL_TRY(R.Recv(c->d_recv + 4 * ro, 4 * nr, kNcclFloat64, g, c->comm, h->stream));
+    so += ns;
+    ro += nr;
+  }
+  RR_NCCL_TRY(R.GroupEnd());
+  // E: adopt
+  return rr_pf_shard_adopt(h, c->d_recv);
+}
+
+uint64_t rr_pf_shard_last_migrated(const rr_pf* h) { return h ? h->last_migrated : 0; }
+
+rr_status rr_pf_shard_estimate(rr_pf* h, rr_comm* c, double est[4], double cov[16]) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!c) return fail(RR_INVALID_PARAMETER, "null communicator");
+  double e[4], cv[16];
+  if ((s = compute_moments(h, e, cv)) != RR_OK) return s;
+  // weight share of this shard: 1/G after a resample, T_local / T otherwise
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  const Ctl& k = *h->ctl_host;
+  double share = 1.0 / c->n_ranks;
+  if (!k.weights_uniform && k.total > 0) share = (double)k.total_local / (double)k.total;
+  double* rec = c->h_mom + 21 * (size_t)c->n_ranks;
+  rec[0] = share;
+  std::memcpy(rec + 1, e, sizeof e);
+  std::memcpy(rec + 5, cv, sizeof cv);
+  double* d_rec = c->d_mom + 21 * (size_t)c->n_ranks;
+  RR_HIP_TRY(hipMemcpyAsync(d_rec, rec, 21 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  RR_NCCL_TRY(rccl().AllGather(d_rec, c->d_mom, 21, kNcclFloat64, c->comm, h->stream));
+  RR_HIP_TRY(hipMemcpyAsync(c->h_mom, c->d_mom, 21 * (size_t)c->n_ranks * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  double W = 0.0, mean[4] = {0, 0, 0, 0};
+  for (int g = 0; g < c->n_ranks; ++g) {
+    const double* a = c->h_mom + 21 * (size_t)g;
+    W += a[0];
+    for (int q = 0; q < 4; ++q) mean[q] += a[0] * a[1 + q];
+  }
+  for (int q = 0; q < 4; ++q) mean[q] /= W;
+  if (est) std::memcpy(est, mean, sizeof mean);
+  if (cov) {
+    for (int q = 0; q < 16; ++q) cov[q] = 0.0;
+    for (int g = 0; g < c->n_ranks; ++g) {
+      const double* a = c->h_mom + 21 * (size_t)g;
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) cov[4 * i + j] += a[0] * (a[5 + 4 * i + j] + (a[1 + i] - mean[i]) * (a[1 + j] - mean[j]));
+    }
+    for (int q = 0; q < 16; ++q) cov[q] /= W;
+  }
+  return RR_OK;
 }
 
 rr_status rr_pf_profile_enable(rr_pf* h, int32_t enable) {

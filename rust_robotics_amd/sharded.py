@@ -242,44 +242,143 @@ class ShardedLocalizer:
         return mean, cov / W
 
 
+class NativeShard:
+    """One shard driven entirely from inside the library: ``rr_pf_shard_step`` runs the phases
+    and calls RCCL itself (include/rr_pf.h "native sharded step").  Python only creates the
+    communicator -- the 128-byte unique id is created on rank 0 and handed over by ``exchange``,
+    any callable that broadcasts a bytes object from rank 0 (bench.py uses torch.distributed/gloo)."""
+
+    def __init__(self, rank: int, world: int, device: int, n_local: int, exchange, *, seed: int, range_noise=0.2,
+                 velocity_noise=2.0, yaw_rate_noise=math.radians(40.0), dt=0.1, gate=_ffi.RR_GATE_ALWAYS,
+                 resample_threshold=1.0, likelihood_mode=_ffi.RR_LIK_FUSED, initial_state=None):
+        L = _ffi.lib()
+        self.L, self.rank, self.world, self.n_local = L, rank, world, n_local
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            self._check(L.rr_comm_unique_id(uid))
+        raw = exchange(bytes(uid))
+        uid = (C.c_uint8 * 128).from_buffer_copy(raw)
+        self.comm = C.c_void_p()
+        self._check(L.rr_comm_create(uid, rank, world, device, C.byref(self.comm)))
+        cfg = _ffi.PfConfig(n_local, resample_threshold, range_noise, velocity_noise, yaw_rate_noise, dt)
+        opt = _ffi.PfOptions()
+        L.rr_pf_options_default(C.byref(opt))
+        opt.device, opt.seed = device, seed
+        opt.resample_scheme, opt.resample_gate, opt.likelihood_mode = _ffi.RR_RESAMPLE_SYSTEMATIC, gate, likelihood_mode
+        opt.first_global_index, opt.n_global = rank * n_local, n_local * world
+        self.h = C.c_void_p()
+        if initial_state is None:
+            self._check(L.rr_pf_create(C.byref(cfg), C.byref(opt), C.byref(self.h)))
+        else:
+            st = np.ascontiguousarray(initial_state, dtype=np.float64)
+            self._check(L.rr_pf_create_with_state(C.byref(cfg), C.byref(opt), st.ctypes.data_as(C.POINTER(C.c_double)), C.byref(self.h)))
+
+    def _check(self, status: int) -> None:
+        if status != _ffi.RR_OK:
+            kind = RoboticsError.invalid_parameter if status == _ffi.RR_INVALID_PARAMETER else RoboticsError.runtime
+            raise kind(_ffi.last_error())
+
+    def step(self, u, obs) -> None:
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, 3)
+        dp = C.POINTER(C.c_double)
+        self._check(self.L.rr_pf_shard_step(self.h, self.comm, u.ctypes.data_as(dp), obs.ctypes.data_as(dp) if obs.size else None,
+                                            obs.shape[0]))
+
+    def estimate(self):
+        e, c = np.empty(4), np.empty(16)
+        dp = C.POINTER(C.c_double)
+        self._check(self.L.rr_pf_shard_estimate(self.h, self.comm, e.ctypes.data_as(dp), c.ctypes.data_as(dp)))
+        return e, c.reshape(4, 4)
+
+    def particles(self) -> np.ndarray:
+        out = np.empty((self.n_local, 5))
+        self._check(self.L.rr_pf_get_particles(self.h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def migrated(self) -> int:
+        return int(self.L.rr_pf_shard_last_migrated(self.h))
+
+    def synchronize(self) -> None:
+        self._check(self.L.rr_pf_synchronize(self.h))
+
+    def profile(self, on: bool) -> None:
+        self._check(self.L.rr_pf_profile_enable(self.h, 1 if on else 0))
+        if on:
+            self._check(self.L.rr_pf_profile_reset(self.h))
+
+    def profile_read(self) -> dict:
+        out = {}
+        for k in range(_ffi.RR_K_COUNT):
+            n, ms = C.c_uint64(), C.c_double()
+            self._check(self.L.rr_pf_profile_read(self.h, k, C.byref(n), C.byref(ms)))
+            out[self.L.rr_pf_kernel_name(k).decode()] = (n.value, ms.value)
+        return out
+
+    def close(self) -> None:
+        if self.h:
+            self.L.rr_pf_destroy(self.h)
+            self.h = None
+        if self.comm:
+            self.L.rr_comm_destroy(self.comm)
+            self.comm = None
+
+
+def gloo_exchange(dist):
+    """broadcast a bytes object from rank 0 over an initialised torch.distributed group"""
+
+    def exchange(raw: bytes) -> bytes:
+        box = [raw]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    return exchange
+
+
 def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, lik):
     """bench.py's N > 1 leg: weak scaling, n_local particles per GPU, barrier + synchronize on
-    both sides of the K timed steps, MAX over ranks."""
+    both sides of the K timed steps, MAX over ranks.  The step itself is the native one
+    (rr_pf_shard_step, RCCL called from inside the library); torch.distributed (gloo) only
+    bootstraps the communicator and provides the timing barrier."""
     import torch
     import torch.distributed as dist
 
     if scheme != _ffi.RR_RESAMPLE_SYSTEMATIC:
         raise SystemExit("the sharded path resamples systematically (use --scheme systematic)")
-    torch.cuda.set_device(local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    shard = HipShard(rank, world, local_rank, n_local, seed=1, likelihood_mode=lik, initial_state=[0.0, 0.0, 0.0, 1.0])
-    loc = ShardedLocalizer(shard, dist)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    shard = NativeShard(rank, world, local_rank, n_local, gloo_exchange(dist), seed=1, likelihood_mode=lik,
+                        initial_state=[0.0, 0.0, 0.0, 1.0])
     u = [1.0, 0.1]
+
+    def fence():
+        shard.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        shard.synchronize()
+        torch.cuda.synchronize()
+
     for t in range(W):
-        loc.step(u, obs_list[t])
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
+        shard.step(u, obs_list[t])
+    fence()
     t0 = time.perf_counter()
     for t in range(W, W + K):
-        loc.step(u, obs_list[t])
-    torch.cuda.synchronize()
-    dist.barrier()
-    torch.cuda.synchronize()
+        shard.step(u, obs_list[t])
+    fence()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    est, _ = loc.estimate()
+    est, _ = shard.estimate()
+    moved = shard.migrated()
     shard.profile(True)
     t1 = time.perf_counter()
     for t in range(W, W + K):
-        loc.step(u, obs_list[t])
-    torch.cuda.synchronize()
+        shard.step(u, obs_list[t])
+    shard.synchronize()
     dt_instr = time.perf_counter() - t1
     prof = shard.profile_read()
     shard.profile(False)
-    moved = int(loc.last_matrix.sum() - np.trace(loc.last_matrix)) if loc.last_matrix is not None else 0
     dist.barrier()
     shard.close()
     dist.destroy_process_group()

@@ -40,6 +40,20 @@ def main():
     np.testing.assert_allclose(est, ref.estimate(), rtol=1e-9, atol=1e-9)
     np.testing.assert_allclose(cov, ref.calc_covariance(), rtol=1e-7, atol=1e-9)
     shard.close()
+    # the native step (RCCL called from inside the library) must give the same particles
+    from rust_robotics_amd.sharded import NativeShard, gloo_exchange
+
+    nat = NativeShard(rank, world, 0, n, gloo_exchange(dist), seed=42, range_noise=0.5, velocity_noise=0.3,
+                      yaw_rate_noise=math.radians(5.0))
+    rng = np.random.default_rng(43)
+    for t in range(steps):
+        nat.step([1.0, 0.1], H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng))
+    got = nat.particles()
+    assert np.array_equal(got.view(np.uint64), exp.view(np.uint64)), "native sharded particles differ from the unsharded engine"
+    e2, c2 = nat.estimate()
+    np.testing.assert_allclose(e2, ref.estimate(), rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(c2, ref.calc_covariance(), rtol=1e-7, atol=1e-9)
+    nat.close()
     dist.destroy_process_group()
     print("SHARDED_OK")
 
