@@ -246,6 +246,24 @@ uint64_t rr_sys_first_slot_above(double rho, uint64_t total_global, uint64_t n_g
 uint64_t rr_sys_segment_matrix(double rho, const uint64_t* totals, int32_t n_shards, uint64_t n_global,
                                uint64_t n_local, int32_t rank, int64_t* out);
 
+/* ---- peer-to-peer transport: the same sharded step with NO host code and NO collective
+ * library inside it.  Every rank maps its peers' particle slab and mailbox (hipIpc handles, or
+ * plain pointers when all shards live in one process) and the exchanges become three tiny
+ * kernels that publish a 32-byte record to every peer over xGMI and wait for theirs (bounded);
+ * the resample gather stores each slot straight into the owning rank's slab.  Results are
+ * bit-identical to the RCCL path and to the unsharded filter. */
+#define RR_P2P_HANDLE_BYTES 128
+/* this rank's IPC handles (slab + mailbox) for the other ranks */
+rr_status rr_pf_p2p_export(rr_pf* h, uint8_t out[RR_P2P_HANDLE_BYTES]);
+/* all_handles = n_ranks blobs from rr_pf_p2p_export in rank order (own entry ignored) */
+rr_status rr_pf_p2p_connect(rr_pf* h, const uint8_t* all_handles, int32_t n_ranks, int32_t rank);
+/* all shards in THIS process (one or several devices with peer access): handles[g] is rank g */
+rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks);
+/* one sharded step, fully asynchronous (nothing is waited for on the host) */
+rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* obs, size_t n_obs);
+/* synchronises and reports whether any wait gave up (a peer did not answer within 3 s) */
+rr_status rr_pf_p2p_status(rr_pf* h, int32_t* timed_out);
+
 /* ---- native sharded step: the phases above driven from inside the library with RCCL called
  * directly (librccl is dlopen'ed on first use, so single-GPU users never load it).  One
  * communicator per process/GPU; the 128-byte unique id is created on one rank and handed to the

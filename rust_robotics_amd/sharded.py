@@ -324,6 +324,104 @@ class NativeShard:
             self.comm = None
 
 
+class P2PShard:
+    """One shard using the peer-to-peer transport (include/rr_pf.h "peer-to-peer transport"):
+    no host code and no collective library inside a step.  ``connect_ipc`` is for one process per
+    GPU (handles travel through ``allgather``: a callable returning every rank's bytes in rank
+    order); ``link_local`` is for several shards inside one process."""
+
+    def __init__(self, rank: int, world: int, device: int, n_local: int, *, seed: int, range_noise=0.2,
+                 velocity_noise=2.0, yaw_rate_noise=math.radians(40.0), dt=0.1, gate=_ffi.RR_GATE_ALWAYS,
+                 resample_threshold=1.0, likelihood_mode=_ffi.RR_LIK_FUSED, initial_state=None):
+        L = _ffi.lib()
+        self.L, self.rank, self.world, self.n_local = L, rank, world, n_local
+        cfg = _ffi.PfConfig(n_local, resample_threshold, range_noise, velocity_noise, yaw_rate_noise, dt)
+        opt = _ffi.PfOptions()
+        L.rr_pf_options_default(C.byref(opt))
+        opt.device, opt.seed = device, seed
+        opt.resample_scheme, opt.resample_gate, opt.likelihood_mode = _ffi.RR_RESAMPLE_SYSTEMATIC, gate, likelihood_mode
+        opt.first_global_index, opt.n_global = rank * n_local, n_local * world
+        self.h = C.c_void_p()
+        if initial_state is None:
+            self._check(L.rr_pf_create(C.byref(cfg), C.byref(opt), C.byref(self.h)))
+        else:
+            st = np.ascontiguousarray(initial_state, dtype=np.float64)
+            self._check(L.rr_pf_create_with_state(C.byref(cfg), C.byref(opt), st.ctypes.data_as(C.POINTER(C.c_double)), C.byref(self.h)))
+
+    def _check(self, status: int) -> None:
+        if status != _ffi.RR_OK:
+            kind = RoboticsError.invalid_parameter if status == _ffi.RR_INVALID_PARAMETER else RoboticsError.runtime
+            raise kind(_ffi.last_error())
+
+    def connect_ipc(self, allgather) -> None:
+        blob = (C.c_uint8 * 128)()
+        self._check(self.L.rr_pf_p2p_export(self.h, blob))
+        parts = allgather(bytes(blob))
+        allb = (C.c_uint8 * (128 * self.world)).from_buffer_copy(b"".join(parts))
+        self._check(self.L.rr_pf_p2p_connect(self.h, allb, self.world, self.rank))
+
+    @staticmethod
+    def link_local(shards) -> None:
+        L = _ffi.lib()
+        arr = (C.c_void_p * len(shards))(*[s.h for s in shards])
+        status = L.rr_pf_p2p_connect_local(arr, len(shards))
+        if status != _ffi.RR_OK:
+            raise RoboticsError.runtime(_ffi.last_error())
+
+    def step(self, u, obs) -> None:
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, 3)
+        dp = C.POINTER(C.c_double)
+        self._check(self.L.rr_pf_shard_step_p2p(self.h, u.ctypes.data_as(dp), obs.ctypes.data_as(dp) if obs.size else None, obs.shape[0]))
+
+    def timed_out(self) -> bool:
+        out = C.c_int32()
+        self._check(self.L.rr_pf_p2p_status(self.h, C.byref(out)))
+        return bool(out.value)
+
+    def particles(self) -> np.ndarray:
+        out = np.empty((self.n_local, 5))
+        self._check(self.L.rr_pf_get_particles(self.h, out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def local_moments(self):
+        e, c = np.empty(4), np.empty(16)
+        dp = C.POINTER(C.c_double)
+        self._check(self.L.rr_pf_estimate(self.h, e.ctypes.data_as(dp)))
+        self._check(self.L.rr_pf_covariance(self.h, c.ctypes.data_as(dp)))
+        return e, c.reshape(4, 4)
+
+    def synchronize(self) -> None:
+        self._check(self.L.rr_pf_synchronize(self.h))
+
+    def profile(self, on: bool) -> None:
+        self._check(self.L.rr_pf_profile_enable(self.h, 1 if on else 0))
+        if on:
+            self._check(self.L.rr_pf_profile_reset(self.h))
+
+    def profile_read(self) -> dict:
+        out = {}
+        for k in range(_ffi.RR_K_COUNT):
+            n, ms = C.c_uint64(), C.c_double()
+            self._check(self.L.rr_pf_profile_read(self.h, k, C.byref(n), C.byref(ms)))
+            out[self.L.rr_pf_kernel_name(k).decode()] = (n.value, ms.value)
+        return out
+
+    def close(self) -> None:
+        if self.h:
+            self.L.rr_pf_destroy(self.h)
+            self.h = None
+
+
+def gloo_allgather(dist):
+    def allgather(raw: bytes):
+        out = [None] * dist.get_world_size()
+        dist.all_gather_object(out, raw)
+        return out
+
+    return allgather
+
+
 def gloo_exchange(dist):
     """broadcast a bytes object from rank 0 over an initialised torch.distributed group"""
 
