@@ -196,7 +196,9 @@ def main():
     ap.add_argument("--scheme", choices=["systematic", "multinomial"], default="systematic")
     ap.add_argument("--likelihood", choices=["fused", "product"], default="fused")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-sharded", action="store_true", help="run the sharded (RCCL) path even at --gpus 1")
+    ap.add_argument("--force-sharded", action="store_true", help="run the sharded path even at --gpus 1")
+    ap.add_argument("--transport", choices=["auto", "p2p", "rccl"], default="auto",
+                    help="sharded exchange: peer-to-peer over xGMI (validated at run time) or RCCL collectives")
     args = ap.parse_args()
 
     if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
@@ -225,7 +227,7 @@ def main():
     if world > 1 or args.force_sharded:
         from rust_robotics_amd import sharded
 
-        res = sharded.bench_sharded(rank, world, local_rank, n, L, K, W, obs_list, scheme, lik)
+        res = sharded.bench_sharded(rank, world, local_rank, n, L, K, W, obs_list, scheme, lik, args.transport)
     else:
         import rust_robotics_amd.localization as loc
 
@@ -284,7 +286,8 @@ def main():
             "particles_per_gpu": n,
             "landmarks": L,
             "resample": args.scheme,
-            "sharding": "none" if world == 1 else f"particle blocks over {world} GPUs, RCCL all-gather of integer sums + segment exchange",
+            "sharding": "none" if world == 1 and not args.force_sharded else
+                        f"contiguous particle blocks over {world} GPUs; transport {res.get('transport')} ({res.get('transport_note')})",
         },
         "roofline": {
             "bound": "hbm",

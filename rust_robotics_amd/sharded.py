@@ -433,11 +433,15 @@ def gloo_exchange(dist):
     return exchange
 
 
-def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, lik):
+def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, lik, transport="auto"):
     """bench.py's N > 1 leg: weak scaling, n_local particles per GPU, barrier + synchronize on
-    both sides of the K timed steps, MAX over ranks.  The step itself is the native one
-    (rr_pf_shard_step, RCCL called from inside the library); torch.distributed (gloo) only
-    bootstraps the communicator and provides the timing barrier."""
+    both sides of the K timed steps, MAX over ranks.  torch.distributed (gloo) only bootstraps
+    (communicator id, IPC handles) and provides the timing barrier; the step runs inside the library.
+
+    transport "auto": the peer-to-peer transport is used iff it (a) connects on every rank and
+    (b) reproduces, bit for bit, the particle set the RCCL transport produces over a dozen steps
+    from the same seed on THIS machine, without any wait timing out -- a run-time proof of the
+    cross-GPU memory hand-off before anything is timed.  Otherwise the RCCL transport is timed."""
     import torch
     import torch.distributed as dist
 
@@ -446,9 +450,34 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
-    shard = NativeShard(rank, world, local_rank, n_local, gloo_exchange(dist), seed=1, likelihood_mode=lik,
-                        initial_state=[0.0, 0.0, 0.0, 1.0])
     u = [1.0, 0.1]
+    kw = dict(seed=1, likelihood_mode=lik, initial_state=[0.0, 0.0, 0.0, 1.0])
+
+    def agree(ok: bool) -> bool:
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    rccl = NativeShard(rank, world, local_rank, n_local, gloo_exchange(dist), **kw)
+    p2p, use_p2p, why = None, False, "disabled"
+    if transport in ("auto", "p2p"):
+        try:
+            p2p = P2PShard(rank, world, local_rank, n_local, **kw)
+            p2p.connect_ipc(gloo_allgather(dist))
+            ok = True
+        except Exception as e:  # noqa: BLE001 -- any failure means "use RCCL"
+            ok, why = False, f"connect failed: {e}"
+        if agree(ok):
+            V = min(12, len(obs_list))
+            for t in range(V):
+                p2p.step(u, obs_list[t])
+                rccl.step(u, obs_list[t])
+            same = (not p2p.timed_out()) and np.array_equal(p2p.particles().view(np.uint64), rccl.particles().view(np.uint64))
+            use_p2p = agree(same)
+            why = f"validated bit-identical to the RCCL transport over {V} steps" if use_p2p else "validation against the RCCL transport failed"
+        elif ok:
+            why = "connect failed on another rank"
+    shard = p2p if use_p2p else rccl
 
     def fence():
         shard.synchronize()
@@ -467,8 +496,14 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    est, _ = shard.estimate()
-    moved = shard.migrated()
+    timed_out = use_p2p and p2p.timed_out()
+    if use_p2p:
+        e, c = p2p.local_moments()
+        est = e  # local estimate of this rank's block (all blocks are samples of the same posterior)
+        moved = -1
+    else:
+        est, _ = rccl.estimate()
+        moved = rccl.migrated()
     shard.profile(True)
     t1 = time.perf_counter()
     for t in range(W, W + K):
@@ -478,7 +513,10 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     prof = shard.profile_read()
     shard.profile(False)
     dist.barrier()
-    shard.close()
+    if p2p is not None:
+        p2p.close()
+    rccl.close()
     dist.destroy_process_group()
     return dict(seconds=float(tmax.item()), seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est],
-                migrated_particles_last_step=moved)
+                migrated_particles_last_step=moved, transport="p2p (xGMI, device-initiated)" if use_p2p else "rccl",
+                transport_note=why, p2p_timed_out=bool(timed_out))
