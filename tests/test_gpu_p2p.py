@@ -30,11 +30,9 @@ def unsharded(n, steps, seed=42):
     return ref.get_particles_array()
 
 
-@pytest.mark.parametrize("world,n_local", [(1, 5000), (2, 6000), (3, 4100)])
-def test_in_process_shards_equal_unsharded(world, n_local):
+def run_in_process(world, n_local, steps=10):
     from rust_robotics_amd.sharded import P2PShard
 
-    steps = 10
     shards = [P2PShard(g, world, 0, n_local, seed=42, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))
               for g in range(world)]
     P2PShard.link_local(shards)
@@ -50,6 +48,19 @@ def test_in_process_shards_equal_unsharded(world, n_local):
         assert np.array_equal(got.view(np.uint64), exp[g * n_local:(g + 1) * n_local].view(np.uint64)), f"rank {g} differs"
     for s in shards:
         s.close()
+    print("P2P_LOCAL_OK")
+
+
+@pytest.mark.parametrize("world,n_local", [(1, 5000), (2, 6000), (3, 4100)])
+def test_in_process_shards_equal_unsharded(world, n_local):
+    """Several shards of one process on ONE GPU only make progress together if each shard's stream
+    has its own hardware queue (a spinning wait kernel would otherwise block the peer kernel queued
+    behind it), so the case runs in a fresh interpreter with a generous queue count.  One process
+    per GPU -- the deployment shape -- has no such constraint."""
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); from tests.test_gpu_p2p import run_in_process; run_in_process({world}, {n_local})"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="8"))
+    assert r.returncode == 0 and "P2P_LOCAL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
 def test_two_processes_over_ipc_handles():
