@@ -261,7 +261,8 @@ rr_status rr_pf_p2p_connect(rr_pf* h, const uint8_t* all_handles, int32_t n_rank
 rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks);
 /* one sharded step, fully asynchronous (nothing is waited for on the host) */
 rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* obs, size_t n_obs);
-/* synchronises and reports whether any wait gave up (a peer did not answer within 3 s) */
+/* synchronises and reports whether any wait gave up (a peer did not answer within 2 s; every
+ * later exchange of the filter then returns at once and the resample is skipped) */
 rr_status rr_pf_p2p_status(rr_pf* h, int32_t* timed_out);
 
 /* ---- native sharded step: the phases above driven from inside the library with RCCL called

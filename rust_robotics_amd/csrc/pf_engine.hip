@@ -492,9 +492,11 @@ __global__ void k_p2p_exchange(P2PPeers peers, int kind, uint64_t seq, const uin
                                PlanArgs pa, int* __restrict__ err) {
   __shared__ int s_bad;
   const int g = threadIdx.x;
-  if (g == 0) s_bad = 0;
+  // once a wait has given up, every later exchange of this filter gives up at once (the host
+  // reads the flag with rr_pf_p2p_status); only the first one costs the timeout
+  if (g == 0) s_bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  if (g < peers.n_ranks) {
+  if (g < peers.n_ranks && !s_bad) {
     uint64_t v0 = 0, v1 = 0, v2 = 0;
     if (kind == kP2PWmax) v0 = payload[0];
     if (kind == kP2PSums) { v0 = payload[0]; v1 = payload[1]; v2 = payload[2]; }
@@ -509,7 +511,7 @@ __global__ void k_p2p_exchange(P2PPeers peers, int kind, uint64_t seq, const uin
     bool ok = true;
     while (__hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
       __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > 300000000ull) {  // 3 s: a peer is gone; do not hang the device
+      if (wall_clock64() - t0 > 200000000ull) {  // 2 s: a peer is gone; do not hang the device
         ok = false;
         break;
       }

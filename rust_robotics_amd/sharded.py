@@ -469,10 +469,16 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
             ok, why = False, f"connect failed: {e}"
         if agree(ok):
             V = min(12, len(obs_list))
+            alive = True
             for t in range(V):
                 p2p.step(u, obs_list[t])
                 rccl.step(u, obs_list[t])
-            same = (not p2p.timed_out()) and np.array_equal(p2p.particles().view(np.uint64), rccl.particles().view(np.uint64))
+                if t == 0:  # a dead transport shows on the first exchange: stop before it costs more
+                    alive = agree(not p2p.timed_out())
+                    if not alive:
+                        break
+            same = alive and (not p2p.timed_out()) and np.array_equal(p2p.particles().view(np.uint64),
+                                                                      rccl.particles().view(np.uint64))
             use_p2p = agree(same)
             why = f"validated bit-identical to the RCCL transport over {V} steps" if use_p2p else "validation against the RCCL transport failed"
         elif ok:
