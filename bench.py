@@ -307,8 +307,10 @@ def main():
         "ms_per_step_instrumented": res.get("seconds_instrumented", 0.0) / K * 1e3,
         "estimate": res.get("estimate"),
     }
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
         out["cpu_baseline"] = cpu_baseline(n, L, obs_list)
+    if world > 1 or args.force_sharded:
+        out["sharded"] = {k: res.get(k) for k in ("transport", "transport_note", "p2p_timed_out", "migrated_particles_last_step")}
     emit(out)
 
 

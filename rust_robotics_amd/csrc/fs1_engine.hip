@@ -559,7 +559,7 @@ rr_status launch_finish(rr_fs1* h, bool lazy = false) {
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_CDF);
     hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl, image_args(h),
-                       h->tile_total, h->cdf);
+                       h->tile_total, h->cdf, (uint64_t*)nullptr, 0);
   }
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_NORMALIZE);

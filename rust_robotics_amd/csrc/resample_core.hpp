@@ -361,17 +361,31 @@ __device__ inline int gate_decision(int image_mode, const TileSums& ts, const Pl
 // ------------------------------------------------------------------------------------------
 // K4: inclusive integer CDF of this shard (multinomial resampling and FastSLAM read it back):
 // cdf[i] = base + tile_offset + within-tile scan.  Reads w (8 B), writes cdf (8 B).
+// coarse[k] = cdf[min((k+1) << coarse_log2, n) - 1]: every 2^coarse_log2-th CDF entry, the table the
+// multinomial gather stages in LDS (nullptr: not wanted)
+__device__ inline void store_cdf(const TileScan& t, uint64_t off, uint64_t i0, uint64_t n, uint64_t* __restrict__ cdf,
+                                 uint64_t* __restrict__ coarse, int coarse_log2) {
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    const uint64_t i = i0 + j;
+    if (i < n) {
+      const uint64_t c = off + t.c[j];
+      cdf[i] = c;
+      if (coarse && ((((i + 1) & ((1ull << coarse_log2) - 1)) == 0) || i == n - 1)) coarse[i >> coarse_log2] = c;
+    }
+  }
+}
+
 static __global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, const Ctl* __restrict__ ctl,
                                                       ImageArgs a, const uint64_t* __restrict__ tile_offset,
-                                                      uint64_t* __restrict__ cdf) {
+                                                      uint64_t* __restrict__ cdf, uint64_t* __restrict__ coarse,
+                                                      int coarse_log2) {
   if (!ctl->fired) return;
   __shared__ uint64_t s_w[kBlock / kWave];
   const TileScan t = tile_scan(w, a, ctl->image_mode, ctl->shift, blockIdx.x, s_w);
   const uint64_t off = ctl->base + tile_offset[blockIdx.x] + t.thread_off;
   const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
-#pragma unroll
-  for (int j = 0; j < kItems; ++j)
-    if (i0 + j < a.n) cdf[i0 + j] = off + t.c[j];
+  store_cdf(t, off, i0, a.n, cdf, coarse, coarse_log2);
 }
 
 // K3+K4 fused (single shard, n_tiles <= kFusedMaxTiles): every workgroup re-derives its tile
@@ -383,7 +397,8 @@ constexpr int kFusedMaxTiles = 4096;
 static __global__ __launch_bounds__(kBlock) void k_plan_cdf(const double* __restrict__ w, Ctl* __restrict__ ctl,
                                                            ImageArgs a, const uint64_t* __restrict__ tile_total,
                                                            const uint64_t* __restrict__ tile_q2, uint64_t n_tiles,
-                                                           PlanArgs pa, uint64_t* __restrict__ cdf) {
+                                                           PlanArgs pa, uint64_t* __restrict__ cdf,
+                                                           uint64_t* __restrict__ coarse, int coarse_log2) {
   __shared__ uint64_t s4[4 * (kBlock / kWave)];
   __shared__ uint64_t s_w[kBlock / kWave];
   const TileSums ts = tile_sums(tile_total, tile_q2, n_tiles, s4);
@@ -393,11 +408,8 @@ static __global__ __launch_bounds__(kBlock) void k_plan_cdf(const double* __rest
   if (blockIdx.x == 0 && threadIdx.x == 0) finalize_plan(ctl, ts.tot, 0, ts.tot, ts.q2, pa);
   if (!fire) return;
   const TileScan t = tile_scan(w, a, mode, shift, blockIdx.x, s_w);
-  const uint64_t off = ts.pre + t.thread_off;
   const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
-#pragma unroll
-  for (int j = 0; j < kItems; ++j)
-    if (i0 + j < a.n) cdf[i0 + j] = off + t.c[j];
+  store_cdf(t, ts.pre + t.thread_off, i0, a.n, cdf, coarse, coarse_log2);
 }
 
 // ------------------------------------------------------------------------------------------
