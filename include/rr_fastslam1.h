@@ -51,6 +51,10 @@ typedef struct rr_fs1_options {
   int32_t obs_chunks;     /* 0 = choose automatically; k >= 1 = split a step's observations over k
                              thread groups (partial weight products are combined in chunk order) */
   int32_t reserved;
+  /* sharding (rr_fs1_shard_*): global index of this shard's particle 0 and the particle count over
+   * all shards; 0 / 0 for a single-GPU filter */
+  uint64_t first_global_index;
+  uint64_t n_global;
 } rr_fs1_options;
 
 typedef struct rr_fs1 rr_fs1; /* opaque */
@@ -109,6 +113,18 @@ rr_status rr_fs1_n_eff(rr_fs1* h, double* out);
 rr_status rr_fs1_get_fixed_sums(rr_fs1* h, rr_pf_fixed_sums* out);
 /* observation chunks the last observe used, and the Philox counters */
 rr_status rr_fs1_get_counters(rr_fs1* h, uint32_t* step, uint32_t* resample_step, int32_t* obs_chunks);
+
+/* ---- sharded FastSLAM: contiguous particle blocks over the GPUs of a node, each
+ * particle's whole map moves with it.  Peer-to-peer transport only (include/rr_pf.h "peer-to-peer
+ * transport" describes the protocol): the weight maximum and the integer sums are exchanged through
+ * the peers' mailboxes, and the systematic resample stores every served slot's 3 + 6L planes
+ * straight into the owning shard's state slab over xGMI.  Bit-identical to the unsharded filter. */
+rr_status rr_fs1_p2p_export(rr_fs1* h, uint8_t out[RR_P2P_HANDLE_BYTES]);
+rr_status rr_fs1_p2p_connect(rr_fs1* h, const uint8_t* all_handles, int32_t n_ranks, int32_t rank);
+rr_status rr_fs1_p2p_connect_local(rr_fs1* const* handles, int32_t n_ranks);
+/* fastslam_update over all shards, fully asynchronous; every shard calls it with the same u and z */
+rr_status rr_fs1_shard_update_p2p(rr_fs1* h, const double u[2], const double* z, size_t n_z);
+rr_status rr_fs1_p2p_status(rr_fs1* h, int32_t* timed_out);
 
 /* ---- measurement hooks */
 typedef enum rr_fs1_kernel_id {

@@ -70,7 +70,7 @@ class Fs1Params(C.Structure):
 
 class Fs1Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("record_indices", C.c_int32), ("seed", C.c_uint64), ("obs_chunks", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("reserved", C.c_int32), ("first_global_index", C.c_uint64), ("n_global", C.c_uint64)]
 
 
 RR_FK_COUNT = 10
@@ -203,6 +203,11 @@ def lib() -> C.CDLL:
     proto("rr_fs1_n_eff", st, [H, P])
     proto("rr_fs1_get_fixed_sums", st, [H, C.POINTER(PfFixedSums)])
     proto("rr_fs1_get_counters", st, [H, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32)])
+    proto("rr_fs1_p2p_export", st, [H, U8])
+    proto("rr_fs1_p2p_connect", st, [H, U8, i32, i32])
+    proto("rr_fs1_p2p_connect_local", st, [C.POINTER(H), i32])
+    proto("rr_fs1_shard_update_p2p", st, [H, P, P, sz])
+    proto("rr_fs1_p2p_status", st, [H, C.POINTER(i32)])
     proto("rr_fs1_profile_enable", st, [H, i32])
     proto("rr_fs1_profile_read", st, [H, i32, C.POINTER(u64), P])
     proto("rr_fs1_profile_reset", st, [H])

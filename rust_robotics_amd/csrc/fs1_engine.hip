@@ -25,6 +25,7 @@
 #include <string>
 #include <vector>
 
+#include "p2p_core.hpp"
 #include "resample_core.hpp"
 #include "rr_common.hpp"
 #include "rr_fastslam1.h"
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(kBlock) void k_fs1_predict(Planes pl, const Ctl* __
                                                        double u0, double u1, rr_fs1_model m, uint64_t seed,
                                                        unsigned int step, const double* __restrict__ z0,
                                                        const double* __restrict__ z1,
-                                                       const unsigned int* __restrict__ idx) {
+                                                       const unsigned int* __restrict__ idx, uint64_t gid0) {
   const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
   const bool pending = LAZY && ctl->pending;
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kBlock) void k_fs1_predict(Planes pl, const Ctl* __
     a = z0[p];
     b = z1[p];
   } else {
-    rr_fs1_motion_noise(seed, step, p, &a, &b);
+    rr_fs1_motion_noise(seed, step, gid0 + p, &a, &b);
   }
   rr_fs1_predict_one(&x, &y, &yaw, u0, u1, a, b, m);
   dst[p] = x;
@@ -185,6 +186,58 @@ __global__ __launch_bounds__(kBlock) void k_fs1_normalize(double* __restrict__ p
   if (ctl->fired || ctl->image_mode != rr::kImageWeights) return;
   const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p < n) pw[p] = pw[p] / ctl->sum;
+}
+
+// sharded variants.  Slots this shard serves: [first, first + n_served) with
+// first = slots_upto(base), n_served = slots_upto(base + T_local) - first (device-side only).
+__device__ inline void served_range(const Ctl* ctl, uint64_t* first, uint64_t* n_served) {
+  const rr_sys_plan plan = ctl->plan;
+  *first = rr_sys_slots_upto_exact(plan, ctl->total, ctl->base);
+  *n_served = rr_sys_slots_upto_exact(plan, ctl->total, ctl->base + ctl->total_local) - *first;
+}
+
+__global__ __launch_bounds__(kBlock) void k_fs1_indices_sharded(const Ctl* __restrict__ ctl,
+                                                               const uint64_t* __restrict__ cdf, uint64_t n,
+                                                               unsigned int* __restrict__ idx) {
+  if (!ctl->fired) return;
+  uint64_t first, n_served;
+  served_range(ctl, &first, &n_served);
+  const rr_sys_plan plan = ctl->plan;
+  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < n_served; k += (uint64_t)gridDim.x * kBlock)
+    idx[k] = (unsigned int)rr_lower_bound_u64(cdf, n, rr_sys_target(plan, first + k));
+}
+
+__global__ __launch_bounds__(kBlock) void k_fs1_uniform_weights(const Ctl* __restrict__ ctl, double* __restrict__ pw,
+                                                               uint64_t n, uint64_t n_global) {
+  if (!ctl->fired) return;
+  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p < n) pw[p] = 1.0 / (double)n_global;  // fastslam1.rs:228
+}
+
+// every served slot's planes straight into the owning shard's slab (set Ctl.cur: the plan kernel
+// flipped it on every shard alike)
+__global__ __launch_bounds__(kBlock) void k_fs1_gather_p2p(Planes pl, const Ctl* __restrict__ ctl,
+                                                          const unsigned int* __restrict__ idx, uint64_t n_local,
+                                                          uint64_t n_planes, rr::P2PPeers peers) {
+  if (!ctl->fired) return;
+  uint64_t first, n_served;
+  served_range(ctl, &first, &n_served);
+  const int cur = ctl->cur;
+  const double* __restrict__ in = pl.s[cur ^ 1];
+  const uint64_t p0 = (uint64_t)blockIdx.y * kPlanesPerThread;
+  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < n_served; k += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t s = first + k;
+    const uint64_t d = s / n_local, li = s - d * n_local;
+    const uint64_t j = idx[k];
+    double* __restrict__ out = peers.slab[d] + (size_t)cur * n_planes * n_local;
+    double v[kPlanesPerThread];
+#pragma unroll
+    for (int q = 0; q < kPlanesPerThread; ++q)
+      if (p0 + q < n_planes) v[q] = in[(p0 + q) * n_local + j];
+#pragma unroll
+    for (int q = 0; q < kPlanesPerThread; ++q)
+      if (p0 + q < n_planes) out[(p0 + q) * n_local + li] = v[q];
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_fs1_indices(const Ctl* __restrict__ ctl, const uint64_t* __restrict__ cdf,
@@ -355,8 +408,11 @@ struct rr_fs1 {
   rr_fs1_params prm;
   rr_fs1_options opt;
   uint64_t n = 0, L = 0, n_planes = 0, n_tiles = 0;
+  uint64_t n_global = 0, gid0 = 0;  // sharding: particles over all shards, global index of local particle 0
   hipStream_t stream = nullptr;
   Planes pl{};
+  double* slab = nullptr;  // [set][plane][n]
+  rr::P2PState p2p;
   double* pw = nullptr;
   uint64_t* cdf = nullptr;
   uint64_t* tile_total = nullptr;
@@ -431,8 +487,8 @@ rr_status validate_z(const rr_fs1* h, const double* z, size_t n_z, bool* has_dup
 ImageArgs image_args(const rr_fs1* h) {
   ImageArgs a{};
   a.n = h->n;
-  a.n_global = h->n;
-  a.gid0 = 0;
+  a.n_global = h->n_global;
+  a.gid0 = h->gid0;
   a.degenerate = rr::kDegenerateLast;
   a.honour_uniform_flag = 0;
   return a;
@@ -440,7 +496,7 @@ ImageArgs image_args(const rr_fs1* h) {
 
 PlanArgs plan_args(const rr_fs1* h, int mode, double rho_override, bool lazy = false) {
   PlanArgs a{};
-  a.n_global = h->n;
+  a.n_global = h->n_global;
   a.neff_threshold = h->prm.nth;  // fastslam1.rs:262-265
   a.gate = RR_GATE_NEFF;
   a.mode = mode;
@@ -472,7 +528,7 @@ rr_status launch_predict(rr_fs1* h, const double u[2]) {
   rr::ScopedTimer t(h->prof, h->stream, RR_FK_PREDICT);
   hipLaunchKernelGGL((k_fs1_predict<EXPLICIT, LAZY>), dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl,
                      h->ctl, h->n, u[0], u[1], host_model(h->prm), h->opt.seed, h->step, (const double*)h->noise,
-                     (const double*)(h->noise ? h->noise + h->n : nullptr), (const unsigned int*)h->idx);
+                     (const double*)(h->noise ? h->noise + h->n : nullptr), (const unsigned int*)h->idx, h->gid0);
   RR_HIP_TRY(hipGetLastError());
   h->step += 1;
   return RR_OK;
@@ -650,6 +706,11 @@ rr_status rr_fs1_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs1
       !std::isfinite(prm.nth) || !std::isfinite(prm.initial_weight) || !std::isfinite(prm.init_cov))
     return fail(RR_INVALID_PARAMETER, "fastslam parameters must be finite (dt > 0, Q >= 0)");
   if (opt.obs_chunks < 0 || opt.obs_chunks > kMaxChunks) return fail(RR_INVALID_PARAMETER, "obs_chunks out of range");
+  {
+    const uint64_t ng = opt.n_global ? opt.n_global : n_particles;
+    if (ng >= (1ull << 31) || opt.first_global_index + n_particles > ng)
+      return fail(RR_INVALID_PARAMETER, "shard range exceeds n_global (< 2^31)");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
     return fail(RR_RUNTIME_ERROR, "no HIP device available: the engine has no CPU fallback");
@@ -660,6 +721,8 @@ rr_status rr_fs1_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs1
   h->opt = opt;
   h->n = n_particles;
   h->L = n_landmarks;
+  h->n_global = opt.n_global ? opt.n_global : n_particles;
+  h->gid0 = opt.first_global_index;
   h->n_planes = 3 + 6 * n_landmarks;
   h->n_tiles = (h->n + kTile - 1) / kTile;
   auto cleanup = [&](rr_status st) {
@@ -673,13 +736,14 @@ rr_status rr_fs1_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs1
   } while (0)
   RR_TRY_OR_CLEAN(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   const size_t state_bytes = h->n_planes * h->n * sizeof(double);
-  RR_TRY_OR_CLEAN(hipMalloc(&h->pl.s[0], state_bytes));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->pl.s[1], state_bytes));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->slab, 2 * state_bytes));  // one slab: peers map the whole state with one IPC handle
+  h->pl.s[0] = h->slab;
+  h->pl.s[1] = h->slab + h->n_planes * h->n;
   RR_TRY_OR_CLEAN(hipMalloc(&h->pw, h->n * sizeof(double)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->cdf, h->n * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->tile_total, h->n_tiles * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->tile_q2, 2 * h->n_tiles * sizeof(uint64_t)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->idx, h->n * sizeof(unsigned int)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->idx, h->n_global * sizeof(unsigned int)));  // a shard may serve up to n_global slots
   RR_TRY_OR_CLEAN(hipMalloc(&h->partial, (size_t)kMaxChunks * h->n * sizeof(double)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->part_bits, 1024 * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->part_idx, 1024 * sizeof(uint64_t)));
@@ -700,8 +764,8 @@ void rr_fs1_destroy(rr_fs1* h) {
   if (!h) return;
   (void)hipSetDevice(h->opt.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  (void)hipFree(h->pl.s[0]);
-  (void)hipFree(h->pl.s[1]);
+  h->p2p.teardown();
+  (void)hipFree(h->slab);
   (void)hipFree(h->pw);
   (void)hipFree(h->cdf);
   (void)hipFree(h->tile_total);
@@ -938,6 +1002,114 @@ size_t rr_fs1_get_observations(const double x_true[3], const double* landmarks_x
     }
   }
   return cnt;
+}
+
+// ---- sharded FastSLAM over the peer-to-peer transport
+static rr_status fs1_check_geometry(const rr_fs1* h, int n_ranks, int rank) {
+  if (n_ranks <= 0 || n_ranks > rr::kMaxP2P || rank < 0 || rank >= n_ranks)
+    return fail(RR_INVALID_PARAMETER, "peer-to-peer transport supports 1..16 ranks");
+  if (h->n_global != h->n * (uint64_t)n_ranks || h->gid0 != h->n * (uint64_t)rank)
+    return fail(RR_INVALID_PARAMETER, "shard geometry does not match the rank layout (equal blocks, rank * n_local)");
+  return RR_OK;
+}
+
+rr_status rr_fs1_p2p_export(rr_fs1* h, uint8_t out[RR_P2P_HANDLE_BYTES]) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  return h->p2p.export_handles(h->slab, out);
+}
+
+rr_status rr_fs1_p2p_connect(rr_fs1* h, const uint8_t* all_handles, int32_t n_ranks, int32_t rank) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!all_handles) return fail(RR_INVALID_PARAMETER, "null handles");
+  if ((s = fs1_check_geometry(h, n_ranks, rank)) != RR_OK) return s;
+  return h->p2p.connect_ipc(h->slab, all_handles, n_ranks, rank);
+}
+
+rr_status rr_fs1_p2p_connect_local(rr_fs1* const* handles, int32_t n_ranks) {
+  if (!handles || n_ranks <= 0 || n_ranks > rr::kMaxP2P) return fail(RR_INVALID_PARAMETER, "bad handle list");
+  rr::P2PState* st[rr::kMaxP2P];
+  double* slabs[rr::kMaxP2P];
+  int devs[rr::kMaxP2P];
+  for (int g = 0; g < n_ranks; ++g) {
+    if (!handles[g]) return fail(RR_INVALID_PARAMETER, "null handle");
+    rr_status s = fs1_check_geometry(handles[g], n_ranks, g);
+    if (s != RR_OK) return s;
+    st[g] = &handles[g]->p2p;
+    slabs[g] = handles[g]->slab;
+    devs[g] = handles[g]->opt.device;
+  }
+  return rr::p2p_link_local(st, slabs, devs, n_ranks);
+}
+
+rr_status rr_fs1_p2p_status(rr_fs1* h, int32_t* timed_out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!timed_out) return fail(RR_INVALID_PARAMETER, "null output");
+  return h->p2p.status(h->stream, timed_out);
+}
+
+rr_status rr_fs1_shard_update_p2p(rr_fs1* h, const double u[2], const double* z, size_t n_z) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_fs1_p2p_connect first");
+  if ((s = validate_u(u)) != RR_OK) return s;
+  bool dup;
+  if ((s = validate_z(h, z, n_z, &dup)) != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
+  const uint64_t seq = ++h->p2p.seq;
+  uint64_t* gathered = h->p2p.gathered();
+  uint64_t* local3 = h->p2p.local3();
+  // local: predict + per-observation EKF (in place), local weight maximum in Ctl.wmax_bits
+  if ((s = launch_predict<false, false>(h, u)) != RR_OK) return s;
+  if ((s = launch_observe(h, z, n_z, dup)) != RR_OK) return s;
+  PlanArgs pa = plan_args(h, 0, NAN);
+  // exchange 1: global maximum -> Ctl.wmax
+  hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PWmax, seq,
+                     (const uint64_t*)&h->ctl->wmax_bits, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_QUANTIZE_REDUCE);
+    hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
+                       (const double*)&h->ctl->wmax, image_args(h), h->tile_total, h->tile_q2, 0);
+  }
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_SCAN_TILES);
+    hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl,
+                       h->n_tiles, 0, pa, local3);
+  }
+  // exchange 2: every shard's sums -> global totals, gate (N_eff < NTH), plan
+  hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PSums, seq,
+                     (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+  h->wmax_live = false;
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_CDF);
+    hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl, image_args(h),
+                       h->tile_total, h->cdf, (uint64_t*)nullptr, 0);
+  }
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_NORMALIZE);
+    hipLaunchKernelGGL(k_fs1_normalize, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
+  }
+  const unsigned gx = grid_for(2 * h->n, kBlock);  // grid-stride: a shard may serve more than 2 n_local slots
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_INDICES);
+    hipLaunchKernelGGL(k_fs1_indices_sharded, dim3(gx), dim3(kBlock), 0, h->stream, h->ctl, h->cdf, h->n, h->idx);
+    hipLaunchKernelGGL(k_fs1_uniform_weights, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->ctl, h->pw, h->n,
+                       h->n_global);
+  }
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_GATHER);
+    hipLaunchKernelGGL(k_fs1_gather_p2p, dim3(gx, grid_for(h->n_planes, kPlanesPerThread)), dim3(kBlock), 0, h->stream, h->pl,
+                       h->ctl, h->idx, h->n, h->n_planes, h->p2p.peers);
+  }
+  // exchange 3: everybody has finished writing into everybody's slab
+  hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PDone, seq,
+                     (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+  RR_HIP_TRY(hipGetLastError());
+  h->rstep += 1;
+  return RR_OK;
 }
 
 rr_status rr_fs1_last_resample_fired(rr_fs1* h, int32_t* out) {

@@ -1,0 +1,238 @@
+// p2p_core.hpp -- device-initiated exchange between the shards of a filter over xGMI, shared by
+// the PF/MCL engine and the FastSLAM engine (include/rr_pf.h "peer-to-peer transport").
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+
+#include "resample_core.hpp"
+#include "rr_common.hpp"
+
+namespace rr {
+
+// ------------------------------------------------------------------------------------------
+// Device-initiated exchange over xGMI: no host code and no collective library inside a step.
+// Every rank owns a fine-grained mailbox that the peers write 32-byte records into
+// {payload[3], seq}; k_p2p_exchange (one workgroup, one thread per peer) publishes this rank's
+// record to every peer with system-scope release and waits, bounded, for every peer's record
+// with system-scope acquire.  The resample gather then stores each served slot straight into
+// the owning rank's particle slab (coarse-grained memory written by a remote kernel and read by
+// a LATER local kernel -- the same hand-off RCCL's direct P2P receive uses).
+constexpr int kMaxP2P = 16;
+constexpr int kP2PHandleBytes = 128;
+struct P2PSlot {
+  uint64_t v[3];
+  uint64_t seq;
+};
+struct P2PMailbox {
+  P2PSlot wmax[kMaxP2P];
+  P2PSlot sums[kMaxP2P];
+  P2PSlot done[kMaxP2P];
+};
+struct P2PPeers {
+  P2PMailbox* mbox[kMaxP2P];
+  double* slab[kMaxP2P];
+  int n_ranks;
+  int rank;
+};
+enum { kP2PWmax = 0, kP2PSums = 1, kP2PDone = 2 };
+
+__device__ inline P2PSlot* p2p_slot(P2PMailbox* m, int kind, int idx) {
+  return kind == kP2PWmax ? &m->wmax[idx] : (kind == kP2PSums ? &m->sums[idx] : &m->done[idx]);
+}
+
+// payload: kind WMAX -> {bits of the local max weight}, SUMS -> {T, q2_hi, q2_lo} (local device
+// memory written by the previous kernel), DONE -> nothing.  gathered[g*3..] receives every
+// rank's payload.  Post-processing by thread 0: WMAX -> *wmax_out = global max;
+// SUMS -> finalize_plan with the global totals (what k_shard_plan does in the RCCL path).
+static __global__ void k_p2p_exchange(P2PPeers peers, int kind, uint64_t seq, const uint64_t* __restrict__ payload,
+                               uint64_t* __restrict__ gathered, Ctl* __restrict__ ctl, double* __restrict__ wmax_out,
+                               PlanArgs pa, int* __restrict__ err) {
+  __shared__ int s_bad;
+  const int g = threadIdx.x;
+  // once a wait has given up, every later exchange of this filter gives up at once (the host
+  // reads the flag with rr_pf_p2p_status); only the first one costs the timeout
+  if (g == 0) s_bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (g < peers.n_ranks && !s_bad) {
+    uint64_t v0 = 0, v1 = 0, v2 = 0;
+    if (kind == kP2PWmax) v0 = payload[0];
+    if (kind == kP2PSums) { v0 = payload[0]; v1 = payload[1]; v2 = payload[2]; }
+    P2PSlot* out = p2p_slot(peers.mbox[g], kind, peers.rank);
+    __hip_atomic_store(&out->v[0], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&out->v[1], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&out->v[2], v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);  // system-scope release of the payload (and of every earlier store of this device)
+    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    P2PSlot* in = p2p_slot(peers.mbox[peers.rank], kind, g);
+    const uint64_t t0 = wall_clock64();  // 100 MHz
+    bool ok = true;
+    while (__hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > 200000000ull) {  // 2 s: a peer is gone; do not hang the device
+        ok = false;
+        break;
+      }
+    }
+    if (!ok) {
+      atomicExch(&s_bad, 1);
+    } else {
+      gathered[3 * g] = __hip_atomic_load(&in->v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      gathered[3 * g + 1] = __hip_atomic_load(&in->v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      gathered[3 * g + 2] = __hip_atomic_load(&in->v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  __syncthreads();
+  if (g != 0) return;
+  if (s_bad) {
+    *err = 1;
+    ctl->fired = 0;  // nothing downstream may act on incomplete data
+    if (kind == kP2PWmax) *wmax_out = 0.0;
+    return;
+  }
+  if (kind == kP2PWmax) {
+    double m = 0.0;
+    for (int k = 0; k < peers.n_ranks; ++k) {
+      const double w = rr_u2d(gathered[3 * k]);
+      if (w > m) m = w;
+    }
+    *wmax_out = m;
+  } else if (kind == kP2PSums) {
+    uint64_t total = 0, base = 0;
+    u128 qq = {0, 0};
+    for (int k = 0; k < peers.n_ranks; ++k) {
+      if (k == peers.rank) base = total;
+      total += gathered[3 * k];
+      qq = add128(qq, u128{gathered[3 * k + 1], gathered[3 * k + 2]});
+    }
+    finalize_plan(ctl, total, base, gathered[3 * peers.rank], qq, pa);
+  }
+}
+
+
+// ---- host side: what a handle owns for the transport
+struct P2PState {
+  P2PMailbox* mbox = nullptr;  // fine-grained: peers write their records here
+  P2PPeers peers{};            // device pointers of every rank's mailbox and slab
+  bool ready = false;
+  void* opened[2 * kMaxP2P] = {};  // IPC mappings to close
+  int n_opened = 0;
+  uint64_t seq = 0;
+  uint64_t* scratch = nullptr;  // [kMaxP2P][3] gathered records + [4] local payload
+  int* err = nullptr;           // device: set when a wait timed out
+  int* err_host = nullptr;
+
+  uint64_t* gathered() const { return scratch; }
+  uint64_t* local3() const { return scratch + 3 * kMaxP2P; }
+
+  void teardown() {
+    for (int k = 0; k < n_opened; ++k) (void)hipIpcCloseMemHandle(opened[k]);
+    n_opened = 0;
+    (void)hipFree(mbox);
+    (void)hipFree(scratch);
+    (void)hipFree(err);
+    if (err_host) (void)hipHostFree(err_host);
+    mbox = nullptr;
+    scratch = nullptr;
+    err = nullptr;
+    err_host = nullptr;
+    ready = false;
+  }
+
+  rr_status local_setup() {
+    if (mbox) return RR_OK;
+    RR_HIP_TRY(hipExtMallocWithFlags((void**)&mbox, sizeof(P2PMailbox), hipDeviceMallocFinegrained));
+    RR_HIP_TRY(hipMemset(mbox, 0, sizeof(P2PMailbox)));
+    RR_HIP_TRY(hipMalloc(&scratch, (3 * kMaxP2P + 4) * sizeof(uint64_t)));
+    RR_HIP_TRY(hipMalloc(&err, sizeof(int)));
+    RR_HIP_TRY(hipMemset(err, 0, sizeof(int)));
+    RR_HIP_TRY(hipHostMalloc(&err_host, sizeof(int)));
+    RR_HIP_TRY(hipDeviceSynchronize());
+    return RR_OK;
+  }
+
+  rr_status export_handles(double* slab, uint8_t out[kP2PHandleBytes]) {
+    rr_status s = local_setup();
+    if (s != RR_OK) return s;
+    static_assert(2 * sizeof(hipIpcMemHandle_t) <= kP2PHandleBytes, "handle blob too small");
+    hipIpcMemHandle_t hs[2];
+    RR_HIP_TRY(hipIpcGetMemHandle(&hs[0], slab));
+    RR_HIP_TRY(hipIpcGetMemHandle(&hs[1], mbox));
+    std::memset(out, 0, kP2PHandleBytes);
+    std::memcpy(out, hs, sizeof hs);
+    return RR_OK;
+  }
+
+  rr_status connect_ipc(double* slab, const uint8_t* all_handles, int n_ranks, int rank) {
+    rr_status s = local_setup();
+    if (s != RR_OK) return s;
+    P2PPeers p{};
+    p.n_ranks = n_ranks;
+    p.rank = rank;
+    for (int g = 0; g < n_ranks; ++g) {
+      if (g == rank) {
+        p.slab[g] = slab;
+        p.mbox[g] = mbox;
+        continue;
+      }
+      hipIpcMemHandle_t hs[2];
+      std::memcpy(hs, all_handles + (size_t)g * kP2PHandleBytes, sizeof hs);
+      void *ps = nullptr, *pm = nullptr;
+      RR_HIP_TRY(hipIpcOpenMemHandle(&ps, hs[0], hipIpcMemLazyEnablePeerAccess));
+      opened[n_opened++] = ps;
+      RR_HIP_TRY(hipIpcOpenMemHandle(&pm, hs[1], hipIpcMemLazyEnablePeerAccess));
+      opened[n_opened++] = pm;
+      p.slab[g] = (double*)ps;
+      p.mbox[g] = (P2PMailbox*)pm;
+    }
+    peers = p;
+    ready = true;
+    seq = 0;
+    return RR_OK;
+  }
+
+  rr_status status(hipStream_t stream, int32_t* timed_out) {
+    *timed_out = 0;
+    if (!err) return RR_OK;
+    RR_HIP_TRY(hipMemcpyAsync(err_host, err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    RR_HIP_TRY(hipStreamSynchronize(stream));
+    *timed_out = *err_host;
+    return RR_OK;
+  }
+};
+
+// in-process wiring: slabs[g], states[g], devices[g] of rank g
+inline rr_status p2p_link_local(P2PState* const* states, double* const* slabs, const int* devices, int n_ranks) {
+  for (int g = 0; g < n_ranks; ++g) {
+    RR_HIP_TRY(hipSetDevice(devices[g]));
+    rr_status s = states[g]->local_setup();
+    if (s != RR_OK) return s;
+  }
+  for (int g = 0; g < n_ranks; ++g) {
+    P2PPeers p{};
+    p.n_ranks = n_ranks;
+    p.rank = g;
+    RR_HIP_TRY(hipSetDevice(devices[g]));
+    for (int k = 0; k < n_ranks; ++k) {
+      if (devices[k] != devices[g]) {
+        int can = 0;
+        RR_HIP_TRY(hipDeviceCanAccessPeer(&can, devices[g], devices[k]));
+        if (!can) return fail(RR_RUNTIME_ERROR, "devices cannot access each other's memory");
+        hipError_t e = hipDeviceEnablePeerAccess(devices[k], 0);
+        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+          return fail(RR_RUNTIME_ERROR, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+        (void)hipGetLastError();
+      }
+      p.slab[k] = slabs[k];
+      p.mbox[k] = states[k]->mbox;
+    }
+    states[g]->peers = p;
+    states[g]->ready = true;
+    states[g]->seq = 0;
+  }
+  return RR_OK;
+}
+
+}  // namespace rr

@@ -25,6 +25,7 @@
 #include <string>
 #include <vector>
 
+#include "p2p_core.hpp"
 #include "resample_core.hpp"
 #include "rr_common.hpp"
 #include "rr_pf.h"
@@ -48,6 +49,8 @@ using rr::kScanThreads;
 using rr::kMaxObsKernarg;
 using rr::kMomentBlocks;
 using rr::kNumMoments;
+using rr::P2PPeers;
+using rr::kMaxP2P;
 
 // layout of ncclUniqueId (rccl.h:43): passed by value to ncclCommInitRank
 struct ncclUniqueIdPod {
@@ -464,104 +467,6 @@ __global__ __launch_bounds__(kBlock) void k_unpack_aos(Bufs b, double* __restric
 
 }  // namespace
 
-// ------------------------------------------------------------------------------------------
-// Device-initiated exchange over xGMI: no host code and no collective library inside a step.
-// Every rank owns a fine-grained mailbox that the peers write 32-byte records into
-// {payload[3], seq}; k_p2p_exchange (one workgroup, one thread per peer) publishes this rank's
-// record to every peer with system-scope release and waits, bounded, for every peer's record
-// with system-scope acquire.  The resample gather then stores each served slot straight into
-// the owning rank's particle slab (coarse-grained memory written by a remote kernel and read by
-// a LATER local kernel -- the same hand-off RCCL's direct P2P receive uses).
-constexpr int kMaxP2P = 16;
-struct P2PSlot {
-  uint64_t v[3];
-  uint64_t seq;
-};
-struct P2PMailbox {
-  P2PSlot wmax[kMaxP2P];
-  P2PSlot sums[kMaxP2P];
-  P2PSlot done[kMaxP2P];
-};
-struct P2PPeers {
-  P2PMailbox* mbox[kMaxP2P];
-  double* slab[kMaxP2P];
-  int n_ranks;
-  int rank;
-};
-enum { kP2PWmax = 0, kP2PSums = 1, kP2PDone = 2 };
-
-__device__ inline P2PSlot* p2p_slot(P2PMailbox* m, int kind, int idx) {
-  return kind == kP2PWmax ? &m->wmax[idx] : (kind == kP2PSums ? &m->sums[idx] : &m->done[idx]);
-}
-
-// payload: kind WMAX -> {bits of the local max weight}, SUMS -> {T, q2_hi, q2_lo} (local device
-// memory written by the previous kernel), DONE -> nothing.  gathered[g*3..] receives every
-// rank's payload.  Post-processing by thread 0: WMAX -> *wmax_out = global max;
-// SUMS -> finalize_plan with the global totals (what k_shard_plan does in the RCCL path).
-__global__ void k_p2p_exchange(P2PPeers peers, int kind, uint64_t seq, const uint64_t* __restrict__ payload,
-                               uint64_t* __restrict__ gathered, Ctl* __restrict__ ctl, double* __restrict__ wmax_out,
-                               PlanArgs pa, int* __restrict__ err) {
-  __shared__ int s_bad;
-  const int g = threadIdx.x;
-  // once a wait has given up, every later exchange of this filter gives up at once (the host
-  // reads the flag with rr_pf_p2p_status); only the first one costs the timeout
-  if (g == 0) s_bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (g < peers.n_ranks && !s_bad) {
-    uint64_t v0 = 0, v1 = 0, v2 = 0;
-    if (kind == kP2PWmax) v0 = payload[0];
-    if (kind == kP2PSums) { v0 = payload[0]; v1 = payload[1]; v2 = payload[2]; }
-    P2PSlot* out = p2p_slot(peers.mbox[g], kind, peers.rank);
-    __hip_atomic_store(&out->v[0], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&out->v[1], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&out->v[2], v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __atomic_thread_fence(__ATOMIC_SEQ_CST);  // system-scope release of the payload (and of every earlier store of this device)
-    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    P2PSlot* in = p2p_slot(peers.mbox[peers.rank], kind, g);
-    const uint64_t t0 = wall_clock64();  // 100 MHz
-    bool ok = true;
-    while (__hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-      __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > 200000000ull) {  // 2 s: a peer is gone; do not hang the device
-        ok = false;
-        break;
-      }
-    }
-    if (!ok) {
-      atomicExch(&s_bad, 1);
-    } else {
-      gathered[3 * g] = __hip_atomic_load(&in->v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      gathered[3 * g + 1] = __hip_atomic_load(&in->v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      gathered[3 * g + 2] = __hip_atomic_load(&in->v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-  __syncthreads();
-  if (g != 0) return;
-  if (s_bad) {
-    *err = 1;
-    ctl->fired = 0;  // nothing downstream may act on incomplete data
-    if (kind == kP2PWmax) *wmax_out = 0.0;
-    return;
-  }
-  if (kind == kP2PWmax) {
-    double m = 0.0;
-    for (int k = 0; k < peers.n_ranks; ++k) {
-      const double w = rr_u2d(gathered[3 * k]);
-      if (w > m) m = w;
-    }
-    *wmax_out = m;
-  } else if (kind == kP2PSums) {
-    uint64_t total = 0, base = 0;
-    u128 qq = {0, 0};
-    for (int k = 0; k < peers.n_ranks; ++k) {
-      if (k == peers.rank) base = total;
-      total += gathered[3 * k];
-      qq = rr::add128(qq, u128{gathered[3 * k + 1], gathered[3 * k + 2]});
-    }
-    rr::finalize_plan(ctl, total, base, gathered[3 * peers.rank], qq, pa);
-  }
-}
-
 // resolve + gather of the slots this rank serves, stored straight into the owners' slabs:
 // global slot s -> rank s / n_local, local index s % n_local, buffer set `Ctl.cur` (every rank
 // flips in lockstep: the gate decision is a function of the global integer sums)
@@ -631,16 +536,7 @@ struct rr_pf {
   bool wmax_live = false;        // Ctl.wmax_bits holds the maximum of the current raw weights
   bool wmax_bits_clean = false;  // Ctl.wmax_bits is known to be zero
   uint64_t last_migrated = 0;
-  // device-initiated exchange over xGMI (rr_pf_p2p_*)
-  P2PMailbox* mbox = nullptr;      // fine-grained: peers write their records here
-  P2PPeers peers{};                // device pointers of every rank's mailbox and slab
-  bool p2p_ready = false;
-  void* p2p_opened[2 * kMaxP2P] = {};  // IPC mappings to close
-  int p2p_n_opened = 0;
-  uint64_t p2p_seq = 0;
-  uint64_t* p2p_scratch = nullptr;  // [kMaxP2P][3] gathered records + [3] local payload
-  int* p2p_err = nullptr;           // device: set when a wait timed out
-  int* p2p_err_host = nullptr;
+  rr::P2PState p2p;  // device-initiated exchange over xGMI (rr_pf_p2p_*)
   bool maybe_pending = false;    // a lazy resample plan was launched and nothing has consumed its markers yet
   rr_pf_lik lik{};
   std::vector<double> landmarks;
@@ -654,32 +550,6 @@ struct rr_pf {
 };
 
 namespace {
-
-void p2p_teardown(rr_pf* h) {
-  for (int k = 0; k < h->p2p_n_opened; ++k) (void)hipIpcCloseMemHandle(h->p2p_opened[k]);
-  h->p2p_n_opened = 0;
-  (void)hipFree(h->mbox);
-  (void)hipFree(h->p2p_scratch);
-  (void)hipFree(h->p2p_err);
-  if (h->p2p_err_host) (void)hipHostFree(h->p2p_err_host);
-  h->mbox = nullptr;
-  h->p2p_scratch = nullptr;
-  h->p2p_err = nullptr;
-  h->p2p_err_host = nullptr;
-  h->p2p_ready = false;
-}
-
-rr_status p2p_local_setup(rr_pf* h) {
-  if (h->mbox) return RR_OK;
-  RR_HIP_TRY(hipExtMallocWithFlags((void**)&h->mbox, sizeof(P2PMailbox), hipDeviceMallocFinegrained));
-  RR_HIP_TRY(hipMemset(h->mbox, 0, sizeof(P2PMailbox)));
-  RR_HIP_TRY(hipMalloc(&h->p2p_scratch, (3 * kMaxP2P + 4) * sizeof(uint64_t)));
-  RR_HIP_TRY(hipMalloc(&h->p2p_err, sizeof(int)));
-  RR_HIP_TRY(hipMemset(h->p2p_err, 0, sizeof(int)));
-  RR_HIP_TRY(hipHostMalloc(&h->p2p_err_host, sizeof(int)));
-  RR_HIP_TRY(hipDeviceSynchronize());
-  return RR_OK;
-}
 
 const char* kKernelNames[RR_K_COUNT] = {"k_propagate_weight", "k_quantize_reduce", "k_scan_tiles", "k_cdf",
                                         "k_resample_gather",  "k_commit",          "k_moments"};
@@ -1152,7 +1022,7 @@ void rr_pf_destroy(rr_pf* h) {
   if (!h) return;
   (void)hipSetDevice(h->opt.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  p2p_teardown(h);
+  h->p2p.teardown();
   (void)hipFree(h->slab);
   (void)hipFree(h->w);
   (void)hipFree(h->cdf);
@@ -1587,20 +1457,6 @@ uint64_t rr_sys_segment_matrix(double rho, const uint64_t* totals, int32_t n_sha
 }
 
 // ---- device-initiated exchange (include/rr_pf.h "peer-to-peer transport")
-rr_status rr_pf_p2p_export(rr_pf* h, uint8_t out[RR_P2P_HANDLE_BYTES]) {
-  rr_status s = bind(h);
-  if (s != RR_OK) return s;
-  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
-  if ((s = p2p_local_setup(h)) != RR_OK) return s;
-  static_assert(2 * sizeof(hipIpcMemHandle_t) <= RR_P2P_HANDLE_BYTES, "handle blob too small");
-  hipIpcMemHandle_t hs[2];
-  RR_HIP_TRY(hipIpcGetMemHandle(&hs[0], h->slab));
-  RR_HIP_TRY(hipIpcGetMemHandle(&hs[1], h->mbox));
-  std::memset(out, 0, RR_P2P_HANDLE_BYTES);
-  std::memcpy(out, hs, sizeof hs);
-  return RR_OK;
-}
-
 static rr_status p2p_check_geometry(const rr_pf* h, int n_ranks, int rank) {
   if (n_ranks <= 0 || n_ranks > kMaxP2P || rank < 0 || rank >= n_ranks)
     return fail(RR_INVALID_PARAMETER, "peer-to-peer transport supports 1..16 ranks");
@@ -1611,79 +1467,44 @@ static rr_status p2p_check_geometry(const rr_pf* h, int n_ranks, int rank) {
   return RR_OK;
 }
 
+rr_status rr_pf_p2p_export(rr_pf* h, uint8_t out[RR_P2P_HANDLE_BYTES]) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  return h->p2p.export_handles(h->slab, out);
+}
+
 rr_status rr_pf_p2p_connect(rr_pf* h, const uint8_t* all_handles, int32_t n_ranks, int32_t rank) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!all_handles) return fail(RR_INVALID_PARAMETER, "null handles");
   if ((s = p2p_check_geometry(h, n_ranks, rank)) != RR_OK) return s;
-  if ((s = p2p_local_setup(h)) != RR_OK) return s;
-  P2PPeers p{};
-  p.n_ranks = n_ranks;
-  p.rank = rank;
-  for (int g = 0; g < n_ranks; ++g) {
-    if (g == rank) {
-      p.slab[g] = h->slab;
-      p.mbox[g] = h->mbox;
-      continue;
-    }
-    hipIpcMemHandle_t hs[2];
-    std::memcpy(hs, all_handles + (size_t)g * RR_P2P_HANDLE_BYTES, sizeof hs);
-    void *slab = nullptr, *mb = nullptr;
-    RR_HIP_TRY(hipIpcOpenMemHandle(&slab, hs[0], hipIpcMemLazyEnablePeerAccess));
-    h->p2p_opened[h->p2p_n_opened++] = slab;
-    RR_HIP_TRY(hipIpcOpenMemHandle(&mb, hs[1], hipIpcMemLazyEnablePeerAccess));
-    h->p2p_opened[h->p2p_n_opened++] = mb;
-    p.slab[g] = (double*)slab;
-    p.mbox[g] = (P2PMailbox*)mb;
-  }
-  h->peers = p;
-  h->p2p_ready = true;
-  h->p2p_seq = 0;
-  return RR_OK;
+  return h->p2p.connect_ipc(h->slab, all_handles, n_ranks, rank);
 }
 
 rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
-  if (!handles) return fail(RR_INVALID_PARAMETER, "null handles");
+  if (!handles || n_ranks <= 0 || n_ranks > kMaxP2P) return fail(RR_INVALID_PARAMETER, "bad handle list");
+  rr::P2PState* st[kMaxP2P];
+  double* slabs[kMaxP2P];
+  int devs[kMaxP2P];
   for (int g = 0; g < n_ranks; ++g) {
-    rr_pf* h = handles[g];
-    rr_status s = bind(h);
+    if (!handles[g]) return fail(RR_INVALID_PARAMETER, "null handle");
+    rr_status s = p2p_check_geometry(handles[g], n_ranks, g);
     if (s != RR_OK) return s;
-    if ((s = p2p_check_geometry(h, n_ranks, g)) != RR_OK) return s;
-    if ((s = p2p_local_setup(h)) != RR_OK) return s;
+    st[g] = &handles[g]->p2p;
+    slabs[g] = handles[g]->slab;
+    devs[g] = handles[g]->opt.device;
   }
-  for (int g = 0; g < n_ranks; ++g) {
-    rr_pf* h = handles[g];
-    P2PPeers p{};
-    p.n_ranks = n_ranks;
-    p.rank = g;
-    for (int k = 0; k < n_ranks; ++k) {
-      if (handles[k]->opt.device != h->opt.device) {
-        int can = 0;
-        RR_HIP_TRY(hipSetDevice(h->opt.device));
-        RR_HIP_TRY(hipDeviceCanAccessPeer(&can, h->opt.device, handles[k]->opt.device));
-        if (!can) return fail(RR_RUNTIME_ERROR, "devices cannot access each other's memory");
-        hipError_t e = hipDeviceEnablePeerAccess(handles[k]->opt.device, 0);
-        if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
-          return fail(RR_RUNTIME_ERROR, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
-        (void)hipGetLastError();
-      }
-      p.slab[k] = handles[k]->slab;
-      p.mbox[k] = handles[k]->mbox;
-    }
-    h->peers = p;
-    h->p2p_ready = true;
-    h->p2p_seq = 0;
-  }
-  return RR_OK;
+  return rr::p2p_link_local(st, slabs, devs, n_ranks);
 }
 
 rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
-  if (!h->p2p_ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_p2p_connect first");
-  const uint64_t seq = ++h->p2p_seq;
-  uint64_t* gathered = h->p2p_scratch;
-  uint64_t* local3 = h->p2p_scratch + 3 * kMaxP2P;
+  if (!h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_p2p_connect first");
+  const uint64_t seq = ++h->p2p.seq;
+  uint64_t* gathered = h->p2p.gathered();
+  uint64_t* local3 = h->p2p.local3();
   // A: propagate + weight; the local maximum stays in Ctl.wmax_bits
   if ((s = materialise(h)) != RR_OK) return s;
   if ((s = validate_control(control)) != RR_OK) return s;
@@ -1696,8 +1517,8 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   h->step += 1;
   PlanArgs pa = plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN);
   // exchange 1: global maximum -> Ctl.wmax (k_quantize_reduce reads it from there)
-  hipLaunchKernelGGL(k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->peers, (int)kP2PWmax, seq,
-                     (const uint64_t*)&h->ctl->wmax_bits, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p_err);
+  hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PWmax, seq,
+                     (const uint64_t*)&h->ctl->wmax_bits, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
   // B: integer image under the global maximum, local sums -> local3
   launch_quantize(h, (const double*)&h->ctl->wmax);
   {
@@ -1706,8 +1527,8 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
                        h->n_tiles, 0, pa, local3);
   }
   // exchange 2: every rank's sums -> plan (gate, base, systematic plan) in Ctl
-  hipLaunchKernelGGL(k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->peers, (int)kP2PSums, seq,
-                     (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p_err);
+  hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PSums, seq,
+                     (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
   // C: mark this shard's sources
   {
     Timed t(h, RR_K_CDF);
@@ -1723,11 +1544,11 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   {
     Timed t(h, RR_K_RESAMPLE_GATHER);
     hipLaunchKernelGGL(k_resolve_gather_p2p, dim3(grid_for(h->n_global, rr::kResolveSlots)), dim3(kBlock), 0, h->stream,
-                       h->b, h->ctl, h->markers, h->carry, h->peers, h->n);
+                       h->b, h->ctl, h->markers, h->carry, h->p2p.peers, h->n);
   }
   // exchange 3: every rank has finished writing into everybody's slab
-  hipLaunchKernelGGL(k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->peers, (int)kP2PDone, seq,
-                     (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p_err);
+  hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PDone, seq,
+                     (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
 }
@@ -1736,12 +1557,7 @@ rr_status rr_pf_p2p_status(rr_pf* h, int32_t* timed_out) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!timed_out) return fail(RR_INVALID_PARAMETER, "null output");
-  *timed_out = 0;
-  if (!h->p2p_err) return RR_OK;
-  RR_HIP_TRY(hipMemcpyAsync(h->p2p_err_host, h->p2p_err, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-  RR_HIP_TRY(hipStreamSynchronize(h->stream));
-  *timed_out = *h->p2p_err_host;
-  return RR_OK;
+  return h->p2p.status(h->stream, timed_out);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -85,13 +85,14 @@ class FastSlam1:
     """Device-resident FastSLAM 1.0 filter (engine extension; the reference has no struct)."""
 
     def __init__(self, n_particles: int, n_landmarks: int, *, params: Optional[_ffi.Fs1Params] = None, seed: int = 0,
-                 device: int = 0, obs_chunks: int = 0):
+                 device: int = 0, obs_chunks: int = 0, first_global_index: int = 0, n_global: int = 0):
         L = _ffi.lib()
         self._L = L
         self.params = params or default_params()
         opt = _ffi.Fs1Options()
         L.rr_fs1_options_default(C.byref(opt))
         opt.device, opt.seed, opt.obs_chunks = device, seed, obs_chunks
+        opt.first_global_index, opt.n_global = int(first_global_index), int(n_global)
         self._h = C.c_void_p()
         _check(L.rr_fs1_create(int(n_particles), int(n_landmarks), C.byref(self.params), C.byref(opt), C.byref(self._h)))
         self.n, self.L = int(n_particles), int(n_landmarks)
@@ -207,6 +208,48 @@ class FastSlam1:
 
 # ---------------------------------------------------------------------------------------------
 # the reference's free functions
+
+class ShardedFastSlam1(FastSlam1):
+    """One shard of a FastSLAM 1.0 filter spread over the GPUs of a node:
+    particles ``[rank * n_local, (rank + 1) * n_local)`` with their whole maps.  The step
+    (``update``) runs over the peer-to-peer transport of include/rr_pf.h -- no host code and no
+    collective library inside it -- and gives the bits the unsharded filter gives.
+
+    ``connect_ipc(allgather)`` is for one process per GPU (``allgather`` returns every rank's
+    handle bytes in rank order, e.g. ``sharded.gloo_allgather(dist)``); ``link_local(shards)``
+    is for several shards inside one process."""
+
+    def __init__(self, rank: int, world: int, n_local: int, n_landmarks: int, *, device: int = 0, **kw):
+        super().__init__(n_local, n_landmarks, device=device, first_global_index=rank * n_local, n_global=world * n_local,
+                         **kw)
+        self.rank, self.world = rank, world
+
+    def connect_ipc(self, allgather) -> None:
+        blob = (C.c_uint8 * 128)()
+        _check(self._L.rr_fs1_p2p_export(self._h, blob))
+        parts = allgather(bytes(blob))
+        allb = (C.c_uint8 * (128 * self.world)).from_buffer_copy(b"".join(parts))
+        _check(self._L.rr_fs1_p2p_connect(self._h, allb, self.world, self.rank))
+
+    @staticmethod
+    def link_local(shards: Sequence["ShardedFastSlam1"]) -> None:
+        arr = (C.c_void_p * len(shards))(*[s._h for s in shards])
+        _check(_ffi.lib().rr_fs1_p2p_connect_local(arr, len(shards)))
+
+    def update_async(self, u, z) -> None:
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        za = _z_array(z)
+        _check(self._L.rr_fs1_shard_update_p2p(self._h, _dp(u), _dp(za) if za.size else None, za.shape[0]))
+
+    def update(self, u, z) -> None:
+        self.update_async(u, z)
+        self.synchronize()
+
+    def timed_out(self) -> bool:
+        out = C.c_int32()
+        _check(self._L.rr_fs1_p2p_status(self._h, C.byref(out)))
+        return bool(out.value)
+
 
 def create_particles(n_particles: int, n_landmarks: int) -> List[Particle]:
     """fastslam1.rs:302-306"""
