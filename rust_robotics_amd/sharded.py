@@ -448,6 +448,7 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     if scheme != _ffi.RR_RESAMPLE_SYSTEMATIC:
         raise SystemExit("the sharded path resamples systematically (use --scheme systematic)")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29555")  # a lone rank started without a launcher
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     u = [1.0, 0.1]
