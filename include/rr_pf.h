@@ -248,10 +248,11 @@ uint64_t rr_sys_segment_matrix(double rho, const uint64_t* totals, int32_t n_sha
 
 /* ---- peer-to-peer transport: the same sharded step with NO host code and NO collective
  * library inside it.  Every rank maps its peers' particle slab and mailbox (hipIpc handles, or
- * plain pointers when all shards live in one process) and the exchanges become three tiny
- * kernels that publish a 32-byte record to every peer over xGMI and wait for theirs (bounded);
- * the resample gather stores each slot straight into the owning rank's slab.  Results are
- * bit-identical to the RCCL path and to the unsharded filter. */
+ * plain pointers when all shards live in one process) and the exchanges become tiny kernels that
+ * publish a 32-byte record to every peer over xGMI and wait for theirs (bounded).  At resample
+ * time only the slots whose source lives on another rank move -- stored straight into the owning
+ * rank's slab -- the others are read through their source index by the next step, exactly as on
+ * one GPU.  Results are bit-identical to the RCCL path and to the unsharded filter. */
 #define RR_P2P_HANDLE_BYTES 128
 /* this rank's IPC handles (slab + mailbox) for the other ranks */
 rr_status rr_pf_p2p_export(rr_pf* h, uint8_t out[RR_P2P_HANDLE_BYTES]);
@@ -261,6 +262,9 @@ rr_status rr_pf_p2p_connect(rr_pf* h, const uint8_t* all_handles, int32_t n_rank
 rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks);
 /* one sharded step, fully asynchronous (nothing is waited for on the host) */
 rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* obs, size_t n_obs);
+/* the same step with an eager gather of ALL slots into their owners' slabs and a separate tile-scan
+ * launch: the plain statement of the protocol, kept for A/B measurement */
+rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const double* obs, size_t n_obs);
 /* synchronises and reports whether any wait gave up (a peer did not answer within 2 s; every
  * later exchange of the filter then returns at once and the resample is skipped) */
 rr_status rr_pf_p2p_status(rr_pf* h, int32_t* timed_out);

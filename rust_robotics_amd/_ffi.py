@@ -174,6 +174,7 @@ def lib() -> C.CDLL:
     proto("rr_pf_p2p_connect", st, [H, U8, i32, i32])
     proto("rr_pf_p2p_connect_local", st, [C.POINTER(H), i32])
     proto("rr_pf_shard_step_p2p", st, [H, P, P, sz])
+    proto("rr_pf_shard_step_p2p_unfused", st, [H, P, P, sz])
     proto("rr_pf_p2p_status", st, [H, C.POINTER(i32)])
     proto("rr_sys_segment_matrix", u64, [d, C.POINTER(u64), i32, u64, u64, i32, C.POINTER(C.c_int64)])
     FP, FO = C.POINTER(Fs1Params), C.POINTER(Fs1Options)

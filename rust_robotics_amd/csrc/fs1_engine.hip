@@ -191,9 +191,8 @@ __global__ __launch_bounds__(kBlock) void k_fs1_normalize(double* __restrict__ p
 // sharded variants.  Slots this shard serves: [first, first + n_served) with
 // first = slots_upto(base), n_served = slots_upto(base + T_local) - first (device-side only).
 __device__ inline void served_range(const Ctl* ctl, uint64_t* first, uint64_t* n_served) {
-  const rr_sys_plan plan = ctl->plan;
-  *first = rr_sys_slots_upto_exact(plan, ctl->total, ctl->base);
-  *n_served = rr_sys_slots_upto_exact(plan, ctl->total, ctl->base + ctl->total_local) - *first;
+  *first = ctl->served_first;
+  *n_served = ctl->served_count;
 }
 
 __global__ __launch_bounds__(kBlock) void k_fs1_indices_sharded(const Ctl* __restrict__ ctl,

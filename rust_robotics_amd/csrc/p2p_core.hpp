@@ -43,13 +43,14 @@ __device__ inline P2PSlot* p2p_slot(P2PMailbox* m, int kind, int idx) {
   return kind == kP2PWmax ? &m->wmax[idx] : (kind == kP2PSums ? &m->sums[idx] : &m->done[idx]);
 }
 
-// payload: kind WMAX -> {bits of the local max weight}, SUMS -> {T, q2_hi, q2_lo} (local device
-// memory written by the previous kernel), DONE -> nothing.  gathered[g*3..] receives every
-// rank's payload.  Post-processing by thread 0: WMAX -> *wmax_out = global max;
-// SUMS -> finalize_plan with the global totals (what k_shard_plan does in the RCCL path).
-static __global__ void k_p2p_exchange(P2PPeers peers, int kind, uint64_t seq, const uint64_t* __restrict__ payload,
-                               uint64_t* __restrict__ gathered, Ctl* __restrict__ ctl, double* __restrict__ wmax_out,
-                               PlanArgs pa, int* __restrict__ err) {
+// One exchange round, executed block-uniformly by a workgroup of >= 64 threads (thread g < n_ranks
+// talks to peer g).  payload (valid in every thread g < n_ranks): kind WMAX -> {bits of the local
+// max weight}, SUMS -> {T, q2_hi, q2_lo}, DONE -> nothing.  gathered[g*3..] receives every rank's
+// payload.  Post-processing by thread 0: WMAX -> *wmax_out = global max; SUMS -> finalize_plan with
+// the global totals (what k_shard_plan does in the RCCL path).
+__device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t seq, uint64_t v0, uint64_t v1, uint64_t v2,
+                                    uint64_t* __restrict__ gathered, Ctl* __restrict__ ctl, double* __restrict__ wmax_out,
+                                    const PlanArgs& pa, int* __restrict__ err) {
   __shared__ int s_bad;
   const int g = threadIdx.x;
   // once a wait has given up, every later exchange of this filter gives up at once (the host
@@ -57,9 +58,6 @@ static __global__ void k_p2p_exchange(P2PPeers peers, int kind, uint64_t seq, co
   if (g == 0) s_bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (g < peers.n_ranks && !s_bad) {
-    uint64_t v0 = 0, v1 = 0, v2 = 0;
-    if (kind == kP2PWmax) v0 = payload[0];
-    if (kind == kP2PSums) { v0 = payload[0]; v1 = payload[1]; v2 = payload[2]; }
     P2PSlot* out = p2p_slot(peers.mbox[g], kind, peers.rank);
     __hip_atomic_store(&out->v[0], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&out->v[1], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -84,6 +82,7 @@ static __global__ void k_p2p_exchange(P2PPeers peers, int kind, uint64_t seq, co
       gathered[3 * g + 2] = __hip_atomic_load(&in->v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
+  __threadfence_block();
   __syncthreads();
   if (g != 0) return;
   if (s_bad) {
@@ -111,6 +110,37 @@ static __global__ void k_p2p_exchange(P2PPeers peers, int kind, uint64_t seq, co
   }
 }
 
+// stand-alone exchange (one workgroup of 64): payload from device memory written by the previous kernel
+static __global__ void k_p2p_exchange(P2PPeers peers, int kind, uint64_t seq, const uint64_t* __restrict__ payload,
+                                      uint64_t* __restrict__ gathered, Ctl* __restrict__ ctl,
+                                      double* __restrict__ wmax_out, PlanArgs pa, int* __restrict__ err) {
+  uint64_t v0 = 0, v1 = 0, v2 = 0;
+  if (kind == kP2PWmax) v0 = payload[0];
+  if (kind == kP2PSums) { v0 = payload[0]; v1 = payload[1]; v2 = payload[2]; }
+  p2p_exchange(peers, kind, seq, v0, v1, v2, gathered, ctl, wmax_out, pa, err);
+}
+
+// k_scan_tiles + the SUMS exchange in one single-workgroup launch: exclusive scan of the tile
+// totals (in place), this shard's sums to every peer, everybody's sums back, gate + plan.
+static __global__ __launch_bounds__(kScanThreads) void k_scan_exchange(P2PPeers peers, uint64_t seq,
+                                                                      uint64_t* __restrict__ tile_total,
+                                                                      const uint64_t* __restrict__ tile_q2,
+                                                                      uint64_t n_tiles, uint64_t* __restrict__ gathered,
+                                                                      Ctl* __restrict__ ctl, PlanArgs pa,
+                                                                      int* __restrict__ err) {
+  __shared__ uint64_t s_pay[3];
+  uint64_t total = 0;
+  u128 qq = {0, 0};
+  scan_tiles_block<kScanThreads>(tile_total, tile_q2, n_tiles, &total, &qq);
+  if (threadIdx.x == 0) {
+    ctl->total_local = total;
+    s_pay[0] = total;
+    s_pay[1] = qq.hi;
+    s_pay[2] = qq.lo;
+  }
+  __syncthreads();
+  p2p_exchange(peers, kP2PSums, seq, s_pay[0], s_pay[1], s_pay[2], gathered, ctl, &ctl->wmax, pa, err);
+}
 
 // ---- host side: what a handle owns for the transport
 struct P2PState {

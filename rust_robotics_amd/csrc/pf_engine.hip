@@ -175,7 +175,13 @@ __global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __r
 // from particle idx[k] of the live buffer set, writing the propagated particle to slot k of the
 // OTHER set; k_quantize_reduce (next in the stream) then flips Ctl.cur.  Without a pending
 // resample it runs in place.  This removes a whole 72 B/particle pass over HBM per step.
-template <bool OBS_KERNARG>
+//
+// SHARDED (rr_pf_shard_step_p2p): the sources come from `lidx` instead of markers -- lidx[k] is the
+// LOCAL source of slot k, or kInPlace when a peer has already stored the resampled particle into
+// slot k of the other buffer set (k_resolve_push) -- and every consumed entry is reset to kInPlace.
+constexpr unsigned int kInPlace = 0xffffffffu;
+
+template <bool OBS_KERNARG, bool SHARDED>
 __global__ __launch_bounds__(kBlock) void k_step_lazy(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
                                                      StepParams p, ObsArg obs_arg,
                                                      const double* __restrict__ obs_dev,
@@ -197,7 +203,13 @@ __global__ __launch_bounds__(kBlock) void k_step_lazy(Bufs b, double* __restrict
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     unsigned int idx[rr::kResolveRows];
     const uint64_t tile_base = tile * rr::kResolveSlots;
-    if (pending) {
+    if (pending && SHARDED) {
+#pragma unroll
+      for (int r = 0; r < rr::kResolveRows; ++r) {
+        const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
+        idx[r] = k < p.n ? markers[k] : 0u;  // `markers` is the lidx array here
+      }
+    } else if (pending) {
       rr::resolve_tile(markers, carry, p.n, tile, idx);
     } else {
 #pragma unroll
@@ -211,9 +223,15 @@ __global__ __launch_bounds__(kBlock) void k_step_lazy(Bufs b, double* __restrict
       x[r] = y[r] = yaw[r] = 0.0;
       if (k < p.n) {
         const uint64_t j = idx[r];
-        x[r] = sx[j];
-        y[r] = sy[j];
-        yaw[r] = syaw[j];
+        if (SHARDED && pending && idx[r] == kInPlace) {  // stored by a peer, already in place
+          x[r] = b.x[dst][k];
+          y[r] = b.y[dst][k];
+          yaw[r] = b.yaw[dst][k];
+        } else {
+          x[r] = sx[j];
+          y[r] = sy[j];
+          yaw[r] = syaw[j];
+        }
       }
     }
 #pragma unroll
@@ -231,7 +249,11 @@ __global__ __launch_bounds__(kBlock) void k_step_lazy(Bufs b, double* __restrict
                                                         : rr_pf_weight_fused(x[r], y[r], s_obs, p.n_obs, p.lik);
         w[k] = wgt;
         if (wgt > wmax_local) wmax_local = wgt;
-        if (pending && idx_out) idx_out[k] = idx[r];
+        if (SHARDED) {
+          if (pending) markers[k] = kInPlace;
+        } else if (pending && idx_out) {
+          idx_out[k] = idx[r];
+        }
       }
     }
   }
@@ -475,9 +497,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_gather_p2p(Bufs b, const Ctl
                                                               const unsigned int* __restrict__ carry,
                                                               P2PPeers peers, uint64_t n_local) {
   if (!ctl->fired) return;
-  const rr_sys_plan plan = ctl->plan;
-  const uint64_t first = rr_sys_slots_upto_exact(plan, ctl->total, ctl->base);
-  const uint64_t n_slots = rr_sys_slots_upto_exact(plan, ctl->total, ctl->base + ctl->total_local) - first;
+  const uint64_t first = ctl->served_first, n_slots = ctl->served_count;
   const uint64_t tile_base = (uint64_t)blockIdx.x * rr::kResolveSlots;
   if (tile_base >= n_slots) return;  // uniform per workgroup
   unsigned int idx[rr::kResolveRows];
@@ -497,6 +517,61 @@ __global__ __launch_bounds__(kBlock) void k_resolve_gather_p2p(Bufs b, const Ctl
       out[3 * n_local + li] = b.v[src][j];
     }
   }
+}
+
+// Sharded lazy resample, phase D: resolve the slots this rank serves.  A slot owned by this rank
+// only gets its LOCAL source index (lidx; the next k_step_lazy<., true> reads through it -- no
+// particle moves); a slot owned by a peer gets the particle stored straight into the peer's OTHER
+// buffer set (the set the next step writes anyway), where the peer's lidx entry says kInPlace.
+// The DONE exchange that follows tells the peers that every store of this rank has landed.
+__global__ __launch_bounds__(kBlock) void k_resolve_push(Bufs b, const Ctl* __restrict__ ctl,
+                                                        unsigned int* __restrict__ markers,
+                                                        const unsigned int* __restrict__ carry,
+                                                        unsigned int* __restrict__ lidx, P2PPeers peers,
+                                                        uint64_t n_local) {
+  if (!ctl->fired) return;
+  const uint64_t first = ctl->served_first, n_slots = ctl->served_count;
+  const uint64_t tile_base = (uint64_t)blockIdx.x * rr::kResolveSlots;
+  if (tile_base >= n_slots) return;  // uniform per workgroup
+  unsigned int idx[rr::kResolveRows];
+  rr::resolve_tile(markers, carry, n_slots, blockIdx.x, idx);
+  const int src = ctl->cur, dst = src ^ 1;  // lazy: Ctl.cur flips when the next step settles
+  const uint64_t me = (uint64_t)peers.rank;
+#pragma unroll
+  for (int r = 0; r < rr::kResolveRows; ++r) {
+    const uint64_t k = tile_base + (uint64_t)r * kBlock + threadIdx.x;
+    if (k < n_slots) {
+      const uint64_t s = first + k;
+      const uint64_t d = s / n_local, li = s - d * n_local;
+      const uint64_t j = idx[r];
+      if (d == me) {
+        lidx[li] = (unsigned int)j;
+      } else {
+        double* __restrict__ out = peers.slab[d] + (size_t)(4 * dst) * n_local;
+        out[li] = b.x[src][j];
+        out[n_local + li] = b.y[src][j];
+        out[2 * n_local + li] = b.yaw[src][j];
+        out[3 * n_local + li] = b.v[src][j];
+      }
+    }
+  }
+}
+
+// make a pending sharded-lazy resample real (accessors): copy the locally-sourced slots, leave
+// the ones a peer stored where they are; k_settle flips the live set afterwards
+__global__ __launch_bounds__(kBlock) void k_gather_lidx(Bufs b, const Ctl* __restrict__ ctl,
+                                                       unsigned int* __restrict__ lidx, uint64_t n) {
+  if (!ctl->pending) return;
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n) return;
+  const unsigned int j = lidx[k];
+  if (j == kInPlace) return;
+  const int src = ctl->cur, dst = src ^ 1;
+  b.x[dst][k] = b.x[src][j];
+  b.y[dst][k] = b.y[src][j];
+  b.yaw[dst][k] = b.yaw[src][j];
+  b.v[dst][k] = b.v[src][j];
+  lidx[k] = kInPlace;
 }
 
 // =============================================================================================
@@ -538,6 +613,8 @@ struct rr_pf {
   uint64_t last_migrated = 0;
   rr::P2PState p2p;  // device-initiated exchange over xGMI (rr_pf_p2p_*)
   bool maybe_pending = false;    // a lazy resample plan was launched and nothing has consumed its markers yet
+  bool pending_sharded = false;  // ... and it is the sharded kind (sources in lidx, not in markers)
+  unsigned int* lidx = nullptr;  // sharded lazy resample: local source per slot, kInPlace = stored by a peer
   rr_pf_lik lik{};
   std::vector<double> landmarks;
   // profiling
@@ -727,6 +804,14 @@ void launch_quantize(rr_pf* h, const double* wmax_src, int settle = 0) {
 // make a pending lazy resample real (accessors and the non-fused entry points call this first)
 rr_status materialise(rr_pf* h) {
   if (!h->maybe_pending) return RR_OK;
+  if (h->pending_sharded) {
+    Timed t(h, RR_K_RESAMPLE_GATHER);
+    hipLaunchKernelGGL(k_gather_lidx, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->lidx, h->n);
+    hipLaunchKernelGGL(k_settle, dim3(1), dim3(1), 0, h->stream, h->ctl);
+    RR_HIP_TRY(hipGetLastError());
+    h->maybe_pending = h->pending_sharded = false;
+    return RR_OK;
+  }
   {
     Timed t(h, RR_K_RESAMPLE_GATHER);
     hipLaunchKernelGGL(k_resolve_gather, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b,
@@ -1031,6 +1116,7 @@ void rr_pf_destroy(rr_pf* h) {
   (void)hipFree(h->tile_q2);
   (void)hipFree(h->idx);
   (void)hipFree(h->markers);
+  (void)hipFree(h->lidx);
   (void)hipFree(h->carry);
   (void)hipFree(h->partials);
   (void)hipFree(h->scratch_a);
@@ -1149,10 +1235,10 @@ rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs,
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
     if (kernarg)
-      hipLaunchKernelGGL((k_step_lazy<true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
+      hipLaunchKernelGGL((k_step_lazy<true, false>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
                          (const double*)nullptr, h->markers, h->carry, h->idx);
     else
-      hipLaunchKernelGGL((k_step_lazy<false>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
+      hipLaunchKernelGGL((k_step_lazy<false, false>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
                          (const double*)h->obs_dev, h->markers, h->carry, h->idx);
   }
   RR_HIP_TRY(hipGetLastError());
@@ -1467,6 +1553,13 @@ static rr_status p2p_check_geometry(const rr_pf* h, int n_ranks, int rank) {
   return RR_OK;
 }
 
+static rr_status p2p_alloc_lidx(rr_pf* h) {
+  if (h->lidx) return RR_OK;
+  RR_HIP_TRY(hipMalloc(&h->lidx, h->n * sizeof(unsigned int)));
+  RR_HIP_TRY(hipMemset(h->lidx, 0xff, h->n * sizeof(unsigned int)));  // kInPlace everywhere
+  return RR_OK;
+}
+
 rr_status rr_pf_p2p_export(rr_pf* h, uint8_t out[RR_P2P_HANDLE_BYTES]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
@@ -1479,6 +1572,7 @@ rr_status rr_pf_p2p_connect(rr_pf* h, const uint8_t* all_handles, int32_t n_rank
   if (s != RR_OK) return s;
   if (!all_handles) return fail(RR_INVALID_PARAMETER, "null handles");
   if ((s = p2p_check_geometry(h, n_ranks, rank)) != RR_OK) return s;
+  if ((s = p2p_alloc_lidx(h)) != RR_OK) return s;
   return h->p2p.connect_ipc(h->slab, all_handles, n_ranks, rank);
 }
 
@@ -1491,6 +1585,8 @@ rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
     if (!handles[g]) return fail(RR_INVALID_PARAMETER, "null handle");
     rr_status s = p2p_check_geometry(handles[g], n_ranks, g);
     if (s != RR_OK) return s;
+    if ((s = bind(handles[g])) != RR_OK) return s;
+    if ((s = p2p_alloc_lidx(handles[g])) != RR_OK) return s;
     st[g] = &handles[g]->p2p;
     slabs[g] = handles[g]->slab;
     devs[g] = handles[g]->opt.device;
@@ -1498,7 +1594,83 @@ rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
   return rr::p2p_link_local(st, slabs, devs, n_ranks);
 }
 
+// Seven launches: propagate+weight (reading through lidx) | WMAX exchange | integer image |
+// tile scan + SUMS exchange + plan | mark | resolve (lidx for own slots, stores into the owners'
+// slabs for the others) | DONE exchange.  Only slots whose source lives on another rank move at
+// resample time; the rest is read through lidx by the next step, as on one GPU.
+// (Running the exchanges in the last workgroup of the producing kernels instead -- ticket
+// counter, scoped atomics -- was measured: the election costs ~5 us per exchange, more than the
+// launch it saves.)
 rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_p2p_connect first");
+  if ((s = validate_control(control)) != RR_OK) return s;
+  if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
+  if (h->maybe_pending && !h->pending_sharded && (s = materialise(h)) != RR_OK) return s;
+  ObsArg arg;
+  bool kernarg;
+  if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
+  StepParams p = make_params(h, control, (int)n_obs);
+  const size_t lds = 3 * n_obs * sizeof(double);
+  if (lds > 150 * 1024) return fail(RR_INVALID_PARAMETER, "too many observations for one LDS block (max 6400)");
+  if (!h->wmax_bits_clean) RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+  const uint64_t seq = ++h->p2p.seq;
+  uint64_t* gathered = h->p2p.gathered();
+  uint64_t* local3 = h->p2p.local3();
+  // A: propagate + weight through lidx
+  const uint64_t n_rtiles = (h->n + rr::kResolveSlots - 1) / rr::kResolveSlots;
+  const unsigned grid = (unsigned)std::min<uint64_t>(n_rtiles, (uint64_t)256 * h->k1_blocks_per_cu);
+  {
+    Timed t(h, RR_K_PROPAGATE_WEIGHT);
+    if (kernarg)
+      hipLaunchKernelGGL((k_step_lazy<true, true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
+                         (const double*)nullptr, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr);
+    else
+      hipLaunchKernelGGL((k_step_lazy<false, true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
+                         (const double*)h->obs_dev, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr);
+  }
+  h->step += 1;
+  PlanArgs pa = plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN);
+  pa.lazy_gather = 1;
+  // exchange 1: global maximum -> Ctl.wmax
+  hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PWmax, seq,
+                     (const uint64_t*)&h->ctl->wmax_bits, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+  // B: integer image under the global maximum (settles the resample K1 consumed)
+  launch_quantize(h, (const double*)&h->ctl->wmax, /*settle=*/1);
+  // tile scan + exchange 2: every rank's sums -> gate, base, plan in Ctl
+  {
+    Timed t(h, RR_K_SCAN_TILES);
+    hipLaunchKernelGGL(rr::k_scan_exchange, dim3(1), dim3(kScanThreads), 0, h->stream, h->p2p.peers, seq, h->tile_total,
+                       (const uint64_t*)h->tile_q2, h->n_tiles, gathered, h->ctl, pa, h->p2p.err);
+  }
+  // C: mark this shard's sources
+  {
+    Timed t(h, RR_K_CDF);
+    hipLaunchKernelGGL(rr::k_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl,
+                       image_args(h), h->tile_total, h->markers, h->carry);
+  }
+  h->wmax_live = false;
+  h->wmax_bits_clean = true;
+  h->rstep += 1;
+  // D: resolve the served slots (worst case: this shard serves all of them; surplus workgroups
+  // return at once) -- own slots -> lidx, the others -> stored into their owners' slabs
+  {
+    Timed t(h, RR_K_RESAMPLE_GATHER);
+    hipLaunchKernelGGL(k_resolve_push, dim3(grid_for(h->n_global, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b,
+                       h->ctl, h->markers, h->carry, h->lidx, h->p2p.peers, h->n);
+  }
+  // exchange 3: every rank's stores into everybody's slab have landed
+  hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PDone, seq,
+                     (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+  RR_HIP_TRY(hipGetLastError());
+  h->maybe_pending = h->pending_sharded = true;
+  return RR_OK;
+}
+
+// The same step with every phase as its own launch (three exchange kernels, eager gather): kept as
+// the plain statement of the protocol and for A/B measurement.
+rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_p2p_connect first");

@@ -65,6 +65,8 @@ struct Ctl {
   double shift_point[4];
   uint64_t best_bits;  // FastSLAM arg-max scratch
   uint64_t best_index;
+  uint64_t served_first;  // systematic plan: this shard's sources feed global slots [served_first,
+  uint64_t served_count;  //   served_first + served_count) -- computed once by finalize_plan
 };
 
 // q_i of local particle i (global index gid0 + i)
@@ -88,12 +90,10 @@ struct ImageArgs {
 // K2: per-tile integer totals and sum of squares.  Tile = 2048 particles; each wave owns 512
 // consecutive particles as 8 coalesced rows of 64.  wmax_src points at the maximum to scale by
 // (Ctl.wmax_bits on one GPU, the all-reduced maximum when sharded).
-static __global__ __launch_bounds__(kTileBlock) void k_quantize_reduce(const double* __restrict__ w,
-                                                                  Ctl* __restrict__ ctl,
-                                                                  const double* __restrict__ wmax_src,
-                                                                  ImageArgs a,
-                                                                  uint64_t* __restrict__ tile_total,
-                                                                  uint64_t* __restrict__ tile_q2, int settle) {
+__device__ inline void quantize_reduce_tile(const double* __restrict__ w, Ctl* __restrict__ ctl,
+                                            const double* __restrict__ wmax_src, const ImageArgs& a,
+                                            uint64_t* __restrict__ tile_total, uint64_t* __restrict__ tile_q2,
+                                            int settle) {
   __shared__ uint64_t s_t[kTileWaves];
   __shared__ uint64_t s_qh[kTileWaves];
   __shared__ uint64_t s_ql[kTileWaves];
@@ -143,6 +143,15 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_reduce(const dou
       ctl->wmax = wmax;
     }
   }
+}
+
+static __global__ __launch_bounds__(kTileBlock) void k_quantize_reduce(const double* __restrict__ w,
+                                                                  Ctl* __restrict__ ctl,
+                                                                  const double* __restrict__ wmax_src,
+                                                                  ImageArgs a,
+                                                                  uint64_t* __restrict__ tile_total,
+                                                                  uint64_t* __restrict__ tile_q2, int settle) {
+  quantize_reduce_tile(w, ctl, wmax_src, a, tile_total, tile_q2, settle);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -205,7 +214,11 @@ __device__ inline void finalize_plan(Ctl* ctl, uint64_t total_global, uint64_t b
       rr_uniform2(a.seed, RR_STREAM_RESAMPLE, a.rstep, 0, &rho, &dummy);
     }
     ctl->rho = rho;
-    ctl->plan = rr_sys_plan_make(rho, total_global, a.n_global);
+    const rr_sys_plan plan = rr_sys_plan_make(rho, total_global, a.n_global);
+    ctl->plan = plan;
+    const uint64_t first = rr_sys_slots_upto_exact(plan, total_global, base);
+    ctl->served_first = first;
+    ctl->served_count = rr_sys_slots_upto_exact(plan, total_global, base + total_local) - first;
   }
 }
 
@@ -213,16 +226,15 @@ __device__ inline void finalize_plan(Ctl* ctl, uint64_t total_global, uint64_t b
 // K3: single workgroup.  Exclusive scan of the tile totals (in place) and the local sums.  On one
 // GPU (single_shard != 0) it also finalises the plan; when sharded it writes the local sums to
 // shard_sums_out (total, q2_hi, q2_lo) for the all-gather and k_shard_plan finishes the job.
-static __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(uint64_t* __restrict__ tile_total,
-                                                                   const uint64_t* __restrict__ tile_q2,
-                                                                   Ctl* __restrict__ ctl, uint64_t n_tiles,
-                                                                   int single_shard, PlanArgs a,
-                                                                   uint64_t* __restrict__ shard_sums_out) {
-  __shared__ uint64_t s_w[kScanThreads / kWave];
-  __shared__ uint64_t s_h[kScanThreads / kWave];
-  __shared__ uint64_t s_l[kScanThreads / kWave];
+// the scan itself, by one workgroup of THREADS threads; thread 0 returns the totals
+template <int THREADS>
+__device__ inline void scan_tiles_block(uint64_t* __restrict__ tile_total, const uint64_t* __restrict__ tile_q2,
+                                        uint64_t n_tiles, uint64_t* total_out, u128* q2_out) {
+  __shared__ uint64_t s_w[THREADS / kWave];
+  __shared__ uint64_t s_h[THREADS / kWave];
+  __shared__ uint64_t s_l[THREADS / kWave];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint64_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
+  const uint64_t per = (n_tiles + THREADS - 1) / THREADS;
   const uint64_t lo = (uint64_t)tid * per;
   const uint64_t hi = lo + per < n_tiles ? lo + per : n_tiles;
   uint64_t local = 0;
@@ -250,10 +262,24 @@ static __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(uint64_t* __
   if (tid == 0) {
     uint64_t total = 0;
     u128 qq = {0, 0};
-    for (int k = 0; k < kScanThreads / kWave; ++k) {
+    for (int k = 0; k < THREADS / kWave; ++k) {
       total += s_w[k];
       qq = add128(qq, u128{s_h[k], s_l[k]});
     }
+    *total_out = total;
+    *q2_out = qq;
+  }
+}
+
+static __global__ __launch_bounds__(kScanThreads) void k_scan_tiles(uint64_t* __restrict__ tile_total,
+                                                                   const uint64_t* __restrict__ tile_q2,
+                                                                   Ctl* __restrict__ ctl, uint64_t n_tiles,
+                                                                   int single_shard, PlanArgs a,
+                                                                   uint64_t* __restrict__ shard_sums_out) {
+  uint64_t total = 0;
+  u128 qq = {0, 0};
+  scan_tiles_block<kScanThreads>(tile_total, tile_q2, n_tiles, &total, &qq);
+  if (threadIdx.x == 0) {
     if (single_shard) {
       finalize_plan(ctl, total, 0, total, qq, a);
     } else {
@@ -482,7 +508,7 @@ static __global__ __launch_bounds__(kBlock) void k_mark(const double* __restrict
   __shared__ uint64_t s_w[kBlock / kWave];
   const TileScan t = tile_scan(w, a, ctl->image_mode, ctl->shift, blockIdx.x, s_w);
   const rr_sys_plan plan = ctl->plan;
-  const uint64_t slot_base = rr_sys_slots_upto_exact(plan, ctl->total, ctl->base);
+  const uint64_t slot_base = ctl->served_first;
   const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
   mark_sources(t, ctl->base + tile_offset[blockIdx.x] + t.thread_off, i0, a.n, plan, ctl->total, slot_base, markers, carry);
 }

@@ -374,6 +374,13 @@ class P2PShard:
         dp = C.POINTER(C.c_double)
         self._check(self.L.rr_pf_shard_step_p2p(self.h, u.ctypes.data_as(dp), obs.ctypes.data_as(dp) if obs.size else None, obs.shape[0]))
 
+    def step_unfused(self, u, obs) -> None:
+        """the same step with every phase as its own launch (A/B measurement)"""
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, 3)
+        dp = C.POINTER(C.c_double)
+        self._check(self.L.rr_pf_shard_step_p2p_unfused(self.h, u.ctypes.data_as(dp), obs.ctypes.data_as(dp) if obs.size else None, obs.shape[0]))
+
     def timed_out(self) -> bool:
         out = C.c_int32()
         self._check(self.L.rr_pf_p2p_status(self.h, C.byref(out)))

@@ -30,7 +30,10 @@ def unsharded(n, steps, seed=42):
     return ref.get_particles_array()
 
 
-def run_in_process(world, n_local, steps=10):
+def run_in_process(world, n_local, steps=10, mode="fused"):
+    """mode: "fused" = the default step (own slots read lazily through their source index, only
+    cross-rank slots move); "unfused" = eager gather of every slot; "mixed" = both alternating, with
+    an accessor (which has to make the pending resample real) in the middle of the run"""
     from rust_robotics_amd.sharded import P2PShard
 
     shards = [P2PShard(g, world, 0, n_local, seed=42, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))
@@ -39,8 +42,12 @@ def run_in_process(world, n_local, steps=10):
     rng = np.random.default_rng(43)
     for t in range(steps):
         obs = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng)
+        fused = mode == "fused" or (mode == "mixed" and t % 3 != 2)
         for s in shards:  # every shard's step is only enqueued; the device-side waits pair them up
-            s.step([1.0, 0.1], obs)
+            (s.step if fused else s.step_unfused)([1.0, 0.1], obs)
+        if mode == "mixed" and t == steps // 2:
+            for s in shards:
+                s.particles()
     exp = unsharded(n_local * world, steps)
     for g, s in enumerate(shards):
         assert not s.timed_out(), f"rank {g}: a peer wait timed out"
@@ -51,13 +58,14 @@ def run_in_process(world, n_local, steps=10):
     print("P2P_LOCAL_OK")
 
 
-@pytest.mark.parametrize("world,n_local", [(1, 5000), (2, 6000), (3, 4100)])
-def test_in_process_shards_equal_unsharded(world, n_local):
+@pytest.mark.parametrize("world,n_local,mode", [(1, 5000, "fused"), (2, 6000, "fused"), (3, 4100, "fused"),
+                                                (2, 6000, "unfused"), (3, 4100, "mixed"), (2, 700_000, "fused")])
+def test_in_process_shards_equal_unsharded(world, n_local, mode):
     """Several shards of one process on ONE GPU only make progress together if each shard's stream
     has its own hardware queue (a spinning wait kernel would otherwise block the peer kernel queued
     behind it), so the case runs in a fresh interpreter with a generous queue count.  One process
     per GPU -- the deployment shape -- has no such constraint."""
-    code = f"import sys; sys.path.insert(0, {ROOT!r}); from tests.test_gpu_p2p import run_in_process; run_in_process({world}, {n_local})"
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); from tests.test_gpu_p2p import run_in_process; run_in_process({world}, {n_local}, mode={mode!r})"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="8"))
     assert r.returncode == 0 and "P2P_LOCAL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
