@@ -43,6 +43,9 @@ namespace {
 
 constexpr int kMaxChunks = 32;
 constexpr int kPlanesPerThread = 8;  // planes one gather thread copies for its output slot
+// sharded lazy resample: idx[p] == kInPlace => a peer has already stored slot p's particle into the
+// OTHER buffer set (k_fs1_push); the consuming kernels then read slot p of that set instead
+constexpr unsigned int kInPlace = 0xffffffffu;
 
 struct Planes {
   double* s[2];  // [(3 + 6L) * N]: planes 0..2 = x, y, yaw; plane 3 + l*6 + f = landmark l field f
@@ -60,9 +63,11 @@ __global__ __launch_bounds__(kBlock) void k_fs1_predict(Planes pl, const Ctl* __
   const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (p >= n) return;
   const bool pending = LAZY && ctl->pending;
-  const double* __restrict__ src = pl.s[ctl->cur];
   double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
-  const uint64_t j = pending ? idx[p] : p;
+  const unsigned int ji = pending ? idx[p] : (unsigned int)p;
+  const bool inplace = pending && ji == kInPlace;
+  const double* __restrict__ src = inplace ? dst : pl.s[ctl->cur];
+  const uint64_t j = inplace ? p : ji;
   double x = src[j], y = src[n + j], yaw = src[2 * n + j];
   double a, b;
   if (EXPLICIT) {
@@ -102,9 +107,11 @@ __global__ __launch_bounds__(kBlock) void k_fs1_observe(Planes pl, double* __res
     // folds the resample gather of the observed landmarks into this kernel's own traffic.  The
     // pose was already moved by k_fs1_predict<LAZY>.
     const bool pending = LAZY && ctl->pending;
-    const double* __restrict__ src = pl.s[ctl->cur];
     double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
-    const uint64_t j = pending ? idx[p] : p;
+    const unsigned int ji = pending ? idx[p] : (unsigned int)p;
+    const bool inplace = pending && ji == kInPlace;
+    const double* src = inplace ? dst : pl.s[ctl->cur];
+    const uint64_t j = inplace ? p : ji;
     const double px = dst[p], py = dst[n + p], pyaw = dst[2 * n + p];
     acc = chunk == 0 ? pw[p] : 1.0;
     // software pipeline: the six plane loads of observation k+1 are issued before the ~300
@@ -195,15 +202,49 @@ __device__ inline void served_range(const Ctl* ctl, uint64_t* first, uint64_t* n
   *n_served = ctl->served_count;
 }
 
+// remote-owned served slots are the two ends of the served range: k in [0, lead) and
+// [tail_start, n_served), with lead / tail_start = where this rank's own slots begin / end in
+// served-slot coordinates
+struct ServedSplit {
+  uint64_t first, n_served, lead, tail_start, n_remote;
+};
+__device__ inline ServedSplit served_split(const Ctl* ctl, uint64_t own_first, uint64_t n_local) {
+  ServedSplit v;
+  served_range(ctl, &v.first, &v.n_served);
+  const uint64_t end = v.first + v.n_served;
+  const uint64_t lo = own_first < v.first ? v.first : (own_first > end ? end : own_first);
+  const uint64_t own_end = own_first + n_local;
+  const uint64_t hi = own_end < v.first ? v.first : (own_end > end ? end : own_end);
+  v.lead = lo - v.first;
+  v.tail_start = hi - v.first;
+  v.n_remote = v.lead + (v.n_served - v.tail_start);
+  return v;
+}
+
+// workgroups [0, own_blocks): one thread per OWN slot -- its local source if this shard serves
+// it, kInPlace if a peer does.  Workgroups beyond: the sources of the served slots that belong to
+// peers (ridx, grid-stride; there are few in steady state).
 __global__ __launch_bounds__(kBlock) void k_fs1_indices_sharded(const Ctl* __restrict__ ctl,
                                                                const uint64_t* __restrict__ cdf, uint64_t n,
-                                                               unsigned int* __restrict__ idx) {
+                                                               uint64_t own_first, unsigned int own_blocks,
+                                                               unsigned int* __restrict__ idx,
+                                                               unsigned int* __restrict__ ridx) {
   if (!ctl->fired) return;
-  uint64_t first, n_served;
-  served_range(ctl, &first, &n_served);
   const rr_sys_plan plan = ctl->plan;
-  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < n_served; k += (uint64_t)gridDim.x * kBlock)
-    idx[k] = (unsigned int)rr_lower_bound_u64(cdf, n, rr_sys_target(plan, first + k));
+  const ServedSplit v = served_split(ctl, own_first, n);
+  if (blockIdx.x < own_blocks) {
+    const uint64_t li = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (li >= n) return;
+    const uint64_t s = own_first + li;
+    idx[li] = (s >= v.first && s < v.first + v.n_served) ? (unsigned int)rr_lower_bound_u64(cdf, n, rr_sys_target(plan, s))
+                                                         : kInPlace;
+    return;
+  }
+  const uint64_t stride = (uint64_t)(gridDim.x - own_blocks) * kBlock;
+  for (uint64_t r = (uint64_t)(blockIdx.x - own_blocks) * kBlock + threadIdx.x; r < v.n_remote; r += stride) {
+    const uint64_t k = r < v.lead ? r : v.tail_start + (r - v.lead);
+    ridx[r] = (unsigned int)rr_lower_bound_u64(cdf, n, rr_sys_target(plan, v.first + k));
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void k_fs1_uniform_weights(const Ctl* __restrict__ ctl, double* __restrict__ pw,
@@ -213,29 +254,29 @@ __global__ __launch_bounds__(kBlock) void k_fs1_uniform_weights(const Ctl* __res
   if (p < n) pw[p] = 1.0 / (double)n_global;  // fastslam1.rs:228
 }
 
-// every served slot's planes straight into the owning shard's slab (set Ctl.cur: the plan kernel
-// flipped it on every shard alike)
-__global__ __launch_bounds__(kBlock) void k_fs1_gather_p2p(Planes pl, const Ctl* __restrict__ ctl,
-                                                          const unsigned int* __restrict__ idx, uint64_t n_local,
-                                                          uint64_t n_planes, rr::P2PPeers peers) {
+// the served slots that belong to peers: all planes of the source particle straight into slot li
+// of the owner's OTHER buffer set (the set its next update writes; the owner's idx says kInPlace)
+__global__ __launch_bounds__(kBlock) void k_fs1_push(Planes pl, const Ctl* __restrict__ ctl,
+                                                    const unsigned int* __restrict__ ridx, uint64_t n_local,
+                                                    uint64_t own_first, uint64_t n_planes, rr::P2PPeers peers) {
   if (!ctl->fired) return;
-  uint64_t first, n_served;
-  served_range(ctl, &first, &n_served);
-  const int cur = ctl->cur;
-  const double* __restrict__ in = pl.s[cur ^ 1];
+  const ServedSplit v = served_split(ctl, own_first, n_local);
+  const int cur = ctl->cur;  // lazy: not flipped yet
+  const double* __restrict__ in = pl.s[cur];
   const uint64_t p0 = (uint64_t)blockIdx.y * kPlanesPerThread;
-  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < n_served; k += (uint64_t)gridDim.x * kBlock) {
-    const uint64_t s = first + k;
+  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < v.n_remote; r += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t k = r < v.lead ? r : v.tail_start + (r - v.lead);
+    const uint64_t s = v.first + k;
     const uint64_t d = s / n_local, li = s - d * n_local;
-    const uint64_t j = idx[k];
-    double* __restrict__ out = peers.slab[d] + (size_t)cur * n_planes * n_local;
-    double v[kPlanesPerThread];
+    const uint64_t j = ridx[r];
+    double* __restrict__ out = peers.slab[d] + (size_t)(cur ^ 1) * n_planes * n_local;
+    double val[kPlanesPerThread];
 #pragma unroll
     for (int q = 0; q < kPlanesPerThread; ++q)
-      if (p0 + q < n_planes) v[q] = in[(p0 + q) * n_local + j];
+      if (p0 + q < n_planes) val[q] = in[(p0 + q) * n_local + j];
 #pragma unroll
     for (int q = 0; q < kPlanesPerThread; ++q)
-      if (p0 + q < n_planes) out[(p0 + q) * n_local + li] = v[q];
+      if (p0 + q < n_planes) out[(p0 + q) * n_local + li] = val[q];
   }
 }
 
@@ -267,6 +308,7 @@ __global__ __launch_bounds__(kBlock) void k_fs1_gather(Planes pl, const Ctl* __r
   const double* __restrict__ in = pl.s[lazy ? cur : cur ^ 1];
   double* __restrict__ out = pl.s[lazy ? cur ^ 1 : cur];
   const uint64_t j = idx[k];
+  if (lazy && idx[k] == kInPlace) return;  // sharded: stored by a peer, already in the other set
   const uint64_t p0 = (uint64_t)blockIdx.y * kPlanesPerThread;
   double v[kPlanesPerThread];
   uint64_t pid[kPlanesPerThread];
@@ -417,6 +459,7 @@ struct rr_fs1 {
   uint64_t* tile_total = nullptr;
   uint64_t* tile_q2 = nullptr;
   unsigned int* idx = nullptr;
+  unsigned int* ridx = nullptr;  // sharded: sources of the served slots that belong to peers (allocated on connect)
   double* partial = nullptr;  // kMaxChunks * n
   double* z_dev = nullptr;
   size_t z_cap = 0;
@@ -742,7 +785,7 @@ rr_status rr_fs1_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs1
   RR_TRY_OR_CLEAN(hipMalloc(&h->cdf, h->n * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->tile_total, h->n_tiles * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->tile_q2, 2 * h->n_tiles * sizeof(uint64_t)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->idx, h->n_global * sizeof(unsigned int)));  // a shard may serve up to n_global slots
+  RR_TRY_OR_CLEAN(hipMalloc(&h->idx, h->n * sizeof(unsigned int)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->partial, (size_t)kMaxChunks * h->n * sizeof(double)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->part_bits, 1024 * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->part_idx, 1024 * sizeof(uint64_t)));
@@ -770,6 +813,7 @@ void rr_fs1_destroy(rr_fs1* h) {
   (void)hipFree(h->tile_total);
   (void)hipFree(h->tile_q2);
   (void)hipFree(h->idx);
+  (void)hipFree(h->ridx);
   (void)hipFree(h->partial);
   (void)hipFree(h->z_dev);
   (void)hipFree(h->noise);
@@ -1012,6 +1056,12 @@ static rr_status fs1_check_geometry(const rr_fs1* h, int n_ranks, int rank) {
   return RR_OK;
 }
 
+static rr_status fs1_alloc_ridx(rr_fs1* h) {
+  if (h->ridx) return RR_OK;
+  RR_HIP_TRY(hipMalloc(&h->ridx, h->n_global * sizeof(unsigned int)));  // worst case: every slot of every peer
+  return RR_OK;
+}
+
 rr_status rr_fs1_p2p_export(rr_fs1* h, uint8_t out[RR_P2P_HANDLE_BYTES]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
@@ -1024,6 +1074,7 @@ rr_status rr_fs1_p2p_connect(rr_fs1* h, const uint8_t* all_handles, int32_t n_ra
   if (s != RR_OK) return s;
   if (!all_handles) return fail(RR_INVALID_PARAMETER, "null handles");
   if ((s = fs1_check_geometry(h, n_ranks, rank)) != RR_OK) return s;
+  if ((s = fs1_alloc_ridx(h)) != RR_OK) return s;
   return h->p2p.connect_ipc(h->slab, all_handles, n_ranks, rank);
 }
 
@@ -1036,6 +1087,8 @@ rr_status rr_fs1_p2p_connect_local(rr_fs1* const* handles, int32_t n_ranks) {
     if (!handles[g]) return fail(RR_INVALID_PARAMETER, "null handle");
     rr_status s = fs1_check_geometry(handles[g], n_ranks, g);
     if (s != RR_OK) return s;
+    if ((s = bind(handles[g])) != RR_OK) return s;
+    if ((s = fs1_alloc_ridx(handles[g])) != RR_OK) return s;
     st[g] = &handles[g]->p2p;
     slabs[g] = handles[g]->slab;
     devs[g] = handles[g]->opt.device;
@@ -1057,30 +1110,36 @@ rr_status rr_fs1_shard_update_p2p(rr_fs1* h, const double u[2], const double* z,
   if ((s = validate_u(u)) != RR_OK) return s;
   bool dup;
   if ((s = validate_z(h, z, n_z, &dup)) != RR_OK) return s;
-  if ((s = materialise(h)) != RR_OK) return s;
   const uint64_t seq = ++h->p2p.seq;
   uint64_t* gathered = h->p2p.gathered();
   uint64_t* local3 = h->p2p.local3();
-  // local: predict + per-observation EKF (in place), local weight maximum in Ctl.wmax_bits
-  if ((s = launch_predict<false, false>(h, u)) != RR_OK) return s;
-  if ((s = launch_observe(h, z, n_z, dup)) != RR_OK) return s;
-  PlanArgs pa = plan_args(h, 0, NAN);
+  // local part, exactly as rr_fs1_update_async: predict + per-observation EKF, reading the previous
+  // resample's survivors through idx (kInPlace = stored by a peer) unless a landmark repeats
+  if (dup) {
+    if ((s = materialise(h)) != RR_OK) return s;
+    if ((s = launch_predict<false, false>(h, u)) != RR_OK) return s;
+    if ((s = launch_observe(h, z, n_z, dup)) != RR_OK) return s;
+  } else {
+    if ((s = launch_predict<false, true>(h, u)) != RR_OK) return s;
+    if ((s = launch_observe(h, z, n_z, dup, /*lazy=*/true)) != RR_OK) return s;
+    if (h->maybe_pending && (s = launch_rest_gather(h, z, n_z)) != RR_OK) return s;
+    h->maybe_pending = false;
+  }
+  PlanArgs pa = plan_args(h, 0, NAN, /*lazy=*/true);
   // exchange 1: global maximum -> Ctl.wmax
   hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PWmax, seq,
                      (const uint64_t*)&h->ctl->wmax_bits, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_QUANTIZE_REDUCE);
     hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
-                       (const double*)&h->ctl->wmax, image_args(h), h->tile_total, h->tile_q2, 0);
+                       (const double*)&h->ctl->wmax, image_args(h), h->tile_total, h->tile_q2, dup ? 0 : 1);
   }
+  // tile scan + exchange 2: every shard's sums -> global totals, gate (N_eff < NTH), plan
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_SCAN_TILES);
-    hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl,
-                       h->n_tiles, 0, pa, local3);
+    hipLaunchKernelGGL(rr::k_scan_exchange, dim3(1), dim3(kScanThreads), 0, h->stream, h->p2p.peers, seq, h->tile_total,
+                       (const uint64_t*)h->tile_q2, h->n_tiles, gathered, h->ctl, pa, h->p2p.err);
   }
-  // exchange 2: every shard's sums -> global totals, gate (N_eff < NTH), plan
-  hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PSums, seq,
-                     (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
   h->wmax_live = false;
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_CDF);
@@ -1091,22 +1150,23 @@ rr_status rr_fs1_shard_update_p2p(rr_fs1* h, const double u[2], const double* z,
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_NORMALIZE);
     hipLaunchKernelGGL(k_fs1_normalize, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
   }
-  const unsigned gx = grid_for(2 * h->n, kBlock);  // grid-stride: a shard may serve more than 2 n_local slots
+  const unsigned own_blocks = grid_for(h->n, kBlock);
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_INDICES);
-    hipLaunchKernelGGL(k_fs1_indices_sharded, dim3(gx), dim3(kBlock), 0, h->stream, h->ctl, h->cdf, h->n, h->idx);
-    hipLaunchKernelGGL(k_fs1_uniform_weights, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->ctl, h->pw, h->n,
-                       h->n_global);
+    hipLaunchKernelGGL(k_fs1_indices_sharded, dim3(own_blocks + 64), dim3(kBlock), 0, h->stream, h->ctl, h->cdf, h->n, h->gid0,
+                       own_blocks, h->idx, h->ridx);
+    hipLaunchKernelGGL(k_fs1_uniform_weights, dim3(own_blocks), dim3(kBlock), 0, h->stream, h->ctl, h->pw, h->n, h->n_global);
   }
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_GATHER);
-    hipLaunchKernelGGL(k_fs1_gather_p2p, dim3(gx, grid_for(h->n_planes, kPlanesPerThread)), dim3(kBlock), 0, h->stream, h->pl,
-                       h->ctl, h->idx, h->n, h->n_planes, h->p2p.peers);
+    hipLaunchKernelGGL(k_fs1_push, dim3(32, grid_for(h->n_planes, kPlanesPerThread)), dim3(kBlock), 0, h->stream, h->pl, h->ctl,
+                       h->ridx, h->n, h->gid0, h->n_planes, h->p2p.peers);
   }
   // exchange 3: everybody has finished writing into everybody's slab
   hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PDone, seq,
                      (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
   RR_HIP_TRY(hipGetLastError());
+  h->maybe_pending = true;  // the next update reads through idx (or an accessor materialises)
   h->rstep += 1;
   return RR_OK;
 }

@@ -67,9 +67,12 @@ def run_in_process(world, n_local, L=7, steps=8, chunks=2):
     for g, s in enumerate(shards):
         s.set_state(poses[g * n_local:(g + 1) * n_local], maps[g * n_local:(g + 1) * n_local])
     ShardedFastSlam1.link_local(shards)
-    for z in zs:
+    for t, z in enumerate(zs):
         for s in shards:  # only enqueued; the device-side waits pair the shards up
             s.update_async([1.0, 0.1], z)
+        if t == 5:  # an accessor in mid-run has to make the pending (lazy) resample real
+            for s in shards:
+                s.poses()
     states = []
     for g, s in enumerate(shards):
         assert not s.timed_out(), f"rank {g}: a peer wait timed out"
