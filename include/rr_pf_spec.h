@@ -108,7 +108,7 @@ RR_HD double rr_pf_weight_fused(double x, double y, const double* obs, int n_obs
     double dx = x - obs[3 * l + 1];
     double dy = y - obs[3 * l + 2];
     double q = rr_fma(dy, dy, dx * dx);
-    qmin = q < qmin ? q : qmin;
+    qmin = __builtin_fmin(q, qmin); /* one v_min_f64; a NaN q leaves qmin alone and poisons ss instead */
     double diff = obs[3 * l] - rr_sqrt_core(q);
     ss = rr_fma(diff, diff, ss);
   }

@@ -341,7 +341,8 @@ __global__ __launch_bounds__(kBlock) void k_resample_gather_mn(Bufs b, const Ctl
                                                               const uint64_t* __restrict__ coarse, int coarse_log2,
                                                               uint64_t n_coarse,
                                                               const double* __restrict__ r_explicit,
-                                                              unsigned int* __restrict__ idx_out, GatherArgs a) {
+                                                              unsigned int* __restrict__ idx_out,
+                                                              unsigned int* __restrict__ lidx_out, GatherArgs a) {
   if (!ctl->fired) return;
   extern __shared__ uint64_t s_coarse[];
   for (uint64_t i = threadIdx.x; i < n_coarse; i += kBlock) s_coarse[i] = coarse[i];
@@ -354,7 +355,8 @@ __global__ __launch_bounds__(kBlock) void k_resample_gather_mn(Bufs b, const Ctl
   const uint64_t lo = blk << coarse_log2;
   const uint64_t len = lo + (1ull << coarse_log2) <= a.n_src ? (1ull << coarse_log2) : a.n_src - lo;
   const uint64_t j = lo + rr_lower_bound_u64(cdf + lo, len, target);
-  copy_particle(b, src, dst, j, k, false, nullptr);
+  if (lidx_out) lidx_out[k] = (unsigned int)j;  // lazy: the next propagate kernel reads through it
+  else copy_particle(b, src, dst, j, k, false, nullptr);
   if (idx_out) idx_out[k] = (unsigned int)j;
 }
 
@@ -613,8 +615,8 @@ struct rr_pf {
   uint64_t last_migrated = 0;
   rr::P2PState p2p;  // device-initiated exchange over xGMI (rr_pf_p2p_*)
   bool maybe_pending = false;    // a lazy resample plan was launched and nothing has consumed its markers yet
-  bool pending_sharded = false;  // ... and it is the sharded kind (sources in lidx, not in markers)
-  unsigned int* lidx = nullptr;  // sharded lazy resample: local source per slot, kInPlace = stored by a peer
+  bool pending_lidx = false;     // ... and its sources are in lidx, not in markers (sharded step, multinomial step)
+  unsigned int* lidx = nullptr;  // source index per slot; kInPlace = a peer stored the particle already (sharded)
   rr_pf_lik lik{};
   std::vector<double> landmarks;
   // profiling
@@ -804,12 +806,12 @@ void launch_quantize(rr_pf* h, const double* wmax_src, int settle = 0) {
 // make a pending lazy resample real (accessors and the non-fused entry points call this first)
 rr_status materialise(rr_pf* h) {
   if (!h->maybe_pending) return RR_OK;
-  if (h->pending_sharded) {
+  if (h->pending_lidx) {
     Timed t(h, RR_K_RESAMPLE_GATHER);
     hipLaunchKernelGGL(k_gather_lidx, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->lidx, h->n);
     hipLaunchKernelGGL(k_settle, dim3(1), dim3(1), 0, h->stream, h->ctl);
     RR_HIP_TRY(hipGetLastError());
-    h->maybe_pending = h->pending_sharded = false;
+    h->maybe_pending = h->pending_lidx = false;
     return RR_OK;
   }
   {
@@ -841,7 +843,8 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
                           bool lazy = false, int settle = 0) {
   launch_quantize(h, wmax_source(h), settle);
   PlanArgs pa = plan_args(h, mode, scheme, rho_override);
-  lazy = lazy && scheme == RR_RESAMPLE_SYSTEMATIC;
+  const bool lazy_mn = lazy && scheme == RR_RESAMPLE_MULTINOMIAL && h->lidx && !r_explicit_dev;
+  lazy = (lazy && scheme == RR_RESAMPLE_SYSTEMATIC) || lazy_mn;
   pa.lazy_gather = lazy ? 1 : 0;
   const bool fused = h->n_tiles <= (uint64_t)rr::kFusedMaxTiles;
   const bool sys = scheme == RR_RESAMPLE_SYSTEMATIC;
@@ -868,7 +871,19 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
   }
   h->wmax_live = false;       // consumed: Ctl.wmax holds the value from now on
   h->wmax_bits_clean = true;  // the plan kernel zeroed the accumulator
-  if (lazy) {
+  if (lazy_mn) {  // only the source indices; the next k_step_lazy<., true> (or materialise) reads through them
+    Timed t(h, RR_K_RESAMPLE_GATHER);
+    GatherArgs g{};
+    g.n_src = h->n;
+    g.n_slots = h->n;
+    g.seed = h->opt.seed;
+    g.rstep = h->rstep;
+    g.scheme = scheme;
+    hipLaunchKernelGGL(k_resample_gather_mn, dim3(grid_for(h->n, kBlock)), dim3(kBlock), h->n_coarse * sizeof(uint64_t),
+                       h->stream, h->b, h->ctl, h->cdf, h->cdf_coarse, h->coarse_log2, h->n_coarse, (const double*)nullptr,
+                       h->idx, h->lidx, g);
+    h->maybe_pending = h->pending_lidx = true;
+  } else if (lazy) {
     h->maybe_pending = true;  // the next k_step_lazy (or materialise) moves the particles
   } else {
     Timed t(h, RR_K_RESAMPLE_GATHER);
@@ -886,7 +901,7 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
       g.to_staging = 0;
       hipLaunchKernelGGL(k_resample_gather_mn, dim3(grid_for(h->n, kBlock)), dim3(kBlock), h->n_coarse * sizeof(uint64_t),
                          h->stream, h->b, h->ctl, h->cdf, h->cdf_coarse, h->coarse_log2, h->n_coarse, r_explicit_dev, h->idx,
-                         g);
+                         (unsigned int*)nullptr, g);
     }
   }
   RR_HIP_TRY(hipGetLastError());
@@ -1012,6 +1027,10 @@ rr_status create_common(const rr_pf_config* cfg, const rr_pf_options* opt_in, co
   RR_TRY_OR_CLEAN(hipMalloc(&h->tile_total, h->n_tiles * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->tile_q2, 2 * h->n_tiles * sizeof(uint64_t)));
   if (opt.record_indices) RR_TRY_OR_CLEAN(hipMalloc(&h->idx, h->n * sizeof(unsigned int)));
+  if (opt.resample_scheme == RR_RESAMPLE_MULTINOMIAL) {  // the fused step resamples lazily through lidx
+    RR_TRY_OR_CLEAN(hipMalloc(&h->lidx, h->n * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(hipMemset(h->lidx, 0xff, h->n * sizeof(unsigned int)));
+  }
   {
     const size_t nm = (size_t)n_global + rr::kResolveSlots;
     RR_TRY_OR_CLEAN(hipMalloc(&h->markers, nm * sizeof(unsigned int)));
@@ -1218,11 +1237,13 @@ rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs,
   bool kernarg;
   if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
   StepParams p = make_params(h, control, (int)n_obs);
-  if (h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC) {
+  const bool multinomial = h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC;
+  if (multinomial && !h->lidx) {
     if ((s = launch_pw<true, true, false>(h, p, arg, kernarg)) != RR_OK) return s;
     h->step += 1;
     return launch_resample(h, 0, h->opt.resample_scheme, NAN, nullptr);
   }
+  if (h->maybe_pending && h->pending_lidx != multinomial && (s = materialise(h)) != RR_OK) return s;
   // systematic: 3 launches per step -- k_step_lazy (propagate + weight, reading through the
   // previous resample's indices), k_quantize_reduce, k_plan_mark
   const size_t lds = 3 * n_obs * sizeof(double);
@@ -1234,17 +1255,25 @@ rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs,
   const unsigned grid = (unsigned)std::min<uint64_t>(n_rtiles, (uint64_t)256 * h->k1_blocks_per_cu);
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
-    if (kernarg)
+    if (multinomial) {  // sources of the previous (multinomial) resample are in lidx
+      if (kernarg)
+        hipLaunchKernelGGL((k_step_lazy<true, true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
+                           (const double*)nullptr, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr);
+      else
+        hipLaunchKernelGGL((k_step_lazy<false, true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
+                           (const double*)h->obs_dev, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr);
+    } else if (kernarg) {
       hipLaunchKernelGGL((k_step_lazy<true, false>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
                          (const double*)nullptr, h->markers, h->carry, h->idx);
-    else
+    } else {
       hipLaunchKernelGGL((k_step_lazy<false, false>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
                          (const double*)h->obs_dev, h->markers, h->carry, h->idx);
+    }
   }
   RR_HIP_TRY(hipGetLastError());
   h->step += 1;
-  h->maybe_pending = false;  // consumed (k_quantize_reduce settles Ctl.cur)
-  return launch_resample(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN, nullptr, /*lazy=*/true, /*settle=*/1);
+  h->maybe_pending = h->pending_lidx = false;  // consumed (k_quantize_reduce settles Ctl.cur)
+  return launch_resample(h, 0, h->opt.resample_scheme, NAN, nullptr, /*lazy=*/true, /*settle=*/1);
 }
 
 rr_status rr_pf_synchronize(rr_pf* h) {
@@ -1607,7 +1636,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   if (!h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_p2p_connect first");
   if ((s = validate_control(control)) != RR_OK) return s;
   if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
-  if (h->maybe_pending && !h->pending_sharded && (s = materialise(h)) != RR_OK) return s;
+  if (h->maybe_pending && !h->pending_lidx && (s = materialise(h)) != RR_OK) return s;
   ObsArg arg;
   bool kernarg;
   if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
@@ -1664,7 +1693,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PDone, seq,
                      (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
   RR_HIP_TRY(hipGetLastError());
-  h->maybe_pending = h->pending_sharded = true;
+  h->maybe_pending = h->pending_lidx = true;
   return RR_OK;
 }
 
