@@ -3,8 +3,9 @@
  * Drop-in boundary for the hot path of
  *   rust_robotics_localization::particle_filter::ParticleFilterLocalizer
  *     (/root/reference/crates/rust_robotics_localization/src/particle_filter.rs:121-573)
- *   rust_robotics_localization::monte_carlo_localization::MonteCarloLocalizer in its
- *     fixed-N mode, min_particles == max_particles
+ *   rust_robotics_localization::monte_carlo_localization::MonteCarloLocalizer, with a fixed
+ *     particle count (min_particles == max_particles: the BASELINE "MCL" configurations) or the
+ *     KLD-adaptive count (rr_pf_create_adaptive)
  *     (/root/reference/crates/rust_robotics_localization/src/monte_carlo_localization.rs:136-462)
  * The reference offers no FFI/plugin interface (it is `#![forbid(unsafe_code)]`
  * Rust, lib.rs:1); the seam is its struct + trait surface.  Every entry point
@@ -87,6 +88,14 @@ typedef struct rr_pf_options {
 
 typedef struct rr_pf rr_pf; /* opaque: device-resident particle set + stream */
 
+/* The KLD part of MonteCarloLocalizationConfig, monte_carlo_localization.rs:51-82 */
+typedef struct rr_mcl_adaptive {
+  uint64_t min_particles; /* 100; the filter starts with this many (try_new :147) */
+  uint64_t max_particles; /* 5000; capacity of the device buffers */
+  double kld_epsilon;     /* 0.05 */
+  double kld_z;           /* 2.326 */
+} rr_mcl_adaptive;
+
 /* ParticleFilterConfig::default(), particle_filter.rs:67-78 */
 void rr_pf_config_default(rr_pf_config* cfg);
 /* ParticleFilterConfig::validate(), particle_filter.rs:81-117 (same messages) */
@@ -103,6 +112,23 @@ rr_status rr_pf_create(const rr_pf_config* cfg, const rr_pf_options* opt, rr_pf*
 rr_status rr_pf_create_with_state(const rr_pf_config* cfg, const rr_pf_options* opt,
                                   const double state[4], rr_pf** out);
 void rr_pf_destroy(rr_pf* h);
+
+/* ---- MonteCarloLocalizer with min_particles < max_particles: the particle count adapts every
+ * step to the KLD bound over the occupied 0.5 m x 0.5 m x 15 deg bins
+ * (resample_adaptive, monte_carlo_localization.rs:322-365; kld_required_particles :367-378).
+ * cfg->n_particles is ignored (the filter starts with kld->min_particles); state may be NULL
+ * (try_new :142-156) or the initial state of try_with_initial_state (:170-199).  The options must
+ * ask for multinomial resampling at every step (rr_pf_options_mcl); sharding is not available.
+ * The reference draws particles one at a time until the bound holds; the engine evaluates all
+ * max_particles candidate draws at once and keeps the same prefix.  Every resample of such a
+ * filter synchronises with the host once (the new count sizes the next launches). */
+void rr_mcl_adaptive_default(rr_mcl_adaptive* kld);
+/* MonteCarloLocalizationConfig::validate, :84-131 (same messages) */
+rr_status rr_mcl_adaptive_validate(const rr_mcl_adaptive* kld);
+rr_status rr_pf_create_adaptive(const rr_pf_config* cfg, const rr_pf_options* opt, const rr_mcl_adaptive* kld,
+                                const double* state, rr_pf** out);
+/* largest particle count the filter can hold (max_particles; n_particles for a fixed-N filter) */
+uint64_t rr_pf_particle_capacity(const rr_pf* h);
 
 /* try_set_landmarks :216-220 (stored only, never read by the update -- Q19);
  * xy = n x (x, y) */
@@ -133,7 +159,7 @@ rr_status rr_pf_synchronize(rr_pf* h);
 rr_status rr_pf_estimate(rr_pf* h, double out[4]);
 /* calc_covariance :363-365 -- 4x4 row-major */
 rr_status rr_pf_covariance(rr_pf* h, double out[16]);
-/* config.n_particles */
+/* particle_count(): config.n_particles, or the current count of an adaptive filter (:318-320) */
 uint64_t rr_pf_particle_count(const rr_pf* h);
 /* get_particles :244-246; out = N x (x, y, yaw, v, w) with normalised w */
 rr_status rr_pf_get_particles(rr_pf* h, double* out_aos);
@@ -150,6 +176,12 @@ rr_status rr_pf_set_particles(rr_pf* h, const double* aos);
  * (n_v[i], n_w[i] are the values Normal(0, sigma).sample() would have returned) */
 rr_status rr_pf_predict_with_noise(rr_pf* h, const double control[2], const double* n_v,
                                    const double* n_w);
+/* adaptive filters only: overwrite the particle set with n <= max_particles particles
+ * (what the reference's own test does through its private field, :521-545) */
+rr_status rr_pf_set_particles_n(rr_pf* h, const double* aos, uint64_t n);
+/* adaptive filters only: resample_adaptive with caller-supplied uniforms r[max_particles]
+ * (draw m consumes r[m]); *n_new receives the new particle count */
+rr_status rr_pf_resample_adaptive_with_uniforms(rr_pf* h, const double* r, size_t n_r, uint64_t* n_new);
 /* unconditional multinomial resample with caller-supplied uniforms r[N] in [0,1) */
 rr_status rr_pf_resample_with_uniforms(rr_pf* h, const double* r, size_t n);
 /* unconditional systematic resample with caller-supplied rho = r0 * N in [0,1) */

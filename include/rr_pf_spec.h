@@ -209,6 +209,52 @@ RR_HD uint64_t rr_fix_target_multinomial(double r, uint64_t total) {
   return t ? t : 1; /* r == 0 selects the first particle of non-zero weight */
 }
 
+/* ===================================================================== KLD-adaptive particle count */
+/* monte_carlo_localization.rs:322-385.  The reference draws particles one at a time and stops at
+ * the first count m with m >= min_particles and m >= required, required = max over the draws so
+ * far of kld_required_particles(number of distinct occupied bins).  Everything below is a pure
+ * function of the draw sequence, so the engine evaluates all max_particles candidate draws in
+ * parallel and takes the first count that satisfies the stop rule. */
+
+/* `x as i32` of Rust: saturating, NaN -> 0 */
+RR_HD int32_t rr_sat_i32(double v) {
+  if (v != v) return 0;
+  if (v <= -2147483648.0) return (int32_t)(-2147483647 - 1);
+  if (v >= 2147483647.0) return 2147483647;
+  return (int32_t)v;
+}
+
+/* quantize_particle :380-385: bins of 0.5 m x 0.5 m x 15 degrees */
+#define RR_KLD_XY_BIN 0.5
+#define RR_KLD_YAW_BIN (15.0 * 3.14159265358979323846 / 180.0)
+RR_HD void rr_kld_bin(double x, double y, double yaw, int32_t* xb, int32_t* yb, int32_t* ab) {
+  *xb = rr_sat_i32(__builtin_floor(x / RR_KLD_XY_BIN));
+  *yb = rr_sat_i32(__builtin_floor(y / RR_KLD_XY_BIN));
+  *ab = rr_sat_i32(__builtin_floor(yaw / RR_KLD_YAW_BIN));
+}
+
+/* kld_required_particles :367-378 (Wilson-Hilferty bound), clamped to [min_p, max_p] */
+RR_HD uint64_t rr_kld_required(uint64_t k_bins, uint64_t min_p, uint64_t max_p, double eps, double z) {
+  if (k_bins <= 1) return min_p;
+  double km1 = (double)(k_bins - 1);
+  double a = 2.0 / (9.0 * km1);
+  double term = (1.0 - a) + z * rr_sqrt(a);
+  double n = (km1 / (2.0 * eps)) * ((term * term) * term); /* powi(3) */
+  double c = __builtin_ceil(n);
+  uint64_t r;
+  if (!(c > 0.0)) r = 0; /* `as usize`: negative and NaN -> 0 */
+  else if (c >= 18446744073709551615.0) r = ~(uint64_t)0;
+  else r = (uint64_t)c;
+  if (r < min_p) r = min_p;
+  if (r > max_p) r = max_p;
+  return r;
+}
+
+/* stop rule :354-357 for the draw with 0-based index m: count = m + 1 particles so far */
+RR_HD int rr_kld_stop(uint64_t m, uint64_t required, uint64_t min_p) {
+  return (m + 1 >= min_p) && (m + 1 >= required);
+}
+
 /* Systematic resampling (fastslam1.rs:219-231): output i sits at (i + rho)/n,
  * rho = u0 in [0,1); offs = floor(rho*T); target_i = ceil((i*T + offs)/n). */
 typedef struct rr_sys_plan {

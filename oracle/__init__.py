@@ -91,6 +91,10 @@ def ref() -> C.CDLL:
     for f in (L.ref_pf_resample_indices, L.ref_pf_resample_indices_bsearch, L.ref_mcl_resample_indices):
         f.argtypes = [sz, P, P, u32]
         f.restype = None
+    L.ref_kld_required.argtypes = [sz, sz, sz, d, d]
+    L.ref_kld_required.restype = sz
+    L.ref_mcl_resample_adaptive.argtypes = [sz, P, P, P, P, P, sz, sz, d, d, u32]
+    L.ref_mcl_resample_adaptive.restype = sz
     L.ref_pf_gather.argtypes = [sz, P, P, P, P, P, u32]
     L.ref_pf_gather.restype = None
     L.ref_pf_step.argtypes = [sz, P, P, P, P, P, d, d, d, P, P, P, sz, d, d, i, P, u32, P]
@@ -161,6 +165,10 @@ def det() -> C.CDLL:
     L.det_fix_neff.restype = d
     L.det_indices_multinomial.argtypes = [sz, c_u64_p, u64, sz, sz, P, u64, u32v, u32]
     L.det_indices_multinomial.restype = None
+    L.det_kld_required.argtypes = [u64, u64, u64, d, d]
+    L.det_kld_required.restype = u64
+    L.det_mcl_resample_adaptive.argtypes = [sz, P, P, P, c_u64_p, u64, P, u64, u32v, u64, u64, d, d, u32]
+    L.det_mcl_resample_adaptive.restype = sz
     L.det_resample_rho.argtypes = [u64, u32v]
     L.det_resample_rho.restype = d
     L.det_indices_systematic.argtypes = [sz, c_u64_p, u64, u64, sz, sz, d, u32]

@@ -124,6 +124,43 @@ void det_indices_multinomial(size_t n, const uint64_t* cdf, uint64_t total, size
   }
 }
 
+/* KLD-adaptive resample of the D-spec: multinomial draws over the integer CDF (n entries, grand
+ * total `total`), r explicit or Philox (seed, RESAMPLE stream, rstep, draw index); sequential
+ * evaluation of the stop rule.  Returns the new particle count, idx[0..count) = sources. */
+uint64_t det_kld_required(uint64_t k, uint64_t min_p, uint64_t max_p, double eps, double z) {
+  return rr_kld_required(k, min_p, max_p, eps, z);
+}
+
+size_t det_mcl_resample_adaptive(size_t n, const double* x, const double* y, const double* yaw, const uint64_t* cdf,
+                                 uint64_t total, const double* r, uint64_t seed, uint32_t rstep, uint64_t min_p,
+                                 uint64_t max_p, double eps, double z, uint32_t* idx) {
+  int32_t* bins = (int32_t*)malloc(3 * max_p * sizeof(int32_t));
+  size_t k = 0, count = 0;
+  uint64_t required = min_p;
+  while (count < max_p) {
+    double rk, dummy;
+    if (r) rk = r[count]; else rr_uniform2(seed, RR_STREAM_RESAMPLE, rstep, count, &rk, &dummy);
+    size_t j = rr_lower_bound_u64(cdf, n, rr_fix_target_multinomial(rk, total));
+    if (j >= n) j = n - 1;
+    int32_t b0, b1, b2;
+    rr_kld_bin(x[j], y[j], yaw[j], &b0, &b1, &b2);
+    int seen = 0;
+    for (size_t q = 0; q < k && !seen; ++q) seen = bins[3 * q] == b0 && bins[3 * q + 1] == b1 && bins[3 * q + 2] == b2;
+    if (!seen) {
+      bins[3 * k] = b0; bins[3 * k + 1] = b1; bins[3 * k + 2] = b2;
+      ++k;
+    }
+    uint64_t need = rr_kld_required(k, min_p, max_p, eps, z);
+    if (need > required) required = need;
+    idx[count] = (uint32_t)j;
+    const int stop = rr_kld_stop(count, required, min_p);
+    ++count;
+    if (stop) break;
+  }
+  free(bins);
+  return count;
+}
+
 double det_resample_rho(uint64_t seed, uint32_t rstep) {
   double a, b;
   rr_uniform2(seed, RR_STREAM_RESAMPLE, rstep, 0, &a, &b);

@@ -183,6 +183,64 @@ void ref_mcl_resample_indices(size_t n, const double* w, const double* r, uint32
   free(cum);
 }
 
+/* monte_carlo_localization.rs:322-385, resample_adaptive with min_particles <= max_particles.
+ * w = normalised weights of the n current particles, r = the uniforms the reference would have
+ * drawn (at most max_p of them are consumed).  Writes the source index of every new particle to
+ * idx (capacity max_p) and returns the new particle count.  The bin set is a plain list (the
+ * reference's HashSet only answers "seen before?"). */
+static int32_t ref_sat_i32(double v) {
+  if (v != v) return 0;
+  if (v <= -2147483648.0) return (int32_t)(-2147483647 - 1);
+  if (v >= 2147483647.0) return 2147483647;
+  return (int32_t)v;
+}
+
+size_t ref_kld_required(size_t k_bins, size_t min_p, size_t max_p, double eps, double z) {
+  if (k_bins <= 1) return min_p; /* :368-370 */
+  double k_minus_one = (double)(k_bins - 1);
+  double term = 1.0 - 2.0 / (9.0 * k_minus_one) + z * sqrt(2.0 / (9.0 * k_minus_one));
+  double n = (k_minus_one / (2.0 * eps)) * (term * term * term);
+  double c = ceil(n);
+  size_t r = !(c > 0.0) ? 0 : (c >= 18446744073709551615.0 ? (size_t)-1 : (size_t)c);
+  if (r < min_p) r = min_p;
+  if (r > max_p) r = max_p;
+  return r;
+}
+
+size_t ref_mcl_resample_adaptive(size_t n, const double* x, const double* y, const double* yaw, const double* w,
+                                 const double* r, size_t min_p, size_t max_p, double eps, double z, uint32_t* idx) {
+  if (n == 0) return 0;
+  double* cum = (double*)malloc(n * sizeof(double));
+  double cs = 0.0;
+  for (size_t i = 0; i < n; ++i) {
+    cs += w[i];
+    cum[i] = cs;
+  }
+  cum[n - 1] = 1.0; /* :334-336 */
+  int32_t* bins = (int32_t*)malloc(3 * max_p * sizeof(int32_t));
+  size_t k = 0, count = 0, required = min_p;
+  const double yaw_bin = 15.0 * M_PI / 180.0;
+  while (count < max_p) {
+    size_t j = n - 1; /* sample_index :387-392: first i with r <= c[i], else last */
+    for (size_t i = 0; i < n; ++i)
+      if (r[count] <= cum[i]) { j = i; break; }
+    int32_t b0 = ref_sat_i32(floor(x[j] / 0.5)), b1 = ref_sat_i32(floor(y[j] / 0.5)), b2 = ref_sat_i32(floor(yaw[j] / yaw_bin));
+    int seen = 0;
+    for (size_t q = 0; q < k && !seen; ++q) seen = bins[3 * q] == b0 && bins[3 * q + 1] == b1 && bins[3 * q + 2] == b2;
+    if (!seen) {
+      bins[3 * k] = b0; bins[3 * k + 1] = b1; bins[3 * k + 2] = b2;
+      ++k;
+    }
+    size_t need = ref_kld_required(k, min_p, max_p, eps, z);
+    if (need > required) required = need;
+    idx[count++] = (uint32_t)j;
+    if (count >= min_p && count >= required) break;
+  }
+  free(cum);
+  free(bins);
+  return count;
+}
+
 /* gather + uniform weights, particle_filter.rs:467-469 */
 void ref_pf_gather(size_t n, double* x, double* y, double* yaw, double* v, double* w,
                    const uint32_t* idx) {

@@ -61,6 +61,13 @@ class PfFixedSums(C.Structure):
     ]
 
 
+class MclAdaptive(C.Structure):
+    """rr_mcl_adaptive (include/rr_pf.h)"""
+
+    _fields_ = [("min_particles", C.c_uint64), ("max_particles", C.c_uint64), ("kld_epsilon", C.c_double),
+                ("kld_z", C.c_double)]
+
+
 class Fs1Params(C.Structure):
     """rr_fs1_params: the constants of fastslam1.rs:13-23 as fields"""
 
@@ -173,6 +180,13 @@ def lib() -> C.CDLL:
     proto("rr_pf_p2p_export", st, [H, U8])
     proto("rr_pf_p2p_connect", st, [H, U8, i32, i32])
     proto("rr_pf_p2p_connect_local", st, [C.POINTER(H), i32])
+    KP = C.POINTER(MclAdaptive)
+    proto("rr_mcl_adaptive_default", None, [KP])
+    proto("rr_mcl_adaptive_validate", st, [KP])
+    proto("rr_pf_create_adaptive", st, [C.POINTER(PfConfig), C.POINTER(PfOptions), KP, P, C.POINTER(H)])
+    proto("rr_pf_particle_capacity", u64, [H])
+    proto("rr_pf_set_particles_n", st, [H, P, u64])
+    proto("rr_pf_resample_adaptive_with_uniforms", st, [H, P, sz, C.POINTER(u64)])
     proto("rr_pf_shard_step_p2p", st, [H, P, P, sz])
     proto("rr_pf_shard_step_p2p_unfused", st, [H, P, P, sz])
     proto("rr_pf_p2p_status", st, [H, C.POINTER(i32)])

@@ -576,6 +576,139 @@ __global__ __launch_bounds__(kBlock) void k_gather_lidx(Bufs b, const Ctl* __res
   lidx[k] = kInPlace;
 }
 
+// ------------------------------------------------------------------------------------------
+// KLD-adaptive resampling (monte_carlo_localization.rs:322-385).  The reference draws one
+// particle at a time and stops at the first count that satisfies the KLD bound for the number of
+// bins occupied so far.  Here all max_particles candidate draws are evaluated at once:
+//   k_kld_draw    draw m -> source index (multinomial, as k_resample_gather_mn) and its bin,
+//   k_kld_insert  exact "first draw with this bin" through an open-addressing table keyed by the
+//                 full (x, y, yaw) bin triple: a slot is claimed once (CAS) by some draw, later
+//                 draws compare their bin with the claimant's and keep the minimum draw index,
+//   k_kld_count   one workgroup: occupied-bin count after every draw (scan of the first-occurrence
+//                 flags), running maximum of rr_kld_required, first draw satisfying rr_kld_stop.
+// The new count goes to the host (the only synchronisation of an adaptive step); a plain gather
+// of that many particles follows.
+constexpr unsigned int kKldEmpty = 0xffffffffu;
+
+__global__ __launch_bounds__(kBlock) void k_kld_draw(Bufs b, const Ctl* __restrict__ ctl,
+                                                    const uint64_t* __restrict__ cdf,
+                                                    const uint64_t* __restrict__ coarse, int coarse_log2,
+                                                    uint64_t n_coarse, const double* __restrict__ r_explicit,
+                                                    unsigned int* __restrict__ idx, int32_t* __restrict__ keys,
+                                                    uint64_t n_src, uint64_t n_draws, uint64_t seed, unsigned int rstep) {
+  extern __shared__ uint64_t s_coarse[];
+  for (uint64_t i = threadIdx.x; i < n_coarse; i += kBlock) s_coarse[i] = coarse[i];
+  __syncthreads();
+  const uint64_t m = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (m >= n_draws) return;
+  const int src = ctl->cur ^ 1;  // the plan kernel flipped Ctl.cur already
+  const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, m, seed, rstep, r_explicit, m);
+  const uint64_t blk = rr_lower_bound_u64(s_coarse, n_coarse, target);
+  const uint64_t lo = blk << coarse_log2;
+  const uint64_t len = lo + (1ull << coarse_log2) <= n_src ? (1ull << coarse_log2) : n_src - lo;
+  uint64_t j = lo + rr_lower_bound_u64(cdf + lo, len, target);
+  if (j >= n_src) j = n_src - 1;
+  idx[m] = (unsigned int)j;
+  int32_t xb, yb, ab;
+  rr_kld_bin(b.x[src][j], b.y[src][j], b.yaw[src][j], &xb, &yb, &ab);
+  keys[3 * m] = xb;
+  keys[3 * m + 1] = yb;
+  keys[3 * m + 2] = ab;
+}
+
+__device__ inline uint64_t kld_hash(int32_t a, int32_t b, int32_t c) {
+  uint64_t h = ((uint64_t)(uint32_t)a << 32) | (uint32_t)b;
+  h ^= (uint64_t)(uint32_t)c * 0x9e3779b97f4a7c15ull;
+  h ^= h >> 33;
+  h *= 0xff51afd7ed558ccdull;
+  h ^= h >> 33;
+  h *= 0xc4ceb9fe1a85ec53ull;
+  h ^= h >> 33;
+  return h;
+}
+
+__global__ __launch_bounds__(kBlock) void k_kld_insert(const int32_t* __restrict__ keys, unsigned int* __restrict__ table,
+                                                      unsigned int* __restrict__ minslot,
+                                                      unsigned int* __restrict__ myslot, uint64_t n_draws,
+                                                      uint64_t hash_size) {
+  const uint64_t m = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (m >= n_draws) return;
+  const int32_t a = keys[3 * m], bb = keys[3 * m + 1], c = keys[3 * m + 2];
+  uint64_t s = kld_hash(a, bb, c) & (hash_size - 1);
+  for (;;) {
+    unsigned int o = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (o == kKldEmpty) {
+      o = atomicCAS(&table[s], kKldEmpty, (unsigned int)m);
+      if (o == kKldEmpty) o = (unsigned int)m;
+    }
+    if (o == m || (keys[3 * (uint64_t)o] == a && keys[3 * (uint64_t)o + 1] == bb && keys[3 * (uint64_t)o + 2] == c)) {
+      atomicMin(&minslot[s], (unsigned int)m);
+      myslot[m] = (unsigned int)s;
+      return;
+    }
+    s = (s + 1) & (hash_size - 1);  // another bin lives here: linear probing (the table is at most half full)
+  }
+}
+
+constexpr int kKldThreads = 1024;
+__global__ __launch_bounds__(kKldThreads) void k_kld_count(const unsigned int* __restrict__ minslot,
+                                                          const unsigned int* __restrict__ myslot, uint64_t n_draws,
+                                                          rr_mcl_adaptive kld, uint64_t* __restrict__ out) {
+  __shared__ uint64_t s_cnt[kKldThreads / rr::kWave];
+  __shared__ uint64_t s_req[kKldThreads / rr::kWave];
+  __shared__ uint64_t s_stop;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  uint64_t k_carry = 0, req_carry = kld.min_particles;
+  if (tid == 0) s_stop = ~0ull;
+  __syncthreads();
+  for (uint64_t base = 0; base < n_draws; base += kKldThreads) {
+    const uint64_t m = base + tid;
+    const uint64_t flag = (m < n_draws && minslot[myslot[m]] == (unsigned int)m) ? 1ull : 0ull;
+    // occupied bins after draw m
+    uint64_t incl = rr::wave_scan_u64(flag, lane);
+    if (lane == 63) s_cnt[wv] = incl;
+    __syncthreads();
+    uint64_t off = k_carry;
+    for (int q = 0; q < wv; ++q) off += s_cnt[q];
+    const uint64_t k = off + incl;
+    uint64_t chunk_total = 0;
+    for (int q = 0; q < kKldThreads / rr::kWave; ++q) chunk_total += s_cnt[q];
+    // running maximum of the bound (:350: required = required.max(...))
+    uint64_t req = m < n_draws ? rr_kld_required(k, kld.min_particles, kld.max_particles, kld.kld_epsilon, kld.kld_z) : 0;
+#pragma unroll
+    for (int o = 1; o < rr::kWave; o <<= 1) {
+      const uint64_t t = rr::shfl_up_u64(req, o);
+      if (lane >= o && t > req) req = t;
+    }
+    if (lane == 63) s_req[wv] = req;
+    __syncthreads();
+    uint64_t pre = req_carry;
+    for (int q = 0; q < wv; ++q) pre = s_req[q] > pre ? s_req[q] : pre;
+    if (pre > req) req = pre;
+    uint64_t chunk_req = req_carry;
+    for (int q = 0; q < kKldThreads / rr::kWave; ++q) chunk_req = s_req[q] > chunk_req ? s_req[q] : chunk_req;
+    if (m < n_draws && rr_kld_stop(m, req, kld.min_particles)) atomicMin((unsigned long long*)&s_stop, (unsigned long long)m);
+    __syncthreads();
+    if (s_stop != ~0ull) break;  // uniform: read after the barrier
+    k_carry += chunk_total;
+    req_carry = chunk_req;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const uint64_t stop = s_stop;
+    out[0] = stop == ~0ull ? n_draws : stop + 1;  // :342: at most max_particles
+  }
+}
+
+// the first n_new draws become the particle set (set cur^1 -> set cur)
+__global__ __launch_bounds__(kBlock) void k_kld_gather(Bufs b, const Ctl* __restrict__ ctl,
+                                                      const unsigned int* __restrict__ idx, uint64_t n_new) {
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= n_new) return;
+  const int dst = ctl->cur, src = dst ^ 1;
+  copy_particle(b, src, dst, idx[k], k, false, nullptr);
+}
+
 // =============================================================================================
 // host side
 // =============================================================================================
@@ -584,6 +717,17 @@ struct rr_pf {
   rr_pf_config cfg;
   rr_pf_options opt;
   uint64_t n = 0, n_global = 0;
+  uint64_t cap = 0;  // particles the buffers hold (== n unless the filter is KLD-adaptive: max_particles)
+  // KLD-adaptive particle count (monte_carlo_localization.rs:322-385)
+  bool adaptive = false;
+  rr_mcl_adaptive kld{};
+  int32_t* kld_keys = nullptr;         // [cap][3] bin of every candidate draw
+  unsigned int* kld_table = nullptr;   // open-addressing table: draw that claimed the slot
+  unsigned int* kld_minslot = nullptr; // smallest draw index with the slot's bin
+  unsigned int* kld_myslot = nullptr;  // table slot of every draw
+  uint64_t kld_hash_size = 0;
+  uint64_t* kld_out = nullptr;         // {new particle count, occupied bins}
+  uint64_t* kld_out_host = nullptr;
   hipStream_t stream = nullptr;      // the stream all work is enqueued on
   hipStream_t own_stream = nullptr;  // created with the handle
   bool owns_stream = false;
@@ -909,6 +1053,63 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
   return RR_OK;
 }
 
+void set_particle_count(rr_pf* h, uint64_t n) {
+  h->n = h->n_global = n;
+  h->cfg.n_particles = n;
+  h->n_tiles = (n + kTile - 1) / kTile;
+  h->n_coarse = (n + (1ull << h->coarse_log2) - 1) >> h->coarse_log2;
+}
+
+// resample_adaptive, monte_carlo_localization.rs:322-365 (see the kernels above).  r_explicit_dev:
+// max_particles uniforms on the device, or nullptr for the engine's Philox stream.
+rr_status resample_adaptive(rr_pf* h, const double* r_explicit_dev) {
+  const uint64_t M = h->kld.max_particles;
+  launch_quantize(h, wmax_source(h), 0);
+  PlanArgs pa = plan_args(h, /*mode=*/1, RR_RESAMPLE_MULTINOMIAL, NAN);
+  const bool fused = h->n_tiles <= (uint64_t)rr::kFusedMaxTiles;
+  if (!fused) {
+    Timed t(h, RR_K_SCAN_TILES);
+    hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl,
+                       h->n_tiles, 1, pa, (uint64_t*)nullptr);
+  }
+  {
+    Timed t(h, RR_K_CDF);
+    const dim3 grid((unsigned)h->n_tiles), block(rr::kTileBlock);
+    if (fused)
+      hipLaunchKernelGGL(rr::k_plan_cdf, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total,
+                         h->tile_q2, h->n_tiles, pa, h->cdf, h->cdf_coarse, h->coarse_log2);
+    else
+      hipLaunchKernelGGL(rr::k_cdf, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total, h->cdf,
+                         h->cdf_coarse, h->coarse_log2);
+  }
+  h->wmax_live = false;
+  h->wmax_bits_clean = true;
+  {
+    Timed t(h, RR_K_RESAMPLE_GATHER);
+    RR_HIP_TRY(hipMemsetAsync(h->kld_table, 0xff, h->kld_hash_size * sizeof(unsigned int), h->stream));
+    RR_HIP_TRY(hipMemsetAsync(h->kld_minslot, 0xff, h->kld_hash_size * sizeof(unsigned int), h->stream));
+    hipLaunchKernelGGL(k_kld_draw, dim3(grid_for(M, kBlock)), dim3(kBlock), h->n_coarse * sizeof(uint64_t), h->stream, h->b,
+                       h->ctl, h->cdf, h->cdf_coarse, h->coarse_log2, h->n_coarse, r_explicit_dev, h->idx, h->kld_keys, h->n, M,
+                       h->opt.seed, h->rstep);
+    hipLaunchKernelGGL(k_kld_insert, dim3(grid_for(M, kBlock)), dim3(kBlock), 0, h->stream, (const int32_t*)h->kld_keys,
+                       h->kld_table, h->kld_minslot, h->kld_myslot, M, h->kld_hash_size);
+    hipLaunchKernelGGL(k_kld_count, dim3(1), dim3(kKldThreads), 0, h->stream, (const unsigned int*)h->kld_minslot,
+                       (const unsigned int*)h->kld_myslot, M, h->kld, h->kld_out);
+    RR_HIP_TRY(hipGetLastError());
+    // the new count sizes every later launch: the one host synchronisation of an adaptive step
+    RR_HIP_TRY(hipMemcpyAsync(h->kld_out_host, h->kld_out, sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    RR_HIP_TRY(hipStreamSynchronize(h->stream));
+    const uint64_t n_new = h->kld_out_host[0];
+    if (n_new == 0 || n_new > M) return fail(RR_RUNTIME_ERROR, "adaptive resample produced an impossible particle count");
+    hipLaunchKernelGGL(k_kld_gather, dim3(grid_for(n_new, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl,
+                       (const unsigned int*)h->idx, n_new);
+    RR_HIP_TRY(hipGetLastError());
+    set_particle_count(h, n_new);  // weights are uniform 1/n_new from here (Ctl.weights_uniform, :359-362)
+  }
+  h->rstep += 1;
+  return RR_OK;
+}
+
 rr_status fetch_ctl(rr_pf* h) {
   RR_HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
@@ -959,13 +1160,41 @@ void drain_events(rr_pf* h) {
   h->events.clear();
 }
 
-rr_status create_common(const rr_pf_config* cfg, const rr_pf_options* opt_in, const double* state, rr_pf** out) {
+rr_status validate_kld(const rr_mcl_adaptive* k) {
+  // messages are the reference's (monte_carlo_localization.rs:84-104)
+  if (!k) return fail(RR_INVALID_PARAMETER, "null KLD parameters");
+  if (k->min_particles == 0) return fail(RR_INVALID_PARAMETER, "MCL min_particles must be greater than zero");
+  if (k->max_particles < k->min_particles)
+    return fail(RR_INVALID_PARAMETER, "MCL max_particles must be greater than or equal to min_particles");
+  if (!std::isfinite(k->kld_epsilon) || k->kld_epsilon <= 0.0)
+    return fail(RR_INVALID_PARAMETER, "MCL kld_epsilon must be positive and finite");
+  if (!std::isfinite(k->kld_z) || k->kld_z <= 0.0) return fail(RR_INVALID_PARAMETER, "MCL kld_z must be positive and finite");
+  return RR_OK;
+}
+
+rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in, const double* state, rr_pf** out,
+                        const rr_mcl_adaptive* kld = nullptr) {
   if (!out) return fail(RR_INVALID_PARAMETER, "null output handle");
   *out = nullptr;
-  rr_status s = validate_config(cfg);
+  if (!cfg_in) return fail(RR_INVALID_PARAMETER, "null config");
+  rr_pf_config cfg_v = *cfg_in;
+  rr_status s;
+  if (kld) {
+    if ((s = validate_kld(kld)) != RR_OK) return s;
+    cfg_v.n_particles = kld->min_particles;  // try_new :147: the filter starts with min_particles
+    if (kld->max_particles >= (1ull << 31)) return fail(RR_INVALID_PARAMETER, "max_particles must be below 2^31");
+  }
+  const rr_pf_config* cfg = &cfg_v;
+  s = validate_config(cfg);
   if (s != RR_OK) return s;
   rr_pf_options opt;
   if (opt_in) opt = *opt_in; else rr_pf_options_default(&opt);
+  if (kld) {
+    if (opt.resample_scheme != RR_RESAMPLE_MULTINOMIAL || opt.resample_gate != RR_GATE_ALWAYS)
+      return fail(RR_INVALID_PARAMETER, "the KLD-adaptive filter resamples multinomially at every step (rr_pf_options_mcl)");
+    if (opt.n_global != 0 || opt.first_global_index != 0)
+      return fail(RR_INVALID_PARAMETER, "the KLD-adaptive filter cannot be sharded");
+  }
   if (state)
     for (int k = 0; k < 4; ++k)
       if (!std::isfinite(state[k]))  // particle_filter.rs:505-513
@@ -993,6 +1222,14 @@ rr_status create_common(const rr_pf_config* cfg, const rr_pf_options* opt_in, co
   h->n = cfg->n_particles;
   h->n_global = n_global;
   h->n_tiles = (h->n + kTile - 1) / kTile;
+  h->cap = kld ? kld->max_particles : h->n;
+  if (kld) {
+    h->adaptive = true;
+    h->kld = *kld;
+    h->opt.record_indices = 1;
+    opt.record_indices = 1;
+  }
+  const uint64_t cap_tiles = (h->cap + kTile - 1) / kTile;
   h->lik = rr_pf_lik_make(cfg->range_noise);
   if (const char* e = std::getenv("RR_K1_BLOCKS_PER_CU")) {
     const int v = std::atoi(e);
@@ -1010,29 +1247,39 @@ rr_status create_common(const rr_pf_config* cfg, const rr_pf_options* opt_in, co
   RR_TRY_OR_CLEAN(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   h->owns_stream = true;
-  const size_t nb = h->n * sizeof(double);
-  // one slab [set][field][n] so that peers can map the whole particle state with one IPC handle
+  const size_t nb = h->cap * sizeof(double);
+  // one slab [set][field][cap] so that peers can map the whole particle state with one IPC handle
   RR_TRY_OR_CLEAN(hipMalloc(&h->slab, 8 * nb));
   for (int k = 0; k < 2; ++k) {
-    h->b.x[k] = h->slab + (size_t)(4 * k + 0) * h->n;
-    h->b.y[k] = h->slab + (size_t)(4 * k + 1) * h->n;
-    h->b.yaw[k] = h->slab + (size_t)(4 * k + 2) * h->n;
-    h->b.v[k] = h->slab + (size_t)(4 * k + 3) * h->n;
+    h->b.x[k] = h->slab + (size_t)(4 * k + 0) * h->cap;
+    h->b.y[k] = h->slab + (size_t)(4 * k + 1) * h->cap;
+    h->b.yaw[k] = h->slab + (size_t)(4 * k + 2) * h->cap;
+    h->b.v[k] = h->slab + (size_t)(4 * k + 3) * h->cap;
   }
   RR_TRY_OR_CLEAN(hipMalloc(&h->w, nb));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->cdf, h->n * sizeof(uint64_t)));
-  while (((h->n + (1ull << h->coarse_log2) - 1) >> h->coarse_log2) > 7680) h->coarse_log2 += 1;  // <= 60 KB of LDS
+  RR_TRY_OR_CLEAN(hipMalloc(&h->cdf, h->cap * sizeof(uint64_t)));
+  while (((h->cap + (1ull << h->coarse_log2) - 1) >> h->coarse_log2) > 7680) h->coarse_log2 += 1;  // <= 60 KB of LDS
   h->n_coarse = (h->n + (1ull << h->coarse_log2) - 1) >> h->coarse_log2;
-  RR_TRY_OR_CLEAN(hipMalloc(&h->cdf_coarse, (h->n_coarse + 1) * sizeof(uint64_t)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->tile_total, h->n_tiles * sizeof(uint64_t)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->tile_q2, 2 * h->n_tiles * sizeof(uint64_t)));
-  if (opt.record_indices) RR_TRY_OR_CLEAN(hipMalloc(&h->idx, h->n * sizeof(unsigned int)));
-  if (opt.resample_scheme == RR_RESAMPLE_MULTINOMIAL) {  // the fused step resamples lazily through lidx
+  RR_TRY_OR_CLEAN(hipMalloc(&h->cdf_coarse, (((h->cap + (1ull << h->coarse_log2) - 1) >> h->coarse_log2) + 1) * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->tile_total, cap_tiles * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->tile_q2, 2 * cap_tiles * sizeof(uint64_t)));
+  if (opt.record_indices) RR_TRY_OR_CLEAN(hipMalloc(&h->idx, h->cap * sizeof(unsigned int)));
+  if (kld) {
+    h->kld_hash_size = 2;
+    while (h->kld_hash_size < 2 * h->cap) h->kld_hash_size *= 2;  // at most half full
+    RR_TRY_OR_CLEAN(hipMalloc(&h->kld_keys, 3 * h->cap * sizeof(int32_t)));
+    RR_TRY_OR_CLEAN(hipMalloc(&h->kld_table, h->kld_hash_size * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(hipMalloc(&h->kld_minslot, h->kld_hash_size * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(hipMalloc(&h->kld_myslot, h->cap * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(hipMalloc(&h->kld_out, 2 * sizeof(uint64_t)));
+    RR_TRY_OR_CLEAN(hipHostMalloc(&h->kld_out_host, 2 * sizeof(uint64_t)));
+  }
+  if (opt.resample_scheme == RR_RESAMPLE_MULTINOMIAL && !kld) {  // the fused step resamples lazily through lidx
     RR_TRY_OR_CLEAN(hipMalloc(&h->lidx, h->n * sizeof(unsigned int)));
     RR_TRY_OR_CLEAN(hipMemset(h->lidx, 0xff, h->n * sizeof(unsigned int)));
   }
   {
-    const size_t nm = (size_t)n_global + rr::kResolveSlots;
+    const size_t nm = (size_t)std::max<uint64_t>(n_global, h->cap) + rr::kResolveSlots;
     RR_TRY_OR_CLEAN(hipMalloc(&h->markers, nm * sizeof(unsigned int)));
     RR_TRY_OR_CLEAN(hipMemset(h->markers, 0, nm * sizeof(unsigned int)));
     RR_TRY_OR_CLEAN(hipMalloc(&h->carry, (nm / rr::kResolveSlots + 2) * sizeof(unsigned int)));
@@ -1064,10 +1311,10 @@ rr_status ensure_scratch(rr_pf* h, size_t doubles_a, size_t doubles_b) {
   // scratch_a doubles as the AoS staging area (5n), scratch_b only ever needs n
   static_assert(sizeof(double) == 8, "");
   if (doubles_a) {
-    size_t want = std::max<size_t>(doubles_a, 5 * h->n);
+    size_t want = std::max<size_t>(doubles_a, 5 * h->cap);
     if (!h->scratch_a) RR_HIP_TRY(hipMalloc(&h->scratch_a, want * sizeof(double)));
   }
-  if (doubles_b && !h->scratch_b) RR_HIP_TRY(hipMalloc(&h->scratch_b, h->n * sizeof(double)));
+  if (doubles_b && !h->scratch_b) RR_HIP_TRY(hipMalloc(&h->scratch_b, h->cap * sizeof(double)));
   return RR_OK;
 }
 
@@ -1122,6 +1369,51 @@ rr_status rr_pf_create_with_state(const rr_pf_config* cfg, const rr_pf_options* 
   return create_common(cfg, opt, state, out);
 }
 
+void rr_mcl_adaptive_default(rr_mcl_adaptive* k) {
+  if (!k) return;
+  k->min_particles = 100;  // monte_carlo_localization.rs:68-81
+  k->max_particles = 5000;
+  k->kld_epsilon = 0.05;
+  k->kld_z = 2.326;
+}
+
+rr_status rr_mcl_adaptive_validate(const rr_mcl_adaptive* k) { return validate_kld(k); }
+
+rr_status rr_pf_create_adaptive(const rr_pf_config* cfg, const rr_pf_options* opt, const rr_mcl_adaptive* kld,
+                                const double* state, rr_pf** out) {
+  if (!kld) return fail(RR_INVALID_PARAMETER, "null KLD parameters");
+  rr_pf_options o;
+  if (opt) o = *opt; else rr_pf_options_mcl(&o);
+  return create_common(cfg, &o, state, out, kld);
+}
+
+uint64_t rr_pf_particle_capacity(const rr_pf* h) { return h ? h->cap : 0; }
+
+rr_status rr_pf_set_particles_n(rr_pf* h, const double* aos, uint64_t n) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!h->adaptive) return fail(RR_INVALID_PARAMETER, "only an adaptive filter can change its particle count");
+  if (n == 0 || n > h->cap) return fail(RR_INVALID_PARAMETER, "particle count must lie in [1, max_particles]");
+  if ((s = materialise(h)) != RR_OK) return s;
+  set_particle_count(h, n);
+  return rr_pf_set_particles(h, aos);
+}
+
+rr_status rr_pf_resample_adaptive_with_uniforms(rr_pf* h, const double* r, size_t n_r, uint64_t* n_new) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!h->adaptive) return fail(RR_INVALID_PARAMETER, "not an adaptive filter");
+  if (!r || n_r != h->kld.max_particles) return fail(RR_INVALID_PARAMETER, "need exactly max_particles uniforms");
+  for (size_t k = 0; k < n_r; ++k)
+    if (!(r[k] >= 0.0 && r[k] < 1.0)) return fail(RR_INVALID_PARAMETER, "uniforms must lie in [0, 1)");
+  if ((s = materialise(h)) != RR_OK) return s;
+  if ((s = ensure_scratch(h, h->cap, 0)) != RR_OK) return s;
+  RR_HIP_TRY(hipMemcpyAsync(h->scratch_a, r, n_r * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  if ((s = resample_adaptive(h, h->scratch_a)) != RR_OK) return s;
+  if (n_new) *n_new = h->n;
+  return RR_OK;
+}
+
 void rr_pf_destroy(rr_pf* h) {
   if (!h) return;
   (void)hipSetDevice(h->opt.device);
@@ -1136,6 +1428,12 @@ void rr_pf_destroy(rr_pf* h) {
   (void)hipFree(h->idx);
   (void)hipFree(h->markers);
   (void)hipFree(h->lidx);
+  (void)hipFree(h->kld_keys);
+  (void)hipFree(h->kld_table);
+  (void)hipFree(h->kld_minslot);
+  (void)hipFree(h->kld_myslot);
+  (void)hipFree(h->kld_out);
+  if (h->kld_out_host) (void)hipHostFree(h->kld_out_host);
   (void)hipFree(h->carry);
   (void)hipFree(h->partials);
   (void)hipFree(h->scratch_a);
@@ -1225,6 +1523,7 @@ rr_status rr_pf_resample(rr_pf* h) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if ((s = materialise(h)) != RR_OK) return s;
+  if (h->adaptive) return resample_adaptive(h, nullptr);
   return launch_resample(h, 0, h->opt.resample_scheme, NAN, nullptr);
 }
 
@@ -1237,6 +1536,11 @@ rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs,
   bool kernarg;
   if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
   StepParams p = make_params(h, control, (int)n_obs);
+  if (h->adaptive) {  // try_step, monte_carlo_localization.rs:291-300
+    if ((s = launch_pw<true, true, false>(h, p, arg, kernarg)) != RR_OK) return s;
+    h->step += 1;
+    return resample_adaptive(h, nullptr);
+  }
   const bool multinomial = h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC;
   if (multinomial && !h->lidx) {
     if ((s = launch_pw<true, true, false>(h, p, arg, kernarg)) != RR_OK) return s;
@@ -1383,6 +1687,7 @@ rr_status rr_pf_resample_with_uniforms(rr_pf* h, const double* r, size_t n) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if ((s = materialise(h)) != RR_OK) return s;
+  if (h->adaptive) return fail(RR_INVALID_PARAMETER, "adaptive filter: use rr_pf_resample_adaptive_with_uniforms");
   if (!r || n != h->n) return fail(RR_INVALID_PARAMETER, "need exactly one uniform per particle");
   for (size_t k = 0; k < n; ++k)
     if (!(r[k] >= 0.0 && r[k] < 1.0)) return fail(RR_INVALID_PARAMETER, "uniforms must lie in [0, 1)");
@@ -1395,6 +1700,7 @@ rr_status rr_pf_resample_systematic(rr_pf* h, double rho) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if ((s = materialise(h)) != RR_OK) return s;
+  if (h->adaptive) return fail(RR_INVALID_PARAMETER, "adaptive filter: use rr_pf_resample_adaptive_with_uniforms");
   if (!(rho >= 0.0 && rho < 1.0)) return fail(RR_INVALID_PARAMETER, "rho must lie in [0, 1)");
   return launch_resample(h, 1, RR_RESAMPLE_SYSTEMATIC, rho, nullptr);
 }

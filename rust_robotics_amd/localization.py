@@ -387,29 +387,73 @@ class MonteCarloLocalizationConfig:
 
 
 class MonteCarloLocalizer(ParticleFilterLocalizer):
-    """monte_carlo_localization.rs:136-462 in its fixed-N mode (min_particles == max_particles):
-    the same propagate/weight arithmetic as the PF (:209-288) and an unconditional resample every
-    step (:298).  The KLD-adaptive particle count (:322-385) is a SURVEY section 8(f) "next" row: asking
-    for min_particles != max_particles raises InvalidParameter instead of silently changing meaning.
+    """monte_carlo_localization.rs:136-462: the same propagate/weight arithmetic as the PF
+    (:209-288) and an unconditional resample every step (:298).  With min_particles ==
+    max_particles the particle count is fixed (the BASELINE "MCL" configurations: fused
+    three-launch step); otherwise the count adapts every step to the KLD bound (:322-385,
+    ``rr_pf_create_adaptive``) and ``particle_count()`` follows it.
     """
 
     _GATE = _ffi.RR_GATE_ALWAYS
     _SCHEME = _ffi.RR_RESAMPLE_MULTINOMIAL
 
     def __init__(self, config: Optional[MonteCarloLocalizationConfig] = None, *, _initial_state=None, **kw):
-        config = config or MonteCarloLocalizationConfig(min_particles=100, max_particles=100)
+        config = config or MonteCarloLocalizationConfig()
         config.validate()
-        if config.min_particles != config.max_particles:
-            raise RoboticsError.invalid_parameter(
-                "MCL on the GPU engine runs with a fixed particle count: set min_particles == max_particles "
-                "(KLD-adaptive resampling is not built yet)")
         if _initial_state is not None and not np.all(np.isfinite(np.asarray(_initial_state, dtype=np.float64))):
             raise RoboticsError.invalid_parameter("MCL initial state must contain only finite values")
         pf_cfg = ParticleFilterConfig(n_particles=config.min_particles, resample_threshold=1.0,
                                       range_noise=config.range_noise, velocity_noise=config.velocity_noise,
                                       yaw_rate_noise=config.yaw_rate_noise, dt=config.dt)
-        super().__init__(pf_cfg, _initial_state=_initial_state, **kw)
         self.mcl_config = config
+        if config.min_particles == config.max_particles:
+            super().__init__(pf_cfg, _initial_state=_initial_state, **kw)
+            return
+        scheme = kw.pop("resample_scheme", None)
+        if scheme not in (None, _ffi.RR_RESAMPLE_MULTINOMIAL):
+            raise RoboticsError.invalid_parameter("the KLD-adaptive filter resamples multinomially (monte_carlo_localization.rs:343-355)")
+        L = _ffi.lib()
+        opt = _ffi.PfOptions()
+        L.rr_pf_options_mcl(C.byref(opt))
+        opt.device = kw.pop("device", 0)
+        opt.seed = kw.pop("seed", 0)
+        opt.likelihood_mode = kw.pop("likelihood_mode", _ffi.RR_LIK_FUSED)
+        kw.pop("record_indices", None)
+        if kw:
+            raise TypeError(f"unexpected arguments for an adaptive MonteCarloLocalizer: {sorted(kw)}")
+        kld = _ffi.MclAdaptive(config.min_particles, config.max_particles, config.kld_epsilon, config.kld_z)
+        self._h = C.c_void_p()
+        cfg = pf_cfg._c()
+        st = None if _initial_state is None else _vec(_initial_state, 4, "MCL initial state")
+        _check(L.rr_pf_create_adaptive(C.byref(cfg), C.byref(opt), C.byref(kld), _dp(st) if st is not None else None,
+                                       C.byref(self._h)))
+        self.config = pf_cfg
+        self._L = L
+        self._state_estimate = np.zeros(4)
+        self._covariance = np.zeros((4, 4))
+        self._cache_valid = False
+
+    def is_adaptive(self) -> bool:
+        return self.mcl_config.min_particles != self.mcl_config.max_particles
+
+    def particle_capacity(self) -> int:
+        return int(self._L.rr_pf_particle_capacity(self._h))
+
+    # ---- parity seams of the adaptive filter
+    def set_particles_array(self, aos: np.ndarray) -> None:
+        if not self.is_adaptive():
+            return super().set_particles_array(aos)
+        a = np.ascontiguousarray(aos, dtype=np.float64).reshape(-1, 5)
+        _check(self._L.rr_pf_set_particles_n(self._h, _dp(a), a.shape[0]))
+        self._cache_valid = False
+
+    def resample_adaptive_with_uniforms(self, r: np.ndarray) -> int:
+        """resample_adaptive (:322-365) with the uniforms the reference would have drawn; returns the new count"""
+        a = np.ascontiguousarray(r, dtype=np.float64)
+        n_new = C.c_uint64()
+        _check(self._L.rr_pf_resample_adaptive_with_uniforms(self._h, _dp(a), a.size, C.byref(n_new)))
+        self._cache_valid = False
+        return int(n_new.value)
 
     @classmethod
     def new(cls, config: MonteCarloLocalizationConfig, **kw) -> "MonteCarloLocalizer":

@@ -1,0 +1,149 @@
+"""GPU parity of the KLD-adaptive MonteCarloLocalizer (rr_pf_create_adaptive) through the C ABI:
+  * the adaptive resample against the literal restatement of monte_carlo_localization.rs:322-385
+    and against the D-spec on identical uniforms: same particle count, same source indices;
+  * whole steps against the D-spec with the engine's Philox streams: bit-exact particle sets;
+  * the reference's own unit tests (:489-577) re-expressed against the engine."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import dp, u32p, u64p
+from tests import helpers as H
+from tests.test_kld_oracles import clouds, det_adaptive
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def loc():
+    import rust_robotics_amd.localization as m
+
+    return m
+
+
+def make(loc, lo, hi, **kw):
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=lo, max_particles=hi, **kw)
+    return loc.MonteCarloLocalizer(cfg, seed=13), cfg
+
+
+@pytest.mark.parametrize("lo,hi", [(100, 1500), (1, 40), (50, 5000), (256, 3000)])
+def test_adaptive_resample_matches_oracles(loc, det, ref, lo, hi):
+    rng = np.random.default_rng(8)
+    for name, x, y, yaw, w in clouds():
+        n = x.size
+        if n > hi:
+            x, y, yaw, w = x[:hi], y[:hi], yaw[:hi], w[:hi] + (0.01 if w[:hi].sum() == 0 else 0.0)
+            n = hi
+        x, y, yaw = (np.ascontiguousarray(a) for a in (x, y, yaw))
+        mcl, _ = make(loc, lo, hi)
+        assert mcl.particle_count() == lo and mcl.particle_capacity() == hi
+        mcl.set_particles_array(np.column_stack([x, y, yaw, np.zeros(n), w]))
+        assert mcl.particle_count() == n
+        r = np.floor(rng.random(hi) * 2**53) / 2**53
+        n_new = mcl.resample_adaptive_with_uniforms(r)
+        wn = np.ascontiguousarray(w / w.sum())
+        idx_l = np.empty(hi, np.uint32)
+        cnt_l = ref.ref_mcl_resample_adaptive(n, dp(x), dp(y), dp(yaw), dp(wn), dp(r), lo, hi, 0.05, 2.326, u32p(idx_l))
+        cnt_d, idx_d = det_adaptive(det, x, y, yaw, np.ascontiguousarray(w), r, lo, hi)
+        assert n_new == cnt_d == cnt_l, name
+        assert mcl.particle_count() == n_new
+        got = mcl.last_resample_indices()
+        assert np.array_equal(got, idx_d) and np.array_equal(got, idx_l[:cnt_l]), name
+        p = mcl.get_particles_array()
+        assert p.shape == (n_new, 5)
+        assert np.array_equal(p[:, 0].view(np.uint64), x[got].view(np.uint64))
+        assert np.array_equal(p[:, 2].view(np.uint64), yaw[got].view(np.uint64))
+        assert np.all(p[:, 4] == 1.0 / n_new)  # :359-362
+
+
+def test_steps_bit_exact_vs_det(loc, det):
+    """try_step x 25 (:291-300) with the engine's Philox streams against a D-spec loop on the CPU"""
+    lo, hi, sig = 80, 900, 0.4
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=lo, max_particles=hi, range_noise=sig, velocity_noise=0.4,
+                                           yaw_rate_noise=math.radians(8.0))
+    mcl = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=21)
+    n = lo
+    st = np.array([0.0, 0.0, 0.0, 1.0])
+    x, y, yaw, v = (np.zeros(hi) for _ in range(4))
+    det.det_pf_init(n, 21, 0, dp(st), dp(x), dp(y), dp(yaw), dp(v))
+    w = np.zeros(hi)
+    rng = np.random.default_rng(3)
+    counts = []
+    for t in range(25):
+        obs = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), sig, rng)
+        mcl.try_step([1.0, 0.1], obs)
+        det.det_pf_predict(n, dp(x), dp(y), dp(yaw), dp(v), 1.0, 0.1, 0.1, None, None, 21, t, 0, 0.4, math.radians(8.0))
+        det.det_pf_weights(n, dp(x), dp(y), dp(w), dp(np.ascontiguousarray(obs)), len(obs), sig, 0)
+        fx = H.det_fixed(det, w[:n].copy())
+        cdf = H.det_cdf(det, w[:n].copy(), fx)
+        idx = np.empty(hi, np.uint32)
+        cnt = det.det_mcl_resample_adaptive(n, dp(x), dp(y), dp(yaw), u64p(cdf), int(cdf[-1]), None, 21, t, lo, hi, 0.05, 2.326, u32p(idx))
+        for a in (x, y, yaw, v):
+            a[:cnt] = a[idx[:cnt]]
+        n = cnt
+        counts.append(n)
+        assert mcl.particle_count() == n, f"step {t}"
+        p = mcl.get_particles_array()
+        for k, a in enumerate((x, y, yaw, v)):
+            assert np.array_equal(p[:, k].view(np.uint64), a[:n].view(np.uint64)), f"step {t} field {k}"
+    assert len(set(counts)) > 1, counts  # the count really moved
+    assert all(lo <= c <= hi for c in counts)
+
+
+def test_reference_particle_count_adapts(loc):
+    """monte_carlo_localization.rs:519-552"""
+    mcl, cfg = make(loc, 100, 1500)
+    n = 800
+    i = np.arange(n)
+    mcl.set_particles_array(np.column_stack([(i % 4) * 3.0 + i * 0.002, (i % 4) * 2.0, np.zeros(n), np.zeros(n), np.full(n, 1.0 / n)]))
+    mcl.resample()
+    expanded = mcl.particle_count()
+    assert expanded > cfg.min_particles
+    n = 600
+    mcl.set_particles_array(np.column_stack([np.full(n, 1.0), np.full(n, 1.0), np.full(n, 0.1), np.zeros(n), np.full(n, 1.0 / n)]))
+    mcl.resample()
+    assert mcl.particle_count() <= expanded
+
+
+def test_reference_count_stays_within_bounds_and_converges(loc):
+    """monte_carlo_localization.rs:554-577 and :489-516"""
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=120, max_particles=600, velocity_noise=0.5, yaw_rate_noise=0.2)
+    mcl = loc.MonteCarloLocalizer(cfg, seed=4)
+    lms = [(0.0, 0.0), (15.0, 0.0), (8.0, 12.0)]
+    truth = np.zeros(3)
+    for _ in range(40):
+        truth += [0.8 * math.cos(truth[2]) * 0.1, 0.8 * math.sin(truth[2]) * 0.1, 0.05 * 0.1]
+        obs = [(math.hypot(truth[0] - lx, truth[1] - ly), lx, ly) for lx, ly in lms]
+        mcl.try_step([0.8, 0.05], obs)
+        assert 120 <= mcl.particle_count() <= 600
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=250, max_particles=1200, range_noise=0.25, velocity_noise=0.05,
+                                           yaw_rate_noise=0.02)
+    mcl = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 0.0], cfg, seed=5)
+    lms = [(0.0, 0.0), (10.0, 0.0), (5.0, 8.0)]
+    truth = np.zeros(4)
+    for _ in range(60):
+        truth[:3] += [1.0 * math.cos(truth[2]) * 0.1, 1.0 * math.sin(truth[2]) * 0.1, 0.03 * 0.1]
+        est = mcl.try_step([1.0, 0.03], [(math.hypot(truth[0] - lx, truth[1] - ly), lx, ly) for lx, ly in lms])
+    assert math.hypot(est[0] - truth[0], est[1] - truth[1]) < 1.0
+
+
+def test_validation_and_misuse(loc):
+    inv = loc.RoboticsError
+    for bad, msg in ((dict(min_particles=0), "min_particles must be greater than zero"),
+                     (dict(min_particles=10, max_particles=5), "max_particles must be greater than or equal"),
+                     (dict(kld_epsilon=0.0), "kld_epsilon must be positive"), (dict(kld_z=float("nan")), "kld_z must be positive")):
+        with pytest.raises(inv) as ei:
+            loc.MonteCarloLocalizer(loc.MonteCarloLocalizationConfig(**bad))
+        assert msg in str(ei.value)
+    mcl, _ = make(loc, 10, 50)
+    with pytest.raises(inv):
+        mcl.resample_with_uniforms(np.zeros(10))  # the fixed-N seam is refused
+    with pytest.raises(inv):
+        mcl.resample_adaptive_with_uniforms(np.zeros(7))  # needs max_particles uniforms
+    with pytest.raises(inv):
+        mcl.set_particles_array(np.zeros((51, 5)))  # beyond the capacity
+    with pytest.raises(inv):
+        loc.MonteCarloLocalizer(loc.MonteCarloLocalizationConfig(min_particles=10, max_particles=50), resample_scheme=1)

@@ -399,8 +399,9 @@ def test_invalid_inputs_raise_invalid_parameter(loc):
         pf.set_landmarks([loc.Point2D(float("nan"), 0.0)])
     with pytest.raises(loc.RoboticsError):
         loc.ParticleFilterLocalizer.with_initial_state([0.0, float("nan"), 0.0, 0.0], loc.ParticleFilterConfig())
-    with pytest.raises(loc.RoboticsError):
-        loc.MonteCarloLocalizer(loc.MonteCarloLocalizationConfig(min_particles=10, max_particles=20))
+    with pytest.raises(loc.RoboticsError) as ei:
+        loc.MonteCarloLocalizer(loc.MonteCarloLocalizationConfig(min_particles=20, max_particles=10))
+    assert "max_particles must be greater than or equal to min_particles" in str(ei.value)
 
 
 def test_mcl_reference_tests_reexpressed(loc):
