@@ -119,7 +119,8 @@ class ParticleFilterLocalizer {
   rr_pf* handle() { return h_; }
 
  protected:
-  virtual void options(rr_pf_options* o) const { rr_pf_options_default(o); }
+  explicit ParticleFilterLocalizer(rr_pf* adopted) : h_(adopted) {}
+  static void options(rr_pf_options* o) { rr_pf_options_default(o); }
   static std::vector<double> flatten(const PFMeasurement& obs) {
     std::vector<double> f;
     f.reserve(3 * obs.size());
@@ -133,13 +134,46 @@ class ParticleFilterLocalizer {
   rr_pf* h_ = nullptr;
 };
 
-// fixed-N Monte Carlo localization: resample every step (monte_carlo_localization.rs:291-300)
+// MonteCarloLocalizationConfig, monte_carlo_localization.rs:50-82
+struct MonteCarloLocalizationConfig {
+  uint64_t min_particles = 100, max_particles = 5000;
+  double kld_epsilon = 0.05, kld_z = 2.326;
+  double range_noise = 0.2, velocity_noise = 2.0, yaw_rate_noise = 40.0 * 3.14159265358979323846 / 180.0, dt = 0.1;
+};
+
+// Monte Carlo localization: resample every step (monte_carlo_localization.rs:291-300); the particle
+// count is fixed when min_particles == max_particles and KLD-adaptive otherwise (:322-385)
 class MonteCarloLocalizer : public ParticleFilterLocalizer {
  public:
-  using ParticleFilterLocalizer::ParticleFilterLocalizer;
+  explicit MonteCarloLocalizer(const MonteCarloLocalizationConfig& c = {}, uint64_t seed = 0, int device = 0)
+      : ParticleFilterLocalizer(make(c, nullptr, seed, device)) {}
+  MonteCarloLocalizer(const PFState& initial, const MonteCarloLocalizationConfig& c, uint64_t seed = 0, int device = 0)
+      : ParticleFilterLocalizer(make(c, initial.data(), seed, device)) {}
+  uint64_t particle_count() const { return rr_pf_particle_count(h_); }  // :318-320
 
- protected:
-  void options(rr_pf_options* o) const override { rr_pf_options_mcl(o); }
+ private:
+  static rr_pf* make(const MonteCarloLocalizationConfig& c, const double* state, uint64_t seed, int device) {
+    rr_pf_config cfg;
+    rr_pf_config_default(&cfg);
+    cfg.n_particles = c.min_particles;
+    cfg.resample_threshold = 1.0;
+    cfg.range_noise = c.range_noise;
+    cfg.velocity_noise = c.velocity_noise;
+    cfg.yaw_rate_noise = c.yaw_rate_noise;
+    cfg.dt = c.dt;
+    rr_pf_options o;
+    rr_pf_options_mcl(&o);
+    o.seed = seed;
+    o.device = device;
+    rr_pf* h = nullptr;
+    if (c.min_particles == c.max_particles) {
+      check(state ? rr_pf_create_with_state(&cfg, &o, state, &h) : rr_pf_create(&cfg, &o, &h));
+    } else {
+      rr_mcl_adaptive k{c.min_particles, c.max_particles, c.kld_epsilon, c.kld_z};
+      check(rr_pf_create_adaptive(&cfg, &o, &k, state, &h));
+    }
+    return h;
+  }
 };
 
 namespace fastslam1 {

@@ -93,3 +93,24 @@ def test_mirror_exposes_reference_names():
     for name in ("try_new", "try_with_initial_state", "try_predict_with_control", "try_update_with_observations",
                  "try_step", "estimate", "state_2d", "particle_count"):  # monte_carlo_localization.rs:144-320
         assert hasattr(loc.MonteCarloLocalizer, name), name
+
+
+def test_cpp_wrapper_compiles(tmp_path):
+    """include/rust_robotics.hpp (header-only C++ mirror of the reference's struct surface) must
+    parse against the C ABI headers and link against the library's exported symbols"""
+    import shutil
+    import subprocess
+
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "rust_robotics.hpp"\n'
+                   "int main() {\n"
+                   "  rr::MonteCarloLocalizationConfig c; c.min_particles = 10; c.max_particles = 20;\n"
+                   "  try { rr::MonteCarloLocalizer m(c); rr::ParticleFilterLocalizer p; (void)m.particle_count(); }\n"
+                   "  catch (const std::exception&) { return 0; }\n"  # no GPU here: creation fails loudly
+                   "  return 0;\n}\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)], capture_output=True,
+                       text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
