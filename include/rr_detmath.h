@@ -306,7 +306,8 @@ enum {
   RR_STREAM_INIT_YV = 2,   /* initial cloud jitter yaw,v    (particle_filter.rs:184-185) */
   RR_STREAM_MOTION = 3,    /* (n_v, n_w) per particle/step  (particle_filter.rs:280-287; fastslam1.rs:129-130) */
   RR_STREAM_RESAMPLE = 4,  /* per-draw uniform / r0         (particle_filter.rs:456; fastslam1.rs:219-220) */
-  RR_STREAM_SIM = 5        /* observation simulator noise   (fastslam1.rs:291-292) */
+  RR_STREAM_SIM = 5,       /* observation simulator noise   (fastslam1.rs:291-292) */
+  RR_STREAM_PROPOSAL = 6   /* third proposal normal per particle/step (fastslam2.rs:248; the first two come from MOTION) */
 };
 
 /* two uniforms in [0,1) with 53 random bits each */

@@ -357,6 +357,10 @@ typedef struct rr_fs1_model {
   double r00, r11;      /* R_SIM diagonal 0.5, 0.0305 */
   double init_threshold;/* 100.0: cov[(0,0)] > threshold => first observation (fastslam1.rs:143) */
   double init_cov;      /* NaN => reference-faithful "leave cov untouched" (Q11); else cov := init_cov * I */
+  /* the two places where fastslam2.rs:255-291 differs from fastslam1.rs:140-183 */
+  double init_test_lt;  /* 0 => first observation iff cov00 > threshold (fastslam1.rs:143);
+                           1 => iff !(cov00 < threshold) (fastslam2.rs:49-51,262) */
+  double nonpos_det_w;  /* likelihood factor when det S <= 0: 1.0 (fastslam1.rs:182), 1e-10 (fastslam2.rs:289) */
 } rr_fs1_model;
 
 /* fastslam1.rs:80-89 */
@@ -386,7 +390,7 @@ RR_HD double rr_fs1_update_one(double px, double py, double pyaw, double zd, dou
                                double* lm, rr_fs1_model m) {
   double lx = lm[0], ly = lm[1];
   double p00 = lm[2], p10 = lm[3], p01 = lm[4], p11 = lm[5];
-  if (p00 > m.init_threshold) { /* :143-149 */
+  if (m.init_test_lt != 0.0 ? !(p00 < m.init_threshold) : (p00 > m.init_threshold)) { /* :143-149 */
     double s, c;
     rr_sincos(pyaw + za, &s, &c);
     lm[0] = rr_fma(zd, c, px);
@@ -452,12 +456,170 @@ RR_HD double rr_fs1_update_one(double px, double py, double pyaw, double zd, dou
     double mahal = rr_fma(t1, y1, t0 * y0);
     return rr_exp(-0.5 * mahal) / (RR_TWO_PI * rr_sqrt(det));
   }
-  return 1.0;
+  return m.nonpos_det_w;
 }
 
 /* unit motion noise for FastSLAM particle gid at step (fastslam1.rs:129-130) */
 RR_HD void rr_fs1_motion_noise(uint64_t seed, uint32_t step, uint64_t gid, double* z0, double* z1) {
   rr_normal2(seed, RR_STREAM_MOTION, step, gid, z0, z1);
+}
+
+/* ===================================================================== FastSLAM 2.0 proposal */
+/* rust_robotics_slam/src/fastslam2.rs.  Everything after the pose has been sampled is the
+ * FastSLAM 1.0 observation loop with the two model switches above (init_test_lt = 1,
+ * nonpos_det_w = 1e-10, init_cov = 10).  3x3 matrices are row-major arrays of 9. */
+typedef struct rr_fs2_model {
+  rr_fs1_model base;
+  double m0, m1, m2; /* MOTION_COV diagonal 0.1, 0.1, 0.01 (fastslam2.rs:30) */
+} rr_fs2_model;
+
+/* nalgebra 0.33 Matrix3::try_inverse (cofactor formula, None iff det == 0); returns 0 for None */
+RR_HD int rr_inv3(const double* a, double* o) {
+  double m11 = a[0], m12 = a[1], m13 = a[2], m21 = a[3], m22 = a[4], m23 = a[5], m31 = a[6], m32 = a[7], m33 = a[8];
+  double minor_m12_m23 = rr_fma(m22, m33, -(m32 * m23));
+  double minor_m11_m23 = rr_fma(m21, m33, -(m31 * m23));
+  double minor_m11_m22 = rr_fma(m21, m32, -(m31 * m22));
+  double det = rr_fma(m13, minor_m11_m22, rr_fma(m11, minor_m12_m23, -(m12 * minor_m11_m23)));
+  if (det == 0.0) return 0;
+  o[0] = minor_m12_m23 / det;
+  o[1] = rr_fma(m13, m32, -(m33 * m12)) / det;
+  o[2] = rr_fma(m12, m23, -(m22 * m13)) / det;
+  o[3] = -minor_m11_m23 / det;
+  o[4] = rr_fma(m11, m33, -(m31 * m13)) / det;
+  o[5] = rr_fma(m13, m21, -(m23 * m11)) / det;
+  o[6] = minor_m11_m22 / det;
+  o[7] = rr_fma(m12, m31, -(m32 * m11)) / det;
+  o[8] = rr_fma(m11, m22, -(m21 * m12)) / det;
+  return 1;
+}
+
+/* motion_model :92-99 */
+RR_HD void rr_fs2_motion(const double x[3], double u0, double u1, double dt, double o[3]) {
+  double s, c;
+  rr_sincos(x[2], &s, &c);
+  o[0] = rr_fma(u0 * dt, c, x[0]);
+  o[1] = rr_fma(u0 * dt, s, x[1]);
+  o[2] = rr_normalize_angle(rr_fma(u1, dt, x[2]));
+}
+
+/* compute_proposal :173-216: mean and covariance of the proposal for one particle given the
+ * FIRST observation (zd, za) of landmark lm = {x, y, c00, c10, c01, c11}. */
+RR_HD void rr_fs2_proposal(const double pose[3], double u0, double u1, double zd, double za, const double* lm,
+                           rr_fs2_model m, double mean[3], double cov[9]) {
+  double xp[3];
+  rr_fs2_motion(pose, u0, u1, m.base.dt, xp);
+  /* g * MOTION_COV * g^T, g = motion_jacobian :103-118 */
+  double s, c;
+  rr_sincos(pose[2], &s, &c);
+  double a = -u0 * m.base.dt * s; /* g[0][2] */
+  double b = u0 * m.base.dt * c;  /* g[1][2] */
+  double P[9];
+  P[0] = rr_fma(a * m.m2, a, m.m0); P[1] = (a * m.m2) * b;           P[2] = a * m.m2;
+  P[3] = (b * m.m2) * a;           P[4] = rr_fma(b * m.m2, b, m.m1); P[5] = b * m.m2;
+  P[6] = m.m2 * a;                 P[7] = m.m2 * b;                  P[8] = m.m2;
+  double p00 = lm[2], p10 = lm[3], p01 = lm[4], p11 = lm[5];
+  if (!(p00 < m.base.init_threshold)) { /* :186-189 landmark not initialised */
+    for (int i = 0; i < 3; ++i) mean[i] = xp[i];
+    for (int i = 0; i < 9; ++i) cov[i] = P[i];
+    return;
+  }
+  double dx = lm[0] - xp[0], dy = lm[1] - xp[1];
+  double d2 = rr_fma(dy, dy, dx * dx);
+  double d = rr_sqrt(d2);
+  /* h_pose :139-147 (2x3) and h_lm :131-137 (2x2) */
+  double h[6] = {-dx / d, -dy / d, 0.0, dy / d2, -dx / d2, -1.0};
+  double l00 = dx / d, l01 = dy / d, l10 = -dy / d2, l11 = dx / d2;
+  /* q_obs = h_lm * C * h_lm^T + R :195 */
+  double hc00 = rr_fma(l01, p10, l00 * p00), hc01 = rr_fma(l01, p11, l00 * p01);
+  double hc10 = rr_fma(l11, p10, l10 * p00), hc11 = rr_fma(l11, p11, l10 * p01);
+  double q00 = rr_fma(hc01, l01, hc00 * l00) + m.base.r00, q01 = rr_fma(hc01, l11, hc00 * l10);
+  double q10 = rr_fma(hc11, l01, hc10 * l00), q11 = rr_fma(hc11, l11, hc10 * l10) + m.base.r11;
+  double qdet = rr_fma(q00, q11, -(q10 * q01));
+  double i00, i01, i10, i11; /* :200 try_inverse or identity */
+  if (qdet == 0.0) { i00 = 1.0; i01 = 0.0; i10 = 0.0; i11 = 1.0; }
+  else { i00 = q11 / qdet; i01 = -q01 / qdet; i10 = -q10 / qdet; i11 = q00 / qdet; }
+  double Pinv[9]; /* :202 */
+  if (!rr_inv3(P, Pinv)) {
+    for (int i = 0; i < 9; ++i) Pinv[i] = 0.0;
+    Pinv[0] = Pinv[4] = Pinv[8] = 1e-6;
+  }
+  /* (H^T * Qinv) 3x2, then * H :203 */
+  double t[6];
+  for (int r = 0; r < 3; ++r) {
+    t[2 * r] = rr_fma(h[3 + r], i10, h[r] * i00);
+    t[2 * r + 1] = rr_fma(h[3 + r], i11, h[r] * i01);
+  }
+  double Ppi[9];
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) Ppi[3 * r + q] = Pinv[3 * r + q] + rr_fma(t[2 * r + 1], h[3 + q], t[2 * r] * h[q]);
+  double Pp[9]; /* :204 */
+  if (!rr_inv3(Ppi, Pp))
+    for (int i = 0; i < 9; ++i) Pp[i] = P[i];
+  /* innovation :207-208 */
+  double zp_a = rr_normalize_angle(rr_atan2(dy, dx) - xp[2]);
+  double y0 = zd - d, y1 = rr_normalize_angle(za - zp_a);
+  /* x_post = x_pred + ((P_post * H^T) * Qinv) * innovation :210 */
+  for (int r = 0; r < 3; ++r) {
+    double ph0 = rr_fma(Pp[3 * r + 2], h[2], rr_fma(Pp[3 * r + 1], h[1], Pp[3 * r] * h[0]));
+    double ph1 = rr_fma(Pp[3 * r + 2], h[5], rr_fma(Pp[3 * r + 1], h[4], Pp[3 * r] * h[3]));
+    double k0 = rr_fma(ph1, i10, ph0 * i00), k1 = rr_fma(ph1, i11, ph0 * i01);
+    mean[r] = xp[r] + rr_fma(k1, y1, k0 * y0);
+  }
+  for (int i = 0; i < 9; ++i) cov[i] = Pp[i];
+}
+
+/* sample_pose_with_rng :219-239 + set_pose :77-81: mean + L * noise with L the lower Cholesky
+ * factor (nalgebra Cholesky::new, lower triangle of cov) or, when the matrix is not positive
+ * definite, diag(sqrt(max(c_ii, 0))) */
+RR_HD void rr_fs2_sample(const double mean[3], const double c[9], const double z[3], double pose[3]) {
+  double L[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int ok = 0;
+  double d0 = c[0];
+  if (d0 != 0.0 && d0 >= 0.0) {
+    double l00 = rr_sqrt(d0), l10 = c[3] / l00, l20 = c[6] / l00;
+    double d1 = rr_fma(-l10, l10, c[4]);
+    double c21 = rr_fma(-l10, l20, c[7]);
+    if (d1 != 0.0 && d1 >= 0.0) {
+      double l11 = rr_sqrt(d1), l21 = c21 / l11;
+      double d2 = rr_fma(-l21, l21, rr_fma(-l20, l20, c[8]));
+      if (d2 != 0.0 && d2 >= 0.0) {
+        L[0] = l00; L[3] = l10; L[4] = l11; L[6] = l20; L[7] = l21; L[8] = rr_sqrt(d2);
+        ok = 1;
+      }
+    }
+  }
+  if (!ok) {
+    L[0] = rr_sqrt(c[0] > 0.0 ? c[0] : 0.0);
+    L[4] = rr_sqrt(c[4] > 0.0 ? c[4] : 0.0);
+    L[8] = rr_sqrt(c[8] > 0.0 ? c[8] : 0.0);
+  }
+  pose[0] = mean[0] + L[0] * z[0];
+  pose[1] = mean[1] + rr_fma(L[4], z[1], L[3] * z[0]);
+  pose[2] = rr_normalize_angle(mean[2] + rr_fma(L[8], z[2], rr_fma(L[7], z[1], L[6] * z[0])));
+}
+
+/* the sampling step of fastslam2_update_with_rng :339-358 for one particle: proposal from the
+ * first observation, or the noisy motion model when there is none */
+RR_HD void rr_fs2_predict_one(double pose[3], double u0, double u1, int has_obs, double zd, double za,
+                              const double* lm, const double z[3], rr_fs2_model m) {
+  if (has_obs) {
+    double mean[3], cov[9], np[3];
+    rr_fs2_proposal(pose, u0, u1, zd, za, lm, m, mean, cov);
+    rr_fs2_sample(mean, cov, z, np);
+    pose[0] = np[0]; pose[1] = np[1]; pose[2] = np[2];
+  } else { /* :349-357 */
+    double un0 = rr_fma(z[0], m.base.q_sqrt0, u0), un1 = rr_fma(z[1], m.base.q_sqrt1, u1);
+    double np[3];
+    rr_fs2_motion(pose, un0, un1, m.base.dt, np);
+    pose[0] = np[0]; pose[1] = np[1]; pose[2] = rr_normalize_angle(np[2]);
+  }
+}
+
+/* three unit normals of particle gid at step (fastslam2.rs:248) */
+RR_HD void rr_fs2_noise(uint64_t seed, uint32_t step, uint64_t gid, double z[3]) {
+  double spare;
+  rr_normal2(seed, RR_STREAM_MOTION, step, gid, &z[0], &z[1]);
+  rr_normal2(seed, RR_STREAM_PROPOSAL, step, gid, &z[2], &spare);
 }
 
 #endif /* RR_PF_SPEC_H */

@@ -66,7 +66,14 @@ class RefFs1Model(C.Structure):
 class DetFs1Model(C.Structure):
     """mirrors rr_fs1_model (include/rr_pf_spec.h)"""
 
-    _fields_ = [(k, C.c_double) for k in ("dt", "q_sqrt0", "q_sqrt1", "r00", "r11", "init_threshold", "init_cov")]
+    _fields_ = [(k, C.c_double) for k in ("dt", "q_sqrt0", "q_sqrt1", "r00", "r11", "init_threshold", "init_cov",
+                                          "init_test_lt", "nonpos_det_w")]
+
+
+class DetFs2Model(C.Structure):
+    """mirrors rr_fs2_model (include/rr_pf_spec.h)"""
+
+    _fields_ = [("base", DetFs1Model), ("m0", C.c_double), ("m1", C.c_double), ("m2", C.c_double)]
 
 
 @lru_cache(maxsize=None)
@@ -124,6 +131,14 @@ def ref() -> C.CDLL:
     L.ref_fs1_best_particle.restype = sz
     L.ref_fs1_get_observations.argtypes = [P, P, sz, d, P, MP, P]
     L.ref_fs1_get_observations.restype = sz
+    L.ref_fs2_proposal.argtypes = [P, d, d, d, d, P, d, d, P, P]
+    L.ref_fs2_proposal.restype = None
+    L.ref_fs2_sample.argtypes = [P, P, P, P]
+    L.ref_fs2_sample.restype = None
+    L.ref_fs2_update_landmark.argtypes = [d, d, d, d, d, P, d, d]
+    L.ref_fs2_update_landmark.restype = d
+    L.ref_fs2_update.argtypes = [sz, sz, P, P, P, P, P, d, d, P, P, sz, d, d, u32]
+    L.ref_fs2_update.restype = i
     return L
 
 
@@ -188,6 +203,17 @@ def det() -> C.CDLL:
     L.det_fs1_get_observations.argtypes = [P, P, sz, d, d, d, u64, u32v, P]
     L.det_fs1_get_observations.restype = sz
     L.det_fs1_update.restype = i
+    M2 = C.POINTER(DetFs2Model)
+    L.det_fs2_model_default.argtypes = [M2]
+    L.det_fs2_model_default.restype = None
+    L.det_fs2_proposal.argtypes = [P, d, d, d, d, P, M2, P, P]
+    L.det_fs2_proposal.restype = None
+    L.det_fs2_sample.argtypes = [P, P, P, P]
+    L.det_fs2_sample.restype = None
+    L.det_fs2_predict.argtypes = [sz, P, P, P, P, d, d, P, sz, P, u64, u32v, u64, M2]
+    L.det_fs2_predict.restype = None
+    L.det_fs2_update.argtypes = [sz, sz, P, P, P, P, P, d, d, P, sz, M2, P, d, u64, u32v, u32v, i, u32]
+    L.det_fs2_update.restype = i
     L.det_fs1_best_particle.argtypes = [sz, P]
     L.det_fs1_best_particle.restype = sz
     return L
@@ -202,6 +228,12 @@ def ref_fs1_model() -> RefFs1Model:
 def det_fs1_model() -> DetFs1Model:
     m = DetFs1Model()
     det().det_fs1_model_default(C.byref(m))
+    return m
+
+
+def det_fs2_model() -> DetFs2Model:
+    m = DetFs2Model()
+    det().det_fs2_model_default(C.byref(m))
     return m
 
 

@@ -261,6 +261,48 @@ void det_fs1_model_default(rr_fs1_model* m) {
   m->r11 = 0.0305;
   m->init_threshold = 100.0;
   m->init_cov = NAN;
+  m->init_test_lt = 0.0;
+  m->nonpos_det_w = 1.0;
+}
+
+/* fastslam2.rs:18-30 */
+void det_fs2_model_default(rr_fs2_model* m) {
+  det_fs1_model_default(&m->base);
+  m->base.init_cov = 10.0;      /* :255 */
+  m->base.init_test_lt = 1.0;   /* :49-51 */
+  m->base.nonpos_det_w = 1e-10; /* :289 */
+  m->m0 = 0.1;
+  m->m1 = 0.1;
+  m->m2 = 0.01;
+}
+
+void det_fs2_proposal(const double pose[3], double u0, double u1, double zd, double za, const double* lm,
+                      const rr_fs2_model* m, double mean[3], double cov[9]) {
+  rr_fs2_proposal(pose, u0, u1, zd, za, lm, *m, mean, cov);
+}
+
+void det_fs2_sample(const double mean[3], const double cov[9], const double z[3], double pose[3]) {
+  rr_fs2_sample(mean, cov, z, pose);
+}
+
+/* the sampling step for n particles; maps in plane layout [l][6][n]; noise: explicit 3 normals
+ * per particle or NULL for the Philox streams */
+void det_fs2_predict(size_t n, double* px, double* py, double* pyaw, const double* maps, double u0, double u1,
+                     const double* z, size_t n_z, const double* noise, uint64_t seed, uint32_t step, uint64_t first_gid,
+                     const rr_fs2_model* m) {
+  for (size_t p = 0; p < n; ++p) {
+    double zn[3];
+    if (noise) { zn[0] = noise[3 * p]; zn[1] = noise[3 * p + 1]; zn[2] = noise[3 * p + 2]; }
+    else rr_fs2_noise(seed, step, first_gid + p, zn);
+    double pose[3] = {px[p], py[p], pyaw[p]};
+    double lm[6] = {0, 0, 0, 0, 0, 0};
+    if (n_z) {
+      size_t id = (size_t)z[2];
+      for (int f = 0; f < 6; ++f) lm[f] = maps[(id * 6 + (size_t)f) * n + p];
+    }
+    rr_fs2_predict_one(pose, u0, u1, n_z > 0, n_z ? z[0] : 0.0, n_z ? z[1] : 0.0, lm, zn, *m);
+    px[p] = pose[0]; py[p] = pose[1]; pyaw[p] = pose[2];
+  }
 }
 
 void det_fs1_predict(size_t n, double* px, double* py, double* pyaw, double u0, double u1,
@@ -321,10 +363,29 @@ static void fs1_gather(size_t n, size_t L, double* px, double* py, double* pyaw,
 /* fastslam1.rs:237-266 in the D-spec.  Returns 1 if resampled.
  * The integer image (shift, T, sum q^2, CDF) is taken from the accumulated RAW
  * weights; the normalised weight is w / (T * 2^-shift). */
+static int det_fs_observe_resample(size_t n, size_t L, double* px, double* py, double* pyaw, double* pw, double* maps,
+                                   const double* z, size_t n_z, const rr_fs1_model* m, double nth, uint64_t seed,
+                                   uint32_t rstep, int n_chunks, uint32_t* idx_out);
+
 int det_fs1_update(size_t n, size_t L, double* px, double* py, double* pyaw, double* pw, double* maps,
                    double u0, double u1, const double* z, size_t n_z, const rr_fs1_model* m,
                    double nth, uint64_t seed, uint32_t step, uint32_t rstep, int n_chunks, uint32_t* idx_out) {
   det_fs1_predict(n, px, py, pyaw, u0, u1, NULL, NULL, seed, step, 0, m);
+  return det_fs_observe_resample(n, L, px, py, pyaw, pw, maps, z, n_z, m, nth, seed, rstep, n_chunks, idx_out);
+}
+
+/* fastslam2.rs:331-374 in the D-spec: proposal sampling, then the FastSLAM 1.0 observation loop
+ * with the FastSLAM 2.0 model switches, normalise / N_eff gate / systematic resample */
+int det_fs2_update(size_t n, size_t L, double* px, double* py, double* pyaw, double* pw, double* maps,
+                   double u0, double u1, const double* z, size_t n_z, const rr_fs2_model* m, const double* noise,
+                   double nth, uint64_t seed, uint32_t step, uint32_t rstep, int n_chunks, uint32_t* idx_out) {
+  det_fs2_predict(n, px, py, pyaw, maps, u0, u1, z, n_z, noise, seed, step, 0, m);
+  return det_fs_observe_resample(n, L, px, py, pyaw, pw, maps, z, n_z, &m->base, nth, seed, rstep, n_chunks, idx_out);
+}
+
+static int det_fs_observe_resample(size_t n, size_t L, double* px, double* py, double* pyaw, double* pw, double* maps,
+                                   const double* z, size_t n_z, const rr_fs1_model* m, double nth, uint64_t seed,
+                                   uint32_t rstep, int n_chunks, uint32_t* idx_out) {
   det_fs1_observe(n, px, py, pyaw, pw, maps, z, n_z, m, n_chunks);
   double wmax = det_wmax(n, pw);
   int shift;

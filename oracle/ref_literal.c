@@ -510,3 +510,189 @@ size_t ref_fs1_get_observations(const double xt[3], const double* lms, size_t L,
   }
   return cnt;
 }
+
+/* ------------------------------------------------------------------ FastSLAM 2.0 */
+/* rust_robotics_slam/src/fastslam2.rs.  3x3 matrices are row-major arrays of 9; matrix products
+ * are evaluated as nalgebra 0.33 does for small static matrices (each entry summed over k in
+ * ascending order, no FMA); Matrix3::try_inverse is nalgebra's cofactor formula (linalg/inverse.rs),
+ * Cholesky is linalg/cholesky.rs (lower triangle, None when a pivot is zero or negative).
+ * nalgebra itself is a crates.io dependency and not part of /root/reference. */
+
+static void ref_mul33(const double* a, const double* b, double* o) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) o[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+
+static int ref_inv3(const double* a, double* o) {
+  double m11 = a[0], m12 = a[1], m13 = a[2], m21 = a[3], m22 = a[4], m23 = a[5], m31 = a[6], m32 = a[7], m33 = a[8];
+  double minor_m12_m23 = m22 * m33 - m32 * m23;
+  double minor_m11_m23 = m21 * m33 - m31 * m23;
+  double minor_m11_m22 = m21 * m32 - m31 * m22;
+  double det = m11 * minor_m12_m23 - m12 * minor_m11_m23 + m13 * minor_m11_m22;
+  if (det == 0.0) return 0;
+  o[0] = minor_m12_m23 / det;
+  o[1] = (m13 * m32 - m33 * m12) / det;
+  o[2] = (m12 * m23 - m22 * m13) / det;
+  o[3] = -minor_m11_m23 / det;
+  o[4] = (m11 * m33 - m31 * m13) / det;
+  o[5] = (m13 * m21 - m23 * m11) / det;
+  o[6] = minor_m11_m22 / det;
+  o[7] = (m12 * m31 - m32 * m11) / det;
+  o[8] = (m11 * m22 - m21 * m12) / det;
+  return 1;
+}
+
+/* motion_model :92-99 */
+static void ref_fs2_motion_model(const double x[3], double u0, double u1, double o[3]) {
+  double yaw = x[2];
+  o[0] = x[0] + u0 * 0.1 * cos(yaw);
+  o[1] = x[1] + u0 * 0.1 * sin(yaw);
+  o[2] = ref_normalize_angle(x[2] + u1 * 0.1);
+}
+
+/* compute_proposal :173-216; lm = {x, y, c00, c10, c01, c11}; r = diag(r00, r11) */
+void ref_fs2_proposal(const double pose[3], double u0, double u1, double zd, double za, const double* lm, double r00,
+                      double r11, double mean[3], double cov[9]) {
+  const double DT = 0.1;
+  double xp[3];
+  ref_fs2_motion_model(pose, u0, u1, xp);
+  double yaw = pose[2], v = u0;
+  double g[9] = {1.0, 0.0, -v * DT * sin(yaw), 0.0, 1.0, v * DT * cos(yaw), 0.0, 0.0, 1.0}; /* :103-118 */
+  double mc[9] = {0.1, 0.0, 0.0, 0.0, 0.1, 0.0, 0.0, 0.0, 0.01};                              /* :30 */
+  double gt[9] = {g[0], g[3], g[6], g[1], g[4], g[7], g[2], g[5], g[8]};
+  double gm[9], P[9];
+  ref_mul33(g, mc, gm);
+  ref_mul33(gm, gt, P); /* :183 */
+  double c00 = lm[2], c10 = lm[3], c01 = lm[4], c11 = lm[5];
+  if (!(c00 < 100.0)) { /* is_initialized :49-51 */
+    memcpy(mean, xp, 3 * sizeof(double));
+    memcpy(cov, P, 9 * sizeof(double));
+    return;
+  }
+  double dx = lm[0] - xp[0], dy = lm[1] - xp[1];
+  double d2 = dx * dx + dy * dy;
+  double d = sqrt(d2);
+  double h[6] = {-dx / d, -dy / d, 0.0, dy / d2, -dx / d2, -1.0}; /* :139-147 */
+  double l00 = dx / d, l01 = dy / d, l10 = -dy / d2, l11 = dx / d2; /* :131-137 */
+  double hc00 = l00 * c00 + l01 * c10, hc01 = l00 * c01 + l01 * c11;
+  double hc10 = l10 * c00 + l11 * c10, hc11 = l10 * c01 + l11 * c11;
+  double q00 = hc00 * l00 + hc01 * l01 + r00, q01 = hc00 * l10 + hc01 * l11 + 0.0;
+  double q10 = hc10 * l00 + hc11 * l01 + 0.0, q11 = hc10 * l10 + hc11 * l11 + r11; /* :195 */
+  double qdet = q00 * q11 - q10 * q01;
+  double i00, i01, i10, i11;
+  if (qdet == 0.0) { i00 = 1.0; i01 = 0.0; i10 = 0.0; i11 = 1.0; }
+  else { i00 = q11 / qdet; i01 = -q01 / qdet; i10 = -q10 / qdet; i11 = q00 / qdet; } /* :200 */
+  double Pinv[9];
+  if (!ref_inv3(P, Pinv)) { /* :202 */
+    memset(Pinv, 0, sizeof Pinv);
+    Pinv[0] = Pinv[4] = Pinv[8] = 1.0 * 1e-6;
+  }
+  double t[6]; /* h_pose^T * q_obs_inv, 3x2 */
+  for (int r = 0; r < 3; ++r) {
+    t[2 * r] = h[r] * i00 + h[3 + r] * i10;
+    t[2 * r + 1] = h[r] * i01 + h[3 + r] * i11;
+  }
+  double Ppi[9];
+  for (int r = 0; r < 3; ++r)
+    for (int q = 0; q < 3; ++q) Ppi[3 * r + q] = Pinv[3 * r + q] + (t[2 * r] * h[q] + t[2 * r + 1] * h[3 + q]); /* :203 */
+  double Pp[9];
+  if (!ref_inv3(Ppi, Pp)) memcpy(Pp, P, sizeof Pp); /* :204 */
+  double zp_a = ref_normalize_angle(atan2(dy, dx) - xp[2]); /* :207, observation_model :122-128 */
+  double y0 = zd - d, y1 = ref_normalize_angle(za - zp_a);
+  for (int r = 0; r < 3; ++r) { /* :210, ((p_post * h^T) * q_inv) * innovation */
+    double ph0 = Pp[3 * r] * h[0] + Pp[3 * r + 1] * h[1] + Pp[3 * r + 2] * h[2];
+    double ph1 = Pp[3 * r] * h[3] + Pp[3 * r + 1] * h[4] + Pp[3 * r + 2] * h[5];
+    double k0 = ph0 * i00 + ph1 * i10, k1 = ph0 * i01 + ph1 * i11;
+    mean[r] = xp[r] + (k0 * y0 + k1 * y1);
+  }
+  memcpy(cov, Pp, 9 * sizeof(double));
+}
+
+/* sample_pose_with_rng :219-239 followed by set_pose :77-81; z = three unit normals */
+void ref_fs2_sample(const double mean[3], const double c[9], const double z[3], double pose[3]) {
+  double L[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int ok = 0;
+  if (c[0] != 0.0 && c[0] >= 0.0) {
+    double l00 = sqrt(c[0]), l10 = c[3] / l00, l20 = c[6] / l00;
+    double d1 = -l10 * l10 + c[4];
+    double c21 = -l10 * l20 + c[7];
+    if (d1 != 0.0 && d1 >= 0.0) {
+      double l11 = sqrt(d1), l21 = c21 / l11;
+      double d2 = -l21 * l21 + (-l20 * l20 + c[8]);
+      if (d2 != 0.0 && d2 >= 0.0) {
+        L[0] = l00; L[3] = l10; L[4] = l11; L[6] = l20; L[7] = l21; L[8] = sqrt(d2);
+        ok = 1;
+      }
+    }
+  }
+  if (!ok) { /* :227-233 */
+    L[0] = sqrt(fmax(c[0], 0.0));
+    L[4] = sqrt(fmax(c[4], 0.0));
+    L[8] = sqrt(fmax(c[8], 0.0));
+  }
+  pose[0] = mean[0] + (L[0] * z[0] + L[1] * z[1] + L[2] * z[2]);
+  pose[1] = mean[1] + (L[3] * z[0] + L[4] * z[1] + L[5] * z[2]);
+  pose[2] = ref_normalize_angle(mean[2] + (L[6] * z[0] + L[7] * z[1] + L[8] * z[2]));
+}
+
+/* update_landmark_and_weight :242-291; returns the factor the particle weight is multiplied by */
+double ref_fs2_update_landmark(double px, double py, double pyaw, double zd, double za, double* e, double r00, double r11) {
+  if (!(e[2] < 100.0)) { /* :251-257 */
+    e[0] = px + zd * cos(pyaw + za);
+    e[1] = py + zd * sin(pyaw + za);
+    e[2] = 10.0; e[3] = 0.0; e[4] = 0.0; e[5] = 10.0;
+    return 1.0;
+  }
+  double w = 1.0;
+  ref_fs1_model m;
+  ref_fs1_model_default(&m);
+  m.r00 = r00;
+  m.r11 = r11;
+  m.init_threshold = INFINITY; /* the branch above already decided */
+  /* :259-283 are line for line fastslam1.rs:152-182 (same Jacobian, S, K, (I - K H) P, likelihood) */
+  /* det S is needed here because the weight of the det <= 0 case differs (1e-10, :288-290) */
+  double p00 = e[2], p10 = e[3], p01 = e[4], p11 = e[5];
+  double dx = e[0] - px, dy = e[1] - py;
+  double d2 = dx * dx + dy * dy, dd = sqrt(d2);
+  double h00 = dx / dd, h01 = dy / dd, h10 = -dy / d2, h11 = dx / d2;
+  double hp00 = h00 * p00 + h01 * p10, hp01 = h00 * p01 + h01 * p11;
+  double hp10 = h10 * p00 + h11 * p10, hp11 = h10 * p01 + h11 * p11;
+  double s00 = hp00 * h00 + hp01 * h01 + r00, s01 = hp00 * h10 + hp01 * h11 + 0.0;
+  double s10 = hp10 * h00 + hp11 * h01 + 0.0, s11 = hp10 * h10 + hp11 * h11 + r11;
+  double det_s = s00 * s11 - s10 * s01;
+  ref_fs1_update_landmark(px, py, pyaw, &w, zd, za, e, &m);
+  if (!(det_s > 0.0)) return 1e-10; /* :288-290 */
+  return w;
+}
+
+/* fastslam2_update_with_rng :331-374.  noise = 3 unit normals per particle (the proposal sample,
+ * or the two motion normals when z is empty); r0 = the resample offset in [0, 1/n). */
+int ref_fs2_update(size_t n, size_t L, double* px, double* py, double* pyaw, double* pw, double* lm, double u0, double u1,
+                   const double* noise, const double* z, size_t n_z, double nth, double r0, uint32_t* idx_scratch) {
+  const double r00 = 0.5, r11 = 0.0305;
+  for (size_t p = 0; p < n; ++p) {
+    double pose[3] = {px[p], py[p], pyaw[p]};
+    if (n_z > 0) { /* :341-347 */
+      double mean[3], cov[9], np[3];
+      size_t id = (size_t)z[2];
+      ref_fs2_proposal(pose, u0, u1, z[0], z[1], lm + (p * L + id) * 6, r00, r11, mean, cov);
+      ref_fs2_sample(mean, cov, noise + 3 * p, np);
+      px[p] = np[0]; py[p] = np[1]; pyaw[p] = np[2];
+    } else { /* :349-357 */
+      double un0 = u0 + noise[3 * p] * sqrt(0.3), un1 = u1 + noise[3 * p + 1] * sqrt(0.0305);
+      double np[3];
+      ref_fs2_motion_model(pose, un0, un1, np);
+      px[p] = np[0]; py[p] = np[1]; pyaw[p] = ref_normalize_angle(np[2]);
+    }
+    for (size_t k = 0; k < n_z; ++k) /* :361-365 */
+      pw[p] *= ref_fs2_update_landmark(px[p], py[p], pyaw[p], z[3 * k], z[3 * k + 1], lm + (p * L + (size_t)z[3 * k + 2]) * 6, r00, r11);
+  }
+  ref_fs1_normalize(n, pw); /* :368, same as fastslam1.rs:196-203 */
+  double neff = ref_fs1_neff(n, pw);
+  if (neff < nth) { /* :370-373; resample_with_rng :303-328 is fastslam1.rs:205-234 */
+    ref_fs1_resample_indices(n, pw, r0, idx_scratch);
+    ref_fs1_gather(n, L, px, py, pyaw, pw, lm, idx_scratch);
+    return 1;
+  }
+  return 0;
+}

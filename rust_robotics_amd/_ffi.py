@@ -75,6 +75,12 @@ class Fs1Params(C.Structure):
                                           "init_cov", "init_threshold", "first_obs_cov")]
 
 
+class Fs2Params(C.Structure):
+    """rr_fs2_params (include/rr_fastslam2.h)"""
+
+    _fields_ = [("base", Fs1Params), ("motion_cov", C.c_double * 3), ("nonpos_det_weight", C.c_double)]
+
+
 class Fs1Options(C.Structure):
     _fields_ = [("device", C.c_int32), ("record_indices", C.c_int32), ("seed", C.c_uint64), ("obs_chunks", C.c_int32),
                 ("reserved", C.c_int32), ("first_global_index", C.c_uint64), ("n_global", C.c_uint64)]
@@ -195,6 +201,13 @@ def lib() -> C.CDLL:
     proto("rr_fs1_params_default", None, [FP])
     proto("rr_fs1_options_default", None, [FO])
     proto("rr_fs1_create", st, [u64, u64, FP, FO, C.POINTER(H)])
+    F2 = C.POINTER(Fs2Params)
+    proto("rr_fs2_params_default", None, [F2])
+    proto("rr_fs2_create", st, [u64, u64, F2, FO, C.POINTER(H)])
+    proto("rr_fs2_update", st, [H, P, P, sz])
+    proto("rr_fs2_update_async", st, [H, P, P, sz])
+    proto("rr_fs2_predict_with_noise", st, [H, P, P, sz, P])
+    proto("rr_fs2_predict", st, [H, P, P, sz])
     proto("rr_fs1_destroy", None, [H])
     proto("rr_fs1_particle_count", u64, [H])
     proto("rr_fs1_landmark_count", u64, [H])

@@ -29,6 +29,7 @@
 #include "resample_core.hpp"
 #include "rr_common.hpp"
 #include "rr_fastslam1.h"
+#include "rr_fastslam2.h"
 #include "rr_pf_spec.h"
 
 using rr::Ctl;
@@ -80,6 +81,46 @@ __global__ __launch_bounds__(kBlock) void k_fs1_predict(Planes pl, const Ctl* __
   dst[p] = x;
   dst[n + p] = y;
   dst[2 * n + p] = yaw;
+}
+
+// FastSLAM 2.0 (fastslam2.rs:339-358): the pose is not pushed through the noisy motion model but
+// SAMPLED from the proposal that fuses the motion prior with the first observation of the step --
+// per particle a 3x3 prior, a 2x2 innovation covariance, two 3x3 inverses, a Cholesky factor and
+// three normals (rr_fs2_predict_one).  Reads the six planes of the first observation's landmark;
+// LAZY as in k_fs1_predict.  noise (EXPLICIT): 3 unit normals per particle, [3p + k].
+template <bool EXPLICIT, bool LAZY>
+__global__ __launch_bounds__(kBlock) void k_fs2_predict(Planes pl, const Ctl* __restrict__ ctl, uint64_t n, double u0,
+                                                       double u1, rr_fs2_model m, uint64_t seed, unsigned int step,
+                                                       const double* __restrict__ noise,
+                                                       const unsigned int* __restrict__ idx, uint64_t gid0, int has_obs,
+                                                       double zd, double za, uint64_t id0) {
+  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (p >= n) return;
+  const bool pending = LAZY && ctl->pending;
+  double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
+  const unsigned int ji = pending ? idx[p] : (unsigned int)p;
+  const bool inplace = pending && ji == kInPlace;
+  const double* __restrict__ src = inplace ? dst : pl.s[ctl->cur];
+  const uint64_t j = inplace ? p : ji;
+  double pose[3] = {src[j], src[n + j], src[2 * n + j]};
+  double lm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  if (has_obs) {
+    const double* in = src + (3 + id0 * 6) * n + j;
+#pragma unroll
+    for (int f = 0; f < 6; ++f) lm[f] = in[f * n];
+  }
+  double z[3];
+  if (EXPLICIT) {
+    z[0] = noise[3 * p];
+    z[1] = noise[3 * p + 1];
+    z[2] = noise[3 * p + 2];
+  } else {
+    rr_fs2_noise(seed, step, gid0 + p, z);
+  }
+  rr_fs2_predict_one(pose, u0, u1, has_obs, zd, za, lm, z, m);
+  dst[p] = pose[0];
+  dst[n + p] = pose[1];
+  dst[2 * n + p] = pose[2];
 }
 
 // (particle, observation chunk).  blockIdx.y = chunk.  The chunk's observations are staged in
@@ -448,6 +489,9 @@ __global__ void k_fs1_one_landmarks(const double* __restrict__ planes, uint64_t 
 struct rr_fs1 {
   rr_fs1_params prm;
   rr_fs1_options opt;
+  int algorithm = 1;                      // 1 = FastSLAM 1.0, 2 = FastSLAM 2.0 (proposal sampling, fastslam2.rs)
+  double motion_cov[3] = {0.1, 0.1, 0.01};  // FastSLAM 2.0: MOTION_COV diagonal
+  double nonpos_det_w = 1.0;
   uint64_t n = 0, L = 0, n_planes = 0, n_tiles = 0;
   uint64_t n_global = 0, gid0 = 0;  // sharding: particles over all shards, global index of local particle 0
   hipStream_t stream = nullptr;
@@ -491,7 +535,7 @@ rr_status bind(rr_fs1* h) {
   return RR_OK;
 }
 
-rr_fs1_model host_model(const rr_fs1_params& p) {
+rr_fs1_model host_model(const rr_fs1_params& p, int algorithm = 1, double nonpos_det_w = 1.0) {
   rr_fs1_model m;
   m.dt = p.dt;
   m.q_sqrt0 = rr_sqrt(p.q00);
@@ -500,8 +544,12 @@ rr_fs1_model host_model(const rr_fs1_params& p) {
   m.r11 = p.r11;
   m.init_threshold = p.init_threshold;
   m.init_cov = p.first_obs_cov;
+  m.init_test_lt = algorithm == 2 ? 1.0 : 0.0;
+  m.nonpos_det_w = nonpos_det_w;
   return m;
 }
+
+rr_fs1_model model_of(const rr_fs1* h);
 
 rr_status validate_u(const double u[2]) {
   if (!u || !std::isfinite(u[0]) || !std::isfinite(u[1]))
@@ -551,6 +599,8 @@ PlanArgs plan_args(const rr_fs1* h, int mode, double rho_override, bool lazy = f
   return a;
 }
 
+rr_fs1_model model_of(const rr_fs1* h) { return host_model(h->prm, h->algorithm, h->nonpos_det_w); }
+
 // make a pending lazy resample real: gather every plane, flip the live set
 rr_status materialise(rr_fs1* h) {
   if (!h->maybe_pending) return RR_OK;
@@ -569,11 +619,35 @@ template <bool EXPLICIT, bool LAZY>
 rr_status launch_predict(rr_fs1* h, const double u[2]) {
   rr::ScopedTimer t(h->prof, h->stream, RR_FK_PREDICT);
   hipLaunchKernelGGL((k_fs1_predict<EXPLICIT, LAZY>), dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl,
-                     h->ctl, h->n, u[0], u[1], host_model(h->prm), h->opt.seed, h->step, (const double*)h->noise,
+                     h->ctl, h->n, u[0], u[1], model_of(h), h->opt.seed, h->step, (const double*)h->noise,
                      (const double*)(h->noise ? h->noise + h->n : nullptr), (const unsigned int*)h->idx, h->gid0);
   RR_HIP_TRY(hipGetLastError());
   h->step += 1;
   return RR_OK;
+}
+
+// FastSLAM 2.0: sample the pose from the proposal built on the first observation (fastslam2.rs:341-347)
+template <bool EXPLICIT, bool LAZY>
+rr_status launch_propose(rr_fs1* h, const double u[2], const double* z, size_t n_z) {
+  rr_fs2_model m;
+  m.base = model_of(h);
+  m.m0 = h->motion_cov[0];
+  m.m1 = h->motion_cov[1];
+  m.m2 = h->motion_cov[2];
+  rr::ScopedTimer t(h->prof, h->stream, RR_FK_PREDICT);
+  hipLaunchKernelGGL((k_fs2_predict<EXPLICIT, LAZY>), dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl, h->ctl,
+                     h->n, u[0], u[1], m, h->opt.seed, h->step, (const double*)h->noise, (const unsigned int*)h->idx, h->gid0,
+                     n_z > 0 ? 1 : 0, n_z ? z[0] : 0.0, n_z ? z[1] : 0.0, n_z ? (uint64_t)z[2] : 0ull);
+  RR_HIP_TRY(hipGetLastError());
+  h->step += 1;
+  return RR_OK;
+}
+
+// the pose step of an update: noisy motion model (FastSLAM 1.0) or proposal sampling (2.0)
+template <bool LAZY>
+rr_status launch_motion(rr_fs1* h, const double u[2], const double* z, size_t n_z) {
+  if (h->algorithm == 2) return launch_propose<false, LAZY>(h, u, z, n_z);
+  return launch_predict<false, LAZY>(h, u);
 }
 
 int choose_chunks(const rr_fs1* h, size_t n_z, bool dup) {
@@ -616,11 +690,11 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool 
     const size_t lds = 3 * (size_t)len * sizeof(double);
     if (lazy)
       hipLaunchKernelGGL(k_fs1_observe<true>, grid, dim3(kBlock), lds, h->stream, h->pl, h->pw, h->ctl, h->n,
-                         (const double*)h->z_dev, (int)n_z, len, chunks, host_model(h->prm), h->partial,
+                         (const double*)h->z_dev, (int)n_z, len, chunks, model_of(h), h->partial,
                          (const unsigned int*)h->idx);
     else
       hipLaunchKernelGGL(k_fs1_observe<false>, grid, dim3(kBlock), lds, h->stream, h->pl, h->pw, h->ctl, h->n,
-                         (const double*)h->z_dev, (int)n_z, len, chunks, host_model(h->prm), h->partial,
+                         (const double*)h->z_dev, (int)n_z, len, chunks, model_of(h), h->partial,
                          (const unsigned int*)h->idx);
   }
   if (chunks > 1) {
@@ -706,7 +780,7 @@ rr_status fetch_ctl(rr_fs1* h) {
 }
 
 rr_status ensure_noise(rr_fs1* h) {
-  if (!h->noise) RR_HIP_TRY(hipMalloc(&h->noise, 2 * h->n * sizeof(double)));
+  if (!h->noise) RR_HIP_TRY(hipMalloc(&h->noise, 3 * h->n * sizeof(double)));  // FastSLAM 2.0 draws three normals
   return RR_OK;
 }
 
@@ -850,6 +924,64 @@ rr_status rr_fs1_predict_with_noise(rr_fs1* h, const double u[2], const double* 
   return launch_predict<true, false>(h, u);
 }
 
+// ---- FastSLAM 2.0 (include/rr_fastslam2.h)
+void rr_fs2_params_default(rr_fs2_params* p) {
+  if (!p) return;
+  rr_fs1_params_default(&p->base);
+  p->base.first_obs_cov = 10.0;  // fastslam2.rs:255
+  p->motion_cov[0] = 0.1;        // :30
+  p->motion_cov[1] = 0.1;
+  p->motion_cov[2] = 0.01;
+  p->nonpos_det_weight = 1e-10;  // :289
+}
+
+rr_status rr_fs2_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs2_params* params,
+                        const rr_fs1_options* opt, rr_fs2** out) {
+  rr_fs2_params prm;
+  if (params) prm = *params; else rr_fs2_params_default(&prm);
+  for (int k = 0; k < 3; ++k)
+    if (!std::isfinite(prm.motion_cov[k]) || prm.motion_cov[k] < 0.0)
+      return fail(RR_INVALID_PARAMETER, "fastslam2 motion covariance must be finite and non-negative");
+  if (!std::isfinite(prm.nonpos_det_weight)) return fail(RR_INVALID_PARAMETER, "fastslam2 nonpos_det_weight must be finite");
+  if (!(prm.base.first_obs_cov == prm.base.first_obs_cov))
+    return fail(RR_INVALID_PARAMETER, "fastslam2 initialises a landmark's covariance on its first observation: first_obs_cov must be a number");
+  rr_status s = rr_fs1_create(n_particles, n_landmarks, &prm.base, opt, out);
+  if (s != RR_OK) return s;
+  (*out)->algorithm = 2;
+  for (int k = 0; k < 3; ++k) (*out)->motion_cov[k] = prm.motion_cov[k];
+  (*out)->nonpos_det_w = prm.nonpos_det_weight;
+  return RR_OK;
+}
+
+rr_status rr_fs2_update(rr_fs2* h, const double u[2], const double* z, size_t n_z) { return rr_fs1_update(h, u, z, n_z); }
+rr_status rr_fs2_update_async(rr_fs2* h, const double u[2], const double* z, size_t n_z) {
+  return rr_fs1_update_async(h, u, z, n_z);
+}
+
+static rr_status fs2_predict_common(rr_fs2* h, const double u[2], const double* z, size_t n_z, const double* noise) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (h->algorithm != 2) return fail(RR_INVALID_PARAMETER, "not a FastSLAM 2.0 filter");
+  if ((s = validate_u(u)) != RR_OK) return s;
+  bool dup;
+  if ((s = validate_z(h, z, n_z, &dup)) != RR_OK) return s;
+  if (noise) {
+    if ((s = ensure_noise(h)) != RR_OK) return s;
+    RR_HIP_TRY(hipMemcpyAsync(h->noise, noise, 3 * h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
+  if ((s = materialise(h)) != RR_OK) return s;
+  return noise ? launch_propose<true, false>(h, u, z, n_z) : launch_propose<false, false>(h, u, z, n_z);
+}
+
+rr_status rr_fs2_predict_with_noise(rr_fs2* h, const double u[2], const double* z, size_t n_z, const double* noise) {
+  if (!noise) return fail(RR_INVALID_PARAMETER, "null noise array");
+  return fs2_predict_common(h, u, z, n_z, noise);
+}
+
+rr_status rr_fs2_predict(rr_fs2* h, const double u[2], const double* z, size_t n_z) {
+  return fs2_predict_common(h, u, z, n_z, nullptr);
+}
+
 rr_status rr_fs1_observe(rr_fs1* h, const double* z, size_t n_z) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
@@ -886,14 +1018,14 @@ rr_status rr_fs1_update_async(rr_fs1* h, const double u[2], const double* z, siz
     // the same landmark twice in one step: the second update must see the first one's result,
     // which the read-through-idx scheme cannot give -- settle first, then update in place
     if ((s = materialise(h)) != RR_OK) return s;
-    if ((s = launch_predict<false, false>(h, u)) != RR_OK) return s;
+    if ((s = launch_motion<false>(h, u, z, n_z)) != RR_OK) return s;
     if ((s = launch_observe(h, z, n_z, dup)) != RR_OK) return s;
     if ((s = launch_sums(h, 0, NAN, /*lazy=*/true, /*settle=*/0)) != RR_OK) return s;
     return launch_finish(h, /*lazy=*/true);
   }
   // lazy: predict and observe read the previous resample's survivors through idx and write the
   // other buffer set; unobserved landmarks are gathered separately; k_quantize_reduce settles
-  if ((s = launch_predict<false, true>(h, u)) != RR_OK) return s;
+  if ((s = launch_motion<true>(h, u, z, n_z)) != RR_OK) return s;
   if ((s = launch_observe(h, z, n_z, dup, /*lazy=*/true)) != RR_OK) return s;
   if (h->maybe_pending && (s = launch_rest_gather(h, z, n_z)) != RR_OK) return s;
   h->maybe_pending = false;
@@ -1117,10 +1249,10 @@ rr_status rr_fs1_shard_update_p2p(rr_fs1* h, const double u[2], const double* z,
   // resample's survivors through idx (kInPlace = stored by a peer) unless a landmark repeats
   if (dup) {
     if ((s = materialise(h)) != RR_OK) return s;
-    if ((s = launch_predict<false, false>(h, u)) != RR_OK) return s;
+    if ((s = launch_motion<false>(h, u, z, n_z)) != RR_OK) return s;
     if ((s = launch_observe(h, z, n_z, dup)) != RR_OK) return s;
   } else {
-    if ((s = launch_predict<false, true>(h, u)) != RR_OK) return s;
+    if ((s = launch_motion<true>(h, u, z, n_z)) != RR_OK) return s;
     if ((s = launch_observe(h, z, n_z, dup, /*lazy=*/true)) != RR_OK) return s;
     if (h->maybe_pending && (s = launch_rest_gather(h, z, n_z)) != RR_OK) return s;
     h->maybe_pending = false;

@@ -94,8 +94,11 @@ class FastSlam1:
         opt.device, opt.seed, opt.obs_chunks = device, seed, obs_chunks
         opt.first_global_index, opt.n_global = int(first_global_index), int(n_global)
         self._h = C.c_void_p()
-        _check(L.rr_fs1_create(int(n_particles), int(n_landmarks), C.byref(self.params), C.byref(opt), C.byref(self._h)))
+        self._create(int(n_particles), int(n_landmarks), opt)
         self.n, self.L = int(n_particles), int(n_landmarks)
+
+    def _create(self, n_particles: int, n_landmarks: int, opt) -> None:
+        _check(self._L.rr_fs1_create(n_particles, n_landmarks, C.byref(self.params), C.byref(opt), C.byref(self._h)))
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -282,15 +285,16 @@ _SHIM_CACHE = {}
 
 
 def fastslam_update(particles: List[Particle], u, z: Sequence[Tuple[float, float, int]], *, seed: int = 0,
-                    device: int = 0) -> None:
+                    device: int = 0, _engine=None) -> None:
     """fastslam1.rs:237-266 on the GPU: upload the caller's particles, one update, download."""
     if not particles:
         return
     n, L = len(particles), len(particles[0].landmarks)
-    key = (n, L, seed, device)
+    engine = _engine or FastSlam1
+    key = (engine.__name__, n, L, seed, device)
     fs = _SHIM_CACHE.get(key)
     if fs is None:
-        fs = _SHIM_CACHE[key] = FastSlam1(n, L, seed=seed, device=device)
+        fs = _SHIM_CACHE[key] = engine(n, L, seed=seed, device=device)
     poses, maps = _pack(particles)
     u = np.ascontiguousarray(u, dtype=np.float64)
     za = _z_array(z)
