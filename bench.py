@@ -122,6 +122,31 @@ def fs1_cpu_baseline(n, L, z_list, max_seconds=20.0):
                        f"{steps} steps (first step takes the initialisation branch), {t_total:.1f} s")
 
 
+def fs2_cpu_baseline(n, L, z_list, max_seconds=20.0):
+    """fastslam2_update of the literal C restatement (oracle/ref_literal.c), one host core."""
+    import oracle
+    from oracle import dp, u32p
+
+    ref = oracle.ref()
+    px, py, pyaw = (np.zeros(n) for _ in range(3))
+    pw = np.full(n, 0.01)
+    lm = np.tile(np.array([0, 0, 1000.0, 0, 0, 1000.0]), (n, L, 1)).reshape(-1).copy()
+    idx = np.empty(n, np.uint32)
+    rng = np.random.default_rng(2)
+    steps, t_total, updates = 0, 0.0, 0
+    while steps < len(z_list) and t_total < max_seconds:
+        z = np.ascontiguousarray(z_list[steps])
+        noise = np.ascontiguousarray(rng.normal(size=(n, 3)))
+        t0 = time.perf_counter()
+        ref.ref_fs2_update(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(lm), 0.5, 0.1, dp(noise), dp(z), len(z), n / 1.5, 0.3 / n, u32p(idx))
+        t_total += time.perf_counter() - t0
+        updates += n * len(z)
+        steps += 1
+    return dict(value=updates / t_total, unit="particle-landmark updates/s", cores=1, kind="port",
+                sample=f"oracle/ref_literal.c ref_fs2_update (literal fastslam2.rs arithmetic), {n} particles x {L} landmarks x "
+                       f"{steps} steps (first step takes the initialisation branch), {t_total:.1f} s, normals pre-drawn")
+
+
 def run_fastslam(args):
     """BASELINE.json configs[2]: FastSLAM 1.0, 100 000 particles x 200 landmarks, every landmark observed
     every step, EKF branch (first_obs_cov = 0.5 initialises the maps on the first, untimed, step),
@@ -131,10 +156,18 @@ def run_fastslam(args):
 
     n, L, K, W = args.particles, args.landmarks, args.steps, args.warmup
     lms = fs1_scene(L, 2)
-    prm = fs.default_params()
-    prm.first_obs_cov = 0.5
-    prm.nth = n / 1.5
-    f = fs.FastSlam1(n, L, params=prm, seed=2)
+    v2 = args.workload == "fastslam2"
+    if v2:  # the same configuration with the FastSLAM 2.0 proposal (fastslam2.rs); first_obs_cov = 10 is its own constant
+        from rust_robotics_amd.slam import fastslam2 as fs2
+
+        prm2 = fs2.default_params()
+        prm2.base.nth = n / 1.5
+        f = fs2.FastSlam2(n, L, params=prm2, seed=2)
+    else:
+        prm = fs.default_params()
+        prm.first_obs_cov = 0.5
+        prm.nth = n / 1.5
+        f = fs.FastSlam1(n, L, params=prm, seed=2)
     zs = [np.array(fs.get_observations(H.true_pose(t + 1, v=0.5), [tuple(p) for p in lms], seed=2, step=t)).reshape(-1, 3)
           for t in range(K + W)]
     u = [0.5, 0.1]
@@ -166,11 +199,13 @@ def run_fastslam(args):
         "metric": "particle-landmark updates/sec", "value": updates / dt, "unit": "particle-landmark updates/s", "n_gpus": 1,
         "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"FastSLAM 1.0 (BASELINE.json configs[2]): {n} particles x {L} landmarks, all observed, 2x2 EKF "
-                               f"branch, N_eff-gated systematic resample", "particles_per_gpu": n, "landmarks": L},
+        "config": {"workload": (f"FastSLAM 2.0 (the configs[2] shape with the proposal of fastslam2.rs): " if v2 else
+                                "FastSLAM 1.0 (BASELINE.json configs[2]): ") +
+                               f"{n} particles x {L} landmarks, all observed, 2x2 EKF branch, N_eff-gated systematic resample",
+                   "particles_per_gpu": n, "landmarks": L},
         "roofline": {"bound": "hbm", "kernel": "k_fs1_observe", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK,
-                     "traffic": measured_traffic("k_fs1_observe", "fs1") if (n, L) == (100_000, 200) else None,
+                     "traffic": measured_traffic("k_fs1_observe", "fs1") if (n, L) == (100_000, 200) and not v2 else None,
                      "traffic_source": "profiles/r01c_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
                      "avg_kernel_ms": avg_s * 1e3,
                      "algorithmic_bytes_per_launch": per_launch},
@@ -181,7 +216,7 @@ def run_fastslam(args):
         "best_particle": {"index": i, "weight": w, "pose": [float(a) for a in pose]},
     }
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = fs1_cpu_baseline(min(n, 20000), L, zs)
+        out["cpu_baseline"] = (fs2_cpu_baseline if v2 else fs1_cpu_baseline)(min(n, 20000), L, zs)
     emit(out)
 
 
@@ -307,7 +342,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["mcl", "fastslam"], default="mcl")
+    ap.add_argument("--workload", choices=["mcl", "fastslam", "fastslam2"], default="mcl")
     ap.add_argument("--particles", type=int, default=None, help="particles PER GPU (default 1e6 for mcl, 1e5 for fastslam)")
     ap.add_argument("--landmarks", type=int, default=None, help="default 32 for mcl, 200 for fastslam")
     ap.add_argument("--scheme", choices=["systematic", "multinomial"], default="systematic")
@@ -330,9 +365,11 @@ def main():
         args.particles = 1_000_000 if args.workload == "mcl" else 100_000
     if args.landmarks is None:
         args.landmarks = 32 if args.workload == "mcl" else 200
-    if args.workload == "fastslam":
+    if args.workload in ("fastslam", "fastslam2"):
         if args.steps == 200 and args.warmup == 20:
             args.steps, args.warmup = 50, 5
+        if (world != 1 or args.force_sharded) and args.workload == "fastslam2":
+            raise SystemExit("the sharded bench leg times FastSLAM 1.0 (the sharded update itself also serves FastSLAM 2.0 handles)")
         if world != 1 or args.force_sharded:
             if args.particles == 100_000 and world == 8:
                 args.particles = 125_000  # configs[3]: 1e6 particles over 8 GPUs

@@ -14,7 +14,7 @@
 #include <utility>
 #include <vector>
 
-#include "rr_fastslam1.h"
+#include "rr_fastslam2.h"
 #include "rr_pf.h"
 
 namespace rr {
@@ -216,8 +216,33 @@ class FastSlam1 {
     return out;
   }
 
- private:
+ protected:
+  explicit FastSlam1(rr_fs1* adopted) : h_(adopted) {}
   rr_fs1* h_ = nullptr;
 };
 }  // namespace fastslam1
+
+namespace fastslam2 {
+struct Params : rr_fs2_params {
+  Params() { rr_fs2_params_default(this); }
+};
+
+// fastslam2.rs: the FastSLAM 1.0 engine with the proposal-sampling step; update() is fastslam2_update :376-383
+class FastSlam2 : public fastslam1::FastSlam1 {
+ public:
+  FastSlam2(uint64_t n_particles, uint64_t n_landmarks, const Params& p = {}, uint64_t seed = 0, int device = 0)
+      : fastslam1::FastSlam1(make(n_particles, n_landmarks, p, seed, device)) {}
+
+ private:
+  static rr_fs2* make(uint64_t n, uint64_t L, const Params& p, uint64_t seed, int device) {
+    rr_fs1_options o;
+    rr_fs1_options_default(&o);
+    o.seed = seed;
+    o.device = device;
+    rr_fs2* h = nullptr;
+    check(rr_fs2_create(n, L, &p, &o, &h));
+    return h;
+  }
+};
+}  // namespace fastslam2
 }  // namespace rr
