@@ -147,3 +147,103 @@ def test_gpu_engine_matches_fs1_golden(fg):
         np.testing.assert_allclose(poses[:, 3], fg[f"pyaw{t}"], **TOL)
         np.testing.assert_allclose(maps.reshape(-1), fg[f"lm{t}"], **TOL)
         assert f.best_particle()[2] == int(fg[f"best{t}"])
+
+
+# ------------------------------------------------------------------ FastSLAM 2.0 and the KLD-adaptive resample
+@pytest.fixture(scope="module")
+def f2g():
+    return np.load(os.path.join(G, "fs2_n40_l4.npz"))
+
+
+@pytest.fixture(scope="module")
+def kg():
+    return np.load(os.path.join(G, "kld_adaptive.npz"))
+
+
+def test_oracles_reproduce_fs2_golden(ref, det, f2g):
+    n, L = int(f2g["n"]), int(f2g["L"])
+    px, py, pyaw = (np.zeros(n) for _ in range(3))
+    pw = np.full(n, 1.0 / n)
+    lm = np.tile(np.array([0, 0, 1000.0, 0, 0, 1000.0]), (n, L, 1)).reshape(-1).copy()
+    qx, qy, qyaw, qw = px.copy(), py.copy(), pyaw.copy(), pw.copy()
+    planes = oracle.maps_aos_to_planes(lm.copy(), n, L)
+    m = oracle.det_fs2_model()
+    idx = np.empty(n, np.uint32)
+    fired_any = False
+    for t in range(int(f2g["steps"])):
+        z = np.ascontiguousarray(f2g[f"z{t}"]).reshape(-1, 3)
+        noise = np.ascontiguousarray(f2g[f"noise{t}"])
+        rho = float(f2g[f"rho{t}"])
+        fired = ref.ref_fs2_update(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(lm), 1.0, 0.1, dp(noise), dp(z) if len(z) else None, len(z),
+                                   float(f2g["nth"]), rho / n, u32p(idx))
+        assert fired == int(f2g[f"fired{t}"])
+        if fired:
+            assert np.array_equal(idx, f2g[f"idx{t}"])
+        np.testing.assert_allclose(px, f2g[f"px{t}"], rtol=1e-12, atol=1e-13)
+        np.testing.assert_allclose(lm, f2g[f"lm{t}"], rtol=1e-12, atol=1e-13)
+        # the D-spec on the same inputs: same gate, same indices, state within 1e-6
+        from tests.test_fs2_oracles import det_update_with_rho
+
+        fd = det_update_with_rho(det, n, L, qx, qy, qyaw, qw, planes, z, m, noise, float(f2g["nth"]), rho, idx)
+        assert fd == fired
+        if fired:
+            assert np.array_equal(idx, f2g[f"idx{t}"])
+        np.testing.assert_allclose(qx, f2g[f"px{t}"], **TOL)
+        np.testing.assert_allclose(qyaw, f2g[f"pyaw{t}"], **TOL)
+        np.testing.assert_allclose(qw, f2g[f"pw{t}"], **TOL)
+        np.testing.assert_allclose(oracle.maps_planes_to_aos(planes, n, L), f2g[f"lm{t}"], **TOL)
+        fired_any |= bool(fired)
+    assert fired_any
+
+
+def test_oracles_reproduce_kld_golden(ref, det, kg):
+    for c in range(int(kg["cases"])):
+        x, y, yaw, w, r = (np.ascontiguousarray(kg[f"{k}{c}"]) for k in ("x", "y", "yaw", "w", "r"))
+        lo, hi = int(kg[f"min{c}"]), int(kg[f"max{c}"])
+        idx = np.empty(hi, np.uint32)
+        cnt = ref.ref_mcl_resample_adaptive(x.size, dp(x), dp(y), dp(yaw), dp(w), dp(r), lo, hi, 0.05, 2.326, u32p(idx))
+        assert cnt == int(kg[f"count{c}"]) and np.array_equal(idx[:cnt], kg[f"idx{c}"])
+        fx = H.det_fixed(det, w)
+        cdf = H.det_cdf(det, w, fx)
+        cnt_d = det.det_mcl_resample_adaptive(x.size, dp(x), dp(y), dp(yaw), u64p(cdf), int(cdf[-1]), dp(r), 0, 0, lo, hi, 0.05, 2.326, u32p(idx))
+        assert cnt_d == int(kg[f"count{c}"]) and np.array_equal(idx[:cnt_d], kg[f"idx{c}"])
+
+
+@pytest.mark.gpu
+def test_gpu_engine_matches_fs2_golden(f2g):
+    from rust_robotics_amd.slam import fastslam2 as fs2
+
+    n, L = int(f2g["n"]), int(f2g["L"])
+    prm = fs2.default_params()
+    prm.base.nth = 0.0  # the gate is replayed from the golden record below
+    prm.base.initial_weight = 1.0 / n
+    f = fs2.FastSlam2(n, L, params=prm, obs_chunks=1)
+    for t in range(int(f2g["steps"])):
+        z = np.ascontiguousarray(f2g[f"z{t}"]).reshape(-1, 3)
+        f.propose_with_noise(f2g["u"], z, f2g[f"noise{t}"])
+        f.observe(z)
+        if int(f2g[f"fired{t}"]):
+            f.resample_systematic(float(f2g[f"rho{t}"]))
+            assert np.array_equal(f.last_resample_indices(), f2g[f"idx{t}"])
+        else:
+            f.normalize_resample()
+            assert not f.last_resample_fired()
+        poses, maps = f.get_state()
+        np.testing.assert_allclose(poses[:, 0], f2g[f"pw{t}"], **TOL)
+        np.testing.assert_allclose(poses[:, 1], f2g[f"px{t}"], **TOL)
+        np.testing.assert_allclose(poses[:, 2], f2g[f"py{t}"], **TOL)
+        np.testing.assert_allclose(poses[:, 3], f2g[f"pyaw{t}"], **TOL)
+        np.testing.assert_allclose(maps.reshape(-1), f2g[f"lm{t}"], **TOL)
+
+
+@pytest.mark.gpu
+def test_gpu_engine_matches_kld_golden(kg):
+    import rust_robotics_amd.localization as loc
+
+    for c in range(int(kg["cases"])):
+        x, y, yaw, w, r = (np.ascontiguousarray(kg[f"{k}{c}"]) for k in ("x", "y", "yaw", "w", "r"))
+        lo, hi = int(kg[f"min{c}"]), int(kg[f"max{c}"])
+        mcl = loc.MonteCarloLocalizer(loc.MonteCarloLocalizationConfig(min_particles=lo, max_particles=hi))
+        mcl.set_particles_array(np.column_stack([x, y, yaw, np.zeros(x.size), w]))
+        assert mcl.resample_adaptive_with_uniforms(r) == int(kg[f"count{c}"])
+        assert np.array_equal(mcl.last_resample_indices(), kg[f"idx{c}"])

@@ -15,16 +15,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SEED = 77
 
 
-def scenario(n, L, steps):
+def engines(variant):
+    """(unsharded class, sharded class, params with the gate at n / 1.5) of FastSLAM 1.0 or 2.0"""
+    from rust_robotics_amd.slam import fastslam1 as fs
+    from rust_robotics_amd.slam import fastslam2 as fs2
+
+    if variant == 2:
+        return fs2.FastSlam2, fs2.ShardedFastSlam2, fs2.default_params()
+    return fs.FastSlam1, fs.ShardedFastSlam1, fs.default_params()
+
+
+def scenario(n, L, steps, variant=1):
     """initial state, controls and observations shared by the sharded and unsharded runs"""
     from rust_robotics_amd.slam import fastslam1 as fs
     from tests.test_gpu_fs1_parity import make_state, scene
 
     lms = scene(L, 5)
     poses, maps = make_state(n, L, lms, 6)
-    prm = fs.default_params()
-    prm.nth = n / 1.5
-    prm.initial_weight = 1.0 / n
+    prm = engines(variant)[2]
+    base = prm.base if variant == 2 else prm
+    base.nth = n / 1.5
+    base.initial_weight = 1.0 / n
     xt = np.zeros(3)
     zs = []
     for t in range(steps):
@@ -36,11 +47,9 @@ def scenario(n, L, steps):
     return prm, poses, maps, zs
 
 
-def unsharded(n, L, steps, chunks):
-    from rust_robotics_amd.slam import fastslam1 as fs
-
-    prm, poses, maps, zs = scenario(n, L, steps)
-    f = fs.FastSlam1(n, L, params=prm, seed=SEED, obs_chunks=chunks)
+def unsharded(n, L, steps, chunks, variant=1):
+    prm, poses, maps, zs = scenario(n, L, steps, variant)
+    f = engines(variant)[0](n, L, params=prm, seed=SEED, obs_chunks=chunks)
     f.set_state(poses, maps)
     fired = []
     for z in zs:
@@ -49,8 +58,8 @@ def unsharded(n, L, steps, chunks):
     return f.get_state(), fired
 
 
-def check(shard_states, n_local, L, steps, chunks):
-    (ep, em), fired = unsharded(n_local * len(shard_states), L, steps, chunks)
+def check(shard_states, n_local, L, steps, chunks, variant=1):
+    (ep, em), fired = unsharded(n_local * len(shard_states), L, steps, chunks, variant)
     assert any(fired) and not all(fired), fired  # both branches of the gate were exercised
     for g, (p, m) in enumerate(shard_states):
         sl = slice(g * n_local, (g + 1) * n_local)
@@ -58,12 +67,12 @@ def check(shard_states, n_local, L, steps, chunks):
         assert np.array_equal(m.view(np.uint64), em[sl].view(np.uint64)), f"rank {g}: maps differ"
 
 
-def run_in_process(world, n_local, L=7, steps=8, chunks=2):
+def run_in_process(world, n_local, L=7, steps=8, chunks=2, variant=1):
     from rust_robotics_amd.slam.fastslam1 import ShardedFastSlam1
 
     n = world * n_local
-    prm, poses, maps, zs = scenario(n, L, steps)
-    shards = [ShardedFastSlam1(g, world, n_local, L, params=prm, seed=SEED, obs_chunks=chunks) for g in range(world)]
+    prm, poses, maps, zs = scenario(n, L, steps, variant)
+    shards = [engines(variant)[1](g, world, n_local, L, params=prm, seed=SEED, obs_chunks=chunks) for g in range(world)]
     for g, s in enumerate(shards):
         s.set_state(poses[g * n_local:(g + 1) * n_local], maps[g * n_local:(g + 1) * n_local])
     ShardedFastSlam1.link_local(shards)
@@ -77,15 +86,16 @@ def run_in_process(world, n_local, L=7, steps=8, chunks=2):
     for g, s in enumerate(shards):
         assert not s.timed_out(), f"rank {g}: a peer wait timed out"
         states.append(s.get_state())
-    check(states, n_local, L, steps, chunks)
+    check(states, n_local, L, steps, chunks, variant)
     print("FS1_P2P_LOCAL_OK")
 
 
-@pytest.mark.parametrize("world,n_local", [(1, 3000), (2, 2500), (3, 1300)])
-def test_in_process_shards_equal_unsharded(world, n_local):
-    """fresh interpreter with enough hardware queues: see tests/test_gpu_p2p.py"""
+@pytest.mark.parametrize("world,n_local,variant", [(1, 3000, 1), (2, 2500, 1), (3, 1300, 1), (2, 2500, 2), (3, 1300, 2)])
+def test_in_process_shards_equal_unsharded(world, n_local, variant):
+    """fresh interpreter with enough hardware queues: see tests/test_gpu_p2p.py; variant 2 = FastSLAM 2.0
+    (the proposal kernel reads the first observation's landmark through the lazy resample indices)"""
     code = (f"import sys; sys.path.insert(0, {ROOT!r}); from tests.test_gpu_fs1_sharded import run_in_process; "
-            f"run_in_process({world}, {n_local})")
+            f"run_in_process({world}, {n_local}, variant={variant})")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="8"))
     assert r.returncode == 0 and "FS1_P2P_LOCAL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
