@@ -765,6 +765,7 @@ struct rr_pf {
   std::vector<double> landmarks;
   // profiling
   bool profiling = false;
+  bool profile_dispatch_only = false;
   struct Ev { int id; hipEvent_t a, b; };
   std::vector<Ev> events;
   std::vector<hipEvent_t> event_pool;
@@ -782,7 +783,7 @@ struct Timed {
   int id;
   hipEvent_t a = nullptr, b = nullptr;
   Timed(rr_pf* h_, int id_) : h(h_), id(id_) {
-    if (!h->profiling) return;
+    if (!h->profiling || h->profile_dispatch_only) return;
     auto take = [&]() {
       hipEvent_t e;
       if (!h->event_pool.empty()) {
@@ -798,7 +799,7 @@ struct Timed {
     (void)hipEventRecord(a, h->stream);
   }
   ~Timed() {
-    if (!h->profiling) return;
+    if (!h->profiling || h->profile_dispatch_only) return;
     (void)hipEventRecord(b, h->stream);
     h->events.push_back({id, a, b});
   }
@@ -1145,6 +1146,17 @@ rr_status compute_moments(rr_pf* h, double est[4], double cov[16]) {
       for (int c = 0; c < 4; ++c) cov[4 * r + c] = m[idx[r][c]] / W - d[r] * d[c];
   }
   return RR_OK;
+}
+
+hipEvent_t take_event(rr_pf* h) {
+  hipEvent_t e;
+  if (!h->event_pool.empty()) {
+    e = h->event_pool.back();
+    h->event_pool.pop_back();
+  } else {
+    (void)hipEventCreate(&e);
+  }
+  return e;
 }
 
 void drain_events(rr_pf* h) {
@@ -1566,12 +1578,25 @@ rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs,
       else
         hipLaunchKernelGGL((k_step_lazy<false, true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
                            (const double*)h->obs_dev, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr);
-    } else if (kernarg) {
-      hipLaunchKernelGGL((k_step_lazy<true, false>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
-                         (const double*)nullptr, h->markers, h->carry, h->idx);
     } else {
-      hipLaunchKernelGGL((k_step_lazy<false, false>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
-                         (const double*)h->obs_dev, h->markers, h->carry, h->idx);
+      hipEvent_t ea = nullptr, eb = nullptr;
+      if (h->profiling && h->profile_dispatch_only) {  // timestamps of this dispatch itself: nothing extra in the stream
+        ea = take_event(h);
+        eb = take_event(h);
+        h->events.push_back({RR_K_PROPAGATE_WEIGHT, ea, eb});
+      }
+      if (ea && kernarg)
+        hipExtLaunchKernelGGL((k_step_lazy<true, false>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl,
+                              p, arg, (const double*)nullptr, h->markers, h->carry, h->idx);
+      else if (ea)
+        hipExtLaunchKernelGGL((k_step_lazy<false, false>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w,
+                              h->ctl, p, arg, (const double*)h->obs_dev, h->markers, h->carry, h->idx);
+      else if (kernarg)
+        hipLaunchKernelGGL((k_step_lazy<true, false>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
+                           (const double*)nullptr, h->markers, h->carry, h->idx);
+      else
+        hipLaunchKernelGGL((k_step_lazy<false, false>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
+                           (const double*)h->obs_dev, h->markers, h->carry, h->idx);
     }
   }
   RR_HIP_TRY(hipGetLastError());
@@ -1958,7 +1983,19 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   const unsigned grid = (unsigned)std::min<uint64_t>(n_rtiles, (uint64_t)256 * h->k1_blocks_per_cu);
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
-    if (kernarg)
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (h->profiling && h->profile_dispatch_only) {  // timestamps of this dispatch itself
+      ea = take_event(h);
+      eb = take_event(h);
+      h->events.push_back({RR_K_PROPAGATE_WEIGHT, ea, eb});
+    }
+    if (ea && kernarg)
+      hipExtLaunchKernelGGL((k_step_lazy<true, true>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl, p,
+                            arg, (const double*)nullptr, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr);
+    else if (ea)
+      hipExtLaunchKernelGGL((k_step_lazy<false, true>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl, p,
+                            arg, (const double*)h->obs_dev, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr);
+    else if (kernarg)
       hipLaunchKernelGGL((k_step_lazy<true, true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
                          (const double*)nullptr, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr);
     else
@@ -2321,6 +2358,7 @@ rr_status rr_pf_profile_enable(rr_pf* h, int32_t enable) {
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
   drain_events(h);
   h->profiling = enable != 0;
+  h->profile_dispatch_only = enable == 2;  // 2 = only the propagate+weight kernel, timed by its own dispatch packet
   return RR_OK;
 }
 

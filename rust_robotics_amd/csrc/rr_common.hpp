@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <cstdio>
@@ -35,6 +36,10 @@ struct Profiler {
     hipEvent_t a, b;
   };
   bool on = false;
+  // dominant-only mode: only the engine's dominant kernel is timed, through the start/stop events
+  // of its own dispatch packet (hipExtLaunchKernelGGL) -- no extra packets in the stream, so the
+  // kernel runs exactly as in an un-instrumented loop.  ScopedTimer is inert in this mode.
+  bool dispatch_only = false;
   std::vector<Ev> events;
   std::vector<hipEvent_t> pool;
   std::vector<uint64_t> launches;
@@ -85,13 +90,13 @@ struct ScopedTimer {
   int id;
   hipEvent_t a = nullptr, b = nullptr;
   ScopedTimer(Profiler& p_, hipStream_t s, int id_) : p(p_), stream(s), id(id_) {
-    if (!p.on) return;
+    if (!p.on || p.dispatch_only) return;
     a = p.take();
     b = p.take();
     (void)hipEventRecord(a, stream);
   }
   ~ScopedTimer() {
-    if (!p.on) return;
+    if (!p.on || p.dispatch_only) return;
     (void)hipEventRecord(b, stream);
     p.events.push_back({id, a, b});
   }

@@ -331,8 +331,10 @@ class ParticleFilterLocalizer:
         return a.value, b.value
 
     # ---- measurement hooks
-    def profile_enable(self, on: bool) -> None:
-        _check(self._L.rr_pf_profile_enable(self._h, 1 if on else 0))
+    def profile_enable(self, on) -> None:
+        """False/0 off; True/1 HIP events around every launch (adds ~3 us per launch); 2 only the
+        propagate+weight kernel, timed by the timestamps of its own dispatch (nothing extra in the stream)"""
+        _check(self._L.rr_pf_profile_enable(self._h, int(on)))
 
     def profile_reset(self) -> None:
         _check(self._L.rr_pf_profile_reset(self._h))

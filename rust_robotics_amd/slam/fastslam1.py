@@ -194,8 +194,10 @@ class FastSlam1:
         return a.value, b.value, c.value
 
     # ---- measurement hooks
-    def profile_enable(self, on: bool) -> None:
-        _check(self._L.rr_fs1_profile_enable(self._h, 1 if on else 0))
+    def profile_enable(self, on) -> None:
+        """False/0 off; True/1 HIP events around every launch; 2 only k_fs1_observe, timed by the
+        timestamps of its own dispatch (nothing extra in the stream)"""
+        _check(self._L.rr_fs1_profile_enable(self._h, int(on)))
 
     def profile_reset(self) -> None:
         _check(self._L.rr_fs1_profile_reset(self._h))
