@@ -353,6 +353,50 @@ def run_fastslam_sharded(args, rank, world, local_rank):
     })
 
 
+def replicas_fallback(rank, world, local_rank, n, L, K, W, obs_list, scheme, lik, reason):
+    import torch
+    import torch.distributed as dist
+
+    import rust_robotics_amd.localization as loc
+
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
+    pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1 + rank, device=local_rank,
+                                                    resample_scheme=scheme, likelihood_mode=lik)
+    u = [1.0, 0.1]
+
+    def fence():
+        pf.synchronize()
+        torch.cuda.synchronize()
+        dist.barrier()
+        pf.synchronize()
+        torch.cuda.synchronize()
+
+    for t in range(W):
+        pf.step_async(u, obs_list[t])
+    fence()
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        pf.step_async(u, obs_list[t])
+    fence()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    pf.profile_enable(1)
+    pf.profile_reset()
+    t1 = time.perf_counter()
+    for t in range(W, W + K):
+        pf.step_async(u, obs_list[t])
+    pf.synchronize()
+    dt_instr = time.perf_counter() - t1
+    prof = pf.profile_read()
+    pf.profile_enable(0)
+    est = pf.estimate()
+    dist.barrier()
+    dist.destroy_process_group()
+    return dict(seconds=float(tmax.item()), seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est],
+                dominant=None, transport="NONE -- independent replicas, no exchange",
+                transport_note="SHARDING FAILED: " + reason, p2p_timed_out=False, migrated_particles_last_step=0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -367,8 +411,9 @@ def main():
     ap.add_argument("--no-breakdown", action="store_true",
                     help="skip the instrumented per-kernel re-run (use under rocprofv3 so that its averages cover the timed launches only)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded path even at --gpus 1")
-    ap.add_argument("--transport", choices=["auto", "p2p", "rccl"], default="auto",
-                    help="sharded exchange: peer-to-peer over xGMI (validated at run time) or RCCL collectives")
+    ap.add_argument("--transport", choices=["auto", "p2p", "rccl", "torch", "p2p-only"], default="auto",
+                    help="sharded exchange: auto = peer-to-peer over xGMI if it validates at run time, else native RCCL, else "
+                         "torch.distributed NCCL; p2p / rccl / torch restrict the ladder; p2p-only validates against the unsharded filter")
     args = ap.parse_args()
 
     if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
@@ -401,7 +446,13 @@ def main():
     if world > 1 or args.force_sharded:
         from rust_robotics_amd import sharded
 
-        res = sharded.bench_sharded(rank, world, local_rank, n, L, K, W, obs_list, scheme, lik, args.transport)
+        try:
+            res = sharded.bench_sharded(rank, world, local_rank, n, L, K, W, obs_list, scheme, lik, args.transport)
+        except RuntimeError as e:
+            # no sharded transport works on this machine.  Last resort so that the run still leaves a line:
+            # every rank steps its own, independent filter (NO exchange, NOT one sharded filter) and the line
+            # says so in config.sharding -- the number is an upper bound for the sharded step, not a measurement of it.
+            res = replicas_fallback(rank, world, local_rank, n, L, K, W, obs_list, scheme, lik, str(e))
     else:
         import rust_robotics_amd.localization as loc
 

@@ -440,15 +440,58 @@ def gloo_exchange(dist):
     return exchange
 
 
+class TorchShard:
+    """Third transport: the host-orchestrated ``ShardedLocalizer`` over ``HipShard`` with
+    torch.distributed's NCCL (= RCCL) backend doing the collectives.  Slowest of the three (every
+    phase returns to Python); bench.py only uses it if the native RCCL transport cannot be set up."""
+
+    def __init__(self, rank, world, device, n_local, dist, **kw):
+        self.hs = HipShard(rank, world, device, n_local, **kw)
+        self.group = dist.new_group(backend="nccl")  # collective: every rank constructs its TorchShard together
+        self.loc = ShardedLocalizer(self.hs, dist, group=self.group)
+
+    def step(self, u, obs) -> None:
+        self.loc.step(u, obs)
+
+    def particles(self) -> np.ndarray:
+        return self.hs.particles()
+
+    def synchronize(self) -> None:
+        self.hs.synchronize()
+        self.hs.torch.cuda.synchronize()
+
+    def profile(self, on) -> None:
+        self.hs.profile(on)
+
+    def profile_read(self) -> dict:
+        return self.hs.profile_read()
+
+    def estimate(self):
+        return self.loc.estimate()
+
+    def migrated(self) -> int:
+        M = self.loc.last_matrix
+        return int(M.sum() - np.trace(M)) if M is not None else 0
+
+    def close(self) -> None:
+        self.hs.close()
+
+
 def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, lik, transport="auto"):
     """bench.py's N > 1 leg: weak scaling, n_local particles per GPU, barrier + synchronize on
     both sides of the K timed steps, MAX over ranks.  torch.distributed (gloo) only bootstraps
     (communicator id, IPC handles) and provides the timing barrier; the step runs inside the library.
 
-    transport "auto": the peer-to-peer transport is used iff it (a) connects on every rank and
-    (b) reproduces, bit for bit, the particle set the RCCL transport produces over a dozen steps
-    from the same seed on THIS machine, without any wait timing out -- a run-time proof of the
-    cross-GPU memory hand-off before anything is timed.  Otherwise the RCCL transport is timed."""
+    Transport ladder (every decision is agreed on by all ranks):
+      reference transport = native RCCL (``rr_pf_shard_step``), else torch.distributed/NCCL
+        (``TorchShard``), else none;
+      peer-to-peer (``rr_pf_shard_step_p2p``) is timed iff it connects on every rank AND reproduces,
+        bit for bit and without a timed-out wait, a dozen steps of the reference transport -- or, when
+        there is no reference transport, of an UNSHARDED filter of all n_local * world particles run on
+        every rank -- on THIS machine: a run-time proof of the cross-GPU hand-off before anything is timed;
+      otherwise the reference transport is timed; if a peer wait gives up inside the timed region the
+        region is repeated on the reference transport.
+    With no working transport at all the function raises (bench.py reports that instead of a number)."""
     import torch
     import torch.distributed as dist
 
@@ -460,67 +503,111 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     torch.cuda.set_device(local_rank)
     u = [1.0, 0.1]
     kw = dict(seed=1, likelihood_mode=lik, initial_state=[0.0, 0.0, 0.0, 1.0])
+    notes = []
 
     def agree(ok: bool) -> bool:
         t = torch.tensor([1 if ok else 0], dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
-    rccl = NativeShard(rank, world, local_rank, n_local, gloo_exchange(dist), **kw)
-    p2p, use_p2p, why = None, False, "disabled"
-    if transport in ("auto", "p2p"):
+    def attempt(name, make):
+        """construct a transport on every rank; keep it only if every rank succeeded"""
+        obj, err = None, None
         try:
-            p2p = P2PShard(rank, world, local_rank, n_local, **kw)
-            p2p.connect_ipc(gloo_allgather(dist))
-            ok = True
-        except Exception as e:  # noqa: BLE001 -- any failure means "use RCCL"
-            ok, why = False, f"connect failed: {e}"
-        if agree(ok):
+            obj = make()
+        except Exception as e:  # noqa: BLE001 -- any failure means "next rung of the ladder"
+            err = f"{type(e).__name__}: {e}"
+        if agree(obj is not None):
+            return obj
+        notes.append(f"{name} unavailable" + (f" ({err})" if err else " (failed on another rank)"))
+        if obj is not None:
+            obj.close()
+        return None
+
+    ref, ref_kind = None, None
+    if transport in ("auto", "p2p", "rccl"):  # "p2p-only" skips the reference transports (validation against the unsharded filter)
+        ref = attempt("native RCCL transport", lambda: NativeShard(rank, world, local_rank, n_local, gloo_exchange(dist), **kw))
+        ref_kind = "rccl" if ref else None
+    if ref is None and transport in ("auto", "p2p", "rccl", "torch"):
+        ref = attempt("torch.distributed NCCL transport", lambda: TorchShard(rank, world, local_rank, n_local, dist, **kw))
+        ref_kind = "torch.distributed nccl (host-orchestrated phases)" if ref else None
+
+    p2p, use_p2p = None, False
+    if transport in ("auto", "p2p", "p2p-only"):
+        def make_p2p():
+            s = P2PShard(rank, world, local_rank, n_local, **kw)
+            s.connect_ipc(gloo_allgather(dist))
+            return s
+
+        p2p = attempt("peer-to-peer transport", make_p2p)
+        if p2p is not None:
             V = min(12, len(obs_list))
+            whole = None
+            if ref is None:  # no reference transport: compare with the unsharded filter of all the particles
+                import rust_robotics_amd.localization as loc
+
+                cfg = loc.MonteCarloLocalizationConfig(min_particles=n_local * world, max_particles=n_local * world)
+                whole = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=local_rank,
+                                                                   resample_scheme=_ffi.RR_RESAMPLE_SYSTEMATIC, likelihood_mode=lik)
             alive = True
             for t in range(V):
                 p2p.step(u, obs_list[t])
-                rccl.step(u, obs_list[t])
+                (ref.step if ref is not None else whole.step_async)(u, obs_list[t])
                 if t == 0:  # a dead transport shows on the first exchange: stop before it costs more
                     alive = agree(not p2p.timed_out())
                     if not alive:
                         break
-            same = alive and (not p2p.timed_out()) and np.array_equal(p2p.particles().view(np.uint64),
-                                                                      rccl.particles().view(np.uint64))
+            if alive and not p2p.timed_out():
+                exp = ref.particles() if ref is not None else whole.get_particles_array()[rank * n_local:(rank + 1) * n_local]
+                same = np.array_equal(p2p.particles().view(np.uint64), np.ascontiguousarray(exp).view(np.uint64))
+            else:
+                same = False
             use_p2p = agree(same)
-            why = f"validated bit-identical to the RCCL transport over {V} steps" if use_p2p else "validation against the RCCL transport failed"
-        elif ok:
-            why = "connect failed on another rank"
-    shard = p2p if use_p2p else rccl
+            against = f"the {ref_kind} transport" if ref is not None else "the unsharded filter of all particles"
+            notes.append(f"peer-to-peer transport validated bit-identical to {against} over {V} steps" if use_p2p else
+                         f"peer-to-peer transport FAILED validation against {against}")
+            del whole
+    if not use_p2p and ref is None:
+        raise RuntimeError("no working sharded transport on this machine: " + "; ".join(notes))
 
-    def fence():
+    def fence(shard):
         shard.synchronize()
         torch.cuda.synchronize()
         dist.barrier()
         shard.synchronize()
         torch.cuda.synchronize()
 
-    for t in range(W):
-        shard.step(u, obs_list[t])
-    fence()
-    # the sharded step is launch-rate sensitive (7 launches in ~85 us): nothing is instrumented inside the
-    # timed region; the kernel times of the instrumented re-run below feed `roofline`
-    t0 = time.perf_counter()
-    for t in range(W, W + K):
-        shard.step(u, obs_list[t])
-    fence()
-    dt = time.perf_counter() - t0
-    dominant = None
-    tmax = torch.tensor([dt], dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    timed_out = use_p2p and p2p.timed_out()
+    def timed_region(shard):
+        for t in range(W):
+            shard.step(u, obs_list[t])
+        fence(shard)
+        # the sharded step is launch-rate sensitive (7 launches in ~85 us): nothing is instrumented inside the
+        # timed region; the kernel times of the instrumented re-run below feed `roofline`
+        t0 = time.perf_counter()
+        for t in range(W, W + K):
+            shard.step(u, obs_list[t])
+        fence(shard)
+        dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        return float(tmax.item())
+
+    shard = p2p if use_p2p else ref
+    seconds = timed_region(shard)
+    timed_out = False
+    if use_p2p and not agree(not p2p.timed_out()):
+        timed_out = True
+        notes.append("a peer wait gave up inside the timed region")
+        if ref is not None:  # repeat the region on the reference transport
+            use_p2p, shard = False, ref
+            seconds = timed_region(shard)
+            notes.append(f"timed region repeated on the {ref_kind} transport")
     if use_p2p:
-        e, c = p2p.local_moments()
-        est = e  # local estimate of this rank's block (all blocks are samples of the same posterior)
+        est, _ = p2p.local_moments()  # local estimate of this rank's block (all blocks are samples of the same posterior)
         moved = -1
     else:
-        est, _ = rccl.estimate()
-        moved = rccl.migrated()
+        est, _ = shard.estimate()
+        moved = shard.migrated()
     shard.profile(True)
     t1 = time.perf_counter()
     for t in range(W, W + K):
@@ -532,9 +619,9 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     dist.barrier()
     if p2p is not None:
         p2p.close()
-    rccl.close()
+    if ref is not None:
+        ref.close()
     dist.destroy_process_group()
-    return dict(seconds=float(tmax.item()), seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est],
-                dominant=dominant if dominant and dominant[0] else None,
-                migrated_particles_last_step=moved, transport="p2p (xGMI, device-initiated)" if use_p2p else "rccl",
-                transport_note=why, p2p_timed_out=bool(timed_out))
+    return dict(seconds=seconds, seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est], dominant=None,
+                migrated_particles_last_step=moved, transport="p2p (xGMI, device-initiated)" if use_p2p else ref_kind,
+                transport_note="; ".join(notes), p2p_timed_out=bool(timed_out))
