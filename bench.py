@@ -371,8 +371,8 @@ def replicas_fallback(rank, world, local_rank, n, L, K, W, obs_list, scheme, lik
         pf.synchronize()
         torch.cuda.synchronize()
 
-    for t in range(W):
-        pf.step_async(u, obs_list[t])
+    for t in range(W + 100):  # + host-runtime warm-up of a process that has torch's HIP context loaded
+        pf.step_async(u, obs_list[t % W if W else 0])
     fence()
     t0 = time.perf_counter()
     for t in range(W, W + K):
@@ -528,7 +528,8 @@ def main():
             "landmarks": L,
             "resample": args.scheme,
             "sharding": "none" if world == 1 and not args.force_sharded else
-                        f"contiguous particle blocks over {world} GPUs; transport {res.get('transport')} ({res.get('transport_note')})",
+                        (f"{res.get('transport')} ({res.get('transport_note')})" if str(res.get("transport", "")).startswith("NONE") else
+                         f"contiguous particle blocks over {world} GPUs; transport {res.get('transport')} ({res.get('transport_note')})"),
         },
         "roofline": {
             "bound": "hbm",

@@ -524,6 +524,8 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
             obj.close()
         return None
 
+    if os.environ.get("RR_BENCH_SIMULATE_NO_TRANSPORT"):  # test hook for bench.py's last-resort line
+        raise RuntimeError("no working sharded transport on this machine: simulated")
     ref, ref_kind = None, None
     if transport in ("auto", "p2p", "rccl"):  # "p2p-only" skips the reference transports (validation against the unsharded filter)
         ref = attempt("native RCCL transport", lambda: NativeShard(rank, world, local_rank, n_local, gloo_exchange(dist), **kw))
