@@ -504,6 +504,11 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     u = [1.0, 0.1]
     kw = dict(seed=1, likelihood_mode=lik, initial_state=[0.0, 0.0, 0.0, 1.0])
     notes = []
+    # observation schedule (time only moves forward for every filter): [0, V) validation, [V, T0) warm-up (W steps plus
+    # whatever surplus bench.py handed over), [T0, T0 + K) timed region, [T0 + K, T0 + 2K) instrumented continuation
+    V = min(12, len(obs_list))
+    T0 = max(len(obs_list) - 2 * K, V + W)
+    assert T0 + 2 * K <= len(obs_list), "bench.py must hand over at least 12 + W + 2K steps of observations"
 
     def agree(ok: bool) -> bool:
         t = torch.tensor([1 if ok else 0], dtype=torch.int32)
@@ -543,7 +548,6 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
 
         p2p = attempt("peer-to-peer transport", make_p2p)
         if p2p is not None:
-            V = min(12, len(obs_list))
             whole = None
             if ref is None:  # no reference transport: compare with the unsharded filter of all the particles
                 import rust_robotics_amd.localization as loc
@@ -572,6 +576,7 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     if not use_p2p and ref is None:
         raise RuntimeError("no working sharded transport on this machine: " + "; ".join(notes))
 
+
     def fence(shard):
         shard.synchronize()
         torch.cuda.synchronize()
@@ -582,13 +587,13 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     def timed_region(shard):
         # W warm-up steps plus 64 more: in a process that has torch's HIP context loaded the host enqueues the
         # first ~50 steps of a large filter an order of magnitude slower than later ones
-        for t in range(W + 64):
-            shard.step(u, obs_list[t % max(W, 1)])
+        for t in range(V, T0):
+            shard.step(u, obs_list[t])
         fence(shard)
         # the sharded step is launch-rate sensitive (7 launches in ~85 us): nothing is instrumented inside the
         # timed region; the kernel times of the instrumented re-run below feed `roofline`
         t0 = time.perf_counter()
-        for t in range(W, W + K):
+        for t in range(T0, T0 + K):
             shard.step(u, obs_list[t])
         fence(shard)
         dt = time.perf_counter() - t0
@@ -597,6 +602,9 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
         return float(tmax.item())
 
     shard = p2p if use_p2p else ref
+    if p2p is None:  # no validation ran: the reference transport has not seen the first V steps yet
+        for t in range(V):
+            ref.step(u, obs_list[t])
     seconds = timed_region(shard)
     timed_out = False
     if use_p2p and not agree(not p2p.timed_out()):
@@ -614,7 +622,7 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
         moved = shard.migrated()
     shard.profile(True)
     t1 = time.perf_counter()
-    for t in range(W, W + K):
+    for t in range(T0 + K, T0 + 2 * K):
         shard.step(u, obs_list[t])
     shard.synchronize()
     dt_instr = time.perf_counter() - t1
