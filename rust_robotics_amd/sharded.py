@@ -533,7 +533,12 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
         raise RuntimeError("no working sharded transport on this machine: simulated")
     ref, ref_kind = None, None
     if transport in ("auto", "p2p", "rccl"):  # "p2p-only" skips the reference transports (validation against the unsharded filter)
-        ref = attempt("native RCCL transport", lambda: NativeShard(rank, world, local_rank, n_local, gloo_exchange(dist), **kw))
+        # librccl must load on EVERY rank before anybody enters the collective communicator set-up
+        probe = (C.c_uint8 * 128)()
+        if agree(_ffi.lib().rr_comm_unique_id(probe) == _ffi.RR_OK):
+            ref = attempt("native RCCL transport", lambda: NativeShard(rank, world, local_rank, n_local, gloo_exchange(dist), **kw))
+        else:
+            notes.append("librccl could not be loaded on every rank")
         ref_kind = "rccl" if ref else None
     if ref is None and transport in ("auto", "p2p", "rccl", "torch"):
         ref = attempt("torch.distributed NCCL transport", lambda: TorchShard(rank, world, local_rank, n_local, dist, **kw))
