@@ -29,15 +29,15 @@ def measured_traffic(kernel_prefix, workload):
     """HBM bytes per launch of `kernel_prefix` from the committed PMC passes (separate
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, read side doubled as MI355X_MICROARCH.md
     prescribes for gfx950): profiles/r01c_pmc_hbm_traffic.csv.  None if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01c_pmc_hbm_traffic.csv")
-    try:
-        import csv
+    import csv
 
-        for r in csv.DictReader(open(path)):
-            if r["workload"] == workload and r["kernel"].startswith(kernel_prefix):
-                return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6
-    except Exception:
-        pass
+    for name, wl in (("r01f_pmc_hbm_traffic_fastslam_timed_region.csv", workload + "_timed_region"), ("r01c_pmc_hbm_traffic.csv", workload)):
+        try:
+            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", name))):
+                if r["workload"] == wl and r["kernel"].startswith(kernel_prefix):
+                    return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6
+        except Exception:
+            pass
     return None
 
 
@@ -212,7 +212,8 @@ def run_fastslam(args):
         "roofline": {"bound": "hbm", "kernel": "k_fs1_observe", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK,
                      "traffic": measured_traffic("k_fs1_observe", "fs1") if (n, L) == (100_000, 200) and not v2 else None,
-                     "traffic_source": "profiles/r01c_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
+                     "traffic_source": "profiles/r01f_pmc_hbm_traffic_fastslam_timed_region.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                       "passes over `bench.py --workload fastslam --no-breakdown`, bytes per launch, read side x2)",
                      "avg_kernel_ms": avg_s * 1e3, "timed_launches": k_n,
                      "timing": "dispatch timestamps of the K launches inside the timed region",
                      "algorithmic_bytes_per_launch": per_launch},
