@@ -1,0 +1,328 @@
+//! Safe wrappers over `rust_robotics_amd-sys` with the method names, argument meaning and error
+//! behaviour of the reference types they stand in for:
+//!
+//! * `ParticleFilterLocalizer`  -- rust_robotics_localization/src/particle_filter.rs:121-573
+//! * `MonteCarloLocalizer`      -- rust_robotics_localization/src/monte_carlo_localization.rs:136-462
+//!   (fixed particle count when `min_particles == max_particles`, KLD-adaptive otherwise)
+//! * `fastslam1::*`, `fastslam2::*` -- rust_robotics_slam/src/fastslam{1,2}.rs free functions
+//!
+//! NOT COMPILED in the image this repository is built in (it has no Rust toolchain): the file is the
+//! binding a maintainer of the reference would add, written against the generated `-sys` crate.
+//! The particle set lives on the GPU; `estimate()` / `get_covariance()` refresh a host-side cache
+//! (one 300-byte D2H) because the reference's accessors take `&self`.
+
+use nalgebra::{DMatrix, Matrix4, Vector2, Vector4};
+use rust_robotics_amd_sys as sys;
+use rust_robotics_core::{RoboticsError, RoboticsResult, StateEstimator};
+use std::ffi::CStr;
+
+pub type PFState = Vector4<f64>;
+pub type PFControl = Vector2<f64>;
+pub type PFMeasurement = Vec<(f64, f64, f64)>; // (distance, landmark_x, landmark_y)
+
+fn check(status: sys::rr_status) -> RoboticsResult<()> {
+    if status == sys::RR_OK {
+        return Ok(());
+    }
+    let msg = unsafe { CStr::from_ptr(sys::rr_last_error()) }.to_string_lossy().into_owned();
+    if status == sys::RR_INVALID_PARAMETER {
+        Err(RoboticsError::InvalidParameter(msg))
+    } else {
+        Err(RoboticsError::NumericalError(msg)) // device / runtime failure
+    }
+}
+
+/// ParticleFilterConfig, particle_filter.rs:51-78 (field for field)
+#[derive(Debug, Clone)]
+pub struct ParticleFilterConfig {
+    pub n_particles: usize,
+    pub resample_threshold: f64,
+    pub range_noise: f64,
+    pub velocity_noise: f64,
+    pub yaw_rate_noise: f64,
+    pub dt: f64,
+}
+
+impl Default for ParticleFilterConfig {
+    fn default() -> Self {
+        let mut c = sys::rr_pf_config { n_particles: 0, resample_threshold: 0.0, range_noise: 0.0, velocity_noise: 0.0, yaw_rate_noise: 0.0, dt: 0.0 };
+        unsafe { sys::rr_pf_config_default(&mut c) };
+        Self { n_particles: c.n_particles as usize, resample_threshold: c.resample_threshold, range_noise: c.range_noise,
+               velocity_noise: c.velocity_noise, yaw_rate_noise: c.yaw_rate_noise, dt: c.dt }
+    }
+}
+
+impl ParticleFilterConfig {
+    fn raw(&self) -> sys::rr_pf_config {
+        sys::rr_pf_config { n_particles: self.n_particles as u64, resample_threshold: self.resample_threshold, range_noise: self.range_noise,
+                            velocity_noise: self.velocity_noise, yaw_rate_noise: self.yaw_rate_noise, dt: self.dt }
+    }
+    /// particle_filter.rs:81-117 (same messages)
+    pub fn validate(&self) -> RoboticsResult<()> {
+        check(unsafe { sys::rr_pf_config_validate(&self.raw()) })
+    }
+}
+
+/// The handle plus the host-side cache the `&self` accessors of the reference need.
+pub struct ParticleFilterLocalizer {
+    h: *mut sys::rr_pf,
+    state_estimate: PFState,
+    covariance: Matrix4<f64>,
+    covariance_dyn: DMatrix<f64>,
+}
+
+unsafe impl Send for ParticleFilterLocalizer {}
+
+impl Drop for ParticleFilterLocalizer {
+    fn drop(&mut self) {
+        unsafe { sys::rr_pf_destroy(self.h) }
+    }
+}
+
+fn flatten(obs: &PFMeasurement) -> Vec<f64> {
+    obs.iter().flat_map(|&(d, x, y)| [d, x, y]).collect()
+}
+
+impl ParticleFilterLocalizer {
+    fn options(mcl: bool, seed: u64, device: i32) -> sys::rr_pf_options {
+        let mut o: sys::rr_pf_options = unsafe { std::mem::zeroed() };
+        unsafe {
+            if mcl { sys::rr_pf_options_mcl(&mut o) } else { sys::rr_pf_options_default(&mut o) }
+        }
+        o.seed = seed;
+        o.device = device;
+        o
+    }
+
+    fn from_handle(h: *mut sys::rr_pf) -> RoboticsResult<Self> {
+        let mut s = Self { h, state_estimate: PFState::zeros(), covariance: Matrix4::zeros(), covariance_dyn: DMatrix::zeros(4, 4) };
+        s.refresh_cache()?;
+        Ok(s)
+    }
+
+    /// try_new, particle_filter.rs:139-156
+    pub fn try_new(config: ParticleFilterConfig) -> RoboticsResult<Self> {
+        let mut h = std::ptr::null_mut();
+        check(unsafe { sys::rr_pf_create(&config.raw(), &Self::options(false, 0, 0), &mut h) })?;
+        Self::from_handle(h)
+    }
+
+    /// new, particle_filter.rs:131-136: panics on an invalid configuration like the reference
+    pub fn new(config: ParticleFilterConfig) -> Self {
+        Self::try_new(config).expect("invalid particle filter configuration")
+    }
+
+    /// try_with_initial_state, particle_filter.rs:170-199
+    pub fn try_with_initial_state(initial_state: PFState, config: ParticleFilterConfig) -> RoboticsResult<Self> {
+        let mut h = std::ptr::null_mut();
+        check(unsafe { sys::rr_pf_create_with_state(&config.raw(), &Self::options(false, 0, 0), initial_state.as_ptr(), &mut h) })?;
+        Self::from_handle(h)
+    }
+
+    /// try_predict_with_control, :255-301
+    pub fn try_predict_with_control(&mut self, control: &PFControl) -> RoboticsResult<()> {
+        check(unsafe { sys::rr_pf_predict(self.h, control.as_ptr()) })?;
+        self.refresh_cache()
+    }
+
+    /// try_update_with_observations, :310-334
+    pub fn try_update_with_observations(&mut self, observations: &PFMeasurement) -> RoboticsResult<()> {
+        let flat = flatten(observations);
+        check(unsafe { sys::rr_pf_update(self.h, flat.as_ptr(), observations.len()) })?;
+        self.refresh_cache()
+    }
+
+    /// resample, :337-345
+    pub fn resample(&mut self) {
+        check(unsafe { sys::rr_pf_resample(self.h) }).expect("particle filter resample failed on the device");
+        self.refresh_cache().expect("particle filter moments failed on the device");
+    }
+
+    /// try_step, :488-497 -- one fused launch sequence on the GPU
+    pub fn try_step(&mut self, control: &PFControl, observations: &PFMeasurement) -> RoboticsResult<PFState> {
+        let flat = flatten(observations);
+        let mut out = [0.0f64; 4];
+        check(unsafe { sys::rr_pf_step(self.h, control.as_ptr(), flat.as_ptr(), observations.len(), out.as_mut_ptr()) })?;
+        self.refresh_cache()?;
+        Ok(self.state_estimate)
+    }
+
+    /// estimate, :348-350
+    pub fn estimate(&self) -> PFState {
+        self.state_estimate
+    }
+
+    /// calc_covariance, :363-365
+    pub fn calc_covariance(&self) -> Matrix4<f64> {
+        self.covariance
+    }
+
+    pub fn particle_count(&self) -> usize {
+        unsafe { sys::rr_pf_particle_count(self.h) as usize }
+    }
+
+    /// set_range_noise, :228-236
+    pub fn set_range_noise(&mut self, range_noise: f64) -> RoboticsResult<()> {
+        check(unsafe { sys::rr_pf_set_range_noise(self.h, range_noise) })
+    }
+
+    fn refresh_cache(&mut self) -> RoboticsResult<()> {
+        let mut e = [0.0f64; 4];
+        let mut c = [0.0f64; 16];
+        check(unsafe { sys::rr_pf_estimate(self.h, e.as_mut_ptr()) })?;
+        check(unsafe { sys::rr_pf_covariance(self.h, c.as_mut_ptr()) })?;
+        self.state_estimate = PFState::from_column_slice(&e);
+        self.covariance = Matrix4::from_row_slice(&c);
+        self.covariance_dyn = DMatrix::from_row_slice(4, 4, &c);
+        Ok(())
+    }
+}
+
+/// StateEstimator, rust_robotics_core/src/traits.rs:31-52 (dt is ignored as in particle_filter.rs:557-559)
+impl StateEstimator for ParticleFilterLocalizer {
+    type State = PFState;
+    type Measurement = PFMeasurement;
+    type Control = PFControl;
+
+    fn predict(&mut self, control: &PFControl, _dt: f64) {
+        self.try_predict_with_control(control).expect("invalid particle filter prediction input")
+    }
+    fn update(&mut self, measurement: &PFMeasurement) {
+        self.try_update_with_observations(measurement).expect("invalid particle filter observations");
+        self.resample();
+    }
+    fn get_state(&self) -> &PFState {
+        &self.state_estimate
+    }
+    fn get_covariance(&self) -> Option<&DMatrix<f64>> {
+        Some(&self.covariance_dyn)
+    }
+}
+
+/// MonteCarloLocalizationConfig, monte_carlo_localization.rs:50-82
+#[derive(Debug, Clone)]
+pub struct MonteCarloLocalizationConfig {
+    pub min_particles: usize,
+    pub max_particles: usize,
+    pub kld_epsilon: f64,
+    pub kld_z: f64,
+    pub range_noise: f64,
+    pub velocity_noise: f64,
+    pub yaw_rate_noise: f64,
+    pub dt: f64,
+}
+
+impl Default for MonteCarloLocalizationConfig {
+    fn default() -> Self {
+        Self { min_particles: 100, max_particles: 5000, kld_epsilon: 0.05, kld_z: 2.326, range_noise: 0.2, velocity_noise: 2.0,
+               yaw_rate_noise: 40.0_f64.to_radians(), dt: 0.1 }
+    }
+}
+
+/// MonteCarloLocalizer: the same engine with multinomial resampling at every step; the particle
+/// count follows the KLD bound when `min_particles < max_particles` (rr_pf_create_adaptive).
+pub struct MonteCarloLocalizer(ParticleFilterLocalizer);
+
+impl MonteCarloLocalizer {
+    fn create(config: &MonteCarloLocalizationConfig, state: Option<&PFState>) -> RoboticsResult<Self> {
+        let cfg = sys::rr_pf_config { n_particles: config.min_particles as u64, resample_threshold: 1.0, range_noise: config.range_noise,
+                                      velocity_noise: config.velocity_noise, yaw_rate_noise: config.yaw_rate_noise, dt: config.dt };
+        let opt = ParticleFilterLocalizer::options(true, 0, 0);
+        let sp = state.map_or(std::ptr::null(), |s| s.as_ptr());
+        let mut h = std::ptr::null_mut();
+        if config.min_particles == config.max_particles {
+            check(unsafe { if sp.is_null() { sys::rr_pf_create(&cfg, &opt, &mut h) } else { sys::rr_pf_create_with_state(&cfg, &opt, sp, &mut h) } })?;
+        } else {
+            let kld = sys::rr_mcl_adaptive { min_particles: config.min_particles as u64, max_particles: config.max_particles as u64,
+                                             kld_epsilon: config.kld_epsilon, kld_z: config.kld_z };
+            check(unsafe { sys::rr_pf_create_adaptive(&cfg, &opt, &kld, sp, &mut h) })?;
+        }
+        Ok(Self(ParticleFilterLocalizer::from_handle(h)?))
+    }
+    /// try_new, monte_carlo_localization.rs:142-156
+    pub fn try_new(config: MonteCarloLocalizationConfig) -> RoboticsResult<Self> {
+        Self::create(&config, None)
+    }
+    /// try_with_initial_state, :170-199
+    pub fn try_with_initial_state(initial_state: PFState, config: MonteCarloLocalizationConfig) -> RoboticsResult<Self> {
+        Self::create(&config, Some(&initial_state))
+    }
+    /// try_step, :291-300
+    pub fn try_step(&mut self, control: &PFControl, observations: &PFMeasurement) -> RoboticsResult<PFState> {
+        self.0.try_step(control, observations)
+    }
+    pub fn estimate(&self) -> PFState {
+        self.0.estimate()
+    }
+    /// particle_count, :318-320
+    pub fn particle_count(&self) -> usize {
+        self.0.particle_count()
+    }
+}
+
+/// rust_robotics_slam::fastslam1 / fastslam2: the reference's free functions over a caller-owned
+/// `Vec<Particle>` on top of the upload -> update -> download shim `rr_fs1_update_host`.
+pub mod fastslam {
+    use super::{check, sys};
+    use nalgebra::{Matrix2, Vector2};
+    use rust_robotics_core::RoboticsResult;
+
+    #[derive(Clone)]
+    pub struct Landmark { pub x: f64, pub y: f64, pub cov: Matrix2<f64> } // fastslam1.rs:26-31
+    #[derive(Clone)]
+    pub struct Particle { pub weight: f64, pub x: f64, pub y: f64, pub yaw: f64, pub landmarks: Vec<Landmark> } // :44-51
+
+    /// create_particles, fastslam1.rs:302-306 / fastslam2.rs:425-429
+    pub fn create_particles(n_particles: usize, n_landmarks: usize) -> Vec<Particle> {
+        let lm = Landmark { x: 0.0, y: 0.0, cov: Matrix2::identity() * 1000.0 };
+        vec![Particle { weight: 1.0 / 100.0, x: 0.0, y: 0.0, yaw: 0.0, landmarks: vec![lm; n_landmarks] }; n_particles]
+    }
+
+    /// One engine handle per (particle count, landmark count, algorithm); keep it next to the particle vector.
+    pub struct Engine { h: *mut sys::rr_fs1, n: usize, l: usize }
+    impl Drop for Engine { fn drop(&mut self) { unsafe { sys::rr_fs1_destroy(self.h) } } }
+
+    impl Engine {
+        pub fn fastslam1(n: usize, l: usize, seed: u64) -> RoboticsResult<Self> {
+            let mut o: sys::rr_fs1_options = unsafe { std::mem::zeroed() };
+            unsafe { sys::rr_fs1_options_default(&mut o) };
+            o.seed = seed;
+            let mut h = std::ptr::null_mut();
+            check(unsafe { sys::rr_fs1_create(n as u64, l as u64, std::ptr::null(), &o, &mut h) })?;
+            Ok(Self { h, n, l })
+        }
+        pub fn fastslam2(n: usize, l: usize, seed: u64) -> RoboticsResult<Self> {
+            let mut o: sys::rr_fs1_options = unsafe { std::mem::zeroed() };
+            unsafe { sys::rr_fs1_options_default(&mut o) };
+            o.seed = seed;
+            let mut h = std::ptr::null_mut();
+            check(unsafe { sys::rr_fs2_create(n as u64, l as u64, std::ptr::null(), &o, &mut h) })?;
+            Ok(Self { h, n, l })
+        }
+        /// fastslam_update (fastslam1.rs:237-266) / fastslam2_update (fastslam2.rs:376-383), by the handle's algorithm
+        pub fn update(&mut self, particles: &mut Vec<Particle>, u: Vector2<f64>, z: &[(f64, f64, usize)]) -> RoboticsResult<()> {
+            assert_eq!(particles.len(), self.n);
+            let mut poses = Vec::with_capacity(4 * self.n);
+            let mut maps = Vec::with_capacity(6 * self.n * self.l);
+            for p in particles.iter() {
+                poses.extend_from_slice(&[p.weight, p.x, p.y, p.yaw]);
+                for lm in &p.landmarks { maps.extend_from_slice(&[lm.x, lm.y, lm.cov[(0, 0)], lm.cov[(1, 0)], lm.cov[(0, 1)], lm.cov[(1, 1)]]); }
+            }
+            let zf: Vec<f64> = z.iter().flat_map(|&(d, a, id)| [d, a, id as f64]).collect();
+            check(unsafe { sys::rr_fs1_update_host(self.h, poses.as_mut_ptr(), maps.as_mut_ptr(), u.as_ptr(), zf.as_ptr(), z.len()) })?;
+            for (i, p) in particles.iter_mut().enumerate() {
+                p.weight = poses[4 * i]; p.x = poses[4 * i + 1]; p.y = poses[4 * i + 2]; p.yaw = poses[4 * i + 3];
+                for (l, lm) in p.landmarks.iter_mut().enumerate() {
+                    let e = &maps[(i * self.l + l) * 6..][..6];
+                    lm.x = e[0]; lm.y = e[1]; lm.cov = Matrix2::new(e[2], e[4], e[3], e[5]);
+                }
+            }
+            Ok(())
+        }
+    }
+
+    /// get_best_particle, fastslam1.rs:269-274 (ties -> last)
+    pub fn get_best_particle(particles: &[Particle]) -> &Particle {
+        particles.iter().max_by(|a, b| a.weight.partial_cmp(&b.weight).unwrap()).unwrap()
+    }
+}

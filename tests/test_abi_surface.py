@@ -8,7 +8,7 @@ import re
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADERS = ["rr_pf.h", "rr_fastslam1.h"]
+HEADERS = ["rr_pf.h", "rr_fastslam1.h", "rr_fastslam2.h"]
 
 
 def declared_functions(header):
@@ -114,3 +114,17 @@ def test_cpp_wrapper_compiles(tmp_path):
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", os.path.join(root, "include"), str(src)], capture_output=True,
                        text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_rust_sys_bindings_are_current():
+    """bindings/rust/rust_robotics_amd-sys/src/lib.rs is generated from include/*.h: it must be up to
+    date and declare every entry point the headers declare (the crate itself cannot be compiled here)"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_rust_sys.py"), "--check"])
+    assert r.returncode == 0, "run `python tools/gen_rust_sys.py`"
+    text = open(os.path.join(root, "bindings", "rust", "rust_robotics_amd-sys", "src", "lib.rs")).read()
+    for sym in (n for h in HEADERS for n in declared_functions(h)):
+        assert f"pub fn {sym}(" in text, sym
