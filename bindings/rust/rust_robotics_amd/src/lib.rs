@@ -28,7 +28,7 @@ fn check(status: sys::rr_status) -> RoboticsResult<()> {
     if status == sys::RR_INVALID_PARAMETER {
         Err(RoboticsError::InvalidParameter(msg))
     } else {
-        Err(RoboticsError::NumericalError(msg)) // device / runtime failure
+        Err(RoboticsError::EstimationError(msg)) // device / runtime failure (rust_robotics_core/src/error.rs:11)
     }
 }
 
