@@ -87,6 +87,7 @@ class Fs1Options(C.Structure):
 
 
 RR_FK_COUNT = 10
+RR_P2P_HANDLE_BYTES = 256  # include/rr_pf.h
 
 
 class PfShardSums(C.Structure):

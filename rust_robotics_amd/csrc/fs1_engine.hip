@@ -44,12 +44,13 @@ namespace {
 
 constexpr int kMaxChunks = 32;
 constexpr int kPlanesPerThread = 8;  // planes one gather thread copies for its output slot
-// sharded lazy resample: idx[p] == kInPlace => a peer has already stored slot p's particle into the
-// OTHER buffer set (k_fs1_push); the consuming kernels then read slot p of that set instead
+// sharded lazy resample: idx[p] == kInPlace => a peer has delivered slot p's particle into this rank's
+// fine-grained inbox (k_fs1_push); the consuming kernels then read slot p of the inbox instead
 constexpr unsigned int kInPlace = 0xffffffffu;
 
 struct Planes {
-  double* s[2];  // [(3 + 6L) * N]: planes 0..2 = x, y, yaw; plane 3 + l*6 + f = landmark l field f
+  double* s[2];         // [(3 + 6L) * N]: planes 0..2 = x, y, yaw; plane 3 + l*6 + f = landmark l field f
+  const double* inbox;  // sharded: fine-grained mirror of one set where peers deliver cross-rank particles (else null)
 };
 
 // LAZY: consume a pending resample -- read the pose of slot p from particle idx[p] of the live
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(kBlock) void k_fs1_predict(Planes pl, const Ctl* __
   double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
   const unsigned int ji = pending ? idx[p] : (unsigned int)p;
   const bool inplace = pending && ji == kInPlace;
-  const double* __restrict__ src = inplace ? dst : pl.s[ctl->cur];
+  const double* __restrict__ src = inplace ? pl.inbox : pl.s[ctl->cur];
   const uint64_t j = inplace ? p : ji;
   double x = src[j], y = src[n + j], yaw = src[2 * n + j];
   double a, b;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(kBlock) void k_fs2_predict(Planes pl, const Ctl* __
   double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
   const unsigned int ji = pending ? idx[p] : (unsigned int)p;
   const bool inplace = pending && ji == kInPlace;
-  const double* __restrict__ src = inplace ? dst : pl.s[ctl->cur];
+  const double* __restrict__ src = inplace ? pl.inbox : pl.s[ctl->cur];
   const uint64_t j = inplace ? p : ji;
   double pose[3] = {src[j], src[n + j], src[2 * n + j]};
   double lm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void k_fs1_observe(Planes pl, double* __res
     double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
     const unsigned int ji = pending ? idx[p] : (unsigned int)p;
     const bool inplace = pending && ji == kInPlace;
-    const double* src = inplace ? dst : pl.s[ctl->cur];
+    const double* src = inplace ? pl.inbox : pl.s[ctl->cur];
     const uint64_t j = inplace ? p : ji;
     const double px = dst[p], py = dst[n + p], pyaw = dst[2 * n + p];
     acc = chunk == 0 ? pw[p] : 1.0;
@@ -295,8 +296,8 @@ __global__ __launch_bounds__(kBlock) void k_fs1_uniform_weights(const Ctl* __res
   if (p < n) pw[p] = 1.0 / (double)n_global;  // fastslam1.rs:228
 }
 
-// the served slots that belong to peers: all planes of the source particle straight into slot li
-// of the owner's OTHER buffer set (the set its next update writes; the owner's idx says kInPlace)
+// the served slots that belong to peers: all planes of the source particle into slot li of the
+// owner's fine-grained inbox (the owner's idx says kInPlace)
 __global__ __launch_bounds__(kBlock) void k_fs1_push(Planes pl, const Ctl* __restrict__ ctl,
                                                     const unsigned int* __restrict__ ridx, uint64_t n_local,
                                                     uint64_t own_first, uint64_t n_planes, rr::P2PPeers peers) {
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(kBlock) void k_fs1_push(Planes pl, const Ctl* __res
     const uint64_t s = v.first + k;
     const uint64_t d = s / n_local, li = s - d * n_local;
     const uint64_t j = ridx[r];
-    double* __restrict__ out = peers.slab[d] + (size_t)(cur ^ 1) * n_planes * n_local;
+    double* __restrict__ out = peers.inbox[d];  // fine-grained, [plane][n_local]
     double val[kPlanesPerThread];
 #pragma unroll
     for (int q = 0; q < kPlanesPerThread; ++q)
@@ -346,10 +347,13 @@ __global__ __launch_bounds__(kBlock) void k_fs1_gather(Planes pl, const Ctl* __r
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= n) return;
   const int cur = ctl->cur;
-  const double* __restrict__ in = pl.s[lazy ? cur : cur ^ 1];
+  const double* in = pl.s[lazy ? cur : cur ^ 1];
   double* __restrict__ out = pl.s[lazy ? cur ^ 1 : cur];
-  const uint64_t j = idx[k];
-  if (lazy && idx[k] == kInPlace) return;  // sharded: stored by a peer, already in the other set
+  uint64_t j = idx[k];
+  if (lazy && idx[k] == kInPlace) {  // sharded: delivered by a peer -- take it out of the inbox
+    in = pl.inbox;
+    j = k;
+  }
   const uint64_t p0 = (uint64_t)blockIdx.y * kPlanesPerThread;
   double v[kPlanesPerThread];
   uint64_t pid[kPlanesPerThread];
@@ -1212,7 +1216,7 @@ rr_status rr_fs1_p2p_export(rr_fs1* h, uint8_t out[RR_P2P_HANDLE_BYTES]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!out) return fail(RR_INVALID_PARAMETER, "null output");
-  return h->p2p.export_handles(h->slab, out);
+  return h->p2p.export_handles(h->slab, h->n_planes * h->n, out);
 }
 
 rr_status rr_fs1_p2p_connect(rr_fs1* h, const uint8_t* all_handles, int32_t n_ranks, int32_t rank) {
@@ -1221,13 +1225,16 @@ rr_status rr_fs1_p2p_connect(rr_fs1* h, const uint8_t* all_handles, int32_t n_ra
   if (!all_handles) return fail(RR_INVALID_PARAMETER, "null handles");
   if ((s = fs1_check_geometry(h, n_ranks, rank)) != RR_OK) return s;
   if ((s = fs1_alloc_ridx(h)) != RR_OK) return s;
-  return h->p2p.connect_ipc(h->slab, all_handles, n_ranks, rank);
+  if ((s = h->p2p.connect_ipc(h->slab, h->n_planes * h->n, all_handles, n_ranks, rank)) != RR_OK) return s;
+  h->pl.inbox = h->p2p.inbox;
+  return RR_OK;
 }
 
 rr_status rr_fs1_p2p_connect_local(rr_fs1* const* handles, int32_t n_ranks) {
   if (!handles || n_ranks <= 0 || n_ranks > rr::kMaxP2P) return fail(RR_INVALID_PARAMETER, "bad handle list");
   rr::P2PState* st[rr::kMaxP2P];
   double* slabs[rr::kMaxP2P];
+  size_t inboxes[rr::kMaxP2P];
   int devs[rr::kMaxP2P];
   for (int g = 0; g < n_ranks; ++g) {
     if (!handles[g]) return fail(RR_INVALID_PARAMETER, "null handle");
@@ -1237,9 +1244,13 @@ rr_status rr_fs1_p2p_connect_local(rr_fs1* const* handles, int32_t n_ranks) {
     if ((s = fs1_alloc_ridx(handles[g])) != RR_OK) return s;
     st[g] = &handles[g]->p2p;
     slabs[g] = handles[g]->slab;
+    inboxes[g] = handles[g]->n_planes * handles[g]->n;
     devs[g] = handles[g]->opt.device;
   }
-  return rr::p2p_link_local(st, slabs, devs, n_ranks);
+  rr_status s = rr::p2p_link_local(st, slabs, inboxes, devs, n_ranks);
+  if (s != RR_OK) return s;
+  for (int g = 0; g < n_ranks; ++g) handles[g]->pl.inbox = handles[g]->p2p.inbox;
+  return RR_OK;
 }
 
 rr_status rr_fs1_p2p_status(rr_fs1* h, int32_t* timed_out) {

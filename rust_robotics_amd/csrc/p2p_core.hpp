@@ -17,11 +17,13 @@ namespace rr {
 // Every rank owns a fine-grained mailbox that the peers write 32-byte records into
 // {payload[3], seq}; k_p2p_exchange (one workgroup, one thread per peer) publishes this rank's
 // record to every peer with system-scope release and waits, bounded, for every peer's record
-// with system-scope acquire.  The resample gather then stores each served slot straight into
-// the owning rank's particle slab (coarse-grained memory written by a remote kernel and read by
-// a LATER local kernel -- the same hand-off RCCL's direct P2P receive uses).
+// with system-scope acquire.  Particles that cross ranks at resample time are delivered into the
+// owning rank's INBOX: a fine-grained (uncached, device-coherent) mirror of one buffer set, the
+// kind of memory RCCL uses for its own peer-written buffers -- a store from a remote kernel is
+// visible to a later local kernel without any assumption about what either GPU's L2 still holds.
+// The consumer reads an "in place" slot from its inbox instead of its slab.
 constexpr int kMaxP2P = 16;
-constexpr int kP2PHandleBytes = 128;
+constexpr int kP2PHandleBytes = 256;
 struct P2PSlot {
   uint64_t v[3];
   uint64_t seq;
@@ -33,7 +35,8 @@ struct P2PMailbox {
 };
 struct P2PPeers {
   P2PMailbox* mbox[kMaxP2P];
-  double* slab[kMaxP2P];
+  double* slab[kMaxP2P];   // the peers' state slabs (the plain, eager protocol stores straight into them)
+  double* inbox[kMaxP2P];  // the peers' fine-grained inboxes: where the lazy protocol delivers cross-rank particles
   int n_ranks;
   int rank;
 };
@@ -145,9 +148,11 @@ static __global__ __launch_bounds__(kScanThreads) void k_scan_exchange(P2PPeers 
 // ---- host side: what a handle owns for the transport
 struct P2PState {
   P2PMailbox* mbox = nullptr;  // fine-grained: peers write their records here
+  double* inbox = nullptr;     // fine-grained: peers deliver cross-rank particles here (engine-defined layout)
+  size_t inbox_doubles = 0;
   P2PPeers peers{};            // device pointers of every rank's mailbox and slab
   bool ready = false;
-  void* opened[2 * kMaxP2P] = {};  // IPC mappings to close
+  void* opened[3 * kMaxP2P] = {};  // IPC mappings to close
   int n_opened = 0;
   uint64_t seq = 0;
   uint64_t* scratch = nullptr;  // [kMaxP2P][3] gathered records + [4] local payload
@@ -161,6 +166,8 @@ struct P2PState {
     for (int k = 0; k < n_opened; ++k) (void)hipIpcCloseMemHandle(opened[k]);
     n_opened = 0;
     (void)hipFree(mbox);
+    (void)hipFree(inbox);
+    inbox = nullptr;
     (void)hipFree(scratch);
     (void)hipFree(err);
     if (err_host) (void)hipHostFree(err_host);
@@ -171,8 +178,10 @@ struct P2PState {
     ready = false;
   }
 
-  rr_status local_setup() {
+  rr_status local_setup(size_t inbox_doubles_) {
     if (mbox) return RR_OK;
+    inbox_doubles = inbox_doubles_;
+    RR_HIP_TRY(hipExtMallocWithFlags((void**)&inbox, inbox_doubles * sizeof(double), hipDeviceMallocFinegrained));
     RR_HIP_TRY(hipExtMallocWithFlags((void**)&mbox, sizeof(P2PMailbox), hipDeviceMallocFinegrained));
     RR_HIP_TRY(hipMemset(mbox, 0, sizeof(P2PMailbox)));
     RR_HIP_TRY(hipMalloc(&scratch, (3 * kMaxP2P + 4) * sizeof(uint64_t)));
@@ -183,20 +192,21 @@ struct P2PState {
     return RR_OK;
   }
 
-  rr_status export_handles(double* slab, uint8_t out[kP2PHandleBytes]) {
-    rr_status s = local_setup();
+  rr_status export_handles(double* slab, size_t inbox_doubles_, uint8_t out[kP2PHandleBytes]) {
+    rr_status s = local_setup(inbox_doubles_);
     if (s != RR_OK) return s;
-    static_assert(2 * sizeof(hipIpcMemHandle_t) <= kP2PHandleBytes, "handle blob too small");
-    hipIpcMemHandle_t hs[2];
+    static_assert(3 * sizeof(hipIpcMemHandle_t) <= kP2PHandleBytes, "handle blob too small");
+    hipIpcMemHandle_t hs[3];
     RR_HIP_TRY(hipIpcGetMemHandle(&hs[0], slab));
     RR_HIP_TRY(hipIpcGetMemHandle(&hs[1], mbox));
+    RR_HIP_TRY(hipIpcGetMemHandle(&hs[2], inbox));
     std::memset(out, 0, kP2PHandleBytes);
     std::memcpy(out, hs, sizeof hs);
     return RR_OK;
   }
 
-  rr_status connect_ipc(double* slab, const uint8_t* all_handles, int n_ranks, int rank) {
-    rr_status s = local_setup();
+  rr_status connect_ipc(double* slab, size_t inbox_doubles_, const uint8_t* all_handles, int n_ranks, int rank) {
+    rr_status s = local_setup(inbox_doubles_);
     if (s != RR_OK) return s;
     P2PPeers p{};
     p.n_ranks = n_ranks;
@@ -205,17 +215,21 @@ struct P2PState {
       if (g == rank) {
         p.slab[g] = slab;
         p.mbox[g] = mbox;
+        p.inbox[g] = inbox;
         continue;
       }
-      hipIpcMemHandle_t hs[2];
+      hipIpcMemHandle_t hs[3];
       std::memcpy(hs, all_handles + (size_t)g * kP2PHandleBytes, sizeof hs);
-      void *ps = nullptr, *pm = nullptr;
+      void *ps = nullptr, *pm = nullptr, *pi = nullptr;
       RR_HIP_TRY(hipIpcOpenMemHandle(&ps, hs[0], hipIpcMemLazyEnablePeerAccess));
       opened[n_opened++] = ps;
       RR_HIP_TRY(hipIpcOpenMemHandle(&pm, hs[1], hipIpcMemLazyEnablePeerAccess));
       opened[n_opened++] = pm;
+      RR_HIP_TRY(hipIpcOpenMemHandle(&pi, hs[2], hipIpcMemLazyEnablePeerAccess));
+      opened[n_opened++] = pi;
       p.slab[g] = (double*)ps;
       p.mbox[g] = (P2PMailbox*)pm;
+      p.inbox[g] = (double*)pi;
     }
     peers = p;
     ready = true;
@@ -234,10 +248,11 @@ struct P2PState {
 };
 
 // in-process wiring: slabs[g], states[g], devices[g] of rank g
-inline rr_status p2p_link_local(P2PState* const* states, double* const* slabs, const int* devices, int n_ranks) {
+inline rr_status p2p_link_local(P2PState* const* states, double* const* slabs, const size_t* inbox_doubles, const int* devices,
+                                int n_ranks) {
   for (int g = 0; g < n_ranks; ++g) {
     RR_HIP_TRY(hipSetDevice(devices[g]));
-    rr_status s = states[g]->local_setup();
+    rr_status s = states[g]->local_setup(inbox_doubles[g]);
     if (s != RR_OK) return s;
   }
   for (int g = 0; g < n_ranks; ++g) {
@@ -257,6 +272,7 @@ inline rr_status p2p_link_local(P2PState* const* states, double* const* slabs, c
       }
       p.slab[k] = slabs[k];
       p.mbox[k] = states[k]->mbox;
+      p.inbox[k] = states[k]->inbox;
     }
     states[g]->peers = p;
     states[g]->ready = true;

@@ -177,8 +177,8 @@ __global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __r
 // resample it runs in place.  This removes a whole 72 B/particle pass over HBM per step.
 //
 // SHARDED (rr_pf_shard_step_p2p): the sources come from `lidx` instead of markers -- lidx[k] is the
-// LOCAL source of slot k, or kInPlace when a peer has already stored the resampled particle into
-// slot k of the other buffer set (k_resolve_push) -- and every consumed entry is reset to kInPlace.
+// LOCAL source of slot k, or kInPlace when a peer has delivered the resampled particle into slot k
+// of this rank's inbox (k_resolve_push) -- and every consumed entry is reset to kInPlace.
 constexpr unsigned int kInPlace = 0xffffffffu;
 
 template <bool OBS_KERNARG, bool SHARDED>
@@ -187,7 +187,8 @@ __global__ __launch_bounds__(kBlock) void k_step_lazy(Bufs b, double* __restrict
                                                      const double* __restrict__ obs_dev,
                                                      unsigned int* __restrict__ markers,
                                                      const unsigned int* __restrict__ carry,
-                                                     unsigned int* __restrict__ idx_out) {
+                                                     unsigned int* __restrict__ idx_out,
+                                                     const double* __restrict__ inbox) {
   extern __shared__ double s_obs[];
   __shared__ double s_wmax[kBlock / rr::kWave];
   const int tid = threadIdx.x;
@@ -223,10 +224,10 @@ __global__ __launch_bounds__(kBlock) void k_step_lazy(Bufs b, double* __restrict
       x[r] = y[r] = yaw[r] = 0.0;
       if (k < p.n) {
         const uint64_t j = idx[r];
-        if (SHARDED && pending && idx[r] == kInPlace) {  // stored by a peer, already in place
-          x[r] = b.x[dst][k];
-          y[r] = b.y[dst][k];
-          yaw[r] = b.yaw[dst][k];
+        if (SHARDED && pending && idx[r] == kInPlace) {  // delivered by a peer into this rank's inbox [field][n]
+          x[r] = inbox[k];
+          y[r] = inbox[p.n + k];
+          yaw[r] = inbox[2 * p.n + k];
         } else {
           x[r] = sx[j];
           y[r] = sy[j];
@@ -523,9 +524,9 @@ __global__ __launch_bounds__(kBlock) void k_resolve_gather_p2p(Bufs b, const Ctl
 
 // Sharded lazy resample, phase D: resolve the slots this rank serves.  A slot owned by this rank
 // only gets its LOCAL source index (lidx; the next k_step_lazy<., true> reads through it -- no
-// particle moves); a slot owned by a peer gets the particle stored straight into the peer's OTHER
-// buffer set (the set the next step writes anyway), where the peer's lidx entry says kInPlace.
-// The DONE exchange that follows tells the peers that every store of this rank has landed.
+// particle moves); a slot owned by a peer gets the particle delivered into the peer's fine-grained
+// inbox, where the peer's lidx entry says kInPlace.  The DONE exchange that follows tells the
+// peers that every store of this rank has landed.
 __global__ __launch_bounds__(kBlock) void k_resolve_push(Bufs b, const Ctl* __restrict__ ctl,
                                                         unsigned int* __restrict__ markers,
                                                         const unsigned int* __restrict__ carry,
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_push(Bufs b, const Ctl* __re
   if (tile_base >= n_slots) return;  // uniform per workgroup
   unsigned int idx[rr::kResolveRows];
   rr::resolve_tile(markers, carry, n_slots, blockIdx.x, idx);
-  const int src = ctl->cur, dst = src ^ 1;  // lazy: Ctl.cur flips when the next step settles
+  const int src = ctl->cur;  // lazy: Ctl.cur flips when the next step settles
   const uint64_t me = (uint64_t)peers.rank;
 #pragma unroll
   for (int r = 0; r < rr::kResolveRows; ++r) {
@@ -549,7 +550,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_push(Bufs b, const Ctl* __re
       if (d == me) {
         lidx[li] = (unsigned int)j;
       } else {
-        double* __restrict__ out = peers.slab[d] + (size_t)(4 * dst) * n_local;
+        double* __restrict__ out = peers.inbox[d];  // fine-grained, [field][n_local]
         out[li] = b.x[src][j];
         out[n_local + li] = b.y[src][j];
         out[2 * n_local + li] = b.yaw[src][j];
@@ -562,13 +563,21 @@ __global__ __launch_bounds__(kBlock) void k_resolve_push(Bufs b, const Ctl* __re
 // make a pending sharded-lazy resample real (accessors): copy the locally-sourced slots, leave
 // the ones a peer stored where they are; k_settle flips the live set afterwards
 __global__ __launch_bounds__(kBlock) void k_gather_lidx(Bufs b, const Ctl* __restrict__ ctl,
-                                                       unsigned int* __restrict__ lidx, uint64_t n) {
+                                                       unsigned int* __restrict__ lidx, uint64_t n,
+                                                       const double* __restrict__ inbox) {
   if (!ctl->pending) return;
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= n) return;
   const unsigned int j = lidx[k];
-  if (j == kInPlace) return;
   const int src = ctl->cur, dst = src ^ 1;
+  if (j == kInPlace) {  // delivered by a peer: take it out of the inbox (multinomial, unsharded: never happens)
+    if (!inbox) return;
+    b.x[dst][k] = inbox[k];
+    b.y[dst][k] = inbox[n + k];
+    b.yaw[dst][k] = inbox[2 * n + k];
+    b.v[dst][k] = inbox[3 * n + k];
+    return;
+  }
   b.x[dst][k] = b.x[src][j];
   b.y[dst][k] = b.y[src][j];
   b.yaw[dst][k] = b.yaw[src][j];
@@ -953,7 +962,8 @@ rr_status materialise(rr_pf* h) {
   if (!h->maybe_pending) return RR_OK;
   if (h->pending_lidx) {
     Timed t(h, RR_K_RESAMPLE_GATHER);
-    hipLaunchKernelGGL(k_gather_lidx, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->lidx, h->n);
+    hipLaunchKernelGGL(k_gather_lidx, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->lidx, h->n,
+                       (const double*)(h->p2p.ready ? h->p2p.inbox : nullptr));
     hipLaunchKernelGGL(k_settle, dim3(1), dim3(1), 0, h->stream, h->ctl);
     RR_HIP_TRY(hipGetLastError());
     h->maybe_pending = h->pending_lidx = false;
@@ -1574,10 +1584,12 @@ rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs,
     if (multinomial) {  // sources of the previous (multinomial) resample are in lidx
       if (kernarg)
         hipLaunchKernelGGL((k_step_lazy<true, true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
-                           (const double*)nullptr, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr);
+                           (const double*)nullptr, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr,
+                            (const double*)h->p2p.inbox);
       else
         hipLaunchKernelGGL((k_step_lazy<false, true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
-                           (const double*)h->obs_dev, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr);
+                           (const double*)h->obs_dev, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr,
+                            (const double*)h->p2p.inbox);
     } else {
       hipEvent_t ea = nullptr, eb = nullptr;
       if (h->profiling && h->profile_dispatch_only) {  // timestamps of this dispatch itself: nothing extra in the stream
@@ -1587,16 +1599,16 @@ rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs,
       }
       if (ea && kernarg)
         hipExtLaunchKernelGGL((k_step_lazy<true, false>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl,
-                              p, arg, (const double*)nullptr, h->markers, h->carry, h->idx);
+                              p, arg, (const double*)nullptr, h->markers, h->carry, h->idx, (const double*)nullptr);
       else if (ea)
         hipExtLaunchKernelGGL((k_step_lazy<false, false>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w,
-                              h->ctl, p, arg, (const double*)h->obs_dev, h->markers, h->carry, h->idx);
+                              h->ctl, p, arg, (const double*)h->obs_dev, h->markers, h->carry, h->idx, (const double*)nullptr);
       else if (kernarg)
         hipLaunchKernelGGL((k_step_lazy<true, false>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
-                           (const double*)nullptr, h->markers, h->carry, h->idx);
+                           (const double*)nullptr, h->markers, h->carry, h->idx, (const double*)nullptr);
       else
         hipLaunchKernelGGL((k_step_lazy<false, false>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
-                           (const double*)h->obs_dev, h->markers, h->carry, h->idx);
+                           (const double*)h->obs_dev, h->markers, h->carry, h->idx, (const double*)nullptr);
     }
   }
   RR_HIP_TRY(hipGetLastError());
@@ -1924,7 +1936,7 @@ rr_status rr_pf_p2p_export(rr_pf* h, uint8_t out[RR_P2P_HANDLE_BYTES]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!out) return fail(RR_INVALID_PARAMETER, "null output");
-  return h->p2p.export_handles(h->slab, out);
+  return h->p2p.export_handles(h->slab, 4 * h->n, out);
 }
 
 rr_status rr_pf_p2p_connect(rr_pf* h, const uint8_t* all_handles, int32_t n_ranks, int32_t rank) {
@@ -1933,13 +1945,14 @@ rr_status rr_pf_p2p_connect(rr_pf* h, const uint8_t* all_handles, int32_t n_rank
   if (!all_handles) return fail(RR_INVALID_PARAMETER, "null handles");
   if ((s = p2p_check_geometry(h, n_ranks, rank)) != RR_OK) return s;
   if ((s = p2p_alloc_lidx(h)) != RR_OK) return s;
-  return h->p2p.connect_ipc(h->slab, all_handles, n_ranks, rank);
+  return h->p2p.connect_ipc(h->slab, 4 * h->n, all_handles, n_ranks, rank);
 }
 
 rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
   if (!handles || n_ranks <= 0 || n_ranks > kMaxP2P) return fail(RR_INVALID_PARAMETER, "bad handle list");
   rr::P2PState* st[kMaxP2P];
   double* slabs[kMaxP2P];
+  size_t inboxes[kMaxP2P];
   int devs[kMaxP2P];
   for (int g = 0; g < n_ranks; ++g) {
     if (!handles[g]) return fail(RR_INVALID_PARAMETER, "null handle");
@@ -1949,9 +1962,10 @@ rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
     if ((s = p2p_alloc_lidx(handles[g])) != RR_OK) return s;
     st[g] = &handles[g]->p2p;
     slabs[g] = handles[g]->slab;
+    inboxes[g] = 4 * handles[g]->n;
     devs[g] = handles[g]->opt.device;
   }
-  return rr::p2p_link_local(st, slabs, devs, n_ranks);
+  return rr::p2p_link_local(st, slabs, inboxes, devs, n_ranks);
 }
 
 // Seven launches: propagate+weight (reading through lidx) | WMAX exchange | integer image |
@@ -1991,16 +2005,20 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
     }
     if (ea && kernarg)
       hipExtLaunchKernelGGL((k_step_lazy<true, true>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl, p,
-                            arg, (const double*)nullptr, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr);
+                            arg, (const double*)nullptr, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr,
+                            (const double*)h->p2p.inbox);
     else if (ea)
       hipExtLaunchKernelGGL((k_step_lazy<false, true>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl, p,
-                            arg, (const double*)h->obs_dev, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr);
+                            arg, (const double*)h->obs_dev, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr,
+                            (const double*)h->p2p.inbox);
     else if (kernarg)
       hipLaunchKernelGGL((k_step_lazy<true, true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
-                         (const double*)nullptr, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr);
+                         (const double*)nullptr, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr,
+                            (const double*)h->p2p.inbox);
     else
       hipLaunchKernelGGL((k_step_lazy<false, true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
-                         (const double*)h->obs_dev, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr);
+                         (const double*)h->obs_dev, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr,
+                            (const double*)h->p2p.inbox);
   }
   h->step += 1;
   PlanArgs pa = plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN);

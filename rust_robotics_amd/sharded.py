@@ -354,10 +354,10 @@ class P2PShard:
             raise kind(_ffi.last_error())
 
     def connect_ipc(self, allgather) -> None:
-        blob = (C.c_uint8 * 128)()
+        blob = (C.c_uint8 * _ffi.RR_P2P_HANDLE_BYTES)()
         self._check(self.L.rr_pf_p2p_export(self.h, blob))
         parts = allgather(bytes(blob))
-        allb = (C.c_uint8 * (128 * self.world)).from_buffer_copy(b"".join(parts))
+        allb = (C.c_uint8 * (_ffi.RR_P2P_HANDLE_BYTES * self.world)).from_buffer_copy(b"".join(parts))
         self._check(self.L.rr_pf_p2p_connect(self.h, allb, self.world, self.rank))
 
     @staticmethod

@@ -230,10 +230,10 @@ class ShardedFastSlam1(FastSlam1):
         self.rank, self.world = rank, world
 
     def connect_ipc(self, allgather) -> None:
-        blob = (C.c_uint8 * 128)()
+        blob = (C.c_uint8 * _ffi.RR_P2P_HANDLE_BYTES)()
         _check(self._L.rr_fs1_p2p_export(self._h, blob))
         parts = allgather(bytes(blob))
-        allb = (C.c_uint8 * (128 * self.world)).from_buffer_copy(b"".join(parts))
+        allb = (C.c_uint8 * (_ffi.RR_P2P_HANDLE_BYTES * self.world)).from_buffer_copy(b"".join(parts))
         _check(self._L.rr_fs1_p2p_connect(self._h, allb, self.world, self.rank))
 
     @staticmethod
