@@ -147,3 +147,25 @@ def test_validation_and_misuse(loc):
         mcl.set_particles_array(np.zeros((51, 5)))  # beyond the capacity
     with pytest.raises(inv):
         loc.MonteCarloLocalizer(loc.MonteCarloLocalizationConfig(min_particles=10, max_particles=50), resample_scheme=1)
+
+
+def test_large_adaptive_resample_matches_det(loc, det):
+    """several tiles of particles, a capacity that needs many chunks of the counting kernel, thousands of
+    occupied bins: count and indices against the sequential D-spec loop"""
+    rng = np.random.default_rng(12)
+    n, lo, hi = 30_000, 2_000, 120_000
+    x, y, yaw = rng.uniform(-30, 30, n), rng.uniform(-30, 30, n), rng.uniform(-3, 3, n)
+    w = rng.random(n) ** 4 + 1e-6
+    mcl, _ = make(loc, lo, hi)
+    mcl.set_particles_array(np.column_stack([x, y, yaw, np.zeros(n), w]))
+    r = np.floor(rng.random(hi) * 2**53) / 2**53
+    n_new = mcl.resample_adaptive_with_uniforms(r)
+    cnt_d, idx_d = det_adaptive(det, np.ascontiguousarray(x), np.ascontiguousarray(y), np.ascontiguousarray(yaw), np.ascontiguousarray(w), r, lo, hi)
+    assert n_new == cnt_d and lo < n_new <= hi
+    assert np.array_equal(mcl.last_resample_indices(), idx_d)
+    # and a second resample from the new (uniform-weight) set, Philox draws this time
+    before = mcl.get_particles_array()
+    mcl.resample()
+    after = mcl.get_particles_array()
+    assert lo <= mcl.particle_count() <= hi
+    assert set(map(tuple, np.round(after[:50, :2], 12))) <= set(map(tuple, np.round(before[:, :2], 12)))
