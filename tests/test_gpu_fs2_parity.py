@@ -138,3 +138,42 @@ def test_sharded_equals_unsharded_world1(fs2):
     assert not b.timed_out()
     (pa, ma), (pb, mb) = a.get_state(), b.get_state()
     assert bits_equal(pa, pb) and bits_equal(ma, mb)
+
+
+def test_duplicate_observations_and_parameter_validation(fs2, det):
+    """the same landmark twice in one step (the second update must see the first one's result: the engine
+    settles a pending resample first and updates in place) and rr_fs2_create's parameter checks"""
+    n, L = 900, 4
+    lms = scene(L, 8)
+    prm = fs2.default_params()
+    prm.base.nth = n / 1.5
+    prm.base.initial_weight = 1.0 / n
+    f = fs2.FastSlam2(n, L, params=prm, seed=31, obs_chunks=0)
+    px, py, pyaw = (np.zeros(n) for _ in range(3))
+    pw = np.full(n, 1.0 / n)
+    planes = oracle.maps_aos_to_planes(np.tile(np.array([0, 0, 1000.0, 0, 0, 1000.0]), (n, L, 1)), n, L)
+    m = oracle.det_fs2_model()
+    idx = np.empty(n, np.uint32)
+    for t in range(8):
+        z = obs_for(fs2, H.true_pose(t + 1), lms, seed=31, step=t)
+        if t % 2:
+            z = np.ascontiguousarray(np.vstack([z, z[1:2], z[0:1]]))  # landmarks 1 and 0 observed twice
+        f.update([1.0, 0.1], z)
+        fired = det.det_fs2_update(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(planes), 1.0, 0.1, dp(z), len(z), C.byref(m), None,
+                                   n / 1.5, 31, t, t, f.counters()[2], u32p(idx))
+        assert f.last_resample_fired() == bool(fired)
+    gp, gm = f.get_state()
+    assert bits_equal(gp[:, 0], pw) and bits_equal(gp[:, 1], px) and bits_equal(gp[:, 3], pyaw)
+    assert bits_equal(gm.reshape(-1), oracle.maps_planes_to_aos(planes, n, L))
+    from rust_robotics_amd.core import RoboticsError
+
+    bad = fs2.default_params()
+    bad.motion_cov[1] = -1.0
+    with pytest.raises(RoboticsError):
+        fs2.FastSlam2(10, 2, params=bad)
+    bad = fs2.default_params()
+    bad.base.first_obs_cov = float("nan")
+    with pytest.raises(RoboticsError):
+        fs2.FastSlam2(10, 2, params=bad)
+    with pytest.raises(RoboticsError):
+        f.update([1.0, 0.1], [(1.0, 0.0, L)])  # landmark id out of range
