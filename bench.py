@@ -550,7 +550,7 @@ def main():
                       "HIP events in an instrumented re-run of the K steps",
             "algorithmic_bytes_per_launch": k1_bytes * n,
             "note": "this kernel is FP64-VALU bound at L=32 (~19 f64-rate instructions per particle-landmark pair, "
-                    "VALU ~96 % busy per rocprofv3 PMC); the HBM-bound workload is `--workload fastslam` (DESIGN.md section 4)",
+                    "VALU issue slots ~94 % busy per rocprofv3 PMC, profiles/r01f_mcl_pmc_sq_summary.csv); the HBM-bound workload is `--workload fastslam` (DESIGN.md section 4)",
         },
         "kernel_ms_avg": step_kernel_ms,
         "ms_per_step_instrumented": res.get("seconds_instrumented", 0.0) / K * 1e3,
