@@ -9,8 +9,11 @@
  *
  * Reference files restated (all under /root/reference/crates):
  *   rust_robotics_localization/src/particle_filter.rs
- *   rust_robotics_localization/src/monte_carlo_localization.rs  (fixed-N resample variant)
+ *   rust_robotics_localization/src/monte_carlo_localization.rs  (fixed-N and KLD-adaptive resample)
  *   rust_robotics_slam/src/fastslam1.rs
+ *   rust_robotics_slam/src/fastslam2.rs  (with nalgebra 0.33.2's Matrix3::try_inverse and Cholesky restated
+ *                                        from that crate's published source: it is a crates.io dependency,
+ *                                        not part of /root/reference -- that part is parity-unpinned too)
  *
  * PARITY PINNING: the reference cannot be compiled here (no rustc/cargo in the
  * image) and its hot path is not seedable (rand::rng() at particle_filter.rs:258,443;
