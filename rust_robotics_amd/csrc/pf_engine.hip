@@ -348,17 +348,18 @@ __global__ __launch_bounds__(kBlock) void k_resample_gather_mn(Bufs b, const Ctl
   extern __shared__ uint64_t s_coarse[];
   for (uint64_t i = threadIdx.x; i < n_coarse; i += kBlock) s_coarse[i] = coarse[i];
   __syncthreads();
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= a.n_slots) return;
   const int dst = ctl->cur, src = dst ^ 1;
-  const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, a.first_slot + k, a.seed, a.rstep, r_explicit, k);
-  const uint64_t blk = rr_lower_bound_u64(s_coarse, n_coarse, target);  // first window whose last entry >= target
-  const uint64_t lo = blk << coarse_log2;
-  const uint64_t len = lo + (1ull << coarse_log2) <= a.n_src ? (1ull << coarse_log2) : a.n_src - lo;
-  const uint64_t j = lo + rr_lower_bound_u64(cdf + lo, len, target);
-  if (lidx_out) lidx_out[k] = (unsigned int)j;  // lazy: the next propagate kernel reads through it
-  else copy_particle(b, src, dst, j, k, false, nullptr);
-  if (idx_out) idx_out[k] = (unsigned int)j;
+  // grid-stride: a workgroup stages the coarse table once and serves several blocks of slots
+  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < a.n_slots; k += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, a.first_slot + k, a.seed, a.rstep, r_explicit, k);
+    const uint64_t blk = rr_lower_bound_u64(s_coarse, n_coarse, target);  // first window whose last entry >= target
+    const uint64_t lo = blk << coarse_log2;
+    const uint64_t len = lo + (1ull << coarse_log2) <= a.n_src ? (1ull << coarse_log2) : a.n_src - lo;
+    const uint64_t j = lo + rr_lower_bound_u64(cdf + lo, len, target);
+    if (lidx_out) lidx_out[k] = (unsigned int)j;  // lazy: the next propagate kernel reads through it
+    else copy_particle(b, src, dst, j, k, false, nullptr);
+    if (idx_out) idx_out[k] = (unsigned int)j;
+  }
 }
 
 // sharded adopt: unpack the received n x (x, y, yaw, v) records into the live buffer set (the
@@ -763,6 +764,7 @@ struct rr_pf {
   uint64_t n_tiles = 0;
   unsigned int step = 0, rstep = 0;
   int k1_blocks_per_cu = 8;
+  int mn_grid = 1024;  // workgroups of the multinomial search kernel (RR_MN_GRID)
   bool wmax_live = false;        // Ctl.wmax_bits holds the maximum of the current raw weights
   bool wmax_bits_clean = false;  // Ctl.wmax_bits is known to be zero
   uint64_t last_migrated = 0;
@@ -1034,9 +1036,9 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
     g.seed = h->opt.seed;
     g.rstep = h->rstep;
     g.scheme = scheme;
-    hipLaunchKernelGGL(k_resample_gather_mn, dim3(grid_for(h->n, kBlock)), dim3(kBlock), h->n_coarse * sizeof(uint64_t),
-                       h->stream, h->b, h->ctl, h->cdf, h->cdf_coarse, h->coarse_log2, h->n_coarse, (const double*)nullptr,
-                       h->idx, h->lidx, g);
+    hipLaunchKernelGGL(k_resample_gather_mn, dim3(std::min<unsigned>(grid_for(h->n, kBlock), (unsigned)h->mn_grid)), dim3(kBlock),
+                       h->n_coarse * sizeof(uint64_t), h->stream, h->b, h->ctl, h->cdf, h->cdf_coarse, h->coarse_log2, h->n_coarse,
+                       (const double*)nullptr, h->idx, h->lidx, g);
     h->maybe_pending = h->pending_lidx = true;
   } else if (lazy) {
     h->maybe_pending = true;  // the next k_step_lazy (or materialise) moves the particles
@@ -1054,9 +1056,9 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
       g.rstep = h->rstep;
       g.scheme = scheme;
       g.to_staging = 0;
-      hipLaunchKernelGGL(k_resample_gather_mn, dim3(grid_for(h->n, kBlock)), dim3(kBlock), h->n_coarse * sizeof(uint64_t),
-                         h->stream, h->b, h->ctl, h->cdf, h->cdf_coarse, h->coarse_log2, h->n_coarse, r_explicit_dev, h->idx,
-                         (unsigned int*)nullptr, g);
+      hipLaunchKernelGGL(k_resample_gather_mn, dim3(std::min<unsigned>(grid_for(h->n, kBlock), (unsigned)h->mn_grid)), dim3(kBlock),
+                         h->n_coarse * sizeof(uint64_t), h->stream, h->b, h->ctl, h->cdf, h->cdf_coarse, h->coarse_log2, h->n_coarse,
+                         r_explicit_dev, h->idx, (unsigned int*)nullptr, g);
     }
   }
   RR_HIP_TRY(hipGetLastError());
@@ -1253,6 +1255,10 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
   }
   const uint64_t cap_tiles = (h->cap + kTile - 1) / kTile;
   h->lik = rr_pf_lik_make(cfg->range_noise);
+  if (const char* e = std::getenv("RR_MN_GRID")) {
+    const int v = std::atoi(e);
+    if (v >= 1) h->mn_grid = v;
+  }
   if (const char* e = std::getenv("RR_K1_BLOCKS_PER_CU")) {
     const int v = std::atoi(e);
     if (v >= 1 && v <= 64) h->k1_blocks_per_cu = v;
