@@ -170,7 +170,14 @@ RR_HD uint64_t rr_fix_quantize(double w, int shift) {
     m |= 0x0010000000000000ull;
     sh = e - 1075 + shift;
   }
-  if (sh >= 0) return m << (sh > 10 ? 10 : sh); /* sh <= 10 by construction */
+  /* w <= w_max and shift = (62 - ceil_log2 N) - ilogb(w_max) give sh <= 10 - ceil_log2 N for a NORMAL
+   * w_max.  For a subnormal w_max rr_fix_shift grows up to 1136 - ceil_log2 N while m has fewer than 52
+   * significant bits; the clamp below then keeps only the top 10 extra bits on purpose: every weight
+   * of such a set is itself subnormal (<= 52 - k significant bits), the image stays monotone and
+   * < 2^63 / N, and CPU, 1 GPU and 8 GPUs still agree bit for bit.  Precision, not exactness, is what
+   * is given up in that regime (weights below 2^-1022, where RR_LIK_PRODUCT's running product has
+   * already lost its low bits as well). */
+  if (sh >= 0) return m << (sh > 10 ? 10 : sh);
   if (sh <= -64) return 0;
   return m >> (-sh);
 }

@@ -128,7 +128,11 @@ __global__ __launch_bounds__(kBlock) void k_fs2_predict(Planes pl, const Ctl* __
 // LDS and read back with wave-uniform addresses; each update loads the 6 planes of the observed
 // landmark for 64 consecutive particles (coalesced), runs the 2x2 EKF of rr_fs1_update_one and
 // stores only the fields that changed.
-template <bool LAZY>
+// SEQ (a landmark id repeats inside the step; host side: one chunk, in place, nothing pending): the
+// second update of a landmark must see the first one's result (fastslam1.rs:250-256 runs the
+// observations one after the other), so every update loads its planes only after the previous
+// update's stores -- no software pipeline, no restrict-qualified alias of the live set.
+template <bool LAZY, bool SEQ>
 __global__ __launch_bounds__(kBlock) void k_fs1_observe(Planes pl, double* __restrict__ pw, Ctl* __restrict__ ctl,
                                                        uint64_t n, const double* __restrict__ z, int n_z,
                                                        int chunk_len, int n_chunks, rr_fs1_model m,
@@ -160,13 +164,27 @@ __global__ __launch_bounds__(kBlock) void k_fs1_observe(Planes pl, double* __res
     // FP64 instructions of update k, so two updates' worth of HBM requests are in flight per wave
     // (the kernel runs at 3 waves per SIMD; bytes in flight, not arithmetic, set its speed)
     const int nk = k1 - k0;
+    if (SEQ) {
+      double* live = pl.s[ctl->cur];
+      for (int k = 0; k < nk; ++k) {
+        const double zd = s_z[3 * k], za = s_z[3 * k + 1];
+        double* io = live + (3 + (uint64_t)s_z[3 * k + 2] * 6) * n + p;
+        double e[6], o[6];
+#pragma unroll
+        for (int f = 0; f < 6; ++f) o[f] = e[f] = io[f * n];
+        acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
+#pragma unroll
+        for (int f = 0; f < 6; ++f)
+          if (rr_d2u(e[f]) != rr_d2u(o[f])) io[f * n] = e[f];
+      }
+    }
     double nxt[6];
-    if (nk > 0) {
+    if (!SEQ && nk > 0) {
       const double* in0 = src + (3 + (uint64_t)s_z[2] * 6) * n + j;
 #pragma unroll
       for (int f = 0; f < 6; ++f) nxt[f] = in0[f * n];
     }
-    for (int k = 0; k < nk; ++k) {
+    for (int k = 0; !SEQ && k < nk; ++k) {
       const double zd = s_z[3 * k], za = s_z[3 * k + 1];
       const uint64_t id = (uint64_t)s_z[3 * k + 2];
       double* out0 = dst + (3 + id * 6) * n + p;
@@ -512,6 +530,7 @@ struct rr_fs1 {
   double* z_dev = nullptr;
   size_t z_cap = 0;
   double* noise = nullptr;  // 2n
+  double* pose_stage = nullptr;  // 4n: AoS (w, x, y, yaw) image for get_state / set_state (the inactive set only holds 3n when L == 0)
   uint64_t* part_bits = nullptr;
   uint64_t* part_idx = nullptr;
   Ctl* ctl = nullptr;
@@ -693,25 +712,29 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool 
     const dim3 grid(grid_for(h->n, kBlock), chunks);
     const size_t lds = 3 * (size_t)len * sizeof(double);
     hipEvent_t ea = nullptr, eb = nullptr;
-    if (h->prof.on && h->prof.dispatch_only) {  // timestamps of this dispatch itself: nothing extra in the stream
+    if (h->prof.on && h->prof.dispatch_only && !dup) {  // timestamps of this dispatch itself: nothing extra in the stream
       ea = h->prof.take();
       eb = h->prof.take();
       h->prof.events.push_back({RR_FK_OBSERVE, ea, eb});
     }
-    if (ea && lazy)
-      hipExtLaunchKernelGGL(k_fs1_observe<true>, grid, dim3(kBlock), lds, h->stream, ea, eb, 0, h->pl, h->pw, h->ctl, h->n,
+    if (dup)  // repeated landmark ids: strictly sequential updates (chunks == 1, in place)
+      hipLaunchKernelGGL((k_fs1_observe<false, true>), grid, dim3(kBlock), lds, h->stream, h->pl, h->pw, h->ctl, h->n,
+                         (const double*)h->z_dev, (int)n_z, len, chunks, model_of(h), h->partial,
+                         (const unsigned int*)h->idx);
+    else if (ea && lazy)
+      hipExtLaunchKernelGGL((k_fs1_observe<true, false>), grid, dim3(kBlock), lds, h->stream, ea, eb, 0, h->pl, h->pw, h->ctl, h->n,
                             (const double*)h->z_dev, (int)n_z, len, chunks, model_of(h), h->partial,
                             (const unsigned int*)h->idx);
     else if (ea)
-      hipExtLaunchKernelGGL(k_fs1_observe<false>, grid, dim3(kBlock), lds, h->stream, ea, eb, 0, h->pl, h->pw, h->ctl, h->n,
+      hipExtLaunchKernelGGL((k_fs1_observe<false, false>), grid, dim3(kBlock), lds, h->stream, ea, eb, 0, h->pl, h->pw, h->ctl, h->n,
                             (const double*)h->z_dev, (int)n_z, len, chunks, model_of(h), h->partial,
                             (const unsigned int*)h->idx);
     else if (lazy)
-      hipLaunchKernelGGL(k_fs1_observe<true>, grid, dim3(kBlock), lds, h->stream, h->pl, h->pw, h->ctl, h->n,
+      hipLaunchKernelGGL((k_fs1_observe<true, false>), grid, dim3(kBlock), lds, h->stream, h->pl, h->pw, h->ctl, h->n,
                          (const double*)h->z_dev, (int)n_z, len, chunks, model_of(h), h->partial,
                          (const unsigned int*)h->idx);
     else
-      hipLaunchKernelGGL(k_fs1_observe<false>, grid, dim3(kBlock), lds, h->stream, h->pl, h->pw, h->ctl, h->n,
+      hipLaunchKernelGGL((k_fs1_observe<false, false>), grid, dim3(kBlock), lds, h->stream, h->pl, h->pw, h->ctl, h->n,
                          (const double*)h->z_dev, (int)n_z, len, chunks, model_of(h), h->partial,
                          (const unsigned int*)h->idx);
   }
@@ -794,6 +817,11 @@ rr_status launch_rest_gather(rr_fs1* h, const double* z, size_t n_z) {
 rr_status fetch_ctl(rr_fs1* h) {
   RR_HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return h->p2p.check(h->stream);  // a latched peer-wait timeout must not look like a healthy filter
+}
+
+rr_status ensure_pose_stage(rr_fs1* h) {
+  if (!h->pose_stage) RR_HIP_TRY(hipMalloc(&h->pose_stage, 4 * h->n * sizeof(double)));
   return RR_OK;
 }
 
@@ -909,6 +937,7 @@ void rr_fs1_destroy(rr_fs1* h) {
   (void)hipFree(h->partial);
   (void)hipFree(h->z_dev);
   (void)hipFree(h->noise);
+  (void)hipFree(h->pose_stage);
   (void)hipFree(h->part_bits);
   (void)hipFree(h->part_idx);
   (void)hipFree(h->plane_list);
@@ -1055,7 +1084,7 @@ rr_status rr_fs1_synchronize(rr_fs1* h) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
-  return RR_OK;
+  return h->p2p.check(h->stream);
 }
 
 rr_status rr_fs1_update(rr_fs1* h, const double u[2], const double* z, size_t n_z) {
@@ -1112,10 +1141,11 @@ rr_status rr_fs1_get_state(rr_fs1* h, double* poses_out, double* maps_out) {
   const int cur = h->ctl_host->cur;
   double* tmp = h->pl.s[cur ^ 1];
   if (poses_out) {
-    hipLaunchKernelGGL(k_fs1_poses, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl.s[cur], h->pw, tmp,
-                       h->n, 1);
+    if ((s = ensure_pose_stage(h)) != RR_OK) return s;
+    hipLaunchKernelGGL(k_fs1_poses, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl.s[cur], h->pw,
+                       h->pose_stage, h->n, 1);
     RR_HIP_TRY(hipGetLastError());
-    RR_HIP_TRY(hipMemcpyAsync(poses_out, tmp, 4 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    RR_HIP_TRY(hipMemcpyAsync(poses_out, h->pose_stage, 4 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     RR_HIP_TRY(hipStreamSynchronize(h->stream));
   }
   if (maps_out && h->L) {
@@ -1141,9 +1171,10 @@ rr_status rr_fs1_set_state(rr_fs1* h, const double* poses, const double* maps) {
   const int cur = h->ctl_host->cur;
   double* tmp = h->pl.s[cur ^ 1];
   if (poses) {
-    RR_HIP_TRY(hipMemcpyAsync(tmp, poses, 4 * h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_fs1_poses, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl.s[cur], h->pw, tmp,
-                       h->n, 0);
+    if ((s = ensure_pose_stage(h)) != RR_OK) return s;
+    RR_HIP_TRY(hipMemcpyAsync(h->pose_stage, poses, 4 * h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_fs1_poses, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl.s[cur], h->pw,
+                       h->pose_stage, h->n, 0);
     RR_HIP_TRY(hipGetLastError());
     RR_HIP_TRY(hipStreamSynchronize(h->stream));
   }

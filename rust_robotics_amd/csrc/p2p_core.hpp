@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -39,6 +40,7 @@ struct P2PPeers {
   double* inbox[kMaxP2P];  // the peers' fine-grained inboxes: where the lazy protocol delivers cross-rank particles
   int n_ranks;
   int rank;
+  uint64_t timeout_ticks;  // bound of one peer wait in 100 MHz wall-clock ticks (RR_P2P_TIMEOUT_MS, default 2 s)
 };
 enum { kP2PWmax = 0, kP2PSums = 1, kP2PDone = 2 };
 
@@ -72,7 +74,9 @@ __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t se
     bool ok = true;
     while (__hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
       __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > 200000000ull) {  // 2 s: a peer is gone; do not hang the device
+      // a peer is gone: do not hang the device.  The first exchanges of a filter get ten times the
+      // budget -- process start-up and code-object loading skew the ranks by far more than a step does
+      if (wall_clock64() - t0 > (seq <= 3 ? 10 * peers.timeout_ticks : peers.timeout_ticks)) {
         ok = false;
         break;
       }
@@ -178,6 +182,23 @@ struct P2PState {
     ready = false;
   }
 
+  static uint64_t timeout_ticks_from_env() {
+    const char* e = std::getenv("RR_P2P_TIMEOUT_MS");
+    double ms = e ? std::atof(e) : 2000.0;
+    if (!(ms > 0.0)) ms = 2000.0;
+    return (uint64_t)(ms * 1e5);  // wall_clock64 ticks at 100 MHz
+  }
+
+  // (re)connecting: forget every record of an earlier connection.  Called before the handles are
+  // exchanged (export) or before any rank is linked (in-process), i.e. before a peer can write.
+  rr_status reset_records() {
+    RR_HIP_TRY(hipMemset(mbox, 0, sizeof(P2PMailbox)));
+    RR_HIP_TRY(hipMemset(err, 0, sizeof(int)));
+    RR_HIP_TRY(hipDeviceSynchronize());
+    seq = 0;
+    return RR_OK;
+  }
+
   rr_status local_setup(size_t inbox_doubles_) {
     if (mbox) return RR_OK;
     inbox_doubles = inbox_doubles_;
@@ -193,8 +214,10 @@ struct P2PState {
   }
 
   rr_status export_handles(double* slab, size_t inbox_doubles_, uint8_t out[kP2PHandleBytes]) {
+    const bool again = mbox != nullptr;
     rr_status s = local_setup(inbox_doubles_);
     if (s != RR_OK) return s;
+    if (again && (s = reset_records()) != RR_OK) return s;
     static_assert(3 * sizeof(hipIpcMemHandle_t) <= kP2PHandleBytes, "handle blob too small");
     hipIpcMemHandle_t hs[3];
     RR_HIP_TRY(hipIpcGetMemHandle(&hs[0], slab));
@@ -231,9 +254,22 @@ struct P2PState {
       p.mbox[g] = (P2PMailbox*)pm;
       p.inbox[g] = (double*)pi;
     }
+    p.timeout_ticks = timeout_ticks_from_env();
     peers = p;
     ready = true;
     seq = 0;
+    return RR_OK;
+  }
+
+  // RR_RUNTIME_ERROR once a peer wait has given up: from then on no exchange runs and no resample is
+  // applied, so results read back after this point would silently be those of a non-resampled filter
+  rr_status check(hipStream_t stream) {
+    if (!ready || !err) return RR_OK;
+    RR_HIP_TRY(hipMemcpyAsync(err_host, err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    RR_HIP_TRY(hipStreamSynchronize(stream));
+    if (*err_host)
+      return fail(RR_RUNTIME_ERROR, "peer-to-peer exchange: a wait for a peer's record timed out (RR_P2P_TIMEOUT_MS); "
+                                    "the sharded filter is no longer consistent -- reconnect or recreate it");
     return RR_OK;
   }
 
@@ -252,8 +288,10 @@ inline rr_status p2p_link_local(P2PState* const* states, double* const* slabs, c
                                 int n_ranks) {
   for (int g = 0; g < n_ranks; ++g) {
     RR_HIP_TRY(hipSetDevice(devices[g]));
+    const bool again = states[g]->mbox != nullptr;
     rr_status s = states[g]->local_setup(inbox_doubles[g]);
     if (s != RR_OK) return s;
+    if (again && (s = states[g]->reset_records()) != RR_OK) return s;
   }
   for (int g = 0; g < n_ranks; ++g) {
     P2PPeers p{};
@@ -274,6 +312,7 @@ inline rr_status p2p_link_local(P2PState* const* states, double* const* slabs, c
       p.mbox[k] = states[k]->mbox;
       p.inbox[k] = states[k]->inbox;
     }
+    p.timeout_ticks = P2PState::timeout_ticks_from_env();
     states[g]->peers = p;
     states[g]->ready = true;
     states[g]->seq = 0;

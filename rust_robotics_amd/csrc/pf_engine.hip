@@ -1126,7 +1126,7 @@ rr_status resample_adaptive(rr_pf* h, const double* r_explicit_dev) {
 rr_status fetch_ctl(rr_pf* h) {
   RR_HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
-  return RR_OK;
+  return h->p2p.check(h->stream);  // a latched peer-wait timeout must not look like a healthy filter
 }
 
 rr_status compute_moments(rr_pf* h, double est[4], double cov[16]) {
@@ -1627,7 +1627,7 @@ rr_status rr_pf_synchronize(rr_pf* h) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
-  return RR_OK;
+  return h->p2p.check(h->stream);
 }
 
 rr_status rr_pf_estimate(rr_pf* h, double out[4]) {
@@ -1706,7 +1706,7 @@ rr_status rr_pf_get_particles(rr_pf* h, double* out_aos) {
   RR_HIP_TRY(hipGetLastError());
   RR_HIP_TRY(hipMemcpyAsync(out_aos, h->scratch_a, 5 * h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
-  return RR_OK;
+  return h->p2p.check(h->stream);
 }
 
 rr_status rr_pf_set_particles(rr_pf* h, const double* aos) {

@@ -297,6 +297,8 @@ class ParticleFilterLocalizer:
         u = _vec(control, 2, "particle filter control input")
         a = np.ascontiguousarray(n_v, dtype=np.float64)
         b = np.ascontiguousarray(n_w, dtype=np.float64)
+        if a.size != self.particle_count() or b.size != self.particle_count():  # the C entry point copies n doubles from each
+            raise RoboticsError.invalid_parameter("need one noise sample per particle")
         _check(self._L.rr_pf_predict_with_noise(self._h, _dp(u), _dp(a), _dp(b)))
         self._cache_valid = False
 

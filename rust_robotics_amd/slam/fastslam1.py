@@ -156,6 +156,8 @@ class FastSlam1:
     def predict_with_noise(self, u, z0, z1) -> None:
         u = np.ascontiguousarray(u, dtype=np.float64)
         a, b = np.ascontiguousarray(z0, dtype=np.float64), np.ascontiguousarray(z1, dtype=np.float64)
+        if a.size != self.n or b.size != self.n:  # the C entry point copies n doubles from each
+            raise RoboticsError.invalid_parameter("need one noise sample per particle")
         _check(self._L.rr_fs1_predict_with_noise(self._h, _dp(u), _dp(a), _dp(b)))
 
     def observe(self, z) -> None:

@@ -113,3 +113,25 @@ def test_config5_per_gpu_shape_properties(loc, det):
     rstep = pf.counters()[1] - 1
     det.det_indices_systematic(n, u64p(cdf), fx["total"], n, 0, n, det.det_resample_rho(2, rstep), u32p(e))
     assert np.array_equal(idx, e)
+
+
+def test_fastslam_without_landmarks():
+    """create_particles(n, 0) is legal in the reference (fastslam1.rs:302-306): poses only.  The AoS pose
+    image (4 doubles per particle) must not be staged in a buffer set that holds 3 planes."""
+    from rust_robotics_amd.slam import fastslam1 as fs
+
+    n = 3000
+    f = fs.FastSlam1(n, 0, seed=5)
+    rng = np.random.default_rng(6)
+    poses = np.column_stack([np.full(n, 1.0 / n), rng.normal(0, 1, n), rng.normal(0, 1, n), rng.uniform(-3, 3, n)])
+    for _ in range(2):  # both buffer sets take a turn as "the inactive one"
+        f.set_state(poses, None)
+        got = f.get_poses()
+        assert bits_eq(got, poses)
+        f.update([1.0, 0.1], [])
+        f.resample_systematic(0.25)
+        moved = f.get_poses()
+        assert np.all(np.isfinite(moved)) and moved.shape == (n, 4)
+        assert np.allclose(moved[:, 0], 1.0 / n)
+    pose, w, i = f.best_particle()
+    assert 0 <= i < n and np.all(np.isfinite(pose))

@@ -146,6 +146,57 @@ def test_observe_ekf_matches_oracles(fs, det, ref, n, L, chunks):
         np.testing.assert_allclose(gp[big, 0], rw[big], rtol=1e-6)
 
 
+@pytest.mark.parametrize("first_obs_cov", [None, 10.0])
+def test_adjacent_duplicate_ids_update_sequentially(fs, det, ref, first_obs_cov):
+    """fastslam1.rs:250-256 runs a step's observations one after the other, so a landmark that is
+    observed twice in a row gets init-then-EKF (or EKF-then-EKF): the second update must see the
+    first one's result.  Adjacent repeats are the case a software-pipelined plane load gets wrong."""
+    n, L = 700, 3
+    lms = scene(L, 61)
+    if first_obs_cov is None:  # maps initialised: EKF branch twice
+        poses, maps = make_state(n, L, lms, 62)
+        f = fs.FastSlam1(n, L, obs_chunks=0)
+    else:  # fresh maps (cov = 1000 I): initialise on the first observation, EKF on the repeat
+        prm = fs.default_params()
+        prm.first_obs_cov = first_obs_cov
+        poses, maps = make_state(n, L, lms, 62)
+        maps[:] = np.array([0, 0, 1000.0, 0, 0, 1000.0])
+        f = fs.FastSlam1(n, L, params=prm, obs_chunks=0)
+    z1 = observations_for(fs, np.array([0.0, 0.0, 0.0]), lms, seed=63, step=0)
+    z2 = observations_for(fs, np.array([0.0, 0.0, 0.0]), lms, seed=63, step=1)
+    # ids 1, 1, 0, 0, 2, 1: two adjacent repeats and a distant one
+    z = np.ascontiguousarray(np.vstack([z1[1], z2[1], z1[0], z2[0], z1[2], z1[1]]))
+    f.set_state(poses, maps)
+    f.observe(z)
+    assert f.counters()[2] == 1  # repeated ids force a single chunk
+    gp, gm = f.get_state()
+    px, py, pyaw, pw = (np.array(poses[:, k], dtype=np.float64, order='C', copy=True) for k in (1, 2, 3, 0))
+    planes = oracle.maps_aos_to_planes(maps, n, L)
+    md = oracle.det_fs1_model()
+    if first_obs_cov is not None:
+        md.init_cov = first_obs_cov
+    det.det_fs1_observe(n, dp(px), dp(py), dp(pyaw), dp(pw), dp(planes), dp(z), len(z), C.byref(md), 1)
+    assert bits_equal(gp[:, 0], pw), "accumulated weights"
+    assert bits_equal(gm.reshape(-1), oracle.maps_planes_to_aos(planes, n, L)), "maps"
+    if first_obs_cov is not None:
+        assert np.ptp(gp[:, 0]) > 0.0, "the repeat of a freshly initialised landmark must take the EKF branch and reweight"
+    # literal reference: observation outer, particle inner
+    rw = np.array(poses[:, 0], copy=True)
+    rm = maps.copy().reshape(-1)
+    mr = oracle.ref_fs1_model()
+    if first_obs_cov is not None:
+        mr.init_cov = first_obs_cov
+    for k in range(len(z)):
+        for p in range(n):
+            wv = C.c_double(rw[p])
+            e = rm[(p * L + int(z[k, 2])) * 6:(p * L + int(z[k, 2])) * 6 + 6]
+            ref.ref_fs1_update_landmark(poses[p, 1], poses[p, 2], poses[p, 3], C.byref(wv), z[k, 0], z[k, 1], dp(e), C.byref(mr))
+            rw[p] = wv.value
+    np.testing.assert_allclose(gm.reshape(-1), rm, **TOL)
+    big = rw > 1e-250
+    np.testing.assert_allclose(gp[big, 0], rw[big], rtol=1e-6)
+
+
 def test_first_observation_branch_reference_quirk(fs, det):
     """Q11: with the reference's parameters the first observation sets x,y and leaves cov at 1000,
     so the weights never change through fastslam_update alone; first_obs_cov switches that."""

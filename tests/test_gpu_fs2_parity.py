@@ -156,8 +156,10 @@ def test_duplicate_observations_and_parameter_validation(fs2, det):
     idx = np.empty(n, np.uint32)
     for t in range(8):
         z = obs_for(fs2, H.true_pose(t + 1), lms, seed=31, step=t)
-        if t % 2:
+        if t % 4 == 1:
             z = np.ascontiguousarray(np.vstack([z, z[1:2], z[0:1]]))  # landmarks 1 and 0 observed twice
+        elif t % 4 == 3:  # ADJACENT repeats (incl. init-then-EKF of a landmark on its first step when t == 3 is its first sighting)
+            z = np.ascontiguousarray(np.vstack([z[0:1], z[0:1], z[1:], z[-1:]]))
         f.update([1.0, 0.1], z)
         fired = det.det_fs2_update(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(planes), 1.0, 0.1, dp(z), len(z), C.byref(m), None,
                                    n / 1.5, 31, t, t, f.counters()[2], u32p(idx))
