@@ -1,16 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- particle-landmark updates/s of the MCL hot path on N MI355X.
+"""bench.py -- particle-landmark updates/s of the sampling-based localization hot path on N MI355X.
 
-Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched
-under torch.distributed.run with one rank per GPU.  One "step" = one full pass of the hot path
-(propagate + weight + resample) over the whole particle set; the workload at N = 1 is
-BASELINE.json configs[1]: fixed-N MCL, 1 000 000 particles x 32 landmarks, resampling every step
-(weak scaling: 1e6 particles per GPU).  Prints ONE JSON line on rank 0.
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``.  For N > 1 the driver launches it
+under torch.distributed.run with one rank per GPU; started WITHOUT a launcher (``python bench.py --gpus 8``
+from a bare shell) it re-executes itself under ``python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1`` and forwards the ranks' output.  One "step" = one full pass of
+the hot path over the whole particle set.  Prints ONE JSON line on rank 0.
+
+What the line holds
+  headline      BASELINE.json configs[1]: fixed-N MCL, 1 000 000 particles per GPU x 32 landmarks, propagate +
+                weight + resample every step (weak scaling over N GPUs: contiguous particle blocks, RCCL / xGMI
+                peer-to-peer exchange of the weight maximum, the integer sums and the migrating particles).
+  "fastslam"    N = 1: BASELINE.json configs[2], FastSLAM 1.0, 100 000 particles x 200 landmarks (the HBM-bound
+                workload) -- value, ms_per_step, roofline{}, cpu_baseline{} of its own, measured in the same run.
+  "fastslam_sharded", "mcl_config5"
+                N = 8 (or --all-legs): BASELINE.json configs[3] (1e6 x 200 over 8 GPUs = 125 000 per GPU) and
+                configs[4] (1.6e7 x 64 over 8 GPUs = 2e6 per GPU).
+``--workload fastslam|fastslam2`` prints that workload's line alone (rocprofv3 runs use this).
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,25 +33,40 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
+FP64_VALU_PEAK = 256 * 4 * 16 * 2.4e9  # FP64 FMA lane-instructions / s: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 3.93e13
 # algorithmic HBM bytes per particle of the dominant kernel: read x,y,yaw (24 B) + write
 # x,y,yaw,v,w (40 B); the systematic path's k_step_lazy also reads and clears the 4-byte resample marker
 K1_BYTES = {"systematic": 72.0, "multinomial": 64.0}
+FS1_BYTES_PER_UPDATE = 96.0  # k_fs1_observe: read 48 B + write 48 B per (particle, observed landmark), EKF branch
 
 
 def measured_traffic(kernel_prefix, workload):
-    """HBM bytes per launch of `kernel_prefix` from the committed PMC passes (separate
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, read side doubled as MI355X_MICROARCH.md
-    prescribes for gfx950): profiles/r01c_pmc_hbm_traffic.csv.  None if the file is absent."""
+    """HBM bytes per launch of `kernel_prefix` from the committed PMC passes (separate rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE runs, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    Newest round first; None if no file has the row."""
     import csv
 
-    for name, wl in (("r01f_pmc_hbm_traffic_fastslam_timed_region.csv", workload + "_timed_region"), ("r01c_pmc_hbm_traffic.csv", workload)):
+    for name, wl in (("r02_pmc_hbm_traffic.csv", workload), ("r01f_pmc_hbm_traffic_fastslam_timed_region.csv", workload + "_timed_region"),
+                     ("r01c_pmc_hbm_traffic.csv", workload)):
         try:
             for r in csv.DictReader(open(os.path.join(ROOT, "profiles", name))):
                 if r["workload"] == wl and r["kernel"].startswith(kernel_prefix):
-                    return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6
+                    return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6, "profiles/" + name
         except Exception:
             pass
-    return None
+    return None, None
+
+
+def host_cpu():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count() or 1
 
 
 def make_scene(L, steps, seed):
@@ -49,42 +77,62 @@ def make_scene(L, steps, seed):
     return [H.observations(lms, H.true_pose(t + 1), 0.2, rng) for t in range(steps)]
 
 
-def cpu_baseline(n, L, obs_list, max_seconds=25.0):
-    """The literal C restatement of the reference (oracle/ref_literal.c), one host core,
-    same workload; runs whole steps until ~max_seconds have elapsed."""
+# ------------------------------------------------------------------------------------------------------
+# CPU baselines: oracle/ref_literal.c (the reference's arithmetic restated line by line) timed on this
+# box's host cores.  SURVEY.md 8d: per-particle stages under OpenMP on all cores, cumsum / resample walk
+# serial as in the reference; the reference's own O(N^2) multinomial resample timed separately at N = 1e4.
+def cpu_baseline(n, L, obs_list, max_seconds=12.0):
     import oracle
     from oracle import dp, u32p
 
     ref = oracle.ref()
     det = oracle.det()
-    x, y, yaw, v = (np.zeros(n) for _ in range(4))
-    st = np.array([0.0, 0.0, 0.0, 1.0])
-    det.det_pf_init(n, 1, 0, dp(st), dp(x), dp(y), dp(yaw), dp(v))
-    w = np.full(n, 1.0 / n)
-    idx = np.empty(n, np.uint32)
-    est = np.empty(4)
+    model, nproc = host_cpu()
     sv, sw = 2.0, math.radians(40.0)
-    z0, z1, r, r2 = (np.empty(n) for _ in range(4))
-    steps = 0
-    t_total = 0.0
-    while steps < len(obs_list) and t_total < max_seconds:
-        obs = np.ascontiguousarray(obs_list[steps])
-        # noise generation is not part of the reference's timed arithmetic budget here: the
-        # reference draws from ChaCha12/ziggurat; we hand it ready samples (DESIGN.md)
-        det.det_normal2_v(1, 3, steps, 0, n, dp(z0), dp(z1))
-        det.det_uniform2_v(1, 4, steps, 0, n, dp(r), dp(r2))
-        nv, nw = sv * z0, sw * z1
-        t0 = time.perf_counter()
-        ref.ref_pf_step(n, dp(x), dp(y), dp(yaw), dp(v), dp(w), 1.0, 0.1, 0.1, dp(nv), dp(nw), dp(obs), L, 0.2, 1.0, 1,
-                        dp(r), u32p(idx), dp(est))
-        t_total += time.perf_counter() - t0
-        steps += 1
-    return dict(value=n * L * steps / t_total, unit="particle-landmark updates/s", cores=1, kind="port",
-                sample=f"oracle/ref_literal.c ref_pf_step (literal reference arithmetic, binary-search multinomial "
-                       f"resample), {n} particles x {L} landmarks x {steps} steps, {t_total:.1f} s, noise samples pre-drawn")
 
+    def run(threads, n_run, budget, literal_scan, scheme):
+        used = ref.ref_set_threads(threads)
+        x, y, yaw, v = (np.zeros(n_run) for _ in range(4))
+        st = np.array([0.0, 0.0, 0.0, 1.0])
+        det.det_pf_init(n_run, 1, 0, dp(st), dp(x), dp(y), dp(yaw), dp(v))
+        w = np.full(n_run, 1.0 / n_run)
+        idx = np.empty(n_run, np.uint32)
+        est = np.empty(4)
+        z0, z1, r, r2 = (np.empty(n_run) for _ in range(4))
+        steps, t_total = 0, 0.0
+        while steps < len(obs_list) and t_total < budget:
+            obs = np.ascontiguousarray(obs_list[steps])
+            # noise generation is not part of the timed arithmetic: the reference draws from ChaCha12/ziggurat,
+            # we hand it ready samples
+            det.det_normal2_v(1, 3, steps, 0, n_run, dp(z0), dp(z1))
+            det.det_uniform2_v(1, 4, steps, 0, n_run, dp(r), dp(r2))
+            nv, nw = sv * z0, sw * z1
+            t0 = time.perf_counter()
+            ref.ref_pf_step_ex(n_run, dp(x), dp(y), dp(yaw), dp(v), dp(w), 1.0, 0.1, 0.1, dp(nv), dp(nw), dp(obs), L, 0.2, 1.0, scheme,
+                               dp(r), u32p(idx), dp(est), 1 if literal_scan else 0)
+            dt = time.perf_counter() - t0
+            if steps or budget < 1.0:  # the first step also pays for the thread team's creation
+                t_total += dt
+            steps += 1
+        ref.ref_set_threads(1)
+        timed = max(steps - (0 if budget < 1.0 else 1), 1)
+        return n_run * L * timed / max(t_total, 1e-9), used, timed, t_total
 
-FS1_BYTES_PER_UPDATE = 96.0  # k_fs1_observe: read 48 B + write 48 B per (particle, observed landmark), EKF branch
+    v_all, cores, s_all, t_all = run(0, n, max_seconds, False, 1)
+    v_one, _, s_one, t_one = run(1, n, max_seconds / 2, False, 1)
+    # the reference's own resample: a linear scan of the cumulative weights per draw (particle_filter.rs:455-470),
+    # gate forced open (threshold 1.0 + scheme 0 fires whenever N_eff < N, i.e. always after a weight update)
+    n_f = min(n, 10_000)
+    v_f, _, s_f, t_f = run(0, n_f, 4.0, True, 0)
+    return dict(value=v_all, unit="particle-landmark updates/s", cores=cores, kind="port",
+                sample=f"oracle/ref_literal.c ref_pf_step (literal reference arithmetic; predict / weight / gather under OpenMP on "
+                       f"{cores} threads, cumsum + binary-search multinomial resample serial), {n} particles x {L} landmarks x {s_all} "
+                       f"steps, {t_all:.1f} s, noise samples pre-drawn",
+                host={"cpu_model": model, "nproc": nproc, "threads": cores},
+                single_thread={"value": v_one, "steps": s_one, "seconds": round(t_one, 2)},
+                reference_faithful={"value": v_f, "particles": n_f, "steps": s_f, "seconds": round(t_f, 2), "threads": cores,
+                                    "note": "the reference's own O(N^2) resample (linear scan per draw, particle_filter.rs:455-470); "
+                                            "infeasible at 1e6 particles (~5e11 compares per step), so measured at N = 1e4 and never extrapolated"})
 
 
 def fs1_scene(L, seed, half=13.0):
@@ -92,42 +140,57 @@ def fs1_scene(L, seed, half=13.0):
     return rng.uniform(-half, half, size=(L, 2))
 
 
-def fs1_cpu_baseline(n, L, z_list, max_seconds=20.0):
-    """fastslam_update of the literal C restatement (oracle/ref_literal.c), one host core."""
+def fs1_cpu_baseline(n, L, z_list, max_seconds=10.0):
+    """fastslam_update of the literal C restatement (oracle/ref_literal.c), all host cores + one core."""
     import ctypes as C
 
     import oracle
     from oracle import dp, u32p
 
     ref, det = oracle.ref(), oracle.det()
-    m = oracle.ref_fs1_model()
-    m.init_cov = 0.5
-    px, py, pyaw = (np.zeros(n) for _ in range(3))
-    pw = np.full(n, 0.01)
-    lm = np.tile(np.array([0, 0, 1000.0, 0, 0, 1000.0]), (n, L, 1)).reshape(-1).copy()
-    idx = np.empty(n, np.uint32)
-    z0, z1 = np.empty(n), np.empty(n)
-    steps, t_total, updates = 0, 0.0, 0
-    while steps < len(z_list) and t_total < max_seconds:
-        z = np.ascontiguousarray(z_list[steps])
-        det.det_normal2_v(2, 3, steps, 0, n, dp(z0), dp(z1))
-        t0 = time.perf_counter()
-        ref.ref_fs1_update(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(lm), 0.5, 0.1, dp(z0), dp(z1), dp(z), len(z), C.byref(m),
-                           n / 1.5, 0.3 / n, u32p(idx))
-        t_total += time.perf_counter() - t0
-        updates += n * len(z)
-        steps += 1
-    return dict(value=updates / t_total, unit="particle-landmark updates/s", cores=1, kind="port",
-                sample=f"oracle/ref_literal.c ref_fs1_update (literal fastslam1.rs arithmetic), {n} particles x {L} landmarks x "
-                       f"{steps} steps (first step takes the initialisation branch), {t_total:.1f} s")
+    model, nproc = host_cpu()
+
+    def run(threads, budget):
+        used = ref.ref_set_threads(threads)
+        m = oracle.ref_fs1_model()
+        m.init_cov = 0.5
+        px, py, pyaw = (np.zeros(n) for _ in range(3))
+        pw = np.full(n, 0.01)
+        lm = np.tile(np.array([0, 0, 1000.0, 0, 0, 1000.0]), (n, L, 1)).reshape(-1).copy()
+        idx = np.empty(n, np.uint32)
+        z0, z1 = np.empty(n), np.empty(n)
+        steps, t_total, updates = 0, 0.0, 0
+        while steps < len(z_list) and t_total < budget:
+            z = np.ascontiguousarray(z_list[steps])
+            det.det_normal2_v(2, 3, steps, 0, n, dp(z0), dp(z1))
+            t0 = time.perf_counter()
+            ref.ref_fs1_update(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(lm), 0.5, 0.1, dp(z0), dp(z1), dp(z), len(z), C.byref(m),
+                               n / 1.5, 0.3 / n, u32p(idx))
+            dt = time.perf_counter() - t0
+            if steps:  # step 0 takes the initialisation branch and creates the thread team
+                t_total += dt
+                updates += n * len(z)
+            steps += 1
+        ref.ref_set_threads(1)
+        return updates / max(t_total, 1e-9), used, steps - 1, t_total
+
+    v_all, cores, s_all, t_all = run(0, max_seconds)
+    v_one, _, s_one, t_one = run(1, max_seconds / 2)
+    return dict(value=v_all, unit="particle-landmark updates/s", cores=cores, kind="port",
+                sample=f"oracle/ref_literal.c ref_fs1_update (literal fastslam1.rs arithmetic; predict / EKF / clone under OpenMP on {cores} "
+                       f"threads, normalise + systematic walk serial), {n} particles x {L} landmarks x {s_all} EKF-branch steps, {t_all:.1f} s",
+                host={"cpu_model": model, "nproc": nproc, "threads": cores},
+                single_thread={"value": v_one, "steps": s_one, "seconds": round(t_one, 2)})
 
 
-def fs2_cpu_baseline(n, L, z_list, max_seconds=20.0):
-    """fastslam2_update of the literal C restatement (oracle/ref_literal.c), one host core."""
+def fs2_cpu_baseline(n, L, z_list, max_seconds=10.0):
+    """fastslam2_update of the literal C restatement (oracle/ref_literal.c), all host cores."""
     import oracle
     from oracle import dp, u32p
 
     ref = oracle.ref()
+    model, nproc = host_cpu()
+    cores = ref.ref_set_threads(0)
     px, py, pyaw = (np.zeros(n) for _ in range(3))
     pw = np.full(n, 0.01)
     lm = np.tile(np.array([0, 0, 1000.0, 0, 0, 1000.0]), (n, L, 1)).reshape(-1).copy()
@@ -139,24 +202,73 @@ def fs2_cpu_baseline(n, L, z_list, max_seconds=20.0):
         noise = np.ascontiguousarray(rng.normal(size=(n, 3)))
         t0 = time.perf_counter()
         ref.ref_fs2_update(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(lm), 0.5, 0.1, dp(noise), dp(z), len(z), n / 1.5, 0.3 / n, u32p(idx))
-        t_total += time.perf_counter() - t0
-        updates += n * len(z)
+        dt = time.perf_counter() - t0
+        if steps:
+            t_total += dt
+            updates += n * len(z)
         steps += 1
-    return dict(value=updates / t_total, unit="particle-landmark updates/s", cores=1, kind="port",
-                sample=f"oracle/ref_literal.c ref_fs2_update (literal fastslam2.rs arithmetic), {n} particles x {L} landmarks x "
-                       f"{steps} steps (first step takes the initialisation branch), {t_total:.1f} s, normals pre-drawn")
+    ref.ref_set_threads(1)
+    return dict(value=updates / max(t_total, 1e-9), unit="particle-landmark updates/s", cores=cores, kind="port",
+                sample=f"oracle/ref_literal.c ref_fs2_update (literal fastslam2.rs arithmetic, OpenMP over particles on {cores} threads), "
+                       f"{n} particles x {L} landmarks x {steps - 1} steps, {t_total:.1f} s, normals pre-drawn",
+                host={"cpu_model": model, "nproc": nproc, "threads": cores})
 
 
-def run_fastslam(args):
+# ------------------------------------------------------------------------------------------------------
+class Ctx:
+    """rank / world / device of this process and, for world > 1 (or --force-sharded), the gloo group that
+    carries bootstrap data and the timing barrier (never particle data)."""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.sharded = self.world > 1 or args.force_sharded
+        self.dist = None
+
+    def init_group(self):
+        if self.dist is not None or not self.sharded:
+            return
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")  # a lone rank started without a launcher
+        dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+        self.dist = dist
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+            self.dist = None
+
+
+def require_devices(ctx):
+    """The engine has no CPU fallback: say so once, clearly, instead of failing somewhere inside a rank."""
+    from rust_robotics_amd import _ffi
+
+    have = int(_ffi.lib().rr_device_count())
+    need = ctx.local_rank + 1
+    if have < need:
+        msg = (f"bench.py: no HIP device available for rank {ctx.rank} (local rank {ctx.local_rank}; {have} device(s) visible) -- "
+               f"the engine has no CPU fallback; run on an MI355X box")
+        if ctx.dist is not None:
+            try:
+                ctx.close()
+            except Exception:
+                pass
+        raise SystemExit(msg)
+
+
+# ------------------------------------------------------------------------------------------------------
+def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True):
     """BASELINE.json configs[2]: FastSLAM 1.0, 100 000 particles x 200 landmarks, every landmark observed
     every step, EKF branch (first_obs_cov = 0.5 initialises the maps on the first, untimed, step),
     N_eff threshold N/1.5 so that resampling triggers data-dependently."""
     from rust_robotics_amd.slam import fastslam1 as fs
     from tests import helpers as H
 
-    n, L, K, W = args.particles, args.landmarks, args.steps, args.warmup
     lms = fs1_scene(L, 2)
-    v2 = args.workload == "fastslam2"
     if v2:  # the same configuration with the FastSLAM 2.0 proposal (fastslam2.rs); first_obs_cov = 10 is its own constant
         from rust_robotics_amd.slam import fastslam2 as fs2
 
@@ -169,7 +281,7 @@ def run_fastslam(args):
         prm.nth = n / 1.5
         f = fs.FastSlam1(n, L, params=prm, seed=2)
     zs = [np.array(fs.get_observations(H.true_pose(t + 1, v=0.5), [tuple(p) for p in lms], seed=2, step=t)).reshape(-1, 3)
-          for t in range(K + W)]
+          for t in range(2 * K + W)]
     u = [0.5, 0.1]
     for t in range(W):
         f.update_async(u, zs[t])
@@ -184,23 +296,26 @@ def run_fastslam(args):
     dt = time.perf_counter() - t0
     k_n, k_ms = f.profile_read()["k_fs1_observe"]
     updates = float(sum(n * len(zs[t]) for t in range(W, W + K)))
-    # per-kernel breakdown: instrumented CONTINUATION over the same inputs (HIP events around every launch;
-    # the filter has moved on, so these averages belong to later, calmer steps -- informational only)
+    # per-kernel breakdown: instrumented CONTINUATION (HIP events around every launch; the filter has moved
+    # on, so these averages belong to later steps -- informational only)
     prof, dt_i = {"k_fs1_observe": (k_n, k_ms)}, 0.0
-    if not args.no_breakdown:
+    if breakdown:
         f.profile_enable(1)
         f.profile_reset()
         t1 = time.perf_counter()
-        for t in range(W, W + K):
+        for t in range(W + K, W + 2 * K):
             f.update_async(u, zs[t])
         f.synchronize()
         dt_i = time.perf_counter() - t1
         prof = f.profile_read()
     f.profile_enable(0)
     pose, w, i = f.best_particle()
+    chunks = f.counters()[2]
+    del f
     avg_s = k_ms / max(k_n, 1) * 1e-3
     per_launch = FS1_BYTES_PER_UPDATE * n * np.mean([len(zs[t]) for t in range(W, W + K)])
-    achieved = per_launch / avg_s
+    achieved = per_launch / avg_s if avg_s > 0 else 0.0
+    traffic, traffic_src = measured_traffic("k_fs1_observe", "fs1") if (n, L) == (100_000, 200) and not v2 else (None, None)
     out = {
         "metric": "particle-landmark updates/sec", "value": updates / dt, "unit": "particle-landmark updates/s", "n_gpus": 1,
         "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -210,90 +325,125 @@ def run_fastslam(args):
                                f"{n} particles x {L} landmarks, all observed, 2x2 EKF branch, N_eff-gated systematic resample",
                    "particles_per_gpu": n, "landmarks": L},
         "roofline": {"bound": "hbm", "kernel": "k_fs1_observe", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK,
-                     "traffic": measured_traffic("k_fs1_observe", "fs1") if (n, L) == (100_000, 200) and not v2 else None,
-                     "traffic_source": "profiles/r01f_pmc_hbm_traffic_fastslam_timed_region.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                       "passes over `bench.py --workload fastslam --no-breakdown`, bytes per launch, read side x2)",
+                     "frac": achieved / HBM_PEAK, "traffic": traffic,
+                     "traffic_source": (traffic_src or "") + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --workload fastslam "
+                                       "--no-breakdown`, bytes per launch, read side x2)" if traffic_src else None,
                      "avg_kernel_ms": avg_s * 1e3, "timed_launches": k_n,
                      "timing": "dispatch timestamps of the K launches inside the timed region",
                      "algorithmic_bytes_per_launch": per_launch},
         "kernel_ms_avg": {k: v[1] / max(v[0], 1) for k, v in prof.items() if v[0]},
         "kernel_launches": {k: v[0] for k, v in prof.items() if v[0]},
         "ms_per_step_instrumented": dt_i / K * 1e3,
-        "obs_chunks": f.counters()[2],
+        "obs_chunks": chunks,
         "best_particle": {"index": i, "weight": w, "pose": [float(a) for a in pose]},
     }
-    if not args.no_cpu_baseline:
+    if with_cpu:
         out["cpu_baseline"] = (fs2_cpu_baseline if v2 else fs1_cpu_baseline)(min(n, 20000), L, zs)
-    emit(out)
+    return out
 
 
-def run_fastslam_sharded(args, rank, world, local_rank):
+def leg_fastslam_sharded(ctx, n, L, K, W):
     """BASELINE.json configs[3] shape: FastSLAM 1.0 sharded over the GPUs of a node (125 000 particles x 200
-    landmarks per GPU at 8 GPUs = 1e6 x 200), weak scaling.  The step runs over the peer-to-peer transport
-    (include/rr_fastslam1.h rr_fs1_shard_update_p2p); torch.distributed (gloo) only carries the IPC handles and
-    the timing barrier.  Before anything is timed every rank checks, on this machine, that a small sharded run
-    reproduces its block of the unsharded filter bit for bit."""
+    landmarks per GPU at 8 GPUs = 1e6 x 200), weak scaling.  Transport ladder as for MCL: the peer-to-peer
+    transport (rr_fs1_shard_update_p2p) is timed iff it connects and reproduces its block of the unsharded
+    filter bit for bit on this machine; otherwise the RCCL transport (rr_fs1_shard_update: all-reduce MAX,
+    all-gather of the integer sums, grouped send/recv of whole particles) -- itself validated the same way."""
     import torch
-    import torch.distributed as dist
 
-    from rust_robotics_amd.sharded import gloo_allgather
+    from rust_robotics_amd.sharded import gloo_allgather, gloo_exchange
     from rust_robotics_amd.slam import fastslam1 as fs
     from tests import helpers as H
 
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29555")  # a lone rank started without a launcher
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    torch.cuda.set_device(local_rank)
-    n, L, K, W = args.particles, args.landmarks, args.steps, args.warmup
+    dist = ctx.dist
+    rank, world, local_rank = ctx.rank, ctx.world, ctx.local_rank
     u = [0.5, 0.1]
+    notes = []
+
+    def agree(ok):
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
 
     def observations(lms, steps, seed):
         return [np.array(fs.get_observations(H.true_pose(t + 1, v=0.5), [tuple(p) for p in lms], seed=seed, step=t)).reshape(-1, 3)
                 for t in range(steps)]
 
-    def make(n_local, Lm, chunks):
+    def params(n_local):
         prm = fs.default_params()
         prm.first_obs_cov = 0.5
         prm.nth = n_local * world / 1.5
         prm.initial_weight = 1.0 / (n_local * world)
-        f = fs.ShardedFastSlam1(rank, world, n_local, Lm, device=local_rank, params=prm, seed=2, obs_chunks=chunks)
-        f.connect_ipc(gloo_allgather(dist))
-        return f, prm
+        return prm
 
-    # run-time validation of the cross-GPU hand-off
+    def make(kind, n_local, Lm, chunks):
+        f = fs.ShardedFastSlam1(rank, world, n_local, Lm, device=local_rank, params=params(n_local), seed=2, obs_chunks=chunks)
+        if kind == "p2p":
+            f.connect_ipc(gloo_allgather(dist))
+        else:
+            f.connect_rccl(gloo_exchange(dist))
+        return f
+
+    def attempt(kind, *a):
+        obj, err = None, None
+        try:
+            obj = make(kind, *a)
+        except Exception as e:  # noqa: BLE001 -- any failure means "next rung of the ladder"
+            err = f"{type(e).__name__}: {e}"
+        if agree(obj is not None):
+            return obj
+        notes.append(f"{kind} transport unavailable" + (f" ({err})" if err else " (failed on another rank)"))
+        if obj is not None:
+            obj.close()
+        return None
+
+    # run-time validation of the cross-GPU hand-off on a small filter
     nv, Lv, Sv = 4096, 8, 8
-    fv, prm_v = make(nv, Lv, 2)
     zv = observations(fs1_scene(Lv, 3), Sv, 3)
-    dist.barrier()
-    for z in zv:
-        fv.update_async(u, z)
-    ok = not fv.timed_out()
-    if ok:
-        whole = fs.FastSlam1(nv * world, Lv, params=prm_v, seed=2, device=local_rank, obs_chunks=2)
-        for z in zv:
-            whole.update_async(u, z)
-        ep, em = whole.get_state()
-        gp, gm = fv.get_state()
-        sl = slice(rank * nv, (rank + 1) * nv)
-        ok = np.array_equal(gp.view(np.uint64), ep[sl].view(np.uint64)) and np.array_equal(gm.view(np.uint64), em[sl].view(np.uint64))
-        del whole
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    dist.barrier()
-    # host-runtime warm-up: in a process that has torch's HIP context loaded, the first ~50 updates of the first
-    # big filter are enqueued at ~0.85 ms each instead of ~0.05 ms (measured, scratch experiment in DESIGN.md
-    # section 6); spend them on the small validation filter instead of inside the timed region
-    for k in range(96):
-        fv.update_async(u, zv[k % Sv])
-    fv.synchronize()
-    dist.barrier()
-    del fv
-    if not flag.item():
-        raise SystemExit("sharded FastSLAM: the peer-to-peer transport did not reproduce the unsharded filter on this machine")
 
-    f, _ = make(n, L, 0)
-    zs = observations(fs1_scene(L, 2), K + W, 2)
+    def validate(fv):
+        ok = True
+        try:
+            for z in zv:
+                fv.update_async(u, z)
+            fv.synchronize()
+            ok = not fv.timed_out()
+        except Exception:  # a latched peer-wait timeout surfaces as an error
+            ok = False
+        if ok:
+            whole = fs.FastSlam1(nv * world, Lv, params=params(nv), seed=2, device=local_rank, obs_chunks=2)
+            for z in zv:
+                whole.update_async(u, z)
+            ep, em = whole.get_state()
+            gp, gm = fv.get_state()
+            sl = slice(rank * nv, (rank + 1) * nv)
+            ok = np.array_equal(gp.view(np.uint64), ep[sl].view(np.uint64)) and np.array_equal(gm.view(np.uint64), em[sl].view(np.uint64))
+            del whole
+        return agree(ok)
+
+    kind = None
+    for cand in (("p2p", "rccl") if ctx_transport(ctx) == "auto" else (ctx_transport(ctx),)):
+        fv = attempt(cand, nv, Lv, 2)
+        if fv is None:
+            continue
+        dist.barrier()
+        good = validate(fv)
+        if good:
+            # host-runtime warm-up: in a process that has torch's HIP context loaded, the first ~50 updates of the first
+            # big filter are enqueued at ~0.85 ms each instead of ~0.05 ms (DESIGN.md section 6); spend them here
+            for k in range(96):
+                fv.update_async(u, zv[k % Sv])
+            fv.synchronize()
+        dist.barrier()
+        fv.close()
+        notes.append(f"{cand} transport " + ("validated bit-identical to the unsharded filter" if good else "FAILED validation against the unsharded filter"))
+        if good:
+            kind = cand
+            break
+    if kind is None:
+        return {"error": "sharded FastSLAM: no transport reproduced the unsharded filter on this machine", "transport_note": "; ".join(notes)}
+
+    f = make(kind, n, L, 0)
+    zs = observations(fs1_scene(L, 2), 2 * K + W, 2)
 
     def fence():
         f.synchronize()
@@ -319,7 +469,7 @@ def run_fastslam_sharded(args, rank, world, local_rank):
     f.profile_enable(1)
     f.profile_reset()
     t1 = time.perf_counter()
-    for t in range(W, W + K):
+    for t in range(W + K, W + 2 * K):
         f.update_async(u, zs[t])
     f.synchronize()
     dt_i = time.perf_counter() - t1
@@ -327,41 +477,47 @@ def run_fastslam_sharded(args, rank, world, local_rank):
     f.profile_enable(0)
     chunks = f.counters()[2]
     dist.barrier()
-    del f
-    dist.destroy_process_group()
-    if rank != 0:
-        return
+    f.close()
     seconds = float(tmax.item())
     updates = float(sum(n * world * len(zs[t]) for t in range(W, W + K)))
     k_n, k_ms = dom
     avg_s = k_ms / max(k_n, 1) * 1e-3
     per_launch = FS1_BYTES_PER_UPDATE * n * np.mean([len(zs[t]) for t in range(W, W + K)])
-    achieved = per_launch / avg_s
-    emit({
+    achieved = per_launch / avg_s if avg_s > 0 else 0.0
+    return {
         "metric": "particle-landmark updates/sec", "value": updates / seconds, "unit": "particle-landmark updates/s", "n_gpus": world,
         "steps": K, "warmup": W, "ms_per_step": seconds / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"FastSLAM 1.0 sharded (BASELINE.json configs[3] shape): {n} particles x {L} landmarks per GPU, "
                                f"{n * world} particles over {world} GPU(s), all landmarks observed, 2x2 EKF branch, N_eff-gated "
                                f"global systematic resample", "particles_per_gpu": n, "landmarks": L,
-                   "transport": "p2p (xGMI, device-initiated); validated bit-identical to the unsharded filter at run time"},
+                   "transport": ("p2p (xGMI, device-initiated)" if kind == "p2p" else "RCCL (all-reduce MAX, all-gather sums, grouped send/recv of whole particles)"),
+                   "transport_note": "; ".join(notes)},
         "roofline": {"bound": "hbm", "kernel": "k_fs1_observe", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": None, "avg_kernel_ms": avg_s * 1e3,
                      "algorithmic_bytes_per_launch": per_launch},
         "kernel_ms_avg": {k: v[1] / max(v[0], 1) for k, v in prof.items() if v[0]},
         "kernel_launches": {k: v[0] for k, v in prof.items() if v[0]},
         "ms_per_step_instrumented": dt_i / K * 1e3, "obs_chunks": chunks, "p2p_timed_out": bool(timed_out),
-    })
+    }
 
 
-def replicas_fallback(rank, world, local_rank, n, L, K, W, obs_list, scheme, lik, reason):
+_TRANSPORT = {"value": "auto"}
+
+
+def ctx_transport(ctx):
+    t = _TRANSPORT["value"]
+    return {"auto": "auto", "p2p": "p2p", "p2p-only": "p2p", "rccl": "rccl", "torch": "rccl"}[t]
+
+
+def replicas_fallback(ctx, n, L, K, W, obs_list, scheme, lik, reason):
     import torch
-    import torch.distributed as dist
 
     import rust_robotics_amd.localization as loc
 
+    dist = ctx.dist
     cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
-    pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1 + rank, device=local_rank,
+    pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1 + ctx.rank, device=ctx.local_rank,
                                                     resample_scheme=scheme, likelihood_mode=lik)
     u = [1.0, 0.1]
 
@@ -393,10 +549,190 @@ def replicas_fallback(rank, world, local_rank, n, L, K, W, obs_list, scheme, lik
     pf.profile_enable(0)
     est = pf.estimate()
     dist.barrier()
-    dist.destroy_process_group()
     return dict(seconds=float(tmax.item()), seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est],
                 dominant=None, transport="NONE -- independent replicas, no exchange",
                 transport_note="SHARDING FAILED: " + reason, p2p_timed_out=False, migrated_particles_last_step=0)
+
+
+def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]"):
+    """Fixed-N MCL: n particles per GPU x L landmarks, propagate + weight + resample every step."""
+    world = ctx.world
+    # time only moves forward for every filter: W warm-up + K timed + K estimate-every-step + K dispatch-stamped + K breakdown
+    # steps; the sharded legs also validate (12 steps) and warm up 64 steps longer
+    obs_list = make_scene(L, W + 4 * K + (76 if ctx.sharded else 0), seed=1)
+    scheme = 1 if args.scheme == "systematic" else 0
+    lik = 0 if args.likelihood == "fused" else 1
+    extra = {}
+    if ctx.sharded:
+        from rust_robotics_amd import sharded
+
+        try:
+            res = sharded.bench_sharded(ctx.rank, world, ctx.local_rank, n, L, K, W, obs_list[:W + 2 * K + 76], scheme, lik, args.transport)
+        except RuntimeError as e:
+            # no sharded transport works on this machine.  Last resort so that the run still leaves a line:
+            # every rank steps its own, independent filter (NO exchange, NOT one sharded filter) and the line
+            # says so in config.sharding -- the number is an upper bound for the sharded step, not a measurement of it.
+            res = replicas_fallback(ctx, n, L, K, W, obs_list[:W + 2 * K + 76], scheme, lik, str(e))
+    else:
+        import rust_robotics_amd.localization as loc
+
+        cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
+        pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=ctx.local_rank,
+                                                        resample_scheme=scheme, likelihood_mode=lik)
+        u = [1.0, 0.1]
+        for t in range(W):
+            pf.step_async(u, obs_list[t])
+        pf.synchronize()
+        t0 = time.perf_counter()
+        for t in range(W, W + K):
+            pf.step_async(u, obs_list[t])
+        pf.synchronize()
+        dt = time.perf_counter() - t0
+        est = pf.estimate()
+        # the reference's try_step returns the refreshed mean EVERY step (particle_filter.rs:299,332,343,496): the same K
+        # steps again with the estimate produced on the device inside every step (rr_pf_step_async_estimate; one
+        # synchronisation at the end, the K estimates read back from the device-side ring afterwards)
+        t_est = None
+        if hasattr(pf, "step_async_estimate"):
+            for t in range(W + K, W + K + min(W, 10)):
+                pf.step_async_estimate(u, obs_list[t])
+            pf.synchronize()
+            t1 = time.perf_counter()
+            for t in range(W + K + min(W, 10), W + 2 * K):
+                pf.step_async_estimate(u, obs_list[t])
+            pf.synchronize()
+            t_est = (time.perf_counter() - t1) / max(K - min(W, 10), 1)
+            extra["estimate_every_step"] = {"ms_per_step": t_est * 1e3, "last_estimate": [float(a) for a in pf.last_step_estimate()],
+                                            "note": "rr_pf_step_async_estimate: the mean of the resampled set (particle_filter.rs:382-396,496) "
+                                                    "is accumulated inside the step's plan kernel and kept on the device; value/ms_per_step above "
+                                                    "are the plain asynchronous step"}
+        # roofline kernel: the NEXT K steps (the filter resamples every step, so the work per step is stationary) in
+        # which ONLY the propagate+weight kernel is timed, by the start/stop timestamps of its own dispatch packets
+        # (hipExtLaunchKernelGGL on the filter's stream): no event packets in the stream, the kernel runs as in the
+        # timed loop.  Kept out of the timed region because the stamped launch costs the host ~3 us per step.
+        pf.profile_enable(2)
+        pf.profile_reset()
+        for t in range(W + 2 * K, W + 3 * K):
+            pf.step_async(u, obs_list[t])
+        pf.synchronize()
+        dominant = pf.profile_read()["k_propagate_weight"]
+        # per-kernel breakdown: an instrumented re-run of K steps with HIP events around every launch (adds
+        # ~3 us per launch; informational, kept out of `value` and of `roofline`)
+        prof, dt_instr = {"k_propagate_weight": dominant}, 0.0
+        if breakdown:
+            pf.profile_enable(1)
+            pf.profile_reset()
+            t1 = time.perf_counter()
+            for t in range(W + 3 * K, W + 4 * K):
+                pf.step_async(u, obs_list[t])
+            pf.synchronize()
+            dt_instr = time.perf_counter() - t1
+            prof = pf.profile_read()
+        pf.profile_enable(0)
+        del pf
+        res = dict(seconds=dt, seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est], dominant=dominant)
+
+    if ctx.rank != 0:
+        return None
+    total_updates = float(n) * world * L * K
+    value = total_updates / res["seconds"]
+    kern = res["kernels"]
+    dominant = res.get("dominant")
+    if dominant and not dominant[0]:
+        dominant = None  # this path does not stamp its dispatches (multinomial): fall back to the instrumented re-run
+    k1_n, k1_ms = dominant or kern["k_propagate_weight"]
+    k1_avg_s = (k1_ms / max(k1_n, 1)) * 1e-3
+    k1_bytes = K1_BYTES[args.scheme] if not ctx.sharded else 64.0
+    achieved = k1_bytes * n / k1_avg_s if k1_avg_s > 0 else 0.0
+    step_kernel_ms = {k: (v[1] / max(v[0], 1)) for k, v in kern.items() if v[0]}
+    traffic, traffic_src = measured_traffic("k_step_lazy", "mcl") if k1_bytes == 72.0 and n == 1_000_000 else (None, None)
+    # FP64-VALU side of the same kernel: f64-rate lane-instructions per particle (DESIGN.md section 4: a per-pair count
+    # times L plus a per-particle count, both read off the ISA and checked against SQ_INSTS_VALU) over the kernel time
+    pair_i, part_i = mcl_instruction_budget()
+    valu_rate = (pair_i * L + part_i) * n / k1_avg_s if k1_avg_s > 0 else 0.0
+    out = {
+        "metric": "particle-landmark updates/sec",
+        "value": value,
+        "unit": "particle-landmark updates/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": res["seconds"] / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"fixed-N MCL (BASELINE.json {label}): {n} particles/GPU x {L} landmarks, "
+                        f"propagate+weight+{args.scheme} resample every step, likelihood={args.likelihood}",
+            "particles_per_gpu": n,
+            "landmarks": L,
+            "resample": args.scheme,
+            "sharding": "none" if not ctx.sharded else
+                        (f"{res.get('transport')} ({res.get('transport_note')})" if str(res.get("transport", "")).startswith("NONE") else
+                         f"contiguous particle blocks over {world} GPUs; transport {res.get('transport')} ({res.get('transport_note')})"),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_step_lazy (propagate + weight + folded resample gather)" if k1_bytes == 72.0 else "k_propagate_weight",
+            "achieved": achieved / 1e9,
+            "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK,
+            "traffic": traffic,
+            "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)") if traffic_src else None,
+            "avg_kernel_ms": k1_avg_s * 1e3,
+            "timed_launches": k1_n,
+            "timing": "dispatch timestamps (hipExtLaunchKernelGGL) of K launches that follow the timed region" if dominant else
+                      "HIP events in an instrumented re-run of the K steps",
+            "algorithmic_bytes_per_launch": k1_bytes * n,
+            "fp64_valu": {"lane_instr_per_pair": pair_i, "lane_instr_per_particle": part_i, "achieved_lane_instr_per_s": valu_rate,
+                          "peak_lane_instr_per_s": FP64_VALU_PEAK, "frac": valu_rate / FP64_VALU_PEAK},
+            "note": "this kernel is FP64-VALU bound at L >= 32 (fp64_valu.frac is its binding fraction; the working set of ~90 MB is "
+                    "Infinity-Cache resident, so `traffic` is fabric traffic, not DRAM traffic); the HBM-bound workload is the "
+                    "`fastslam` leg of this line (DESIGN.md section 4)",
+        },
+        "kernel_ms_avg": step_kernel_ms,
+        "ms_per_step_instrumented": res.get("seconds_instrumented", 0.0) / K * 1e3,
+        "estimate": res.get("estimate"),
+    }
+    out.update(extra)
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(n, L, obs_list)
+    if ctx.sharded:
+        out["sharded"] = {k: res.get(k) for k in ("transport", "transport_note", "p2p_timed_out", "migrated_particles_last_step")}
+    return out
+
+
+def mcl_instruction_budget():
+    """(f64-rate lane-instructions per particle-landmark pair, per particle) of k_step_lazy, maintained next to the kernel
+    (rust_robotics_amd/csrc/INSTRUCTION_BUDGET.json, written from the ISA dump by tools/count_isa.py)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "rust_robotics_amd", "csrc", "INSTRUCTION_BUDGET.json")))
+        return float(d["per_pair"]), float(d["per_particle"])
+    except Exception:
+        return 19.0, 530.0  # round-1 ISA count
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` from a bare shell: re-execute under torch.distributed.run, one rank per GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: hipIpcGetMemHandle and RCCL need it on this host driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: no launcher detected (WORLD_SIZE unset); starting " + " ".join(cmd[1:8]) + " ...\n")
+    sys.stderr.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -412,155 +748,76 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-breakdown", action="store_true",
                     help="skip the instrumented per-kernel re-run (use under rocprofv3 so that its averages cover the timed launches only)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="headline workload only (no fastslam / configs[3] / configs[4] legs)")
+    ap.add_argument("--all-legs", action="store_true", help="run the configs[3] / configs[4] legs at any --gpus (default: only at 8)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded path even at --gpus 1")
     ap.add_argument("--transport", choices=["auto", "p2p", "rccl", "torch", "p2p-only"], default="auto",
                     help="sharded exchange: auto = peer-to-peer over xGMI if it validates at run time, else native RCCL, else "
                          "torch.distributed NCCL; p2p / rccl / torch restrict the ladder; p2p-only validates against the unsharded filter")
     args = ap.parse_args()
+    _TRANSPORT["value"] = args.transport
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
     if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
         os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's version banner off stdout
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    ctx = Ctx(args)
+    if ctx.world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.world}: launch with torch.distributed.run --nproc-per-node {args.gpus} "
+                         f"(or unset WORLD_SIZE and let bench.py launch itself)")
+    ctx.init_group()
+    require_devices(ctx)
+    if ctx.sharded:
+        import torch
 
+        torch.cuda.set_device(ctx.local_rank)
+
+    fast = args.workload in ("fastslam", "fastslam2")
     if args.particles is None:
-        args.particles = 1_000_000 if args.workload == "mcl" else 100_000
+        args.particles = 100_000 if fast else 1_000_000
     if args.landmarks is None:
-        args.landmarks = 32 if args.workload == "mcl" else 200
-    if args.workload in ("fastslam", "fastslam2"):
-        if args.steps == 200 and args.warmup == 20:
-            args.steps, args.warmup = 50, 5
-        if (world != 1 or args.force_sharded) and args.workload == "fastslam2":
-            raise SystemExit("the sharded bench leg times FastSLAM 1.0 (the sharded update itself also serves FastSLAM 2.0 handles)")
-        if world != 1 or args.force_sharded:
-            if args.particles == 100_000 and world == 8:
-                args.particles = 125_000  # configs[3]: 1e6 particles over 8 GPUs
-            return run_fastslam_sharded(args, rank, world, local_rank)
-        return run_fastslam(args)
+        args.landmarks = 200 if fast else 32
     n, L, K, W = args.particles, args.landmarks, args.steps, args.warmup
-    # time only moves forward for every filter: W warm-up + K timed + K dispatch-stamped + K breakdown steps; the sharded
-    # legs also validate (12 steps) and warm up 64 steps longer
-    obs_list = make_scene(L, W + 3 * K + (76 if (world > 1 or args.force_sharded) else 0), seed=1)
-    scheme = 1 if args.scheme == "systematic" else 0
-    lik = 0 if args.likelihood == "fused" else 1
+    with_cpu = not args.no_cpu_baseline and ctx.world == 1 and not args.force_sharded  # rank 0 at N = 1 only
 
-    if world > 1 or args.force_sharded:
-        from rust_robotics_amd import sharded
-
-        try:
-            res = sharded.bench_sharded(rank, world, local_rank, n, L, K, W, obs_list, scheme, lik, args.transport)
-        except RuntimeError as e:
-            # no sharded transport works on this machine.  Last resort so that the run still leaves a line:
-            # every rank steps its own, independent filter (NO exchange, NOT one sharded filter) and the line
-            # says so in config.sharding -- the number is an upper bound for the sharded step, not a measurement of it.
-            res = replicas_fallback(rank, world, local_rank, n, L, K, W, obs_list, scheme, lik, str(e))
-    else:
-        import rust_robotics_amd.localization as loc
-
-        cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
-        pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=local_rank,
-                                                        resample_scheme=scheme, likelihood_mode=lik)
-        u = [1.0, 0.1]
-        for t in range(W):
-            pf.step_async(u, obs_list[t])
-        pf.synchronize()
-        t0 = time.perf_counter()
-        for t in range(W, W + K):
-            pf.step_async(u, obs_list[t])
-        pf.synchronize()
-        dt = time.perf_counter() - t0
-        est = pf.estimate()
-        # roofline kernel: the NEXT K steps (the filter resamples every step, so the work
-        # per step is stationary) in which ONLY the propagate+weight kernel is timed, by the start/stop
-        # timestamps of its own dispatch packets (hipExtLaunchKernelGGL on the filter's stream): no event
-        # packets in the stream, the kernel runs as in the timed loop.  Kept out of the timed region because
-        # the stamped launch costs the host ~3 us per step on this launch-rate-sensitive 3-launch step.
-        pf.profile_enable(2)
-        pf.profile_reset()
-        for t in range(W + K, W + 2 * K):
-            pf.step_async(u, obs_list[t])
-        pf.synchronize()
-        dominant = pf.profile_read()["k_propagate_weight"]
-        # per-kernel breakdown: an instrumented re-run of the same K steps with HIP events around every
-        # launch (adds ~3 us per launch; informational, kept out of `value` and of `roofline`)
-        prof, dt_instr = {"k_propagate_weight": dominant}, 0.0
-        if not args.no_breakdown:
-            pf.profile_enable(1)
-            pf.profile_reset()
-            t1 = time.perf_counter()
-            for t in range(W + 2 * K, W + 3 * K):
-                pf.step_async(u, obs_list[t])
-            pf.synchronize()
-            dt_instr = time.perf_counter() - t1
-            prof = pf.profile_read()
-        pf.profile_enable(0)
-        res = dict(seconds=dt, seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est], dominant=dominant)
-
-    if rank != 0:
+    if fast:
+        if K == 200 and W == 20:
+            K, W = 50, 5
+        if ctx.sharded:
+            if args.workload == "fastslam2":
+                raise SystemExit("the sharded bench leg times FastSLAM 1.0 (the sharded update itself also serves FastSLAM 2.0 handles)")
+            if n == 100_000 and ctx.world == 8:
+                n = 125_000  # configs[3]: 1e6 particles over 8 GPUs
+            out = leg_fastslam_sharded(ctx, n, L, K, W)
+            ctx.close()
+            if ctx.rank == 0:
+                if "error" in out:
+                    raise SystemExit(out["error"] + " (" + out.get("transport_note", "") + ")")
+                emit(out)
+            return
+        emit(leg_fastslam(args, n, L, K, W, v2=args.workload == "fastslam2", with_cpu=with_cpu, breakdown=not args.no_breakdown))
         return
-    total_updates = float(n) * world * L * K
-    value = total_updates / res["seconds"]
-    kern = res["kernels"]
-    dominant = res.get("dominant")
-    if dominant and not dominant[0]:
-        dominant = None  # this path does not stamp its dispatches (multinomial): fall back to the instrumented re-run
-    k1_n, k1_ms = dominant or kern["k_propagate_weight"]
-    k1_avg_s = (k1_ms / max(k1_n, 1)) * 1e-3
-    k1_bytes = K1_BYTES[args.scheme] if world == 1 and not args.force_sharded else 64.0
-    achieved = k1_bytes * n / k1_avg_s if k1_avg_s > 0 else 0.0
-    step_kernel_ms = {k: (v[1] / max(v[0], 1)) for k, v in kern.items() if v[0]}
-    out = {
-        "metric": "particle-landmark updates/sec",
-        "value": value,
-        "unit": "particle-landmark updates/s",
-        "n_gpus": world,
-        "steps": K,
-        "warmup": W,
-        "ms_per_step": res["seconds"] / K * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {
-            "workload": f"fixed-N MCL (BASELINE.json configs[1]): {n} particles/GPU x {L} landmarks, "
-                        f"propagate+weight+{args.scheme} resample every step, likelihood={args.likelihood}",
-            "particles_per_gpu": n,
-            "landmarks": L,
-            "resample": args.scheme,
-            "sharding": "none" if world == 1 and not args.force_sharded else
-                        (f"{res.get('transport')} ({res.get('transport_note')})" if str(res.get("transport", "")).startswith("NONE") else
-                         f"contiguous particle blocks over {world} GPUs; transport {res.get('transport')} ({res.get('transport_note')})"),
-        },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": "k_step_lazy (propagate + weight + folded resample gather)" if k1_bytes == 72.0 else "k_propagate_weight",
-            "achieved": achieved / 1e9,
-            "peak": HBM_PEAK / 1e9,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK,
-            "traffic": measured_traffic("k_step_lazy", "mcl") if k1_bytes == 72.0 and n == 1_000_000 else None,
-            "traffic_source": "profiles/r01c_pmc_hbm_traffic.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)",
-            "avg_kernel_ms": k1_avg_s * 1e3,
-            "timed_launches": k1_n,
-            "timing": "dispatch timestamps (hipExtLaunchKernelGGL) of the K launches of the K steps that follow the timed region" if dominant else
-                      "HIP events in an instrumented re-run of the K steps",
-            "algorithmic_bytes_per_launch": k1_bytes * n,
-            "note": "this kernel is FP64-VALU bound at L=32 (~19 f64-rate instructions per particle-landmark pair, "
-                    "VALU issue slots ~94 % busy per rocprofv3 PMC, profiles/r01f_mcl_pmc_sq_summary.csv); the HBM-bound workload is `--workload fastslam` (DESIGN.md section 4)",
-        },
-        "kernel_ms_avg": step_kernel_ms,
-        "ms_per_step_instrumented": res.get("seconds_instrumented", 0.0) / K * 1e3,
-        "estimate": res.get("estimate"),
-    }
-    if not args.no_cpu_baseline and world == 1:  # rank 0 at N = 1 only
-        out["cpu_baseline"] = cpu_baseline(n, L, obs_list)
-    if world > 1 or args.force_sharded:
-        out["sharded"] = {k: res.get(k) for k in ("transport", "transport_note", "p2p_timed_out", "migrated_particles_last_step")}
-    emit(out)
+
+    out = leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=not args.no_breakdown)
+    if not args.no_extra_legs and args.scheme == "systematic" and (n, L) == (1_000_000, 32):
+        if not ctx.sharded:
+            # configs[2], the HBM-bound workload, in the same run: its roofline fraction is the one the HBM target is about
+            leg = leg_fastslam(args, 100_000, 200, 50, 5, with_cpu=with_cpu, breakdown=not args.no_breakdown)
+            out["fastslam"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernel_ms_avg",
+                                                   "obs_chunks") if k in leg}
+            if "cpu_baseline" in leg:
+                out["fastslam"]["cpu_baseline"] = leg["cpu_baseline"]
+        elif ctx.world == 8 or args.all_legs:
+            per_gpu = 1_000_000 // 8 if ctx.world == 8 else 125_000
+            leg3 = leg_fastslam_sharded(ctx, per_gpu, 200, 50, 5)
+            leg5 = leg_mcl(args, ctx, 2_000_000, 64, min(K, 100), W, False, breakdown=not args.no_breakdown, label="configs[4]")
+            if ctx.rank == 0:
+                out["fastslam_sharded"] = leg3
+                out["mcl_config5"] = {k: leg5[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "steps", "warmup", "config", "roofline",
+                                                           "kernel_ms_avg", "sharded") if k in leg5}
+    ctx.close()
+    if ctx.rank == 0:
+        emit(out)
 
 
 def emit(out):

@@ -126,6 +126,26 @@ rr_status rr_fs1_p2p_connect_local(rr_fs1* const* handles, int32_t n_ranks);
 rr_status rr_fs1_shard_update_p2p(rr_fs1* h, const double u[2], const double* z, size_t n_z);
 rr_status rr_fs1_p2p_status(rr_fs1* h, int32_t* timed_out);
 
+/* ---- the same sharded update over RCCL (BASELINE.json configs[3]: "RCCL weight all-reduce + global
+ * resample"; replaces fastslam1.rs:186-234 over all shards): all-reduce(MAX) of the weight maximum,
+ * all-gather of every shard's integer sums (T, sum q^2), one small D2H of the totals, then a grouped
+ * ncclSend / ncclRecv of the whole particles (3 + 6L planes each) whose source lives on another rank,
+ * one contiguous [plane][count] block per (source, destination) pair.  Own slots are resampled lazily
+ * as on one GPU.  `c` comes from rr_comm_create (include/rr_pf.h); one host synchronisation per update. */
+rr_status rr_fs1_shard_update(rr_fs1* h, rr_comm* c, const double u[2], const double* z, size_t n_z);
+uint64_t rr_fs1_shard_last_migrated(const rr_fs1* h);
+/* The phases of rr_fs1_shard_update for a host-orchestrated transport (any collective library; the
+ * CPU tests drive the same sequence with the oracle standing in for the kernels).  d_* are device pointers. */
+rr_status rr_fs1_shard_local(rr_fs1* h, const double u[2], const double* z, size_t n_z, double* d_wmax_out);
+rr_status rr_fs1_shard_quantize(rr_fs1* h, const double* d_wmax_global, uint64_t* d_sums_out /* [3] */);
+rr_status rr_fs1_shard_plan(rr_fs1* h, const uint64_t* d_all_sums /* [n_shards][3] */, int32_t n_shards, int32_t rank);
+rr_status rr_fs1_shard_get_plan(rr_fs1* h, rr_pf_shard_plan* out); /* synchronises the stream */
+/* matrix = rr_sys_segment_matrix(...)[src * n_shards + dst].  Block of destination g (g != rank, ascending g):
+ * matrix[rank][g] particles x (3 + 6L) planes, laid out [plane][count], blocks back to back in d_send;
+ * d_recv holds the blocks of the sources g != rank in the same order. */
+rr_status rr_fs1_shard_pack(rr_fs1* h, const int64_t* matrix, int32_t n_shards, int32_t rank, double* d_send);
+rr_status rr_fs1_shard_unpack(rr_fs1* h, const int64_t* matrix, int32_t n_shards, int32_t rank, const double* d_recv);
+
 /* ---- measurement hooks */
 typedef enum rr_fs1_kernel_id {
   RR_FK_PREDICT = 0,

@@ -83,6 +83,9 @@ def ref() -> C.CDLL:
     P = c_double_p
     L.ref_gauss_likelihood.restype = d
     L.ref_gauss_likelihood.argtypes = [d, d]
+    L.ref_set_threads.argtypes = [i]
+    L.ref_set_threads.restype = i
+    L.ref_get_threads.restype = i
     L.ref_pf_predict.argtypes = [sz, P, P, P, P, d, d, d, P, P]
     L.ref_pf_predict.restype = None
     L.ref_pf_update_raw.argtypes = [sz, P, P, P, P, sz, d]
@@ -106,6 +109,8 @@ def ref() -> C.CDLL:
     L.ref_pf_gather.restype = None
     L.ref_pf_step.argtypes = [sz, P, P, P, P, P, d, d, d, P, P, P, sz, d, d, i, P, u32, P]
     L.ref_pf_step.restype = i
+    L.ref_pf_step_ex.argtypes = [sz, P, P, P, P, P, d, d, d, P, P, P, sz, d, d, i, P, u32, P, i]
+    L.ref_pf_step_ex.restype = i
     MP = C.POINTER(RefFs1Model)
     L.ref_fs1_model_default.argtypes = [MP]
     L.ref_fs1_model_default.restype = None

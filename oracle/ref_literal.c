@@ -1,6 +1,6 @@
 /* ref_literal.c -- TEST INFRASTRUCTURE, not product code.
  *
- * A plain-C, single-threaded restatement of the reference's CPU algorithm for
+ * A plain-C restatement of the reference's CPU algorithm for
  * the sampling-based localization hot path, following the reference line by
  * line: same loop order, same operation order, serial left-to-right sums,
  * libm transcendentals (Rust's f64::{sin,cos,exp,sqrt,atan2} are the platform
@@ -24,7 +24,13 @@
  * (tests/test_known_answers.py).  RNG-level parity with rand/rand_distr is
  * UNPINNED by construction: all random draws enter as explicit arrays.
  *
- * Build: see oracle/Makefile (compiled with -ffp-contract=off).
+ * Threads: the reference is single-threaded.  For bench.py's cpu_baseline ("embarrassingly
+ * parallel stages run under OpenMP over particles on all host cores; serial stages -- cumsum, resample
+ * walk -- stay serial") the per-particle loops carry `omp parallel for`; every particle's arithmetic and
+ * every sum's order is unchanged, so results do not depend on the thread count.  ref_set_threads(1)
+ * (the default) is the reference as written.
+ *
+ * Build: see oracle/Makefile (compiled with -ffp-contract=off -fopenmp).
  */
 #include <math.h>
 #include <stddef.h>
@@ -33,6 +39,25 @@
 #include <string.h>
 
 #define REF_PI 3.14159265358979323846 /* std::f64::consts::PI */
+
+/* ------------------------------------------------------------------ threads (bench.py cpu_baseline only) */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+static int g_ref_threads = 1;
+/* n <= 0 => all host cores; returns the thread count now in use */
+int ref_set_threads(int n) {
+#ifdef _OPENMP
+  if (n <= 0) n = omp_get_num_procs();
+  g_ref_threads = n;
+#else
+  (void)n;
+  g_ref_threads = 1;
+#endif
+  return g_ref_threads;
+}
+int ref_get_threads(void) { return g_ref_threads; }
+#define REF_PARALLEL_FOR _Pragma("omp parallel for schedule(static) num_threads(g_ref_threads)")
 
 /* ------------------------------------------------------------------ PF */
 
@@ -46,6 +71,7 @@ double ref_gauss_likelihood(double x, double sigma) {
  * by sigma (Normal::new(0, sigma).sample), NULL => the `None` arm (exactly 0.0). */
 void ref_pf_predict(size_t n, double* x, double* y, double* yaw, double* v,
                     double u0, double u1, double dt, const double* nv, const double* nw) {
+  REF_PARALLEL_FOR
   for (size_t i = 0; i < n; ++i) {
     double v_noise = nv ? nv[i] : 0.0;
     double yaw_noise = nw ? nw[i] : 0.0;
@@ -61,6 +87,7 @@ void ref_pf_predict(size_t n, double* x, double* y, double* yaw, double* v,
 /* particle_filter.rs:316-329: weight overwritten with the product of likelihoods */
 void ref_pf_update_raw(size_t n, const double* x, const double* y, double* w,
                        const double* obs, size_t n_obs, double sigma) {
+  REF_PARALLEL_FOR
   for (size_t i = 0; i < n; ++i) {
     double wi = 1.0;
     for (size_t l = 0; l < n_obs; ++l) {
@@ -248,6 +275,7 @@ size_t ref_mcl_resample_adaptive(size_t n, const double* x, const double* y, con
 void ref_pf_gather(size_t n, double* x, double* y, double* yaw, double* v, double* w,
                    const uint32_t* idx) {
   double* t = (double*)malloc(4 * n * sizeof(double));
+  REF_PARALLEL_FOR
   for (size_t k = 0; k < n; ++k) {
     t[k] = x[idx[k]];
     t[n + k] = y[idx[k]];
@@ -267,10 +295,25 @@ void ref_pf_gather(size_t n, double* x, double* y, double* yaw, double* v, doubl
  * scheme: 0 = PF (:441-473, gate n_eff < n*threshold, default index 0)
  *         1 = fixed-N MCL (monte_carlo_localization.rs:298, every step, fallback last)
  * Returns 1 if it resampled.  est_out (4) = estimate after the step (Q15). */
+int ref_pf_step_ex(size_t n, double* x, double* y, double* yaw, double* v, double* w,
+                   double u0, double u1, double dt, const double* nv, const double* nw,
+                   const double* obs, size_t n_obs, double sigma, double resample_threshold,
+                   int scheme, const double* r_draws, uint32_t* idx_scratch, double* est_out, int literal_scan);
+
 int ref_pf_step(size_t n, double* x, double* y, double* yaw, double* v, double* w,
                 double u0, double u1, double dt, const double* nv, const double* nw,
                 const double* obs, size_t n_obs, double sigma, double resample_threshold,
                 int scheme, const double* r_draws, uint32_t* idx_scratch, double* est_out) {
+  return ref_pf_step_ex(n, x, y, yaw, v, w, u0, u1, dt, nv, nw, obs, n_obs, sigma, resample_threshold, scheme, r_draws,
+                        idx_scratch, est_out, 0);
+}
+
+/* literal_scan != 0: the PF resample walks the cumulative weights linearly for every draw exactly as
+ * particle_filter.rs:455-470 does (O(N^2)); 0: the binary search that returns the same indices. */
+int ref_pf_step_ex(size_t n, double* x, double* y, double* yaw, double* v, double* w,
+                   double u0, double u1, double dt, const double* nv, const double* nw,
+                   const double* obs, size_t n_obs, double sigma, double resample_threshold,
+                   int scheme, const double* r_draws, uint32_t* idx_scratch, double* est_out, int literal_scan) {
   ref_pf_predict(n, x, y, yaw, v, u0, u1, dt, nv, nw);
   ref_pf_update_raw(n, x, y, w, obs, n_obs, sigma);
   ref_pf_normalize(n, w);
@@ -282,7 +325,8 @@ int ref_pf_step(size_t n, double* x, double* y, double* yaw, double* v, double* 
   } else {
     double n_eff = ref_pf_neff(n, w);
     if (n_eff < (double)n * resample_threshold) {
-      ref_pf_resample_indices_bsearch(n, w, r_draws, idx_scratch);
+      if (literal_scan) ref_pf_resample_indices(n, w, r_draws, idx_scratch);
+      else ref_pf_resample_indices_bsearch(n, w, r_draws, idx_scratch);
       ref_pf_gather(n, x, y, yaw, v, w, idx_scratch);
       fired = 1;
     }
@@ -335,6 +379,7 @@ void ref_fs1_create(size_t n, size_t L, double* px, double* py, double* pyaw, do
 /* fastslam1.rs:123-137 + 70-77; z0,z1 = unit normal draws per particle */
 void ref_fs1_predict(size_t n, double* px, double* py, double* pyaw, double u0, double u1,
                      const double* z0, const double* z1, const ref_fs1_model* m) {
+  REF_PARALLEL_FOR
   for (size_t p = 0; p < n; ++p) {
     double un0 = u0 + z0[p] * sqrt(m->q00);
     double un1 = u1 + z1[p] * sqrt(m->q11);
@@ -450,6 +495,7 @@ void ref_fs1_gather(size_t n, size_t L, double* px, double* py, double* pyaw, do
                     double* lm, const uint32_t* idx) {
   double* t = (double*)malloc((3 * n + n * L * 6) * sizeof(double));
   double* tl = t + 3 * n;
+  REF_PARALLEL_FOR
   for (size_t k = 0; k < n; ++k) {
     size_t j = idx[k];
     t[k] = px[j]; t[n + k] = py[j]; t[2 * n + k] = pyaw[j];
@@ -473,6 +519,7 @@ int ref_fs1_update(size_t n, size_t L, double* px, double* py, double* pyaw, dou
   for (size_t k = 0; k < n_z; ++k) { /* observation outer, particle inner :250-256 */
     double zd = z[3 * k], za = z[3 * k + 1];
     size_t id = (size_t)z[3 * k + 2];
+    REF_PARALLEL_FOR
     for (size_t p = 0; p < n; ++p)
       ref_fs1_update_landmark(px[p], py[p], pyaw[p], &pw[p], zd, za, lm + (p * L + id) * 6, m);
   }
@@ -673,6 +720,7 @@ double ref_fs2_update_landmark(double px, double py, double pyaw, double zd, dou
 int ref_fs2_update(size_t n, size_t L, double* px, double* py, double* pyaw, double* pw, double* lm, double u0, double u1,
                    const double* noise, const double* z, size_t n_z, double nth, double r0, uint32_t* idx_scratch) {
   const double r00 = 0.5, r11 = 0.0305;
+  REF_PARALLEL_FOR
   for (size_t p = 0; p < n; ++p) {
     double pose[3] = {px[p], py[p], pyaw[p]};
     if (n_z > 0) { /* :341-347 */

@@ -237,6 +237,14 @@ def lib() -> C.CDLL:
     proto("rr_fs1_p2p_connect_local", st, [C.POINTER(H), i32])
     proto("rr_fs1_shard_update_p2p", st, [H, P, P, sz])
     proto("rr_fs1_p2p_status", st, [H, C.POINTER(i32)])
+    proto("rr_fs1_shard_update", st, [H, H, P, P, sz])
+    proto("rr_fs1_shard_last_migrated", u64, [H])
+    proto("rr_fs1_shard_local", st, [H, P, P, sz, V])
+    proto("rr_fs1_shard_quantize", st, [H, V, V])
+    proto("rr_fs1_shard_plan", st, [H, V, i32, i32])
+    proto("rr_fs1_shard_get_plan", st, [H, C.POINTER(PfShardPlan)])
+    proto("rr_fs1_shard_pack", st, [H, C.POINTER(C.c_int64), i32, i32, V])
+    proto("rr_fs1_shard_unpack", st, [H, C.POINTER(C.c_int64), i32, i32, V])
     proto("rr_fs1_profile_enable", st, [H, i32])
     proto("rr_fs1_profile_read", st, [H, i32, C.POINTER(u64), P])
     proto("rr_fs1_profile_reset", st, [H])

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "p2p_core.hpp"
+#include "rccl_core.hpp"
 #include "resample_core.hpp"
 #include "rr_common.hpp"
 #include "rr_fastslam1.h"
@@ -385,6 +386,64 @@ __global__ __launch_bounds__(kBlock) void k_fs1_gather(Planes pl, const Ctl* __r
     if (p0 + q < n_planes) out[pid[q] * n + k] = v[q];
 }
 
+// ---- RCCL / host-orchestrated transport (rr_fs1_shard_update): whole particles that cross ranks travel
+// as one contiguous block per (source, destination) pair, laid out [plane][count] so that both the
+// packing reads (non-decreasing source indices along a plane) and the unpacking writes are coalesced.
+// ChunkTable: start[g] .. start[g + 1] = the block of rank g in remote-slot order (ascending global
+// slot, this rank's own slots left out); first_local[g] = local slot the block of SOURCE g starts at.
+struct ChunkTable {
+  uint64_t start[rr::kMaxP2P + 1];
+  uint64_t first_local[rr::kMaxP2P];
+  int n_ranks;
+};
+
+__device__ inline int chunk_of(const ChunkTable& t, uint64_t r) {
+  int g = 0;
+  while (g + 1 < t.n_ranks && r >= t.start[g + 1]) ++g;
+  return g;
+}
+
+// served slots that belong to peers -> send buffer.  ridx[r] = local source of remote slot r (k_fs1_indices_sharded).
+__global__ __launch_bounds__(kBlock) void k_fs1_pack(Planes pl, const Ctl* __restrict__ ctl,
+                                                    const unsigned int* __restrict__ ridx, uint64_t n_local,
+                                                    uint64_t n_planes, ChunkTable t, double* __restrict__ out) {
+  if (!ctl->fired) return;
+  const double* __restrict__ in = pl.s[ctl->cur];  // lazy: not flipped yet
+  const uint64_t n_remote = t.start[t.n_ranks];
+  const uint64_t p0 = (uint64_t)blockIdx.y * kPlanesPerThread;
+  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n_remote; r += (uint64_t)gridDim.x * kBlock) {
+    const int g = chunk_of(t, r);
+    const uint64_t cnt = t.start[g + 1] - t.start[g], k = r - t.start[g];
+    const uint64_t j = ridx[r];
+    double* __restrict__ o = out + t.start[g] * n_planes + k;
+    double val[kPlanesPerThread];
+#pragma unroll
+    for (int q = 0; q < kPlanesPerThread; ++q)
+      if (p0 + q < n_planes) val[q] = in[(p0 + q) * n_local + j];
+#pragma unroll
+    for (int q = 0; q < kPlanesPerThread; ++q)
+      if (p0 + q < n_planes) o[(p0 + q) * cnt] = val[q];
+  }
+}
+
+// receive buffer -> this rank's inbox (the owner's idx says kInPlace for exactly these slots)
+__global__ __launch_bounds__(kBlock) void k_fs1_unpack(double* __restrict__ inbox, const Ctl* __restrict__ ctl,
+                                                      uint64_t n_local, uint64_t n_planes, ChunkTable t,
+                                                      const double* __restrict__ in) {
+  if (!ctl->fired) return;
+  const uint64_t n_remote = t.start[t.n_ranks];
+  const uint64_t p0 = (uint64_t)blockIdx.y * kPlanesPerThread;
+  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n_remote; r += (uint64_t)gridDim.x * kBlock) {
+    const int g = chunk_of(t, r);
+    const uint64_t cnt = t.start[g + 1] - t.start[g], k = r - t.start[g];
+    const uint64_t li = t.first_local[g] + k;
+    const double* __restrict__ i0 = in + t.start[g] * n_planes + k;
+#pragma unroll
+    for (int q = 0; q < kPlanesPerThread; ++q)
+      if (p0 + q < n_planes) inbox[(p0 + q) * n_local + li] = i0[(p0 + q) * cnt];
+  }
+}
+
 __global__ void k_fs1_settle(Ctl* ctl) {
   if (ctl->pending) {
     ctl->cur ^= 1;
@@ -520,6 +579,9 @@ struct rr_fs1 {
   Planes pl{};
   double* slab = nullptr;  // [set][plane][n]
   rr::P2PState p2p;
+  double* own_inbox = nullptr;  // RCCL transport: plain device mirror of one buffer set (the peer-to-peer transport brings its own)
+  int shard_settle = 0;         // RCCL transport: the local phase consumed a pending resample (k_quantize_reduce flips Ctl.cur)
+  uint64_t last_migrated = 0;
   double* pw = nullptr;
   uint64_t* cdf = nullptr;
   uint64_t* tile_total = nullptr;
@@ -927,6 +989,7 @@ void rr_fs1_destroy(rr_fs1* h) {
   (void)hipSetDevice(h->opt.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   h->p2p.teardown();
+  (void)hipFree(h->own_inbox);
   (void)hipFree(h->slab);
   (void)hipFree(h->pw);
   (void)hipFree(h->cdf);
@@ -1357,6 +1420,221 @@ rr_status rr_fs1_shard_update_p2p(rr_fs1* h, const double u[2], const double* z,
   h->maybe_pending = true;  // the next update reads through idx (or an accessor materialises)
   h->rstep += 1;
   return RR_OK;
+}
+
+// ---- sharded FastSLAM over RCCL (and the same phases for a host-orchestrated transport / the tests):
+//   local    predict + per-observation EKF, local weight maximum
+//            all-reduce(MAX) of one double
+//   quantize integer image under the GLOBAL maximum, local (T, sum q^2)
+//            all-gather of 3 x u64 per rank
+//   plan     global totals, N_eff gate (fastslam1.rs:262-265), systematic plan (:205-234), local CDF, source of every
+//            own slot (kInPlace when a peer serves it), sources of the served slots that belong to peers
+//   pack     those particles (3 + 6L planes each) into one block per destination
+//            grouped send / recv of the blocks
+//   unpack   received blocks into this rank's inbox; the next update reads through idx as on one GPU
+rr_status rr_fs1_shard_local(rr_fs1* h, const double u[2], const double* z, size_t n_z, double* d_wmax_out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = validate_u(u)) != RR_OK) return s;
+  bool dup;
+  if ((s = validate_z(h, z, n_z, &dup)) != RR_OK) return s;
+  if ((s = fs1_alloc_ridx(h)) != RR_OK) return s;
+  if (dup) {
+    if ((s = materialise(h)) != RR_OK) return s;
+    if ((s = launch_motion<false>(h, u, z, n_z)) != RR_OK) return s;
+    if ((s = launch_observe(h, z, n_z, dup)) != RR_OK) return s;
+  } else {
+    if ((s = launch_motion<true>(h, u, z, n_z)) != RR_OK) return s;
+    if ((s = launch_observe(h, z, n_z, dup, /*lazy=*/true)) != RR_OK) return s;
+    if (h->maybe_pending && (s = launch_rest_gather(h, z, n_z)) != RR_OK) return s;
+    h->maybe_pending = false;
+  }
+  h->shard_settle = dup ? 0 : 1;
+  if (d_wmax_out)  // bit pattern of a non-negative double == the double
+    RR_HIP_TRY(hipMemcpyAsync(d_wmax_out, &h->ctl->wmax_bits, sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  return RR_OK;
+}
+
+rr_status rr_fs1_shard_quantize(rr_fs1* h, const double* d_wmax_global, uint64_t* d_sums_out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!d_wmax_global || !d_sums_out) return fail(RR_INVALID_PARAMETER, "null device pointer");
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_QUANTIZE_REDUCE);
+    hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
+                       d_wmax_global, image_args(h), h->tile_total, h->tile_q2, h->shard_settle);
+  }
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_SCAN_TILES);
+    hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl,
+                       h->n_tiles, 0, plan_args(h, 0, NAN, /*lazy=*/true), d_sums_out);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  h->shard_settle = 0;
+  h->wmax_live = false;
+  return RR_OK;
+}
+
+rr_status rr_fs1_shard_plan(rr_fs1* h, const uint64_t* d_all_sums, int32_t n_shards, int32_t rank) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!d_all_sums) return fail(RR_INVALID_PARAMETER, "null device pointer");
+  if ((s = fs1_check_geometry(h, n_shards, rank)) != RR_OK) return s;
+  hipLaunchKernelGGL(rr::k_shard_plan, dim3(1), dim3(64), 0, h->stream, h->ctl, d_all_sums, (int)n_shards, (int)rank,
+                     plan_args(h, 0, NAN, /*lazy=*/true));
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_CDF);
+    hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl, image_args(h),
+                       h->tile_total, h->cdf, (uint64_t*)nullptr, 0);
+  }
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_NORMALIZE);
+    hipLaunchKernelGGL(k_fs1_normalize, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
+  }
+  const unsigned own_blocks = grid_for(h->n, kBlock);
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_INDICES);
+    hipLaunchKernelGGL(k_fs1_indices_sharded, dim3(own_blocks + 64), dim3(kBlock), 0, h->stream, h->ctl, h->cdf, h->n, h->gid0,
+                       own_blocks, h->idx, h->ridx);
+    hipLaunchKernelGGL(k_fs1_uniform_weights, dim3(own_blocks), dim3(kBlock), 0, h->stream, h->ctl, h->pw, h->n, h->n_global);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  h->maybe_pending = true;  // the next update reads through idx (or an accessor materialises)
+  h->rstep += 1;
+  return RR_OK;
+}
+
+rr_status rr_fs1_shard_get_plan(rr_fs1* h, rr_pf_shard_plan* out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  const Ctl& c = *h->ctl_host;
+  out->fired = c.fired;
+  out->usable = c.usable;
+  out->total_global = c.total;
+  out->base = c.base;
+  out->total_local = c.total_local;
+  out->rho = c.rho;
+  return RR_OK;
+}
+
+// block tables of one exchange from the segment matrix (row `rank` = what this rank sends, column `rank` = what it receives)
+static void fs1_chunk_tables(const int64_t* M, int G, int r, ChunkTable* send, ChunkTable* recv) {
+  send->n_ranks = recv->n_ranks = G;
+  uint64_t so = 0, ro = 0, li = 0;
+  for (int g = 0; g < G; ++g) {
+    send->start[g] = so;
+    recv->start[g] = ro;
+    recv->first_local[g] = li;
+    send->first_local[g] = 0;
+    li += (uint64_t)M[(size_t)g * G + r];
+    if (g == r) continue;  // own slots stay where they are (lazy gather through idx)
+    so += (uint64_t)M[(size_t)r * G + g];
+    ro += (uint64_t)M[(size_t)g * G + r];
+  }
+  send->start[G] = so;
+  recv->start[G] = ro;
+}
+
+rr_status rr_fs1_shard_pack(rr_fs1* h, const int64_t* matrix, int32_t n_shards, int32_t rank, double* d_send) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!matrix) return fail(RR_INVALID_PARAMETER, "null segment matrix");
+  if ((s = fs1_check_geometry(h, n_shards, rank)) != RR_OK) return s;
+  ChunkTable st, rt;
+  fs1_chunk_tables(matrix, n_shards, rank, &st, &rt);
+  if (st.start[n_shards] == 0) return RR_OK;
+  if (!d_send) return fail(RR_INVALID_PARAMETER, "null send buffer");
+  rr::ScopedTimer t(h->prof, h->stream, RR_FK_GATHER);
+  const unsigned gx = std::min<unsigned>(grid_for(st.start[n_shards], kBlock), 1024u);
+  hipLaunchKernelGGL(k_fs1_pack, dim3(gx, grid_for(h->n_planes, kPlanesPerThread)), dim3(kBlock), 0, h->stream, h->pl, h->ctl,
+                     (const unsigned int*)h->ridx, h->n, h->n_planes, st, d_send);
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+rr_status rr_fs1_shard_unpack(rr_fs1* h, const int64_t* matrix, int32_t n_shards, int32_t rank, const double* d_recv) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!matrix) return fail(RR_INVALID_PARAMETER, "null segment matrix");
+  if ((s = fs1_check_geometry(h, n_shards, rank)) != RR_OK) return s;
+  ChunkTable st, rt;
+  fs1_chunk_tables(matrix, n_shards, rank, &st, &rt);
+  if (rt.start[n_shards] == 0) return RR_OK;
+  if (!d_recv) return fail(RR_INVALID_PARAMETER, "null receive buffer");
+  if (!h->pl.inbox) {  // no peer-to-peer connection: a plain device mirror of one buffer set serves as the inbox
+    RR_HIP_TRY(hipMalloc(&h->own_inbox, h->n_planes * h->n * sizeof(double)));
+    h->pl.inbox = h->own_inbox;
+  }
+  rr::ScopedTimer t(h->prof, h->stream, RR_FK_GATHER);
+  const unsigned gx = std::min<unsigned>(grid_for(rt.start[n_shards], kBlock), 1024u);
+  hipLaunchKernelGGL(k_fs1_unpack, dim3(gx, grid_for(h->n_planes, kPlanesPerThread)), dim3(kBlock), 0, h->stream,
+                     const_cast<double*>(h->pl.inbox), h->ctl, h->n, h->n_planes, rt, d_recv);
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+uint64_t rr_fs1_shard_last_migrated(const rr_fs1* h) { return h ? h->last_migrated : 0; }
+
+rr_status rr_fs1_shard_update(rr_fs1* h, rr_comm* c, const double u[2], const double* z, size_t n_z) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!c) return fail(RR_INVALID_PARAMETER, "null communicator");
+  if ((s = fs1_check_geometry(h, c->n_ranks, c->rank)) != RR_OK) return s;
+  rr::Rccl& R = rr::rccl();
+  const int G = c->n_ranks, r = c->rank;
+  if ((s = rr_fs1_shard_local(h, u, z, n_z, c->d_wmax)) != RR_OK) return s;
+  RR_NCCL_TRY(R.AllReduce(c->d_wmax, c->d_wmax, 1, rr::kNcclFloat64, rr::kNcclMax, c->comm, h->stream));
+  if ((s = rr_fs1_shard_quantize(h, c->d_wmax, c->d_sums)) != RR_OK) return s;
+  RR_NCCL_TRY(R.AllGather(c->d_sums, c->d_all, 3, rr::kNcclUint64, c->comm, h->stream));
+  if ((s = rr_fs1_shard_plan(h, c->d_all, G, r)) != RR_OK) return s;
+  RR_HIP_TRY(hipMemcpyAsync(c->h_all, c->d_all, 3 * (size_t)G * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  rr_pf_shard_plan plan;
+  if ((s = rr_fs1_shard_get_plan(h, &plan)) != RR_OK) return s;  // synchronises the stream
+  h->last_migrated = 0;
+  if (!plan.fired || G == 1) return RR_OK;
+  std::vector<uint64_t> totals(G);
+  for (int g = 0; g < G; ++g) totals[g] = c->h_all[3 * g];
+  (void)rr_sys_segment_matrix(plan.rho, totals.data(), G, h->n_global, h->n, r, c->matrix.data());
+  const int64_t* M = c->matrix.data();
+  uint64_t n_recv = 0, n_send_remote = 0, n_recv_remote = 0, migrated = 0;
+  for (int g = 0; g < G; ++g) {
+    n_recv += (uint64_t)M[(size_t)g * G + r];
+    if (g != r) {
+      n_send_remote += (uint64_t)M[(size_t)r * G + g];
+      n_recv_remote += (uint64_t)M[(size_t)g * G + r];
+    }
+    for (int d = 0; d < G; ++d)
+      if (g != d) migrated += (uint64_t)M[(size_t)g * G + d];
+  }
+  h->last_migrated = migrated;
+  if (n_recv != h->n) return fail(RR_RUNTIME_ERROR, "segment plan does not cover this shard's slots exactly once");
+  auto ensure = [&](double** buf, size_t* cap, size_t need) -> rr_status {
+    if (need <= *cap) return RR_OK;
+    if (*buf) RR_HIP_TRY(hipFree(*buf));
+    *buf = nullptr;
+    *cap = 0;
+    const size_t want = need + need / 4 + 4096;
+    RR_HIP_TRY(hipMalloc(buf, want * sizeof(double)));
+    *cap = want;
+    return RR_OK;
+  };
+  if ((s = ensure(&c->d_fsend, &c->cap_fsend, n_send_remote * h->n_planes)) != RR_OK) return s;
+  if ((s = ensure(&c->d_frecv, &c->cap_frecv, n_recv_remote * h->n_planes)) != RR_OK) return s;
+  if ((s = rr_fs1_shard_pack(h, M, G, r, c->d_fsend)) != RR_OK) return s;
+  RR_NCCL_TRY(R.GroupStart());
+  uint64_t so = 0, ro = 0;
+  for (int g = 0; g < G; ++g) {
+    if (g == r) continue;
+    const uint64_t ns = (uint64_t)M[(size_t)r * G + g] * h->n_planes, nr = (uint64_t)M[(size_t)g * G + r] * h->n_planes;
+    if (ns) RR_NCCL_TRY(R.Send(c->d_fsend + so, ns, rr::kNcclFloat64, g, c->comm, h->stream));
+    if (nr) RR_NCCL_TRY(R.Recv(c->d_frecv + ro, nr, rr::kNcclFloat64, g, c->comm, h->stream));
+    so += ns;
+    ro += nr;
+  }
+  RR_NCCL_TRY(R.GroupEnd());
+  return rr_fs1_shard_unpack(h, M, G, r, c->d_frecv);
 }
 
 rr_status rr_fs1_last_resample_fired(rr_fs1* h, int32_t* out) {

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "p2p_core.hpp"
+#include "rccl_core.hpp"
 #include "resample_core.hpp"
 #include "rr_common.hpp"
 #include "rr_pf.h"
@@ -51,11 +52,13 @@ using rr::kMomentBlocks;
 using rr::kNumMoments;
 using rr::P2PPeers;
 using rr::kMaxP2P;
-
-// layout of ncclUniqueId (rccl.h:43): passed by value to ncclCommInitRank
-struct ncclUniqueIdPod {
-  char internal[128];
-};
+using rr::rccl;
+using rr::rccl_load;
+using rr::Rccl;
+using rr::kNcclUint64;
+using rr::kNcclFloat64;
+using rr::kNcclMax;
+using rr::ncclUniqueIdPod;
 
 namespace {
 
@@ -2134,80 +2137,6 @@ rr_status rr_pf_p2p_status(rr_pf* h, int32_t* timed_out) {
 
 #include <dlfcn.h>
 
-namespace {
-struct Rccl {
-  void* lib = nullptr;
-  int (*GetUniqueId)(void*) = nullptr;
-  int (*CommInitRank)(void**, int, ncclUniqueIdPod, int) = nullptr;
-  int (*CommDestroy)(void*) = nullptr;
-  int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
-  int (*GroupStart)() = nullptr;
-  int (*GroupEnd)() = nullptr;
-  const char* (*GetErrorString)(int) = nullptr;
-};
-// nccl.h enum values (stable ABI): ncclUint64 = 5, ncclFloat64 = 8; ncclSum = 0, ncclMax = 2
-constexpr int kNcclUint64 = 5, kNcclFloat64 = 8, kNcclMax = 2;
-
-Rccl& rccl() {
-  static Rccl r;
-  return r;
-}
-
-rr_status rccl_load() {
-  Rccl& r = rccl();
-  if (r.lib) return RR_OK;
-  // librccl.so.1 already mapped by the process (e.g. by torch) is reused; otherwise /opt/rocm/lib's
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names)
-    if ((r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
-  if (!r.lib) return fail(RR_RUNTIME_ERROR, std::string("cannot load librccl: ") + dlerror());
-  auto sym = [&](const char* n) { return dlsym(r.lib, n); };
-  r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
-  r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
-  r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
-  r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
-  r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
-  r.Send = (decltype(r.Send))sym("ncclSend");
-  r.Recv = (decltype(r.Recv))sym("ncclRecv");
-  r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
-  r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
-  r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
-  if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce || !r.AllGather || !r.Send || !r.Recv ||
-      !r.GroupStart || !r.GroupEnd) {
-    r.lib = nullptr;
-    return fail(RR_RUNTIME_ERROR, "librccl is missing a required symbol");
-  }
-  return RR_OK;
-}
-
-#define RR_NCCL_TRY(expr)                                                                                     \
-  do {                                                                                                        \
-    int _e = (expr);                                                                                          \
-    if (_e != 0)                                                                                              \
-      return fail(RR_RUNTIME_ERROR, std::string(#expr) + ": " +                                              \
-                                        (rccl().GetErrorString ? rccl().GetErrorString(_e) : "rccl error")); \
-  } while (0)
-}  // namespace
-
-struct rr_comm {
-  void* comm = nullptr;
-  int rank = 0, n_ranks = 1, device = 0;
-  // device scratch for the collectives
-  double* d_wmax = nullptr;      // [1]
-  uint64_t* d_sums = nullptr;    // [3]
-  uint64_t* d_all = nullptr;     // [n_ranks][3]
-  uint64_t* h_all = nullptr;     // pinned
-  double* d_send = nullptr;      // [cap_send][4]
-  double* d_recv = nullptr;      // [n_local][4]
-  size_t cap_send = 0, cap_recv = 0;
-  double* d_mom = nullptr;       // moments all-gather: [n_ranks][21]
-  double* h_mom = nullptr;       // pinned
-  std::vector<int64_t> matrix;
-};
-
 extern "C" {
 
 rr_status rr_comm_unique_id(uint8_t out[RR_COMM_UNIQUE_ID_BYTES]) {
@@ -2264,6 +2193,8 @@ void rr_comm_destroy(rr_comm* c) {
   if (c->h_all) (void)hipHostFree(c->h_all);
   (void)hipFree(c->d_send);
   (void)hipFree(c->d_recv);
+  (void)hipFree(c->d_fsend);
+  (void)hipFree(c->d_frecv);
   (void)hipFree(c->d_mom);
   if (c->h_mom) (void)hipHostFree(c->h_mom);
   delete c;

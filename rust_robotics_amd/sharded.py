@@ -497,9 +497,11 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
 
     if scheme != _ffi.RR_RESAMPLE_SYSTEMATIC:
         raise SystemExit("the sharded path resamples systematically (use --scheme systematic)")
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29555")  # a lone rank started without a launcher
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    own_group = not dist.is_initialized()  # bench.py keeps one gloo group for all its legs
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29555")  # a lone rank started without a launcher
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     u = [1.0, 0.1]
     kw = dict(seed=1, likelihood_mode=lik, initial_state=[0.0, 0.0, 0.0, 1.0])
@@ -644,7 +646,8 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
         p2p.close()
     if ref is not None:
         ref.close()
-    dist.destroy_process_group()
+    if own_group:
+        dist.destroy_process_group()
     return dict(seconds=seconds, seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est], dominant=None,
                 migrated_particles_last_step=moved, transport="p2p (xGMI, device-initiated)" if use_p2p else ref_kind,
                 transport_note="; ".join(notes), p2p_timed_out=bool(timed_out))

@@ -100,11 +100,14 @@ class FastSlam1:
     def _create(self, n_particles: int, n_landmarks: int, opt) -> None:
         _check(self._L.rr_fs1_create(n_particles, n_landmarks, C.byref(self.params), C.byref(opt), C.byref(self._h)))
 
-    def __del__(self):
+    def close(self) -> None:
         h = getattr(self, "_h", None)
         if h:
             self._L.rr_fs1_destroy(h)
             self._h = None
+
+    def __del__(self):
+        self.close()
 
     # ---- the reference's step
     def update(self, u, z) -> None:
@@ -229,7 +232,32 @@ class ShardedFastSlam1(FastSlam1):
     def __init__(self, rank: int, world: int, n_local: int, n_landmarks: int, *, device: int = 0, **kw):
         super().__init__(n_local, n_landmarks, device=device, first_global_index=rank * n_local, n_global=world * n_local,
                          **kw)
-        self.rank, self.world = rank, world
+        self.rank, self.world, self.device = rank, world, device
+        self._comm = None  # RCCL communicator (connect_rccl); None => the peer-to-peer transport
+
+    def connect_rccl(self, exchange) -> None:
+        """Use the RCCL transport (``rr_fs1_shard_update``: all-reduce MAX, all-gather of the integer sums,
+        grouped send/recv of whole particles).  ``exchange(bytes) -> bytes`` broadcasts rank 0's value
+        (e.g. ``sharded.gloo_exchange(dist)``); every rank calls this together."""
+        uid = (C.c_uint8 * 128)()
+        if self.rank == 0:
+            _check(self._L.rr_comm_unique_id(uid))
+        raw = exchange(bytes(uid))
+        uid = (C.c_uint8 * 128).from_buffer_copy(raw)
+        comm = C.c_void_p()
+        _check(self._L.rr_comm_create(uid, self.rank, self.world, self.device, C.byref(comm)))
+        self._comm = comm
+
+    def close(self) -> None:
+        if getattr(self, "_comm", None):
+            if getattr(self, "_h", None):
+                self._L.rr_fs1_synchronize(self._h)
+            self._L.rr_comm_destroy(self._comm)
+            self._comm = None
+        super().close()
+
+    def migrated(self) -> int:
+        return int(self._L.rr_fs1_shard_last_migrated(self._h))
 
     def connect_ipc(self, allgather) -> None:
         blob = (C.c_uint8 * _ffi.RR_P2P_HANDLE_BYTES)()
@@ -246,13 +274,18 @@ class ShardedFastSlam1(FastSlam1):
     def update_async(self, u, z) -> None:
         u = np.ascontiguousarray(u, dtype=np.float64)
         za = _z_array(z)
-        _check(self._L.rr_fs1_shard_update_p2p(self._h, _dp(u), _dp(za) if za.size else None, za.shape[0]))
+        if self._comm:
+            _check(self._L.rr_fs1_shard_update(self._h, self._comm, _dp(u), _dp(za) if za.size else None, za.shape[0]))
+        else:
+            _check(self._L.rr_fs1_shard_update_p2p(self._h, _dp(u), _dp(za) if za.size else None, za.shape[0]))
 
     def update(self, u, z) -> None:
         self.update_async(u, z)
         self.synchronize()
 
     def timed_out(self) -> bool:
+        if self._comm:
+            return False  # RCCL has no bounded waits of its own to report
         out = C.c_int32()
         _check(self._L.rr_fs1_p2p_status(self._h, C.byref(out)))
         return bool(out.value)
