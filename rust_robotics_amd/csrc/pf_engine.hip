@@ -758,6 +758,8 @@ struct rr_pf {
   unsigned int* markers = nullptr;  // n_global + kResolveSlots, zero between steps
   unsigned int* carry = nullptr;    // one per kResolveSlots slots
   double* partials = nullptr;
+  double* est_partials = nullptr;      // [kFusedMaxTiles][4] per-workgroup sums of the fused per-step estimate
+  unsigned int* est_ticket = nullptr;  // arrival counter of its last-workgroup reduction (zero between launches)
   double* scratch_a = nullptr;  // n doubles: explicit noise v / uniforms / AoS staging (5n)
   double* scratch_b = nullptr;  // n doubles: explicit noise w
   double* obs_dev = nullptr;
@@ -1000,7 +1002,7 @@ rr_status launch_sums(rr_pf* h, int mode, int scheme, double rho_override) {
 // The resample pipeline: integer image -> plan (gate) + CDF -> gather.  Every kernel after the
 // plan decides on the device whether it has anything to do.  mode 0 = gate, 1 = forced.
 rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, const double* r_explicit_dev,
-                          bool lazy = false, int settle = 0) {
+                          bool lazy = false, int settle = 0, bool want_estimate = false) {
   launch_quantize(h, wmax_source(h), settle);
   PlanArgs pa = plan_args(h, mode, scheme, rho_override);
   const bool lazy_mn = lazy && scheme == RR_RESAMPLE_MULTINOMIAL && h->lidx && !r_explicit_dev;
@@ -1016,9 +1018,22 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
   {
     Timed t(h, RR_K_CDF);
     const dim3 grid((unsigned)h->n_tiles), block(rr::kTileBlock);
-    if (sys && fused)
+    if (sys && fused) {
+      rr::EstArgs ea{};
+      if (want_estimate && lazy) {  // the mean the reference's try_step returns, from inside the plan kernel
+        for (int k = 0; k < 2; ++k) {
+          ea.field[k][0] = h->b.x[k];
+          ea.field[k][1] = h->b.y[k];
+          ea.field[k][2] = h->b.yaw[k];
+          ea.field[k][3] = h->b.v[k];
+        }
+        ea.partials = h->est_partials;
+        ea.ticket = h->est_ticket;
+        ea.want = 1;
+      }
       hipLaunchKernelGGL(rr::k_plan_mark, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total,
-                         h->tile_q2, h->n_tiles, pa, h->markers, h->carry);
+                         h->tile_q2, h->n_tiles, pa, h->markers, h->carry, ea);
+    }
     else if (sys)
       hipLaunchKernelGGL(rr::k_mark, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total, h->markers,
                          h->carry);
@@ -1316,6 +1331,9 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
     RR_TRY_OR_CLEAN(hipMalloc(&h->carry, (nm / rr::kResolveSlots + 2) * sizeof(unsigned int)));
   }
   RR_TRY_OR_CLEAN(hipMalloc(&h->partials, (size_t)kMomentBlocks * kNumMoments * sizeof(double)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->est_partials, (size_t)rr::kFusedMaxTiles * 4 * sizeof(double)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->est_ticket, sizeof(unsigned int)));
+  RR_TRY_OR_CLEAN(hipMemsetAsync(h->est_ticket, 0, sizeof(unsigned int), h->stream));
   RR_TRY_OR_CLEAN(hipMalloc(&h->ctl, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipHostMalloc(&h->ctl_host, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipMemsetAsync(h->ctl, 0, sizeof(Ctl), h->stream));
@@ -1467,6 +1485,8 @@ void rr_pf_destroy(rr_pf* h) {
   if (h->kld_out_host) (void)hipHostFree(h->kld_out_host);
   (void)hipFree(h->carry);
   (void)hipFree(h->partials);
+  (void)hipFree(h->est_partials);
+  (void)hipFree(h->est_ticket);
   (void)hipFree(h->scratch_a);
   (void)hipFree(h->scratch_b);
   (void)hipFree(h->obs_dev);
@@ -1558,7 +1578,13 @@ rr_status rr_pf_resample(rr_pf* h) {
   return launch_resample(h, 0, h->opt.resample_scheme, NAN, nullptr);
 }
 
-rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
+// want_estimate: the fused systematic step also leaves the mean of the particle set in Ctl.est
+static bool fused_estimate_available(const rr_pf* h) {
+  return !h->adaptive && h->opt.resample_scheme == RR_RESAMPLE_SYSTEMATIC && h->n_tiles <= (uint64_t)rr::kFusedMaxTiles &&
+         h->n == h->n_global;
+}
+
+static rr_status step_async_impl(rr_pf* h, const double control[2], const double* obs, size_t n_obs, bool want_estimate) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if ((s = validate_control(control)) != RR_OK) return s;
@@ -1623,7 +1649,28 @@ rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs,
   RR_HIP_TRY(hipGetLastError());
   h->step += 1;
   h->maybe_pending = h->pending_lidx = false;  // consumed (k_quantize_reduce settles Ctl.cur)
-  return launch_resample(h, 0, h->opt.resample_scheme, NAN, nullptr, /*lazy=*/true, /*settle=*/1);
+  return launch_resample(h, 0, h->opt.resample_scheme, NAN, nullptr, /*lazy=*/true, /*settle=*/1, want_estimate);
+}
+
+rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
+  return step_async_impl(h, control, obs, n_obs, false);
+}
+
+rr_status rr_pf_step_async_estimate(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
+  if (h && !fused_estimate_available(h))
+    return fail(RR_INVALID_PARAMETER, "the in-step estimate needs the fused systematic step (fixed N, systematic scheme, one shard, "
+                                      "<= 8 388 608 particles); use rr_pf_step / rr_pf_estimate");
+  return step_async_impl(h, control, obs, n_obs, true);
+}
+
+rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  if (h->ctl_host->est_step == 0) return fail(RR_INVALID_PARAMETER, "no step has produced an in-step estimate yet");
+  std::memcpy(out, h->ctl_host->est, 4 * sizeof(double));
+  return RR_OK;
 }
 
 rr_status rr_pf_synchronize(rr_pf* h) {
@@ -1650,6 +1697,13 @@ rr_status rr_pf_covariance(rr_pf* h, double out[16]) {
 }
 
 rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_t n_obs, double out_state[4]) {
+  if (h && out_state && fused_estimate_available(h)) {
+    // try_step (particle_filter.rs:488-497): the returned mean comes out of the step's own plan kernel -- one
+    // 300-byte read-back instead of a gather + a two-kernel moment reduction
+    rr_status s = step_async_impl(h, control, obs, n_obs, true);
+    if (s != RR_OK) return s;
+    return rr_pf_last_step_estimate(h, out_state);
+  }
   rr_status s = rr_pf_step_async(h, control, obs, n_obs);
   if (s != RR_OK) return s;
   if (!out_state) return rr_pf_synchronize(h);

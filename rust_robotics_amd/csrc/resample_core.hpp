@@ -67,6 +67,8 @@ struct Ctl {
   uint64_t best_index;
   uint64_t served_first;  // systematic plan: this shard's sources feed global slots [served_first,
   uint64_t served_count;  //   served_first + served_count) -- computed once by finalize_plan
+  double est[4];          // mean of the particle set after the step (fused plan kernel, EstArgs.want)
+  uint64_t est_step;      // resample-step counter the mean belongs to (+1; 0 = none yet)
 };
 
 // q_i of local particle i (global index gid0 + i)
@@ -453,16 +455,19 @@ constexpr int kResolveRows = 2;
 constexpr int kResolveSlots = kResolveRows * kBlock;  // slots per resolve workgroup
 
 // this thread's 8 consecutive sources: exclusive CDF prefix `off`, inclusive prefixes off + c[j]
+// offspring (may be null): number of output slots each of this thread's sources feeds
 __device__ inline void mark_sources(const TileScan& t, uint64_t off, uint64_t i0, uint64_t n, const rr_sys_plan plan,
                                     uint64_t total, uint64_t slot_base, unsigned int* __restrict__ markers,
-                                    unsigned int* __restrict__ carry) {
+                                    unsigned int* __restrict__ carry, unsigned int* offspring = nullptr) {
   const rr_sys_inv inv = rr_sys_inv_make(plan, total);
   uint64_t h_run = rr_sys_slots_upto(plan, inv, total, off);  // H of the source just before this thread's first
 #pragma unroll
   for (int j = 0; j < kItems; ++j) {
+    if (offspring) offspring[j] = 0;
     if (t.q[j] == 0 || i0 + j >= n) continue;  // zero-weight sources feed no slot: H_j == H_{j-1}
     const uint64_t h = rr_sys_slots_upto(plan, inv, total, off + t.c[j]);
     if (h > h_run) {
+      if (offspring) offspring[j] = (unsigned int)(h - h_run);
       const uint64_t lo = h_run - slot_base, hi = h - slot_base;
       markers[lo] = (unsigned int)(i0 + j + 1);
       for (uint64_t b = (lo + kResolveSlots - 1) / kResolveSlots; b * kResolveSlots < hi; ++b)
@@ -472,12 +477,75 @@ __device__ inline void mark_sources(const TileScan& t, uint64_t off, uint64_t i0
   }
 }
 
+// The estimate the reference's try_step returns (particle_filter.rs:382-396 evaluated at :343 / :332,
+// Q15), produced INSIDE the plan kernel: the mean of the particle set as the step leaves it is
+//   fired:      sum_j offspring_j * p_j / N     (the resampled set has uniform weights, :468)
+//   not fired:  sum_j q_j * p_j / T             (q = the integer image of the weights, T = sum q)
+// and this kernel already holds offspring_j / q_j of its 8 sources per thread.  Per-workgroup partial
+// sums go to `partials`; the last workgroup to arrive (ticket) adds them in workgroup order -- a
+// fixed order, so the result is reproducible -- and publishes Ctl.est.  Lazy-gather plans only
+// (Ctl.cur is not touched by this kernel then).
+struct EstArgs {
+  const double* field[2][4];  // x, y, yaw, v of both buffer sets
+  double* partials;           // [n_tiles][4]
+  unsigned int* ticket;       // zero between launches
+  int want;
+};
+
+__device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, const TileScan& t, const unsigned int* offspring,
+                                     int fire, uint64_t i0, uint64_t n, double denom, unsigned int rstep) {
+  __shared__ double s_acc[kBlock / kWave][4];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cur = ctl->cur;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    const double c = fire ? (double)offspring[j] : (double)t.q[j];
+    if (c != 0.0 && i0 + j < n) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[k] = rr_fma(c, ea.field[cur][k][i0 + j], acc[k]);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double v = wave_sum(acc[k]);
+    if (lane == 0) s_acc[wv][k] = v;
+  }
+  __syncthreads();
+  if (tid == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      double v = 0.0;
+      for (int q = 0; q < kBlock / kWave; ++q) v += s_acc[q][k];
+      ea.partials[(uint64_t)blockIdx.x * 4 + k] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int ticket = atomicAdd(ea.ticket, 1u);
+    s_last = ticket == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  // wave k adds moment k over the workgroups: lanes stride (fixed order per lane), then a shuffle tree
+  double v = 0.0;
+  for (unsigned int b = lane; b < gridDim.x; b += 64) v += __builtin_nontemporal_load(&ea.partials[(uint64_t)b * 4 + wv]);
+  v = wave_sum(v);
+  if (lane == 0) ctl->est[wv] = v / denom;
+  if (tid == 0) {
+    ctl->est_step = (uint64_t)rstep + 1;
+    *ea.ticket = 0;
+  }
+}
+
 // fused plan + mark (single shard, systematic, n_tiles <= kFusedMaxTiles)
 static __global__ __launch_bounds__(kBlock) void k_plan_mark(const double* __restrict__ w, Ctl* __restrict__ ctl,
                                                             ImageArgs a, const uint64_t* __restrict__ tile_total,
                                                             const uint64_t* __restrict__ tile_q2, uint64_t n_tiles,
                                                             PlanArgs pa, unsigned int* __restrict__ markers,
-                                                            unsigned int* __restrict__ carry) {
+                                                            unsigned int* __restrict__ carry, EstArgs ea) {
   __shared__ uint64_t s4[4 * (kBlock / kWave)];
   __shared__ uint64_t s_w[kBlock / kWave];
   const TileSums ts = tile_sums(tile_total, tile_q2, n_tiles, s4);
@@ -491,11 +559,15 @@ static __global__ __launch_bounds__(kBlock) void k_plan_mark(const double* __res
     rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) finalize_plan(ctl, ts.tot, 0, ts.tot, ts.q2, pa);
-  if (!fire) return;
-  const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
+  if (!fire && !ea.want) return;
   const TileScan t = tile_scan(w, a, mode, shift, blockIdx.x, s_w);
   const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
-  mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry);
+  unsigned int offspring[kItems];
+  if (fire) {
+    const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
+    mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry, ea.want ? offspring : nullptr);
+  }
+  if (ea.want) plan_estimate(ea, ctl, t, offspring, fire, i0, a.n, fire ? (double)pa.n_global : (double)ts.tot, pa.rstep);
 }
 
 // sharded: the plan is already in Ctl (k_shard_plan); mark this shard's sources.  tile_offset =

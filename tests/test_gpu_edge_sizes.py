@@ -126,11 +126,11 @@ def test_fastslam_without_landmarks():
     poses = np.column_stack([np.full(n, 1.0 / n), rng.normal(0, 1, n), rng.normal(0, 1, n), rng.uniform(-3, 3, n)])
     for _ in range(2):  # both buffer sets take a turn as "the inactive one"
         f.set_state(poses, None)
-        got = f.get_poses()
+        got = f.poses()
         assert bits_eq(got, poses)
         f.update([1.0, 0.1], [])
         f.resample_systematic(0.25)
-        moved = f.get_poses()
+        moved = f.poses()
         assert np.all(np.isfinite(moved)) and moved.shape == (n, 4)
         assert np.allclose(moved[:, 0], 1.0 / n)
     pose, w, i = f.best_particle()
