@@ -222,13 +222,11 @@ RR_HD double rr_atan_pos(double y, double x) {
   int swap = y > x;
   double num = swap ? x : y;
   double den = swap ? y : x;
-  double t = num / den; /* in [0,1] */
-  double base_hi = 0.0, base_lo = 0.0;
-  if (t > RR_TAN_PIO8) {
-    t = (t - 1.0) / (t + 1.0); /* atan(t) = pi/4 + atan(t') */
-    base_hi = RR_PIO4_HI;
-    base_lo = RR_PIO4_LO;
-  }
+  /* num/den in [0,1]; above tan(pi/8): atan(t) = pi/4 + atan((t - 1)/(t + 1)) with the quotient formed
+   * directly as (num - den)/(num + den) -- one division on either branch */
+  int big = num > RR_TAN_PIO8 * den;
+  double t = (big ? num - den : num) / (big ? num + den : den);
+  double base_hi = big ? RR_PIO4_HI : 0.0, base_lo = big ? RR_PIO4_LO : 0.0;
   double z = t * t;
   double p = RR_ATAN_C_13;
   p = rr_fma(p, z, RR_ATAN_C_12);

@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -128,17 +129,22 @@ __global__ __launch_bounds__(kBlock) void k_fs2_predict(Planes pl, const Ctl* __
 // (particle, observation chunk).  blockIdx.y = chunk.  The chunk's observations are staged in
 // LDS and read back with wave-uniform addresses; each update loads the 6 planes of the observed
 // landmark for 64 consecutive particles (coalesced), runs the 2x2 EKF of rr_fs1_update_one and
-// stores only the fields that changed.
+// stores the six fields back (a field the update left alone is rewritten with the same bits).
 // SEQ (a landmark id repeats inside the step; host side: one chunk, in place, nothing pending): the
 // second update of a landmark must see the first one's result (fastslam1.rs:250-256 runs the
 // observations one after the other), so every update loads its planes only after the previous
 // update's stores -- no software pipeline, no restrict-qualified alias of the live set.
-template <bool LAZY, bool SEQ>
-__global__ __launch_bounds__(kBlock) void k_fs1_observe(Planes pl, double* __restrict__ pw, Ctl* __restrict__ ctl,
-                                                       uint64_t n, const double* __restrict__ z, int n_z,
-                                                       int chunk_len, int n_chunks, rr_fs1_model m,
-                                                       double* __restrict__ partial,
-                                                       const unsigned int* __restrict__ idx) {
+// VAR: tuning variants of the same arithmetic (RR_FS1_VARIANT; identical results):
+//   bit 0  non-temporal stores while a pending resample is being consumed (separate read and write streams)
+//   bit 1  non-temporal loads on that path as well
+//   bit 2  no software pipeline (loads at the top of each update)
+//   bit 3  register budget for 4 waves per SIMD instead of 3
+constexpr int kObsNtStore = 1, kObsNtLoad = 2, kObsNoPipe = 4, kObsFourWaves = 8;
+
+template <bool LAZY, bool SEQ, int VAR>
+__global__ __launch_bounds__(kBlock, (VAR & kObsFourWaves) ? 4 : 1) void k_fs1_observe(
+    Planes pl, double* __restrict__ pw, Ctl* __restrict__ ctl, uint64_t n, const double* __restrict__ z, int n_z, int chunk_len,
+    int n_chunks, rr_fs1_model m, double* __restrict__ partial, const unsigned int* __restrict__ idx) {
   extern __shared__ double s_z[];
   __shared__ double s_wmax[kBlock / rr::kWave];
   const int chunk = blockIdx.y;
@@ -154,6 +160,7 @@ __global__ __launch_bounds__(kBlock) void k_fs1_observe(Planes pl, double* __res
     // folds the resample gather of the observed landmarks into this kernel's own traffic.  The
     // pose was already moved by k_fs1_predict<LAZY>.
     const bool pending = LAZY && ctl->pending;
+    const bool nt_st = pending && (VAR & kObsNtStore), nt_ld = pending && (VAR & kObsNtLoad);
     double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
     const unsigned int ji = pending ? idx[p] : (unsigned int)p;
     const bool inplace = pending && ji == kInPlace;
@@ -161,46 +168,61 @@ __global__ __launch_bounds__(kBlock) void k_fs1_observe(Planes pl, double* __res
     const uint64_t j = inplace ? p : ji;
     const double px = dst[p], py = dst[n + p], pyaw = dst[2 * n + p];
     acc = chunk == 0 ? pw[p] : 1.0;
-    // software pipeline: the six plane loads of observation k+1 are issued before the ~300
-    // FP64 instructions of update k, so two updates' worth of HBM requests are in flight per wave
-    // (the kernel runs at 3 waves per SIMD; bytes in flight, not arithmetic, set its speed)
     const int nk = k1 - k0;
+    auto load6 = [&](const double* in, double* v) {
+      if (nt_ld) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) v[f] = __builtin_nontemporal_load(in + f * n);
+      } else {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) v[f] = in[f * n];
+      }
+    };
+    auto store6 = [&](double* out, const double* v) {
+      if (nt_st) {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) __builtin_nontemporal_store(v[f], out + f * n);
+      } else {
+#pragma unroll
+        for (int f = 0; f < 6; ++f) out[f * n] = v[f];
+      }
+    };
     if (SEQ) {
       double* live = pl.s[ctl->cur];
       for (int k = 0; k < nk; ++k) {
         const double zd = s_z[3 * k], za = s_z[3 * k + 1];
         double* io = live + (3 + (uint64_t)s_z[3 * k + 2] * 6) * n + p;
-        double e[6], o[6];
+        double e[6];
 #pragma unroll
-        for (int f = 0; f < 6; ++f) o[f] = e[f] = io[f * n];
+        for (int f = 0; f < 6; ++f) e[f] = io[f * n];
         acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
 #pragma unroll
-        for (int f = 0; f < 6; ++f)
-          if (rr_d2u(e[f]) != rr_d2u(o[f])) io[f * n] = e[f];
+        for (int f = 0; f < 6; ++f) io[f * n] = e[f];
       }
-    }
-    double nxt[6];
-    if (!SEQ && nk > 0) {
-      const double* in0 = src + (3 + (uint64_t)s_z[2] * 6) * n + j;
-#pragma unroll
-      for (int f = 0; f < 6; ++f) nxt[f] = in0[f * n];
-    }
-    for (int k = 0; !SEQ && k < nk; ++k) {
-      const double zd = s_z[3 * k], za = s_z[3 * k + 1];
-      const uint64_t id = (uint64_t)s_z[3 * k + 2];
-      double* out0 = dst + (3 + id * 6) * n + p;
-      double e[6], o[6];
-#pragma unroll
-      for (int f = 0; f < 6; ++f) o[f] = e[f] = nxt[f];
-      if (k + 1 < nk) {
-        const double* in1 = src + (3 + (uint64_t)s_z[3 * k + 5] * 6) * n + j;
-#pragma unroll
-        for (int f = 0; f < 6; ++f) nxt[f] = in1[f * n];
+    } else if (VAR & kObsNoPipe) {
+      for (int k = 0; k < nk; ++k) {
+        const double zd = s_z[3 * k], za = s_z[3 * k + 1];
+        const uint64_t id = (uint64_t)s_z[3 * k + 2];
+        double e[6];
+        load6(src + (3 + id * 6) * n + j, e);
+        acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
+        store6(dst + (3 + id * 6) * n + p, e);
       }
-      acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
+    } else {
+      // software pipeline: the six plane loads of observation k+1 are issued before the FP64
+      // instructions of update k, so two updates' worth of HBM requests are in flight per wave
+      double nxt[6];
+      if (nk > 0) load6(src + (3 + (uint64_t)s_z[2] * 6) * n + j, nxt);
+      for (int k = 0; k < nk; ++k) {
+        const double zd = s_z[3 * k], za = s_z[3 * k + 1];
+        const uint64_t id = (uint64_t)s_z[3 * k + 2];
+        double e[6];
 #pragma unroll
-      for (int f = 0; f < 6; ++f)
-        if (pending || rr_d2u(e[f]) != rr_d2u(o[f])) out0[f * n] = e[f];
+        for (int f = 0; f < 6; ++f) e[f] = nxt[f];
+        if (k + 1 < nk) load6(src + (3 + (uint64_t)s_z[3 * k + 5] * 6) * n + j, nxt);
+        acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
+        store6(dst + (3 + id * 6) * n + p, e);
+      }
     }
     if (n_chunks == 1) pw[p] = acc;
     else partial[(uint64_t)chunk * n + p] = acc;
@@ -580,6 +602,7 @@ struct rr_fs1 {
   double* slab = nullptr;  // [set][plane][n]
   rr::P2PState p2p;
   double* own_inbox = nullptr;  // RCCL transport: plain device mirror of one buffer set (the peer-to-peer transport brings its own)
+  int obs_variant = 0;          // RR_FS1_VARIANT: tuning variant of k_fs1_observe (identical results)
   int shard_settle = 0;         // RCCL transport: the local phase consumed a pending resample (k_quantize_reduce flips Ctl.cur)
   uint64_t last_migrated = 0;
   double* pw = nullptr;
@@ -779,26 +802,35 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool 
       eb = h->prof.take();
       h->prof.events.push_back({RR_FK_OBSERVE, ea, eb});
     }
-    if (dup)  // repeated landmark ids: strictly sequential updates (chunks == 1, in place)
-      hipLaunchKernelGGL((k_fs1_observe<false, true>), grid, dim3(kBlock), lds, h->stream, h->pl, h->pw, h->ctl, h->n,
-                         (const double*)h->z_dev, (int)n_z, len, chunks, model_of(h), h->partial,
-                         (const unsigned int*)h->idx);
-    else if (ea && lazy)
-      hipExtLaunchKernelGGL((k_fs1_observe<true, false>), grid, dim3(kBlock), lds, h->stream, ea, eb, 0, h->pl, h->pw, h->ctl, h->n,
-                            (const double*)h->z_dev, (int)n_z, len, chunks, model_of(h), h->partial,
-                            (const unsigned int*)h->idx);
-    else if (ea)
-      hipExtLaunchKernelGGL((k_fs1_observe<false, false>), grid, dim3(kBlock), lds, h->stream, ea, eb, 0, h->pl, h->pw, h->ctl, h->n,
-                            (const double*)h->z_dev, (int)n_z, len, chunks, model_of(h), h->partial,
-                            (const unsigned int*)h->idx);
-    else if (lazy)
-      hipLaunchKernelGGL((k_fs1_observe<true, false>), grid, dim3(kBlock), lds, h->stream, h->pl, h->pw, h->ctl, h->n,
-                         (const double*)h->z_dev, (int)n_z, len, chunks, model_of(h), h->partial,
-                         (const unsigned int*)h->idx);
-    else
-      hipLaunchKernelGGL((k_fs1_observe<false, false>), grid, dim3(kBlock), lds, h->stream, h->pl, h->pw, h->ctl, h->n,
-                         (const double*)h->z_dev, (int)n_z, len, chunks, model_of(h), h->partial,
-                         (const unsigned int*)h->idx);
+    const void* kfn = nullptr;
+    // (the kernel pointer is chosen first so that the stamped and the plain launch share one argument list)
+#define RR_OBS_KERNEL(LAZY_, SEQ_, VAR_) ((const void*)(k_fs1_observe<LAZY_, SEQ_, VAR_>))
+    if (dup) kfn = RR_OBS_KERNEL(false, true, 0);  // repeated landmark ids: strictly sequential updates (chunks == 1, in place)
+    else if (!lazy) kfn = RR_OBS_KERNEL(false, false, 0);
+    else {
+      switch (h->obs_variant) {
+        case 1: kfn = RR_OBS_KERNEL(true, false, kObsNtStore); break;
+        case 2: kfn = RR_OBS_KERNEL(true, false, kObsNtStore | kObsNtLoad); break;
+        case 3: kfn = RR_OBS_KERNEL(true, false, kObsNoPipe | kObsFourWaves); break;
+        case 4: kfn = RR_OBS_KERNEL(true, false, kObsNoPipe | kObsFourWaves | kObsNtStore); break;
+        case 5: kfn = RR_OBS_KERNEL(true, false, kObsFourWaves); break;
+        case 6: kfn = RR_OBS_KERNEL(true, false, kObsNoPipe); break;
+        default: kfn = RR_OBS_KERNEL(true, false, 0); break;
+      }
+    }
+#undef RR_OBS_KERNEL
+    Planes a_pl = h->pl;
+    double* a_pw = h->pw;
+    Ctl* a_ctl = h->ctl;
+    uint64_t a_n = h->n;
+    const double* a_z = h->z_dev;
+    int a_nz = (int)n_z, a_len = len, a_chunks = chunks;
+    rr_fs1_model a_m = model_of(h);
+    double* a_partial = h->partial;
+    const unsigned int* a_idx = h->idx;
+    void* args[] = {&a_pl, &a_pw, &a_ctl, &a_n, &a_z, &a_nz, &a_len, &a_chunks, &a_m, &a_partial, &a_idx};
+    if (ea && !dup) RR_HIP_TRY(hipExtLaunchKernel(kfn, grid, dim3(kBlock), args, lds, h->stream, ea, eb, 0));
+    else RR_HIP_TRY(hipLaunchKernel(kfn, grid, dim3(kBlock), args, lds, h->stream));
   }
   if (chunks > 1) {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_COMBINE);
@@ -949,6 +981,7 @@ rr_status rr_fs1_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs1
   h->gid0 = opt.first_global_index;
   h->n_planes = 3 + 6 * n_landmarks;
   h->n_tiles = (h->n + kTile - 1) / kTile;
+  if (const char* e = std::getenv("RR_FS1_VARIANT")) h->obs_variant = std::atoi(e);
   auto cleanup = [&](rr_status st) {
     rr_fs1_destroy(h);
     return st;

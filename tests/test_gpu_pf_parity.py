@@ -352,6 +352,41 @@ def test_trajectory_vs_literal_reference(loc, det, ref):
     assert mism == 0, f"{mism} resample indices differ from the literal reference walk"
 
 
+@pytest.mark.parametrize("mcl", [False, True])
+def test_in_step_estimate_matches_the_accessor_and_the_reference(loc, ref, mcl):
+    """rr_pf_step_async_estimate: the mean try_step returns (particle_filter.rs:496), accumulated inside the plan kernel
+    from the offspring counts (fired) or the integer image of the weights (gate closed), against (a) the lazy accessor
+    (gather + moment kernels) and (b) ref_pf_estimate of the literal restatement on the same particle set."""
+    n, L, T = 20_000, 6, 14
+    lms = H.landmarks_grid(L, 3)
+    kw = dict(seed=7, resample_scheme=1)
+    if mcl:
+        cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.5)
+        pf = loc.MonteCarloLocalizer(cfg, **kw)
+    else:
+        cfg = loc.ParticleFilterConfig(n_particles=n, range_noise=0.5, resample_threshold=0.5)  # the gate opens on 5 of the 14 steps (D-spec run)
+        pf = loc.ParticleFilterLocalizer(cfg, **kw)
+    rng = np.random.default_rng(8)
+    fired = []
+    for t in range(T):
+        obs = H.observations(lms, H.true_pose(t + 1), 0.5, rng)
+        pf.step_async_estimate([1.0, 0.1], obs)
+        got = pf.last_step_estimate()
+        fired.append(pf.last_resample_fired())
+        p = pf.get_particles_array()
+        acc = pf.estimate()
+        np.testing.assert_allclose(got, acc, rtol=1e-11, atol=1e-11)
+        est = np.empty(4)
+        x, y, yaw, v, w = (np.ascontiguousarray(p[:, k]) for k in range(5))
+        ref.ref_pf_estimate(n, dp(x), dp(y), dp(yaw), dp(v), dp(w), dp(est))
+        np.testing.assert_allclose(got, est, **TOL)
+        # rr_pf_step returns the same number through the same path
+    if not mcl:
+        assert any(fired) and not all(fired), fired
+    est2 = pf.step([1.0, 0.1], H.observations(lms, H.true_pose(T + 1), 0.5, rng))
+    np.testing.assert_allclose(est2, pf.estimate(), rtol=1e-11, atol=1e-11)
+
+
 # ------------------------------------------------------------------ API surface / error behaviour
 def test_reference_unit_tests_reexpressed(loc):
     """particle_filter.rs:575-707 against the engine"""
