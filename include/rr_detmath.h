@@ -110,17 +110,8 @@ RR_HD double rr_exp(double x) {
 }
 
 /* ------------------------------------------------------------------ log (x > 0) */
-RR_HD double rr_log(double x) {
-  if (x != x || x < 0.0) return rr_u2d(0x7ff8000000000000ull);
-  if (x == 0.0) return rr_u2d(0xfff0000000000000ull);
-  uint64_t u = rr_d2u(x);
-  if (u >= 0x7ff0000000000000ull) return x; /* +inf */
-  int e = 0;
-  if (u < 0x0010000000000000ull) { /* subnormal */
-    x = x * 0x1p54;
-    u = rr_d2u(x);
-    e = -54;
-  }
+/* log of a finite positive NORMAL double with bit pattern u, times 2^e_bias: the branch-free core */
+RR_HD double rr_log_core(uint64_t u, int e) {
   e += (int)(u >> 52) - 1023;
   double m = rr_u2d((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull); /* [1,2) */
   if (m > RR_SQRT2) {
@@ -145,6 +136,20 @@ RR_HD double rr_log(double x) {
   double lm = 2.0 * rr_fma(t, p, s);
   double de = (double)e;
   return rr_fma(de, RR_LN2_HI, rr_fma(de, RR_LN2_LO, lm));
+}
+
+RR_HD double rr_log(double x) {
+  if (x != x || x < 0.0) return rr_u2d(0x7ff8000000000000ull);
+  if (x == 0.0) return rr_u2d(0xfff0000000000000ull);
+  uint64_t u = rr_d2u(x);
+  if (u >= 0x7ff0000000000000ull) return x; /* +inf */
+  int e = 0;
+  if (u < 0x0010000000000000ull) { /* subnormal */
+    x = x * 0x1p54;
+    u = rr_d2u(x);
+    e = -54;
+  }
+  return rr_log_core(u, e);
 }
 
 /* ------------------------------------------------------------------ sin/cos kernels, |r| <= pi/4 */
@@ -281,8 +286,13 @@ typedef struct rr_philox4 {
   uint32_t v[4];
 } rr_philox4;
 
-RR_HD rr_philox4 rr_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
-  for (int i = 0; i < 10; ++i) {
+/* The engine's streams run RR_PHILOX_ROUNDS = 7 rounds: the smallest round count Salmon et al. report as
+ * Crush-resistant for Philox4x32 (their Table 2; 10 is the conservative default).  The round function is pinned
+ * by the published Random123 known answers of the 10-round form (tests/test_detmath.py). */
+#define RR_PHILOX_ROUNDS 7
+
+RR_HD rr_philox4 rr_philox4x32_n(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int rounds) {
+  for (int i = 0; i < rounds; ++i) {
     uint64_t p0 = (uint64_t)RR_PHILOX_M0 * c0;
     uint64_t p1 = (uint64_t)RR_PHILOX_M1 * c2;
     uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
@@ -297,6 +307,12 @@ RR_HD rr_philox4 rr_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_
   r.v[0] = c0; r.v[1] = c1; r.v[2] = c2; r.v[3] = c3;
   return r;
 }
+RR_HD rr_philox4 rr_philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  return rr_philox4x32_n(c0, c1, c2, c3, k0, k1, 10);
+}
+RR_HD rr_philox4 rr_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+  return rr_philox4x32_n(c0, c1, c2, c3, k0, k1, RR_PHILOX_ROUNDS);
+}
 
 /* Streams of the engine: what a (seed, stream, step, index) counter is used for. */
 enum {
@@ -310,20 +326,31 @@ enum {
 
 /* two uniforms in [0,1) with 53 random bits each */
 RR_HD void rr_uniform2(uint64_t seed, uint32_t stream, uint32_t step, uint64_t index, double* u0, double* u1) {
-  rr_philox4 r = rr_philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), step, stream,
-                                  (uint32_t)seed, (uint32_t)(seed >> 32));
+  rr_philox4 r = rr_philox4x32((uint32_t)index, (uint32_t)(index >> 32), step, stream,
+                               (uint32_t)seed, (uint32_t)(seed >> 32));
   uint64_t a = ((uint64_t)r.v[1] << 32) | r.v[0];
   uint64_t b = ((uint64_t)r.v[3] << 32) | r.v[2];
   *u0 = (double)(a >> 11) * 0x1p-53;
   *u1 = (double)(b >> 11) * 0x1p-53;
 }
 
-/* two independent N(0,1) draws (Box-Muller on the two uniforms above) */
+/* Two independent N(0,1) draws: Box-Muller on one Philox block.  The radius uniform v is an odd multiple
+ * of 2^-53 in (0,1) -- 52 random bits placed in the mantissa of a double in [1,2), minus (1 - 2^-53),
+ * exact -- so log(v) < 0 strictly, the argument of the square root lies in [2^-52, 73.5) and neither the
+ * log nor the sqrt needs a special case; the angle uniform is a multiple of 2^-52 in [0,1). */
 RR_HD void rr_normal2(uint64_t seed, uint32_t stream, uint32_t step, uint64_t index, double* z0, double* z1) {
-  double u0, u1;
-  rr_uniform2(seed, stream, step, index, &u0, &u1);
-  double v = 1.0 - u0; /* (0,1], exact */
-  double rad = rr_sqrt(-2.0 * rr_log(v));
+  rr_philox4 r = rr_philox4x32((uint32_t)index, (uint32_t)(index >> 32), step, stream,
+                               (uint32_t)seed, (uint32_t)(seed >> 32));
+  uint64_t a = ((uint64_t)r.v[1] << 32) | r.v[0];
+  uint64_t b = ((uint64_t)r.v[3] << 32) | r.v[2];
+  double v = rr_u2d(0x3ff0000000000000ull | (a >> 12)) - 0x1.fffffffffffffp-1;
+  double u1 = rr_u2d(0x3ff0000000000000ull | (b >> 12)) - 1.0;
+  double t = -2.0 * rr_log_core(rr_d2u(v), 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+  double rad = rr_sqrt_core(t); /* == rr_sqrt(t) on [2^-767, inf) */
+#else
+  double rad = rr_sqrt(t);
+#endif
   double s, c;
   rr_sincos2pi(u1, &s, &c);
   *z0 = rad * c;

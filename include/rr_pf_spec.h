@@ -99,29 +99,39 @@ RR_HD double rr_pf_weight_product(double x, double y, const double* obs, int n_o
  * one exp per particle instead of one per pair (SURVEY.md section 7 "hard parts").
  * Differs from the product form by ~1e-13 relative, and in the deep-underflow
  * regime (w < 1e-290) where the running product loses bits first. */
+/* The squared range carries a floor of 2^-700 m^2 (q = dy^2 + (dx^2 + 2^-700), two fmas): it changes no
+ * q above 2^-647 and moves the predicted range of a particle sitting on a landmark by < 2^-350 m, and it keeps
+ * every argument of the device's bare square-root core inside its exact range without a per-pair check. */
+#define RR_PF_Q_FLOOR 0x1p-700
+RR_HD double rr_pf_residual_fused(double x, double y, double d_obs, double lx, double ly) {
+  double dx = x - lx;
+  double dy = y - ly;
+  double q = rr_fma(dy, dy, rr_fma(dx, dx, RR_PF_Q_FLOOR));
+  return d_obs - rr_sqrt(q);
+}
+
 RR_HD double rr_pf_weight_fused(double x, double y, const double* obs, int n_obs, rr_pf_lik k) {
   double ss = 0.0;
 #if defined(__HIP_DEVICE_COMPILE__)
-  /* branch-free inner loop on the sqrt core; one range check per particle afterwards */
-  double qmin = 0x1p+1000;
+  /* branch-free inner loop on the sqrt core (== rr_sqrt for finite q >= 2^-767); an overflowing q (inf) turns
+   * ss into NaN, which sends the particle through the exact form once */
   for (int l = 0; l < n_obs; ++l) {
     double dx = x - obs[3 * l + 1];
     double dy = y - obs[3 * l + 2];
-    double q = rr_fma(dy, dy, dx * dx);
-    qmin = __builtin_fmin(q, qmin); /* one v_min_f64; a NaN q leaves qmin alone and poisons ss instead */
+    double q = rr_fma(dy, dy, rr_fma(dx, dx, RR_PF_Q_FLOOR));
     double diff = obs[3 * l] - rr_sqrt_core(q);
     ss = rr_fma(diff, diff, ss);
   }
-  if (!(qmin >= 0x1p-767) || ss != ss) { /* some q was 0, tiny, inf or NaN: exact slow path */
+  if (ss != ss) {
     ss = 0.0;
     for (int l = 0; l < n_obs; ++l) {
-      double diff = rr_pf_residual(x, y, obs[3 * l], obs[3 * l + 1], obs[3 * l + 2]);
+      double diff = rr_pf_residual_fused(x, y, obs[3 * l], obs[3 * l + 1], obs[3 * l + 2]);
       ss = rr_fma(diff, diff, ss);
     }
   }
 #else
   for (int l = 0; l < n_obs; ++l) {
-    double diff = rr_pf_residual(x, y, obs[3 * l], obs[3 * l + 1], obs[3 * l + 2]);
+    double diff = rr_pf_residual_fused(x, y, obs[3 * l], obs[3 * l + 1], obs[3 * l + 2]);
     ss = rr_fma(diff, diff, ss);
   }
 #endif

@@ -278,6 +278,58 @@ __global__ __launch_bounds__(kBlock) void k_fs1_normalize(double* __restrict__ p
   if (p < n) pw[p] = pw[p] / ctl->sum;
 }
 
+// Single-GPU plan, fused (the MCL engine's k_plan_mark shape, resample_core.hpp): every workgroup re-derives its tile
+// offset and the grand totals from the tile totals, takes the gate decision (fastslam1.rs:262-265) and then either
+// normalises its tile's weights (:196-203, gate shut) or marks the slot run each of its sources feeds (:205-234) and
+// sets the weights to 1/n (:228).  One launch instead of k_scan_tiles + k_cdf + k_fs1_normalize + k_fs1_indices, no
+// CDF array, no per-slot binary search.  k_fs1_resolve turns the markers into idx[] (running maximum per 512 slots).
+__global__ __launch_bounds__(kBlock) void k_fs1_plan(double* pw /* read (tile_scan) and rewritten: no restrict */, Ctl* __restrict__ ctl, ImageArgs a,
+                                                    const uint64_t* __restrict__ tile_total,
+                                                    const uint64_t* __restrict__ tile_q2, uint64_t n_tiles, PlanArgs pa,
+                                                    unsigned int* __restrict__ markers, unsigned int* __restrict__ carry) {
+  __shared__ uint64_t s4[4 * (kBlock / rr::kWave)];
+  __shared__ uint64_t s_w[kBlock / rr::kWave];
+  const rr::TileSums ts = rr::tile_sums(tile_total, tile_q2, n_tiles, s4);
+  const int mode = ctl->image_mode;
+  const int shift = ctl->shift;
+  const int fire = rr::gate_decision(mode, ts, pa);
+  double rho = pa.rho_override;
+  if (rho != rho) {
+    double dummy;
+    rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) rr::finalize_plan(ctl, ts.tot, 0, ts.tot, ts.q2, pa);
+  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * rr::kItems;
+  if (!fire) {
+    if (mode != rr::kImageWeights) return;  // all-zero weights stay untouched (fastslam1.rs:198-202)
+    const double sum = rr_fix_total_to_double(ts.tot, shift);
+#pragma unroll
+    for (int j = 0; j < rr::kItems; ++j)
+      if (i0 + j < a.n) pw[i0 + j] = pw[i0 + j] / sum;
+    return;
+  }
+  const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
+  const rr::TileScan t = rr::tile_scan(pw, a, mode, shift, blockIdx.x, s_w);  // reads this tile's weights ...
+  rr::mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry);
+  const double w_new = 1.0 / (double)pa.n_global;
+#pragma unroll
+  for (int j = 0; j < rr::kItems; ++j)
+    if (i0 + j < a.n) pw[i0 + j] = w_new;  // ... before the same threads overwrite them
+}
+
+__global__ __launch_bounds__(kBlock) void k_fs1_resolve(const Ctl* __restrict__ ctl, unsigned int* __restrict__ markers,
+                                                       const unsigned int* __restrict__ carry, uint64_t n,
+                                                       unsigned int* __restrict__ idx) {
+  if (!ctl->fired) return;
+  unsigned int src[rr::kResolveRows];
+  rr::resolve_tile(markers, carry, n, blockIdx.x, src);
+#pragma unroll
+  for (int r = 0; r < rr::kResolveRows; ++r) {
+    const uint64_t k = (uint64_t)blockIdx.x * rr::kResolveSlots + (uint64_t)r * kBlock + threadIdx.x;
+    if (k < n) idx[k] = src[r];
+  }
+}
+
 // sharded variants.  Slots this shard serves: [first, first + n_served) with
 // first = slots_upto(base), n_served = slots_upto(base + T_local) - first (device-side only).
 __device__ inline void served_range(const Ctl* ctl, uint64_t* first, uint64_t* n_served) {
@@ -610,6 +662,8 @@ struct rr_fs1 {
   uint64_t* tile_total = nullptr;
   uint64_t* tile_q2 = nullptr;
   unsigned int* idx = nullptr;
+  unsigned int* markers = nullptr;  // n + kResolveSlots, zero between resamples (fused single-GPU plan)
+  unsigned int* carry = nullptr;    // one per kResolveSlots slots
   unsigned int* ridx = nullptr;  // sharded: sources of the served slots that belong to peers (allocated on connect)
   double* partial = nullptr;  // kMaxChunks * n
   double* z_dev = nullptr;
@@ -889,6 +943,37 @@ rr_status launch_finish(rr_fs1* h, bool lazy = false) {
   return RR_OK;
 }
 
+// gate + normalise-or-resample of a single-GPU update in two launches after k_quantize_reduce (lazy: the particles
+// move when the next update, or an accessor, reads them through idx)
+rr_status launch_plan_fused(rr_fs1* h, int settle) {
+  if (!h->wmax_live) {
+    RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+    hipLaunchKernelGGL(k_fs1_wmax, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
+  }
+  h->wmax_live = false;
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_QUANTIZE_REDUCE);
+    hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
+                       (const double*)&h->ctl->wmax_bits, image_args(h), h->tile_total, h->tile_q2, settle);
+  }
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_CDF);
+    hipLaunchKernelGGL(k_fs1_plan, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl, image_args(h),
+                       h->tile_total, h->tile_q2, h->n_tiles, plan_args(h, 0, NAN, /*lazy=*/true), h->markers, h->carry);
+  }
+  {
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_INDICES);
+    hipLaunchKernelGGL(k_fs1_resolve, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->ctl, h->markers,
+                       h->carry, h->n, h->idx);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  h->maybe_pending = true;
+  h->rstep += 1;
+  return RR_OK;
+}
+
+bool plan_fusable(const rr_fs1* h) { return h->n_tiles <= (uint64_t)rr::kFusedMaxTiles && h->n == h->n_global; }
+
 // lazy consume, part 3: the landmarks this step does NOT observe still have to move with their
 // particle -- gather just their planes (list built on the host from the observation ids)
 rr_status launch_rest_gather(rr_fs1* h, const double* z, size_t n_z) {
@@ -1001,6 +1086,9 @@ rr_status rr_fs1_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs1
   RR_TRY_OR_CLEAN(hipMalloc(&h->tile_total, h->n_tiles * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->tile_q2, 2 * h->n_tiles * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->idx, h->n * sizeof(unsigned int)));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->markers, (h->n + rr::kResolveSlots) * sizeof(unsigned int)));
+  RR_TRY_OR_CLEAN(hipMemsetAsync(h->markers, 0, (h->n + rr::kResolveSlots) * sizeof(unsigned int), h->stream));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->carry, (h->n / rr::kResolveSlots + 2) * sizeof(unsigned int)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->partial, (size_t)kMaxChunks * h->n * sizeof(double)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->part_bits, 1024 * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->part_idx, 1024 * sizeof(uint64_t)));
@@ -1029,6 +1117,8 @@ void rr_fs1_destroy(rr_fs1* h) {
   (void)hipFree(h->tile_total);
   (void)hipFree(h->tile_q2);
   (void)hipFree(h->idx);
+  (void)hipFree(h->markers);
+  (void)hipFree(h->carry);
   (void)hipFree(h->ridx);
   (void)hipFree(h->partial);
   (void)hipFree(h->z_dev);
@@ -1163,6 +1253,7 @@ rr_status rr_fs1_update_async(rr_fs1* h, const double u[2], const double* z, siz
     if ((s = materialise(h)) != RR_OK) return s;
     if ((s = launch_motion<false>(h, u, z, n_z)) != RR_OK) return s;
     if ((s = launch_observe(h, z, n_z, dup)) != RR_OK) return s;
+    if (plan_fusable(h)) return launch_plan_fused(h, /*settle=*/0);
     if ((s = launch_sums(h, 0, NAN, /*lazy=*/true, /*settle=*/0)) != RR_OK) return s;
     return launch_finish(h, /*lazy=*/true);
   }
@@ -1172,6 +1263,7 @@ rr_status rr_fs1_update_async(rr_fs1* h, const double u[2], const double* z, siz
   if ((s = launch_observe(h, z, n_z, dup, /*lazy=*/true)) != RR_OK) return s;
   if (h->maybe_pending && (s = launch_rest_gather(h, z, n_z)) != RR_OK) return s;
   h->maybe_pending = false;
+  if (plan_fusable(h)) return launch_plan_fused(h, /*settle=*/1);
   if ((s = launch_sums(h, 0, NAN, /*lazy=*/true, /*settle=*/1)) != RR_OK) return s;
   return launch_finish(h, /*lazy=*/true);
 }

@@ -495,16 +495,24 @@ struct EstArgs {
 __device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, const TileScan& t, const unsigned int* offspring,
                                      int fire, uint64_t i0, uint64_t n, double denom, unsigned int rstep) {
   __shared__ double s_acc[kBlock / kWave][4];
+  __shared__ double s_c[kBlock * (kItems + 1)];  // coefficient of the tile's particle i at [i + i / kItems] (padded rows)
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int cur = ctl->cur;
+  // the coefficients are known per thread for its 8 CONSECUTIVE sources; the particle fields are read row-wise
+  // (256 consecutive particles per instruction, coalesced), so the coefficients change hands through LDS
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) s_c[tid * (kItems + 1) + j] = (i0 + j < n) ? (fire ? (double)offspring[j] : (double)t.q[j]) : 0.0;
+  __syncthreads();
+  const uint64_t tile0 = i0 - (uint64_t)tid * kItems;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int j = 0; j < kItems; ++j) {
-    const double c = fire ? (double)offspring[j] : (double)t.q[j];
-    if (c != 0.0 && i0 + j < n) {
+  for (int r = 0; r < kItems; ++r) {
+    const int i = r * kBlock + tid;
+    const double c = s_c[i + i / kItems];
+    if (c != 0.0) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] = rr_fma(c, ea.field[cur][k][i0 + j], acc[k]);
+      for (int k = 0; k < 4; ++k) acc[k] = rr_fma(c, ea.field[cur][k][tile0 + i], acc[k]);
     }
   }
 #pragma unroll

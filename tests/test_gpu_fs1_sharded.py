@@ -136,7 +136,16 @@ def test_rccl_phases_in_process_equal_unsharded(world, n_local, variant):
     """The phases rr_fs1_shard_update is made of (local / quantize / plan / pack / unpack), for `world` shards
     living on ONE device, with the three collectives done by hand on the host (max, concatenation, and the
     per-pair [plane][count] blocks copied from the senders' buffers into the receivers') -- everything of the
-    RCCL transport except the RCCL calls themselves, whole particles crossing shards included."""
+    RCCL transport except the RCCL calls themselves, whole particles crossing shards included.  Fresh interpreter
+    with torch imported FIRST: torch (device buffers here) brings its own HIP runtime, which has to be the one
+    the engine library binds to."""
+    code = (f"import torch, sys; sys.path.insert(0, {ROOT!r}); from tests.test_gpu_fs1_sharded import run_rccl_phases; "
+            f"run_rccl_phases({world}, {n_local}, {variant})")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0 and "FS1_RCCL_PHASES_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def run_rccl_phases(world, n_local, variant):
     import ctypes as C
 
     import torch
@@ -215,6 +224,7 @@ def test_rccl_phases_in_process_equal_unsharded(world, n_local, variant):
                 s.poses()
     assert moved_total > 0, "expected whole particles to cross shards"
     check([s.get_state() for s in shards], n_local, L, steps, chunks, variant)
+    print("FS1_RCCL_PHASES_OK")
 
 
 def test_shard_geometry_is_checked():
