@@ -12,7 +12,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librust_robotics_amd.so")
+# RR_AMD_LIBRARY: development override (A/B timing of two builds of the same ABI); never a fallback
+LIB_PATH = os.environ.get("RR_AMD_LIBRARY") or os.path.join(_HERE, "librust_robotics_amd.so")
 
 RR_OK, RR_INVALID_PARAMETER, RR_RUNTIME_ERROR = 0, 1, 2
 RR_RESAMPLE_MULTINOMIAL, RR_RESAMPLE_SYSTEMATIC = 0, 1

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __r
 constexpr unsigned int kInPlace = 0xffffffffu;
 
 template <bool OBS_KERNARG, bool SHARDED>
-__global__ __launch_bounds__(kBlock) void k_step_lazy(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
+__global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
                                                      StepParams p, ObsArg obs_arg,
                                                      const double* __restrict__ obs_dev,
                                                      unsigned int* __restrict__ markers,
