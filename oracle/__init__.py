@@ -157,7 +157,7 @@ def det() -> C.CDLL:
         f = getattr(L, name)
         f.argtypes = [sz, P, P]
         f.restype = None
-    for name in ("det_sincos_v", "det_sincos2pi_v", "det_atan2_v", "det_div_v"):
+    for name in ("det_sincos_v", "det_sincos2pi_v", "det_atan2_v", "det_div_v", "det_fma_v"):
         f = getattr(L, name)
         f.argtypes = [sz, P, P, P]
         f.restype = None

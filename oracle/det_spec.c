@@ -31,6 +31,8 @@ void det_sincos2pi_v(size_t n, const double* x, double* s, double* c) { for (siz
 void det_atan2_v(size_t n, const double* y, const double* x, double* o) { for (size_t i = 0; i < n; ++i) o[i] = rr_atan2(y[i], x[i]); }
 void det_sqrt_v(size_t n, const double* x, double* o) { for (size_t i = 0; i < n; ++i) o[i] = rr_sqrt(x[i]); }
 void det_div_v(size_t n, const double* a, const double* b, double* o) { for (size_t i = 0; i < n; ++i) o[i] = a[i] / b[i]; }
+/* a * b + a in one rounding: the explicit-FMA contract of the spec headers (compiled to vfmadd here, v_fma_f64 on gfx950) */
+void det_fma_v(size_t n, const double* a, const double* b, double* o) { for (size_t i = 0; i < n; ++i) o[i] = rr_fma(a[i], b[i], a[i]); }
 void det_uniform2_v(uint64_t seed, uint32_t stream, uint32_t step, uint64_t first, size_t n, double* u0, double* u1) {
   for (size_t i = 0; i < n; ++i) rr_uniform2(seed, stream, step, first + i, &u0[i], &u1[i]);
 }

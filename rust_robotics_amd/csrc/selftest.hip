@@ -24,6 +24,7 @@ __global__ void k_selftest(int fn, size_t n, const double* __restrict__ a, const
     case 6: r0 = a[i] / b[i]; break;
     case 7: rr_normal2(rr_d2u(a[0]), RR_STREAM_MOTION, (uint32_t)rr_d2u(b[0]), i, &r0, &r1); break;
     case 8: r0 = rr_fma(a[i], b[i], a[i]); break;
+    case 9: r0 = rr_sqrt_core(a[i]); break;  // the bare square-root core of the fused likelihood / Box-Muller radius
     default: break;
   }
   o0[i] = r0;

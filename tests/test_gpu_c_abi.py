@@ -17,3 +17,15 @@ def test_plain_c_consumer(tmp_path):
     subprocess.run(cmd, check=True, capture_output=True, text=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "C_ABI_OK" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
+def test_cpp_wrapper_consumer(tmp_path):
+    """include/rust_robotics.hpp (the reference-named C++ classes over the C ABI) compiled with g++ and RUN:
+    step loops, error kinds / messages, adaptive MCL, FastSLAM 1.0 / 2.0 through the wrapper"""
+    exe = str(tmp_path / "hpp_smoke")
+    lib = os.path.join(ROOT, "rust_robotics_amd")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "hpp_smoke.cpp"),
+           "-L", lib, "-lrust_robotics_amd", f"-Wl,-rpath,{lib}", "-o", exe]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "HPP_OK" in r.stdout, (r.returncode, r.stdout, r.stderr)

@@ -135,3 +135,43 @@ def test_fastslam_without_landmarks():
         assert np.allclose(moved[:, 0], 1.0 / n)
     pose, w, i = f.best_particle()
     assert 0 <= i < n and np.all(np.isfinite(pose))
+
+
+def test_index_drift_against_the_literal_walk_at_1e6(loc):
+    """the integer CDF picks the same particle as the reference's serial float cumsum except
+    for draws within the cumsum's own accumulated rounding error of a step.  Bounded here on the DEVICE's own
+    weights at BASELINE size: identical draws into the engine (resample seams) and into the literal restatement
+    (ref_mcl_resample_indices = monte_carlo_localization.rs:328-392; ref_fs1_resample_indices = fastslam1.rs:205-234);
+    at most a handful of the 1e6 slots differ and every differing slot picks the neighbouring particle."""
+    n, L = 1_000_000, 32
+    ref = oracle.ref()
+    lms = H.landmarks_grid(L, 1)
+    rng = np.random.default_rng(17)
+    cfg = loc.ParticleFilterConfig(n_particles=n, range_noise=0.2)
+    for scheme in (0, 1):
+        pf = loc.ParticleFilterLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=3, resample_scheme=scheme, record_indices=True)
+        for t in range(3):  # a few real steps so that the cloud and the weights are those of a tracking filter
+            pf.step_async([1.0, 0.1], H.observations(lms, H.true_pose(t + 1), 0.2, rng))
+        pf.predict_with_control([1.0, 0.1])
+        pf.update_with_observations(H.observations(lms, H.true_pose(4), 0.2, rng))
+        w = pf.get_particles_array()[:, 4].copy()  # normalised weights as the reference would hold them
+        nz = np.count_nonzero(w)
+        assert nz > n // 100
+        if scheme == 0:
+            r = np.floor(rng.random(n) * 2**53) / 2**53
+            pf.resample_with_uniforms(r)
+            lit = np.empty(n, np.uint32)
+            ref.ref_mcl_resample_indices(n, dp(w), dp(r), u32p(lit))
+        else:
+            rho = float(np.floor(rng.random() * 2**53) / 2**53)
+            pf.resample_systematic(rho)
+            lit = np.empty(n, np.uint32)
+            ref.ref_fs1_resample_indices(n, dp(w.copy()), rho / n, u32p(lit))
+        got = pf.last_resample_indices().astype(np.int64)
+        lit = lit.astype(np.int64)
+        diff = np.nonzero(got != lit)[0]
+        assert diff.size <= 8, f"scheme {scheme}: {diff.size} of {n} slots differ from the literal walk"
+        zeros_before = np.concatenate([[0], np.cumsum(w == 0.0)])
+        for k in diff:  # neighbours, skipping zero-weight particles in between (they feed no slot in either walk)
+            a, b = sorted((int(got[k]), int(lit[k])))
+            assert (b - a) - (zeros_before[b] - zeros_before[a + 1]) <= 1, (k, a, b)

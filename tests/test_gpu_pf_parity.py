@@ -6,6 +6,8 @@
 import ctypes as C
 import math
 
+from fractions import Fraction
+
 import numpy as np
 import pytest
 
@@ -45,7 +47,8 @@ def assert_bits_equal(a, b, what=""):
 
 
 # ------------------------------------------------------------------ arithmetic contract on the device
-@pytest.mark.parametrize("fn,name", [(0, "exp"), (1, "log"), (2, "sincos"), (3, "sincos2pi"), (4, "atan2"), (5, "sqrt"), (6, "div"), (8, "fma")])
+@pytest.mark.parametrize("fn,name", [(0, "exp"), (1, "log"), (2, "sincos"), (3, "sincos2pi"), (4, "atan2"), (5, "sqrt"), (6, "div"), (8, "fma"),
+                                     (9, "sqrt_core")])
 def test_device_math_bit_identical(ffi, det, fn, name):
     rng = np.random.default_rng(100 + fn)
     n = 1 << 16
@@ -59,6 +62,8 @@ def test_device_math_bit_identical(ffi, det, fn, name):
         a = np.floor(rng.uniform(0, 1, n) * 2**53) / 2**53
     elif fn in (5,):
         a = 10.0 ** rng.uniform(-300, 300, n)
+    elif fn == 9:  # the core's exact range is [2^-767, inf): squared ranges with the 2^-700 floor, Box-Muller radii, the extremes
+        a = np.concatenate([10.0 ** rng.uniform(-230, 300, n - 4), [2.0**-767, 2.0**-700, 2.0**-52, 1.7e308]])
     else:
         a = rng.normal(size=n) * 10.0 ** rng.uniform(-5, 5, n)
     b = rng.normal(size=n) * 10.0 ** rng.uniform(-5, 5, n)
@@ -81,10 +86,11 @@ def test_device_math_bit_identical(ffi, det, fn, name):
     elif fn == 6:
         det.det_div_v(n, dp(a), dp(b), dp(e0))
     elif fn == 8:
-        e0 = np.array([math.fma(x, y, x) for x, y in zip(a[:2000], b[:2000])]) if hasattr(math, "fma") else None
-        if e0 is None:
-            pytest.skip("no host fma to compare with")
-        o0 = o0[:2000]
+        det.det_fma_v(n, dp(a), dp(b), dp(e0))
+        exact = np.array([float(Fraction(x) * Fraction(y) + Fraction(x)) for x, y in zip(a[:3000], b[:3000])])  # one rounding
+        assert_bits_equal(e0[:3000], exact, "host fma is a true fused multiply-add")
+    elif fn == 9:
+        e0 = np.sqrt(a)  # correctly rounded
     assert_bits_equal(o0, e0, name)
     if fn in (2, 3):
         assert_bits_equal(o1, e1, name + "/cos")

@@ -1,0 +1,46 @@
+#!/bin/bash
+# Collect the rocprofv3 evidence of one round on a gpurun MI355X box:
+#   tools/collect_profiles.sh r02a        (from the repo root; writes gpurun_out/<tag>/, copy the summaries to profiles/)
+# Kernel timings (--kernel-trace) and every PMC pass run separately: FETCH_SIZE and WRITE_SIZE do not fit one pass
+# (TCC slots, MI355X_MICROARCH.md "rocprofv3 PMC slots"), and no trace domain other than the kernel trace is combined
+# with --pmc.
+set -u
+TAG=${1:-r02}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+MCL="python $REPO/bench.py --no-cpu-baseline --no-breakdown --no-extra-legs"
+FS1="python $REPO/bench.py --workload fastslam --no-cpu-baseline --no-breakdown"
+run() {  # name, rocprof args..., -- command
+  local name=$1; shift
+  (cd /tmp && rocprofv3 -d "$OUT/raw_$name" -o p --output-format csv "$@" > "$OUT/$name.bench.json" 2> "$OUT/$name.err")
+}
+find_csv() { find "$OUT/raw_$1" -name "p_$2.csv" | head -1; }
+
+run mcl_trace --kernel-trace --stats -- $MCL
+run fs1_trace --kernel-trace --stats -- $FS1
+python tools/summarize_rocprof.py stats "$(find_csv mcl_trace kernel_trace)" > "$OUT/${TAG}_mcl_1e6x32_kernel_stats.csv"
+python tools/summarize_rocprof.py stats "$(find_csv fs1_trace kernel_trace)" > "$OUT/${TAG}_fastslam_1e5x200_kernel_stats.csv"
+grep '^{' "$OUT/mcl_trace.bench.json" | tail -1 > "$OUT/${TAG}_mcl_1e6x32_bench_under_rocprof.json"
+grep '^{' "$OUT/fs1_trace.bench.json" | tail -1 > "$OUT/${TAG}_fastslam_1e5x200_bench_under_rocprof.json"
+
+for wl in mcl fs1; do
+  cmd=$MCL; [ $wl = fs1 ] && cmd=$FS1
+  run ${wl}_fetch --kernel-trace --pmc FETCH_SIZE -- $cmd --steps 40 --warmup 5
+  run ${wl}_write --kernel-trace --pmc WRITE_SIZE -- $cmd --steps 40 --warmup 5
+  python tools/summarize_rocprof.py hbm $wl "$(find_csv ${wl}_fetch counter_collection)" "$(find_csv ${wl}_write counter_collection)" > "$OUT/hbm_$wl.csv"
+done
+{ cat "$OUT/hbm_mcl.csv"; tail -n +2 "$OUT/hbm_fs1.csv"; } > "$OUT/${TAG}_pmc_hbm_traffic.csv"
+
+run mcl_sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS -- $MCL --steps 40 --warmup 5
+python tools/summarize_rocprof.py sq "$(find_csv mcl_sq counter_collection)" > "$OUT/${TAG}_mcl_pmc_sq_summary.csv"
+run fs1_sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS -- $FS1 --steps 20 --warmup 5
+python tools/summarize_rocprof.py sq "$(find_csv fs1_sq counter_collection)" > "$OUT/${TAG}_fastslam_pmc_sq_summary.csv"
+
+# un-profiled lines of the same build
+python bench.py > "$OUT/${TAG}_bench_default.json" 2> "$OUT/bench_default.err"
+python bench.py --scheme multinomial --no-cpu-baseline --no-extra-legs > "$OUT/${TAG}_mcl_1e6x32_multinomial_bench.json" 2>/dev/null
+python bench.py --workload fastslam2 > "$OUT/${TAG}_fastslam2_1e5x200_bench.json" 2>/dev/null
+rm -rf "$OUT"/raw_*   # the raw traces are large; the summaries above are what gets committed
+ls -la "$OUT"
