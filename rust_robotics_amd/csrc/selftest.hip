@@ -24,7 +24,11 @@ __global__ void k_selftest(int fn, size_t n, const double* __restrict__ a, const
     case 6: r0 = a[i] / b[i]; break;
     case 7: rr_normal2(rr_d2u(a[0]), RR_STREAM_MOTION, (uint32_t)rr_d2u(b[0]), i, &r0, &r1); break;
     case 8: r0 = rr_fma(a[i], b[i], a[i]); break;
-    case 9: r0 = rr_sqrt_core(a[i]); break;  // the bare square-root core of the fused likelihood / Box-Muller radius
+    case 9:  // the bare square-root core of the fused likelihood / Box-Muller radius (device-only function)
+#if defined(__HIP_DEVICE_COMPILE__)
+      r0 = rr_sqrt_core(a[i]);
+#endif
+      break;
     default: break;
   }
   o0[i] = r0;
@@ -35,7 +39,7 @@ __global__ void k_selftest(int fn, size_t n, const double* __restrict__ a, const
 extern "C" rr_status rr_selftest_math(int32_t device, int32_t fn, size_t n, const double* a, const double* b,
                                       double* out0, double* out1) {
   if (!a || !out0 || n == 0) return rr::fail(RR_INVALID_PARAMETER, "selftest: null input/output");
-  if (fn < 0 || fn > 8) return rr::fail(RR_INVALID_PARAMETER, "selftest: unknown function id");
+  if (fn < 0 || fn > 9) return rr::fail(RR_INVALID_PARAMETER, "selftest: unknown function id");
   RR_HIP_TRY(hipSetDevice(device));
   double *da = nullptr, *db = nullptr, *d0 = nullptr, *d1 = nullptr;
   const size_t nb = n * sizeof(double);
