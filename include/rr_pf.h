@@ -275,6 +275,18 @@ typedef struct rr_pf_shard_plan {
 rr_status rr_pf_shard_get_plan(rr_pf* h, rr_pf_shard_plan* out);
 rr_status rr_pf_shard_gather_slots(rr_pf* h, uint64_t first_slot, uint64_t n_slots, double* d_out);
 rr_status rr_pf_shard_adopt(rr_pf* h, const double* d_in);
+/* Multinomial shards (RR_RESAMPLE_MULTINOMIAL: the resampler MonteCarloLocalizer really uses,
+ * monte_carlo_localization.rs:322-365,387-392; particle_filter.rs:441-473).  Draw k is output slot k of the
+ * GLOBAL index and a pure function of (seed, resample step, k); the shard whose CDF interval contains its
+ * target serves it.  After rr_pf_shard_cdf (which materialises the local CDF slice for such shards):
+ *   select        -> d_counts_out[n_shards]: slots this shard serves per destination (row `rank` of the matrix)
+ *   pack_selected -> d_send: those records, ordered by global slot (= grouped by destination), 5 doubles each:
+ *                    x, y, yaw, v, destination-local slot index
+ *   adopt_records <- the n_local records of this shard's slots, in any order
+ * Bit-identical to the unsharded multinomial filter for any shard count (tests/test_sharded_gloo.py). */
+rr_status rr_pf_shard_select(rr_pf* h, int32_t n_shards, uint64_t* d_counts_out);
+rr_status rr_pf_shard_pack_selected(rr_pf* h, int32_t n_shards, double* d_send);
+rr_status rr_pf_shard_adopt_records(rr_pf* h, const double* d_in, uint64_t n_records);
 /* Host-only integer helper (no GPU needed): the first global output slot i in [0, n_global]
  * whose systematic CDF target exceeds `bound` (n_global if none).  Slots served by a shard
  * with CDF interval (base, base + T] are [first_slot_above(base), first_slot_above(base + T)). */

@@ -165,6 +165,8 @@ def det() -> C.CDLL:
         f = getattr(L, name)
         f.argtypes = [u64, u32v, u32v, u64, sz, P, P]
         f.restype = None
+    L.det_targets_multinomial.argtypes = [u64, sz, sz, u64, u32v, c_u64_p]
+    L.det_targets_multinomial.restype = None
     L.det_philox_raw.argtypes = [u32v] * 6 + [c_u32_p]
     L.det_philox_raw.restype = None
     L.det_pf_init.argtypes = [sz, u64, u64, P, P, P, P, P]

@@ -126,6 +126,16 @@ void det_indices_multinomial(size_t n, const uint64_t* cdf, uint64_t total, size
   }
 }
 
+/* CDF targets of the multinomial draws of output slots [first_slot, first_slot + n_out) (Philox RESAMPLE stream):
+ * what a shard compares with its CDF interval (base, base + T_local] to find the slots it serves */
+void det_targets_multinomial(uint64_t total, size_t first_slot, size_t n_out, uint64_t seed, uint32_t rstep, uint64_t* out) {
+  for (size_t k = 0; k < n_out; ++k) {
+    double rk, dummy;
+    rr_uniform2(seed, RR_STREAM_RESAMPLE, rstep, first_slot + k, &rk, &dummy);
+    out[k] = rr_fix_target_multinomial(rk, total);
+  }
+}
+
 /* KLD-adaptive resample of the D-spec: multinomial draws over the integer CDF (n entries, grand
  * total `total`), r explicit or Philox (seed, RESAMPLE stream, rstep, draw index); sequential
  * evaluation of the stop rule.  Returns the new particle count, idx[0..count) = sources. */

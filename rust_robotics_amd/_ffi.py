@@ -179,6 +179,9 @@ def lib() -> C.CDLL:
     proto("rr_pf_shard_get_plan", st, [H, C.POINTER(PfShardPlan)])
     proto("rr_pf_shard_gather_slots", st, [H, u64, u64, V])
     proto("rr_pf_shard_adopt", st, [H, V])
+    proto("rr_pf_shard_select", st, [H, i32, V])
+    proto("rr_pf_shard_pack_selected", st, [H, i32, V])
+    proto("rr_pf_shard_adopt_records", st, [H, V, u64])
     proto("rr_sys_first_slot_above", u64, [d, u64, u64, u64])
     U8 = C.POINTER(C.c_uint8)
     proto("rr_comm_unique_id", st, [U8])

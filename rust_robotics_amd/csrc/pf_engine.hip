@@ -603,6 +603,142 @@ __global__ __launch_bounds__(kBlock) void k_gather_lidx(Bufs b, const Ctl* __res
 // of that many particles follows.
 constexpr unsigned int kKldEmpty = 0xffffffffu;
 
+// ------------------------------------------------------------------------------------------
+// Sharded MULTINOMIAL resample (the resampler MonteCarloLocalizer uses, monte_carlo_localization.rs:322-365,387-392,
+// and particle_filter.rs:441-473).  Draw k belongs to output slot k of the GLOBAL particle index and is a pure
+// function of (seed, resample step, k), so every shard can evaluate all n_global targets; the shard whose CDF
+// interval (base, base + T_local] contains target_k serves slot k.  Unlike the systematic plan the served slots
+// are scattered, so they are COMPACTED in slot order: tiles of 2048 slots that never straddle a destination rank
+// (destination d owns slots [d n_local, (d+1) n_local)), count -> scan -> write.  The send buffer is therefore
+// ordered by global slot, i.e. grouped by destination, and its per-destination counts are row `rank` of the
+// exchange matrix.  Records are 5 doubles: x, y, yaw, v and the destination's LOCAL slot index.
+struct MnSelectArgs {
+  uint64_t n_local, n_global, tiles_per_dest;
+  uint64_t seed;
+  unsigned int rstep;
+  int n_shards;
+};
+
+__device__ inline bool mn_slot_target(const Ctl* __restrict__ ctl, const MnSelectArgs& a, uint64_t tile, int item,
+                                      uint64_t* slot_out, uint64_t* target_out) {
+  const uint64_t d = tile / a.tiles_per_dest, t = tile - d * a.tiles_per_dest;
+  const uint64_t li = t * kTile + (uint64_t)threadIdx.x * rr::kItems + item;
+  if (li >= a.n_local) return false;
+  const uint64_t slot = d * a.n_local + li;
+  double r, dummy;
+  rr_uniform2(a.seed, RR_STREAM_RESAMPLE, a.rstep, slot, &r, &dummy);
+  const uint64_t target = rr_fix_target_multinomial(r, ctl->total);
+  *slot_out = slot;
+  *target_out = target;
+  return target > ctl->base && target <= ctl->base + ctl->total_local;
+}
+
+__global__ __launch_bounds__(kBlock) void k_mn_select_count(const Ctl* __restrict__ ctl, MnSelectArgs a,
+                                                           unsigned int* __restrict__ tile_cnt) {
+  __shared__ unsigned int s_c[kBlock / rr::kWave];
+  unsigned int c = 0;
+  if (ctl->fired) {
+#pragma unroll
+    for (int j = 0; j < rr::kItems; ++j) {
+      uint64_t slot, target;
+      c += mn_slot_target(ctl, a, blockIdx.x, j, &slot, &target) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, rr::kWave);
+  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned int t = 0;
+    for (int k = 0; k < kBlock / rr::kWave; ++k) t += s_c[k];
+    tile_cnt[blockIdx.x] = t;
+  }
+}
+
+// one workgroup: exclusive scan of the tile counts (in place), counts per destination
+__global__ __launch_bounds__(kScanThreads) void k_mn_select_scan(unsigned int* __restrict__ tile_cnt, uint64_t n_tiles,
+                                                                uint64_t tiles_per_dest, int n_shards,
+                                                                uint64_t* __restrict__ counts_out) {
+  __shared__ uint64_t s_w[kScanThreads / rr::kWave];
+  __shared__ uint64_t s_dest[kMaxP2P + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint64_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
+  const uint64_t lo = (uint64_t)tid * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
+  uint64_t local = 0;
+  for (uint64_t k = lo; k < hi; ++k) local += tile_cnt[k];
+  const uint64_t incl = rr::wave_scan_u64(local, lane);
+  if (lane == 63) s_w[wv] = incl;
+  __syncthreads();
+  uint64_t run = incl - local;
+  for (int k = 0; k < wv; ++k) run += s_w[k];
+  for (uint64_t k = lo; k < hi; ++k) {
+    if (k % tiles_per_dest == 0) s_dest[k / tiles_per_dest] = run;  // first tile of a destination: its block starts here
+    const unsigned int t = tile_cnt[k];
+    tile_cnt[k] = (unsigned int)run;
+    run += t;
+  }
+  if (tid == kScanThreads - 1 || hi == n_tiles) {
+    if (hi == n_tiles && lo < hi) s_dest[n_shards] = run;  // grand total (the thread that owns the last tile)
+  }
+  __syncthreads();
+  if (tid < n_shards) counts_out[tid] = s_dest[tid + 1] - s_dest[tid];
+}
+
+__global__ __launch_bounds__(kBlock) void k_mn_select_pack(Bufs b, const Ctl* __restrict__ ctl, MnSelectArgs a,
+                                                          const unsigned int* __restrict__ tile_off,
+                                                          const uint64_t* __restrict__ cdf, uint64_t n_src,
+                                                          double* __restrict__ out) {
+  if (!ctl->fired) return;
+  __shared__ unsigned int s_c[kBlock / rr::kWave];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  uint64_t slot[rr::kItems], target[rr::kItems];
+  bool mine[rr::kItems];
+  unsigned int c = 0;
+#pragma unroll
+  for (int j = 0; j < rr::kItems; ++j) {
+    mine[j] = mn_slot_target(ctl, a, blockIdx.x, j, &slot[j], &target[j]);
+    c += mine[j] ? 1u : 0u;
+  }
+  unsigned int incl = c;
+#pragma unroll
+  for (int o = 1; o < rr::kWave; o <<= 1) {
+    const unsigned int t = __shfl_up(incl, o, rr::kWave);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) s_c[wv] = incl;
+  __syncthreads();
+  unsigned int pos = tile_off[blockIdx.x] + incl - c;
+  for (int k = 0; k < wv; ++k) pos += s_c[k];
+  const int src = ctl->cur ^ 1;  // the plan kernel has flipped Ctl.cur: the weighted set is the other one
+#pragma unroll
+  for (int j = 0; j < rr::kItems; ++j) {
+    if (!mine[j]) continue;
+    const uint64_t i = rr_lower_bound_u64(cdf, n_src, target[j]);
+    double* __restrict__ o = out + 5 * (uint64_t)pos;
+    o[0] = b.x[src][i];
+    o[1] = b.y[src][i];
+    o[2] = b.yaw[src][i];
+    o[3] = b.v[src][i];
+    o[4] = (double)(slot[j] % a.n_local);
+    ++pos;
+  }
+}
+
+// received records -> the live buffer set, each to the local slot it names
+__global__ __launch_bounds__(kBlock) void k_adopt_records(Bufs b, const Ctl* __restrict__ ctl,
+                                                         const double* __restrict__ in, uint64_t n) {
+  if (!ctl->fired) return;
+  const uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (r >= n) return;
+  const int dst = ctl->cur;
+  const uint64_t k = (uint64_t)in[5 * r + 4];
+  if (k >= n) return;
+  b.x[dst][k] = in[5 * r];
+  b.y[dst][k] = in[5 * r + 1];
+  b.yaw[dst][k] = in[5 * r + 2];
+  b.v[dst][k] = in[5 * r + 3];
+}
+
 __global__ __launch_bounds__(kBlock) void k_kld_draw(Bufs b, const Ctl* __restrict__ ctl,
                                                     const uint64_t* __restrict__ cdf,
                                                     const uint64_t* __restrict__ coarse, int coarse_log2,
@@ -773,6 +909,8 @@ struct rr_pf {
   bool wmax_live = false;        // Ctl.wmax_bits holds the maximum of the current raw weights
   bool wmax_bits_clean = false;  // Ctl.wmax_bits is known to be zero
   uint64_t last_migrated = 0;
+  unsigned int* mn_tile_cnt = nullptr;  // sharded multinomial: selected slots per (destination, tile), scanned in place
+  uint64_t mn_tiles = 0;
   rr::P2PState p2p;  // device-initiated exchange over xGMI (rr_pf_p2p_*)
   bool maybe_pending = false;    // a lazy resample plan was launched and nothing has consumed its markers yet
   bool pending_lidx = false;     // ... and its sources are in lidx, not in markers (sharded step, multinomial step)
@@ -1486,6 +1624,7 @@ void rr_pf_destroy(rr_pf* h) {
   (void)hipFree(h->carry);
   (void)hipFree(h->partials);
   (void)hipFree(h->est_partials);
+  (void)hipFree(h->mn_tile_cnt);
   (void)hipFree(h->est_ticket);
   (void)hipFree(h->scratch_a);
   (void)hipFree(h->scratch_b);
@@ -1849,7 +1988,8 @@ rr_status rr_pf_set_stream(rr_pf* h, void* stream) {
 
 static rr_status require_systematic_shard(const rr_pf* h) {
   if (h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC)
-    return fail(RR_INVALID_PARAMETER, "sharded resampling is systematic only: create the shard with RR_RESAMPLE_SYSTEMATIC");
+    return fail(RR_INVALID_PARAMETER, "this entry point serves the systematic sharded resample (contiguous served slots); a multinomial "
+                                      "shard uses rr_pf_shard_select / rr_pf_shard_pack_selected / rr_pf_shard_adopt_records");
   return RR_OK;
 }
 
@@ -1858,7 +1998,6 @@ rr_status rr_pf_shard_propagate_weight(rr_pf* h, const double control[2], const 
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if ((s = materialise(h)) != RR_OK) return s;
-  if ((s = require_systematic_shard(h)) != RR_OK) return s;
   if (!d_wmax_out) return fail(RR_INVALID_PARAMETER, "null d_wmax_out");
   if ((s = validate_control(control)) != RR_OK) return s;
   if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
@@ -1892,11 +2031,15 @@ rr_status rr_pf_shard_cdf(rr_pf* h, const uint64_t* d_all_sums, int32_t n_shards
   if (!d_all_sums || n_shards <= 0 || rank < 0 || rank >= n_shards)
     return fail(RR_INVALID_PARAMETER, "bad shard sums / rank");
   hipLaunchKernelGGL(rr::k_shard_plan, dim3(1), dim3(1), 0, h->stream, h->ctl, d_all_sums, (int)n_shards, (int)rank,
-                     plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN));
+                     plan_args(h, 0, h->opt.resample_scheme, NAN));
   {
     Timed t(h, RR_K_CDF);
-    hipLaunchKernelGGL(rr::k_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl, image_args(h),
-                       h->tile_total, h->markers, h->carry);
+    if (h->opt.resample_scheme == RR_RESAMPLE_SYSTEMATIC)
+      hipLaunchKernelGGL(rr::k_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl, image_args(h),
+                         h->tile_total, h->markers, h->carry);
+    else  // multinomial: the local slice of the global CDF is searched per draw (rr_pf_shard_select / _pack_selected)
+      hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl, image_args(h),
+                         h->tile_total, h->cdf, (uint64_t*)nullptr, 0);
   }
   RR_HIP_TRY(hipGetLastError());
   h->wmax_live = false;
@@ -1923,6 +2066,7 @@ rr_status rr_pf_shard_get_plan(rr_pf* h, rr_pf_shard_plan* out) {
 rr_status rr_pf_shard_gather_slots(rr_pf* h, uint64_t first_slot, uint64_t n_slots, double* d_out) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
+  if ((s = require_systematic_shard(h)) != RR_OK) return s;
   if (n_slots == 0) return RR_OK;
   if (!d_out) return fail(RR_INVALID_PARAMETER, "null d_out");
   if (first_slot + n_slots > h->n_global) return fail(RR_INVALID_PARAMETER, "slot range exceeds n_global");
@@ -1941,6 +2085,66 @@ rr_status rr_pf_shard_adopt(rr_pf* h, const double* d_in) {
   if (s != RR_OK) return s;
   if (!d_in) return fail(RR_INVALID_PARAMETER, "null d_in");
   hipLaunchKernelGGL(k_adopt, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, d_in, h->n);
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+// ---- sharded multinomial resample (see the kernels): select -> counts, pack -> records, adopt
+static MnSelectArgs mn_args(const rr_pf* h, int n_shards) {
+  MnSelectArgs a{};
+  a.n_local = h->n;
+  a.n_global = h->n_global;
+  a.tiles_per_dest = (h->n + kTile - 1) / kTile;
+  a.seed = h->opt.seed;
+  a.rstep = h->rstep - 1;  // rr_pf_shard_cdf has advanced the counter
+  a.n_shards = n_shards;
+  return a;
+}
+
+rr_status rr_pf_shard_select(rr_pf* h, int32_t n_shards, uint64_t* d_counts_out) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (h->opt.resample_scheme != RR_RESAMPLE_MULTINOMIAL) return fail(RR_INVALID_PARAMETER, "rr_pf_shard_select serves multinomial shards");
+  if (!d_counts_out || n_shards <= 0 || n_shards > kMaxP2P || h->n_global != h->n * (uint64_t)n_shards)
+    return fail(RR_INVALID_PARAMETER, "bad shard count (equal blocks, at most 16 shards)");
+  const MnSelectArgs a = mn_args(h, n_shards);
+  const uint64_t n_tiles = a.tiles_per_dest * (uint64_t)n_shards;
+  if (n_tiles > h->mn_tiles) {
+    if (h->mn_tile_cnt) RR_HIP_TRY(hipFree(h->mn_tile_cnt));
+    h->mn_tile_cnt = nullptr;
+    h->mn_tiles = 0;
+    RR_HIP_TRY(hipMalloc(&h->mn_tile_cnt, n_tiles * sizeof(unsigned int)));
+    h->mn_tiles = n_tiles;
+  }
+  Timed t(h, RR_K_RESAMPLE_GATHER);
+  hipLaunchKernelGGL(k_mn_select_count, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->ctl, a, h->mn_tile_cnt);
+  hipLaunchKernelGGL(k_mn_select_scan, dim3(1), dim3(kScanThreads), 0, h->stream, h->mn_tile_cnt, n_tiles, a.tiles_per_dest, (int)n_shards,
+                     d_counts_out);
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+rr_status rr_pf_shard_pack_selected(rr_pf* h, int32_t n_shards, double* d_send) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (h->opt.resample_scheme != RR_RESAMPLE_MULTINOMIAL) return fail(RR_INVALID_PARAMETER, "rr_pf_shard_pack_selected serves multinomial shards");
+  if (!d_send) return fail(RR_INVALID_PARAMETER, "null send buffer");
+  const MnSelectArgs a = mn_args(h, n_shards);
+  const uint64_t n_tiles = a.tiles_per_dest * (uint64_t)n_shards;
+  if (n_tiles != h->mn_tiles && n_tiles > h->mn_tiles) return fail(RR_INVALID_PARAMETER, "call rr_pf_shard_select first");
+  Timed t(h, RR_K_RESAMPLE_GATHER);
+  hipLaunchKernelGGL(k_mn_select_pack, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->b, h->ctl, a,
+                     (const unsigned int*)h->mn_tile_cnt, (const uint64_t*)h->cdf, h->n, d_send);
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+rr_status rr_pf_shard_adopt_records(rr_pf* h, const double* d_in, uint64_t n_records) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!d_in) return fail(RR_INVALID_PARAMETER, "null d_in");
+  if (n_records != h->n) return fail(RR_INVALID_PARAMETER, "every output slot of the shard needs exactly one record");
+  hipLaunchKernelGGL(k_adopt_records, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, d_in, h->n);
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
 }
@@ -2249,6 +2453,8 @@ void rr_comm_destroy(rr_comm* c) {
   (void)hipFree(c->d_recv);
   (void)hipFree(c->d_fsend);
   (void)hipFree(c->d_frecv);
+  (void)hipFree(c->d_cnt);
+  if (c->h_cnt) (void)hipHostFree(c->h_cnt);
   (void)hipFree(c->d_mom);
   if (c->h_mom) (void)hipHostFree(c->h_mom);
   delete c;
@@ -2277,6 +2483,50 @@ rr_status rr_pf_shard_step(rr_pf* h, rr_comm* c, const double control[2], const 
     return RR_OK;
   }
   const int G = c->n_ranks, r = c->rank;
+  if (h->opt.resample_scheme == RR_RESAMPLE_MULTINOMIAL) {
+    // scattered served slots: every rank counts what it serves per destination, the counts are all-gathered into
+    // the exchange matrix, records (x, y, yaw, v, local slot) travel in one grouped send/recv
+    if (!c->d_cnt) {
+      RR_HIP_TRY(hipMalloc(&c->d_cnt, ((size_t)G + (size_t)G * G) * sizeof(uint64_t)));
+      RR_HIP_TRY(hipHostMalloc(&c->h_cnt, (size_t)G * G * sizeof(uint64_t)));
+    }
+    if ((s = rr_pf_shard_select(h, G, c->d_cnt)) != RR_OK) return s;
+    RR_NCCL_TRY(R.AllGather(c->d_cnt, c->d_cnt + G, G, kNcclUint64, c->comm, h->stream));
+    RR_HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt + G, (size_t)G * G * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    RR_HIP_TRY(hipStreamSynchronize(h->stream));
+    uint64_t n_send = 0, n_recv = 0, migrated = 0;
+    for (int g = 0; g < G; ++g) {
+      n_send += c->h_cnt[(size_t)r * G + g];
+      n_recv += c->h_cnt[(size_t)g * G + r];
+      for (int d = 0; d < G; ++d)
+        if (g != d) migrated += c->h_cnt[(size_t)g * G + d];
+    }
+    h->last_migrated = migrated;
+    if (n_recv != h->n) return fail(RR_RUNTIME_ERROR, "multinomial exchange does not cover this shard's slots exactly once");
+    auto ensure = [&](double** buf, size_t* cap, size_t need) -> rr_status {
+      if (need <= *cap) return RR_OK;
+      if (*buf) RR_HIP_TRY(hipFree(*buf));
+      *buf = nullptr;
+      *cap = 0;
+      RR_HIP_TRY(hipMalloc(buf, (need + need / 4 + 1024) * sizeof(double)));
+      *cap = need + need / 4 + 1024;
+      return RR_OK;
+    };
+    if ((s = ensure(&c->d_fsend, &c->cap_fsend, 5 * n_send)) != RR_OK) return s;
+    if ((s = ensure(&c->d_frecv, &c->cap_frecv, 5 * h->n)) != RR_OK) return s;
+    if ((s = rr_pf_shard_pack_selected(h, G, c->d_fsend)) != RR_OK) return s;
+    RR_NCCL_TRY(R.GroupStart());
+    uint64_t so = 0, ro = 0;
+    for (int g = 0; g < G; ++g) {
+      const uint64_t ns = c->h_cnt[(size_t)r * G + g], nr = c->h_cnt[(size_t)g * G + r];
+      if (ns) RR_NCCL_TRY(R.Send(c->d_fsend + 5 * so, 5 * ns, kNcclFloat64, g, c->comm, h->stream));
+      if (nr) RR_NCCL_TRY(R.Recv(c->d_frecv + 5 * ro, 5 * nr, kNcclFloat64, g, c->comm, h->stream));
+      so += ns;
+      ro += nr;
+    }
+    RR_NCCL_TRY(R.GroupEnd());
+    return rr_pf_shard_adopt_records(h, c->d_frecv, h->n);
+  }
   std::vector<uint64_t> totals(G);
   for (int g = 0; g < G; ++g) totals[g] = c->h_all[3 * g];
   const uint64_t first = rr_sys_segment_matrix(plan.rho, totals.data(), G, h->n_global, h->n, r, c->matrix.data());

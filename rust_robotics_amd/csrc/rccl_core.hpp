@@ -91,6 +91,8 @@ struct rr_comm {
   double* d_fsend = nullptr;     // FastSLAM: whole particles, per destination a [plane][count] block
   double* d_frecv = nullptr;
   size_t cap_fsend = 0, cap_frecv = 0;  // in doubles
+  uint64_t* d_cnt = nullptr;     // multinomial: [n_ranks] own send counts + [n_ranks][n_ranks] everybody's
+  uint64_t* h_cnt = nullptr;     // pinned mirror of the matrix
   double* d_mom = nullptr;       // moments all-gather: [n_ranks][21]
   double* h_mom = nullptr;       // pinned
   std::vector<int64_t> matrix;

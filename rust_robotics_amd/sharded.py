@@ -74,10 +74,12 @@ class HipShard:
 
     def __init__(self, rank: int, world: int, device: int, n_local: int, *, seed: int, range_noise=0.2,
                  velocity_noise=2.0, yaw_rate_noise=math.radians(40.0), dt=0.1, gate=_ffi.RR_GATE_ALWAYS,
-                 resample_threshold=1.0, likelihood_mode=_ffi.RR_LIK_FUSED, initial_state=None):
+                 resample_threshold=1.0, likelihood_mode=_ffi.RR_LIK_FUSED, initial_state=None,
+                 scheme=_ffi.RR_RESAMPLE_SYSTEMATIC):
         import torch
 
         self.torch = torch
+        self.scheme = scheme
         self.rank, self.world, self.n_local = rank, world, n_local
         self.n_global = n_local * world
         self.device = torch.device("cuda", device)
@@ -88,7 +90,7 @@ class HipShard:
         L.rr_pf_options_default(C.byref(opt))
         opt.device = device
         opt.seed = seed
-        opt.resample_scheme = _ffi.RR_RESAMPLE_SYSTEMATIC
+        opt.resample_scheme = scheme
         opt.resample_gate = gate
         opt.likelihood_mode = likelihood_mode
         opt.first_global_index = rank * n_local
@@ -105,8 +107,11 @@ class HipShard:
             self.sums = torch.zeros(3, dtype=torch.int64, device=self.device)
             self.all_sums = torch.zeros(world * 3, dtype=torch.int64, device=self.device)
             self.all_sums_host = torch.zeros(world * 3, dtype=torch.int64).pin_memory()
-            self.send_buf = torch.empty((n_local * 2, 4), dtype=torch.float64, device=self.device)
-            self.recv_buf = torch.empty((n_local, 4), dtype=torch.float64, device=self.device)
+            width = 4 if scheme == _ffi.RR_RESAMPLE_SYSTEMATIC else 5  # multinomial records carry the destination slot
+            self.send_buf = torch.empty((n_local * 2, width), dtype=torch.float64, device=self.device)
+            self.recv_buf = torch.empty((n_local, width), dtype=torch.float64, device=self.device)
+            self.counts = torch.zeros(world, dtype=torch.int64, device=self.device)
+            self.all_counts = torch.zeros(world * world, dtype=torch.int64, device=self.device)
             stream = torch.cuda.current_stream(self.device)
         self._check(L.rr_pf_set_stream(self.h, C.c_void_p(stream.cuda_stream)))
 
@@ -155,6 +160,21 @@ class HipShard:
 
     def adopt(self, recv) -> None:
         self._check(self.L.rr_pf_shard_adopt(self.h, C.c_void_p(recv.data_ptr())))
+
+    # ---- multinomial shards: scattered served slots (include/rr_pf.h "Multinomial shards")
+    def select(self) -> None:
+        """counts of the slots this shard serves per destination -> self.counts"""
+        self._check(self.L.rr_pf_shard_select(self.h, self.world, C.c_void_p(self.counts.data_ptr())))
+
+    def pack_selected(self, n_send: int):
+        if n_send > self.send_buf.shape[0]:
+            self.send_buf = self.torch.empty((n_send + n_send // 4, 5), dtype=self.torch.float64, device=self.device)
+        out = self.send_buf[:n_send]
+        self._check(self.L.rr_pf_shard_pack_selected(self.h, self.world, C.c_void_p(self.send_buf.data_ptr())))
+        return out
+
+    def adopt_records(self, recv) -> None:
+        self._check(self.L.rr_pf_shard_adopt_records(self.h, C.c_void_p(recv.data_ptr()), recv.shape[0]))
 
     # ---- read-out (local)
     def particles(self) -> np.ndarray:
@@ -209,8 +229,23 @@ class ShardedLocalizer:
         if not plan.fired:
             self.weight_share = plan.total_local / plan.total_global if plan.total_global else 1.0 / b.world
             return False
-        totals = b.totals()
         r = b.rank
+        if getattr(b, "scheme", _ffi.RR_RESAMPLE_SYSTEMATIC) == _ffi.RR_RESAMPLE_MULTINOMIAL:
+            # iid draws: the slots a shard serves are scattered over all ranks.  Every rank counts what it serves per
+            # destination, the counts are all-gathered into the exchange matrix, the records travel in one all-to-all
+            b.select()
+            dist.all_gather_into_tensor(b.all_counts, b.counts, group=self.group)
+            M = b.all_counts.cpu().numpy().reshape(b.world, b.world).astype(np.int64)
+            self.last_matrix = M
+            assert int(M[:, r].sum()) == b.n_local, "every output slot of this rank must have exactly one source"
+            send = b.pack_selected(int(M[r].sum()))
+            recv = b.recv_buf
+            dist.all_to_all_single(recv, send, output_split_sizes=[int(v) for v in M[:, r]],
+                                   input_split_sizes=[int(v) for v in M[r]], group=self.group)
+            b.adopt_records(recv)
+            self.weight_share = 1.0 / b.world
+            return True
+        totals = b.totals()
         M, first = segment_matrix(plan.rho, totals, b.n_global, b.n_local, r)
         self.last_matrix = M
         n_send = int(M[r].sum())
@@ -250,7 +285,8 @@ class NativeShard:
 
     def __init__(self, rank: int, world: int, device: int, n_local: int, exchange, *, seed: int, range_noise=0.2,
                  velocity_noise=2.0, yaw_rate_noise=math.radians(40.0), dt=0.1, gate=_ffi.RR_GATE_ALWAYS,
-                 resample_threshold=1.0, likelihood_mode=_ffi.RR_LIK_FUSED, initial_state=None):
+                 resample_threshold=1.0, likelihood_mode=_ffi.RR_LIK_FUSED, initial_state=None,
+                 scheme=_ffi.RR_RESAMPLE_SYSTEMATIC):
         L = _ffi.lib()
         self.L, self.rank, self.world, self.n_local = L, rank, world, n_local
         uid = (C.c_uint8 * 128)()
@@ -264,7 +300,7 @@ class NativeShard:
         opt = _ffi.PfOptions()
         L.rr_pf_options_default(C.byref(opt))
         opt.device, opt.seed = device, seed
-        opt.resample_scheme, opt.resample_gate, opt.likelihood_mode = _ffi.RR_RESAMPLE_SYSTEMATIC, gate, likelihood_mode
+        opt.resample_scheme, opt.resample_gate, opt.likelihood_mode = scheme, gate, likelihood_mode
         opt.first_global_index, opt.n_global = rank * n_local, n_local * world
         self.h = C.c_void_p()
         if initial_state is None:
@@ -495,8 +531,9 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     import torch
     import torch.distributed as dist
 
-    if scheme != _ffi.RR_RESAMPLE_SYSTEMATIC:
-        raise SystemExit("the sharded path resamples systematically (use --scheme systematic)")
+    multinomial = scheme != _ffi.RR_RESAMPLE_SYSTEMATIC
+    if multinomial and transport in ("auto", "p2p", "p2p-only"):
+        transport = "rccl"  # iid draws scatter the served slots over all ranks: all-to-all exchange, RCCL / torch transports only
     own_group = not dist.is_initialized()  # bench.py keeps one gloo group for all its legs
     if own_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -505,6 +542,8 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     torch.cuda.set_device(local_rank)
     u = [1.0, 0.1]
     kw = dict(seed=1, likelihood_mode=lik, initial_state=[0.0, 0.0, 0.0, 1.0])
+    if multinomial:
+        kw["scheme"] = _ffi.RR_RESAMPLE_MULTINOMIAL
     notes = []
     # observation schedule (time only moves forward for every filter): [0, V) validation, [V, T0) warm-up (W steps plus
     # whatever surplus bench.py handed over), [T0, T0 + K) timed region, [T0 + K, T0 + 2K) instrumented continuation

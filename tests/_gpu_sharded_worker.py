@@ -20,14 +20,15 @@ def main():
     from tests import helpers as H
 
     n, steps = int(sys.argv[1]), int(sys.argv[2])
+    scheme = int(sys.argv[3]) if len(sys.argv) > 3 else _ffi.RR_RESAMPLE_SYSTEMATIC  # 0 = multinomial shards
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     rank, world = dist.get_rank(), dist.get_world_size()
-    shard = HipShard(rank, world, 0, n, seed=42, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))
+    shard = HipShard(rank, world, 0, n, seed=42, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0), scheme=scheme)
     sl = ShardedLocalizer(shard, dist)
     cfg = loc.MonteCarloLocalizationConfig(min_particles=n * world, max_particles=n * world, range_noise=0.5, velocity_noise=0.3,
                                            yaw_rate_noise=math.radians(5.0))
-    ref = loc.MonteCarloLocalizer(cfg, seed=42, resample_scheme=_ffi.RR_RESAMPLE_SYSTEMATIC)
+    ref = loc.MonteCarloLocalizer(cfg, seed=42, resample_scheme=scheme)
     rng = np.random.default_rng(43)
     for t in range(steps):
         obs = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng)
@@ -44,7 +45,7 @@ def main():
     from rust_robotics_amd.sharded import NativeShard, gloo_exchange
 
     nat = NativeShard(rank, world, 0, n, gloo_exchange(dist), seed=42, range_noise=0.5, velocity_noise=0.3,
-                      yaw_rate_noise=math.radians(5.0))
+                      yaw_rate_noise=math.radians(5.0), scheme=scheme)
     rng = np.random.default_rng(43)
     for t in range(steps):
         nat.step([1.0, 0.1], H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng))

@@ -17,10 +17,11 @@ from tests.sharded_cpu_backend import CpuShard  # noqa: E402
 
 def main():
     out_dir, n_local, steps, gate_always = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    scheme = int(sys.argv[5]) if len(sys.argv) > 5 else 1
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     shard = CpuShard(rank, world, n_local, seed=42, sigma=0.5, sigma_v=0.3, sigma_w=math.radians(5.0),
-                     gate_always=bool(gate_always), threshold=0.9)
+                     gate_always=bool(gate_always), threshold=0.9, scheme=scheme)
     loc = ShardedLocalizer(shard, dist)
     rng = np.random.default_rng(43)
     fired, moved = [], 0

@@ -16,8 +16,9 @@ class CpuShard:
     torch = torch
 
     def __init__(self, rank, world, n_local, *, seed, sigma=0.2, sigma_v=2.0, sigma_w=math.radians(40.0), dt=0.1,
-                 gate_always=True, threshold=1.0, lik=0, initial_state=None):
+                 gate_always=True, threshold=1.0, lik=0, initial_state=None, scheme=1):
         self.det = oracle.det()
+        self.scheme = scheme  # 1 = systematic, 0 = multinomial (rust_robotics_amd._ffi.RR_RESAMPLE_*)
         self.rank, self.world, self.n_local = rank, world, n_local
         self.n_global = n_local * world
         self.gid0 = rank * n_local
@@ -34,7 +35,9 @@ class CpuShard:
         self.wmax = torch.zeros(1, dtype=torch.float64)
         self.sums = torch.zeros(3, dtype=torch.int64)
         self.all_sums = torch.zeros(world * 3, dtype=torch.int64)
-        self.recv_buf = torch.empty((n, 4), dtype=torch.float64)
+        self.recv_buf = torch.empty((n, 4 if scheme == 1 else 5), dtype=torch.float64)
+        self.counts = torch.zeros(world, dtype=torch.int64)
+        self.all_counts = torch.zeros(world * world, dtype=torch.int64)
         self._plan = None
 
     def propagate_weight(self, u, obs):
@@ -88,6 +91,35 @@ class CpuShard:
                                             n_slots, self._plan.rho, u32p(idx))
         rows = np.column_stack([self.x[idx], self.y[idx], self.yaw[idx], self.v[idx]]) if n_slots else np.zeros((0, 4))
         return torch.from_numpy(np.ascontiguousarray(rows))
+
+    # ---- multinomial shards: the slots this shard serves are those whose draw lands in its CDF interval
+    def select(self):
+        p = self._plan
+        targets = np.empty(self.n_global, np.uint64)
+        self.det.det_targets_multinomial(p.total_global, 0, self.n_global, self.p["seed"], self.rstep_ctr - 1, u64p(targets))
+        t = targets.astype(object)  # exact integer comparison (values up to 2^63)
+        lo, hi = p.base, p.base + p.total_local
+        mine = np.array([lo < int(v) <= hi for v in t])
+        self._served = np.nonzero(mine)[0]  # ascending global slot = grouped by destination
+        self._served_targets = targets[self._served]
+        cnt = np.bincount(self._served // self.n_local, minlength=self.world)
+        self.counts[:] = torch.from_numpy(cnt.astype(np.int64))
+
+    def pack_selected(self, n_send):
+        assert n_send == self._served.size
+        src = np.searchsorted(self._cdf, self._served_targets, side="left")  # first j with C_j >= target
+        rows = np.column_stack([self.x[src], self.y[src], self.yaw[src], self.v[src], (self._served % self.n_local).astype(np.float64)])
+        return torch.from_numpy(np.ascontiguousarray(rows.reshape(-1, 5)))
+
+    def adopt_records(self, recv):
+        a = recv.numpy()
+        k = a[:, 4].astype(np.int64)
+        assert np.array_equal(np.sort(k), np.arange(self.n_local)), "every slot exactly once"
+        x, y, yaw, v = (np.empty(self.n_local) for _ in range(4))
+        x[k], y[k], yaw[k], v[k] = a[:, 0], a[:, 1], a[:, 2], a[:, 3]
+        self.x, self.y, self.yaw, self.v = x, y, yaw, v
+        self.w = np.full(self.n_local, 1.0 / self.n_global)
+        self.uniform = True
 
     def adopt(self, recv):
         a = recv.numpy()

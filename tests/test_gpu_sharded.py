@@ -11,8 +11,77 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_world1_nccl_equals_unsharded():
+@pytest.mark.parametrize("scheme,port", [(1, 29715), (0, 29716)])
+def test_world1_nccl_equals_unsharded(scheme, port):
+    """scheme 1 = systematic shards, 0 = multinomial shards (select / pack_selected / adopt_records)"""
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
-           "--master-port", "29715", os.path.join(ROOT, "tests", "_gpu_sharded_worker.py"), "20000", "8"]
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_gpu_sharded_worker.py"), "20000", "8", str(scheme)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
     assert r.returncode == 0 and "SHARDED_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("world,n_local", [(2, 5000), (3, 2100)])
+def test_multinomial_phases_in_process_equal_unsharded(world, n_local):
+    """The phases of the sharded MULTINOMIAL resample for `world` shards on one device, the collectives done by hand on
+    the host (max, concatenation of the sums, the count matrix, and the per-pair record blocks copied between the
+    shards' buffers): slots served by OTHER shards really travel.  Fresh interpreter with torch imported first."""
+    code = (f"import torch, sys; sys.path.insert(0, {ROOT!r}); from tests.test_gpu_sharded import run_multinomial_phases; "
+            f"run_multinomial_phases({world}, {n_local})")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0 and "MN_PHASES_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def run_multinomial_phases(world, n_local, steps=8):
+    import ctypes as C
+    import math
+
+    import numpy as np
+    import torch
+
+    import rust_robotics_amd.localization as loc
+    from rust_robotics_amd import _ffi
+    from rust_robotics_amd.sharded import HipShard
+    from tests import helpers as H
+
+    kw = dict(seed=42, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))
+    shards = [HipShard(g, world, 0, n_local, scheme=_ffi.RR_RESAMPLE_MULTINOMIAL, **kw) for g in range(world)]
+    n = n_local * world
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))
+    ref = loc.MonteCarloLocalizer(cfg, seed=42, resample_scheme=_ffi.RR_RESAMPLE_MULTINOMIAL)
+    rng = np.random.default_rng(43)
+    moved = 0
+    for t in range(steps):
+        obs = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng)
+        ref.step([1.0, 0.1], obs)
+        for s in shards:
+            s.propagate_weight([1.0, 0.1], obs)
+        torch.cuda.synchronize()
+        gmax = torch.stack([s.wmax for s in shards]).max()  # "all-reduce MAX"
+        for s in shards:
+            s.wmax.fill_(float(gmax))
+            s.quantize()
+        torch.cuda.synchronize()
+        allv = torch.cat([s.sums for s in shards])  # "all-gather"
+        for s in shards:
+            s.all_sums.copy_(allv)
+            s.cdf()
+            assert s.plan().fired
+            s.select()
+        torch.cuda.synchronize()
+        M = torch.stack([s.counts for s in shards]).cpu().numpy()  # M[src][dst]
+        assert np.all(M.sum(axis=0) == n_local), M
+        moved += int(M.sum() - np.trace(M))
+        sends = [s.pack_selected(int(M[g].sum())).clone() for g, s in enumerate(shards)]
+        torch.cuda.synchronize()
+        for d, s in enumerate(shards):  # "all-to-all": the block (src -> d) of every source, sources ascending
+            blocks = [sends[g][int(M[g, :d].sum()):int(M[g, :d + 1].sum())] for g in range(world)]
+            recv = torch.cat(blocks).contiguous()
+            torch.cuda.synchronize()
+            s.adopt_records(recv)
+            s.synchronize()
+    assert moved > 0
+    exp = ref.get_particles_array()
+    for g, s in enumerate(shards):
+        got = s.particles()
+        assert np.array_equal(got.view(np.uint64), exp[g * n_local:(g + 1) * n_local].view(np.uint64)), f"shard {g} differs from the unsharded multinomial filter"
+    print("MN_PHASES_OK")

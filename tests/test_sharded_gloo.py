@@ -14,24 +14,27 @@ from tests import helpers as H
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_world(tmp_path, world, n_local, steps, gate_always, port):
+def run_world(tmp_path, world, n_local, steps, gate_always, port, scheme=1):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "_sharded_worker.py"), str(tmp_path),
-           str(n_local), str(steps), str(int(gate_always))]
+           str(n_local), str(steps), str(int(gate_always)), str(scheme)]
     env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
     return [np.load(os.path.join(tmp_path, f"rank{g}.npz")) for g in range(world)]
 
 
-@pytest.mark.parametrize("world,gate_always,port", [(2, True, 29611), (3, True, 29612), (2, False, 29613)])
-def test_sharded_equals_single_shard(tmp_path, det, world, gate_always, port):
+@pytest.mark.parametrize("world,gate_always,port,scheme", [(2, True, 29611, 1), (3, True, 29612, 1), (2, False, 29613, 1),
+                                                          (2, True, 29614, 0), (3, False, 29615, 0)])
+def test_sharded_equals_single_shard(tmp_path, det, world, gate_always, port, scheme):
+    """scheme 1 = systematic (contiguous served slots, segment matrix), 0 = multinomial (the resampler
+    MonteCarloLocalizer uses, monte_carlo_localization.rs:322-365,387-392: scattered served slots, count matrix)"""
     n_local, steps = 600, 12
     n = n_local * world
-    ranks = run_world(tmp_path, world, n_local, steps, gate_always, port)
+    ranks = run_world(tmp_path, world, n_local, steps, gate_always, port, scheme)
     z = np.zeros(n)
     d = H.DetPF(det, z, z, z, z, dt=0.1, sigma=0.5, sigma_v=0.3, sigma_w=math.radians(5.0), threshold=1.0 if gate_always else 0.9,
-                gate=1 if gate_always else 0, scheme=1, lik=0, seed=42)
+                gate=1 if gate_always else 0, scheme=scheme, lik=0, seed=42)
     rng = np.random.default_rng(43)
     fired = []
     for t in range(steps):
