@@ -113,6 +113,13 @@ class HipShard:
             self.counts = torch.zeros(world, dtype=torch.int64, device=self.device)
             self.all_counts = torch.zeros(world * world, dtype=torch.int64, device=self.device)
             stream = torch.cuda.current_stream(self.device)
+            if stream.cuda_stream == 0:
+                # the legacy default stream has handle 0, which rr_pf_set_stream reads as "use your own stream" -- the
+                # library's kernels and torch's tensor ops / collectives would then run unordered.  Give the shard a
+                # real stream and make it torch's current one for this device.
+                stream = torch.cuda.Stream(device=self.device)
+                torch.cuda.set_stream(stream)
+            self.stream = stream
         self._check(L.rr_pf_set_stream(self.h, C.c_void_p(stream.cuda_stream)))
 
     def _check(self, status: int) -> None:

@@ -44,7 +44,9 @@ def run_multinomial_phases(world, n_local, steps=8):
     from tests import helpers as H
 
     kw = dict(seed=42, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))
+    torch.cuda.set_stream(torch.cuda.Stream())  # one explicit stream for torch and for every shard (HipShard binds the current one)
     shards = [HipShard(g, world, 0, n_local, scheme=_ffi.RR_RESAMPLE_MULTINOMIAL, **kw) for g in range(world)]
+    assert len({s.stream.cuda_stream for s in shards}) == 1 and shards[0].stream.cuda_stream != 0
     n = n_local * world
     cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))
     ref = loc.MonteCarloLocalizer(cfg, seed=42, resample_scheme=_ffi.RR_RESAMPLE_MULTINOMIAL)
@@ -83,5 +85,8 @@ def run_multinomial_phases(world, n_local, steps=8):
     exp = ref.get_particles_array()
     for g, s in enumerate(shards):
         got = s.particles()
-        assert np.array_equal(got.view(np.uint64), exp[g * n_local:(g + 1) * n_local].view(np.uint64)), f"shard {g} differs from the unsharded multinomial filter"
+        e = exp[g * n_local:(g + 1) * n_local]
+        bad = np.nonzero((got.view(np.uint64) != e.view(np.uint64)).any(axis=1))[0]
+        assert bad.size == 0, (f"shard {g} differs from the unsharded multinomial filter: {bad.size} of {n_local} rows, first {bad[:6]}, "
+                               f"got {got[bad[:2]]}, expected {e[bad[:2]]}")
     print("MN_PHASES_OK")
