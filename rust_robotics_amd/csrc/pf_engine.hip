@@ -340,6 +340,39 @@ __global__ void k_settle(Ctl* ctl) {
 // draws); instead every workgroup stages the coarse table (every 2^coarse_log2-th CDF entry,
 // <= 60 KB) in LDS, searches that, and finishes inside one 2^coarse_log2-entry window of the
 // full CDF (8 probes over 16 cache lines at 256 entries).
+// lower bound inside one CDF window of <= 256 entries by two rounds of 16 INDEPENDENT probes (the last entry of each
+// group of 16, then the 16 entries of the chosen group) instead of 8 dependent ones: the search is latency-bound on
+// L2 / Infinity-Cache hits, so four times the loads in a quarter of the round trips is the better trade.  Reads past
+// `len` are clamped to the last entry (the CDF is non-decreasing, so the count stays right).
+__device__ inline uint64_t window_lower_bound(const uint64_t* __restrict__ c, uint64_t len, uint64_t target) {
+  if (len <= 16) {
+    uint64_t below = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) below += ((uint64_t)i < len && c[(uint64_t)i < len ? i : 0] < target) ? 1u : 0u;
+    return below < len ? below : len - 1;
+  }
+  const uint64_t last = len - 1;
+  uint64_t v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint64_t k = (uint64_t)16 * i + 15;
+    v[i] = c[k < last ? k : last];
+  }
+  uint64_t g = 0;  // groups whose last entry is still below the target
+#pragma unroll
+  for (int i = 0; i < 16; ++i) g += (v[i] < target && (uint64_t)16 * i + 15 < last) ? 1u : 0u;
+  const uint64_t base = 16 * g;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint64_t k = base + i;
+    v[i] = c[k < last ? k : last];
+  }
+  uint64_t below = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) below += (v[i] < target && base + i < last) ? 1u : 0u;
+  return base + below;
+}
+
 __global__ __launch_bounds__(kBlock) void k_resample_gather_mn(Bufs b, const Ctl* __restrict__ ctl,
                                                               const uint64_t* __restrict__ cdf,
                                                               const uint64_t* __restrict__ coarse, int coarse_log2,
@@ -358,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void k_resample_gather_mn(Bufs b, const Ctl
     const uint64_t blk = rr_lower_bound_u64(s_coarse, n_coarse, target);  // first window whose last entry >= target
     const uint64_t lo = blk << coarse_log2;
     const uint64_t len = lo + (1ull << coarse_log2) <= a.n_src ? (1ull << coarse_log2) : a.n_src - lo;
-    const uint64_t j = lo + rr_lower_bound_u64(cdf + lo, len, target);
+    const uint64_t j = lo + (coarse_log2 == 8 ? window_lower_bound(cdf + lo, len, target) : rr_lower_bound_u64(cdf + lo, len, target));
     if (lidx_out) lidx_out[k] = (unsigned int)j;  // lazy: the next propagate kernel reads through it
     else copy_particle(b, src, dst, j, k, false, nullptr);
     if (idx_out) idx_out[k] = (unsigned int)j;
