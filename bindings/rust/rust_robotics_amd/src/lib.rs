@@ -147,6 +147,21 @@ impl ParticleFilterLocalizer {
         Ok(self.state_estimate)
     }
 
+    /// Engine extension: enqueue one step without waiting for it; the mean `try_step` would return (:496) is
+    /// produced on the device inside the step's own plan kernel (fused systematic step only).
+    pub fn try_step_async(&mut self, control: &PFControl, observations: &PFMeasurement) -> RoboticsResult<()> {
+        let flat = flatten(observations);
+        check(unsafe { sys::rr_pf_step_async_estimate(self.h, control.as_ptr(), flat.as_ptr(), observations.len()) })
+    }
+
+    /// Wait for the stream and read the mean of the last step enqueued with `try_step_async` (300-byte copy).
+    pub fn last_step_estimate(&mut self) -> RoboticsResult<PFState> {
+        let mut out = [0.0f64; 4];
+        check(unsafe { sys::rr_pf_last_step_estimate(self.h, out.as_mut_ptr()) })?;
+        self.state_estimate = PFState::from_column_slice(&out);
+        Ok(self.state_estimate)
+    }
+
     /// estimate, :348-350
     pub fn estimate(&self) -> PFState {
         self.state_estimate
