@@ -338,42 +338,9 @@ __global__ void k_settle(Ctl* ctl) {
 // Multinomial (particle_filter.rs:455-470): independent draws, one thread per output slot.  A
 // lower bound over the whole CDF is ~20 DEPENDENT probes of HBM/L2 per draw (137 us for 1e6
 // draws); instead every workgroup stages the coarse table (every 2^coarse_log2-th CDF entry,
-// <= 60 KB) in LDS, searches that, and finishes inside one 2^coarse_log2-entry window of the
-// full CDF (8 probes over 16 cache lines at 256 entries).
-// lower bound inside one CDF window of <= 256 entries by two rounds of 16 INDEPENDENT probes (the last entry of each
-// group of 16, then the 16 entries of the chosen group) instead of 8 dependent ones: the search is latency-bound on
-// L2 / Infinity-Cache hits, so four times the loads in a quarter of the round trips is the better trade.  Reads past
-// `len` are clamped to the last entry (the CDF is non-decreasing, so the count stays right).
-__device__ inline uint64_t window_lower_bound(const uint64_t* __restrict__ c, uint64_t len, uint64_t target) {
-  if (len <= 16) {
-    uint64_t below = 0;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) below += ((uint64_t)i < len && c[(uint64_t)i < len ? i : 0] < target) ? 1u : 0u;
-    return below < len ? below : len - 1;
-  }
-  const uint64_t last = len - 1;
-  uint64_t v[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const uint64_t k = (uint64_t)16 * i + 15;
-    v[i] = c[k < last ? k : last];
-  }
-  uint64_t g = 0;  // groups whose last entry is still below the target
-#pragma unroll
-  for (int i = 0; i < 16; ++i) g += (v[i] < target && (uint64_t)16 * i + 15 < last) ? 1u : 0u;
-  const uint64_t base = 16 * g;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const uint64_t k = base + i;
-    v[i] = c[k < last ? k : last];
-  }
-  uint64_t below = 0;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) below += (v[i] < target && base + i < last) ? 1u : 0u;
-  return base + below;
-}
-
-__global__ __launch_bounds__(kBlock) void k_resample_gather_mn(Bufs b, const Ctl* __restrict__ ctl,
+// <= 144 KB: 64-entry windows up to 1.18e6 particles) in LDS, searches that, and finishes inside one
+// 2^coarse_log2-entry window of the full CDF (6 probes over 4 cache lines at 64 entries).
+__global__ __launch_bounds__(1024) void k_resample_gather_mn(Bufs b, const Ctl* __restrict__ ctl,
                                                               const uint64_t* __restrict__ cdf,
                                                               const uint64_t* __restrict__ coarse, int coarse_log2,
                                                               uint64_t n_coarse,
@@ -382,16 +349,16 @@ __global__ __launch_bounds__(kBlock) void k_resample_gather_mn(Bufs b, const Ctl
                                                               unsigned int* __restrict__ lidx_out, GatherArgs a) {
   if (!ctl->fired) return;
   extern __shared__ uint64_t s_coarse[];
-  for (uint64_t i = threadIdx.x; i < n_coarse; i += kBlock) s_coarse[i] = coarse[i];
+  for (uint64_t i = threadIdx.x; i < n_coarse; i += blockDim.x) s_coarse[i] = coarse[i];
   __syncthreads();
   const int dst = ctl->cur, src = dst ^ 1;
   // grid-stride: a workgroup stages the coarse table once and serves several blocks of slots
-  for (uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x; k < a.n_slots; k += (uint64_t)gridDim.x * kBlock) {
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.n_slots; k += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, a.first_slot + k, a.seed, a.rstep, r_explicit, k);
     const uint64_t blk = rr_lower_bound_u64(s_coarse, n_coarse, target);  // first window whose last entry >= target
     const uint64_t lo = blk << coarse_log2;
     const uint64_t len = lo + (1ull << coarse_log2) <= a.n_src ? (1ull << coarse_log2) : a.n_src - lo;
-    const uint64_t j = lo + (coarse_log2 == 8 ? window_lower_bound(cdf + lo, len, target) : rr_lower_bound_u64(cdf + lo, len, target));
+    const uint64_t j = lo + rr_lower_bound_u64(cdf + lo, len, target);
     if (lidx_out) lidx_out[k] = (unsigned int)j;  // lazy: the next propagate kernel reads through it
     else copy_particle(b, src, dst, j, k, false, nullptr);
     if (idx_out) idx_out[k] = (unsigned int)j;
@@ -919,7 +886,7 @@ struct rr_pf {
   double* w = nullptr;
   uint64_t* cdf = nullptr;
   uint64_t* cdf_coarse = nullptr;  // every 2^coarse_log2-th CDF entry (multinomial gather's LDS table)
-  int coarse_log2 = 8;
+  int coarse_log2 = 6;  // finest window whose table still fits the LDS (raised at create time for large N)
   uint64_t n_coarse = 0;
   uint64_t* tile_total = nullptr;
   uint64_t* tile_q2 = nullptr;
@@ -938,7 +905,8 @@ struct rr_pf {
   uint64_t n_tiles = 0;
   unsigned int step = 0, rstep = 0;
   int k1_blocks_per_cu = 8;
-  int mn_grid = 1024;  // workgroups of the multinomial search kernel (RR_MN_GRID)
+  int mn_grid = 256;     // workgroups of the multinomial search kernel (RR_MN_GRID; set at create time from the table size)
+  int mn_block = 1024;   // its workgroup size (RR_MN_BLOCK): one large workgroup per CU shares one big LDS table
   bool wmax_live = false;        // Ctl.wmax_bits holds the maximum of the current raw weights
   bool wmax_bits_clean = false;  // Ctl.wmax_bits is known to be zero
   uint64_t last_migrated = 0;
@@ -1225,7 +1193,7 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
     g.seed = h->opt.seed;
     g.rstep = h->rstep;
     g.scheme = scheme;
-    hipLaunchKernelGGL(k_resample_gather_mn, dim3(std::min<unsigned>(grid_for(h->n, kBlock), (unsigned)h->mn_grid)), dim3(kBlock),
+    hipLaunchKernelGGL(k_resample_gather_mn, dim3(std::min<unsigned>(grid_for(h->n, h->mn_block), (unsigned)h->mn_grid)), dim3(h->mn_block),
                        h->n_coarse * sizeof(uint64_t), h->stream, h->b, h->ctl, h->cdf, h->cdf_coarse, h->coarse_log2, h->n_coarse,
                        (const double*)nullptr, h->idx, h->lidx, g);
     h->maybe_pending = h->pending_lidx = true;
@@ -1245,7 +1213,7 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
       g.rstep = h->rstep;
       g.scheme = scheme;
       g.to_staging = 0;
-      hipLaunchKernelGGL(k_resample_gather_mn, dim3(std::min<unsigned>(grid_for(h->n, kBlock), (unsigned)h->mn_grid)), dim3(kBlock),
+      hipLaunchKernelGGL(k_resample_gather_mn, dim3(std::min<unsigned>(grid_for(h->n, h->mn_block), (unsigned)h->mn_grid)), dim3(h->mn_block),
                          h->n_coarse * sizeof(uint64_t), h->stream, h->b, h->ctl, h->cdf, h->cdf_coarse, h->coarse_log2, h->n_coarse,
                          r_explicit_dev, h->idx, (unsigned int*)nullptr, g);
     }
@@ -1475,8 +1443,20 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
   }
   RR_TRY_OR_CLEAN(hipMalloc(&h->w, nb));
   RR_TRY_OR_CLEAN(hipMalloc(&h->cdf, h->cap * sizeof(uint64_t)));
-  while (((h->cap + (1ull << h->coarse_log2) - 1) >> h->coarse_log2) > 7680) h->coarse_log2 += 1;  // <= 60 KB of LDS
+  if (const char* e = std::getenv("RR_MN_COARSE_LOG2")) h->coarse_log2 = std::max(4, std::min(16, std::atoi(e)));
+  if (const char* e = std::getenv("RR_MN_BLOCK")) h->mn_block = std::max(64, std::min(1024, std::atoi(e) / 64 * 64));
+  while (((h->cap + (1ull << h->coarse_log2) - 1) >> h->coarse_log2) > 18432) h->coarse_log2 += 1;  // <= 144 KB of LDS
   h->n_coarse = (h->n + (1ull << h->coarse_log2) - 1) >> h->coarse_log2;
+  {
+    const size_t lds = (((h->cap + (1ull << h->coarse_log2) - 1) >> h->coarse_log2) + 1) * sizeof(uint64_t);
+    if (lds > 48 * 1024) {  // more dynamic LDS than the default launch limit
+      RR_TRY_OR_CLEAN(hipFuncSetAttribute((const void*)k_resample_gather_mn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      RR_TRY_OR_CLEAN(hipFuncSetAttribute((const void*)k_kld_draw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    // measured at 1e6 draws (gpurun_out/r02h): 64-entry windows + one 1024-thread workgroup per CU 43.9 us, 256-entry windows +
+    // 1024 workgroups of 256 threads 51.1 us -- the search is bound by its random 8-byte requests, a finer table saves two of them
+    if (!std::getenv("RR_MN_GRID")) h->mn_grid = 256 * (int)std::max<size_t>(1, std::min<size_t>(4, (144 * 1024) / std::max<size_t>(lds, 1)));
+  }
   RR_TRY_OR_CLEAN(hipMalloc(&h->cdf_coarse, (((h->cap + (1ull << h->coarse_log2) - 1) >> h->coarse_log2) + 1) * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->tile_total, cap_tiles * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->tile_q2, 2 * cap_tiles * sizeof(uint64_t)));
