@@ -34,6 +34,10 @@ struct Point2D { double x = 0, y = 0; };                       // core/src/types
 struct State2D { double x = 0, y = 0, yaw = 0, v = 0; };       // core/src/types.rs:141-146
 struct ControlInput { double v = 0, omega = 0; };              // core/src/types.rs:189-192
 struct Particle { double x, y, yaw, v, w; };                   // particle_filter.rs:25-32
+struct Obstacles {                                             // core/src/types.rs:344-346
+  std::vector<Point2D> points;
+  static Obstacles from_points(std::vector<Point2D> p) { return Obstacles{std::move(p)}; }
+};
 using PFState = std::array<double, 4>;
 using PFControl = std::array<double, 2>;
 using PFMeasurement = std::vector<std::tuple<double, double, double>>;  // (d, landmark_x, landmark_y)
@@ -60,6 +64,12 @@ class ParticleFilterLocalizer {
     check(rr_pf_create_with_state(&cfg, &o, initial.data(), &h_));
   }
   static ParticleFilterLocalizer with_defaults() { return ParticleFilterLocalizer(); }
+  // with_initial_state_2d, particle_filter.rs:202-207
+  static ParticleFilterLocalizer with_initial_state_2d(const State2D& s, const ParticleFilterConfig& cfg, uint64_t seed = 0, int device = 0) {
+    return ParticleFilterLocalizer(PFState{s.x, s.y, s.yaw, s.v}, cfg, seed, device);
+  }
+  // set_landmarks_from_obstacles, :223-225
+  void set_landmarks_from_obstacles(const Obstacles& o) { try_set_landmarks(o.points); }
   ParticleFilterLocalizer(ParticleFilterLocalizer&& o) noexcept : h_(std::exchange(o.h_, nullptr)) {}
   ParticleFilterLocalizer(const ParticleFilterLocalizer&) = delete;
   virtual ~ParticleFilterLocalizer() { rr_pf_destroy(h_); }
