@@ -420,15 +420,22 @@ RR_HD double rr_fs1_update_one(double px, double py, double pyaw, double zd, dou
   /* observation model :92-99 (landmark - particle, Q2) and Jacobian :102-110 */
   double dx = lx - px;
   double dy = ly - py;
-  double d2 = rr_fma(dy, dy, dx * dx);
+  /* squared range with the 2^-700 m^2 floor of the MCL likelihood (RR_PF_Q_FLOOR): no division by zero when a
+   * particle sits exactly on its landmark estimate (the reference divides by 0 there), and every argument of the
+   * device's bare square-root core is inside its exact range */
+  double d2 = rr_fma(dy, dy, rr_fma(dx, dx, RR_PF_Q_FLOOR));
+#if defined(__HIP_DEVICE_COMPILE__)
+  double d = rr_sqrt_core(d2); /* == rr_sqrt(d2) for finite d2 >= 2^-767 */
+#else
   double d = rr_sqrt(d2);
+#endif
   double zp_a = rr_normalize_angle(rr_atan2(dy, dx) - pyaw);
   double y0 = zd - d;
   double y1 = rr_normalize_angle(za - zp_a);
   /* D-spec: the Jacobian's four quotients (:105-108: dx/d, dy/d, -dy/d2, dx/d2) and the four of S^-1
    * below (:164) share two reciprocals -- 2 divisions instead of 8 (+1 instead of 2 in the likelihood);
    * each entry differs from the literal quotient by <= 1.5 ulp (tests/test_oracle_agreement.py, 1e-6). */
-  double rd = 1.0 / d, rd2 = 1.0 / d2;
+  double rd = 1.0 / d, rd2 = rd * rd;
   double h00 = dx * rd, h01 = dy * rd, h10 = -dy * rd2, h11 = dx * rd2;
   /* HP = H * P */
   double hp00 = rr_fma(h01, p10, h00 * p00);

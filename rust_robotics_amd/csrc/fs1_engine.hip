@@ -139,7 +139,8 @@ __global__ __launch_bounds__(kBlock) void k_fs2_predict(Planes pl, const Ctl* __
 //   bit 1  non-temporal loads on that path as well
 //   bit 2  no software pipeline (loads at the top of each update)
 //   bit 3  register budget for 4 waves per SIMD instead of 3
-constexpr int kObsNtStore = 1, kObsNtLoad = 2, kObsNoPipe = 4, kObsFourWaves = 8;
+//   bit 4  MEASUREMENT ONLY (wrong results): the EKF arithmetic is replaced by a copy -- the kernel's memory pattern alone
+constexpr int kObsNtStore = 1, kObsNtLoad = 2, kObsNoPipe = 4, kObsFourWaves = 8, kObsCopyOnly = 16;
 
 template <bool LAZY, bool SEQ, int VAR>
 __global__ __launch_bounds__(kBlock, (VAR & kObsFourWaves) ? 4 : 1) void k_fs1_observe(
@@ -220,7 +221,8 @@ __global__ __launch_bounds__(kBlock, (VAR & kObsFourWaves) ? 4 : 1) void k_fs1_o
 #pragma unroll
         for (int f = 0; f < 6; ++f) e[f] = nxt[f];
         if (k + 1 < nk) load6(src + (3 + (uint64_t)s_z[3 * k + 5] * 6) * n + j, nxt);
-        acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
+        if (VAR & kObsCopyOnly) acc += e[0] * zd + za;
+        else acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
         store6(dst + (3 + id * 6) * n + p, e);
       }
     }
@@ -869,6 +871,7 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool 
         case 4: kfn = RR_OBS_KERNEL(true, false, kObsNoPipe | kObsFourWaves | kObsNtStore); break;
         case 5: kfn = RR_OBS_KERNEL(true, false, kObsFourWaves); break;
         case 6: kfn = RR_OBS_KERNEL(true, false, kObsNoPipe); break;
+        case 16: kfn = RR_OBS_KERNEL(true, false, kObsCopyOnly); break;
         default: kfn = RR_OBS_KERNEL(true, false, 0); break;
       }
     }
