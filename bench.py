@@ -339,8 +339,8 @@ def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True):
     else:
         prm = fs.default_params()
         prm.first_obs_cov = 0.5
-        prm.nth = n / 1.5
-        f = fs.FastSlam1(n, L, params=prm, seed=2)
+        prm.nth = n / 1.5 * float(os.environ.get("RR_BENCH_NTH_SCALE", "1"))  # development knob: 0 = never resample, 10 = every step
+        f = fs.FastSlam1(n, L, params=prm, seed=2, obs_chunks=int(os.environ.get("RR_BENCH_OBS_CHUNKS", "0")))  # 0 = the engine's own choice
     zs = [np.array(fs.get_observations(H.true_pose(t + 1, v=0.5), [tuple(p) for p in lms], seed=2, step=t)).reshape(-1, 3)
           for t in range(2 * K + W)]
     u = [0.5, 0.1]

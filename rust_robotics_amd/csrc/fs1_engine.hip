@@ -44,7 +44,7 @@ using rr::PlanArgs;
 
 namespace {
 
-constexpr int kMaxChunks = 32;
+constexpr int kMaxChunks = 64;
 constexpr int kPlanesPerThread = 8;  // planes one gather thread copies for its output slot
 // sharded lazy resample: idx[p] == kInPlace => a peer has delivered slot p's particle into this rank's
 // fine-grained inbox (k_fs1_push); the consuming kernels then read slot p of the inbox instead
@@ -667,7 +667,8 @@ struct rr_fs1 {
   unsigned int* markers = nullptr;  // n + kResolveSlots, zero between resamples (fused single-GPU plan)
   unsigned int* carry = nullptr;    // one per kResolveSlots slots
   unsigned int* ridx = nullptr;  // sharded: sources of the served slots that belong to peers (allocated on connect)
-  double* partial = nullptr;  // kMaxChunks * n
+  double* partial = nullptr;  // partial_chunks * n: per-chunk weight products (grown on demand)
+  int partial_chunks = 0;
   double* z_dev = nullptr;
   size_t z_cap = 0;
   double* noise = nullptr;  // 2n
@@ -818,9 +819,14 @@ int choose_chunks(const rr_fs1* h, size_t n_z, bool dup) {
   if (dup || n_z <= 1) return 1;
   int want = h->opt.obs_chunks;
   if (want <= 0) {
-    // aim for >= ~8 waves per SIMD over the 256 CUs (1024 SIMDs) of an MI355X
+    // Short per-wave loops and many more waves than the 3072 the chip holds at 3 waves per SIMD: measured at 200
+    // observations (gpurun_out/r02m) 1e5 particles 6 / 13 / 29 chunks 0.395 / 0.374 / 0.364 ms, 125 000 particles
+    // 5 / 16 / 25 chunks 0.503 / 0.461 / 0.450 ms, 1e6 particles 1 / 2 / 4 chunks 4.02 / 3.78 / 3.88 ms -- about
+    // 45 000 waves per launch, but never fewer than ~7 observations per wave (the pose / index prologue)
     const uint64_t waves = (h->n + 63) / 64;
-    want = (int)((8192 + waves - 1) / waves);
+    want = (int)((45000 + waves - 1) / waves);
+    want = std::min<int>(want, (int)std::max<size_t>(1, n_z / 7));
+    if (const char* e = std::getenv("RR_FS1_TARGET_WAVES")) want = (int)((std::max(1, std::atoi(e)) + waves - 1) / waves);
   }
   want = std::max(1, std::min<int>({want, kMaxChunks, (int)n_z}));
   const int len = (int)((n_z + want - 1) / want);
@@ -883,6 +889,13 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool 
     const double* a_z = h->z_dev;
     int a_nz = (int)n_z, a_len = len, a_chunks = chunks;
     rr_fs1_model a_m = model_of(h);
+    if (chunks > 1 && chunks > h->partial_chunks) {  // per-chunk weight products
+      if (h->partial) RR_HIP_TRY(hipFree(h->partial));
+      h->partial = nullptr;
+      h->partial_chunks = 0;
+      RR_HIP_TRY(hipMalloc(&h->partial, (size_t)chunks * h->n * sizeof(double)));
+      h->partial_chunks = chunks;
+    }
     double* a_partial = h->partial;
     const unsigned int* a_idx = h->idx;
     void* args[] = {&a_pl, &a_pw, &a_ctl, &a_n, &a_z, &a_nz, &a_len, &a_chunks, &a_m, &a_partial, &a_idx};
@@ -1092,7 +1105,6 @@ rr_status rr_fs1_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs1
   RR_TRY_OR_CLEAN(hipMalloc(&h->markers, (h->n + rr::kResolveSlots) * sizeof(unsigned int)));
   RR_TRY_OR_CLEAN(hipMemsetAsync(h->markers, 0, (h->n + rr::kResolveSlots) * sizeof(unsigned int), h->stream));
   RR_TRY_OR_CLEAN(hipMalloc(&h->carry, (h->n / rr::kResolveSlots + 2) * sizeof(unsigned int)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->partial, (size_t)kMaxChunks * h->n * sizeof(double)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->part_bits, 1024 * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->part_idx, 1024 * sizeof(uint64_t)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->plane_list, (h->n_planes + 1) * sizeof(unsigned int)));
