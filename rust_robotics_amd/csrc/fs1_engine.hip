@@ -680,6 +680,7 @@ struct rr_fs1 {
   unsigned int step = 0, rstep = 0;
   int last_chunks = 1;
   bool wmax_live = false;  // Ctl.wmax_bits holds the maximum of the current weights
+  bool wmax_bits_clean = false;  // Ctl.wmax_bits is known to be zero (the last plan kernel consumed and zeroed it)
   bool maybe_pending = false;  // a lazy resample plan was launched; its gather has not been consumed yet
   unsigned int* plane_list = nullptr;  // device: planes of the landmarks a lazy observe leaves untouched
   std::vector<unsigned int> plane_list_host;
@@ -833,9 +834,17 @@ int choose_chunks(const rr_fs1* h, size_t n_z, bool dup) {
   return (int)((n_z + len - 1) / len);
 }
 
+// Ctl.wmax_bits must be zero before a kernel accumulates a weight maximum into it; the plan kernel of every
+// real (gate or forced) plan leaves it zeroed, anything else needs the memset
+rr_status zero_wmax(rr_fs1* h) {
+  if (!h->wmax_bits_clean) RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+  h->wmax_bits_clean = false;
+  return RR_OK;
+}
+
 rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool lazy = false) {
   if (n_z == 0) {  // no observation: weights untouched, but the max must still be known
-    RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+    if (rr_status zs = zero_wmax(h); zs != RR_OK) return zs;
     hipLaunchKernelGGL(k_fs1_wmax, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
     h->last_chunks = 1;
     h->wmax_live = true;
@@ -849,7 +858,7 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool 
     h->z_cap = n_z;
   }
   RR_HIP_TRY(hipMemcpyAsync(h->z_dev, z, 3 * n_z * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+  if (rr_status zs = zero_wmax(h); zs != RR_OK) return zs;
   h->wmax_live = true;
   const int chunks = choose_chunks(h, n_z, dup);
   const int len = (int)((n_z + chunks - 1) / chunks);
@@ -913,10 +922,11 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool 
 
 rr_status launch_sums(rr_fs1* h, int mode, double rho_override, bool lazy = false, int settle = 0) {
   if (!h->wmax_live) {  // the last plan kernel consumed the maximum (or the weights were renormalised since)
-    RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+    if (rr_status zs = zero_wmax(h); zs != RR_OK) return zs;
     hipLaunchKernelGGL(k_fs1_wmax, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
   }
   h->wmax_live = mode == 2;  // statistics leave everything in place; a real plan consumes it
+  h->wmax_bits_clean = mode != 2;  // ... and zeroes the accumulator (finalize_plan)
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_QUANTIZE_REDUCE);
     hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
@@ -963,10 +973,11 @@ rr_status launch_finish(rr_fs1* h, bool lazy = false) {
 // move when the next update, or an accessor, reads them through idx)
 rr_status launch_plan_fused(rr_fs1* h, int settle) {
   if (!h->wmax_live) {
-    RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+    if (rr_status zs = zero_wmax(h); zs != RR_OK) return zs;
     hipLaunchKernelGGL(k_fs1_wmax, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
   }
   h->wmax_live = false;
+  h->wmax_bits_clean = true;  // k_fs1_plan's finalize_plan zeroes the accumulator
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_QUANTIZE_REDUCE);
     hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
@@ -1389,7 +1400,7 @@ rr_status rr_fs1_set_state(rr_fs1* h, const double* poses, const double* maps) {
     RR_HIP_TRY(hipStreamSynchronize(h->stream));
   }
   // the weight maximum of the uploaded set (needed if normalize_resample is called next)
-  RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+  if ((s = zero_wmax(h)) != RR_OK) return s;
   hipLaunchKernelGGL(k_fs1_wmax, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
   RR_HIP_TRY(hipGetLastError());
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
@@ -1532,6 +1543,7 @@ rr_status rr_fs1_shard_update_p2p(rr_fs1* h, const double u[2], const double* z,
                        (const uint64_t*)h->tile_q2, h->n_tiles, gathered, h->ctl, pa, h->p2p.err);
   }
   h->wmax_live = false;
+  h->wmax_bits_clean = false;  // a peer wait that gave up skips finalize_plan: do not rely on the zeroed accumulator here
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_CDF);
     hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl, image_args(h),
@@ -1640,6 +1652,7 @@ rr_status rr_fs1_shard_plan(rr_fs1* h, const uint64_t* d_all_sums, int32_t n_sha
   }
   RR_HIP_TRY(hipGetLastError());
   h->maybe_pending = true;  // the next update reads through idx (or an accessor materialises)
+  h->wmax_bits_clean = true;  // k_shard_plan's finalize_plan zeroed the accumulator
   h->rstep += 1;
   return RR_OK;
 }

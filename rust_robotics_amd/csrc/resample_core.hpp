@@ -451,7 +451,10 @@ static __global__ __launch_bounds__(kBlock) void k_plan_cdf(const double* __rest
 // a running maximum per slot tile seeded by carry[tile] -- markers are increasing in the slot
 // index -- and clears them for the next step.  Everything is O(N), balanced on the output side,
 // and free of dependent HBM probe chains (the old lower_bound cost 20 of them per slot).
-constexpr int kResolveRows = 2;
+#ifndef RR_RESOLVE_ROWS
+#define RR_RESOLVE_ROWS 2
+#endif
+constexpr int kResolveRows = RR_RESOLVE_ROWS;
 constexpr int kResolveSlots = kResolveRows * kBlock;  // slots per resolve workgroup
 
 // this thread's 8 consecutive sources: exclusive CDF prefix `off`, inclusive prefixes off + c[j]
