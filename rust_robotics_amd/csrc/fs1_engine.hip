@@ -285,12 +285,12 @@ __global__ __launch_bounds__(kBlock) void k_fs1_normalize(double* __restrict__ p
 // normalises its tile's weights (:196-203, gate shut) or marks the slot run each of its sources feeds (:205-234) and
 // sets the weights to 1/n (:228).  One launch instead of k_scan_tiles + k_cdf + k_fs1_normalize + k_fs1_indices, no
 // CDF array, no per-slot binary search.  k_fs1_resolve turns the markers into idx[] (running maximum per 512 slots).
-__global__ __launch_bounds__(kBlock) void k_fs1_plan(double* pw /* read (tile_scan) and rewritten: no restrict */, Ctl* __restrict__ ctl, ImageArgs a,
+__global__ __launch_bounds__(rr::kTileBlock) void k_fs1_plan(double* pw /* read (tile_scan) and rewritten: no restrict */, Ctl* __restrict__ ctl, ImageArgs a,
                                                     const uint64_t* __restrict__ tile_total,
                                                     const uint64_t* __restrict__ tile_q2, uint64_t n_tiles, PlanArgs pa,
                                                     unsigned int* __restrict__ markers, unsigned int* __restrict__ carry) {
-  __shared__ uint64_t s4[4 * (kBlock / rr::kWave)];
-  __shared__ uint64_t s_w[kBlock / rr::kWave];
+  __shared__ uint64_t s4[4 * (rr::kTileBlock / rr::kWave)];
+  __shared__ uint64_t s_w[rr::kTileBlock / rr::kWave];
   const rr::TileSums ts = rr::tile_sums(tile_total, tile_q2, n_tiles, s4);
   const int mode = ctl->image_mode;
   const int shift = ctl->shift;

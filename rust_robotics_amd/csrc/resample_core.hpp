@@ -18,9 +18,13 @@
 
 namespace rr {
 
-constexpr int kBlock = 256;      // every kernel: 4 waves per workgroup
-constexpr int kTileBlock = kBlock;
-constexpr int kItems = 8;        // particles per thread in the tile kernels
+constexpr int kBlock = 256;      // propagate / gather / resolve kernels: 4 waves per workgroup
+// tile kernels (quantize-reduce, tile scan, CDF, plan + mark): a tile is kTileBlock * kItems = 2048 particles
+#ifndef RR_TILE_BLOCK
+#define RR_TILE_BLOCK 512
+#endif
+constexpr int kTileBlock = RR_TILE_BLOCK;
+constexpr int kItems = 2048 / RR_TILE_BLOCK;  // particles per thread in the tile kernels
 constexpr int kTile = kTileBlock * kItems;  // 2048 particles per scan tile
 constexpr int kTileWaves = kTileBlock / 64;
 constexpr int kWaveSpan = kTile / kTileWaves;  // consecutive particles owned by one wave in k_quantize_reduce
@@ -321,7 +325,7 @@ struct TileScan {
 };
 
 __device__ inline TileScan tile_scan(const double* __restrict__ w, const ImageArgs& a, int mode, int shift,
-                                     uint64_t tile, uint64_t* s_w /* [kBlock / kWave] */) {
+                                     uint64_t tile, uint64_t* s_w /* [kTileBlock / kWave] */) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   TileScan t;
   const uint64_t i0 = tile * kTile + (uint64_t)tid * kItems;
@@ -348,12 +352,12 @@ struct TileSums {
 };
 
 __device__ inline TileSums tile_sums(const uint64_t* __restrict__ tile_total, const uint64_t* __restrict__ tile_q2,
-                                     uint64_t n_tiles, uint64_t* s4 /* [4][kBlock / kWave] */) {
+                                     uint64_t n_tiles, uint64_t* s4 /* [4][kTileBlock / kWave] */) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  constexpr int W = kBlock / kWave;
+  constexpr int W = kTileBlock / kWave;
   uint64_t pre = 0, tot = 0;
   u128 q2 = {0, 0};
-  for (uint64_t k = tid; k < n_tiles; k += kBlock) {
+  for (uint64_t k = tid; k < n_tiles; k += kTileBlock) {
     const uint64_t t = tile_total[k];
     tot += t;
     if (k < blockIdx.x) pre += t;
@@ -404,12 +408,12 @@ __device__ inline void store_cdf(const TileScan& t, uint64_t off, uint64_t i0, u
   }
 }
 
-static __global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict__ w, const Ctl* __restrict__ ctl,
+static __global__ __launch_bounds__(kTileBlock) void k_cdf(const double* __restrict__ w, const Ctl* __restrict__ ctl,
                                                       ImageArgs a, const uint64_t* __restrict__ tile_offset,
                                                       uint64_t* __restrict__ cdf, uint64_t* __restrict__ coarse,
                                                       int coarse_log2) {
   if (!ctl->fired) return;
-  __shared__ uint64_t s_w[kBlock / kWave];
+  __shared__ uint64_t s_w[kTileBlock / kWave];
   const TileScan t = tile_scan(w, a, ctl->image_mode, ctl->shift, blockIdx.x, s_w);
   const uint64_t off = ctl->base + tile_offset[blockIdx.x] + t.thread_off;
   const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
@@ -422,13 +426,13 @@ static __global__ __launch_bounds__(kBlock) void k_cdf(const double* __restrict_
 // CDF.  Workgroup 0 publishes the plan.  Saves one launch and one dependent single-block kernel.
 constexpr int kFusedMaxTiles = 4096;
 
-static __global__ __launch_bounds__(kBlock) void k_plan_cdf(const double* __restrict__ w, Ctl* __restrict__ ctl,
+static __global__ __launch_bounds__(kTileBlock) void k_plan_cdf(const double* __restrict__ w, Ctl* __restrict__ ctl,
                                                            ImageArgs a, const uint64_t* __restrict__ tile_total,
                                                            const uint64_t* __restrict__ tile_q2, uint64_t n_tiles,
                                                            PlanArgs pa, uint64_t* __restrict__ cdf,
                                                            uint64_t* __restrict__ coarse, int coarse_log2) {
-  __shared__ uint64_t s4[4 * (kBlock / kWave)];
-  __shared__ uint64_t s_w[kBlock / kWave];
+  __shared__ uint64_t s4[4 * (kTileBlock / kWave)];
+  __shared__ uint64_t s_w[kTileBlock / kWave];
   const TileSums ts = tile_sums(tile_total, tile_q2, n_tiles, s4);
   const int mode = ctl->image_mode;  // written by k_quantize_reduce; nothing below reads what block 0 writes
   const int shift = ctl->shift;
@@ -497,8 +501,8 @@ struct EstArgs {
 
 __device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, const TileScan& t, const unsigned int* offspring,
                                      int fire, uint64_t i0, uint64_t n, double denom, unsigned int rstep) {
-  __shared__ double s_acc[kBlock / kWave][4];
-  __shared__ double s_c[kBlock * (kItems + 1)];  // coefficient of the tile's particle i at [i + i / kItems] (padded rows)
+  __shared__ double s_acc[kTileBlock / kWave][4];
+  __shared__ double s_c[kTileBlock * (kItems + 1)];  // coefficient of the tile's particle i at [i + i / kItems] (padded rows)
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int cur = ctl->cur;
@@ -511,7 +515,7 @@ __device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, c
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
   for (int r = 0; r < kItems; ++r) {
-    const int i = r * kBlock + tid;
+    const int i = r * kTileBlock + tid;
     const double c = s_c[i + i / kItems];
     if (c != 0.0) {
 #pragma unroll
@@ -528,7 +532,7 @@ __device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, c
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       double v = 0.0;
-      for (int q = 0; q < kBlock / kWave; ++q) v += s_acc[q][k];
+      for (int q = 0; q < kTileBlock / kWave; ++q) v += s_acc[q][k];
       ea.partials[(uint64_t)blockIdx.x * 4 + k] = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -541,10 +545,12 @@ __device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, c
   if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   __syncthreads();
   // wave k adds moment k over the workgroups: lanes stride (fixed order per lane), then a shuffle tree
-  double v = 0.0;
-  for (unsigned int b = lane; b < gridDim.x; b += 64) v += __builtin_nontemporal_load(&ea.partials[(uint64_t)b * 4 + wv]);
-  v = wave_sum(v);
-  if (lane == 0) ctl->est[wv] = v / denom;
+  if (wv < 4) {
+    double v = 0.0;
+    for (unsigned int b = lane; b < gridDim.x; b += 64) v += __builtin_nontemporal_load(&ea.partials[(uint64_t)b * 4 + wv]);
+    v = wave_sum(v);
+    if (lane == 0) ctl->est[wv] = v / denom;
+  }
   if (tid == 0) {
     ctl->est_step = (uint64_t)rstep + 1;
     *ea.ticket = 0;
@@ -552,13 +558,13 @@ __device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, c
 }
 
 // fused plan + mark (single shard, systematic, n_tiles <= kFusedMaxTiles)
-static __global__ __launch_bounds__(kBlock) void k_plan_mark(const double* __restrict__ w, Ctl* __restrict__ ctl,
+static __global__ __launch_bounds__(kTileBlock) void k_plan_mark(const double* __restrict__ w, Ctl* __restrict__ ctl,
                                                             ImageArgs a, const uint64_t* __restrict__ tile_total,
                                                             const uint64_t* __restrict__ tile_q2, uint64_t n_tiles,
                                                             PlanArgs pa, unsigned int* __restrict__ markers,
                                                             unsigned int* __restrict__ carry, EstArgs ea) {
-  __shared__ uint64_t s4[4 * (kBlock / kWave)];
-  __shared__ uint64_t s_w[kBlock / kWave];
+  __shared__ uint64_t s4[4 * (kTileBlock / kWave)];
+  __shared__ uint64_t s_w[kTileBlock / kWave];
   const TileSums ts = tile_sums(tile_total, tile_q2, n_tiles, s4);
   const int mode = ctl->image_mode;
   const int shift = ctl->shift;
@@ -583,12 +589,12 @@ static __global__ __launch_bounds__(kBlock) void k_plan_mark(const double* __res
 
 // sharded: the plan is already in Ctl (k_shard_plan); mark this shard's sources.  tile_offset =
 // exclusive tile prefix written by k_scan_tiles.
-static __global__ __launch_bounds__(kBlock) void k_mark(const double* __restrict__ w, const Ctl* __restrict__ ctl,
+static __global__ __launch_bounds__(kTileBlock) void k_mark(const double* __restrict__ w, const Ctl* __restrict__ ctl,
                                                        ImageArgs a, const uint64_t* __restrict__ tile_offset,
                                                        unsigned int* __restrict__ markers,
                                                        unsigned int* __restrict__ carry) {
   if (!ctl->fired) return;
-  __shared__ uint64_t s_w[kBlock / kWave];
+  __shared__ uint64_t s_w[kTileBlock / kWave];
   const TileScan t = tile_scan(w, a, ctl->image_mode, ctl->shift, blockIdx.x, s_w);
   const rr_sys_plan plan = ctl->plan;
   const uint64_t slot_base = ctl->served_first;
