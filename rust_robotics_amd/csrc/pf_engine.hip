@@ -633,9 +633,9 @@ __device__ inline bool mn_slot_target(const Ctl* __restrict__ ctl, const MnSelec
   return target > ctl->base && target <= ctl->base + ctl->total_local;
 }
 
-__global__ __launch_bounds__(kBlock) void k_mn_select_count(const Ctl* __restrict__ ctl, MnSelectArgs a,
+__global__ __launch_bounds__(rr::kTileBlock) void k_mn_select_count(const Ctl* __restrict__ ctl, MnSelectArgs a,
                                                            unsigned int* __restrict__ tile_cnt) {
-  __shared__ unsigned int s_c[kBlock / rr::kWave];
+  __shared__ unsigned int s_c[rr::kTileBlock / rr::kWave];
   unsigned int c = 0;
   if (ctl->fired) {
 #pragma unroll
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(kBlock) void k_mn_select_count(const Ctl* __restric
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned int t = 0;
-    for (int k = 0; k < kBlock / rr::kWave; ++k) t += s_c[k];
+    for (int k = 0; k < rr::kTileBlock / rr::kWave; ++k) t += s_c[k];
     tile_cnt[blockIdx.x] = t;
   }
 }
@@ -684,12 +684,12 @@ __global__ __launch_bounds__(kScanThreads) void k_mn_select_scan(unsigned int* _
   if (tid < n_shards) counts_out[tid] = s_dest[tid + 1] - s_dest[tid];
 }
 
-__global__ __launch_bounds__(kBlock) void k_mn_select_pack(Bufs b, const Ctl* __restrict__ ctl, MnSelectArgs a,
+__global__ __launch_bounds__(rr::kTileBlock) void k_mn_select_pack(Bufs b, const Ctl* __restrict__ ctl, MnSelectArgs a,
                                                           const unsigned int* __restrict__ tile_off,
                                                           const uint64_t* __restrict__ cdf, uint64_t n_src,
                                                           double* __restrict__ out) {
   if (!ctl->fired) return;
-  __shared__ unsigned int s_c[kBlock / rr::kWave];
+  __shared__ unsigned int s_c[rr::kTileBlock / rr::kWave];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   uint64_t slot[rr::kItems], target[rr::kItems];
   bool mine[rr::kItems];
@@ -2130,7 +2130,7 @@ rr_status rr_pf_shard_select(rr_pf* h, int32_t n_shards, uint64_t* d_counts_out)
     h->mn_tiles = n_tiles;
   }
   Timed t(h, RR_K_RESAMPLE_GATHER);
-  hipLaunchKernelGGL(k_mn_select_count, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->ctl, a, h->mn_tile_cnt);
+  hipLaunchKernelGGL(k_mn_select_count, dim3((unsigned)n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->ctl, a, h->mn_tile_cnt);
   hipLaunchKernelGGL(k_mn_select_scan, dim3(1), dim3(kScanThreads), 0, h->stream, h->mn_tile_cnt, n_tiles, a.tiles_per_dest, (int)n_shards,
                      d_counts_out);
   RR_HIP_TRY(hipGetLastError());
@@ -2146,7 +2146,7 @@ rr_status rr_pf_shard_pack_selected(rr_pf* h, int32_t n_shards, double* d_send) 
   const uint64_t n_tiles = a.tiles_per_dest * (uint64_t)n_shards;
   if (n_tiles != h->mn_tiles && n_tiles > h->mn_tiles) return fail(RR_INVALID_PARAMETER, "call rr_pf_shard_select first");
   Timed t(h, RR_K_RESAMPLE_GATHER);
-  hipLaunchKernelGGL(k_mn_select_pack, dim3((unsigned)n_tiles), dim3(kBlock), 0, h->stream, h->b, h->ctl, a,
+  hipLaunchKernelGGL(k_mn_select_pack, dim3((unsigned)n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->b, h->ctl, a,
                      (const unsigned int*)h->mn_tile_cnt, (const uint64_t*)h->cdf, h->n, d_send);
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
