@@ -2144,7 +2144,7 @@ rr_status rr_pf_shard_pack_selected(rr_pf* h, int32_t n_shards, double* d_send) 
   if (!d_send) return fail(RR_INVALID_PARAMETER, "null send buffer");
   const MnSelectArgs a = mn_args(h, n_shards);
   const uint64_t n_tiles = a.tiles_per_dest * (uint64_t)n_shards;
-  if (n_tiles != h->mn_tiles && n_tiles > h->mn_tiles) return fail(RR_INVALID_PARAMETER, "call rr_pf_shard_select first");
+  if (n_tiles > h->mn_tiles) return fail(RR_INVALID_PARAMETER, "call rr_pf_shard_select first");
   Timed t(h, RR_K_RESAMPLE_GATHER);
   hipLaunchKernelGGL(k_mn_select_pack, dim3((unsigned)n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->b, h->ctl, a,
                      (const unsigned int*)h->mn_tile_cnt, (const uint64_t*)h->cdf, h->n, d_send);
