@@ -538,27 +538,30 @@ __global__ __launch_bounds__(kBlock) void k_resolve_push(Bufs b, const Ctl* __re
                                                         uint64_t n_local) {
   if (!ctl->fired) return;
   const uint64_t first = ctl->served_first, n_slots = ctl->served_count;
-  const uint64_t tile_base = (uint64_t)blockIdx.x * rr::kResolveSlots;
-  if (tile_base >= n_slots) return;  // uniform per workgroup
-  unsigned int idx[rr::kResolveRows];
-  rr::resolve_tile(markers, carry, n_slots, blockIdx.x, idx);
   const int src = ctl->cur;  // lazy: Ctl.cur flips when the next step settles
   const uint64_t me = (uint64_t)peers.rank;
+  // grid-stride over the served slot tiles: the grid is sized for the usual case (about n_local served slots), a shard
+  // that serves more loops (uniform per workgroup: resolve_tile synchronises)
+  for (uint64_t tile = blockIdx.x; tile * rr::kResolveSlots < n_slots; tile += gridDim.x) {
+    const uint64_t tile_base = tile * rr::kResolveSlots;
+    unsigned int idx[rr::kResolveRows];
+    rr::resolve_tile(markers, carry, n_slots, tile, idx);
 #pragma unroll
-  for (int r = 0; r < rr::kResolveRows; ++r) {
-    const uint64_t k = tile_base + (uint64_t)r * kBlock + threadIdx.x;
-    if (k < n_slots) {
-      const uint64_t s = first + k;
-      const uint64_t d = s / n_local, li = s - d * n_local;
-      const uint64_t j = idx[r];
-      if (d == me) {
-        lidx[li] = (unsigned int)j;
-      } else {
-        double* __restrict__ out = peers.inbox[d];  // fine-grained, [field][n_local]
-        out[li] = b.x[src][j];
-        out[n_local + li] = b.y[src][j];
-        out[2 * n_local + li] = b.yaw[src][j];
-        out[3 * n_local + li] = b.v[src][j];
+    for (int r = 0; r < rr::kResolveRows; ++r) {
+      const uint64_t k = tile_base + (uint64_t)r * kBlock + threadIdx.x;
+      if (k < n_slots) {
+        const uint64_t s = first + k;
+        const uint64_t d = s / n_local, li = s - d * n_local;
+        const uint64_t j = idx[r];
+        if (d == me) {
+          lidx[li] = (unsigned int)j;
+        } else {
+          double* __restrict__ out = peers.inbox[d];  // fine-grained, [field][n_local]
+          out[li] = b.x[src][j];
+          out[n_local + li] = b.y[src][j];
+          out[2 * n_local + li] = b.yaw[src][j];
+          out[3 * n_local + li] = b.v[src][j];
+        }
       }
     }
   }
@@ -2327,8 +2330,8 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   // return at once) -- own slots -> lidx, the others -> stored into their owners' slabs
   {
     Timed t(h, RR_K_RESAMPLE_GATHER);
-    hipLaunchKernelGGL(k_resolve_push, dim3(grid_for(h->n_global, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b,
-                       h->ctl, h->markers, h->carry, h->lidx, h->p2p.peers, h->n);
+    hipLaunchKernelGGL(k_resolve_push, dim3(grid_for(std::min<uint64_t>(h->n_global, 2 * h->n), rr::kResolveSlots)), dim3(kBlock), 0,
+                       h->stream, h->b, h->ctl, h->markers, h->carry, h->lidx, h->p2p.peers, h->n);
   }
   // exchange 3: every rank's stores into everybody's slab have landed
   hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PDone, seq,
