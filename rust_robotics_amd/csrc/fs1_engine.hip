@@ -249,8 +249,16 @@ __global__ __launch_bounds__(kBlock) void k_fs1_combine(double* __restrict__ pw,
   const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   double w = 0.0;
   if (p < n) {
+    // the product keeps its chunk order (the D-spec's), the loads do not wait for it: eight in flight per thread, a
+    // chunk past the end contributes an exact factor 1  (18 -> 12 us at 1e5 particles x 25 chunks)
     w = partial[p];
-    for (int c = 1; c < n_chunks; ++c) w *= partial[(uint64_t)c * n + p];
+    for (int c0 = 1; c0 < n_chunks; c0 += 8) {
+      double f[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) f[k] = c0 + k < n_chunks ? __builtin_nontemporal_load(&partial[(uint64_t)(c0 + k) * n + p]) : 1.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) w *= f[k];
+    }
     pw[p] = w;
   }
   double mx = w > 0.0 ? w : 0.0;
