@@ -138,6 +138,95 @@ RR_HD double rr_pf_weight_fused(double x, double y, const double* obs, int n_obs
   return rr_exp(rr_fma(-ss, k.inv_two_s2, (double)n_obs * k.log_coeff));
 }
 
+#if defined(__cplusplus) && defined(__HIPCC__)
+/* rr_pf_weight_fused for R particles of one thread at once -- per particle the very same operations in the same
+ * order (so the same bits); what changes is the instruction stream: each observation is read once for all R
+ * particles and fetched one iteration ahead, and the R dependency chains (~16 FP64 instructions per pair, every
+ * one waiting for its predecessor) are independent of each other, so a wave always has an instruction ready. */
+template <int R>
+__device__ inline void rr_pf_weight_fused_rows(const double (&x)[R], const double (&y)[R], const double* obs, int n_obs,
+                                               rr_pf_lik k, double (&out)[R]) {
+  double ss[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) ss[r] = 0.0;
+  if (n_obs > 0) {
+    double d = obs[0], lx = obs[1], ly = obs[2];
+    for (int l = 0; l < n_obs; ++l) {
+      const int ln = l + 1 < n_obs ? l + 1 : l;
+      const double dn = obs[3 * ln], lxn = obs[3 * ln + 1], lyn = obs[3 * ln + 2];
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RR_PF_ROWS_STEP_MAJOR)
+      /* the same operations written step by step across the rows (rr_sqrt_core spelled out), the next observation's
+       * loads pinned in front of them */
+      __builtin_amdgcn_sched_barrier(0);
+      double q[R], g[R], h[R], t[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) t[r] = x[r] - lx;
+#pragma unroll
+      for (int r = 0; r < R; ++r) q[r] = rr_fma(t[r], t[r], RR_PF_Q_FLOOR);
+#pragma unroll
+      for (int r = 0; r < R; ++r) t[r] = y[r] - ly;
+#pragma unroll
+      for (int r = 0; r < R; ++r) q[r] = rr_fma(t[r], t[r], q[r]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) t[r] = __builtin_amdgcn_rsq(q[r]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) g[r] = q[r] * t[r];
+#pragma unroll
+      for (int r = 0; r < R; ++r) h[r] = 0.5 * t[r];
+#pragma unroll
+      for (int r = 0; r < R; ++r) t[r] = __builtin_fma(-h[r], g[r], 0.5);
+#pragma unroll
+      for (int r = 0; r < R; ++r) g[r] = __builtin_fma(g[r], t[r], g[r]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) h[r] = __builtin_fma(h[r], t[r], h[r]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) t[r] = __builtin_fma(-g[r], g[r], q[r]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) g[r] = __builtin_fma(t[r], h[r], g[r]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) t[r] = __builtin_fma(-g[r], g[r], q[r]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) g[r] = __builtin_fma(t[r], h[r], g[r]);
+#pragma unroll
+      for (int r = 0; r < R; ++r) t[r] = d - g[r];
+#pragma unroll
+      for (int r = 0; r < R; ++r) ss[r] = rr_fma(t[r], t[r], ss[r]);
+#if RR_PF_ROWS_STEP_MAJOR > 1
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+#else
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        double dx = x[r] - lx;
+        double dy = y[r] - ly;
+        double q = rr_fma(dy, dy, rr_fma(dx, dx, RR_PF_Q_FLOOR));
+#if defined(__HIP_DEVICE_COMPILE__)
+        double diff = d - rr_sqrt_core(q);
+#else
+        double diff = d - rr_sqrt(q); /* (host pass of the compiler: never called) */
+#endif
+        ss[r] = rr_fma(diff, diff, ss[r]);
+      }
+#endif
+      d = dn;
+      lx = lxn;
+      ly = lyn;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    if (ss[r] != ss[r]) { /* an overflowing q: the exact form once (as rr_pf_weight_fused) */
+      ss[r] = 0.0;
+      for (int l = 0; l < n_obs; ++l) {
+        double diff = rr_pf_residual_fused(x[r], y[r], obs[3 * l], obs[3 * l + 1], obs[3 * l + 2]);
+        ss[r] = rr_fma(diff, diff, ss[r]);
+      }
+    }
+    out[r] = rr_exp(rr_fma(-ss[r], k.inv_two_s2, (double)n_obs * k.log_coeff));
+  }
+}
+#endif
+
 /* ===================================================================== fixed-point CDF */
 /* The resampling CDF is built from integer weights so that its value does not
  * depend on summation order (1 GPU, 8 GPUs and the CPU agree bit for bit):

@@ -184,8 +184,20 @@ __global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __r
 // of this rank's inbox (k_resolve_push) -- and every consumed entry is reset to kInPlace.
 constexpr unsigned int kInPlace = 0xffffffffu;
 
-template <bool OBS_KERNARG, bool SHARDED>
-__global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
+#ifndef RR_K1_WAVES
+#define RR_K1_WAVES 4
+#endif
+#ifndef RR_K1_ROWS
+#define RR_K1_ROWS 1  // weights of the thread's rows in one interleaved pass (rr_pf_weight_fused_rows)
+#endif
+#ifndef RR_K1_ONE_TILE
+#define RR_K1_ONE_TILE 1
+#endif
+#ifndef RR_K1_NOISE_EARLY
+#define RR_K1_NOISE_EARLY 1  // motion noise (independent of the particles) evaluated while the marker / particle loads fly
+#endif
+template <bool OBS_KERNARG, bool SHARDED, int LIK>
+__global__ __launch_bounds__(kBlock, RR_K1_WAVES) void k_step_lazy(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
                                                      StepParams p, ObsArg obs_arg,
                                                      const double* __restrict__ obs_dev,
                                                      unsigned int* __restrict__ markers,
@@ -204,9 +216,23 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
   const double* __restrict__ syaw = b.yaw[src];
   const uint64_t n_tiles = (p.n + rr::kResolveSlots - 1) / rr::kResolveSlots;
   double wmax_local = 0.0;
+#if RR_K1_ONE_TILE
+  const uint64_t tile = blockIdx.x;  // one tile per workgroup: nothing is loop-invariant, so no constant outlives its use
+  if (tile < n_tiles) {
+#else
   for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+#endif
     unsigned int idx[rr::kResolveRows];
     const uint64_t tile_base = tile * rr::kResolveSlots;
+    double na[rr::kResolveRows], nc[rr::kResolveRows];
+#if RR_K1_NOISE_EARLY
+    // The noise of a slot depends on (seed, step, slot) only: evaluate it first, so that this FP64 work runs while
+    // the first dependent loads of the tile (control word, markers) are in flight and the workgroups of a CU, which
+    // all start together, do not all sit in their load prologue at the same time.
+#pragma unroll
+    for (int r = 0; r < rr::kResolveRows; ++r)
+      rr_pf_motion_noise(p.seed, p.step, p.first_gid + tile_base + (uint64_t)r * kBlock + tid, p.sigma_v, p.sigma_w, &na[r], &nc[r]);
+#endif
     if (pending && SHARDED) {
 #pragma unroll
       for (int r = 0; r < rr::kResolveRows; ++r) {
@@ -242,22 +268,42 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
     for (int r = 0; r < rr::kResolveRows; ++r) {
       const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
       if (k < p.n) {
-        double v, a, c;
-        rr_pf_motion_noise(p.seed, p.step, p.first_gid + k, p.sigma_v, p.sigma_w, &a, &c);
-        rr_pf_propagate_one(&x[r], &y[r], &yaw[r], &v, p.u0, p.u1, p.dt, a, c);
+        double v;
+#if !RR_K1_NOISE_EARLY
+        rr_pf_motion_noise(p.seed, p.step, p.first_gid + k, p.sigma_v, p.sigma_w, &na[r], &nc[r]);
+#endif
+        rr_pf_propagate_one(&x[r], &y[r], &yaw[r], &v, p.u0, p.u1, p.dt, na[r], nc[r]);
         b.x[dst][k] = x[r];
         b.y[dst][k] = y[r];
         b.yaw[dst][k] = yaw[r];
         b.v[dst][k] = v;
-        const double wgt = p.lik_mode == RR_LIK_PRODUCT ? rr_pf_weight_product(x[r], y[r], s_obs, p.n_obs, p.lik)
-                                                        : rr_pf_weight_fused(x[r], y[r], s_obs, p.n_obs, p.lik);
-        w[k] = wgt;
-        if (wgt > wmax_local) wmax_local = wgt;
         if (SHARDED) {
           if (pending) markers[k] = kInPlace;
         } else if (pending && idx_out) {
           idx_out[k] = idx[r];
         }
+      }
+    }
+    double wgt[rr::kResolveRows];
+    if (LIK == RR_LIK_PRODUCT) {
+#pragma unroll
+      for (int r = 0; r < rr::kResolveRows; ++r) wgt[r] = rr_pf_weight_product(x[r], y[r], s_obs, p.n_obs, p.lik);
+    } else {
+#if RR_K1_ROWS
+      // one pass over the observation block for the thread's rows, independent chains per row (a row past the end
+      // of the set weighs a dummy particle at the origin and stores nothing)
+      rr_pf_weight_fused_rows<rr::kResolveRows>(x, y, s_obs, p.n_obs, p.lik, wgt);
+#else
+#pragma unroll
+      for (int r = 0; r < rr::kResolveRows; ++r) wgt[r] = rr_pf_weight_fused(x[r], y[r], s_obs, p.n_obs, p.lik);
+#endif
+    }
+#pragma unroll
+    for (int r = 0; r < rr::kResolveRows; ++r) {
+      const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
+      if (k < p.n) {
+        w[k] = wgt[r];
+        if (wgt[r] > wmax_local) wmax_local = wgt[r];
       }
     }
   }
@@ -1526,6 +1572,31 @@ rr_status ensure_scratch(rr_pf* h, size_t doubles_a, size_t doubles_b) {
 // =============================================================================================
 // C ABI
 // =============================================================================================
+// one launch of k_step_lazy: the template arguments from run-time facts (ea/eb: dispatch timestamps when profiling)
+template <bool KA, bool SH, int LIK>
+static void launch_k1_as(rr_pf* h, unsigned grid, size_t lds, hipEvent_t ea, hipEvent_t eb, const StepParams& p, const ObsArg& arg,
+                         unsigned int* markers, const unsigned int* carry, unsigned int* idx_out, const double* inbox) {
+  const double* obs_dev = KA ? nullptr : h->obs_dev;
+  if (ea)
+    hipExtLaunchKernelGGL((k_step_lazy<KA, SH, LIK>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl, p, arg,
+                          obs_dev, markers, carry, idx_out, inbox);
+  else
+    hipLaunchKernelGGL((k_step_lazy<KA, SH, LIK>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg, obs_dev,
+                       markers, carry, idx_out, inbox);
+}
+
+static void launch_k1(rr_pf* h, bool kernarg, bool sharded, unsigned grid, size_t lds, hipEvent_t ea, hipEvent_t eb,
+                      const StepParams& p, const ObsArg& arg, unsigned int* markers, const unsigned int* carry,
+                      unsigned int* idx_out, const double* inbox) {
+  const bool product = p.lik_mode == RR_LIK_PRODUCT;
+#define RR_K1_GO(KA_, SH_, LIK_) launch_k1_as<KA_, SH_, LIK_>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, inbox)
+  if (kernarg && sharded) product ? RR_K1_GO(true, true, RR_LIK_PRODUCT) : RR_K1_GO(true, true, RR_LIK_FUSED);
+  else if (kernarg) product ? RR_K1_GO(true, false, RR_LIK_PRODUCT) : RR_K1_GO(true, false, RR_LIK_FUSED);
+  else if (sharded) product ? RR_K1_GO(false, true, RR_LIK_PRODUCT) : RR_K1_GO(false, true, RR_LIK_FUSED);
+  else product ? RR_K1_GO(false, false, RR_LIK_PRODUCT) : RR_K1_GO(false, false, RR_LIK_FUSED);
+#undef RR_K1_GO
+}
+
 extern "C" {
 
 const char* rr_last_error(void) { return rr::last_error_slot().c_str(); }
@@ -1768,18 +1839,11 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
   h->wmax_bits_clean = false;
   h->wmax_live = true;
   const uint64_t n_rtiles = (h->n + rr::kResolveSlots - 1) / rr::kResolveSlots;
-  const unsigned grid = (unsigned)std::min<uint64_t>(n_rtiles, (uint64_t)256 * h->k1_blocks_per_cu);
+  const unsigned grid = RR_K1_ONE_TILE ? (unsigned)n_rtiles : (unsigned)std::min<uint64_t>(n_rtiles, (uint64_t)256 * h->k1_blocks_per_cu);
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
     if (multinomial) {  // sources of the previous (multinomial) resample are in lidx
-      if (kernarg)
-        hipLaunchKernelGGL((k_step_lazy<true, true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
-                           (const double*)nullptr, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr,
-                            (const double*)h->p2p.inbox);
-      else
-        hipLaunchKernelGGL((k_step_lazy<false, true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
-                           (const double*)h->obs_dev, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr,
-                            (const double*)h->p2p.inbox);
+      launch_k1(h, kernarg, /*sharded=*/true, grid, lds, nullptr, nullptr, p, arg, h->lidx, nullptr, nullptr, h->p2p.inbox);
     } else {
       hipEvent_t ea = nullptr, eb = nullptr;
       if (h->profiling && h->profile_dispatch_only) {  // timestamps of this dispatch itself: nothing extra in the stream
@@ -1787,18 +1851,7 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
         eb = take_event(h);
         h->events.push_back({RR_K_PROPAGATE_WEIGHT, ea, eb});
       }
-      if (ea && kernarg)
-        hipExtLaunchKernelGGL((k_step_lazy<true, false>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl,
-                              p, arg, (const double*)nullptr, h->markers, h->carry, h->idx, (const double*)nullptr);
-      else if (ea)
-        hipExtLaunchKernelGGL((k_step_lazy<false, false>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w,
-                              h->ctl, p, arg, (const double*)h->obs_dev, h->markers, h->carry, h->idx, (const double*)nullptr);
-      else if (kernarg)
-        hipLaunchKernelGGL((k_step_lazy<true, false>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
-                           (const double*)nullptr, h->markers, h->carry, h->idx, (const double*)nullptr);
-      else
-        hipLaunchKernelGGL((k_step_lazy<false, false>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
-                           (const double*)h->obs_dev, h->markers, h->carry, h->idx, (const double*)nullptr);
+      launch_k1(h, kernarg, /*sharded=*/false, grid, lds, ea, eb, p, arg, h->markers, h->carry, h->idx, nullptr);
     }
   }
   RR_HIP_TRY(hipGetLastError());
@@ -2277,7 +2330,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   uint64_t* local3 = h->p2p.local3();
   // A: propagate + weight through lidx
   const uint64_t n_rtiles = (h->n + rr::kResolveSlots - 1) / rr::kResolveSlots;
-  const unsigned grid = (unsigned)std::min<uint64_t>(n_rtiles, (uint64_t)256 * h->k1_blocks_per_cu);
+  const unsigned grid = RR_K1_ONE_TILE ? (unsigned)n_rtiles : (unsigned)std::min<uint64_t>(n_rtiles, (uint64_t)256 * h->k1_blocks_per_cu);
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
     hipEvent_t ea = nullptr, eb = nullptr;
@@ -2286,22 +2339,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
       eb = take_event(h);
       h->events.push_back({RR_K_PROPAGATE_WEIGHT, ea, eb});
     }
-    if (ea && kernarg)
-      hipExtLaunchKernelGGL((k_step_lazy<true, true>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl, p,
-                            arg, (const double*)nullptr, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr,
-                            (const double*)h->p2p.inbox);
-    else if (ea)
-      hipExtLaunchKernelGGL((k_step_lazy<false, true>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl, p,
-                            arg, (const double*)h->obs_dev, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr,
-                            (const double*)h->p2p.inbox);
-    else if (kernarg)
-      hipLaunchKernelGGL((k_step_lazy<true, true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
-                         (const double*)nullptr, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr,
-                            (const double*)h->p2p.inbox);
-    else
-      hipLaunchKernelGGL((k_step_lazy<false, true>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg,
-                         (const double*)h->obs_dev, h->lidx, (const unsigned int*)nullptr, (unsigned int*)nullptr,
-                            (const double*)h->p2p.inbox);
+    launch_k1(h, kernarg, /*sharded=*/true, grid, lds, ea, eb, p, arg, h->lidx, nullptr, nullptr, h->p2p.inbox);
   }
   h->step += 1;
   PlanArgs pa = plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN);
