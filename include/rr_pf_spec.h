@@ -154,47 +154,6 @@ __device__ inline void rr_pf_weight_fused_rows(const double (&x)[R], const doubl
     for (int l = 0; l < n_obs; ++l) {
       const int ln = l + 1 < n_obs ? l + 1 : l;
       const double dn = obs[3 * ln], lxn = obs[3 * ln + 1], lyn = obs[3 * ln + 2];
-#if defined(__HIP_DEVICE_COMPILE__) && defined(RR_PF_ROWS_STEP_MAJOR)
-      /* the same operations written step by step across the rows (rr_sqrt_core spelled out), the next observation's
-       * loads pinned in front of them */
-      __builtin_amdgcn_sched_barrier(0);
-      double q[R], g[R], h[R], t[R];
-#pragma unroll
-      for (int r = 0; r < R; ++r) t[r] = x[r] - lx;
-#pragma unroll
-      for (int r = 0; r < R; ++r) q[r] = rr_fma(t[r], t[r], RR_PF_Q_FLOOR);
-#pragma unroll
-      for (int r = 0; r < R; ++r) t[r] = y[r] - ly;
-#pragma unroll
-      for (int r = 0; r < R; ++r) q[r] = rr_fma(t[r], t[r], q[r]);
-#pragma unroll
-      for (int r = 0; r < R; ++r) t[r] = __builtin_amdgcn_rsq(q[r]);
-#pragma unroll
-      for (int r = 0; r < R; ++r) g[r] = q[r] * t[r];
-#pragma unroll
-      for (int r = 0; r < R; ++r) h[r] = 0.5 * t[r];
-#pragma unroll
-      for (int r = 0; r < R; ++r) t[r] = __builtin_fma(-h[r], g[r], 0.5);
-#pragma unroll
-      for (int r = 0; r < R; ++r) g[r] = __builtin_fma(g[r], t[r], g[r]);
-#pragma unroll
-      for (int r = 0; r < R; ++r) h[r] = __builtin_fma(h[r], t[r], h[r]);
-#pragma unroll
-      for (int r = 0; r < R; ++r) t[r] = __builtin_fma(-g[r], g[r], q[r]);
-#pragma unroll
-      for (int r = 0; r < R; ++r) g[r] = __builtin_fma(t[r], h[r], g[r]);
-#pragma unroll
-      for (int r = 0; r < R; ++r) t[r] = __builtin_fma(-g[r], g[r], q[r]);
-#pragma unroll
-      for (int r = 0; r < R; ++r) g[r] = __builtin_fma(t[r], h[r], g[r]);
-#pragma unroll
-      for (int r = 0; r < R; ++r) t[r] = d - g[r];
-#pragma unroll
-      for (int r = 0; r < R; ++r) ss[r] = rr_fma(t[r], t[r], ss[r]);
-#if RR_PF_ROWS_STEP_MAJOR > 1
-      __builtin_amdgcn_sched_barrier(0);
-#endif
-#else
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         double dx = x[r] - lx;
@@ -207,7 +166,6 @@ __device__ inline void rr_pf_weight_fused_rows(const double (&x)[R], const doubl
 #endif
         ss[r] = rr_fma(diff, diff, ss[r]);
       }
-#endif
       d = dn;
       lx = lxn;
       ly = lyn;

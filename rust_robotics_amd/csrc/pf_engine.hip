@@ -184,20 +184,21 @@ __global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __r
 // of this rank's inbox (k_resolve_push) -- and every consumed entry is reset to kInPlace.
 constexpr unsigned int kInPlace = 0xffffffffu;
 
-#ifndef RR_K1_WAVES
-#define RR_K1_WAVES 4
-#endif
-#ifndef RR_K1_ROWS
-#define RR_K1_ROWS 1  // weights of the thread's rows in one interleaved pass (rr_pf_weight_fused_rows)
-#endif
-#ifndef RR_K1_ONE_TILE
-#define RR_K1_ONE_TILE 1
-#endif
-#ifndef RR_K1_NOISE_EARLY
-#define RR_K1_NOISE_EARLY 1  // motion noise (independent of the particles) evaluated while the marker / particle loads fly
-#endif
+//
+// Shape of the kernel, each point measured at 1e6 x 32 (A/B on one box, tools/ab_bench.sh):
+//  * ONE 512-slot tile per workgroup, no grid-stride loop.  With the loop every polynomial coefficient of log / sincos /
+//    exp was loop-invariant, the compiler kept them all in registers for the whole kernel (128 VGPRs, 106 SGPRs with
+//    spills into VGPR lanes, 4 waves per SIMD); without it they are materialised where they are used: 52 VGPRs,
+//    8 waves per SIMD, 44.7 -> 37.7 us.
+//  * the likelihood form is a template argument (only one form's code and constants in the kernel);
+//  * the weights of the thread's two rows come from ONE pass over the observation block (rr_pf_weight_fused_rows):
+//    half the LDS reads and two independent chains per wave, -3 us;
+//  * the motion noise (a function of seed, step and slot only) is evaluated before the marker / particle loads are
+//    needed, so the kernel's first microseconds are not spent waiting, -1.3 us;
+//  * the weight maximum goes through rr::atomic_max_u64's look-first form: one same-address atomic per workgroup cost
+//    14.6 us of queueing at L = 1 and 2 us at L = 32.
 template <bool OBS_KERNARG, bool SHARDED, int LIK>
-__global__ __launch_bounds__(kBlock, RR_K1_WAVES) void k_step_lazy(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
+__global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
                                                      StepParams p, ObsArg obs_arg,
                                                      const double* __restrict__ obs_dev,
                                                      unsigned int* __restrict__ markers,
@@ -216,23 +217,17 @@ __global__ __launch_bounds__(kBlock, RR_K1_WAVES) void k_step_lazy(Bufs b, doubl
   const double* __restrict__ syaw = b.yaw[src];
   const uint64_t n_tiles = (p.n + rr::kResolveSlots - 1) / rr::kResolveSlots;
   double wmax_local = 0.0;
-#if RR_K1_ONE_TILE
   const uint64_t tile = blockIdx.x;  // one tile per workgroup: nothing is loop-invariant, so no constant outlives its use
   if (tile < n_tiles) {
-#else
-  for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-#endif
     unsigned int idx[rr::kResolveRows];
     const uint64_t tile_base = tile * rr::kResolveSlots;
     double na[rr::kResolveRows], nc[rr::kResolveRows];
-#if RR_K1_NOISE_EARLY
     // The noise of a slot depends on (seed, step, slot) only: evaluate it first, so that this FP64 work runs while
     // the first dependent loads of the tile (control word, markers) are in flight and the workgroups of a CU, which
     // all start together, do not all sit in their load prologue at the same time.
 #pragma unroll
     for (int r = 0; r < rr::kResolveRows; ++r)
       rr_pf_motion_noise(p.seed, p.step, p.first_gid + tile_base + (uint64_t)r * kBlock + tid, p.sigma_v, p.sigma_w, &na[r], &nc[r]);
-#endif
     if (pending && SHARDED) {
 #pragma unroll
       for (int r = 0; r < rr::kResolveRows; ++r) {
@@ -269,9 +264,6 @@ __global__ __launch_bounds__(kBlock, RR_K1_WAVES) void k_step_lazy(Bufs b, doubl
       const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
       if (k < p.n) {
         double v;
-#if !RR_K1_NOISE_EARLY
-        rr_pf_motion_noise(p.seed, p.step, p.first_gid + k, p.sigma_v, p.sigma_w, &na[r], &nc[r]);
-#endif
         rr_pf_propagate_one(&x[r], &y[r], &yaw[r], &v, p.u0, p.u1, p.dt, na[r], nc[r]);
         b.x[dst][k] = x[r];
         b.y[dst][k] = y[r];
@@ -289,14 +281,9 @@ __global__ __launch_bounds__(kBlock, RR_K1_WAVES) void k_step_lazy(Bufs b, doubl
 #pragma unroll
       for (int r = 0; r < rr::kResolveRows; ++r) wgt[r] = rr_pf_weight_product(x[r], y[r], s_obs, p.n_obs, p.lik);
     } else {
-#if RR_K1_ROWS
       // one pass over the observation block for the thread's rows, independent chains per row (a row past the end
       // of the set weighs a dummy particle at the origin and stores nothing)
       rr_pf_weight_fused_rows<rr::kResolveRows>(x, y, s_obs, p.n_obs, p.lik, wgt);
-#else
-#pragma unroll
-      for (int r = 0; r < rr::kResolveRows; ++r) wgt[r] = rr_pf_weight_fused(x[r], y[r], s_obs, p.n_obs, p.lik);
-#endif
     }
 #pragma unroll
     for (int r = 0; r < rr::kResolveRows; ++r) {
@@ -944,7 +931,7 @@ struct rr_pf {
   unsigned int* carry = nullptr;    // one per kResolveSlots slots
   double* partials = nullptr;
   double* est_partials = nullptr;      // [kFusedMaxTiles][4] per-workgroup sums of the fused per-step estimate
-  unsigned int* est_ticket = nullptr;  // arrival counter of its last-workgroup reduction (zero between launches)
+  unsigned int* est_ticket = nullptr;  // arrival counters of its last-workgroup reduction (rr::last_arrival; zero between launches)
   double* scratch_a = nullptr;  // n doubles: explicit noise v / uniforms / AoS staging (5n)
   double* scratch_b = nullptr;  // n doubles: explicit noise w
   double* obs_dev = nullptr;
@@ -1532,8 +1519,8 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
   }
   RR_TRY_OR_CLEAN(hipMalloc(&h->partials, (size_t)kMomentBlocks * kNumMoments * sizeof(double)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->est_partials, (size_t)rr::kFusedMaxTiles * 4 * sizeof(double)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->est_ticket, sizeof(unsigned int)));
-  RR_TRY_OR_CLEAN(hipMemsetAsync(h->est_ticket, 0, sizeof(unsigned int), h->stream));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->est_ticket, rr::kTicketWords * sizeof(unsigned int)));
+  RR_TRY_OR_CLEAN(hipMemsetAsync(h->est_ticket, 0, rr::kTicketWords * sizeof(unsigned int), h->stream));
   RR_TRY_OR_CLEAN(hipMalloc(&h->ctl, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipHostMalloc(&h->ctl_host, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipMemsetAsync(h->ctl, 0, sizeof(Ctl), h->stream));
@@ -1839,7 +1826,7 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
   h->wmax_bits_clean = false;
   h->wmax_live = true;
   const uint64_t n_rtiles = (h->n + rr::kResolveSlots - 1) / rr::kResolveSlots;
-  const unsigned grid = RR_K1_ONE_TILE ? (unsigned)n_rtiles : (unsigned)std::min<uint64_t>(n_rtiles, (uint64_t)256 * h->k1_blocks_per_cu);
+  const unsigned grid = (unsigned)n_rtiles;  // one tile per workgroup
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
     if (multinomial) {  // sources of the previous (multinomial) resample are in lidx
@@ -2330,7 +2317,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   uint64_t* local3 = h->p2p.local3();
   // A: propagate + weight through lidx
   const uint64_t n_rtiles = (h->n + rr::kResolveSlots - 1) / rr::kResolveSlots;
-  const unsigned grid = RR_K1_ONE_TILE ? (unsigned)n_rtiles : (unsigned)std::min<uint64_t>(n_rtiles, (uint64_t)256 * h->k1_blocks_per_cu);
+  const unsigned grid = (unsigned)n_rtiles;  // one tile per workgroup
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
     hipEvent_t ea = nullptr, eb = nullptr;

@@ -492,10 +492,29 @@ __device__ inline void mark_sources(const TileScan& t, uint64_t off, uint64_t i0
 // sums go to `partials`; the last workgroup to arrive (ticket) adds them in workgroup order -- a
 // fixed order, so the result is reproducible -- and publishes Ctl.est.  Lazy-gather plans only
 // (Ctl.cur is not touched by this kernel then).
+// "Am I the last workgroup of this launch to get here?"  One counter for everybody means one same-address atomic per
+// workgroup, and those are carried out one after the other at the memory side (7.5 ns each, rr::atomic_max_u64): two
+// levels instead -- kTicketGroups counters on separate cache lines, the last arrival of each group then takes a ticket
+// of the final counter.  Call from ONE thread after the workgroup's results are stored; the caller provides the
+// release before and the acquire after (as for a single counter).  The overall last arrival zeroes the counters.
+constexpr int kTicketGroups = 8;
+constexpr int kTicketStride = 32;  // words between counters: 128 B
+constexpr int kTicketWords = (kTicketGroups + 1) * kTicketStride;
+__device__ inline bool last_arrival(unsigned int* ticket, unsigned int block, unsigned int n_blocks) {
+  const unsigned int g = block % kTicketGroups;
+  const unsigned int in_group = (n_blocks - g + kTicketGroups - 1) / kTicketGroups;  // blocks b < n_blocks with b % G == g
+  if (atomicAdd(&ticket[g * kTicketStride], 1u) != in_group - 1) return false;
+  const unsigned int groups = n_blocks < (unsigned int)kTicketGroups ? n_blocks : (unsigned int)kTicketGroups;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // the group's stores before the final ticket
+  if (atomicAdd(&ticket[kTicketGroups * kTicketStride], 1u) != groups - 1) return false;
+  for (int k = 0; k <= kTicketGroups; ++k) ticket[k * kTicketStride] = 0;
+  return true;
+}
+
 struct EstArgs {
   const double* field[2][4];  // x, y, yaw, v of both buffer sets
   double* partials;           // [n_tiles][4]
-  unsigned int* ticket;       // zero between launches
+  unsigned int* ticket;       // kTicketWords counters (last_arrival), zero between launches
   int want;
 };
 
@@ -537,8 +556,7 @@ __device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, c
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned int ticket = atomicAdd(ea.ticket, 1u);
-    s_last = ticket == gridDim.x - 1;
+    s_last = last_arrival(ea.ticket, blockIdx.x, gridDim.x);
   }
   __syncthreads();
   if (!s_last) return;
@@ -551,10 +569,7 @@ __device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, c
     v = wave_sum(v);
     if (lane == 0) ctl->est[wv] = v / denom;
   }
-  if (tid == 0) {
-    ctl->est_step = (uint64_t)rstep + 1;
-    *ea.ticket = 0;
-  }
+  if (tid == 0) ctl->est_step = (uint64_t)rstep + 1;
 }
 
 // fused plan + mark (single shard, systematic, n_tiles <= kFusedMaxTiles)

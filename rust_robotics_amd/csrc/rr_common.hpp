@@ -146,7 +146,14 @@ struct u128 {
   uint64_t hi, lo;
 };
 
-__device__ inline void atomic_max_u64(uint64_t* p, uint64_t v) { atomicMax((ull*)p, (ull)v); }
+// Running maximum of a value that only grows within a kernel.  Device-scope atomics on ONE address are carried out one
+// after the other at the memory side -- measured 7.5 ns each: the 1954 workgroups of k_step_lazy at 1e6 particles spent
+// 14.6 us queueing there -- so look first: a coherent load (never newer than the truth, and the truth only grows) lets
+// every caller that cannot raise the maximum skip its atomic.
+__device__ inline void atomic_max_u64(uint64_t* p, uint64_t v) {
+  const uint64_t seen = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (v > seen) atomicMax((ull*)p, (ull)v);
+}
 
 __host__ __device__ inline u128 add128(u128 a, u128 b) {
   u128 r;
