@@ -931,6 +931,12 @@ struct rr_pf {
   unsigned int* carry = nullptr;    // one per kResolveSlots slots
   double* partials = nullptr;
   double* est_partials = nullptr;      // [kFusedMaxTiles][4] per-workgroup sums of the fused per-step estimate
+  // k_quantize_plan_mark (K2 + fused plan in one launch): one record per tile, the launch epoch, the largest grid whose
+  // workgroups are all resident at once (0: not available), RR_PF_FUSED_PLAN=0 turns it off
+  uint64_t* grid_rec = nullptr;
+  unsigned int* grid_ticket = nullptr;
+  uint64_t grid_epoch = 0;
+  uint64_t grid_capacity = 0;
   unsigned int* est_ticket = nullptr;  // arrival counters of its last-workgroup reduction (rr::last_arrival; zero between launches)
   double* scratch_a = nullptr;  // n doubles: explicit noise v / uniforms / AoS staging (5n)
   double* scratch_b = nullptr;  // n doubles: explicit noise w
@@ -1178,7 +1184,9 @@ rr_status launch_sums(rr_pf* h, int mode, int scheme, double rho_override) {
 // plan decides on the device whether it has anything to do.  mode 0 = gate, 1 = forced.
 rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, const double* r_explicit_dev,
                           bool lazy = false, int settle = 0, bool want_estimate = false) {
-  launch_quantize(h, wmax_source(h), settle);
+  // K2 + fused plan in one launch when every tile's workgroup is resident at once (k_quantize_plan_mark)
+  const bool one_launch = scheme == RR_RESAMPLE_SYSTEMATIC && h->n_tiles <= h->grid_capacity && h->n == h->n_global;
+  if (!one_launch) launch_quantize(h, wmax_source(h), settle);
   PlanArgs pa = plan_args(h, mode, scheme, rho_override);
   const bool lazy_mn = lazy && scheme == RR_RESAMPLE_MULTINOMIAL && h->lidx && !r_explicit_dev;
   lazy = (lazy && scheme == RR_RESAMPLE_SYSTEMATIC) || lazy_mn;
@@ -1206,8 +1214,13 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
         ea.ticket = h->est_ticket;
         ea.want = 1;
       }
-      hipLaunchKernelGGL(rr::k_plan_mark, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total,
-                         h->tile_q2, h->n_tiles, pa, h->markers, h->carry, ea);
+      if (one_launch)
+        hipLaunchKernelGGL(rr::k_quantize_plan_mark, grid, block, 0, h->stream, (const double*)h->w, h->ctl, wmax_source(h),
+                           image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, settle, h->n_tiles, pa, h->markers,
+                           h->carry, ea);
+      else
+        hipLaunchKernelGGL(rr::k_plan_mark, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total,
+                           h->tile_q2, h->n_tiles, pa, h->markers, h->carry, ea);
     }
     else if (sys)
       hipLaunchKernelGGL(rr::k_mark, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total, h->markers,
@@ -1319,6 +1332,9 @@ rr_status resample_adaptive(rr_pf* h, const double* r_explicit_dev) {
 rr_status fetch_ctl(rr_pf* h) {
   RR_HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->ctl_host->grid_timeout)  // latched: the filter state after it is not to be trusted
+    return fail(RR_RUNTIME_ERROR, "a workgroup of the one-launch resample plan timed out waiting for another one's tile sums "
+                                  "(the device did not run them concurrently); set RR_PF_FUSED_PLAN=0");
   return h->p2p.check(h->stream);  // a latched peer-wait timeout must not look like a healthy filter
 }
 
@@ -1519,6 +1535,20 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
   }
   RR_TRY_OR_CLEAN(hipMalloc(&h->partials, (size_t)kMomentBlocks * kNumMoments * sizeof(double)));
   RR_TRY_OR_CLEAN(hipMalloc(&h->est_partials, (size_t)rr::kFusedMaxTiles * 4 * sizeof(double)));
+  {
+    int per_cu = 0, dev_cus = 0;
+    RR_TRY_OR_CLEAN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rr::k_quantize_plan_mark, rr::kTileBlock, 0));
+    RR_TRY_OR_CLEAN(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
+    h->grid_capacity = std::min<uint64_t>((uint64_t)per_cu * (uint64_t)dev_cus, (uint64_t)rr::kTileBlock);
+    if (const char* e = std::getenv("RR_PF_FUSED_PLAN")) {
+      if (std::atoi(e) == 0) h->grid_capacity = 0;
+    }
+    const size_t rec_bytes = (size_t)(rr::kTileBlock + 1) * rr::kRecWords * sizeof(uint64_t);
+    RR_TRY_OR_CLEAN(hipMalloc(&h->grid_rec, rec_bytes));
+    RR_TRY_OR_CLEAN(hipMemsetAsync(h->grid_rec, 0, rec_bytes, h->stream));
+    RR_TRY_OR_CLEAN(hipMalloc(&h->grid_ticket, rr::kTicketWords * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(hipMemsetAsync(h->grid_ticket, 0, rr::kTicketWords * sizeof(unsigned int), h->stream));
+  }
   RR_TRY_OR_CLEAN(hipMalloc(&h->est_ticket, rr::kTicketWords * sizeof(unsigned int)));
   RR_TRY_OR_CLEAN(hipMemsetAsync(h->est_ticket, 0, rr::kTicketWords * sizeof(unsigned int), h->stream));
   RR_TRY_OR_CLEAN(hipMalloc(&h->ctl, sizeof(Ctl)));
@@ -1700,6 +1730,8 @@ void rr_pf_destroy(rr_pf* h) {
   (void)hipFree(h->est_partials);
   (void)hipFree(h->mn_tile_cnt);
   (void)hipFree(h->est_ticket);
+  (void)hipFree(h->grid_rec);
+  (void)hipFree(h->grid_ticket);
   (void)hipFree(h->scratch_a);
   (void)hipFree(h->scratch_b);
   (void)hipFree(h->obs_dev);

@@ -54,7 +54,7 @@ struct Ctl {
   int shift;            // fixed-point shift of the current integer image
   int fired;            // last gate decision
   int pending;          // 1 => a fired resample is still only markers: particles not moved yet (lazy gather)
-  int pad_;
+  int grid_timeout;     // set when a workgroup of k_quantize_plan_mark gave up waiting for another one's tile sums
   uint64_t wmax_bits;   // atomic max of the raw weights (bit pattern of a double >= 0)
   uint64_t total;       // T over all shards
   uint64_t total_local;
@@ -500,12 +500,12 @@ __device__ inline void mark_sources(const TileScan& t, uint64_t off, uint64_t i0
 constexpr int kTicketGroups = 8;
 constexpr int kTicketStride = 32;  // words between counters: 128 B
 constexpr int kTicketWords = (kTicketGroups + 1) * kTicketStride;
-__device__ inline bool last_arrival(unsigned int* ticket, unsigned int block, unsigned int n_blocks) {
+__device__ inline bool last_arrival(unsigned int* ticket, unsigned int block, unsigned int n_blocks, bool fence = true) {
   const unsigned int g = block % kTicketGroups;
   const unsigned int in_group = (n_blocks - g + kTicketGroups - 1) / kTicketGroups;  // blocks b < n_blocks with b % G == g
   if (atomicAdd(&ticket[g * kTicketStride], 1u) != in_group - 1) return false;
   const unsigned int groups = n_blocks < (unsigned int)kTicketGroups ? n_blocks : (unsigned int)kTicketGroups;
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // the group's stores before the final ticket
+  if (fence) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");  // the group's stores before the final ticket
   if (atomicAdd(&ticket[kTicketGroups * kTicketStride], 1u) != groups - 1) return false;
   for (int k = 0; k <= kTicketGroups; ++k) ticket[k * kTicketStride] = 0;
   return true;
@@ -519,12 +519,11 @@ struct EstArgs {
 };
 
 __device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, const TileScan& t, const unsigned int* offspring,
-                                     int fire, uint64_t i0, uint64_t n, double denom, unsigned int rstep) {
+                                     int fire, uint64_t i0, uint64_t n, double denom, unsigned int rstep, int cur) {
   __shared__ double s_acc[kTileBlock / kWave][4];
   __shared__ double s_c[kTileBlock * (kItems + 1)];  // coefficient of the tile's particle i at [i + i / kItems] (padded rows)
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int cur = ctl->cur;
   // the coefficients are known per thread for its 8 CONSECUTIVE sources; the particle fields are read row-wise
   // (256 consecutive particles per instruction, coalesced), so the coefficients change hands through LDS
 #pragma unroll
@@ -599,7 +598,172 @@ static __global__ __launch_bounds__(kTileBlock) void k_plan_mark(const double* _
     const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
     mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry, ea.want ? offspring : nullptr);
   }
-  if (ea.want) plan_estimate(ea, ctl, t, offspring, fire, i0, a.n, fire ? (double)pa.n_global : (double)ts.tot, pa.rstep);
+  if (ea.want) plan_estimate(ea, ctl, t, offspring, fire, i0, a.n, fire ? (double)pa.n_global : (double)ts.tot, pa.rstep, ctl->cur);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2 and the fused plan in ONE launch (single shard, systematic, n_tiles <= kTileBlock and every workgroup resident at
+// once -- the host checks the occupancy).  A kernel boundary costs ~6 us here (drain, the ~4.5 us floor of any launch,
+// the gap), two thirds of what either kernel needs on its own, and the only thing that crosses it is 24 B per tile.
+// So: each workgroup quantises its tile (the integer weights stay in registers), stores its tile sums in its own
+// record and takes an arrival ticket (two-level, last_arrival); the LAST workgroup to arrive scans the records --
+// exclusive prefix per tile, grand totals -- writes them back and raises the launch's flag; every workgroup polls
+// that one flag with one thread, then reads its prefix and the totals.  All of this traffic uses device-scope
+// (cache-bypassing) loads and stores, so no fence -- no L2 write-back or invalidate -- is needed inside the kernel.
+// Timeline at 1e6 particles (489 workgroups, s_memrealtime stamps, us after the first workgroup starts): records stored
+// 4.4 - 6.4, last ticket 7.1, flag raised 10.7, sums known everywhere 11.7 - 12.0, markers written 13.7 - 15.6 -- every
+// hop through device-scope memory costs ~1.2 us, which is why this is only ~2 us better than two launches and why
+// the same trick is not worth it between k_step_lazy and this kernel.
+// A workgroup that polls for ~1 s sets Ctl.grid_timeout and goes on (wrong results, reported by the host, not a hang).
+// Reads of Ctl that the settle / finalize writes of workgroup 0 could race with happen before the ticket is taken;
+// workgroup 0 writes after it has seen the flag, i.e. after every workgroup has arrived.
+constexpr int kRecWords = 4;  // total, q2_hi, q2_lo, exclusive prefix (written back by the last arrival)
+// rec layout: [n_tiles][kRecWords] records, then kRecWords words {grand total, q2_hi, q2_lo, flag = epoch}
+__device__ inline uint64_t ld_dev(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_dev(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
+    const double* __restrict__ w, Ctl* __restrict__ ctl, const double* __restrict__ wmax_src, ImageArgs a,
+    uint64_t* __restrict__ rec, unsigned int* __restrict__ ticket /* kTicketWords, zero between launches */, uint64_t epoch,
+    int settle, uint64_t n_tiles, PlanArgs pa, unsigned int* __restrict__ markers, unsigned int* __restrict__ carry,
+    EstArgs ea) {
+  constexpr int W = kTileBlock / kWave;
+  __shared__ uint64_t s4[4 * W];
+  __shared__ uint64_t s_w[W];
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // ---- A: the integer image of this tile (quantize_reduce_tile's decisions, tile_scan's blocked layout)
+  const double wmax = *wmax_src;
+  const bool forced_uniform = a.honour_uniform_flag && ctl->weights_uniform;
+  const bool usable = !forced_uniform && wmax > 0.0 && wmax < INFINITY;
+  const int mode = usable ? (int)kImageWeights : (forced_uniform ? (int)kImageUniform : a.degenerate);
+  const int shift = usable ? rr_fix_shift(wmax, a.n_global) : 0;
+  const int cur_after = (settle && ctl->pending) ? ctl->cur ^ 1 : ctl->cur;  // what workgroup 0 will settle Ctl.cur to
+  TileScan t;
+  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)tid * kItems;
+  uint64_t run = 0;
+  u128 q2 = {0, 0};
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    t.q[j] = quantize_at(w, i0 + j, a.n, mode, shift, a.gid0, a.n_global);
+    run += t.q[j];
+    t.c[j] = run;
+    u128 sq;
+    rr_mul64wide(t.q[j], t.q[j], &sq.hi, &sq.lo);
+    q2 = add128(q2, sq);
+  }
+  const uint64_t incl = wave_scan_u64(run, lane);
+  q2 = wave_sum_u128(q2);
+  if (lane == 63) s_w[wv] = incl;
+  if (lane == 0) {
+    s4[wv] = q2.hi;
+    s4[W + wv] = q2.lo;
+  }
+  __syncthreads();
+  uint64_t off = incl - run;
+  for (int k = 0; k < wv; ++k) off += s_w[k];
+  t.thread_off = off;
+  uint64_t* const head = rec + n_tiles * kRecWords;
+  if (tid == 0) {
+    uint64_t tt = 0;
+    u128 qq = {0, 0};
+    for (int k = 0; k < W; ++k) {
+      tt += s_w[k];
+      qq = add128(qq, u128{s4[k], s4[W + k]});
+    }
+    uint64_t* r = rec + (uint64_t)blockIdx.x * kRecWords;
+    st_dev(&r[0], tt);
+    st_dev(&r[1], qq.hi);
+    st_dev(&r[2], qq.lo);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged at device scope before the ticket says so
+    s_last = last_arrival(ticket, blockIdx.x, (unsigned int)n_tiles, /*fence=*/false) ? 1 : 0;
+  }
+  __syncthreads();
+  // ---- the last arrival: exclusive prefix per tile and the grand totals, then the flag
+  if (s_last) {
+    uint64_t tk = 0;
+    u128 qk = {0, 0};
+    if ((uint64_t)tid < n_tiles) {
+      const uint64_t* r = rec + (uint64_t)tid * kRecWords;
+      tk = ld_dev(&r[0]);
+      qk.hi = ld_dev(&r[1]);
+      qk.lo = ld_dev(&r[2]);
+    }
+    const uint64_t inc = wave_scan_u64(tk, lane);
+    const u128 qw = wave_sum_u128(qk);
+    __syncthreads();  // (s_w / s4 were read above)
+    if (lane == 63) s_w[wv] = inc;
+    if (lane == 0) {
+      s4[wv] = qw.hi;
+      s4[W + wv] = qw.lo;
+    }
+    __syncthreads();
+    uint64_t wave_off = 0;
+    for (int k = 0; k < wv; ++k) wave_off += s_w[k];
+    if ((uint64_t)tid < n_tiles) st_dev(&rec[(uint64_t)tid * kRecWords + 3], wave_off + inc - tk);
+    if (tid == 0) {
+      uint64_t tt = 0;
+      u128 qq = {0, 0};
+      for (int k = 0; k < W; ++k) {
+        tt += s_w[k];
+        qq = add128(qq, u128{s4[k], s4[W + k]});
+      }
+      st_dev(&head[0], tt);
+      st_dev(&head[1], qq.hi);
+      st_dev(&head[2], qq.lo);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();  // every prefix is acknowledged
+    if (tid == 0) st_dev(&head[3], epoch);
+  }
+  // ---- everybody: one thread polls the flag, then the workgroup's prefix and the totals
+  if (tid == 0) {
+    long spins = 0;
+    while (ld_dev(&head[3]) != epoch) {
+      if (++spins > (1l << 22)) {
+        ctl->grid_timeout = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+    s4[0] = ld_dev(&rec[(uint64_t)blockIdx.x * kRecWords + 3]);
+    s4[1] = ld_dev(&head[0]);
+    s4[2] = ld_dev(&head[1]);
+    s4[3] = ld_dev(&head[2]);
+  }
+  __syncthreads();
+  TileSums ts;
+  ts.pre = s4[0];
+  ts.tot = s4[1];
+  ts.q2 = u128{s4[2], s4[3]};
+  // ---- workgroup 0: what k_quantize_reduce's and k_plan_mark's first threads leave in Ctl
+  if (blockIdx.x == 0 && tid == 0) {
+    if (settle && ctl->pending) {
+      ctl->cur ^= 1;
+      ctl->pending = 0;
+    }
+    ctl->usable = usable ? 1 : 0;
+    ctl->image_mode = mode;
+    ctl->shift = shift;
+    ctl->wmax = wmax;
+    finalize_plan(ctl, ts.tot, 0, ts.tot, ts.q2, pa);
+  }
+  // ---- B: plan_mark_tile from here on
+  const int fire = gate_decision(mode, ts, pa);
+  double rho = pa.rho_override;
+  if (rho != rho) {
+    double dummy;
+    rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
+  }
+  if (!fire && !ea.want) return;
+  unsigned int offspring[kItems];
+  if (fire) {
+    const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
+    mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry, ea.want ? offspring : nullptr);
+  }
+  if (ea.want)
+    plan_estimate(ea, ctl, t, offspring, fire, i0, a.n, fire ? (double)pa.n_global : (double)ts.tot, pa.rstep, cur_after);
 }
 
 // sharded: the plan is already in Ctl (k_shard_plan); mark this shard's sources.  tile_offset =
@@ -634,11 +798,7 @@ __device__ inline void resolve_tile(unsigned int* __restrict__ markers, const un
       m = markers[k];
       if (m) markers[k] = 0;
     }
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-      const unsigned int t = __shfl_up(m, o, kWave);
-      if (lane >= o && t > m) m = t;
-    }
+    m = wave_scan_max_u32(m);
     if (lane == 63) s_m[wv] = m;
     __syncthreads();
     unsigned int pre = run;

@@ -105,13 +105,51 @@ struct ScopedTimer {
 // ---- wave64 primitives (gfx950: a wavefront is 64 lanes) ------------------------------
 constexpr int kWave = 64;
 
-__device__ inline double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    double t = __shfl_xor(v, o, kWave);
-    v = t > v ? t : v;
-  }
+// Exact, order-independent reductions (integer sums, maxima) run on DPP -- lane data moved inside the VALU, ~10 cycles a
+// step -- instead of __shfl (ds_bpermute_b32 through the LDS crossbar, ~100+ cycles a step, and the steps depend on each
+// other): row_shr 1 / 2 / 4 / 8 give an inclusive scan inside each row of 16 lanes, row_bcast:15 (rows 1, 3) and
+// row_bcast:31 (rows 2, 3) carry it across the rows.  Lane 63 ends up with the reduction of the whole wave.
+// (Floating-point SUMS keep their fixed __shfl_xor butterfly: their value depends on the order.)
+template <int CTRL, int ROW_MASK>
+__device__ inline unsigned int dpp_u32(unsigned int v) {  // lanes without a source lane (or outside ROW_MASK) read 0
+  return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ inline uint64_t dpp_u64(uint64_t v) {
+  return ((uint64_t)dpp_u32<CTRL, ROW_MASK>((unsigned int)(v >> 32)) << 32) | dpp_u32<CTRL, ROW_MASK>((unsigned int)v);
+}
+__device__ inline unsigned int umax(unsigned int a, unsigned int b) { return a > b ? a : b; }
+__device__ inline uint64_t umax(uint64_t a, uint64_t b) { return a > b ? a : b; }
+#define RR_DPP_SCAN(V, STEP)                  \
+  do {                                        \
+    V = STEP(V, 0x111, 0xf); /* row_shr:1 */  \
+    V = STEP(V, 0x112, 0xf); /* row_shr:2 */  \
+    V = STEP(V, 0x114, 0xf); /* row_shr:4 */  \
+    V = STEP(V, 0x118, 0xf); /* row_shr:8 */  \
+    V = STEP(V, 0x142, 0xa); /* row_bcast:15 */ \
+    V = STEP(V, 0x143, 0xc); /* row_bcast:31 */ \
+  } while (0)
+
+__device__ inline uint64_t last_lane_u64(uint64_t v) {
+  return ((uint64_t)(unsigned int)__builtin_amdgcn_readlane((int)(v >> 32), 63) << 32) |
+         (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, 63);
+}
+
+// inclusive running maximum across the 64 lanes (0 is the identity: unsigned values)
+__device__ inline unsigned int wave_scan_max_u32(unsigned int v) {
+#define RR_STEP_MAX32(V, C, M) umax(V, dpp_u32<C, M>(V))
+  RR_DPP_SCAN(v, RR_STEP_MAX32);
+#undef RR_STEP_MAX32
   return v;
+}
+
+// maximum of non-negative doubles (NaN / negative lanes must have been replaced by 0): the bit patterns order like the values
+__device__ inline double wave_max(double v) {
+  uint64_t u = (uint64_t)__double_as_longlong(v);
+#define RR_STEP_MAX64(V, C, M) umax(V, dpp_u64<C, M>(V))
+  RR_DPP_SCAN(u, RR_STEP_MAX64);
+#undef RR_STEP_MAX64
+  return __longlong_as_double((long long)last_lane_u64(u));
 }
 
 __device__ inline double wave_sum(double v) {
@@ -126,21 +164,15 @@ __device__ inline uint64_t shfl_xor_u64(uint64_t v, int o) { return (uint64_t)__
 __device__ inline uint64_t shfl_up_u64(uint64_t v, int o) { return (uint64_t)__shfl_up((ull)v, o, kWave); }
 __device__ inline uint64_t shfl_u64(uint64_t v, int src) { return (uint64_t)__shfl((ull)v, src, kWave); }
 
-__device__ inline uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += shfl_xor_u64(v, o);
+// inclusive prefix sum across the 64 lanes
+__device__ inline uint64_t wave_scan_u64(uint64_t v, int /*lane*/) {
+#define RR_STEP_ADD64(V, C, M) (V + dpp_u64<C, M>(V))
+  RR_DPP_SCAN(v, RR_STEP_ADD64);
+#undef RR_STEP_ADD64
   return v;
 }
 
-// inclusive prefix sum across the 64 lanes
-__device__ inline uint64_t wave_scan_u64(uint64_t v, int lane) {
-#pragma unroll
-  for (int o = 1; o < kWave; o <<= 1) {
-    uint64_t t = shfl_up_u64(v, o);
-    if (lane >= o) v += t;
-  }
-  return v;
-}
+__device__ inline uint64_t wave_sum_u64(uint64_t v) { return last_lane_u64(wave_scan_u64(v, 0)); }
 
 struct u128 {
   uint64_t hi, lo;
@@ -163,14 +195,10 @@ __host__ __device__ inline u128 add128(u128 a, u128 b) {
 }
 
 __device__ inline u128 wave_sum_u128(u128 v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    u128 t;
-    t.hi = shfl_xor_u64(v.hi, o);
-    t.lo = shfl_xor_u64(v.lo, o);
-    v = add128(v, t);
-  }
-  return v;
+#define RR_STEP_ADD128(V, C, M) add128(V, u128{dpp_u64<C, M>(V.hi), dpp_u64<C, M>(V.lo)})
+  RR_DPP_SCAN(v, RR_STEP_ADD128);
+#undef RR_STEP_ADD128
+  return u128{last_lane_u64(v.hi), last_lane_u64(v.lo)};
 }
 
 }  // namespace rr
