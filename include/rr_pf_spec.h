@@ -141,19 +141,19 @@ RR_HD double rr_pf_weight_fused(double x, double y, const double* obs, int n_obs
 #if defined(__cplusplus) && defined(__HIPCC__)
 /* rr_pf_weight_fused for R particles of one thread at once -- per particle the very same operations in the same
  * order (so the same bits); what changes is the instruction stream: each observation is read once for all R
- * particles and fetched one iteration ahead, and the R dependency chains (~16 FP64 instructions per pair, every
- * one waiting for its predecessor) are independent of each other, so a wave always has an instruction ready. */
+ * particles (four observations per LDS address computation), and the R dependency chains (~16 FP64 instructions per
+ * pair, every one waiting for its predecessor) are independent of each other, so a wave always has an instruction
+ * ready. */
 template <int R>
 __device__ inline void rr_pf_weight_fused_rows(const double (&x)[R], const double (&y)[R], const double* obs, int n_obs,
                                                rr_pf_lik k, double (&out)[R]) {
   double ss[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) ss[r] = 0.0;
-  if (n_obs > 0) {
-    double d = obs[0], lx = obs[1], ly = obs[2];
+  {
+#pragma unroll 4
     for (int l = 0; l < n_obs; ++l) {
-      const int ln = l + 1 < n_obs ? l + 1 : l;
-      const double dn = obs[3 * ln], lxn = obs[3 * ln + 1], lyn = obs[3 * ln + 2];
+      const double d = obs[3 * l], lx = obs[3 * l + 1], ly = obs[3 * l + 2];
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         double dx = x[r] - lx;
@@ -166,9 +166,6 @@ __device__ inline void rr_pf_weight_fused_rows(const double (&x)[R], const doubl
 #endif
         ss[r] = rr_fma(diff, diff, ss[r]);
       }
-      d = dn;
-      lx = lxn;
-      ly = lyn;
     }
   }
 #pragma unroll

@@ -1850,8 +1850,8 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
     return launch_resample(h, 0, h->opt.resample_scheme, NAN, nullptr);
   }
   if (h->maybe_pending && h->pending_lidx != multinomial && (s = materialise(h)) != RR_OK) return s;
-  // systematic: 3 launches per step -- k_step_lazy (propagate + weight, reading through the
-  // previous resample's indices), k_quantize_reduce, k_plan_mark
+  // systematic: 2 launches per step -- k_step_lazy (propagate + weight, reading through the previous resample's
+  // indices) and k_quantize_plan_mark (3 beyond 2^20 particles: k_quantize_reduce, k_plan_mark)
   const size_t lds = 3 * n_obs * sizeof(double);
   if (lds > 150 * 1024) return fail(RR_INVALID_PARAMETER, "too many observations for one LDS block (max 6400)");
   if (!h->wmax_bits_clean) RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));

@@ -393,6 +393,46 @@ def test_in_step_estimate_matches_the_accessor_and_the_reference(loc, ref, mcl):
     np.testing.assert_allclose(est2, pf.estimate(), rtol=1e-11, atol=1e-11)
 
 
+@pytest.mark.parametrize("mcl", [False, True])
+def test_one_launch_plan_equals_the_two_kernel_plan(loc, mcl, monkeypatch):
+    """k_quantize_plan_mark (tile sums handed over inside one launch: records, two-level ticket, flag) against
+    k_quantize_reduce + k_plan_mark (RR_PF_FUSED_PLAN=0, read when the filter is created): same particles, weights,
+    gate decisions, resample indices and in-step estimates, bit for bit, over a gated and an every-step trajectory."""
+    n, L, T = 300_000, 8, 12  # 147 tiles: a real exchange between workgroups
+    lms = H.landmarks_grid(L, 5)
+
+    def run(fused):
+        monkeypatch.setenv("RR_PF_FUSED_PLAN", "1" if fused else "0")
+        kw = dict(seed=11, resample_scheme=1, record_indices=True)
+        if mcl:
+            pf = loc.MonteCarloLocalizer(loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.5), **kw)
+        else:
+            pf = loc.ParticleFilterLocalizer(loc.ParticleFilterConfig(n_particles=n, range_noise=0.5, resample_threshold=0.5), **kw)
+        rng = np.random.default_rng(12)
+        out = []
+        for t in range(T):
+            obs = H.observations(lms, H.true_pose(t + 1), 0.5, rng)
+            if t % 2:
+                pf.step_async_estimate([1.0, 0.1], obs)
+                e = pf.last_step_estimate()
+            else:
+                pf.step_async([1.0, 0.1], obs)
+                e = np.zeros(4)
+            fired = pf.last_resample_fired()
+            out.append((fired, pf.last_resample_indices().copy() if fired else None, pf.get_particles_array().copy(), np.array(e)))
+        return out
+
+    a, b = run(True), run(False)
+    assert any(f for f, *_ in a)
+    for t, ((fa, ia, pa, ea), (fb, ib, pb, eb)) in enumerate(zip(a, b)):
+        assert fa == fb, f"gate decision differs at step {t}"
+        if fa:
+            assert np.array_equal(ia, ib), f"resample indices differ at step {t}"
+        for k in range(5):
+            assert_bits_equal(pa[:, k], pb[:, k], f"step {t} col {k}")
+        assert_bits_equal(ea, eb, f"step {t} in-step estimate")
+
+
 # ------------------------------------------------------------------ API surface / error behaviour
 def test_reference_unit_tests_reexpressed(loc):
     """particle_filter.rs:575-707 against the engine"""
