@@ -149,6 +149,184 @@ static __global__ __launch_bounds__(kScanThreads) void k_scan_exchange(P2PPeers 
   p2p_exchange(peers, kP2PSums, seq, s_pay[0], s_pay[1], s_pay[2], gathered, ctl, &ctl->wmax, pa, err);
 }
 
+// ------------------------------------------------------------------------------------------
+// The plan of a sharded systematic step in ONE launch: WMAX exchange, integer image, SUMS exchange and the marking of
+// this shard's sources -- k_p2p_exchange + k_quantize_reduce + k_scan_exchange + k_mark, four launches whose ~6 us
+// boundaries (resample_core.hpp, k_quantize_plan_mark) cost more than their work.  Same in-kernel hand-over as
+// k_quantize_plan_mark, with the two exchanges between the GPUs inside it:
+//   workgroup 0 trades the weight maximum with the peers and raises flag 0 (the global maximum);
+//   every workgroup quantises its tile under it, stores its tile sums in its record, takes an arrival ticket;
+//   the last arrival scans the records (prefix per tile, this shard's sums), settles Ctl as k_quantize_reduce would,
+//   trades the sums with the peers (p2p_exchange -> finalize_plan: gate, base, plan) and raises flag 1;
+//   every workgroup reads its prefix, the base and the global totals and marks its sources exactly as k_mark does.
+// rec layout: [n_tiles][kRecWords], then head0 {wmax bits, flag 0}, then head1 {base, T, q2_hi, q2_lo, flag 1}.
+// All workgroups must be resident at once (host: n_tiles <= grid capacity).  A local wait is bounded by twelve peer
+// time-outs (the first exchanges of a filter are allowed ten); giving up sets *err like a peer time-out does.
+constexpr int kShardHeadWords = 8;
+__device__ inline bool wait_flag(const uint64_t* flag, uint64_t epoch, uint64_t limit_ticks) {
+  const uint64_t t0 = wall_clock64();
+  while (ld_dev(flag) != epoch) {
+    __builtin_amdgcn_s_sleep(1);
+    if (wall_clock64() - t0 > limit_ticks) return false;
+  }
+  asm volatile("" ::: "memory");
+  return true;
+}
+
+static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
+    P2PPeers peers, uint64_t seq, const double* __restrict__ w, Ctl* __restrict__ ctl, ImageArgs a, uint64_t* __restrict__ rec,
+    unsigned int* __restrict__ ticket, uint64_t epoch, int settle, uint64_t n_tiles, PlanArgs pa,
+    unsigned int* __restrict__ markers, unsigned int* __restrict__ carry, uint64_t* __restrict__ gathered,
+    int* __restrict__ err) {
+  constexpr int W = kTileBlock / kWave;
+  __shared__ uint64_t s4[4 * W];
+  __shared__ uint64_t s_w[W];
+  __shared__ uint64_t s_pay[3];
+  __shared__ double s_wmax;
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  uint64_t* const head0 = rec + n_tiles * kRecWords;
+  uint64_t* const head1 = head0 + 2;
+  const uint64_t limit = 12 * peers.timeout_ticks;
+  // reads of Ctl that the last arrival's settle / finalize could race with come first (they precede this workgroup's ticket)
+  const bool forced_uniform = a.honour_uniform_flag && ctl->weights_uniform;
+  // ---- 0: the global maximum
+  if (blockIdx.x == 0) {
+    const uint64_t local_bits = ctl->wmax_bits;
+    p2p_exchange(peers, kP2PWmax, seq, local_bits, 0, 0, gathered, ctl, &s_wmax, pa, err);  // thread 0 leaves the maximum in s_wmax
+    if (tid == 0) {
+      st_dev(&head0[0], rr_d2u(s_wmax));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      st_dev(&head0[1], epoch);
+    }
+  }
+  if (tid == 0) {
+    if (!wait_flag(&head0[1], epoch, limit)) *err = 1;
+    s_wmax = rr_u2d(ld_dev(&head0[0]));
+  }
+  __syncthreads();
+  const double wmax = s_wmax;
+  // ---- A: the integer image of this tile (k_quantize_plan_mark, phase A)
+  const bool usable = !forced_uniform && wmax > 0.0 && wmax < INFINITY;
+  const int mode = usable ? (int)kImageWeights : (forced_uniform ? (int)kImageUniform : a.degenerate);
+  const int shift = usable ? rr_fix_shift(wmax, a.n_global) : 0;
+  TileScan t;
+  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)tid * kItems;
+  uint64_t run = 0;
+  u128 q2 = {0, 0};
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    t.q[j] = quantize_at(w, i0 + j, a.n, mode, shift, a.gid0, a.n_global);
+    run += t.q[j];
+    t.c[j] = run;
+    u128 sq;
+    rr_mul64wide(t.q[j], t.q[j], &sq.hi, &sq.lo);
+    q2 = add128(q2, sq);
+  }
+  const uint64_t incl = wave_scan_u64(run, lane);
+  q2 = wave_sum_u128(q2);
+  if (lane == 63) s_w[wv] = incl;
+  if (lane == 0) {
+    s4[wv] = q2.hi;
+    s4[W + wv] = q2.lo;
+  }
+  __syncthreads();
+  uint64_t off = incl - run;
+  for (int k = 0; k < wv; ++k) off += s_w[k];
+  t.thread_off = off;
+  if (tid == 0) {
+    uint64_t tt = 0;
+    u128 qq = {0, 0};
+    for (int k = 0; k < W; ++k) {
+      tt += s_w[k];
+      qq = add128(qq, u128{s4[k], s4[W + k]});
+    }
+    uint64_t* r = rec + (uint64_t)blockIdx.x * kRecWords;
+    st_dev(&r[0], tt);
+    st_dev(&r[1], qq.hi);
+    st_dev(&r[2], qq.lo);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = last_arrival(ticket, blockIdx.x, (unsigned int)n_tiles, /*fence=*/false) ? 1 : 0;
+  }
+  __syncthreads();
+  // ---- the last arrival: prefixes, this shard's sums, Ctl, the exchange with the peers, flag 1
+  if (s_last) {
+    uint64_t tk = 0;
+    u128 qk = {0, 0};
+    if ((uint64_t)tid < n_tiles) {
+      const uint64_t* r = rec + (uint64_t)tid * kRecWords;
+      tk = ld_dev(&r[0]);
+      qk.hi = ld_dev(&r[1]);
+      qk.lo = ld_dev(&r[2]);
+    }
+    const uint64_t inc = wave_scan_u64(tk, lane);
+    const u128 qw = wave_sum_u128(qk);
+    __syncthreads();
+    if (lane == 63) s_w[wv] = inc;
+    if (lane == 0) {
+      s4[wv] = qw.hi;
+      s4[W + wv] = qw.lo;
+    }
+    __syncthreads();
+    uint64_t wave_off = 0;
+    for (int k = 0; k < wv; ++k) wave_off += s_w[k];
+    if ((uint64_t)tid < n_tiles) st_dev(&rec[(uint64_t)tid * kRecWords + 3], wave_off + inc - tk);
+    if (tid == 0) {
+      uint64_t tt = 0;
+      u128 qq = {0, 0};
+      for (int k = 0; k < W; ++k) {
+        tt += s_w[k];
+        qq = add128(qq, u128{s4[k], s4[W + k]});
+      }
+      s_pay[0] = tt;
+      s_pay[1] = qq.hi;
+      s_pay[2] = qq.lo;
+      // what k_quantize_reduce's first thread leaves in Ctl (finalize_plan, inside the exchange, reads it)
+      if (settle && ctl->pending) {
+        ctl->cur ^= 1;
+        ctl->pending = 0;
+      }
+      ctl->usable = usable ? 1 : 0;
+      ctl->image_mode = mode;
+      ctl->shift = shift;
+      ctl->wmax = wmax;
+      ctl->total_local = tt;
+    }
+    __syncthreads();
+    p2p_exchange(peers, kP2PSums, seq, s_pay[0], s_pay[1], s_pay[2], gathered, ctl, &ctl->wmax, pa, err);
+    if (tid == 0) {  // finalize_plan has run in this thread: Ctl holds base, the global totals, the gate decision
+      st_dev(&head1[0], ctl->base);
+      st_dev(&head1[1], ctl->total);
+      st_dev(&head1[2], ctl->q2_hi);
+      st_dev(&head1[3], ctl->q2_lo);
+      st_dev(&head1[4], (uint64_t)ctl->fired);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) st_dev(&head1[5], epoch);
+  }
+  // ---- everybody: flag 1, then the workgroup's prefix, the base and the global totals
+  if (tid == 0) {
+    if (!wait_flag(&head1[5], epoch, limit)) *err = 1;
+    s4[0] = ld_dev(&rec[(uint64_t)blockIdx.x * kRecWords + 3]);
+    s4[1] = ld_dev(&head1[0]);
+    s4[2] = ld_dev(&head1[1]);
+    s4[3] = ld_dev(&head1[4]);
+  }
+  __syncthreads();
+  const uint64_t pre = s4[0], base = s4[1], total = s4[2];
+  if (!s4[3]) return;  // gate shut (or a peer timed out)
+  // ---- B: k_mark
+  double rho = pa.rho_override;
+  if (rho != rho) {
+    double dummy;
+    rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
+  }
+  const rr_sys_plan plan = rr_sys_plan_make(rho, total, pa.n_global);
+  const uint64_t slot_base = rr_sys_slots_upto_exact(plan, total, base);  // == Ctl.served_first
+  mark_sources(t, base + pre + t.thread_off, i0, a.n, plan, total, slot_base, markers, carry);
+}
+
 // ---- host side: what a handle owns for the transport
 struct P2PState {
   P2PMailbox* mbox = nullptr;  // fine-grained: peers write their records here

@@ -937,6 +937,7 @@ struct rr_pf {
   unsigned int* grid_ticket = nullptr;
   uint64_t grid_epoch = 0;
   uint64_t grid_capacity = 0;
+  uint64_t shard_capacity = ~0ull;  // the same for k_shard_plan_mark (sharded step over the peer-to-peer transport); ~0: not asked yet
   unsigned int* est_ticket = nullptr;  // arrival counters of its last-workgroup reduction (rr::last_arrival; zero between launches)
   double* scratch_a = nullptr;  // n doubles: explicit noise v / uniforms / AoS staging (5n)
   double* scratch_b = nullptr;  // n doubles: explicit noise w
@@ -1543,7 +1544,7 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
     if (const char* e = std::getenv("RR_PF_FUSED_PLAN")) {
       if (std::atoi(e) == 0) h->grid_capacity = 0;
     }
-    const size_t rec_bytes = (size_t)(rr::kTileBlock + 1) * rr::kRecWords * sizeof(uint64_t);
+    const size_t rec_bytes = (size_t)(rr::kTileBlock + 1) * rr::kRecWords * sizeof(uint64_t) + rr::kShardHeadWords * sizeof(uint64_t);
     RR_TRY_OR_CLEAN(hipMalloc(&h->grid_rec, rec_bytes));
     RR_TRY_OR_CLEAN(hipMemsetAsync(h->grid_rec, 0, rec_bytes, h->stream));
     RR_TRY_OR_CLEAN(hipMalloc(&h->grid_ticket, rr::kTicketWords * sizeof(unsigned int)));
@@ -2363,22 +2364,36 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   h->step += 1;
   PlanArgs pa = plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN);
   pa.lazy_gather = 1;
-  // exchange 1: global maximum -> Ctl.wmax
-  hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PWmax, seq,
-                     (const uint64_t*)&h->ctl->wmax_bits, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
-  // B: integer image under the global maximum (settles the resample K1 consumed)
-  launch_quantize(h, (const double*)&h->ctl->wmax, /*settle=*/1);
-  // tile scan + exchange 2: every rank's sums -> gate, base, plan in Ctl
-  {
-    Timed t(h, RR_K_SCAN_TILES);
-    hipLaunchKernelGGL(rr::k_scan_exchange, dim3(1), dim3(kScanThreads), 0, h->stream, h->p2p.peers, seq, h->tile_total,
-                       (const uint64_t*)h->tile_q2, h->n_tiles, gathered, h->ctl, pa, h->p2p.err);
+  if (h->shard_capacity == ~0ull) {  // every workgroup of k_shard_plan_mark resident at once?
+    int per_cu = 0, dev_cus = 0;
+    RR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rr::k_shard_plan_mark, rr::kTileBlock, 0));
+    RR_HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
+    h->shard_capacity = h->grid_capacity ? std::min<uint64_t>((uint64_t)per_cu * (uint64_t)dev_cus, (uint64_t)rr::kTileBlock) : 0;
   }
-  // C: mark this shard's sources
-  {
+  if (h->n_tiles <= h->shard_capacity) {
+    // exchange 1 + B + exchange 2 + C in one launch (k_shard_plan_mark)
     Timed t(h, RR_K_CDF);
-    hipLaunchKernelGGL(rr::k_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl,
-                       image_args(h), h->tile_total, h->markers, h->carry);
+    hipLaunchKernelGGL(rr::k_shard_plan_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->p2p.peers, seq,
+                       (const double*)h->w, h->ctl, image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, /*settle=*/1,
+                       h->n_tiles, pa, h->markers, h->carry, gathered, h->p2p.err);
+  } else {
+    // exchange 1: global maximum -> Ctl.wmax
+    hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PWmax, seq,
+                       (const uint64_t*)&h->ctl->wmax_bits, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+    // B: integer image under the global maximum (settles the resample K1 consumed)
+    launch_quantize(h, (const double*)&h->ctl->wmax, /*settle=*/1);
+    // tile scan + exchange 2: every rank's sums -> gate, base, plan in Ctl
+    {
+      Timed t(h, RR_K_SCAN_TILES);
+      hipLaunchKernelGGL(rr::k_scan_exchange, dim3(1), dim3(kScanThreads), 0, h->stream, h->p2p.peers, seq, h->tile_total,
+                         (const uint64_t*)h->tile_q2, h->n_tiles, gathered, h->ctl, pa, h->p2p.err);
+    }
+    // C: mark this shard's sources
+    {
+      Timed t(h, RR_K_CDF);
+      hipLaunchKernelGGL(rr::k_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl,
+                         image_args(h), h->tile_total, h->markers, h->carry);
+    }
   }
   h->wmax_live = false;
   h->wmax_bits_clean = true;
