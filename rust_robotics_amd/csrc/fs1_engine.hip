@@ -672,6 +672,12 @@ struct rr_fs1 {
   uint64_t* tile_total = nullptr;
   uint64_t* tile_q2 = nullptr;
   unsigned int* idx = nullptr;
+  // rr::k_quantize_plan_mark<true> (integer image + plan in one launch, resample_core.hpp): tile records, arrival
+  // counters, launch epoch, the largest grid whose workgroups are all resident (~0: not asked yet; RR_PF_FUSED_PLAN=0: off)
+  uint64_t* grid_rec = nullptr;
+  unsigned int* grid_ticket = nullptr;
+  uint64_t grid_epoch = 0;
+  uint64_t grid_capacity = ~0ull;
   unsigned int* markers = nullptr;  // n + kResolveSlots, zero between resamples (fused single-GPU plan)
   unsigned int* carry = nullptr;    // one per kResolveSlots slots
   unsigned int* ridx = nullptr;  // sharded: sources of the served slots that belong to peers (allocated on connect)
@@ -985,16 +991,39 @@ rr_status launch_plan_fused(rr_fs1* h, int settle) {
     hipLaunchKernelGGL(k_fs1_wmax, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n);
   }
   h->wmax_live = false;
-  h->wmax_bits_clean = true;  // k_fs1_plan's finalize_plan zeroes the accumulator
-  {
-    rr::ScopedTimer t(h->prof, h->stream, RR_FK_QUANTIZE_REDUCE);
-    hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
-                       (const double*)&h->ctl->wmax_bits, image_args(h), h->tile_total, h->tile_q2, settle);
+  h->wmax_bits_clean = true;  // the plan kernel's finalize_plan zeroes the accumulator
+  if (h->grid_capacity == ~0ull) {
+    int per_cu = 0, dev_cus = 0;
+    RR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rr::k_quantize_plan_mark<true>, rr::kTileBlock, 0));
+    RR_HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
+    h->grid_capacity = std::min<uint64_t>((uint64_t)per_cu * (uint64_t)dev_cus, (uint64_t)rr::kTileBlock);
+    if (const char* e = std::getenv("RR_PF_FUSED_PLAN")) {
+      if (std::atoi(e) == 0) h->grid_capacity = 0;
+    }
+    if (h->grid_capacity) {
+      const size_t rec_bytes = (size_t)(rr::kTileBlock + 1) * rr::kRecWords * sizeof(uint64_t);
+      RR_HIP_TRY(hipMalloc(&h->grid_rec, rec_bytes));
+      RR_HIP_TRY(hipMemsetAsync(h->grid_rec, 0, rec_bytes, h->stream));
+      RR_HIP_TRY(hipMalloc(&h->grid_ticket, rr::kTicketWords * sizeof(unsigned int)));
+      RR_HIP_TRY(hipMemsetAsync(h->grid_ticket, 0, rr::kTicketWords * sizeof(unsigned int), h->stream));
+    }
   }
-  {
+  if (h->n_tiles <= h->grid_capacity) {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_CDF);
-    hipLaunchKernelGGL(k_fs1_plan, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl, image_args(h),
-                       h->tile_total, h->tile_q2, h->n_tiles, plan_args(h, 0, NAN, /*lazy=*/true), h->markers, h->carry);
+    hipLaunchKernelGGL(rr::k_quantize_plan_mark<true>, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
+                       (const double*)&h->ctl->wmax_bits, image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, settle,
+                       h->n_tiles, plan_args(h, 0, NAN, /*lazy=*/true), h->markers, h->carry, rr::EstArgs{});
+  } else {
+    {
+      rr::ScopedTimer t(h->prof, h->stream, RR_FK_QUANTIZE_REDUCE);
+      hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
+                         (const double*)&h->ctl->wmax_bits, image_args(h), h->tile_total, h->tile_q2, settle);
+    }
+    {
+      rr::ScopedTimer t(h->prof, h->stream, RR_FK_CDF);
+      hipLaunchKernelGGL(k_fs1_plan, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl, image_args(h),
+                         h->tile_total, h->tile_q2, h->n_tiles, plan_args(h, 0, NAN, /*lazy=*/true), h->markers, h->carry);
+    }
   }
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_INDICES);
@@ -1152,6 +1181,8 @@ void rr_fs1_destroy(rr_fs1* h) {
   (void)hipFree(h->tile_q2);
   (void)hipFree(h->idx);
   (void)hipFree(h->markers);
+  (void)hipFree(h->grid_rec);
+  (void)hipFree(h->grid_ticket);
   (void)hipFree(h->carry);
   (void)hipFree(h->ridx);
   (void)hipFree(h->partial);

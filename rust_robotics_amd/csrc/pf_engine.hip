@@ -1216,7 +1216,7 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
         ea.want = 1;
       }
       if (one_launch)
-        hipLaunchKernelGGL(rr::k_quantize_plan_mark, grid, block, 0, h->stream, (const double*)h->w, h->ctl, wmax_source(h),
+        hipLaunchKernelGGL(rr::k_quantize_plan_mark<false>, grid, block, 0, h->stream, (const double*)h->w, h->ctl, wmax_source(h),
                            image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, settle, h->n_tiles, pa, h->markers,
                            h->carry, ea);
       else
@@ -1538,7 +1538,7 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
   RR_TRY_OR_CLEAN(hipMalloc(&h->est_partials, (size_t)rr::kFusedMaxTiles * 4 * sizeof(double)));
   {
     int per_cu = 0, dev_cus = 0;
-    RR_TRY_OR_CLEAN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rr::k_quantize_plan_mark, rr::kTileBlock, 0));
+    RR_TRY_OR_CLEAN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rr::k_quantize_plan_mark<false>, rr::kTileBlock, 0));
     RR_TRY_OR_CLEAN(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
     h->grid_capacity = std::min<uint64_t>((uint64_t)per_cu * (uint64_t)dev_cus, (uint64_t)rr::kTileBlock);
     if (const char* e = std::getenv("RR_PF_FUSED_PLAN")) {

@@ -8,6 +8,7 @@
 //   cumulative weights       particle_filter.rs:448-453, fastslam1.rs:213-216
 // as the integer image of include/rr_pf_spec.h ("fixed-point CDF").
 #pragma once
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -622,8 +623,12 @@ constexpr int kRecWords = 4;  // total, q2_hi, q2_lo, exclusive prefix (written 
 __device__ inline uint64_t ld_dev(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_dev(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// FS_WEIGHTS (FastSLAM, k_fs1_plan's weight handling): the weights are explicit -- w /= sum when the gate stays shut
+// (fastslam1.rs:196-203), w = 1/n when it fires (:228) -- and are rewritten by the threads that read them.
+template <bool FS_WEIGHTS>
 static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
-    const double* __restrict__ w, Ctl* __restrict__ ctl, const double* __restrict__ wmax_src, ImageArgs a,
+    typename std::conditional<FS_WEIGHTS, double*, const double*>::type w, Ctl* __restrict__ ctl,
+    const double* __restrict__ wmax_src, ImageArgs a,
     uint64_t* __restrict__ rec, unsigned int* __restrict__ ticket /* kTicketWords, zero between launches */, uint64_t epoch,
     int settle, uint64_t n_tiles, PlanArgs pa, unsigned int* __restrict__ markers, unsigned int* __restrict__ carry,
     EstArgs ea) {
@@ -643,9 +648,17 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
   const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)tid * kItems;
   uint64_t run = 0;
   u128 q2 = {0, 0};
+  double w_in[FS_WEIGHTS ? kItems : 1];
 #pragma unroll
   for (int j = 0; j < kItems; ++j) {
-    t.q[j] = quantize_at(w, i0 + j, a.n, mode, shift, a.gid0, a.n_global);
+    if (FS_WEIGHTS) {
+      w_in[j] = i0 + j < a.n ? w[i0 + j] : 0.0;
+      t.q[j] = i0 + j >= a.n ? 0ull
+                             : (mode == kImageWeights ? rr_fix_quantize(w_in[j], shift)
+                                                      : (mode == kImageUniform ? 1ull : (a.gid0 + i0 + j == a.n_global - 1 ? 1ull : 0ull)));
+    } else {
+      t.q[j] = quantize_at(w, i0 + j, a.n, mode, shift, a.gid0, a.n_global);
+    }
     run += t.q[j];
     t.c[j] = run;
     u128 sq;
@@ -755,6 +768,23 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
   if (rho != rho) {
     double dummy;
     rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
+  }
+  if constexpr (FS_WEIGHTS) {
+    if (!fire) {
+      if (mode != kImageWeights) return;  // all-zero weights stay untouched (fastslam1.rs:198-202)
+      const double sum = rr_fix_total_to_double(ts.tot, shift);
+#pragma unroll
+      for (int j = 0; j < kItems; ++j)
+        if (i0 + j < a.n) w[i0 + j] = w_in[j] / sum;
+      return;
+    }
+    const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
+    mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry);
+    const double w_new = 1.0 / (double)pa.n_global;
+#pragma unroll
+    for (int j = 0; j < kItems; ++j)
+      if (i0 + j < a.n) w[i0 + j] = w_new;
+    return;
   }
   if (!fire && !ea.want) return;
   unsigned int offspring[kItems];
