@@ -1060,6 +1060,9 @@ rr_status launch_rest_gather(rr_fs1* h, const double* z, size_t n_z) {
 rr_status fetch_ctl(rr_fs1* h) {
   RR_HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->ctl_host->grid_timeout)  // latched: the filter state after it is not to be trusted
+    return fail(RR_RUNTIME_ERROR, "a workgroup of the one-launch resample plan timed out waiting for another one's tile sums "
+                                  "(the device did not run them concurrently); set RR_PF_FUSED_PLAN=0");
   return h->p2p.check(h->stream);  // a latched peer-wait timeout must not look like a healthy filter
 }
 
