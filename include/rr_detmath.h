@@ -41,12 +41,17 @@ RR_HD double rr_fma(double a, double b, double c) { return __builtin_fma(a, b, c
 RR_HD double rr_rint(double x) { return __builtin_rint(x); }
 RR_HD double rr_sqrt(double x) { return __builtin_sqrt(x); }
 #if defined(__HIP_DEVICE_COMPILE__)
-/* The core of LLVM's own correctly rounded f64 sqrt lowering for gfx950 -- v_rsq_f64, two
- * Goldschmidt refinements, two residual corrections -- WITHOUT the 2^256 rescale it wraps around
- * inputs below 2^-767 and without the 0/inf select.  For 2^-767 <= x < inf the rescale is the
- * identity, so this returns exactly __builtin_sqrt(x); for x == 0, inf or NaN it returns NaN.
- * Callers (rr_pf_weight_fused) track the minimum argument and fall back to rr_sqrt when any
- * argument was outside the range or the result is NaN.  6 fewer VALU instructions per call. */
+/* Square root for the device's hot loops: v_rsq_f64, one Goldschmidt refinement, ONE residual correction -- the core of
+ * LLVM's correctly rounded f64 sqrt lowering for gfx950 without its second residual correction, without the 2^256
+ * rescale it wraps around inputs below 2^-767 and without the 0/inf select (for x == 0, inf or NaN this returns NaN;
+ * callers -- rr_pf_weight_fused -- redo such particles with rr_sqrt).
+ * Agreement with the correctly rounded root (what the CPU side of the D-spec computes): the hardware seed is accurate
+ * to e <= 2^-24.17 (measured over 2^36 arguments, tools/ubench/rsq_accuracy.hip); Goldschmidt leaves g and h with the
+ * same relative error 1.5 e^2, and the correction g + (x - g^2) h then misses sqrt(x) by 2.25 e^4 <= 2^-95.6 relative =
+ * 2^-42.6 ulp before the final rounding.  The result therefore differs from the correctly rounded one only if sqrt(x)
+ * lies within 2^-42.6 ulp of a rounding boundary: probability < 2^-41 per evaluation for the worst seed, ~2^-47 for a
+ * typical one; measured 0 of 6.9e10.  (Two corrections WITHOUT the Goldschmidt step: 1468 of 6.9e10; the second
+ * correction after it: 2 more VALU instructions per (particle, landmark) pair for the last 2^-41.) */
 __device__ static inline double rr_sqrt_core(double x) {
   double y = __builtin_amdgcn_rsq(x);
   double g = x * y;
@@ -55,8 +60,6 @@ __device__ static inline double rr_sqrt_core(double x) {
   g = __builtin_fma(g, r, g);
   h = __builtin_fma(h, r, h);
   double d = __builtin_fma(-g, g, x);
-  g = __builtin_fma(d, h, g);
-  d = __builtin_fma(-g, g, x);
   g = __builtin_fma(d, h, g);
   return g;
 }
