@@ -139,8 +139,9 @@ __global__ __launch_bounds__(kBlock) void k_fs2_predict(Planes pl, const Ctl* __
 //   bit 1  non-temporal loads on that path as well
 //   bit 2  no software pipeline (loads at the top of each update)
 //   bit 3  register budget for 4 waves per SIMD instead of 3
-//   bit 4  MEASUREMENT ONLY (wrong results): the EKF arithmetic is replaced by a copy -- the kernel's memory pattern alone
-constexpr int kObsNtStore = 1, kObsNtLoad = 2, kObsNoPipe = 4, kObsFourWaves = 8, kObsCopyOnly = 16;
+// (The memory pattern alone -- same grid, same pipeline, synthetic arithmetic -- is tools/ubench/plane_layout.hip: 5.2-5.4 TB/s
+// whether 0 or 300 FMAs sit between a wave's loads and its stores; this kernel runs at 5.25 TB/s.)
+constexpr int kObsNtStore = 1, kObsNtLoad = 2, kObsNoPipe = 4, kObsFourWaves = 8;
 
 template <bool LAZY, bool SEQ, int VAR>
 __global__ __launch_bounds__(kBlock, (VAR & kObsFourWaves) ? 4 : 1) void k_fs1_observe(
@@ -221,8 +222,7 @@ __global__ __launch_bounds__(kBlock, (VAR & kObsFourWaves) ? 4 : 1) void k_fs1_o
 #pragma unroll
         for (int f = 0; f < 6; ++f) e[f] = nxt[f];
         if (k + 1 < nk) load6(src + (3 + (uint64_t)s_z[3 * k + 5] * 6) * n + j, nxt);
-        if (VAR & kObsCopyOnly) acc += e[0] * zd + za;
-        else acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
+        acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
         store6(dst + (3 + id * 6) * n + p, e);
       }
     }
@@ -900,7 +900,6 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool 
         case 4: kfn = RR_OBS_KERNEL(true, false, kObsNoPipe | kObsFourWaves | kObsNtStore); break;
         case 5: kfn = RR_OBS_KERNEL(true, false, kObsFourWaves); break;
         case 6: kfn = RR_OBS_KERNEL(true, false, kObsNoPipe); break;
-        case 16: kfn = RR_OBS_KERNEL(true, false, kObsCopyOnly); break;
         default: kfn = RR_OBS_KERNEL(true, false, 0); break;
       }
     }

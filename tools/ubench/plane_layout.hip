@@ -1,0 +1,89 @@
+// Does the landmark-major PLANE layout of the FastSLAM map (field f of landmark l of particle p at
+// ((3 + 6 l + f) * n + p)) cost bandwidth once ~0.7 us of arithmetic sits between a wave's loads and its stores?
+// Same traffic, same grid and software pipeline as k_fs1_observe (1e5 particles x 200 landmarks, 25 chunks), synthetic
+// arithmetic of K dependent FMAs per field, two layouts:
+//   A  planes:  field f of 64 consecutive particles = 512 contiguous bytes, six 800 KB-strided pieces per update
+//   B  blocks:  [landmark][particle / 64][field][particle % 64] -- the six fields of a wave's update are 3 KB contiguous
+//   hipcc --offload-arch=gfx950 -O3 plane_layout.hip -o plane_layout && ./plane_layout
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+template <int LAYOUT, int K>
+__global__ __launch_bounds__(256) void k(const double* src, double* dst, uint64_t n, int L, int chunk_len) {
+  const uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= n) return;
+  const int l0 = blockIdx.y * chunk_len, l1 = min(l0 + chunk_len, L);
+  auto addr = [&](int l, int f) -> uint64_t {
+    if (LAYOUT == 0) return ((uint64_t)(3 + 6 * l + f)) * n + p;
+    const uint64_t nb = (n + 63) / 64;  // blocks per landmark
+    return 3 * n + (((uint64_t)l * nb + p / 64) * 6 + f) * 64 + (p % 64);
+  };
+  double nxt[6];
+#pragma unroll
+  for (int f = 0; f < 6; ++f) nxt[f] = src[addr(l0, f)];
+  double acc = 1.0;
+  for (int l = l0; l < l1; ++l) {
+    double e[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) e[f] = nxt[f];
+    if (l + 1 < l1) {
+#pragma unroll
+      for (int f = 0; f < 6; ++f) nxt[f] = src[addr(l + 1, f)];
+    }
+    // K dependent FMAs per field, ILP 6 (about what the EKF offers)
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+      double v = e[f];
+#pragma unroll
+      for (int i = 0; i < K; ++i) v = __builtin_fma(v, 0.999999, 1e-9);
+      e[f] = v;
+    }
+    acc *= e[0] + e[5];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) dst[addr(l, f)] = e[f];
+  }
+  dst[p] = acc;
+}
+
+template <int LAYOUT, int K>
+float run(const double* src, double* dst, uint64_t n, int L, int chunks) {
+  const int len = (L + chunks - 1) / chunks;
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)chunks);
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((k<LAYOUT, K>), grid, dim3(256), 0, 0, src, dst, n, L, len);
+  (void)hipEventRecord(a);
+  const int reps = 10;
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k<LAYOUT, K>), grid, dim3(256), 0, 0, src, dst, n, L, len);
+  (void)hipEventRecord(b);
+  (void)hipEventSynchronize(b);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, a, b);
+  return ms / reps;
+}
+
+int main() {
+  const uint64_t n = 100000;
+  const int L = 200, chunks = 25;
+  const size_t doubles = (3 + 6 * (size_t)L) * (((n + 63) / 64) * 64) + 64;
+  double *src, *dst;
+  (void)hipMalloc(&src, doubles * sizeof(double));
+  (void)hipMalloc(&dst, doubles * sizeof(double));
+  (void)hipMemset(src, 0, doubles * sizeof(double));
+  (void)hipMemset(dst, 0, doubles * sizeof(double));
+  const double gb = 96.0 * n * L / 1e9;
+  float t;
+#define RUN(LAY, KK) t = run<LAY, KK>(src, dst, n, L, chunks); std::printf("layout %s  K=%3d (%4d FMAs per update)  %.1f us  %.2f TB/s\n", LAY ? "blocks" : "planes", KK, 6 * KK, t * 1e3, gb / t)
+  RUN(0, 0); RUN(1, 0);
+  std::printf("-- in place (dst == src)\n");
+  { double* keep = dst; dst = src; RUN(0, 0); RUN(0, 50); RUN(1, 50); dst = keep; }
+  std::printf("-- out of place\n");
+  RUN(0, 16); RUN(1, 16);
+  RUN(0, 32); RUN(1, 32);
+  RUN(0, 50); RUN(1, 50);
+  RUN(0, 80); RUN(1, 80);
+  return 0;
+}
