@@ -391,7 +391,10 @@ def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True):
                                        "--no-breakdown`, bytes per launch, read side x2)" if traffic_src else None,
                      "avg_kernel_ms": avg_s * 1e3, "timed_launches": k_n,
                      "timing": "dispatch timestamps of the K launches inside the timed region",
-                     "algorithmic_bytes_per_launch": per_launch},
+                     "algorithmic_bytes_per_launch": per_launch,
+                     "note": "`peak` is the HBM peak; a plain streaming copy of the same bytes (dst[i] = src[i], 16 B per thread) reaches "
+                             "4.9-5.2 TB/s on this GPU and the kernel's own access pattern with synthetic arithmetic 5.2-5.4 TB/s "
+                             "(tools/ubench/plane_layout.hip, DESIGN.md section 4): the kernel runs at the rate at which the device copies memory"},
         "kernel_ms_avg": {k: v[1] / max(v[0], 1) for k, v in prof.items() if v[0]},
         "kernel_launches": {k: v[0] for k, v in prof.items() if v[0]},
         "ms_per_step_instrumented": dt_i / K * 1e3,
