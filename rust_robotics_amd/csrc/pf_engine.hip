@@ -197,14 +197,19 @@ constexpr unsigned int kInPlace = 0xffffffffu;
 //    needed, so the kernel's first microseconds are not spent waiting, -1.3 us;
 //  * the weight maximum goes through rr::atomic_max_u64's look-first form: one same-address atomic per workgroup cost
 //    14.6 us of queueing at L = 1 and 2 us at L = 32.
-template <bool OBS_KERNARG, bool SHARDED, int LIK>
+//  * PACKED (the lazy MULTINOMIAL resample of one GPU: sources are iid draws, so the reads through `lidx` are random):
+//    the kernel also keeps an array-of-structures mirror {x, y, yaw, v} of the set it writes, and reads a source
+//    particle from the mirror of the live set -- one random 32-byte record instead of three random 8-byte words
+//    from three arrays.  The mirror is only ever read while a resample is pending, and a resample only becomes
+//    pending right after a launch of this kernel has written the mirror of the then-live set.
+template <bool OBS_KERNARG, bool SHARDED, int LIK, bool PACKED = false>
 __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
                                                      StepParams p, ObsArg obs_arg,
                                                      const double* __restrict__ obs_dev,
                                                      unsigned int* __restrict__ markers,
                                                      const unsigned int* __restrict__ carry,
                                                      unsigned int* __restrict__ idx_out,
-                                                     const double* __restrict__ inbox) {
+                                                     const double* __restrict__ inbox, double* pk0, double* pk1) {
   extern __shared__ double s_obs[];
   __shared__ double s_wmax[kBlock / rr::kWave];
   const int tid = threadIdx.x;
@@ -252,6 +257,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
           x[r] = inbox[k];
           y[r] = inbox[p.n + k];
           yaw[r] = inbox[2 * p.n + k];
+        } else if (PACKED && pending) {
+          const double4 rec = *reinterpret_cast<const double4*>((src ? pk1 : pk0) + 4 * j);
+          x[r] = rec.x;
+          y[r] = rec.y;
+          yaw[r] = rec.z;
         } else {
           x[r] = sx[j];
           y[r] = sy[j];
@@ -269,6 +279,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
         b.y[dst][k] = y[r];
         b.yaw[dst][k] = yaw[r];
         b.v[dst][k] = v;
+        if (PACKED) *reinterpret_cast<double4*>((dst ? pk1 : pk0) + 4 * k) = make_double4(x[r], y[r], yaw[r], v);
         if (SHARDED) {
           if (pending) markers[k] = kInPlace;
         } else if (pending && idx_out) {
@@ -933,6 +944,7 @@ struct rr_pf {
   double* est_partials = nullptr;      // [kFusedMaxTiles][4] per-workgroup sums of the fused per-step estimate
   // k_quantize_plan_mark (K2 + fused plan in one launch): one record per tile, the launch epoch, the largest grid whose
   // workgroups are all resident at once (0: not available), RR_PF_FUSED_PLAN=0 turns it off
+  double* packed[2] = {nullptr, nullptr};  // {x, y, yaw, v} mirrors of the two buffer sets (k_step_lazy<PACKED>; lazy multinomial only)
   uint64_t* grid_rec = nullptr;
   unsigned int* grid_ticket = nullptr;
   uint64_t grid_epoch = 0;
@@ -1527,6 +1539,9 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
   if (opt.resample_scheme == RR_RESAMPLE_MULTINOMIAL && !kld) {  // the fused step resamples lazily through lidx
     RR_TRY_OR_CLEAN(hipMalloc(&h->lidx, h->n * sizeof(unsigned int)));
     RR_TRY_OR_CLEAN(hipMemset(h->lidx, 0xff, h->n * sizeof(unsigned int)));
+    if (h->n == h->n_global && !std::getenv("RR_MN_NO_PACKED")) {
+      for (int k = 0; k < 2; ++k) RR_TRY_OR_CLEAN(hipMalloc(&h->packed[k], 4 * h->n * sizeof(double)));
+    }
   }
   {
     const size_t nm = (size_t)std::max<uint64_t>(n_global, h->cap) + rr::kResolveSlots;
@@ -1591,28 +1606,34 @@ rr_status ensure_scratch(rr_pf* h, size_t doubles_a, size_t doubles_b) {
 // C ABI
 // =============================================================================================
 // one launch of k_step_lazy: the template arguments from run-time facts (ea/eb: dispatch timestamps when profiling)
-template <bool KA, bool SH, int LIK>
+template <bool KA, bool SH, int LIK, bool PK = false>
 static void launch_k1_as(rr_pf* h, unsigned grid, size_t lds, hipEvent_t ea, hipEvent_t eb, const StepParams& p, const ObsArg& arg,
                          unsigned int* markers, const unsigned int* carry, unsigned int* idx_out, const double* inbox) {
   const double* obs_dev = KA ? nullptr : h->obs_dev;
   if (ea)
-    hipExtLaunchKernelGGL((k_step_lazy<KA, SH, LIK>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl, p, arg,
-                          obs_dev, markers, carry, idx_out, inbox);
+    hipExtLaunchKernelGGL((k_step_lazy<KA, SH, LIK, PK>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl, p, arg,
+                          obs_dev, markers, carry, idx_out, inbox, h->packed[0], h->packed[1]);
   else
-    hipLaunchKernelGGL((k_step_lazy<KA, SH, LIK>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg, obs_dev,
-                       markers, carry, idx_out, inbox);
+    hipLaunchKernelGGL((k_step_lazy<KA, SH, LIK, PK>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg, obs_dev,
+                       markers, carry, idx_out, inbox, h->packed[0], h->packed[1]);
 }
 
 static void launch_k1(rr_pf* h, bool kernarg, bool sharded, unsigned grid, size_t lds, hipEvent_t ea, hipEvent_t eb,
                       const StepParams& p, const ObsArg& arg, unsigned int* markers, const unsigned int* carry,
-                      unsigned int* idx_out, const double* inbox) {
+                      unsigned int* idx_out, const double* inbox, bool packed = false) {
   const bool product = p.lik_mode == RR_LIK_PRODUCT;
 #define RR_K1_GO(KA_, SH_, LIK_) launch_k1_as<KA_, SH_, LIK_>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, inbox)
+#define RR_K1_GO_PK(KA_, LIK_) launch_k1_as<KA_, true, LIK_, true>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, inbox)
+  if (sharded && packed) {
+    if (kernarg) product ? RR_K1_GO_PK(true, RR_LIK_PRODUCT) : RR_K1_GO_PK(true, RR_LIK_FUSED);
+    else product ? RR_K1_GO_PK(false, RR_LIK_PRODUCT) : RR_K1_GO_PK(false, RR_LIK_FUSED);
+  } else
   if (kernarg && sharded) product ? RR_K1_GO(true, true, RR_LIK_PRODUCT) : RR_K1_GO(true, true, RR_LIK_FUSED);
   else if (kernarg) product ? RR_K1_GO(true, false, RR_LIK_PRODUCT) : RR_K1_GO(true, false, RR_LIK_FUSED);
   else if (sharded) product ? RR_K1_GO(false, true, RR_LIK_PRODUCT) : RR_K1_GO(false, true, RR_LIK_FUSED);
   else product ? RR_K1_GO(false, false, RR_LIK_PRODUCT) : RR_K1_GO(false, false, RR_LIK_FUSED);
 #undef RR_K1_GO
+#undef RR_K1_GO_PK
 }
 
 extern "C" {
@@ -1720,6 +1741,8 @@ void rr_pf_destroy(rr_pf* h) {
   (void)hipFree(h->idx);
   (void)hipFree(h->markers);
   (void)hipFree(h->lidx);
+  (void)hipFree(h->packed[0]);
+  (void)hipFree(h->packed[1]);
   (void)hipFree(h->kld_keys);
   (void)hipFree(h->kld_table);
   (void)hipFree(h->kld_minslot);
@@ -1863,7 +1886,8 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
     if (multinomial) {  // sources of the previous (multinomial) resample are in lidx
-      launch_k1(h, kernarg, /*sharded=*/true, grid, lds, nullptr, nullptr, p, arg, h->lidx, nullptr, nullptr, h->p2p.inbox);
+      launch_k1(h, kernarg, /*sharded=*/true, grid, lds, nullptr, nullptr, p, arg, h->lidx, nullptr, nullptr, h->p2p.inbox,
+                /*packed=*/h->packed[0] != nullptr);
     } else {
       hipEvent_t ea = nullptr, eb = nullptr;
       if (h->profiling && h->profile_dispatch_only) {  // timestamps of this dispatch itself: nothing extra in the stream
