@@ -394,7 +394,10 @@ def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True):
                      "algorithmic_bytes_per_launch": per_launch,
                      "note": "`peak` is the HBM peak; a plain streaming copy of the same bytes (dst[i] = src[i], 16 B per thread) reaches "
                              "4.9-5.2 TB/s on this GPU and the kernel's own access pattern with synthetic arithmetic 5.2-5.4 TB/s "
-                             "(tools/ubench/plane_layout.hip, DESIGN.md section 4): the kernel runs at the rate at which the device copies memory"},
+                             "(tools/ubench/plane_layout.hip, DESIGN.md section 4): the kernel runs at the rate at which the device copies memory"
+                             + ("; FastSLAM 2.0 on this trajectory resamples to few distinct ancestors, so lanes share source lines and the "
+                                "launch READS 0.74 GB instead of the algorithmic 0.96 GB (rocprofv3 FETCH_SIZE, DESIGN.md section 6): "
+                                "`frac` is by algorithmic bytes, the moved bytes correspond to ~5.5 TB/s" if v2 else "")},
         "kernel_ms_avg": {k: v[1] / max(v[0], 1) for k, v in prof.items() if v[0]},
         "kernel_launches": {k: v[0] for k, v in prof.items() if v[0]},
         "ms_per_step_instrumented": dt_i / K * 1e3,
