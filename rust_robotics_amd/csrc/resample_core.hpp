@@ -733,7 +733,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
   if (tid == 0) {
     long spins = 0;
     while (ld_dev(&head[3]) != epoch) {
-      if (++spins > (1l << 22)) {
+      if (++spins > (1l << 20)) {  // ~1.5 s
         ctl->grid_timeout = 1;
         break;
       }
