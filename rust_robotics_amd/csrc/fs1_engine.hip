@@ -1007,7 +1007,7 @@ rr_status launch_plan_fused(rr_fs1* h, int settle) {
       RR_HIP_TRY(hipMemsetAsync(h->grid_ticket, 0, rr::kTicketWords * sizeof(unsigned int), h->stream));
     }
   }
-  if (h->n_tiles <= h->grid_capacity) {
+  if (h->n_tiles <= h->grid_capacity && rr::live_handles(h->opt.device).load() == 1) {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_CDF);
     hipLaunchKernelGGL(rr::k_quantize_plan_mark<true>, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
                        (const double*)&h->ctl->wmax_bits, image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, settle,
@@ -1166,6 +1166,7 @@ rr_status rr_fs1_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs1
   RR_TRY_OR_CLEAN(hipGetLastError());
   RR_TRY_OR_CLEAN(hipStreamSynchronize(h->stream));
 #undef RR_TRY_OR_CLEAN
+  rr::live_handles(h->opt.device).fetch_add(1);
   *out = h;
   return RR_OK;
 }
@@ -1198,6 +1199,7 @@ void rr_fs1_destroy(rr_fs1* h) {
   if (h->ctl_host) (void)hipHostFree(h->ctl_host);
   h->prof.destroy();
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  rr::live_handles(h->opt.device).fetch_sub(1);
   delete h;
 }
 

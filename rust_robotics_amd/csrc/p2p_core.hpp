@@ -307,11 +307,12 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
   }
   // ---- everybody: flag 1, then the workgroup's prefix, the base and the global totals
   if (tid == 0) {
-    if (!wait_flag(&head1[5], epoch, limit)) *err = 1;
+    const bool ok = wait_flag(&head1[5], epoch, limit);
+    if (!ok) *err = 1;
     s4[0] = ld_dev(&rec[(uint64_t)blockIdx.x * kRecWords + 3]);
     s4[1] = ld_dev(&head1[0]);
     s4[2] = ld_dev(&head1[1]);
-    s4[3] = ld_dev(&head1[4]);
+    s4[3] = ok ? ld_dev(&head1[4]) : 0;  // gave up: as if the gate were shut -- nothing is marked with unknown sums
   }
   __syncthreads();
   const uint64_t pre = s4[0], base = s4[1], total = s4[2];

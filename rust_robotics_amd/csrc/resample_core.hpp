@@ -732,9 +732,11 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
   // ---- everybody: one thread polls the flag, then the workgroup's prefix and the totals
   if (tid == 0) {
     long spins = 0;
+    s_last = 0;  // reused: 1 = gave up
     while (ld_dev(&head[3]) != epoch) {
       if (++spins > (1l << 20)) {  // ~1.5 s
         ctl->grid_timeout = 1;
+        s_last = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(1);
@@ -746,6 +748,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
     s4[3] = ld_dev(&head[2]);
   }
   __syncthreads();
+  if (s_last) return;  // no sums: nothing may be marked or written with them (the host reports Ctl.grid_timeout)
   TileSums ts;
   ts.pre = s4[0];
   ts.tot = s4[1];

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -101,6 +102,15 @@ struct ScopedTimer {
     p.events.push_back({id, a, b});
   }
 };
+
+// Handles (PF / MCL and FastSLAM together) alive on a device in this process.  The one-launch resample plans
+// (k_quantize_plan_mark, k_shard_plan_mark) spin inside the kernel until every workgroup of their grid has arrived, so
+// two of them running at the same time on one device could each hold the slots the other's missing workgroups need;
+// they are only used while the device has a single handle (another handle: the multi-launch plans, identical results).
+inline std::atomic<int>& live_handles(int device) {
+  static std::atomic<int> count[64];
+  return count[device & 63];
+}
 
 // ---- wave64 primitives (gfx950: a wavefront is 64 lanes) ------------------------------
 constexpr int kWave = 64;

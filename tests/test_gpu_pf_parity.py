@@ -433,6 +433,35 @@ def test_one_launch_plan_equals_the_two_kernel_plan(loc, mcl, monkeypatch):
         assert_bits_equal(ea, eb, f"step {t} in-step estimate")
 
 
+def test_two_filters_on_one_device_run_side_by_side(loc):
+    """Two handles stepping asynchronously on their own streams: the one-launch plans spin inside the kernel and are
+    only used while a device has a single handle (rr::live_handles), so the two filters share the device without
+    waiting for each other's workgroups -- and give the bits of a filter that runs alone."""
+    n, L, T = 600_000, 8, 20  # 293 tiles each: two one-launch plans at once would not fit the device
+    lms = H.landmarks_grid(L, 5)
+
+    def make(seed):
+        return loc.MonteCarloLocalizer(loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.5), seed=seed,
+                                       resample_scheme=1)
+
+    rng = np.random.default_rng(21)
+    obs = [H.observations(lms, H.true_pose(t + 1), 0.5, rng) for t in range(T)]
+    a, b = make(31), make(32)
+    for t in range(T):
+        a.step_async([1.0, 0.1], obs[t])
+        b.step_async([1.0, 0.1], obs[t])
+    pa, pb = a.get_particles_array().copy(), b.get_particles_array().copy()
+    del a, b
+    for seed, want in ((31, pa), (32, pb)):
+        solo = make(seed)  # alone on the device: the one-launch plan
+        for t in range(T):
+            solo.step_async([1.0, 0.1], obs[t])
+        got = solo.get_particles_array()
+        for k in range(5):
+            assert_bits_equal(got[:, k], want[:, k], f"seed {seed} col {k}")
+        del solo
+
+
 # ------------------------------------------------------------------ API surface / error behaviour
 def test_reference_unit_tests_reexpressed(loc):
     """particle_filter.rs:575-707 against the engine"""
