@@ -1007,7 +1007,7 @@ rr_status launch_plan_fused(rr_fs1* h, int settle) {
       RR_HIP_TRY(hipMemsetAsync(h->grid_ticket, 0, rr::kTicketWords * sizeof(unsigned int), h->stream));
     }
   }
-  if (h->n_tiles <= h->grid_capacity && rr::live_handles(h->opt.device).load() == 1) {
+  if (h->n_tiles <= h->grid_capacity && rr::spin_permit(h->opt.device, h)) {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_CDF);
     hipLaunchKernelGGL(rr::k_quantize_plan_mark<true>, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
                        (const double*)&h->ctl->wmax_bits, image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, settle,
@@ -1059,6 +1059,7 @@ rr_status launch_rest_gather(rr_fs1* h, const double* z, size_t n_z) {
 rr_status fetch_ctl(rr_fs1* h) {
   RR_HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  rr::spin_release(h->opt.device, h);
   if (h->ctl_host->grid_timeout)  // latched: the filter state after it is not to be trusted
     return fail(RR_RUNTIME_ERROR, "a workgroup of the one-launch resample plan timed out waiting for another one's tile sums "
                                   "(the device did not run them concurrently); set RR_PF_FUSED_PLAN=0");
@@ -1166,7 +1167,6 @@ rr_status rr_fs1_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs1
   RR_TRY_OR_CLEAN(hipGetLastError());
   RR_TRY_OR_CLEAN(hipStreamSynchronize(h->stream));
 #undef RR_TRY_OR_CLEAN
-  rr::live_handles(h->opt.device).fetch_add(1);
   *out = h;
   return RR_OK;
 }
@@ -1199,7 +1199,7 @@ void rr_fs1_destroy(rr_fs1* h) {
   if (h->ctl_host) (void)hipHostFree(h->ctl_host);
   h->prof.destroy();
   if (h->stream) (void)hipStreamDestroy(h->stream);
-  rr::live_handles(h->opt.device).fetch_sub(1);
+  rr::spin_release(h->opt.device, h);
   delete h;
 }
 
@@ -1341,6 +1341,7 @@ rr_status rr_fs1_synchronize(rr_fs1* h) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  rr::spin_release(h->opt.device, h);
   return h->p2p.check(h->stream);
 }
 

@@ -1199,7 +1199,7 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
                           bool lazy = false, int settle = 0, bool want_estimate = false) {
   // K2 + fused plan in one launch when every tile's workgroup is resident at once (k_quantize_plan_mark)
   const bool one_launch = scheme == RR_RESAMPLE_SYSTEMATIC && h->n_tiles <= h->grid_capacity && h->n == h->n_global &&
-                          rr::live_handles(h->opt.device).load() == 1;
+                          rr::spin_permit(h->opt.device, h);
   if (!one_launch) launch_quantize(h, wmax_source(h), settle);
   PlanArgs pa = plan_args(h, mode, scheme, rho_override);
   const bool lazy_mn = lazy && scheme == RR_RESAMPLE_MULTINOMIAL && h->lidx && !r_explicit_dev;
@@ -1346,6 +1346,7 @@ rr_status resample_adaptive(rr_pf* h, const double* r_explicit_dev) {
 rr_status fetch_ctl(rr_pf* h) {
   RR_HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  rr::spin_release(h->opt.device, h);
   if (h->ctl_host->grid_timeout)  // latched: the filter state after it is not to be trusted
     return fail(RR_RUNTIME_ERROR, "a workgroup of the one-launch resample plan timed out waiting for another one's tile sums "
                                   "(the device did not run them concurrently); set RR_PF_FUSED_PLAN=0");
@@ -1586,7 +1587,6 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
   RR_TRY_OR_CLEAN(hipMemcpyAsync(h->ctl, h->ctl_host, sizeof(Ctl), hipMemcpyHostToDevice, h->stream));
   RR_TRY_OR_CLEAN(hipStreamSynchronize(h->stream));
 #undef RR_TRY_OR_CLEAN
-  rr::live_handles(h->opt.device).fetch_add(1);
   *out = h;
   return RR_OK;
 }
@@ -1769,7 +1769,7 @@ void rr_pf_destroy(rr_pf* h) {
   }
   for (auto e : h->event_pool) (void)hipEventDestroy(e);
   if (h->owns_stream && h->own_stream) (void)hipStreamDestroy(h->own_stream);
-  rr::live_handles(h->opt.device).fetch_sub(1);
+  rr::spin_release(h->opt.device, h);
   delete h;
 }
 
@@ -1932,6 +1932,7 @@ rr_status rr_pf_synchronize(rr_pf* h) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  rr::spin_release(h->opt.device, h);
   return h->p2p.check(h->stream);
 }
 
@@ -2397,7 +2398,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
     RR_HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
     h->shard_capacity = h->grid_capacity ? std::min<uint64_t>((uint64_t)per_cu * (uint64_t)dev_cus, (uint64_t)rr::kTileBlock) : 0;
   }
-  if (h->n_tiles <= h->shard_capacity && rr::live_handles(h->opt.device).load() == 1) {
+  if (h->n_tiles <= h->shard_capacity && rr::spin_permit(h->opt.device, h)) {
     // exchange 1 + B + exchange 2 + C in one launch (k_shard_plan_mark)
     Timed t(h, RR_K_CDF);
     hipLaunchKernelGGL(rr::k_shard_plan_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->p2p.peers, seq,

@@ -5,7 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
-#include <atomic>
+#include <mutex>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -103,13 +103,31 @@ struct ScopedTimer {
   }
 };
 
-// Handles (PF / MCL and FastSLAM together) alive on a device in this process.  The one-launch resample plans
-// (k_quantize_plan_mark, k_shard_plan_mark) spin inside the kernel until every workgroup of their grid has arrived, so
-// two of them running at the same time on one device could each hold the slots the other's missing workgroups need;
-// they are only used while the device has a single handle (another handle: the multi-launch plans, identical results).
-inline std::atomic<int>& live_handles(int device) {
-  static std::atomic<int> count[64];
-  return count[device & 63];
+// The one-launch resample plans (k_quantize_plan_mark, k_shard_plan_mark) spin inside the kernel until every workgroup
+// of their grid has arrived.  Two such kernels running at the same time on one device could each hold the slots the
+// other's missing workgroups need, so per device (and process) only ONE handle at a time may have spinning kernels in
+// flight: a handle asks before it launches one (spin_permit) and keeps the permit until its stream has been
+// synchronised (spin_release); a handle that is refused takes the multi-launch plan -- identical results, and kernels
+// that do not spin always finish, so the permit holder's grid gets its slots.  (Found by running two 1e6-particle
+// filters side by side: without this each waited ~1.5 s for the other and gave up.)
+struct SpinGate {
+  std::mutex m;
+  const void* holder = nullptr;
+};
+inline SpinGate& spin_gate(int device) {
+  static SpinGate g[64];
+  return g[device & 63];
+}
+inline bool spin_permit(int device, const void* handle) {
+  SpinGate& g = spin_gate(device);
+  std::lock_guard<std::mutex> lock(g.m);
+  if (g.holder == nullptr) g.holder = handle;
+  return g.holder == handle;
+}
+inline void spin_release(int device, const void* handle) {  // the handle's stream is idle (or the handle is going away)
+  SpinGate& g = spin_gate(device);
+  std::lock_guard<std::mutex> lock(g.m);
+  if (g.holder == handle) g.holder = nullptr;
 }
 
 // ---- wave64 primitives (gfx950: a wavefront is 64 lanes) ------------------------------

@@ -434,9 +434,9 @@ def test_one_launch_plan_equals_the_two_kernel_plan(loc, mcl, monkeypatch):
 
 
 def test_two_filters_on_one_device_run_side_by_side(loc):
-    """Two handles stepping asynchronously on their own streams: the one-launch plans spin inside the kernel and are
-    only used while a device has a single handle (rr::live_handles), so the two filters share the device without
-    waiting for each other's workgroups -- and give the bits of a filter that runs alone."""
+    """Two handles stepping asynchronously on their own streams: the one-launch plans spin inside the kernel, and only one
+    handle per device at a time may launch them (rr::spin_permit), so the two filters share the device without waiting
+    for each other's workgroups -- and give the bits of a filter that runs alone."""
     n, L, T = 600_000, 8, 20  # 293 tiles each: two one-launch plans at once would not fit the device
     lms = H.landmarks_grid(L, 5)
 
