@@ -63,7 +63,12 @@ def test_device_math_bit_identical(ffi, det, fn, name):
     elif fn in (5,):
         a = 10.0 ** rng.uniform(-300, 300, n)
     elif fn == 9:  # the core's exact range is [2^-767, inf): squared ranges with the 2^-700 floor, Box-Muller radii, the extremes
-        a = np.concatenate([10.0 ** rng.uniform(-230, 300, n - 4), [2.0**-767, 2.0**-700, 2.0**-52, 1.7e308]])
+        # ... and the arguments a one-correction core could get wrong first: exact squares (the root is a double: any
+        # error shows), their neighbours one ulp away, and k^2 + k (roots next to a rounding boundary)
+        k = np.floor(rng.uniform(1.0, 2.0**26, n // 8))
+        sq = k * k
+        hard = np.concatenate([sq, np.nextafter(sq, np.inf), np.nextafter(sq, 0.0), sq + k, (sq + k) * 2.0**-40, sq * 2.0**101])
+        a = np.concatenate([10.0 ** rng.uniform(-230, 300, n - 4 - hard.size), hard, [2.0**-767, 2.0**-700, 2.0**-52, 1.7e308]])
     else:
         a = rng.normal(size=n) * 10.0 ** rng.uniform(-5, 5, n)
     b = rng.normal(size=n) * 10.0 ** rng.uniform(-5, 5, n)
