@@ -392,9 +392,9 @@ def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True):
                      "avg_kernel_ms": avg_s * 1e3, "timed_launches": k_n,
                      "timing": "dispatch timestamps of the K launches inside the timed region",
                      "algorithmic_bytes_per_launch": per_launch,
-                     "note": "`peak` is the HBM peak; a plain streaming copy of the same bytes (dst[i] = src[i], 16 B per thread) reaches "
-                             "4.9-5.2 TB/s on this GPU and the kernel's own access pattern with synthetic arithmetic 5.2-5.4 TB/s "
-                             "(tools/ubench/plane_layout.hip, DESIGN.md section 4): the kernel runs at the rate at which the device copies memory"
+                     "note": "`peak` is the HBM peak; a plain copy of the same bytes (dst[i] = src[i], 16 B per thread) runs at 4.6-6.2 TB/s on this "
+                             "GPU depending on its launch shape (hipMemcpyAsync D2D: 5.1; tools/ubench/copy_rates.hip) and the kernel's own "
+                             "access pattern with synthetic arithmetic at 5.2-5.4 TB/s (tools/ubench/plane_layout.hip, DESIGN.md section 4)"
                              + ("; FastSLAM 2.0 on this trajectory resamples to few distinct ancestors, so lanes share source lines and the "
                                 "launch READS 0.74 GB instead of the algorithmic 0.96 GB (rocprofv3 FETCH_SIZE, DESIGN.md section 6): "
                                 "`frac` is by algorithmic bytes, the moved bytes correspond to ~5.5 TB/s" if v2 else "")},
