@@ -157,5 +157,26 @@ int main() {
   RUN(0, 32); RUN(1, 32);
   RUN(0, 50); RUN(1, 50);
   RUN(0, 80); RUN(1, 80);
+  // shape sweep of the plane pattern (K = 50): observation chunks x workgroups per CU (capped by dynamic LDS)
+  std::printf("-- planes, K=50: chunks x resident workgroups per CU\n");
+  for (int ch : {8, 13, 25, 50, 100, 200}) {
+    for (int per_cu : {2, 4, 6, 8}) {
+      const size_t lds = (size_t)(150 * 1024) / per_cu;  // bytes of dynamic LDS per workgroup: at most per_cu fit in 160 KB
+      const int len = (L + ch - 1) / ch;
+      dim3 grid((unsigned)((n + 255) / 256), (unsigned)ch);
+      hipEvent_t a, b;
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      (void)hipFuncSetAttribute((const void*)k<0, 50>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((k<0, 50>), grid, dim3(256), lds, 0, src, dst, n, L, len);
+      (void)hipEventRecord(a);
+      for (int i = 0; i < 5; ++i) hipLaunchKernelGGL((k<0, 50>), grid, dim3(256), lds, 0, src, dst, n, L, len);
+      (void)hipEventRecord(b);
+      (void)hipEventSynchronize(b);
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, a, b);
+      std::printf("chunks %3d  <= %d WG/CU: %.1f us  %.2f TB/s\n", ch, per_cu, ms / 5 * 1e3, gb / (ms / 5));
+    }
+  }
   return 0;
 }
