@@ -8,15 +8,17 @@
 // touching 64 consecutive particles of one landmark field is one coalesced 512-byte access, the
 // observation list is wave-uniform (LDS), and the systematic resample is a monotone plane gather.
 //
-// Kernels
-//   k_fs1_predict      pose planes in place                               48 B / particle
+// Kernels of one update (rr_fs1_update_async): 5 launches
+//   k_fs1_predict      pose planes (through idx when a resample is pending)          48 B / particle
 //   k_fs1_observe      (particle, observation chunk): 2x2 EKF per observed landmark,
-//                      R 48 B + W <= 48 B per (particle, landmark) update  <- dominant
-//   k_fs1_combine      partial weight products -> weight, atomic max
-//   rr::k_quantize_reduce / k_scan_tiles / k_cdf   integer CDF (resample_core.hpp)
-//   k_fs1_normalize    w /= sum when the gate did not fire
-//   k_fs1_indices      CDF search per output slot
-//   k_fs1_gather       out[plane][k] = in[plane][idx[k]] over 3 + 6L planes  16 B / element
+//                      R 48 B + W 48 B per (particle, landmark) update               <- dominant
+//   k_fs1_combine      partial weight products (chunk order) -> weight, running maximum
+//   rr::k_quantize_plan_mark<FS_WEIGHTS>   integer image + gate + w /= sum or slot-run markers + w = 1/n, one launch
+//                      (resample_core.hpp; beyond 2^20 particles rr::k_quantize_reduce + k_fs1_plan)
+//   k_fs1_resolve      markers -> idx[] (the next update reads every observed landmark through it: lazy gather)
+// and of the separate / sharded entry points:
+//   rr::k_scan_tiles / k_cdf, k_fs1_normalize, k_fs1_indices(_sharded)   integer CDF, CDF search per output slot
+//   k_fs1_gather       out[plane][k] = in[plane][idx[k]] over 3 + 6L planes          16 B / element
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

@@ -5,17 +5,26 @@
 //   :337-345,416-473 (N_eff gate + resample), :382-413 (mean / covariance)
 //   rust_robotics_localization/src/monte_carlo_localization.rs:209-288,322-365 (fixed-N mode)
 // (paths under /root/reference/crates).  Not a translation: the particle set lives in HBM as
-// structure-of-arrays, one thread per particle, the observation block is staged in LDS, weight
-// maxima/sums are wave64 shuffle reductions, and the resampling CDF is an integer
-// reduce-then-scan whose value is independent of summation order (include/rr_pf_spec.h).
+// structure-of-arrays, the observation block is staged in LDS, exact reductions (integer sums, maxima) run on DPP,
+// and the resampling CDF is an integer reduce-then-scan whose value is independent of summation order
+// (include/rr_pf_spec.h).
 //
 // Kernels (one HIP stream per filter, no host synchronisation inside a step):
-//   k_propagate_weight   x,y,yaw -> x,y,yaw,v,w + atomic max(w)        64 B / particle
-//   k_quantize_reduce    w -> per-tile integer totals, sum q^2           8 B / particle
-//   k_scan_tiles         tile totals -> exclusive offsets, gate decision (single block)
-//   k_cdf                w -> inclusive integer CDF                     16 B / particle
-//   k_resample_gather    CDF search + SoA gather into the other buffer  ~72 B / particle
-//   k_moments(+final)    weighted first/second moments about particle 0 40 B / particle
+//  the fused step (rr_pf_step_async, systematic resampling): 2 launches
+//   k_step_lazy            resolve the previous resample's markers, read x,y,yaw through them, propagate, weigh,
+//                          write x,y,yaw,v,w, running maximum of w                                 72 B / particle
+//   k_quantize_plan_mark   integer image + tile sums handed over inside the launch + gate + slot-run markers
+//                          (+ the mean try_step returns); beyond 2^20 particles k_quantize_reduce + k_plan_mark
+//                          (resample_core.hpp)                                                      8-12 B / particle
+//  multinomial: k_step_lazy<PACKED> (reads through lidx), k_quantize_reduce, k_plan_cdf, k_resample_gather_mn
+//  the separate entry points (predict / update / resample, the RCCL sharded step, the adaptive filter):
+//   k_propagate_weight     x,y,yaw -> x,y,yaw,v,w + maximum of w                                   64 B / particle
+//   k_quantize_reduce      w -> per-tile integer totals, sum q^2                                    8 B / particle
+//   k_scan_tiles           tile totals -> exclusive offsets, gate decision (single block)
+//   k_cdf / k_mark         inclusive integer CDF / slot-run markers of this shard                  16 B / particle
+//   k_resolve_gather, k_resample_gather_mn   markers or CDF search -> SoA gather into the other buffer set
+//   k_moments(+final)      weighted first/second moments about particle 0                          40 B / particle
+//  sharded over the peer-to-peer transport: k_step_lazy<sharded>, k_shard_plan_mark (p2p_core.hpp), k_resolve_push
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
