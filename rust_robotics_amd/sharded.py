@@ -649,6 +649,22 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
         for t in range(V, T0):
             shard.step(u, obs_list[t])
         fence(shard)
+        # ... and that stall lands at an unpredictable launch count (a few milliseconds, once): keep warming up in blocks
+        # of 40 steps (replaying the last warm-up observations: a tracking filter does not mind) until two blocks in a
+        # row run at the pace of the fastest one seen, at most 8 blocks
+        best, good = None, 0
+        for _ in range(8):
+            tb = time.perf_counter()
+            for t in range(max(V, T0 - 40), T0):
+                shard.step(u, obs_list[t])
+            fence(shard)
+            blk = torch.tensor([time.perf_counter() - tb], dtype=torch.float64)
+            dist.all_reduce(blk, op=dist.ReduceOp.MAX)
+            blk = float(blk.item())
+            best = blk if best is None else min(best, blk)
+            good = good + 1 if blk <= 1.25 * best else 0
+            if good >= 2:
+                break
         # the sharded step is launch-rate sensitive (7 launches in ~85 us): nothing is instrumented inside the
         # timed region; the kernel times of the instrumented re-run below feed `roofline`
         t0 = time.perf_counter()
