@@ -320,6 +320,47 @@ def test_trajectory_bit_exact_vs_det(fs, det, chunks, read_every, n_observed):
     assert np.hypot(*(pose[:2] - H.true_pose(T)[:2])) < 2.0
 
 
+@pytest.mark.parametrize("algorithm", [1, 2])
+def test_one_launch_plan_equals_the_two_kernel_plan(fs, algorithm, monkeypatch):
+    """rr::k_quantize_plan_mark<FS_WEIGHTS> (integer image, gate, normalise-or-mark in one launch with the tile sums handed
+    over in-kernel) against k_quantize_reduce + k_fs1_plan (RR_PF_FUSED_PLAN=0, read at the first update): the same
+    weights, poses, maps, gate decisions and resample indices, bit for bit, with several tiles and a gate that opens
+    on some updates only."""
+    n, L, T = 30_000, 12, 10  # 15 tiles
+    lms = scene(L, 43)
+
+    def run(fused):
+        monkeypatch.setenv("RR_PF_FUSED_PLAN", "1" if fused else "0")
+        prm = fs.default_params()
+        prm.first_obs_cov = 2.0
+        prm.nth = n / 1.5
+        if algorithm == 2:
+            from rust_robotics_amd.slam import fastslam2
+
+            f = fastslam2.FastSlam2(n, L, seed=78)
+        else:
+            f = fs.FastSlam1(n, L, params=prm, seed=78)
+        out = []
+        for t in range(T):
+            z = np.ascontiguousarray(observations_for(fs, H.true_pose(t + 1), lms, seed=78, step=t))
+            f.update([1.0, 0.1], z)
+            fired = f.last_resample_fired()
+            gp, gm = f.get_state()
+            out.append((fired, f.last_resample_indices().copy() if fired else None, gp.copy(), gm.copy()))
+        return out
+
+    a, b = run(True), run(False)
+    if algorithm == 1:
+        fired = [x[0] for x in a]
+        assert any(fired), fired
+    for t, ((fa, ia, pa, ma), (fb, ib, pb, mb)) in enumerate(zip(a, b)):
+        assert fa == fb, f"gate differs at update {t}"
+        if fa:
+            assert np.array_equal(ia, ib), f"indices differ at update {t}"
+        assert bits_equal(pa, pb), f"poses / weights differ at update {t}"
+        assert bits_equal(ma, mb), f"maps differ at update {t}"
+
+
 def test_trajectory_vs_literal_reference(fs, det, ref):
     n, L, T = 400, 6, 10
     lms = scene(L, 51, half=8.0)
