@@ -420,16 +420,20 @@ __global__ __launch_bounds__(1024) void k_resample_gather_mn(Bufs b, const Ctl* 
 
 // sharded adopt: unpack the received n x (x, y, yaw, v) records into the live buffer set (the
 // plan kernel already made it the other one)
+// slots [self_lo, self_hi) are the ones this rank serves to ITSELF: their records are taken straight from the send
+// buffer (`in_self`, record 0 = slot self_lo) instead of travelling through a send / receive to the same rank
 __global__ __launch_bounds__(kBlock) void k_adopt(Bufs b, const Ctl* __restrict__ ctl,
-                                                 const double* __restrict__ in, uint64_t n) {
+                                                 const double* __restrict__ in, uint64_t n,
+                                                 const double* __restrict__ in_self, uint64_t self_lo, uint64_t self_hi) {
   if (!ctl->fired) return;
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= n) return;
   const int dst = ctl->cur;
-  b.x[dst][k] = in[4 * k];
-  b.y[dst][k] = in[4 * k + 1];
-  b.yaw[dst][k] = in[4 * k + 2];
-  b.v[dst][k] = in[4 * k + 3];
+  const double* __restrict__ r = (k >= self_lo && k < self_hi) ? in_self + 4 * (k - self_lo) : in + 4 * k;
+  b.x[dst][k] = r[0];
+  b.y[dst][k] = r[1];
+  b.yaw[dst][k] = r[2];
+  b.v[dst][k] = r[3];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2210,7 +2214,16 @@ rr_status rr_pf_shard_adopt(rr_pf* h, const double* d_in) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!d_in) return fail(RR_INVALID_PARAMETER, "null d_in");
-  hipLaunchKernelGGL(k_adopt, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, d_in, h->n);
+  hipLaunchKernelGGL(k_adopt, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, d_in, h->n,
+                     (const double*)nullptr, (uint64_t)0, (uint64_t)0);
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+// the same with the self-served slots [self_lo, self_hi) read from d_self (rr_pf_shard_step: no send to oneself)
+static rr_status shard_adopt_with_self(rr_pf* h, const double* d_in, const double* d_self, uint64_t self_lo, uint64_t self_hi) {
+  hipLaunchKernelGGL(k_adopt, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, d_in, h->n, d_self, self_lo,
+                     self_hi);
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
 }
@@ -2680,18 +2693,26 @@ rr_status rr_pf_shard_step(rr_pf* h, rr_comm* c, const double control[2], const 
   }
   // D: gather what the served slots need into one contiguous buffer, exchange the segments
   if ((s = rr_pf_shard_gather_slots(h, first, n_send, c->d_send)) != RR_OK) return s;
+  // (what this rank serves to itself -- nearly everything: systematic resampling moves particles by a boundary's drift --
+  // does not go through a send / receive to the same rank: k_adopt reads it where the gather left it)
   RR_NCCL_TRY(R.GroupStart());
-  uint64_t so = 0, ro = 0;
+  uint64_t so = 0, ro = 0, self_so = 0, self_lo = 0, self_hi = 0;
   for (int g = 0; g < G; ++g) {
     const uint64_t ns = (uint64_t)M[(size_t)r * G + g], nr = (uint64_t)M[(size_t)g * G + r];
-    if (ns) RR_NCCL_TRY(R.Send(c->d_send + 4 * so, 4 * ns, kNcclFloat64, g, c->comm, h->stream));
-    if (nr) RR_NCCL_TRY(R.Recv(c->d_recv + 4 * ro, 4 * nr, kNcclFloat64, g, c->comm, h->stream));
+    if (g == r) {
+      self_so = so;
+      self_lo = ro;
+      self_hi = ro + nr;  // (ns == nr for g == r)
+    } else {
+      if (ns) RR_NCCL_TRY(R.Send(c->d_send + 4 * so, 4 * ns, kNcclFloat64, g, c->comm, h->stream));
+      if (nr) RR_NCCL_TRY(R.Recv(c->d_recv + 4 * ro, 4 * nr, kNcclFloat64, g, c->comm, h->stream));
+    }
     so += ns;
     ro += nr;
   }
   RR_NCCL_TRY(R.GroupEnd());
   // E: adopt
-  return rr_pf_shard_adopt(h, c->d_recv);
+  return shard_adopt_with_self(h, c->d_recv, c->d_send + 4 * self_so, self_lo, self_hi);
 }
 
 uint64_t rr_pf_shard_last_migrated(const rr_pf* h) { return h ? h->last_migrated : 0; }
