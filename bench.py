@@ -39,7 +39,13 @@ FP64_VALU_PEAK = 256 * 4 * 16 * 2.4e9  # FP64 FMA lane-instructions / s: 256 CUs
 K1_BYTES = {"systematic": 72.0, "multinomial": 64.0}
 # sharded legs: a process that has torch's HIP context loaded stalls once on the host (~40 ms) somewhere in its first few
 # hundred launches; this many extra untimed steps keep that out of the timed region
-EXTRA_WARMUP = 300
+EXTRA_WARMUP = 1000
+# every leg: the device itself needs ~50 ms of this work before it runs at its steady rate -- measured, MCL 1e6 x 32 with
+# --steps 20: 51.2 us/step after 5 warm-up steps, 48.3 after 300, 46.5 after 1000, 47.0 after 3000 (`k_step_lazy` 35.8 ->
+# 31.2 us); FastSLAM 1e5 x 200: 408 us/update after 5 warm-up updates, 397 after 50.  These untimed steps run BEFORE the W
+# warm-up steps of the command line and are reported as `device_warmup_steps`; the timed region is still exactly K steps.
+DEVICE_WARMUP_MCL = 1000
+DEVICE_WARMUP_FS = 60
 FS1_BYTES_PER_UPDATE = 96.0  # k_fs1_observe: read 48 B + write 48 B per (particle, observed landmark), EKF branch
 
 
@@ -341,9 +347,13 @@ def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True):
         prm.first_obs_cov = 0.5
         prm.nth = n / 1.5 * float(os.environ.get("RR_BENCH_NTH_SCALE", "1"))  # development knob: 0 = never resample, 10 = every step
         f = fs.FastSlam1(n, L, params=prm, seed=2, obs_chunks=int(os.environ.get("RR_BENCH_OBS_CHUNKS", "0")))  # 0 = the engine's own choice
+    D = DEVICE_WARMUP_FS
     zs = [np.array(fs.get_observations(H.true_pose(t + 1, v=0.5), [tuple(p) for p in lms], seed=2, step=t)).reshape(-1, 3)
-          for t in range(2 * K + W)]
+          for t in range(D + 2 * K + W)]
     u = [0.5, 0.1]
+    for t in range(D):  # device warm-up (see DEVICE_WARMUP_FS), then time moves on
+        f.update_async(u, zs[t])
+    zs = zs[D:]
     for t in range(W):
         f.update_async(u, zs[t])
     f.synchronize()
@@ -402,6 +412,7 @@ def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True):
         "kernel_launches": {k: v[0] for k, v in prof.items() if v[0]},
         "ms_per_step_instrumented": dt_i / K * 1e3,
         "obs_chunks": chunks,
+        "device_warmup_steps": DEVICE_WARMUP_FS,
         "best_particle": {"index": i, "weight": w, "pose": [float(a) for a in pose]},
     }
     if with_cpu:
@@ -626,7 +637,8 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
     world = ctx.world
     # time only moves forward for every filter: W warm-up + K timed + K estimate-every-step + K dispatch-stamped + K breakdown
     # steps; the sharded legs also validate (12 steps) and warm up 64 steps longer
-    obs_list = make_scene(L, W + 4 * K + (EXTRA_WARMUP if ctx.sharded else 0), seed=1)
+    D = 0 if ctx.sharded else DEVICE_WARMUP_MCL  # (the sharded legs warm up EXTRA_WARMUP steps + settle blocks inside bench_sharded)
+    obs_list = make_scene(L, D + W + 4 * K + (EXTRA_WARMUP if ctx.sharded else 0), seed=1)
     scheme = 1 if args.scheme == "systematic" else 0
     lik = 0 if args.likelihood == "fused" else 1
     extra = {}
@@ -647,6 +659,9 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
         pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=ctx.local_rank,
                                                         resample_scheme=scheme, likelihood_mode=lik)
         u = [1.0, 0.1]
+        for t in range(D):  # device warm-up (see DEVICE_WARMUP_MCL), then time moves on
+            pf.step_async(u, obs_list[t])
+        obs_list = obs_list[D:]
         for t in range(W):
             pf.step_async(u, obs_list[t])
         pf.synchronize()
@@ -761,6 +776,7 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
                     "`fastslam` leg of this line (DESIGN.md section 4)",
         },
         "kernel_ms_avg": step_kernel_ms,
+        "device_warmup_steps": (EXTRA_WARMUP if ctx.sharded else DEVICE_WARMUP_MCL),
         "ms_per_step_instrumented": res.get("seconds_instrumented", 0.0) / K * 1e3,
         "estimate": res.get("estimate"),
     }
@@ -872,7 +888,7 @@ def main():
             try:
                 leg = leg_fastslam(args, 100_000, 200, 50, 5, with_cpu=with_cpu, breakdown=not args.no_breakdown)
                 out["fastslam"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernel_ms_avg",
-                                                       "obs_chunks") if k in leg}
+                                                       "obs_chunks", "device_warmup_steps") if k in leg}
                 if "cpu_baseline" in leg:
                     out["fastslam"]["cpu_baseline"] = leg["cpu_baseline"]
             except Exception as e:  # noqa: BLE001 -- the headline line survives a failing extra leg
