@@ -16,7 +16,9 @@
 //   k_quantize_plan_mark   integer image + tile sums handed over inside the launch + gate + slot-run markers
 //                          (+ the mean try_step returns); beyond 2^20 particles k_quantize_reduce + k_plan_mark
 //                          (resample_core.hpp)                                                      8-12 B / particle
-//  multinomial: k_step_lazy<PACKED> (reads through lidx), k_quantize_reduce, k_plan_cdf, k_resample_gather_mn
+//  multinomial: k_step_lazy<PACKED> (reads through lidx), k_quantize_reduce, k_plan_cdf (CDF + guide markers),
+//               k_guide_resolve, k_resample_guide_mn (guide table over the target space; sharded / adaptive / beyond
+//               8.4e6 particles: k_resample_gather_mn, coarse table of the CDF in LDS)
 //  the separate entry points (predict / update / resample, the RCCL sharded step, the adaptive filter):
 //   k_propagate_weight     x,y,yaw -> x,y,yaw,v,w + maximum of w                                   64 B / particle
 //   k_quantize_reduce      w -> per-tile integer totals, sum q^2                                    8 B / particle
@@ -416,6 +418,41 @@ __global__ __launch_bounds__(1024) void k_resample_gather_mn(Bufs b, const Ctl* 
     else copy_particle(b, src, dst, j, k, false, nullptr);
     if (idx_out) idx_out[k] = (unsigned int)j;
   }
+}
+
+// The same draws through the guide table (resample_core.hpp: buckets of the target space, built by k_plan_cdf's markers
+// and k_guide_resolve): two adjacent table entries bracket the answer, the CDF is only read inside the bracket -- not at
+// all when a heavy particle spans the whole bucket.  No LDS table to stage, one draw per thread.  Same index as the
+// lower bound over the whole CDF (tests: identical to the coarse-table kernel and to the literal walk).
+struct __attribute__((packed, aligned(4))) GuidePair {
+  unsigned int lo, hi;
+};
+__global__ __launch_bounds__(kBlock) void k_resample_guide_mn(Bufs b, const Ctl* __restrict__ ctl,
+                                                             const uint64_t* __restrict__ cdf,
+                                                             const unsigned int* __restrict__ guide, int guide_log2,
+                                                             const double* __restrict__ r_explicit,
+                                                             unsigned int* __restrict__ idx_out,
+                                                             unsigned int* __restrict__ lidx_out, GatherArgs a) {
+  if (!ctl->fired) return;
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (k >= a.n_slots) return;
+  const uint64_t total = ctl->total;
+  const int s = rr::guide_shift(total, guide_log2);
+  const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, a.first_slot + k, a.seed, a.rstep, r_explicit, k);
+  const uint64_t bucket = target >> s;
+  const GuidePair g = *reinterpret_cast<const GuidePair*>(guide + bucket);
+  const uint64_t lo = g.lo;
+  const uint64_t hi = bucket < (total >> s) ? (uint64_t)g.hi : a.n_src - 1;  // the last bucket ends with the last source
+  uint64_t j = lo, end = hi;  // the answer lies in [j, end]: no CDF entry is read when the bracket is one source
+  while (j < end) {
+    const uint64_t mid = j + ((end - j) >> 1);
+    if (cdf[mid] >= target) end = mid;
+    else j = mid + 1;
+  }
+  const int dst = ctl->cur, src = dst ^ 1;
+  if (lidx_out) lidx_out[k] = (unsigned int)j;  // lazy: the next propagate kernel reads through it
+  else copy_particle(b, src, dst, j, k, false, nullptr);
+  if (idx_out) idx_out[k] = (unsigned int)j;
 }
 
 // sharded adopt: unpack the received n x (x, y, yaw, v) records into the live buffer set (the
@@ -948,6 +985,12 @@ struct rr_pf {
   uint64_t* cdf_coarse = nullptr;  // every 2^coarse_log2-th CDF entry (multinomial gather's LDS table)
   int coarse_log2 = 6;  // finest window whose table still fits the LDS (raised at create time for large N)
   uint64_t n_coarse = 0;
+  // multinomial search through a guide table over the target space (k_resample_guide_mn; single shard, fused plan;
+  // RR_MN_GUIDE=0: the coarse-table search instead); allocated on first use
+  unsigned int* guide = nullptr;          // 2^guide_log2 + 2 entries
+  unsigned int* guide_markers = nullptr;  // zero between steps
+  unsigned int* guide_carry = nullptr;    // one per kResolveSlots buckets; [0] = 1 for good
+  int guide_log2 = 0;                     // 0: switched off
   uint64_t* tile_total = nullptr;
   uint64_t* tile_q2 = nullptr;
   unsigned int* idx = nullptr;
@@ -1206,6 +1249,57 @@ rr_status launch_sums(rr_pf* h, int mode, int scheme, double rho_override) {
   return RR_OK;
 }
 
+// the guide table of the multinomial search, made when the first multinomial resample of a single-shard filter asks for it
+rr_status ensure_guide(rr_pf* h) {
+  if (h->guide_log2 != 0) return RR_OK;  // made already, or switched off
+  if (const char* e = std::getenv("RR_MN_GUIDE")) {
+    if (std::atoi(e) == 0) {
+      h->guide_log2 = -1;
+      return RR_OK;
+    }
+  }
+  int lg = 10;
+  while ((1ull << lg) < h->cap) ++lg;  // about one bucket per particle: between n/2 and n buckets are in use
+  if (const char* e = std::getenv("RR_MN_GUIDE_LOG2")) lg = std::max(10, std::min(28, std::atoi(e)));
+  const size_t nb = ((size_t)1 << lg) + rr::kResolveSlots + 2, nc = nb / rr::kResolveSlots + 2;
+  const unsigned int one = 1;  // bucket 0 starts at source 0; no source ever writes carry[0]
+  const auto make = [&]() -> hipError_t {
+    hipError_t e;
+    if ((e = hipMalloc(&h->guide, nb * sizeof(unsigned int))) != hipSuccess) return e;
+    if ((e = hipMalloc(&h->guide_markers, nb * sizeof(unsigned int))) != hipSuccess) return e;
+    if ((e = hipMalloc(&h->guide_carry, nc * sizeof(unsigned int))) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(h->guide, 0, nb * sizeof(unsigned int), h->stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(h->guide_markers, 0, nb * sizeof(unsigned int), h->stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(h->guide_carry, 0, nc * sizeof(unsigned int), h->stream)) != hipSuccess) return e;
+    if ((e = hipMemcpyAsync(h->guide_carry, &one, sizeof(one), hipMemcpyHostToDevice, h->stream)) != hipSuccess) return e;
+    return hipStreamSynchronize(h->stream);  // `one` is a local
+  };
+  const hipError_t e = make();
+  if (e != hipSuccess) {
+    (void)hipFree(h->guide);
+    (void)hipFree(h->guide_markers);
+    (void)hipFree(h->guide_carry);
+    h->guide = h->guide_markers = h->guide_carry = nullptr;
+    return rr::fail(RR_RUNTIME_ERROR, std::string("guide table of the multinomial search: ") + hipGetErrorString(e));
+  }
+  h->guide_log2 = lg;
+  return RR_OK;
+}
+
+// the multinomial draws -> source indices (and, unless lidx is given, the particles themselves)
+void launch_mn_search(rr_pf* h, bool guide, const double* r_explicit_dev, unsigned int* lidx, const GatherArgs& g) {
+  if (guide) {
+    hipLaunchKernelGGL(rr::k_guide_resolve, dim3((unsigned)((((size_t)1 << h->guide_log2) + rr::kResolveSlots) / rr::kResolveSlots)),
+                       dim3(kBlock), 0, h->stream, h->ctl, h->guide_markers, h->guide_carry, h->guide, h->guide_log2);
+    hipLaunchKernelGGL(k_resample_guide_mn, dim3(grid_for(g.n_slots, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->cdf,
+                       h->guide, h->guide_log2, r_explicit_dev, h->idx, lidx, g);
+    return;
+  }
+  hipLaunchKernelGGL(k_resample_gather_mn, dim3(std::min<unsigned>(grid_for(h->n, h->mn_block), (unsigned)h->mn_grid)), dim3(h->mn_block),
+                     h->n_coarse * sizeof(uint64_t), h->stream, h->b, h->ctl, h->cdf, h->cdf_coarse, h->coarse_log2, h->n_coarse,
+                     r_explicit_dev, h->idx, lidx, g);
+}
+
 // The resample pipeline: integer image -> plan (gate) + CDF -> gather.  Every kernel after the
 // plan decides on the device whether it has anything to do.  mode 0 = gate, 1 = forced.
 rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, const double* r_explicit_dev,
@@ -1220,6 +1314,11 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
   pa.lazy_gather = lazy ? 1 : 0;
   const bool fused = h->n_tiles <= (uint64_t)rr::kFusedMaxTiles;
   const bool sys = scheme == RR_RESAMPLE_SYSTEMATIC;
+  bool guide = false;
+  if (!sys && fused && h->n == h->n_global) {
+    if (rr_status st = ensure_guide(h)) return st;
+    guide = h->guide_log2 > 0;
+  }
   if (!fused) {
     Timed t(h, RR_K_SCAN_TILES);
     hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl,
@@ -1254,7 +1353,8 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
                          h->carry);
     else if (fused)
       hipLaunchKernelGGL(rr::k_plan_cdf, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total,
-                         h->tile_q2, h->n_tiles, pa, h->cdf, h->cdf_coarse, h->coarse_log2);
+                         h->tile_q2, h->n_tiles, pa, h->cdf, guide ? (uint64_t*)nullptr : h->cdf_coarse, h->coarse_log2,
+                         guide ? h->guide_markers : (unsigned int*)nullptr, h->guide_carry, h->guide_log2);
     else
       hipLaunchKernelGGL(rr::k_cdf, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total, h->cdf,
                          h->cdf_coarse, h->coarse_log2);
@@ -1269,9 +1369,7 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
     g.seed = h->opt.seed;
     g.rstep = h->rstep;
     g.scheme = scheme;
-    hipLaunchKernelGGL(k_resample_gather_mn, dim3(std::min<unsigned>(grid_for(h->n, h->mn_block), (unsigned)h->mn_grid)), dim3(h->mn_block),
-                       h->n_coarse * sizeof(uint64_t), h->stream, h->b, h->ctl, h->cdf, h->cdf_coarse, h->coarse_log2, h->n_coarse,
-                       (const double*)nullptr, h->idx, h->lidx, g);
+    launch_mn_search(h, guide, (const double*)nullptr, h->lidx, g);
     h->maybe_pending = h->pending_lidx = true;
   } else if (lazy) {
     h->maybe_pending = true;  // the next k_step_lazy (or materialise) moves the particles
@@ -1289,9 +1387,7 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
       g.rstep = h->rstep;
       g.scheme = scheme;
       g.to_staging = 0;
-      hipLaunchKernelGGL(k_resample_gather_mn, dim3(std::min<unsigned>(grid_for(h->n, h->mn_block), (unsigned)h->mn_grid)), dim3(h->mn_block),
-                         h->n_coarse * sizeof(uint64_t), h->stream, h->b, h->ctl, h->cdf, h->cdf_coarse, h->coarse_log2, h->n_coarse,
-                         r_explicit_dev, h->idx, (unsigned int*)nullptr, g);
+      launch_mn_search(h, guide, r_explicit_dev, (unsigned int*)nullptr, g);
     }
   }
   RR_HIP_TRY(hipGetLastError());
@@ -1323,7 +1419,8 @@ rr_status resample_adaptive(rr_pf* h, const double* r_explicit_dev) {
     const dim3 grid((unsigned)h->n_tiles), block(rr::kTileBlock);
     if (fused)
       hipLaunchKernelGGL(rr::k_plan_cdf, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total,
-                         h->tile_q2, h->n_tiles, pa, h->cdf, h->cdf_coarse, h->coarse_log2);
+                         h->tile_q2, h->n_tiles, pa, h->cdf, h->cdf_coarse, h->coarse_log2, (unsigned int*)nullptr,
+                         (unsigned int*)nullptr, 0);
     else
       hipLaunchKernelGGL(rr::k_cdf, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total, h->cdf,
                          h->cdf_coarse, h->coarse_log2);
@@ -1751,6 +1848,9 @@ void rr_pf_destroy(rr_pf* h) {
   (void)hipFree(h->w);
   (void)hipFree(h->cdf);
   (void)hipFree(h->cdf_coarse);
+  (void)hipFree(h->guide);
+  (void)hipFree(h->guide_markers);
+  (void)hipFree(h->guide_carry);
   (void)hipFree(h->tile_total);
   (void)hipFree(h->tile_q2);
   (void)hipFree(h->idx);

@@ -409,6 +409,35 @@ __device__ inline void store_cdf(const TileScan& t, uint64_t off, uint64_t i0, u
   }
 }
 
+// ---- guide table of the multinomial search (index search: bucket the TARGET space, not the index space)
+// The draws' targets are uniform on [1, T].  Cut [0, T] into buckets of 2^s targets, s the smallest shift that leaves at
+// most 2^guide_log2 buckets, and keep guide[k] = first source i with C_i >= k * 2^s: a draw with target t then lies in
+// [guide[t >> s], guide[(t >> s) + 1]] -- every bucket is hit with the same probability and holds ~n / #buckets CDF
+// entries on average, a heavy particle spans many buckets and is found WITHOUT reading the CDF at all.  Source i is the
+// entry of the bucket run [H_{i-1}, H_i), H_i = (C_i >> s) + 1: the same marker / carry / running-maximum machinery as the
+// systematic resample's slot runs (below), with a trivial H.  Bucket 0 always starts at source 0 (carry[0] = 1, set once).
+constexpr int kGuideTile = 2 * 256;  // buckets per resolve workgroup (= kResolveSlots, asserted below)
+
+__host__ __device__ inline int guide_shift(uint64_t total, int guide_log2) {
+  const int bits = total ? 64 - __builtin_clzll((unsigned long long)total) : 0;  // bit length of T
+  return bits > guide_log2 ? bits - guide_log2 : 0;
+}
+
+__device__ inline void mark_guide(const TileScan& t, uint64_t off, uint64_t i0, uint64_t n, int s,
+                                  unsigned int* __restrict__ markers, unsigned int* __restrict__ carry) {
+  uint64_t h_run = (off >> s) + 1;  // buckets settled by the sources before this thread's first
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    if (t.q[j] == 0 || i0 + j >= n) continue;
+    const uint64_t h = ((off + t.c[j]) >> s) + 1;
+    if (h > h_run) {
+      markers[h_run] = (unsigned int)(i0 + j + 1);
+      for (uint64_t b = (h_run + kGuideTile - 1) / kGuideTile; b * kGuideTile < h; ++b) carry[b] = (unsigned int)(i0 + j + 1);
+      h_run = h;
+    }
+  }
+}
+
 static __global__ __launch_bounds__(kTileBlock) void k_cdf(const double* __restrict__ w, const Ctl* __restrict__ ctl,
                                                       ImageArgs a, const uint64_t* __restrict__ tile_offset,
                                                       uint64_t* __restrict__ cdf, uint64_t* __restrict__ coarse,
@@ -431,7 +460,9 @@ static __global__ __launch_bounds__(kTileBlock) void k_plan_cdf(const double* __
                                                            ImageArgs a, const uint64_t* __restrict__ tile_total,
                                                            const uint64_t* __restrict__ tile_q2, uint64_t n_tiles,
                                                            PlanArgs pa, uint64_t* __restrict__ cdf,
-                                                           uint64_t* __restrict__ coarse, int coarse_log2) {
+                                                           uint64_t* __restrict__ coarse, int coarse_log2,
+                                                           unsigned int* __restrict__ guide_markers,
+                                                           unsigned int* __restrict__ guide_carry, int guide_log2) {
   __shared__ uint64_t s4[4 * (kTileBlock / kWave)];
   __shared__ uint64_t s_w[kTileBlock / kWave];
   const TileSums ts = tile_sums(tile_total, tile_q2, n_tiles, s4);
@@ -443,6 +474,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_plan_cdf(const double* __
   const TileScan t = tile_scan(w, a, mode, shift, blockIdx.x, s_w);
   const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
   store_cdf(t, ts.pre + t.thread_off, i0, a.n, cdf, coarse, coarse_log2);
+  if (guide_markers) mark_guide(t, ts.pre + t.thread_off, i0, a.n, guide_shift(ts.tot, guide_log2), guide_markers, guide_carry);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -461,6 +493,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_plan_cdf(const double* __
 #endif
 constexpr int kResolveRows = RR_RESOLVE_ROWS;
 constexpr int kResolveSlots = kResolveRows * kBlock;  // slots per resolve workgroup
+static_assert(kGuideTile == kResolveSlots, "the guide table is resolved by resolve_tile");
 
 // this thread's 8 consecutive sources: exclusive CDF prefix `off`, inclusive prefixes off + c[j]
 // offspring (may be null): number of output slots each of this thread's sources feeds
@@ -842,6 +875,23 @@ __device__ inline void resolve_tile(unsigned int* __restrict__ markers, const un
     for (int q = 0; q < kBlock / kWave; ++q) row_max = s_m[q] > row_max ? s_m[q] : row_max;
     run = row_max;
     __syncthreads();
+  }
+}
+
+// guide markers -> guide table (and the markers are cleared for the next step)
+static __global__ __launch_bounds__(kBlock) void k_guide_resolve(const Ctl* __restrict__ ctl, unsigned int* __restrict__ markers,
+                                                            const unsigned int* __restrict__ carry,
+                                                            unsigned int* __restrict__ guide, int guide_log2) {
+  if (!ctl->fired) return;
+  const uint64_t total = ctl->total;
+  const uint64_t n_buckets = (total >> guide_shift(total, guide_log2)) + 1;
+  if ((uint64_t)blockIdx.x * kResolveSlots >= n_buckets) return;
+  unsigned int idx[kResolveRows];
+  resolve_tile(markers, carry, n_buckets, blockIdx.x, idx);
+#pragma unroll
+  for (int r = 0; r < kResolveRows; ++r) {
+    const uint64_t k = (uint64_t)blockIdx.x * kResolveSlots + (uint64_t)r * kBlock + threadIdx.x;
+    if (k < n_buckets) guide[k] = idx[r];
   }
 }
 

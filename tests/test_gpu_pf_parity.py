@@ -438,6 +438,45 @@ def test_one_launch_plan_equals_the_two_kernel_plan(loc, mcl, monkeypatch):
         assert_bits_equal(ea, eb, f"step {t} in-step estimate")
 
 
+@pytest.mark.parametrize("n,guide_log2", [(300_000, None), (70_001, "10"), (5, None)])
+def test_guide_table_search_equals_the_coarse_table_search(loc, n, guide_log2, monkeypatch):
+    """Multinomial draws through the guide table over the target space (k_plan_cdf's bucket markers, k_guide_resolve,
+    k_resample_guide_mn) against the coarse-table search of the CDF (RR_MN_GUIDE=0, read at the filter's first multinomial
+    resample): the same source index for every draw, lazily (MCL step) and eagerly (PF resample), also with far fewer
+    buckets than particles (RR_MN_GUIDE_LOG2=10: long brackets, the binary search inside them does the work)."""
+    L, T = 8, 6
+    lms = H.landmarks_grid(L, 5)
+
+    def run(guide):
+        monkeypatch.setenv("RR_MN_GUIDE", "1" if guide else "0")
+        if guide_log2 is not None:
+            monkeypatch.setenv("RR_MN_GUIDE_LOG2", guide_log2)
+        out = []
+        mcl = loc.MonteCarloLocalizer(loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.5),
+                                      seed=21, resample_scheme=0, record_indices=True)
+        pf = loc.ParticleFilterLocalizer(loc.ParticleFilterConfig(n_particles=n, range_noise=0.5, resample_threshold=1.0),
+                                         seed=22, resample_scheme=0, record_indices=True)
+        rng = np.random.default_rng(23)
+        for t in range(T):
+            obs = H.observations(lms, H.true_pose(t + 1), 0.5, rng)
+            mcl.step_async([1.0, 0.1], obs)
+            assert mcl.last_resample_fired()
+            out.append(mcl.last_resample_indices().copy())
+            out.append(mcl.get_particles_array().copy())
+            pf.predict([1.0, 0.1])
+            pf.update(obs)
+            pf.resample()
+            if pf.last_resample_fired():
+                out.append(pf.last_resample_indices().copy())
+            out.append(pf.get_particles_array().copy())
+        return out
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b)
+    for k, (x, y) in enumerate(zip(a, b)):
+        assert np.array_equal(x, y), f"record {k} differs"
+
+
 def test_two_filters_on_one_device_run_side_by_side(loc):
     """Two handles stepping asynchronously on their own streams: the one-launch plans spin inside the kernel, and only one
     handle per device at a time may launch them (rr::spin_permit), so the two filters share the device without waiting
