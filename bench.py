@@ -287,6 +287,8 @@ class Ctx:
         self.rank = int(os.environ.get("RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if os.environ.get("RR_BENCH_SHARE_DEVICE"):  # development knob: every rank on device 0, so that the multi-process
+            self.local_rank = 0                       # flow (launcher, gloo group, IPC hand-off, ladder) runs on a one-GPU box
         self.sharded = self.world > 1 or args.force_sharded
         self.dist = None
 

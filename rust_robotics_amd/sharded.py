@@ -490,7 +490,19 @@ class TorchShard:
 
     def __init__(self, rank, world, device, n_local, dist, **kw):
         self.hs = HipShard(rank, world, device, n_local, **kw)
-        self.group = dist.new_group(backend="nccl")  # collective: every rank constructs its TorchShard together
+        try:
+            self.group = dist.new_group(backend="nccl")  # collective: every rank constructs its TorchShard together
+            # the communicator is only made by the first collective: run one now, so that a machine on which RCCL cannot
+            # connect the ranks fails HERE (bench_sharded's ladder then moves on) and not in the middle of a step
+            torch = self.hs.torch
+            probe = torch.ones(1, dtype=torch.float64, device=f"cuda:{device}")
+            dist.all_reduce(probe, group=self.group)
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError(f"trial all-reduce over {world} ranks returned {probe.item()}")
+        except Exception:
+            self.hs.close()
+            raise
         self.loc = ShardedLocalizer(self.hs, dist, group=self.group)
 
     def step(self, u, obs) -> None:
@@ -616,15 +628,22 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
                     alive = agree(not p2p.timed_out())
                     if not alive:
                         break
+            why = ""
             if alive and not p2p.timed_out():
                 exp = ref.particles() if ref is not None else whole.get_particles_array()[rank * n_local:(rank + 1) * n_local]
-                same = np.array_equal(p2p.particles().view(np.uint64), np.ascontiguousarray(exp).view(np.uint64))
+                got = p2p.particles().view(np.uint64)
+                exp = np.ascontiguousarray(exp).view(np.uint64)
+                same = np.array_equal(got, exp)
+                if not same:
+                    why = f"rank {rank}: {int(np.any(got != exp, axis=1).sum())} of {n_local} particles differ"
             else:
                 same = False
+                why = f"rank {rank}: a wait for a peer's flag gave up" + ("" if alive else " on the first exchange")
             use_p2p = agree(same)
             against = f"the {ref_kind} transport" if ref is not None else "the unsharded filter of all particles"
             notes.append(f"peer-to-peer transport validated bit-identical to {against} over {V} steps" if use_p2p else
-                         f"peer-to-peer transport FAILED validation against {against}")
+                         f"peer-to-peer transport FAILED validation against {against}" +
+                         (f" ({why})" if why else " (on another rank)"))
             del whole
     if not use_p2p and ref is None:
         raise RuntimeError("no working sharded transport on this machine: " + "; ".join(notes))
