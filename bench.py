@@ -40,6 +40,50 @@ K1_BYTES = {"systematic": 72.0, "multinomial": 64.0}
 # sharded legs: a process that has torch's HIP context loaded stalls once on the host (~40 ms) somewhere in its first few
 # hundred launches; this many extra untimed steps keep that out of the timed region
 EXTRA_WARMUP = 1000
+
+# ---- one JSON line on stdout, whatever the native libraries print; progress on stderr; a deadline
+_T0 = time.time()
+_OUT = {"fd": None, "partial": None, "emitted": False}
+
+
+def log(msg):
+    """progress on stderr (the driver keeps it): which leg a rank is in when something takes long"""
+    sys.stderr.write(f"[bench rank {os.environ.get('RANK', '0')} +{time.time() - _T0:6.1f}s] {msg}\n")
+    sys.stderr.flush()
+
+
+def claim_stdout():
+    """gloo and RCCL print banners and warnings on file descriptor 1 from C++: from here on descriptor 1 IS stderr, and
+    the one JSON line goes to a private copy of the real stdout (emit)."""
+    if _OUT["fd"] is None:
+        sys.stdout.flush()
+        _OUT["fd"] = os.dup(1)
+        os.dup2(2, 1)
+
+
+def start_deadline(rank):
+    """A rank that dies or a transport that stalls must not keep the whole job (and whoever launched it) waiting for a
+    chain of collective time-outs: after RR_BENCH_DEADLINE_S seconds (default 600, 0 = none) rank 0 prints what it has --
+    the headline leg if that finished, flagged `deadline_exceeded` -- and every rank leaves."""
+    import threading
+
+    limit = float(os.environ.get("RR_BENCH_DEADLINE_S", "600"))
+    if limit <= 0:
+        return
+
+    def fire():
+        log(f"deadline of {limit:.0f} s exceeded -- leaving")
+        rc = 3
+        if rank == 0 and _OUT["partial"] is not None and not _OUT["emitted"]:
+            line = dict(_OUT["partial"])
+            line["deadline_exceeded"] = True
+            emit(line)
+            rc = 0
+        os._exit(rc if rank == 0 else 0)
+
+    t = threading.Timer(limit, fire)
+    t.daemon = True
+    t.start()
 # every leg: the device itself needs ~50 ms of this work before it runs at its steady rate -- measured, MCL 1e6 x 32 with
 # --steps 20: 51.2 us/step after 5 warm-up steps, 48.3 after 300, 46.5 after 1000, 47.0 after 3000 (`k_step_lazy` 35.8 ->
 # 31.2 us); FastSLAM 1e5 x 200: 408 us/update after 5 warm-up updates, 397 after 50.  These untimed steps run BEFORE the W
@@ -502,6 +546,7 @@ def leg_fastslam_sharded(ctx, n, L, K, W):
 
     kind = None
     for cand in (("p2p", "rccl") if ctx_transport(ctx) == "auto" else (ctx_transport(ctx),)):
+        log(f"fastslam sharded: trying the {cand} transport")
         fv = attempt(cand, nv, Lv, 2)
         if fv is None:
             continue
@@ -522,42 +567,64 @@ def leg_fastslam_sharded(ctx, n, L, K, W):
     if kind is None:
         return {"error": "sharded FastSLAM: no transport reproduced the unsharded filter on this machine", "transport_note": "; ".join(notes)}
 
-    f = make(kind, n, L, 0)
+    log(f"fastslam sharded: {kind} transport validated, timing {n} particles x {L} landmarks per GPU")
+    f = attempt(kind, n, L, 0)
+    if f is None:
+        return {"error": "sharded FastSLAM: the validated transport could not be set up at full size", "transport_note": "; ".join(notes)}
     zs = observations(fs1_scene(L, 2), 2 * K + W, 2)
+    # From here to the end every rank runs the SAME sequence of collectives whatever happens on its device: an error of one
+    # rank (a latched peer-wait time-out surfaces as an exception of synchronize / update_async) is remembered, not raised,
+    # and the ranks decide together at the end -- a rank that left early would leave the others in a barrier.
+    trouble = []
+
+    def quiet(fn, *a):
+        try:
+            return fn(*a)
+        except Exception as e:  # noqa: BLE001
+            if not trouble:
+                trouble.append(f"rank {rank}: {type(e).__name__}: {e}")
+            return None
 
     def fence():
-        f.synchronize()
+        quiet(f.synchronize)
         torch.cuda.synchronize()
         dist.barrier()
-        f.synchronize()
+        quiet(f.synchronize)
         torch.cuda.synchronize()
 
     for t in range(W):
-        f.update_async(u, zs[t])
+        quiet(f.update_async, u, zs[t])
     fence()
-    f.profile_enable(2)  # k_fs1_observe timed by its own dispatch timestamps, inside the timed region
-    f.profile_reset()
+    if not agree(not trouble and not quiet(f.timed_out)):  # do not spend K steps on a transport that is already dead
+        note = "; ".join(notes + trouble + ["a peer wait gave up during the warm-up steps at full size"])
+        quiet(f.close)
+        return {"error": "sharded FastSLAM: the transport failed at full size", "transport_note": note}
+    quiet(f.profile_enable, 2)  # k_fs1_observe timed by its own dispatch timestamps, inside the timed region
+    quiet(f.profile_reset)
     t0 = time.perf_counter()
     for t in range(W, W + K):
-        f.update_async(u, zs[t])
+        quiet(f.update_async, u, zs[t])
     fence()
     dt = time.perf_counter() - t0
-    dom = f.profile_read()["k_fs1_observe"]
+    dom = (quiet(f.profile_read) or {}).get("k_fs1_observe", (0, 0.0))
     tmax = torch.tensor([dt], dtype=torch.float64)
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    timed_out = f.timed_out()
-    f.profile_enable(1)
-    f.profile_reset()
+    timed_out = bool(quiet(f.timed_out))
+    quiet(f.profile_enable, 1)
+    quiet(f.profile_reset)
     t1 = time.perf_counter()
     for t in range(W + K, W + 2 * K):
-        f.update_async(u, zs[t])
-    f.synchronize()
+        quiet(f.update_async, u, zs[t])
+    quiet(f.synchronize)
     dt_i = time.perf_counter() - t1
-    prof = f.profile_read()
-    f.profile_enable(0)
-    chunks = f.counters()[2]
+    prof = quiet(f.profile_read) or {}
+    quiet(f.profile_enable, 0)
+    chunks = (quiet(f.counters) or (0, 0, 0))[2]
     dist.barrier()
-    f.close()
+    quiet(f.close)
+    if not agree(not trouble and not timed_out):
+        return {"error": "sharded FastSLAM: the transport failed inside the timed region",
+                "transport_note": "; ".join(notes + trouble + (["a peer wait gave up"] if timed_out else []))}
     seconds = float(tmax.item())
     updates = float(sum(n * world * len(zs[t]) for t in range(W, W + K)))
     k_n, k_ms = dom
@@ -844,6 +911,8 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
+    claim_stdout()
+    start_deadline(int(os.environ.get("RANK", "0")))
     if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
         os.environ["NCCL_DEBUG"] = "WARN"  # keep RCCL's version banner off stdout
     ctx = Ctx(args)
@@ -883,11 +952,16 @@ def main():
         emit(leg_fastslam(args, n, L, K, W, v2=args.workload == "fastslam2", with_cpu=with_cpu, breakdown=not args.no_breakdown))
         return
 
+    log(f"headline leg: MCL {n} particles/GPU x {L} landmarks, world {ctx.world}")
     out = leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=not args.no_breakdown)
+    if ctx.rank == 0:
+        _OUT["partial"] = out
+    log("headline leg done")
     if not args.no_extra_legs and args.scheme == "systematic" and (n, L) == (1_000_000, 32):
         if not ctx.sharded:
             # configs[2], the HBM-bound workload, in the same run: its roofline fraction is the one the HBM target is about
             try:
+                log("extra leg fastslam (configs[2])")
                 leg = leg_fastslam(args, 100_000, 200, 50, 5, with_cpu=with_cpu, breakdown=not args.no_breakdown)
                 out["fastslam"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernel_ms_avg",
                                                        "obs_chunks", "device_warmup_steps") if k in leg}
@@ -899,6 +973,7 @@ def main():
             per_gpu = 1_000_000 // 8 if ctx.world == 8 else 125_000
             # the extra legs never take the headline down with them: an exception becomes an "error" entry
             def guarded(name, fn):
+                log(f"extra leg {name}")
                 try:
                     return fn()
                 except BaseException as e:  # noqa: BLE001 -- SystemExit from a leg included
@@ -927,8 +1002,13 @@ def emit(out):
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
-    sys.stdout.write(json.dumps(out) + "\n")
-    sys.stdout.flush()
+    _OUT["emitted"] = True
+    data = (json.dumps(out) + "\n").encode()
+    if _OUT["fd"] is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_OUT["fd"], data)
 
 
 if __name__ == "__main__":

@@ -30,6 +30,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import sys
 import time
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
@@ -570,6 +571,12 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     T0 = max(len(obs_list) - 2 * K, V + W)
     assert T0 + 2 * K <= len(obs_list), "bench.py must hand over at least 12 + W + 2K steps of observations"
 
+    t_start = time.time()
+
+    def log(msg):  # progress on stderr: where a rank is when something takes long
+        sys.stderr.write(f"[sharded rank {rank} +{time.time() - t_start:6.1f}s] {msg}\n")
+        sys.stderr.flush()
+
     def agree(ok: bool) -> bool:
         t = torch.tensor([1 if ok else 0], dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
@@ -578,6 +585,7 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     def attempt(name, make):
         """construct a transport on every rank; keep it only if every rank succeeded"""
         obj, err = None, None
+        log(f"trying the {name}")
         try:
             obj = make()
         except Exception as e:  # noqa: BLE001 -- any failure means "next rung of the ladder"
@@ -640,20 +648,37 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
                 same = False
                 why = f"rank {rank}: a wait for a peer's flag gave up" + ("" if alive else " on the first exchange")
             use_p2p = agree(same)
+            log("peer-to-peer transport " + ("validated" if use_p2p else "failed validation"))
             against = f"the {ref_kind} transport" if ref is not None else "the unsharded filter of all particles"
             notes.append(f"peer-to-peer transport validated bit-identical to {against} over {V} steps" if use_p2p else
                          f"peer-to-peer transport FAILED validation against {against}" +
                          (f" ({why})" if why else " (on another rank)"))
             del whole
     if not use_p2p and ref is None:
+        if p2p is not None:  # leave nothing behind on the device: its stream drained, the spin permit and the IPC mappings released
+            try:
+                p2p.close()
+            except RoboticsError:
+                pass
+        dist.barrier()
         raise RuntimeError("no working sharded transport on this machine: " + "; ".join(notes))
 
+
+    trouble = []  # errors of THIS rank inside a region: remembered, not raised -- every rank keeps to the same sequence of
+                  # collectives and the ranks decide together afterwards (a rank that left early would leave the others in a barrier)
 
     def quiet_sync(shard):
         try:
             shard.synchronize()
         except RoboticsError:  # a latched peer-wait timeout (rr_pf_synchronize reports it): the ladder asks
             pass               # p2p.timed_out() on every rank right after the region and decides collectively
+
+    def quiet_step(shard, obs):
+        try:
+            shard.step(u, obs)
+        except RoboticsError as e:
+            if not trouble:
+                trouble.append(f"rank {rank}: {e}")
 
     def fence(shard):
         quiet_sync(shard)
@@ -666,7 +691,7 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
         # W warm-up steps plus 64 more: in a process that has torch's HIP context loaded the host enqueues the
         # first ~50 steps of a large filter an order of magnitude slower than later ones
         for t in range(V, T0):
-            shard.step(u, obs_list[t])
+            quiet_step(shard, obs_list[t])
         fence(shard)
         # ... and that stall lands at an unpredictable launch count (a few milliseconds, once): keep warming up in blocks
         # of 40 steps (replaying the last warm-up observations: a tracking filter does not mind) until two blocks in a
@@ -675,7 +700,7 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
         for _ in range(8):
             tb = time.perf_counter()
             for t in range(max(V, T0 - 40), T0):
-                shard.step(u, obs_list[t])
+                quiet_step(shard, obs_list[t])
             fence(shard)
             blk = torch.tensor([time.perf_counter() - tb], dtype=torch.float64)
             dist.all_reduce(blk, op=dist.ReduceOp.MAX)
@@ -688,7 +713,7 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
         # timed region; the kernel times of the instrumented re-run below feed `roofline`
         t0 = time.perf_counter()
         for t in range(T0, T0 + K):
-            shard.step(u, obs_list[t])
+            quiet_step(shard, obs_list[t])
         fence(shard)
         dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], dtype=torch.float64)
@@ -696,14 +721,16 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
         return float(tmax.item())
 
     shard = p2p if use_p2p else ref
+    log("timed region on " + ("the peer-to-peer transport" if use_p2p else f"the {ref_kind} transport"))
     if p2p is None:  # no validation ran: the reference transport has not seen the first V steps yet
         for t in range(V):
             ref.step(u, obs_list[t])
     seconds = timed_region(shard)
     timed_out = False
-    if use_p2p and not agree(not p2p.timed_out()):
+    if use_p2p and not agree(not p2p.timed_out() and not trouble):
         timed_out = True
-        notes.append("a peer wait gave up inside the timed region")
+        notes.append("a peer wait gave up inside the timed region" + (f" ({trouble[0]})" if trouble else ""))
+        del trouble[:]
         if ref is not None:  # repeat the region on the reference transport
             use_p2p, shard = False, ref
             seconds = timed_region(shard)

@@ -31,3 +31,41 @@ def test_self_launch_reaches_the_device_check():
 def test_single_gpu_run_fails_loudly_without_a_device():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "no HIP device available" in r.stderr
+
+
+def _run_snippet(code, env_extra=None, timeout=60):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+
+
+def test_stdout_carries_the_json_line_and_nothing_else():
+    """gloo / RCCL write banners to file descriptor 1 from C++: after claim_stdout() those land on stderr and the one
+    line emit() prints is all there is on stdout (and a world-2 self-launch prints nothing there without a measurement)."""
+    r = _run_snippet("import os, bench\n"
+                     "bench.claim_stdout()\n"
+                     "os.write(1, b'[Gloo] Rank 0 is connected to 1 peer ranks\\n')\n"
+                     "print('a library that prints')\n"
+                     "bench.emit({'metric': 'm', 'value': 1.5})\n")
+    assert r.returncode == 0, r.stderr
+    assert r.stdout == '{"metric": "m", "value": 1.5}\n'
+    assert "[Gloo] Rank 0" in r.stderr and "a library that prints" in r.stderr
+
+
+def test_deadline_prints_the_headline_and_leaves():
+    """a stalled extra leg (or a dead rank) costs at most RR_BENCH_DEADLINE_S: rank 0 prints the headline leg it already
+    has, flagged, and exits 0; a rank without a finished headline exits non-zero and prints nothing."""
+    code = ("import time, bench\n"
+            "bench.claim_stdout()\n"
+            "bench._OUT['partial'] = %s\n"
+            "bench.start_deadline(0)\n"
+            "time.sleep(30)\n")
+    r = _run_snippet(code % "{'metric': 'm', 'value': 2.0}", {"RR_BENCH_DEADLINE_S": "0.5"})
+    assert r.returncode == 0, r.stderr
+    import json
+
+    line = json.loads(r.stdout)
+    assert line == {"metric": "m", "value": 2.0, "deadline_exceeded": True}
+    assert "deadline of" in r.stderr
+    r = _run_snippet(code % "None", {"RR_BENCH_DEADLINE_S": "0.5"})
+    assert r.returncode != 0 and r.stdout == ""
