@@ -24,6 +24,9 @@ python tools/summarize_rocprof.py stats "$(find_csv mcl_trace kernel_trace)" > "
 python tools/summarize_rocprof.py stats "$(find_csv fs1_trace kernel_trace)" > "$OUT/${TAG}_fastslam_1e5x200_kernel_stats.csv"
 grep '^{' "$OUT/mcl_trace.bench.json" | tail -1 > "$OUT/${TAG}_mcl_1e6x32_bench_under_rocprof.json"
 grep '^{' "$OUT/fs1_trace.bench.json" | tail -1 > "$OUT/${TAG}_fastslam_1e5x200_bench_under_rocprof.json"
+run mn_trace --kernel-trace --stats -- $MCL --scheme multinomial
+python tools/summarize_rocprof.py stats "$(find_csv mn_trace kernel_trace)" > "$OUT/${TAG}_mcl_1e6x32_multinomial_kernel_stats.csv"
+[ -n "${ONLY_TRACE:-}" ] && exit 0  # kernel timings only (the PMC passes take several minutes)
 
 for wl in mcl fs1; do
   cmd=$MCL; [ $wl = fs1 ] && cmd=$FS1
