@@ -17,6 +17,11 @@ What the line holds
                 N = 8 (or --all-legs): BASELINE.json configs[3] (1e6 x 200 over 8 GPUs = 125 000 per GPU) and
                 configs[4] (1.6e7 x 64 over 8 GPUs = 2e6 per GPU).
 ``--workload fastslam|fastslam2`` prints that workload's line alone (rocprofv3 runs use this).
+
+stdout carries that one line and nothing else: once the arguments are parsed, file descriptor 1 is handed to stderr (gloo
+and RCCL print banners there from C++) and the line goes to a private copy of the real stdout.  Progress
+(``[bench rank r +t s] ...``) goes to stderr.  ``RR_BENCH_DEADLINE_S`` (default 600; 0 = none): a stalled extra leg or a dead
+rank costs at most this long -- rank 0 then prints the headline leg it already has, flagged ``deadline_exceeded``.
 """
 import argparse
 import json
