@@ -76,3 +76,24 @@ def test_two_processes_over_ipc_handles():
            "--master-port", "29721", os.path.join(ROOT, "tests", "_gpu_p2p_worker.py"), "8000", "8"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, PYTHONPATH=ROOT))
     assert r.returncode == 0 and r.stdout.count("P2P_OK") == 2, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_bench_two_ranks_from_a_bare_shell():
+    """`python bench.py --gpus 2` end to end on a one-GPU box (RR_BENCH_SHARE_DEVICE=1: both ranks on device 0): the
+    self-launch under torch.distributed.run, the gloo group, the transport ladder (RCCL refuses two ranks on one device,
+    so the peer-to-peer transport is validated against the unsharded filter of all particles ACROSS the two processes),
+    the timed region, and rank 0's line -- the only thing on stdout, whatever gloo and RCCL print."""
+    import json
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(PYTHONPATH=ROOT, RR_BENCH_SHARE_DEVICE="1", RR_BENCH_DEADLINE_S="240")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--particles", "100000",
+                        "--no-extra-legs", "--no-cpu-baseline"], capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0 and "deadline_exceeded" not in d
+    assert "peer-to-peer transport validated bit-identical" in d["config"]["sharding"], d["config"]["sharding"]
+    assert d["sharded"]["transport"].startswith("p2p") and not d["sharded"]["p2p_timed_out"]
+    assert "[bench rank 0" in r.stderr and "[bench rank 1" in r.stderr
