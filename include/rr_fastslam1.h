@@ -113,6 +113,9 @@ rr_status rr_fs1_n_eff(rr_fs1* h, double* out);
 rr_status rr_fs1_get_fixed_sums(rr_fs1* h, rr_pf_fixed_sums* out);
 /* observation chunks the last observe used, and the Philox counters */
 rr_status rr_fs1_get_counters(rr_fs1* h, uint32_t* step, uint32_t* resample_step, int32_t* obs_chunks);
+/* one-launch resample plan of this handle: launches that degraded to the serial plan because the device did not run all
+ * of their workgroups at once (rr_pf_plan_stats in rr_pf.h tells the story), and whether the handle still uses it */
+rr_status rr_fs1_plan_stats(rr_fs1* h, uint64_t* giveups, int32_t* one_launch_enabled);
 
 /* ---- sharded FastSLAM: contiguous particle blocks over the GPUs of a node, each
  * particle's whole map moves with it.  Peer-to-peer transport only (include/rr_pf.h "peer-to-peer

@@ -208,6 +208,13 @@ typedef struct rr_pf_fixed_sums {
   double sum; /* total * 2^-shift */
 } rr_pf_fixed_sums;
 rr_status rr_pf_get_fixed_sums(rr_pf* h, rr_pf_fixed_sums* out);
+/* The fused systematic step plans its resample in ONE launch whose workgroups hand their tile sums to each other inside
+ * the kernel; that needs every workgroup on the device at once.  When another process keeps some of them off the CUs the
+ * launch does not fail: after RR_PF_PLAN_TIMEOUT_US (default 2000) it plans serially in its last workgroup -- same bits,
+ * milliseconds instead of microseconds -- and the handle takes the multi-launch plan from its next host read on.
+ * giveups: launches that degraded so far; one_launch_enabled: 0 once the handle has left the one-launch plan
+ * (or never used it: RR_PF_FUSED_PLAN=0, more than 2^20 particles).  Synchronises the stream. */
+rr_status rr_pf_plan_stats(rr_pf* h, uint64_t* giveups, int32_t* one_launch_enabled);
 /* step / resample counters that key the Philox streams */
 rr_status rr_pf_get_counters(rr_pf* h, uint32_t* step, uint32_t* resample_step);
 

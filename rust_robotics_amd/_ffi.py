@@ -166,6 +166,7 @@ def lib() -> C.CDLL:
     proto("rr_pf_get_raw_weights", st, [H, P])
     proto("rr_pf_get_fixed_sums", st, [H, C.POINTER(PfFixedSums)])
     proto("rr_pf_get_counters", st, [H, C.POINTER(u32), C.POINTER(u32)])
+    proto("rr_pf_plan_stats", st, [H, C.POINTER(u64), C.POINTER(i32)])
     proto("rr_pf_profile_enable", st, [H, i32])
     proto("rr_pf_profile_read", st, [H, i32, C.POINTER(u64), P])
     proto("rr_pf_profile_reset", st, [H])
@@ -238,6 +239,7 @@ def lib() -> C.CDLL:
     proto("rr_fs1_n_eff", st, [H, P])
     proto("rr_fs1_get_fixed_sums", st, [H, C.POINTER(PfFixedSums)])
     proto("rr_fs1_get_counters", st, [H, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32)])
+    proto("rr_fs1_plan_stats", st, [H, C.POINTER(u64), C.POINTER(i32)])
     proto("rr_fs1_p2p_export", st, [H, U8])
     proto("rr_fs1_p2p_connect", st, [H, U8, i32, i32])
     proto("rr_fs1_p2p_connect_local", st, [C.POINTER(H), i32])

@@ -680,6 +680,7 @@ struct rr_fs1 {
   unsigned int* grid_ticket = nullptr;
   uint64_t grid_epoch = 0;
   uint64_t grid_capacity = ~0ull;
+  uint64_t plan_giveups = 0;  // launches of the one-launch plan that degraded to the serial plan
   unsigned int* markers = nullptr;  // n + kResolveSlots, zero between resamples (fused single-GPU plan)
   unsigned int* carry = nullptr;    // one per kResolveSlots slots
   unsigned int* ridx = nullptr;  // sharded: sources of the served slots that belong to peers (allocated on connect)
@@ -1013,7 +1014,7 @@ rr_status launch_plan_fused(rr_fs1* h, int settle) {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_CDF);
     hipLaunchKernelGGL(rr::k_quantize_plan_mark<true>, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
                        (const double*)&h->ctl->wmax_bits, image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, settle,
-                       h->n_tiles, plan_args(h, 0, NAN, /*lazy=*/true), h->markers, h->carry, rr::EstArgs{});
+                       h->n_tiles, plan_args(h, 0, NAN, /*lazy=*/true), h->markers, h->carry, rr::EstArgs{}, rr::plan_giveup_ticks());
   } else {
     {
       rr::ScopedTimer t(h->prof, h->stream, RR_FK_QUANTIZE_REDUCE);
@@ -1062,9 +1063,14 @@ rr_status fetch_ctl(rr_fs1* h) {
   RR_HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
   rr::spin_release(h->opt.device, h);
-  if (h->ctl_host->grid_timeout)  // latched: the filter state after it is not to be trusted
-    return fail(RR_RUNTIME_ERROR, "a workgroup of the one-launch resample plan timed out waiting for another one's tile sums "
-                                  "(the device did not run them concurrently); set RR_PF_FUSED_PLAN=0");
+  if (h->ctl_host->grid_timeout) {
+    // launches of the one-launch plan degraded to the serial plan (another process kept workgroups off the device): same
+    // results; this handle takes the multi-launch plan from now on (resample_core.hpp, k_quantize_plan_mark)
+    h->plan_giveups += (uint64_t)h->ctl_host->grid_timeout;
+    h->grid_capacity = 0;
+    RR_HIP_TRY(hipMemsetAsync(&h->ctl->grid_timeout, 0, sizeof(int), h->stream));
+    h->ctl_host->grid_timeout = 0;
+  }
   return h->p2p.check(h->stream);  // a latched peer-wait timeout must not look like a healthy filter
 }
 
@@ -1878,6 +1884,15 @@ rr_status rr_fs1_get_fixed_sums(rr_fs1* h, rr_pf_fixed_sums* out) {
   out->q2_lo = c.q2_lo;
   out->w_max = c.wmax;
   out->sum = c.sum;
+  return RR_OK;
+}
+
+rr_status rr_fs1_plan_stats(rr_fs1* h, uint64_t* giveups, int32_t* one_launch_enabled) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  if (giveups) *giveups = h->plan_giveups;
+  if (one_launch_enabled) *one_launch_enabled = (h->grid_capacity != 0 && h->grid_capacity != ~0ull) ? 1 : 0;
   return RR_OK;
 }
 

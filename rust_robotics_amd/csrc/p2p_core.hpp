@@ -177,7 +177,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
     P2PPeers peers, uint64_t seq, const double* __restrict__ w, Ctl* __restrict__ ctl, ImageArgs a, uint64_t* __restrict__ rec,
     unsigned int* __restrict__ ticket, uint64_t epoch, int settle, uint64_t n_tiles, PlanArgs pa,
     unsigned int* __restrict__ markers, unsigned int* __restrict__ carry, uint64_t* __restrict__ gathered,
-    int* __restrict__ err) {
+    int* __restrict__ err, uint64_t slot_pad) {
   constexpr int W = kTileBlock / kWave;
   __shared__ uint64_t s4[4 * W];
   __shared__ uint64_t s_w[W];
@@ -324,8 +324,51 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
     rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
   }
   const rr_sys_plan plan = rr_sys_plan_make(rho, total, pa.n_global);
-  const uint64_t slot_base = rr_sys_slots_upto_exact(plan, total, base);  // == Ctl.served_first
-  mark_sources(t, base + pre + t.thread_off, i0, a.n, plan, total, slot_base, markers, carry);
+  // marker position of global slot s: s + slot_pad (resolve_tile_window)
+  mark_sources(t, base + pre + t.thread_off, i0, a.n, plan, total, (uint64_t)0 - slot_pad, markers, carry);
+}
+
+// ------------------------------------------------------------------------------------------
+// DONE: "every particle this rank had to deliver into a peer's inbox has landed".  Sent by the last workgroup of
+// k_push_window (one thread per peer, system-scope release after the workgroups' own system-scope fences) and awaited
+// only by those who need it: a workgroup of the next step's k_step_lazy whose tile holds a slot that a peer served, or
+// k_p2p_wait_done before an accessor materialises the resampled set.  Nobody waits in between -- a rank that has nothing
+// to receive never looks at the flag, and a slow peer costs the others nothing until its particles are actually read.
+__device__ inline void p2p_send_done(const P2PPeers& peers, uint64_t seq) {
+  const int g = threadIdx.x;
+  if (g < peers.n_ranks) {
+    P2PSlot* out = p2p_slot(peers.mbox[g], kP2PDone, peers.rank);
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// block-uniform; returns false (and latches *err) when a peer's DONE does not arrive in time
+__device__ inline bool p2p_wait_done(const P2PMailbox* own, int n_ranks, uint64_t seq, uint64_t timeout_ticks, int* __restrict__ err) {
+  __shared__ int s_bad;
+  const int g = threadIdx.x;
+  if (g == 0) s_bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (g < n_ranks && !s_bad) {
+    const P2PSlot* in = &own->done[g];
+    const uint64_t t0 = wall_clock64();
+    while (__hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      __builtin_amdgcn_s_sleep(8);
+      if (wall_clock64() - t0 > (seq <= 3 ? 10 * timeout_ticks : timeout_ticks)) {
+        atomicExch(&s_bad, 1);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  const bool bad = s_bad != 0;
+  if (bad && g == 0) *err = 1;
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);  // system scope, every wave: what the peers stored before their DONE is visible from here on
+  return !bad;
+}
+
+static __global__ void k_p2p_wait_done(const P2PMailbox* own, int n_ranks, uint64_t seq, uint64_t timeout_ticks, int* __restrict__ err) {
+  (void)p2p_wait_done(own, n_ranks, seq, timeout_ticks, err);
 }
 
 // ---- host side: what a handle owns for the transport

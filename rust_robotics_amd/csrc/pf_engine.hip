@@ -190,10 +190,13 @@ __global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __r
 // OTHER set; k_quantize_reduce (next in the stream) then flips Ctl.cur.  Without a pending
 // resample it runs in place.  This removes a whole 72 B/particle pass over HBM per step.
 //
-// SHARDED (rr_pf_shard_step_p2p): the sources come from `lidx` instead of markers -- lidx[k] is the
-// LOCAL source of slot k, or kInPlace when a peer has delivered the resampled particle into slot k
-// of this rank's inbox (k_resolve_push) -- and every consumed entry is reset to kInPlace.
+// Sharded (rr_pf_shard_step_p2p, StepSrc::kSrcWindow): the markers live in the GLOBAL slot index (rr::resolve_tile_window);
+// the own slots inside the window this shard serves are resolved and read exactly as on one GPU, the few outside it were
+// delivered into this rank's inbox by the peer that serves them (k_push_window) -- a tile that holds such a slot first
+// waits for the peers' DONE of the previous step.  Round 2 resolved every served slot in a separate launch
+// (k_resolve_push -> lidx, 7.9 us at 1e6 particles) and waited for DONE in a fourth one.
 constexpr unsigned int kInPlace = 0xffffffffu;
+constexpr unsigned kPushGrid = 64;  // workgroups of k_push_window (grid-stride over the foreign tiles: usually a handful)
 
 //
 // Shape of the kernel, each point measured at 1e6 x 32 (A/B on one box, tools/ab_bench.sh):
@@ -213,14 +216,31 @@ constexpr unsigned int kInPlace = 0xffffffffu;
 //    particle from the mirror of the live set -- one random 32-byte record instead of three random 8-byte words
 //    from three arrays.  The mirror is only ever read while a resample is pending, and a resample only becomes
 //    pending right after a launch of this kernel has written the mirror of the then-live set.
-template <bool OBS_KERNARG, bool SHARDED, int LIK, bool PACKED = false>
+// where the sources of a pending resample come from
+enum StepSrc {
+  kSrcMarkers = 0,  // one GPU, systematic: slot-run markers, resolved here (rr::resolve_tile)
+  kSrcLidx = 1,     // one GPU, multinomial: the search kernel left one source index per slot
+  kSrcWindow = 2    // a shard of the peer-to-peer transport: markers over the global slot index (rr::resolve_tile_window);
+                    // own slots outside the window this shard serves were delivered into the inbox by a peer
+};
+struct WindowArgs {
+  const rr::P2PMailbox* mbox;  // this rank's mailbox (the peers' DONE records)
+  const double* inbox;         // this rank's inbox [field][n]
+  int* err;
+  uint64_t pad;                // marker position of global slot s = s + pad
+  uint64_t wait_seq;           // the DONE a tile with peer-served slots waits for
+  uint64_t timeout_ticks;
+  int n_ranks;
+};
+
+template <bool OBS_KERNARG, int SRC, int LIK, bool PACKED = false>
 __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
                                                      StepParams p, ObsArg obs_arg,
                                                      const double* __restrict__ obs_dev,
                                                      unsigned int* __restrict__ markers,
                                                      const unsigned int* __restrict__ carry,
                                                      unsigned int* __restrict__ idx_out,
-                                                     const double* __restrict__ inbox, double* pk0, double* pk1) {
+                                                     WindowArgs wa, double* pk0, double* pk1) {
   extern __shared__ double s_obs[];
   __shared__ double s_wmax[kBlock / rr::kWave];
   const int tid = threadIdx.x;
@@ -244,12 +264,23 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
 #pragma unroll
     for (int r = 0; r < rr::kResolveRows; ++r)
       rr_pf_motion_noise(p.seed, p.step, p.first_gid + tile_base + (uint64_t)r * kBlock + tid, p.sigma_v, p.sigma_w, &na[r], &nc[r]);
-    if (pending && SHARDED) {
+    // kSrcWindow: positions of the window this shard serves, of this tile's slots
+    uint64_t win_lo = 0, win_hi = 0, pos0 = 0;
+    if (pending && SRC == kSrcLidx) {
 #pragma unroll
       for (int r = 0; r < rr::kResolveRows; ++r) {
         const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
         idx[r] = k < p.n ? markers[k] : 0u;  // `markers` is the lidx array here
       }
+    } else if (pending && SRC == kSrcWindow) {
+      const uint64_t own0 = p.first_gid + wa.pad;  // position of own slot 0: a multiple of kResolveSlots
+      win_lo = ctl->served_first + wa.pad;
+      win_hi = win_lo + ctl->served_count;
+      pos0 = own0 + tile_base;
+      rr::resolve_tile_window(markers, carry, own0 / rr::kResolveSlots + tile, win_lo, win_hi, own0, own0 + p.n, idx);
+      const uint64_t pos1 = pos0 + rr::kResolveSlots < own0 + p.n ? pos0 + rr::kResolveSlots : own0 + p.n;
+      if (pos0 < win_lo || pos1 > win_hi)  // (uniform) a peer serves some slot of this tile: its delivery must have landed
+        (void)rr::p2p_wait_done(wa.mbox, wa.n_ranks, wa.wait_seq, wa.timeout_ticks, wa.err);
     } else if (pending) {
       rr::resolve_tile(markers, carry, p.n, tile, idx);
     } else {
@@ -264,10 +295,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
       x[r] = y[r] = yaw[r] = 0.0;
       if (k < p.n) {
         const uint64_t j = idx[r];
-        if (SHARDED && pending && idx[r] == kInPlace) {  // delivered by a peer into this rank's inbox [field][n]
-          x[r] = inbox[k];
-          y[r] = inbox[p.n + k];
-          yaw[r] = inbox[2 * p.n + k];
+        if (SRC == kSrcWindow && pending && (pos0 + (uint64_t)r * kBlock + tid < win_lo || pos0 + (uint64_t)r * kBlock + tid >= win_hi)) {
+          x[r] = wa.inbox[k];  // delivered by a peer into this rank's inbox [field][n]
+          y[r] = wa.inbox[p.n + k];
+          yaw[r] = wa.inbox[2 * p.n + k];
         } else if (PACKED && pending) {
           const double4 rec = *reinterpret_cast<const double4*>((src ? pk1 : pk0) + 4 * j);
           x[r] = rec.x;
@@ -291,9 +322,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
         b.yaw[dst][k] = yaw[r];
         b.v[dst][k] = v;
         if (PACKED) *reinterpret_cast<double4*>((dst ? pk1 : pk0) + 4 * k) = make_double4(x[r], y[r], yaw[r], v);
-        if (SHARDED) {
+        if (SRC == kSrcLidx) {
           if (pending) markers[k] = kInPlace;
-        } else if (pending && idx_out) {
+        } else if (SRC == kSrcMarkers && pending && idx_out) {
           idx_out[k] = idx[r];
         }
       }
@@ -620,43 +651,93 @@ __global__ __launch_bounds__(kBlock) void k_resolve_gather_p2p(Bufs b, const Ctl
   }
 }
 
-// Sharded lazy resample, phase D: resolve the slots this rank serves.  A slot owned by this rank
-// only gets its LOCAL source index (lidx; the next k_step_lazy<., true> reads through it -- no
-// particle moves); a slot owned by a peer gets the particle delivered into the peer's fine-grained
-// inbox, where the peer's lidx entry says kInPlace.  The DONE exchange that follows tells the
-// peers that every store of this rank has landed.
-__global__ __launch_bounds__(kBlock) void k_resolve_push(Bufs b, const Ctl* __restrict__ ctl,
-                                                        unsigned int* __restrict__ markers,
-                                                        const unsigned int* __restrict__ carry,
-                                                        unsigned int* __restrict__ lidx, P2PPeers peers,
-                                                        uint64_t n_local) {
-  if (!ctl->fired) return;
-  const uint64_t first = ctl->served_first, n_slots = ctl->served_count;
-  const int src = ctl->cur;  // lazy: Ctl.cur flips when the next step settles
-  const uint64_t me = (uint64_t)peers.rank;
-  // grid-stride over the served slot tiles: the grid is sized for the usual case (about n_local served slots), a shard
-  // that serves more loops (uniform per workgroup: resolve_tile synchronises)
-  for (uint64_t tile = blockIdx.x; tile * rr::kResolveSlots < n_slots; tile += gridDim.x) {
-    const uint64_t tile_base = tile * rr::kResolveSlots;
-    unsigned int idx[rr::kResolveRows];
-    rr::resolve_tile(markers, carry, n_slots, tile, idx);
+// Sharded lazy resample, phase D: deliver what this shard serves to OTHER ranks.  The window of positions this shard's
+// sources feed, [served_first, +served_count) + pad, sticks out of its own block [own0, own0 + n) on either side by the
+// drift of the cumulative weight across the block boundaries (10^3 - 10^4 slots of 10^6 in steady state, everything in
+// the worst case): those positions are resolved here, tile by tile (grid-stride over the foreign tiles only), and each
+// particle is stored into the owning rank's fine-grained inbox.  Own positions are left to the next step's k_step_lazy.
+// The last workgroup to finish -- every workgroup's stores system-scope-released before its ticket -- sends DONE.
+__global__ __launch_bounds__(kBlock) void k_push_window(Bufs b, const Ctl* __restrict__ ctl,
+                                                       unsigned int* __restrict__ markers,
+                                                       const unsigned int* __restrict__ carry, P2PPeers peers,
+                                                       uint64_t n_local, uint64_t pad, unsigned int* __restrict__ ticket,
+                                                       uint64_t seq) {
+  __shared__ int s_last;
+  if (ctl->fired) {
+    const uint64_t own0 = (uint64_t)peers.rank * n_local + pad, own1 = own0 + n_local;
+    const uint64_t win_lo = ctl->served_first + pad, win_hi = win_lo + ctl->served_count;
+    const int src = ctl->cur;  // lazy: Ctl.cur flips when the next step settles
+    // foreign positions: left of the own block [l_lo, l_hi), right of it [r_lo, r_hi)
+    const uint64_t S = rr::kResolveSlots;
+    const uint64_t l_lo = win_lo, l_hi = own0 < win_hi ? own0 : win_hi;
+    const uint64_t r_lo = own1 > win_lo ? own1 : win_lo, r_hi = win_hi;
+    const uint64_t lt0 = l_lo / S, n_left = l_lo < l_hi ? (l_hi + S - 1) / S - lt0 : 0;
+    const uint64_t rt0 = r_lo / S, n_right = r_lo < r_hi ? (r_hi + S - 1) / S - rt0 : 0;
+    const uint64_t n_tiles = n_left + n_right;
+    for (uint64_t q = blockIdx.x; q < n_tiles; q += gridDim.x) {
+      const uint64_t tile = q < n_left ? lt0 + q : rt0 + (q - n_left);
+      const uint64_t lo = q < n_left ? l_lo : r_lo, hi = q < n_left ? l_hi : r_hi;  // positions this kernel consumes
+      unsigned int idx[rr::kResolveRows];
+      rr::resolve_tile_window(markers, carry, tile, win_lo, win_hi, lo, hi, idx);
+      bool stored = false;
 #pragma unroll
-    for (int r = 0; r < rr::kResolveRows; ++r) {
-      const uint64_t k = tile_base + (uint64_t)r * kBlock + threadIdx.x;
-      if (k < n_slots) {
-        const uint64_t s = first + k;
-        const uint64_t d = s / n_local, li = s - d * n_local;
-        const uint64_t j = idx[r];
-        if (d == me) {
-          lidx[li] = (unsigned int)j;
-        } else {
+      for (int r = 0; r < rr::kResolveRows; ++r) {
+        const uint64_t pos = tile * S + (uint64_t)r * kBlock + threadIdx.x;
+        if (pos >= lo && pos < hi) {
+          const uint64_t s = pos - pad;  // global slot
+          const uint64_t d = s / n_local, li = s - d * n_local;
+          const uint64_t j = idx[r];
           double* __restrict__ out = peers.inbox[d];  // fine-grained, [field][n_local]
           out[li] = b.x[src][j];
           out[n_local + li] = b.y[src][j];
           out[2 * n_local + li] = b.yaw[src][j];
           out[3 * n_local + li] = b.v[src][j];
+          stored = true;
         }
       }
+      if (stored) __atomic_thread_fence(__ATOMIC_SEQ_CST);  // system scope: in the owner's memory before this workgroup's ticket
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = rr::last_arrival(ticket, blockIdx.x, gridDim.x) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  rr::p2p_send_done(peers, seq);
+}
+
+// accessors: make a pending window resample real -- own slots inside the window through the markers, the others out of
+// the inbox (k_p2p_wait_done has run); k_settle flips the live set afterwards
+__global__ __launch_bounds__(kBlock) void k_resolve_gather_window(Bufs b, const Ctl* __restrict__ ctl,
+                                                                 unsigned int* __restrict__ markers,
+                                                                 const unsigned int* __restrict__ carry, uint64_t n,
+                                                                 uint64_t first_gid, uint64_t pad,
+                                                                 const double* __restrict__ inbox,
+                                                                 unsigned int* __restrict__ idx_out) {
+  if (!ctl->pending) return;
+  const uint64_t own0 = first_gid + pad;
+  const uint64_t win_lo = ctl->served_first + pad, win_hi = win_lo + ctl->served_count;
+  unsigned int idx[rr::kResolveRows];
+  rr::resolve_tile_window(markers, carry, own0 / rr::kResolveSlots + blockIdx.x, win_lo, win_hi, own0, own0 + n, idx);
+  const int src = ctl->cur, dst = src ^ 1;
+#pragma unroll
+  for (int r = 0; r < rr::kResolveRows; ++r) {
+    const uint64_t k = (uint64_t)blockIdx.x * rr::kResolveSlots + (uint64_t)r * kBlock + threadIdx.x;
+    if (k >= n) continue;
+    const uint64_t pos = own0 + k;
+    if (pos < win_lo || pos >= win_hi) {
+      b.x[dst][k] = inbox[k];
+      b.y[dst][k] = inbox[n + k];
+      b.yaw[dst][k] = inbox[2 * n + k];
+      b.v[dst][k] = inbox[3 * n + k];
+      if (idx_out) idx_out[k] = kInPlace;
+    } else {
+      const uint64_t j = idx[r];
+      b.x[dst][k] = b.x[src][j];
+      b.y[dst][k] = b.y[src][j];
+      b.yaw[dst][k] = b.yaw[src][j];
+      b.v[dst][k] = b.v[src][j];
+      if (idx_out) idx_out[k] = (unsigned int)j;
     }
   }
 }
@@ -1005,6 +1086,7 @@ struct rr_pf {
   unsigned int* grid_ticket = nullptr;
   uint64_t grid_epoch = 0;
   uint64_t grid_capacity = 0;
+  uint64_t plan_giveups = 0;  // launches of the one-launch plan that degraded to the serial plan (seen at the last read of Ctl)
   uint64_t shard_capacity = ~0ull;  // the same for k_shard_plan_mark (sharded step over the peer-to-peer transport); ~0: not asked yet
   unsigned int* est_ticket = nullptr;  // arrival counters of its last-workgroup reduction (rr::last_arrival; zero between launches)
   double* scratch_a = nullptr;  // n doubles: explicit noise v / uniforms / AoS staging (5n)
@@ -1025,7 +1107,9 @@ struct rr_pf {
   uint64_t mn_tiles = 0;
   rr::P2PState p2p;  // device-initiated exchange over xGMI (rr_pf_p2p_*)
   bool maybe_pending = false;    // a lazy resample plan was launched and nothing has consumed its markers yet
-  bool pending_lidx = false;     // ... and its sources are in lidx, not in markers (sharded step, multinomial step)
+  int pending_kind = kSrcMarkers;  // ... StepSrc: where its sources are (markers / lidx of the multinomial step / window of a shard)
+  uint64_t slot_pad = 0;           // shard of the peer-to-peer transport: marker position of global slot s = s + slot_pad
+  unsigned int* push_ticket = nullptr;  // arrival counters of k_push_window (zero between launches)
   unsigned int* lidx = nullptr;  // source index per slot; kInPlace = a peer stored the particle already (sharded)
   rr_pf_lik lik{};
   std::vector<double> landmarks;
@@ -1217,13 +1301,26 @@ void launch_quantize(rr_pf* h, const double* wmax_src, int settle = 0) {
 // make a pending lazy resample real (accessors and the non-fused entry points call this first)
 rr_status materialise(rr_pf* h) {
   if (!h->maybe_pending) return RR_OK;
-  if (h->pending_lidx) {
+  if (h->pending_kind == kSrcLidx) {
     Timed t(h, RR_K_RESAMPLE_GATHER);
     hipLaunchKernelGGL(k_gather_lidx, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->lidx, h->n,
-                       (const double*)(h->p2p.ready ? h->p2p.inbox : nullptr));
+                       (const double*)nullptr);
     hipLaunchKernelGGL(k_settle, dim3(1), dim3(1), 0, h->stream, h->ctl);
     RR_HIP_TRY(hipGetLastError());
-    h->maybe_pending = h->pending_lidx = false;
+    h->maybe_pending = false;
+    h->pending_kind = kSrcMarkers;
+    return RR_OK;
+  }
+  if (h->pending_kind == kSrcWindow) {  // a shard: the peers' deliveries of the last step must have landed first
+    Timed t(h, RR_K_RESAMPLE_GATHER);
+    hipLaunchKernelGGL(rr::k_p2p_wait_done, dim3(1), dim3(64), 0, h->stream, (const rr::P2PMailbox*)h->p2p.mbox, h->p2p.peers.n_ranks,
+                       h->p2p.seq, h->p2p.peers.timeout_ticks, h->p2p.err);
+    hipLaunchKernelGGL(k_resolve_gather_window, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b, h->ctl,
+                       h->markers, h->carry, h->n, h->opt.first_global_index, h->slot_pad, (const double*)h->p2p.inbox, h->idx);
+    hipLaunchKernelGGL(k_settle, dim3(1), dim3(1), 0, h->stream, h->ctl);
+    RR_HIP_TRY(hipGetLastError());
+    h->maybe_pending = false;
+    h->pending_kind = kSrcMarkers;
     return RR_OK;
   }
   {
@@ -1234,6 +1331,7 @@ rr_status materialise(rr_pf* h) {
   }
   RR_HIP_TRY(hipGetLastError());
   h->maybe_pending = false;
+  h->pending_kind = kSrcMarkers;
   return RR_OK;
 }
 
@@ -1343,7 +1441,7 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
       if (one_launch)
         hipLaunchKernelGGL(rr::k_quantize_plan_mark<false>, grid, block, 0, h->stream, (const double*)h->w, h->ctl, wmax_source(h),
                            image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, settle, h->n_tiles, pa, h->markers,
-                           h->carry, ea);
+                           h->carry, ea, rr::plan_giveup_ticks());
       else
         hipLaunchKernelGGL(rr::k_plan_mark, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total,
                            h->tile_q2, h->n_tiles, pa, h->markers, h->carry, ea);
@@ -1370,9 +1468,11 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
     g.rstep = h->rstep;
     g.scheme = scheme;
     launch_mn_search(h, guide, (const double*)nullptr, h->lidx, g);
-    h->maybe_pending = h->pending_lidx = true;
+    h->maybe_pending = true;
+    h->pending_kind = kSrcLidx;
   } else if (lazy) {
     h->maybe_pending = true;  // the next k_step_lazy (or materialise) moves the particles
+    h->pending_kind = kSrcMarkers;
   } else {
     Timed t(h, RR_K_RESAMPLE_GATHER);
     if (sys) {
@@ -1457,9 +1557,15 @@ rr_status fetch_ctl(rr_pf* h) {
   RR_HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
   rr::spin_release(h->opt.device, h);
-  if (h->ctl_host->grid_timeout)  // latched: the filter state after it is not to be trusted
-    return fail(RR_RUNTIME_ERROR, "a workgroup of the one-launch resample plan timed out waiting for another one's tile sums "
-                                  "(the device did not run them concurrently); set RR_PF_FUSED_PLAN=0");
+  if (h->ctl_host->grid_timeout) {
+    // launches of the one-launch plan gave up waiting for workgroups the device did not run concurrently (another process
+    // on the GPU) and planned serially instead -- same results, milliseconds instead of microseconds: this handle takes
+    // the multi-launch plan from now on (resample_core.hpp, k_quantize_plan_mark)
+    h->plan_giveups += (uint64_t)h->ctl_host->grid_timeout;
+    h->grid_capacity = 0;
+    RR_HIP_TRY(hipMemsetAsync(&h->ctl->grid_timeout, 0, sizeof(int), h->stream));
+    h->ctl_host->grid_timeout = 0;
+  }
   return h->p2p.check(h->stream);  // a latched peer-wait timeout must not look like a healthy filter
 }
 
@@ -1656,7 +1762,8 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
     }
   }
   {
-    const size_t nm = (size_t)std::max<uint64_t>(n_global, h->cap) + rr::kResolveSlots;
+    // (+ one tile of padding in front of a shard's own block, peer-to-peer transport: rr::resolve_tile_window)
+    const size_t nm = (size_t)std::max<uint64_t>(n_global, h->cap) + 3 * (size_t)rr::kResolveSlots;
     RR_TRY_OR_CLEAN(hipMalloc(&h->markers, nm * sizeof(unsigned int)));
     RR_TRY_OR_CLEAN(hipMemset(h->markers, 0, nm * sizeof(unsigned int)));
     RR_TRY_OR_CLEAN(hipMalloc(&h->carry, (nm / rr::kResolveSlots + 2) * sizeof(unsigned int)));
@@ -1679,6 +1786,9 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
   }
   RR_TRY_OR_CLEAN(hipMalloc(&h->est_ticket, rr::kTicketWords * sizeof(unsigned int)));
   RR_TRY_OR_CLEAN(hipMemsetAsync(h->est_ticket, 0, rr::kTicketWords * sizeof(unsigned int), h->stream));
+  RR_TRY_OR_CLEAN(hipMalloc(&h->push_ticket, rr::kTicketWords * sizeof(unsigned int)));
+  RR_TRY_OR_CLEAN(hipMemsetAsync(h->push_ticket, 0, rr::kTicketWords * sizeof(unsigned int), h->stream));
+  h->slot_pad = (rr::kResolveSlots - h->opt.first_global_index % rr::kResolveSlots) % rr::kResolveSlots;
   RR_TRY_OR_CLEAN(hipMalloc(&h->ctl, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipHostMalloc(&h->ctl_host, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipMemsetAsync(h->ctl, 0, sizeof(Ctl), h->stream));
@@ -1718,32 +1828,36 @@ rr_status ensure_scratch(rr_pf* h, size_t doubles_a, size_t doubles_b) {
 // C ABI
 // =============================================================================================
 // one launch of k_step_lazy: the template arguments from run-time facts (ea/eb: dispatch timestamps when profiling)
-template <bool KA, bool SH, int LIK, bool PK = false>
+template <bool KA, int SRC, int LIK, bool PK = false>
 static void launch_k1_as(rr_pf* h, unsigned grid, size_t lds, hipEvent_t ea, hipEvent_t eb, const StepParams& p, const ObsArg& arg,
-                         unsigned int* markers, const unsigned int* carry, unsigned int* idx_out, const double* inbox) {
+                         unsigned int* markers, const unsigned int* carry, unsigned int* idx_out, const WindowArgs& wa) {
   const double* obs_dev = KA ? nullptr : h->obs_dev;
   if (ea)
-    hipExtLaunchKernelGGL((k_step_lazy<KA, SH, LIK, PK>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl, p, arg,
-                          obs_dev, markers, carry, idx_out, inbox, h->packed[0], h->packed[1]);
+    hipExtLaunchKernelGGL((k_step_lazy<KA, SRC, LIK, PK>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl, p, arg,
+                          obs_dev, markers, carry, idx_out, wa, h->packed[0], h->packed[1]);
   else
-    hipLaunchKernelGGL((k_step_lazy<KA, SH, LIK, PK>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg, obs_dev,
-                       markers, carry, idx_out, inbox, h->packed[0], h->packed[1]);
+    hipLaunchKernelGGL((k_step_lazy<KA, SRC, LIK, PK>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg, obs_dev,
+                       markers, carry, idx_out, wa, h->packed[0], h->packed[1]);
 }
 
-static void launch_k1(rr_pf* h, bool kernarg, bool sharded, unsigned grid, size_t lds, hipEvent_t ea, hipEvent_t eb,
+static void launch_k1(rr_pf* h, bool kernarg, int src, unsigned grid, size_t lds, hipEvent_t ea, hipEvent_t eb,
                       const StepParams& p, const ObsArg& arg, unsigned int* markers, const unsigned int* carry,
-                      unsigned int* idx_out, const double* inbox, bool packed = false) {
+                      unsigned int* idx_out, const WindowArgs& wa = WindowArgs{}, bool packed = false) {
   const bool product = p.lik_mode == RR_LIK_PRODUCT;
-#define RR_K1_GO(KA_, SH_, LIK_) launch_k1_as<KA_, SH_, LIK_>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, inbox)
-#define RR_K1_GO_PK(KA_, LIK_) launch_k1_as<KA_, true, LIK_, true>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, inbox)
-  if (sharded && packed) {
+#define RR_K1_GO(KA_, SRC_, LIK_) launch_k1_as<KA_, SRC_, LIK_>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa)
+#define RR_K1_GO_PK(KA_, LIK_) launch_k1_as<KA_, kSrcLidx, LIK_, true>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa)
+#define RR_K1_SRC(SRC_)                                                                                       \
+  do {                                                                                                        \
+    if (kernarg) product ? RR_K1_GO(true, SRC_, RR_LIK_PRODUCT) : RR_K1_GO(true, SRC_, RR_LIK_FUSED);          \
+    else product ? RR_K1_GO(false, SRC_, RR_LIK_PRODUCT) : RR_K1_GO(false, SRC_, RR_LIK_FUSED);                \
+  } while (0)
+  if (src == kSrcLidx && packed) {
     if (kernarg) product ? RR_K1_GO_PK(true, RR_LIK_PRODUCT) : RR_K1_GO_PK(true, RR_LIK_FUSED);
     else product ? RR_K1_GO_PK(false, RR_LIK_PRODUCT) : RR_K1_GO_PK(false, RR_LIK_FUSED);
-  } else
-  if (kernarg && sharded) product ? RR_K1_GO(true, true, RR_LIK_PRODUCT) : RR_K1_GO(true, true, RR_LIK_FUSED);
-  else if (kernarg) product ? RR_K1_GO(true, false, RR_LIK_PRODUCT) : RR_K1_GO(true, false, RR_LIK_FUSED);
-  else if (sharded) product ? RR_K1_GO(false, true, RR_LIK_PRODUCT) : RR_K1_GO(false, true, RR_LIK_FUSED);
-  else product ? RR_K1_GO(false, false, RR_LIK_PRODUCT) : RR_K1_GO(false, false, RR_LIK_FUSED);
+  } else if (src == kSrcLidx) RR_K1_SRC(kSrcLidx);
+  else if (src == kSrcWindow) RR_K1_SRC(kSrcWindow);
+  else RR_K1_SRC(kSrcMarkers);
+#undef RR_K1_SRC
 #undef RR_K1_GO
 #undef RR_K1_GO_PK
 }
@@ -1869,6 +1983,7 @@ void rr_pf_destroy(rr_pf* h) {
   (void)hipFree(h->est_partials);
   (void)hipFree(h->mn_tile_cnt);
   (void)hipFree(h->est_ticket);
+  (void)hipFree(h->push_ticket);
   (void)hipFree(h->grid_rec);
   (void)hipFree(h->grid_ticket);
   (void)hipFree(h->scratch_a);
@@ -1989,7 +2104,7 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
     h->step += 1;
     return launch_resample(h, 0, h->opt.resample_scheme, NAN, nullptr);
   }
-  if (h->maybe_pending && h->pending_lidx != multinomial && (s = materialise(h)) != RR_OK) return s;
+  if (h->maybe_pending && h->pending_kind != (multinomial ? kSrcLidx : kSrcMarkers) && (s = materialise(h)) != RR_OK) return s;
   // systematic: 2 launches per step -- k_step_lazy (propagate + weight, reading through the previous resample's
   // indices) and k_quantize_plan_mark (3 beyond 2^20 particles: k_quantize_reduce, k_plan_mark)
   const size_t lds = 3 * n_obs * sizeof(double);
@@ -2002,7 +2117,7 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
     if (multinomial) {  // sources of the previous (multinomial) resample are in lidx
-      launch_k1(h, kernarg, /*sharded=*/true, grid, lds, nullptr, nullptr, p, arg, h->lidx, nullptr, nullptr, h->p2p.inbox,
+      launch_k1(h, kernarg, kSrcLidx, grid, lds, nullptr, nullptr, p, arg, h->lidx, nullptr, nullptr, WindowArgs{},
                 /*packed=*/h->packed[0] != nullptr);
     } else {
       hipEvent_t ea = nullptr, eb = nullptr;
@@ -2011,12 +2126,13 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
         eb = take_event(h);
         h->events.push_back({RR_K_PROPAGATE_WEIGHT, ea, eb});
       }
-      launch_k1(h, kernarg, /*sharded=*/false, grid, lds, ea, eb, p, arg, h->markers, h->carry, h->idx, nullptr);
+      launch_k1(h, kernarg, kSrcMarkers, grid, lds, ea, eb, p, arg, h->markers, h->carry, h->idx);
     }
   }
   RR_HIP_TRY(hipGetLastError());
   h->step += 1;
-  h->maybe_pending = h->pending_lidx = false;  // consumed (k_quantize_reduce settles Ctl.cur)
+  h->maybe_pending = false;  // consumed (k_quantize_reduce settles Ctl.cur)
+  h->pending_kind = kSrcMarkers;
   return launch_resample(h, 0, h->opt.resample_scheme, NAN, nullptr, /*lazy=*/true, /*settle=*/1, want_estimate);
 }
 
@@ -2191,6 +2307,15 @@ rr_status rr_pf_get_raw_weights(rr_pf* h, double* out) {
   if (!out) return fail(RR_INVALID_PARAMETER, "null output");
   RR_HIP_TRY(hipMemcpyAsync(out, h->w, h->n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return RR_OK;
+}
+
+rr_status rr_pf_plan_stats(rr_pf* h, uint64_t* giveups, int32_t* one_launch_enabled) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  if (giveups) *giveups = h->plan_giveups;
+  if (one_launch_enabled) *one_launch_enabled = h->grid_capacity != 0 ? 1 : 0;
   return RR_OK;
 }
 
@@ -2474,20 +2599,23 @@ rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
   return rr::p2p_link_local(st, slabs, inboxes, devs, n_ranks);
 }
 
-// Seven launches: propagate+weight (reading through lidx) | WMAX exchange | integer image |
-// tile scan + SUMS exchange + plan | mark | resolve (lidx for own slots, stores into the owners'
-// slabs for the others) | DONE exchange.  Only slots whose source lives on another rank move at
-// resample time; the rest is read through lidx by the next step, as on one GPU.
-// (Running the exchanges in the last workgroup of the producing kernels instead -- ticket
-// counter, scoped atomics -- was measured: the election costs ~5 us per exchange, more than the
-// launch it saves.)
+// THREE launches: k_step_lazy<kSrcWindow> (propagate + weight; the own slots inside the window this shard served last
+// step are resolved from the markers and read in place exactly as on one GPU, the few a peer served come out of the inbox
+// after that peer's DONE) | k_shard_plan_mark (WMAX exchange, integer image, SUMS exchange, gate + plan, markers over the
+// global slot index -- one launch) | k_push_window (only the window's overhang over the own block: those particles go to
+// their owners' inboxes; its last workgroup sends DONE, nobody waits for it here).  Shards beyond 2^20 particles take the
+// plan as four launches (WMAX exchange | k_quantize_reduce | k_scan_exchange | k_mark).  Round 2: 4 launches with a
+// full-size resolve pass (k_resolve_push, 7.9 us at 1e6 particles) and a DONE exchange everybody waited in.
+// (Running the exchanges in the last workgroup of the producing kernels instead -- ticket counter, scoped atomics -- was
+// measured in round 1 for the WMAX / SUMS exchanges: the election costs ~5 us per exchange behind ~500 busy workgroups,
+// more than the launch it saves; k_push_window's workgroups have next to nothing to do, so its election is cheap.)
 rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_p2p_connect first");
   if ((s = validate_control(control)) != RR_OK) return s;
   if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
-  if (h->maybe_pending && !h->pending_lidx && (s = materialise(h)) != RR_OK) return s;
+  if (h->maybe_pending && h->pending_kind != kSrcWindow && (s = materialise(h)) != RR_OK) return s;
   ObsArg arg;
   bool kernarg;
   if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
@@ -2495,10 +2623,17 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   const size_t lds = 3 * n_obs * sizeof(double);
   if (lds > 150 * 1024) return fail(RR_INVALID_PARAMETER, "too many observations for one LDS block (max 6400)");
   if (!h->wmax_bits_clean) RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+  WindowArgs wa{};
+  wa.mbox = h->p2p.mbox;
+  wa.inbox = h->p2p.inbox;
+  wa.err = h->p2p.err;
+  wa.pad = h->slot_pad;
+  wa.wait_seq = h->p2p.seq;  // the DONE of the step whose resample this launch consumes
+  wa.timeout_ticks = h->p2p.peers.timeout_ticks;
+  wa.n_ranks = h->p2p.peers.n_ranks;
   const uint64_t seq = ++h->p2p.seq;
   uint64_t* gathered = h->p2p.gathered();
-  uint64_t* local3 = h->p2p.local3();
-  // A: propagate + weight through lidx
+  // A: propagate + weight through the window
   const uint64_t n_rtiles = (h->n + rr::kResolveSlots - 1) / rr::kResolveSlots;
   const unsigned grid = (unsigned)n_rtiles;  // one tile per workgroup
   {
@@ -2509,7 +2644,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
       eb = take_event(h);
       h->events.push_back({RR_K_PROPAGATE_WEIGHT, ea, eb});
     }
-    launch_k1(h, kernarg, /*sharded=*/true, grid, lds, ea, eb, p, arg, h->lidx, nullptr, nullptr, h->p2p.inbox);
+    launch_k1(h, kernarg, kSrcWindow, grid, lds, ea, eb, p, arg, h->markers, h->carry, nullptr, wa);
   }
   h->step += 1;
   PlanArgs pa = plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN);
@@ -2525,7 +2660,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
     Timed t(h, RR_K_CDF);
     hipLaunchKernelGGL(rr::k_shard_plan_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->p2p.peers, seq,
                        (const double*)h->w, h->ctl, image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, /*settle=*/1,
-                       h->n_tiles, pa, h->markers, h->carry, gathered, h->p2p.err);
+                       h->n_tiles, pa, h->markers, h->carry, gathered, h->p2p.err, h->slot_pad);
   } else {
     // exchange 1: global maximum -> Ctl.wmax
     hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PWmax, seq,
@@ -2542,24 +2677,21 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
     {
       Timed t(h, RR_K_CDF);
       hipLaunchKernelGGL(rr::k_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl,
-                         image_args(h), h->tile_total, h->markers, h->carry);
+                         image_args(h), h->tile_total, h->markers, h->carry, /*window=*/1, h->slot_pad);
     }
   }
   h->wmax_live = false;
   h->wmax_bits_clean = true;
   h->rstep += 1;
-  // D: resolve the served slots (worst case: this shard serves all of them; surplus workgroups
-  // return at once) -- own slots -> lidx, the others -> stored into their owners' slabs
+  // D: the overhang of the served window goes to its owners; the last workgroup sends DONE (k_push_window)
   {
     Timed t(h, RR_K_RESAMPLE_GATHER);
-    hipLaunchKernelGGL(k_resolve_push, dim3(grid_for(std::min<uint64_t>(h->n_global, 2 * h->n), rr::kResolveSlots)), dim3(kBlock), 0,
-                       h->stream, h->b, h->ctl, h->markers, h->carry, h->lidx, h->p2p.peers, h->n);
+    hipLaunchKernelGGL(k_push_window, dim3(kPushGrid), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->markers, h->carry, h->p2p.peers,
+                       h->n, h->slot_pad, h->push_ticket, seq);
   }
-  // exchange 3: every rank's stores into everybody's slab have landed
-  hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PDone, seq,
-                     (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
   RR_HIP_TRY(hipGetLastError());
-  h->maybe_pending = h->pending_lidx = true;
+  h->maybe_pending = true;
+  h->pending_kind = kSrcWindow;
   return RR_OK;
 }
 

@@ -552,27 +552,43 @@ struct EstArgs {
   int want;
 };
 
-__device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, const TileScan& t, const unsigned int* offspring,
-                                     int fire, uint64_t i0, uint64_t n, double denom, unsigned int rstep, int cur) {
-  __shared__ double s_acc[kTileBlock / kWave][4];
-  __shared__ double s_c[kTileBlock * (kItems + 1)];  // coefficient of the tile's particle i at [i + i / kItems] (padded rows)
-  __shared__ int s_last;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // the coefficients are known per thread for its 8 CONSECUTIVE sources; the particle fields are read row-wise
-  // (256 consecutive particles per instruction, coalesced), so the coefficients change hands through LDS
+// The particle fields of this thread's kItems CONSECUTIVE sources (the blocked layout of tile_scan: a lane reads 8 * kItems
+// contiguous bytes per field, a wave 64 of those back to back -- every fetched line is used in full).  Issued at the very
+// start of the plan kernels, before the tile sums are known: the loads depend on nothing the kernel computes, so they are
+// in flight while the workgroup waits for the other workgroups' sums and cost the estimate no time of their own.  (Round 2
+// read them row-wise AFTER the marks were written and moved the coefficients through LDS: +12 us per step.)
+struct EstFields {
+  double f[4][kItems];
+};
+__device__ inline void est_prefetch(const EstArgs& ea, int cur, uint64_t i0, uint64_t n, EstFields& e) {
 #pragma unroll
-  for (int j = 0; j < kItems; ++j) s_c[tid * (kItems + 1) + j] = (i0 + j < n) ? (fire ? (double)offspring[j] : (double)t.q[j]) : 0.0;
-  __syncthreads();
-  const uint64_t tile0 = i0 - (uint64_t)tid * kItems;
+  for (int k = 0; k < 4; ++k) {
+    const double* __restrict__ p = ea.field[cur][k] + i0;
+    if ((kItems % 2) == 0 && i0 + kItems <= n && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {  // uniform except in the last tile
+#pragma unroll
+      for (int j = 0; j < kItems; j += 2) {
+        const double2 v = *reinterpret_cast<const double2*>(p + j);
+        e.f[k][j] = v.x;
+        e.f[k][j + (kItems > 1 ? 1 : 0)] = v.y;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < kItems; ++j) e.f[k][j] = (i0 + j < n) ? p[j] : 0.0;
+    }
+  }
+}
+
+// per-workgroup part: this tile's four partial sums -> partials[tile] (thread 0 stores them; nothing is fenced here)
+__device__ inline void est_tile_partial(const EstArgs& ea, const TileScan& t, const unsigned int* offspring, int fire, uint64_t i0,
+                                        uint64_t n, const EstFields& e, uint64_t tile) {
+  __shared__ double s_acc[kTileBlock / kWave][4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int r = 0; r < kItems; ++r) {
-    const int i = r * kTileBlock + tid;
-    const double c = s_c[i + i / kItems];
-    if (c != 0.0) {
+  for (int j = 0; j < kItems; ++j) {
+    const double c = (i0 + j < n) ? (fire ? (double)offspring[j] : (double)t.q[j]) : 0.0;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) acc[k] = rr_fma(c, ea.field[cur][k][tile0 + i], acc[k]);
-    }
+    for (int k = 0; k < 4; ++k) acc[k] = rr_fma(c, e.f[k][j], acc[k]);
   }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -585,8 +601,31 @@ __device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, c
     for (int k = 0; k < 4; ++k) {
       double v = 0.0;
       for (int q = 0; q < kTileBlock / kWave; ++q) v += s_acc[q][k];
-      ea.partials[(uint64_t)blockIdx.x * 4 + k] = v;
+      ea.partials[tile * 4 + k] = v;
     }
+  }
+  __syncthreads();  // (s_acc may be reused by the next tile of the serial plan)
+}
+
+// the workgroup that knows every tile's partial sums are in memory adds them in tile order: wave k adds moment k, lanes
+// stride over the tiles (fixed order per lane), then a shuffle tree
+__device__ inline void est_finalize(const EstArgs& ea, Ctl* __restrict__ ctl, unsigned int n_tiles, double denom, unsigned int rstep) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (wv < 4) {
+    double v = 0.0;
+    for (unsigned int b = lane; b < n_tiles; b += 64) v += __builtin_nontemporal_load(&ea.partials[(uint64_t)b * 4 + wv]);
+    v = wave_sum(v);
+    if (lane == 0) ctl->est[wv] = v / denom;
+  }
+  if (tid == 0) ctl->est_step = (uint64_t)rstep + 1;
+}
+
+__device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, const TileScan& t, const unsigned int* offspring,
+                                     int fire, uint64_t i0, uint64_t n, double denom, unsigned int rstep, const EstFields& e) {
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
+  est_tile_partial(ea, t, offspring, fire, i0, n, e, blockIdx.x);
+  if (tid == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     s_last = last_arrival(ea.ticket, blockIdx.x, gridDim.x);
@@ -595,14 +634,7 @@ __device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, c
   if (!s_last) return;
   if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   __syncthreads();
-  // wave k adds moment k over the workgroups: lanes stride (fixed order per lane), then a shuffle tree
-  if (wv < 4) {
-    double v = 0.0;
-    for (unsigned int b = lane; b < gridDim.x; b += 64) v += __builtin_nontemporal_load(&ea.partials[(uint64_t)b * 4 + wv]);
-    v = wave_sum(v);
-    if (lane == 0) ctl->est[wv] = v / denom;
-  }
-  if (tid == 0) ctl->est_step = (uint64_t)rstep + 1;
+  est_finalize(ea, ctl, gridDim.x, denom, rstep);
 }
 
 // fused plan + mark (single shard, systematic, n_tiles <= kFusedMaxTiles)
@@ -613,6 +645,9 @@ static __global__ __launch_bounds__(kTileBlock) void k_plan_mark(const double* _
                                                             unsigned int* __restrict__ carry, EstArgs ea) {
   __shared__ uint64_t s4[4 * (kTileBlock / kWave)];
   __shared__ uint64_t s_w[kTileBlock / kWave];
+  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
+  EstFields ef;
+  if (ea.want) est_prefetch(ea, ctl->cur, i0, a.n, ef);  // (lazy plans never flip Ctl.cur in this kernel)
   const TileSums ts = tile_sums(tile_total, tile_q2, n_tiles, s4);
   const int mode = ctl->image_mode;
   const int shift = ctl->shift;
@@ -626,13 +661,12 @@ static __global__ __launch_bounds__(kTileBlock) void k_plan_mark(const double* _
   if (blockIdx.x == 0 && threadIdx.x == 0) finalize_plan(ctl, ts.tot, 0, ts.tot, ts.q2, pa);
   if (!fire && !ea.want) return;
   const TileScan t = tile_scan(w, a, mode, shift, blockIdx.x, s_w);
-  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
   unsigned int offspring[kItems];
   if (fire) {
     const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
     mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry, ea.want ? offspring : nullptr);
   }
-  if (ea.want) plan_estimate(ea, ctl, t, offspring, fire, i0, a.n, fire ? (double)pa.n_global : (double)ts.tot, pa.rstep, ctl->cur);
+  if (ea.want) plan_estimate(ea, ctl, t, offspring, fire, i0, a.n, fire ? (double)pa.n_global : (double)ts.tot, pa.rstep, ef);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -648,40 +682,50 @@ static __global__ __launch_bounds__(kTileBlock) void k_plan_mark(const double* _
 // 4.4 - 6.4, last ticket 7.1, flag raised 10.7, sums known everywhere 11.7 - 12.0, markers written 13.7 - 15.6 -- every
 // hop through device-scope memory costs ~1.2 us, which is why this is only ~2 us better than two launches and why
 // the same trick is not worth it between k_step_lazy and this kernel.
-// A workgroup that polls for ~1 s sets Ctl.grid_timeout and goes on (wrong results, reported by the host, not a hang).
 // Reads of Ctl that the settle / finalize writes of workgroup 0 could race with happen before the ticket is taken;
 // workgroup 0 writes after it has seen the flag, i.e. after every workgroup has arrived.
 constexpr int kRecWords = 4;  // total, q2_hi, q2_lo, exclusive prefix (written back by the last arrival)
-// rec layout: [n_tiles][kRecWords] records, then kRecWords words {grand total, q2_hi, q2_lo, flag = epoch}
+// rec layout: [n_tiles][kRecWords] records, then kRecWords words {grand total, q2_hi, q2_lo, state}
 __device__ inline uint64_t ld_dev(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_dev(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// FS_WEIGHTS (FastSLAM, k_fs1_plan's weight handling): the weights are explicit -- w /= sum when the gate stays shut
-// (fastslam1.rs:196-203), w = 1/n when it fires (:228) -- and are rewritten by the threads that read them.
+// The launch's state word: 2 * epoch     = RAISED: every workgroup has arrived, the sums are out, go on;
+//                          2 * epoch + 1 = GIVEN UP: a waiting workgroup ran out of patience before that.
+// Waiting in a kernel for OTHER workgroups of the same kernel only works if all of them are on the device at once.  The
+// host launches this kernel when an idle device holds the whole grid (occupancy query, one such kernel per process at a
+// time: rr::spin_permit) -- but another PROCESS on the same GPU can keep some workgroups off the CUs while the ones that
+// run hold their slots and spin (two such kernels of two processes can do that to each other).  So the wait is bounded
+// (`giveup_ticks` of the 100 MHz wall clock, default 2 ms -- a healthy launch waits ~5 us), and when it runs out the
+// launch DEGRADES instead of failing: whoever is first moves the state word from an older epoch to RAISED (the last
+// arrival) or to GIVEN UP (an impatient waiter) with a compare-and-swap, so all workgroups of the launch see ONE outcome.
+// Given up: every waiting workgroup leaves without writing anything -- its record and its ticket are already in -- which
+// frees its slots for the workgroups that had not started; each of those posts its record and leaves too; the LAST
+// arrival, whoever that is, then does the marking (weights, estimate partials) of EVERY tile itself, one after the other:
+// the same integer sums, the same markers, the same bits, ~1-2 ms instead of ~12 us.  It also raises Ctl.grid_timeout,
+// which (a) makes every later launch of the kernel skip the wait outright (serial plan at once, no 2 ms each) until (b) the
+// host sees it at its next read of Ctl and moves the handle to the multi-launch plan for good.  Nothing is reported as an
+// error: the results are those of the undisturbed filter.
+constexpr uint64_t kPlanGiveupTicksDefault = 200000;  // 2 ms
+__device__ inline uint64_t plan_state_decide(uint64_t* state, uint64_t epoch, uint64_t want_bit) {
+  // returns the state of THIS epoch, moving the word there if nobody has yet
+  for (;;) {
+    const uint64_t seen = ld_dev(state);
+    if ((seen >> 1) == epoch) return seen;
+    const uint64_t mine = 2 * epoch + want_bit;
+    if (atomicCAS((ull*)state, (ull)seen, (ull)mine) == (ull)seen) return mine;
+  }
+}
+
+// integer image + blocked scan of tile `tile` (phase A of the plan kernels; tile_scan with the FastSLAM weights kept)
 template <bool FS_WEIGHTS>
-static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
-    typename std::conditional<FS_WEIGHTS, double*, const double*>::type w, Ctl* __restrict__ ctl,
-    const double* __restrict__ wmax_src, ImageArgs a,
-    uint64_t* __restrict__ rec, unsigned int* __restrict__ ticket /* kTicketWords, zero between launches */, uint64_t epoch,
-    int settle, uint64_t n_tiles, PlanArgs pa, unsigned int* __restrict__ markers, unsigned int* __restrict__ carry,
-    EstArgs ea) {
+__device__ inline void plan_image_tile(typename std::conditional<FS_WEIGHTS, double*, const double*>::type w, const ImageArgs& a,
+                                       int mode, int shift, uint64_t tile, uint64_t* s_w, uint64_t* s4, TileScan& t,
+                                       double (&w_in)[FS_WEIGHTS ? kItems : 1], uint64_t* tile_total, u128* tile_q2) {
   constexpr int W = kTileBlock / kWave;
-  __shared__ uint64_t s4[4 * W];
-  __shared__ uint64_t s_w[W];
-  __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // ---- A: the integer image of this tile (quantize_reduce_tile's decisions, tile_scan's blocked layout)
-  const double wmax = *wmax_src;
-  const bool forced_uniform = a.honour_uniform_flag && ctl->weights_uniform;
-  const bool usable = !forced_uniform && wmax > 0.0 && wmax < INFINITY;
-  const int mode = usable ? (int)kImageWeights : (forced_uniform ? (int)kImageUniform : a.degenerate);
-  const int shift = usable ? rr_fix_shift(wmax, a.n_global) : 0;
-  const int cur_after = (settle && ctl->pending) ? ctl->cur ^ 1 : ctl->cur;  // what workgroup 0 will settle Ctl.cur to
-  TileScan t;
-  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)tid * kItems;
+  const uint64_t i0 = tile * kTile + (uint64_t)tid * kItems;
   uint64_t run = 0;
   u128 q2 = {0, 0};
-  double w_in[FS_WEIGHTS ? kItems : 1];
 #pragma unroll
   for (int j = 0; j < kItems; ++j) {
     if (FS_WEIGHTS) {
@@ -709,7 +753,6 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
   uint64_t off = incl - run;
   for (int k = 0; k < wv; ++k) off += s_w[k];
   t.thread_off = off;
-  uint64_t* const head = rec + n_tiles * kRecWords;
   if (tid == 0) {
     uint64_t tt = 0;
     u128 qq = {0, 0};
@@ -717,16 +760,93 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
       tt += s_w[k];
       qq = add128(qq, u128{s4[k], s4[W + k]});
     }
-    uint64_t* r = rec + (uint64_t)blockIdx.x * kRecWords;
-    st_dev(&r[0], tt);
-    st_dev(&r[1], qq.hi);
-    st_dev(&r[2], qq.lo);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged at device scope before the ticket says so
-    s_last = last_arrival(ticket, blockIdx.x, (unsigned int)n_tiles, /*fence=*/false) ? 1 : 0;
+    *tile_total = tt;
+    *tile_q2 = qq;
+  }
+}
+
+// phase B of the plan for one tile whose image is in `t` (k_plan_mark's second half): FastSLAM rewrites the weights
+// (normalised, or 1/n + markers when the gate fires), PF/MCL marks and adds the tile's share of the estimate
+template <bool FS_WEIGHTS>
+__device__ inline void plan_apply_tile(typename std::conditional<FS_WEIGHTS, double*, const double*>::type w, const ImageArgs& a,
+                                       int mode, int shift, const TileScan& t, const double (&w_in)[FS_WEIGHTS ? kItems : 1],
+                                       const TileSums& ts, int fire, double rho, const PlanArgs& pa, uint64_t tile,
+                                       unsigned int* __restrict__ markers, unsigned int* __restrict__ carry, const EstArgs& ea,
+                                       const EstFields& ef, unsigned int (&offspring)[kItems]) {
+  const uint64_t i0 = tile * kTile + (uint64_t)threadIdx.x * kItems;
+  if constexpr (FS_WEIGHTS) {
+    if (!fire) {
+      if (mode != kImageWeights) return;  // all-zero weights stay untouched (fastslam1.rs:198-202)
+      const double sum = rr_fix_total_to_double(ts.tot, shift);
+#pragma unroll
+      for (int j = 0; j < kItems; ++j)
+        if (i0 + j < a.n) w[i0 + j] = w_in[j] / sum;
+      return;
+    }
+    const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
+    mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry);
+    const double w_new = 1.0 / (double)pa.n_global;
+#pragma unroll
+    for (int j = 0; j < kItems; ++j)
+      if (i0 + j < a.n) w[i0 + j] = w_new;
+  } else {
+    if (!fire && !ea.want) return;
+    if (fire) {
+      const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
+      mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry, ea.want ? offspring : nullptr);
+    }
+  }
+}
+
+// FS_WEIGHTS (FastSLAM, k_fs1_plan's weight handling): the weights are explicit -- w /= sum when the gate stays shut
+// (fastslam1.rs:196-203), w = 1/n when it fires (:228) -- and are rewritten by the threads that read them.
+template <bool FS_WEIGHTS>
+static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
+    typename std::conditional<FS_WEIGHTS, double*, const double*>::type w, Ctl* __restrict__ ctl,
+    const double* __restrict__ wmax_src, ImageArgs a,
+    uint64_t* __restrict__ rec, unsigned int* __restrict__ ticket /* kTicketWords, zero between launches */, uint64_t epoch,
+    int settle, uint64_t n_tiles, PlanArgs pa, unsigned int* __restrict__ markers, unsigned int* __restrict__ carry,
+    EstArgs ea, uint64_t giveup_ticks) {
+  constexpr int W = kTileBlock / kWave;
+  __shared__ uint64_t s4[4 * W];
+  __shared__ uint64_t s_w[W];
+  __shared__ uint64_t s_tile[3];
+  __shared__ int s_last;
+  __shared__ int s_gaveup;
+  const int tid = threadIdx.x;
+  // ---- A: the integer image of this tile (quantize_reduce_tile's decisions, tile_scan's blocked layout)
+  const double wmax = *wmax_src;
+  const bool forced_uniform = a.honour_uniform_flag && ctl->weights_uniform;
+  const bool usable = !forced_uniform && wmax > 0.0 && wmax < INFINITY;
+  const int mode = usable ? (int)kImageWeights : (forced_uniform ? (int)kImageUniform : a.degenerate);
+  const int shift = usable ? rr_fix_shift(wmax, a.n_global) : 0;
+  const int cur_after = (settle && ctl->pending) ? ctl->cur ^ 1 : ctl->cur;  // what Ctl.cur will be settled to
+  const bool serial_only = ctl->grid_timeout != 0;  // an earlier launch gave up: nobody waits any more (see above)
+  TileScan t;
+  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)tid * kItems;
+  EstFields ef;
+  if (!FS_WEIGHTS && ea.want) est_prefetch(ea, cur_after, i0, a.n, ef);
+  double w_in[FS_WEIGHTS ? kItems : 1];
+  uint64_t* const head = rec + n_tiles * kRecWords;
+  {
+    uint64_t tt;
+    u128 qq;
+    plan_image_tile<FS_WEIGHTS>(w, a, mode, shift, blockIdx.x, s_w, s4, t, w_in, &tt, &qq);
+    if (tid == 0) {
+      uint64_t* r = rec + (uint64_t)blockIdx.x * kRecWords;
+      st_dev(&r[0], tt);
+      st_dev(&r[1], qq.hi);
+      st_dev(&r[2], qq.lo);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged at device scope before the ticket says so
+      s_last = last_arrival(ticket, blockIdx.x, (unsigned int)n_tiles, /*fence=*/false) ? 1 : 0;
+      s_gaveup = 0;
+    }
   }
   __syncthreads();
-  // ---- the last arrival: exclusive prefix per tile and the grand totals, then the flag
-  if (s_last) {
+  // ---- the last arrival: exclusive prefix per tile and the grand totals, then the state word
+  const bool last = s_last != 0;
+  if (last) {
+    const int lane = tid & 63, wv = tid >> 6;
     uint64_t tk = 0;
     u128 qk = {0, 0};
     if ((uint64_t)tid < n_tiles) {
@@ -760,20 +880,28 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // every prefix is acknowledged
-    if (tid == 0) st_dev(&head[3], epoch);
-  }
-  // ---- everybody: one thread polls the flag, then the workgroup's prefix and the totals
-  if (tid == 0) {
-    long spins = 0;
-    s_last = 0;  // reused: 1 = gave up
-    while (ld_dev(&head[3]) != epoch) {
-      if (++spins > (1l << 20)) {  // ~1.5 s
-        ctl->grid_timeout = 1;
-        s_last = 1;
-        break;
+    if (tid == 0) s_gaveup = (int)(plan_state_decide(&head[3], epoch, serial_only ? 1 : 0) & 1);
+  } else if (tid == 0) {
+    // ---- everybody else: one thread waits for the state word of this launch
+    if (serial_only) {
+      s_gaveup = 1;
+    } else {
+      const uint64_t t0 = wall_clock64();
+      uint64_t st;
+      while (((st = ld_dev(&head[3])) >> 1) != epoch) {
+        if (wall_clock64() - t0 > giveup_ticks) {
+          st = plan_state_decide(&head[3], epoch, 1);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(1);
       }
-      __builtin_amdgcn_s_sleep(1);
+      s_gaveup = (int)(st & 1);
     }
+  }
+  __syncthreads();
+  const bool gaveup = s_gaveup != 0;
+  if (gaveup && !last) return;  // record and ticket are in; the last arrival plans this tile as well
+  if (tid == 0) {
     asm volatile("" ::: "memory");
     s4[0] = ld_dev(&rec[(uint64_t)blockIdx.x * kRecWords + 3]);
     s4[1] = ld_dev(&head[0]);
@@ -781,13 +909,13 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
     s4[3] = ld_dev(&head[2]);
   }
   __syncthreads();
-  if (s_last) return;  // no sums: nothing may be marked or written with them (the host reports Ctl.grid_timeout)
   TileSums ts;
   ts.pre = s4[0];
   ts.tot = s4[1];
   ts.q2 = u128{s4[2], s4[3]};
-  // ---- workgroup 0: what k_quantize_reduce's and k_plan_mark's first threads leave in Ctl
-  if (blockIdx.x == 0 && tid == 0) {
+  // ---- what k_quantize_reduce's and k_plan_mark's first threads leave in Ctl: workgroup 0 after it has seen the sums,
+  // i.e. after every workgroup has arrived (and read what it needs of Ctl); the last arrival when the launch gave up
+  if (tid == 0 && (gaveup ? last : blockIdx.x == 0)) {
     if (settle && ctl->pending) {
       ctl->cur ^= 1;
       ctl->pending = 0;
@@ -797,6 +925,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
     ctl->shift = shift;
     ctl->wmax = wmax;
     finalize_plan(ctl, ts.tot, 0, ts.tot, ts.q2, pa);
+    if (gaveup) ctl->grid_timeout += 1;
   }
   // ---- B: plan_mark_tile from here on
   const int fire = gate_decision(mode, ts, pa);
@@ -805,44 +934,56 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
     double dummy;
     rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
   }
-  if constexpr (FS_WEIGHTS) {
-    if (!fire) {
-      if (mode != kImageWeights) return;  // all-zero weights stay untouched (fastslam1.rs:198-202)
-      const double sum = rr_fix_total_to_double(ts.tot, shift);
-#pragma unroll
-      for (int j = 0; j < kItems; ++j)
-        if (i0 + j < a.n) w[i0 + j] = w_in[j] / sum;
-      return;
-    }
-    const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
-    mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry);
-    const double w_new = 1.0 / (double)pa.n_global;
-#pragma unroll
-    for (int j = 0; j < kItems; ++j)
-      if (i0 + j < a.n) w[i0 + j] = w_new;
-    return;
-  }
-  if (!fire && !ea.want) return;
   unsigned int offspring[kItems];
-  if (fire) {
-    const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
-    mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry, ea.want ? offspring : nullptr);
+  const double denom = fire ? (double)pa.n_global : (double)ts.tot;
+  const bool want_est = !FS_WEIGHTS && ea.want;
+  if (FS_WEIGHTS ? (!fire && mode != kImageWeights) : (!fire && !want_est)) return;  // nothing to write
+  // One tile -- this workgroup's, its image still in registers -- or, when the launch gave up and this workgroup arrived
+  // last, every tile one after the other (the serial plan): the same code either way.
+  uint64_t tile = gaveup ? 0 : blockIdx.x;
+  const uint64_t tile_end = gaveup ? n_tiles : tile + 1;
+  for (; tile < tile_end; ++tile) {
+    const uint64_t j0 = tile * kTile + (uint64_t)tid * kItems;
+    if (gaveup) {
+      __syncthreads();
+      uint64_t tt;
+      u128 qq;
+      plan_image_tile<FS_WEIGHTS>(w, a, mode, shift, tile, s_w, s4, t, w_in, &tt, &qq);
+      if (tid == 0) s_tile[0] = ld_dev(&rec[tile * kRecWords + 3]);
+      if (want_est) est_prefetch(ea, cur_after, j0, a.n, ef);
+      __syncthreads();
+      ts.pre = s_tile[0];
+    }
+    plan_apply_tile<FS_WEIGHTS>(w, a, mode, shift, t, w_in, ts, fire, rho, pa, tile, markers, carry, ea, ef, offspring);
+    if (want_est) est_tile_partial(ea, t, offspring, fire, j0, a.n, ef, tile);
   }
-  if (ea.want)
-    plan_estimate(ea, ctl, t, offspring, fire, i0, a.n, fire ? (double)pa.n_global : (double)ts.tot, pa.rstep, cur_after);
+  if (!want_est) return;
+  // the estimate: the last workgroup to get here adds the tiles' partial sums (the serial plan: this one)
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = gaveup ? 1 : (last_arrival(ea.ticket, blockIdx.x, gridDim.x) ? 1 : 0);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  est_finalize(ea, ctl, (unsigned int)n_tiles, denom, pa.rstep);
 }
 
 // sharded: the plan is already in Ctl (k_shard_plan); mark this shard's sources.  tile_offset =
 // exclusive tile prefix written by k_scan_tiles.
+// window != 0 (peer-to-peer step): marker position of global slot s is s + pad (see resolve_tile_window) instead of
+// s - served_first
 static __global__ __launch_bounds__(kTileBlock) void k_mark(const double* __restrict__ w, const Ctl* __restrict__ ctl,
                                                        ImageArgs a, const uint64_t* __restrict__ tile_offset,
                                                        unsigned int* __restrict__ markers,
-                                                       unsigned int* __restrict__ carry) {
+                                                       unsigned int* __restrict__ carry, int window = 0, uint64_t pad = 0) {
   if (!ctl->fired) return;
   __shared__ uint64_t s_w[kTileBlock / kWave];
   const TileScan t = tile_scan(w, a, ctl->image_mode, ctl->shift, blockIdx.x, s_w);
   const rr_sys_plan plan = ctl->plan;
-  const uint64_t slot_base = ctl->served_first;
+  const uint64_t slot_base = window ? (uint64_t)0 - pad : ctl->served_first;
   const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
   mark_sources(t, ctl->base + tile_offset[blockIdx.x] + t.thread_off, i0, a.n, plan, ctl->total, slot_base, markers, carry);
 }
@@ -863,6 +1004,47 @@ __device__ inline void resolve_tile(unsigned int* __restrict__ markers, const un
     if (k < n_slots) {
       m = markers[k];
       if (m) markers[k] = 0;
+    }
+    m = wave_scan_max_u32(m);
+    if (lane == 63) s_m[wv] = m;
+    __syncthreads();
+    unsigned int pre = run;
+    for (int q = 0; q < wv; ++q) pre = s_m[q] > pre ? s_m[q] : pre;
+    if (pre > m) m = pre;
+    idx[r] = m - 1;
+    unsigned int row_max = run;
+    for (int q = 0; q < kBlock / kWave; ++q) row_max = s_m[q] > row_max ? s_m[q] : row_max;
+    run = row_max;
+    __syncthreads();
+  }
+}
+
+// Sharded step over the peer-to-peer transport: the marker space is the GLOBAL slot index shifted by `pad`, pad chosen so
+// that this shard's own block of slots starts on a tile boundary (position P0 = first own global slot + pad, P0 % kResolveSlots
+// == 0): own slot k sits at P0 + k, and the consumer -- the next step's k_step_lazy -- resolves the tiles of its own block
+// exactly as the unsharded kernel does, no index array in between.  This shard's sources feed the positions
+// [p_first, p_end) (Ctl.served_first/count + pad): a window that overlaps the own block almost entirely and sticks out of it
+// by the few slots the cumulative weight has drifted across the block boundaries.  Slots of the own block outside the
+// window are served by a peer (delivered into this rank's inbox); positions of the window outside the own block belong
+// to peers (k_push_window delivers them).  Differences to resolve_tile: markers outside the window are not read (they are
+// zero anyway), the carry of a tile is only meaningful when the tile STARTS inside the window (a slot run crosses or begins
+// at its first position; the tile that contains p_first starts with no source), and only positions in [clear_lo, clear_hi)
+// are consumed -- the own block by the consumer, the rest by the push kernel, which reads own positions of a shared
+// boundary tile for its running maximum but leaves them set.
+__device__ inline void resolve_tile_window(unsigned int* __restrict__ markers, const unsigned int* __restrict__ carry, uint64_t tile,
+                                           uint64_t p_first, uint64_t p_end, uint64_t clear_lo, uint64_t clear_hi,
+                                           unsigned int idx[kResolveRows]) {
+  __shared__ unsigned int s_m[kBlock / kWave];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint64_t tile_base = tile * kResolveSlots;
+  unsigned int run = (tile_base >= p_first && tile_base < p_end) ? carry[tile] : 0u;
+#pragma unroll
+  for (int r = 0; r < kResolveRows; ++r) {
+    const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
+    unsigned int m = 0;
+    if (k >= p_first && k < p_end) {
+      m = markers[k];
+      if (m && k >= clear_lo && k < clear_hi) markers[k] = 0;
     }
     m = wave_scan_max_u32(m);
     if (lane == 63) s_m[wv] = m;

@@ -8,6 +8,7 @@
 #include <mutex>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -128,6 +129,18 @@ inline void spin_release(int device, const void* handle) {  // the handle's stre
   SpinGate& g = spin_gate(device);
   std::lock_guard<std::mutex> lock(g.m);
   if (g.holder == handle) g.holder = nullptr;
+}
+
+// how long a workgroup of a one-launch plan waits for the others before the launch degrades to the serial plan
+// (resample_core.hpp, k_quantize_plan_mark), in ticks of the 100 MHz wall clock: RR_PF_PLAN_TIMEOUT_US, default 2000 us
+// (0: give up at once -- the test hook that exercises the serial plan on an idle device)
+inline uint64_t plan_giveup_ticks() {
+  static const uint64_t ticks = [] {
+    const char* e = std::getenv("RR_PF_PLAN_TIMEOUT_US");
+    const double us = e ? std::atof(e) : 2000.0;
+    return (uint64_t)((us >= 0.0 ? us : 2000.0) * 100.0);
+  }();
+  return ticks;
 }
 
 // ---- wave64 primitives (gfx950: a wavefront is 64 lanes) ------------------------------

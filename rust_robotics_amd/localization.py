@@ -345,6 +345,13 @@ class ParticleFilterLocalizer:
         _check(self._L.rr_pf_get_counters(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def plan_stats(self) -> Tuple[int, bool]:
+        """(launches of the one-launch resample plan that degraded to the serial plan because the device did not run
+        all of their workgroups at once, whether the handle still uses the one-launch plan) -- ``rr_pf_plan_stats``"""
+        g, e = C.c_uint64(), C.c_int32()
+        _check(self._L.rr_pf_plan_stats(self._h, C.byref(g), C.byref(e)))
+        return g.value, bool(e.value)
+
     # ---- measurement hooks
     def profile_enable(self, on) -> None:
         """False/0 off; True/1 HIP events around every launch (adds ~3 us per launch); 2 only the

@@ -198,6 +198,13 @@ class FastSlam1:
         _check(self._L.rr_fs1_get_counters(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def plan_stats(self) -> Tuple[int, bool]:
+        """(launches of the one-launch resample plan that degraded to the serial plan, whether the handle still uses
+        the one-launch plan) -- ``rr_fs1_plan_stats``"""
+        g, e = C.c_uint64(), C.c_int32()
+        _check(self._L.rr_fs1_plan_stats(self._h, C.byref(g), C.byref(e)))
+        return g.value, bool(e.value)
+
     # ---- measurement hooks
     def profile_enable(self, on) -> None:
         """False/0 off; True/1 HIP events around every launch; 2 only k_fs1_observe, timed by the
