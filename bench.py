@@ -190,7 +190,10 @@ def make_scene(L, steps, seed):
 # CPU baselines: oracle/ref_literal.c (the reference's arithmetic restated line by line) timed on this
 # box's host cores.  SURVEY.md 8d: per-particle stages under OpenMP on all cores, cumsum / resample walk
 # serial as in the reference; the reference's own O(N^2) multinomial resample timed separately at N = 1e4.
-def cpu_baseline(n, L, obs_list, max_seconds=12.0):
+def cpu_baseline(n, L, obs_list, max_seconds=12.0, scheme="systematic"):
+    """`value` = the literal restatement running the SAME step as the GPU leg it stands beside: the MCL step with the
+    reference's systematic walk (fastslam1.rs:205-234) for the systematic legs, with its multinomial draws
+    (monte_carlo_localization.rs:322-365, binary search) for the multinomial leg; the other variant is reported next to it."""
     import oracle
     from oracle import dp, u32p
 
@@ -199,7 +202,7 @@ def cpu_baseline(n, L, obs_list, max_seconds=12.0):
     model, nproc = host_cpu()
     sv, sw = 2.0, math.radians(40.0)
 
-    def run(threads, n_run, budget, literal_scan, scheme):
+    def run(threads, n_run, budget, literal_scan, scheme_id):
         used = ref.ref_set_threads(threads)
         x, y, yaw, v = (np.zeros(n_run) for _ in range(4))
         st = np.array([0.0, 0.0, 0.0, 1.0])
@@ -217,7 +220,7 @@ def cpu_baseline(n, L, obs_list, max_seconds=12.0):
             det.det_uniform2_v(1, 4, steps, 0, n_run, dp(r), dp(r2))
             nv, nw = sv * z0, sw * z1
             t0 = time.perf_counter()
-            ref.ref_pf_step_ex(n_run, dp(x), dp(y), dp(yaw), dp(v), dp(w), 1.0, 0.1, 0.1, dp(nv), dp(nw), dp(obs), L, 0.2, 1.0, scheme,
+            ref.ref_pf_step_ex(n_run, dp(x), dp(y), dp(yaw), dp(v), dp(w), 1.0, 0.1, 0.1, dp(nv), dp(nw), dp(obs), L, 0.2, 1.0, scheme_id,
                                dp(r), u32p(idx), dp(est), 1 if literal_scan else 0)
             dt = time.perf_counter() - t0
             if steps or budget < 1.0:  # the first step also pays for the thread team's creation
@@ -228,22 +231,59 @@ def cpu_baseline(n, L, obs_list, max_seconds=12.0):
         return n_run * L * timed / max(t_total, 1e-9), used, timed, t_total
 
     threads, table = pick_threads()
-    v_all, cores, s_all, t_all = run(threads, n, max_seconds, False, 1)
-    v_one, _, s_one, t_one = run(1, n, max_seconds / 2, False, 1)
+    main_id, other_id = (2, 1) if scheme == "systematic" else (1, 2)
+    names = {1: "multinomial draws + binary search (monte_carlo_localization.rs:322-365,387-392)", 2: "systematic walk (fastslam1.rs:205-234)"}
+    v_all, cores, s_all, t_all = run(threads, n, max_seconds, False, main_id)
+    v_one, _, s_one, t_one = run(1, n, max_seconds / 2, False, main_id)
+    v_oth, _, s_oth, t_oth = run(threads, n, max_seconds / 3, False, other_id)
     # the reference's own resample: a linear scan of the cumulative weights per draw (particle_filter.rs:455-470),
     # gate forced open (threshold 1.0 + scheme 0 fires whenever N_eff < N, i.e. always after a weight update)
     n_f = min(n, 10_000)
     v_f, _, s_f, t_f = run(threads, n_f, 4.0, True, 0)
     return dict(value=v_all, unit="particle-landmark updates/s", cores=cores, kind="port",
                 sample=f"oracle/ref_literal.c ref_pf_step (literal reference arithmetic; predict / weight / gather under OpenMP on "
-                       f"{cores} threads, cumsum + binary-search multinomial resample serial), {n} particles x {L} landmarks x {s_all} "
+                       f"{cores} threads, cumsum + resample -- {names[main_id]} -- serial), {n} particles x {L} landmarks x {s_all} "
                        f"steps, {t_all:.1f} s, noise samples pre-drawn",
                 host={"cpu_model": model, "nproc": nproc, "usable_cpus": _THREADS.get("avail"), "threads": cores,
                       "thread_calibration_updates_per_s": table},
                 single_thread={"value": v_one, "steps": s_one, "seconds": round(t_one, 2)},
+                other_resampler={"value": v_oth, "resample": names[other_id], "steps": s_oth, "seconds": round(t_oth, 2), "threads": cores},
                 reference_faithful={"value": v_f, "particles": n_f, "steps": s_f, "seconds": round(t_f, 2), "threads": cores,
                                     "note": "the reference's own O(N^2) resample (linear scan per draw, particle_filter.rs:455-470); "
                                             "infeasible at 1e6 particles (~5e11 compares per step), so measured at N = 1e4 and never extrapolated"})
+
+
+def index_parity(pf, n, L, scheme, obs):
+    """Checker, not product: how many output slots of ONE resample at this size pick a different particle than the reference's
+    own float walk over the same normalised weights and the same draws (the integer CDF is order-independent, the reference's
+    serial float cumsum is not: DESIGN.md section 2).  Runs after the timed regions on the filter the leg just timed."""
+    import oracle
+    from oracle import dp, u32p
+
+    ref = oracle.ref()
+    rng = np.random.default_rng(17)
+    pf.predict_with_control([1.0, 0.1])
+    pf.update_with_observations(obs)
+    w = pf.get_particles_array()[:, 4].copy()
+    lit = np.empty(n, np.uint32)
+    if scheme == "systematic":
+        rho = float(np.floor(rng.random() * 2**53) / 2**53)
+        pf.resample_systematic(rho)
+        ref.ref_fs1_resample_indices(n, dp(w.copy()), rho / n, u32p(lit))
+        walk = "fastslam1.rs:205-234 (r += 1/n accumulated serially)"
+    else:
+        r = np.floor(rng.random(n) * 2**53) / 2**53
+        pf.resample_with_uniforms(r)
+        ref.ref_mcl_resample_indices(n, dp(w), dp(r), u32p(lit))
+        walk = "monte_carlo_localization.rs:328-392 (serial float cumsum, first i with r <= c[i])"
+    got = pf.last_resample_indices()
+    diff = np.nonzero(got != lit)[0]
+    far = int(np.max(np.abs(got[diff].astype(np.int64) - lit[diff].astype(np.int64)))) if diff.size else 0
+    return {"resample": scheme, "slots": n, "differing_slots_vs_literal_float_walk": int(diff.size), "max_index_distance": far,
+            "literal_walk": walk,
+            "note": "identical weights and draws into the engine and into the literal restatement; a differing slot picks the neighbouring "
+                    "particle (the draw lies within the float cumsum's own rounding error of a boundary); bit-exact against the "
+                    "order-independent integer CDF of the D-spec at every size (tests/)"}
 
 
 def fs1_scene(L, seed, half=13.0):
@@ -467,7 +507,9 @@ def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True):
         "best_particle": {"index": i, "weight": w, "pose": [float(a) for a in pose]},
     }
     if with_cpu:
-        out["cpu_baseline"] = (fs2_cpu_baseline if v2 else fs1_cpu_baseline)(min(n, 20000), L, zs)
+        # FastSLAM 1.0: the literal restatement at the FULL particle count (1e5 x 200: ~2 GB of host memory for the maps and the
+        # clone buffer of the resample); FastSLAM 2.0 (not a BASELINE config) keeps the 20 000-particle sample
+        out["cpu_baseline"] = fs2_cpu_baseline(min(n, 20000), L, zs) if v2 else fs1_cpu_baseline(n, L, zs)
     return out
 
 
@@ -733,35 +775,40 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
         pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=ctx.local_rank,
                                                         resample_scheme=scheme, likelihood_mode=lik)
         u = [1.0, 0.1]
+        # The reference's try_step returns the refreshed mean EVERY step (particle_filter.rs:299,332,343,496), so the headline
+        # step is the one that produces it: rr_pf_step_async_estimate -- the mean of the resampled set accumulated inside the
+        # step's own plan kernel and kept on the device (one synchronisation at the end of the K steps).  The multinomial
+        # scheme has no in-step estimate: its step is the plain asynchronous one (the line says which).
+        with_est = args.scheme == "systematic"
+        step_fn = pf.step_async_estimate if with_est else pf.step_async
         for t in range(D):  # device warm-up (see DEVICE_WARMUP_MCL), then time moves on
-            pf.step_async(u, obs_list[t])
+            step_fn(u, obs_list[t])
         obs_list = obs_list[D:]
         for t in range(W):
-            pf.step_async(u, obs_list[t])
+            step_fn(u, obs_list[t])
         pf.synchronize()
         t0 = time.perf_counter()
         for t in range(W, W + K):
-            pf.step_async(u, obs_list[t])
+            step_fn(u, obs_list[t])
         pf.synchronize()
         dt = time.perf_counter() - t0
+        extra["headline_step"] = ("rr_pf_step_async_estimate: propagate + weight + resample + the mean try_step returns, every step"
+                                  if with_est else "rr_pf_step_async: propagate + weight + resample (no per-step estimate in the multinomial scheme)")
+        if with_est:
+            extra["last_step_estimate"] = [float(a) for a in pf.last_step_estimate()]
         est = pf.estimate()
-        # the reference's try_step returns the refreshed mean EVERY step (particle_filter.rs:299,332,343,496): the same K
-        # steps again with the estimate produced on the device inside every step (rr_pf_step_async_estimate; one
-        # synchronisation at the end, the K estimates read back from the device-side ring afterwards)
-        t_est = None
-        if args.scheme == "systematic":  # the in-step estimate belongs to the fused systematic step
+        # the same K steps again WITHOUT the per-step estimate (what a node that publishes every k-th estimate runs)
+        if with_est:
             for t in range(W + K, W + K + min(W, 10)):
-                pf.step_async_estimate(u, obs_list[t])
+                pf.step_async(u, obs_list[t])
             pf.synchronize()
             t1 = time.perf_counter()
             for t in range(W + K + min(W, 10), W + 2 * K):
-                pf.step_async_estimate(u, obs_list[t])
+                pf.step_async(u, obs_list[t])
             pf.synchronize()
-            t_est = (time.perf_counter() - t1) / max(K - min(W, 10), 1)
-            extra["estimate_every_step"] = {"ms_per_step": t_est * 1e3, "last_estimate": [float(a) for a in pf.last_step_estimate()],
-                                            "note": "rr_pf_step_async_estimate: the mean of the resampled set (particle_filter.rs:382-396,496) "
-                                                    "is accumulated inside the step's plan kernel and kept on the device; value/ms_per_step above "
-                                                    "are the plain asynchronous step"}
+            t_plain = (time.perf_counter() - t1) / max(K - min(W, 10), 1)
+            extra["plain_async_step"] = {"ms_per_step": t_plain * 1e3, "value": float(n) * L / t_plain,
+                                         "note": "rr_pf_step_async: the step without the per-step estimate"}
         # roofline kernel: the NEXT K steps (the filter resamples every step, so the work per step is stationary) in
         # which ONLY the propagate+weight kernel is timed, by the start/stop timestamps of its own dispatch packets
         # (hipExtLaunchKernelGGL on the filter's stream): no event packets in the stream, the kernel runs as in the
@@ -769,7 +816,7 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
         pf.profile_enable(2)
         pf.profile_reset()
         for t in range(W + 2 * K, W + 3 * K):
-            pf.step_async(u, obs_list[t])
+            step_fn(u, obs_list[t])
         pf.synchronize()
         dominant = pf.profile_read()["k_propagate_weight"]
         # per-kernel breakdown: an instrumented re-run of K steps with HIP events around every launch (adds
@@ -780,11 +827,18 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
             pf.profile_reset()
             t1 = time.perf_counter()
             for t in range(W + 3 * K, W + 4 * K):
-                pf.step_async(u, obs_list[t])
+                step_fn(u, obs_list[t])
             pf.synchronize()
             dt_instr = time.perf_counter() - t1
             prof = pf.profile_read()
         pf.profile_enable(0)
+        if with_cpu and n <= 4_000_000:  # (checker use of the oracle: part of the cpu_baseline leg)
+            pf2 = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=ctx.local_rank,
+                                                             resample_scheme=scheme, likelihood_mode=lik, record_indices=True)
+            for t in range(3):
+                pf2.step_async(u, obs_list[t])
+            extra["index_parity"] = index_parity(pf2, n, L, args.scheme, obs_list[3])
+            del pf2
         del pf
         res = dict(seconds=dt, seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est], dominant=dominant)
 
@@ -856,9 +910,32 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
     }
     out.update(extra)
     if with_cpu:
-        out["cpu_baseline"] = cpu_baseline(n, L, obs_list)
+        out["cpu_baseline"] = cpu_baseline(n, L, obs_list, max_seconds=getattr(args, "cpu_seconds", 12.0), scheme=args.scheme)
     if ctx.sharded:
         out["sharded"] = {k: res.get(k) for k in ("transport", "transport_note", "p2p_timed_out", "migrated_particles_last_step")}
+    return out
+
+
+def leg_sharded_world1(args, n, L, K, W):
+    """The sharded MCL step with ONE rank, once per transport: the peer-to-peer transport (validated against the unsharded
+    filter first, as in the multi-GPU run) and the native RCCL transport (a one-rank communicator: RCCL really called)."""
+    from rust_robotics_amd import sharded
+
+    out = {}
+    scheme = 1
+    lik = 0 if args.likelihood == "fused" else 1
+    obs = make_scene(L, 12 + W + 2 * K + EXTRA_WARMUP, seed=1)
+    unsharded_ms = None
+    for name, transport in (("p2p", "p2p-only"), ("rccl", "rccl")):
+        log(f"extra leg sharded_world1 / {name}")
+        try:
+            res = sharded.bench_sharded(0, 1, 0, n, L, K, W, obs, scheme, lik, transport)
+            out[name] = {"ms_per_step": res["seconds"] / K * 1e3, "value": float(n) * L * K / res["seconds"], "transport": res["transport"],
+                         "transport_note": res["transport_note"], "kernel_ms_avg": {k: v[1] / max(v[0], 1) for k, v in res["kernels"].items() if v[0]}}
+        except Exception as e:  # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+    out["note"] = ("world size 1 on this GPU: every exchange talks to itself, so this is the per-rank cost of the sharded step before any "
+                   "cross-device latency; steps = --steps, warm-up as in the multi-GPU legs")
     return out
 
 
@@ -908,11 +985,15 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="headline workload only (no fastslam / configs[3] / configs[4] legs)")
     ap.add_argument("--all-legs", action="store_true", help="run the configs[3] / configs[4] legs at any --gpus (default: only at 8)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded path even at --gpus 1")
+    ap.add_argument("--no-sharded-world1", action="store_true", help="skip the world-size-1 sharded legs of the default line")
     ap.add_argument("--transport", choices=["auto", "p2p", "rccl", "torch", "p2p-only"], default="auto",
                     help="sharded exchange: auto = peer-to-peer over xGMI if it validates at run time, else native RCCL, else "
                          "torch.distributed NCCL; p2p / rccl / torch restrict the ladder; p2p-only validates against the unsharded filter")
     args = ap.parse_args()
     _TRANSPORT["value"] = args.transport
+    # dmabuf IPC: hipIpcGetMemHandle and RCCL need it on this host driver.  Set before the first HIP / RCCL load of THIS
+    # process, so that ranks started by somebody else's launcher (the driver's torchrun) get it too, not only self-launched ones.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args.gpus)
@@ -974,6 +1055,24 @@ def main():
                     out["fastslam"]["cpu_baseline"] = leg["cpu_baseline"]
             except Exception as e:  # noqa: BLE001 -- the headline line survives a failing extra leg
                 out["fastslam"] = {"error": f"{type(e).__name__}: {e}"}
+            # the resampler the reference's ParticleFilterLocalizer / MonteCarloLocalizer really use (multinomial draws,
+            # particle_filter.rs:441-473, monte_carlo_localization.rs:322-365): the same workload with it, own roofline and CPU baseline
+            try:
+                log("extra leg mcl_multinomial")
+                import copy
+
+                a2 = copy.copy(args)
+                a2.scheme = "multinomial"
+                a2.cpu_seconds = 6.0
+                leg = leg_mcl(a2, ctx, n, L, K, W, with_cpu, breakdown=not args.no_breakdown)
+                out["mcl_multinomial"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernel_ms_avg",
+                                                              "headline_step", "index_parity", "cpu_baseline", "device_warmup_steps") if k in leg}
+            except Exception as e:  # noqa: BLE001
+                out["mcl_multinomial"] = {"error": f"{type(e).__name__}: {e}"}
+            # the sharded step at world size 1, both transports: what a rank of the 8-GPU run pays before any cross-device latency
+            # (weak-scaling ceiling = 8 x unsharded step / this)
+            if not args.no_sharded_world1:
+                out["sharded_world1"] = leg_sharded_world1(args, n, L, K, W)
         elif ctx.world == 8 or args.all_legs:
             per_gpu = 1_000_000 // 8 if ctx.world == 8 else 125_000
             # the extra legs never take the headline down with them: an exception becomes an "error" entry

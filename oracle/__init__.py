@@ -130,6 +130,8 @@ def ref() -> C.CDLL:
     L.ref_fs1_resample_indices.restype = None
     L.ref_fs1_gather.argtypes = [sz, sz, P, P, P, P, P, u32]
     L.ref_fs1_gather.restype = None
+    L.ref_fs1_observe.argtypes = [sz, sz, P, P, P, P, P, P, sz, MP]
+    L.ref_fs1_observe.restype = None
     L.ref_fs1_update.argtypes = [sz, sz, P, P, P, P, P, d, d, P, P, P, sz, MP, d, d, u32]
     L.ref_fs1_update.restype = i
     L.ref_fs1_best_particle.argtypes = [sz, P]

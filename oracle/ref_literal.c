@@ -294,11 +294,15 @@ void ref_pf_gather(size_t n, double* x, double* y, double* yaw, double* v, doubl
  * N_eff-gated resample (:337-345).  r_draws: n uniforms used iff the gate fires.
  * scheme: 0 = PF (:441-473, gate n_eff < n*threshold, default index 0)
  *         1 = fixed-N MCL (monte_carlo_localization.rs:298, every step, fallback last)
+ *         2 = the MCL step with the reference's SYSTEMATIC walk (fastslam1.rs:205-234; r0 = r_draws[0] / n) instead of
+ *             its multinomial draws: the CPU counterpart of the engine's systematic option (bench.py's like-for-like baseline)
  * Returns 1 if it resampled.  est_out (4) = estimate after the step (Q15). */
 int ref_pf_step_ex(size_t n, double* x, double* y, double* yaw, double* v, double* w,
                    double u0, double u1, double dt, const double* nv, const double* nw,
                    const double* obs, size_t n_obs, double sigma, double resample_threshold,
                    int scheme, const double* r_draws, uint32_t* idx_scratch, double* est_out, int literal_scan);
+
+void ref_fs1_resample_indices(size_t n, double* pw, double r0, uint32_t* idx);
 
 int ref_pf_step(size_t n, double* x, double* y, double* yaw, double* v, double* w,
                 double u0, double u1, double dt, const double* nv, const double* nw,
@@ -320,6 +324,10 @@ int ref_pf_step_ex(size_t n, double* x, double* y, double* yaw, double* v, doubl
   int fired = 0;
   if (scheme == 1) {
     ref_mcl_resample_indices(n, w, r_draws, idx_scratch);
+    ref_pf_gather(n, x, y, yaw, v, w, idx_scratch);
+    fired = 1;
+  } else if (scheme == 2) {
+    ref_fs1_resample_indices(n, w, r_draws[0] / (double)n, idx_scratch);
     ref_pf_gather(n, x, y, yaw, v, w, idx_scratch);
     fired = 1;
   } else {
@@ -509,6 +517,19 @@ void ref_fs1_gather(size_t n, size_t L, double* px, double* py, double* pyaw, do
   free(t);
 }
 
+/* the observation loop of fastslam_update, fastslam1.rs:250-256: observation outer, particle inner (the particles
+ * are independent of each other, so the inner loop may run under OpenMP) */
+void ref_fs1_observe(size_t n, size_t L, const double* px, const double* py, const double* pyaw, double* pw, double* lm,
+                     const double* z, size_t n_z, const ref_fs1_model* m) {
+  for (size_t k = 0; k < n_z; ++k) {
+    double zd = z[3 * k], za = z[3 * k + 1];
+    size_t id = (size_t)z[3 * k + 2];
+    REF_PARALLEL_FOR
+    for (size_t p = 0; p < n; ++p)
+      ref_fs1_update_landmark(px[p], py[p], pyaw[p], &pw[p], zd, za, lm + (p * L + id) * 6, m);
+  }
+}
+
 /* fastslam1.rs:237-266.  z = n_z x (d, angle, id as double); nth = NTH (66.67 in the
  * reference); r0 used iff the gate fires.  Returns 1 if it resampled. */
 int ref_fs1_update(size_t n, size_t L, double* px, double* py, double* pyaw, double* pw, double* lm,
@@ -516,13 +537,7 @@ int ref_fs1_update(size_t n, size_t L, double* px, double* py, double* pyaw, dou
                    const double* z, size_t n_z, const ref_fs1_model* m, double nth, double r0,
                    uint32_t* idx_scratch) {
   ref_fs1_predict(n, px, py, pyaw, u0, u1, z0, z1, m);
-  for (size_t k = 0; k < n_z; ++k) { /* observation outer, particle inner :250-256 */
-    double zd = z[3 * k], za = z[3 * k + 1];
-    size_t id = (size_t)z[3 * k + 2];
-    REF_PARALLEL_FOR
-    for (size_t p = 0; p < n; ++p)
-      ref_fs1_update_landmark(px[p], py[p], pyaw[p], &pw[p], zd, za, lm + (p * L + id) * 6, m);
-  }
+  ref_fs1_observe(n, L, px, py, pyaw, pw, lm, z, n_z, m);
   ref_fs1_normalize(n, pw);
   double neff = ref_fs1_neff(n, pw);
   if (neff < nth) {
