@@ -918,24 +918,28 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
 
 def leg_sharded_world1(args, n, L, K, W):
     """The sharded MCL step with ONE rank, once per transport: the peer-to-peer transport (validated against the unsharded
-    filter first, as in the multi-GPU run) and the native RCCL transport (a one-rank communicator: RCCL really called)."""
-    from rust_robotics_amd import sharded
-
+    filter first, as in the multi-GPU run) and the native RCCL transport (a one-rank communicator: RCCL really called).
+    Each in a process of its own (`bench.py --force-sharded --transport ...`): the sharded legs need torch.distributed, and
+    torch's bundled HIP runtime has to be the first one a process loads."""
     out = {}
-    scheme = 1
-    lik = 0 if args.likelihood == "fused" else 1
-    obs = make_scene(L, 12 + W + 2 * K + EXTRA_WARMUP, seed=1)
-    unsharded_ms = None
     for name, transport in (("p2p", "p2p-only"), ("rccl", "rccl")):
         log(f"extra leg sharded_world1 / {name}")
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR")}
+        env["MASTER_PORT"] = str(free_port())
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-sharded", "--transport", transport, "--no-extra-legs",
+               "--no-cpu-baseline", "--steps", str(K), "--warmup", str(W), "--particles", str(n), "--landmarks", str(L), "--likelihood", args.likelihood]
         try:
-            res = sharded.bench_sharded(0, 1, 0, n, L, K, W, obs, scheme, lik, transport)
-            out[name] = {"ms_per_step": res["seconds"] / K * 1e3, "value": float(n) * L * K / res["seconds"], "transport": res["transport"],
-                         "transport_note": res["transport_note"], "kernel_ms_avg": {k: v[1] / max(v[0], 1) for k, v in res["kernels"].items() if v[0]}}
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+            if r.returncode != 0 or not lines:
+                raise RuntimeError(f"rc {r.returncode}: {r.stderr[-400:]}")
+            d = json.loads(lines[-1])
+            out[name] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "sharding": d["config"]["sharding"],
+                         "kernel_ms_avg": d.get("kernel_ms_avg"), "steps": d["steps"], "warmup": d["warmup"]}
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": f"{type(e).__name__}: {e}"}
     out["note"] = ("world size 1 on this GPU: every exchange talks to itself, so this is the per-rank cost of the sharded step before any "
-                   "cross-device latency; steps = --steps, warm-up as in the multi-GPU legs")
+                   "cross-device latency (weak-scaling ceiling at 8 GPUs = 8 x plain_async_step / this)")
     return out
 
 

@@ -1348,9 +1348,7 @@ rr_status rr_fs1_update_async(rr_fs1* h, const double u[2], const double* z, siz
 rr_status rr_fs1_synchronize(rr_fs1* h) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
-  RR_HIP_TRY(hipStreamSynchronize(h->stream));
-  rr::spin_release(h->opt.device, h);
-  return h->p2p.check(h->stream);
+  return fetch_ctl(h);  // waits for the stream; also where a handle learns that its one-launch plan had to degrade
 }
 
 rr_status rr_fs1_update(rr_fs1* h, const double u[2], const double* z, size_t n_z) {

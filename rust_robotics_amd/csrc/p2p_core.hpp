@@ -328,6 +328,18 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
   mark_sources(t, base + pre + t.thread_off, i0, a.n, plan, total, (uint64_t)0 - slot_pad, markers, carry);
 }
 
+// Inbox traffic goes around every cache: system-scope (sc0 sc1) stores on the delivering side, system-scope loads on the
+// reading side.  The reader consumes a delivery INSIDE a kernel (after an in-kernel wait for DONE), not behind a kernel
+// boundary, so nothing may depend on which lines an L2 -- eight of them per device, one per XCD -- still holds from the
+// step before or on how a peer's mapping of the buffer is cached.  Only the slots that cross a shard boundary take this
+// path (10^3 - 10^4 of 10^6 in steady state).
+__device__ inline void st_sys(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<uint64_t*>(p), (uint64_t)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline double ld_sys(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+
 // ------------------------------------------------------------------------------------------
 // DONE: "every particle this rank had to deliver into a peer's inbox has landed".  Sent by the last workgroup of
 // k_push_window (one thread per peer, system-scope release after the workgroups' own system-scope fences) and awaited

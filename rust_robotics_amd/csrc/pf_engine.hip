@@ -296,9 +296,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
       if (k < p.n) {
         const uint64_t j = idx[r];
         if (SRC == kSrcWindow && pending && (pos0 + (uint64_t)r * kBlock + tid < win_lo || pos0 + (uint64_t)r * kBlock + tid >= win_hi)) {
-          x[r] = wa.inbox[k];  // delivered by a peer into this rank's inbox [field][n]
-          y[r] = wa.inbox[p.n + k];
-          yaw[r] = wa.inbox[2 * p.n + k];
+          x[r] = rr::ld_sys(wa.inbox + k);  // delivered by a peer into this rank's inbox [field][n]
+          y[r] = rr::ld_sys(wa.inbox + p.n + k);
+          yaw[r] = rr::ld_sys(wa.inbox + 2 * p.n + k);
         } else if (PACKED && pending) {
           const double4 rec = *reinterpret_cast<const double4*>((src ? pk1 : pk0) + 4 * j);
           x[r] = rec.x;
@@ -688,10 +688,10 @@ __global__ __launch_bounds__(kBlock) void k_push_window(Bufs b, const Ctl* __res
           const uint64_t d = s / n_local, li = s - d * n_local;
           const uint64_t j = idx[r];
           double* __restrict__ out = peers.inbox[d];  // fine-grained, [field][n_local]
-          out[li] = b.x[src][j];
-          out[n_local + li] = b.y[src][j];
-          out[2 * n_local + li] = b.yaw[src][j];
-          out[3 * n_local + li] = b.v[src][j];
+          rr::st_sys(out + li, b.x[src][j]);
+          rr::st_sys(out + n_local + li, b.y[src][j]);
+          rr::st_sys(out + 2 * n_local + li, b.yaw[src][j]);
+          rr::st_sys(out + 3 * n_local + li, b.v[src][j]);
           stored = true;
         }
       }
@@ -726,10 +726,10 @@ __global__ __launch_bounds__(kBlock) void k_resolve_gather_window(Bufs b, const 
     if (k >= n) continue;
     const uint64_t pos = own0 + k;
     if (pos < win_lo || pos >= win_hi) {
-      b.x[dst][k] = inbox[k];
-      b.y[dst][k] = inbox[n + k];
-      b.yaw[dst][k] = inbox[2 * n + k];
-      b.v[dst][k] = inbox[3 * n + k];
+      b.x[dst][k] = rr::ld_sys(inbox + k);
+      b.y[dst][k] = rr::ld_sys(inbox + n + k);
+      b.yaw[dst][k] = rr::ld_sys(inbox + 2 * n + k);
+      b.v[dst][k] = rr::ld_sys(inbox + 3 * n + k);
       if (idx_out) idx_out[k] = kInPlace;
     } else {
       const uint64_t j = idx[r];
@@ -1079,6 +1079,7 @@ struct rr_pf {
   unsigned int* carry = nullptr;    // one per kResolveSlots slots
   double* partials = nullptr;
   double* est_partials = nullptr;      // [kFusedMaxTiles][4] per-workgroup sums of the fused per-step estimate
+  double* est_partials_host = nullptr; // pinned copy, made when the estimate is read
   // k_quantize_plan_mark (K2 + fused plan in one launch): one record per tile, the launch epoch, the largest grid whose
   // workgroups are all resident at once (0: not available), RR_PF_FUSED_PLAN=0 turns it off
   double* packed[2] = {nullptr, nullptr};  // {x, y, yaw, v} mirrors of the two buffer sets (k_step_lazy<PACKED>; lazy multinomial only)
@@ -1109,6 +1110,7 @@ struct rr_pf {
   bool maybe_pending = false;    // a lazy resample plan was launched and nothing has consumed its markers yet
   int pending_kind = kSrcMarkers;  // ... StepSrc: where its sources are (markers / lidx of the multinomial step / window of a shard)
   uint64_t slot_pad = 0;           // shard of the peer-to-peer transport: marker position of global slot s = s + slot_pad
+  uint64_t window_seq = 0;         // ... and the exchange sequence number of the step whose window resample is pending (its DONE)
   unsigned int* push_ticket = nullptr;  // arrival counters of k_push_window (zero between launches)
   unsigned int* lidx = nullptr;  // source index per slot; kInPlace = a peer stored the particle already (sharded)
   rr_pf_lik lik{};
@@ -1314,7 +1316,7 @@ rr_status materialise(rr_pf* h) {
   if (h->pending_kind == kSrcWindow) {  // a shard: the peers' deliveries of the last step must have landed first
     Timed t(h, RR_K_RESAMPLE_GATHER);
     hipLaunchKernelGGL(rr::k_p2p_wait_done, dim3(1), dim3(64), 0, h->stream, (const rr::P2PMailbox*)h->p2p.mbox, h->p2p.peers.n_ranks,
-                       h->p2p.seq, h->p2p.peers.timeout_ticks, h->p2p.err);
+                       h->window_seq, h->p2p.peers.timeout_ticks, h->p2p.err);
     hipLaunchKernelGGL(k_resolve_gather_window, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b, h->ctl,
                        h->markers, h->carry, h->n, h->opt.first_global_index, h->slot_pad, (const double*)h->p2p.inbox, h->idx);
     hipLaunchKernelGGL(k_settle, dim3(1), dim3(1), 0, h->stream, h->ctl);
@@ -1981,6 +1983,7 @@ void rr_pf_destroy(rr_pf* h) {
   (void)hipFree(h->carry);
   (void)hipFree(h->partials);
   (void)hipFree(h->est_partials);
+  if (h->est_partials_host) (void)hipHostFree(h->est_partials_host);
   (void)hipFree(h->mn_tile_cnt);
   (void)hipFree(h->est_ticket);
   (void)hipFree(h->push_ticket);
@@ -2151,18 +2154,22 @@ rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!out) return fail(RR_INVALID_PARAMETER, "null output");
-  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  if (!h->est_partials_host) RR_HIP_TRY(hipHostMalloc(&h->est_partials_host, (size_t)rr::kFusedMaxTiles * 4 * sizeof(double)));
+  RR_HIP_TRY(hipMemcpyAsync(h->est_partials_host, h->est_partials, (size_t)h->n_tiles * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if ((s = fetch_ctl(h)) != RR_OK) return s;  // (synchronises the stream)
   if (h->ctl_host->est_step == 0) return fail(RR_INVALID_PARAMETER, "no step has produced an in-step estimate yet");
-  std::memcpy(out, h->ctl_host->est, 4 * sizeof(double));
+  // the tiles' partial sums in tile order (a fixed order: the same bits whichever plan kernel produced them)
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (uint64_t t = 0; t < h->n_tiles; ++t)
+    for (int k = 0; k < 4; ++k) acc[k] += h->est_partials_host[4 * t + k];
+  for (int k = 0; k < 4; ++k) out[k] = acc[k] / h->ctl_host->est_denom;
   return RR_OK;
 }
 
 rr_status rr_pf_synchronize(rr_pf* h) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
-  RR_HIP_TRY(hipStreamSynchronize(h->stream));
-  rr::spin_release(h->opt.device, h);
-  return h->p2p.check(h->stream);
+  return fetch_ctl(h);  // waits for the stream; also the place where a handle learns that its one-launch plan had to degrade
 }
 
 rr_status rr_pf_estimate(rr_pf* h, double out[4]) {
@@ -2628,7 +2635,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   wa.inbox = h->p2p.inbox;
   wa.err = h->p2p.err;
   wa.pad = h->slot_pad;
-  wa.wait_seq = h->p2p.seq;  // the DONE of the step whose resample this launch consumes
+  wa.wait_seq = h->window_seq;  // the DONE of the step whose resample this launch consumes
   wa.timeout_ticks = h->p2p.peers.timeout_ticks;
   wa.n_ranks = h->p2p.peers.n_ranks;
   const uint64_t seq = ++h->p2p.seq;
@@ -2692,6 +2699,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   RR_HIP_TRY(hipGetLastError());
   h->maybe_pending = true;
   h->pending_kind = kSrcWindow;
+  h->window_seq = seq;
   return RR_OK;
 }
 

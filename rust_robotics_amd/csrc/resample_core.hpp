@@ -72,8 +72,9 @@ struct Ctl {
   uint64_t best_index;
   uint64_t served_first;  // systematic plan: this shard's sources feed global slots [served_first,
   uint64_t served_count;  //   served_first + served_count) -- computed once by finalize_plan
-  double est[4];          // mean of the particle set after the step (fused plan kernel, EstArgs.want)
-  uint64_t est_step;      // resample-step counter the mean belongs to (+1; 0 = none yet)
+  double est[4];          // (unused since round 3: the tiles' partial sums are added on the host when the estimate is read)
+  uint64_t est_step;      // resample-step counter the in-step estimate belongs to (+1; 0 = none yet)
+  double est_denom;       // ... and what the sum of the tiles' partial sums is divided by (N when the resample fired, else T)
 };
 
 // q_i of local particle i (global index gid0 + i)
@@ -548,7 +549,7 @@ __device__ inline bool last_arrival(unsigned int* ticket, unsigned int block, un
 struct EstArgs {
   const double* field[2][4];  // x, y, yaw, v of both buffer sets
   double* partials;           // [n_tiles][4]
-  unsigned int* ticket;       // kTicketWords counters (last_arrival), zero between launches
+  unsigned int* ticket;       // (unused since round 3)
   int want;
 };
 
@@ -607,34 +608,13 @@ __device__ inline void est_tile_partial(const EstArgs& ea, const TileScan& t, co
   __syncthreads();  // (s_acc may be reused by the next tile of the serial plan)
 }
 
-// the workgroup that knows every tile's partial sums are in memory adds them in tile order: wave k adds moment k, lanes
-// stride over the tiles (fixed order per lane), then a shuffle tree
-__device__ inline void est_finalize(const EstArgs& ea, Ctl* __restrict__ ctl, unsigned int n_tiles, double denom, unsigned int rstep) {
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (wv < 4) {
-    double v = 0.0;
-    for (unsigned int b = lane; b < n_tiles; b += 64) v += __builtin_nontemporal_load(&ea.partials[(uint64_t)b * 4 + wv]);
-    v = wave_sum(v);
-    if (lane == 0) ctl->est[wv] = v / denom;
-  }
-  if (tid == 0) ctl->est_step = (uint64_t)rstep + 1;
-}
-
-__device__ inline void plan_estimate(const EstArgs& ea, Ctl* __restrict__ ctl, const TileScan& t, const unsigned int* offspring,
-                                     int fire, uint64_t i0, uint64_t n, double denom, unsigned int rstep, const EstFields& e) {
-  __shared__ int s_last;
-  const int tid = threadIdx.x;
-  est_tile_partial(ea, t, offspring, fire, i0, n, e, blockIdx.x);
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    s_last = last_arrival(ea.ticket, blockIdx.x, gridDim.x);
-  }
-  __syncthreads();
-  if (!s_last) return;
-  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  __syncthreads();
-  est_finalize(ea, ctl, gridDim.x, denom, rstep);
+// Nothing in the kernel waits for the tiles' partial sums: whoever reads the estimate (rr_pf_last_step_estimate, after the
+// stream has drained) adds the n_tiles x 4 numbers on the host, in tile order, and divides by Ctl.est_denom.  Round 2 had
+// the last workgroup to arrive do that inside the kernel: a fence, a ticket and a dependent read-back at the tail of
+// every step for a number that is read once in a while.  One thread of the launch records which step the sums belong to.
+__device__ inline void est_publish(Ctl* __restrict__ ctl, double denom, unsigned int rstep) {
+  ctl->est_denom = denom;
+  ctl->est_step = (uint64_t)rstep + 1;
 }
 
 // fused plan + mark (single shard, systematic, n_tiles <= kFusedMaxTiles)
@@ -666,7 +646,10 @@ static __global__ __launch_bounds__(kTileBlock) void k_plan_mark(const double* _
     const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
     mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry, ea.want ? offspring : nullptr);
   }
-  if (ea.want) plan_estimate(ea, ctl, t, offspring, fire, i0, a.n, fire ? (double)pa.n_global : (double)ts.tot, pa.rstep, ef);
+  if (ea.want) {
+    est_tile_partial(ea, t, offspring, fire, i0, a.n, ef, blockIdx.x);
+    if (blockIdx.x == 0 && threadIdx.x == 0) est_publish(ctl, fire ? (double)pa.n_global : (double)ts.tot, pa.rstep);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -800,8 +783,10 @@ __device__ inline void plan_apply_tile(typename std::conditional<FS_WEIGHTS, dou
 
 // FS_WEIGHTS (FastSLAM, k_fs1_plan's weight handling): the weights are explicit -- w /= sum when the gate stays shut
 // (fastslam1.rs:196-203), w = 1/n when it fires (:228) -- and are rewritten by the threads that read them.
+// (amdgpu_waves_per_eu(4): at most 128 VGPRs, i.e. two of these 512-thread workgroups per CU -- the 489 workgroups of a
+// 1e6-particle filter must all be on the 256 CUs at once)
 template <bool FS_WEIGHTS>
-static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
+static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_quantize_plan_mark(
     typename std::conditional<FS_WEIGHTS, double*, const double*>::type w, Ctl* __restrict__ ctl,
     const double* __restrict__ wmax_src, ImageArgs a,
     uint64_t* __restrict__ rec, unsigned int* __restrict__ ticket /* kTicketWords, zero between launches */, uint64_t epoch,
@@ -825,7 +810,6 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
   TileScan t;
   const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)tid * kItems;
   EstFields ef;
-  if (!FS_WEIGHTS && ea.want) est_prefetch(ea, cur_after, i0, a.n, ef);
   double w_in[FS_WEIGHTS ? kItems : 1];
   uint64_t* const head = rec + n_tiles * kRecWords;
   {
@@ -843,6 +827,10 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
     }
   }
   __syncthreads();
+  // the particle fields of the estimate: requested HERE -- after this workgroup's record and ticket are out (the
+  // s_waitcnt in front of the ticket would otherwise wait for them too and delay every arrival), before the wait for the
+  // other workgroups' sums, which is when the memory system has nothing else to do
+  if (!FS_WEIGHTS && ea.want) est_prefetch(ea, cur_after, i0, a.n, ef);
   // ---- the last arrival: exclusive prefix per tile and the grand totals, then the state word
   const bool last = s_last != 0;
   if (last) {
@@ -957,18 +945,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_plan_mark(
     plan_apply_tile<FS_WEIGHTS>(w, a, mode, shift, t, w_in, ts, fire, rho, pa, tile, markers, carry, ea, ef, offspring);
     if (want_est) est_tile_partial(ea, t, offspring, fire, j0, a.n, ef, tile);
   }
-  if (!want_est) return;
-  // the estimate: the last workgroup to get here adds the tiles' partial sums (the serial plan: this one)
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    s_last = gaveup ? 1 : (last_arrival(ea.ticket, blockIdx.x, gridDim.x) ? 1 : 0);
-  }
-  __syncthreads();
-  if (!s_last) return;
-  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  __syncthreads();
-  est_finalize(ea, ctl, (unsigned int)n_tiles, denom, pa.rstep);
+  if (want_est && tid == 0 && (gaveup ? last : blockIdx.x == 0)) est_publish(ctl, denom, pa.rstep);
 }
 
 // sharded: the plan is already in Ctl (k_shard_plan); mark this shard's sources.  tile_offset =

@@ -99,7 +99,7 @@ def serial_fs():
 def contend(box, who):
     import rust_robotics_amd.localization as loc
 
-    n, L, T = 1_000_000, 32, 400
+    n, L, T = 1_000_000, 32, 1500
     cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
     pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, resample_scheme=1)
     lms = H.landmarks_grid(L, 1)
@@ -129,7 +129,7 @@ def contend_reference():
     import rust_robotics_amd.localization as loc
 
     os.environ["RR_PF_FUSED_PLAN"] = "0"
-    n, L, T = 1_000_000, 32, 400
+    n, L, T = 1_000_000, 32, 1500
     cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
     pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, resample_scheme=1)
     lms = H.landmarks_grid(L, 1)

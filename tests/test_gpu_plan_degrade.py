@@ -44,3 +44,27 @@ def test_two_processes_on_one_gpu_do_not_break_each_other():
         f = so.split("CONTEND")[1].split()
         assert f[1] == want, f"process {f[0]} ended with a different particle set (give-ups {f[2]}, one-launch still on: {f[3]}, {f[4]} s)"
     print("give-ups / seconds:", [(so.split("CONTEND")[1].split()[2], so.split("CONTEND")[1].split()[4]) for so, _ in outs])
+
+
+def test_one_launch_plan_serves_the_headline_size():
+    """1e6 particles = 489 tiles: all of k_quantize_plan_mark's workgroups have to fit the device at once (two 512-thread
+    workgroups per CU, i.e. at most 128 VGPRs).  A register-count regression silently sends the headline workload down the
+    two-launch plan (round 3 saw exactly that while the kernel was being reworked); this notices."""
+    import numpy as np
+
+    import rust_robotics_amd.localization as loc
+    from tests import helpers as H
+
+    n, L = 1_000_000, 32
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
+    pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, resample_scheme=1)
+    lms = H.landmarks_grid(L, 1)
+    rng = np.random.default_rng(2)
+    pf.profile_enable(1)
+    for t in range(4):
+        (pf.step_async_estimate if t % 2 else pf.step_async)([1.0, 0.1], H.observations(lms, H.true_pose(t + 1), 0.2, rng))
+    prof = pf.profile_read()
+    pf.profile_enable(0)
+    assert prof["k_quantize_reduce"][0] == 0, f"the two-launch plan ran: {prof}"
+    assert prof["k_cdf"][0] == 4
+    assert pf.plan_stats() == (0, True)
