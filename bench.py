@@ -916,6 +916,94 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
     return out
 
 
+def leg_small_n(with_cpu):
+    """BASELINE.json configs[0]: the size every caller in the reference runs -- 1 000 particles x 4 landmarks (the reference's own
+    4-landmark scene, tests/unified_filter_comparison.rs:43), ParticleFilterLocalizer semantics (multinomial resample behind the
+    N_eff gate, particle_filter.rs:337-345,441-473).  One workgroup, one launch per step (k_step_small) or per batch of steps
+    (rr_pf_step_many); the literal restatement on ONE host core (the reference is single-threaded) beside it."""
+    import rust_robotics_amd.localization as loc
+    from tests import helpers as H
+
+    n, L, K = 1000, 4, 2000
+    cfg = loc.ParticleFilterConfig(n_particles=n, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))  # unified_filter_comparison.rs:278-285
+    rng = np.random.default_rng(42)
+    obs = np.stack([H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng) for t in range(K)])
+    u = np.tile([1.0, 0.1], (K, 1))
+    out = {"config": {"workload": f"particle filter (BASELINE.json configs[0]): {n} particles x {L} landmarks, multinomial resample behind the N_eff gate",
+                      "particles": n, "landmarks": L}, "steps": K}
+
+    def fresh():
+        return loc.ParticleFilterLocalizer.with_initial_state([0.0, 0.0, 0.0, 0.0], cfg, seed=42)
+
+    def timed(fn):
+        pf = fresh()
+        for t in range(200):
+            pf.step_async(u[t], obs[t])
+        pf.synchronize()
+        t0 = time.perf_counter()
+        fn(pf)
+        pf.synchronize()
+        return (time.perf_counter() - t0) / K * 1e6
+
+    def loop(method):
+        def run(pf):
+            f = getattr(pf, method)
+            for t in range(K):
+                f(u[t], obs[t])
+        return run
+
+    out["us_per_step"] = {
+        "step_async": timed(loop("step_async")),
+        "step_async_estimate": timed(loop("step_async_estimate")),
+        "step (synchronous, returns the estimate: try_step)": timed(loop("step")),
+        "step_many (one launch, estimates read back at the end)": timed(lambda pf: pf.step_many(u, obs)),
+        "step_many (one launch, no estimates)": timed(lambda pf: pf.step_many(u, obs, estimates=False)),
+    }
+    best = out["us_per_step"]["step_many (one launch, estimates read back at the end)"]
+    out["value"] = n * L / (best * 1e-6)
+    out["unit"] = "particle-landmark updates/s"
+    out["note"] = "value = rr_pf_step_many with the per-step estimates; a single workgroup on one of 256 CUs (the work of a step does not fill more)"
+    os.environ["RR_PF_SMALL"] = "0"
+    try:
+        pf = fresh()
+    finally:
+        del os.environ["RR_PF_SMALL"]
+    for t in range(200):
+        pf.step_async(u[t], obs[t])
+    pf.synchronize()
+    t0 = time.perf_counter()
+    for t in range(K):
+        pf.step_async(u[t], obs[t])
+    pf.synchronize()
+    out["us_per_step"]["step_async through the large kernels (RR_PF_SMALL=0)"] = (time.perf_counter() - t0) / K * 1e6
+    del pf
+    if with_cpu:
+        import oracle
+        from oracle import dp, u32p
+
+        ref, det = oracle.ref(), oracle.det()
+        ref.ref_set_threads(1)
+        x, y, yaw, v = (np.zeros(n) for _ in range(4))
+        w = np.full(n, 1.0 / n)
+        idx, est = np.empty(n, np.uint32), np.empty(4)
+        z0, z1, r, r2 = (np.empty(n) for _ in range(4))
+        t_total = 0.0
+        for t in range(K):
+            det.det_normal2_v(42, 3, t, 0, n, dp(z0), dp(z1))
+            det.det_uniform2_v(42, 4, t, 0, n, dp(r), dp(r2))
+            nv, nw = 0.3 * z0, math.radians(5.0) * z1
+            o = np.ascontiguousarray(obs[t])
+            t0 = time.perf_counter()
+            ref.ref_pf_step_ex(n, dp(x), dp(y), dp(yaw), dp(v), dp(w), 1.0, 0.1, 0.1, dp(nv), dp(nw), dp(o), L, 0.5, 0.5, 0, dp(r), u32p(idx), dp(est), 1)
+            t_total += time.perf_counter() - t0
+        model, nproc = host_cpu()
+        out["cpu_baseline"] = {"value": n * L * K / t_total, "unit": "particle-landmark updates/s", "cores": 1, "kind": "port", "us_per_step": t_total / K * 1e6,
+                               "sample": f"oracle/ref_literal.c ref_pf_step, literal reference arithmetic incl. its O(N^2) linear-scan resample "
+                                         f"(particle_filter.rs:455-470) and the estimate, {n} particles x {L} landmarks x {K} steps on one core "
+                                         f"({model}), noise samples pre-drawn"}
+    return out
+
+
 def leg_sharded_world1(args, n, L, K, W):
     """The sharded MCL step with ONE rank, once per transport: the peer-to-peer transport (validated against the unsharded
     filter first, as in the multi-GPU run) and the native RCCL transport (a one-rank communicator: RCCL really called).
@@ -1073,6 +1161,11 @@ def main():
                                                               "headline_step", "index_parity", "cpu_baseline", "device_warmup_steps") if k in leg}
             except Exception as e:  # noqa: BLE001
                 out["mcl_multinomial"] = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                log("extra leg small_n (configs[0])")
+                out["small_n"] = leg_small_n(with_cpu)
+            except Exception as e:  # noqa: BLE001
+                out["small_n"] = {"error": f"{type(e).__name__}: {e}"}
             # the sharded step at world size 1, both transports: what a rank of the 8-GPU run pays before any cross-device latency
             # (weak-scaling ceiling = 8 x unsharded step / this)
             if not args.no_sharded_world1:

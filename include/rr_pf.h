@@ -160,6 +160,15 @@ rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs,
  * step only (fixed N, one shard); rr_pf_step uses it automatically when it applies. */
 rr_status rr_pf_step_async_estimate(rr_pf* h, const double control[2], const double* obs, size_t n_obs);
 rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]);
+/* n_steps steps in one call: controls = n_steps x (v, yaw_rate), obs = n_steps x n_obs x (d, landmark_x, landmark_y) (the
+ * same number of observations every step).  out_estimates = n_steps x 4 receives what try_step would have returned after
+ * each step (the call then waits for the device), or NULL (asynchronous).  For particle sets of up to 2048 particles --
+ * every caller in the reference runs 100 - 1200 -- all steps run inside ONE kernel launch of one workgroup, the particles in
+ * registers from the first step to the last: a step costs its arithmetic instead of a launch.  The single-step entry points
+ * above use the same kernel for such sets (RR_PF_SMALL=0 at create time: never).  Larger filters: a loop over rr_pf_step /
+ * rr_pf_step_async.  Results are bit-identical to n_steps single steps. */
+rr_status rr_pf_step_many(rr_pf* h, const double* controls, const double* obs, size_t n_obs, size_t n_steps,
+                          double* out_estimates);
 /* wait for everything enqueued on the filter's stream */
 rr_status rr_pf_synchronize(rr_pf* h);
 

@@ -151,6 +151,7 @@ def lib() -> C.CDLL:
     proto("rr_pf_step_async", st, [H, P, P, sz])
     proto("rr_pf_step_async_estimate", st, [H, P, P, sz])
     proto("rr_pf_last_step_estimate", st, [H, P])
+    proto("rr_pf_step_many", st, [H, P, P, sz, sz, P])
     proto("rr_pf_synchronize", st, [H])
     proto("rr_pf_estimate", st, [H, P])
     proto("rr_pf_covariance", st, [H, P])

@@ -564,6 +564,324 @@ __global__ __launch_bounds__(kNumMoments * 64) void k_moments_final(Bufs b, Ctl*
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// SMALL particle sets: the whole step -- and K of them -- in ONE launch of ONE workgroup.
+// Every caller in the reference runs 100 - 1200 particles (headless_localizers.rs:56, render_gif_particle_filter.rs:77-79,
+// playground/src/localization.rs:58-66, tests/unified_filter_comparison.rs:286-295).  At that size the fused step of the
+// large filters (2 launches, 5 for the multinomial resampler) is nothing but launch latency: 16 us a step for 2 us of work.
+// Here the particles live in REGISTERS from the first step of the launch to the last (thread t owns the R consecutive slots
+// [t R, t R + R), R = 1 / 2 / 4 for N <= 512 / 1024 / 2048), the maximum and the integer sums are workgroup reductions, the
+// resample runs through LDS (systematic: slot-run markers + running maximum, exactly the large kernels' scheme; multinomial:
+// the integer CDF and one binary search per slot), the gather is an LDS round trip, and the mean try_step returns
+// (particle_filter.rs:488-497) is a workgroup sum.  Same per-element arithmetic (include/rr_pf_spec.h), same Philox
+// counters, same integer image: bit-identical to the large path and to the D-spec (tests/test_gpu_small_n.py).
+// rr_pf_step_many hands K controls and observation blocks over in one buffer; the single-step entry points use K = 1 with the
+// observations in the launch packet.
+constexpr int kSmallBlock = 512;
+constexpr uint64_t kSmallMaxParticles = 4 * kSmallBlock;
+
+struct SmallArgs {
+  uint64_t n;
+  uint64_t seed;
+  unsigned int step0, rstep0;
+  int n_obs, K;
+  int gate, scheme;       // rr_resample_gate, rr_resample_scheme
+  double neff_threshold;  // N * resample_threshold
+  double dt, sigma_v, sigma_w;
+  double u0, u1;          // K == 1: the control (else in steps_in)
+  rr_pf_lik lik;
+  int want_est;
+  int inputs_in_kernarg;  // K == 1 and the observations fit the launch packet
+};
+
+// workgroup-wide helpers of the small kernel (kSmallBlock threads); every thread gets the result
+__device__ inline double small_block_max(double v, double* s_red) {
+  const int tid = threadIdx.x;
+  const double m = rr::wave_max(v);
+  __syncthreads();
+  if ((tid & 63) == 0) s_red[tid >> 6] = m;
+  __syncthreads();
+  double r = s_red[0];
+#pragma unroll
+  for (int k = 1; k < kSmallBlock / rr::kWave; ++k) r = s_red[k] > r ? s_red[k] : r;
+  return r;
+}
+__device__ inline double small_block_sum(double v, double* s_red) {
+  const int tid = threadIdx.x;
+  const double m = rr::wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) s_red[tid >> 6] = m;
+  __syncthreads();
+  double r = 0.0;
+#pragma unroll
+  for (int k = 0; k < kSmallBlock / rr::kWave; ++k) r += s_red[k];
+  return r;
+}
+
+template <int R, int LIK>
+__global__ __launch_bounds__(kSmallBlock) void k_step_small(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl, SmallArgs a,
+                                                            ObsArg obs_arg, const double* __restrict__ steps_in,
+                                                            unsigned int* __restrict__ idx_out, double* __restrict__ est_out,
+                                                            double* __restrict__ est_partials) {
+  extern __shared__ double s_dyn[];  // [3 n_obs] observations | [4][n] gather fields | [n + 1] markers (u32) or [n] CDF (u64)
+  constexpr int W = kSmallBlock / rr::kWave;
+  __shared__ uint64_t s_u[4 * W];
+  __shared__ double s_red[W];
+  __shared__ unsigned int s_mx[W];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint64_t n = a.n;
+  double* const s_obs = s_dyn;
+  double* const s_f = s_dyn + 3 * (size_t)a.n_obs;
+  uint64_t* const s_cdf = reinterpret_cast<uint64_t*>(s_f + 4 * n);
+  unsigned int* const s_mark = reinterpret_cast<unsigned int*>(s_f + 4 * n);
+  const int cur = ctl->cur;
+  const uint64_t k0 = (uint64_t)tid * R;
+  double x[R], y[R], yaw[R], v[R], wgt[R];
+  unsigned int last_idx[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const uint64_t k = k0 + j;
+    x[j] = k < n ? b.x[cur][k] : 0.0;
+    y[j] = k < n ? b.y[cur][k] : 0.0;
+    yaw[j] = k < n ? b.yaw[cur][k] : 0.0;
+    v[j] = k < n ? b.v[cur][k] : 0.0;
+    wgt[j] = 0.0;
+    last_idx[j] = (unsigned int)k;
+  }
+  // what the last step leaves in Ctl (thread 0 writes it once, after the loop)
+  int c_usable = 0, c_mode = rr::kImageUniform, c_shift = 0, c_fired = 0, any_fired = 0;
+  uint64_t c_total = 0;
+  u128 c_q2 = {0, 0};
+  double c_wmax = 0.0, c_rho = 0.0, c_est[4] = {0.0, 0.0, 0.0, 0.0}, c_den = 1.0;
+  rr_sys_plan c_plan = {};
+  for (int s = 0; s < a.K; ++s) {
+    // ---- inputs of this step
+    double u0 = a.u0, u1 = a.u1;
+    __syncthreads();
+    if (a.inputs_in_kernarg) {
+      for (int i = tid; i < 3 * a.n_obs; i += kSmallBlock) s_obs[i] = obs_arg.v[i];
+    } else {
+      const double* in = steps_in + (size_t)s * (2 + 3 * (size_t)a.n_obs);
+      u0 = in[0];
+      u1 = in[1];
+      for (int i = tid; i < 3 * a.n_obs; i += kSmallBlock) s_obs[i] = in[2 + i];
+    }
+    __syncthreads();
+    // ---- propagate + weight (particle_filter.rs:279-296, :310-329)
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      double na, nc;
+      rr_pf_motion_noise(a.seed, a.step0 + (unsigned int)s, k0 + j, a.sigma_v, a.sigma_w, &na, &nc);
+      rr_pf_propagate_one(&x[j], &y[j], &yaw[j], &v[j], u0, u1, a.dt, na, nc);
+    }
+    if (LIK == RR_LIK_PRODUCT) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) wgt[j] = rr_pf_weight_product(x[j], y[j], s_obs, a.n_obs, a.lik);
+    } else {
+      rr_pf_weight_fused_rows<R>(x, y, s_obs, a.n_obs, a.lik, wgt);
+    }
+    double wl = 0.0;
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+      if (k0 + j < n && wgt[j] > wl) wl = wgt[j];  // NaN and negatives drop out
+    const double wmax = small_block_max(wl, s_red);
+    // ---- integer image, sums (resample_core.hpp: quantize_reduce_tile / tile_scan)
+    const bool usable = wmax > 0.0 && wmax < INFINITY;
+    const int mode = usable ? (int)rr::kImageWeights : (int)rr::kImageUniform;  // PF / MCL: sum w <= 0 => uniform (:433-438)
+    const int shift = usable ? rr_fix_shift(wmax, n) : 0;
+    uint64_t q[R], c[R], run = 0;
+    u128 q2 = {0, 0};
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      q[j] = k0 + j >= n ? 0ull : (mode == rr::kImageWeights ? rr_fix_quantize(wgt[j], shift) : 1ull);
+      run += q[j];
+      c[j] = run;
+      u128 sq;
+      rr_mul64wide(q[j], q[j], &sq.hi, &sq.lo);
+      q2 = rr::add128(q2, sq);
+    }
+    const uint64_t incl = rr::wave_scan_u64(run, lane);
+    q2 = rr::wave_sum_u128(q2);
+    __syncthreads();
+    if (lane == 63) s_u[wv] = incl;
+    if (lane == 0) {
+      s_u[W + wv] = q2.hi;
+      s_u[2 * W + wv] = q2.lo;
+    }
+    __syncthreads();
+    uint64_t off = incl - run, total = 0;
+    u128 qq = {0, 0};
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      if (k < wv) off += s_u[k];
+      total += s_u[k];
+      qq = rr::add128(qq, u128{s_u[W + k], s_u[2 * W + k]});
+    }
+    rr::TileSums ts;
+    ts.pre = 0;
+    ts.tot = total;
+    ts.q2 = qq;
+    PlanArgs pa{};
+    pa.n_global = n;
+    pa.neff_threshold = a.neff_threshold;
+    pa.gate = a.gate;
+    pa.mode = 0;
+    const int fire = rr::gate_decision(mode, ts, pa);
+    const unsigned int rstep = a.rstep0 + (unsigned int)s;
+    c_usable = usable ? 1 : 0;
+    c_mode = mode;
+    c_shift = shift;
+    c_fired = fire;
+    c_total = total;
+    c_q2 = qq;
+    c_wmax = wmax;
+    double est_acc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (!fire) {
+      if (a.want_est) {  // sum_j q_j p_j / T  (the cache refreshed at particle_filter.rs:332)
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const double cq = (double)q[j];
+          est_acc[0] = rr_fma(cq, x[j], est_acc[0]);
+          est_acc[1] = rr_fma(cq, y[j], est_acc[1]);
+          est_acc[2] = rr_fma(cq, yaw[j], est_acc[2]);
+          est_acc[3] = rr_fma(cq, v[j], est_acc[3]);
+        }
+        c_den = (double)total;
+      }
+    } else {
+      any_fired = 1;
+      unsigned int idx[R];
+      if (a.scheme == RR_RESAMPLE_SYSTEMATIC) {
+        double rho, dummy;
+        rr_uniform2(a.seed, RR_STREAM_RESAMPLE, rstep, 0, &rho, &dummy);
+        const rr_sys_plan plan = rr_sys_plan_make(rho, total, n);
+        c_rho = rho;
+        c_plan = plan;
+        const rr_sys_inv inv = rr_sys_inv_make(plan, total);
+        __syncthreads();
+        for (uint64_t k = tid; k <= n; k += kSmallBlock) s_mark[k] = 0;
+        __syncthreads();
+        uint64_t h_run = rr_sys_slots_upto(plan, inv, total, off);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          if (q[j] == 0 || k0 + j >= n) continue;
+          const uint64_t h = rr_sys_slots_upto(plan, inv, total, off + c[j]);
+          if (h > h_run) {
+            s_mark[h_run] = (unsigned int)(k0 + j + 1);
+            h_run = h;
+          }
+        }
+        __syncthreads();
+        // running maximum over the slots in slot order: serial inside the thread, DPP across the wave, LDS across waves
+        unsigned int m[R], mrun = 0;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const unsigned int mk = k0 + j < n ? s_mark[k0 + j] : 0u;
+          mrun = mk > mrun ? mk : mrun;
+          m[j] = mrun;
+        }
+        const unsigned int mincl = rr::wave_scan_max_u32(mrun);
+        if (lane == 63) s_mx[wv] = mincl;
+        __syncthreads();
+        unsigned int pre = 0;
+#pragma unroll
+        for (int k = 0; k < W; ++k)
+          if (k < wv) pre = s_mx[k] > pre ? s_mx[k] : pre;
+        // exclusive carry into this thread: the maximum of the lanes before it in the wave and of the waves before that
+        unsigned int before = __shfl_up(mincl, 1, rr::kWave);
+        if (lane == 0) before = 0;
+        before = before > pre ? before : pre;
+#pragma unroll
+        for (int j = 0; j < R; ++j) idx[j] = (m[j] > before ? m[j] : before) - 1u;
+      } else {  // multinomial (particle_filter.rs:455-470; monte_carlo_localization.rs:343-355,387-392)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+          if (k0 + j < n) s_cdf[k0 + j] = off + c[j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          double r, dummy;
+          rr_uniform2(a.seed, RR_STREAM_RESAMPLE, rstep, k0 + j, &r, &dummy);
+          idx[j] = k0 + j < n ? (unsigned int)rr_lower_bound_u64(s_cdf, n, rr_fix_target_multinomial(r, total)) : 0u;
+        }
+      }
+      // ---- gather through LDS (particle_filter.rs:467-469)
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < R; ++j)
+        if (k0 + j < n) {
+          s_f[k0 + j] = x[j];
+          s_f[n + k0 + j] = y[j];
+          s_f[2 * n + k0 + j] = yaw[j];
+          s_f[3 * n + k0 + j] = v[j];
+        }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < R; ++j)
+        if (k0 + j < n) {
+          const unsigned int i = idx[j];
+          x[j] = s_f[i];
+          y[j] = s_f[n + i];
+          yaw[j] = s_f[2 * n + i];
+          v[j] = s_f[3 * n + i];
+          last_idx[j] = i;
+          if (a.want_est) {  // the mean of the resampled set, uniform weights (:343)
+            est_acc[0] += x[j];
+            est_acc[1] += y[j];
+            est_acc[2] += yaw[j];
+            est_acc[3] += v[j];
+          }
+        }
+      c_den = (double)n;
+    }
+    if (a.want_est) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) c_est[k] = small_block_sum(est_acc[k], s_red);
+      if (tid == 0 && est_out)
+        for (int k = 0; k < 4; ++k) est_out[4 * (size_t)s + k] = c_est[k] / c_den;
+    }
+  }
+  // ---- the state after the last step
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const uint64_t k = k0 + j;
+    if (k < n) {
+      b.x[cur][k] = x[j];
+      b.y[cur][k] = y[j];
+      b.yaw[cur][k] = yaw[j];
+      b.v[cur][k] = v[j];
+      w[k] = wgt[j];
+      if (idx_out && any_fired) idx_out[k] = last_idx[j];
+    }
+  }
+  if (tid == 0) {
+    ctl->weights_uniform = c_fired ? 1 : 0;
+    ctl->usable = c_usable;
+    ctl->image_mode = c_mode;
+    ctl->shift = c_shift;
+    ctl->wmax = c_wmax;
+    ctl->pending = 0;
+    PlanArgs pa{};
+    pa.n_global = n;
+    pa.mode = 2;  // sums only: the decision, the plan and the flags are set below
+    rr::finalize_plan(ctl, c_total, 0, c_total, c_q2, pa);
+    ctl->fired = c_fired;
+    ctl->wmax_bits = 0;
+    if (c_fired && a.scheme == RR_RESAMPLE_SYSTEMATIC) {
+      ctl->rho = c_rho;
+      ctl->plan = c_plan;
+      ctl->served_first = 0;
+      ctl->served_count = n;
+    }
+    if (a.want_est) {
+      for (int k = 0; k < 4; ++k) est_partials[k] = c_est[k];
+      ctl->est_denom = c_den;
+      ctl->est_step = (uint64_t)(a.rstep0 + (unsigned int)a.K - 1) + 1;
+    }
+  }
+}
+
 // initial clouds
 __global__ __launch_bounds__(kBlock) void k_init(Bufs b, double* __restrict__ w, uint64_t n,
                                                 uint64_t n_global, uint64_t first_gid,
@@ -1080,6 +1398,13 @@ struct rr_pf {
   double* partials = nullptr;
   double* est_partials = nullptr;      // [kFusedMaxTiles][4] per-workgroup sums of the fused per-step estimate
   double* est_partials_host = nullptr; // pinned copy, made when the estimate is read
+  // small particle sets (k_step_small): the step inputs of rr_pf_step_many and its per-step estimates on the device
+  bool small_ok = true;  // RR_PF_SMALL=0 at create time: always take the large path
+  double* steps_dev = nullptr;
+  size_t steps_cap = 0;
+  double* est_ring = nullptr;
+  size_t est_ring_cap = 0;
+  std::vector<double> steps_host;
   // k_quantize_plan_mark (K2 + fused plan in one launch): one record per tile, the launch epoch, the largest grid whose
   // workgroups are all resident at once (0: not available), RR_PF_FUSED_PLAN=0 turns it off
   double* packed[2] = {nullptr, nullptr};  // {x, y, yaw, v} mirrors of the two buffer sets (k_step_lazy<PACKED>; lazy multinomial only)
@@ -1701,6 +2026,7 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
     const int v = std::atoi(e);
     if (v >= 1) h->mn_grid = v;
   }
+  if (const char* e = std::getenv("RR_PF_SMALL")) h->small_ok = std::atoi(e) != 0;
   if (const char* e = std::getenv("RR_K1_BLOCKS_PER_CU")) {
     const int v = std::atoi(e);
     if (v >= 1 && v <= 64) h->k1_blocks_per_cu = v;
@@ -1864,6 +2190,87 @@ static void launch_k1(rr_pf* h, bool kernarg, int src, unsigned grid, size_t lds
 #undef RR_K1_GO_PK
 }
 
+// ---- small particle sets: one launch of one workgroup per step, or per K steps (k_step_small)
+static size_t small_lds_bytes(uint64_t n, size_t n_obs) { return (3 * n_obs + 5 * (size_t)n + 1) * sizeof(double); }
+static bool small_path(const rr_pf* h, size_t n_obs) {
+  return h->small_ok && !h->adaptive && h->n == h->n_global && h->n <= kSmallMaxParticles && !h->p2p.ready && !h->using_external_stream &&
+         small_lds_bytes(h->n, n_obs) <= 150 * 1024;
+}
+
+template <int R, int LIK>
+static rr_status launch_small_as(rr_pf* h, const SmallArgs& a, const ObsArg& arg, size_t lds, double* est_out) {
+  static bool raised = false;  // more dynamic LDS than the default launch limit: once per instantiation
+  if (lds > 48 * 1024 && !raised) {
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)k_step_small<R, LIK>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    raised = true;
+  }
+  hipLaunchKernelGGL((k_step_small<R, LIK>), dim3(1), dim3(kSmallBlock), lds, h->stream, h->b, h->w, h->ctl, a, arg,
+                     (const double*)h->steps_dev, h->idx, est_out, h->est_partials);
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+// K steps (controls: K x 2, obs: K x n_obs x 3, both validated by the caller) in one launch.  est_out: device, K x 4, or null.
+static rr_status step_small(rr_pf* h, const double* controls, const double* obs, size_t n_obs, size_t K, bool want_est, double* est_out) {
+  rr_status s = materialise(h);
+  if (s != RR_OK) return s;
+  SmallArgs a{};
+  a.n = h->n;
+  a.seed = h->opt.seed;
+  a.step0 = h->step;
+  a.rstep0 = h->rstep;
+  a.n_obs = (int)n_obs;
+  a.K = (int)K;
+  a.gate = h->opt.resample_gate;
+  a.scheme = h->opt.resample_scheme;
+  a.neff_threshold = (double)h->n_global * h->cfg.resample_threshold;
+  a.dt = h->cfg.dt;
+  a.sigma_v = h->cfg.velocity_noise;
+  a.sigma_w = h->cfg.yaw_rate_noise;
+  a.lik = h->lik;
+  a.want_est = want_est ? 1 : 0;
+  ObsArg arg;
+  a.inputs_in_kernarg = (K == 1 && n_obs <= (size_t)kMaxObsKernarg) ? 1 : 0;
+  if (a.inputs_in_kernarg) {
+    a.u0 = controls[0];
+    a.u1 = controls[1];
+    if (n_obs) std::memcpy(arg.v, obs, 3 * n_obs * sizeof(double));
+  } else {
+    const size_t per = 2 + 3 * n_obs;
+    h->steps_host.resize(K * per);
+    for (size_t k = 0; k < K; ++k) {
+      h->steps_host[k * per] = controls[2 * k];
+      h->steps_host[k * per + 1] = controls[2 * k + 1];
+      if (n_obs) std::memcpy(&h->steps_host[k * per + 2], obs + 3 * n_obs * k, 3 * n_obs * sizeof(double));
+    }
+    if (K * per > h->steps_cap) {
+      if (h->steps_dev) RR_HIP_TRY(hipFree(h->steps_dev));
+      h->steps_dev = nullptr;
+      h->steps_cap = 0;
+      RR_HIP_TRY(hipMalloc(&h->steps_dev, (K * per + K * per / 2) * sizeof(double)));
+      h->steps_cap = K * per + K * per / 2;
+    }
+    // pageable source: HIP stages it before returning, so steps_host may be reused by the next call
+    RR_HIP_TRY(hipMemcpyAsync(h->steps_dev, h->steps_host.data(), K * per * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  }
+  const size_t lds = small_lds_bytes(h->n, n_obs);
+  const bool product = h->opt.likelihood_mode == RR_LIK_PRODUCT;
+  {
+    Timed t(h, RR_K_PROPAGATE_WEIGHT);
+    if (h->n <= (uint64_t)kSmallBlock) s = product ? launch_small_as<1, RR_LIK_PRODUCT>(h, a, arg, lds, est_out) : launch_small_as<1, RR_LIK_FUSED>(h, a, arg, lds, est_out);
+    else if (h->n <= 2 * (uint64_t)kSmallBlock) s = product ? launch_small_as<2, RR_LIK_PRODUCT>(h, a, arg, lds, est_out) : launch_small_as<2, RR_LIK_FUSED>(h, a, arg, lds, est_out);
+    else s = product ? launch_small_as<4, RR_LIK_PRODUCT>(h, a, arg, lds, est_out) : launch_small_as<4, RR_LIK_FUSED>(h, a, arg, lds, est_out);
+  }
+  if (s != RR_OK) return s;
+  h->step += (unsigned int)K;
+  h->rstep += (unsigned int)K;
+  h->wmax_live = false;       // Ctl.wmax holds the maximum of the last step's weights
+  h->wmax_bits_clean = true;  // ... and the accumulator is zero
+  h->maybe_pending = false;
+  h->pending_kind = kSrcMarkers;
+  return RR_OK;
+}
+
 extern "C" {
 
 const char* rr_last_error(void) { return rr::last_error_slot().c_str(); }
@@ -1984,6 +2391,8 @@ void rr_pf_destroy(rr_pf* h) {
   (void)hipFree(h->partials);
   (void)hipFree(h->est_partials);
   if (h->est_partials_host) (void)hipHostFree(h->est_partials_host);
+  (void)hipFree(h->steps_dev);
+  (void)hipFree(h->est_ring);
   (void)hipFree(h->mn_tile_cnt);
   (void)hipFree(h->est_ticket);
   (void)hipFree(h->push_ticket);
@@ -2081,8 +2490,9 @@ rr_status rr_pf_resample(rr_pf* h) {
   return launch_resample(h, 0, h->opt.resample_scheme, NAN, nullptr);
 }
 
-// want_estimate: the fused systematic step also leaves the mean of the particle set in Ctl.est
+// want_estimate: the fused systematic step (and the small-set step, either resampler) also leaves the mean of the particle set
 static bool fused_estimate_available(const rr_pf* h) {
+  if (small_path(h, 0)) return true;
   return !h->adaptive && h->opt.resample_scheme == RR_RESAMPLE_SYSTEMATIC && h->n_tiles <= (uint64_t)rr::kFusedMaxTiles &&
          h->n == h->n_global;
 }
@@ -2092,6 +2502,9 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
   if (s != RR_OK) return s;
   if ((s = validate_control(control)) != RR_OK) return s;
   if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
+  if (small_path(h, n_obs)) return step_small(h, control, obs, n_obs, 1, want_estimate, nullptr);
+  if (want_estimate && (h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC || h->n_tiles > (uint64_t)rr::kFusedMaxTiles))
+    return fail(RR_INVALID_PARAMETER, "the in-step estimate of a large filter needs the systematic scheme");
   ObsArg arg;
   bool kernarg;
   if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
@@ -2188,8 +2601,44 @@ rr_status rr_pf_covariance(rr_pf* h, double out[16]) {
   return compute_moments(h, nullptr, out);
 }
 
+rr_status rr_pf_step_many(rr_pf* h, const double* controls, const double* obs, size_t n_obs, size_t n_steps, double* out_estimates) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (n_steps == 0) return RR_OK;
+  if (!controls) return fail(RR_INVALID_PARAMETER, "null controls");
+  if (n_steps > (size_t)1 << 20) return fail(RR_INVALID_PARAMETER, "at most 1 048 576 steps per call");
+  for (size_t k = 0; k < n_steps; ++k)
+    if ((s = validate_control(controls + 2 * k)) != RR_OK) return s;
+  if ((s = validate_obs(obs, n_obs * n_steps)) != RR_OK) return s;
+  if (small_path(h, n_obs)) {
+    double* ring = nullptr;
+    if (out_estimates) {
+      if (4 * n_steps > h->est_ring_cap) {
+        if (h->est_ring) RR_HIP_TRY(hipFree(h->est_ring));
+        h->est_ring = nullptr;
+        h->est_ring_cap = 0;
+        RR_HIP_TRY(hipMalloc(&h->est_ring, 4 * n_steps * sizeof(double)));
+        h->est_ring_cap = 4 * n_steps;
+      }
+      ring = h->est_ring;
+    }
+    if ((s = step_small(h, controls, obs, n_obs, n_steps, out_estimates != nullptr, ring)) != RR_OK) return s;
+    if (!out_estimates) return RR_OK;
+    RR_HIP_TRY(hipMemcpyAsync(out_estimates, ring, 4 * n_steps * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    return fetch_ctl(h);  // waits for the stream
+  }
+  // large filters: the steps one after the other (each of them fills the device on its own)
+  for (size_t k = 0; k < n_steps; ++k) {
+    const double* o = n_obs ? obs + 3 * n_obs * k : nullptr;
+    if (out_estimates) s = rr_pf_step(h, controls + 2 * k, o, n_obs, out_estimates + 4 * k);
+    else s = rr_pf_step_async(h, controls + 2 * k, o, n_obs);
+    if (s != RR_OK) return s;
+  }
+  return RR_OK;
+}
+
 rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_t n_obs, double out_state[4]) {
-  if (h && out_state && fused_estimate_available(h)) {
+  if (h && out_state && fused_estimate_available(h) && (small_path(h, n_obs) || !small_path(h, 0))) {
     // try_step (particle_filter.rs:488-497): the returned mean comes out of the step's own plan kernel -- one
     // 300-byte read-back instead of a gather + a two-kernel moment reduction
     rr_status s = step_async_impl(h, control, obs, n_obs, true);

@@ -243,6 +243,20 @@ class ParticleFilterLocalizer:
         _check(self._L.rr_pf_step_async_estimate(self._h, _dp(u), _dp(obs) if obs.size else None, obs.shape[0]))
         self._cache_valid = False
 
+    def step_many(self, controls, observations, estimates: bool = True):
+        """``len(controls)`` steps in one call (``rr_pf_step_many``): controls K x 2, observations K x n_obs x 3 (the same
+        number of observations every step).  Returns the K estimates ``try_step`` would have returned (K x 4), or None
+        with ``estimates=False`` (asynchronous).  Up to 2048 particles the whole batch is ONE kernel launch (engine extension)."""
+        u = np.ascontiguousarray(controls, dtype=np.float64).reshape(-1, 2)
+        K = u.shape[0]
+        obs = np.ascontiguousarray(observations, dtype=np.float64).reshape(K, -1, 3) if K else np.zeros((0, 0, 3))
+        out = np.empty((K, 4)) if estimates else None
+        _check(self._L.rr_pf_step_many(self._h, _dp(u), _dp(obs) if obs.size else None, obs.shape[1], K, _dp(out) if estimates else None))
+        self._cache_valid = False
+        if estimates and K:
+            self._state_estimate = out[-1].copy()
+        return out
+
     def last_step_estimate(self) -> np.ndarray:
         e = np.empty(4)
         _check(self._L.rr_pf_last_step_estimate(self._h, _dp(e)))
