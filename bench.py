@@ -936,14 +936,19 @@ def leg_small_n(with_cpu):
         return loc.ParticleFilterLocalizer.with_initial_state([0.0, 0.0, 0.0, 0.0], cfg, seed=42)
 
     def timed(fn):
-        pf = fresh()
-        for t in range(200):
-            pf.step_async(u[t], obs[t])
-        pf.synchronize()
-        t0 = time.perf_counter()
-        fn(pf)
-        pf.synchronize()
-        return (time.perf_counter() - t0) / K * 1e6
+        # best of three, each right after ~40 ms of the same work: a host-paced loop (the synchronous step) lets the device clock
+        # down, and the next measurement would start on a cold clock
+        best = None
+        for _ in range(3):
+            pf = fresh()
+            pf.step_many(np.tile(u, (3, 1)), np.tile(obs, (3, 1, 1)), estimates=False)
+            pf.synchronize()
+            t0 = time.perf_counter()
+            fn(pf)
+            pf.synchronize()
+            dt = (time.perf_counter() - t0) / K * 1e6
+            best = dt if best is None else min(best, dt)
+        return best
 
     def loop(method):
         def run(pf):

@@ -577,8 +577,7 @@ __global__ __launch_bounds__(kNumMoments * 64) void k_moments_final(Bufs b, Ctl*
 // counters, same integer image: bit-identical to the large path and to the D-spec (tests/test_gpu_small_n.py).
 // rr_pf_step_many hands K controls and observation blocks over in one buffer; the single-step entry points use K = 1 with the
 // observations in the launch packet.
-constexpr int kSmallBlock = 512;
-constexpr uint64_t kSmallMaxParticles = 4 * kSmallBlock;
+constexpr uint64_t kSmallMaxParticles = 2048;
 
 struct SmallArgs {
   uint64_t n;
@@ -592,9 +591,20 @@ struct SmallArgs {
   rr_pf_lik lik;
   int want_est;
   int inputs_in_kernarg;  // K == 1 and the observations fit the launch packet
+  uint64_t mail_seq;      // != 0: the last step's estimate also goes to the host mailbox, stamped with this number
 };
 
+// Host-visible mailbox of a filter (pinned, host-coherent memory): the synchronous try_step of a small filter reads the
+// estimate the kernel wrote there instead of paying two device-to-host copies and a stream synchronisation (~20 us) for
+// four doubles; the host polls `seq`.
+struct HostMail {
+  double est[4];
+  uint64_t seq;
+};
+constexpr int kEstRing = 32;  // per-step estimates of rr_pf_step_many gather in LDS and leave in blocks of this many steps
+
 // workgroup-wide helpers of the small kernel (kSmallBlock threads); every thread gets the result
+template <int BLOCK>
 __device__ inline double small_block_max(double v, double* s_red) {
   const int tid = threadIdx.x;
   const double m = rr::wave_max(v);
@@ -603,31 +613,43 @@ __device__ inline double small_block_max(double v, double* s_red) {
   __syncthreads();
   double r = s_red[0];
 #pragma unroll
-  for (int k = 1; k < kSmallBlock / rr::kWave; ++k) r = s_red[k] > r ? s_red[k] : r;
+  for (int k = 1; k < BLOCK / rr::kWave; ++k) r = s_red[k] > r ? s_red[k] : r;
   return r;
 }
-__device__ inline double small_block_sum(double v, double* s_red) {
+// four sums at once (the estimate): DPP inside the waves, one LDS exchange
+template <int BLOCK>
+__device__ inline void small_block_sum4(double (&v)[4], double* s_red4 /* [4][BLOCK / 64] */) {
+  constexpr int W = BLOCK / rr::kWave;
   const int tid = threadIdx.x;
-  const double m = rr::wave_sum(v);
-  __syncthreads();
-  if ((tid & 63) == 0) s_red[tid >> 6] = m;
-  __syncthreads();
-  double r = 0.0;
+  double m[4];
 #pragma unroll
-  for (int k = 0; k < kSmallBlock / rr::kWave; ++k) r += s_red[k];
-  return r;
+  for (int k = 0; k < 4; ++k) m[k] = rr::wave_sum_dpp(v[k]);
+  __syncthreads();
+  if ((tid & 63) == 63) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_red4[k * W + (tid >> 6)] = m[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    double r = 0.0;
+#pragma unroll
+    for (int q = 0; q < W; ++q) r += s_red4[k * W + q];
+    v[k] = r;
+  }
 }
 
-template <int R, int LIK>
-__global__ __launch_bounds__(kSmallBlock) void k_step_small(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl, SmallArgs a,
+template <int BLOCK, int R, int LIK>
+__global__ __launch_bounds__(BLOCK) void k_step_small(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl, SmallArgs a,
                                                             ObsArg obs_arg, const double* __restrict__ steps_in,
                                                             unsigned int* __restrict__ idx_out, double* __restrict__ est_out,
-                                                            double* __restrict__ est_partials) {
+                                                            double* __restrict__ est_partials, HostMail* mail) {
   extern __shared__ double s_dyn[];  // [3 n_obs] observations | [4][n] gather fields | [n + 1] markers (u32) or [n] CDF (u64)
-  constexpr int W = kSmallBlock / rr::kWave;
+  constexpr int W = BLOCK / rr::kWave;
   __shared__ uint64_t s_u[4 * W];
-  __shared__ double s_red[W];
+  __shared__ double s_red[4 * W];
   __shared__ unsigned int s_mx[W];
+  __shared__ double s_ring[kEstRing * 4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const uint64_t n = a.n;
   double* const s_obs = s_dyn;
@@ -659,12 +681,12 @@ __global__ __launch_bounds__(kSmallBlock) void k_step_small(Bufs b, double* __re
     double u0 = a.u0, u1 = a.u1;
     __syncthreads();
     if (a.inputs_in_kernarg) {
-      for (int i = tid; i < 3 * a.n_obs; i += kSmallBlock) s_obs[i] = obs_arg.v[i];
+      for (int i = tid; i < 3 * a.n_obs; i += BLOCK) s_obs[i] = obs_arg.v[i];
     } else {
       const double* in = steps_in + (size_t)s * (2 + 3 * (size_t)a.n_obs);
       u0 = in[0];
       u1 = in[1];
-      for (int i = tid; i < 3 * a.n_obs; i += kSmallBlock) s_obs[i] = in[2 + i];
+      for (int i = tid; i < 3 * a.n_obs; i += BLOCK) s_obs[i] = in[2 + i];
     }
     __syncthreads();
     // ---- propagate + weight (particle_filter.rs:279-296, :310-329)
@@ -684,7 +706,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_step_small(Bufs b, double* __re
 #pragma unroll
     for (int j = 0; j < R; ++j)
       if (k0 + j < n && wgt[j] > wl) wl = wgt[j];  // NaN and negatives drop out
-    const double wmax = small_block_max(wl, s_red);
+    const double wmax = small_block_max<BLOCK>(wl, s_red);
     // ---- integer image, sums (resample_core.hpp: quantize_reduce_tile / tile_scan)
     const bool usable = wmax > 0.0 && wmax < INFINITY;
     const int mode = usable ? (int)rr::kImageWeights : (int)rr::kImageUniform;  // PF / MCL: sum w <= 0 => uniform (:433-438)
@@ -759,7 +781,7 @@ __global__ __launch_bounds__(kSmallBlock) void k_step_small(Bufs b, double* __re
         c_plan = plan;
         const rr_sys_inv inv = rr_sys_inv_make(plan, total);
         __syncthreads();
-        for (uint64_t k = tid; k <= n; k += kSmallBlock) s_mark[k] = 0;
+        for (uint64_t k = tid; k <= n; k += BLOCK) s_mark[k] = 0;
         __syncthreads();
         uint64_t h_run = rr_sys_slots_upto(plan, inv, total, off);
 #pragma unroll
@@ -836,10 +858,20 @@ __global__ __launch_bounds__(kSmallBlock) void k_step_small(Bufs b, double* __re
       c_den = (double)n;
     }
     if (a.want_est) {
+      small_block_sum4<BLOCK>(est_acc, s_red);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) c_est[k] = small_block_sum(est_acc[k], s_red);
-      if (tid == 0 && est_out)
-        for (int k = 0; k < 4; ++k) est_out[4 * (size_t)s + k] = c_est[k] / c_den;
+      for (int k = 0; k < 4; ++k) c_est[k] = est_acc[k];
+      if (est_out) {  // K x 4 estimates: collected in LDS, flushed (coalesced) every kEstRing steps -- no global store per step
+        if (tid == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) s_ring[(s % kEstRing) * 4 + k] = c_est[k] / c_den;
+        }
+        if ((s % kEstRing) == kEstRing - 1 || s == a.K - 1) {
+          __syncthreads();
+          const int s0 = s - (s % kEstRing), cnt = (s - s0 + 1) * 4;
+          if (tid < cnt) est_out[4 * (size_t)s0 + tid] = s_ring[tid];
+        }
+      }
     }
   }
   // ---- the state after the last step
@@ -878,6 +910,12 @@ __global__ __launch_bounds__(kSmallBlock) void k_step_small(Bufs b, double* __re
       for (int k = 0; k < 4; ++k) est_partials[k] = c_est[k];
       ctl->est_denom = c_den;
       ctl->est_step = (uint64_t)(a.rstep0 + (unsigned int)a.K - 1) + 1;
+      if (a.mail_seq) {
+        for (int k = 0; k < 4; ++k)
+          __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[k]), (uint64_t)__double_as_longlong(c_est[k] / c_den), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mail->seq, a.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
 }
@@ -1400,6 +1438,8 @@ struct rr_pf {
   double* est_partials_host = nullptr; // pinned copy, made when the estimate is read
   // small particle sets (k_step_small): the step inputs of rr_pf_step_many and its per-step estimates on the device
   bool small_ok = true;  // RR_PF_SMALL=0 at create time: always take the large path
+  HostMail* mail = nullptr;  // pinned, host-coherent: where the small kernel leaves the estimate of a synchronous step
+  uint64_t mail_seq = 0;
   double* steps_dev = nullptr;
   size_t steps_cap = 0;
   double* est_ring = nullptr;
@@ -2197,24 +2237,32 @@ static bool small_path(const rr_pf* h, size_t n_obs) {
          small_lds_bytes(h->n, n_obs) <= 150 * 1024;
 }
 
-template <int R, int LIK>
+template <int BLOCK, int R, int LIK>
 static rr_status launch_small_as(rr_pf* h, const SmallArgs& a, const ObsArg& arg, size_t lds, double* est_out) {
   static bool raised = false;  // more dynamic LDS than the default launch limit: once per instantiation
   if (lds > 48 * 1024 && !raised) {
-    RR_HIP_TRY(hipFuncSetAttribute((const void*)k_step_small<R, LIK>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    RR_HIP_TRY(hipFuncSetAttribute((const void*)k_step_small<BLOCK, R, LIK>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     raised = true;
   }
-  hipLaunchKernelGGL((k_step_small<R, LIK>), dim3(1), dim3(kSmallBlock), lds, h->stream, h->b, h->w, h->ctl, a, arg,
-                     (const double*)h->steps_dev, h->idx, est_out, h->est_partials);
+  hipLaunchKernelGGL((k_step_small<BLOCK, R, LIK>), dim3(1), dim3(BLOCK), lds, h->stream, h->b, h->w, h->ctl, a, arg,
+                     (const double*)h->steps_dev, h->idx, est_out, h->est_partials, h->mail);
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
 }
 
 // K steps (controls: K x 2, obs: K x n_obs x 3, both validated by the caller) in one launch.  est_out: device, K x 4, or null.
-static rr_status step_small(rr_pf* h, const double* controls, const double* obs, size_t n_obs, size_t K, bool want_est, double* est_out) {
+static rr_status step_small(rr_pf* h, const double* controls, const double* obs, size_t n_obs, size_t K, bool want_est, double* est_out,
+                            bool to_mailbox = false) {
   rr_status s = materialise(h);
   if (s != RR_OK) return s;
   SmallArgs a{};
+  if (to_mailbox) {
+    if (!h->mail) {
+      RR_HIP_TRY(hipHostMalloc(&h->mail, sizeof(HostMail), hipHostMallocDefault));
+      std::memset(h->mail, 0, sizeof(HostMail));
+    }
+    a.mail_seq = ++h->mail_seq;
+  }
   a.n = h->n;
   a.seed = h->opt.seed;
   a.step0 = h->step;
@@ -2257,9 +2305,15 @@ static rr_status step_small(rr_pf* h, const double* controls, const double* obs,
   const bool product = h->opt.likelihood_mode == RR_LIK_PRODUCT;
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
-    if (h->n <= (uint64_t)kSmallBlock) s = product ? launch_small_as<1, RR_LIK_PRODUCT>(h, a, arg, lds, est_out) : launch_small_as<1, RR_LIK_FUSED>(h, a, arg, lds, est_out);
-    else if (h->n <= 2 * (uint64_t)kSmallBlock) s = product ? launch_small_as<2, RR_LIK_PRODUCT>(h, a, arg, lds, est_out) : launch_small_as<2, RR_LIK_FUSED>(h, a, arg, lds, est_out);
-    else s = product ? launch_small_as<4, RR_LIK_PRODUCT>(h, a, arg, lds, est_out) : launch_small_as<4, RR_LIK_FUSED>(h, a, arg, lds, est_out);
+    // shape of the workgroup: 512 threads x 1 / 2 / 4 consecutive particles.  Measured at 1000 x 4 (step_many, us per step):
+    // 512 x 2: 7.2, 1024 x 1: 8.7 -- sixteen waves pay more at the step's dozen barriers than their extra latency hiding
+    // brings.  RR_PF_SMALL_BLOCK=1024 selects 1024 threads x 1 / 2 (A/B).
+    static const int forced = [] { const char* e = std::getenv("RR_PF_SMALL_BLOCK"); return e ? std::atoi(e) : 0; }();
+#define RR_SMALL_GO(B_, R_) (product ? launch_small_as<B_, R_, RR_LIK_PRODUCT>(h, a, arg, lds, est_out) : launch_small_as<B_, R_, RR_LIK_FUSED>(h, a, arg, lds, est_out))
+    if (h->n <= 512) s = RR_SMALL_GO(512, 1);
+    else if (forced == 1024) s = h->n <= 1024 ? RR_SMALL_GO(1024, 1) : RR_SMALL_GO(1024, 2);
+    else s = h->n <= 1024 ? RR_SMALL_GO(512, 2) : RR_SMALL_GO(512, 4);
+#undef RR_SMALL_GO
   }
   if (s != RR_OK) return s;
   h->step += (unsigned int)K;
@@ -2393,6 +2447,7 @@ void rr_pf_destroy(rr_pf* h) {
   if (h->est_partials_host) (void)hipHostFree(h->est_partials_host);
   (void)hipFree(h->steps_dev);
   (void)hipFree(h->est_ring);
+  if (h->mail) (void)hipHostFree(h->mail);
   (void)hipFree(h->mn_tile_cnt);
   (void)hipFree(h->est_ticket);
   (void)hipFree(h->push_ticket);
@@ -2638,7 +2693,31 @@ rr_status rr_pf_step_many(rr_pf* h, const double* controls, const double* obs, s
 }
 
 rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_t n_obs, double out_state[4]) {
-  if (h && out_state && fused_estimate_available(h) && (small_path(h, n_obs) || !small_path(h, 0))) {
+  if (h && out_state && small_path(h, n_obs)) {
+    // try_step of a small filter: one launch; the kernel writes the mean into the host-visible mailbox and the host polls
+    // its stamp -- no device-to-host copy, no stream synchronisation in the common case
+    rr_status s = bind(h);
+    if (s != RR_OK) return s;
+    if ((s = validate_control(control)) != RR_OK) return s;
+    if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
+    if ((s = step_small(h, control, obs, n_obs, 1, true, nullptr, /*to_mailbox=*/true)) != RR_OK) return s;
+    const uint64_t want = h->mail_seq;
+    const volatile uint64_t* seq = &h->mail->seq;
+    bool seen = false;
+    for (long spins = 0; spins < 2000000; ++spins) {  // ~ tens of milliseconds; a healthy step answers within ~15 us
+      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) {
+        seen = true;
+        break;
+      }
+    }
+    if (!seen) {  // slow device / contended queue: wait the ordinary way
+      RR_HIP_TRY(hipStreamSynchronize(h->stream));
+      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != want) return fail(RR_RUNTIME_ERROR, "the step's estimate never reached the host mailbox");
+    }
+    for (int k = 0; k < 4; ++k) out_state[k] = h->mail->est[k];
+    return RR_OK;
+  }
+  if (h && out_state && fused_estimate_available(h) && !small_path(h, 0)) {
     // try_step (particle_filter.rs:488-497): the returned mean comes out of the step's own plan kernel -- one
     // 300-byte read-back instead of a gather + a two-kernel moment reduction
     rr_status s = step_async_impl(h, control, obs, n_obs, true);

@@ -199,6 +199,15 @@ __device__ inline double wave_sum(double v) {
   return v;
 }
 
+// the same sum on DPP (a different -- but equally fixed -- order of additions: results are reproducible, not equal to wave_sum's);
+// lane 63 holds the sum, which is what the callers read
+__device__ inline double wave_sum_dpp(double v) {
+#define RR_STEP_ADDF(V, C, M) (V + __longlong_as_double((long long)dpp_u64<C, M>((uint64_t)__double_as_longlong(V))))
+  RR_DPP_SCAN(v, RR_STEP_ADDF);
+#undef RR_STEP_ADDF
+  return v;
+}
+
 // HIP's 64-bit shuffles are declared on (unsigned) long long; uint64_t is unsigned long here
 using ull = unsigned long long;
 __device__ inline uint64_t shfl_xor_u64(uint64_t v, int o) { return (uint64_t)__shfl_xor((ull)v, o, kWave); }

@@ -101,7 +101,9 @@ def test_step_many_equals_single_steps(n, L, scheme, lik):
     np.testing.assert_allclose(pa[:, 4], pc[:, 4], rtol=0, atol=0)
     assert np.array_equal(bits(est_a), bits(est_b))
     assert a.counters() == b.counters() == c.counters() == (K, K)
-    assert np.array_equal(a.last_resample_indices(), c.last_resample_indices())
+    assert a.last_resample_fired() == c.last_resample_fired()
+    if L:  # (without observations the weights stay uniform and the N_eff gate never opens: there are no indices)
+        assert np.array_equal(a.last_resample_indices(), c.last_resample_indices())
     np.testing.assert_allclose(a.estimate(), c.estimate(), rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(a.calc_covariance(), c.calc_covariance(), rtol=1e-9, atol=1e-12)
     # asynchronous form + accessors afterwards
