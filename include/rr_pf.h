@@ -350,6 +350,13 @@ rr_status rr_comm_unique_id(uint8_t out[RR_COMM_UNIQUE_ID_BYTES]);
 rr_status rr_comm_create(const uint8_t id[RR_COMM_UNIQUE_ID_BYTES], int32_t rank, int32_t n_ranks, int32_t device,
                          rr_comm** out);
 void rr_comm_destroy(rr_comm* c);
+/* Bring-up / test seam: the same sharded step (rr_pf_shard_step, systematic) for n_ranks shards that all live in THIS
+ * process, with the three exchanges done as plain device copies instead of RCCL calls -- every kernel and all of the host's
+ * segment arithmetic are those of the RCCL transport, so a one-GPU box can check them for 2 and 3 shards (RCCL refuses two
+ * ranks on one device).  rr_comm_create_local makes the per-rank scratch without a communicator. */
+rr_status rr_comm_create_local(int32_t rank, int32_t n_ranks, int32_t device, rr_comm** out);
+rr_status rr_pf_shard_step_local(rr_pf* const* handles, rr_comm* const* comms, int32_t n_ranks, const double control[2],
+                                 const double* obs, size_t n_obs);
 /* One whole sharded MCL/PF step (systematic resampling) of this rank: phases A-E with
  * all-reduce(MAX) / all-gather / grouped send-recv in between, everything enqueued on the
  * filter's stream; the only host wait is the D2H of the G totals that sizes the segments.

@@ -189,6 +189,8 @@ def lib() -> C.CDLL:
     proto("rr_comm_unique_id", st, [U8])
     proto("rr_comm_create", st, [U8, i32, i32, i32, C.POINTER(H)])
     proto("rr_comm_destroy", None, [H])
+    proto("rr_comm_create_local", st, [i32, i32, i32, C.POINTER(H)])
+    proto("rr_pf_shard_step_local", st, [C.POINTER(H), C.POINTER(H), i32, P, P, sz])
     proto("rr_pf_shard_step", st, [H, H, P, P, sz])
     proto("rr_pf_shard_estimate", st, [H, H, P, P])
     proto("rr_pf_shard_last_migrated", u64, [H])

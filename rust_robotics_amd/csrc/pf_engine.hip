@@ -279,8 +279,9 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
       pos0 = own0 + tile_base;
       rr::resolve_tile_window(markers, carry, own0 / rr::kResolveSlots + tile, win_lo, win_hi, own0, own0 + p.n, idx);
       const uint64_t pos1 = pos0 + rr::kResolveSlots < own0 + p.n ? pos0 + rr::kResolveSlots : own0 + p.n;
-      if (pos0 < win_lo || pos1 > win_hi)  // (uniform) a peer serves some slot of this tile: its delivery must have landed
-        (void)rr::p2p_wait_done(wa.mbox, wa.n_ranks, wa.wait_seq, wa.timeout_ticks, wa.err);
+      // (uniform) a peer serves some slot of this tile: its delivery must have landed.  (n_ranks == 0: the RCCL transport --
+      // the inbox was filled by an earlier kernel of this stream.)
+      if (wa.n_ranks > 0 && (pos0 < win_lo || pos1 > win_hi)) (void)rr::p2p_wait_done(wa.mbox, wa.n_ranks, wa.wait_seq, wa.timeout_ticks, wa.err);
     } else if (pending) {
       rr::resolve_tile(markers, carry, p.n, tile, idx);
     } else {
@@ -1062,6 +1063,62 @@ __global__ __launch_bounds__(kBlock) void k_push_window(Bufs b, const Ctl* __res
   rr::p2p_send_done(peers, seq);
 }
 
+// RCCL transport, the same overhang into a SEND BUFFER instead of the peers' inboxes: record q (x, y, yaw, v) is the q-th
+// foreign position of the window in ascending order -- left overhang, then right overhang -- which is also ascending
+// destination rank, so the buffer is cut into one contiguous segment per destination.  If the overhang does not fit the
+// buffer (`cap` records) the kernel leaves everything as it is and the host, which learns the size a moment later, grows
+// the buffer and launches it again.
+__global__ __launch_bounds__(kBlock) void k_pack_window(Bufs b, const Ctl* __restrict__ ctl, unsigned int* __restrict__ markers,
+                                                       const unsigned int* __restrict__ carry, int rank, uint64_t n_local,
+                                                       uint64_t pad, double* __restrict__ send, uint64_t cap) {
+  if (!ctl->fired) return;
+  const uint64_t own0 = (uint64_t)rank * n_local + pad, own1 = own0 + n_local;
+  const uint64_t win_lo = ctl->served_first + pad, win_hi = win_lo + ctl->served_count;
+  const int src = ctl->cur;
+  const uint64_t S = rr::kResolveSlots;
+  const uint64_t l_lo = win_lo, l_hi = own0 < win_hi ? own0 : win_hi;
+  const uint64_t r_lo = own1 > win_lo ? own1 : win_lo, r_hi = win_hi;
+  const uint64_t n_lpos = l_lo < l_hi ? l_hi - l_lo : 0, n_rpos = r_lo < r_hi ? r_hi - r_lo : 0;
+  if (n_lpos + n_rpos > cap) return;
+  const uint64_t lt0 = l_lo / S, n_left = n_lpos ? (l_hi + S - 1) / S - lt0 : 0;
+  const uint64_t rt0 = r_lo / S, n_right = n_rpos ? (r_hi + S - 1) / S - rt0 : 0;
+  for (uint64_t q = blockIdx.x; q < n_left + n_right; q += gridDim.x) {
+    const bool left = q < n_left;
+    const uint64_t tile = left ? lt0 + q : rt0 + (q - n_left);
+    const uint64_t lo = left ? l_lo : r_lo, hi = left ? l_hi : r_hi;
+    unsigned int idx[rr::kResolveRows];
+    rr::resolve_tile_window(markers, carry, tile, win_lo, win_hi, lo, hi, idx);
+#pragma unroll
+    for (int r = 0; r < rr::kResolveRows; ++r) {
+      const uint64_t pos = tile * S + (uint64_t)r * kBlock + threadIdx.x;
+      if (pos >= lo && pos < hi) {
+        const uint64_t rec = left ? pos - l_lo : n_lpos + (pos - r_lo);
+        const uint64_t j = idx[r];
+        double* __restrict__ o = send + 4 * rec;
+        o[0] = b.x[src][j];
+        o[1] = b.y[src][j];
+        o[2] = b.yaw[src][j];
+        o[3] = b.v[src][j];
+      }
+    }
+  }
+}
+
+// received records -> this rank's inbox: record q is the q-th own slot OUTSIDE the own window, in ascending order
+// (`below` of them lie below the window, the rest above the `self` slots this rank serves to itself)
+__global__ __launch_bounds__(kBlock) void k_unpack_inbox(const double* __restrict__ recv, uint64_t n_recv, uint64_t below, uint64_t self,
+                                                        uint64_t n, double* __restrict__ inbox) {
+  const uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= n_recv) return;
+  const uint64_t k = q < below ? q : q + self;
+  if (k >= n) return;
+  const double* __restrict__ r = recv + 4 * q;
+  inbox[k] = r[0];
+  inbox[n + k] = r[1];
+  inbox[2 * n + k] = r[2];
+  inbox[3 * n + k] = r[3];
+}
+
 // accessors: make a pending window resample real -- own slots inside the window through the markers, the others out of
 // the inbox (k_p2p_wait_done has run); k_settle flips the live set afterwards
 __global__ __launch_bounds__(kBlock) void k_resolve_gather_window(Bufs b, const Ctl* __restrict__ ctl,
@@ -1476,6 +1533,8 @@ struct rr_pf {
   int pending_kind = kSrcMarkers;  // ... StepSrc: where its sources are (markers / lidx of the multinomial step / window of a shard)
   uint64_t slot_pad = 0;           // shard of the peer-to-peer transport: marker position of global slot s = s + slot_pad
   uint64_t window_seq = 0;         // ... and the exchange sequence number of the step whose window resample is pending (its DONE)
+  double* rccl_inbox = nullptr;    // RCCL transport: [field][n] particles peers served for this shard's slots (plain device memory)
+  bool window_rccl = false;        // the pending window resample came through the RCCL transport (inbox filled in stream order)
   unsigned int* push_ticket = nullptr;  // arrival counters of k_push_window (zero between launches)
   unsigned int* lidx = nullptr;  // source index per slot; kInPlace = a peer stored the particle already (sharded)
   rr_pf_lik lik{};
@@ -1680,10 +1739,13 @@ rr_status materialise(rr_pf* h) {
   }
   if (h->pending_kind == kSrcWindow) {  // a shard: the peers' deliveries of the last step must have landed first
     Timed t(h, RR_K_RESAMPLE_GATHER);
-    hipLaunchKernelGGL(rr::k_p2p_wait_done, dim3(1), dim3(64), 0, h->stream, (const rr::P2PMailbox*)h->p2p.mbox, h->p2p.peers.n_ranks,
-                       h->window_seq, h->p2p.peers.timeout_ticks, h->p2p.err);
+    const bool via_p2p = !h->window_rccl;  // (RCCL transport: the inbox was filled in stream order, nothing to wait for)
+    if (via_p2p)
+      hipLaunchKernelGGL(rr::k_p2p_wait_done, dim3(1), dim3(64), 0, h->stream, (const rr::P2PMailbox*)h->p2p.mbox, h->p2p.peers.n_ranks,
+                         h->window_seq, h->p2p.peers.timeout_ticks, h->p2p.err);
     hipLaunchKernelGGL(k_resolve_gather_window, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b, h->ctl,
-                       h->markers, h->carry, h->n, h->opt.first_global_index, h->slot_pad, (const double*)h->p2p.inbox, h->idx);
+                       h->markers, h->carry, h->n, h->opt.first_global_index, h->slot_pad,
+                       (const double*)(via_p2p ? h->p2p.inbox : h->rccl_inbox), h->idx);
     hipLaunchKernelGGL(k_settle, dim3(1), dim3(1), 0, h->stream, h->ctl);
     RR_HIP_TRY(hipGetLastError());
     h->maybe_pending = false;
@@ -2451,6 +2513,7 @@ void rr_pf_destroy(rr_pf* h) {
   (void)hipFree(h->mn_tile_cnt);
   (void)hipFree(h->est_ticket);
   (void)hipFree(h->push_ticket);
+  (void)hipFree(h->rccl_inbox);
   (void)hipFree(h->grid_rec);
   (void)hipFree(h->grid_ticket);
   (void)hipFree(h->scratch_a);
@@ -3150,7 +3213,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   if (!h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_p2p_connect first");
   if ((s = validate_control(control)) != RR_OK) return s;
   if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
-  if (h->maybe_pending && h->pending_kind != kSrcWindow && (s = materialise(h)) != RR_OK) return s;
+  if (h->maybe_pending && (h->pending_kind != kSrcWindow || h->window_rccl) && (s = materialise(h)) != RR_OK) return s;
   ObsArg arg;
   bool kernarg;
   if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
@@ -3228,6 +3291,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   h->maybe_pending = true;
   h->pending_kind = kSrcWindow;
   h->window_seq = seq;
+  h->window_rccl = false;
   return RR_OK;
 }
 
@@ -3337,8 +3401,9 @@ rr_status rr_comm_create(const uint8_t id[RR_COMM_UNIQUE_ID_BYTES], int32_t rank
   hipError_t err;
   if ((err = hipMalloc(&c->d_wmax, sizeof(double))) != hipSuccess) return bad(err);
   if ((err = hipMalloc(&c->d_sums, 3 * sizeof(uint64_t))) != hipSuccess) return bad(err);
-  if ((err = hipMalloc(&c->d_all, 3 * n_ranks * sizeof(uint64_t))) != hipSuccess) return bad(err);
-  if ((err = hipHostMalloc(&c->h_all, 3 * n_ranks * sizeof(uint64_t))) != hipSuccess) return bad(err);
+  if ((err = hipMalloc(&c->d_all, (3 * n_ranks + 1) * sizeof(uint64_t))) != hipSuccess) return bad(err);
+  if ((err = hipHostMalloc(&c->h_all, (3 * n_ranks + 1) * sizeof(uint64_t))) != hipSuccess) return bad(err);
+  if ((err = hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming)) != hipSuccess) return bad(err);
   if ((err = hipMalloc(&c->d_mom, 21 * (n_ranks + 1) * sizeof(double))) != hipSuccess) return bad(err);
   if ((err = hipHostMalloc(&c->h_mom, 21 * (n_ranks + 1) * sizeof(double))) != hipSuccess) return bad(err);
   c->matrix.assign((size_t)n_ranks * n_ranks, 0);
@@ -3355,6 +3420,7 @@ void rr_comm_destroy(rr_comm* c) {
   (void)hipFree(c->d_sums);
   (void)hipFree(c->d_all);
   if (c->h_all) (void)hipHostFree(c->h_all);
+  if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
   (void)hipFree(c->d_send);
   (void)hipFree(c->d_recv);
   (void)hipFree(c->d_fsend);
@@ -3366,12 +3432,205 @@ void rr_comm_destroy(rr_comm* c) {
   delete c;
 }
 
+// The systematic sharded step over RCCL, lazy like the peer-to-peer one: k_step_lazy<kSrcWindow> | all-reduce(MAX) |
+// k_quantize_reduce | k_scan_tiles | all-gather(sums) | k_shard_plan | k_mark (window) | D2H of the sums + event |
+// k_pack_window | grouped send/recv of the window's overhang only | k_unpack_inbox.  Own slots inside the own window never
+// move (the next step reads them through the markers); the host's one wait -- for the G sums that size the segments --
+// is an EVENT recorded right behind the copy, so it overlaps k_mark and k_pack_window instead of draining the stream.
+// Round 2 propagated with the non-lazy kernel, gathered ALL served slots into a send buffer and adopted all n slots
+// (two 64 MB passes at 1e6 particles) behind a full stream synchronisation: 99 us at world size 1.
+// The step is written as phases with the three exchanges between them, so that the same code runs over RCCL
+// (rr_pf_shard_step) and over plain device copies between shards of ONE process (rr_pf_shard_step_local: the seam that
+// lets a one-GPU box check the segment logic for 2 and 3 shards).
+struct WinPlan {
+  bool fired = false;
+  uint64_t n_send = 0, n_recv = 0, below = 0, self = 0;
+};
+
+static double* win_wmax_slot(rr_comm* c) { return reinterpret_cast<double*>(c->d_all + 3 * (size_t)c->n_ranks); }
+
+static rr_status win_ensure(double** buf, size_t* cap, size_t records) {
+  if (records <= *cap) return RR_OK;
+  if (*buf) RR_HIP_TRY(hipFree(*buf));
+  *buf = nullptr;
+  *cap = 0;
+  const size_t want = records + records / 4 + 1024;
+  RR_HIP_TRY(hipMalloc(buf, want * 4 * sizeof(double)));
+  *cap = want;
+  return RR_OK;
+}
+
+static void win_pack(rr_pf* h, rr_comm* c) {
+  Timed t(h, RR_K_RESAMPLE_GATHER);
+  hipLaunchKernelGGL(k_pack_window, dim3(kPushGrid), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->markers, h->carry, c->rank, h->n, h->slot_pad,
+                     c->d_send, (uint64_t)c->cap_send);
+}
+
+// A: propagate + weight through the window; the local maximum stays in Ctl.wmax_bits
+static rr_status win_phase_a(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
+  rr_status s;
+  if ((s = validate_control(control)) != RR_OK) return s;
+  if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
+  if (h->maybe_pending && !(h->pending_kind == kSrcWindow && h->window_rccl) && (s = materialise(h)) != RR_OK) return s;
+  ObsArg arg;
+  bool kernarg;
+  if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
+  StepParams p = make_params(h, control, (int)n_obs);
+  const size_t lds = 3 * n_obs * sizeof(double);
+  if (lds > 150 * 1024) return fail(RR_INVALID_PARAMETER, "too many observations for one LDS block (max 6400)");
+  if (!h->rccl_inbox) RR_HIP_TRY(hipMalloc(&h->rccl_inbox, 4 * h->n * sizeof(double)));
+  if (!h->wmax_bits_clean) RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
+  WindowArgs wa{};
+  wa.inbox = h->rccl_inbox;
+  wa.pad = h->slot_pad;
+  wa.n_ranks = 0;  // nothing to wait for inside the kernel
+  {
+    Timed t(h, RR_K_PROPAGATE_WEIGHT);
+    launch_k1(h, kernarg, kSrcWindow, (unsigned)((h->n + rr::kResolveSlots - 1) / rr::kResolveSlots), lds, nullptr, nullptr, p, arg,
+              h->markers, h->carry, nullptr, wa);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  h->step += 1;
+  return RR_OK;
+}
+
+// B: the integer image under the GLOBAL maximum (in the slot behind the gathered sums), local sums -> c->d_sums
+static rr_status win_phase_b(rr_pf* h, rr_comm* c) {
+  launch_quantize(h, win_wmax_slot(c), /*settle=*/1);
+  PlanArgs pa = plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN);
+  pa.lazy_gather = 1;
+  Timed t(h, RR_K_SCAN_TILES);
+  hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl, h->n_tiles, 0, pa, c->d_sums);
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+// C: gate + plan + markers over the global slot index, the sums on their way to the host, the overhang into the send buffer
+static rr_status win_phase_c(rr_pf* h, rr_comm* c) {
+  const int G = c->n_ranks;
+  PlanArgs pa = plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN);
+  pa.lazy_gather = 1;
+  {
+    Timed t(h, RR_K_CDF);
+    hipLaunchKernelGGL(rr::k_shard_plan, dim3(1), dim3(1), 0, h->stream, h->ctl, (const uint64_t*)c->d_all, G, c->rank, pa);
+    hipLaunchKernelGGL(rr::k_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl, image_args(h),
+                       h->tile_total, h->markers, h->carry, /*window=*/1, h->slot_pad);
+  }
+  RR_HIP_TRY(hipMemcpyAsync(c->h_all, c->d_all, (3 * (size_t)G + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  RR_HIP_TRY(hipEventRecord(c->ev_plan, h->stream));
+  if (G > 1) {
+    rr_status s = win_ensure(&c->d_send, &c->cap_send, std::max<size_t>(65536, h->n / 8));
+    if (s != RR_OK) return s;
+    win_pack(h, c);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  h->wmax_live = false;
+  h->wmax_bits_clean = true;
+  h->rstep += 1;
+  return RR_OK;
+}
+
+// the host's part: gate decision and segment sizes from the G sums (pure integer arithmetic, the same on every rank)
+static rr_status win_host(rr_pf* h, rr_comm* c, WinPlan* out) {
+  const int G = c->n_ranks, r = c->rank;
+  RR_HIP_TRY(hipEventSynchronize(c->ev_plan));
+  const double wmax = rr_u2d(c->h_all[3 * (size_t)G]);
+  const bool usable = wmax > 0.0 && wmax < INFINITY;
+  std::vector<uint64_t> totals(G);
+  uint64_t total = 0;
+  u128 qq = {0, 0};
+  for (int g = 0; g < G; ++g) {
+    totals[g] = c->h_all[3 * g];
+    total += totals[g];
+    qq = rr::add128(qq, u128{c->h_all[3 * g + 1], c->h_all[3 * g + 2]});
+  }
+  const double neff = (usable && total > 0) ? rr_fix_neff(total, qq.hi, qq.lo) : (double)h->n_global;  // (unusable: the uniform image)
+  const double threshold = (double)h->n_global * h->cfg.resample_threshold;
+  *out = WinPlan{};
+  out->fired = h->opt.resample_gate == RR_GATE_ALWAYS || neff < threshold;
+  h->last_migrated = 0;
+  if (!out->fired) {
+    h->maybe_pending = false;
+    h->pending_kind = kSrcMarkers;
+    return RR_OK;
+  }
+  h->maybe_pending = true;
+  h->pending_kind = kSrcWindow;
+  h->window_rccl = true;
+  h->window_seq = 0;
+  out->self = h->n;
+  if (G == 1) return RR_OK;
+  double rho, dummy;
+  rr_uniform2(h->opt.seed, RR_STREAM_RESAMPLE, h->rstep - 1, 0, &rho, &dummy);  // (phase C has advanced the counter)
+  (void)rr_sys_segment_matrix(rho, totals.data(), G, h->n_global, h->n, r, c->matrix.data());
+  const int64_t* M = c->matrix.data();
+  uint64_t migrated = 0;
+  for (int g = 0; g < G; ++g) {
+    if (g != r) {
+      out->n_send += (uint64_t)M[(size_t)r * G + g];
+      out->n_recv += (uint64_t)M[(size_t)g * G + r];
+      if (g < r) out->below += (uint64_t)M[(size_t)g * G + r];
+    }
+    for (int d = 0; d < G; ++d)
+      if (g != d) migrated += (uint64_t)M[(size_t)g * G + d];
+  }
+  h->last_migrated = migrated;
+  out->self = (uint64_t)M[(size_t)r * G + r];
+  if (out->n_recv + out->self != h->n) return fail(RR_RUNTIME_ERROR, "segment plan does not cover this shard's slots exactly once");
+  rr_status s;
+  if (out->n_send > c->cap_send) {  // the overhang did not fit: the kernel left everything in place
+    if ((s = win_ensure(&c->d_send, &c->cap_send, out->n_send)) != RR_OK) return s;
+    win_pack(h, c);
+    RR_HIP_TRY(hipGetLastError());
+  }
+  return win_ensure(&c->d_recv, &c->cap_recv, out->n_recv);
+}
+
+// D: what the peers served for this shard's slots -> the inbox
+static rr_status win_phase_d(rr_pf* h, rr_comm* c, const WinPlan& w) {
+  if (!w.fired || !w.n_recv) return RR_OK;
+  hipLaunchKernelGGL(k_unpack_inbox, dim3(grid_for(w.n_recv, kBlock)), dim3(kBlock), 0, h->stream, (const double*)c->d_recv, w.n_recv, w.below,
+                     w.self, h->n, h->rccl_inbox);
+  RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+static rr_status shard_step_rccl_window(rr_pf* h, rr_comm* c, const double control[2], const double* obs, size_t n_obs) {
+  rr_status s;
+  Rccl& R = rccl();
+  const int G = c->n_ranks, r = c->rank;
+  if ((s = win_phase_a(h, control, obs, n_obs)) != RR_OK) return s;
+  RR_NCCL_TRY(R.AllReduce(&h->ctl->wmax_bits, win_wmax_slot(c), 1, kNcclFloat64, kNcclMax, c->comm, h->stream));  // (doubles >= 0)
+  if ((s = win_phase_b(h, c)) != RR_OK) return s;
+  RR_NCCL_TRY(R.AllGather(c->d_sums, c->d_all, 3, kNcclUint64, c->comm, h->stream));
+  if ((s = win_phase_c(h, c)) != RR_OK) return s;
+  WinPlan w;
+  if ((s = win_host(h, c, &w)) != RR_OK) return s;
+  if (w.fired && (w.n_send || w.n_recv)) {
+    const int64_t* M = c->matrix.data();
+    RR_NCCL_TRY(R.GroupStart());
+    uint64_t so = 0, ro = 0;
+    for (int g = 0; g < G; ++g) {
+      if (g == r) continue;
+      const uint64_t ns = (uint64_t)M[(size_t)r * G + g], nr = (uint64_t)M[(size_t)g * G + r];
+      if (ns) RR_NCCL_TRY(R.Send(c->d_send + 4 * so, 4 * ns, kNcclFloat64, g, c->comm, h->stream));
+      if (nr) RR_NCCL_TRY(R.Recv(c->d_recv + 4 * ro, 4 * nr, kNcclFloat64, g, c->comm, h->stream));
+      so += ns;
+      ro += nr;
+    }
+    RR_NCCL_TRY(R.GroupEnd());
+  }
+  return win_phase_d(h, c, w);
+}
+
 rr_status rr_pf_shard_step(rr_pf* h, rr_comm* c, const double control[2], const double* obs, size_t n_obs) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!c) return fail(RR_INVALID_PARAMETER, "null communicator");
   if (h->n_global != h->n * (uint64_t)c->n_ranks || h->opt.first_global_index != h->n * (uint64_t)c->rank)
     return fail(RR_INVALID_PARAMETER, "shard geometry does not match the communicator (equal blocks, rank * n_local)");
+  static const bool eager = [] { const char* e = std::getenv("RR_PF_RCCL_EAGER"); return e && std::atoi(e) != 0; }();
+  if (h->opt.resample_scheme == RR_RESAMPLE_SYSTEMATIC && !eager) return shard_step_rccl_window(h, c, control, obs, n_obs);
   Rccl& R = rccl();
   // A: propagate + weight, local maximum
   if ((s = rr_pf_shard_propagate_weight(h, control, obs, n_obs, c->d_wmax)) != RR_OK) return s;
@@ -3485,11 +3744,98 @@ rr_status rr_pf_shard_step(rr_pf* h, rr_comm* c, const double control[2], const 
 
 uint64_t rr_pf_shard_last_migrated(const rr_pf* h) { return h ? h->last_migrated : 0; }
 
+rr_status rr_comm_create_local(int32_t rank, int32_t n_ranks, int32_t device, rr_comm** out) {
+  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  *out = nullptr;
+  if (n_ranks <= 0 || n_ranks > kMaxP2P || rank < 0 || rank >= n_ranks) return fail(RR_INVALID_PARAMETER, "bad rank layout (1..16 ranks)");
+  RR_HIP_TRY(hipSetDevice(device));
+  rr_comm* c = new rr_comm();
+  c->rank = rank;
+  c->n_ranks = n_ranks;
+  c->device = device;
+  auto bad = [&](hipError_t err) {
+    rr_comm_destroy(c);
+    return fail(RR_RUNTIME_ERROR, std::string("communicator scratch: ") + hipGetErrorString(err));
+  };
+  hipError_t err;
+  if ((err = hipMalloc(&c->d_wmax, sizeof(double))) != hipSuccess) return bad(err);
+  if ((err = hipMalloc(&c->d_sums, 3 * sizeof(uint64_t))) != hipSuccess) return bad(err);
+  if ((err = hipMalloc(&c->d_all, (3 * n_ranks + 1) * sizeof(uint64_t))) != hipSuccess) return bad(err);
+  if ((err = hipHostMalloc(&c->h_all, (3 * n_ranks + 1) * sizeof(uint64_t))) != hipSuccess) return bad(err);
+  if ((err = hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming)) != hipSuccess) return bad(err);
+  c->matrix.assign((size_t)n_ranks * n_ranks, 0);
+  *out = c;
+  return RR_OK;
+}
+
+rr_status rr_pf_shard_step_local(rr_pf* const* hs, rr_comm* const* cs, int32_t n_ranks, const double control[2], const double* obs,
+                                 size_t n_obs) {
+  if (!hs || !cs || n_ranks <= 0 || n_ranks > kMaxP2P) return fail(RR_INVALID_PARAMETER, "bad shard list");
+  const int G = n_ranks;
+  rr_status s;
+  for (int g = 0; g < G; ++g) {
+    if (!hs[g] || !cs[g] || cs[g]->n_ranks != G || cs[g]->rank != g) return fail(RR_INVALID_PARAMETER, "shard / communicator list does not match the rank layout");
+    if (hs[g]->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC) return fail(RR_INVALID_PARAMETER, "systematic shards only");
+    if (hs[g]->n_global != hs[g]->n * (uint64_t)G || hs[g]->opt.first_global_index != hs[g]->n * (uint64_t)g)
+      return fail(RR_INVALID_PARAMETER, "shard geometry does not match the rank layout (equal blocks, rank * n_local)");
+  }
+  // A, then the all-reduce(MAX) by hand
+  uint64_t wmax_bits = 0;
+  for (int g = 0; g < G; ++g) {
+    if ((s = bind(hs[g])) != RR_OK) return s;
+    if ((s = win_phase_a(hs[g], control, obs, n_obs)) != RR_OK) return s;
+  }
+  for (int g = 0; g < G; ++g) {
+    if ((s = bind(hs[g])) != RR_OK) return s;
+    uint64_t b = 0;
+    RR_HIP_TRY(hipMemcpyAsync(&b, &hs[g]->ctl->wmax_bits, sizeof b, hipMemcpyDeviceToHost, hs[g]->stream));
+    RR_HIP_TRY(hipStreamSynchronize(hs[g]->stream));
+    if (rr_u2d(b) > rr_u2d(wmax_bits)) wmax_bits = b;
+  }
+  // B, then the all-gather by hand
+  std::vector<uint64_t> all(3 * (size_t)G + 1);
+  for (int g = 0; g < G; ++g) {
+    if ((s = bind(hs[g])) != RR_OK) return s;
+    RR_HIP_TRY(hipMemcpyAsync(win_wmax_slot(cs[g]), &wmax_bits, sizeof wmax_bits, hipMemcpyHostToDevice, hs[g]->stream));
+    if ((s = win_phase_b(hs[g], cs[g])) != RR_OK) return s;
+    RR_HIP_TRY(hipMemcpyAsync(&all[3 * (size_t)g], cs[g]->d_sums, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, hs[g]->stream));
+    RR_HIP_TRY(hipStreamSynchronize(hs[g]->stream));
+  }
+  std::vector<WinPlan> plans(G);
+  for (int g = 0; g < G; ++g) {
+    if ((s = bind(hs[g])) != RR_OK) return s;
+    RR_HIP_TRY(hipMemcpyAsync(cs[g]->d_all, all.data(), 3 * (size_t)G * sizeof(uint64_t), hipMemcpyHostToDevice, hs[g]->stream));
+    if ((s = win_phase_c(hs[g], cs[g])) != RR_OK) return s;
+    if ((s = win_host(hs[g], cs[g], &plans[g])) != RR_OK) return s;
+    RR_HIP_TRY(hipStreamSynchronize(hs[g]->stream));  // the send buffer is complete
+  }
+  // the exchange: segment (src -> dst) = M[src][dst] records, the src's send buffer and the dst's receive buffer both in rank order
+  for (int d = 0; d < G; ++d) {
+    if (!plans[d].fired) continue;
+    if ((s = bind(hs[d])) != RR_OK) return s;
+    const int64_t* M = cs[d]->matrix.data();
+    uint64_t ro = 0;
+    for (int g = 0; g < G; ++g) {
+      if (g == d) continue;
+      const uint64_t nr = (uint64_t)M[(size_t)g * G + d];
+      uint64_t so = 0;  // offset of the (g -> d) segment in g's send buffer
+      for (int q = 0; q < d; ++q)
+        if (q != g) so += (uint64_t)M[(size_t)g * G + q];
+      if (nr) RR_HIP_TRY(hipMemcpyAsync(cs[d]->d_recv + 4 * ro, cs[g]->d_send + 4 * so, 4 * nr * sizeof(double), hipMemcpyDeviceToDevice, hs[d]->stream));
+      ro += nr;
+    }
+    if ((s = win_phase_d(hs[d], cs[d], plans[d])) != RR_OK) return s;
+    RR_HIP_TRY(hipStreamSynchronize(hs[d]->stream));
+  }
+  return RR_OK;
+}
+
 rr_status rr_pf_shard_estimate(rr_pf* h, rr_comm* c, double est[4], double cov[16]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!c) return fail(RR_INVALID_PARAMETER, "null communicator");
   double e[4], cv[16];
+  if ((s = materialise(h)) != RR_OK) return s;
   if ((s = compute_moments(h, e, cv)) != RR_OK) return s;
   // weight share of this shard: 1/G after a resample, T_local / T otherwise
   if ((s = fetch_ctl(h)) != RR_OK) return s;

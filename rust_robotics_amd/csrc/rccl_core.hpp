@@ -83,8 +83,9 @@ struct rr_comm {
   // device scratch for the collectives
   double* d_wmax = nullptr;      // [1]
   uint64_t* d_sums = nullptr;    // [3]
-  uint64_t* d_all = nullptr;     // [n_ranks][3]
+  uint64_t* d_all = nullptr;     // [n_ranks][3] + 1: every rank's sums, then the bits of the global weight maximum
   uint64_t* h_all = nullptr;     // pinned
+  hipEvent_t ev_plan = nullptr;  // "the sums are on the host": the host sizes the segments while the device marks and packs
   double* d_send = nullptr;      // MCL: [cap_send][4]
   double* d_recv = nullptr;      // MCL: [n_local][4]
   size_t cap_send = 0, cap_recv = 0;

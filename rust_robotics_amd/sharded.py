@@ -368,6 +368,66 @@ class NativeShard:
             self.comm = None
 
 
+class LocalWindowShards:
+    """Bring-up / test seam (``rr_pf_shard_step_local``): the RCCL transport's sharded step for ``world`` shards that all live
+    in this process on one device, the three exchanges done as device copies.  Every kernel and all of the host's segment
+    arithmetic are the RCCL transport's own."""
+
+    def __init__(self, world: int, n_local: int, device: int = 0, *, seed: int, range_noise=0.2, velocity_noise=2.0,
+                 yaw_rate_noise=math.radians(40.0), dt=0.1, gate=_ffi.RR_GATE_ALWAYS, resample_threshold=1.0,
+                 likelihood_mode=_ffi.RR_LIK_FUSED, initial_state=None):
+        L = _ffi.lib()
+        self.L, self.world, self.n_local = L, world, n_local
+        self.hs = (C.c_void_p * world)()
+        self.cs = (C.c_void_p * world)()
+        for g in range(world):
+            cfg = _ffi.PfConfig(n_local, resample_threshold, range_noise, velocity_noise, yaw_rate_noise, dt)
+            opt = _ffi.PfOptions()
+            L.rr_pf_options_default(C.byref(opt))
+            opt.device, opt.seed = device, seed
+            opt.resample_scheme, opt.resample_gate, opt.likelihood_mode = _ffi.RR_RESAMPLE_SYSTEMATIC, gate, likelihood_mode
+            opt.first_global_index, opt.n_global = g * n_local, n_local * world
+            h = C.c_void_p()
+            if initial_state is None:
+                self._check(L.rr_pf_create(C.byref(cfg), C.byref(opt), C.byref(h)))
+            else:
+                st = np.ascontiguousarray(initial_state, dtype=np.float64)
+                self._check(L.rr_pf_create_with_state(C.byref(cfg), C.byref(opt), st.ctypes.data_as(C.POINTER(C.c_double)), C.byref(h)))
+            self.hs[g] = h.value
+            c = C.c_void_p()
+            self._check(L.rr_comm_create_local(g, world, device, C.byref(c)))
+            self.cs[g] = c.value
+
+    def _check(self, status: int) -> None:
+        if status != _ffi.RR_OK:
+            kind = RoboticsError.invalid_parameter if status == _ffi.RR_INVALID_PARAMETER else RoboticsError.runtime
+            raise kind(_ffi.last_error())
+
+    def step(self, u, obs) -> None:
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        obs = np.ascontiguousarray(obs, dtype=np.float64).reshape(-1, 3)
+        dp = C.POINTER(C.c_double)
+        self._check(self.L.rr_pf_shard_step_local(self.hs, self.cs, self.world, u.ctypes.data_as(dp), obs.ctypes.data_as(dp) if obs.size else None,
+                                                  obs.shape[0]))
+
+    def particles(self, g: int) -> np.ndarray:
+        out = np.empty((self.n_local, 5))
+        self._check(self.L.rr_pf_get_particles(C.c_void_p(self.hs[g]), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
+    def migrated(self) -> int:
+        return int(self.L.rr_pf_shard_last_migrated(C.c_void_p(self.hs[0])))
+
+    def close(self) -> None:
+        for g in range(self.world):
+            if self.hs[g]:
+                self.L.rr_pf_destroy(C.c_void_p(self.hs[g]))
+                self.hs[g] = None
+            if self.cs[g]:
+                self.L.rr_comm_destroy(C.c_void_p(self.cs[g]))
+                self.cs[g] = None
+
+
 class P2PShard:
     """One shard using the peer-to-peer transport (include/rr_pf.h "peer-to-peer transport"):
     no host code and no collective library inside a step.  ``connect_ipc`` is for one process per

@@ -90,3 +90,50 @@ def run_multinomial_phases(world, n_local, steps=8):
         assert bad.size == 0, (f"shard {g} differs from the unsharded multinomial filter: {bad.size} of {n_local} rows, first {bad[:6]}, "
                                f"got {got[bad[:2]]}, expected {e[bad[:2]]}")
     print("MN_PHASES_OK")
+
+
+@pytest.mark.parametrize("world,n_local,peaked", [(2, 6000, False), (3, 4100, False), (2, 100_000, True), (4, 30_001, True), (2, 700_000, False)])
+def test_rccl_window_step_in_process_equals_unsharded(world, n_local, peaked):
+    """The RCCL transport's systematic step (lazy: window markers, only the window's overhang packed, exchanged and unpacked
+    into the inbox) for 2 - 4 shards in ONE process through the loopback seam rr_pf_shard_step_local: every kernel and all
+    of the host's segment arithmetic are the transport's own, only the three exchanges are device copies.  `peaked`: the
+    bench configuration (32 landmarks, sigma 0.2, large motion noise) -- a few heavy particles, so whole shards are served
+    by a neighbour and the overhang is most of a block.  An accessor in mid-run makes a pending resample real."""
+    import math
+
+    import numpy as np
+
+    import rust_robotics_amd.localization as loc
+    from rust_robotics_amd import _ffi
+    from rust_robotics_amd.sharded import LocalWindowShards
+    from tests import helpers as H
+
+    steps = 9
+    if peaked:
+        kw = dict(seed=1, initial_state=[0.0, 0.0, 0.0, 1.0])
+        lms, sigma = H.landmarks_grid(32, 1), 0.2
+        cfg = loc.MonteCarloLocalizationConfig(min_particles=n_local * world, max_particles=n_local * world)
+        ref = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, resample_scheme=_ffi.RR_RESAMPLE_SYSTEMATIC)
+    else:
+        kw = dict(seed=42, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))
+        lms, sigma = H.REF_SCENE_LANDMARKS, 0.5
+        cfg = loc.MonteCarloLocalizationConfig(min_particles=n_local * world, max_particles=n_local * world, range_noise=0.5, velocity_noise=0.3,
+                                               yaw_rate_noise=math.radians(5.0))
+        ref = loc.MonteCarloLocalizer(cfg, seed=42, resample_scheme=_ffi.RR_RESAMPLE_SYSTEMATIC)
+    sh = LocalWindowShards(world, n_local, **kw)
+    rng = np.random.default_rng(43)
+    moved = 0
+    for t in range(steps):
+        obs = H.observations(lms, H.true_pose(t + 1), sigma, rng)
+        sh.step([1.0, 0.1], obs)
+        ref.step_async([1.0, 0.1], obs)
+        moved += sh.migrated()
+        if t in (3, steps - 1):
+            exp = ref.get_particles_array()
+            for g in range(world):
+                got = sh.particles(g)
+                e = exp[g * n_local:(g + 1) * n_local]
+                bad = np.nonzero((got.view(np.uint64) != e.view(np.uint64)).any(axis=1))[0]
+                assert bad.size == 0, f"step {t} shard {g}: {bad.size} of {n_local} particles differ, first {bad[:6]}, last {bad[-3:]}"
+    assert moved > 0, "no particle ever crossed a shard boundary: the exchange was not exercised"
+    sh.close()
