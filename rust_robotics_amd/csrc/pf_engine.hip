@@ -3433,8 +3433,8 @@ void rr_comm_destroy(rr_comm* c) {
 }
 
 // The systematic sharded step over RCCL, lazy like the peer-to-peer one: k_step_lazy<kSrcWindow> | all-reduce(MAX) |
-// k_quantize_reduce | k_scan_tiles | all-gather(sums) | k_shard_plan | k_mark (window) | D2H of the sums + event |
-// k_pack_window | grouped send/recv of the window's overhang only | k_unpack_inbox.  Own slots inside the own window never
+// k_quantize_reduce_sums (image + this shard's sums by its last workgroup) | all-gather(sums) | k_mark_plan (gate + plan +
+// window markers) | D2H of the sums + event | k_pack_window | grouped send/recv of the window's overhang only | k_unpack_inbox.  Own slots inside the own window never
 // move (the next step reads them through the markers); the host's one wait -- for the G sums that size the segments --
 // is an EVENT recorded right behind the copy, so it overlaps k_mark and k_pack_window instead of draining the stream.
 // Round 2 propagated with the non-lazy kernel, gathered ALL served slots into a send buffer and adopted all n slots
@@ -3496,11 +3496,10 @@ static rr_status win_phase_a(rr_pf* h, const double control[2], const double* ob
 
 // B: the integer image under the GLOBAL maximum (in the slot behind the gathered sums), local sums -> c->d_sums
 static rr_status win_phase_b(rr_pf* h, rr_comm* c) {
-  launch_quantize(h, win_wmax_slot(c), /*settle=*/1);
-  PlanArgs pa = plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN);
-  pa.lazy_gather = 1;
-  Timed t(h, RR_K_SCAN_TILES);
-  hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl, h->n_tiles, 0, pa, c->d_sums);
+  Timed t(h, RR_K_QUANTIZE_REDUCE);
+  hipLaunchKernelGGL(rr::k_quantize_reduce_sums, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, (const double*)h->w, h->ctl,
+                     (const double*)win_wmax_slot(c), image_args(h), h->tile_total, h->tile_q2, /*settle=*/1, h->n_tiles, h->grid_ticket,
+                     c->d_sums);
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
 }
@@ -3512,9 +3511,8 @@ static rr_status win_phase_c(rr_pf* h, rr_comm* c) {
   pa.lazy_gather = 1;
   {
     Timed t(h, RR_K_CDF);
-    hipLaunchKernelGGL(rr::k_shard_plan, dim3(1), dim3(1), 0, h->stream, h->ctl, (const uint64_t*)c->d_all, G, c->rank, pa);
-    hipLaunchKernelGGL(rr::k_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl, image_args(h),
-                       h->tile_total, h->markers, h->carry, /*window=*/1, h->slot_pad);
+    hipLaunchKernelGGL(rr::k_mark_plan, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, (const double*)h->w, h->ctl, image_args(h),
+                       (const uint64_t*)h->tile_total, (const uint64_t*)c->d_all, G, c->rank, pa, h->markers, h->carry, h->slot_pad);
   }
   RR_HIP_TRY(hipMemcpyAsync(c->h_all, c->d_all, (3 * (size_t)G + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipEventRecord(c->ev_plan, h->stream));

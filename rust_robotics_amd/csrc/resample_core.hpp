@@ -546,6 +546,56 @@ __device__ inline bool last_arrival(unsigned int* ticket, unsigned int block, un
   return true;
 }
 
+// k_quantize_reduce that also leaves this shard's sums (T, sum q^2) for the all-gather: the last workgroup to arrive adds the
+// tile totals -- no separate single-workgroup k_scan_tiles launch (7 us at 1e6 particles for 12 KB of input); the tile
+// PREFIXES are formed by the consumer (k_mark_plan: every workgroup adds the totals of the tiles before its own).
+static __global__ __launch_bounds__(kTileBlock) void k_quantize_reduce_sums(const double* __restrict__ w, Ctl* __restrict__ ctl,
+                                                                       const double* __restrict__ wmax_src, ImageArgs a,
+                                                                       uint64_t* __restrict__ tile_total, uint64_t* __restrict__ tile_q2,
+                                                                       int settle, uint64_t n_tiles, unsigned int* __restrict__ ticket,
+                                                                       uint64_t* __restrict__ shard_sums_out) {
+  constexpr int W = kTileBlock / kWave;
+  __shared__ uint64_t s3[3 * W];
+  __shared__ int s_last;
+  quantize_reduce_tile(w, ctl, wmax_src, a, tile_total, tile_q2, settle);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    s_last = last_arrival(ticket, blockIdx.x, gridDim.x) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  __syncthreads();
+  uint64_t t = 0;
+  u128 q2 = {0, 0};
+  for (uint64_t k = tid; k < n_tiles; k += kTileBlock) {
+    t += __builtin_nontemporal_load(&tile_total[k]);
+    q2 = add128(q2, u128{__builtin_nontemporal_load(&tile_q2[2 * k]), __builtin_nontemporal_load(&tile_q2[2 * k + 1])});
+  }
+  t = wave_sum_u64(t);
+  q2 = wave_sum_u128(q2);
+  if (lane == 0) {
+    s3[wv] = t;
+    s3[W + wv] = q2.hi;
+    s3[2 * W + wv] = q2.lo;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    uint64_t tt = 0;
+    u128 qq = {0, 0};
+    for (int k = 0; k < W; ++k) {
+      tt += s3[k];
+      qq = add128(qq, u128{s3[W + k], s3[2 * W + k]});
+    }
+    ctl->total_local = tt;
+    shard_sums_out[0] = tt;
+    shard_sums_out[1] = qq.hi;
+    shard_sums_out[2] = qq.lo;
+  }
+}
+
 struct EstArgs {
   const double* field[2][4];  // x, y, yaw, v of both buffer sets
   double* partials;           // [n_tiles][4]
@@ -963,6 +1013,51 @@ static __global__ __launch_bounds__(kTileBlock) void k_mark(const double* __rest
   const uint64_t slot_base = window ? (uint64_t)0 - pad : ctl->served_first;
   const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
   mark_sources(t, ctl->base + tile_offset[blockIdx.x] + t.thread_off, i0, a.n, plan, ctl->total, slot_base, markers, carry);
+}
+
+// k_shard_plan + k_mark in one launch, over RAW tile totals (k_quantize_reduce_sums): every workgroup combines the shards' sums
+// itself (G <= 16 triples: the same integer adds on every workgroup, so the same gate decision and plan), adds the totals of
+// the tiles before its own, and marks its sources in the window layout; workgroup 0 also leaves the plan in Ctl.
+static __global__ __launch_bounds__(kTileBlock) void k_mark_plan(const double* __restrict__ w, Ctl* __restrict__ ctl, ImageArgs a,
+                                                            const uint64_t* __restrict__ tile_total, const uint64_t* __restrict__ all_sums,
+                                                            int n_shards, int rank, PlanArgs pa, unsigned int* __restrict__ markers,
+                                                            unsigned int* __restrict__ carry, uint64_t pad) {
+  constexpr int W = kTileBlock / kWave;
+  __shared__ uint64_t s_pre[W];
+  __shared__ uint64_t s_w[W];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  uint64_t total = 0, base = 0;
+  u128 qq = {0, 0};
+  for (int g = 0; g < n_shards; ++g) {
+    if (g == rank) base = total;
+    total += all_sums[3 * g];
+    qq = add128(qq, u128{all_sums[3 * g + 1], all_sums[3 * g + 2]});
+  }
+  const int mode = ctl->image_mode, shift = ctl->shift;  // written by the quantize kernel; workgroup 0's finalize_plan does not touch them
+  TileSums ts;
+  ts.pre = 0;
+  ts.tot = total;
+  ts.q2 = qq;
+  const int fire = gate_decision(mode, ts, pa);
+  uint64_t pre = 0;
+  for (uint64_t k = tid; k < blockIdx.x; k += kTileBlock) pre += tile_total[k];
+  pre = wave_sum_u64(pre);
+  if (lane == 0) s_pre[wv] = pre;
+  __syncthreads();
+  pre = 0;
+  for (int k = 0; k < W; ++k) pre += s_pre[k];
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0) finalize_plan(ctl, total, base, all_sums[3 * rank], qq, pa);
+  if (!fire) return;
+  double rho = pa.rho_override;
+  if (rho != rho) {
+    double dummy;
+    rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
+  }
+  const rr_sys_plan plan = rr_sys_plan_make(rho, total, pa.n_global);
+  const TileScan t = tile_scan(w, a, mode, shift, blockIdx.x, s_w);
+  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)tid * kItems;
+  mark_sources(t, base + pre + t.thread_off, i0, a.n, plan, total, (uint64_t)0 - pad, markers, carry);
 }
 
 // markers -> source indices for the kResolveSlots slots of one workgroup; returns this thread's
