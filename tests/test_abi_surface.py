@@ -128,3 +128,48 @@ def test_rust_sys_bindings_are_current():
     text = open(os.path.join(root, "bindings", "rust", "rust_robotics_amd-sys", "src", "lib.rs")).read()
     for sym in (n for h in HEADERS for n in declared_functions(h)):
         assert f"pub fn {sym}(" in text, sym
+
+
+def test_rust_sys_struct_layouts_match_the_c_headers(tmp_path):
+    """The generated `#[repr(C)]` structs cannot be compiled here (no rustc): instead the generator computes, from the RUST field
+    types alone, the size / alignment / offset of every field as repr(C) lays it out, writes them as `const` assertions into
+    the -sys crate and as _Static_asserts into tests/c/abi_layout.c -- and this makes the C compiler confirm every one of them
+    against include/*.h."""
+    import shutil
+    import subprocess
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "c", "abi_layout.c")
+    text = open(src).read()
+    assert text.count("_Static_assert") >= 60
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"), "-c", src, "-o", str(tmp_path / "abi_layout.o")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lib = open(os.path.join(root, "bindings", "rust", "rust_robotics_amd-sys", "src", "lib.rs")).read()
+    assert lib.count("::core::mem::offset_of!(") == text.count("offsetof(")
+    # a deliberately wrong number must fail: the assertions are live
+    bad = tmp_path / "bad.c"
+    bad.write_text(text.replace("sizeof(rr_pf_config) == 48", "sizeof(rr_pf_config) == 56"))
+    r = subprocess.run(["gcc", "-std=c11", "-I", os.path.join(root, "include"), "-c", str(bad), "-o", str(tmp_path / "bad.o")], capture_output=True, text=True)
+    assert r.returncode != 0
+
+
+def test_instruction_budget_is_reproducible_from_the_isa():
+    """rust_robotics_amd/csrc/INSTRUCTION_BUDGET.json (bench.py's roofline.fp64_valu) cites tools/count_isa.py: the tool must
+    exist and read the same per-pair count off the compiler's ISA for the kernel as it is today (hipcc cross-compiles here)."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+
+    if not os.path.exists("/opt/rocm/bin/hipcc") and not shutil.which("hipcc"):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "count_isa.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = float(r.stdout.split("per_pair =")[1].split()[0])
+    want = json.load(open(os.path.join(root, "rust_robotics_amd", "csrc", "INSTRUCTION_BUDGET.json")))
+    assert abs(got - want["per_pair"]) < 1e-3, (got, want["per_pair"], "run `python tools/count_isa.py --write`")
+    assert "tools/count_isa.py" in want["source"]
