@@ -41,7 +41,18 @@ RR_HD double rr_fma(double a, double b, double c) { return __builtin_fma(a, b, c
 RR_HD double rr_rint(double x) { return __builtin_rint(x); }
 RR_HD double rr_sqrt(double x) { return __builtin_sqrt(x); }
 #if defined(__HIP_DEVICE_COMPILE__)
-/* Square root for the device's hot loops: v_rsq_f64, one Goldschmidt refinement, ONE residual correction -- the core of
+#if !defined(__gfx950__)
+#error "rr_sqrt_core's agreement bound rests on the accuracy of gfx950's v_rsq_f64 seed (measured, tools/ubench/rsq_accuracy.hip): build with --offload-arch=gfx950 only"
+#endif
+/* CONTRACT (read this before relying on "bit-exact"): every GPU evaluates this function identically, so 1 GPU, 8 GPUs and
+ * any two runs agree bit for bit, always.  Against the CPU side of the D-spec (oracle/det_spec.c: a correctly rounded sqrt)
+ * the agreement is PROBABILISTIC: identical except when sqrt(x) lies within 2^-42.6 ulp of a rounding boundary, i.e. with
+ * probability < 2^-41 per evaluation (0 of 6.9e10 measured).  At 1e6 x 32 pairs per step that is about one last-bit
+ * difference per 1e5 steps; a difference can move one quantised weight by one unit and, rarely, one resample index.  The
+ * CPU <-> GPU parity tests are therefore exact on every case they run but not a proof for arbitrarily long runs; the second
+ * residual correction that would make it one costs 2 of the pair loop's 14.4 VALU instructions (~3 us of a 50 us step).
+ *
+ * Square root for the device's hot loops: v_rsq_f64, one Goldschmidt refinement, ONE residual correction -- the core of
  * LLVM's correctly rounded f64 sqrt lowering for gfx950 without its second residual correction, without the 2^256
  * rescale it wraps around inputs below 2^-767 and without the 0/inf select (for x == 0, inf or NaN this returns NaN;
  * callers -- rr_pf_weight_fused -- redo such particles with rr_sqrt).
@@ -290,8 +301,11 @@ typedef struct rr_philox4 {
 } rr_philox4;
 
 /* The engine's streams run RR_PHILOX_ROUNDS = 7 rounds: the smallest round count Salmon et al. report as
- * Crush-resistant for Philox4x32 (their Table 2; 10 is the conservative default).  The round function is pinned
- * by the published Random123 known answers of the 10-round form (tests/test_detmath.py). */
+ * Crush-resistant for Philox4x32 (their Table 2; 10 is the conservative default) -- no safety margin by the authors'
+ * own account, taken because the generator is ~150 of k_step_lazy's ~870 instructions per particle.  Both forms are pinned by
+ * the published Random123 known answers (7 and 10 rounds) and by an independent integer evaluation of the round function;
+ * the streams' moments, lag / step / stream / seed correlations and 2-D equidistribution are smoke-tested over the engine's
+ * own (structured) counter layout (tests/test_detmath.py). */
 #define RR_PHILOX_ROUNDS 7
 
 RR_HD rr_philox4 rr_philox4x32_n(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int rounds) {
@@ -350,7 +364,7 @@ RR_HD void rr_normal2(uint64_t seed, uint32_t stream, uint32_t step, uint64_t in
   double u1 = rr_u2d(0x3ff0000000000000ull | (b >> 12)) - 1.0;
   double t = -2.0 * rr_log_core(rr_d2u(v), 0);
 #if defined(__HIP_DEVICE_COMPILE__)
-  double rad = rr_sqrt_core(t); /* == rr_sqrt(t) on [2^-767, inf) */
+  double rad = rr_sqrt_core(t); /* == rr_sqrt(t) on [2^-767, inf) except with probability < 2^-41 (rr_sqrt_core's contract) */
 #else
   double rad = rr_sqrt(t);
 #endif

@@ -299,7 +299,9 @@ rr_status rr_pf_shard_adopt(rr_pf* h, const double* d_in);
  *   pack_selected -> d_send: those records, ordered by global slot (= grouped by destination), 5 doubles each:
  *                    x, y, yaw, v, destination-local slot index
  *   adopt_records <- the n_local records of this shard's slots, in any order
- * Bit-identical to the unsharded multinomial filter for any shard count (tests/test_sharded_gloo.py). */
+ * Bit-identical to the unsharded multinomial filter for any shard count (tests/test_sharded_gloo.py).
+ * Order is enforced: select needs the plan of a preceding rr_pf_shard_cdf made for the same n_shards, pack_selected a
+ * preceding select with the same n_shards (RR_INVALID_PARAMETER otherwise -- they draw from the Philox stream of THAT resample). */
 rr_status rr_pf_shard_select(rr_pf* h, int32_t n_shards, uint64_t* d_counts_out);
 rr_status rr_pf_shard_pack_selected(rr_pf* h, int32_t n_shards, double* d_send);
 rr_status rr_pf_shard_adopt_records(rr_pf* h, const double* d_in, uint64_t n_records);

@@ -113,7 +113,8 @@ RR_HD double rr_pf_residual_fused(double x, double y, double d_obs, double lx, d
 RR_HD double rr_pf_weight_fused(double x, double y, const double* obs, int n_obs, rr_pf_lik k) {
   double ss = 0.0;
 #if defined(__HIP_DEVICE_COMPILE__)
-  /* branch-free inner loop on the sqrt core (== rr_sqrt for finite q >= 2^-767); an overflowing q (inf) turns
+  /* branch-free inner loop on the sqrt core (== rr_sqrt for finite q >= 2^-767 except with probability < 2^-41 per
+   * evaluation: rr_sqrt_core's contract in rr_detmath.h); an overflowing q (inf) turns
    * ss into NaN, which sends the particle through the exact form once */
   for (int l = 0; l < n_obs; ++l) {
     double dx = x - obs[3 * l + 1];
@@ -469,7 +470,7 @@ RR_HD double rr_fs1_update_one(double px, double py, double pyaw, double zd, dou
    * device's bare square-root core is inside its exact range */
   double d2 = rr_fma(dy, dy, rr_fma(dx, dx, RR_PF_Q_FLOOR));
 #if defined(__HIP_DEVICE_COMPILE__)
-  double d = rr_sqrt_core(d2); /* == rr_sqrt(d2) for finite d2 >= 2^-767 */
+  double d = rr_sqrt_core(d2); /* == rr_sqrt(d2) for finite d2 >= 2^-767, up to rr_sqrt_core's 2^-41 contract */
 #else
   double d = rr_sqrt(d2);
 #endif
@@ -527,7 +528,9 @@ RR_HD double rr_fs1_update_one(double px, double py, double pyaw, double zd, dou
     double t0 = rr_fma(y1, i10, y0 * i00);
     double t1 = rr_fma(y1, i11, y0 * i01);
     double mahal = rr_fma(t1, y1, t0 * y0);
-    /* exp(-m/2) / (2 pi sqrt(det)) = exp(-m/2) * sqrt(det) * (1/det) * (1/(2 pi)) */
+    /* exp(-m/2) / (2 pi sqrt(det)) = exp(-m/2) * sqrt(det) * (1/det) * (1/(2 pi)); below 2^-1000 the reciprocal of det
+     * is on its way to overflow (inf from 2^-1024 down) while the reference's quotient is still finite: its literal form there */
+    if (det < 0x1p-1000) return rr_exp(-0.5 * mahal) / (RR_TWO_PI * rr_sqrt(det));
     return ((rr_exp(-0.5 * mahal) * rr_sqrt(det)) * rdet) * RR_INV_TWO_PI;
   }
   return m.nonpos_det_w;

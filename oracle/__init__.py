@@ -171,6 +171,9 @@ def det() -> C.CDLL:
     L.det_targets_multinomial.restype = None
     L.det_philox_raw.argtypes = [u32v] * 6 + [c_u32_p]
     L.det_philox_raw.restype = None
+    L.det_philox_raw_n.argtypes = [u32v] * 6 + [i, c_u32_p]
+    L.det_philox_raw_n.restype = None
+    L.det_philox_rounds.restype = i
     L.det_pf_init.argtypes = [sz, u64, u64, P, P, P, P, P]
     L.det_pf_init.restype = None
     L.det_pf_predict.argtypes = [sz, P, P, P, P, d, d, d, P, P, u64, u32v, u64, d, d]

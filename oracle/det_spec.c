@@ -43,6 +43,12 @@ void det_philox_raw(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t
   rr_philox4 r = rr_philox4x32_10(c0, c1, c2, c3, k0, k1);
   memcpy(out, r.v, 16);
 }
+/* the same with a given number of rounds; rounds == 0: the engine's own form (RR_PHILOX_ROUNDS) */
+void det_philox_raw_n(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, int rounds, uint32_t out[4]) {
+  rr_philox4 r = rounds ? rr_philox4x32_n(c0, c1, c2, c3, k0, k1, rounds) : rr_philox4x32(c0, c1, c2, c3, k0, k1);
+  memcpy(out, r.v, 16);
+}
+int det_philox_rounds(void) { return RR_PHILOX_ROUNDS; }
 
 /* ------------------------------------------------------------------ PF / MCL */
 

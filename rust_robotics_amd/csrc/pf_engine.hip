@@ -1526,6 +1526,11 @@ struct rr_pf {
   bool wmax_live = false;        // Ctl.wmax_bits holds the maximum of the current raw weights
   bool wmax_bits_clean = false;  // Ctl.wmax_bits is known to be zero
   uint64_t last_migrated = 0;
+  // sharded multinomial resample: the plan rr_pf_shard_cdf made (select / pack_selected draw from the stream of THAT resample)
+  bool shard_plan_valid = false;
+  unsigned int shard_plan_rstep = 0;
+  int shard_plan_shards = 0;   // as passed to rr_pf_shard_cdf
+  int shard_select_shards = 0; // as passed to rr_pf_shard_select (0: not selected yet)
   unsigned int* mn_tile_cnt = nullptr;  // sharded multinomial: selected slots per (destination, tile), scanned in place
   uint64_t mn_tiles = 0;
   rr::P2PState p2p;  // device-initiated exchange over xGMI (rr_pf_p2p_*)
@@ -2184,6 +2189,8 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
     RR_TRY_OR_CLEAN(hipMalloc(&h->kld_out, 2 * sizeof(uint64_t)));
     RR_TRY_OR_CLEAN(hipHostMalloc(&h->kld_out_host, 2 * sizeof(uint64_t)));
   }
+  const bool guide_at_create = opt.resample_scheme == RR_RESAMPLE_MULTINOMIAL && !kld && h->n == h->n_global && cap_tiles <= (uint64_t)rr::kFusedMaxTiles &&
+                               h->n > kSmallMaxParticles;
   if (opt.resample_scheme == RR_RESAMPLE_MULTINOMIAL && !kld) {  // the fused step resamples lazily through lidx
     RR_TRY_OR_CLEAN(hipMalloc(&h->lidx, h->n * sizeof(unsigned int)));
     RR_TRY_OR_CLEAN(hipMemset(h->lidx, 0xff, h->n * sizeof(unsigned int)));
@@ -2237,6 +2244,11 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
   RR_TRY_OR_CLEAN(hipMemcpyAsync(h->ctl, h->ctl_host, sizeof(Ctl), hipMemcpyHostToDevice, h->stream));
   RR_TRY_OR_CLEAN(hipStreamSynchronize(h->stream));
 #undef RR_TRY_OR_CLEAN
+  // the guide table of the multinomial search: made here, not inside the first rr_pf_step_async (which promises no host wait)
+  if (guide_at_create) {
+    const rr_status gs = ensure_guide(h);
+    if (gs != RR_OK) return cleanup(gs);
+  }
   *out = h;
   return RR_OK;
 }
@@ -2997,6 +3009,10 @@ rr_status rr_pf_shard_cdf(rr_pf* h, const uint64_t* d_all_sums, int32_t n_shards
   RR_HIP_TRY(hipGetLastError());
   h->wmax_live = false;
   h->wmax_bits_clean = true;
+  h->shard_plan_valid = true;
+  h->shard_plan_rstep = h->rstep;
+  h->shard_plan_shards = n_shards;
+  h->shard_select_shards = 0;
   h->rstep += 1;
   return RR_OK;
 }
@@ -3058,7 +3074,7 @@ static MnSelectArgs mn_args(const rr_pf* h, int n_shards) {
   a.n_global = h->n_global;
   a.tiles_per_dest = (h->n + kTile - 1) / kTile;
   a.seed = h->opt.seed;
-  a.rstep = h->rstep - 1;  // rr_pf_shard_cdf has advanced the counter
+  a.rstep = h->shard_plan_rstep;  // the resample rr_pf_shard_cdf planned (it has advanced the counter since)
   a.n_shards = n_shards;
   return a;
 }
@@ -3069,6 +3085,8 @@ rr_status rr_pf_shard_select(rr_pf* h, int32_t n_shards, uint64_t* d_counts_out)
   if (h->opt.resample_scheme != RR_RESAMPLE_MULTINOMIAL) return fail(RR_INVALID_PARAMETER, "rr_pf_shard_select serves multinomial shards");
   if (!d_counts_out || n_shards <= 0 || n_shards > kMaxP2P || h->n_global != h->n * (uint64_t)n_shards)
     return fail(RR_INVALID_PARAMETER, "bad shard count (equal blocks, at most 16 shards)");
+  if (!h->shard_plan_valid || h->shard_plan_shards != n_shards)
+    return fail(RR_INVALID_PARAMETER, "rr_pf_shard_select needs the plan of a preceding rr_pf_shard_cdf with the same number of shards");
   const MnSelectArgs a = mn_args(h, n_shards);
   const uint64_t n_tiles = a.tiles_per_dest * (uint64_t)n_shards;
   if (n_tiles > h->mn_tiles) {
@@ -3083,6 +3101,7 @@ rr_status rr_pf_shard_select(rr_pf* h, int32_t n_shards, uint64_t* d_counts_out)
   hipLaunchKernelGGL(k_mn_select_scan, dim3(1), dim3(kScanThreads), 0, h->stream, h->mn_tile_cnt, n_tiles, a.tiles_per_dest, (int)n_shards,
                      d_counts_out);
   RR_HIP_TRY(hipGetLastError());
+  h->shard_select_shards = n_shards;
   return RR_OK;
 }
 
@@ -3091,6 +3110,8 @@ rr_status rr_pf_shard_pack_selected(rr_pf* h, int32_t n_shards, double* d_send) 
   if (s != RR_OK) return s;
   if (h->opt.resample_scheme != RR_RESAMPLE_MULTINOMIAL) return fail(RR_INVALID_PARAMETER, "rr_pf_shard_pack_selected serves multinomial shards");
   if (!d_send) return fail(RR_INVALID_PARAMETER, "null send buffer");
+  if (!h->shard_plan_valid || h->shard_select_shards == 0 || h->shard_select_shards != n_shards)
+    return fail(RR_INVALID_PARAMETER, "rr_pf_shard_pack_selected needs a preceding rr_pf_shard_select with the same number of shards");
   const MnSelectArgs a = mn_args(h, n_shards);
   const uint64_t n_tiles = a.tiles_per_dest * (uint64_t)n_shards;
   if (n_tiles > h->mn_tiles) return fail(RR_INVALID_PARAMETER, "call rr_pf_shard_select first");
@@ -3108,6 +3129,7 @@ rr_status rr_pf_shard_adopt_records(rr_pf* h, const double* d_in, uint64_t n_rec
   if (n_records != h->n) return fail(RR_INVALID_PARAMETER, "every output slot of the shard needs exactly one record");
   hipLaunchKernelGGL(k_adopt_records, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, d_in, h->n);
   RR_HIP_TRY(hipGetLastError());
+  h->shard_plan_valid = false;  // this resample is done
   return RR_OK;
 }
 

@@ -1,6 +1,7 @@
 """include/rr_detmath.h against mpmath (the contract's accuracy claim) and its
 structural properties (Philox known-answer vectors, uniform ranges)."""
 import ctypes as C
+import math
 
 import mpmath as mp
 import numpy as np
@@ -134,6 +135,69 @@ def test_philox_known_answers(det):
     assert [hex(v) for v in out] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
     det.det_philox_raw(0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344, 0xA4093822, 0x299F31D0, out)
     assert [hex(v) for v in out] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_philox_seven_round_known_answers(det):
+    """The engine's streams run Philox4x32-7 (RR_PHILOX_ROUNDS): pinned by the Random123 kat_vectors of the 7-round form, and
+    by an independent evaluation of the published round function in plain Python integers."""
+    assert det.det_philox_rounds() == 7
+    out = (C.c_uint32 * 4)()
+    kat = [((0, 0, 0, 0), (0, 0), ["0x5f6fb709", "0xd893f64", "0x4f121f81", "0x4f730a48"]),
+           ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, ["0x5207ddc2", "0x45165e59", "0x4d8ee751", "0x8c52f662"]),
+           ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0), ["0x4dfccaba", "0x190a87f0", "0xc47362ba", "0xb6b5242a"])]
+    for c, k, want in kat:
+        det.det_philox_raw_n(*c, *k, 7, out)
+        assert [hex(v) for v in out] == want
+        det.det_philox_raw_n(*c, *k, 0, out)  # the engine's own form
+        assert [hex(v) for v in out] == want
+
+    def philox_py(c, k, rounds):
+        c, k = list(c), list(k)
+        for _ in range(rounds):
+            p0, p1 = 0xD2511F53 * c[0], 0xCD9E8D57 * c[2]
+            c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xFFFFFFFF, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xFFFFFFFF]
+            k = [(k[0] + 0x9E3779B9) & 0xFFFFFFFF, (k[1] + 0xBB67AE85) & 0xFFFFFFFF]
+        return c
+
+    rng = np.random.default_rng(5)
+    for _ in range(200):
+        c = [int(v) for v in rng.integers(0, 2**32, 4)]
+        k = [int(v) for v in rng.integers(0, 2**32, 2)]
+        for rounds in (7, 10):
+            det.det_philox_raw_n(*c, *k, rounds, out)
+            assert list(out) == philox_py(c, k, rounds)
+
+
+def test_streams_are_uncorrelated_across_index_step_and_stream(det):
+    """Seven rounds leave no safety margin by the authors' own account, and the engine's counters are highly structured
+    (particle index, step, stream in fixed words): a statistical smoke test over exactly those axes -- neighbouring particle
+    indices, consecutive steps, the motion and resample streams of one (index, step), two seeds one bit apart -- on moments,
+    lag correlations and a 2-D equidistribution chi-square of the uniforms."""
+    n = 1 << 18
+    u = {}
+    for name, (seed, stream, step) in {"base": (42, 3, 7), "next_step": (42, 3, 8), "other_stream": (42, 4, 7), "seed_bit": (43, 3, 7)}.items():
+        a, b = np.empty(n), np.empty(n)
+        det.det_uniform2_v(seed, stream, step, 0, n, dp(a), dp(b))
+        u[name] = (a, b)
+    a, b = u["base"]
+    lim = 4.5 / math.sqrt(12 * n) * math.sqrt(12)  # |corr| of n iid pairs: sigma = 1/sqrt(n)
+    for lag in (1, 2, 3, 64, 256, 4096):  # neighbouring / wave-strided / tile-strided particle indices
+        assert abs(np.corrcoef(a[:-lag], a[lag:])[0, 1]) < lim, lag
+        assert abs(np.corrcoef(a[:-lag], b[lag:])[0, 1]) < lim, lag
+    assert abs(np.corrcoef(a, b)[0, 1]) < lim
+    for other in ("next_step", "other_stream", "seed_bit"):
+        for x in u[other]:
+            assert abs(np.corrcoef(a, x)[0, 1]) < lim, other
+            assert not np.array_equal(a, x)
+    # 2-D equidistribution of (u_i, u_{i+1}) on a 32 x 32 grid: chi-square with 1023 degrees of freedom
+    h, _, _ = np.histogram2d(a[:-1], a[1:], bins=32, range=[[0, 1], [0, 1]])
+    chi2 = ((h - (n - 1) / 1024) ** 2 / ((n - 1) / 1024)).sum()
+    assert 1023 - 5 * math.sqrt(2 * 1023) < chi2 < 1023 + 5 * math.sqrt(2 * 1023), chi2
+    # bit balance of the 53-bit mantissa image
+    bits = (a * 2**53).astype(np.uint64)
+    for k in range(0, 53, 4):
+        frac = np.mean((bits >> np.uint64(k)) & np.uint64(1))
+        assert abs(frac - 0.5) < 4.5 * 0.5 / math.sqrt(n), k
 
 
 def test_uniform_and_normal_streams(det):
