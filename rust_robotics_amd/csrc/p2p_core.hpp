@@ -67,12 +67,25 @@ __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t se
     __hip_atomic_store(&out->v[0], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&out->v[1], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(&out->v[2], v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __atomic_thread_fence(__ATOMIC_SEQ_CST);  // system-scope release of the payload (and of every earlier store of this device)
-    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (kind == kP2PDone) {
+      // DONE of the eager / FastSLAM protocols vouches for bulk data written with ORDINARY stores by other workgroups and
+      // earlier kernels: a full system-scope release (L2 write-back) has to come first
+      __atomic_thread_fence(__ATOMIC_SEQ_CST);
+      __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      // WMAX / SUMS carry nothing but their own three words, and those are system-scope (write-through) stores: once they
+      // are acknowledged they are in the peer's memory, and the stamp may follow -- no cache maintenance at all.  (The fence
+      // this replaces wrote the whole L2 back twice per step: ~2 us per exchange at 1e6 particles.)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&out->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     P2PSlot* in = p2p_slot(peers.mbox[peers.rank], kind, g);
     const uint64_t t0 = wall_clock64();  // 100 MHz
     bool ok = true;
-    while (__hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+    // (the payload is read with system-scope loads below, which bypass the caches: no acquire -- no invalidate -- needed
+    // for WMAX / SUMS; the loads are issued after the stamp has been seen, and a wave's loads return in order)
+    while ((kind == kP2PDone ? __hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)
+                             : __hip_atomic_load(&in->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < seq) {
       __builtin_amdgcn_s_sleep(8);
       // a peer is gone: do not hang the device.  The first exchanges of a filter get ten times the
       // budget -- process start-up and code-object loading skew the ranks by far more than a step does
@@ -81,6 +94,7 @@ __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t se
         break;
       }
     }
+    asm volatile("" ::: "memory");
     if (!ok) {
       atomicExch(&s_bad, 1);
     } else {
@@ -347,11 +361,12 @@ __device__ inline double ld_sys(const double* p) {
 // k_p2p_wait_done before an accessor materialises the resampled set.  Nobody waits in between -- a rank that has nothing
 // to receive never looks at the flag, and a slow peer costs the others nothing until its particles are actually read.
 __device__ inline void p2p_send_done(const P2PPeers& peers, uint64_t seq) {
+  // (the deliveries this vouches for are system-scope stores that their workgroups have waited for -- s_waitcnt before the
+  // ticket -- so they are in the owners' memory already: no fence, no cache maintenance)
   const int g = threadIdx.x;
   if (g < peers.n_ranks) {
     P2PSlot* out = p2p_slot(peers.mbox[g], kP2PDone, peers.rank);
-    __atomic_thread_fence(__ATOMIC_SEQ_CST);
-    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -364,7 +379,7 @@ __device__ inline bool p2p_wait_done(const P2PMailbox* own, int n_ranks, uint64_
   if (g < n_ranks && !s_bad) {
     const P2PSlot* in = &own->done[g];
     const uint64_t t0 = wall_clock64();
-    while (__hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+    while (__hip_atomic_load(&in->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
       __builtin_amdgcn_s_sleep(8);
       if (wall_clock64() - t0 > (seq <= 3 ? 10 * timeout_ticks : timeout_ticks)) {
         atomicExch(&s_bad, 1);
@@ -372,10 +387,10 @@ __device__ inline bool p2p_wait_done(const P2PMailbox* own, int n_ranks, uint64_
       }
     }
   }
-  __syncthreads();
+  __syncthreads();  // (the inbox is read with system-scope loads, issued after this barrier: nothing cached can be stale)
   const bool bad = s_bad != 0;
   if (bad && g == 0) *err = 1;
-  __atomic_thread_fence(__ATOMIC_ACQUIRE);  // system scope, every wave: what the peers stored before their DONE is visible from here on
+  asm volatile("" ::: "memory");
   return !bad;
 }
 

@@ -1052,7 +1052,7 @@ __global__ __launch_bounds__(kBlock) void k_push_window(Bufs b, const Ctl* __res
           stored = true;
         }
       }
-      if (stored) __atomic_thread_fence(__ATOMIC_SEQ_CST);  // system scope: in the owner's memory before this workgroup's ticket
+      if (stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (system-scope stores) acknowledged = in the owner's memory, before this workgroup's ticket
     }
   }
   __syncthreads();
@@ -2215,7 +2215,8 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
     if (const char* e = std::getenv("RR_PF_FUSED_PLAN")) {
       if (std::atoi(e) == 0) h->grid_capacity = 0;
     }
-    const size_t rec_bytes = (size_t)(rr::kTileBlock + 1) * rr::kRecWords * sizeof(uint64_t) + rr::kShardHeadWords * sizeof(uint64_t);
+    const size_t rec_bytes = (size_t)(rr::kTileBlock + 1) * rr::kRecWords * sizeof(uint64_t) + 16 * sizeof(uint64_t) +
+                             (size_t)rr::kTileBlock * rr::kTimelineWords * sizeof(uint64_t);  // records, heads, (instrumented build) stamps
     RR_TRY_OR_CLEAN(hipMalloc(&h->grid_rec, rec_bytes));
     RR_TRY_OR_CLEAN(hipMemsetAsync(h->grid_rec, 0, rec_bytes, h->stream));
     RR_TRY_OR_CLEAN(hipMalloc(&h->grid_ticket, rr::kTicketWords * sizeof(unsigned int)));
@@ -2928,6 +2929,18 @@ rr_status rr_pf_plan_stats(rr_pf* h, uint64_t* giveups, int32_t* one_launch_enab
   if (one_launch_enabled) *one_launch_enabled = h->grid_capacity != 0 ? 1 : 0;
   return RR_OK;
 }
+
+#if defined(RR_PLAN_TIMELINE)
+// instrumented build only (tools/plan_timeline.py): the stamps of the last k_quantize_plan_mark launch, n_tiles x kTimelineWords
+rr_status rr_pf_debug_plan_timeline(rr_pf* h, uint64_t* out, size_t cap_words) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  const size_t words = std::min<size_t>(cap_words, (size_t)h->n_tiles * rr::kTimelineWords);
+  RR_HIP_TRY(hipMemcpyAsync(out, h->grid_rec + (rr::kTileBlock + 1) * rr::kRecWords + 16, words * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return RR_OK;
+}
+#endif
 
 rr_status rr_pf_get_counters(rr_pf* h, uint32_t* step, uint32_t* resample_step) {
   if (!h) return fail(RR_INVALID_PARAMETER, "null handle");

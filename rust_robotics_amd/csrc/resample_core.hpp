@@ -739,13 +739,27 @@ __device__ inline void st_dev(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v
 // host sees it at its next read of Ctl and moves the handle to the multi-launch plan for good.  Nothing is reported as an
 // error: the results are those of the undisturbed filter.
 constexpr uint64_t kPlanGiveupTicksDefault = 200000;  // 2 ms
-__device__ inline uint64_t plan_state_decide(uint64_t* state, uint64_t epoch, uint64_t want_bit) {
-  // returns the state of THIS epoch, moving the word there if nobody has yet
+// Instrumented build (make -C csrc timeline: -DRR_PLAN_TIMELINE, a separate .so for tools/plan_timeline.py): thread 0 of
+// every workgroup stamps the 100 MHz wall clock at the kernel's stations into the words behind the records:
+//   0 start, 1 record stored, 2 ticket taken, 3 state word seen / decided, 4 sums read, 5 markers written (6 estimate partial)
+constexpr int kTimelineWords = 8;
+#if defined(RR_PLAN_TIMELINE)
+#define RR_TL(K_) do { if (threadIdx.x == 0) tl[(uint64_t)blockIdx.x * kTimelineWords + (K_)] = wall_clock64(); } while (0)
+#else
+#define RR_TL(K_) do { } while (0)
+#endif
+__device__ inline uint64_t plan_state_decide(uint64_t* state, uint64_t epoch, uint64_t want_bit, bool guess_previous = false) {
+  // returns the state of THIS epoch, moving the word there if nobody has yet.  guess_previous (the last arrival, which is on
+  // everybody's critical path): try the compare-and-swap straight away against what the previous launch most likely left
+  // (RAISED, epoch - 1) instead of loading the word first -- one memory round trip instead of two; a wrong guess costs
+  // nothing but the retry, because the failed swap returns the word.
+  uint64_t seen = guess_previous ? 2 * (epoch - 1) : ld_dev(state);
   for (;;) {
-    const uint64_t seen = ld_dev(state);
     if ((seen >> 1) == epoch) return seen;
     const uint64_t mine = 2 * epoch + want_bit;
-    if (atomicCAS((ull*)state, (ull)seen, (ull)mine) == (ull)seen) return mine;
+    const uint64_t was = (uint64_t)atomicCAS((ull*)state, (ull)seen, (ull)mine);
+    if (was == seen) return mine;
+    seen = was;
   }
 }
 
@@ -849,6 +863,10 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
   __shared__ int s_last;
   __shared__ int s_gaveup;
   const int tid = threadIdx.x;
+#if defined(RR_PLAN_TIMELINE)
+  uint64_t* const tl = rec + (kTileBlock + 1) * kRecWords + 16;  // (behind the records and the heads: sized by the host)
+#endif
+  RR_TL(0);
   // ---- A: the integer image of this tile (quantize_reduce_tile's decisions, tile_scan's blocked layout)
   const double wmax = *wmax_src;
   const bool forced_uniform = a.honour_uniform_flag && ctl->weights_uniform;
@@ -872,8 +890,10 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
       st_dev(&r[1], qq.hi);
       st_dev(&r[2], qq.lo);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged at device scope before the ticket says so
+      RR_TL(1);
       s_last = last_arrival(ticket, blockIdx.x, (unsigned int)n_tiles, /*fence=*/false) ? 1 : 0;
       s_gaveup = 0;
+      RR_TL(2);
     }
   }
   __syncthreads();
@@ -918,7 +938,7 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // every prefix is acknowledged
-    if (tid == 0) s_gaveup = (int)(plan_state_decide(&head[3], epoch, serial_only ? 1 : 0) & 1);
+    if (tid == 0) s_gaveup = (int)(plan_state_decide(&head[3], epoch, serial_only ? 1 : 0, /*guess_previous=*/true) & 1);
   } else if (tid == 0) {
     // ---- everybody else: one thread waits for the state word of this launch
     if (serial_only) {
@@ -937,6 +957,7 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
     }
   }
   __syncthreads();
+  RR_TL(3);
   const bool gaveup = s_gaveup != 0;
   if (gaveup && !last) return;  // record and ticket are in; the last arrival plans this tile as well
   if (tid == 0) {
@@ -947,6 +968,7 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
     s4[3] = ld_dev(&head[2]);
   }
   __syncthreads();
+  RR_TL(4);
   TileSums ts;
   ts.pre = s4[0];
   ts.tot = s4[1];
@@ -993,7 +1015,9 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
       ts.pre = s_tile[0];
     }
     plan_apply_tile<FS_WEIGHTS>(w, a, mode, shift, t, w_in, ts, fire, rho, pa, tile, markers, carry, ea, ef, offspring);
+    RR_TL(5);
     if (want_est) est_tile_partial(ea, t, offspring, fire, j0, a.n, ef, tile);
+    RR_TL(6);
   }
   if (want_est && tid == 0 && (gaveup ? last : blockIdx.x == 0)) est_publish(ctl, denom, pa.rstep);
 }

@@ -707,6 +707,13 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
             else:
                 same = False
                 why = f"rank {rank}: a wait for a peer's flag gave up" + ("" if alive else " on the first exchange")
+            if not same:  # every rank says what it saw (stderr), not only the one whose notes end up in the line
+                detail = why
+                if alive and not p2p.timed_out():
+                    bad = np.nonzero(np.any(got != exp, axis=1))[0]
+                    cols = [int(np.count_nonzero(got[:, k] != exp[:, k])) for k in range(got.shape[1])]
+                    detail += f"; differing rows first {bad[:4].tolist()} last {bad[-4:].tolist()}, per column {cols}"
+                log("VALIDATION MISMATCH: " + detail)
             use_p2p = agree(same)
             log("peer-to-peer transport " + ("validated" if use_p2p else "failed validation"))
             against = f"the {ref_kind} transport" if ref is not None else "the unsharded filter of all particles"

@@ -41,8 +41,13 @@ python tools/summarize_rocprof.py sq "$(find_csv mcl_sq counter_collection)" > "
 run fs1_sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS -- $FS1 --steps 20 --warmup 5
 python tools/summarize_rocprof.py sq "$(find_csv fs1_sq counter_collection)" > "$OUT/${TAG}_fastslam_pmc_sq_summary.csv"
 
-# un-profiled lines of the same build
+# in-kernel timeline of the one-launch resample plan (instrumented build: make -C rust_robotics_amd/csrc timeline)
+if [ -f "$REPO/rust_robotics_amd/librust_robotics_amd_timeline.so" ]; then
+  RR_AMD_LIBRARY="$REPO/rust_robotics_amd/librust_robotics_amd_timeline.so" python tools/plan_timeline.py "$OUT/${TAG}_plan_kernel_timeline.json" > /dev/null 2> "$OUT/plan_timeline.err"
+fi
+# un-profiled lines of the same build: the default line, the driver's own command, the sharded legs at world size 1
 python bench.py > "$OUT/${TAG}_bench_default.json" 2> "$OUT/bench_default.err"
+python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_command.json" 2> "$OUT/bench_driver.err"
 python bench.py --scheme multinomial --no-cpu-baseline --no-extra-legs > "$OUT/${TAG}_mcl_1e6x32_multinomial_bench.json" 2>/dev/null
 python bench.py --workload fastslam2 > "$OUT/${TAG}_fastslam2_1e5x200_bench.json" 2>/dev/null
 rm -rf "$OUT"/raw_*   # the raw traces are large; the summaries above are what gets committed
