@@ -783,6 +783,11 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
         step_fn = pf.step_async_estimate if with_est else pf.step_async
         for t in range(D):  # device warm-up (see DEVICE_WARMUP_MCL), then time moves on
             step_fn(u, obs_list[t])
+            # in blocks with a synchronisation in between, the shape of the timed region: a thousand steps enqueued in one go leave
+            # the host ~40 ms ahead of the device, and one run in five then paid a ~0.45 ms stall of the runtime somewhere in the
+            # 20 steps that follow (measured with the driver's --steps 20: 75 instead of 53 us/step); in blocks: none in 300 blocks
+            if (t + 1) % 50 == 0:
+                pf.synchronize()
         obs_list = obs_list[D:]
         for t in range(W):
             step_fn(u, obs_list[t])
