@@ -154,6 +154,25 @@ impl ParticleFilterLocalizer {
         check(unsafe { sys::rr_pf_step_async_estimate(self.h, control.as_ptr(), flat.as_ptr(), observations.len()) })
     }
 
+    /// Engine extension: `controls.len()` steps in one call (`rr_pf_step_many`); `observations[k]` are the observations of step
+    /// k (the same number every step).  Returns what `try_step` would have returned after each step.  Up to 2048 particles --
+    /// every caller in the reference runs 100 - 1200 -- the whole batch is ONE kernel launch of one workgroup.
+    pub fn try_step_many(&mut self, controls: &[PFControl], observations: &[PFMeasurement]) -> RoboticsResult<Vec<PFState>> {
+        if controls.len() != observations.len() {
+            return Err(RoboticsError::InvalidParameter("one observation list per control".into()));
+        }
+        let n_obs = observations.first().map_or(0, |o| o.len());
+        if observations.iter().any(|o| o.len() != n_obs) {
+            return Err(RoboticsError::InvalidParameter("every step of a batch needs the same number of observations".into()));
+        }
+        let u: Vec<f64> = controls.iter().flat_map(|c| [c[0], c[1]]).collect();
+        let flat: Vec<f64> = observations.iter().flat_map(|o| flatten(o)).collect();
+        let mut out = vec![0.0f64; 4 * controls.len()];
+        check(unsafe { sys::rr_pf_step_many(self.h, u.as_ptr(), flat.as_ptr(), n_obs, controls.len(), out.as_mut_ptr()) })?;
+        self.refresh_cache()?;
+        Ok(out.chunks_exact(4).map(PFState::from_column_slice).collect())
+    }
+
     /// Wait for the stream and read the mean of the last step enqueued with `try_step_async` (300-byte copy).
     pub fn last_step_estimate(&mut self) -> RoboticsResult<PFState> {
         let mut out = [0.0f64; 4];

@@ -96,6 +96,25 @@ class ParticleFilterLocalizer {
     check(rr_pf_step(h_, u.data(), flat.data(), obs.size(), out.data()));
     return out;
   }
+  // engine extension: controls.size() steps in one call (rr_pf_step_many; up to 2048 particles: ONE kernel launch for all of
+  // them); obs[k] = the observations of step k, the same number every step; returns what try_step returns after each step
+  std::vector<PFState> try_step_many(const std::vector<PFControl>& controls, const std::vector<PFMeasurement>& obs) {
+    if (controls.size() != obs.size()) throw RoboticsError(RoboticsError::InvalidParameter, "one observation list per control");
+    const size_t n_obs = obs.empty() ? 0 : obs[0].size();
+    std::vector<double> u, flat;
+    for (size_t k = 0; k < controls.size(); ++k) {
+      if (obs[k].size() != n_obs) throw RoboticsError(RoboticsError::InvalidParameter, "every step of a batch needs the same number of observations");
+      u.push_back(controls[k][0]);
+      u.push_back(controls[k][1]);
+      const std::vector<double> f = flatten(obs[k]);
+      flat.insert(flat.end(), f.begin(), f.end());
+    }
+    std::vector<double> out(4 * controls.size());
+    check(rr_pf_step_many(h_, u.data(), flat.data(), n_obs, controls.size(), out.data()));
+    std::vector<PFState> r(controls.size());
+    for (size_t k = 0; k < controls.size(); ++k) r[k] = {out[4 * k], out[4 * k + 1], out[4 * k + 2], out[4 * k + 3]};
+    return r;
+  }
   State2D try_step_state(const ControlInput& c, const PFMeasurement& obs) {
     PFState e = try_step({c.v, c.omega}, obs);
     return {e[0], e[1], e[2], e[3]};

@@ -98,6 +98,31 @@ int main() {
     REQUIRE(amcl.particle_count() >= 200 && amcl.particle_count() <= 3000);  // :518-545
   }
 
+  // ---- the reference's own sizes (150 particles, render_gif_particle_filter.rs:77-79): a batch of steps in one launch must
+  // return exactly what single synchronous steps return
+  {
+    rr::ParticleFilterConfig sc;
+    sc.n_particles = 150;
+    sc.range_noise = 0.5;
+    rr::ParticleFilterLocalizer a(sc, 11), b(sc, 11);
+    std::vector<rr::PFControl> us;
+    std::vector<rr::PFMeasurement> zs;
+    double tr[3] = {0, 0, 0};
+    for (int t = 0; t < 30; ++t) {
+      tr[0] += std::cos(tr[2]) * sc.dt;
+      tr[1] += std::sin(tr[2]) * sc.dt;
+      tr[2] += 0.1 * sc.dt;
+      us.push_back({1.0, 0.1});
+      zs.push_back(observe(tr, rng, 0.5));
+    }
+    const std::vector<rr::PFState> many = a.try_step_many(us, zs);
+    REQUIRE(many.size() == 30);
+    for (int t = 0; t < 30; ++t) {
+      const rr::PFState one = b.try_step(us[t], zs[t]);
+      for (int k = 0; k < 4; ++k) REQUIRE(many[t][k] == one[k]);
+    }
+  }
+
   // ---- fastslam1 / fastslam2
   rr::fastslam1::Params prm;
   prm.first_obs_cov = 10.0;
