@@ -163,6 +163,56 @@ static __global__ __launch_bounds__(kScanThreads) void k_scan_exchange(P2PPeers 
   p2p_exchange(peers, kP2PSums, seq, s_pay[0], s_pay[1], s_pay[2], gathered, ctl, &ctl->wmax, pa, err);
 }
 
+// Inbox traffic goes around every cache: system-scope (sc0 sc1) stores on the delivering side, system-scope loads on the
+// reading side.  The reader consumes a delivery INSIDE a kernel (after an in-kernel wait for DONE), not behind a kernel
+// boundary, so nothing may depend on which lines an L2 -- eight of them per device, one per XCD -- still holds from the
+// step before or on how a peer's mapping of the buffer is cached.  Only the slots that cross a shard boundary take this
+// path (10^3 - 10^4 of 10^6 in steady state).
+__device__ inline void st_sys(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<uint64_t*>(p), (uint64_t)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline double ld_sys(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+// A delivered slot vouches for itself: the inbox has a fifth plane of TAGS, and the deliverer writes the step's sequence number
+// there AFTER the slot's four fields have been acknowledged.  The reader of a slot polls that one word (bounded) and then reads
+// the fields -- no DONE message, no election of a last workgroup to send it, nobody waits who has nothing to receive.
+__device__ inline void inbox_tag(double* inbox, uint64_t n_local, uint64_t li, uint64_t seq) {
+  __hip_atomic_store(reinterpret_cast<uint64_t*>(inbox + 4 * n_local + li), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// false (and *err latched) if the slot's delivery of step `seq` does not show up in time
+__device__ inline bool inbox_await(const double* inbox, uint64_t n_local, uint64_t li, uint64_t seq, uint64_t timeout_ticks, int* __restrict__ err) {
+  const uint64_t* tag = reinterpret_cast<const uint64_t*>(inbox + 4 * n_local + li);
+  if (__hip_atomic_load(tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == seq) return true;
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;  // the filter is broken already: do not wait again
+  const uint64_t t0 = wall_clock64();
+  while (__hip_atomic_load(tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+    __builtin_amdgcn_s_sleep(8);
+    if (wall_clock64() - t0 > (seq <= 3 ? 10 * timeout_ticks : timeout_ticks)) {
+      *err = 1;
+      return false;
+    }
+  }
+  asm volatile("" ::: "memory");
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// DONE: "every particle this rank had to deliver into a peer's inbox has landed".  Sent by the last workgroup of
+// k_push_window (one thread per peer, system-scope release after the workgroups' own system-scope fences) and awaited
+// only by those who need it: a workgroup of the next step's k_step_lazy whose tile holds a slot that a peer served, or
+// k_p2p_wait_done before an accessor materialises the resampled set.  Nobody waits in between -- a rank that has nothing
+// to receive never looks at the flag, and a slow peer costs the others nothing until its particles are actually read.
+__device__ inline void p2p_send_done(const P2PPeers& peers, uint64_t seq) {
+  // (the deliveries this vouches for are system-scope stores that their workgroups have waited for -- s_waitcnt before the
+  // ticket -- so they are in the owners' memory already: no fence, no cache maintenance)
+  const int g = threadIdx.x;
+  if (g < peers.n_ranks) {
+    P2PSlot* out = p2p_slot(peers.mbox[g], kP2PDone, peers.rank);
+    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // The plan of a sharded systematic step in ONE launch: WMAX exchange, integer image, SUMS exchange and the marking of
 // this shard's sources -- k_p2p_exchange + k_quantize_reduce + k_scan_exchange + k_mark, four launches whose ~6 us
@@ -177,6 +227,13 @@ static __global__ __launch_bounds__(kScanThreads) void k_scan_exchange(P2PPeers 
 // All workgroups must be resident at once (host: n_tiles <= grid capacity).  A local wait is bounded by twelve peer
 // time-outs (the first exchanges of a filter are allowed ten); giving up sets *err like a peer time-out does.
 constexpr int kShardHeadWords = 8;
+// what k_shard_plan_mark needs to deliver the window's overhang itself (enable == 0: markers for all served positions,
+// k_push_window follows)
+struct ShardPush {
+  const double* f[2][4];  // x, y, yaw, v of both buffer sets
+  unsigned int* ticket;   // kTicketWords arrival counters of the DONE election (zero between launches)
+  int enable;
+};
 __device__ inline bool wait_flag(const uint64_t* flag, uint64_t epoch, uint64_t limit_ticks) {
   const uint64_t t0 = wall_clock64();
   while (ld_dev(flag) != epoch) {
@@ -191,7 +248,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
     P2PPeers peers, uint64_t seq, const double* __restrict__ w, Ctl* __restrict__ ctl, ImageArgs a, uint64_t* __restrict__ rec,
     unsigned int* __restrict__ ticket, uint64_t epoch, int settle, uint64_t n_tiles, PlanArgs pa,
     unsigned int* __restrict__ markers, unsigned int* __restrict__ carry, uint64_t* __restrict__ gathered,
-    int* __restrict__ err, uint64_t slot_pad) {
+    int* __restrict__ err, uint64_t slot_pad, ShardPush push) {
   constexpr int W = kTileBlock / kWave;
   __shared__ uint64_t s4[4 * W];
   __shared__ uint64_t s_w[W];
@@ -204,6 +261,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
   const uint64_t limit = 12 * peers.timeout_ticks;
   // reads of Ctl that the last arrival's settle / finalize could race with come first (they precede this workgroup's ticket)
   const bool forced_uniform = a.honour_uniform_flag && ctl->weights_uniform;
+  const int push_cur = (settle && ctl->pending) ? ctl->cur ^ 1 : ctl->cur;  // the live set once this launch has settled Ctl.cur
   // ---- 0: the global maximum
   if (blockIdx.x == 0) {
     const uint64_t local_bits = ctl->wmax_bits;
@@ -330,43 +388,76 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
   }
   __syncthreads();
   const uint64_t pre = s4[0], base = s4[1], total = s4[2];
-  if (!s4[3]) return;  // gate shut (or a peer timed out)
-  // ---- B: k_mark
-  double rho = pa.rho_override;
-  if (rho != rho) {
-    double dummy;
-    rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
-  }
-  const rr_sys_plan plan = rr_sys_plan_make(rho, total, pa.n_global);
-  // marker position of global slot s: s + slot_pad (resolve_tile_window)
-  mark_sources(t, base + pre + t.thread_off, i0, a.n, plan, total, (uint64_t)0 - slot_pad, markers, carry);
-}
-
-// Inbox traffic goes around every cache: system-scope (sc0 sc1) stores on the delivering side, system-scope loads on the
-// reading side.  The reader consumes a delivery INSIDE a kernel (after an in-kernel wait for DONE), not behind a kernel
-// boundary, so nothing may depend on which lines an L2 -- eight of them per device, one per XCD -- still holds from the
-// step before or on how a peer's mapping of the buffer is cached.  Only the slots that cross a shard boundary take this
-// path (10^3 - 10^4 of 10^6 in steady state).
-__device__ inline void st_sys(double* p, double v) {
-  __hip_atomic_store(reinterpret_cast<uint64_t*>(p), (uint64_t)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ inline double ld_sys(const double* p) {
-  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
-}
-
-// ------------------------------------------------------------------------------------------
-// DONE: "every particle this rank had to deliver into a peer's inbox has landed".  Sent by the last workgroup of
-// k_push_window (one thread per peer, system-scope release after the workgroups' own system-scope fences) and awaited
-// only by those who need it: a workgroup of the next step's k_step_lazy whose tile holds a slot that a peer served, or
-// k_p2p_wait_done before an accessor materialises the resampled set.  Nobody waits in between -- a rank that has nothing
-// to receive never looks at the flag, and a slow peer costs the others nothing until its particles are actually read.
-__device__ inline void p2p_send_done(const P2PPeers& peers, uint64_t seq) {
-  // (the deliveries this vouches for are system-scope stores that their workgroups have waited for -- s_waitcnt before the
-  // ticket -- so they are in the owners' memory already: no fence, no cache maintenance)
-  const int g = threadIdx.x;
-  if (g < peers.n_ranks) {
-    P2PSlot* out = p2p_slot(peers.mbox[g], kP2PDone, peers.rank);
-    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const bool fired = s4[3] != 0;
+  if (fired) {
+    // ---- B: k_mark
+    double rho = pa.rho_override;
+    if (rho != rho) {
+      double dummy;
+      rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
+    }
+    const rr_sys_plan plan = rr_sys_plan_make(rho, total, pa.n_global);
+    // marker position of global slot s: s + slot_pad (resolve_tile_window)
+    if (!push.enable) {
+      mark_sources(t, base + pre + t.thread_off, i0, a.n, plan, total, (uint64_t)0 - slot_pad, markers, carry);
+    } else {
+      // ---- C: the overhang, delivered from the SOURCE side.  A source knows the position run [lo, hi) it feeds; whatever
+      // of it lies outside this shard's own block belongs to a peer, and the particle goes straight into that peer's
+      // inbox (fields, then the slot's tag) -- no markers for those positions (nobody would consume them), no resolve pass, no
+      // extra launch, no DONE message.  The runs
+      // with a foreign part (a handful per shard in steady state) are collected in LDS and the workgroup's threads share
+      // their slots, so one heavy particle that feeds a whole neighbouring block is 512 lanes' work, not one's.
+      __shared__ unsigned int s_cnt;
+      __shared__ unsigned int s_rsrc[kTile], s_rlo[kTile], s_rhi[kTile];
+      const uint64_t own0 = a.gid0 + slot_pad, own1 = own0 + a.n;
+      SlotRun runs[kItems];
+      if (tid == 0) s_cnt = 0;
+      __syncthreads();
+      mark_sources(t, base + pre + t.thread_off, i0, a.n, plan, total, (uint64_t)0 - slot_pad, markers, carry, nullptr, runs, own0, own1);
+#pragma unroll
+      for (int j = 0; j < kItems; ++j) {
+        if (runs[j].hi > runs[j].lo && (runs[j].lo < own0 || runs[j].hi > own1)) {
+          const unsigned int k = atomicAdd(&s_cnt, 1u);
+          s_rsrc[k] = (unsigned int)(i0 + j);
+          s_rlo[k] = (unsigned int)runs[j].lo;
+          s_rhi[k] = (unsigned int)runs[j].hi;
+        }
+      }
+      __syncthreads();
+      const unsigned int n_runs = s_cnt;
+      // two passes over this thread's share of the foreign slots: the fields, one wait for their acknowledgement, the tags
+      for (int pass = 0; pass < 2; ++pass) {
+        bool stored = false;
+        for (unsigned int r = 0; r < n_runs; ++r) {
+          const uint64_t src = s_rsrc[r], lo = s_rlo[r], hi = s_rhi[r];
+          double px = 0.0, py = 0.0, pyaw = 0.0, pv = 0.0;
+          if (pass == 0) {
+            px = push.f[push_cur][0][src];
+            py = push.f[push_cur][1][src];
+            pyaw = push.f[push_cur][2][src];
+            pv = push.f[push_cur][3][src];
+          }
+          for (int part = 0; part < 2; ++part) {  // the part below the own block, then the part above it
+            const uint64_t plo = part == 0 ? lo : (lo > own1 ? lo : own1), phi = part == 0 ? (hi < own0 ? hi : own0) : hi;
+            for (uint64_t pos = plo + tid; pos < phi; pos += kTileBlock) {
+              const uint64_t slot = pos - slot_pad;
+              const uint64_t d = slot / a.n, li = slot - d * a.n;
+              double* __restrict__ out = peers.inbox[d];  // fine-grained, [4 fields + tag][n_local]
+              if (pass == 0) {
+                st_sys(out + li, px);
+                st_sys(out + a.n + li, py);
+                st_sys(out + 2 * a.n + li, pyaw);
+                st_sys(out + 3 * a.n + li, pv);
+                stored = true;
+              } else {
+                inbox_tag(out, a.n, li, seq);
+              }
+            }
+          }
+        }
+        if (pass == 0 && stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (system-scope stores) acknowledged = in the owner's memory
+      }
+    }
   }
 }
 
@@ -443,6 +534,7 @@ struct P2PState {
   rr_status reset_records() {
     RR_HIP_TRY(hipMemset(mbox, 0, sizeof(P2PMailbox)));
     RR_HIP_TRY(hipMemset(err, 0, sizeof(int)));
+    RR_HIP_TRY(hipMemset(inbox, 0, inbox_doubles * sizeof(double)));  // (the tag plane: sequence numbers start over)
     RR_HIP_TRY(hipDeviceSynchronize());
     seq = 0;
     return RR_OK;
@@ -452,6 +544,7 @@ struct P2PState {
     if (mbox) return RR_OK;
     inbox_doubles = inbox_doubles_;
     RR_HIP_TRY(hipExtMallocWithFlags((void**)&inbox, inbox_doubles * sizeof(double), hipDeviceMallocFinegrained));
+    RR_HIP_TRY(hipMemset(inbox, 0, inbox_doubles * sizeof(double)));  // the engines' tag planes must not hold an earlier filter's stamps
     RR_HIP_TRY(hipExtMallocWithFlags((void**)&mbox, sizeof(P2PMailbox), hipDeviceMallocFinegrained));
     RR_HIP_TRY(hipMemset(mbox, 0, sizeof(P2PMailbox)));
     RR_HIP_TRY(hipMalloc(&scratch, (3 * kMaxP2P + 4) * sizeof(uint64_t)));

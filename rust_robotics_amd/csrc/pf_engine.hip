@@ -279,9 +279,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
       pos0 = own0 + tile_base;
       rr::resolve_tile_window(markers, carry, own0 / rr::kResolveSlots + tile, win_lo, win_hi, own0, own0 + p.n, idx);
       const uint64_t pos1 = pos0 + rr::kResolveSlots < own0 + p.n ? pos0 + rr::kResolveSlots : own0 + p.n;
-      // (uniform) a peer serves some slot of this tile: its delivery must have landed.  (n_ranks == 0: the RCCL transport --
-      // the inbox was filled by an earlier kernel of this stream.)
-      if (wa.n_ranks > 0 && (pos0 < win_lo || pos1 > win_hi)) (void)rr::p2p_wait_done(wa.mbox, wa.n_ranks, wa.wait_seq, wa.timeout_ticks, wa.err);
+      (void)pos1;  // (a slot a peer serves waits for its own delivery below: the tag plane of the inbox)
     } else if (pending) {
       rr::resolve_tile(markers, carry, p.n, tile, idx);
     } else {
@@ -297,7 +295,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
       if (k < p.n) {
         const uint64_t j = idx[r];
         if (SRC == kSrcWindow && pending && (pos0 + (uint64_t)r * kBlock + tid < win_lo || pos0 + (uint64_t)r * kBlock + tid >= win_hi)) {
-          x[r] = rr::ld_sys(wa.inbox + k);  // delivered by a peer into this rank's inbox [field][n]
+          // delivered by a peer into this rank's inbox [4 fields + tag][n]: wait (bounded) for THIS slot's tag of the step
+          // whose resample is being consumed, then read its fields.  (n_ranks == 0: the RCCL transport -- an earlier kernel
+          // of this stream filled the inbox.)
+          if (wa.n_ranks > 0) (void)rr::inbox_await(wa.inbox, p.n, k, wa.wait_seq, wa.timeout_ticks, wa.err);
+          x[r] = rr::ld_sys(wa.inbox + k);
           y[r] = rr::ld_sys(wa.inbox + p.n + k);
           yaw[r] = rr::ld_sys(wa.inbox + 2 * p.n + k);
         } else if (PACKED && pending) {
@@ -1012,55 +1014,56 @@ __global__ __launch_bounds__(kBlock) void k_resolve_gather_p2p(Bufs b, const Ctl
 // sources feed, [served_first, +served_count) + pad, sticks out of its own block [own0, own0 + n) on either side by the
 // drift of the cumulative weight across the block boundaries (10^3 - 10^4 slots of 10^6 in steady state, everything in
 // the worst case): those positions are resolved here, tile by tile (grid-stride over the foreign tiles only), and each
-// particle is stored into the owning rank's fine-grained inbox.  Own positions are left to the next step's k_step_lazy.
-// The last workgroup to finish -- every workgroup's stores system-scope-released before its ticket -- sends DONE.
+// particle is stored into the owning rank's fine-grained inbox, fields first, then -- once those are acknowledged -- the slot's
+// tag (rr::inbox_tag).  Own positions are left to the next step's k_step_lazy.  (Shards of <= 2^20 particles deliver their
+// overhang from inside k_shard_plan_mark and never launch this kernel.)
 __global__ __launch_bounds__(kBlock) void k_push_window(Bufs b, const Ctl* __restrict__ ctl,
                                                        unsigned int* __restrict__ markers,
                                                        const unsigned int* __restrict__ carry, P2PPeers peers,
-                                                       uint64_t n_local, uint64_t pad, unsigned int* __restrict__ ticket,
-                                                       uint64_t seq) {
-  __shared__ int s_last;
-  if (ctl->fired) {
-    const uint64_t own0 = (uint64_t)peers.rank * n_local + pad, own1 = own0 + n_local;
-    const uint64_t win_lo = ctl->served_first + pad, win_hi = win_lo + ctl->served_count;
-    const int src = ctl->cur;  // lazy: Ctl.cur flips when the next step settles
-    // foreign positions: left of the own block [l_lo, l_hi), right of it [r_lo, r_hi)
-    const uint64_t S = rr::kResolveSlots;
-    const uint64_t l_lo = win_lo, l_hi = own0 < win_hi ? own0 : win_hi;
-    const uint64_t r_lo = own1 > win_lo ? own1 : win_lo, r_hi = win_hi;
-    const uint64_t lt0 = l_lo / S, n_left = l_lo < l_hi ? (l_hi + S - 1) / S - lt0 : 0;
-    const uint64_t rt0 = r_lo / S, n_right = r_lo < r_hi ? (r_hi + S - 1) / S - rt0 : 0;
-    const uint64_t n_tiles = n_left + n_right;
-    for (uint64_t q = blockIdx.x; q < n_tiles; q += gridDim.x) {
-      const uint64_t tile = q < n_left ? lt0 + q : rt0 + (q - n_left);
-      const uint64_t lo = q < n_left ? l_lo : r_lo, hi = q < n_left ? l_hi : r_hi;  // positions this kernel consumes
-      unsigned int idx[rr::kResolveRows];
-      rr::resolve_tile_window(markers, carry, tile, win_lo, win_hi, lo, hi, idx);
-      bool stored = false;
+                                                       uint64_t n_local, uint64_t pad, uint64_t seq) {
+  if (!ctl->fired) return;
+  const uint64_t own0 = (uint64_t)peers.rank * n_local + pad, own1 = own0 + n_local;
+  const uint64_t win_lo = ctl->served_first + pad, win_hi = win_lo + ctl->served_count;
+  const int src = ctl->cur;  // lazy: Ctl.cur flips when the next step settles
+  // foreign positions: left of the own block [l_lo, l_hi), right of it [r_lo, r_hi)
+  const uint64_t S = rr::kResolveSlots;
+  const uint64_t l_lo = win_lo, l_hi = own0 < win_hi ? own0 : win_hi;
+  const uint64_t r_lo = own1 > win_lo ? own1 : win_lo, r_hi = win_hi;
+  const uint64_t lt0 = l_lo / S, n_left = l_lo < l_hi ? (l_hi + S - 1) / S - lt0 : 0;
+  const uint64_t rt0 = r_lo / S, n_right = r_lo < r_hi ? (r_hi + S - 1) / S - rt0 : 0;
+  const uint64_t n_tiles = n_left + n_right;
+  for (uint64_t q = blockIdx.x; q < n_tiles; q += gridDim.x) {
+    const uint64_t tile = q < n_left ? lt0 + q : rt0 + (q - n_left);
+    const uint64_t lo = q < n_left ? l_lo : r_lo, hi = q < n_left ? l_hi : r_hi;  // positions this kernel consumes
+    unsigned int idx[rr::kResolveRows];
+    rr::resolve_tile_window(markers, carry, tile, win_lo, win_hi, lo, hi, idx);
+    bool stored = false;
 #pragma unroll
-      for (int r = 0; r < rr::kResolveRows; ++r) {
-        const uint64_t pos = tile * S + (uint64_t)r * kBlock + threadIdx.x;
-        if (pos >= lo && pos < hi) {
-          const uint64_t s = pos - pad;  // global slot
-          const uint64_t d = s / n_local, li = s - d * n_local;
-          const uint64_t j = idx[r];
-          double* __restrict__ out = peers.inbox[d];  // fine-grained, [field][n_local]
-          rr::st_sys(out + li, b.x[src][j]);
-          rr::st_sys(out + n_local + li, b.y[src][j]);
-          rr::st_sys(out + 2 * n_local + li, b.yaw[src][j]);
-          rr::st_sys(out + 3 * n_local + li, b.v[src][j]);
-          stored = true;
-        }
+    for (int r = 0; r < rr::kResolveRows; ++r) {
+      const uint64_t pos = tile * S + (uint64_t)r * kBlock + threadIdx.x;
+      if (pos >= lo && pos < hi) {
+        const uint64_t s = pos - pad;  // global slot
+        const uint64_t d = s / n_local, li = s - d * n_local;
+        const uint64_t j = idx[r];
+        double* __restrict__ out = peers.inbox[d];  // fine-grained, [4 fields + tag][n_local]
+        rr::st_sys(out + li, b.x[src][j]);
+        rr::st_sys(out + n_local + li, b.y[src][j]);
+        rr::st_sys(out + 2 * n_local + li, b.yaw[src][j]);
+        rr::st_sys(out + 3 * n_local + li, b.v[src][j]);
+        stored = true;
       }
-      if (stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (system-scope stores) acknowledged = in the owner's memory, before this workgroup's ticket
+    }
+    if (stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (system-scope stores) acknowledged = in the owner's memory ...
+#pragma unroll
+    for (int r = 0; r < rr::kResolveRows; ++r) {  // ... then each slot's tag says so
+      const uint64_t pos = tile * S + (uint64_t)r * kBlock + threadIdx.x;
+      if (pos >= lo && pos < hi) {
+        const uint64_t s = pos - pad;
+        const uint64_t d = s / n_local;
+        rr::inbox_tag(peers.inbox[d], n_local, s - d * n_local, seq);
+      }
     }
   }
-  __syncthreads();
-  if (threadIdx.x == 0) s_last = rr::last_arrival(ticket, blockIdx.x, gridDim.x) ? 1 : 0;
-  __syncthreads();
-  if (!s_last) return;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  rr::p2p_send_done(peers, seq);
 }
 
 // RCCL transport, the same overhang into a SEND BUFFER instead of the peers' inboxes: record q (x, y, yaw, v) is the q-th
@@ -1120,13 +1123,14 @@ __global__ __launch_bounds__(kBlock) void k_unpack_inbox(const double* __restric
 }
 
 // accessors: make a pending window resample real -- own slots inside the window through the markers, the others out of
-// the inbox (k_p2p_wait_done has run); k_settle flips the live set afterwards
+// the inbox (peer-to-peer transport: each after its own tag has arrived); k_settle flips the live set afterwards
 __global__ __launch_bounds__(kBlock) void k_resolve_gather_window(Bufs b, const Ctl* __restrict__ ctl,
                                                                  unsigned int* __restrict__ markers,
                                                                  const unsigned int* __restrict__ carry, uint64_t n,
                                                                  uint64_t first_gid, uint64_t pad,
                                                                  const double* __restrict__ inbox,
-                                                                 unsigned int* __restrict__ idx_out) {
+                                                                 unsigned int* __restrict__ idx_out, uint64_t wait_seq,
+                                                                 uint64_t timeout_ticks, int* __restrict__ err) {
   if (!ctl->pending) return;
   const uint64_t own0 = first_gid + pad;
   const uint64_t win_lo = ctl->served_first + pad, win_hi = win_lo + ctl->served_count;
@@ -1139,6 +1143,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_gather_window(Bufs b, const 
     if (k >= n) continue;
     const uint64_t pos = own0 + k;
     if (pos < win_lo || pos >= win_hi) {
+      if (wait_seq) (void)rr::inbox_await(inbox, n, k, wait_seq, timeout_ticks, err);
       b.x[dst][k] = rr::ld_sys(inbox + k);
       b.y[dst][k] = rr::ld_sys(inbox + n + k);
       b.yaw[dst][k] = rr::ld_sys(inbox + 2 * n + k);
@@ -1745,12 +1750,10 @@ rr_status materialise(rr_pf* h) {
   if (h->pending_kind == kSrcWindow) {  // a shard: the peers' deliveries of the last step must have landed first
     Timed t(h, RR_K_RESAMPLE_GATHER);
     const bool via_p2p = !h->window_rccl;  // (RCCL transport: the inbox was filled in stream order, nothing to wait for)
-    if (via_p2p)
-      hipLaunchKernelGGL(rr::k_p2p_wait_done, dim3(1), dim3(64), 0, h->stream, (const rr::P2PMailbox*)h->p2p.mbox, h->p2p.peers.n_ranks,
-                         h->window_seq, h->p2p.peers.timeout_ticks, h->p2p.err);
     hipLaunchKernelGGL(k_resolve_gather_window, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b, h->ctl,
                        h->markers, h->carry, h->n, h->opt.first_global_index, h->slot_pad,
-                       (const double*)(via_p2p ? h->p2p.inbox : h->rccl_inbox), h->idx);
+                       (const double*)(via_p2p ? h->p2p.inbox : h->rccl_inbox), h->idx, via_p2p ? h->window_seq : (uint64_t)0,
+                       via_p2p ? h->p2p.peers.timeout_ticks : (uint64_t)0, via_p2p ? h->p2p.err : (int*)nullptr);
     hipLaunchKernelGGL(k_settle, dim3(1), dim3(1), 0, h->stream, h->ctl);
     RR_HIP_TRY(hipGetLastError());
     h->maybe_pending = false;
@@ -3200,7 +3203,7 @@ rr_status rr_pf_p2p_export(rr_pf* h, uint8_t out[RR_P2P_HANDLE_BYTES]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!out) return fail(RR_INVALID_PARAMETER, "null output");
-  return h->p2p.export_handles(h->slab, 4 * h->n, out);
+  return h->p2p.export_handles(h->slab, 5 * h->n, out);  // inbox: 4 fields + the tag plane
 }
 
 rr_status rr_pf_p2p_connect(rr_pf* h, const uint8_t* all_handles, int32_t n_ranks, int32_t rank) {
@@ -3209,7 +3212,7 @@ rr_status rr_pf_p2p_connect(rr_pf* h, const uint8_t* all_handles, int32_t n_rank
   if (!all_handles) return fail(RR_INVALID_PARAMETER, "null handles");
   if ((s = p2p_check_geometry(h, n_ranks, rank)) != RR_OK) return s;
   if ((s = p2p_alloc_lidx(h)) != RR_OK) return s;
-  return h->p2p.connect_ipc(h->slab, 4 * h->n, all_handles, n_ranks, rank);
+  return h->p2p.connect_ipc(h->slab, 5 * h->n, all_handles, n_ranks, rank);
 }
 
 rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
@@ -3226,7 +3229,7 @@ rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
     if ((s = p2p_alloc_lidx(handles[g])) != RR_OK) return s;
     st[g] = &handles[g]->p2p;
     slabs[g] = handles[g]->slab;
-    inboxes[g] = 4 * handles[g]->n;
+    inboxes[g] = 5 * handles[g]->n;
     devs[g] = handles[g]->opt.device;
   }
   return rr::p2p_link_local(st, slabs, inboxes, devs, n_ranks);
@@ -3288,12 +3291,24 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
     RR_HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
     h->shard_capacity = h->grid_capacity ? std::min<uint64_t>((uint64_t)per_cu * (uint64_t)dev_cus, (uint64_t)rr::kTileBlock) : 0;
   }
+  bool pushed = false;
   if (h->n_tiles <= h->shard_capacity && rr::spin_permit(h->opt.device, h)) {
-    // exchange 1 + B + exchange 2 + C in one launch (k_shard_plan_mark)
+    // exchange 1 + B + exchange 2 + C + the overhang's delivery + DONE in one launch (k_shard_plan_mark)
     Timed t(h, RR_K_CDF);
+    static const bool push_inside = [] { const char* e = std::getenv("RR_P2P_PUSH_IN_PLAN"); return !e || std::atoi(e) != 0; }();
+    rr::ShardPush sp{};
+    for (int k = 0; k < 2; ++k) {
+      sp.f[k][0] = h->b.x[k];
+      sp.f[k][1] = h->b.y[k];
+      sp.f[k][2] = h->b.yaw[k];
+      sp.f[k][3] = h->b.v[k];
+    }
+    sp.ticket = h->push_ticket;
+    sp.enable = push_inside ? 1 : 0;
+    pushed = push_inside;
     hipLaunchKernelGGL(rr::k_shard_plan_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->p2p.peers, seq,
                        (const double*)h->w, h->ctl, image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, /*settle=*/1,
-                       h->n_tiles, pa, h->markers, h->carry, gathered, h->p2p.err, h->slot_pad);
+                       h->n_tiles, pa, h->markers, h->carry, gathered, h->p2p.err, h->slot_pad, sp);
   } else {
     // exchange 1: global maximum -> Ctl.wmax
     hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PWmax, seq,
@@ -3316,11 +3331,12 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   h->wmax_live = false;
   h->wmax_bits_clean = true;
   h->rstep += 1;
-  // D: the overhang of the served window goes to its owners; the last workgroup sends DONE (k_push_window)
-  {
+  // D: the overhang of the served window goes to its owners; the last workgroup sends DONE (k_push_window) -- unless the plan
+  // kernel has done both already
+  if (!pushed) {
     Timed t(h, RR_K_RESAMPLE_GATHER);
     hipLaunchKernelGGL(k_push_window, dim3(kPushGrid), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->markers, h->carry, h->p2p.peers,
-                       h->n, h->slot_pad, h->push_ticket, seq);
+                       h->n, h->slot_pad, seq);
   }
   RR_HIP_TRY(hipGetLastError());
   h->maybe_pending = true;
