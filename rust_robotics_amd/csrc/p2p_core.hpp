@@ -198,22 +198,6 @@ __device__ inline bool inbox_await(const double* inbox, uint64_t n_local, uint64
 }
 
 // ------------------------------------------------------------------------------------------
-// DONE: "every particle this rank had to deliver into a peer's inbox has landed".  Sent by the last workgroup of
-// k_push_window (one thread per peer, system-scope release after the workgroups' own system-scope fences) and awaited
-// only by those who need it: a workgroup of the next step's k_step_lazy whose tile holds a slot that a peer served, or
-// k_p2p_wait_done before an accessor materialises the resampled set.  Nobody waits in between -- a rank that has nothing
-// to receive never looks at the flag, and a slow peer costs the others nothing until its particles are actually read.
-__device__ inline void p2p_send_done(const P2PPeers& peers, uint64_t seq) {
-  // (the deliveries this vouches for are system-scope stores that their workgroups have waited for -- s_waitcnt before the
-  // ticket -- so they are in the owners' memory already: no fence, no cache maintenance)
-  const int g = threadIdx.x;
-  if (g < peers.n_ranks) {
-    P2PSlot* out = p2p_slot(peers.mbox[g], kP2PDone, peers.rank);
-    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-}
-
-// ------------------------------------------------------------------------------------------
 // The plan of a sharded systematic step in ONE launch: WMAX exchange, integer image, SUMS exchange and the marking of
 // this shard's sources -- k_p2p_exchange + k_quantize_reduce + k_scan_exchange + k_mark, four launches whose ~6 us
 // boundaries (resample_core.hpp, k_quantize_plan_mark) cost more than their work.  Same in-kernel hand-over as
@@ -231,7 +215,6 @@ constexpr int kShardHeadWords = 8;
 // k_push_window follows)
 struct ShardPush {
   const double* f[2][4];  // x, y, yaw, v of both buffer sets
-  unsigned int* ticket;   // kTicketWords arrival counters of the DONE election (zero between launches)
   int enable;
 };
 __device__ inline bool wait_flag(const uint64_t* flag, uint64_t epoch, uint64_t limit_ticks) {
@@ -459,34 +442,6 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
       }
     }
   }
-}
-
-// block-uniform; returns false (and latches *err) when a peer's DONE does not arrive in time
-__device__ inline bool p2p_wait_done(const P2PMailbox* own, int n_ranks, uint64_t seq, uint64_t timeout_ticks, int* __restrict__ err) {
-  __shared__ int s_bad;
-  const int g = threadIdx.x;
-  if (g == 0) s_bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (g < n_ranks && !s_bad) {
-    const P2PSlot* in = &own->done[g];
-    const uint64_t t0 = wall_clock64();
-    while (__hip_atomic_load(&in->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-      __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > (seq <= 3 ? 10 * timeout_ticks : timeout_ticks)) {
-        atomicExch(&s_bad, 1);
-        break;
-      }
-    }
-  }
-  __syncthreads();  // (the inbox is read with system-scope loads, issued after this barrier: nothing cached can be stale)
-  const bool bad = s_bad != 0;
-  if (bad && g == 0) *err = 1;
-  asm volatile("" ::: "memory");
-  return !bad;
-}
-
-static __global__ void k_p2p_wait_done(const P2PMailbox* own, int n_ranks, uint64_t seq, uint64_t timeout_ticks, int* __restrict__ err) {
-  (void)p2p_wait_done(own, n_ranks, seq, timeout_ticks, err);
 }
 
 // ---- host side: what a handle owns for the transport

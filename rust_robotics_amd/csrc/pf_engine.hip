@@ -192,9 +192,9 @@ __global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __r
 //
 // Sharded (rr_pf_shard_step_p2p, StepSrc::kSrcWindow): the markers live in the GLOBAL slot index (rr::resolve_tile_window);
 // the own slots inside the window this shard serves are resolved and read exactly as on one GPU, the few outside it were
-// delivered into this rank's inbox by the peer that serves them (k_push_window) -- a tile that holds such a slot first
-// waits for the peers' DONE of the previous step.  Round 2 resolved every served slot in a separate launch
-// (k_resolve_push -> lidx, 7.9 us at 1e6 particles) and waited for DONE in a fourth one.
+// delivered into this rank's inbox by the peer that serves them (from inside its plan kernel) -- such a slot waits, bounded,
+// for its own tag of the previous step.  Round 2 resolved every served slot in a separate launch
+// (k_resolve_push -> lidx, 7.9 us at 1e6 particles) and waited for a DONE message in a fourth one.
 constexpr unsigned int kInPlace = 0xffffffffu;
 constexpr unsigned kPushGrid = 64;  // workgroups of k_push_window (grid-stride over the foreign tiles: usually a handful)
 
@@ -224,13 +224,12 @@ enum StepSrc {
                     // own slots outside the window this shard serves were delivered into the inbox by a peer
 };
 struct WindowArgs {
-  const rr::P2PMailbox* mbox;  // this rank's mailbox (the peers' DONE records)
-  const double* inbox;         // this rank's inbox [field][n]
+  const double* inbox;         // this rank's inbox [4 fields + tag][n]
   int* err;
   uint64_t pad;                // marker position of global slot s = s + pad
-  uint64_t wait_seq;           // the DONE a tile with peer-served slots waits for
+  uint64_t wait_seq;           // the tag a peer-served slot must carry: the sequence number of the step being consumed
   uint64_t timeout_ticks;
-  int n_ranks;
+  int n_ranks;                 // 0: nothing to wait for (RCCL transport: an earlier kernel of the stream filled the inbox)
 };
 
 template <bool OBS_KERNARG, int SRC, int LIK, bool PACKED = false>
@@ -1545,7 +1544,6 @@ struct rr_pf {
   uint64_t window_seq = 0;         // ... and the exchange sequence number of the step whose window resample is pending (its DONE)
   double* rccl_inbox = nullptr;    // RCCL transport: [field][n] particles peers served for this shard's slots (plain device memory)
   bool window_rccl = false;        // the pending window resample came through the RCCL transport (inbox filled in stream order)
-  unsigned int* push_ticket = nullptr;  // arrival counters of k_push_window (zero between launches)
   unsigned int* lidx = nullptr;  // source index per slot; kInPlace = a peer stored the particle already (sharded)
   rr_pf_lik lik{};
   std::vector<double> landmarks;
@@ -2227,8 +2225,6 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
   }
   RR_TRY_OR_CLEAN(hipMalloc(&h->est_ticket, rr::kTicketWords * sizeof(unsigned int)));
   RR_TRY_OR_CLEAN(hipMemsetAsync(h->est_ticket, 0, rr::kTicketWords * sizeof(unsigned int), h->stream));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->push_ticket, rr::kTicketWords * sizeof(unsigned int)));
-  RR_TRY_OR_CLEAN(hipMemsetAsync(h->push_ticket, 0, rr::kTicketWords * sizeof(unsigned int), h->stream));
   h->slot_pad = (rr::kResolveSlots - h->opt.first_global_index % rr::kResolveSlots) % rr::kResolveSlots;
   RR_TRY_OR_CLEAN(hipMalloc(&h->ctl, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipHostMalloc(&h->ctl_host, sizeof(Ctl)));
@@ -2528,7 +2524,6 @@ void rr_pf_destroy(rr_pf* h) {
   if (h->mail) (void)hipHostFree(h->mail);
   (void)hipFree(h->mn_tile_cnt);
   (void)hipFree(h->est_ticket);
-  (void)hipFree(h->push_ticket);
   (void)hipFree(h->rccl_inbox);
   (void)hipFree(h->grid_rec);
   (void)hipFree(h->grid_ticket);
@@ -3235,16 +3230,13 @@ rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
   return rr::p2p_link_local(st, slabs, inboxes, devs, n_ranks);
 }
 
-// THREE launches: k_step_lazy<kSrcWindow> (propagate + weight; the own slots inside the window this shard served last
-// step are resolved from the markers and read in place exactly as on one GPU, the few a peer served come out of the inbox
-// after that peer's DONE) | k_shard_plan_mark (WMAX exchange, integer image, SUMS exchange, gate + plan, markers over the
-// global slot index -- one launch) | k_push_window (only the window's overhang over the own block: those particles go to
-// their owners' inboxes; its last workgroup sends DONE, nobody waits for it here).  Shards beyond 2^20 particles take the
-// plan as four launches (WMAX exchange | k_quantize_reduce | k_scan_exchange | k_mark).  Round 2: 4 launches with a
+// TWO launches: k_step_lazy<kSrcWindow> (propagate + weight; the own slots inside the window this shard served last step
+// are resolved from the markers and read in place exactly as on one GPU, the few a peer served come out of the inbox, each
+// after its own tag has arrived) | k_shard_plan_mark (WMAX exchange, integer image, SUMS exchange, gate + plan, markers for
+// the own block over the global slot index, and the window's overhang over the own block delivered from the SOURCE side into
+// the owners' inboxes: fields, acknowledgement, tags).  Shards beyond 2^20 particles take the plan as four launches (WMAX
+// exchange | k_quantize_reduce | k_scan_exchange | k_mark) and deliver with k_push_window.  Round 2: 4 launches with a
 // full-size resolve pass (k_resolve_push, 7.9 us at 1e6 particles) and a DONE exchange everybody waited in.
-// (Running the exchanges in the last workgroup of the producing kernels instead -- ticket counter, scoped atomics -- was
-// measured in round 1 for the WMAX / SUMS exchanges: the election costs ~5 us per exchange behind ~500 busy workgroups,
-// more than the launch it saves; k_push_window's workgroups have next to nothing to do, so its election is cheap.)
 rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
@@ -3260,7 +3252,6 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   if (lds > 150 * 1024) return fail(RR_INVALID_PARAMETER, "too many observations for one LDS block (max 6400)");
   if (!h->wmax_bits_clean) RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
   WindowArgs wa{};
-  wa.mbox = h->p2p.mbox;
   wa.inbox = h->p2p.inbox;
   wa.err = h->p2p.err;
   wa.pad = h->slot_pad;
@@ -3303,7 +3294,6 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
       sp.f[k][2] = h->b.yaw[k];
       sp.f[k][3] = h->b.v[k];
     }
-    sp.ticket = h->push_ticket;
     sp.enable = push_inside ? 1 : 0;
     pushed = push_inside;
     hipLaunchKernelGGL(rr::k_shard_plan_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->p2p.peers, seq,
