@@ -120,8 +120,10 @@ void rr_pf_destroy(rr_pf* h);
  * (try_new :142-156) or the initial state of try_with_initial_state (:170-199).  The options must
  * ask for multinomial resampling at every step (rr_pf_options_mcl); sharding is not available.
  * The reference draws particles one at a time until the bound holds; the engine evaluates all
- * max_particles candidate draws at once and keeps the same prefix.  Every resample of such a
- * filter synchronises with the host once (the new count sizes the next launches). */
+ * max_particles candidate draws at once and keeps the same prefix.  The new particle count stays on
+ * the device: rr_pf_step_async does not wait for it (every kernel of such a filter reads its n from
+ * device memory, launches are sized for max_particles); the host's copy -- rr_pf_particle_count, the
+ * accessors, the synchronous entry points -- is refreshed on demand (one 8-byte copy + a wait). */
 void rr_mcl_adaptive_default(rr_mcl_adaptive* kld);
 /* MonteCarloLocalizationConfig::validate, :84-131 (same messages) */
 rr_status rr_mcl_adaptive_validate(const rr_mcl_adaptive* kld);

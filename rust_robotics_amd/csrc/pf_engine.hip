@@ -96,6 +96,7 @@ struct StepParams {
   double u0, u1, dt;
   double sigma_v, sigma_w;
   rr_pf_lik lik;
+  int dyn_n;  // KLD-adaptive filter: the particle count is Ctl.n_active (k_propagate_weight only)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -119,6 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __r
     __syncthreads();
   }
   const int cur = ctl->cur;
+  if (p.dyn_n) p.n = ctl->n_active;
   double* __restrict__ bx = b.x[cur];
   double* __restrict__ by = b.y[cur];
   double* __restrict__ byaw = b.yaw[cur];
@@ -1339,8 +1341,12 @@ __global__ __launch_bounds__(kBlock) void k_kld_draw(Bufs b, const Ctl* __restri
                                                     const uint64_t* __restrict__ coarse, int coarse_log2,
                                                     uint64_t n_coarse, const double* __restrict__ r_explicit,
                                                     unsigned int* __restrict__ idx, int32_t* __restrict__ keys,
-                                                    uint64_t n_src, uint64_t n_draws, uint64_t seed, unsigned int rstep) {
+                                                    uint64_t n_src, uint64_t n_draws, uint64_t seed, unsigned int rstep, int dyn_n) {
   extern __shared__ uint64_t s_coarse[];
+  if (dyn_n) {  // the current particle count lives on the device (Ctl.n_active); the launch was sized for the capacity
+    n_src = ctl->n_active;
+    n_coarse = (n_src + (1ull << coarse_log2) - 1) >> coarse_log2;
+  }
   for (uint64_t i = threadIdx.x; i < n_coarse; i += kBlock) s_coarse[i] = coarse[i];
   __syncthreads();
   const uint64_t m = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1395,9 +1401,12 @@ __global__ __launch_bounds__(kBlock) void k_kld_insert(const int32_t* __restrict
 }
 
 constexpr int kKldThreads = 1024;
-__global__ __launch_bounds__(kKldThreads) void k_kld_count(const unsigned int* __restrict__ minslot,
+// (it also wipes the bin table and the first-occurrence slots for the NEXT resample once it has read them -- two memset
+// launches less per adaptive step; both arrays are cleared once when the filter is created)
+__global__ __launch_bounds__(kKldThreads) void k_kld_count(unsigned int* __restrict__ minslot,
                                                           const unsigned int* __restrict__ myslot, uint64_t n_draws,
-                                                          rr_mcl_adaptive kld, uint64_t* __restrict__ out) {
+                                                          rr_mcl_adaptive kld, uint64_t* __restrict__ out,
+                                                          unsigned int* __restrict__ table, uint64_t hash_size) {
   __shared__ uint64_t s_cnt[kKldThreads / rr::kWave];
   __shared__ uint64_t s_req[kKldThreads / rr::kWave];
   __shared__ uint64_t s_stop;
@@ -1442,6 +1451,24 @@ __global__ __launch_bounds__(kKldThreads) void k_kld_count(const unsigned int* _
     const uint64_t stop = s_stop;
     out[0] = stop == ~0ull ? n_draws : stop + 1;  // :342: at most max_particles
   }
+  // every read of minslot[] above happened before a barrier all threads have passed (the loop ends with one, or breaks
+  // right after one): the table can go
+  __syncthreads();
+  for (uint64_t k = tid; k < hash_size; k += kKldThreads) {
+    table[k] = kKldEmpty;
+    minslot[k] = kKldEmpty;
+  }
+}
+
+// the first n_new = kld_out[0] draws become the particle set (set cur^1 -> set cur), and n_new becomes the filter's particle
+// count ON THE DEVICE: every later kernel of an adaptive filter reads Ctl.n_active, so the host need not wait for the number
+__global__ __launch_bounds__(kBlock) void k_kld_gather_dyn(Bufs b, Ctl* __restrict__ ctl, const unsigned int* __restrict__ idx,
+                                                          const uint64_t* __restrict__ kld_out) {
+  const uint64_t n_new = kld_out[0];
+  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const int dst = ctl->cur, src = dst ^ 1;
+  if (k < n_new) copy_particle(b, src, dst, idx[k], k, false, nullptr);
+  if (k == 0) ctl->n_active = n_new;  // (nothing in this launch reads it)
 }
 
 // the first n_new draws become the particle set (set cur^1 -> set cur)
@@ -1464,6 +1491,7 @@ struct rr_pf {
   uint64_t cap = 0;  // particles the buffers hold (== n unless the filter is KLD-adaptive: max_particles)
   // KLD-adaptive particle count (monte_carlo_localization.rs:322-385)
   bool adaptive = false;
+  bool n_dirty = false;  // adaptive: the device (Ctl.n_active) knows a newer particle count than h->n (refresh_count)
   rr_mcl_adaptive kld{};
   int32_t* kld_keys = nullptr;         // [cap][3] bin of every candidate draw
   unsigned int* kld_table = nullptr;   // open-addressing table: draw that claimed the slot
@@ -1624,9 +1652,21 @@ rr_status validate_obs(const double* obs, size_t n_obs) {  // particle_filter.rs
   return RR_OK;
 }
 
-rr_status bind(rr_pf* h) {
+void set_particle_count(rr_pf* h, uint64_t n);
+
+// keep_lazy: the caller enqueues work that reads the particle count from the device (the asynchronous step of an adaptive
+// filter); everybody else gets the host's copy brought up to date first (one small copy + a wait)
+rr_status bind(rr_pf* h, bool keep_lazy = false) {
   if (!h) return fail(RR_INVALID_PARAMETER, "null handle");
   RR_HIP_TRY(hipSetDevice(h->opt.device));
+  if (h->n_dirty && !keep_lazy) {
+    RR_HIP_TRY(hipMemcpyAsync(h->kld_out_host, h->kld_out, sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    RR_HIP_TRY(hipStreamSynchronize(h->stream));
+    const uint64_t n_new = h->kld_out_host[0];
+    if (n_new == 0 || n_new > h->cap) return fail(RR_RUNTIME_ERROR, "adaptive resample produced an impossible particle count");
+    h->n_dirty = false;
+    set_particle_count(h, n_new);
+  }
   return RR_OK;
 }
 
@@ -1646,6 +1686,7 @@ StepParams make_params(const rr_pf* h, const double u[2], int n_obs) {
   p.sigma_v = h->cfg.velocity_noise;
   p.sigma_w = h->cfg.yaw_rate_noise;
   p.lik = h->lik;
+  p.dyn_n = h->adaptive ? 1 : 0;
   return p;
 }
 
@@ -1671,7 +1712,7 @@ rr_status stage_obs(rr_pf* h, const double* obs, size_t n_obs, ObsArg* arg, bool
 template <bool PREDICT, bool WEIGHT, bool EXPLICIT>
 rr_status launch_pw(rr_pf* h, const StepParams& p, const ObsArg& arg, bool kernarg) {
   // grid-stride kernel: at most k1_blocks_per_cu workgroups per CU (256 CUs)
-  const unsigned grid = std::min<unsigned>(grid_for(h->n, kBlock), (unsigned)(256 * h->k1_blocks_per_cu));
+  const unsigned grid = std::min<unsigned>(grid_for(h->adaptive ? h->cap : h->n, kBlock), (unsigned)(256 * h->k1_blocks_per_cu));
   const size_t lds = WEIGHT ? 3 * (size_t)p.n_obs * sizeof(double) : 0;
   if (lds > 150 * 1024) return fail(RR_INVALID_PARAMETER, "too many observations for one LDS block (max 6400)");
   if (WEIGHT) {
@@ -1702,6 +1743,7 @@ ImageArgs image_args(const rr_pf* h) {
   a.gid0 = h->opt.first_global_index;
   a.degenerate = rr::kDegenerateUniform;
   a.honour_uniform_flag = 1;
+  a.dyn_n = h->adaptive ? 1 : 0;
   return a;
 }
 
@@ -1937,54 +1979,54 @@ void set_particle_count(rr_pf* h, uint64_t n) {
   h->n_coarse = (n + (1ull << h->coarse_log2) - 1) >> h->coarse_log2;
 }
 
+// the host changes an adaptive filter's particle count (rr_pf_set_particles_n): the device's copy follows
+rr_status publish_particle_count(rr_pf* h) {
+  if (!h->adaptive) return RR_OK;
+  h->kld_out_host[1] = h->n;
+  RR_HIP_TRY(hipMemcpyAsync(&h->ctl->n_active, &h->kld_out_host[1], sizeof(uint64_t), hipMemcpyHostToDevice, h->stream));
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  return RR_OK;
+}
+
 // resample_adaptive, monte_carlo_localization.rs:322-365 (see the kernels above).  r_explicit_dev:
 // max_particles uniforms on the device, or nullptr for the engine's Philox stream.
-rr_status resample_adaptive(rr_pf* h, const double* r_explicit_dev) {
+// lazy: do not wait for the new particle count -- every kernel of an adaptive filter reads it from Ctl.n_active, launches are
+// sized for the capacity, and the host's copy is refreshed by the next entry point that needs it (bind)
+rr_status resample_adaptive(rr_pf* h, const double* r_explicit_dev, bool lazy = false) {
   const uint64_t M = h->kld.max_particles;
-  launch_quantize(h, wmax_source(h), 0);
-  PlanArgs pa = plan_args(h, /*mode=*/1, RR_RESAMPLE_MULTINOMIAL, NAN);
-  const bool fused = h->n_tiles <= (uint64_t)rr::kFusedMaxTiles;
-  if (!fused) {
-    Timed t(h, RR_K_SCAN_TILES);
-    hipLaunchKernelGGL(rr::k_scan_tiles, dim3(1), dim3(kScanThreads), 0, h->stream, h->tile_total, h->tile_q2, h->ctl,
-                       h->n_tiles, 1, pa, (uint64_t*)nullptr);
+  const uint64_t cap_tiles = (h->cap + kTile - 1) / kTile;
+  const uint64_t cap_coarse = ((h->cap + (1ull << h->coarse_log2) - 1) >> h->coarse_log2) + 1;
+  {
+    Timed t(h, RR_K_QUANTIZE_REDUCE);
+    hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)cap_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl, wmax_source(h),
+                       image_args(h), h->tile_total, h->tile_q2, 0);
   }
+  PlanArgs pa = plan_args(h, /*mode=*/1, RR_RESAMPLE_MULTINOMIAL, NAN);
+  const bool fused = cap_tiles <= (uint64_t)rr::kFusedMaxTiles;
+  if (!fused) return fail(RR_INVALID_PARAMETER, "adaptive filters are limited to 8 388 608 particles");
   {
     Timed t(h, RR_K_CDF);
-    const dim3 grid((unsigned)h->n_tiles), block(rr::kTileBlock);
-    if (fused)
-      hipLaunchKernelGGL(rr::k_plan_cdf, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total,
-                         h->tile_q2, h->n_tiles, pa, h->cdf, h->cdf_coarse, h->coarse_log2, (unsigned int*)nullptr,
-                         (unsigned int*)nullptr, 0);
-    else
-      hipLaunchKernelGGL(rr::k_cdf, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total, h->cdf,
-                         h->cdf_coarse, h->coarse_log2);
+    hipLaunchKernelGGL(rr::k_plan_cdf, dim3((unsigned)cap_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total,
+                       h->tile_q2, cap_tiles, pa, h->cdf, h->cdf_coarse, h->coarse_log2, (unsigned int*)nullptr, (unsigned int*)nullptr, 0);
   }
   h->wmax_live = false;
   h->wmax_bits_clean = true;
   {
     Timed t(h, RR_K_RESAMPLE_GATHER);
-    RR_HIP_TRY(hipMemsetAsync(h->kld_table, 0xff, h->kld_hash_size * sizeof(unsigned int), h->stream));
-    RR_HIP_TRY(hipMemsetAsync(h->kld_minslot, 0xff, h->kld_hash_size * sizeof(unsigned int), h->stream));
-    hipLaunchKernelGGL(k_kld_draw, dim3(grid_for(M, kBlock)), dim3(kBlock), h->n_coarse * sizeof(uint64_t), h->stream, h->b,
+    hipLaunchKernelGGL(k_kld_draw, dim3(grid_for(M, kBlock)), dim3(kBlock), cap_coarse * sizeof(uint64_t), h->stream, h->b,
                        h->ctl, h->cdf, h->cdf_coarse, h->coarse_log2, h->n_coarse, r_explicit_dev, h->idx, h->kld_keys, h->n, M,
-                       h->opt.seed, h->rstep);
+                       h->opt.seed, h->rstep, 1);
     hipLaunchKernelGGL(k_kld_insert, dim3(grid_for(M, kBlock)), dim3(kBlock), 0, h->stream, (const int32_t*)h->kld_keys,
                        h->kld_table, h->kld_minslot, h->kld_myslot, M, h->kld_hash_size);
-    hipLaunchKernelGGL(k_kld_count, dim3(1), dim3(kKldThreads), 0, h->stream, (const unsigned int*)h->kld_minslot,
-                       (const unsigned int*)h->kld_myslot, M, h->kld, h->kld_out);
+    hipLaunchKernelGGL(k_kld_count, dim3(1), dim3(kKldThreads), 0, h->stream, h->kld_minslot, (const unsigned int*)h->kld_myslot, M, h->kld,
+                       h->kld_out, h->kld_table, h->kld_hash_size);
+    hipLaunchKernelGGL(k_kld_gather_dyn, dim3(grid_for(M, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, (const unsigned int*)h->idx,
+                       (const uint64_t*)h->kld_out);
     RR_HIP_TRY(hipGetLastError());
-    // the new count sizes every later launch: the one host synchronisation of an adaptive step
-    RR_HIP_TRY(hipMemcpyAsync(h->kld_out_host, h->kld_out, sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
-    RR_HIP_TRY(hipStreamSynchronize(h->stream));
-    const uint64_t n_new = h->kld_out_host[0];
-    if (n_new == 0 || n_new > M) return fail(RR_RUNTIME_ERROR, "adaptive resample produced an impossible particle count");
-    hipLaunchKernelGGL(k_kld_gather, dim3(grid_for(n_new, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl,
-                       (const unsigned int*)h->idx, n_new);
-    RR_HIP_TRY(hipGetLastError());
-    set_particle_count(h, n_new);  // weights are uniform 1/n_new from here (Ctl.weights_uniform, :359-362)
+    h->n_dirty = true;  // weights are uniform 1/n_new from here (Ctl.weights_uniform, :359-362)
   }
   h->rstep += 1;
+  if (!lazy) return bind(h);  // the callers that hand the new count back, or go on with host-sized work
   return RR_OK;
 }
 
@@ -2186,6 +2228,8 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
     RR_TRY_OR_CLEAN(hipMalloc(&h->kld_keys, 3 * h->cap * sizeof(int32_t)));
     RR_TRY_OR_CLEAN(hipMalloc(&h->kld_table, h->kld_hash_size * sizeof(unsigned int)));
     RR_TRY_OR_CLEAN(hipMalloc(&h->kld_minslot, h->kld_hash_size * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(hipMemsetAsync(h->kld_table, 0xff, h->kld_hash_size * sizeof(unsigned int), h->stream));  // (k_kld_count keeps them clean)
+    RR_TRY_OR_CLEAN(hipMemsetAsync(h->kld_minslot, 0xff, h->kld_hash_size * sizeof(unsigned int), h->stream));
     RR_TRY_OR_CLEAN(hipMalloc(&h->kld_myslot, h->cap * sizeof(unsigned int)));
     RR_TRY_OR_CLEAN(hipMalloc(&h->kld_out, 2 * sizeof(uint64_t)));
     RR_TRY_OR_CLEAN(hipHostMalloc(&h->kld_out_host, 2 * sizeof(uint64_t)));
@@ -2240,6 +2284,7 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
   init.image_mode = rr::kImageUniform;
   init.sum = 1.0;
   init.neff = (double)n_global;
+  init.n_active = h->n;
   *h->ctl_host = init;
   RR_TRY_OR_CLEAN(hipMemcpyAsync(h->ctl, h->ctl_host, sizeof(Ctl), hipMemcpyHostToDevice, h->stream));
   RR_TRY_OR_CLEAN(hipStreamSynchronize(h->stream));
@@ -2472,6 +2517,7 @@ rr_status rr_pf_set_particles_n(rr_pf* h, const double* aos, uint64_t n) {
   if (n == 0 || n > h->cap) return fail(RR_INVALID_PARAMETER, "particle count must lie in [1, max_particles]");
   if ((s = materialise(h)) != RR_OK) return s;
   set_particle_count(h, n);
+  if ((s = publish_particle_count(h)) != RR_OK) return s;
   return rr_pf_set_particles(h, aos);
 }
 
@@ -2627,7 +2673,7 @@ static bool fused_estimate_available(const rr_pf* h) {
 }
 
 static rr_status step_async_impl(rr_pf* h, const double control[2], const double* obs, size_t n_obs, bool want_estimate) {
-  rr_status s = bind(h);
+  rr_status s = bind(h, /*keep_lazy=*/h && h->adaptive);  // an adaptive filter steps without knowing its current count on the host
   if (s != RR_OK) return s;
   if ((s = validate_control(control)) != RR_OK) return s;
   if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
@@ -2638,10 +2684,10 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
   bool kernarg;
   if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
   StepParams p = make_params(h, control, (int)n_obs);
-  if (h->adaptive) {  // try_step, monte_carlo_localization.rs:291-300
+  if (h->adaptive) {  // try_step, monte_carlo_localization.rs:291-300 -- no host synchronisation: the count stays on the device
     if ((s = launch_pw<true, true, false>(h, p, arg, kernarg)) != RR_OK) return s;
     h->step += 1;
-    return resample_adaptive(h, nullptr);
+    return resample_adaptive(h, nullptr, /*lazy=*/true);
   }
   const bool multinomial = h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC;
   if (multinomial && !h->lidx) {
@@ -2805,7 +2851,11 @@ rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_
   return compute_moments(h, out_state, nullptr);
 }
 
-uint64_t rr_pf_particle_count(const rr_pf* h) { return h ? h->n : 0; }
+uint64_t rr_pf_particle_count(const rr_pf* h) {
+  if (!h) return 0;
+  if (h->n_dirty) (void)bind(const_cast<rr_pf*>(h));  // an adaptive filter after asynchronous steps: wait for the device's count
+  return h->n;
+}
 
 rr_status rr_pf_get_fixed_sums(rr_pf* h, rr_pf_fixed_sums* out) {
   rr_status s = bind(h);

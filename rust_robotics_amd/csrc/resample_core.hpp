@@ -75,6 +75,8 @@ struct Ctl {
   double est[4];          // (unused since round 3: the tiles' partial sums are added on the host when the estimate is read)
   uint64_t est_step;      // resample-step counter the in-step estimate belongs to (+1; 0 = none yet)
   double est_denom;       // ... and what the sum of the tiles' partial sums is divided by (N when the resample fired, else T)
+  uint64_t n_active;      // KLD-adaptive filters: the CURRENT particle count (k_kld_count sets it; the kernels of such a filter read
+                          // their n from here instead of their launch packet, so the host does not have to know it to enqueue a step)
 };
 
 // q_i of local particle i (global index gid0 + i)
@@ -92,16 +94,22 @@ struct ImageArgs {
   uint64_t gid0;      // global index of local particle 0
   int degenerate;     // DegeneratePolicy
   int honour_uniform_flag;  // PF: Ctl.weights_uniform forces the uniform image
+  int dyn_n;          // KLD-adaptive filter: n = n_global = Ctl.n_active (launches are sized for the capacity)
 };
+__device__ inline ImageArgs image_args_now(ImageArgs a, const Ctl* __restrict__ ctl) {
+  if (a.dyn_n) a.n = a.n_global = ctl->n_active;
+  return a;
+}
 
 // ------------------------------------------------------------------------------------------
 // K2: per-tile integer totals and sum of squares.  Tile = 2048 particles; each wave owns 512
 // consecutive particles as 8 coalesced rows of 64.  wmax_src points at the maximum to scale by
 // (Ctl.wmax_bits on one GPU, the all-reduced maximum when sharded).
 __device__ inline void quantize_reduce_tile(const double* __restrict__ w, Ctl* __restrict__ ctl,
-                                            const double* __restrict__ wmax_src, const ImageArgs& a,
+                                            const double* __restrict__ wmax_src, const ImageArgs& a_in,
                                             uint64_t* __restrict__ tile_total, uint64_t* __restrict__ tile_q2,
                                             int settle) {
+  const ImageArgs a = image_args_now(a_in, ctl);
   __shared__ uint64_t s_t[kTileWaves];
   __shared__ uint64_t s_qh[kTileWaves];
   __shared__ uint64_t s_ql[kTileWaves];
@@ -444,6 +452,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_cdf(const double* __restr
                                                       uint64_t* __restrict__ cdf, uint64_t* __restrict__ coarse,
                                                       int coarse_log2) {
   if (!ctl->fired) return;
+  a = image_args_now(a, ctl);
   __shared__ uint64_t s_w[kTileBlock / kWave];
   const TileScan t = tile_scan(w, a, ctl->image_mode, ctl->shift, blockIdx.x, s_w);
   const uint64_t off = ctl->base + tile_offset[blockIdx.x] + t.thread_off;
@@ -466,6 +475,8 @@ static __global__ __launch_bounds__(kTileBlock) void k_plan_cdf(const double* __
                                                            unsigned int* __restrict__ guide_carry, int guide_log2) {
   __shared__ uint64_t s4[4 * (kTileBlock / kWave)];
   __shared__ uint64_t s_w[kTileBlock / kWave];
+  a = image_args_now(a, ctl);  // (Ctl.n_active is only rewritten by a later kernel)
+  if (a.dyn_n) pa.n_global = a.n_global;
   const TileSums ts = tile_sums(tile_total, tile_q2, n_tiles, s4);
   const int mode = ctl->image_mode;  // written by k_quantize_reduce; nothing below reads what block 0 writes
   const int shift = ctl->shift;

@@ -169,3 +169,34 @@ def test_large_adaptive_resample_matches_det(loc, det):
     after = mcl.get_particles_array()
     assert lo <= mcl.particle_count() <= hi
     assert set(map(tuple, np.round(after[:50, :2], 12))) <= set(map(tuple, np.round(before[:, :2], 12)))
+
+
+def test_asynchronous_steps_need_no_host_count(loc):
+    """Round 3: an adaptive filter's particle count lives on the device (Ctl.n_active, read by every kernel of such a filter),
+    so `step_async` does not wait for it.  40 asynchronous steps in a row -- the host never learns a count in between -- must
+    leave exactly the particle set and the count of 40 synchronous steps (which read the count back every step), and the
+    estimate / covariance accessors must agree."""
+    lo, hi, sig = 80, 3000, 0.4
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=lo, max_particles=hi, range_noise=sig, velocity_noise=0.4, yaw_rate_noise=math.radians(8.0))
+    a = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=23)
+    b = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=23)
+    rng = np.random.default_rng(5)
+    counts = []
+    for t in range(40):
+        obs = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), sig, rng)
+        a.step_async([1.0, 0.1], obs)
+        b.try_step([1.0, 0.1], obs)
+        counts.append(b.particle_count())
+    assert len(set(counts)) > 3, counts
+    assert a.particle_count() == b.particle_count()
+    pa, pb = a.get_particles_array(), b.get_particles_array()
+    assert pa.shape == pb.shape and np.array_equal(pa.view(np.uint64), pb.view(np.uint64))
+    np.testing.assert_allclose(a.estimate(), b.estimate(), rtol=0, atol=0)
+    np.testing.assert_allclose(a.calc_covariance(), b.calc_covariance(), rtol=0, atol=0)
+    # and on from there, mixing the two forms
+    for t in range(40, 50):
+        obs = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), sig, rng)
+        (a.step_async if t % 2 else a.try_step)([1.0, 0.1], obs)
+        b.try_step([1.0, 0.1], obs)
+    assert a.particle_count() == b.particle_count()
+    assert np.array_equal(a.get_particles_array().view(np.uint64), b.get_particles_array().view(np.uint64))

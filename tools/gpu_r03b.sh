@@ -1,12 +1,12 @@
 set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r03c
-python -m pytest tests -m gpu -q --maxfail=40 > gpurun_out/r03c/pytest_main.log 2>&1; echo "rc=$?" >> gpurun_out/r03c/pytest_main.log
-tail -30 gpurun_out/r03c/pytest_main.log
-timeout 600 python bench.py > gpurun_out/r03c/bench_default.json 2> gpurun_out/r03c/bench_default.err; echo "bench rc=$?"
+mkdir -p gpurun_out/r03g
+python -m pytest tests -m gpu -q --maxfail=40 > gpurun_out/r03g/pytest_main.log 2>&1; echo "rc=$?" >> gpurun_out/r03g/pytest_main.log
+tail -30 gpurun_out/r03g/pytest_main.log
+timeout 600 python bench.py > gpurun_out/r03g/bench_default.json 2> gpurun_out/r03g/bench_default.err; echo "bench rc=$?"
 python - <<'PY'
 import json
-d=json.load(open('gpurun_out/r03c/bench_default.json'))
+d=json.load(open('gpurun_out/r03g/bench_default.json'))
 def g(*k):
     x=d
     for a in k:
