@@ -71,6 +71,17 @@ def test_in_process_shards_equal_unsharded(world, n_local, mode):
     assert r.returncode == 0 and "P2P_LOCAL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+@pytest.mark.parametrize("world,n_local,mode", [(2, 6000, "fused"), (3, 4100, "mixed")])
+def test_in_process_shards_multi_launch_plan(world, n_local, mode):
+    """The same with RR_PF_FUSED_PLAN=0: the plan of a shard as separate launches (WMAX exchange | k_quantize_reduce |
+    k_scan_exchange | k_mark in the window layout) and the overhang delivered by k_push_window -- the form shards beyond 2^20
+    particles take."""
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); from tests.test_gpu_p2p import run_in_process; run_in_process({world}, {n_local}, mode={mode!r})"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="8", RR_PF_FUSED_PLAN="0"))
+    assert r.returncode == 0 and "P2P_LOCAL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_two_processes_over_ipc_handles():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29721", os.path.join(ROOT, "tests", "_gpu_p2p_worker.py"), "8000", "8"]
