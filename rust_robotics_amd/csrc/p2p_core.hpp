@@ -25,6 +25,7 @@ namespace rr {
 // The consumer reads an "in place" slot from its inbox instead of its slab.
 constexpr int kMaxP2P = 16;
 constexpr int kP2PHandleBytes = 256;
+constexpr int kBusIdBytes = 32;  // the PCI bus id of the exporting device, after the three IPC handles
 struct P2PSlot {
   uint64_t v[3];
   uint64_t seq;
@@ -174,27 +175,50 @@ __device__ inline void st_sys(double* p, double v) {
 __device__ inline double ld_sys(const double* p) {
   return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
 }
-// A delivered slot vouches for itself: the inbox has a fifth plane of TAGS, and the deliverer writes the step's sequence number
-// there AFTER the slot's four fields have been acknowledged.  The reader of a slot polls that one word (bounded) and then reads
-// the fields -- no DONE message, no election of a last workgroup to send it, nobody waits who has nothing to receive.
-__device__ inline void inbox_tag(double* inbox, uint64_t n_local, uint64_t li, uint64_t seq) {
-  __hip_atomic_store(reinterpret_cast<uint64_t*>(inbox + 4 * n_local + li), seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+// A delivered slot vouches for itself: the inbox has a fifth plane of SEALS, and a slot's seal is a 64-bit mix of the step's
+// sequence number and the slot's four fields.  The deliverer stores the five words in one go, in any order, without waiting for
+// anything; the reader takes all five and accepts them when the seal fits the fields it has just read -- a slot of which only
+// a part has arrived yet (or none: the words of an earlier step, or the zeros of a fresh inbox) does not fit, and the reader
+// looks again.  No DONE message, no election of a last workgroup to send it, nobody waits who has nothing to receive, and no
+// "fields, wait for their acknowledgement, then the tag" on the deliverer's side (4 - 5 us of a system-scope round trip that
+// the receiving shard's next step sat through).  Multiplying by odd constants is one-to-one, so a slot with exactly ONE
+// stale word never fits; two or more stale words fit with probability 2^-64 per look.
+__device__ inline uint64_t inbox_seal(uint64_t seq, double x, double y, double yaw, double v) {
+  const uint64_t z = seq * 0x9E3779B97F4A7C15ull + rr_d2u(x) * 0xC2B2AE3D27D4EB4Full + rr_d2u(y) * 0x165667B19E3779F9ull +
+                     rr_d2u(yaw) * 0xD6E8FEB86659FD93ull + rr_d2u(v) * 0xFF51AFD7ED558CCDull;
+  return z ^ (z >> 31);  // one-to-one, 0 only for z == 0: a zeroed slot (seal 0, fields 0) fits no seq >= 1
 }
-// false (and *err latched) if the slot's delivery of step `seq` does not show up in time
-__device__ inline bool inbox_await(const double* inbox, uint64_t n_local, uint64_t li, uint64_t seq, uint64_t timeout_ticks, int* __restrict__ err) {
-  const uint64_t* tag = reinterpret_cast<const uint64_t*>(inbox + 4 * n_local + li);
-  if (__hip_atomic_load(tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == seq) return true;
-  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;  // the filter is broken already: do not wait again
-  const uint64_t t0 = wall_clock64();
-  while (__hip_atomic_load(tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != seq) {
+__device__ inline void inbox_put(double* inbox, uint64_t n_local, uint64_t li, uint64_t seq, double x, double y, double yaw, double v) {
+  st_sys(inbox + li, x);
+  st_sys(inbox + n_local + li, y);
+  st_sys(inbox + 2 * n_local + li, yaw);
+  st_sys(inbox + 3 * n_local + li, v);
+  __hip_atomic_store(reinterpret_cast<uint64_t*>(inbox + 4 * n_local + li), inbox_seal(seq, x, y, yaw, v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// the slot's fields (x, y, yaw, v) of step `seq`; seq == 0: whatever is there (an earlier kernel of the stream filled the slot).
+// false (and *err latched) if the delivery does not show up in time -- f then holds what was there.
+__device__ inline bool inbox_take(const double* inbox, uint64_t n_local, uint64_t li, uint64_t seq, uint64_t timeout_ticks,
+                                  int* __restrict__ err, double f[4]) {
+  const uint64_t* seal = reinterpret_cast<const uint64_t*>(inbox + 4 * n_local + li);
+  uint64_t t0 = 0;
+  for (;;) {
+    f[0] = ld_sys(inbox + li);
+    f[1] = ld_sys(inbox + n_local + li);
+    f[2] = ld_sys(inbox + 2 * n_local + li);
+    f[3] = ld_sys(inbox + 3 * n_local + li);
+    if (seq == 0) return true;
+    if (__hip_atomic_load(seal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == inbox_seal(seq, f[0], f[1], f[2], f[3])) return true;
+    if (t0 == 0) {
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;  // the filter is broken already: do not wait again
+      t0 = wall_clock64() | 1;
+    }
     __builtin_amdgcn_s_sleep(8);
     if (wall_clock64() - t0 > (seq <= 3 ? 10 * timeout_ticks : timeout_ticks)) {
       *err = 1;
       return false;
     }
   }
-  asm volatile("" ::: "memory");
-  return true;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -211,12 +235,6 @@ __device__ inline bool inbox_await(const double* inbox, uint64_t n_local, uint64
 // All workgroups must be resident at once (host: n_tiles <= grid capacity).  A local wait is bounded by twelve peer
 // time-outs (the first exchanges of a filter are allowed ten); giving up sets *err like a peer time-out does.
 constexpr int kShardHeadWords = 8;
-// what k_shard_plan_mark needs to deliver the window's overhang itself (enable == 0: markers for all served positions,
-// k_push_window follows)
-struct ShardPush {
-  const double* f[2][4];  // x, y, yaw, v of both buffer sets
-  int enable;
-};
 __device__ inline bool wait_flag(const uint64_t* flag, uint64_t epoch, uint64_t limit_ticks) {
   const uint64_t t0 = wall_clock64();
   while (ld_dev(flag) != epoch) {
@@ -231,7 +249,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
     P2PPeers peers, uint64_t seq, const double* __restrict__ w, Ctl* __restrict__ ctl, ImageArgs a, uint64_t* __restrict__ rec,
     unsigned int* __restrict__ ticket, uint64_t epoch, int settle, uint64_t n_tiles, PlanArgs pa,
     unsigned int* __restrict__ markers, unsigned int* __restrict__ carry, uint64_t* __restrict__ gathered,
-    int* __restrict__ err, uint64_t slot_pad, ShardPush push) {
+    int* __restrict__ err, uint64_t slot_pad) {
   constexpr int W = kTileBlock / kWave;
   __shared__ uint64_t s4[4 * W];
   __shared__ uint64_t s_w[W];
@@ -244,7 +262,6 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
   const uint64_t limit = 12 * peers.timeout_ticks;
   // reads of Ctl that the last arrival's settle / finalize could race with come first (they precede this workgroup's ticket)
   const bool forced_uniform = a.honour_uniform_flag && ctl->weights_uniform;
-  const int push_cur = (settle && ctl->pending) ? ctl->cur ^ 1 : ctl->cur;  // the live set once this launch has settled Ctl.cur
   // ---- 0: the global maximum
   if (blockIdx.x == 0) {
     const uint64_t local_bits = ctl->wmax_bits;
@@ -380,67 +397,9 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
       rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
     }
     const rr_sys_plan plan = rr_sys_plan_make(rho, total, pa.n_global);
-    // marker position of global slot s: s + slot_pad (resolve_tile_window)
-    if (!push.enable) {
-      mark_sources(t, base + pre + t.thread_off, i0, a.n, plan, total, (uint64_t)0 - slot_pad, markers, carry);
-    } else {
-      // ---- C: the overhang, delivered from the SOURCE side.  A source knows the position run [lo, hi) it feeds; whatever
-      // of it lies outside this shard's own block belongs to a peer, and the particle goes straight into that peer's
-      // inbox (fields, then the slot's tag) -- no markers for those positions (nobody would consume them), no resolve pass, no
-      // extra launch, no DONE message.  The runs
-      // with a foreign part (a handful per shard in steady state) are collected in LDS and the workgroup's threads share
-      // their slots, so one heavy particle that feeds a whole neighbouring block is 512 lanes' work, not one's.
-      __shared__ unsigned int s_cnt;
-      __shared__ unsigned int s_rsrc[kTile], s_rlo[kTile], s_rhi[kTile];
-      const uint64_t own0 = a.gid0 + slot_pad, own1 = own0 + a.n;
-      SlotRun runs[kItems];
-      if (tid == 0) s_cnt = 0;
-      __syncthreads();
-      mark_sources(t, base + pre + t.thread_off, i0, a.n, plan, total, (uint64_t)0 - slot_pad, markers, carry, nullptr, runs, own0, own1);
-#pragma unroll
-      for (int j = 0; j < kItems; ++j) {
-        if (runs[j].hi > runs[j].lo && (runs[j].lo < own0 || runs[j].hi > own1)) {
-          const unsigned int k = atomicAdd(&s_cnt, 1u);
-          s_rsrc[k] = (unsigned int)(i0 + j);
-          s_rlo[k] = (unsigned int)runs[j].lo;
-          s_rhi[k] = (unsigned int)runs[j].hi;
-        }
-      }
-      __syncthreads();
-      const unsigned int n_runs = s_cnt;
-      // two passes over this thread's share of the foreign slots: the fields, one wait for their acknowledgement, the tags
-      for (int pass = 0; pass < 2; ++pass) {
-        bool stored = false;
-        for (unsigned int r = 0; r < n_runs; ++r) {
-          const uint64_t src = s_rsrc[r], lo = s_rlo[r], hi = s_rhi[r];
-          double px = 0.0, py = 0.0, pyaw = 0.0, pv = 0.0;
-          if (pass == 0) {
-            px = push.f[push_cur][0][src];
-            py = push.f[push_cur][1][src];
-            pyaw = push.f[push_cur][2][src];
-            pv = push.f[push_cur][3][src];
-          }
-          for (int part = 0; part < 2; ++part) {  // the part below the own block, then the part above it
-            const uint64_t plo = part == 0 ? lo : (lo > own1 ? lo : own1), phi = part == 0 ? (hi < own0 ? hi : own0) : hi;
-            for (uint64_t pos = plo + tid; pos < phi; pos += kTileBlock) {
-              const uint64_t slot = pos - slot_pad;
-              const uint64_t d = slot / a.n, li = slot - d * a.n;
-              double* __restrict__ out = peers.inbox[d];  // fine-grained, [4 fields + tag][n_local]
-              if (pass == 0) {
-                st_sys(out + li, px);
-                st_sys(out + a.n + li, py);
-                st_sys(out + 2 * a.n + li, pyaw);
-                st_sys(out + 3 * a.n + li, pv);
-                stored = true;
-              } else {
-                inbox_tag(out, a.n, li, seq);
-              }
-            }
-          }
-        }
-        if (pass == 0 && stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (system-scope stores) acknowledged = in the owner's memory
-      }
-    }
+    // marker position of global slot s: s + slot_pad (resolve_tile_window); the overhang over the own block is
+    // k_push_window's (see DESIGN.md section 5 for the variant that delivered it from here, and why it lost)
+    mark_sources(t, base + pre + t.thread_off, i0, a.n, plan, total, (uint64_t)0 - slot_pad, markers, carry);
   }
 }
 
@@ -451,6 +410,7 @@ struct P2PState {
   size_t inbox_doubles = 0;
   P2PPeers peers{};            // device pointers of every rank's mailbox and slab
   bool ready = false;
+  int n_sharing = 1;               // ranks of this filter whose shard lives on THIS device (this one included)
   void* opened[3 * kMaxP2P] = {};  // IPC mappings to close
   int n_opened = 0;
   uint64_t seq = 0;
@@ -489,7 +449,7 @@ struct P2PState {
   rr_status reset_records() {
     RR_HIP_TRY(hipMemset(mbox, 0, sizeof(P2PMailbox)));
     RR_HIP_TRY(hipMemset(err, 0, sizeof(int)));
-    RR_HIP_TRY(hipMemset(inbox, 0, inbox_doubles * sizeof(double)));  // (the tag plane: sequence numbers start over)
+    RR_HIP_TRY(hipMemset(inbox, 0, inbox_doubles * sizeof(double)));  // (the seal plane: sequence numbers start over)
     RR_HIP_TRY(hipDeviceSynchronize());
     seq = 0;
     return RR_OK;
@@ -499,7 +459,7 @@ struct P2PState {
     if (mbox) return RR_OK;
     inbox_doubles = inbox_doubles_;
     RR_HIP_TRY(hipExtMallocWithFlags((void**)&inbox, inbox_doubles * sizeof(double), hipDeviceMallocFinegrained));
-    RR_HIP_TRY(hipMemset(inbox, 0, inbox_doubles * sizeof(double)));  // the engines' tag planes must not hold an earlier filter's stamps
+    RR_HIP_TRY(hipMemset(inbox, 0, inbox_doubles * sizeof(double)));  // the engines' seal planes must not hold an earlier filter's seals
     RR_HIP_TRY(hipExtMallocWithFlags((void**)&mbox, sizeof(P2PMailbox), hipDeviceMallocFinegrained));
     RR_HIP_TRY(hipMemset(mbox, 0, sizeof(P2PMailbox)));
     RR_HIP_TRY(hipMalloc(&scratch, (3 * kMaxP2P + 4) * sizeof(uint64_t)));
@@ -522,6 +482,11 @@ struct P2PState {
     RR_HIP_TRY(hipIpcGetMemHandle(&hs[2], inbox));
     std::memset(out, 0, kP2PHandleBytes);
     std::memcpy(out, hs, sizeof hs);
+    // which physical device the shard lives on (ranks that share one must leave each other room, see n_sharing)
+    static_assert(sizeof hs + kBusIdBytes <= kP2PHandleBytes, "handle blob too small");
+    int dev = 0;
+    RR_HIP_TRY(hipGetDevice(&dev));
+    RR_HIP_TRY(hipDeviceGetPCIBusId(reinterpret_cast<char*>(out) + sizeof hs, kBusIdBytes, dev));
     return RR_OK;
   }
 
@@ -531,6 +496,11 @@ struct P2PState {
     P2PPeers p{};
     p.n_ranks = n_ranks;
     p.rank = rank;
+    char own_bus[kBusIdBytes] = {};
+    int dev = 0;
+    RR_HIP_TRY(hipGetDevice(&dev));
+    RR_HIP_TRY(hipDeviceGetPCIBusId(own_bus, kBusIdBytes, dev));
+    n_sharing = 1;
     for (int g = 0; g < n_ranks; ++g) {
       if (g == rank) {
         p.slab[g] = slab;
@@ -540,6 +510,8 @@ struct P2PState {
       }
       hipIpcMemHandle_t hs[3];
       std::memcpy(hs, all_handles + (size_t)g * kP2PHandleBytes, sizeof hs);
+      const char* bus = reinterpret_cast<const char*>(all_handles) + (size_t)g * kP2PHandleBytes + sizeof hs;
+      if (bus[0] && std::strncmp(bus, own_bus, kBusIdBytes) == 0) n_sharing += 1;
       void *ps = nullptr, *pm = nullptr, *pi = nullptr;
       RR_HIP_TRY(hipIpcOpenMemHandle(&ps, hs[0], hipIpcMemLazyEnablePeerAccess));
       opened[n_opened++] = ps;
@@ -613,6 +585,8 @@ inline rr_status p2p_link_local(P2PState* const* states, double* const* slabs, c
     states[g]->peers = p;
     states[g]->ready = true;
     states[g]->seq = 0;
+    states[g]->n_sharing = 0;
+    for (int k = 0; k < n_ranks; ++k) states[g]->n_sharing += devices[k] == devices[g] ? 1 : 0;
   }
   return RR_OK;
 }

@@ -194,8 +194,8 @@ __global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __r
 //
 // Sharded (rr_pf_shard_step_p2p, StepSrc::kSrcWindow): the markers live in the GLOBAL slot index (rr::resolve_tile_window);
 // the own slots inside the window this shard serves are resolved and read exactly as on one GPU, the few outside it were
-// delivered into this rank's inbox by the peer that serves them (from inside its plan kernel) -- such a slot waits, bounded,
-// for its own tag of the previous step.  Round 2 resolved every served slot in a separate launch
+// delivered into this rank's inbox by the peer that serves them (k_push_window) -- such a slot waits, bounded, until the seal
+// of the previous step fits its fields (rr::inbox_take).  Round 2 resolved every served slot in a separate launch
 // (k_resolve_push -> lidx, 7.9 us at 1e6 particles) and waited for a DONE message in a fourth one.
 constexpr unsigned int kInPlace = 0xffffffffu;
 constexpr unsigned kPushGrid = 64;  // workgroups of k_push_window (grid-stride over the foreign tiles: usually a handful)
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
       pos0 = own0 + tile_base;
       rr::resolve_tile_window(markers, carry, own0 / rr::kResolveSlots + tile, win_lo, win_hi, own0, own0 + p.n, idx);
       const uint64_t pos1 = pos0 + rr::kResolveSlots < own0 + p.n ? pos0 + rr::kResolveSlots : own0 + p.n;
-      (void)pos1;  // (a slot a peer serves waits for its own delivery below: the tag plane of the inbox)
+      (void)pos1;  // (a slot a peer serves waits for its own delivery below: the seal plane of the inbox)
     } else if (pending) {
       rr::resolve_tile(markers, carry, p.n, tile, idx);
     } else {
@@ -299,10 +299,11 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
           // delivered by a peer into this rank's inbox [4 fields + tag][n]: wait (bounded) for THIS slot's tag of the step
           // whose resample is being consumed, then read its fields.  (n_ranks == 0: the RCCL transport -- an earlier kernel
           // of this stream filled the inbox.)
-          if (wa.n_ranks > 0) (void)rr::inbox_await(wa.inbox, p.n, k, wa.wait_seq, wa.timeout_ticks, wa.err);
-          x[r] = rr::ld_sys(wa.inbox + k);
-          y[r] = rr::ld_sys(wa.inbox + p.n + k);
-          yaw[r] = rr::ld_sys(wa.inbox + 2 * p.n + k);
+          double f[4];
+          (void)rr::inbox_take(wa.inbox, p.n, k, wa.n_ranks > 0 ? wa.wait_seq : (uint64_t)0, wa.timeout_ticks, wa.err, f);
+          x[r] = f[0];
+          y[r] = f[1];
+          yaw[r] = f[2];
         } else if (PACKED && pending) {
           const double4 rec = *reinterpret_cast<const double4*>((src ? pk1 : pk0) + 4 * j);
           x[r] = rec.x;
@@ -1015,9 +1016,8 @@ __global__ __launch_bounds__(kBlock) void k_resolve_gather_p2p(Bufs b, const Ctl
 // sources feed, [served_first, +served_count) + pad, sticks out of its own block [own0, own0 + n) on either side by the
 // drift of the cumulative weight across the block boundaries (10^3 - 10^4 slots of 10^6 in steady state, everything in
 // the worst case): those positions are resolved here, tile by tile (grid-stride over the foreign tiles only), and each
-// particle is stored into the owning rank's fine-grained inbox, fields first, then -- once those are acknowledged -- the slot's
-// tag (rr::inbox_tag).  Own positions are left to the next step's k_step_lazy.  (Shards of <= 2^20 particles deliver their
-// overhang from inside k_shard_plan_mark and never launch this kernel.)
+// particle is stored into the owning rank's fine-grained inbox, its four fields and the seal that vouches for them in one go
+// (rr::inbox_put).  Own positions are left to the next step's k_step_lazy.
 __global__ __launch_bounds__(kBlock) void k_push_window(Bufs b, const Ctl* __restrict__ ctl,
                                                        unsigned int* __restrict__ markers,
                                                        const unsigned int* __restrict__ carry, P2PPeers peers,
@@ -1038,7 +1038,6 @@ __global__ __launch_bounds__(kBlock) void k_push_window(Bufs b, const Ctl* __res
     const uint64_t lo = q < n_left ? l_lo : r_lo, hi = q < n_left ? l_hi : r_hi;  // positions this kernel consumes
     unsigned int idx[rr::kResolveRows];
     rr::resolve_tile_window(markers, carry, tile, win_lo, win_hi, lo, hi, idx);
-    bool stored = false;
 #pragma unroll
     for (int r = 0; r < rr::kResolveRows; ++r) {
       const uint64_t pos = tile * S + (uint64_t)r * kBlock + threadIdx.x;
@@ -1046,22 +1045,8 @@ __global__ __launch_bounds__(kBlock) void k_push_window(Bufs b, const Ctl* __res
         const uint64_t s = pos - pad;  // global slot
         const uint64_t d = s / n_local, li = s - d * n_local;
         const uint64_t j = idx[r];
-        double* __restrict__ out = peers.inbox[d];  // fine-grained, [4 fields + tag][n_local]
-        rr::st_sys(out + li, b.x[src][j]);
-        rr::st_sys(out + n_local + li, b.y[src][j]);
-        rr::st_sys(out + 2 * n_local + li, b.yaw[src][j]);
-        rr::st_sys(out + 3 * n_local + li, b.v[src][j]);
-        stored = true;
-      }
-    }
-    if (stored) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (system-scope stores) acknowledged = in the owner's memory ...
-#pragma unroll
-    for (int r = 0; r < rr::kResolveRows; ++r) {  // ... then each slot's tag says so
-      const uint64_t pos = tile * S + (uint64_t)r * kBlock + threadIdx.x;
-      if (pos >= lo && pos < hi) {
-        const uint64_t s = pos - pad;
-        const uint64_t d = s / n_local;
-        rr::inbox_tag(peers.inbox[d], n_local, s - d * n_local, seq);
+        // fine-grained, [4 fields + seal][n_local]: the five words in one go, the seal vouches for them (rr::inbox_put)
+        rr::inbox_put(peers.inbox[d], n_local, li, seq, b.x[src][j], b.y[src][j], b.yaw[src][j], b.v[src][j]);
       }
     }
   }
@@ -1124,7 +1109,7 @@ __global__ __launch_bounds__(kBlock) void k_unpack_inbox(const double* __restric
 }
 
 // accessors: make a pending window resample real -- own slots inside the window through the markers, the others out of
-// the inbox (peer-to-peer transport: each after its own tag has arrived); k_settle flips the live set afterwards
+// the inbox (peer-to-peer transport: each as soon as its seal fits); k_settle flips the live set afterwards
 __global__ __launch_bounds__(kBlock) void k_resolve_gather_window(Bufs b, const Ctl* __restrict__ ctl,
                                                                  unsigned int* __restrict__ markers,
                                                                  const unsigned int* __restrict__ carry, uint64_t n,
@@ -1144,11 +1129,12 @@ __global__ __launch_bounds__(kBlock) void k_resolve_gather_window(Bufs b, const 
     if (k >= n) continue;
     const uint64_t pos = own0 + k;
     if (pos < win_lo || pos >= win_hi) {
-      if (wait_seq) (void)rr::inbox_await(inbox, n, k, wait_seq, timeout_ticks, err);
-      b.x[dst][k] = rr::ld_sys(inbox + k);
-      b.y[dst][k] = rr::ld_sys(inbox + n + k);
-      b.yaw[dst][k] = rr::ld_sys(inbox + 2 * n + k);
-      b.v[dst][k] = rr::ld_sys(inbox + 3 * n + k);
+      double f[4];
+      (void)rr::inbox_take(inbox, n, k, wait_seq, timeout_ticks, err, f);
+      b.x[dst][k] = f[0];
+      b.y[dst][k] = f[1];
+      b.yaw[dst][k] = f[2];
+      b.v[dst][k] = f[3];
       if (idx_out) idx_out[k] = kInPlace;
     } else {
       const uint64_t j = idx[r];
@@ -1542,6 +1528,7 @@ struct rr_pf {
   uint64_t grid_epoch = 0;
   uint64_t grid_capacity = 0;
   uint64_t plan_giveups = 0;  // launches of the one-launch plan that degraded to the serial plan (seen at the last read of Ctl)
+  int dev_cus = 0;
   uint64_t shard_capacity = ~0ull;  // the same for k_shard_plan_mark (sharded step over the peer-to-peer transport); ~0: not asked yet
   unsigned int* est_ticket = nullptr;  // arrival counters of its last-workgroup reduction (rr::last_arrival; zero between launches)
   double* scratch_a = nullptr;  // n doubles: explicit noise v / uniforms / AoS staging (5n)
@@ -3248,7 +3235,7 @@ rr_status rr_pf_p2p_export(rr_pf* h, uint8_t out[RR_P2P_HANDLE_BYTES]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!out) return fail(RR_INVALID_PARAMETER, "null output");
-  return h->p2p.export_handles(h->slab, 5 * h->n, out);  // inbox: 4 fields + the tag plane
+  return h->p2p.export_handles(h->slab, 5 * h->n, out);  // inbox: 4 fields + the seal plane
 }
 
 rr_status rr_pf_p2p_connect(rr_pf* h, const uint8_t* all_handles, int32_t n_ranks, int32_t rank) {
@@ -3280,13 +3267,15 @@ rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
   return rr::p2p_link_local(st, slabs, inboxes, devs, n_ranks);
 }
 
-// TWO launches: k_step_lazy<kSrcWindow> (propagate + weight; the own slots inside the window this shard served last step
+// THREE launches: k_step_lazy<kSrcWindow> (propagate + weight; the own slots inside the window this shard served last step
 // are resolved from the markers and read in place exactly as on one GPU, the few a peer served come out of the inbox, each
-// after its own tag has arrived) | k_shard_plan_mark (WMAX exchange, integer image, SUMS exchange, gate + plan, markers for
-// the own block over the global slot index, and the window's overhang over the own block delivered from the SOURCE side into
-// the owners' inboxes: fields, acknowledgement, tags).  Shards beyond 2^20 particles take the plan as four launches (WMAX
-// exchange | k_quantize_reduce | k_scan_exchange | k_mark) and deliver with k_push_window.  Round 2: 4 launches with a
-// full-size resolve pass (k_resolve_push, 7.9 us at 1e6 particles) and a DONE exchange everybody waited in.
+// as soon as its own seal fits) | k_shard_plan_mark (WMAX exchange, integer image, SUMS exchange, gate + plan, markers for the
+// served window over the global slot index) | k_push_window (the window's overhang over the own block, resolved and stored
+// into the owners' inboxes, every slot sealed -- no acknowledgement round trip, no DONE message).  Shards beyond 2^20
+// particles, or several ranks on one device, take the plan as four launches (WMAX exchange | k_quantize_reduce |
+// k_scan_exchange | k_mark).  Round 2: 4 launches with a full-size resolve pass (k_resolve_push, 7.9 us at 1e6 particles) and
+// a DONE exchange everybody waited in.  (Delivering the overhang from inside the plan kernel, source side, was built and
+// measured in round 3: DESIGN.md section 5 -- it loses to this on every count.)
 rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
@@ -3305,7 +3294,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   wa.inbox = h->p2p.inbox;
   wa.err = h->p2p.err;
   wa.pad = h->slot_pad;
-  wa.wait_seq = h->window_seq;  // the DONE of the step whose resample this launch consumes
+  wa.wait_seq = h->window_seq;  // the step whose resample this launch consumes (its deliveries carry that seal)
   wa.timeout_ticks = h->p2p.peers.timeout_ticks;
   wa.n_ranks = h->p2p.peers.n_ranks;
   const uint64_t seq = ++h->p2p.seq;
@@ -3330,25 +3319,21 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
     int per_cu = 0, dev_cus = 0;
     RR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rr::k_shard_plan_mark, rr::kTileBlock, 0));
     RR_HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
+    h->dev_cus = dev_cus;
     h->shard_capacity = h->grid_capacity ? std::min<uint64_t>((uint64_t)per_cu * (uint64_t)dev_cus, (uint64_t)rr::kTileBlock) : 0;
   }
-  bool pushed = false;
-  if (h->n_tiles <= h->shard_capacity && rr::spin_permit(h->opt.device, h)) {
-    // exchange 1 + B + exchange 2 + C + the overhang's delivery + DONE in one launch (k_shard_plan_mark)
+  // Ranks that share this device (a test rig: several shards of one filter on one GPU) run their kernels beside this one's;
+  // a plan kernel that spins on every CU would leave a peer's exchange workgroup -- the one it is waiting for -- nowhere to
+  // go (seen as stalls of seconds with two 1e6-particle shards on one device).  All sharers together keep to one
+  // workgroup per CU.
+  const uint64_t fused_cap = h->p2p.n_sharing > 1 ? std::min<uint64_t>(h->shard_capacity, (uint64_t)h->dev_cus / (uint64_t)h->p2p.n_sharing)
+                                                  : h->shard_capacity;
+  if (h->n_tiles <= fused_cap && rr::spin_permit(h->opt.device, h)) {
+    // exchange 1 + B + exchange 2 + C in one launch (k_shard_plan_mark)
     Timed t(h, RR_K_CDF);
-    static const bool push_inside = [] { const char* e = std::getenv("RR_P2P_PUSH_IN_PLAN"); return !e || std::atoi(e) != 0; }();
-    rr::ShardPush sp{};
-    for (int k = 0; k < 2; ++k) {
-      sp.f[k][0] = h->b.x[k];
-      sp.f[k][1] = h->b.y[k];
-      sp.f[k][2] = h->b.yaw[k];
-      sp.f[k][3] = h->b.v[k];
-    }
-    sp.enable = push_inside ? 1 : 0;
-    pushed = push_inside;
     hipLaunchKernelGGL(rr::k_shard_plan_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->p2p.peers, seq,
                        (const double*)h->w, h->ctl, image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, /*settle=*/1,
-                       h->n_tiles, pa, h->markers, h->carry, gathered, h->p2p.err, h->slot_pad, sp);
+                       h->n_tiles, pa, h->markers, h->carry, gathered, h->p2p.err, h->slot_pad);
   } else {
     // exchange 1: global maximum -> Ctl.wmax
     hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PWmax, seq,
@@ -3371,9 +3356,9 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   h->wmax_live = false;
   h->wmax_bits_clean = true;
   h->rstep += 1;
-  // D: the overhang of the served window goes to its owners; the last workgroup sends DONE (k_push_window) -- unless the plan
-  // kernel has done both already
-  if (!pushed) {
+  // D: the overhang of the served window goes to its owners, every slot sealed (k_push_window); a filter of one rank has
+  // no peers and its window is its own block
+  if (h->p2p.peers.n_ranks > 1) {
     Timed t(h, RR_K_RESAMPLE_GATHER);
     hipLaunchKernelGGL(k_push_window, dim3(kPushGrid), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->markers, h->carry, h->p2p.peers,
                        h->n, h->slot_pad, seq);

@@ -509,31 +509,21 @@ static_assert(kGuideTile == kResolveSlots, "the guide table is resolved by resol
 
 // this thread's 8 consecutive sources: exclusive CDF prefix `off`, inclusive prefixes off + c[j]
 // offspring (may be null): number of output slots each of this thread's sources feeds
-// runs (may be null): the position run [lo, hi) of each of this thread's sources (lo == hi: none).  clip (window layout of a
-// shard whose overhang is delivered by the marking kernel itself): markers and carries are only written inside
-// [clip_lo, clip_hi) -- nobody would ever consume (and clear) the others.
-struct SlotRun {
-  uint64_t lo, hi;
-};
 __device__ inline void mark_sources(const TileScan& t, uint64_t off, uint64_t i0, uint64_t n, const rr_sys_plan plan,
                                     uint64_t total, uint64_t slot_base, unsigned int* __restrict__ markers,
-                                    unsigned int* __restrict__ carry, unsigned int* offspring = nullptr, SlotRun* runs = nullptr,
-                                    uint64_t clip_lo = 0, uint64_t clip_hi = ~0ull) {
+                                    unsigned int* __restrict__ carry, unsigned int* offspring = nullptr) {
   const rr_sys_inv inv = rr_sys_inv_make(plan, total);
   uint64_t h_run = rr_sys_slots_upto(plan, inv, total, off);  // H of the source just before this thread's first
 #pragma unroll
   for (int j = 0; j < kItems; ++j) {
     if (offspring) offspring[j] = 0;
-    if (runs) runs[j] = SlotRun{0, 0};
     if (t.q[j] == 0 || i0 + j >= n) continue;  // zero-weight sources feed no slot: H_j == H_{j-1}
     const uint64_t h = rr_sys_slots_upto(plan, inv, total, off + t.c[j]);
     if (h > h_run) {
       if (offspring) offspring[j] = (unsigned int)(h - h_run);
       const uint64_t lo = h_run - slot_base, hi = h - slot_base;
-      if (runs) runs[j] = SlotRun{lo, hi};
-      if (lo >= clip_lo && lo < clip_hi) markers[lo] = (unsigned int)(i0 + j + 1);
-      const uint64_t cl = lo > clip_lo ? lo : clip_lo, ch = hi < clip_hi ? hi : clip_hi;
-      for (uint64_t b = (cl + kResolveSlots - 1) / kResolveSlots; b * kResolveSlots < ch; ++b)
+      markers[lo] = (unsigned int)(i0 + j + 1);
+      for (uint64_t b = (lo + kResolveSlots - 1) / kResolveSlots; b * kResolveSlots < hi; ++b)
         carry[b] = (unsigned int)(i0 + j + 1);
       h_run = h;
     }

@@ -680,47 +680,72 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
             return s
 
         p2p = attempt("peer-to-peer transport", make_p2p)
-        if p2p is not None:
-            whole = None
-            if ref is None:  # no reference transport: compare with the unsharded filter of all the particles
-                import rust_robotics_amd.localization as loc
+    # ---- run-time proof on THIS machine, before anything is timed: V steps of every transport that could be set up, next to the
+    # UNSHARDED filter of all n_local * world particles on every rank (systematic shards; it fits one GPU up to tens of millions
+    # of particles) -- both native transports share the window kernels, so agreeing with each other would not be enough
+    validated_ref = False
+    if (ref is not None or p2p is not None) and not multinomial and n_local * world <= (1 << 25):
+        import rust_robotics_amd.localization as loc
 
-                cfg = loc.MonteCarloLocalizationConfig(min_particles=n_local * world, max_particles=n_local * world)
-                whole = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=local_rank,
-                                                                   resample_scheme=_ffi.RR_RESAMPLE_SYSTEMATIC, likelihood_mode=lik)
-            alive = True
-            for t in range(V):
+        cfg = loc.MonteCarloLocalizationConfig(min_particles=n_local * world, max_particles=n_local * world)
+        whole = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=local_rank,
+                                                           resample_scheme=_ffi.RR_RESAMPLE_SYSTEMATIC, likelihood_mode=lik)
+        alive = True
+        for t in range(V):
+            if p2p is not None and alive:
                 p2p.step(u, obs_list[t])
-                (ref.step if ref is not None else whole.step_async)(u, obs_list[t])
-                if t == 0:  # a dead transport shows on the first exchange: stop before it costs more
-                    alive = agree(not p2p.timed_out())
-                    if not alive:
-                        break
-            why = ""
-            if alive and not p2p.timed_out():
-                exp = ref.particles() if ref is not None else whole.get_particles_array()[rank * n_local:(rank + 1) * n_local]
-                got = p2p.particles().view(np.uint64)
-                exp = np.ascontiguousarray(exp).view(np.uint64)
-                same = np.array_equal(got, exp)
-                if not same:
-                    why = f"rank {rank}: {int(np.any(got != exp, axis=1).sum())} of {n_local} particles differ"
+            if ref is not None:
+                ref.step(u, obs_list[t])
+            whole.step_async(u, obs_list[t])
+            if t == 0 and p2p is not None:  # a dead transport shows on the first exchange: stop before it costs more
+                alive = agree(not p2p.timed_out())
+        exp = np.ascontiguousarray(whole.get_particles_array()[rank * n_local:(rank + 1) * n_local]).view(np.uint64)
+        del whole
+
+        def check(name, shard, dead):
+            if dead:
+                why, same = f"rank {rank}: a wait for a peer's flag gave up", False
             else:
-                same = False
-                why = f"rank {rank}: a wait for a peer's flag gave up" + ("" if alive else " on the first exchange")
-            if not same:  # every rank says what it saw (stderr), not only the one whose notes end up in the line
-                detail = why
-                if alive and not p2p.timed_out():
+                got = np.ascontiguousarray(shard.particles()).view(np.uint64)
+                same = np.array_equal(got, exp)
+                why = ""
+                if not same:
                     bad = np.nonzero(np.any(got != exp, axis=1))[0]
                     cols = [int(np.count_nonzero(got[:, k] != exp[:, k])) for k in range(got.shape[1])]
-                    detail += f"; differing rows first {bad[:4].tolist()} last {bad[-4:].tolist()}, per column {cols}"
-                log("VALIDATION MISMATCH: " + detail)
-            use_p2p = agree(same)
-            log("peer-to-peer transport " + ("validated" if use_p2p else "failed validation"))
-            against = f"the {ref_kind} transport" if ref is not None else "the unsharded filter of all particles"
-            notes.append(f"peer-to-peer transport validated bit-identical to {against} over {V} steps" if use_p2p else
-                         f"peer-to-peer transport FAILED validation against {against}" +
-                         (f" ({why})" if why else " (on another rank)"))
-            del whole
+                    why = (f"rank {rank}: {bad.size} of {n_local} particles differ; rows first {bad[:4].tolist()} last {bad[-4:].tolist()}, "
+                           f"per column {cols}")
+                    log(f"VALIDATION MISMATCH ({name}): " + why)  # every rank says what it saw (stderr)
+            ok = agree(same)
+            notes.append(f"{name} validated bit-identical to the unsharded filter of all particles over {V} steps" if ok else
+                         f"{name} FAILED validation against the unsharded filter of all particles" + (f" ({why})" if why else " (on another rank)"))
+            log(f"{name} " + ("validated" if ok else "failed validation"))
+            return ok
+
+        if ref is not None:
+            validated_ref = check(f"{ref_kind} transport", ref, False)
+            if not validated_ref:
+                ref.close()
+                ref, ref_kind = None, None
+        if p2p is not None:
+            dead = (not alive) or p2p.timed_out()
+            use_p2p = check("peer-to-peer transport", p2p, dead)
+    elif p2p is not None and ref is not None:
+        # (multinomial shards / a filter too large for one GPU: the peer-to-peer transport against the reference transport)
+        alive = True
+        for t in range(V):
+            p2p.step(u, obs_list[t])
+            ref.step(u, obs_list[t])
+            if t == 0:
+                alive = agree(not p2p.timed_out())
+                if not alive:
+                    break
+        same = False
+        if alive and not p2p.timed_out():
+            same = np.array_equal(np.ascontiguousarray(p2p.particles()).view(np.uint64), np.ascontiguousarray(ref.particles()).view(np.uint64))
+        use_p2p = agree(same)
+        validated_ref = True  # (its V steps are done)
+        notes.append(f"peer-to-peer transport " + (f"validated bit-identical to the {ref_kind} transport over {V} steps" if use_p2p else
+                                                   f"FAILED validation against the {ref_kind} transport"))
     if not use_p2p and ref is None:
         if p2p is not None:  # leave nothing behind on the device: its stream drained, the spin permit and the IPC mappings released
             try:
@@ -789,7 +814,7 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
 
     shard = p2p if use_p2p else ref
     log("timed region on " + ("the peer-to-peer transport" if use_p2p else f"the {ref_kind} transport"))
-    if p2p is None:  # no validation ran: the reference transport has not seen the first V steps yet
+    if not validated_ref and not use_p2p:  # no validation ran on it: the reference transport has not seen the first V steps yet
         for t in range(V):
             ref.step(u, obs_list[t])
     seconds = timed_region(shard)
