@@ -8,15 +8,17 @@
 // touching 64 consecutive particles of one landmark field is one coalesced 512-byte access, the
 // observation list is wave-uniform (LDS), and the systematic resample is a monotone plane gather.
 //
-// Kernels of one update (rr_fs1_update_async): 5 launches
-//   k_fs1_predict      pose planes (through idx when a resample is pending)          48 B / particle
+// Kernels of one update (rr_fs1_update_async): 3 launches (round 2: 5)
+//   k_fs1_resolve_predict   the last plan's markers -> idx[] (the update reads every observed landmark through it: lazy
+//                      gather) and the pose planes moved through it                   48 B / particle
 //   k_fs1_observe      (particle, observation chunk): 2x2 EKF per observed landmark,
 //                      R 48 B + W 48 B per (particle, landmark) update               <- dominant
-//   k_fs1_combine      partial weight products (chunk order) -> weight, running maximum
+//                      the last chunk's workgroup of a particle block forms the weight (product of the chunks' factors in
+//                      chunk order) and the block's maximum
 //   rr::k_quantize_plan_mark<FS_WEIGHTS>   integer image + gate + w /= sum or slot-run markers + w = 1/n, one launch
 //                      (resample_core.hpp; beyond 2^20 particles rr::k_quantize_reduce + k_fs1_plan)
-//   k_fs1_resolve      markers -> idx[] (the next update reads every observed landmark through it: lazy gather)
 // and of the separate / sharded entry points:
+//   k_fs1_predict, k_fs1_resolve   the two halves of k_fs1_resolve_predict on their own
 //   rr::k_scan_tiles / k_cdf, k_fs1_normalize, k_fs1_indices(_sharded)   integer CDF, CDF search per output slot
 //   k_fs1_gather       out[plane][k] = in[plane][idx[k]] over 3 + 6L planes          16 B / element
 #include <hip/hip_runtime.h>
@@ -88,6 +90,79 @@ __global__ __launch_bounds__(kBlock) void k_fs1_predict(Planes pl, const Ctl* __
   dst[2 * n + p] = yaw;
 }
 
+// observations of an update staged through the first kernel (k_fs1_resolve_predict)
+constexpr int kZStagePerThread = 4;              // words one thread of the staging workgroup carries
+constexpr int kZStageWords = kZStagePerThread * kBlock;  // 1024 doubles = 341 observations; more: hipMemcpyAsync as before
+constexpr int kZRing = 32;                       // pinned slots: the host runs at most this many updates ahead of the device
+struct ZStage {
+  const double* host;  // pinned, device-visible: 3 * n_z doubles of this update
+  double* dev;         // where k_fs1_observe reads them
+  uint64_t* done;      // pinned: sequence number of the last slot the device has consumed
+  uint64_t seq;
+  int words;           // 0: nothing to stage
+};
+
+// The same with the resample plan's markers resolved on the way (single GPU, FastSLAM 1.0): the plan kernel leaves markers,
+// the first kernel of the NEXT update turns them into source indices (running maximum per 2048 slots, rr::resolve_tile), keeps
+// them in idx[] for k_fs1_observe / k_fs1_gather and moves the poses through them -- one launch instead of k_fs1_resolve at
+// the end of an update and k_fs1_predict at the start of the next.
+__global__ __launch_bounds__(kBlock) void k_fs1_resolve_predict(Planes pl, const Ctl* __restrict__ ctl, uint64_t n, double u0, double u1,
+                                                               rr_fs1_model m, uint64_t seed, unsigned int step,
+                                                               unsigned int* __restrict__ markers, const unsigned int* __restrict__ carry,
+                                                               unsigned int* __restrict__ idx, uint64_t gid0, ZStage zs) {
+  // The update's observations come along: the host has left them in a pinned slot, the last workgroup reads them over the
+  // bus while it does its share of the poses and leaves them in device memory for k_fs1_observe -- no H2D copy operation in
+  // the stream (4.7 us blit kernel + a boundary per update at 200 observations; they do not fit a kernel argument).
+  const bool stager = zs.words > 0 && blockIdx.x == gridDim.x - 1;
+  double zv[kZStagePerThread];
+  if (stager) {
+#pragma unroll
+    for (int k = 0; k < kZStagePerThread; ++k) {
+      const int i = k * kBlock + (int)threadIdx.x;
+      zv[k] = i < zs.words ? rr::ld_sys(zs.host + i) : 0.0;
+    }
+  }
+  const bool pending = ctl->pending != 0;  // uniform
+  unsigned int from[rr::kResolveRows];
+  if (pending) rr::resolve_tile(markers, carry, n, blockIdx.x, from);
+  const double* __restrict__ src = pl.s[ctl->cur];
+  double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
+  double x[rr::kResolveRows], y[rr::kResolveRows], yaw[rr::kResolveRows];
+#pragma unroll
+  for (int r = 0; r < rr::kResolveRows; ++r) {  // every row's loads first
+    const uint64_t p = (uint64_t)blockIdx.x * rr::kResolveSlots + (uint64_t)r * kBlock + threadIdx.x;
+    x[r] = y[r] = yaw[r] = 0.0;
+    if (p < n) {
+      const uint64_t j = pending ? (uint64_t)from[r] : p;
+      if (pending) idx[p] = from[r];
+      x[r] = src[j];
+      y[r] = src[n + j];
+      yaw[r] = src[2 * n + j];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < rr::kResolveRows; ++r) {
+    const uint64_t p = (uint64_t)blockIdx.x * rr::kResolveSlots + (uint64_t)r * kBlock + threadIdx.x;
+    if (p < n) {
+      double a, b;
+      rr_fs1_motion_noise(seed, step, gid0 + p, &a, &b);
+      rr_fs1_predict_one(&x[r], &y[r], &yaw[r], u0, u1, a, b, m);
+      dst[p] = x[r];
+      dst[n + p] = y[r];
+      dst[2 * n + p] = yaw[r];
+    }
+  }
+  if (stager) {
+#pragma unroll
+    for (int k = 0; k < kZStagePerThread; ++k) {
+      const int i = k * kBlock + (int)threadIdx.x;
+      if (i < zs.words) zs.dev[i] = zv[k];
+    }
+    __syncthreads();  // every thread's loads of the slot have returned (their values have been stored)
+    if (threadIdx.x == 0) rr::st_sys_u64(zs.done, zs.seq);  // the host may reuse the slot
+  }
+}
+
 // FastSLAM 2.0 (fastslam2.rs:339-358): the pose is not pushed through the noisy motion model but
 // SAMPLED from the proposal that fuses the motion prior with the first observation of the step --
 // per particle a 3x3 prior, a 2x2 innovation covariance, two 3x3 inverses, a Cholesky factor and
@@ -144,19 +219,31 @@ __global__ __launch_bounds__(kBlock) void k_fs2_predict(Planes pl, const Ctl* __
 // (The memory pattern alone -- same grid, same pipeline, synthetic arithmetic -- is tools/ubench/plane_layout.hip: 5.2-5.4 TB/s
 // whether 0 or 300 FMAs sit between a wave's loads and its stores; this kernel runs at 5.25 TB/s.)
 constexpr int kObsNtStore = 1, kObsNtLoad = 2, kObsNoPipe = 4, kObsFourWaves = 8;
+constexpr uint64_t kNoFactor = 0x7FF45EA1ED000001ull;  // "no factor here yet": a signalling NaN (k_fs1_observe)
+constexpr uint64_t kFactorWaitTicks = 200000000ull;    // 2 s of the 100 MHz wall clock
+
+__global__ __launch_bounds__(kBlock) void k_fs1_no_factors(uint64_t* __restrict__ partial, uint64_t words) {
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < words; i += (uint64_t)gridDim.x * kBlock) partial[i] = kNoFactor;
+}
 
 template <bool LAZY, bool SEQ, int VAR>
 __global__ __launch_bounds__(kBlock, (VAR & kObsFourWaves) ? 4 : 1) void k_fs1_observe(
     Planes pl, double* __restrict__ pw, Ctl* __restrict__ ctl, uint64_t n, const double* __restrict__ z, int n_z, int chunk_len,
-    int n_chunks, rr_fs1_model m, double* __restrict__ partial, const unsigned int* __restrict__ idx) {
+    int n_chunks, rr_fs1_model m, double* partial /* written by the other chunks while the closing one reads */,
+    const unsigned int* __restrict__ idx, unsigned int n_pblocks) {
   extern __shared__ double s_z[];
   __shared__ double s_wmax[kBlock / rr::kWave];
-  const int chunk = blockIdx.y;
+  // Dispatch order (one-dimensional grid of n_pblocks x n_chunks workgroups): chunk by chunk, a chunk's particle blocks side
+  // by side -- the order the memory system likes (block by block, all chunks of a block side by side: 20 % slower; bands of
+  // blocks, each band chunk by chunk: no better, RR_FS1_BANDS experiment of round 3).  A block's last chunk is therefore
+  // dispatched after its other chunks; it forms the block's weights (below).
+  const int chunk = (int)(blockIdx.x / n_pblocks);
+  const unsigned int pblock = blockIdx.x % n_pblocks;
   const int k0 = chunk * chunk_len;
   const int k1 = min(k0 + chunk_len, n_z);
   for (int i = threadIdx.x; i < 3 * (k1 - k0); i += kBlock) s_z[i] = z[3 * k0 + i];
   __syncthreads();
-  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  const uint64_t p = (uint64_t)pblock * kBlock + threadIdx.x;
   double acc = 0.0;
   if (p < n) {
     // LAZY + pending: the maps of slot p still sit at particle idx[p] of the live set; every observed
@@ -228,10 +315,50 @@ __global__ __launch_bounds__(kBlock, (VAR & kObsFourWaves) ? 4 : 1) void k_fs1_o
         store6(dst + (3 + id * 6) * n + p, e);
       }
     }
-    if (n_chunks == 1) pw[p] = acc;
-    else partial[(uint64_t)chunk * n + p] = acc;
   }
-  if (n_chunks == 1) {
+  // The weight is the product of the chunks' factors in chunk order (the D-spec's).  The LAST chunk's workgroup of a
+  // particle block forms it: the other chunks leave their factor in `partial` and are done -- no wait, no ticket, nothing at
+  // their end -- and the last chunk, dispatched after the others, reads the factors back when its own updates are through.
+  // A factor that has not landed yet shows as kNoFactor, a signalling-NaN pattern no arithmetic produces (results are quiet
+  // NaNs); the reader looks again (bounded: Ctl.obs_timeout) and puts the pattern back for the next update.  No
+  // k_fs1_combine launch (round 2: 10.8 - 12.5 us + a launch boundary at 1e5 particles x 25 chunks).
+  const bool closing = chunk == n_chunks - 1;  // uniform per workgroup
+  if (!closing) {
+    if (p < n) rr::st_dev(reinterpret_cast<uint64_t*>(&partial[(uint64_t)chunk * n + p]), rr_d2u(acc));  // device scope: read from any XCD
+  } else if (n_chunks > 1) {
+    if (p < n) {
+      double w = 1.0;
+      constexpr int kBatch = 16;  // loads in flight
+      for (int c0 = 0; c0 < n_chunks - 1; c0 += kBatch) {
+        uint64_t f[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k)
+          f[k] = c0 + k < n_chunks - 1 ? rr::ld_dev(reinterpret_cast<const uint64_t*>(&partial[(uint64_t)(c0 + k) * n + p])) : rr_d2u(1.0);
+#pragma unroll
+        for (int k = 0; k < kBatch; ++k) {
+          if (c0 + k >= n_chunks - 1) continue;  // a chunk past the end contributes an exact factor 1
+          uint64_t* slot = reinterpret_cast<uint64_t*>(&partial[(uint64_t)(c0 + k) * n + p]);
+          if (f[k] == kNoFactor) {
+            const uint64_t t0 = wall_clock64();
+            while ((f[k] = rr::ld_dev(slot)) == kNoFactor) {
+              __builtin_amdgcn_s_sleep(8);
+              if (wall_clock64() - t0 > kFactorWaitTicks) {
+                ctl->obs_timeout = 1;
+                break;
+              }
+            }
+          }
+          rr::st_dev(slot, kNoFactor);
+          w = (c0 + k == 0) ? rr_u2d(f[k]) : w * rr_u2d(f[k]);
+        }
+      }
+      acc = w * acc;  // this chunk's own factor is the last one
+      pw[p] = acc;
+    }
+  } else if (p < n) {
+    pw[p] = acc;
+  }
+  if (closing) {
     double mx = acc > 0.0 ? acc : 0.0;
     mx = rr::wave_max(mx);
     if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = mx;
@@ -241,36 +368,6 @@ __global__ __launch_bounds__(kBlock, (VAR & kObsFourWaves) ? 4 : 1) void k_fs1_o
       for (int k = 1; k < kBlock / rr::kWave; ++k) bm = s_wmax[k] > bm ? s_wmax[k] : bm;
       if (bm > 0.0) rr::atomic_max_u64(&ctl->wmax_bits, rr_d2u(bm));
     }
-  }
-}
-
-// weight = partial[0] * partial[1] * ... (chunk order), max into Ctl
-__global__ __launch_bounds__(kBlock) void k_fs1_combine(double* __restrict__ pw, Ctl* __restrict__ ctl, uint64_t n,
-                                                       const double* __restrict__ partial, int n_chunks) {
-  __shared__ double s_wmax[kBlock / rr::kWave];
-  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  double w = 0.0;
-  if (p < n) {
-    // the product keeps its chunk order (the D-spec's), the loads do not wait for it: eight in flight per thread, a
-    // chunk past the end contributes an exact factor 1  (18 -> 12 us at 1e5 particles x 25 chunks)
-    w = partial[p];
-    for (int c0 = 1; c0 < n_chunks; c0 += 8) {
-      double f[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) f[k] = c0 + k < n_chunks ? __builtin_nontemporal_load(&partial[(uint64_t)(c0 + k) * n + p]) : 1.0;
-#pragma unroll
-      for (int k = 0; k < 8; ++k) w *= f[k];
-    }
-    pw[p] = w;
-  }
-  double mx = w > 0.0 ? w : 0.0;
-  mx = rr::wave_max(mx);
-  if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = mx;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double bm = s_wmax[0];
-    for (int k = 1; k < kBlock / rr::kWave; ++k) bm = s_wmax[k] > bm ? s_wmax[k] : bm;
-    if (bm > 0.0) rr::atomic_max_u64(&ctl->wmax_bits, rr_d2u(bm));
   }
 }
 
@@ -688,6 +785,10 @@ struct rr_fs1 {
   int partial_chunks = 0;
   double* z_dev = nullptr;
   size_t z_cap = 0;
+  double* z_ring = nullptr;      // pinned [kZRing][kZStageWords]: observations on their way through k_fs1_resolve_predict
+  uint64_t* z_done = nullptr;    // pinned: last ring sequence number the device has consumed
+  uint64_t z_seq = 0;
+  bool z_staged = false;         // this update's observations are already on their way to z_dev
   double* noise = nullptr;  // 2n
   double* pose_stage = nullptr;  // 4n: AoS (w, x, y, yaw) image for get_state / set_state (the inactive set only holds 3n when L == 0)
   uint64_t* part_bits = nullptr;
@@ -699,6 +800,7 @@ struct rr_fs1 {
   bool wmax_live = false;  // Ctl.wmax_bits holds the maximum of the current weights
   bool wmax_bits_clean = false;  // Ctl.wmax_bits is known to be zero (the last plan kernel consumed and zeroed it)
   bool maybe_pending = false;  // a lazy resample plan was launched; its gather has not been consumed yet
+  bool idx_unresolved = false; // ... and its markers have not been turned into idx[] yet (ensure_resolved / k_fs1_resolve_predict)
   unsigned int* plane_list = nullptr;  // device: planes of the landmarks a lazy observe leaves untouched
   std::vector<unsigned int> plane_list_host;
   rr::Profiler prof{RR_FK_COUNT};
@@ -784,8 +886,62 @@ PlanArgs plan_args(const rr_fs1* h, int mode, double rho_override, bool lazy = f
 
 rr_fs1_model model_of(const rr_fs1* h) { return host_model(h->prm, h->algorithm, h->nonpos_det_w); }
 
+rr_status ensure_z_dev(rr_fs1* h, size_t n_z) {
+  if (n_z <= h->z_cap) return RR_OK;
+  // (a kernel that still reads the old buffer has been enqueued before this free: hipFree waits for the device)
+  if (h->z_dev) RR_HIP_TRY(hipFree(h->z_dev));
+  h->z_dev = nullptr;
+  h->z_cap = 0;
+  const size_t cap = std::max<size_t>(n_z, 64);
+  RR_HIP_TRY(hipMalloc(&h->z_dev, 3 * cap * sizeof(double)));
+  h->z_cap = cap;
+  return RR_OK;
+}
+
+// this update's observations into the next pinned slot; the kernel that gets `out` carries them to z_dev
+rr_status stage_z(rr_fs1* h, const double* z, size_t n_z, ZStage* out) {
+  *out = ZStage{};
+  if (n_z == 0 || 3 * n_z > (size_t)kZStageWords) return RR_OK;
+  if (rr_status s = ensure_z_dev(h, n_z); s != RR_OK) return s;
+  if (!h->z_ring) {
+    RR_HIP_TRY(hipHostMalloc(&h->z_ring, (size_t)kZRing * kZStageWords * sizeof(double), hipHostMallocDefault));
+    RR_HIP_TRY(hipHostMalloc(&h->z_done, sizeof(uint64_t), hipHostMallocDefault));
+    *h->z_done = 0;
+    h->z_seq = 0;
+  }
+  const uint64_t seq = ++h->z_seq;
+  // the slot's previous user (seq - kZRing) must have been consumed: the device says so in z_done
+  if (seq > (uint64_t)kZRing) {
+    volatile uint64_t* done = h->z_done;
+    if (*done + kZRing < seq) {
+      RR_HIP_TRY(hipStreamSynchronize(h->stream));  // (only when the host is kZRing updates ahead)
+      if (*done + kZRing < seq) return fail(RR_RUNTIME_ERROR, "observation staging ring: the device did not consume its slots");
+    }
+  }
+  double* slot = h->z_ring + (size_t)(seq % kZRing) * kZStageWords;
+  std::memcpy(slot, z, 3 * n_z * sizeof(double));
+  out->host = slot;
+  out->dev = h->z_dev;
+  out->done = h->z_done;
+  out->seq = seq;
+  out->words = (int)(3 * n_z);
+  return RR_OK;
+}
+
+// the markers of the last single-GPU plan -> idx[] (normally the next update's k_fs1_resolve_predict does it on the way)
+rr_status ensure_resolved(rr_fs1* h) {
+  if (!h->idx_unresolved) return RR_OK;
+  rr::ScopedTimer t(h->prof, h->stream, RR_FK_INDICES);
+  hipLaunchKernelGGL(k_fs1_resolve, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->ctl, h->markers,
+                     h->carry, h->n, h->idx);
+  RR_HIP_TRY(hipGetLastError());
+  h->idx_unresolved = false;
+  return RR_OK;
+}
+
 // make a pending lazy resample real: gather every plane, flip the live set
 rr_status materialise(rr_fs1* h) {
+  if (rr_status rs = ensure_resolved(h); rs != RR_OK) return rs;
   if (!h->maybe_pending) return RR_OK;
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_GATHER);
@@ -799,7 +955,22 @@ rr_status materialise(rr_fs1* h) {
 }
 
 template <bool EXPLICIT, bool LAZY>
-rr_status launch_predict(rr_fs1* h, const double u[2]) {
+rr_status launch_predict(rr_fs1* h, const double u[2], const double* z = nullptr, size_t n_z = 0) {
+  if (LAZY && !EXPLICIT && h->idx_unresolved && !h->pl.inbox) {  // resolve the last plan's markers on the way
+    ZStage zs{};
+    if (z && (n_z > 0)) {
+      if (rr_status st = stage_z(h, z, n_z, &zs); st != RR_OK) return st;
+    }
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_PREDICT);
+    hipLaunchKernelGGL(k_fs1_resolve_predict, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->pl, h->ctl, h->n,
+                       u[0], u[1], model_of(h), h->opt.seed, h->step, h->markers, (const unsigned int*)h->carry, h->idx, h->gid0, zs);
+    RR_HIP_TRY(hipGetLastError());
+    h->z_staged = zs.words > 0;
+    h->idx_unresolved = false;
+    h->step += 1;
+    return RR_OK;
+  }
+  if (rr_status rs = ensure_resolved(h); rs != RR_OK) return rs;
   rr::ScopedTimer t(h->prof, h->stream, RR_FK_PREDICT);
   hipLaunchKernelGGL((k_fs1_predict<EXPLICIT, LAZY>), dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl,
                      h->ctl, h->n, u[0], u[1], model_of(h), h->opt.seed, h->step, (const double*)h->noise,
@@ -817,6 +988,7 @@ rr_status launch_propose(rr_fs1* h, const double u[2], const double* z, size_t n
   m.m0 = h->motion_cov[0];
   m.m1 = h->motion_cov[1];
   m.m2 = h->motion_cov[2];
+  if (rr_status rs = ensure_resolved(h); rs != RR_OK) return rs;
   rr::ScopedTimer t(h->prof, h->stream, RR_FK_PREDICT);
   hipLaunchKernelGGL((k_fs2_predict<EXPLICIT, LAZY>), dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl, h->ctl,
                      h->n, u[0], u[1], m, h->opt.seed, h->step, (const double*)h->noise, (const unsigned int*)h->idx, h->gid0,
@@ -830,7 +1002,7 @@ rr_status launch_propose(rr_fs1* h, const double u[2], const double* z, size_t n
 template <bool LAZY>
 rr_status launch_motion(rr_fs1* h, const double u[2], const double* z, size_t n_z) {
   if (h->algorithm == 2) return launch_propose<false, LAZY>(h, u, z, n_z);
-  return launch_predict<false, LAZY>(h, u);
+  return launch_predict<false, LAZY>(h, u, z, n_z);
 }
 
 int choose_chunks(const rr_fs1* h, size_t n_z, bool dup) {
@@ -867,14 +1039,11 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool 
     h->wmax_live = true;
     return RR_OK;
   }
-  if (n_z > h->z_cap) {
-    if (h->z_dev) RR_HIP_TRY(hipFree(h->z_dev));
-    h->z_dev = nullptr;
-    h->z_cap = 0;
-    RR_HIP_TRY(hipMalloc(&h->z_dev, 3 * n_z * sizeof(double)));
-    h->z_cap = n_z;
+  if (!h->z_staged) {
+    if (rr_status zs = ensure_z_dev(h, n_z); zs != RR_OK) return zs;
+    RR_HIP_TRY(hipMemcpyAsync(h->z_dev, z, 3 * n_z * sizeof(double), hipMemcpyHostToDevice, h->stream));
   }
-  RR_HIP_TRY(hipMemcpyAsync(h->z_dev, z, 3 * n_z * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  h->z_staged = false;
   if (rr_status zs = zero_wmax(h); zs != RR_OK) return zs;
   h->wmax_live = true;
   const int chunks = choose_chunks(h, n_z, dup);
@@ -920,17 +1089,16 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool 
       h->partial_chunks = 0;
       RR_HIP_TRY(hipMalloc(&h->partial, (size_t)chunks * h->n * sizeof(double)));
       h->partial_chunks = chunks;
+      hipLaunchKernelGGL(k_fs1_no_factors, dim3(1024), dim3(kBlock), 0, h->stream, reinterpret_cast<uint64_t*>(h->partial),
+                         (uint64_t)chunks * h->n);  // every slot reads "no factor yet" between updates
     }
     double* a_partial = h->partial;
     const unsigned int* a_idx = h->idx;
-    void* args[] = {&a_pl, &a_pw, &a_ctl, &a_n, &a_z, &a_nz, &a_len, &a_chunks, &a_m, &a_partial, &a_idx};
-    if (ea && !dup) RR_HIP_TRY(hipExtLaunchKernel(kfn, grid, dim3(kBlock), args, lds, h->stream, ea, eb, 0));
-    else RR_HIP_TRY(hipLaunchKernel(kfn, grid, dim3(kBlock), args, lds, h->stream));
-  }
-  if (chunks > 1) {
-    rr::ScopedTimer t(h->prof, h->stream, RR_FK_COMBINE);
-    hipLaunchKernelGGL(k_fs1_combine, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n,
-                       (const double*)h->partial, chunks);
+    unsigned int a_pblocks = grid.x;
+    const dim3 grid_l((unsigned int)((uint64_t)a_pblocks * (uint64_t)chunks));
+    void* args[] = {&a_pl, &a_pw, &a_ctl, &a_n, &a_z, &a_nz, &a_len, &a_chunks, &a_m, &a_partial, &a_idx, &a_pblocks};
+    if (ea && !dup) RR_HIP_TRY(hipExtLaunchKernel(kfn, grid_l, dim3(kBlock), args, lds, h->stream, ea, eb, 0));
+    else RR_HIP_TRY(hipLaunchKernel(kfn, grid_l, dim3(kBlock), args, lds, h->stream));
   }
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
@@ -1027,13 +1195,9 @@ rr_status launch_plan_fused(rr_fs1* h, int settle) {
                          h->tile_total, h->tile_q2, h->n_tiles, plan_args(h, 0, NAN, /*lazy=*/true), h->markers, h->carry);
     }
   }
-  {
-    rr::ScopedTimer t(h->prof, h->stream, RR_FK_INDICES);
-    hipLaunchKernelGGL(k_fs1_resolve, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->ctl, h->markers,
-                       h->carry, h->n, h->idx);
-  }
   RR_HIP_TRY(hipGetLastError());
   h->maybe_pending = true;
+  h->idx_unresolved = true;  // the markers wait for the next update's first kernel (or ensure_resolved)
   h->rstep += 1;
   return RR_OK;
 }
@@ -1063,6 +1227,8 @@ rr_status fetch_ctl(rr_fs1* h) {
   RR_HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
   rr::spin_release(h->opt.device, h);
+  if (h->ctl_host->obs_timeout)
+    return fail(RR_RUNTIME_ERROR, "k_fs1_observe: a chunk's weight factor did not arrive within 2 s; the weights of this update are not valid");
   if (h->ctl_host->grid_timeout) {
     // launches of the one-launch plan degraded to the serial plan (another process kept workgroups off the device): same
     // results; this handle takes the multi-launch plan from now on (resample_core.hpp, k_quantize_plan_mark)
@@ -1198,6 +1364,8 @@ void rr_fs1_destroy(rr_fs1* h) {
   (void)hipFree(h->ridx);
   (void)hipFree(h->partial);
   (void)hipFree(h->z_dev);
+  (void)hipHostFree(h->z_ring);
+  (void)hipHostFree(h->z_done);
   (void)hipFree(h->noise);
   (void)hipFree(h->pose_stage);
   (void)hipFree(h->part_bits);
@@ -1853,6 +2021,7 @@ rr_status rr_fs1_last_resample_indices(rr_fs1* h, uint32_t* out, size_t n) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!out || n != h->n) return fail(RR_INVALID_PARAMETER, "need room for one index per particle");
+  if ((s = ensure_resolved(h)) != RR_OK) return s;
   RR_HIP_TRY(hipMemcpyAsync(out, h->idx, n * sizeof(uint32_t), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
   return RR_OK;

@@ -172,6 +172,7 @@ static __global__ __launch_bounds__(kScanThreads) void k_scan_exchange(P2PPeers 
 __device__ inline void st_sys(double* p, double v) {
   __hip_atomic_store(reinterpret_cast<uint64_t*>(p), (uint64_t)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+__device__ inline void st_sys_u64(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ inline double ld_sys(const double* p) {
   return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
 }

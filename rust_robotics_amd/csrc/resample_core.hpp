@@ -75,6 +75,7 @@ struct Ctl {
   double est[4];          // (unused since round 3: the tiles' partial sums are added on the host when the estimate is read)
   uint64_t est_step;      // resample-step counter the in-step estimate belongs to (+1; 0 = none yet)
   double est_denom;       // ... and what the sum of the tiles' partial sums is divided by (N when the resample fired, else T)
+  int obs_timeout;        // FastSLAM: a chunk's weight factor did not show up in k_fs1_observe (never seen; reported as an error)
   uint64_t n_active;      // KLD-adaptive filters: the CURRENT particle count (k_kld_count sets it; the kernels of such a filter read
                           // their n from here instead of their launch packet, so the host does not have to know it to enqueue a step)
 };
@@ -732,6 +733,8 @@ constexpr int kRecWords = 4;  // total, q2_hi, q2_lo, exclusive prefix (written 
 // rec layout: [n_tiles][kRecWords] records, then kRecWords words {grand total, q2_hi, q2_lo, state}
 __device__ inline uint64_t ld_dev(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_dev(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline double ld_dev(const double* p) { return rr_u2d(ld_dev(reinterpret_cast<const uint64_t*>(p))); }
+__device__ inline void st_dev(double* p, double v) { st_dev(reinterpret_cast<uint64_t*>(p), rr_d2u(v)); }
 
 // The launch's state word: 2 * epoch     = RAISED: every workgroup has arrived, the sums are out, go on;
 //                          2 * epoch + 1 = GIVEN UP: a waiting workgroup ran out of patience before that.

@@ -361,6 +361,40 @@ def test_one_launch_plan_equals_the_two_kernel_plan(fs, algorithm, monkeypatch):
         assert bits_equal(ma, mb), f"maps differ at update {t}"
 
 
+def test_async_updates_equal_synchronised_updates(fs):
+    """A run of rr_fs1_update_async calls with nothing in between takes the three-launch update: the first kernel resolves the
+    previous plan's markers, moves the poses and carries the update's observations from a pinned ring slot to the device
+    (k_fs1_resolve_predict), k_fs1_observe's last chunk forms the weights, the plan kernel follows.  With an accessor after
+    every update the same filter takes k_fs1_resolve + k_fs1_predict and an H2D copy of the observations instead.  Same
+    poses, weights and maps, bit for bit -- over more updates than the ring has slots, the observations different every time,
+    with the host far ahead of the device (a slot overwritten too early would change the result)."""
+    n, L, T = 150_000, 30, 100
+    lms = scene(L, 47)
+    zs = [np.ascontiguousarray(observations_for(fs, H.true_pose(t + 1), lms, seed=79, step=t)[(t % 4):]) for t in range(T)]
+
+    def run(asynchronous):
+        prm = fs.default_params()
+        prm.first_obs_cov = 2.0
+        prm.nth = n / 1.5
+        f = fs.FastSlam1(n, L, params=prm, seed=79)
+        fired = 0
+        for t in range(T):
+            if asynchronous:
+                f.update_async([1.0, 0.1], zs[t])
+            else:
+                f.update([1.0, 0.1], zs[t])
+                if f.last_resample_fired():
+                    fired += 1
+                    f.last_resample_indices()
+        return f.get_state(), fired
+
+    (pa, ma), _ = run(True)
+    (pb, mb), fired = run(False)
+    assert fired > 5
+    assert bits_equal(pa, pb)
+    assert bits_equal(ma, mb)
+
+
 def test_trajectory_vs_literal_reference(fs, det, ref):
     n, L, T = 400, 6, 10
     lms = scene(L, 51, half=8.0)
