@@ -323,11 +323,12 @@ uint64_t rr_sys_segment_matrix(double rho, const uint64_t* totals, int32_t n_sha
  * plain pointers when all shards live in one process) and the exchanges become tiny kernels that
  * publish a 32-byte record to every peer over xGMI and wait for theirs (bounded).  At resample
  * time only the slots whose source lives on another rank move -- stored into the owning rank's
- * fine-grained inbox, from which the owner's next step reads them -- the others are read through
+ * fine-grained inbox, each with a seal over its fields that the owner's next step checks before it uses them -- the others are read through
  * their source index by the next step, exactly as on one GPU.  Results are bit-identical to the
  * RCCL path and to the unsharded filter. */
 #define RR_P2P_HANDLE_BYTES 256
-/* this rank's IPC handles (state slab, mailbox, inbox) for the other ranks */
+/* this rank's IPC handles (state slab, mailbox, inbox) for the other ranks, followed by the PCI bus id of the exporting
+ * device: ranks that find a peer on their own device keep their spinning plan kernels small enough to leave it room */
 rr_status rr_pf_p2p_export(rr_pf* h, uint8_t out[RR_P2P_HANDLE_BYTES]);
 /* all_handles = n_ranks blobs from rr_pf_p2p_export in rank order (own entry ignored) */
 rr_status rr_pf_p2p_connect(rr_pf* h, const uint8_t* all_handles, int32_t n_ranks, int32_t rank);

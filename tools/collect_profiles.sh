@@ -50,5 +50,12 @@ python bench.py > "$OUT/${TAG}_bench_default.json" 2> "$OUT/bench_default.err"
 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_command.json" 2> "$OUT/bench_driver.err"
 python bench.py --scheme multinomial --no-cpu-baseline --no-extra-legs > "$OUT/${TAG}_mcl_1e6x32_multinomial_bench.json" 2>/dev/null
 python bench.py --workload fastslam2 > "$OUT/${TAG}_fastslam2_1e5x200_bench.json" 2>/dev/null
+# the sharded step at world size 1, both transports, as their own lines (the default line carries the same two as `sharded_world1`)
+{ for tr in p2p-only rccl; do python bench.py --gpus 1 --force-sharded --transport $tr --no-extra-legs --no-cpu-baseline 2>/dev/null | tail -1; done; } > "$OUT/${TAG}_bench_sharded_world1_all_legs.json"
+# two ranks of one filter on this one device (development knob RR_BENCH_SHARE_DEVICE: IPC transport, real overhang traffic
+# between the ranks; both ranks' kernels share the GPU, so this is a protocol check with a time attached, not a scaling number)
+RR_BENCH_SHARE_DEVICE=1 GPU_MAX_HW_QUEUES=8 timeout 300 python bench.py --gpus 2 --steps 300 --warmup 50 --particles 100000 --no-cpu-baseline --no-extra-legs 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_2ranks_shared_device.json"
+run p2p_trace --kernel-trace --stats -- python $REPO/bench.py --gpus 1 --force-sharded --transport p2p-only --no-extra-legs --no-cpu-baseline --no-breakdown
+python tools/summarize_rocprof.py stats "$(find_csv p2p_trace kernel_trace)" > "$OUT/${TAG}_mcl_sharded_p2p_world1_kernel_stats.csv"
 rm -rf "$OUT"/raw_*   # the raw traces are large; the summaries above are what gets committed
 ls -la "$OUT"
