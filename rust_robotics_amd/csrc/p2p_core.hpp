@@ -24,6 +24,8 @@ namespace rr {
 // visible to a later local kernel without any assumption about what either GPU's L2 still holds.
 // The consumer reads an "in place" slot from its inbox instead of its slab.
 constexpr int kMaxP2P = 16;
+// what gave up (the value latched in P2PState::err; the error message names it)
+constexpr int kGaveUpWmax = 1, kGaveUpSums = 2, kGaveUpRecord = 3, kGaveUpInboxSlot = 4, kGaveUpPlanFlag = 5;
 constexpr int kP2PHandleBytes = 256;
 constexpr int kBusIdBytes = 32;  // the PCI bus id of the exporting device, after the three IPC handles
 struct P2PSlot {
@@ -108,7 +110,7 @@ __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t se
   __syncthreads();
   if (g != 0) return;
   if (s_bad) {
-    *err = 1;
+    *err = kind == kP2PWmax ? kGaveUpWmax : (kind == kP2PSums ? kGaveUpSums : kGaveUpRecord);
     ctl->fired = 0;  // nothing downstream may act on incomplete data
     if (kind == kP2PWmax) *wmax_out = 0.0;
     return;
@@ -216,7 +218,7 @@ __device__ inline bool inbox_take(const double* inbox, uint64_t n_local, uint64_
     }
     __builtin_amdgcn_s_sleep(8);
     if (wall_clock64() - t0 > (seq <= 3 ? 10 * timeout_ticks : timeout_ticks)) {
-      *err = 1;
+      *err = kGaveUpInboxSlot;
       return false;
     }
   }
@@ -274,7 +276,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
     }
   }
   if (tid == 0) {
-    if (!wait_flag(&head0[1], epoch, limit)) *err = 1;
+    if (!wait_flag(&head0[1], epoch, limit)) *err = kGaveUpPlanFlag;
     s_wmax = rr_u2d(ld_dev(&head0[0]));
   }
   __syncthreads();
@@ -381,7 +383,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
   // ---- everybody: flag 1, then the workgroup's prefix, the base and the global totals
   if (tid == 0) {
     const bool ok = wait_flag(&head1[5], epoch, limit);
-    if (!ok) *err = 1;
+    if (!ok) *err = kGaveUpPlanFlag;
     s4[0] = ld_dev(&rec[(uint64_t)blockIdx.x * kRecWords + 3]);
     s4[1] = ld_dev(&head1[0]);
     s4[2] = ld_dev(&head1[1]);
@@ -537,9 +539,13 @@ struct P2PState {
     if (!ready || !err) return RR_OK;
     RR_HIP_TRY(hipMemcpyAsync(err_host, err, sizeof(int), hipMemcpyDeviceToHost, stream));
     RR_HIP_TRY(hipStreamSynchronize(stream));
-    if (*err_host)
-      return fail(RR_RUNTIME_ERROR, "peer-to-peer exchange: a wait for a peer's record timed out (RR_P2P_TIMEOUT_MS); "
-                                    "the sharded filter is no longer consistent -- reconnect or recreate it");
+    if (*err_host) {
+      static const char* const what[] = {"", "the peers' weight maxima", "the peers' integer sums", "a peer's record",
+                                         "a particle a peer serves (inbox slot)", "the plan kernel's own hand-over"};
+      const int k = *err_host > 0 && *err_host <= 5 ? *err_host : 3;
+      return fail(RR_RUNTIME_ERROR, std::string("peer-to-peer exchange: a wait for a peer's record timed out (RR_P2P_TIMEOUT_MS; waiting for ") +
+                                        what[k] + "); the sharded filter is no longer consistent -- reconnect or recreate it");
+    }
     return RR_OK;
   }
 
@@ -548,7 +554,7 @@ struct P2PState {
     if (!err) return RR_OK;
     RR_HIP_TRY(hipMemcpyAsync(err_host, err, sizeof(int), hipMemcpyDeviceToHost, stream));
     RR_HIP_TRY(hipStreamSynchronize(stream));
-    *timed_out = *err_host;
+    *timed_out = *err_host != 0 ? 1 : 0;
     return RR_OK;
   }
 };

@@ -771,6 +771,7 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
         except RoboticsError as e:
             if not trouble:
                 trouble.append(f"rank {rank}: {e}")
+                log(f"a step failed on this rank: {e}")
 
     def fence(shard):
         quiet_sync(shard)
@@ -822,6 +823,7 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     if use_p2p and not agree(not p2p.timed_out() and not trouble):
         timed_out = True
         notes.append("a peer wait gave up inside the timed region" + (f" ({trouble[0]})" if trouble else ""))
+        log(notes[-1])
         del trouble[:]
         if ref is not None:  # repeat the region on the reference transport
             use_p2p, shard = False, ref
