@@ -16,9 +16,11 @@
 //   k_quantize_plan_mark   integer image + tile sums handed over inside the launch + gate + slot-run markers
 //                          (+ the mean try_step returns); beyond 2^20 particles k_quantize_reduce + k_plan_mark
 //                          (resample_core.hpp)                                                      8-12 B / particle
-//  multinomial: k_step_lazy<PACKED> (reads through lidx), k_quantize_reduce, k_plan_cdf (CDF + guide markers),
-//               k_guide_resolve, k_resample_guide_mn (guide table over the target space; sharded / adaptive / beyond
-//               8.4e6 particles: k_resample_gather_mn, coarse table of the CDF in LDS)
+//  multinomial: k_step_lazy<kSrcDraw, PACKED> (draws and searches the previous resample's sources for its own slots through
+//               the guide table over the target space), k_quantize_reduce, k_plan_cdf (CDF + guide markers), k_guide_resolve;
+//               k_resample_guide_mn is the same search as a launch of its own (accessors, RR_MN_DEFER=0; then
+//               k_step_lazy<kSrcLidx, PACKED> reads through lidx); sharded / adaptive / beyond 8.4e6 particles:
+//               k_resample_gather_mn, coarse table of the CDF in LDS
 //  the separate entry points (predict / update / resample, the RCCL sharded step, the adaptive filter):
 //   k_propagate_weight     x,y,yaw -> x,y,yaw,v,w + maximum of w                                   64 B / particle
 //   k_quantize_reduce      w -> per-tile integer totals, sum q^2                                    8 B / particle
@@ -222,8 +224,11 @@ constexpr unsigned kPushGrid = 64;  // workgroups of k_push_window (grid-stride 
 enum StepSrc {
   kSrcMarkers = 0,  // one GPU, systematic: slot-run markers, resolved here (rr::resolve_tile)
   kSrcLidx = 1,     // one GPU, multinomial: the search kernel left one source index per slot
-  kSrcWindow = 2    // a shard of the peer-to-peer transport: markers over the global slot index (rr::resolve_tile_window);
+  kSrcWindow = 2,   // a shard of the peer-to-peer transport: markers over the global slot index (rr::resolve_tile_window);
                     // own slots outside the window this shard serves were delivered into the inbox by a peer
+  kSrcDraw = 3      // one GPU, multinomial, the search not run yet: this kernel draws and searches for its own slots
+                    // (mn_guide_search) -- the latency-bound search hides under this kernel's FP64 work instead of being a
+                    // launch of its own (k_resample_guide_mn: 17.7 us at 1e6 particles)
 };
 struct WindowArgs {
   const double* inbox;         // this rank's inbox [4 fields + tag][n]
@@ -232,7 +237,36 @@ struct WindowArgs {
   uint64_t wait_seq;           // the tag a peer-served slot must carry: the sequence number of the step being consumed
   uint64_t timeout_ticks;
   int n_ranks;                 // 0: nothing to wait for (RCCL transport: an earlier kernel of the stream filled the inbox)
+  // kSrcDraw: the pending multinomial resample's CDF, guide table and draw stream
+  const uint64_t* cdf;
+  const unsigned int* guide;
+  uint64_t n_src;
+  unsigned int rstep;
+  int guide_log2;
 };
+
+// The multinomial draw of output slot `slot` through the guide table (resample_core.hpp: buckets of the target space, built
+// by k_plan_cdf's markers and k_guide_resolve): two adjacent table entries bracket the answer, the CDF is only read inside
+// the bracket -- not at all when a heavy particle spans the whole bucket.  Same index as the lower bound over the whole CDF
+// (tests: identical to the coarse-table kernel and to the literal walk).
+struct __attribute__((packed, aligned(4))) GuidePair {
+  unsigned int lo, hi;
+};
+__device__ inline uint64_t mn_guide_search(const Ctl* __restrict__ ctl, const uint64_t* __restrict__ cdf,
+                                           const unsigned int* __restrict__ guide, int guide_log2, uint64_t target, uint64_t n_src) {
+  const uint64_t total = ctl->total;
+  const int s = rr::guide_shift(total, guide_log2);
+  const uint64_t bucket = target >> s;
+  const GuidePair g = *reinterpret_cast<const GuidePair*>(guide + bucket);
+  const uint64_t hi = bucket < (total >> s) ? (uint64_t)g.hi : n_src - 1;  // the last bucket ends with the last source
+  uint64_t j = g.lo, end = hi;  // the answer lies in [j, end]: no CDF entry is read when the bracket is one source
+  while (j < end) {
+    const uint64_t mid = j + ((end - j) >> 1);
+    if (cdf[mid] >= target) end = mid;
+    else j = mid + 1;
+  }
+  return j;
+}
 
 template <bool OBS_KERNARG, int SRC, int LIK, bool PACKED = false>
 __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
@@ -272,6 +306,17 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
       for (int r = 0; r < rr::kResolveRows; ++r) {
         const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
         idx[r] = k < p.n ? markers[k] : 0u;  // `markers` is the lidx array here
+      }
+    } else if (pending && SRC == kSrcDraw) {
+#pragma unroll
+      for (int r = 0; r < rr::kResolveRows; ++r) {
+        const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
+        idx[r] = 0u;
+        if (k < p.n) {
+          const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, p.first_gid + k, p.seed, wa.rstep, nullptr, k);
+          idx[r] = (unsigned int)mn_guide_search(ctl, wa.cdf, wa.guide, wa.guide_log2, target, wa.n_src);
+          if (idx_out) idx_out[k] = idx[r];
+        }
       }
     } else if (pending && SRC == kSrcWindow) {
       const uint64_t own0 = p.first_gid + wa.pad;  // position of own slot 0: a multiple of kResolveSlots
@@ -456,13 +501,7 @@ __global__ __launch_bounds__(1024) void k_resample_gather_mn(Bufs b, const Ctl* 
   }
 }
 
-// The same draws through the guide table (resample_core.hpp: buckets of the target space, built by k_plan_cdf's markers
-// and k_guide_resolve): two adjacent table entries bracket the answer, the CDF is only read inside the bracket -- not at
-// all when a heavy particle spans the whole bucket.  No LDS table to stage, one draw per thread.  Same index as the
-// lower bound over the whole CDF (tests: identical to the coarse-table kernel and to the literal walk).
-struct __attribute__((packed, aligned(4))) GuidePair {
-  unsigned int lo, hi;
-};
+// The same draws through the guide table (mn_guide_search): no LDS table to stage, one draw per thread.
 __global__ __launch_bounds__(kBlock) void k_resample_guide_mn(Bufs b, const Ctl* __restrict__ ctl,
                                                              const uint64_t* __restrict__ cdf,
                                                              const unsigned int* __restrict__ guide, int guide_log2,
@@ -472,19 +511,8 @@ __global__ __launch_bounds__(kBlock) void k_resample_guide_mn(Bufs b, const Ctl*
   if (!ctl->fired) return;
   const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (k >= a.n_slots) return;
-  const uint64_t total = ctl->total;
-  const int s = rr::guide_shift(total, guide_log2);
   const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, a.first_slot + k, a.seed, a.rstep, r_explicit, k);
-  const uint64_t bucket = target >> s;
-  const GuidePair g = *reinterpret_cast<const GuidePair*>(guide + bucket);
-  const uint64_t lo = g.lo;
-  const uint64_t hi = bucket < (total >> s) ? (uint64_t)g.hi : a.n_src - 1;  // the last bucket ends with the last source
-  uint64_t j = lo, end = hi;  // the answer lies in [j, end]: no CDF entry is read when the bracket is one source
-  while (j < end) {
-    const uint64_t mid = j + ((end - j) >> 1);
-    if (cdf[mid] >= target) end = mid;
-    else j = mid + 1;
-  }
+  const uint64_t j = mn_guide_search(ctl, cdf, guide, guide_log2, target, a.n_src);
   const int dst = ctl->cur, src = dst ^ 1;
   if (lidx_out) lidx_out[k] = (unsigned int)j;  // lazy: the next propagate kernel reads through it
   else copy_particle(b, src, dst, j, k, false, nullptr);
@@ -1555,6 +1583,9 @@ struct rr_pf {
   rr::P2PState p2p;  // device-initiated exchange over xGMI (rr_pf_p2p_*)
   bool maybe_pending = false;    // a lazy resample plan was launched and nothing has consumed its markers yet
   int pending_kind = kSrcMarkers;  // ... StepSrc: where its sources are (markers / lidx of the multinomial step / window of a shard)
+  bool mn_deferred = false;        // a lazy multinomial resample is planned (CDF, guide table) but its draws have not been searched yet
+  bool mn_defer_ok = true;         // RR_MN_DEFER=0: always run the search as a launch of its own (k_resample_guide_mn)
+  GatherArgs mn_deferred_args{};
   uint64_t slot_pad = 0;           // shard of the peer-to-peer transport: marker position of global slot s = s + slot_pad
   uint64_t window_seq = 0;         // ... and the exchange sequence number of the step whose window resample is pending (its DONE)
   double* rccl_inbox = nullptr;    // RCCL transport: [field][n] particles peers served for this shard's slots (plain device memory)
@@ -1762,10 +1793,16 @@ void launch_quantize(rr_pf* h, const double* wmax_src, int settle = 0) {
 }
 
 // make a pending lazy resample real (accessors and the non-fused entry points call this first)
+void launch_guide_search(rr_pf* h, const double* r_explicit_dev, unsigned int* lidx, const GatherArgs& g);
+
 rr_status materialise(rr_pf* h) {
   if (!h->maybe_pending) return RR_OK;
   if (h->pending_kind == kSrcLidx) {
     Timed t(h, RR_K_RESAMPLE_GATHER);
+    if (h->mn_deferred) {  // the multinomial search has not run yet (the next step would have done it on the way)
+      launch_guide_search(h, (const double*)nullptr, h->lidx, h->mn_deferred_args);
+      h->mn_deferred = false;
+    }
     hipLaunchKernelGGL(k_gather_lidx, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->lidx, h->n,
                        (const double*)nullptr);
     hipLaunchKernelGGL(k_settle, dim3(1), dim3(1), 0, h->stream, h->ctl);
@@ -1849,12 +1886,18 @@ rr_status ensure_guide(rr_pf* h) {
 }
 
 // the multinomial draws -> source indices (and, unless lidx is given, the particles themselves)
+void launch_guide_resolve(rr_pf* h) {
+  hipLaunchKernelGGL(rr::k_guide_resolve, dim3((unsigned)((((size_t)1 << h->guide_log2) + rr::kResolveSlots) / rr::kResolveSlots)),
+                     dim3(kBlock), 0, h->stream, h->ctl, h->guide_markers, h->guide_carry, h->guide, h->guide_log2);
+}
+void launch_guide_search(rr_pf* h, const double* r_explicit_dev, unsigned int* lidx, const GatherArgs& g) {
+  hipLaunchKernelGGL(k_resample_guide_mn, dim3(grid_for(g.n_slots, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->cdf,
+                     h->guide, h->guide_log2, r_explicit_dev, h->idx, lidx, g);
+}
 void launch_mn_search(rr_pf* h, bool guide, const double* r_explicit_dev, unsigned int* lidx, const GatherArgs& g) {
   if (guide) {
-    hipLaunchKernelGGL(rr::k_guide_resolve, dim3((unsigned)((((size_t)1 << h->guide_log2) + rr::kResolveSlots) / rr::kResolveSlots)),
-                       dim3(kBlock), 0, h->stream, h->ctl, h->guide_markers, h->guide_carry, h->guide, h->guide_log2);
-    hipLaunchKernelGGL(k_resample_guide_mn, dim3(grid_for(g.n_slots, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->cdf,
-                       h->guide, h->guide_log2, r_explicit_dev, h->idx, lidx, g);
+    launch_guide_resolve(h);
+    launch_guide_search(h, r_explicit_dev, lidx, g);
     return;
   }
   hipLaunchKernelGGL(k_resample_gather_mn, dim3(std::min<unsigned>(grid_for(h->n, h->mn_block), (unsigned)h->mn_grid)), dim3(h->mn_block),
@@ -1931,7 +1974,15 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
     g.seed = h->opt.seed;
     g.rstep = h->rstep;
     g.scheme = scheme;
-    launch_mn_search(h, guide, (const double*)nullptr, h->lidx, g);
+    if (guide && h->packed[0] && h->mn_defer_ok) {
+      // the draws and their search wait for the kernel that consumes them: the next step's k_step_lazy<kSrcDraw> (or
+      // ensure_searched, when an accessor comes first)
+      launch_guide_resolve(h);
+      h->mn_deferred = true;
+      h->mn_deferred_args = g;
+    } else {
+      launch_mn_search(h, guide, (const double*)nullptr, h->lidx, g);
+    }
     h->maybe_pending = true;
     h->pending_kind = kSrcLidx;
   } else if (lazy) {
@@ -2164,6 +2215,7 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
     if (v >= 1) h->mn_grid = v;
   }
   if (const char* e = std::getenv("RR_PF_SMALL")) h->small_ok = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RR_MN_DEFER")) h->mn_defer_ok = std::atoi(e) != 0;
   if (const char* e = std::getenv("RR_K1_BLOCKS_PER_CU")) {
     const int v = std::atoi(e);
     if (v >= 1 && v <= 64) h->k1_blocks_per_cu = v;
@@ -2320,12 +2372,16 @@ static void launch_k1(rr_pf* h, bool kernarg, int src, unsigned grid, size_t lds
   const bool product = p.lik_mode == RR_LIK_PRODUCT;
 #define RR_K1_GO(KA_, SRC_, LIK_) launch_k1_as<KA_, SRC_, LIK_>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa)
 #define RR_K1_GO_PK(KA_, LIK_) launch_k1_as<KA_, kSrcLidx, LIK_, true>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa)
+#define RR_K1_GO_DRAW(KA_, LIK_) launch_k1_as<KA_, kSrcDraw, LIK_, true>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa)
 #define RR_K1_SRC(SRC_)                                                                                       \
   do {                                                                                                        \
     if (kernarg) product ? RR_K1_GO(true, SRC_, RR_LIK_PRODUCT) : RR_K1_GO(true, SRC_, RR_LIK_FUSED);          \
     else product ? RR_K1_GO(false, SRC_, RR_LIK_PRODUCT) : RR_K1_GO(false, SRC_, RR_LIK_FUSED);                \
   } while (0)
-  if (src == kSrcLidx && packed) {
+  if (src == kSrcDraw) {  // (always with the packed mirror)
+    if (kernarg) product ? RR_K1_GO_DRAW(true, RR_LIK_PRODUCT) : RR_K1_GO_DRAW(true, RR_LIK_FUSED);
+    else product ? RR_K1_GO_DRAW(false, RR_LIK_PRODUCT) : RR_K1_GO_DRAW(false, RR_LIK_FUSED);
+  } else if (src == kSrcLidx && packed) {
     if (kernarg) product ? RR_K1_GO_PK(true, RR_LIK_PRODUCT) : RR_K1_GO_PK(true, RR_LIK_FUSED);
     else product ? RR_K1_GO_PK(false, RR_LIK_PRODUCT) : RR_K1_GO_PK(false, RR_LIK_FUSED);
   } else if (src == kSrcLidx) RR_K1_SRC(kSrcLidx);
@@ -2334,6 +2390,7 @@ static void launch_k1(rr_pf* h, bool kernarg, int src, unsigned grid, size_t lds
 #undef RR_K1_SRC
 #undef RR_K1_GO
 #undef RR_K1_GO_PK
+#undef RR_K1_GO_DRAW
 }
 
 // ---- small particle sets: one launch of one workgroup per step, or per K steps (k_step_small)
@@ -2694,7 +2751,16 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
   const unsigned grid = (unsigned)n_rtiles;  // one tile per workgroup
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
-    if (multinomial) {  // sources of the previous (multinomial) resample are in lidx
+    if (multinomial && h->mn_deferred) {  // ... are still to be drawn: this launch does it for its own slots
+      WindowArgs wa{};
+      wa.cdf = h->cdf;
+      wa.guide = h->guide;
+      wa.n_src = h->mn_deferred_args.n_src;
+      wa.rstep = h->mn_deferred_args.rstep;
+      wa.guide_log2 = h->guide_log2;
+      launch_k1(h, kernarg, kSrcDraw, grid, lds, nullptr, nullptr, p, arg, nullptr, nullptr, h->idx, wa, /*packed=*/true);
+      h->mn_deferred = false;
+    } else if (multinomial) {  // sources of the previous (multinomial) resample are in lidx
       launch_k1(h, kernarg, kSrcLidx, grid, lds, nullptr, nullptr, p, arg, h->lidx, nullptr, nullptr, WindowArgs{},
                 /*packed=*/h->packed[0] != nullptr);
     } else {
