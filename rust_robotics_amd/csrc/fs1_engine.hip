@@ -109,7 +109,7 @@ struct ZStage {
 __global__ __launch_bounds__(kBlock) void k_fs1_resolve_predict(Planes pl, const Ctl* __restrict__ ctl, uint64_t n, double u0, double u1,
                                                                rr_fs1_model m, uint64_t seed, unsigned int step,
                                                                unsigned int* __restrict__ markers, const unsigned int* __restrict__ carry,
-                                                               unsigned int* __restrict__ idx, uint64_t gid0, ZStage zs) {
+                                                               unsigned int* __restrict__ idx, uint64_t gid0, ZStage zs, int resolve) {
   // The update's observations come along: the host has left them in a pinned slot, the last workgroup reads them over the
   // bus while it does its share of the poses and leaves them in device memory for k_fs1_observe -- no H2D copy operation in
   // the stream (4.7 us blit kernel + a boundary per update at 200 observations; they do not fit a kernel argument).
@@ -124,7 +124,15 @@ __global__ __launch_bounds__(kBlock) void k_fs1_resolve_predict(Planes pl, const
   }
   const bool pending = ctl->pending != 0;  // uniform
   unsigned int from[rr::kResolveRows];
-  if (pending) rr::resolve_tile(markers, carry, n, blockIdx.x, from);
+  if (pending && resolve) {
+    rr::resolve_tile(markers, carry, n, blockIdx.x, from);
+  } else if (pending) {  // an accessor has had the markers resolved already (k_fs1_resolve)
+#pragma unroll
+    for (int r = 0; r < rr::kResolveRows; ++r) {
+      const uint64_t p = (uint64_t)blockIdx.x * rr::kResolveSlots + (uint64_t)r * kBlock + threadIdx.x;
+      from[r] = p < n ? idx[p] : 0u;
+    }
+  }
   const double* __restrict__ src = pl.s[ctl->cur];
   double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
   double x[rr::kResolveRows], y[rr::kResolveRows], yaw[rr::kResolveRows];
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void k_fs1_resolve_predict(Planes pl, const
     x[r] = y[r] = yaw[r] = 0.0;
     if (p < n) {
       const uint64_t j = pending ? (uint64_t)from[r] : p;
-      if (pending) idx[p] = from[r];
+      if (pending && resolve) idx[p] = from[r];
       x[r] = src[j];
       y[r] = src[n + j];
       yaw[r] = src[2 * n + j];
@@ -634,61 +642,108 @@ __global__ void k_fs1_settle(Ctl* ctl) {
   }
 }
 
-// arg max of the weight with ties -> highest index (fastslam1.rs:269-274, Q14): the key
-// (weight bits, index) is order preserving for non-negative doubles
-__global__ __launch_bounds__(kBlock) void k_fs1_argmax(const double* __restrict__ pw, uint64_t n,
-                                                      uint64_t* __restrict__ part_bits, uint64_t* __restrict__ part_idx) {
+// arg max of the weight with ties -> highest index (fastslam1.rs:269-274, Q14): the key (weight bits, index) is order
+// preserving for non-negative doubles.  ONE launch: every workgroup leaves its best key, the workgroup that takes the last
+// ticket picks the best of those and leaves index, pose and weight of that particle in Ctl and in the handle's
+// host-visible mailbox (pinned memory; the host polls its stamp -- no device-to-host copies, no stream synchronisation).
+// Round 2: two launches, a read-back of Ctl and four 8-byte copies behind a second synchronisation -- 95 us per call, more
+// than the reference spends on a whole update of its 100 particles.
+struct BestMail {
+  uint64_t index;
+  double pose[3];
+  double weight;
+  uint64_t flags;  // != 0: Ctl holds something the host has to look at (obs_timeout, grid_timeout)
+  uint64_t seq;    // stamped last
+};
+__global__ __launch_bounds__(kBlock) void k_fs1_best(const double* __restrict__ pw, uint64_t n, const double* __restrict__ planes0,
+                                                    const double* __restrict__ planes1, Ctl* __restrict__ ctl,
+                                                    uint64_t* __restrict__ part_bits, uint64_t* __restrict__ part_idx,
+                                                    unsigned int* __restrict__ ticket, BestMail* __restrict__ mail, uint64_t seq,
+                                                    const unsigned int* __restrict__ idx) {
   __shared__ uint64_t s_b[kBlock / rr::kWave], s_i[kBlock / rr::kWave];
-  uint64_t bb = 0, bi = 0;
-  bool have = false;
+  __shared__ int s_last;
+  auto better = [](uint64_t ob, uint64_t oi, uint64_t bb, uint64_t bi) { return ob > bb || (ob == bb && oi > bi); };
+  auto wave_best = [&](uint64_t& bb, uint64_t& bi) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t ob = rr::shfl_xor_u64(bb, o), oi = rr::shfl_xor_u64(bi, o);
+      if (better(ob, oi, bb, bi)) {
+        bb = ob;
+        bi = oi;
+      }
+    }
+  };
+  auto block_best = [&](uint64_t& bb, uint64_t& bi) {  // thread 0 ends up with the workgroup's best
+    wave_best(bb, bi);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+      s_b[threadIdx.x >> 6] = bb;
+      s_i[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int k = 1; k < kBlock / rr::kWave; ++k)
+        if (better(s_b[k], s_i[k], bb, bi)) {
+          bb = s_b[k];
+          bi = s_i[k];
+        }
+  };
+  uint64_t bb = 0, bi = 0;  // (an empty share ranks lowest: key (0, 0))
   for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (uint64_t)gridDim.x * kBlock) {
     const double w = pw[p];
     const uint64_t b = w > 0.0 ? rr_d2u(w) : 0ull;  // NaN / negative weights rank lowest
-    if (!have || b > bb || (b == bb && p > bi)) {
+    if (better(b, p, bb, bi) || (b == bb && p == bi)) {
       bb = b;
       bi = p;
-      have = true;
     }
   }
-  if (!have) {
-    bb = 0;
-    bi = 0;
+  block_best(bb, bi);
+  if (threadIdx.x == 0) {
+    rr::st_dev(&part_bits[blockIdx.x], bb);
+    rr::st_dev(&part_idx[blockIdx.x], bi);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned int before = atomicAdd(ticket, 1u);
+    s_last = before == gridDim.x - 1 ? 1 : 0;
+    if (s_last) *ticket = 0;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const uint64_t ob = rr::shfl_xor_u64(bb, o), oi = rr::shfl_xor_u64(bi, o);
-    if (ob > bb || (ob == bb && oi > bi)) {
+  __syncthreads();
+  if (!s_last) return;
+  bb = 0;
+  bi = 0;
+  for (unsigned int k = threadIdx.x; k < gridDim.x; k += kBlock) {
+    const uint64_t ob = rr::ld_dev(&part_bits[k]), oi = rr::ld_dev(&part_idx[k]);
+    if (better(ob, oi, bb, bi)) {
       bb = ob;
       bi = oi;
     }
   }
-  if ((threadIdx.x & 63) == 0) {
-    s_b[threadIdx.x >> 6] = bb;
-    s_i[threadIdx.x >> 6] = bi;
-  }
-  __syncthreads();
+  block_best(bb, bi);
   if (threadIdx.x == 0) {
-    for (int k = 1; k < kBlock / rr::kWave; ++k)
-      if (s_b[k] > bb || (s_b[k] == bb && s_i[k] > bi)) {
-        bb = s_b[k];
-        bi = s_i[k];
-      }
-    part_bits[blockIdx.x] = bb;
-    part_idx[blockIdx.x] = bi;
+    // a pending (lazy) resample has set the weights already; the particle of slot bi still sits at its source in the live set
+    const double* __restrict__ live = ctl->cur ? planes1 : planes0;
+    const uint64_t j = (idx && ctl->pending) ? (uint64_t)idx[bi] : bi;
+    const double x = live[j], y = live[n + j], yaw = live[2 * n + j], w = pw[bi];
+    ctl->best_bits = bb;
+    ctl->best_index = bi;
+    if (mail) {
+      rr::st_sys_u64(&mail->index, bi);
+      rr::st_sys(&mail->pose[0], x);
+      rr::st_sys(&mail->pose[1], y);
+      rr::st_sys(&mail->pose[2], yaw);
+      rr::st_sys(&mail->weight, w);
+      rr::st_sys_u64(&mail->flags, (uint64_t)(ctl->obs_timeout != 0) | ((uint64_t)(ctl->grid_timeout != 0) << 1));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stamp goes last
+      rr::st_sys_u64(&mail->seq, seq);
+    }
   }
 }
 
-__global__ void k_fs1_argmax_final(Ctl* __restrict__ ctl, const uint64_t* __restrict__ part_bits,
-                                   const uint64_t* __restrict__ part_idx, int n_blocks) {
-  if (threadIdx.x != 0) return;
-  uint64_t bb = part_bits[0], bi = part_idx[0];
-  for (int k = 1; k < n_blocks; ++k)
-    if (part_bits[k] > bb || (part_bits[k] == bb && part_idx[k] > bi)) {
-      bb = part_bits[k];
-      bi = part_idx[k];
-    }
-  ctl->best_bits = bb;
-  ctl->best_index = bi;
+// "everything before me in this stream is done, and this is what Ctl has to report": the stamp of a synchronous call
+// (rr_fs1_update, rr_fs1_synchronize) -- the host polls the mailbox instead of copying Ctl back behind a stream synchronisation
+__global__ void k_fs1_stamp(const Ctl* __restrict__ ctl, BestMail* __restrict__ mail, uint64_t seq) {
+  rr::st_sys_u64(&mail->flags, (uint64_t)(ctl->obs_timeout != 0) | ((uint64_t)(ctl->grid_timeout != 0) << 1));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  rr::st_sys_u64(&mail->seq, seq);
 }
 
 // host layouts <-> planes.  tmp holds the AoS image on the device.
@@ -793,6 +848,9 @@ struct rr_fs1 {
   double* pose_stage = nullptr;  // 4n: AoS (w, x, y, yaw) image for get_state / set_state (the inactive set only holds 3n when L == 0)
   uint64_t* part_bits = nullptr;
   uint64_t* part_idx = nullptr;
+  BestMail* best_mail = nullptr;        // pinned: where k_fs1_best leaves the best particle for the host
+  unsigned int* best_ticket = nullptr;  // arrivals of k_fs1_best's workgroups
+  uint64_t best_seq = 0;
   Ctl* ctl = nullptr;
   Ctl* ctl_host = nullptr;
   unsigned int step = 0, rstep = 0;
@@ -956,14 +1014,16 @@ rr_status materialise(rr_fs1* h) {
 
 template <bool EXPLICIT, bool LAZY>
 rr_status launch_predict(rr_fs1* h, const double u[2], const double* z = nullptr, size_t n_z = 0) {
-  if (LAZY && !EXPLICIT && h->idx_unresolved && !h->pl.inbox) {  // resolve the last plan's markers on the way
+  if (LAZY && !EXPLICIT && !h->pl.inbox && h->n == h->n_global) {  // one GPU: resolve the last plan's markers on the way (unless an
+                                                               // accessor has had that done), carry the observations
     ZStage zs{};
     if (z && (n_z > 0)) {
       if (rr_status st = stage_z(h, z, n_z, &zs); st != RR_OK) return st;
     }
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_PREDICT);
     hipLaunchKernelGGL(k_fs1_resolve_predict, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->pl, h->ctl, h->n,
-                       u[0], u[1], model_of(h), h->opt.seed, h->step, h->markers, (const unsigned int*)h->carry, h->idx, h->gid0, zs);
+                       u[0], u[1], model_of(h), h->opt.seed, h->step, h->markers, (const unsigned int*)h->carry, h->idx, h->gid0, zs,
+                       h->idx_unresolved ? 1 : 0);
     RR_HIP_TRY(hipGetLastError());
     h->z_staged = zs.words > 0;
     h->idx_unresolved = false;
@@ -1240,6 +1300,39 @@ rr_status fetch_ctl(rr_fs1* h) {
   return h->p2p.check(h->stream);  // a latched peer-wait timeout must not look like a healthy filter
 }
 
+rr_status ensure_mailbox(rr_fs1* h) {
+  if (h->best_mail) return RR_OK;
+  RR_HIP_TRY(hipHostMalloc(&h->best_mail, sizeof(BestMail), hipHostMallocDefault));
+  std::memset(h->best_mail, 0, sizeof(BestMail));
+  RR_HIP_TRY(hipMalloc(&h->best_ticket, sizeof(unsigned int)));
+  RR_HIP_TRY(hipMemsetAsync(h->best_ticket, 0, sizeof(unsigned int), h->stream));
+  return RR_OK;
+}
+
+// wait for stamp `want` of the mailbox: polls (a healthy device answers within ~15 us), then waits the ordinary way
+rr_status await_mailbox(rr_fs1* h, uint64_t want) {
+  const volatile uint64_t* seq = &h->best_mail->seq;
+  for (long spins = 0; spins < 2000000; ++spins)  // ~ tens of milliseconds
+    if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) return RR_OK;
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));  // slow device / long queue in front of the kernel
+  if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != want) return fail(RR_RUNTIME_ERROR, "the device's stamp never reached the host mailbox");
+  return RR_OK;
+}
+
+// rr_fs1_synchronize for a filter on one GPU: a one-thread kernel stamps the mailbox behind everything enqueued so far; Ctl is
+// only copied back when the stamp says there is something to report
+rr_status synchronize_light(rr_fs1* h) {
+  if (h->p2p.ready || h->n != h->n_global) return fetch_ctl(h);
+  rr_status s = ensure_mailbox(h);
+  if (s != RR_OK) return s;
+  const uint64_t want = ++h->best_seq;
+  hipLaunchKernelGGL(k_fs1_stamp, dim3(1), dim3(1), 0, h->stream, (const Ctl*)h->ctl, h->best_mail, want);
+  RR_HIP_TRY(hipGetLastError());
+  if ((s = await_mailbox(h, want)) != RR_OK) return s;
+  rr::spin_release(h->opt.device, h);  // the stream is idle
+  return h->best_mail->flags ? fetch_ctl(h) : RR_OK;
+}
+
 rr_status ensure_pose_stage(rr_fs1* h) {
   if (!h->pose_stage) RR_HIP_TRY(hipMalloc(&h->pose_stage, 4 * h->n * sizeof(double)));
   return RR_OK;
@@ -1369,6 +1462,8 @@ void rr_fs1_destroy(rr_fs1* h) {
   (void)hipFree(h->noise);
   (void)hipFree(h->pose_stage);
   (void)hipFree(h->part_bits);
+  (void)hipFree(h->best_ticket);
+  if (h->best_mail) (void)hipHostFree(h->best_mail);
   (void)hipFree(h->part_idx);
   (void)hipFree(h->plane_list);
   (void)hipFree(h->ctl);
@@ -1516,7 +1611,7 @@ rr_status rr_fs1_update_async(rr_fs1* h, const double u[2], const double* z, siz
 rr_status rr_fs1_synchronize(rr_fs1* h) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
-  return fetch_ctl(h);  // waits for the stream; also where a handle learns that its one-launch plan had to degrade
+  return synchronize_light(h);  // waits for the stream; also where a handle learns that its one-launch plan had to degrade
 }
 
 rr_status rr_fs1_update(rr_fs1* h, const double u[2], const double* z, size_t n_z) {
@@ -1528,22 +1623,22 @@ rr_status rr_fs1_update(rr_fs1* h, const double u[2], const double* z, size_t n_
 rr_status rr_fs1_best_particle(rr_fs1* h, double out_pose[3], double* out_weight, uint64_t* out_index) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
-  if ((s = materialise(h)) != RR_OK) return s;
-  const int blocks = (int)std::min<uint64_t>(1024, grid_for(h->n, kBlock));
-  hipLaunchKernelGGL(k_fs1_argmax, dim3(blocks), dim3(kBlock), 0, h->stream, h->pw, h->n, h->part_bits, h->part_idx);
-  hipLaunchKernelGGL(k_fs1_argmax_final, dim3(1), dim3(64), 0, h->stream, h->ctl, h->part_bits, h->part_idx, blocks);
+  // one GPU: a pending resample stays pending (the pose is read through idx), so the next update keeps its three launches;
+  // a shard's idx may point into the inbox: settle first
+  const bool through_idx = !h->pl.inbox && h->n == h->n_global;
+  if ((s = through_idx ? ensure_resolved(h) : materialise(h)) != RR_OK) return s;
+  if ((s = ensure_mailbox(h)) != RR_OK) return s;
+  const int blocks = (int)std::min<uint64_t>(256, grid_for(h->n, kBlock));
+  const uint64_t want = ++h->best_seq;
+  hipLaunchKernelGGL(k_fs1_best, dim3(blocks), dim3(kBlock), 0, h->stream, (const double*)h->pw, h->n, (const double*)h->pl.s[0],
+                     (const double*)h->pl.s[1], h->ctl, h->part_bits, h->part_idx, h->best_ticket, h->best_mail, want,
+                     (const unsigned int*)(through_idx ? h->idx : nullptr));
   RR_HIP_TRY(hipGetLastError());
-  if ((s = fetch_ctl(h)) != RR_OK) return s;
-  const uint64_t bi = h->ctl_host->best_index;
-  const int cur = h->ctl_host->cur;
-  double pose[3], w;
-  for (int k = 0; k < 3; ++k)
-    RR_HIP_TRY(hipMemcpyAsync(&pose[k], h->pl.s[cur] + k * h->n + bi, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  RR_HIP_TRY(hipMemcpyAsync(&w, h->pw + bi, sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  RR_HIP_TRY(hipStreamSynchronize(h->stream));
-  if (out_pose) std::memcpy(out_pose, pose, sizeof pose);
-  if (out_weight) *out_weight = w;
-  if (out_index) *out_index = bi;
+  if ((s = await_mailbox(h, want)) != RR_OK) return s;
+  if (h->best_mail->flags && (s = fetch_ctl(h)) != RR_OK) return s;  // a latched device-side condition: report it as usual
+  if (out_pose) std::memcpy(out_pose, h->best_mail->pose, sizeof(double) * 3);
+  if (out_weight) *out_weight = h->best_mail->weight;
+  if (out_index) *out_index = h->best_mail->index;
   return RR_OK;
 }
 

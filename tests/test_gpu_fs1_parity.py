@@ -361,6 +361,31 @@ def test_one_launch_plan_equals_the_two_kernel_plan(fs, algorithm, monkeypatch):
         assert bits_equal(ma, mb), f"maps differ at update {t}"
 
 
+def test_best_particle_reads_through_a_pending_resample(fs):
+    """rr_fs1_best_particle while the last update's resample is still only markers (one launch, host mailbox, no settling):
+    index, weight and pose must be those of the settled set that get_state produces afterwards (fastslam1.rs:269-274 after
+    :205-234: equal weights 1/n, ties -> the last index, whose particle is a clone of some source)."""
+    n, L = 3000, 10
+    lms = scene(L, 53)
+    prm = fs.default_params()
+    prm.first_obs_cov = 2.0
+    prm.nth = n / 1.5
+    f = fs.FastSlam1(n, L, params=prm, seed=81)
+    fired = 0
+    for t in range(12):
+        f.update_async([1.0, 0.1], np.ascontiguousarray(observations_for(fs, H.true_pose(t + 1), lms, seed=81, step=t)))
+        pose, w, i = f.best_particle()          # the resample (if the gate opened) is still pending here
+        f.update_async([1.0, 0.1], np.ascontiguousarray(observations_for(fs, H.true_pose(t + 1), lms, seed=81, step=100 + t)))
+        pose, w, i = f.best_particle()
+        gp, _ = f.get_state()                   # settles
+        fired += int(f.last_resample_fired())
+        assert bits_equal(np.array([w, *pose]), gp[i]), f"round {t}"
+        assert i == max(k for k in range(n) if gp[k, 0] == gp[:, 0].max())
+        pose2, w2, i2 = f.best_particle()       # and once more on the settled set
+        assert i2 == i and bits_equal(pose2, pose) and w2 == w
+    assert fired > 0
+
+
 def test_async_updates_equal_synchronised_updates(fs):
     """A run of rr_fs1_update_async calls with nothing in between takes the three-launch update: the first kernel resolves the
     previous plan's markers, moves the poses and carries the update's observations from a pinned ring slot to the device
