@@ -632,9 +632,40 @@ struct SmallArgs {
 // four doubles; the host polls `seq`.
 struct HostMail {
   double est[4];
+  uint64_t flags;  // k_est_mail: != 0 => Ctl holds something the host has to look at (a degraded plan) -- take the long way
   uint64_t seq;
 };
 constexpr int kEstRing = 32;  // per-step estimates of rr_pf_step_many gather in LDS and leave in blocks of this many steps
+
+// The synchronous try_step of a LARGE filter (rr_pf_step, fused systematic step): the step's estimate is the sum of the plan
+// kernel's per-tile partial sums in tile order, divided by Ctl.est_denom -- formed here exactly as rr_pf_last_step_estimate
+// forms it on the host (same order, same operations) and left in the mailbox, so the host polls a stamp instead of copying
+// 16 KB of partial sums and Ctl back behind a stream synchronisation (~20 us of a 70 us synchronous step at 1e6 particles).
+__global__ void k_est_mail(const Ctl* __restrict__ ctl, const double* __restrict__ partials, uint64_t n_tiles,
+                           HostMail* __restrict__ mail, uint64_t seq) {
+  // the sums are serial (tile order), the loads must not be: stage 512 tiles at a time in LDS with all threads
+  constexpr int kStage = 512;
+  __shared__ double s_part[4 * kStage];
+  const int k = threadIdx.x;
+  double acc = 0.0;
+  for (uint64_t t0 = 0; t0 < n_tiles; t0 += kStage) {
+    const uint64_t m = n_tiles - t0 < (uint64_t)kStage ? n_tiles - t0 : (uint64_t)kStage;
+    __syncthreads();
+    for (uint64_t i = threadIdx.x; i < 4 * m; i += blockDim.x) s_part[i] = partials[4 * t0 + i];
+    __syncthreads();
+    if (k < 4)
+      for (uint64_t t = 0; t < m; ++t) acc += s_part[4 * t + k];
+  }
+  if (k < 4) {
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[k]), (uint64_t)__double_as_longlong(acc / ctl->est_denom), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (k == 0) __hip_atomic_store(&mail->flags, (uint64_t)(ctl->grid_timeout != 0) | ((uint64_t)(ctl->est_step == 0) << 1), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (k == 0) __hip_atomic_store(&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // workgroup-wide helpers of the small kernel (kSmallBlock threads); every thread gets the result
 template <int BLOCK>
@@ -2895,7 +2926,30 @@ rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_
     // 300-byte read-back instead of a gather + a two-kernel moment reduction
     rr_status s = step_async_impl(h, control, obs, n_obs, true);
     if (s != RR_OK) return s;
-    return rr_pf_last_step_estimate(h, out_state);
+    if (h->p2p.ready) return rr_pf_last_step_estimate(h, out_state);
+    if (!h->mail) {
+      RR_HIP_TRY(hipHostMalloc(&h->mail, sizeof(HostMail), hipHostMallocDefault));
+      std::memset(h->mail, 0, sizeof(HostMail));
+    }
+    const uint64_t want = ++h->mail_seq;
+    hipLaunchKernelGGL(k_est_mail, dim3(1), dim3(256), 0, h->stream, (const Ctl*)h->ctl, (const double*)h->est_partials, h->n_tiles, h->mail, want);
+    RR_HIP_TRY(hipGetLastError());
+    const volatile uint64_t* seq = &h->mail->seq;
+    bool seen = false;
+    for (long spins = 0; spins < 4000000; ++spins) {
+      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) {
+        seen = true;
+        break;
+      }
+    }
+    if (!seen) {
+      RR_HIP_TRY(hipStreamSynchronize(h->stream));
+      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != want) return fail(RR_RUNTIME_ERROR, "the step's estimate never reached the host mailbox");
+    }
+    rr::spin_release(h->opt.device, h);  // the stream is idle
+    if (h->mail->flags) return rr_pf_last_step_estimate(h, out_state);  // a degraded plan to take note of (fetch_ctl), or no estimate
+    for (int k = 0; k < 4; ++k) out_state[k] = h->mail->est[k];
+    return RR_OK;
   }
   rr_status s = rr_pf_step_async(h, control, obs, n_obs);
   if (s != RR_OK) return s;
