@@ -500,6 +500,13 @@ RR_HD double rr_fs1_update_one(double px, double py, double pyaw, double zd, dou
     i00 = 1.0; i01 = 0.0; i10 = 0.0; i11 = 1.0;
   } else {
     i00 = s11 * rdet; i01 = -s01 * rdet; i10 = -s10 * rdet; i11 = s00 * rdet;
+    if (rr_fabs(det) < 0x1p-1000) {
+      /* the reciprocal of det is on its way to overflow (inf from 2^-1024 down) while the reference's four quotients are
+       * still finite (a collapsed landmark covariance under a tiny R; never seen in a tracking filter): det and the entries
+       * of S scaled by 2^512 first -- exact -- then entry * reciprocal as above */
+      const double rs = 1.0 / (det * 0x1p512);
+      i00 = (s11 * 0x1p512) * rs; i01 = (-s01 * 0x1p512) * rs; i10 = (-s10 * 0x1p512) * rs; i11 = (s00 * 0x1p512) * rs;
+    }
   }
   /* K = P * H^T * S^-1 :165 */
   double pht00 = rr_fma(p01, h01, p00 * h00);

@@ -75,6 +75,29 @@ def test_KA4_fastslam_ekf(ref, det):
     assert close(pw[0], 0.6772339004082811)
 
 
+def test_KA4b_fastslam_ekf_near_singular_innovation_covariance(ref, det):
+    """det(S) positive but below 2^-1000 (fastslam1.rs:161-181 with a tiny R and a collapsed landmark covariance): the literal
+    likelihood exp(..)/(2 pi sqrt(det)) is finite; the D-spec's reciprocal form 1/det would overflow to inf there (weight inf ->
+    maximum inf -> the degenerate image for the whole filter), so below 2^-1000 it takes the literal quotient
+    (include/rr_pf_spec.h, rr_fs1_update_one).  Just above the guard the reciprocal form must agree as well."""
+    for r, guarded in ((1e-160, True), (1e-140, False)):
+        m = oracle.ref_fs1_model()
+        m.r00, m.r11 = r, r
+        e = np.array([5.0, 0.0, 0.0, 0.0, 0.0, 0.0])  # covariance 0: S = R
+        w = C.c_double(1.0)
+        ref.ref_fs1_update_landmark(0.0, 0.0, 0.0, C.byref(w), 5.0, 0.0, dp(e), C.byref(m))  # innovation exactly 0
+        assert (r * r < 2.0 ** -1000) == guarded
+        assert np.isfinite(w.value) and close(w.value, 1.0 / (2.0 * np.pi * r), 1e-4)  # (det = r^2 is subnormal in the first case: few bits)
+        md = oracle.det_fs1_model()
+        md.r00, md.r11 = r, r
+        maps = np.array([5.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+        pw = np.array([1.0])
+        zero = np.zeros(1)
+        det.det_fs1_observe(1, dp(zero), dp(zero.copy()), dp(zero.copy()), dp(pw), dp(maps), dp(np.array([5.0, 0.0, 0.0])), 1, C.byref(md), 1)
+        assert np.isfinite(pw[0]) and close(pw[0], w.value, 1e-9)
+        assert close(maps[0], e[0]) and close(maps[1], e[1]) and close(maps[2], e[2]) and close(maps[5], e[5])
+
+
 def test_KA5_systematic(ref, det):
     w = np.array([0.1, 0.2, 0.3, 0.4])
     idx = np.empty(4, np.uint32)
