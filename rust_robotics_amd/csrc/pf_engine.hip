@@ -578,22 +578,45 @@ __global__ __launch_bounds__(kBlock) void k_moments(Bufs b, const double* __rest
   }
 }
 
+// Host-visible mailbox of a filter (pinned, host-coherent memory): the synchronous try_step of a small filter reads the
+// estimate the kernel wrote there instead of paying two device-to-host copies and a stream synchronisation (~20 us) for
+// four doubles; the host polls `seq`.
+struct HostMail {
+  double est[4];
+  uint64_t flags;  // k_est_mail: != 0 => Ctl holds something the host has to look at (a degraded plan) -- take the long way
+  uint64_t seq;
+};
 // one wave per moment: lanes stride over the per-block partials (fixed order per lane), then a
-// shuffle tree -- deterministic for a given grid
+// shuffle tree -- deterministic for a given grid.  mail != null: the estimate (rr_pf_estimate: shift point + first moments / W,
+// formed as compute_moments forms it on the host) also goes to the host mailbox, stamped `seq`; flags != 0 when the weights do
+// not sum to a positive finite number (the host then takes the uniform-weights retry of particle_filter.rs:433-438)
 __global__ __launch_bounds__(kNumMoments * 64) void k_moments_final(Bufs b, Ctl* __restrict__ ctl,
                                                                    const double* __restrict__ partials,
-                                                                   int n_blocks) {
+                                                                   int n_blocks, HostMail* __restrict__ mail, uint64_t seq) {
+  __shared__ double s_m[kNumMoments];
   const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double s = 0.0;
   for (int j = lane; j < n_blocks; j += 64) s += partials[j * kNumMoments + k];
   s = rr::wave_sum(s);
-  if (lane == 0) ctl->moments[k] = s;
+  if (lane == 0) {
+    ctl->moments[k] = s;
+    s_m[k] = s;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
     const int cur = ctl->cur;
-    ctl->shift_point[0] = b.x[cur][0];
-    ctl->shift_point[1] = b.y[cur][0];
-    ctl->shift_point[2] = b.yaw[cur][0];
-    ctl->shift_point[3] = b.v[cur][0];
+    const double p0[4] = {b.x[cur][0], b.y[cur][0], b.yaw[cur][0], b.v[cur][0]};
+    for (int q = 0; q < 4; ++q) ctl->shift_point[q] = p0[q];
+    if (mail) {
+      const double W = s_m[0];
+      const bool ok = W > 0.0 && W < INFINITY;
+      for (int q = 0; q < 4; ++q)
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[q]), (uint64_t)__double_as_longlong(p0[q] + s_m[1 + q] / W), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&mail->flags, (uint64_t)(ok ? 0 : 1) | ((uint64_t)(ctl->grid_timeout != 0) << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
   }
 }
 
@@ -627,14 +650,6 @@ struct SmallArgs {
   uint64_t mail_seq;      // != 0: the last step's estimate also goes to the host mailbox, stamped with this number
 };
 
-// Host-visible mailbox of a filter (pinned, host-coherent memory): the synchronous try_step of a small filter reads the
-// estimate the kernel wrote there instead of paying two device-to-host copies and a stream synchronisation (~20 us) for
-// four doubles; the host polls `seq`.
-struct HostMail {
-  double est[4];
-  uint64_t flags;  // k_est_mail: != 0 => Ctl holds something the host has to look at (a degraded plan) -- take the long way
-  uint64_t seq;
-};
 constexpr int kEstRing = 32;  // per-step estimates of rr_pf_step_many gather in LDS and leave in blocks of this many steps
 
 // The synchronous try_step of a LARGE filter (rr_pf_step, fused systematic step): the step's estimate is the sum of the plan
@@ -1422,27 +1437,54 @@ __device__ inline uint64_t kld_hash(int32_t a, int32_t b, int32_t c) {
   return h;
 }
 
+// One lane per DISTINCT value of `slot` among the wave's valid lanes: the lowest such lane (its draw index is the smallest of
+// the group, draw indices ascend with the lane).  A tracking filter's draws fall into a few dozen bins, and same-address
+// atomics are carried out one after the other at the memory side (7.5 ns each): 5000 draws claiming and lowering ~100
+// slots took 36 us; with one atomic per bin and wave, and none when a look shows that nothing would change, 5 us.
+__device__ inline bool wave_first_of_slot(uint32_t slot, bool valid) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(valid);
+  bool first = false;
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t s_l = (uint32_t)__builtin_amdgcn_readlane((int)slot, leader);
+    const unsigned long long same = __ballot(valid && slot == s_l);
+    if (lane == leader) first = true;
+    todo &= ~same;
+  }
+  return first;
+}
+
 __global__ __launch_bounds__(kBlock) void k_kld_insert(const int32_t* __restrict__ keys, unsigned int* __restrict__ table,
                                                       unsigned int* __restrict__ minslot,
                                                       unsigned int* __restrict__ myslot, uint64_t n_draws,
                                                       uint64_t hash_size) {
   const uint64_t m = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (m >= n_draws) return;
-  const int32_t a = keys[3 * m], bb = keys[3 * m + 1], c = keys[3 * m + 2];
+  const bool valid = m < n_draws;  // (every lane stays for the wave-wide steps)
+  int32_t a = 0, bb = 0, c = 0;
+  if (valid) {
+    a = keys[3 * m];
+    bb = keys[3 * m + 1];
+    c = keys[3 * m + 2];
+  }
   uint64_t s = kld_hash(a, bb, c) & (hash_size - 1);
-  for (;;) {
+  // the home slot of a bin is claimed once per wave, not once per draw
+  if (wave_first_of_slot((uint32_t)s, valid) && __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kKldEmpty)
+    (void)atomicCAS(&table[s], kKldEmpty, (unsigned int)m);
+  bool placed = !valid;
+  while (!placed) {
     unsigned int o = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (o == kKldEmpty) {
       o = atomicCAS(&table[s], kKldEmpty, (unsigned int)m);
       if (o == kKldEmpty) o = (unsigned int)m;
     }
-    if (o == m || (keys[3 * (uint64_t)o] == a && keys[3 * (uint64_t)o + 1] == bb && keys[3 * (uint64_t)o + 2] == c)) {
-      atomicMin(&minslot[s], (unsigned int)m);
-      myslot[m] = (unsigned int)s;
-      return;
-    }
-    s = (s + 1) & (hash_size - 1);  // another bin lives here: linear probing (the table is at most half full)
+    if (o == m || (keys[3 * (uint64_t)o] == a && keys[3 * (uint64_t)o + 1] == bb && keys[3 * (uint64_t)o + 2] == c)) placed = true;
+    else s = (s + 1) & (hash_size - 1);  // another bin lives here: linear probing (the table is at most half full)
   }
+  if (valid) myslot[m] = (unsigned int)s;
+  // the bin's smallest draw index: the wave's smallest draw of the bin speaks for the wave, and only if a look says it matters
+  if (wave_first_of_slot((uint32_t)s, valid) && __hip_atomic_load(&minslot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned int)m)
+    atomicMin(&minslot[s], (unsigned int)m);
 }
 
 constexpr int kKldThreads = 1024;
@@ -1451,7 +1493,8 @@ constexpr int kKldThreads = 1024;
 __global__ __launch_bounds__(kKldThreads) void k_kld_count(unsigned int* __restrict__ minslot,
                                                           const unsigned int* __restrict__ myslot, uint64_t n_draws,
                                                           rr_mcl_adaptive kld, uint64_t* __restrict__ out,
-                                                          unsigned int* __restrict__ table, uint64_t hash_size) {
+                                                          unsigned int* __restrict__ table, uint64_t hash_size, Bufs b,
+                                                          Ctl* __restrict__ ctl, const unsigned int* __restrict__ idx, int gather) {
   __shared__ uint64_t s_cnt[kKldThreads / rr::kWave];
   __shared__ uint64_t s_req[kKldThreads / rr::kWave];
   __shared__ uint64_t s_stop;
@@ -1492,16 +1535,19 @@ __global__ __launch_bounds__(kKldThreads) void k_kld_count(unsigned int* __restr
     req_carry = chunk_req;
     __syncthreads();
   }
-  if (tid == 0) {
-    const uint64_t stop = s_stop;
-    out[0] = stop == ~0ull ? n_draws : stop + 1;  // :342: at most max_particles
-  }
+  const uint64_t n_new = s_stop == ~0ull ? n_draws : s_stop + 1;  // :342: at most max_particles
+  if (tid == 0) out[0] = n_new;
   // every read of minslot[] above happened before a barrier all threads have passed (the loop ends with one, or breaks
   // right after one): the table can go
   __syncthreads();
   for (uint64_t k = tid; k < hash_size; k += kKldThreads) {
     table[k] = kKldEmpty;
     minslot[k] = kKldEmpty;
+  }
+  if (gather) {  // a filter of the reference's sizes (<= 16 384 candidate draws): k_kld_gather_dyn's work on the way, one launch less
+    const int dst = ctl->cur, src = dst ^ 1;
+    for (uint64_t k = tid; k < n_new; k += kKldThreads) copy_particle(b, src, dst, idx[k], k, false, nullptr);
+    if (tid == 0) ctl->n_active = n_new;  // (nothing in this launch reads it)
   }
 }
 
@@ -2087,10 +2133,12 @@ rr_status resample_adaptive(rr_pf* h, const double* r_explicit_dev, bool lazy = 
                        h->opt.seed, h->rstep, 1);
     hipLaunchKernelGGL(k_kld_insert, dim3(grid_for(M, kBlock)), dim3(kBlock), 0, h->stream, (const int32_t*)h->kld_keys,
                        h->kld_table, h->kld_minslot, h->kld_myslot, M, h->kld_hash_size);
+    const int gather_in_count = M <= 16384 ? 1 : 0;
     hipLaunchKernelGGL(k_kld_count, dim3(1), dim3(kKldThreads), 0, h->stream, h->kld_minslot, (const unsigned int*)h->kld_myslot, M, h->kld,
-                       h->kld_out, h->kld_table, h->kld_hash_size);
-    hipLaunchKernelGGL(k_kld_gather_dyn, dim3(grid_for(M, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, (const unsigned int*)h->idx,
-                       (const uint64_t*)h->kld_out);
+                       h->kld_out, h->kld_table, h->kld_hash_size, h->b, h->ctl, (const unsigned int*)h->idx, gather_in_count);
+    if (!gather_in_count)
+      hipLaunchKernelGGL(k_kld_gather_dyn, dim3(grid_for(M, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, (const unsigned int*)h->idx,
+                         (const uint64_t*)h->kld_out);
     RR_HIP_TRY(hipGetLastError());
     h->n_dirty = true;  // weights are uniform 1/n_new from here (Ctl.weights_uniform, :359-362)
   }
@@ -2118,13 +2166,45 @@ rr_status fetch_ctl(rr_pf* h) {
 rr_status compute_moments(rr_pf* h, double est[4], double cov[16]) {
   for (int attempt = 0; attempt < 2; ++attempt) {
     const int blocks = (int)std::min<uint64_t>(kMomentBlocks, grid_for(h->n, kBlock));
+    // the mean alone (rr_pf_estimate, the try_step of filters without an in-step estimate) comes back through the host mailbox:
+    // no copy of Ctl, no stream synchronisation
+    const bool by_mail = est && !cov && attempt == 0 && !h->p2p.ready && !h->profiling;
+    uint64_t want = 0;
+    if (by_mail) {
+      if (!h->mail) {
+        RR_HIP_TRY(hipHostMalloc(&h->mail, sizeof(HostMail), hipHostMallocDefault));
+        std::memset(h->mail, 0, sizeof(HostMail));
+      }
+      want = ++h->mail_seq;
+    }
     {
       Timed t(h, RR_K_MOMENTS);
       hipLaunchKernelGGL(k_moments, dim3(blocks), dim3(kBlock), 0, h->stream, h->b, h->w, h->ctl, h->n, attempt,
                          h->partials);
-      hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(kNumMoments * 64), 0, h->stream, h->b, h->ctl, h->partials, blocks);
+      hipLaunchKernelGGL(k_moments_final, dim3(1), dim3(kNumMoments * 64), 0, h->stream, h->b, h->ctl, h->partials, blocks,
+                         by_mail ? h->mail : (HostMail*)nullptr, want);
     }
     RR_HIP_TRY(hipGetLastError());
+    if (by_mail) {
+      const volatile uint64_t* seq = &h->mail->seq;
+      bool seen = false;
+      for (long spins = 0; spins < 4000000; ++spins) {
+        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) {
+          seen = true;
+          break;
+        }
+      }
+      if (!seen) {
+        RR_HIP_TRY(hipStreamSynchronize(h->stream));
+        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != want) return fail(RR_RUNTIME_ERROR, "the estimate never reached the host mailbox");
+      }
+      rr::spin_release(h->opt.device, h);  // the stream is idle
+      if (h->mail->flags == 0) {
+        for (int k = 0; k < 4; ++k) est[k] = h->mail->est[k];
+        return RR_OK;
+      }
+      // degenerate weights or a degraded plan to take note of: the long way (Ctl read back; the moments are in it)
+    }
     rr_status s = fetch_ctl(h);
     if (s != RR_OK) return s;
     const double W = h->ctl_host->moments[0];
