@@ -92,3 +92,98 @@ def test_fastslam_update_agreement(det, ref):
         np.testing.assert_allclose(dw, pw, **TOL)
         np.testing.assert_allclose(np.column_stack([dx, dy, dyaw]), np.column_stack([px, py, pyaw]), **TOL)
         np.testing.assert_allclose(oracle.maps_planes_to_aos(planes, n, L), lm, **TOL)
+
+
+def test_fastslam_ekf_agreement_at_the_edges(det, ref):
+    """One EKF update (fastslam1.rs:140-183) of the D-spec against the literal restatement over geometries that sit on the
+    arithmetic's edges: bearings and headings next to +-pi (both angle wraps), landmarks centimetres to kilometres from the
+    particle (the Jacobian's 1/d and 1/d^2), covariances from collapsed to just under the first-observation threshold and
+    exactly on it (the branch test is `>`), innovations from zero to many sigmas (weights down to the underflow range)."""
+    rng = np.random.default_rng(31)
+    n = 40_000
+    mr, md = oracle.ref_fs1_model(), oracle.det_fs1_model()
+    thr = mr.init_threshold
+    yaw = np.where(rng.random(n) < 0.3, np.sign(rng.standard_normal(n)) * (np.pi - 10.0 ** rng.uniform(-12, -1, n)), rng.uniform(-np.pi, np.pi, n))
+    dist = 10.0 ** rng.uniform(-2, 3, n)
+    bearing = np.where(rng.random(n) < 0.3, np.sign(rng.standard_normal(n)) * (np.pi - 10.0 ** rng.uniform(-12, -1, n)), rng.uniform(-np.pi, np.pi, n))
+    px, py = rng.uniform(-50, 50, n), rng.uniform(-50, 50, n)
+    lx, ly = px + dist * np.cos(yaw + bearing), py + dist * np.sin(yaw + bearing)
+    scale = 10.0 ** rng.uniform(-12, np.log10(thr) - 1e-3, n)
+    scale[rng.random(n) < 0.02] = thr          # exactly on the threshold: still the EKF branch
+    scale[rng.random(n) < 0.02] = 0.0          # collapsed covariance
+    rho = rng.uniform(-0.95, 0.95, n)
+    c00, c11 = scale, scale * 10.0 ** rng.uniform(-2, 0, n)
+    c01 = rho * np.sqrt(c00 * c11)
+    sig = 10.0 ** rng.uniform(-3, 1.2, n)      # innovation in units of sqrt(R)
+    zd = np.maximum(dist + sig * np.sqrt(mr.r00) * rng.standard_normal(n), 0.0)
+    za = bearing + sig * np.sqrt(mr.r11) * rng.standard_normal(n)
+    za = np.where(rng.random(n) < 0.5, za, (za + np.pi) % (2 * np.pi) - np.pi)  # wrapped or not: the update wraps the innovation anyway
+    e_ref = np.column_stack([lx, ly, c00, c01, c01, c11]).copy()
+    w_ref = np.ones(n)
+    for p in range(n):
+        w = C.c_double(1.0)
+        ref.ref_fs1_update_landmark(px[p], py[p], yaw[p], C.byref(w), zd[p], za[p], dp(e_ref[p]), C.byref(mr))
+        w_ref[p] = w.value
+    # D-spec: one landmark, n particles, every particle its own observation -> n single-particle calls on plane views
+    e_det = np.column_stack([lx, ly, c00, c01, c01, c11]).copy()
+    w_det = np.ones(n)
+    for p in range(n):
+        planes = np.ascontiguousarray(e_det[p])
+        pw = np.array([1.0])
+        det.det_fs1_observe(1, dp(np.array([px[p]])), dp(np.array([py[p]])), dp(np.array([yaw[p]])), dp(pw), dp(planes),
+                            dp(np.array([zd[p], za[p], 0.0])), 1, C.byref(md), 1)
+        e_det[p], w_det[p] = planes, pw[0]
+    assert np.all(np.isfinite(w_ref)) and np.all(np.isfinite(e_ref))
+    big = w_ref > 1e-280
+    assert np.count_nonzero(big) > n // 2 and np.count_nonzero(~big) > 0
+    # The literal code's own conditioning sets the bar: its Kalman gain divides by det(S), and where the covariance is collapsed
+    # relative to R the posterior loses digits in BOTH codes.  Relative 1e-6 on the weights that are not underflowing, and
+    # 1e-6 of the entry's scale (distance for the mean, prior covariance for the covariance) on the landmark.
+    np.testing.assert_allclose(w_det[big], w_ref[big], rtol=1e-6, atol=0.0)
+    assert np.all(w_det[~big] <= 1e-279)
+    np.testing.assert_allclose(e_det[:, :2], e_ref[:, :2], rtol=1e-6, atol=1e-6)
+    cov_scale = np.maximum(c00, c11)[:, None]
+    assert np.all(np.abs(e_det[:, 2:] - e_ref[:, 2:]) <= 1e-6 * cov_scale + 1e-300)
+
+
+def test_pf_arithmetic_agreement_at_the_edges(det, ref):
+    """particle_filter.rs:279-296 and :310-329 of the D-spec against the literal restatement where the elementary functions are
+    stretched: headings that have grown for a long run (the reference never wraps a particle filter's yaw: |yaw| up to 2^30 rad,
+    the bound up to which the D-spec's sine / cosine reduction is exact to the last bits -- include/rr_detmath.h; a filter turning at
+    0.1 rad/s and stepping at 10 Hz gets there in 1e11 steps, three centuries), speeds and noises of either sign and any magnitude, ranges from a landmark sitting on
+    the particle to kilometres, range noise from millimetres to tens of metres, innovations from zero to the underflow range."""
+    rng = np.random.default_rng(37)
+    n = 200_000
+    yaw = np.clip(rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 9, n), -(2.0 ** 30) + 1.0, 2.0 ** 30 - 1.0)
+    x, y = rng.uniform(-1e3, 1e3, n), rng.uniform(-1e3, 1e3, n)
+    v = rng.standard_normal(n)
+    nv, nw = rng.standard_normal(n) * 10.0 ** rng.uniform(-6, 2, n), rng.standard_normal(n) * 10.0 ** rng.uniform(-6, 2, n)
+    for u0, u1, dt in ((1.0, 0.1, 0.1), (-37.5, 6.0, 0.01), (0.0, 0.0, 1.0), (250.0, -90.0, 0.5)):
+        rx, ry, ryaw, rv = x.copy(), y.copy(), yaw.copy(), v.copy()
+        dx, dy, dyaw, dv = x.copy(), y.copy(), yaw.copy(), v.copy()
+        ref.ref_pf_predict(n, dp(rx), dp(ry), dp(ryaw), dp(rv), u0, u1, dt, dp(nv), dp(nw))
+        det.det_pf_predict(n, dp(dx), dp(dy), dp(dyaw), dp(dv), u0, u1, dt, dp(nv), dp(nw), 0, 0, 0, 0.0, 0.0)
+        np.testing.assert_allclose(np.column_stack([dx, dy, dyaw, dv]), np.column_stack([rx, ry, ryaw, rv]), **TOL)
+        # the step itself (what was added), not only the sum it disappears in: cos / sin of the large headings
+        np.testing.assert_allclose(dx - x, rx - x, rtol=1e-6, atol=1e-9 * max(1.0, abs(u0) + 100.0) * dt)
+        np.testing.assert_allclose(dy - y, ry - y, rtol=1e-6, atol=1e-9 * max(1.0, abs(u0) + 100.0) * dt)
+    # weights: L observations per particle, each with its own distance error
+    n = 20_000
+    for L, sigma in ((1, 0.2), (4, 0.5), (32, 0.2), (64, 0.001), (16, 30.0)):
+        px, py = rng.uniform(-100, 100, n), rng.uniform(-100, 100, n)
+        lm = rng.uniform(-100, 100, (L, 2))
+        lm[0] = (px[0], py[0])  # a landmark exactly on a particle: distance 0
+        true_d = np.hypot(lm[:, 0] - 3.0, lm[:, 1] + 4.0)
+        obs = np.ascontiguousarray(np.column_stack([np.maximum(true_d + sigma * rng.standard_normal(L) * 10.0 ** rng.uniform(-2, 1, L), 0.0), lm]))
+        # half the cloud near the pose the observations were taken from (weights of ordinary size), half anywhere (underflow)
+        px[: n // 2] = 3.0 + sigma * rng.standard_normal(n // 2)
+        py[: n // 2] = -4.0 + sigma * rng.standard_normal(n // 2)
+        wr, wf, wp = np.empty(n), np.empty(n), np.empty(n)
+        ref.ref_pf_update_raw(n, dp(px), dp(py), dp(wr), dp(obs), L, sigma)
+        det.det_pf_weights(n, dp(px), dp(py), dp(wf), dp(obs), L, sigma, 0)
+        det.det_pf_weights(n, dp(px), dp(py), dp(wp), dp(obs), L, sigma, 1)
+        big = wr > 1e-250
+        assert np.count_nonzero(big) > 100, (L, sigma)
+        np.testing.assert_allclose(wf[big], wr[big], rtol=1e-6)
+        np.testing.assert_allclose(wp[big], wr[big], rtol=1e-6)
+        assert np.all(wf[~big] <= 1e-249) and np.all(wp[~big] <= 1e-249)
