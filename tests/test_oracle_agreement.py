@@ -187,3 +187,28 @@ def test_pf_arithmetic_agreement_at_the_edges(det, ref):
         np.testing.assert_allclose(wf[big], wr[big], rtol=1e-6)
         np.testing.assert_allclose(wp[big], wr[big], rtol=1e-6)
         assert np.all(wf[~big] <= 1e-249) and np.all(wp[~big] <= 1e-249)
+
+
+def test_fastslam_predict_agreement_at_the_edges(det, ref):
+    """fastslam1.rs:123-137 (+ :70-89: the motion model and normalize_angle) of the D-spec against the literal restatement:
+    headings on and next to +-pi, yaw increments that overshoot the wrap by several turns, controls of either sign."""
+    rng = np.random.default_rng(41)
+    n = 100_000
+    mr, md = oracle.ref_fs1_model(), oracle.det_fs1_model()
+    yaw = rng.uniform(-np.pi, np.pi, n)
+    edge = rng.random(n) < 0.4
+    yaw[edge] = np.sign(rng.standard_normal(edge.sum())) * (np.pi - 10.0 ** rng.uniform(-15, -1, edge.sum()))
+    yaw[:4] = [np.pi, -np.pi, np.nextafter(np.pi, 0.0), np.nextafter(-np.pi, 0.0)]
+    px, py = rng.uniform(-200, 200, n), rng.uniform(-200, 200, n)
+    z0, z1 = rng.standard_normal(n), rng.standard_normal(n) * 10.0 ** rng.uniform(-2, 2, n)  # up to ~100 sigma of yaw-rate noise
+    for u0, u1 in ((1.0, 0.1), (-3.0, 25.0), (0.0, 0.0), (40.0, -300.0)):
+        rx, ry, ryaw = px.copy(), py.copy(), yaw.copy()
+        dx, dy, dyaw = px.copy(), py.copy(), yaw.copy()
+        ref.ref_fs1_predict(n, dp(rx), dp(ry), dp(ryaw), u0, u1, dp(z0), dp(z1), C.byref(mr))
+        det.det_fs1_predict(n, dp(dx), dp(dy), dp(dyaw), u0, u1, dp(z0), dp(z1), 0, 0, 0, C.byref(md))
+        np.testing.assert_allclose(np.column_stack([dx, dy]), np.column_stack([rx, ry]), **TOL)
+        # the wrapped heading: equal as angles (a result within rounding of +-pi may come out on either side of the cut)
+        d = np.abs(dyaw - ryaw)
+        d = np.minimum(d, 2 * np.pi - d)
+        assert d.max() <= 1e-9, d.max()
+        assert np.all(np.abs(dyaw) <= np.pi + 1e-12) and np.all(np.abs(ryaw) <= np.pi + 1e-12)
