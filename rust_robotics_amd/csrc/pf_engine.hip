@@ -1455,12 +1455,10 @@ __device__ inline bool wave_first_of_slot(uint32_t slot, bool valid) {
   return first;
 }
 
-__global__ __launch_bounds__(kBlock) void k_kld_insert(const int32_t* __restrict__ keys, unsigned int* __restrict__ table,
-                                                      unsigned int* __restrict__ minslot,
-                                                      unsigned int* __restrict__ myslot, uint64_t n_draws,
-                                                      uint64_t hash_size) {
-  const uint64_t m = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const bool valid = m < n_draws;  // (every lane stays for the wave-wide steps)
+// draw m's bin into the table (all lanes of a wave call this together; valid == false: the lane only takes part in the
+// wave-wide steps)
+__device__ inline void kld_insert_one(uint64_t m, bool valid, const int32_t* __restrict__ keys, unsigned int* __restrict__ table,
+                                      unsigned int* __restrict__ minslot, unsigned int* __restrict__ myslot, uint64_t hash_size) {
   int32_t a = 0, bb = 0, c = 0;
   if (valid) {
     a = keys[3 * m];
@@ -1487,14 +1485,21 @@ __global__ __launch_bounds__(kBlock) void k_kld_insert(const int32_t* __restrict
     atomicMin(&minslot[s], (unsigned int)m);
 }
 
+__global__ __launch_bounds__(kBlock) void k_kld_insert(const int32_t* __restrict__ keys, unsigned int* __restrict__ table,
+                                                      unsigned int* __restrict__ minslot,
+                                                      unsigned int* __restrict__ myslot, uint64_t n_draws,
+                                                      uint64_t hash_size) {
+  const uint64_t m = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  kld_insert_one(m, m < n_draws, keys, table, minslot, myslot, hash_size);
+}
+
 constexpr int kKldThreads = 1024;
-// (it also wipes the bin table and the first-occurrence slots for the NEXT resample once it has read them -- two memset
-// launches less per adaptive step; both arrays are cleared once when the filter is created)
-__global__ __launch_bounds__(kKldThreads) void k_kld_count(unsigned int* __restrict__ minslot,
-                                                          const unsigned int* __restrict__ myslot, uint64_t n_draws,
-                                                          rr_mcl_adaptive kld, uint64_t* __restrict__ out,
-                                                          unsigned int* __restrict__ table, uint64_t hash_size, Bufs b,
-                                                          Ctl* __restrict__ ctl, const unsigned int* __restrict__ idx, int gather) {
+// One workgroup of kKldThreads: the number of draws the reference's loop makes before it stops (:340-352) -- occupied-bin
+// count after every draw (scan of the first-occurrence flags), running maximum of the KLD bound, first draw that satisfies
+// the stop rule.  Every thread gets the result.  Then the bin table and the first-occurrence slots are wiped for the NEXT
+// resample (both arrays are cleared once when the filter is created).
+__device__ inline uint64_t kld_count_body(unsigned int* __restrict__ minslot, const unsigned int* __restrict__ myslot, uint64_t n_draws,
+                                          const rr_mcl_adaptive& kld, unsigned int* __restrict__ table, uint64_t hash_size) {
   __shared__ uint64_t s_cnt[kKldThreads / rr::kWave];
   __shared__ uint64_t s_req[kKldThreads / rr::kWave];
   __shared__ uint64_t s_stop;
@@ -1504,7 +1509,8 @@ __global__ __launch_bounds__(kKldThreads) void k_kld_count(unsigned int* __restr
   __syncthreads();
   for (uint64_t base = 0; base < n_draws; base += kKldThreads) {
     const uint64_t m = base + tid;
-    const uint64_t flag = (m < n_draws && minslot[myslot[m]] == (unsigned int)m) ? 1ull : 0ull;
+    // (device-scope load: in the one-launch adaptive step the minima were formed by atomics of this very launch)
+    const uint64_t flag = (m < n_draws && __hip_atomic_load(&minslot[myslot[m]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)m) ? 1ull : 0ull;
     // occupied bins after draw m
     uint64_t incl = rr::wave_scan_u64(flag, lane);
     if (lane == 63) s_cnt[wv] = incl;
@@ -1536,7 +1542,6 @@ __global__ __launch_bounds__(kKldThreads) void k_kld_count(unsigned int* __restr
     __syncthreads();
   }
   const uint64_t n_new = s_stop == ~0ull ? n_draws : s_stop + 1;  // :342: at most max_particles
-  if (tid == 0) out[0] = n_new;
   // every read of minslot[] above happened before a barrier all threads have passed (the loop ends with one, or breaks
   // right after one): the table can go
   __syncthreads();
@@ -1544,10 +1549,149 @@ __global__ __launch_bounds__(kKldThreads) void k_kld_count(unsigned int* __restr
     table[k] = kKldEmpty;
     minslot[k] = kKldEmpty;
   }
+  return n_new;
+}
+
+__global__ __launch_bounds__(kKldThreads) void k_kld_count(unsigned int* __restrict__ minslot,
+                                                          const unsigned int* __restrict__ myslot, uint64_t n_draws,
+                                                          rr_mcl_adaptive kld, uint64_t* __restrict__ out,
+                                                          unsigned int* __restrict__ table, uint64_t hash_size, Bufs b,
+                                                          Ctl* __restrict__ ctl, const unsigned int* __restrict__ idx, int gather) {
+  const uint64_t n_new = kld_count_body(minslot, myslot, n_draws, kld, table, hash_size);
+  const int tid = threadIdx.x;
+  if (tid == 0) out[0] = n_new;
   if (gather) {  // a filter of the reference's sizes (<= 16 384 candidate draws): k_kld_gather_dyn's work on the way, one launch less
     const int dst = ctl->cur, src = dst ^ 1;
     for (uint64_t k = tid; k < n_new; k += kKldThreads) copy_particle(b, src, dst, idx[k], k, false, nullptr);
     if (tid == 0) ctl->n_active = n_new;  // (nothing in this launch reads it)
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The adaptive step of a filter of the reference's sizes (MonteCarloLocalizationConfig::default(): 100 - 5 000 particles) in
+// ONE launch of ONE workgroup: propagate + weight (k_propagate_weight), integer image and CDF (k_quantize_reduce, k_plan_cdf,
+// finalize_plan), the max_particles candidate draws and their bins (k_kld_draw), the bin table (k_kld_insert), the stop rule
+// (k_kld_count) and the gather -- six launches of a few microseconds of work each otherwise (36 us a step).  Same
+// per-element arithmetic, same integer sums, same draws: bit-identical to the six kernels (tests/test_gpu_kld_adaptive.py runs
+// both routes).  The particle count comes from Ctl.n_active and goes back there.
+struct AdaptSmallArgs {
+  ImageArgs img;
+  PlanArgs plan;
+  rr_mcl_adaptive kld;
+  uint64_t max_draws;
+  uint64_t hash_size;
+};
+__global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl, StepParams p,
+                                                                   ObsArg obs_arg, AdaptSmallArgs a, uint64_t* __restrict__ cdf,
+                                                                   unsigned int* __restrict__ idx, int32_t* __restrict__ keys,
+                                                                   unsigned int* __restrict__ table, unsigned int* __restrict__ minslot,
+                                                                   unsigned int* __restrict__ myslot, uint64_t* __restrict__ out,
+                                                                   uint64_t* __restrict__ coarse, int coarse_log2, int front_only) {
+  extern __shared__ double s_obs[];
+  constexpr int W = kKldThreads / rr::kWave;
+  __shared__ double s_max[W];
+  __shared__ uint64_t s_t[W], s_qh[W], s_ql[W];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int i = tid; i < 3 * p.n_obs; i += kKldThreads) s_obs[i] = obs_arg.v[i];
+  const uint64_t n = ctl->n_active;
+  const int cur = ctl->cur;
+  __syncthreads();
+  // ---- propagate + weight, in place on the live set (k_propagate_weight<true, true, false>)
+  double wmax_local = 0.0;
+  for (uint64_t i = tid; i < n; i += kKldThreads) {
+    double x = b.x[cur][i], y = b.y[cur][i], yaw = b.yaw[cur][i], v, na, nc;
+    rr_pf_motion_noise(p.seed, p.step, p.first_gid + i, p.sigma_v, p.sigma_w, &na, &nc);
+    rr_pf_propagate_one(&x, &y, &yaw, &v, p.u0, p.u1, p.dt, na, nc);
+    b.x[cur][i] = x;
+    b.y[cur][i] = y;
+    b.yaw[cur][i] = yaw;
+    b.v[cur][i] = v;
+    const double wgt = p.lik_mode == RR_LIK_PRODUCT ? rr_pf_weight_product(x, y, s_obs, p.n_obs, p.lik) : rr_pf_weight_fused(x, y, s_obs, p.n_obs, p.lik);
+    w[i] = wgt;
+    if (wgt > wmax_local) wmax_local = wgt;  // NaN and negatives drop out
+  }
+  {
+    const double m = rr::wave_max(wmax_local);
+    if (lane == 0) s_max[wv] = m;
+  }
+  __syncthreads();
+  double wmax = s_max[0];
+  for (int k = 1; k < W; ++k) wmax = s_max[k] > wmax ? s_max[k] : wmax;
+  // ---- integer image (quantize_reduce_tile; the weights have just been set, so Ctl.weights_uniform does not apply)
+  const bool usable = wmax > 0.0 && wmax < INFINITY;
+  const int mode = usable ? (int)rr::kImageWeights : a.img.degenerate;
+  const int shift = usable ? rr_fix_shift(wmax, n) : 0;
+  // ---- inclusive integer CDF, total and sum of squares
+  uint64_t carry = 0;
+  u128 q2 = {0, 0};
+  for (uint64_t base = 0; base < n; base += kKldThreads) {
+    const uint64_t i = base + tid;
+    const uint64_t q = rr::quantize_at(w, i, n, mode, shift, 0, n);
+    u128 sq;
+    rr_mul64wide(q, q, &sq.hi, &sq.lo);
+    q2 = rr::add128(q2, sq);
+    const uint64_t incl = rr::wave_scan_u64(q, lane);
+    __syncthreads();  // (s_t of the previous chunk has been read)
+    if (lane == 63) s_t[wv] = incl;
+    __syncthreads();
+    uint64_t off = carry, chunk = 0;
+    for (int k = 0; k < W; ++k) {
+      if (k < wv) off += s_t[k];
+      chunk += s_t[k];
+    }
+    if (i < n) {
+      cdf[i] = off + incl;
+      // (store_cdf: every 2^coarse_log2-th entry and the last one -- the table k_kld_draw stages in LDS)
+      if ((((i + 1) & ((1ull << coarse_log2) - 1)) == 0) || i == n - 1) coarse[i >> coarse_log2] = off + incl;
+    }
+    carry += chunk;
+  }
+  q2 = rr::wave_sum_u128(q2);
+  __syncthreads();
+  if (lane == 0) {
+    s_qh[wv] = q2.hi;
+    s_ql[wv] = q2.lo;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    u128 qq = {0, 0};
+    for (int k = 0; k < W; ++k) qq = rr::add128(qq, u128{s_qh[k], s_ql[k]});
+    ctl->weights_uniform = 0;
+    ctl->usable = usable ? 1 : 0;
+    ctl->image_mode = mode;
+    ctl->shift = shift;
+    ctl->wmax = wmax;
+    PlanArgs pa = a.plan;
+    pa.n_global = n;
+    rr::finalize_plan(ctl, carry, 0, carry, qq, pa);  // forced, eager: Ctl.cur flips here, the weights become uniform
+  }
+  // more candidate draws than one workgroup should walk through on its own (the default configuration's 5 000): the draws,
+  // the table and the count go on as launches of their own, many workgroups wide -- four launches instead of six
+  if (front_only) return;
+  __syncthreads();
+  // ---- the candidate draws and their bins (k_kld_draw; the lower bound over the whole CDF is the index its two-level search finds)
+  const int src = ctl->cur ^ 1;
+  for (uint64_t m = tid; m < a.max_draws; m += kKldThreads) {
+    const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, m, p.seed, a.plan.rstep, nullptr, m);
+    uint64_t j = rr_lower_bound_u64(cdf, n, target);
+    if (j >= n) j = n - 1;
+    idx[m] = (unsigned int)j;
+    int32_t xb, yb, ab;
+    rr_kld_bin(b.x[src][j], b.y[src][j], b.yaw[src][j], &xb, &yb, &ab);
+    keys[3 * m] = xb;
+    keys[3 * m + 1] = yb;
+    keys[3 * m + 2] = ab;
+  }
+  __syncthreads();
+  // ---- bin table, stop rule, gather
+  for (uint64_t base = 0; base < a.max_draws; base += kKldThreads) kld_insert_one(base + tid, base + tid < a.max_draws, keys, table, minslot, myslot, a.hash_size);
+  __syncthreads();
+  const uint64_t n_new = kld_count_body(minslot, myslot, a.max_draws, a.kld, table, a.hash_size);
+  const int dst = ctl->cur;
+  for (uint64_t k = tid; k < n_new; k += kKldThreads) copy_particle(b, dst ^ 1, dst, idx[k], k, false, nullptr);
+  if (tid == 0) {
+    out[0] = n_new;
+    ctl->n_active = n_new;
   }
 }
 
@@ -1661,6 +1805,7 @@ struct rr_pf {
   bool maybe_pending = false;    // a lazy resample plan was launched and nothing has consumed its markers yet
   int pending_kind = kSrcMarkers;  // ... StepSrc: where its sources are (markers / lidx of the multinomial step / window of a shard)
   bool mn_deferred = false;        // a lazy multinomial resample is planned (CDF, guide table) but its draws have not been searched yet
+  bool adaptive_small_ok = true;   // RR_MCL_SMALL=0: the adaptive step of a small filter takes the six separate launches
   bool mn_defer_ok = true;         // RR_MN_DEFER=0: always run the search as a launch of its own (k_resample_guide_mn)
   GatherArgs mn_deferred_args{};
   uint64_t slot_pad = 0;           // shard of the peer-to-peer transport: marker position of global slot s = s + slot_pad
@@ -2327,6 +2472,7 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
   }
   if (const char* e = std::getenv("RR_PF_SMALL")) h->small_ok = std::atoi(e) != 0;
   if (const char* e = std::getenv("RR_MN_DEFER")) h->mn_defer_ok = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RR_MCL_SMALL")) h->adaptive_small_ok = std::atoi(e) != 0;
   if (const char* e = std::getenv("RR_K1_BLOCKS_PER_CU")) {
     const int v = std::atoi(e);
     if (v >= 1 && v <= 64) h->k1_blocks_per_cu = v;
@@ -2827,6 +2973,44 @@ static bool fused_estimate_available(const rr_pf* h) {
          h->n == h->n_global;
 }
 
+// the adaptive step of a filter of the reference's sizes: one launch of one workgroup (k_mcl_adaptive_small) up to 1 024 candidate
+// draws; beyond that the same kernel does propagate + weight + integer image + CDF + plan and the draws / table / count follow
+// as three wide launches (k_kld_draw, k_kld_insert, k_kld_count with the gather)
+static rr_status step_adaptive_small(rr_pf* h, const StepParams& p, const ObsArg& arg) {
+  AdaptSmallArgs a{};
+  a.img = image_args(h);
+  a.plan = plan_args(h, /*mode=*/1, RR_RESAMPLE_MULTINOMIAL, NAN);
+  a.kld = h->kld;
+  a.max_draws = h->kld.max_particles;
+  a.hash_size = h->kld_hash_size;
+  const uint64_t M = h->kld.max_particles;
+  const int front_only = M > 1024 ? 1 : 0;
+  const size_t lds = 3 * (size_t)p.n_obs * sizeof(double);
+  {
+    Timed t(h, RR_K_PROPAGATE_WEIGHT);
+    hipLaunchKernelGGL(k_mcl_adaptive_small, dim3(1), dim3(kKldThreads), lds, h->stream, h->b, h->w, h->ctl, p, arg, a, h->cdf, h->idx,
+                       h->kld_keys, h->kld_table, h->kld_minslot, h->kld_myslot, h->kld_out, h->cdf_coarse, h->coarse_log2, front_only);
+  }
+  if (front_only) {
+    Timed t(h, RR_K_RESAMPLE_GATHER);
+    const uint64_t cap_coarse = ((h->cap + (1ull << h->coarse_log2) - 1) >> h->coarse_log2) + 1;
+    hipLaunchKernelGGL(k_kld_draw, dim3(grid_for(M, kBlock)), dim3(kBlock), cap_coarse * sizeof(uint64_t), h->stream, h->b,
+                       h->ctl, h->cdf, h->cdf_coarse, h->coarse_log2, h->n_coarse, (const double*)nullptr, h->idx, h->kld_keys, h->n, M,
+                       h->opt.seed, h->rstep, 1);
+    hipLaunchKernelGGL(k_kld_insert, dim3(grid_for(M, kBlock)), dim3(kBlock), 0, h->stream, (const int32_t*)h->kld_keys,
+                       h->kld_table, h->kld_minslot, h->kld_myslot, M, h->kld_hash_size);
+    hipLaunchKernelGGL(k_kld_count, dim3(1), dim3(kKldThreads), 0, h->stream, h->kld_minslot, (const unsigned int*)h->kld_myslot, M, h->kld,
+                       h->kld_out, h->kld_table, h->kld_hash_size, h->b, h->ctl, (const unsigned int*)h->idx, 1);
+  }
+  RR_HIP_TRY(hipGetLastError());
+  h->step += 1;
+  h->rstep += 1;
+  h->wmax_live = false;
+  h->wmax_bits_clean = true;  // finalize_plan zeroes the accumulator (this launch never used it)
+  h->n_dirty = true;          // weights are uniform 1/n_new from here (Ctl.weights_uniform); the count lives on the device
+  return RR_OK;
+}
+
 static rr_status step_async_impl(rr_pf* h, const double control[2], const double* obs, size_t n_obs, bool want_estimate) {
   rr_status s = bind(h, /*keep_lazy=*/h && h->adaptive);  // an adaptive filter steps without knowing its current count on the host
   if (s != RR_OK) return s;
@@ -2840,6 +3024,7 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
   if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
   StepParams p = make_params(h, control, (int)n_obs);
   if (h->adaptive) {  // try_step, monte_carlo_localization.rs:291-300 -- no host synchronisation: the count stays on the device
+    if (kernarg && h->adaptive_small_ok && h->kld.max_particles <= 16384) return step_adaptive_small(h, p, arg);
     if ((s = launch_pw<true, true, false>(h, p, arg, kernarg)) != RR_OK) return s;
     h->step += 1;
     return resample_adaptive(h, nullptr, /*lazy=*/true);

@@ -200,3 +200,35 @@ def test_asynchronous_steps_need_no_host_count(loc):
         b.try_step([1.0, 0.1], obs)
     assert a.particle_count() == b.particle_count()
     assert np.array_equal(a.get_particles_array().view(np.uint64), b.get_particles_array().view(np.uint64))
+
+
+@pytest.mark.parametrize("lo,hi", [(100, 5000), (60, 800)])
+def test_fused_adaptive_step_equals_the_separate_launches(lo, hi):
+    """The adaptive step of a small filter: k_mcl_adaptive_small does propagate + weight + integer image + CDF + plan in one
+    workgroup -- and, up to 1 024 candidate draws, the draws, the bin table, the stop rule and the gather as well; beyond that
+    those follow as three wide launches.  RR_MCL_SMALL=0 (read when the filter is created) keeps the six separate launches.
+    Same particles, weights and counts after every step, bit for bit."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, math, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+        "import rust_robotics_amd.localization as loc\n"
+        "cfg = loc.MonteCarloLocalizationConfig(min_particles=%d, max_particles=%d)\n"
+        "mcl = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=7)\n"
+        "lms = [(10.0, 0.0), (0.0, 15.0), (-5.0, 20.0), (10.0, 10.0)]\n"
+        "truth = np.zeros(3); h = hashlib.sha256(); counts = []\n"
+        "for t in range(60):\n"
+        "    truth += [math.cos(truth[2]) * 0.1, math.sin(truth[2]) * 0.1, 0.01]\n"
+        "    mcl.step_async([1.0, 0.1], [(math.hypot(truth[0] - lx, truth[1] - ly), lx, ly) for lx, ly in lms])\n"
+        "    if t %% 7 == 6:\n"
+        "        h.update(np.ascontiguousarray(mcl.get_particles_array()).tobytes()); counts.append(mcl.particle_count())\n"
+        "print(h.hexdigest(), counts)\n") % (root, lo, hi)
+    outs = []
+    for small in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RR_MCL_SMALL=small), capture_output=True, text=True, timeout=300, cwd=root)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(r.stdout.strip().splitlines()[-1])
+    assert outs[0] == outs[1]
