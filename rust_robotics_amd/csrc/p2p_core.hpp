@@ -167,7 +167,7 @@ static __global__ __launch_bounds__(kScanThreads) void k_scan_exchange(P2PPeers 
 }
 
 // Inbox traffic goes around every cache: system-scope (sc0 sc1) stores on the delivering side, system-scope loads on the
-// reading side.  The reader consumes a delivery INSIDE a kernel (after an in-kernel wait for DONE), not behind a kernel
+// reading side.  The reader consumes a delivery INSIDE a kernel (as soon as the slot's seal fits, below), not behind a kernel
 // boundary, so nothing may depend on which lines an L2 -- eight of them per device, one per XCD -- still holds from the
 // step before or on how a peer's mapping of the buffer is cached.  Only the slots that cross a shard boundary take this
 // path (10^3 - 10^4 of 10^6 in steady state).
