@@ -1665,28 +1665,79 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
     pa.n_global = n;
     rr::finalize_plan(ctl, carry, 0, carry, qq, pa);  // forced, eager: Ctl.cur flips here, the weights become uniform
   }
-  // more candidate draws than one workgroup should walk through on its own (the default configuration's 5 000): the draws,
-  // the table and the count go on as launches of their own, many workgroups wide -- four launches instead of six
-  if (front_only) return;
+  if (front_only) return;  // (the draws, the table and the count follow as launches of their own)
   __syncthreads();
-  // ---- the candidate draws and their bins (k_kld_draw; the lower bound over the whole CDF is the index its two-level search finds)
+  // ---- the candidate draws in blocks of kKldThreads, as far as the reference's loop would go (:340-352): a block's draws and
+  // bins (k_kld_draw; the lower bound over the whole CDF is the index its two-level search finds), its entries in the bin
+  // table (k_kld_insert), then the stop rule over the block (k_kld_count: occupied-bin count after every draw, running
+  // maximum of the KLD bound) -- the first block that contains the stopping draw is the last one looked at.  A bin's smallest
+  // draw index can only come from the blocks seen so far, so the flags of a block are final when it has been inserted: the
+  // result is that of all max_particles candidates evaluated at once, for a fifth of the work at the default configuration
+  // (5 000 candidates, a tracking filter stops around 300).
+  __shared__ uint64_t s_cnt[W];
+  __shared__ uint64_t s_req[W];
+  __shared__ uint64_t s_stop;
   const int src = ctl->cur ^ 1;
-  for (uint64_t m = tid; m < a.max_draws; m += kKldThreads) {
-    const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, m, p.seed, a.plan.rstep, nullptr, m);
-    uint64_t j = rr_lower_bound_u64(cdf, n, target);
-    if (j >= n) j = n - 1;
-    idx[m] = (unsigned int)j;
-    int32_t xb, yb, ab;
-    rr_kld_bin(b.x[src][j], b.y[src][j], b.yaw[src][j], &xb, &yb, &ab);
-    keys[3 * m] = xb;
-    keys[3 * m + 1] = yb;
-    keys[3 * m + 2] = ab;
+  uint64_t k_carry = 0, req_carry = a.kld.min_particles, seen = 0;
+  if (tid == 0) s_stop = ~0ull;
+  __syncthreads();
+  for (uint64_t base = 0; base < a.max_draws; base += kKldThreads) {
+    const uint64_t m = base + tid;
+    const bool valid = m < a.max_draws;
+    if (valid) {
+      const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, m, p.seed, a.plan.rstep, nullptr, m);
+      uint64_t j = rr_lower_bound_u64(cdf, n, target);
+      if (j >= n) j = n - 1;
+      idx[m] = (unsigned int)j;
+      int32_t xb, yb, ab;
+      rr_kld_bin(b.x[src][j], b.y[src][j], b.yaw[src][j], &xb, &yb, &ab);
+      keys[3 * m] = xb;
+      keys[3 * m + 1] = yb;
+      keys[3 * m + 2] = ab;
+    }
+    __syncthreads();  // (a probing draw compares with the keys of the draw that owns a slot)
+    kld_insert_one(m, valid, keys, table, minslot, myslot, a.hash_size);
+    __syncthreads();
+    seen = base + kKldThreads < a.max_draws ? base + kKldThreads : a.max_draws;
+    const uint64_t flag = (valid && __hip_atomic_load(&minslot[myslot[m]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)m) ? 1ull : 0ull;
+    uint64_t incl = rr::wave_scan_u64(flag, lane);
+    if (lane == 63) s_cnt[wv] = incl;
+    __syncthreads();
+    uint64_t off = k_carry, chunk_total = 0;
+    for (int q = 0; q < W; ++q) {
+      if (q < wv) off += s_cnt[q];
+      chunk_total += s_cnt[q];
+    }
+    const uint64_t k = off + incl;
+    uint64_t req = valid ? rr_kld_required(k, a.kld.min_particles, a.kld.max_particles, a.kld.kld_epsilon, a.kld.kld_z) : 0;
+#pragma unroll
+    for (int o = 1; o < rr::kWave; o <<= 1) {
+      const uint64_t t = rr::shfl_up_u64(req, o);
+      if (lane >= o && t > req) req = t;
+    }
+    if (lane == 63) s_req[wv] = req;
+    __syncthreads();
+    uint64_t pre = req_carry, chunk_req = req_carry;
+    for (int q = 0; q < W; ++q) {
+      if (q < wv) pre = s_req[q] > pre ? s_req[q] : pre;
+      chunk_req = s_req[q] > chunk_req ? s_req[q] : chunk_req;
+    }
+    if (pre > req) req = pre;
+    if (valid && rr_kld_stop(m, req, a.kld.min_particles)) atomicMin((unsigned long long*)&s_stop, (unsigned long long)m);
+    __syncthreads();
+    if (s_stop != ~0ull) break;  // uniform: read after the barrier
+    k_carry += chunk_total;
+    req_carry = chunk_req;
+    __syncthreads();
   }
+  const uint64_t n_new = s_stop == ~0ull ? a.max_draws : s_stop + 1;  // :342: at most max_particles
   __syncthreads();
-  // ---- bin table, stop rule, gather
-  for (uint64_t base = 0; base < a.max_draws; base += kKldThreads) kld_insert_one(base + tid, base + tid < a.max_draws, keys, table, minslot, myslot, a.hash_size);
-  __syncthreads();
-  const uint64_t n_new = kld_count_body(minslot, myslot, a.max_draws, a.kld, table, a.hash_size);
+  // the table slots the draws of this step have used go back to empty for the next one (every occupied slot is some draw's)
+  for (uint64_t m = tid; m < seen; m += kKldThreads) {
+    const unsigned int sl = myslot[m];
+    table[sl] = kKldEmpty;
+    minslot[sl] = kKldEmpty;
+  }
   const int dst = ctl->cur;
   for (uint64_t k = tid; k < n_new; k += kKldThreads) copy_particle(b, dst ^ 1, dst, idx[k], k, false, nullptr);
   if (tid == 0) {
@@ -2984,7 +3035,8 @@ static rr_status step_adaptive_small(rr_pf* h, const StepParams& p, const ObsArg
   a.max_draws = h->kld.max_particles;
   a.hash_size = h->kld_hash_size;
   const uint64_t M = h->kld.max_particles;
-  const int front_only = M > 1024 ? 1 : 0;
+  static const bool hybrid = [] { const char* e = std::getenv("RR_MCL_HYBRID"); return e && std::atoi(e) != 0; }();
+  const int front_only = hybrid && M > 1024 ? 1 : 0;  // (A/B: the front half here, the draws / table / count as three wide launches)
   const size_t lds = 3 * (size_t)p.n_obs * sizeof(double);
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
