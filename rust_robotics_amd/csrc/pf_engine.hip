@@ -1586,7 +1586,8 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
                                                                    unsigned int* __restrict__ idx, int32_t* __restrict__ keys,
                                                                    unsigned int* __restrict__ table, unsigned int* __restrict__ minslot,
                                                                    unsigned int* __restrict__ myslot, uint64_t* __restrict__ out,
-                                                                   uint64_t* __restrict__ coarse, int coarse_log2, int front_only) {
+                                                                   uint64_t* __restrict__ coarse, int coarse_log2, int front_only,
+                                                                   HostMail* __restrict__ mail, uint64_t mail_seq) {
   extern __shared__ double s_obs[];
   constexpr int W = kKldThreads / rr::kWave;
   __shared__ double s_max[W];
@@ -1743,6 +1744,60 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
   if (tid == 0) {
     out[0] = n_new;
     ctl->n_active = n_new;
+  }
+  if (!mail) return;
+  // ---- the mean try_step returns (monte_carlo_localization.rs:299-300 after :359-362: uniform weights over the new set), for
+  // the synchronous caller: formed exactly as rr_pf_estimate forms it -- k_moments' grid of ceil(n / 256) workgroups of four
+  // waves holds one particle per thread for n <= 1024, this workgroup's wave w stands for workgroup w / 4's wave w % 4, the
+  // workgroup partials are added in k_moments' order and reduced as k_moments_final does -- and left in the host mailbox.
+  // flags != 0: not formed here (more than 1024 particles, or weights that do not sum to a positive number): the long way.
+  __shared__ double s_mom[W][5];
+  __syncthreads();  // (the gathered set is complete)
+  if (n_new <= (uint64_t)kKldThreads) {
+    const double p0[4] = {b.x[dst][0], b.y[dst][0], b.yaw[dst][0], b.v[dst][0]};
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if ((uint64_t)tid < n_new) {
+      const double wi = 1.0;
+      const double d0 = b.x[dst][tid] - p0[0], d1 = b.y[dst][tid] - p0[1], d2 = b.yaw[dst][tid] - p0[2], d3 = b.v[dst][tid] - p0[3];
+      acc[0] += wi;
+      acc[1] += wi * d0;
+      acc[2] += wi * d1;
+      acc[3] += wi * d2;
+      acc[4] += wi * d3;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const double sw = rr::wave_sum(acc[k]);
+      if (lane == 0) s_mom[wv][k] = sw;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      const int n_blocks = (int)((n_new + kBlock - 1) / kBlock);
+      double mom[5];
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        double part = 0.0;  // k_moments: the workgroup's four wave sums, in wave order
+        if (lane < n_blocks)
+          for (int q = 0; q < kBlock / rr::kWave; ++q) part += s_mom[(kBlock / rr::kWave) * lane + q][k];
+        double v = 0.0;  // k_moments_final: lane j adds the partials j, j + 64, ... (one here), then the shuffle tree
+        if (lane < n_blocks) v += part;
+        mom[k] = rr::wave_sum(v);
+      }
+      if (lane == 0) {
+        const double Wt = mom[0];
+        const bool ok = Wt > 0.0 && Wt < INFINITY;
+        for (int q = 0; q < 4; ++q)
+          __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[q]), (uint64_t)__double_as_longlong(p0[q] + mom[1 + q] / Wt), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mail->flags, (uint64_t)(ok ? 0 : 1) | ((uint64_t)(ctl->grid_timeout != 0) << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&mail->seq, mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  } else if (tid == 0) {
+    __hip_atomic_store(&mail->flags, (uint64_t)4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(&mail->seq, mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
@@ -3027,7 +3082,7 @@ static bool fused_estimate_available(const rr_pf* h) {
 // the adaptive step of a filter of the reference's sizes: one launch of one workgroup (k_mcl_adaptive_small) up to 1 024 candidate
 // draws; beyond that the same kernel does propagate + weight + integer image + CDF + plan and the draws / table / count follow
 // as three wide launches (k_kld_draw, k_kld_insert, k_kld_count with the gather)
-static rr_status step_adaptive_small(rr_pf* h, const StepParams& p, const ObsArg& arg) {
+static rr_status step_adaptive_small(rr_pf* h, const StepParams& p, const ObsArg& arg, uint64_t* mail_seq_out) {
   AdaptSmallArgs a{};
   a.img = image_args(h);
   a.plan = plan_args(h, /*mode=*/1, RR_RESAMPLE_MULTINOMIAL, NAN);
@@ -3038,10 +3093,22 @@ static rr_status step_adaptive_small(rr_pf* h, const StepParams& p, const ObsArg
   static const bool hybrid = [] { const char* e = std::getenv("RR_MCL_HYBRID"); return e && std::atoi(e) != 0; }();
   const int front_only = hybrid && M > 1024 ? 1 : 0;  // (A/B: the front half here, the draws / table / count as three wide launches)
   const size_t lds = 3 * (size_t)p.n_obs * sizeof(double);
+  HostMail* mail = nullptr;
+  uint64_t want = 0;
+  if (mail_seq_out && !front_only) {  // a synchronous caller: the estimate comes back through the host mailbox
+    if (!h->mail) {
+      RR_HIP_TRY(hipHostMalloc(&h->mail, sizeof(HostMail), hipHostMallocDefault));
+      std::memset(h->mail, 0, sizeof(HostMail));
+    }
+    mail = h->mail;
+    want = ++h->mail_seq;
+    *mail_seq_out = want;
+  }
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
     hipLaunchKernelGGL(k_mcl_adaptive_small, dim3(1), dim3(kKldThreads), lds, h->stream, h->b, h->w, h->ctl, p, arg, a, h->cdf, h->idx,
-                       h->kld_keys, h->kld_table, h->kld_minslot, h->kld_myslot, h->kld_out, h->cdf_coarse, h->coarse_log2, front_only);
+                       h->kld_keys, h->kld_table, h->kld_minslot, h->kld_myslot, h->kld_out, h->cdf_coarse, h->coarse_log2, front_only,
+                       mail, want);
   }
   if (front_only) {
     Timed t(h, RR_K_RESAMPLE_GATHER);
@@ -3063,7 +3130,8 @@ static rr_status step_adaptive_small(rr_pf* h, const StepParams& p, const ObsArg
   return RR_OK;
 }
 
-static rr_status step_async_impl(rr_pf* h, const double control[2], const double* obs, size_t n_obs, bool want_estimate) {
+static rr_status step_async_impl(rr_pf* h, const double control[2], const double* obs, size_t n_obs, bool want_estimate,
+                                 uint64_t* mail_seq_out = nullptr) {
   rr_status s = bind(h, /*keep_lazy=*/h && h->adaptive);  // an adaptive filter steps without knowing its current count on the host
   if (s != RR_OK) return s;
   if ((s = validate_control(control)) != RR_OK) return s;
@@ -3076,7 +3144,7 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
   if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
   StepParams p = make_params(h, control, (int)n_obs);
   if (h->adaptive) {  // try_step, monte_carlo_localization.rs:291-300 -- no host synchronisation: the count stays on the device
-    if (kernarg && h->adaptive_small_ok && h->kld.max_particles <= 16384) return step_adaptive_small(h, p, arg);
+    if (kernarg && h->adaptive_small_ok && h->kld.max_particles <= 16384) return step_adaptive_small(h, p, arg, mail_seq_out);
     if ((s = launch_pw<true, true, false>(h, p, arg, kernarg)) != RR_OK) return s;
     h->step += 1;
     return resample_adaptive(h, nullptr, /*lazy=*/true);
@@ -3268,9 +3336,29 @@ rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_
     for (int k = 0; k < 4; ++k) out_state[k] = h->mail->est[k];
     return RR_OK;
   }
-  rr_status s = rr_pf_step_async(h, control, obs, n_obs);
+  uint64_t want = 0;
+  rr_status s = step_async_impl(h, control, obs, n_obs, false, (h && h->adaptive && out_state) ? &want : nullptr);
   if (s != RR_OK) return s;
   if (!out_state) return rr_pf_synchronize(h);
+  if (want) {  // the adaptive step of a small filter has formed the mean itself (k_mcl_adaptive_small): poll the mailbox
+    const volatile uint64_t* seq = &h->mail->seq;
+    bool seen = false;
+    for (long spins = 0; spins < 4000000; ++spins) {
+      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) {
+        seen = true;
+        break;
+      }
+    }
+    if (!seen) {
+      RR_HIP_TRY(hipStreamSynchronize(h->stream));
+      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != want) return fail(RR_RUNTIME_ERROR, "the step's estimate never reached the host mailbox");
+    }
+    rr::spin_release(h->opt.device, h);  // the stream is idle
+    if (h->mail->flags == 0) {
+      for (int k = 0; k < 4; ++k) out_state[k] = h->mail->est[k];
+      return RR_OK;
+    }
+  }
   if ((s = materialise(h)) != RR_OK) return s;  // the estimate is over the resampled set
   return compute_moments(h, out_state, nullptr);
 }

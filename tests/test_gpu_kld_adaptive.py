@@ -232,3 +232,20 @@ def test_fused_adaptive_step_equals_the_separate_launches(lo, hi):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.append(r.stdout.strip().splitlines()[-1])
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("lo,hi", [(100, 5000), (100, 700), (1500, 4000)])
+def test_try_step_returns_the_estimate_of_the_new_set(loc, lo, hi):
+    """monte_carlo_localization.rs:291-300: try_step returns the mean of the resampled set.  For up to 1 024 particles the
+    one-launch adaptive step forms it itself (as k_moments + k_moments_final would, reduction order included) and hands it
+    over through the host mailbox; beyond that, and on the separate-launch route, rr_pf_estimate's kernels run.  The same
+    bits either way."""
+    mcl = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], loc.MonteCarloLocalizationConfig(min_particles=lo, max_particles=hi), seed=9)
+    lms = [(10.0, 0.0), (0.0, 15.0), (-5.0, 20.0), (10.0, 10.0)]
+    truth = np.zeros(3)
+    for t in range(40):
+        truth += [math.cos(truth[2]) * 0.1, math.sin(truth[2]) * 0.1, 0.01]
+        e = np.asarray(mcl.try_step([1.0, 0.1], [(math.hypot(truth[0] - lx, truth[1] - ly), lx, ly) for lx, ly in lms]))
+        e2 = np.asarray(mcl.estimate())
+        assert np.array_equal(e.view(np.uint64), e2.view(np.uint64)), f"step {t}"
+        assert lo <= mcl.particle_count() <= hi
