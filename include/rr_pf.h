@@ -47,6 +47,10 @@ const char* rr_last_error(void);
 const char* rr_version(void);
 /* number of visible HIP devices (0 if none / runtime unusable) */
 int rr_device_count(void);
+/* PCI address of a device as sysfs spells it ("0000:c1:00.0"): /sys/bus/pci/devices/<id>/local_cpulist names the host CPUs on
+ * the device's NUMA node -- the synchronous step is two trips over the host link (rr_pf_set_resident), a caller that stays
+ * on that node saves the socket interconnect on every one of them (nodes/pf_localizer_node pins itself there) */
+rr_status rr_device_pci_bus_id(int32_t device, char* out, size_t cap);
 
 /* ParticleFilterConfig, particle_filter.rs:51-65 (field for field) */
 typedef struct rr_pf_config {
@@ -171,6 +175,20 @@ rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]);
  * rr_pf_step_async.  Results are bit-identical to n_steps single steps. */
 rr_status rr_pf_step_many(rr_pf* h, const double* controls, const double* obs, size_t n_obs, size_t n_steps,
                           double* out_estimates);
+/* Resident service for the filters the reference's callers really run (100 - 1 200 particles through the synchronous try_step:
+ * headless_localizers.rs:39-56, render_gif_particle_filter.rs:77-79, ros2_nodes/ekf_localizer_node/src/main.rs:273): with
+ * idle_us > 0, rr_pf_step and rr_pf_step_async of a filter of up to 2048 particles (and up to 128 observations per step) no
+ * longer launch anything -- ONE kernel of one workgroup stays on the device with the particles in registers, takes each
+ * step's control and observations from a pinned command block and leaves the estimate in a pinned response block the
+ * host polls.  A synchronous step then costs its arithmetic plus two trips over the host link instead of a launch and a
+ * completion wait.  The kernel leaves by itself after idle_us microseconds without a step (the next step starts it again:
+ * nothing is lost, that step just pays a launch) and after max(100 ms, 20 idle_us) in any case, so work queued behind it is
+ * delayed, never blocked; every other entry point of the handle asks it to leave before it touches the particle set.  Same
+ * kernel code, same bits as the launched step.  While it runs it holds one workgroup's registers and LDS of one compute unit.
+ * idle_us == 0 switches the service off (the default; RR_PF_RESIDENT_US=<us> at create time switches it on). */
+rr_status rr_pf_set_resident(rr_pf* h, double idle_us);
+/* incarnations of the resident kernel launched so far and steps served by them */
+rr_status rr_pf_resident_stats(const rr_pf* h, uint64_t* launches, uint64_t* steps);
 /* wait for everything enqueued on the filter's stream */
 rr_status rr_pf_synchronize(rr_pf* h);
 

@@ -133,6 +133,7 @@ def lib() -> C.CDLL:
     proto("rr_last_error", C.c_char_p, [])
     proto("rr_version", C.c_char_p, [])
     proto("rr_device_count", C.c_int, [])
+    proto("rr_device_pci_bus_id", st, [C.c_int32, C.c_char_p, sz])
     proto("rr_pf_config_default", None, [C.POINTER(PfConfig)])
     proto("rr_pf_config_validate", st, [C.POINTER(PfConfig)])
     proto("rr_pf_options_default", None, [C.POINTER(PfOptions)])
@@ -152,6 +153,8 @@ def lib() -> C.CDLL:
     proto("rr_pf_step_async_estimate", st, [H, P, P, sz])
     proto("rr_pf_last_step_estimate", st, [H, P])
     proto("rr_pf_step_many", st, [H, P, P, sz, sz, P])
+    proto("rr_pf_set_resident", st, [H, d])
+    proto("rr_pf_resident_stats", st, [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
     proto("rr_pf_synchronize", st, [H])
     proto("rr_pf_estimate", st, [H, P])
     proto("rr_pf_covariance", st, [H, P])

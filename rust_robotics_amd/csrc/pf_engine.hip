@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -41,6 +42,7 @@
 #include "p2p_core.hpp"
 #include "rccl_core.hpp"
 #include "resample_core.hpp"
+#include "resident_core.hpp"
 #include "rr_common.hpp"
 #include "rr_pf.h"
 #include "rr_pf_spec.h"
@@ -648,6 +650,7 @@ struct SmallArgs {
   int want_est;
   int inputs_in_kernarg;  // K == 1 and the observations fit the launch packet
   uint64_t mail_seq;      // != 0: the last step's estimate also goes to the host mailbox, stamped with this number
+  rr::ResidentArgs res;   // res.on: the kernel stays and serves one step per command of the ring (resident_core.hpp); K is ignored
 };
 
 constexpr int kEstRing = 32;  // per-step estimates of rr_pf_step_many gather in LDS and leave in blocks of this many steps
@@ -718,12 +721,21 @@ __device__ inline void small_block_sum4(double (&v)[4], double* s_red4 /* [4][BL
   }
 }
 
+// instrumented build (make timeline): 100 MHz stamps of a resident step's phases, returned in rsp[8 .. 15] (tools/resident_timeline.py)
+#if defined(RR_PLAN_TIMELINE)
+#define RR_RES_TL(K_) do { if (resident && threadIdx.x == 0) res_tl[(K_)] = wall_clock64(); } while (0)
+#else
+#define RR_RES_TL(K_) do { } while (0)
+#endif
 template <int BLOCK, int R, int LIK>
 __global__ __launch_bounds__(BLOCK) void k_step_small(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl, SmallArgs a,
                                                             ObsArg obs_arg, const double* __restrict__ steps_in,
                                                             unsigned int* __restrict__ idx_out, double* __restrict__ est_out,
-                                                            double* __restrict__ est_partials, HostMail* mail) {
-  extern __shared__ double s_dyn[];  // [3 n_obs] observations | [4][n] gather fields | [n + 1] markers (u32) or [n] CDF (u64)
+                                                            double* __restrict__ est_partials, HostMail* mail,
+                                                            rr::ResidentRing* __restrict__ ring) {
+  // [3 n_obs] observations | [4][n] gather fields | [n + 1] markers (u32) or [n] CDF (u64);
+  // resident: [payload_cap] command payload (u0, u1, observations) in front instead of the observations
+  extern __shared__ double s_dyn[];
   constexpr int W = BLOCK / rr::kWave;
   __shared__ uint64_t s_u[4 * W];
   __shared__ double s_red[4 * W];
@@ -731,8 +743,10 @@ __global__ __launch_bounds__(BLOCK) void k_step_small(Bufs b, double* __restrict
   __shared__ double s_ring[kEstRing * 4];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const uint64_t n = a.n;
-  double* const s_obs = s_dyn;
-  double* const s_f = s_dyn + 3 * (size_t)a.n_obs;
+  const bool resident = a.res.on != 0;
+  __shared__ int s_hdr[2];
+  double* const s_obs = resident ? s_dyn + 2 : s_dyn;
+  double* const s_f = s_dyn + (resident ? (size_t)a.res.payload_cap : 3 * (size_t)a.n_obs);
   uint64_t* const s_cdf = reinterpret_cast<uint64_t*>(s_f + 4 * n);
   unsigned int* const s_mark = reinterpret_cast<unsigned int*>(s_f + 4 * n);
   const int cur = ctl->cur;
@@ -755,37 +769,74 @@ __global__ __launch_bounds__(BLOCK) void k_step_small(Bufs b, double* __restrict
   u128 c_q2 = {0, 0};
   double c_wmax = 0.0, c_rho = 0.0, c_est[4] = {0.0, 0.0, 0.0, 0.0}, c_den = 1.0;
   rr_sys_plan c_plan = {};
-  for (int s = 0; s < a.K; ++s) {
+#if defined(RR_PLAN_TIMELINE)
+  uint64_t res_tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  int n_obs = a.n_obs, steps_done = 0, res_guess = 3 + 3 * a.n_obs < 64 ? 3 + 3 * a.n_obs : 64, res_last_op = rr::kResOpNone;
+  const uint64_t res_deadline = resident ? wall_clock64() + a.res.life_ticks : 0;
+  for (int s = 0; resident || s < a.K; ++s) {
     // ---- inputs of this step
     double u0 = a.u0, u1 = a.u1;
-    __syncthreads();
-    if (a.inputs_in_kernarg) {
-      for (int i = tid; i < 3 * a.n_obs; i += BLOCK) s_obs[i] = obs_arg.v[i];
-    } else {
-      const double* in = steps_in + (size_t)s * (2 + 3 * (size_t)a.n_obs);
-      u0 = in[0];
-      u1 = in[1];
-      for (int i = tid; i < 3 * a.n_obs; i += BLOCK) s_obs[i] = in[2 + i];
+    // the step's random numbers are functions of (seed, step counters, slot) alone -- not of the state, not of the inputs: a
+    // resident incarnation draws them BEFORE it waits for the command, in time the host spends turning the last answer around
+    // (the Philox rounds, the logarithm and the sine/cosine of the Box-Muller pair are ~40 % of a small step's dependent chain)
+    double pre_na[R], pre_nc[R], pre_r[R];
+    if (resident) {
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        double dummy;
+        rr_pf_motion_noise(a.seed, a.step0 + (unsigned int)s, k0 + j, a.sigma_v, a.sigma_w, &pre_na[j], &pre_nc[j]);
+        // multinomial: this slot's draw; systematic: the one offset (index 0 of the stream), the same in every slot
+        rr_uniform2(a.seed, RR_STREAM_RESAMPLE, a.rstep0 + (unsigned int)s, a.scheme == RR_RESAMPLE_SYSTEMATIC ? 0ull : k0 + j, &pre_r[j], &dummy);
+      }
     }
-    __syncthreads();
+    RR_RES_TL(0);  // random numbers drawn, about to wait
+    if (resident) {  // wait for the host's next command; anything but a step ends this incarnation
+      res_last_op = rr::resident_fetch<BLOCK>(ring, a.res.first_seq + (uint64_t)s, a.res.idle_ticks, res_deadline, a.res.payload_cap,
+                                              res_guess, s_dyn, s_hdr);
+      if (res_last_op != rr::kResOpStep) break;
+      n_obs = (s_hdr[1] - 2) / 3;
+      u0 = s_dyn[0];
+      u1 = s_dyn[1];
+    } else {
+      __syncthreads();
+      if (a.inputs_in_kernarg) {
+        for (int i = tid; i < 3 * n_obs; i += BLOCK) s_obs[i] = obs_arg.v[i];
+      } else {
+        const double* in = steps_in + (size_t)s * (2 + 3 * (size_t)n_obs);
+        u0 = in[0];
+        u1 = in[1];
+        for (int i = tid; i < 3 * n_obs; i += BLOCK) s_obs[i] = in[2 + i];
+      }
+      __syncthreads();
+    }
+    steps_done = s + 1;
+    RR_RES_TL(1);  // command here
     // ---- propagate + weight (particle_filter.rs:279-296, :310-329)
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       double na, nc;
-      rr_pf_motion_noise(a.seed, a.step0 + (unsigned int)s, k0 + j, a.sigma_v, a.sigma_w, &na, &nc);
+      if (resident) {
+        na = pre_na[j];
+        nc = pre_nc[j];
+      } else {
+        rr_pf_motion_noise(a.seed, a.step0 + (unsigned int)s, k0 + j, a.sigma_v, a.sigma_w, &na, &nc);
+      }
       rr_pf_propagate_one(&x[j], &y[j], &yaw[j], &v[j], u0, u1, a.dt, na, nc);
     }
     if (LIK == RR_LIK_PRODUCT) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) wgt[j] = rr_pf_weight_product(x[j], y[j], s_obs, a.n_obs, a.lik);
+      for (int j = 0; j < R; ++j) wgt[j] = rr_pf_weight_product(x[j], y[j], s_obs, n_obs, a.lik);
     } else {
-      rr_pf_weight_fused_rows<R>(x, y, s_obs, a.n_obs, a.lik, wgt);
+      rr_pf_weight_fused_rows<R>(x, y, s_obs, n_obs, a.lik, wgt);
     }
     double wl = 0.0;
 #pragma unroll
     for (int j = 0; j < R; ++j)
       if (k0 + j < n && wgt[j] > wl) wl = wgt[j];  // NaN and negatives drop out
+    RR_RES_TL(2);  // propagated, weighted
     const double wmax = small_block_max<BLOCK>(wl, s_red);
+    RR_RES_TL(3);  // maximum
     // ---- integer image, sums (resample_core.hpp: quantize_reduce_tile / tile_scan)
     const bool usable = wmax > 0.0 && wmax < INFINITY;
     const int mode = usable ? (int)rr::kImageWeights : (int)rr::kImageUniform;  // PF / MCL: sum w <= 0 => uniform (:433-438)
@@ -837,6 +888,7 @@ __global__ __launch_bounds__(BLOCK) void k_step_small(Bufs b, double* __restrict
     c_q2 = qq;
     c_wmax = wmax;
     double est_acc[4] = {0.0, 0.0, 0.0, 0.0};
+    RR_RES_TL(4);  // integer image, sums, gate
     if (!fire) {
       if (a.want_est) {  // sum_j q_j p_j / T  (the cache refreshed at particle_filter.rs:332)
 #pragma unroll
@@ -854,7 +906,8 @@ __global__ __launch_bounds__(BLOCK) void k_step_small(Bufs b, double* __restrict
       unsigned int idx[R];
       if (a.scheme == RR_RESAMPLE_SYSTEMATIC) {
         double rho, dummy;
-        rr_uniform2(a.seed, RR_STREAM_RESAMPLE, rstep, 0, &rho, &dummy);
+        if (resident) rho = pre_r[0];
+        else rr_uniform2(a.seed, RR_STREAM_RESAMPLE, rstep, 0, &rho, &dummy);
         const rr_sys_plan plan = rr_sys_plan_make(rho, total, n);
         c_rho = rho;
         c_plan = plan;
@@ -903,7 +956,8 @@ __global__ __launch_bounds__(BLOCK) void k_step_small(Bufs b, double* __restrict
 #pragma unroll
         for (int j = 0; j < R; ++j) {
           double r, dummy;
-          rr_uniform2(a.seed, RR_STREAM_RESAMPLE, rstep, k0 + j, &r, &dummy);
+          if (resident) r = pre_r[j];
+          else rr_uniform2(a.seed, RR_STREAM_RESAMPLE, rstep, k0 + j, &r, &dummy);
           idx[j] = k0 + j < n ? (unsigned int)rr_lower_bound_u64(s_cdf, n, rr_fix_target_multinomial(r, total)) : 0u;
         }
       }
@@ -936,6 +990,7 @@ __global__ __launch_bounds__(BLOCK) void k_step_small(Bufs b, double* __restrict
         }
       c_den = (double)n;
     }
+    RR_RES_TL(5);  // resampled / gathered
     if (a.want_est) {
       small_block_sum4<BLOCK>(est_acc, s_red);
 #pragma unroll
@@ -951,13 +1006,27 @@ __global__ __launch_bounds__(BLOCK) void k_step_small(Bufs b, double* __restrict
           if (tid < cnt) est_out[4 * (size_t)s0 + tid] = s_ring[tid];
         }
       }
+      if (resident && tid < 4) {  // the step's answer: four self-vouching pairs, no fence, no separate stamp
+        const double e = tid == 0 ? c_est[0] : tid == 1 ? c_est[1] : tid == 2 ? c_est[2] : c_est[3];
+        rr::store_pair_sys(&ring->rsp[tid], (uint64_t)__double_as_longlong(e / c_den), a.res.first_seq + (uint64_t)s);
+      }
+#if defined(RR_PLAN_TIMELINE)
+      if (resident && tid == 0) {  // [6]: the estimate summed and its four pairs issued; [7]: did the resample fire
+        res_tl[6] = wall_clock64();
+        res_tl[7] = (uint64_t)fire;
+        for (int k = 0; k < 8; ++k) rr::store_pair_sys(&ring->rsp[8 + k], res_tl[k], a.res.first_seq + (uint64_t)s);
+      }
+#endif
     }
   }
+  if (resident) __syncthreads();
+  // a resident incarnation that served no step leaves the particle set, the weights and Ctl as it found them
+  const bool write_back = !resident || steps_done > 0;
   // ---- the state after the last step
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const uint64_t k = k0 + j;
-    if (k < n) {
+    if (k < n && write_back) {
       b.x[cur][k] = x[j];
       b.y[cur][k] = y[j];
       b.yaw[cur][k] = yaw[j];
@@ -966,7 +1035,7 @@ __global__ __launch_bounds__(BLOCK) void k_step_small(Bufs b, double* __restrict
       if (idx_out && any_fired) idx_out[k] = last_idx[j];
     }
   }
-  if (tid == 0) {
+  if (tid == 0 && write_back) {
     ctl->weights_uniform = c_fired ? 1 : 0;
     ctl->usable = c_usable;
     ctl->image_mode = c_mode;
@@ -988,7 +1057,7 @@ __global__ __launch_bounds__(BLOCK) void k_step_small(Bufs b, double* __restrict
     if (a.want_est) {
       for (int k = 0; k < 4; ++k) est_partials[k] = c_est[k];
       ctl->est_denom = c_den;
-      ctl->est_step = (uint64_t)(a.rstep0 + (unsigned int)a.K - 1) + 1;
+      ctl->est_step = (uint64_t)(a.rstep0 + (unsigned int)(resident ? steps_done : a.K) - 1) + 1;
       if (a.mail_seq) {
         for (int k = 0; k < 4; ++k)
           __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[k]), (uint64_t)__double_as_longlong(c_est[k] / c_den), __ATOMIC_RELAXED,
@@ -996,6 +1065,10 @@ __global__ __launch_bounds__(BLOCK) void k_step_small(Bufs b, double* __restrict
         __hip_atomic_store(&mail->seq, a.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
+  }
+  if (resident && tid == 0) {  // EXIT marker: the last command this incarnation consumed (a quit counts), stamped with the launch id
+    const uint64_t consumed = a.res.first_seq + (uint64_t)steps_done - 1 + (res_last_op == rr::kResOpQuit ? 1 : 0);
+    rr::store_pair_sys(&ring->rsp[rr::kResRspExit], consumed, a.res.launch_id);
   }
 }
 
@@ -1494,6 +1567,7 @@ __global__ __launch_bounds__(kBlock) void k_kld_insert(const int32_t* __restrict
 }
 
 constexpr int kKldThreads = 1024;
+constexpr uint64_t kKldWipeInKernel = 16384;  // candidate draws up to which k_kld_count wipes the bin table itself
 // One workgroup of kKldThreads: the number of draws the reference's loop makes before it stops (:340-352) -- occupied-bin
 // count after every draw (scan of the first-occurrence flags), running maximum of the KLD bound, first draw that satisfies
 // the stop rule.  Every thread gets the result.  Then the bin table and the first-occurrence slots are wiped for the NEXT
@@ -1544,11 +1618,17 @@ __device__ inline uint64_t kld_count_body(unsigned int* __restrict__ minslot, co
   const uint64_t n_new = s_stop == ~0ull ? n_draws : s_stop + 1;  // :342: at most max_particles
   // every read of minslot[] above happened before a barrier all threads have passed (the loop ends with one, or breaks
   // right after one): the table can go
+  // (one workgroup wipes the slots the draws used; beyond kKldWipeInKernel draws the host wipes both arrays with two wide
+  // memsets behind the launch instead -- 2 x 4 x hash_size bytes through one workgroup would cost more than the step)
   __syncthreads();
-  for (uint64_t k = tid; k < hash_size; k += kKldThreads) {
-    table[k] = kKldEmpty;
-    minslot[k] = kKldEmpty;
+  if (n_draws <= kKldWipeInKernel) {
+    for (uint64_t m = tid; m < n_draws; m += kKldThreads) {
+      const unsigned int slot = myslot[m];
+      table[slot] = kKldEmpty;
+      minslot[slot] = kKldEmpty;
+    }
   }
+  (void)hash_size;
   return n_new;
 }
 
@@ -1875,6 +1955,18 @@ struct rr_pf {
   double* est_ring = nullptr;
   size_t est_ring_cap = 0;
   std::vector<double> steps_host;
+  // resident service (resident_core.hpp; rr_pf_set_resident): the small filter's step kernel stays on the device between steps
+  struct Resident {
+    bool enabled = false;
+    bool live = false;     // an incarnation was launched and has not been seen to leave
+    bool pending = false;  // a step was issued without waiting for its answer (rr_pf_step_async)
+    rr::ResidentRing* ring = nullptr;  // pinned, host-coherent
+    uint64_t seq = 0;        // last command issued
+    uint64_t launch_id = 0;  // of the current / last incarnation
+    double idle_us = 0.0, life_us = 100000.0;
+    uint64_t launches = 0, steps = 0;
+    unsigned int cmd_step = 0, cmd_rstep = 0;  // the step counters the command in flight was issued at (a relaunch starts there)
+  } res;
   // k_quantize_plan_mark (K2 + fused plan in one launch): one record per tile, the launch epoch, the largest grid whose
   // workgroups are all resident at once (0: not available), RR_PF_FUSED_PLAN=0 turns it off
   double* packed[2] = {nullptr, nullptr};  // {x, y, yaw, v} mirrors of the two buffer sets (k_step_lazy<PACKED>; lazy multinomial only)
@@ -2002,9 +2094,17 @@ void set_particle_count(rr_pf* h, uint64_t n);
 
 // keep_lazy: the caller enqueues work that reads the particle count from the device (the asynchronous step of an adaptive
 // filter); everybody else gets the host's copy brought up to date first (one small copy + a wait)
-rr_status bind(rr_pf* h, bool keep_lazy = false) {
+rr_status resident_park(rr_pf* h);
+
+// keep_resident: the caller talks to the handle's resident step kernel; everybody else finds the stream idle and the particle
+// set in HBM (the kernel is asked to leave first)
+rr_status bind(rr_pf* h, bool keep_lazy = false, bool keep_resident = false) {
   if (!h) return fail(RR_INVALID_PARAMETER, "null handle");
   RR_HIP_TRY(hipSetDevice(h->opt.device));
+  if ((h->res.live || h->res.pending) && !keep_resident) {
+    rr_status ps = resident_park(h);
+    if (ps != RR_OK) return ps;
+  }
   if (h->n_dirty && !keep_lazy) {
     RR_HIP_TRY(hipMemcpyAsync(h->kld_out_host, h->kld_out, sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     RR_HIP_TRY(hipStreamSynchronize(h->stream));
@@ -2391,6 +2491,10 @@ rr_status resample_adaptive(rr_pf* h, const double* r_explicit_dev, bool lazy = 
       hipLaunchKernelGGL(k_kld_gather_dyn, dim3(grid_for(M, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, (const unsigned int*)h->idx,
                          (const uint64_t*)h->kld_out);
     RR_HIP_TRY(hipGetLastError());
+    if (M > kKldWipeInKernel) {  // the bin table of a large adaptive filter: wiped for the next resample by the copy engine / a wide fill
+      RR_HIP_TRY(hipMemsetAsync(h->kld_table, 0xff, h->kld_hash_size * sizeof(unsigned int), h->stream));
+      RR_HIP_TRY(hipMemsetAsync(h->kld_minslot, 0xff, h->kld_hash_size * sizeof(unsigned int), h->stream));
+    }
     h->n_dirty = true;  // weights are uniform 1/n_new from here (Ctl.weights_uniform, :359-362)
   }
   h->rstep += 1;
@@ -2412,6 +2516,32 @@ rr_status fetch_ctl(rr_pf* h) {
     h->ctl_host->grid_timeout = 0;
   }
   return h->p2p.check(h->stream);  // a latched peer-wait timeout must not look like a healthy filter
+}
+
+// The synchronous entry points wait for the stamp their step's last kernel leaves in the host mailbox: a bounded busy wait
+// (a healthy step answers within tens of microseconds; kMailSpinNs of polling, the clock read every 256 polls), then the
+// ordinary stream wait.  One place for all of them: same bound, same error, and the device's spinning-kernel slot is
+// handed back (spin_release) because the stream is idle once the stamp is there.
+constexpr long long kMailSpinNs = 500 * 1000;
+rr_status await_mail(rr_pf* h, uint64_t want) {
+  const volatile uint64_t* seq = &h->mail->seq;
+  bool seen = false;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) {
+      seen = true;
+      break;
+    }
+    if ((spins & 255u) == 255u &&
+        std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() > kMailSpinNs)
+      break;
+  }
+  if (!seen) {  // slow device / contended queue: wait the ordinary way
+    RR_HIP_TRY(hipStreamSynchronize(h->stream));
+    if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != want) return fail(RR_RUNTIME_ERROR, "the step's estimate never reached the host mailbox");
+  }
+  rr::spin_release(h->opt.device, h);  // the stream is idle
+  return RR_OK;
 }
 
 rr_status compute_moments(rr_pf* h, double est[4], double cov[16]) {
@@ -2437,19 +2567,8 @@ rr_status compute_moments(rr_pf* h, double est[4], double cov[16]) {
     }
     RR_HIP_TRY(hipGetLastError());
     if (by_mail) {
-      const volatile uint64_t* seq = &h->mail->seq;
-      bool seen = false;
-      for (long spins = 0; spins < 4000000; ++spins) {
-        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) {
-          seen = true;
-          break;
-        }
-      }
-      if (!seen) {
-        RR_HIP_TRY(hipStreamSynchronize(h->stream));
-        if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != want) return fail(RR_RUNTIME_ERROR, "the estimate never reached the host mailbox");
-      }
-      rr::spin_release(h->opt.device, h);  // the stream is idle
+      rr_status ms = await_mail(h, want);
+      if (ms != RR_OK) return ms;
       if (h->mail->flags == 0) {
         for (int k = 0; k < 4; ++k) est[k] = h->mail->est[k];
         return RR_OK;
@@ -2577,6 +2696,14 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
     if (v >= 1) h->mn_grid = v;
   }
   if (const char* e = std::getenv("RR_PF_SMALL")) h->small_ok = std::atoi(e) != 0;
+  if (const char* e = std::getenv("RR_PF_RESIDENT_US")) {  // resident service from the start (rr_pf_set_resident)
+    const double us = std::atof(e);
+    if (us > 0.0 && us <= 1e7) {
+      h->res.enabled = true;
+      h->res.idle_us = us;
+      h->res.life_us = std::max(100000.0, 20.0 * us);
+    }
+  }
   if (const char* e = std::getenv("RR_MN_DEFER")) h->mn_defer_ok = std::atoi(e) != 0;
   if (const char* e = std::getenv("RR_MCL_SMALL")) h->adaptive_small_ok = std::atoi(e) != 0;
   if (const char* e = std::getenv("RR_K1_BLOCKS_PER_CU")) {
@@ -2771,10 +2898,159 @@ static rr_status launch_small_as(rr_pf* h, const SmallArgs& a, const ObsArg& arg
     raised = true;
   }
   hipLaunchKernelGGL((k_step_small<BLOCK, R, LIK>), dim3(1), dim3(BLOCK), lds, h->stream, h->b, h->w, h->ctl, a, arg,
-                     (const double*)h->steps_dev, h->idx, est_out, h->est_partials, h->mail);
+                     (const double*)h->steps_dev, h->idx, est_out, h->est_partials, h->mail, h->res.ring);
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
 }
+
+static void small_args_common(const rr_pf* h, SmallArgs* a, size_t n_obs, size_t K, bool want_est) {
+  a->n = h->n;
+  a->seed = h->opt.seed;
+  a->step0 = h->step;
+  a->rstep0 = h->rstep;
+  a->n_obs = (int)n_obs;
+  a->K = (int)K;
+  a->gate = h->opt.resample_gate;
+  a->scheme = h->opt.resample_scheme;
+  a->neff_threshold = (double)h->n_global * h->cfg.resample_threshold;
+  a->dt = h->cfg.dt;
+  a->sigma_v = h->cfg.velocity_noise;
+  a->sigma_w = h->cfg.yaw_rate_noise;
+  a->lik = h->lik;
+  a->want_est = want_est ? 1 : 0;
+}
+
+static rr_status launch_small(rr_pf* h, const SmallArgs& a, const ObsArg& arg, size_t lds, double* est_out) {
+  const bool product = h->opt.likelihood_mode == RR_LIK_PRODUCT;
+  // shape of the workgroup: 512 threads x 1 / 2 / 4 consecutive particles.  Measured at 1000 x 4 (step_many, us per step):
+  // 512 x 2: 7.2, 1024 x 1: 8.7 -- sixteen waves pay more at the step's dozen barriers than their extra latency hiding
+  // brings.  RR_PF_SMALL_BLOCK=1024 selects 1024 threads x 1 / 2 (A/B).
+  static const int forced = [] { const char* e = std::getenv("RR_PF_SMALL_BLOCK"); return e ? std::atoi(e) : 0; }();
+#define RR_SMALL_GO(B_, R_) (product ? launch_small_as<B_, R_, RR_LIK_PRODUCT>(h, a, arg, lds, est_out) : launch_small_as<B_, R_, RR_LIK_FUSED>(h, a, arg, lds, est_out))
+  // the reference's own sizes (100 - 150 particles): two or four waves pay less at the step's barriers and cross-wave sums
+  // than eight mostly idle ones (RR_PF_SMALL_BLOCK=512: always 512 threads, for A/B)
+  if (h->n <= 128 && forced != 512) return RR_SMALL_GO(128, 1);
+  if (h->n <= 256 && forced != 512) return RR_SMALL_GO(256, 1);
+  if (h->n <= 512) return RR_SMALL_GO(512, 1);
+  if (forced == 1024) return h->n <= 1024 ? RR_SMALL_GO(1024, 1) : RR_SMALL_GO(1024, 2);
+  return h->n <= 1024 ? RR_SMALL_GO(512, 2) : RR_SMALL_GO(512, 4);
+#undef RR_SMALL_GO
+}
+
+// ---- resident service of a small filter (resident_core.hpp): the host side
+constexpr size_t kResMaxObs = 128;
+constexpr int kResPayloadCap = 2 + 3 * (int)kResMaxObs;
+static size_t resident_lds_bytes(uint64_t n) { return ((size_t)kResPayloadCap + 5 * (size_t)n + 1) * sizeof(double); }
+static bool small_path(const rr_pf* h, size_t n_obs);
+static bool resident_path(const rr_pf* h, size_t n_obs) {
+  return h->res.enabled && !h->profiling && n_obs <= kResMaxObs && small_path(h, n_obs) && resident_lds_bytes(h->n) <= 150 * 1024;
+}
+
+// launch an incarnation that waits for command `first_seq` (the particle set is in HBM: nothing of this handle is in flight)
+static rr_status resident_launch(rr_pf* h, uint64_t first_seq, unsigned int step0, unsigned int rstep0) {
+  rr_status s = materialise(h);
+  if (s != RR_OK) return s;
+  if (!h->res.ring) {
+    RR_HIP_TRY(hipHostMalloc(&h->res.ring, sizeof(rr::ResidentRing), hipHostMallocDefault));
+    std::memset(h->res.ring, 0, sizeof(rr::ResidentRing));
+  }
+  SmallArgs a{};
+  small_args_common(h, &a, /*n_obs hint=*/4, /*K=*/0, /*want_est=*/true);
+  a.step0 = step0;
+  a.rstep0 = rstep0;
+  a.res.on = 1;
+  a.res.payload_cap = kResPayloadCap;
+  a.res.first_seq = first_seq;
+  a.res.idle_ticks = (uint64_t)(h->res.idle_us * 100.0);
+  a.res.life_ticks = (uint64_t)(h->res.life_us * 100.0);
+  a.res.launch_id = ++h->res.launch_id;
+  ObsArg arg;
+  if ((s = launch_small(h, a, arg, resident_lds_bytes(h->n), nullptr)) != RR_OK) return s;
+  h->res.live = true;
+  h->res.launches += 1;
+  h->maybe_pending = false;
+  h->pending_kind = kSrcMarkers;
+  return RR_OK;
+}
+
+// the answer to command `seq` (out may be null: only wait).  An incarnation that left before it took the command (idle / end
+// of life) is replaced; the command is still in the ring.
+static rr_status resident_await(rr_pf* h, uint64_t seq, double out[4]) {
+  rr_pf::Resident& r = h->res;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    uint64_t e[4];
+    if (rr::ring_take(&r.ring->rsp[3], seq, &e[3]) && rr::ring_take(&r.ring->rsp[2], seq, &e[2]) && rr::ring_take(&r.ring->rsp[1], seq, &e[1]) &&
+        rr::ring_take(&r.ring->rsp[0], seq, &e[0])) {
+      if (out)
+        for (int k = 0; k < 4; ++k) std::memcpy(&out[k], &e[k], sizeof(double));
+      r.pending = false;
+      return RR_OK;
+    }
+    uint64_t consumed = 0;
+    if (r.live && rr::ring_take(&r.ring->rsp[rr::kResRspExit], r.launch_id, &consumed)) {
+      r.live = false;  // this incarnation has left
+      if (consumed < seq) {
+        rr_status s = resident_launch(h, seq, r.cmd_step, r.cmd_rstep);
+        if (s != RR_OK) return s;
+      }
+      continue;  // (consumed >= seq: the answer is on its way)
+    }
+    if ((spins & 1023u) == 1023u &&
+        std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > 2000) {
+      (void)hipStreamSynchronize(h->stream);
+      r.live = false;
+      r.pending = false;
+      return fail(RR_RUNTIME_ERROR, "the resident step kernel did not answer");
+    }
+  }
+}
+
+// one step through the resident kernel; out == null: do not wait for the answer
+static rr_status resident_step(rr_pf* h, const double control[2], const double* obs, size_t n_obs, double out[4]) {
+  rr_pf::Resident& r = h->res;
+  rr_status s;
+  if (r.pending && (s = resident_await(h, r.seq, nullptr)) != RR_OK) return s;  // one command in flight
+  if (!r.ring || !r.live) {  // (also allocates the ring)
+    if ((s = resident_launch(h, r.seq + 1, h->step, h->rstep)) != RR_OK) return s;
+  }
+  const uint64_t seq = ++r.seq;
+  r.cmd_step = h->step;
+  r.cmd_rstep = h->rstep;
+  rr::MailPair* c = r.ring->cmd;
+  auto bits_of = [](double v) {
+    uint64_t u;
+    std::memcpy(&u, &v, sizeof u);
+    return u;
+  };
+  for (size_t i = 0; i < 3 * n_obs; ++i) rr::ring_put(&c[3 + i], bits_of(obs[i]), seq);
+  rr::ring_put(&c[2], bits_of(control[1]), seq);
+  rr::ring_put(&c[1], bits_of(control[0]), seq);
+  rr::ring_put(&c[0], (uint64_t)rr::kResOpStep | ((uint64_t)(2 + 3 * n_obs) << 8), seq);
+  h->step += 1;
+  h->rstep += 1;
+  h->wmax_live = false;
+  h->wmax_bits_clean = true;
+  r.steps += 1;
+  r.pending = true;
+  if (!out) return RR_OK;
+  return resident_await(h, seq, out);
+}
+
+// ask the resident kernel to leave and wait until it has: the particle set, the weights and Ctl are in HBM afterwards
+namespace {
+rr_status resident_park(rr_pf* h) {
+  rr_pf::Resident& r = h->res;
+  rr_status s = RR_OK;
+  if (r.pending) s = resident_await(h, r.seq, nullptr);
+  if (r.live) {
+    rr::ring_put(&r.ring->cmd[0], (uint64_t)rr::kResOpQuit, ++r.seq);
+    RR_HIP_TRY(hipStreamSynchronize(h->stream));
+    r.live = false;
+  }
+  return s;
+}
+}  // namespace
 
 // K steps (controls: K x 2, obs: K x n_obs x 3, both validated by the caller) in one launch.  est_out: device, K x 4, or null.
 static rr_status step_small(rr_pf* h, const double* controls, const double* obs, size_t n_obs, size_t K, bool want_est, double* est_out,
@@ -2789,20 +3065,7 @@ static rr_status step_small(rr_pf* h, const double* controls, const double* obs,
     }
     a.mail_seq = ++h->mail_seq;
   }
-  a.n = h->n;
-  a.seed = h->opt.seed;
-  a.step0 = h->step;
-  a.rstep0 = h->rstep;
-  a.n_obs = (int)n_obs;
-  a.K = (int)K;
-  a.gate = h->opt.resample_gate;
-  a.scheme = h->opt.resample_scheme;
-  a.neff_threshold = (double)h->n_global * h->cfg.resample_threshold;
-  a.dt = h->cfg.dt;
-  a.sigma_v = h->cfg.velocity_noise;
-  a.sigma_w = h->cfg.yaw_rate_noise;
-  a.lik = h->lik;
-  a.want_est = want_est ? 1 : 0;
+  small_args_common(h, &a, n_obs, K, want_est);
   ObsArg arg;
   a.inputs_in_kernarg = (K == 1 && n_obs <= (size_t)kMaxObsKernarg) ? 1 : 0;
   if (a.inputs_in_kernarg) {
@@ -2827,19 +3090,9 @@ static rr_status step_small(rr_pf* h, const double* controls, const double* obs,
     // pageable source: HIP stages it before returning, so steps_host may be reused by the next call
     RR_HIP_TRY(hipMemcpyAsync(h->steps_dev, h->steps_host.data(), K * per * sizeof(double), hipMemcpyHostToDevice, h->stream));
   }
-  const size_t lds = small_lds_bytes(h->n, n_obs);
-  const bool product = h->opt.likelihood_mode == RR_LIK_PRODUCT;
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
-    // shape of the workgroup: 512 threads x 1 / 2 / 4 consecutive particles.  Measured at 1000 x 4 (step_many, us per step):
-    // 512 x 2: 7.2, 1024 x 1: 8.7 -- sixteen waves pay more at the step's dozen barriers than their extra latency hiding
-    // brings.  RR_PF_SMALL_BLOCK=1024 selects 1024 threads x 1 / 2 (A/B).
-    static const int forced = [] { const char* e = std::getenv("RR_PF_SMALL_BLOCK"); return e ? std::atoi(e) : 0; }();
-#define RR_SMALL_GO(B_, R_) (product ? launch_small_as<B_, R_, RR_LIK_PRODUCT>(h, a, arg, lds, est_out) : launch_small_as<B_, R_, RR_LIK_FUSED>(h, a, arg, lds, est_out))
-    if (h->n <= 512) s = RR_SMALL_GO(512, 1);
-    else if (forced == 1024) s = h->n <= 1024 ? RR_SMALL_GO(1024, 1) : RR_SMALL_GO(1024, 2);
-    else s = h->n <= 1024 ? RR_SMALL_GO(512, 2) : RR_SMALL_GO(512, 4);
-#undef RR_SMALL_GO
+    s = launch_small(h, a, arg, small_lds_bytes(h->n, n_obs), est_out);
   }
   if (s != RR_OK) return s;
   h->step += (unsigned int)K;
@@ -2859,6 +3112,14 @@ int rr_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+rr_status rr_device_pci_bus_id(int32_t device, char* out, size_t cap) {
+  if (!out || cap < 13) return fail(RR_INVALID_PARAMETER, "need room for \"0000:00:00.0\" and its terminator");
+  RR_HIP_TRY(hipDeviceGetPCIBusId(out, (int)cap, device));
+  for (char* c = out; *c; ++c)
+    if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');  // as sysfs spells it
+  return RR_OK;
 }
 
 void rr_pf_config_default(rr_pf_config* c) {
@@ -2946,7 +3207,9 @@ rr_status rr_pf_resample_adaptive_with_uniforms(rr_pf* h, const double* r, size_
 void rr_pf_destroy(rr_pf* h) {
   if (!h) return;
   (void)hipSetDevice(h->opt.device);
+  if (h->res.live || h->res.pending) (void)resident_park(h);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->res.ring) (void)hipHostFree(h->res.ring);
   h->p2p.teardown();
   (void)hipFree(h->slab);
   (void)hipFree(h->w);
@@ -3197,7 +3460,35 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
 }
 
 rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
+  if (h && resident_path(h, n_obs)) {
+    rr_status s = bind(h, false, /*keep_resident=*/true);
+    if (s != RR_OK) return s;
+    if ((s = validate_control(control)) != RR_OK) return s;
+    if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
+    return resident_step(h, control, obs, n_obs, nullptr);
+  }
   return step_async_impl(h, control, obs, n_obs, false);
+}
+
+// The resident service of a small filter (<= 2048 particles, <= 128 observations per step): idle_us > 0 switches it on --
+// rr_pf_step / rr_pf_step_async then talk to ONE kernel that stays on the device, keeps the particles in registers and leaves by
+// itself after idle_us without a step (and is started again by the next one); 0 switches it off.  Every other entry point
+// asks the kernel to leave first, so results are those of the launched steps, bit for bit.
+rr_status rr_pf_set_resident(rr_pf* h, double idle_us) {
+  rr_status s = bind(h);  // (parks a live kernel)
+  if (s != RR_OK) return s;
+  if (!(idle_us >= 0.0) || !(idle_us <= 1e7)) return fail(RR_INVALID_PARAMETER, "resident idle time must lie in [0, 1e7] microseconds");
+  h->res.enabled = idle_us > 0.0;
+  h->res.idle_us = idle_us;
+  h->res.life_us = std::max(100000.0, 20.0 * idle_us);
+  return RR_OK;
+}
+
+rr_status rr_pf_resident_stats(const rr_pf* h, uint64_t* launches, uint64_t* steps) {
+  if (!h) return fail(RR_INVALID_PARAMETER, "null handle");
+  if (launches) *launches = h->res.launches;
+  if (steps) *steps = h->res.steps;
+  return RR_OK;
 }
 
 rr_status rr_pf_step_async_estimate(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
@@ -3282,6 +3573,15 @@ rr_status rr_pf_step_many(rr_pf* h, const double* controls, const double* obs, s
 }
 
 rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_t n_obs, double out_state[4]) {
+  if (h && out_state && resident_path(h, n_obs)) {
+    // try_step of a small filter with the resident service switched on: no launch, no completion signal -- the command goes
+    // into pinned memory, the answer comes back the same way (resident_core.hpp)
+    rr_status s = bind(h, false, /*keep_resident=*/true);
+    if (s != RR_OK) return s;
+    if ((s = validate_control(control)) != RR_OK) return s;
+    if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
+    return resident_step(h, control, obs, n_obs, out_state);
+  }
   if (h && out_state && small_path(h, n_obs)) {
     // try_step of a small filter: one launch; the kernel writes the mean into the host-visible mailbox and the host polls
     // its stamp -- no device-to-host copy, no stream synchronisation in the common case
@@ -3290,19 +3590,7 @@ rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_
     if ((s = validate_control(control)) != RR_OK) return s;
     if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
     if ((s = step_small(h, control, obs, n_obs, 1, true, nullptr, /*to_mailbox=*/true)) != RR_OK) return s;
-    const uint64_t want = h->mail_seq;
-    const volatile uint64_t* seq = &h->mail->seq;
-    bool seen = false;
-    for (long spins = 0; spins < 2000000; ++spins) {  // ~ tens of milliseconds; a healthy step answers within ~15 us
-      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) {
-        seen = true;
-        break;
-      }
-    }
-    if (!seen) {  // slow device / contended queue: wait the ordinary way
-      RR_HIP_TRY(hipStreamSynchronize(h->stream));
-      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != want) return fail(RR_RUNTIME_ERROR, "the step's estimate never reached the host mailbox");
-    }
+    if ((s = await_mail(h, h->mail_seq)) != RR_OK) return s;
     for (int k = 0; k < 4; ++k) out_state[k] = h->mail->est[k];
     return RR_OK;
   }
@@ -3319,19 +3607,7 @@ rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_
     const uint64_t want = ++h->mail_seq;
     hipLaunchKernelGGL(k_est_mail, dim3(1), dim3(256), 0, h->stream, (const Ctl*)h->ctl, (const double*)h->est_partials, h->n_tiles, h->mail, want);
     RR_HIP_TRY(hipGetLastError());
-    const volatile uint64_t* seq = &h->mail->seq;
-    bool seen = false;
-    for (long spins = 0; spins < 4000000; ++spins) {
-      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) {
-        seen = true;
-        break;
-      }
-    }
-    if (!seen) {
-      RR_HIP_TRY(hipStreamSynchronize(h->stream));
-      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != want) return fail(RR_RUNTIME_ERROR, "the step's estimate never reached the host mailbox");
-    }
-    rr::spin_release(h->opt.device, h);  // the stream is idle
+    if ((s = await_mail(h, want)) != RR_OK) return s;
     if (h->mail->flags) return rr_pf_last_step_estimate(h, out_state);  // a degraded plan to take note of (fetch_ctl), or no estimate
     for (int k = 0; k < 4; ++k) out_state[k] = h->mail->est[k];
     return RR_OK;
@@ -3341,24 +3617,15 @@ rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_
   if (s != RR_OK) return s;
   if (!out_state) return rr_pf_synchronize(h);
   if (want) {  // the adaptive step of a small filter has formed the mean itself (k_mcl_adaptive_small): poll the mailbox
-    const volatile uint64_t* seq = &h->mail->seq;
-    bool seen = false;
-    for (long spins = 0; spins < 4000000; ++spins) {
-      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) == want) {
-        seen = true;
-        break;
-      }
-    }
-    if (!seen) {
-      RR_HIP_TRY(hipStreamSynchronize(h->stream));
-      if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != want) return fail(RR_RUNTIME_ERROR, "the step's estimate never reached the host mailbox");
-    }
-    rr::spin_release(h->opt.device, h);  // the stream is idle
+    if ((s = await_mail(h, want)) != RR_OK) return s;
     if (h->mail->flags == 0) {
       for (int k = 0; k < 4; ++k) out_state[k] = h->mail->est[k];
       return RR_OK;
     }
   }
+  // an adaptive step leaves the new particle count on the device (Ctl.n_active; h->n is stale while n_dirty): the moment kernels
+  // below are sized from the host's copy, so bring it up to date first (one 8-byte copy + a wait)
+  if ((s = bind(h)) != RR_OK) return s;
   if ((s = materialise(h)) != RR_OK) return s;  // the estimate is over the resampled set
   return compute_moments(h, out_state, nullptr);
 }
@@ -3491,6 +3758,12 @@ rr_status rr_pf_plan_stats(rr_pf* h, uint64_t* giveups, int32_t* one_launch_enab
 }
 
 #if defined(RR_PLAN_TIMELINE)
+// instrumented build only (tools/resident_timeline.py): the stamps the resident kernel sent with its last answer
+rr_status rr_pf_debug_resident_timeline(rr_pf* h, uint64_t out[8]) {
+  if (!h || !h->res.ring) return fail(RR_INVALID_PARAMETER, "no resident service");
+  for (int k = 0; k < 8; ++k) out[k] = __atomic_load_n(&h->res.ring->rsp[8 + k].bits, __ATOMIC_RELAXED);
+  return RR_OK;
+}
 // instrumented build only (tools/plan_timeline.py): the stamps of the last k_quantize_plan_mark launch, n_tiles x kTimelineWords
 rr_status rr_pf_debug_plan_timeline(rr_pf* h, uint64_t* out, size_t cap_words) {
   rr_status s = bind(h);

@@ -265,6 +265,20 @@ class ParticleFilterLocalizer:
     def synchronize(self) -> None:
         _check(self._L.rr_pf_synchronize(self._h))
 
+    def set_resident(self, idle_us: float) -> None:
+        """Resident service (``rr_pf_set_resident``, engine extension): with ``idle_us > 0`` the steps of a filter of up to
+        2048 particles are served by ONE kernel that stays on the device between them (no launch per step); it leaves by
+        itself after ``idle_us`` microseconds without a step.  0 switches it off."""
+        _check(self._L.rr_pf_set_resident(self._h, float(idle_us)))
+
+    def resident_stats(self):
+        """(incarnations of the resident kernel launched, steps served by them)"""
+        import ctypes as C
+
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(self._L.rr_pf_resident_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     # ---- estimate / covariance (particle_filter.rs:347-365; evaluated lazily on the GPU)
     def _refresh(self) -> None:
         if self._cache_valid:

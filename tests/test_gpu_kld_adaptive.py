@@ -249,3 +249,27 @@ def test_try_step_returns_the_estimate_of_the_new_set(loc, lo, hi):
         e2 = np.asarray(mcl.estimate())
         assert np.array_equal(e.view(np.uint64), e2.view(np.uint64)), f"step {t}"
         assert lo <= mcl.particle_count() <= hi
+
+
+def test_try_step_without_accessors_uses_the_new_count(loc):
+    """rr_pf_step of an adaptive filter whose one-launch step hands over to the moment kernels (more than 1 024 particles
+    after the resample): the host's particle count is stale at that point (the step left it on the device) and has to be
+    refreshed before those kernels are sized.  Filter `a` calls nothing but try_step; filter `b` refreshes the host's copy
+    with an accessor after every step.  Same estimates, bit for bit, with a count that moves above 1 024."""
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=100, max_particles=5000, range_noise=3.0)
+    a = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=31)
+    b = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=31)
+    lms = [(10.0, 0.0), (0.0, 15.0), (-5.0, 20.0), (10.0, 10.0)]
+    truth = np.zeros(3)
+    counts = []
+    for t in range(60):
+        truth += [math.cos(truth[2]) * 0.1, math.sin(truth[2]) * 0.1, 0.01]
+        obs = [(math.hypot(truth[0] - lx, truth[1] - ly), lx, ly) for lx, ly in lms]
+        ea = np.asarray(a.try_step([1.0, 0.1], obs))
+        eb = np.asarray(b.try_step([1.0, 0.1], obs))
+        counts.append(b.particle_count())
+        e2 = np.asarray(b.estimate())
+        assert np.array_equal(eb.view(np.uint64), e2.view(np.uint64)), f"step {t}"
+        assert np.array_equal(ea.view(np.uint64), eb.view(np.uint64)), f"step {t}: {ea} vs {eb} (count {counts[-1]})"
+    assert max(counts) > 1024 and len(set(counts)) > 3, counts
+    assert a.particle_count() == b.particle_count()

@@ -1,0 +1,69 @@
+"""nodes/pf_localizer_node: the node process, fed the reference's particle-filter demo scenario
+(render_gif_particle_filter.rs:33-98) through its transport, must publish exactly what the in-process localizer returns --
+the node adds plumbing, not arithmetic -- with the message contract of ros2_nodes/ekf_localizer_node/src/main.rs:116-162."""
+import math
+
+import numpy as np
+import pytest
+
+from tests import node_driver as D
+
+pytestmark = pytest.mark.gpu
+
+
+def in_process_states(steps, seed_filter=42, resident=0.0):
+    import rust_robotics_amd.localization as loc
+
+    cfg = loc.ParticleFilterConfig(n_particles=150, dt=0.1, range_noise=0.25)
+    pf = loc.ParticleFilterLocalizer.with_initial_state(list(D.INITIAL), cfg, seed=seed_filter)
+    if resident:
+        pf.set_resident(resident)
+    u, obs, _ = D.scenario(steps)
+    return np.array([pf.step(u[k], obs[k]) for k in range(steps)])
+
+
+@pytest.mark.parametrize("transport,resident_us", [("stdio", "20000"), ("stdio", "0"), ("unix", "20000")])
+def test_node_publishes_the_in_process_estimates(tmp_path, transport, resident_us):
+    node = D.NodeProcess(env={"PF_SEED": "42", "PF_RESIDENT_IDLE_US": resident_us, "PF_LOG_INTERVAL_S": "0.05"}, transport=transport, tmpdir=str(tmp_path))
+    states, lat, msgs = D.run_scenario(node)
+    rc, err = node.close()
+    assert rc == 0, err
+    want = in_process_states(D.STEPS)
+    # the first message initialises the filter at the odometry pose and is published as is (main.rs:220-256)
+    assert list(states[0]) == list(D.INITIAL)
+    got = states[1:]
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), f"first difference at step {int(np.argmax((got != want).any(axis=1)))}"
+    # message contract: pose then odometry per input, the source's stamp and frames, planar quaternion, twist passed through
+    pose, odom = msgs[2 + 2 * 9], msgs[3 + 2 * 9]  # step 10
+    assert pose["topic"] == "/pf_pose" and odom["topic"] == "/pf_odom"
+    assert pose["stamp"] == odom["stamp"] == [1, 0] and pose["frame_id"] == odom["frame_id"] == "odom" and odom["child_frame_id"] == "base_link"
+    x, y, yaw, v = pose["state"]
+    assert pose["pose"][:3] == [x, y, 0.0] and pose["pose"][3:5] == [0.0, 0.0]
+    assert math.isclose(pose["pose"][5], math.sin(0.5 * yaw), rel_tol=1e-15) and math.isclose(pose["pose"][6], math.cos(0.5 * yaw), rel_tol=1e-15)
+    assert odom["pose"] == pose["pose"] and odom["twist"] == [1.1, 0.0, 0.0, 0.0, 0.0, 0.0]
+    # the filter tracks (the demo's point), and the periodic log line carries the step latency
+    _, _, truth = D.scenario()
+    assert np.hypot(*(got[-1, :2] - truth[-1, :2])) < 1.0
+    log_text = err if transport == "stdio" else "\n".join(m["text"] for m in node.logs) + err
+    assert "pf localizer started" in log_text and "step latency mean=" in log_text and "initialized filtered pose x=5.00 y=5.00" in log_text
+    print(f"node round trip per message pair ({transport}, resident {resident_us} us): median {np.median(lat):.1f} us, p99 {np.percentile(lat, 99):.1f} us")
+
+
+def test_node_survives_bad_messages_and_custom_topics(tmp_path):
+    """Errors are logged and the message dropped (main.rs:266-272); topic names come from the environment (main.rs:174-176)."""
+    env = {"PF_SEED": "7", "PF_INPUT_ODOM_TOPIC": "/robot/odom", "PF_INPUT_RANGES_TOPIC": "/robot/ranges", "PF_OUTPUT_POSE_TOPIC": "/robot/pf_pose",
+           "PF_OUTPUT_ODOM_TOPIC": "/robot/pf_odom"}
+    node = D.NodeProcess(env=env)
+    node.send("this is not json", '{"topic": "/odom", "pose": [0, 0, 0, 0, 0, 0, 1]}', '{"topic": "/robot/ranges", "ranges": [1.0, 2.0]}')
+    node.send(D.odom_line("/robot/odom", 0, (1.0, 2.0, 0.5), 0.0, 0.0, frame=""))
+    pose, odom = node.recv(), node.recv()
+    assert pose["topic"] == "/robot/pf_pose" and odom["topic"] == "/robot/pf_odom" and pose["frame_id"] == "odom"  # empty frame -> "odom" (main.rs:109-116)
+    np.testing.assert_allclose(pose["state"], [1.0, 2.0, 0.5, 0.0], atol=1e-15)
+    # a negative range is InvalidParameter (particle_filter.rs:538-549): logged, dropped, the node lives on
+    node.send(D.ranges_line("/robot/ranges", 1, [(-1.0, 2.0, 2.0)]), D.odom_line("/robot/odom", 1, (0, 0, 0), 1.0, 0.1))
+    node.send(D.ranges_line("/robot/ranges", 2, [(3.0, 2.0, 2.0)]), D.odom_line("/robot/odom", 2, (0, 0, 0), 1.0, 0.1))
+    pose, _ = node.recv(), node.recv()
+    assert pose["stamp"] == [0, 200000000] and all(math.isfinite(v) for v in pose["state"])
+    rc, err = node.close()
+    assert rc == 0
+    assert "malformed message dropped" in err and "does not subscribe" in err and "PF update failed" in err and "n x (distance" in err
