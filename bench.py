@@ -921,96 +921,164 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
     return out
 
 
-def leg_small_n(with_cpu):
-    """BASELINE.json configs[0]: the size every caller in the reference runs -- 1 000 particles x 4 landmarks (the reference's own
-    4-landmark scene, tests/unified_filter_comparison.rs:43), ParticleFilterLocalizer semantics (multinomial resample behind the
-    N_eff gate, particle_filter.rs:337-345,441-473).  One workgroup, one launch per step (k_step_small) or per batch of steps
-    (rr_pf_step_many); the literal restatement on ONE host core (the reference is single-threaded) beside it."""
-    import rust_robotics_amd.localization as loc
-    from tests import helpers as H
+SMALL_ROWS = [
+    # (key, particles, landmarks [x, y], config overrides, initial state, exact observations?, where the reference runs this size)
+    ("100x3", 100, [(5.0, 0.0), (0.0, 5.0), (5.0, 5.0)], {}, (0.0, 0.0, 0.0, 0.0), True,
+     "headless_localizers.rs:29-56: ParticleFilterConfig::default() -- 100 particles, 3 landmarks, exact ranges, try_step_state every step"),
+    ("120x5", 120, [(2.0, 2.0), (10.0, 2.0), (2.0, 8.0), (10.0, 8.0), (6.0, 5.0)], {"range_noise": 0.25}, (5.0, 5.0, 0.0, 0.0), False,
+     "rust_robotics_playground/src/localization.rs:50-66: 120 particles, 5 landmarks, range_noise 0.25"),
+    ("150x5", 150, [(2.0, 2.0), (10.0, 2.0), (2.0, 8.0), (10.0, 8.0), (6.0, 5.0)], {"range_noise": 0.25}, (5.0, 5.0, 0.0, 0.0), False,
+     "render_gif_particle_filter.rs:25-40: 150 particles, 5 landmarks, range_noise 0.25"),
+    ("1000x4", 1000, [(10.0, 0.0), (0.0, 15.0), (-5.0, 20.0), (10.0, 10.0)], {"range_noise": 0.5, "velocity_noise": 0.3, "yaw_rate_noise": math.radians(5.0)},
+     (0.0, 0.0, 0.0, 0.0), False, "BASELINE.json configs[0] / tests/unified_filter_comparison.rs:43,278-285: 1 000 particles, 4 landmarks"),
+]
 
-    n, L, K = 1000, 4, 2000
-    cfg = loc.ParticleFilterConfig(n_particles=n, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))  # unified_filter_comparison.rs:278-285
-    rng = np.random.default_rng(42)
-    obs = np.stack([H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng) for t in range(K)])
-    u = np.tile([1.0, 0.1], (K, 1))
-    out = {"config": {"workload": f"particle filter (BASELINE.json configs[0]): {n} particles x {L} landmarks, multinomial resample behind the N_eff gate",
-                      "particles": n, "landmarks": L}, "steps": K}
 
-    def fresh():
-        return loc.ParticleFilterLocalizer.with_initial_state([0.0, 0.0, 0.0, 0.0], cfg, seed=42)
+def pin_to_gpu_numa_node(device=0):
+    """The synchronous step is two trips over the host link: keep this process on the NUMA node the GPU hangs off (what
+    nodes/pf_localizer_node does at start).  Returns the cpulist it pinned to, or None."""
+    import ctypes as C
 
-    def timed(fn):
-        # best of three, each right after ~40 ms of the same work: a host-paced loop (the synchronous step) lets the device clock
-        # down, and the next measurement would start on a cold clock
-        best = None
-        for _ in range(3):
-            pf = fresh()
-            pf.step_many(np.tile(u, (3, 1)), np.tile(obs, (3, 1, 1)), estimates=False)
-            pf.synchronize()
-            t0 = time.perf_counter()
-            fn(pf)
-            pf.synchronize()
-            dt = (time.perf_counter() - t0) / K * 1e6
-            best = dt if best is None else min(best, dt)
-        return best
+    from rust_robotics_amd import _ffi
 
-    def loop(method):
-        def run(pf):
-            f = getattr(pf, method)
-            for t in range(K):
-                f(u[t], obs[t])
-        return run
-
-    out["us_per_step"] = {
-        "step_async": timed(loop("step_async")),
-        "step_async_estimate": timed(loop("step_async_estimate")),
-        "step (synchronous, returns the estimate: try_step)": timed(loop("step")),
-        "step_many (one launch, estimates read back at the end)": timed(lambda pf: pf.step_many(u, obs)),
-        "step_many (one launch, no estimates)": timed(lambda pf: pf.step_many(u, obs, estimates=False)),
-    }
-    best = out["us_per_step"]["step_many (one launch, estimates read back at the end)"]
-    out["value"] = n * L / (best * 1e-6)
-    out["unit"] = "particle-landmark updates/s"
-    out["note"] = "value = rr_pf_step_many with the per-step estimates; a single workgroup on one of 256 CUs (the work of a step does not fill more)"
-    os.environ["RR_PF_SMALL"] = "0"
     try:
-        pf = fresh()
-    finally:
-        del os.environ["RR_PF_SMALL"]
-    for t in range(200):
-        pf.step_async(u[t], obs[t])
-    pf.synchronize()
-    t0 = time.perf_counter()
-    for t in range(K):
-        pf.step_async(u[t], obs[t])
-    pf.synchronize()
-    out["us_per_step"]["step_async through the large kernels (RR_PF_SMALL=0)"] = (time.perf_counter() - t0) / K * 1e6
-    del pf
-    if with_cpu:
-        import oracle
-        from oracle import dp, u32p
+        buf = C.create_string_buffer(64)
+        if _ffi.lib().rr_device_pci_bus_id(device, buf, 64) != 0:
+            return None
+        cpulist = open(f"/sys/bus/pci/devices/{buf.value.decode()}/local_cpulist").read().strip()
+        cpus = set()
+        for part in cpulist.split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return cpulist
+    except Exception:  # noqa: BLE001 -- a measurement nicety, never a failure
+        return None
 
-        ref, det = oracle.ref(), oracle.det()
-        ref.ref_set_threads(1)
-        x, y, yaw, v = (np.zeros(n) for _ in range(4))
-        w = np.full(n, 1.0 / n)
-        idx, est = np.empty(n, np.uint32), np.empty(4)
-        z0, z1, r, r2 = (np.empty(n) for _ in range(4))
-        t_total = 0.0
+
+def leg_small_n(with_cpu):
+    """The sizes the reference's own callers run (SMALL_ROWS: 100 - 1 000 particles, 3 - 5 landmarks), ParticleFilterLocalizer
+    semantics (multinomial resample behind the N_eff gate, particle_filter.rs:337-345,441-473), through the entry point those
+    callers use -- the SYNCHRONOUS try_step -- in both of its forms: one launch of one workgroup per step (k_step_small + host
+    mailbox) and the resident service (rr_pf_set_resident: the kernel stays, steps travel through pinned memory); beside them
+    the asynchronous and the batched forms, and the literal restatement of the reference's try_step loop (cache refreshes
+    included) on ONE host core, timed inside C.  Calls go through ctypes with prebuilt argument pointers (~1 us of call overhead
+    stays in every GPU number)."""
+    import ctypes as C
+
+    import rust_robotics_amd.localization as loc
+    from rust_robotics_amd import _ffi
+
+    lib = _ffi.lib()
+    K = 2000
+    pinned = pin_to_gpu_numa_node(0)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    out = {"steps": K, "unit_rows": "microseconds per step", "host_pinned_to_cpus": pinned, "rows": {}}
+
+    for key, n, lms, over, init, exact, where in SMALL_ROWS:
+        L = len(lms)
+        cfg = loc.ParticleFilterConfig(n_particles=n, **over)
+        rng = np.random.default_rng(42)
+        truth = np.array(init[:3], dtype=np.float64)
+        obs = np.empty((K, L, 3))
         for t in range(K):
-            det.det_normal2_v(42, 3, t, 0, n, dp(z0), dp(z1))
-            det.det_uniform2_v(42, 4, t, 0, n, dp(r), dp(r2))
-            nv, nw = 0.3 * z0, math.radians(5.0) * z1
-            o = np.ascontiguousarray(obs[t])
+            truth += [math.cos(truth[2]) * 0.1, math.sin(truth[2]) * 0.1, 0.01]
+            for q, (lx, ly) in enumerate(lms):
+                d = math.hypot(truth[0] - lx, truth[1] - ly)
+                obs[t, q] = (d if exact else max(d + rng.normal(0.0, cfg.range_noise), 0.0), lx, ly)
+        u = np.tile([1.0, 0.1], (K, 1))
+        est = np.empty(4)
+
+        def fresh(resident_us=0.0):
+            pf = loc.ParticleFilterLocalizer.with_initial_state(list(init), cfg, seed=42)
+            if resident_us:
+                pf.set_resident(resident_us)
+            return pf
+
+        def best_of(make, body, reps=3):
+            """body(pf) -> microseconds per step, measured around its own loop (argument pointers are built outside it)"""
+            best = None
+            for _ in range(reps):
+                pf = make()
+                for t in range(300):  # warm: clocks, code, the resident incarnation
+                    lib.rr_pf_step(pf._h, dp(u[t]), dp(obs[t]), L, dp(est))
+                dt = body(pf)
+                best = dt if best is None else min(best, dt)
+                del pf
+            return best
+
+        def sync_loop(pf):
+            h, e = pf._h, dp(est)
+            ptrs = [(dp(u[t]), dp(obs[t])) for t in range(K)]
             t0 = time.perf_counter()
-            ref.ref_pf_step_ex(n, dp(x), dp(y), dp(yaw), dp(v), dp(w), 1.0, 0.1, 0.1, dp(nv), dp(nw), dp(o), L, 0.5, 0.5, 0, dp(r), u32p(idx), dp(est), 1)
-            t_total += time.perf_counter() - t0
+            for up, op in ptrs:
+                lib.rr_pf_step(h, up, op, L, e)
+            return (time.perf_counter() - t0) / K * 1e6
+
+        def async_loop(pf):
+            h = pf._h
+            ptrs = [(dp(u[t]), dp(obs[t])) for t in range(K)]
+            t0 = time.perf_counter()
+            for up, op in ptrs:
+                lib.rr_pf_step_async(h, up, op, L)
+            pf.synchronize()
+            return (time.perf_counter() - t0) / K * 1e6
+
+        def many_loop(pf):
+            t0 = time.perf_counter()
+            pf.step_many(u, obs)
+            return (time.perf_counter() - t0) / K * 1e6
+
+        row = {"config": where, "particles": n, "landmarks": L}
+        row["try_step, launched (one launch + mailbox per step)"] = best_of(fresh, sync_loop)
+        row["try_step, resident service"] = best_of(lambda: fresh(5000.0), sync_loop)
+        row["step_async, launched"] = best_of(fresh, async_loop)
+        row["step_many (one launch for all steps, estimates read back at the end)"] = best_of(fresh, many_loop)
+        if with_cpu:
+            import oracle
+            from oracle import dp as odp, u32p
+
+            ref, det = oracle.ref(), oracle.det()
+            ref.ref_set_threads(1)
+            x, y, yaw, v = (np.full(n, init[k]) for k in range(4))
+            w = np.full(n, 1.0 / n)
+            idx, est_k = np.empty(n, np.uint32), np.empty((K, 4))
+            nv, nw, r = np.empty((K, n)), np.empty((K, n)), np.empty((K, n))
+            z0, z1, r2 = np.empty(n), np.empty(n), np.empty(n)
+            for t in range(K):
+                det.det_normal2_v(42, 3, t, 0, n, odp(z0), odp(z1))
+                det.det_uniform2_v(42, 4, t, 0, n, odp(r[t]), odp(r2))
+                nv[t], nw[t] = cfg.velocity_noise * z0, cfg.yaw_rate_noise * z1
+            best = None
+            for _ in range(3):
+                for arr, k in ((x, 0), (y, 1), (yaw, 2), (v, 3)):
+                    arr[:] = init[k]
+                w[:] = 1.0 / n
+                sec = ref.ref_pf_try_step_loop(n, odp(x), odp(y), odp(yaw), odp(v), odp(w), odp(u), cfg.dt, odp(nv), odp(nw), odp(obs), L, cfg.range_noise,
+                                               cfg.resample_threshold, 0, odp(r), u32p(idx), K, odp(est_k), 1, 1)
+                best = sec if best is None else min(best, sec)
+            row["cpu: the reference's try_step loop, one core"] = best / K * 1e6
+        out["rows"][key] = row
+
+    head = out["rows"]["1000x4"]
+    batched = head["step_many (one launch for all steps, estimates read back at the end)"]
+    out["config"] = {"workload": "particle filter at the reference's own sizes (BASELINE.json configs[0] = row 1000x4): multinomial resample behind "
+                                 "the N_eff gate, synchronous try_step", "particles": 1000, "landmarks": 4}
+    out["value"] = 1000 * 4 / (batched * 1e-6)
+    out["unit"] = "particle-landmark updates/s"
+    out["note"] = ("value = rr_pf_step_many at 1000 x 4 with the per-step estimates (a single workgroup on one of 256 CUs: the work of a step does not "
+                   "fill more); the rows are what a caller of try_step sees per step")
+    if with_cpu:
         model, nproc = host_cpu()
-        out["cpu_baseline"] = {"value": n * L * K / t_total, "unit": "particle-landmark updates/s", "cores": 1, "kind": "port", "us_per_step": t_total / K * 1e6,
-                               "sample": f"oracle/ref_literal.c ref_pf_step, literal reference arithmetic incl. its O(N^2) linear-scan resample "
-                                         f"(particle_filter.rs:455-470) and the estimate, {n} particles x {L} landmarks x {K} steps on one core "
-                                         f"({model}), noise samples pre-drawn"}
+        cpu_us = head["cpu: the reference's try_step loop, one core"]
+        out["cpu_baseline"] = {"value": 1000 * 4 / (cpu_us * 1e-6), "unit": "particle-landmark updates/s", "cores": 1, "kind": "port", "us_per_step": cpu_us,
+                               "sample": f"oracle/ref_literal.c ref_pf_try_step_loop: try_step as the reference runs it -- predict, update, its O(N^2) linear-scan "
+                                         f"resample behind the N_eff gate (particle_filter.rs:455-470) and refresh_cache (mean + covariance) after predict, update and "
+                                         f"resample (:299,332,343) -- {K} steps per row on one core ({model}), timed inside C, noise samples pre-drawn (the reference's "
+                                         f"RNG is not in the loop: a lower bound of its cost)"}
     return out
 
 

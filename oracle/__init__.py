@@ -111,6 +111,8 @@ def ref() -> C.CDLL:
     L.ref_pf_step.restype = i
     L.ref_pf_step_ex.argtypes = [sz, P, P, P, P, P, d, d, d, P, P, P, sz, d, d, i, P, u32, P, i]
     L.ref_pf_step_ex.restype = i
+    L.ref_pf_try_step_loop.argtypes = [sz, P, P, P, P, P, P, d, P, P, P, sz, d, d, i, P, u32, sz, P, i, i]
+    L.ref_pf_try_step_loop.restype = d
     MP = C.POINTER(RefFs1Model)
     L.ref_fs1_model_default.argtypes = [MP]
     L.ref_fs1_model_default.restype = None

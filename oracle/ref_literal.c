@@ -343,6 +343,63 @@ int ref_pf_step_ex(size_t n, double* x, double* y, double* yaw, double* v, doubl
   return fired;
 }
 
+/* K calls of try_step as the reference's callers make them (headless_localizers.rs:52-66, render_gif_particle_filter.rs:56-83),
+ * timed INSIDE C with the monotonic clock: at the reference's own sizes (100 - 200 particles) a step costs ~10 us and a
+ * foreign-function call per step would be a quarter of it.  Inputs per step k: controls[2k..], nv/nw[k n ..] (the scaled
+ * normal samples), obs[k 3 n_obs ..], r_draws[k n ..].  with_cache_refresh != 0 also does what try_step really does between
+ * the stages -- refresh_cache() = compute_estimate + compute_covariance after predict (particle_filter.rs:299), after
+ * update (:332) and after a fired resample (:343); est_out (K x 4) receives the mean try_step returns (:496).  The RNG
+ * (rand::rng() + Normal::sample per particle, :259-287) is NOT in the timed loop -- the samples are pre-drawn -- so this is a
+ * lower bound of the reference's own cost.  Returns seconds. */
+#include <time.h>
+double ref_pf_try_step_loop(size_t n, double* x, double* y, double* yaw, double* v, double* w, const double* controls, double dt,
+                            const double* nv, const double* nw, const double* obs, size_t n_obs, double sigma,
+                            double resample_threshold, int scheme, const double* r_draws, uint32_t* idx_scratch, size_t K,
+                            double* est_out, int with_cache_refresh, int literal_scan) {
+  struct timespec t0, t1;
+  double est[4], cov[16];
+  volatile double sink = 0.0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (size_t k = 0; k < K; ++k) {
+    const double* o = obs + 3 * n_obs * k;
+    ref_pf_predict(n, x, y, yaw, v, controls[2 * k], controls[2 * k + 1], dt, nv + n * k, nw + n * k);
+    if (with_cache_refresh) {
+      ref_pf_estimate(n, x, y, yaw, v, w, est);
+      ref_pf_covariance(n, x, y, yaw, v, w, est, cov);
+      sink += cov[0];
+    }
+    ref_pf_update_raw(n, x, y, w, o, n_obs, sigma);
+    ref_pf_normalize(n, w);
+    if (with_cache_refresh) {
+      ref_pf_estimate(n, x, y, yaw, v, w, est);
+      ref_pf_covariance(n, x, y, yaw, v, w, est, cov);
+      sink += cov[0];
+    }
+    int fired = 0;
+    if (scheme == 1) {
+      ref_mcl_resample_indices(n, w, r_draws + n * k, idx_scratch);
+      fired = 1;
+    } else if (ref_pf_neff(n, w) < (double)n * resample_threshold) {
+      if (literal_scan) ref_pf_resample_indices(n, w, r_draws + n * k, idx_scratch);
+      else ref_pf_resample_indices_bsearch(n, w, r_draws + n * k, idx_scratch);
+      fired = 1;
+    }
+    if (fired) ref_pf_gather(n, x, y, yaw, v, w, idx_scratch);
+    if (fired || !with_cache_refresh) {
+      ref_pf_estimate(n, x, y, yaw, v, w, est);
+      if (with_cache_refresh) {
+        ref_pf_covariance(n, x, y, yaw, v, w, est, cov);
+        sink += cov[0];
+      }
+    }
+    if (est_out)
+      for (int q = 0; q < 4; ++q) est_out[4 * k + q] = est[q];
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  (void)sink;
+  return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
 /* ------------------------------------------------------------------ FastSLAM 1.0 */
 /* Particle poses px,py,pyaw and weights pw are arrays of n; the per-particle
  * maps are particle-major AoS lm[(p*L + l)*6 + {x,y,c00,c10,c01,c11}], the memory

@@ -1660,34 +1660,70 @@ struct AdaptSmallArgs {
   rr_mcl_adaptive kld;
   uint64_t max_draws;
   uint64_t hash_size;
+  rr::ResidentArgs res;  // res.on: the kernel stays and serves one step per command of the ring (resident_core.hpp)
 };
+// Resident mode (rr_pf_set_resident on an adaptive filter): the body below runs once per command; the particle set, the CDF and
+// the bin table live in HBM anyway (one workgroup: its writes are its own reads after a barrier), so an incarnation can leave
+// at any command boundary without a write-back.  While it waits it draws the NEXT step's random numbers -- the motion noise of
+// the live particles and the uniforms of all max_particles candidate draws are functions of (seed, counters, index) alone --
+// into `pre` ([cap] noise v | [cap] noise w | [cap] uniforms).
 __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl, StepParams p,
                                                                    ObsArg obs_arg, AdaptSmallArgs a, uint64_t* __restrict__ cdf,
                                                                    unsigned int* __restrict__ idx, int32_t* __restrict__ keys,
                                                                    unsigned int* __restrict__ table, unsigned int* __restrict__ minslot,
                                                                    unsigned int* __restrict__ myslot, uint64_t* __restrict__ out,
                                                                    uint64_t* __restrict__ coarse, int coarse_log2, int front_only,
-                                                                   HostMail* __restrict__ mail, uint64_t mail_seq) {
-  extern __shared__ double s_obs[];
+                                                                   HostMail* __restrict__ mail, uint64_t mail_seq,
+                                                                   rr::ResidentRing* __restrict__ ring, double* __restrict__ pre,
+                                                                   uint64_t cap) {
+  extern __shared__ double s_dyn_a[];  // [3 n_obs] observations; resident: the command's payload (u0, u1, observations)
   constexpr int W = kKldThreads / rr::kWave;
   __shared__ double s_max[W];
   __shared__ uint64_t s_t[W], s_qh[W], s_ql[W];
+  __shared__ int s_hdr[2];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int i = tid; i < 3 * p.n_obs; i += kKldThreads) s_obs[i] = obs_arg.v[i];
+  const bool resident = a.res.on != 0;
+  double* const s_obs = resident ? s_dyn_a + 2 : s_dyn_a;
+  int n_obs = p.n_obs, res_guess = 3 + 3 * p.n_obs < 64 ? 3 + 3 * p.n_obs : 64, res_last_op = rr::kResOpNone, steps_done = 0;
+  double u0 = p.u0, u1 = p.u1;
+  const uint64_t res_deadline = resident ? wall_clock64() + a.res.life_ticks : 0;
+  for (int s = 0;; ++s) {
+  const unsigned int step = p.step + (unsigned int)s, rstep = a.plan.rstep + (unsigned int)s;
   const uint64_t n = ctl->n_active;
   const int cur = ctl->cur;
-  __syncthreads();
+  if (resident) {
+    for (uint64_t i = tid; i < n; i += kKldThreads) rr_pf_motion_noise(p.seed, step, p.first_gid + i, p.sigma_v, p.sigma_w, &pre[i], &pre[cap + i]);
+    for (uint64_t m = tid; m < a.max_draws; m += kKldThreads) {
+      double dummy;
+      rr_uniform2(p.seed, RR_STREAM_RESAMPLE, rstep, m, &pre[2 * cap + m], &dummy);
+    }
+    res_last_op = rr::resident_fetch<kKldThreads>(ring, a.res.first_seq + (uint64_t)s, a.res.idle_ticks, res_deadline, a.res.payload_cap,
+                                                  res_guess, s_dyn_a, s_hdr);
+    if (res_last_op != rr::kResOpStep) break;
+    n_obs = (s_hdr[1] - 2) / 3;
+    u0 = s_dyn_a[0];
+    u1 = s_dyn_a[1];
+  } else {
+    for (int i = tid; i < 3 * n_obs; i += kKldThreads) s_obs[i] = obs_arg.v[i];
+    __syncthreads();
+  }
+  steps_done = s + 1;
   // ---- propagate + weight, in place on the live set (k_propagate_weight<true, true, false>)
   double wmax_local = 0.0;
   for (uint64_t i = tid; i < n; i += kKldThreads) {
     double x = b.x[cur][i], y = b.y[cur][i], yaw = b.yaw[cur][i], v, na, nc;
-    rr_pf_motion_noise(p.seed, p.step, p.first_gid + i, p.sigma_v, p.sigma_w, &na, &nc);
-    rr_pf_propagate_one(&x, &y, &yaw, &v, p.u0, p.u1, p.dt, na, nc);
+    if (resident) {
+      na = pre[i];
+      nc = pre[cap + i];
+    } else {
+      rr_pf_motion_noise(p.seed, step, p.first_gid + i, p.sigma_v, p.sigma_w, &na, &nc);
+    }
+    rr_pf_propagate_one(&x, &y, &yaw, &v, u0, u1, p.dt, na, nc);
     b.x[cur][i] = x;
     b.y[cur][i] = y;
     b.yaw[cur][i] = yaw;
     b.v[cur][i] = v;
-    const double wgt = p.lik_mode == RR_LIK_PRODUCT ? rr_pf_weight_product(x, y, s_obs, p.n_obs, p.lik) : rr_pf_weight_fused(x, y, s_obs, p.n_obs, p.lik);
+    const double wgt = p.lik_mode == RR_LIK_PRODUCT ? rr_pf_weight_product(x, y, s_obs, n_obs, p.lik) : rr_pf_weight_fused(x, y, s_obs, n_obs, p.lik);
     w[i] = wgt;
     if (wgt > wmax_local) wmax_local = wgt;  // NaN and negatives drop out
   }
@@ -1744,9 +1780,10 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
     ctl->wmax = wmax;
     PlanArgs pa = a.plan;
     pa.n_global = n;
+    pa.rstep = rstep;
     rr::finalize_plan(ctl, carry, 0, carry, qq, pa);  // forced, eager: Ctl.cur flips here, the weights become uniform
   }
-  if (front_only) return;  // (the draws, the table and the count follow as launches of their own)
+  if (front_only) return;  // (the draws, the table and the count follow as launches of their own; never resident)
   __syncthreads();
   // ---- the candidate draws in blocks of kKldThreads, as far as the reference's loop would go (:340-352): a block's draws and
   // bins (k_kld_draw; the lower bound over the whole CDF is the index its two-level search finds), its entries in the bin
@@ -1766,7 +1803,7 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
     const uint64_t m = base + tid;
     const bool valid = m < a.max_draws;
     if (valid) {
-      const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, m, p.seed, a.plan.rstep, nullptr, m);
+      const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, m, p.seed, rstep, resident ? pre + 2 * cap : nullptr, m);
       uint64_t j = rr_lower_bound_u64(cdf, n, target);
       if (j >= n) j = n - 1;
       idx[m] = (unsigned int)j;
@@ -1825,20 +1862,24 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
     out[0] = n_new;
     ctl->n_active = n_new;
   }
-  if (!mail) return;
+  if (mail || resident) {
   // ---- the mean try_step returns (monte_carlo_localization.rs:299-300 after :359-362: uniform weights over the new set), for
-  // the synchronous caller: formed exactly as rr_pf_estimate forms it -- k_moments' grid of ceil(n / 256) workgroups of four
-  // waves holds one particle per thread for n <= 1024, this workgroup's wave w stands for workgroup w / 4's wave w % 4, the
-  // workgroup partials are added in k_moments' order and reduced as k_moments_final does -- and left in the host mailbox.
-  // flags != 0: not formed here (more than 1024 particles, or weights that do not sum to a positive number): the long way.
+  // the synchronous caller: formed exactly as rr_pf_estimate forms it -- k_moments runs ceil(n / 256) workgroups of four waves
+  // with one particle per thread (n <= 262 144), so this workgroup's chunk c stands for workgroups 4c .. 4c + 3, its wave w for
+  // wave w % 4 of workgroup 4c + w / 4; the workgroup partials are added in k_moments' order and reduced as k_moments_final
+  // does (lane j takes partial j: at most 64 of them for the 16 384 particles this kernel serves) -- and left in the host
+  // mailbox / the resident answer.  flags != 0: weights that do not sum to a positive number: the host takes the long way.
   __shared__ double s_mom[W][5];
+  __shared__ double s_part[64][5];
   __syncthreads();  // (the gathered set is complete)
-  if (n_new <= (uint64_t)kKldThreads) {
-    const double p0[4] = {b.x[dst][0], b.y[dst][0], b.yaw[dst][0], b.v[dst][0]};
+  const int n_blocks = (int)((n_new + kBlock - 1) / kBlock);
+  const double p0[4] = {b.x[dst][0], b.y[dst][0], b.yaw[dst][0], b.v[dst][0]};
+  for (uint64_t base = 0; base < n_new; base += kKldThreads) {
+    const uint64_t i = base + tid;
     double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if ((uint64_t)tid < n_new) {
+    if (i < n_new) {
       const double wi = 1.0;
-      const double d0 = b.x[dst][tid] - p0[0], d1 = b.y[dst][tid] - p0[1], d2 = b.yaw[dst][tid] - p0[2], d3 = b.v[dst][tid] - p0[3];
+      const double d0 = b.x[dst][i] - p0[0], d1 = b.y[dst][i] - p0[1], d2 = b.yaw[dst][i] - p0[2], d3 = b.v[dst][i] - p0[3];
       acc[0] += wi;
       acc[1] += wi * d0;
       acc[2] += wi * d1;
@@ -1851,33 +1892,50 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
       if (lane == 0) s_mom[wv][k] = sw;
     }
     __syncthreads();
-    if (wv == 0) {
-      const int n_blocks = (int)((n_new + kBlock - 1) / kBlock);
-      double mom[5];
-#pragma unroll
-      for (int k = 0; k < 5; ++k) {
-        double part = 0.0;  // k_moments: the workgroup's four wave sums, in wave order
-        if (lane < n_blocks)
-          for (int q = 0; q < kBlock / rr::kWave; ++q) part += s_mom[(kBlock / rr::kWave) * lane + q][k];
-        double v = 0.0;  // k_moments_final: lane j adds the partials j, j + 64, ... (one here), then the shuffle tree
-        if (lane < n_blocks) v += part;
-        mom[k] = rr::wave_sum(v);
-      }
-      if (lane == 0) {
-        const double Wt = mom[0];
-        const bool ok = Wt > 0.0 && Wt < INFINITY;
-        for (int q = 0; q < 4; ++q)
-          __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[q]), (uint64_t)__double_as_longlong(p0[q] + mom[1 + q] / Wt), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&mail->flags, (uint64_t)(ok ? 0 : 1) | ((uint64_t)(ctl->grid_timeout != 0) << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_store(&mail->seq, mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid < 5 * (kKldThreads / kBlock)) {  // k_moments: a workgroup's four wave sums, in wave order
+      const int q = tid / 5, k = tid % 5, blk = (int)(base / kBlock) + q;
+      if (blk < n_blocks) {
+        double part = 0.0;
+        for (int r = 0; r < kBlock / rr::kWave; ++r) part += s_mom[(kBlock / rr::kWave) * q + r][k];
+        s_part[blk][k] = part;
       }
     }
-  } else if (tid == 0) {
-    __hip_atomic_store(&mail->flags, (uint64_t)4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_store(&mail->seq, mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();
+  }
+  if (wv == 0) {
+    double mom[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      double v = 0.0;  // k_moments_final: lane j adds the partials j, j + 64, ... (one here), then the shuffle tree
+      if (lane < n_blocks) v += s_part[lane][k];
+      mom[k] = rr::wave_sum(v);
+    }
+    const double Wt = mom[0];
+    const bool ok = Wt > 0.0 && Wt < INFINITY;
+    const uint64_t flags = (uint64_t)(ok ? 0 : 1) | ((uint64_t)(ctl->grid_timeout != 0) << 1);
+    if (resident) {
+      const uint64_t seq = a.res.first_seq + (uint64_t)s;
+      if (lane < 4) {
+        const double e = lane == 0 ? p0[0] + mom[1] / Wt : lane == 1 ? p0[1] + mom[2] / Wt : lane == 2 ? p0[2] + mom[3] / Wt : p0[3] + mom[4] / Wt;
+        rr::store_pair_sys(&ring->rsp[lane], (uint64_t)__double_as_longlong(e), seq);
+      }
+      if (lane == 4) rr::store_pair_sys(&ring->rsp[rr::kResRspFlags], flags, seq);
+    } else if (lane == 0) {
+      for (int q = 0; q < 4; ++q)
+        __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[q]), (uint64_t)__double_as_longlong(p0[q] + mom[1 + q] / Wt), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&mail->flags, flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(&mail->seq, mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  }
+  if (!resident) break;
+  __syncthreads();  // (Ctl.n_active, Ctl.cur and the gathered set are read by the next step)
+  }  // for (s)
+  if (resident && tid == 0) {  // EXIT marker (resident_core.hpp)
+    const uint64_t consumed = a.res.first_seq + (uint64_t)steps_done - 1 + (res_last_op == rr::kResOpQuit ? 1 : 0);
+    rr::store_pair_sys(&ring->rsp[rr::kResRspExit], consumed, a.res.launch_id);
   }
 }
 
@@ -2928,7 +2986,8 @@ static rr_status launch_small(rr_pf* h, const SmallArgs& a, const ObsArg& arg, s
   static const int forced = [] { const char* e = std::getenv("RR_PF_SMALL_BLOCK"); return e ? std::atoi(e) : 0; }();
 #define RR_SMALL_GO(B_, R_) (product ? launch_small_as<B_, R_, RR_LIK_PRODUCT>(h, a, arg, lds, est_out) : launch_small_as<B_, R_, RR_LIK_FUSED>(h, a, arg, lds, est_out))
   // the reference's own sizes (100 - 150 particles): two or four waves pay less at the step's barriers and cross-wave sums
-  // than eight mostly idle ones (RR_PF_SMALL_BLOCK=512: always 512 threads, for A/B)
+  // than eight mostly idle ones (RR_PF_SMALL_BLOCK=512: always 512 threads, for A/B; resident try_step at 100 x 3: 7.1 us against
+  // 8.4, and ONE wave with two particles per lane -- no cross-wave hand-over at all -- 8.2: the doubled dependent chain costs more)
   if (h->n <= 128 && forced != 512) return RR_SMALL_GO(128, 1);
   if (h->n <= 256 && forced != 512) return RR_SMALL_GO(256, 1);
   if (h->n <= 512) return RR_SMALL_GO(512, 1);
@@ -2942,30 +3001,57 @@ constexpr size_t kResMaxObs = 128;
 constexpr int kResPayloadCap = 2 + 3 * (int)kResMaxObs;
 static size_t resident_lds_bytes(uint64_t n) { return ((size_t)kResPayloadCap + 5 * (size_t)n + 1) * sizeof(double); }
 static bool small_path(const rr_pf* h, size_t n_obs);
+static bool adaptive_one_launch(const rr_pf* h, size_t n_obs) {  // the filters k_mcl_adaptive_small serves in one launch
+  return h->adaptive && h->adaptive_small_ok && h->kld.max_particles <= 16384 && n_obs <= (size_t)kMaxObsKernarg && !h->p2p.ready &&
+         !h->using_external_stream;
+}
 static bool resident_path(const rr_pf* h, size_t n_obs) {
-  return h->res.enabled && !h->profiling && n_obs <= kResMaxObs && small_path(h, n_obs) && resident_lds_bytes(h->n) <= 150 * 1024;
+  if (!h->res.enabled || h->profiling || n_obs > kResMaxObs) return false;
+  if (h->adaptive) return adaptive_one_launch(h, n_obs);
+  return small_path(h, n_obs) && resident_lds_bytes(h->n) <= 150 * 1024;
 }
 
 // launch an incarnation that waits for command `first_seq` (the particle set is in HBM: nothing of this handle is in flight)
 static rr_status resident_launch(rr_pf* h, uint64_t first_seq, unsigned int step0, unsigned int rstep0) {
-  rr_status s = materialise(h);
+  rr_status s = h->adaptive ? RR_OK : materialise(h);  // (an adaptive filter never has a lazy resample pending)
   if (s != RR_OK) return s;
   if (!h->res.ring) {
     RR_HIP_TRY(hipHostMalloc(&h->res.ring, sizeof(rr::ResidentRing), hipHostMallocDefault));
     std::memset(h->res.ring, 0, sizeof(rr::ResidentRing));
   }
-  SmallArgs a{};
-  small_args_common(h, &a, /*n_obs hint=*/4, /*K=*/0, /*want_est=*/true);
-  a.step0 = step0;
-  a.rstep0 = rstep0;
-  a.res.on = 1;
-  a.res.payload_cap = kResPayloadCap;
-  a.res.first_seq = first_seq;
-  a.res.idle_ticks = (uint64_t)(h->res.idle_us * 100.0);
-  a.res.life_ticks = (uint64_t)(h->res.life_us * 100.0);
-  a.res.launch_id = ++h->res.launch_id;
+  rr::ResidentArgs ra{};
+  ra.on = 1;
+  ra.payload_cap = kResPayloadCap;
+  ra.first_seq = first_seq;
+  ra.idle_ticks = (uint64_t)(h->res.idle_us * 100.0);
+  ra.life_ticks = (uint64_t)(h->res.life_us * 100.0);
+  ra.launch_id = ++h->res.launch_id;
   ObsArg arg;
-  if ((s = launch_small(h, a, arg, resident_lds_bytes(h->n), nullptr)) != RR_OK) return s;
+  if (h->adaptive) {  // k_mcl_adaptive_small, resident: the particle count stays on the device (Ctl.n_active)
+    if ((s = ensure_scratch(h, 5 * h->cap, 0)) != RR_OK) return s;  // [cap] noise v | [cap] noise w | [cap] uniforms
+    const double u[2] = {0.0, 0.0};
+    StepParams p = make_params(h, u, /*n_obs hint=*/4);
+    p.step = step0;
+    AdaptSmallArgs a{};
+    a.img = image_args(h);
+    a.plan = plan_args(h, /*mode=*/1, RR_RESAMPLE_MULTINOMIAL, NAN);
+    a.plan.rstep = rstep0;
+    a.kld = h->kld;
+    a.max_draws = h->kld.max_particles;
+    a.hash_size = h->kld_hash_size;
+    a.res = ra;
+    hipLaunchKernelGGL(k_mcl_adaptive_small, dim3(1), dim3(kKldThreads), (size_t)kResPayloadCap * sizeof(double), h->stream, h->b, h->w, h->ctl,
+                       p, arg, a, h->cdf, h->idx, h->kld_keys, h->kld_table, h->kld_minslot, h->kld_myslot, h->kld_out, h->cdf_coarse,
+                       h->coarse_log2, 0, (HostMail*)nullptr, (uint64_t)0, h->res.ring, h->scratch_a, h->cap);
+    RR_HIP_TRY(hipGetLastError());
+  } else {
+    SmallArgs a{};
+    small_args_common(h, &a, /*n_obs hint=*/4, /*K=*/0, /*want_est=*/true);
+    a.step0 = step0;
+    a.rstep0 = rstep0;
+    a.res = ra;
+    if ((s = launch_small(h, a, arg, resident_lds_bytes(h->n), nullptr)) != RR_OK) return s;
+  }
   h->res.live = true;
   h->res.launches += 1;
   h->maybe_pending = false;
@@ -2982,9 +3068,21 @@ static rr_status resident_await(rr_pf* h, uint64_t seq, double out[4]) {
     uint64_t e[4];
     if (rr::ring_take(&r.ring->rsp[3], seq, &e[3]) && rr::ring_take(&r.ring->rsp[2], seq, &e[2]) && rr::ring_take(&r.ring->rsp[1], seq, &e[1]) &&
         rr::ring_take(&r.ring->rsp[0], seq, &e[0])) {
+      r.pending = false;
+      if (h->adaptive) {  // (the adaptive kernel vouches for its estimate: flags != 0 => form it the long way)
+        uint64_t flags = 0;
+        while (!rr::ring_take(&r.ring->rsp[rr::kResRspFlags], seq, &flags)) {
+        }
+        if (flags != 0) {
+          if (!out) return RR_OK;
+          rr_status s = bind(h);  // parks the kernel, refreshes the host's particle count
+          if (s != RR_OK) return s;
+          if ((s = materialise(h)) != RR_OK) return s;
+          return compute_moments(h, out, nullptr);
+        }
+      }
       if (out)
         for (int k = 0; k < 4; ++k) std::memcpy(&out[k], &e[k], sizeof(double));
-      r.pending = false;
       return RR_OK;
     }
     uint64_t consumed = 0;
@@ -3031,6 +3129,7 @@ static rr_status resident_step(rr_pf* h, const double control[2], const double* 
   h->rstep += 1;
   h->wmax_live = false;
   h->wmax_bits_clean = true;
+  if (h->adaptive) h->n_dirty = true;  // the new particle count lives on the device (Ctl.n_active, kld_out)
   r.steps += 1;
   r.pending = true;
   if (!out) return RR_OK;
@@ -3371,7 +3470,7 @@ static rr_status step_adaptive_small(rr_pf* h, const StepParams& p, const ObsArg
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
     hipLaunchKernelGGL(k_mcl_adaptive_small, dim3(1), dim3(kKldThreads), lds, h->stream, h->b, h->w, h->ctl, p, arg, a, h->cdf, h->idx,
                        h->kld_keys, h->kld_table, h->kld_minslot, h->kld_myslot, h->kld_out, h->cdf_coarse, h->coarse_log2, front_only,
-                       mail, want);
+                       mail, want, (rr::ResidentRing*)nullptr, (double*)nullptr, h->cap);
   }
   if (front_only) {
     Timed t(h, RR_K_RESAMPLE_GATHER);
@@ -3461,7 +3560,7 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
 
 rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
   if (h && resident_path(h, n_obs)) {
-    rr_status s = bind(h, false, /*keep_resident=*/true);
+    rr_status s = bind(h, /*keep_lazy=*/h->adaptive, /*keep_resident=*/true);
     if (s != RR_OK) return s;
     if ((s = validate_control(control)) != RR_OK) return s;
     if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
@@ -3576,7 +3675,7 @@ rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_
   if (h && out_state && resident_path(h, n_obs)) {
     // try_step of a small filter with the resident service switched on: no launch, no completion signal -- the command goes
     // into pinned memory, the answer comes back the same way (resident_core.hpp)
-    rr_status s = bind(h, false, /*keep_resident=*/true);
+    rr_status s = bind(h, /*keep_lazy=*/h->adaptive, /*keep_resident=*/true);
     if (s != RR_OK) return s;
     if ((s = validate_control(control)) != RR_OK) return s;
     if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;

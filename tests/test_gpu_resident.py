@@ -133,3 +133,37 @@ def test_invalid_inputs_leave_the_service_untouched():
     b = make(loc, 100, 0, True)
     b.step(u[0], obs[0])
     assert np.array_equal(bits(a.step(u[1], obs[1])), bits(b.step(u[1], obs[1])))
+
+
+@pytest.mark.parametrize("lo,hi,sig", [(100, 5000, 0.2), (100, 5000, 3.0), (60, 800, 0.2), (1500, 4000, 0.2)])
+def test_resident_adaptive_mcl_equals_launched_steps(lo, hi, sig):
+    """The MonteCarloLocalizer with the KLD-adaptive particle count (monte_carlo_localization.rs:322-385) through the resident
+    service: k_mcl_adaptive_small stays on the device, the particle count never visits the host between steps, the next step's
+    motion noise and candidate-draw uniforms are drawn while it waits.  Same estimates, counts and particles as launched steps."""
+    import rust_robotics_amd.localization as loc
+
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=lo, max_particles=hi, range_noise=sig)
+    a = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=31)
+    b = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=31)
+    a.set_resident(5000.0)
+    lms = [(10.0, 0.0), (0.0, 15.0), (-5.0, 20.0), (10.0, 10.0)]
+    truth = np.zeros(3)
+    counts = []
+    for t in range(60):
+        truth += [math.cos(truth[2]) * 0.1, math.sin(truth[2]) * 0.1, 0.01]
+        obs = [(math.hypot(truth[0] - lx, truth[1] - ly), lx, ly) for lx, ly in lms]
+        if t % 4 == 3:
+            a.step_async([1.0, 0.1], obs)
+            b.step_async([1.0, 0.1], obs)
+        else:
+            ea, eb = np.asarray(a.try_step([1.0, 0.1], obs)), np.asarray(b.try_step([1.0, 0.1], obs))
+            assert np.array_equal(bits(ea), bits(eb)), f"step {t}: {ea} vs {eb}"
+        if t % 17 == 16:
+            counts.append(a.particle_count())
+            assert counts[-1] == b.particle_count()
+            assert np.array_equal(bits(a.get_particles_array()), bits(b.get_particles_array())), f"particles differ at step {t}"
+    launches, steps = a.resident_stats()
+    assert steps == 60 and launches <= 8, (launches, steps)
+    assert a.particle_count() == b.particle_count() and lo <= a.particle_count() <= hi
+    assert np.array_equal(bits(a.get_particles_array()), bits(b.get_particles_array()))
+    np.testing.assert_array_equal(a.estimate(), b.estimate())
