@@ -190,7 +190,7 @@ def make_scene(L, steps, seed):
 # CPU baselines: oracle/ref_literal.c (the reference's arithmetic restated line by line) timed on this
 # box's host cores.  SURVEY.md 8d: per-particle stages under OpenMP on all cores, cumsum / resample walk
 # serial as in the reference; the reference's own O(N^2) multinomial resample timed separately at N = 1e4.
-def cpu_baseline(n, L, obs_list, max_seconds=12.0, scheme="systematic"):
+def cpu_baseline(n, L, obs_list, max_seconds=12.0, scheme="systematic", brief=False):
     """`value` = the literal restatement running the SAME step as the GPU leg it stands beside: the MCL step with the
     reference's systematic walk (fastslam1.rs:205-234) for the systematic legs, with its multinomial draws
     (monte_carlo_localization.rs:322-365, binary search) for the multinomial leg; the other variant is reported next to it."""
@@ -234,6 +234,11 @@ def cpu_baseline(n, L, obs_list, max_seconds=12.0, scheme="systematic"):
     main_id, other_id = (2, 1) if scheme == "systematic" else (1, 2)
     names = {1: "multinomial draws + binary search (monte_carlo_localization.rs:322-365,387-392)", 2: "systematic walk (fastslam1.rs:205-234)"}
     v_all, cores, s_all, t_all = run(threads, n, max_seconds, False, main_id)
+    if brief:  # the extra legs: the like-for-like number only (the variants are in the headline legs of the same line)
+        return dict(value=v_all, unit="particle-landmark updates/s", cores=cores, kind="port",
+                    sample=f"oracle/ref_literal.c ref_pf_step (literal reference arithmetic; predict / weight / gather under OpenMP on {cores} threads, "
+                           f"cumsum + resample -- {names[main_id]} -- serial), {n} particles x {L} landmarks x {s_all} steps, {t_all:.1f} s, noise samples pre-drawn",
+                    host={"cpu_model": model, "nproc": nproc, "threads": cores})
     v_one, _, s_one, t_one = run(1, n, max_seconds / 2, False, main_id)
     v_oth, _, s_oth, t_oth = run(threads, n, max_seconds / 3, False, other_id)
     # the reference's own resample: a linear scan of the cumulative weights per draw (particle_filter.rs:455-470),
@@ -753,7 +758,8 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
     world = ctx.world
     # time only moves forward for every filter: W warm-up + K timed + K estimate-every-step + K dispatch-stamped + K breakdown
     # steps; the sharded legs also validate (12 steps) and warm up 64 steps longer
-    D = 0 if ctx.sharded else DEVICE_WARMUP_MCL  # (the sharded legs warm up EXTRA_WARMUP steps + settle blocks inside bench_sharded)
+    # (the sharded legs warm up EXTRA_WARMUP steps + settle blocks inside bench_sharded; ~50 ms of work is what the device needs)
+    D = 0 if ctx.sharded else (DEVICE_WARMUP_MCL if n <= 2_000_000 else 60)
     obs_list = make_scene(L, D + W + 4 * K + (EXTRA_WARMUP if ctx.sharded else 0), seed=1)
     scheme = 1 if args.scheme == "systematic" else 0
     lik = 0 if args.likelihood == "fused" else 1
@@ -779,7 +785,7 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
         # step is the one that produces it: rr_pf_step_async_estimate -- the mean of the resampled set accumulated inside the
         # step's own plan kernel and kept on the device (one synchronisation at the end of the K steps).  The multinomial
         # scheme has no in-step estimate: its step is the plain asynchronous one (the line says which).
-        with_est = args.scheme == "systematic"
+        with_est = args.scheme == "systematic" and n <= 8_388_608  # (the in-step estimate's limit, rr_pf.h)
         step_fn = pf.step_async_estimate if with_est else pf.step_async
         for t in range(D):  # device warm-up (see DEVICE_WARMUP_MCL), then time moves on
             step_fn(u, obs_list[t])
@@ -798,7 +804,9 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
         pf.synchronize()
         dt = time.perf_counter() - t0
         extra["headline_step"] = ("rr_pf_step_async_estimate: propagate + weight + resample + the mean try_step returns, every step"
-                                  if with_est else "rr_pf_step_async: propagate + weight + resample (no per-step estimate in the multinomial scheme)")
+                                  if with_est else ("rr_pf_step_async: propagate + weight + resample (no per-step estimate in the multinomial scheme)"
+                                                    if args.scheme != "systematic" else
+                                                    "rr_pf_step_async: propagate + weight + resample (the in-step estimate serves up to 8 388 608 particles)"))
         if with_est:
             extra["last_step_estimate"] = [float(a) for a in pf.last_step_estimate()]
         est = pf.estimate()
@@ -860,7 +868,8 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
     k1_bytes = K1_BYTES[args.scheme] if not ctx.sharded else 64.0
     achieved = k1_bytes * n / k1_avg_s if k1_avg_s > 0 else 0.0
     step_kernel_ms = {k: (v[1] / max(v[0], 1)) for k, v in kern.items() if v[0]}
-    traffic, traffic_src = measured_traffic("k_step_lazy", "mcl") if k1_bytes == 72.0 and n == 1_000_000 else (None, None)
+    traffic, traffic_src = measured_traffic("k_step_lazy", getattr(args, "traffic_key", "mcl" if (n, L, args.scheme) == (1_000_000, 32, "systematic") else
+                                                                   f"mcl_{n}x{L}_{args.scheme}"))
     # FP64-VALU side of the same kernel: f64-rate lane-instructions per particle (a per-pair count
     # times L plus a per-particle count, both read off the ISA and checked against SQ_INSTS_VALU) over the kernel time
     pair_i, part_i = mcl_instruction_budget()
@@ -889,7 +898,12 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
                          f"contiguous particle blocks over {world} GPUs; transport {res.get('transport')} ({res.get('transport_note')})"),
         },
         "roofline": {
-            "bound": "hbm",
+            # the binding resource of THIS kernel at THIS L: the FP64 vector pipe once its fraction of the issue peak exceeds the
+            # HBM fraction (L >= ~16), HBM below that.  achieved / peak / frac stay the HBM figures the contract asks for;
+            # binding_frac is the fraction of the binding resource's peak
+            "bound": "fp64_valu" if valu_rate / FP64_VALU_PEAK > achieved / HBM_PEAK else "hbm",
+            "binding_frac": max(valu_rate / FP64_VALU_PEAK, achieved / HBM_PEAK),
+            "hbm_frac": achieved / HBM_PEAK,
             "kernel": "k_step_lazy (propagate + weight + folded resample gather)" if k1_bytes == 72.0 else "k_propagate_weight",
             "achieved": achieved / 1e9,
             "peak": HBM_PEAK / 1e9,
@@ -904,18 +918,23 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
             "algorithmic_bytes_per_launch": k1_bytes * n,
             "fp64_valu": {"lane_instr_per_pair": pair_i, "lane_instr_per_particle": part_i, "achieved_lane_instr_per_s": valu_rate,
                           "peak_lane_instr_per_s": FP64_VALU_PEAK, "frac": valu_rate / FP64_VALU_PEAK},
-            "note": "this kernel is FP64-VALU bound at L >= 32 (fp64_valu.frac is its binding fraction; the working set of ~90 MB is "
-                    "Infinity-Cache resident, so `traffic` is fabric traffic, not DRAM traffic); the HBM-bound workload is the "
-                    "`fastslam` leg of this line (DESIGN.md section 4)",
+            "note": ("FP64-VALU bound at L >= ~16 (fp64_valu.frac is the binding fraction).  " +
+                     ("The working set (~90 B/particle) of 1e6 particles is Infinity-Cache resident, so `traffic` is fabric traffic, not DRAM traffic; "
+                      if n <= 2_000_000 else "At this size the working set is several times the 256 MB Infinity Cache: `achieved` is a DRAM rate; ") +
+                     "the HBM-bound workload of this line is the `fastslam` leg; profiles/r04_mcl_L_sweep.json shows where MCL turns from HBM- to VALU-bound"),
         },
         "kernel_ms_avg": step_kernel_ms,
-        "device_warmup_steps": (EXTRA_WARMUP if ctx.sharded else DEVICE_WARMUP_MCL),
+        "device_warmup_steps": (EXTRA_WARMUP if ctx.sharded else D),
         "ms_per_step_instrumented": res.get("seconds_instrumented", 0.0) / K * 1e3,
         "estimate": res.get("estimate"),
     }
     out.update(extra)
     if with_cpu:
-        out["cpu_baseline"] = cpu_baseline(n, L, obs_list, max_seconds=getattr(args, "cpu_seconds", 12.0), scheme=args.scheme)
+        n_cpu = getattr(args, "cpu_particles", None) or n
+        out["cpu_baseline"] = cpu_baseline(n_cpu, L, obs_list, max_seconds=getattr(args, "cpu_seconds", 12.0), scheme=args.scheme,
+                                           brief=getattr(args, "cpu_brief", False))
+        if n_cpu != n:
+            out["cpu_baseline"]["sample"] += f" -- a BOUNDED SAMPLE: {n_cpu} of the leg's {n} particles (the per-particle work and the serial scan both scale linearly)"
     if ctx.sharded:
         out["sharded"] = {k: res.get(k) for k in ("transport", "transport_note", "p2p_timed_out", "migrated_particles_last_step")}
     return out
@@ -1082,14 +1101,33 @@ def leg_small_n(with_cpu):
     return out
 
 
-def leg_sharded_world1(args, n, L, K, W):
+def leg_fastslam_sharded_world1(n, L):
+    """BASELINE.json configs[3] per-GPU shape (125 000 particles x 200 landmarks) through the sharded FastSLAM update with ONE
+    rank, in a process of its own like the MCL world-1 legs."""
+    log("extra leg fastslam_sharded_world1")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR")}
+    env["MASTER_PORT"] = str(free_port())
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-sharded", "--workload", "fastslam", "--particles", str(n), "--landmarks", str(L),
+           "--no-cpu-baseline"]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            raise RuntimeError(f"rc {r.returncode}: {r.stderr[-400:]}")
+        d = json.loads(lines[-1])
+        return {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernel_ms_avg", "obs_chunks") if k in d}
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"}
+
+
+def leg_sharded_world1(args, n, L, K, W, transports=(("p2p", "p2p-only"), ("rccl", "rccl")), what=None):
     """The sharded MCL step with ONE rank, once per transport: the peer-to-peer transport (validated against the unsharded
     filter first, as in the multi-GPU run) and the native RCCL transport (a one-rank communicator: RCCL really called).
     Each in a process of its own (`bench.py --force-sharded --transport ...`): the sharded legs need torch.distributed, and
     torch's bundled HIP runtime has to be the first one a process loads."""
     out = {}
-    for name, transport in (("p2p", "p2p-only"), ("rccl", "rccl")):
-        log(f"extra leg sharded_world1 / {name}")
+    for name, transport in transports:
+        log(f"extra leg sharded_world1 / {name} ({n} x {L})")
         env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR")}
         env["MASTER_PORT"] = str(free_port())
         cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-sharded", "--transport", transport, "--no-extra-legs",
@@ -1101,9 +1139,11 @@ def leg_sharded_world1(args, n, L, K, W):
                 raise RuntimeError(f"rc {r.returncode}: {r.stderr[-400:]}")
             d = json.loads(lines[-1])
             out[name] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "sharding": d["config"]["sharding"],
-                         "kernel_ms_avg": d.get("kernel_ms_avg"), "steps": d["steps"], "warmup": d["warmup"]}
+                         "kernel_ms_avg": d.get("kernel_ms_avg"), "steps": d["steps"], "warmup": d["warmup"], "roofline": d.get("roofline")}
         except Exception as e:  # noqa: BLE001
             out[name] = {"error": f"{type(e).__name__}: {e}"}
+    if what:
+        out["workload"] = what
     out["note"] = ("world size 1 on this GPU: every exchange talks to itself, so this is the per-rank cost of the sharded step before any "
                    "cross-device latency (weak-scaling ceiling at 8 GPUs = 8 x plain_async_step / this)")
     return out
@@ -1244,10 +1284,34 @@ def main():
                 out["small_n"] = leg_small_n(with_cpu)
             except Exception as e:  # noqa: BLE001
                 out["small_n"] = {"error": f"{type(e).__name__}: {e}"}
+            # FastSLAM 2.0 at the configs[2] shape
+            try:
+                log("extra leg fastslam2")
+                leg = leg_fastslam(args, 100_000, 200, 50, 5, v2=True, with_cpu=with_cpu, breakdown=not args.no_breakdown)
+                out["fastslam2"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernel_ms_avg", "obs_chunks",
+                                                        "device_warmup_steps", "cpu_baseline") if k in leg}
+            except Exception as e:  # noqa: BLE001
+                out["fastslam2"] = {"error": f"{type(e).__name__}: {e}"}
+            # configs[4] at FULL size on this one GPU (1.6e7 x 64: 1.15 GB per launch, several times the Infinity Cache -- the
+            # MCL measurement that is a DRAM measurement), then its per-GPU shape and configs[3]'s through the sharded step at world size 1
+            try:
+                log("extra leg mcl_config5_full (configs[4] unsharded)")
+                import copy
+
+                a5 = copy.copy(args)
+                a5.cpu_seconds, a5.cpu_particles, a5.cpu_brief = 5.0, 2_000_000, True
+                leg = leg_mcl(a5, ctx, 16_000_000, 64, 20, 3, with_cpu, breakdown=False, label="configs[4], all 1.6e7 particles on ONE GPU")
+                out["mcl_config5_full"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernel_ms_avg",
+                                                               "headline_step", "plain_async_step", "cpu_baseline", "device_warmup_steps") if k in leg}
+            except Exception as e:  # noqa: BLE001
+                out["mcl_config5_full"] = {"error": f"{type(e).__name__}: {e}"}
             # the sharded step at world size 1, both transports: what a rank of the 8-GPU run pays before any cross-device latency
             # (weak-scaling ceiling = 8 x unsharded step / this)
             if not args.no_sharded_world1:
                 out["sharded_world1"] = leg_sharded_world1(args, n, L, K, W)
+                out["sharded_world1_config5_shape"] = leg_sharded_world1(args, 2_000_000, 64, K, W, transports=(("p2p", "p2p-only"),),
+                                                                         what="BASELINE.json configs[4] per-GPU shape: 2e6 particles x 64 landmarks")
+                out["fastslam_sharded_world1_config4_shape"] = leg_fastslam_sharded_world1(125_000, 200)
         elif ctx.world == 8 or args.all_legs:
             per_gpu = 1_000_000 // 8 if ctx.world == 8 else 125_000
             # the extra legs never take the headline down with them: an exception becomes an "error" entry
