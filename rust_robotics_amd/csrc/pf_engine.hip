@@ -310,15 +310,52 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
         idx[r] = k < p.n ? markers[k] : 0u;  // `markers` is the lidx array here
       }
     } else if (pending && SRC == kSrcDraw) {
+      // the rows' searches in LOCKSTEP: every dependent read of the chain (guide pair -> CDF probes -> source record) is issued
+      // for all rows before any of them is waited for.  (mn_guide_search per row: the bracket loop's trip count depends on the
+      // data, so the second row's chain only started when the first row's had ended.)
+      const uint64_t total = ctl->total;
+      const int gs = rr::guide_shift(total, wa.guide_log2);
+      uint64_t target[rr::kResolveRows], lo[rr::kResolveRows], hi[rr::kResolveRows];
 #pragma unroll
       for (int r = 0; r < rr::kResolveRows; ++r) {
         const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
-        idx[r] = 0u;
+        target[r] = k < p.n ? rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, p.first_gid + k, p.seed, wa.rstep, nullptr, k) : 0ull;
+      }
+#pragma unroll
+      for (int r = 0; r < rr::kResolveRows; ++r) {
+        const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
+        lo[r] = hi[r] = 0;
         if (k < p.n) {
-          const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, p.first_gid + k, p.seed, wa.rstep, nullptr, k);
-          idx[r] = (unsigned int)mn_guide_search(ctl, wa.cdf, wa.guide, wa.guide_log2, target, wa.n_src);
-          if (idx_out) idx_out[k] = idx[r];
+          const uint64_t bucket = target[r] >> gs;
+          const GuidePair g = *reinterpret_cast<const GuidePair*>(wa.guide + bucket);
+          lo[r] = g.lo;
+          hi[r] = bucket < (total >> gs) ? (uint64_t)g.hi : wa.n_src - 1;  // the last bucket ends with the last source
         }
+      }
+      for (;;) {
+        bool open = false;
+#pragma unroll
+        for (int r = 0; r < rr::kResolveRows; ++r) open |= lo[r] < hi[r];
+        if (!__any(open)) break;
+        uint64_t c[rr::kResolveRows], mid[rr::kResolveRows];
+#pragma unroll
+        for (int r = 0; r < rr::kResolveRows; ++r) {
+          mid[r] = lo[r] + ((hi[r] - lo[r]) >> 1);
+          c[r] = lo[r] < hi[r] ? wa.cdf[mid[r]] : 0ull;
+        }
+#pragma unroll
+        for (int r = 0; r < rr::kResolveRows; ++r) {
+          if (lo[r] < hi[r]) {
+            if (c[r] >= target[r]) hi[r] = mid[r];
+            else lo[r] = mid[r] + 1;
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < rr::kResolveRows; ++r) {
+        const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
+        idx[r] = (unsigned int)lo[r];
+        if (k < p.n && idx_out) idx_out[k] = idx[r];
       }
     } else if (pending && SRC == kSrcWindow) {
       const uint64_t own0 = p.first_gid + wa.pad;  // position of own slot 0: a multiple of kResolveSlots
