@@ -760,7 +760,7 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
     # steps; the sharded legs also validate (12 steps) and warm up 64 steps longer
     # (the sharded legs warm up EXTRA_WARMUP steps + settle blocks inside bench_sharded; ~50 ms of work is what the device needs)
     D = 0 if ctx.sharded else (DEVICE_WARMUP_MCL if n <= 2_000_000 else 60)
-    obs_list = make_scene(L, D + W + 4 * K + (EXTRA_WARMUP if ctx.sharded else 0), seed=1)
+    obs_list = make_scene(L, D + W + 5 * K + 8 + (EXTRA_WARMUP if ctx.sharded else 0), seed=1)
     scheme = 1 if args.scheme == "systematic" else 0
     lik = 0 if args.likelihood == "fused" else 1
     extra = {}
@@ -845,6 +845,18 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
             dt_instr = time.perf_counter() - t1
             prof = pf.profile_read()
         pf.profile_enable(0)
+        # the SYNCHRONOUS try_step (rr_pf_step: the estimate comes back to the host every step -- what the reference's callers do,
+        # particle_filter.rs:488-497 / monte_carlo_localization.rs:291-300), over the same K steps' worth of inputs, outside `value`
+        if n <= 4_000_000:
+            for t in range(5):
+                pf.step(u, obs_list[W + 4 * K + t])
+            t1 = time.perf_counter()
+            for t in range(K):
+                pf.step(u, obs_list[W + 4 * K + 5 + t])
+            t_sync = (time.perf_counter() - t1) / K
+            extra["synchronous_try_step"] = {"ms_per_step": t_sync * 1e3, "value": float(n) * L / t_sync,
+                                             "note": "rr_pf_step: one host round trip per step, the mean of the resampled set returned every step" +
+                                                     ("" if with_est else " (multinomial: the pending draws are searched, gathered and averaged by extra launches)")}
         if with_cpu and n <= 4_000_000:  # (checker use of the oracle: part of the cpu_baseline leg)
             pf2 = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=ctx.local_rank,
                                                              resample_scheme=scheme, likelihood_mode=lik, record_indices=True)
@@ -1276,7 +1288,7 @@ def main():
                 a2.cpu_seconds = 6.0
                 leg = leg_mcl(a2, ctx, n, L, K, W, with_cpu, breakdown=not args.no_breakdown)
                 out["mcl_multinomial"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernel_ms_avg",
-                                                              "headline_step", "index_parity", "cpu_baseline", "device_warmup_steps") if k in leg}
+                                                              "headline_step", "synchronous_try_step", "index_parity", "cpu_baseline", "device_warmup_steps") if k in leg}
             except Exception as e:  # noqa: BLE001
                 out["mcl_multinomial"] = {"error": f"{type(e).__name__}: {e}"}
             try:
