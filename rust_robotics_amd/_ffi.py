@@ -229,6 +229,8 @@ def lib() -> C.CDLL:
     proto("rr_fs1_update_async", st, [H, P, P, sz])
     proto("rr_fs1_synchronize", st, [H])
     proto("rr_fs1_best_particle", st, [H, P, P, C.POINTER(u64)])
+    proto("rr_fs1_set_resident", st, [H, d])
+    proto("rr_fs1_resident_stats", st, [H, C.POINTER(u64), C.POINTER(u64)])
     proto("rr_fs1_get_landmarks", st, [H, u64, P])
     proto("rr_fs1_get_poses", st, [H, P])
     proto("rr_fs1_get_state", st, [H, P, P])

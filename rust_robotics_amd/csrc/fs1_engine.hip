@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -33,6 +34,7 @@
 #include "p2p_core.hpp"
 #include "rccl_core.hpp"
 #include "resample_core.hpp"
+#include "resident_core.hpp"
 #include "rr_common.hpp"
 #include "rr_fastslam1.h"
 #include "rr_fastslam2.h"
@@ -746,6 +748,210 @@ __global__ void k_fs1_stamp(const Ctl* __restrict__ ctl, BestMail* __restrict__ 
   rr::st_sys_u64(&mail->seq, seq);
 }
 
+// ------------------------------------------------------------------------------------------
+// RESIDENT update of a small particle set (rr_fs1_set_resident; resident_core.hpp): fastslam_update (fastslam1.rs:237-266)
+// followed by get_best_particle (:269-274) -- the loop every FastSLAM caller in the reference runs, at its sizes (100
+// particles x 8 landmarks: render_gif_slam.rs:166-200) -- for ONE workgroup that stays on the device and takes one update per
+// command of the ring: (u0, u1, chunk length, n_z x (distance, angle, landmark id)).  The general path spends three
+// launches on an update and a fourth on the best particle (19 + 17 us for a few microseconds of work); here a thread owns a
+// particle, the poses, weights and maps stay where they are (HBM / L2: one workgroup reads its own writes after a barrier),
+// and the resample gather is EAGER, so an incarnation can leave at any command boundary with nothing pending.
+// Same per-element arithmetic (rr_fs1_predict_one, rr_fs1_update_one), the weight as the left-to-right product of the
+// observation chunks' factors (choose_chunks' plan, handed over by the host), the same integer image, gate, systematic plan
+// and tie rule: bit-identical to the launched path (tests/test_gpu_fs1_resident.py).
+struct Fs1SmallArgs {
+  uint64_t n, L, n_global, gid0;
+  uint64_t seed;
+  unsigned int step0, rstep0;
+  rr_fs1_model m;
+  PlanArgs plan;  // mode 0, N_eff gate against NTH, systematic, eager gather
+  rr::ResidentArgs res;
+};
+constexpr int kFs1ResMaxObs = 64;
+constexpr int kFs1ResPayload = 3 + 3 * kFs1ResMaxObs;
+constexpr int kFs1RspIndex = 6;  // rsp[0..2] pose, [3] weight, [4] flags, [5] EXIT marker, [6] index of the best particle
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_fs1_small(Planes pl, double* __restrict__ pw, Ctl* __restrict__ ctl, Fs1SmallArgs a,
+                                                    unsigned int* __restrict__ idx_out, rr::ResidentRing* __restrict__ ring) {
+  constexpr int W = BLOCK / rr::kWave;
+  __shared__ double s_pay[kFs1ResPayload + 1];
+  __shared__ int s_hdr[2];
+  __shared__ double s_red[W];
+  __shared__ uint64_t s_u[3 * W];
+  __shared__ uint64_t s_bb[W], s_bi[W];
+  __shared__ unsigned int s_mx[W];
+  __shared__ unsigned int s_mark[BLOCK + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const uint64_t n = a.n, p = (uint64_t)tid;
+  const bool mine = p < n;
+  int res_guess = 28, res_last_op = rr::kResOpNone, steps_done = 0;
+  const uint64_t deadline = wall_clock64() + a.res.life_ticks;
+  for (int s = 0;; ++s) {
+    // ---- the update's motion noise does not depend on the command: drawn before the wait
+    double na = 0.0, nb = 0.0;
+    if (mine) rr_fs1_motion_noise(a.seed, a.step0 + (unsigned int)s, a.gid0 + p, &na, &nb);
+    double rho, rho_dummy;
+    rr_uniform2(a.plan.seed, RR_STREAM_RESAMPLE, a.rstep0 + (unsigned int)s, 0, &rho, &rho_dummy);
+    res_last_op = rr::resident_fetch<BLOCK>(ring, a.res.first_seq + (uint64_t)s, a.res.idle_ticks, deadline, kFs1ResPayload, res_guess, s_pay, s_hdr);
+    if (res_last_op != rr::kResOpStep) break;
+    steps_done = s + 1;
+    const int n_z = (s_hdr[1] - 3) / 3;
+    const double u0 = s_pay[0], u1 = s_pay[1];
+    const int chunk_len = (int)s_pay[2];
+    const double* s_z = s_pay + 3;
+    const int cur = ctl->cur;
+    double* __restrict__ live = pl.s[cur];
+    // ---- predict_particle (fastslam1.rs:123-137)
+    double px = 0.0, py = 0.0, pyaw = 0.0, w = 0.0;
+    if (mine) {
+      px = live[p];
+      py = live[n + p];
+      pyaw = live[2 * n + p];
+      rr_fs1_predict_one(&px, &py, &pyaw, u0, u1, na, nb, a.m);
+      live[p] = px;
+      live[n + p] = py;
+      live[2 * n + p] = pyaw;
+      // ---- update_landmark per observation (:140-183); the weight: chunk factors multiplied left to right (k_fs1_observe)
+      double total_w = pw[p];  // (no observation: the weight stays as it is)
+      for (int k0 = 0, c = 0; k0 < n_z; k0 += chunk_len, ++c) {
+        double acc = c == 0 ? total_w : 1.0;
+        const int k1 = k0 + chunk_len < n_z ? k0 + chunk_len : n_z;
+        for (int k = k0; k < k1; ++k) {
+          double* io = live + (3 + (uint64_t)s_z[3 * k + 2] * 6) * n + p;
+          double e[6];
+#pragma unroll
+          for (int f = 0; f < 6; ++f) e[f] = io[f * n];
+          acc *= rr_fs1_update_one(px, py, pyaw, s_z[3 * k], s_z[3 * k + 1], e, a.m);
+#pragma unroll
+          for (int f = 0; f < 6; ++f) io[f * n] = e[f];
+        }
+        total_w = c == 0 ? acc : total_w * acc;
+      }
+      w = total_w;
+    }
+    // ---- maximum, integer image, sums (k_quantize_plan_mark<true>'s phase A)
+    double wl = w > 0.0 ? w : 0.0;
+    wl = rr::wave_max(wl);
+    __syncthreads();
+    if (lane == 0) s_red[wv] = wl;
+    __syncthreads();
+    double wmax = s_red[0];
+#pragma unroll
+    for (int k = 1; k < W; ++k) wmax = s_red[k] > wmax ? s_red[k] : wmax;
+    const bool usable = wmax > 0.0 && wmax < INFINITY;
+    const int mode = usable ? (int)rr::kImageWeights : (int)rr::kImageLast;
+    const int shift = usable ? rr_fix_shift(wmax, a.n_global) : 0;
+    const uint64_t q = !mine ? 0ull : (mode == rr::kImageWeights ? rr_fix_quantize(w, shift) : (a.gid0 + p == a.n_global - 1 ? 1ull : 0ull));
+    rr::u128 q2;
+    rr_mul64wide(q, q, &q2.hi, &q2.lo);
+    const uint64_t incl = rr::wave_scan_u64(q, lane);
+    q2 = rr::wave_sum_u128(q2);
+    __syncthreads();
+    if (lane == 63) s_u[wv] = incl;
+    if (lane == 0) {
+      s_u[W + wv] = q2.hi;
+      s_u[2 * W + wv] = q2.lo;
+    }
+    __syncthreads();
+    uint64_t off = incl - q, total = 0;
+    rr::u128 qq = {0, 0};
+#pragma unroll
+    for (int k = 0; k < W; ++k) {
+      if (k < wv) off += s_u[k];
+      total += s_u[k];
+      qq = rr::add128(qq, rr::u128{s_u[W + k], s_u[2 * W + k]});
+    }
+    rr::TileSums ts;
+    ts.pre = 0;
+    ts.tot = total;
+    ts.q2 = qq;
+    PlanArgs pa = a.plan;
+    pa.rstep = a.rstep0 + (unsigned int)s;
+    const int fire = rr::gate_decision(mode, ts, pa);
+    if (tid == 0) {  // what the plan kernel's first workgroup leaves in Ctl
+      ctl->usable = usable ? 1 : 0;
+      ctl->image_mode = mode;
+      ctl->shift = shift;
+      ctl->wmax = wmax;
+      rr::finalize_plan(ctl, total, 0, total, qq, pa);  // eager: Ctl.cur flips here when the gate fires
+    }
+    int cur_now = cur;
+    if (!fire) {  // fastslam1.rs:196-203: w /= sum iff the sum is positive (all-zero weights stay untouched)
+      if (mode == rr::kImageWeights) w = w / rr_fix_total_to_double(total, shift);
+      if (mine) pw[p] = w;
+    } else {  // fastslam1.rs:205-234: systematic walk -> slot-run markers -> running maximum, then every plane moves
+      const rr_sys_plan plan = rr_sys_plan_make(rho, total, a.n_global);
+      const rr_sys_inv inv = rr_sys_inv_make(plan, total);
+      __syncthreads();
+      for (uint64_t k = tid; k <= n; k += BLOCK) s_mark[k] = 0;
+      __syncthreads();
+      if (mine && q != 0) {
+        const uint64_t h0 = rr_sys_slots_upto(plan, inv, total, off), h1 = rr_sys_slots_upto(plan, inv, total, off + q);
+        if (h1 > h0) s_mark[h0] = (unsigned int)(p + 1);
+      }
+      __syncthreads();
+      const unsigned int mk = mine ? s_mark[p] : 0u;
+      const unsigned int mincl = rr::wave_scan_max_u32(mk);
+      if (lane == 63) s_mx[wv] = mincl;
+      __syncthreads();
+      unsigned int pre = 0;
+#pragma unroll
+      for (int k = 0; k < W; ++k)
+        if (k < wv) pre = s_mx[k] > pre ? s_mx[k] : pre;
+      const unsigned int src_i = (mincl > pre ? mincl : pre) - 1u;
+      double* __restrict__ dst = pl.s[cur ^ 1];
+      if (mine) {
+        const uint64_t planes = 3 + 6 * a.L;
+        for (uint64_t f = 0; f < planes; ++f) dst[f * n + p] = live[f * n + src_i];
+        w = 1.0 / (double)a.n_global;
+        pw[p] = w;
+        if (idx_out) idx_out[p] = src_i;
+      }
+      cur_now = cur ^ 1;
+    }
+    // ---- get_best_particle (fastslam1.rs:269-274): arg max of the weight, ties -> the highest index
+    uint64_t bb = mine && w > 0.0 ? rr_d2u(w) : 0ull, bi = mine ? p : 0ull;
+    auto better = [](uint64_t ob, uint64_t oi, uint64_t b0, uint64_t i0) { return ob > b0 || (ob == b0 && oi > i0); };
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const uint64_t ob = rr::shfl_xor_u64(bb, o), oi = rr::shfl_xor_u64(bi, o);
+      if (better(ob, oi, bb, bi)) {
+        bb = ob;
+        bi = oi;
+      }
+    }
+    __syncthreads();  // (the gathered planes are complete, s_mark is free)
+    if (lane == 0) {
+      s_bb[wv] = bb;
+      s_bi[wv] = bi;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int k = 1; k < W; ++k)
+        if (better(s_bb[k], s_bi[k], bb, bi)) {
+          bb = s_bb[k];
+          bi = s_bi[k];
+        }
+      const double* __restrict__ now = pl.s[cur_now];
+      const uint64_t seq = a.res.first_seq + (uint64_t)s;
+      ctl->best_bits = bb;
+      ctl->best_index = bi;
+      rr::store_pair_sys(&ring->rsp[0], rr_d2u(now[bi]), seq);
+      rr::store_pair_sys(&ring->rsp[1], rr_d2u(now[n + bi]), seq);
+      rr::store_pair_sys(&ring->rsp[2], rr_d2u(now[2 * n + bi]), seq);
+      rr::store_pair_sys(&ring->rsp[3], rr_d2u(pw[bi]), seq);
+      rr::store_pair_sys(&ring->rsp[rr::kResRspFlags], 0ull, seq);
+      rr::store_pair_sys(&ring->rsp[kFs1RspIndex], bi, seq);
+    }
+    __syncthreads();  // (Ctl.cur and the weights are read by the next command)
+  }
+  if (tid == 0) {  // EXIT marker: the last command consumed (a quit counts), stamped with the launch id
+    const uint64_t consumed = a.res.first_seq + (uint64_t)steps_done - 1 + (res_last_op == rr::kResOpQuit ? 1 : 0);
+    rr::store_pair_sys(&ring->rsp[rr::kResRspExit], consumed, a.res.launch_id);
+  }
+}
+
 // host layouts <-> planes.  tmp holds the AoS image on the device.
 __global__ __launch_bounds__(kBlock) void k_fs1_init(Planes pl, double* __restrict__ pw, uint64_t n, uint64_t L,
                                                     double w0, double cov0) {
@@ -862,6 +1068,18 @@ struct rr_fs1 {
   unsigned int* plane_list = nullptr;  // device: planes of the landmarks a lazy observe leaves untouched
   std::vector<unsigned int> plane_list_host;
   rr::Profiler prof{RR_FK_COUNT};
+  // resident service (k_fs1_small; rr_fs1_set_resident)
+  struct Resident {
+    bool enabled = false, live = false, pending = false;
+    rr::ResidentRing* ring = nullptr;
+    uint64_t seq = 0, launch_id = 0;
+    double idle_us = 0.0, life_us = 100000.0;
+    uint64_t launches = 0, steps = 0;
+    unsigned int cmd_step = 0, cmd_rstep = 0;
+    bool have_best = false;  // the answer to the last command is the best particle of the CURRENT set
+    double best_pose[3] = {0, 0, 0}, best_weight = 0.0;
+    uint64_t best_index = 0;
+  } res;
 };
 
 namespace {
@@ -872,9 +1090,20 @@ const char* kFkNames[RR_FK_COUNT] = {"k_fs1_predict", "k_fs1_observe", "k_fs1_co
 
 inline unsigned grid_for(uint64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
-rr_status bind(rr_fs1* h) {
+rr_status fs1_resident_park(rr_fs1* h);
+
+// keep_resident: the caller talks to the handle's resident update kernel; everybody else finds the stream idle (the kernel is
+// asked to leave first) and the cached best particle forgotten
+rr_status bind(rr_fs1* h, bool keep_resident = false) {
   if (!h) return fail(RR_INVALID_PARAMETER, "null handle");
   RR_HIP_TRY(hipSetDevice(h->opt.device));
+  if (!keep_resident) {
+    if (h->res.live || h->res.pending) {
+      rr_status ps = fs1_resident_park(h);
+      if (ps != RR_OK) return ps;
+    }
+    h->res.have_best = false;
+  }
   return RR_OK;
 }
 
@@ -1441,7 +1670,9 @@ rr_status rr_fs1_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs1
 void rr_fs1_destroy(rr_fs1* h) {
   if (!h) return;
   (void)hipSetDevice(h->opt.device);
+  if (h->res.live || h->res.pending) (void)fs1_resident_park(h);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->res.ring) (void)hipHostFree(h->res.ring);
   h->p2p.teardown();
   (void)hipFree(h->own_inbox);
   (void)hipFree(h->slab);
@@ -1581,7 +1812,159 @@ rr_status rr_fs1_resample_systematic(rr_fs1* h, double rho) {
   return launch_finish(h);
 }
 
+// ---- resident service: the host side (the protocol is resident_core.hpp's; the PF engine's twin is in pf_engine.hip)
+static bool fs1_resident_path(const rr_fs1* h, size_t n_z) {
+  static const bool target_waves_env = std::getenv("RR_FS1_TARGET_WAVES") != nullptr;  // (a tuning override of the chunk plan: launched path only)
+  return h->res.enabled && h->algorithm == 1 && h->n == h->n_global && !h->pl.inbox && !h->p2p.ready && h->n <= 1024 &&
+         n_z <= (size_t)kFs1ResMaxObs && !h->prof.on && !target_waves_env;
+}
+
+static rr_status fs1_resident_launch(rr_fs1* h, uint64_t first_seq, unsigned int step0, unsigned int rstep0) {
+  rr_status s = materialise(h);  // nothing pending, Ctl.cur settled: the kernel gathers eagerly from here on
+  if (s != RR_OK) return s;
+  if (!h->res.ring) {
+    RR_HIP_TRY(hipHostMalloc(&h->res.ring, sizeof(rr::ResidentRing), hipHostMallocDefault));
+    std::memset(h->res.ring, 0, sizeof(rr::ResidentRing));
+  }
+  Fs1SmallArgs a{};
+  a.n = h->n;
+  a.L = h->L;
+  a.n_global = h->n_global;
+  a.gid0 = h->gid0;
+  a.seed = h->opt.seed;
+  a.step0 = step0;
+  a.rstep0 = rstep0;
+  a.m = model_of(h);
+  a.plan = plan_args(h, 0, NAN, /*lazy=*/false);
+  a.res.on = 1;
+  a.res.payload_cap = kFs1ResPayload;
+  a.res.first_seq = first_seq;
+  a.res.idle_ticks = (uint64_t)(h->res.idle_us * 100.0);
+  a.res.life_ticks = (uint64_t)(h->res.life_us * 100.0);
+  a.res.launch_id = ++h->res.launch_id;
+  unsigned int* idx_out = h->idx;  // (rr_fs1_last_resample_indices reads it)
+  if (h->n <= 128) hipLaunchKernelGGL(k_fs1_small<128>, dim3(1), dim3(128), 0, h->stream, h->pl, h->pw, h->ctl, a, idx_out, h->res.ring);
+  else if (h->n <= 256) hipLaunchKernelGGL(k_fs1_small<256>, dim3(1), dim3(256), 0, h->stream, h->pl, h->pw, h->ctl, a, idx_out, h->res.ring);
+  else if (h->n <= 512) hipLaunchKernelGGL(k_fs1_small<512>, dim3(1), dim3(512), 0, h->stream, h->pl, h->pw, h->ctl, a, idx_out, h->res.ring);
+  else hipLaunchKernelGGL(k_fs1_small<1024>, dim3(1), dim3(1024), 0, h->stream, h->pl, h->pw, h->ctl, a, idx_out, h->res.ring);
+  RR_HIP_TRY(hipGetLastError());
+  h->res.live = true;
+  h->res.launches += 1;
+  h->wmax_live = false;
+  h->wmax_bits_clean = true;  // (finalize_plan zeroes the accumulator after every update)
+  return RR_OK;
+}
+
+static rr_status fs1_resident_await(rr_fs1* h, uint64_t seq) {
+  rr_fs1::Resident& r = h->res;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (unsigned spins = 0;; ++spins) {
+    uint64_t e[5], flags;
+    if (rr::ring_take(&r.ring->rsp[kFs1RspIndex], seq, &e[4]) && rr::ring_take(&r.ring->rsp[rr::kResRspFlags], seq, &flags) &&
+        rr::ring_take(&r.ring->rsp[3], seq, &e[3]) && rr::ring_take(&r.ring->rsp[2], seq, &e[2]) && rr::ring_take(&r.ring->rsp[1], seq, &e[1]) &&
+        rr::ring_take(&r.ring->rsp[0], seq, &e[0])) {
+      for (int k = 0; k < 3; ++k) std::memcpy(&r.best_pose[k], &e[k], sizeof(double));
+      std::memcpy(&r.best_weight, &e[3], sizeof(double));
+      r.best_index = e[4];
+      r.have_best = true;
+      r.pending = false;
+      return RR_OK;
+    }
+    uint64_t consumed = 0;
+    if (r.live && rr::ring_take(&r.ring->rsp[rr::kResRspExit], r.launch_id, &consumed)) {
+      r.live = false;  // this incarnation has left (idle / end of life); a command it did not take waits for the next one
+      if (consumed < seq) {
+        rr_status s = fs1_resident_launch(h, seq, r.cmd_step, r.cmd_rstep);
+        if (s != RR_OK) return s;
+      }
+      continue;
+    }
+    if ((spins & 1023u) == 1023u && std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > 2000) {
+      (void)hipStreamSynchronize(h->stream);
+      r.live = false;
+      r.pending = false;
+      return fail(RR_RUNTIME_ERROR, "the resident FastSLAM kernel did not answer");
+    }
+  }
+}
+
+// one update through the resident kernel; wait: for the answer (the best particle of the updated set)
+static rr_status fs1_resident_update(rr_fs1* h, const double u[2], const double* z, size_t n_z, bool dup, bool wait) {
+  rr_fs1::Resident& r = h->res;
+  rr_status s;
+  if (r.pending && (s = fs1_resident_await(h, r.seq)) != RR_OK) return s;  // one command in flight
+  if (!r.ring || !r.live) {
+    if ((s = fs1_resident_launch(h, r.seq + 1, h->step, h->rstep)) != RR_OK) return s;
+  }
+  const uint64_t seq = ++r.seq;
+  r.cmd_step = h->step;
+  r.cmd_rstep = h->rstep;
+  r.have_best = false;
+  const int chunks = n_z ? choose_chunks(h, n_z, dup) : 1;
+  const int len = n_z ? (int)((n_z + chunks - 1) / chunks) : 1;
+  h->last_chunks = chunks;
+  auto bits_of = [](double v) {
+    uint64_t q;
+    std::memcpy(&q, &v, sizeof q);
+    return q;
+  };
+  rr::MailPair* c = r.ring->cmd;
+  for (size_t i = 0; i < 3 * n_z; ++i) rr::ring_put(&c[4 + i], bits_of(z[i]), seq);
+  rr::ring_put(&c[3], bits_of((double)len), seq);
+  rr::ring_put(&c[2], bits_of(u[1]), seq);
+  rr::ring_put(&c[1], bits_of(u[0]), seq);
+  rr::ring_put(&c[0], (uint64_t)rr::kResOpStep | ((uint64_t)(3 + 3 * n_z) << 8), seq);
+  h->step += 1;
+  h->rstep += 1;
+  h->z_staged = false;
+  r.steps += 1;
+  r.pending = true;
+  return wait ? fs1_resident_await(h, seq) : RR_OK;
+}
+
+namespace {
+rr_status fs1_resident_park(rr_fs1* h) {
+  rr_fs1::Resident& r = h->res;
+  rr_status s = RR_OK;
+  if (r.pending) s = fs1_resident_await(h, r.seq);
+  if (r.live) {
+    rr::ring_put(&r.ring->cmd[0], (uint64_t)rr::kResOpQuit, ++r.seq);
+    RR_HIP_TRY(hipStreamSynchronize(h->stream));
+    r.live = false;
+  }
+  return s;
+}
+}  // namespace
+
+// The resident service of a small FastSLAM 1.0 filter (<= 1024 particles, <= 64 observations per update): idle_us > 0 switches
+// it on -- rr_fs1_update / rr_fs1_update_async then talk to ONE kernel that stays on the device and answers every update with
+// the best particle of the updated set (rr_fs1_best_particle right after it costs nothing); 0 switches it off.
+rr_status rr_fs1_set_resident(rr_fs1* h, double idle_us) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!(idle_us >= 0.0) || !(idle_us <= 1e7)) return fail(RR_INVALID_PARAMETER, "resident idle time must lie in [0, 1e7] microseconds");
+  h->res.enabled = idle_us > 0.0;
+  h->res.idle_us = idle_us;
+  h->res.life_us = std::max(100000.0, 20.0 * idle_us);
+  return RR_OK;
+}
+
+rr_status rr_fs1_resident_stats(const rr_fs1* h, uint64_t* launches, uint64_t* updates) {
+  if (!h) return fail(RR_INVALID_PARAMETER, "null handle");
+  if (launches) *launches = h->res.launches;
+  if (updates) *updates = h->res.steps;
+  return RR_OK;
+}
+
 rr_status rr_fs1_update_async(rr_fs1* h, const double u[2], const double* z, size_t n_z) {
+  if (h && fs1_resident_path(h, n_z)) {
+    rr_status rs = bind(h, /*keep_resident=*/true);
+    if (rs != RR_OK) return rs;
+    if ((rs = validate_u(u)) != RR_OK) return rs;
+    bool rdup;
+    if ((rs = validate_z(h, z, n_z, &rdup)) != RR_OK) return rs;
+    return fs1_resident_update(h, u, z, n_z, rdup, /*wait=*/false);
+  }
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if ((s = validate_u(u)) != RR_OK) return s;
@@ -1615,12 +1998,32 @@ rr_status rr_fs1_synchronize(rr_fs1* h) {
 }
 
 rr_status rr_fs1_update(rr_fs1* h, const double u[2], const double* z, size_t n_z) {
+  if (h && fs1_resident_path(h, n_z)) {
+    rr_status rs = bind(h, /*keep_resident=*/true);
+    if (rs != RR_OK) return rs;
+    if ((rs = validate_u(u)) != RR_OK) return rs;
+    bool rdup;
+    if ((rs = validate_z(h, z, n_z, &rdup)) != RR_OK) return rs;
+    return fs1_resident_update(h, u, z, n_z, rdup, /*wait=*/true);
+  }
   rr_status s = rr_fs1_update_async(h, u, z, n_z);
   if (s != RR_OK) return s;
   return rr_fs1_synchronize(h);
 }
 
 rr_status rr_fs1_best_particle(rr_fs1* h, double out_pose[3], double* out_weight, uint64_t* out_index) {
+  if (h && (h->res.live || h->res.pending || h->res.have_best)) {
+    // right after a resident update: its answer IS the best particle of the current set (fastslam1.rs:269-274)
+    rr_status rs = bind(h, /*keep_resident=*/true);
+    if (rs != RR_OK) return rs;
+    if (h->res.pending && (rs = fs1_resident_await(h, h->res.seq)) != RR_OK) return rs;
+    if (h->res.have_best) {
+      if (out_pose) std::memcpy(out_pose, h->res.best_pose, sizeof(double) * 3);
+      if (out_weight) *out_weight = h->res.best_weight;
+      if (out_index) *out_index = h->res.best_index;
+      return RR_OK;
+    }
+  }
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   // one GPU: a pending resample stays pending (the pose is read through idx), so the next update keeps its three launches;

@@ -123,6 +123,17 @@ class FastSlam1:
     def synchronize(self) -> None:
         _check(self._L.rr_fs1_synchronize(self._h))
 
+    def set_resident(self, idle_us: float) -> None:
+        """Resident service (``rr_fs1_set_resident``, engine extension): with ``idle_us > 0`` the updates of a FastSLAM 1.0 filter
+        of up to 1024 particles are served by ONE kernel that stays on the device and answers each of them with the best
+        particle (``best_particle()`` right after an update is then free); 0 switches it off."""
+        _check(self._L.rr_fs1_set_resident(self._h, float(idle_us)))
+
+    def resident_stats(self) -> Tuple[int, int]:
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        _check(self._L.rr_fs1_resident_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def best_particle(self) -> Tuple[np.ndarray, float, int]:
         pose = np.empty(3)
         w = C.c_double()
