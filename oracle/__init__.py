@@ -22,7 +22,7 @@ from functools import lru_cache
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_BUILD = os.path.join(_HERE, "_build")
+_BUILD = os.environ.get("RR_ORACLE_DIR") or os.path.join(_HERE, "_build")  # RR_ORACLE_DIR: the sanitizer build (make -C oracle asan)
 
 c_double_p = C.POINTER(C.c_double)
 c_u32_p = C.POINTER(C.c_uint32)

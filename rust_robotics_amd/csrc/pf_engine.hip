@@ -1691,6 +1691,7 @@ __global__ __launch_bounds__(kKldThreads) void k_kld_count(unsigned int* __restr
 // (k_kld_count) and the gather -- six launches of a few microseconds of work each otherwise (36 us a step).  Same
 // per-element arithmetic, same integer sums, same draws: bit-identical to the six kernels (tests/test_gpu_kld_adaptive.py runs
 // both routes).  The particle count comes from Ctl.n_active and goes back there.
+constexpr int kAdaptLdsCdf = 4096;
 struct AdaptSmallArgs {
   ImageArgs img;
   PlanArgs plan;
@@ -1718,12 +1719,19 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
   __shared__ double s_max[W];
   __shared__ uint64_t s_t[W], s_qh[W], s_ql[W];
   __shared__ int s_hdr[2];
+  __shared__ uint64_t s_cdf[kAdaptLdsCdf];  // the CDF of a set of up to 4096 particles, for the draws' binary searches
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const bool resident = a.res.on != 0;
   double* const s_obs = resident ? s_dyn_a + 2 : s_dyn_a;
   int n_obs = p.n_obs, res_guess = 3 + 3 * p.n_obs < 64 ? 3 + 3 * p.n_obs : 64, res_last_op = rr::kResOpNone, steps_done = 0;
   double u0 = p.u0, u1 = p.u1;
   const uint64_t res_deadline = resident ? wall_clock64() + a.res.life_ticks : 0;
+#if defined(RR_PLAN_TIMELINE)
+  uint64_t atl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RR_ATL(K_) do { __syncthreads(); if (resident && threadIdx.x == 0) { uint64_t t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); atl[(K_)] = t_; } } while (0)
+#else
+#define RR_ATL(K_) do { } while (0)
+#endif
   for (int s = 0;; ++s) {
   const unsigned int step = p.step + (unsigned int)s, rstep = a.plan.rstep + (unsigned int)s;
   const uint64_t n = ctl->n_active;
@@ -1734,6 +1742,7 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
       double dummy;
       rr_uniform2(p.seed, RR_STREAM_RESAMPLE, rstep, m, &pre[2 * cap + m], &dummy);
     }
+    RR_ATL(0);
     res_last_op = rr::resident_fetch<kKldThreads>(ring, a.res.first_seq + (uint64_t)s, a.res.idle_ticks, res_deadline, a.res.payload_cap,
                                                   res_guess, s_dyn_a, s_hdr);
     if (res_last_op != rr::kResOpStep) break;
@@ -1745,6 +1754,7 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
     __syncthreads();
   }
   steps_done = s + 1;
+  RR_ATL(1);
   // ---- propagate + weight, in place on the live set (k_propagate_weight<true, true, false>)
   double wmax_local = 0.0;
   for (uint64_t i = tid; i < n; i += kKldThreads) {
@@ -1771,6 +1781,7 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
   __syncthreads();
   double wmax = s_max[0];
   for (int k = 1; k < W; ++k) wmax = s_max[k] > wmax ? s_max[k] : wmax;
+  RR_ATL(2);
   // ---- integer image (quantize_reduce_tile; the weights have just been set, so Ctl.weights_uniform does not apply)
   const bool usable = wmax > 0.0 && wmax < INFINITY;
   const int mode = usable ? (int)rr::kImageWeights : a.img.degenerate;
@@ -1795,6 +1806,7 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
     }
     if (i < n) {
       cdf[i] = off + incl;
+      if (n <= (uint64_t)kAdaptLdsCdf) s_cdf[i] = off + incl;  // the draws below search this copy: ~9 dependent reads each
       // (store_cdf: every 2^coarse_log2-th entry and the last one -- the table k_kld_draw stages in LDS)
       if ((((i + 1) & ((1ull << coarse_log2) - 1)) == 0) || i == n - 1) coarse[i >> coarse_log2] = off + incl;
     }
@@ -1822,6 +1834,7 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
   }
   if (front_only) return;  // (the draws, the table and the count follow as launches of their own; never resident)
   __syncthreads();
+  RR_ATL(3);
   // ---- the candidate draws in blocks of kKldThreads, as far as the reference's loop would go (:340-352): a block's draws and
   // bins (k_kld_draw; the lower bound over the whole CDF is the index its two-level search finds), its entries in the bin
   // table (k_kld_insert), then the stop rule over the block (k_kld_count: occupied-bin count after every draw, running
@@ -1841,7 +1854,7 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
     const bool valid = m < a.max_draws;
     if (valid) {
       const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, m, p.seed, rstep, resident ? pre + 2 * cap : nullptr, m);
-      uint64_t j = rr_lower_bound_u64(cdf, n, target);
+      uint64_t j = n <= (uint64_t)kAdaptLdsCdf ? rr_lower_bound_u64(s_cdf, n, target) : rr_lower_bound_u64(cdf, n, target);
       if (j >= n) j = n - 1;
       idx[m] = (unsigned int)j;
       int32_t xb, yb, ab;
@@ -1887,6 +1900,7 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
   }
   const uint64_t n_new = s_stop == ~0ull ? a.max_draws : s_stop + 1;  // :342: at most max_particles
   __syncthreads();
+  RR_ATL(4);
   // the table slots the draws of this step have used go back to empty for the next one (every occupied slot is some draw's)
   for (uint64_t m = tid; m < seen; m += kKldThreads) {
     const unsigned int sl = myslot[m];
@@ -1899,6 +1913,7 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
     out[0] = n_new;
     ctl->n_active = n_new;
   }
+  RR_ATL(5);
   if (mail || resident) {
   // ---- the mean try_step returns (monte_carlo_localization.rs:299-300 after :359-362: uniform weights over the new set), for
   // the synchronous caller: formed exactly as rr_pf_estimate forms it -- k_moments runs ceil(n / 256) workgroups of four waves
@@ -1957,6 +1972,13 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
         rr::store_pair_sys(&ring->rsp[lane], (uint64_t)__double_as_longlong(e), seq);
       }
       if (lane == 4) rr::store_pair_sys(&ring->rsp[rr::kResRspFlags], flags, seq);
+#if defined(RR_PLAN_TIMELINE)
+      if (lane == 0) {
+        { uint64_t t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); atl[6] = t_; }
+        atl[7] = n_new;
+        for (int k = 0; k < 8; ++k) rr::store_pair_sys(&ring->rsp[8 + k], atl[k], seq);
+      }
+#endif
     } else if (lane == 0) {
       for (int q = 0; q < 4; ++q)
         __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[q]), (uint64_t)__double_as_longlong(p0[q] + mom[1 + q] / Wt), __ATOMIC_RELAXED,

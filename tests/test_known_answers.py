@@ -134,8 +134,8 @@ def test_KA6_multinomial(ref, det):
 def test_KA6_default_index_quirks(ref):
     """Q7: PF falls back to index 0, MCL forces the last cum to 1.0 / falls back to last."""
     w = np.array([0.25, 0.25, 0.25, 0.2499999])  # cumsum ends below 1
-    r = np.array([0.99999999])
-    idx = np.empty(1, np.uint32)
+    r = np.full(4, 0.99999999)  # (one draw per output: n of them -- found by `make -C oracle asan`, the test used to pass one)
+    idx = np.empty(4, np.uint32)
     ref.ref_pf_resample_indices(4, dp(w), dp(r), u32p(idx))
     assert idx[0] == 0
     ref.ref_pf_resample_indices_bsearch(4, dp(w), dp(r), u32p(idx))

@@ -60,5 +60,39 @@ def run(n, L, scheme=0, gated=True, steps=4000):
     return res
 
 
+APHASES = ["wait for the command (host turnaround + link)", "propagate + weight + maximum", "integer image, CDF, plan", "draws, bin table, stop rule",
+           "table wipe + gather", "estimate + answer issued"]
+
+
+def run_adaptive(lo, hi, steps=3000):
+    lib = _ffi.lib()
+    lib.rr_pf_debug_resident_timeline.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    lib.rr_pf_debug_resident_timeline.restype = C.c_int
+    mcl = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], loc.MonteCarloLocalizationConfig(min_particles=lo, max_particles=hi), seed=5)
+    mcl.set_resident(5000.0)
+    lms4 = [(10.0, 0.0), (0.0, 15.0), (-5.0, 20.0), (10.0, 10.0)]
+    truth = np.zeros(3)
+    u, out = np.array([1.0, 0.1]), np.empty(4)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    tl = (C.c_uint64 * 8)()
+    rows = []
+    for i in range(steps + 200):
+        truth += [math.cos(truth[2]) * 0.1, math.sin(truth[2]) * 0.1, 0.01]
+        obs = np.ascontiguousarray([(math.hypot(truth[0] - lx, truth[1] - ly), lx, ly) for lx, ly in lms4])
+        lib.rr_pf_step(mcl._h, dp(u), dp(obs), 4, dp(out))
+        lib.rr_pf_debug_resident_timeline(mcl._h, tl)
+        if i >= 200:
+            rows.append(list(tl))
+    a = np.array(rows, dtype=np.float64)
+    d = np.diff(a[:, :7], axis=1) / 100.0
+    res = {"adaptive": [lo, hi], "particles_mean": round(float(a[:, 7].mean()), 1)}
+    res["phases_us"] = {ph: round(float(d[:, k].mean()), 2) for k, ph in enumerate(APHASES)}
+    res["device total after the command"] = round(float(d[:, 1:].sum(axis=1).mean()), 2)
+    return res
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "adaptive":
+        print(json.dumps([run_adaptive(100, 5000), run_adaptive(100, 1000)], indent=1))
+        sys.exit(0)
     print(json.dumps([run(100, 3), run(1000, 4), run(1000, 4, scheme=1, gated=False), run(2048, 4)], indent=1))
