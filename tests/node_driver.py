@@ -105,6 +105,14 @@ class NodeProcess:
                 self.sock.shutdown(socket.SHUT_WR)
         except OSError:
             pass
+        if self.sock is not None:  # what the node still says on its way out (the closing statistics line) comes through the socket
+            try:
+                for line in self.rfile:
+                    m = json.loads(line)
+                    if "log" in m:
+                        self.logs.append(m)
+            except (OSError, ValueError):
+                pass
         rc = self.proc.wait(timeout=timeout)
         err = self.proc.stderr.read().decode()
         if self.sock is not None:

@@ -28,6 +28,7 @@ def test_node_publishes_the_in_process_estimates(tmp_path, transport, resident_u
     states, lat, msgs = D.run_scenario(node)
     rc, err = node.close()
     assert rc == 0, err
+    log_text = err if transport == "stdio" else "\n".join(m["text"] for m in node.logs) + err
     want = in_process_states(D.STEPS)
     # the first message initialises the filter at the odometry pose and is published as is (main.rs:220-256)
     assert list(states[0]) == list(D.INITIAL)
@@ -44,7 +45,6 @@ def test_node_publishes_the_in_process_estimates(tmp_path, transport, resident_u
     # the filter tracks (the demo's point), and the periodic log line carries the step latency
     _, _, truth = D.scenario()
     assert np.hypot(*(got[-1, :2] - truth[-1, :2])) < 1.0
-    log_text = err if transport == "stdio" else "\n".join(m["text"] for m in node.logs) + err
     assert "pf localizer started" in log_text and "step latency mean=" in log_text and "initialized filtered pose x=5.00 y=5.00" in log_text
     print(f"node round trip per message pair ({transport}, resident {resident_us} us): median {np.median(lat):.1f} us, p99 {np.percentile(lat, 99):.1f} us")
 
