@@ -482,7 +482,7 @@ def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True):
     avg_s = k_ms / max(k_n, 1) * 1e-3
     per_launch = FS1_BYTES_PER_UPDATE * n * np.mean([len(zs[t]) for t in range(W, W + K)])
     achieved = per_launch / avg_s if avg_s > 0 else 0.0
-    traffic, traffic_src = measured_traffic("k_fs1_observe", "fs1") if (n, L) == (100_000, 200) and not v2 else (None, None)
+    traffic, traffic_src = measured_traffic("k_fs1_observe", "fs2" if v2 else "fs1") if (n, L) == (100_000, 200) else (None, None)
     out = {
         "metric": "particle-landmark updates/sec", "value": updates / dt, "unit": "particle-landmark updates/s", "n_gpus": 1,
         "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -28,13 +28,24 @@ run mn_trace --kernel-trace --stats -- $MCL --scheme multinomial
 python tools/summarize_rocprof.py stats "$(find_csv mn_trace kernel_trace)" > "$OUT/${TAG}_mcl_1e6x32_multinomial_kernel_stats.csv"
 [ -n "${ONLY_TRACE:-}" ] && exit 0  # kernel timings only (the PMC passes take several minutes)
 
-for wl in mcl fs1; do
-  cmd=$MCL; [ $wl = fs1 ] && cmd=$FS1
-  run ${wl}_fetch --kernel-trace --pmc FETCH_SIZE -- $cmd --steps 40 --warmup 5
-  run ${wl}_write --kernel-trace --pmc WRITE_SIZE -- $cmd --steps 40 --warmup 5
+# workload keys are the ones bench.py's measured_traffic() looks up
+FS2="python $REPO/bench.py --workload fastslam2 --no-cpu-baseline --no-breakdown"
+MCL5="$MCL --particles 16000000 --landmarks 64"
+for wl in mcl fs1 fs2 mcl_1000000x32_multinomial mcl_16000000x64_systematic; do
+  cmd="$MCL --steps 40 --warmup 5"
+  [ $wl = fs1 ] && cmd="$FS1 --steps 40 --warmup 5"
+  [ $wl = fs2 ] && cmd="$FS2 --steps 40 --warmup 5"
+  [ $wl = mcl_1000000x32_multinomial ] && cmd="$MCL --scheme multinomial --steps 40 --warmup 5"
+  [ $wl = mcl_16000000x64_systematic ] && cmd="$MCL5 --steps 10 --warmup 3"
+  run ${wl}_fetch --kernel-trace --pmc FETCH_SIZE -- $cmd
+  run ${wl}_write --kernel-trace --pmc WRITE_SIZE -- $cmd
   python tools/summarize_rocprof.py hbm $wl "$(find_csv ${wl}_fetch counter_collection)" "$(find_csv ${wl}_write counter_collection)" > "$OUT/hbm_$wl.csv"
 done
-{ cat "$OUT/hbm_mcl.csv"; tail -n +2 "$OUT/hbm_fs1.csv"; } > "$OUT/${TAG}_pmc_hbm_traffic.csv"
+{ cat "$OUT/hbm_mcl.csv"; for wl in fs1 fs2 mcl_1000000x32_multinomial mcl_16000000x64_systematic; do tail -n +2 "$OUT/hbm_$wl.csv"; done; } > "$OUT/${TAG}_pmc_hbm_traffic.csv"
+run mcl5_trace --kernel-trace --stats -- $MCL5 --steps 20 --warmup 3
+python tools/summarize_rocprof.py stats "$(find_csv mcl5_trace kernel_trace)" > "$OUT/${TAG}_mcl_1.6e7x64_kernel_stats.csv"
+run fs2_trace --kernel-trace --stats -- $FS2
+python tools/summarize_rocprof.py stats "$(find_csv fs2_trace kernel_trace)" > "$OUT/${TAG}_fastslam2_1e5x200_kernel_stats.csv"
 
 run mcl_sq --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS -- $MCL --steps 40 --warmup 5
 python tools/summarize_rocprof.py sq "$(find_csv mcl_sq counter_collection)" > "$OUT/${TAG}_mcl_pmc_sq_summary.csv"
@@ -45,6 +56,12 @@ python tools/summarize_rocprof.py sq "$(find_csv fs1_sq counter_collection)" > "
 if [ -f "$REPO/rust_robotics_amd/librust_robotics_amd_timeline.so" ]; then
   RR_AMD_LIBRARY="$REPO/rust_robotics_amd/librust_robotics_amd_timeline.so" python tools/plan_timeline.py "$OUT/${TAG}_plan_kernel_timeline.json" > /dev/null 2> "$OUT/plan_timeline.err"
 fi
+if [ -f "$REPO/rust_robotics_amd/librust_robotics_amd_timeline.so" ]; then
+  RR_AMD_LIBRARY="$REPO/rust_robotics_amd/librust_robotics_amd_timeline.so" python tools/resident_timeline.py > "$OUT/${TAG}_resident_step_timeline.json" 2> "$OUT/resident_timeline.err"
+fi
+python tools/reference_size_loops.py > "$OUT/${TAG}_reference_size_loops.json" 2> "$OUT/reference_size_loops.err"
+python tools/l_sweep.py > "$OUT/${TAG}_mcl_L_sweep.json" 2> "$OUT/l_sweep.err"
+./tools/ubench/host_link > "$OUT/${TAG}_host_link_pingpong.json" 2>/dev/null
 # un-profiled lines of the same build: the default line, the driver's own command, the sharded legs at world size 1
 python bench.py > "$OUT/${TAG}_bench_default.json" 2> "$OUT/bench_default.err"
 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/${TAG}_bench_driver_command.json" 2> "$OUT/bench_driver.err"
