@@ -1691,7 +1691,6 @@ __global__ __launch_bounds__(kKldThreads) void k_kld_count(unsigned int* __restr
 // (k_kld_count) and the gather -- six launches of a few microseconds of work each otherwise (36 us a step).  Same
 // per-element arithmetic, same integer sums, same draws: bit-identical to the six kernels (tests/test_gpu_kld_adaptive.py runs
 // both routes).  The particle count comes from Ctl.n_active and goes back there.
-constexpr int kAdaptLdsCdf = 4096;
 struct AdaptSmallArgs {
   ImageArgs img;
   PlanArgs plan;
@@ -1719,7 +1718,6 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
   __shared__ double s_max[W];
   __shared__ uint64_t s_t[W], s_qh[W], s_ql[W];
   __shared__ int s_hdr[2];
-  __shared__ uint64_t s_cdf[kAdaptLdsCdf];  // the CDF of a set of up to 4096 particles, for the draws' binary searches
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const bool resident = a.res.on != 0;
   double* const s_obs = resident ? s_dyn_a + 2 : s_dyn_a;
@@ -1806,7 +1804,6 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
     }
     if (i < n) {
       cdf[i] = off + incl;
-      if (n <= (uint64_t)kAdaptLdsCdf) s_cdf[i] = off + incl;  // the draws below search this copy: ~9 dependent reads each
       // (store_cdf: every 2^coarse_log2-th entry and the last one -- the table k_kld_draw stages in LDS)
       if ((((i + 1) & ((1ull << coarse_log2) - 1)) == 0) || i == n - 1) coarse[i >> coarse_log2] = off + incl;
     }
@@ -1845,29 +1842,66 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
   __shared__ uint64_t s_cnt[W];
   __shared__ uint64_t s_req[W];
   __shared__ uint64_t s_stop;
+  // The FIRST block of draws keeps its bin table in the LDS (the reference's loop stops after a few hundred draws when the filter
+  // tracks, :340-352: the first block is then the only one).  The global table's claim / probe / lower-the-minimum chain is six
+  // dependent device-scope round trips (~7 us of the step); the same chain on ds_ atomics is a few hundred cycles.  The flags
+  // (is draw m the first of its bin?) do not depend on where the table lives.  Only if the loop goes on are the first block's
+  // draws inserted into the global table as well (the later blocks must see their bins).
+  constexpr int kLdsSlots = 2 * kKldThreads;
+  __shared__ int32_t s_keys[3 * kKldThreads];
+  __shared__ unsigned int s_tab[kLdsSlots], s_min[kLdsSlots];
   const int src = ctl->cur ^ 1;
   uint64_t k_carry = 0, req_carry = a.kld.min_particles, seen = 0;
   if (tid == 0) s_stop = ~0ull;
+  for (int q = tid; q < kLdsSlots; q += kKldThreads) {
+    s_tab[q] = kKldEmpty;
+    s_min[q] = kKldEmpty;
+  }
   __syncthreads();
   for (uint64_t base = 0; base < a.max_draws; base += kKldThreads) {
     const uint64_t m = base + tid;
     const bool valid = m < a.max_draws;
+    const bool in_lds = base == 0;
+    int32_t xb = 0, yb = 0, ab = 0;
     if (valid) {
       const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, m, p.seed, rstep, resident ? pre + 2 * cap : nullptr, m);
-      uint64_t j = n <= (uint64_t)kAdaptLdsCdf ? rr_lower_bound_u64(s_cdf, n, target) : rr_lower_bound_u64(cdf, n, target);
+      uint64_t j = rr_lower_bound_u64(cdf, n, target);
       if (j >= n) j = n - 1;
       idx[m] = (unsigned int)j;
-      int32_t xb, yb, ab;
       rr_kld_bin(b.x[src][j], b.y[src][j], b.yaw[src][j], &xb, &yb, &ab);
-      keys[3 * m] = xb;
-      keys[3 * m + 1] = yb;
-      keys[3 * m + 2] = ab;
+      if (in_lds) {
+        s_keys[3 * tid] = xb;
+        s_keys[3 * tid + 1] = yb;
+        s_keys[3 * tid + 2] = ab;
+      } else {
+        keys[3 * m] = xb;
+        keys[3 * m + 1] = yb;
+        keys[3 * m + 2] = ab;
+      }
     }
     __syncthreads();  // (a probing draw compares with the keys of the draw that owns a slot)
-    kld_insert_one(m, valid, keys, table, minslot, myslot, a.hash_size);
-    __syncthreads();
-    seen = base + kKldThreads < a.max_draws ? base + kKldThreads : a.max_draws;
-    const uint64_t flag = (valid && __hip_atomic_load(&minslot[myslot[m]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)m) ? 1ull : 0ull;
+    uint64_t flag;
+    if (in_lds) {
+      unsigned int sl = (unsigned int)(kld_hash(xb, yb, ab) & (uint64_t)(kLdsSlots - 1));
+      bool placed = !valid;
+      while (!placed) {
+        unsigned int o = s_tab[sl];
+        if (o == kKldEmpty) {
+          o = atomicCAS(&s_tab[sl], kKldEmpty, (unsigned int)tid);
+          if (o == kKldEmpty) o = (unsigned int)tid;
+        }
+        if (o == (unsigned int)tid || (s_keys[3 * o] == xb && s_keys[3 * o + 1] == yb && s_keys[3 * o + 2] == ab)) placed = true;
+        else sl = (sl + 1) & (kLdsSlots - 1);
+      }
+      if (valid) atomicMin(&s_min[sl], (unsigned int)tid);
+      __syncthreads();
+      flag = (valid && s_min[sl] == (unsigned int)tid) ? 1ull : 0ull;
+    } else {
+      kld_insert_one(m, valid, keys, table, minslot, myslot, a.hash_size);
+      __syncthreads();
+      seen = base + kKldThreads < a.max_draws ? base + kKldThreads : a.max_draws;
+      flag = (valid && __hip_atomic_load(&minslot[myslot[m]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)m) ? 1ull : 0ull;
+    }
     uint64_t incl = rr::wave_scan_u64(flag, lane);
     if (lane == 63) s_cnt[wv] = incl;
     __syncthreads();
@@ -1878,11 +1912,7 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
     }
     const uint64_t k = off + incl;
     uint64_t req = valid ? rr_kld_required(k, a.kld.min_particles, a.kld.max_particles, a.kld.kld_epsilon, a.kld.kld_z) : 0;
-#pragma unroll
-    for (int o = 1; o < rr::kWave; o <<= 1) {
-      const uint64_t t = rr::shfl_up_u64(req, o);
-      if (lane >= o && t > req) req = t;
-    }
+    req = rr::wave_scan_max_u64(req);  // running maximum inside the wave (:350)
     if (lane == 63) s_req[wv] = req;
     __syncthreads();
     uint64_t pre = req_carry, chunk_req = req_carry;
@@ -1896,6 +1926,16 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
     if (s_stop != ~0ull) break;  // uniform: read after the barrier
     k_carry += chunk_total;
     req_carry = chunk_req;
+    if (in_lds && base + kKldThreads < a.max_draws) {  // the loop goes on: the later blocks must find the first block's bins
+      if (valid) {
+        keys[3 * m] = xb;
+        keys[3 * m + 1] = yb;
+        keys[3 * m + 2] = ab;
+      }
+      __syncthreads();
+      kld_insert_one(m, valid, keys, table, minslot, myslot, a.hash_size);
+      seen = kKldThreads < a.max_draws ? (uint64_t)kKldThreads : a.max_draws;
+    }
     __syncthreads();
   }
   const uint64_t n_new = s_stop == ~0ull ? a.max_draws : s_stop + 1;  // :342: at most max_particles
@@ -3919,7 +3959,12 @@ rr_status rr_pf_plan_stats(rr_pf* h, uint64_t* giveups, int32_t* one_launch_enab
 // instrumented build only (tools/resident_timeline.py): the stamps the resident kernel sent with its last answer
 rr_status rr_pf_debug_resident_timeline(rr_pf* h, uint64_t out[8]) {
   if (!h || !h->res.ring) return fail(RR_INVALID_PARAMETER, "no resident service");
-  for (int k = 0; k < 8; ++k) out[k] = __atomic_load_n(&h->res.ring->rsp[8 + k].bits, __ATOMIC_RELAXED);
+  for (int k = 7; k >= 0; --k) {  // (the stamps leave the device after the answer: wait for THIS step's)
+    uint64_t v = 0;
+    for (long spins = 0; spins < 100000000L && !rr::ring_take(&h->res.ring->rsp[8 + k], h->res.seq, &v); ++spins) {
+    }
+    out[k] = v;
+  }
   return RR_OK;
 }
 // instrumented build only (tools/plan_timeline.py): the stamps of the last k_quantize_plan_mark launch, n_tiles x kTimelineWords

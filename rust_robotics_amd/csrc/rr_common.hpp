@@ -184,6 +184,14 @@ __device__ inline unsigned int wave_scan_max_u32(unsigned int v) {
   return v;
 }
 
+// inclusive running maximum of unsigned 64-bit values across the 64 lanes
+__device__ inline uint64_t wave_scan_max_u64(uint64_t v) {
+#define RR_STEP_MAX64S(V, C, M) umax(V, dpp_u64<C, M>(V))
+  RR_DPP_SCAN(v, RR_STEP_MAX64S);
+#undef RR_STEP_MAX64S
+  return v;
+}
+
 // maximum of non-negative doubles (NaN / negative lanes must have been replaced by 0): the bit patterns order like the values
 __device__ inline double wave_max(double v) {
   uint64_t u = (uint64_t)__double_as_longlong(v);
@@ -193,19 +201,22 @@ __device__ inline double wave_max(double v) {
   return __longlong_as_double((long long)last_lane_u64(u));
 }
 
-__device__ inline double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, kWave);
-  return v;
-}
-
-// the same sum on DPP (a different -- but equally fixed -- order of additions: results are reproducible, not equal to wave_sum's);
-// lane 63 holds the sum, which is what the callers read
+// floating-point sum of the 64 lanes in a FIXED order (row_shr 1 / 2 / 4 / 8 inside each row of 16 lanes, then row_bcast:15 and
+// row_bcast:31 across the rows): reproducible for a given input, lane 63 holds it
 __device__ inline double wave_sum_dpp(double v) {
 #define RR_STEP_ADDF(V, C, M) (V + __longlong_as_double((long long)dpp_u64<C, M>((uint64_t)__double_as_longlong(V))))
   RR_DPP_SCAN(v, RR_STEP_ADDF);
 #undef RR_STEP_ADDF
   return v;
+}
+
+// ... handed to every lane.  (Until round 4 this was a __shfl_xor butterfly: twelve dependent ds_bpermute_b32 per sum, ~1.5 us
+// for the 4 - 5 sums of an estimate -- most of what the in-step estimate added to the plan kernel's tail and of the adaptive
+// step's 5 us estimate phase.  The order of the additions, hence the last bits of means and covariances, changed with it.)
+__device__ inline double wave_sum(double v) {
+  v = wave_sum_dpp(v);
+  const uint64_t u = (uint64_t)__double_as_longlong(v);
+  return __longlong_as_double((long long)last_lane_u64(u));
 }
 
 // HIP's 64-bit shuffles are declared on (unsigned) long long; uint64_t is unsigned long here
