@@ -108,9 +108,10 @@ def measured_traffic(kernel_prefix, workload):
     newest = sorted(os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv")))[::-1]
     for name, wl in [(f, workload) for f in newest] + [("r01f_pmc_hbm_traffic_fastslam_timed_region.csv", workload + "_timed_region")]:
         try:
-            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", name))):
-                if r["workload"] == wl and r["kernel"].startswith(kernel_prefix):
-                    return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6, "profiles/" + name
+            rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", name))) if r["workload"] == wl and r["kernel"].startswith(kernel_prefix)]
+            if rows:  # several instantiations of one kernel in a run (a warm-up variant): the one that did the timed launches
+                r = max(rows, key=lambda q: int(q["dispatches"]))
+                return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6, "profiles/" + name
         except Exception:
             pass
     return None, None
