@@ -1858,10 +1858,14 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
     s_min[q] = kKldEmpty;
   }
   __syncthreads();
-  for (uint64_t base = 0; base < a.max_draws; base += kKldThreads) {
+  // ... and in SUB-blocks of kKldSub draws (four waves, one per SIMD): a tracking filter stops after 100 - 300 draws, and the
+  // sixteen waves of a full block spend 4 us issuing ~500 instructions per draw for 1 024 candidates of which a quarter matter
+  constexpr int kKldSub = 256;
+  for (uint64_t base = 0; base < a.max_draws;) {
+    const bool in_lds = base < (uint64_t)kKldThreads;
+    const uint64_t span = in_lds ? (uint64_t)kKldSub : (uint64_t)kKldThreads;
     const uint64_t m = base + tid;
-    const bool valid = m < a.max_draws;
-    const bool in_lds = base == 0;
+    const bool valid = (uint64_t)tid < span && m < a.max_draws;
     int32_t xb = 0, yb = 0, ab = 0;
     if (valid) {
       const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, m, p.seed, rstep, resident ? pre + 2 * cap : nullptr, m);
@@ -1870,9 +1874,9 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
       idx[m] = (unsigned int)j;
       rr_kld_bin(b.x[src][j], b.y[src][j], b.yaw[src][j], &xb, &yb, &ab);
       if (in_lds) {
-        s_keys[3 * tid] = xb;
-        s_keys[3 * tid + 1] = yb;
-        s_keys[3 * tid + 2] = ab;
+        s_keys[3 * m] = xb;
+        s_keys[3 * m + 1] = yb;
+        s_keys[3 * m + 2] = ab;
       } else {
         keys[3 * m] = xb;
         keys[3 * m + 1] = yb;
@@ -1887,15 +1891,15 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
       while (!placed) {
         unsigned int o = s_tab[sl];
         if (o == kKldEmpty) {
-          o = atomicCAS(&s_tab[sl], kKldEmpty, (unsigned int)tid);
-          if (o == kKldEmpty) o = (unsigned int)tid;
+          o = atomicCAS(&s_tab[sl], kKldEmpty, (unsigned int)m);
+          if (o == kKldEmpty) o = (unsigned int)m;
         }
-        if (o == (unsigned int)tid || (s_keys[3 * o] == xb && s_keys[3 * o + 1] == yb && s_keys[3 * o + 2] == ab)) placed = true;
+        if (o == (unsigned int)m || (s_keys[3 * o] == xb && s_keys[3 * o + 1] == yb && s_keys[3 * o + 2] == ab)) placed = true;
         else sl = (sl + 1) & (kLdsSlots - 1);
       }
-      if (valid) atomicMin(&s_min[sl], (unsigned int)tid);
+      if (valid) atomicMin(&s_min[sl], (unsigned int)m);
       __syncthreads();
-      flag = (valid && s_min[sl] == (unsigned int)tid) ? 1ull : 0ull;
+      flag = (valid && s_min[sl] == (unsigned int)m) ? 1ull : 0ull;
     } else {
       kld_insert_one(m, valid, keys, table, minslot, myslot, a.hash_size);
       __syncthreads();
@@ -1926,15 +1930,18 @@ __global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, doub
     if (s_stop != ~0ull) break;  // uniform: read after the barrier
     k_carry += chunk_total;
     req_carry = chunk_req;
-    if (in_lds && base + kKldThreads < a.max_draws) {  // the loop goes on: the later blocks must find the first block's bins
-      if (valid) {
-        keys[3 * m] = xb;
-        keys[3 * m + 1] = yb;
-        keys[3 * m + 2] = ab;
+    base += span;
+    if (in_lds && base == (uint64_t)kKldThreads && base < a.max_draws) {
+      // the loop leaves the LDS table: the global blocks that follow must find the first 1 024 draws' bins
+      const bool v2 = (uint64_t)tid < a.max_draws;
+      if (v2) {
+        keys[3 * tid] = s_keys[3 * tid];
+        keys[3 * tid + 1] = s_keys[3 * tid + 1];
+        keys[3 * tid + 2] = s_keys[3 * tid + 2];
       }
       __syncthreads();
-      kld_insert_one(m, valid, keys, table, minslot, myslot, a.hash_size);
-      seen = kKldThreads < a.max_draws ? (uint64_t)kKldThreads : a.max_draws;
+      kld_insert_one((uint64_t)tid, v2, keys, table, minslot, myslot, a.hash_size);
+      seen = (uint64_t)kKldThreads < a.max_draws ? (uint64_t)kKldThreads : a.max_draws;
     }
     __syncthreads();
   }
