@@ -230,6 +230,13 @@ __global__ __launch_bounds__(kBlock) void k_fs2_predict(Planes pl, const Ctl* __
 // whether 0 or 300 FMAs sit between a wave's loads and its stores; this kernel runs at 5.25 TB/s.)
 constexpr int kObsNtStore = 1, kObsNtLoad = 2, kObsNoPipe = 4, kObsFourWaves = 8;
 constexpr uint64_t kNoFactor = 0x7FF45EA1ED000001ull;  // "no factor here yet": a signalling NaN (k_fs1_observe)
+// ASSUMPTION: the closing chunk's workgroups of a particle block may wait for the factors of the block's other
+// chunks because those have LOWER workgroup indices in the same one-dimensional launch and the hardware dispatches a grid's
+// workgroups in ascending index order (round-robin over the XCDs): whoever is waited for has at least been handed to a CU
+// before the waiter exists.  HIP does not promise that order.  The wait is therefore bounded: after kFactorWaitTicks the weight
+// of the particle is NaN and Ctl.obs_timeout is latched -- every later accessor and synchronous call of the handle reports
+// RR_RUNTIME_ERROR ("a chunk's weight factor did not arrive") instead of returning numbers.  Never observed (the soak runs of
+// rounds 2-4: > 10^7 launches); a handle that must not depend on the assumption takes obs_chunks = 1 (rr_fs1_options).
 constexpr uint64_t kFactorWaitTicks = 200000000ull;    // 2 s of the 100 MHz wall clock
 
 __global__ __launch_bounds__(kBlock) void k_fs1_no_factors(uint64_t* __restrict__ partial, uint64_t words) {
