@@ -91,7 +91,9 @@ struct Settings {
   rr::ParticleFilterConfig filter;
   uint64_t seed = 0;
   int device = 0;
-  double resident_idle_us = 20000.0;  // rr_pf_set_resident: the step kernel stays on the device between messages (0: launches)
+  // rr_pf_set_resident: the step kernel stays on the device between messages and leaves after this long without one (0: a launch
+  // per step).  250 ms keeps it there for any odometry rate above 4 Hz; the price is one workgroup's slots of one compute unit.
+  double resident_idle_us = 250000.0;
   double log_interval_s = kLogIntervalSeconds;
 
   static Settings from_env() {

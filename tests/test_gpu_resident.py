@@ -167,3 +167,23 @@ def test_resident_adaptive_mcl_equals_launched_steps(lo, hi, sig):
     assert a.particle_count() == b.particle_count() and lo <= a.particle_count() <= hi
     assert np.array_equal(bits(a.get_particles_array()), bits(b.get_particles_array()))
     np.testing.assert_array_equal(a.estimate(), b.estimate())
+
+
+def test_more_resident_filters_than_hardware_queues_still_make_progress():
+    """HIP maps streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default): with more live resident kernels than
+    that, a launch can land behind somebody else's resident kernel and only starts when that one has idled out.  Slower (one idle
+    time per such step), never stuck, same bits."""
+    import rust_robotics_amd.localization as loc
+
+    u, obs = scenario(6)
+    many = [make(loc, 100, 0, True, seed=s) for s in range(7)]
+    ref = [make(loc, 100, 0, True, seed=s) for s in range(7)]
+    for f in many:
+        f.set_resident(400.0)
+    t0 = time.time()
+    for t in range(6):
+        for f, r in zip(many, ref):
+            assert np.array_equal(bits(f.step(u[t], obs[t])), bits(r.step(u[t], obs[t])))
+    assert time.time() - t0 < 20.0
+    for f, r in zip(many, ref):
+        assert np.array_equal(bits(f.get_particles_array()), bits(r.get_particles_array()))
