@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
+
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -99,6 +101,11 @@ __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t se
     }
     asm volatile("" ::: "memory");
     if (!ok) {
+      uint64_t* d = reinterpret_cast<uint64_t*>(err) + 1;  // (the flag's allocation has room for this: P2PState::local_setup)
+      d[0] = (uint64_t)g;
+      d[1] = seq;
+      d[2] = __hip_atomic_load(&in->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      d[3] = __hip_atomic_load(&out->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       atomicExch(&s_bad, 1);
     } else {
       gathered[3 * g] = __hip_atomic_load(&in->v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -110,7 +117,7 @@ __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t se
   __syncthreads();
   if (g != 0) return;
   if (s_bad) {
-    *err = kind == kP2PWmax ? kGaveUpWmax : (kind == kP2PSums ? kGaveUpSums : kGaveUpRecord);
+    (void)atomicCAS(err, 0, kind == kP2PWmax ? kGaveUpWmax : (kind == kP2PSums ? kGaveUpSums : kGaveUpRecord));  // the FIRST give-up names the wait
     ctl->fired = 0;  // nothing downstream may act on incomplete data
     if (kind == kP2PWmax) *wmax_out = 0.0;
     return;
@@ -204,21 +211,62 @@ __device__ inline void inbox_put(double* inbox, uint64_t n_local, uint64_t li, u
 __device__ inline bool inbox_take(const double* inbox, uint64_t n_local, uint64_t li, uint64_t seq, uint64_t timeout_ticks,
                                   int* __restrict__ err, double f[4]) {
   const uint64_t* seal = reinterpret_cast<const uint64_t*>(inbox + 4 * n_local + li);
-  uint64_t t0 = 0;
-  for (;;) {
+  auto look = [&]() {  // all five words; true if the seal vouches for the fields just read
     f[0] = ld_sys(inbox + li);
     f[1] = ld_sys(inbox + n_local + li);
     f[2] = ld_sys(inbox + 2 * n_local + li);
     f[3] = ld_sys(inbox + 3 * n_local + li);
-    if (seq == 0) return true;
-    if (__hip_atomic_load(seal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == inbox_seal(seq, f[0], f[1], f[2], f[3])) return true;
-    if (t0 == 0) {
-      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;  // the filter is broken already: do not wait again
-      t0 = wall_clock64() | 1;
+    return __hip_atomic_load(seal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  if (seq == 0) {  // an earlier kernel of the stream filled the slot (RCCL transport: its inbox has no seal plane)
+    f[0] = ld_sys(inbox + li);
+    f[1] = ld_sys(inbox + n_local + li);
+    f[2] = ld_sys(inbox + 2 * n_local + li);
+    f[3] = ld_sys(inbox + 3 * n_local + li);
+    return true;
+  }
+  uint64_t seen = look();
+  if (seen == inbox_seal(seq, f[0], f[1], f[2], f[3])) return true;
+  // Not there yet.  From here on only the SEAL is polled (one load instead of five), with a back-off that grows to ~3.5 us, and
+  // the fields are read again only when the seal has changed: after a resample that moves most of a shard (a filter that lost
+  // track: ~10^6 slots cross a boundary at once) every lane of the consuming kernel waits here, and what it polls with arrives
+  // through the same memory system as the deliveries it waits for.
+  if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;  // the filter is broken already: do not wait again
+  const uint64_t t0 = wall_clock64();
+  const uint64_t limit = seq <= 3 ? 10 * timeout_ticks : timeout_ticks;
+  int nap = 0;
+  for (;;) {
+    if (nap < 4) {
+      __builtin_amdgcn_s_sleep(8 << 0);
+    } else if (nap < 8) {
+      __builtin_amdgcn_s_sleep(32);
+    } else {
+      __builtin_amdgcn_s_sleep(127);
     }
-    __builtin_amdgcn_s_sleep(8);
-    if (wall_clock64() - t0 > (seq <= 3 ? 10 * timeout_ticks : timeout_ticks)) {
-      *err = kGaveUpInboxSlot;
+    ++nap;
+    const uint64_t now = __hip_atomic_load(seal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (now != seen || (nap & 3) == 0) {  // (the seal may have been the FIRST of the five words to land: look at the fields now and then anyway)
+      seen = look();
+      if (seen == inbox_seal(seq, f[0], f[1], f[2], f[3])) return true;
+      // (a delivery in flight: its words land in any order -- keep looking, briefly at full pace)
+      for (int k = 0; k < 8; ++k) {
+        __builtin_amdgcn_s_sleep(4);
+        seen = look();
+        if (seen == inbox_seal(seq, f[0], f[1], f[2], f[3])) return true;
+      }
+    }
+    if (wall_clock64() - t0 > limit) {
+      if (atomicCAS(err, 0, kGaveUpInboxSlot) == 0) {  // (first give-up of the filter: leave what was seen)
+        uint64_t* d = reinterpret_cast<uint64_t*>(err) + 1;
+        (void)look();
+        d[0] = li;
+        d[1] = seq;
+        d[2] = __hip_atomic_load(seal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        d[3] = inbox_seal(seq, f[0], f[1], f[2], f[3]);
+        d[4] = 0;  // the sequence number (within +-16 of the awaited one) whose seal fits what IS there: a complete delivery of another step?
+        for (uint64_t q = seq > 16 ? seq - 16 : 1; q <= seq + 16; ++q)
+          if (inbox_seal(q, f[0], f[1], f[2], f[3]) == d[2]) d[4] = q;
+      }
       return false;
     }
   }
@@ -276,7 +324,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
     }
   }
   if (tid == 0) {
-    if (!wait_flag(&head0[1], epoch, limit)) *err = kGaveUpPlanFlag;
+    if (!wait_flag(&head0[1], epoch, limit)) (void)atomicCAS(err, 0, kGaveUpPlanFlag);
     s_wmax = rr_u2d(ld_dev(&head0[0]));
   }
   __syncthreads();
@@ -383,7 +431,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
   // ---- everybody: flag 1, then the workgroup's prefix, the base and the global totals
   if (tid == 0) {
     const bool ok = wait_flag(&head1[5], epoch, limit);
-    if (!ok) *err = kGaveUpPlanFlag;
+    if (!ok) (void)atomicCAS(err, 0, kGaveUpPlanFlag);
     s4[0] = ld_dev(&rec[(uint64_t)blockIdx.x * kRecWords + 3]);
     s4[1] = ld_dev(&head1[0]);
     s4[2] = ld_dev(&head1[1]);
@@ -451,7 +499,7 @@ struct P2PState {
   // exchanged (export) or before any rank is linked (in-process), i.e. before a peer can write.
   rr_status reset_records() {
     RR_HIP_TRY(hipMemset(mbox, 0, sizeof(P2PMailbox)));
-    RR_HIP_TRY(hipMemset(err, 0, sizeof(int)));
+    RR_HIP_TRY(hipMemset(err, 0, 64));
     RR_HIP_TRY(hipMemset(inbox, 0, inbox_doubles * sizeof(double)));  // (the seal plane: sequence numbers start over)
     RR_HIP_TRY(hipDeviceSynchronize());
     seq = 0;
@@ -466,9 +514,9 @@ struct P2PState {
     RR_HIP_TRY(hipExtMallocWithFlags((void**)&mbox, sizeof(P2PMailbox), hipDeviceMallocFinegrained));
     RR_HIP_TRY(hipMemset(mbox, 0, sizeof(P2PMailbox)));
     RR_HIP_TRY(hipMalloc(&scratch, (3 * kMaxP2P + 4) * sizeof(uint64_t)));
-    RR_HIP_TRY(hipMalloc(&err, sizeof(int)));
-    RR_HIP_TRY(hipMemset(err, 0, sizeof(int)));
-    RR_HIP_TRY(hipHostMalloc(&err_host, sizeof(int)));
+    RR_HIP_TRY(hipMalloc(&err, 64));  // the flag + 7 words of detail a give-up leaves behind (kP2PErrWords)
+    RR_HIP_TRY(hipMemset(err, 0, 64));
+    RR_HIP_TRY(hipHostMalloc(&err_host, 64));
     RR_HIP_TRY(hipDeviceSynchronize());
     return RR_OK;
   }
@@ -537,14 +585,21 @@ struct P2PState {
   // applied, so results read back after this point would silently be those of a non-resampled filter
   rr_status check(hipStream_t stream) {
     if (!ready || !err) return RR_OK;
-    RR_HIP_TRY(hipMemcpyAsync(err_host, err, sizeof(int), hipMemcpyDeviceToHost, stream));
+    RR_HIP_TRY(hipMemcpyAsync(err_host, err, 64, hipMemcpyDeviceToHost, stream));
     RR_HIP_TRY(hipStreamSynchronize(stream));
     if (*err_host) {
       static const char* const what[] = {"", "the peers' weight maxima", "the peers' integer sums", "a peer's record",
                                          "a particle a peer serves (inbox slot)", "the plan kernel's own hand-over"};
       const int k = *err_host > 0 && *err_host <= 5 ? *err_host : 3;
+      // what the waiter saw when it gave up (exchange waits only): peer, the sequence number it waited for, the one that was there
+      const uint64_t* d = reinterpret_cast<const uint64_t*>(err_host) + 1;
+      char detail[320] = "";
+      if (k <= 3) std::snprintf(detail, sizeof detail, " [peer %llu: waited for sequence %llu, its slot held %llu; this rank had posted %llu]",
+                                (unsigned long long)d[0], (unsigned long long)d[1], (unsigned long long)d[2], (unsigned long long)d[3]);
+      if (k == 4) std::snprintf(detail, sizeof detail, " [local slot %llu of step sequence %llu: seal there %016llx, seal of the fields read %016llx; the slot holds a complete delivery of sequence %llu (0: of none nearby)]",
+                                (unsigned long long)d[0], (unsigned long long)d[1], (unsigned long long)d[2], (unsigned long long)d[3], (unsigned long long)d[4]);
       return fail(RR_RUNTIME_ERROR, std::string("peer-to-peer exchange: a wait for a peer's record timed out (RR_P2P_TIMEOUT_MS; waiting for ") +
-                                        what[k] + "); the sharded filter is no longer consistent -- reconnect or recreate it");
+                                        what[k] + ")" + detail + "; the sharded filter is no longer consistent -- reconnect or recreate it");
     }
     return RR_OK;
   }

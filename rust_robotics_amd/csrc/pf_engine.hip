@@ -33,6 +33,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <chrono>
 #include <cstring>
@@ -4284,12 +4285,26 @@ rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
 // k_scan_exchange | k_mark).  Round 2: 4 launches with a full-size resolve pass (k_resolve_push, 7.9 us at 1e6 particles) and
 // a DONE exchange everybody waited in.  (Delivering the overhang from inside the plan kernel, source side, was built and
 // measured in round 3: DESIGN.md section 5 -- it loses to this on every count.)
+rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const double* obs, size_t n_obs);
+
 rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_p2p_connect first");
   if ((s = validate_control(control)) != RR_OK) return s;
   if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
+  // Ranks that SHARE a device (a test rig; one rank per GPU is the deployment): this step's k_step_lazy waits, inside the
+  // kernel, for the particles a peer's k_push_window delivers.  On separate devices that is a wait for another GPU.  On one
+  // device the waiting kernels of the sharers can hold every workgroup slot while the push kernel they wait for has not been
+  // dispatched yet -- it then never gets a slot, and the waits run into their bound: the round-3 "give-up at 10^6 particles per
+  // rank" (run down in round 4 with tools/p2p_shared_device_jump.py: after a resample that moves most of a shard, every slot
+  // was found delivered and consistent in memory -- AFTER the waiters had given up and freed the device).  Sharers whose step
+  // kernels together can fill the device therefore take the eager form of the step, which has no wait inside a full-size kernel.
+  if (h->p2p.n_sharing > 1) {
+    if (!h->dev_cus) RR_HIP_TRY(hipDeviceGetAttribute(&h->dev_cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
+    const uint64_t step_wgs = (h->n + rr::kResolveSlots - 1) / rr::kResolveSlots;
+    if (step_wgs * (uint64_t)h->p2p.n_sharing > 3ull * (uint64_t)h->dev_cus) return rr_pf_shard_step_p2p_unfused(h, control, obs, n_obs);
+  }
   if (h->maybe_pending && (h->pending_kind != kSrcWindow || h->window_rccl) && (s = materialise(h)) != RR_OK) return s;
   ObsArg arg;
   bool kernarg;

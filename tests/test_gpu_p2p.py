@@ -108,3 +108,19 @@ def test_bench_two_ranks_from_a_bare_shell():
     assert "peer-to-peer transport validated bit-identical" in d["config"]["sharding"], d["config"]["sharding"]
     assert d["sharded"]["transport"].startswith("p2p") and not d["sharded"]["p2p_timed_out"]
     assert "[bench rank 0" in r.stderr and "[bench rank 1" in r.stderr
+
+
+@pytest.mark.parametrize("spec", ["2,100000,40", "2,1000000,40", "3,60000,10"])
+def test_shards_sharing_a_device_survive_a_resample_that_moves_most_of_a_shard(spec):
+    """The round-3 "give-up at 10^6 particles per rank" of ranks sharing ONE device, run down in round 4:
+    observations that jump back in time collapse the weights onto a few particles of one shard, the next resample moves most of
+    the other shard across the boundary, and the consuming step kernels of the sharers -- which wait inside the kernel for those
+    deliveries -- held every workgroup slot of the device before the delivering push kernel had been dispatched.  Sharers that
+    can fill the device now take the eager step (rr_pf_shard_step_p2p); smaller ones keep the lazy step, whose wait polls the
+    seal only.  Every shard must equal its block of the unsharded filter and no wait may time out
+    (tools/p2p_shared_device_jump.py)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "p2p_shared_device_jump.py"), spec], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="8", RR_P2P_TIMEOUT_MS="2000"))
+    lines = [ln for ln in r.stdout.splitlines() if "timed_out=" in ln]
+    assert r.returncode == 0 and len(lines) == int(spec.split(",")[0]), (r.stdout[-1500:], r.stderr[-2000:])
+    assert all("timed_out=False equal=True" in ln for ln in lines), lines
