@@ -80,7 +80,8 @@ rr_status rr_fs1_synchronize(rr_fs1* h);
 rr_status rr_fs1_best_particle(rr_fs1* h, double out_pose[3], double* out_weight, uint64_t* out_index);
 /* Resident service for the filters the reference's callers run (100 particles x 8 landmarks, render_gif_slam.rs:166-200; its
  * loop: fastslam_update, then get_best_particle, every step): with idle_us > 0, rr_fs1_update / rr_fs1_update_async of a
- * FastSLAM 1.0 filter of up to 1024 particles (and up to 64 observations per update) launch nothing -- ONE kernel of one
+ * FastSLAM 1.0 filter of up to 1024 particles with at most 1 MB of maps (particles x (3 + 6 landmarks) <= 131 072 values; up to
+ * 64 observations per update) launch nothing -- ONE kernel of one
  * workgroup stays on the device, takes each update's control and observations from a pinned command block and answers with
  * the best particle of the updated set in a pinned response block, so the rr_fs1_best_particle that follows an update is
  * free.  It leaves by itself after idle_us microseconds without an update and after max(100 ms, 20 idle_us) in any case; every

@@ -177,8 +177,8 @@ rr_status rr_pf_step_many(rr_pf* h, const double* controls, const double* obs, s
                           double* out_estimates);
 /* Resident service for the filters the reference's callers really run (100 - 1 200 particles through the synchronous try_step:
  * headless_localizers.rs:39-56, render_gif_particle_filter.rs:77-79, ros2_nodes/ekf_localizer_node/src/main.rs:273): with
- * idle_us > 0, rr_pf_step and rr_pf_step_async of a filter of up to 2048 particles (and up to 128 observations per step) no
- * longer launch anything -- ONE kernel of one workgroup stays on the device with the particles in registers, takes each
+ * idle_us > 0, rr_pf_step and rr_pf_step_async of a filter of up to 2048 particles -- or of a KLD-adaptive filter of up to 16 384
+ * max_particles -- (and up to 128, adaptive: 96, observations per step) no longer launch anything; other filters keep their launches -- ONE kernel of one workgroup stays on the device with the particles in registers, takes each
  * step's control and observations from a pinned command block and leaves the estimate in a pinned response block the
  * host polls.  A synchronous step then costs its arithmetic plus two trips over the host link instead of a launch and a
  * completion wait.  The kernel leaves by itself after idle_us microseconds without a step (the next step starts it again:

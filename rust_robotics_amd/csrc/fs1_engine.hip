@@ -1822,8 +1822,10 @@ rr_status rr_fs1_resample_systematic(rr_fs1* h, double rho) {
 // ---- resident service: the host side (the protocol is resident_core.hpp's; the PF engine's twin is in pf_engine.hip)
 static bool fs1_resident_path(const rr_fs1* h, size_t n_z) {
   static const bool target_waves_env = std::getenv("RR_FS1_TARGET_WAVES") != nullptr;  // (a tuning override of the chunk plan: launched path only)
+  // (one workgroup moves every plane of every particle when the gate fires: beyond ~1 MB of maps the launched path's grid-wide
+  // gather is faster than the launches it costs)
   return h->res.enabled && h->algorithm == 1 && h->n == h->n_global && !h->pl.inbox && !h->p2p.ready && h->n <= 1024 &&
-         n_z <= (size_t)kFs1ResMaxObs && !h->prof.on && !target_waves_env;
+         h->n * h->n_planes <= 131072 && n_z <= (size_t)kFs1ResMaxObs && !h->prof.on && !target_waves_env;
 }
 
 static rr_status fs1_resident_launch(rr_fs1* h, uint64_t first_seq, unsigned int step0, unsigned int rstep0) {
