@@ -6,7 +6,8 @@
 //   -DPFNODE_WITH_DORA      dora-rs C++ node API (transport_dora.cpp)
 // Environment: PF_INPUT_ODOM_TOPIC, PF_INPUT_RANGES_TOPIC, PF_OUTPUT_ODOM_TOPIC, PF_OUTPUT_POSE_TOPIC (main.rs:174-176),
 // PF_PARTICLES, PF_RESAMPLE_THRESHOLD, PF_RANGE_NOISE, PF_VELOCITY_NOISE, PF_YAW_RATE_NOISE, PF_DT, PF_SEED, PF_DEVICE,
-// PF_RESIDENT_IDLE_US, PF_LOG_INTERVAL_S, PF_TRANSPORT, PF_PIN_TO_GPU_NUMA.
+// PF_RESIDENT_IDLE_US, PF_LOG_INTERVAL_S, PF_TRANSPORT, PF_PIN_TO_GPU_NUMA; PF_LOCALIZER=mcl (+ PF_MIN_PARTICLES, PF_MAX_PARTICLES): the
+// MonteCarloLocalizer with its KLD-adaptive particle count instead of the ParticleFilterLocalizer.
 //   pf_localizer_node --self-test   the reference node's own unit tests (main.rs:303-384) on this node's helpers; no GPU
 #include <sched.h>
 

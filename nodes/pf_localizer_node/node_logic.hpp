@@ -89,6 +89,10 @@ inline rr::State2D initial_state_from_odom(const Odometry& m) {
 struct Settings {
   Topics topics;
   rr::ParticleFilterConfig filter;
+  // PF_LOCALIZER=mcl: rust_robotics_localization's MonteCarloLocalizer instead (resample at every step; the particle count follows the
+  // KLD bound between PF_MIN_PARTICLES and PF_MAX_PARTICLES, monte_carlo_localization.rs:50-82) -- same node, same messages
+  bool use_mcl = false;
+  rr::MonteCarloLocalizationConfig mcl;
   uint64_t seed = 0;
   int device = 0;
   // rr_pf_set_resident: the step kernel stays on the device between messages and leaves after this long without one (0: a launch
@@ -109,6 +113,13 @@ struct Settings {
     s.filter.velocity_noise = number_from_env("PF_VELOCITY_NOISE", s.filter.velocity_noise);
     s.filter.yaw_rate_noise = number_from_env("PF_YAW_RATE_NOISE", s.filter.yaw_rate_noise);
     s.filter.dt = number_from_env("PF_DT", s.filter.dt);
+    s.use_mcl = topic_from_env("PF_LOCALIZER", "pf") == "mcl";
+    s.mcl.min_particles = (uint64_t)number_from_env("PF_MIN_PARTICLES", (double)s.mcl.min_particles);
+    s.mcl.max_particles = (uint64_t)number_from_env("PF_MAX_PARTICLES", (double)s.mcl.max_particles);
+    s.mcl.range_noise = s.filter.range_noise;
+    s.mcl.velocity_noise = s.filter.velocity_noise;
+    s.mcl.yaw_rate_noise = s.filter.yaw_rate_noise;
+    s.mcl.dt = s.filter.dt;
     s.seed = (uint64_t)number_from_env("PF_SEED", 0.0);
     s.device = (int)number_from_env("PF_DEVICE", 0.0);
     s.resident_idle_us = number_from_env("PF_RESIDENT_IDLE_US", s.resident_idle_us);
@@ -169,8 +180,11 @@ class Node {
     if (!st_.initialized) {
       const rr::State2D init = initial_state_from_odom(msg);
       try {
-        st_.localizer = std::make_unique<rr::ParticleFilterLocalizer>(
-            rr::ParticleFilterLocalizer::with_initial_state_2d(init, cfg_.filter, cfg_.seed, cfg_.device));
+        if (cfg_.use_mcl)
+          st_.localizer = std::make_unique<rr::MonteCarloLocalizer>(rr::PFState{init.x, init.y, init.yaw, init.v}, cfg_.mcl, cfg_.seed, cfg_.device);
+        else
+          st_.localizer = std::make_unique<rr::ParticleFilterLocalizer>(
+              rr::ParticleFilterLocalizer::with_initial_state_2d(init, cfg_.filter, cfg_.seed, cfg_.device));
         if (cfg_.resident_idle_us > 0.0) rr::check(rr_pf_set_resident(st_.localizer->handle(), cfg_.resident_idle_us));
       } catch (const rr::RoboticsError& e) {
         io_->log(LogLevel::kWarn, std::string("failed to initialize PF state: ") + e.what());

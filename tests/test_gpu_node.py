@@ -67,3 +67,20 @@ def test_node_survives_bad_messages_and_custom_topics(tmp_path):
     rc, err = node.close()
     assert rc == 0
     assert "malformed message dropped" in err and "does not subscribe" in err and "PF update failed" in err and "n x (distance" in err
+
+
+def test_node_with_the_adaptive_monte_carlo_localizer(tmp_path):
+    """PF_LOCALIZER=mcl: the same node around rust_robotics_localization's MonteCarloLocalizer (KLD-adaptive particle count,
+    monte_carlo_localization.rs:50-82,322-385), stepped through the resident service; published states == the in-process localizer's."""
+    import rust_robotics_amd.localization as loc
+
+    node = D.NodeProcess(env={"PF_SEED": "42", "PF_LOCALIZER": "mcl", "PF_MIN_PARTICLES": "100", "PF_MAX_PARTICLES": "5000", "PF_RESIDENT_IDLE_US": "20000"})
+    states, lat, _ = D.run_scenario(node, steps=120)
+    rc, err = node.close()
+    assert rc == 0, err
+    mcl = loc.MonteCarloLocalizer.with_initial_state(list(D.INITIAL), loc.MonteCarloLocalizationConfig(min_particles=100, max_particles=5000, range_noise=0.25), seed=42)
+    u, obs, truth = D.scenario(120)
+    want = np.array([mcl.try_step(u[k], obs[k]) for k in range(120)])
+    assert np.array_equal(states[1:].view(np.uint64), want.view(np.uint64))
+    assert np.hypot(*(states[-1, :2] - truth[-1, :2])) < 1.0
+    print(f"node (adaptive MCL, resident) round trip per message pair: median {np.median(lat):.1f} us")
