@@ -914,9 +914,13 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
   // the particle fields of the estimate: requested HERE -- after this workgroup's record and ticket are out (the
   // s_waitcnt in front of the ticket would otherwise wait for them too and delay every arrival), before the wait for the
   // other workgroups' sums, which is when the memory system has nothing else to do
-  if (!FS_WEIGHTS && ea.want) est_prefetch(ea, cur_after, i0, a.n, ef);
-  // ---- the last arrival: exclusive prefix per tile and the grand totals, then the state word
   const bool last = s_last != 0;
+  // (not the last arrival: everybody waits for ITS scan, and its s_waitcnt below would wait for these loads too; it fetches its
+  // fields once the flag is up.  Requesting the fields only after the flag for EVERY workgroup was measured too, round 4: the flag
+  // then comes 2 us earlier -- the early workgroups' 32 MB of requests no longer stand in the way of the late workgroups' weights and
+  // records -- but the sums' read-back and the marking wait behind those requests instead: plan kernel 21.3 -> 22.8 us.)
+  if (!FS_WEIGHTS && ea.want && !last) est_prefetch(ea, cur_after, i0, a.n, ef);
+  // ---- the last arrival: exclusive prefix per tile and the grand totals, then the state word
   if (last) {
     const int lane = tid & 63, wv = tid >> 6;
     uint64_t tk = 0;
@@ -974,6 +978,7 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
   RR_TL(3);
   const bool gaveup = s_gaveup != 0;
   if (gaveup && !last) return;  // record and ticket are in; the last arrival plans this tile as well
+  if (!FS_WEIGHTS && ea.want && last && !gaveup) est_prefetch(ea, cur_after, i0, a.n, ef);
   if (tid == 0) {
     asm volatile("" ::: "memory");
     s4[0] = ld_dev(&rec[(uint64_t)blockIdx.x * kRecWords + 3]);
