@@ -107,12 +107,15 @@ class NodeProcess:
             pass
         if self.sock is not None:  # what the node still says on its way out (the closing statistics line) comes through the socket
             try:
-                for line in self.rfile:
+                while True:
+                    line = self.rfile.readline()
+                    if not line:
+                        break
                     m = json.loads(line)
                     if "log" in m:
                         self.logs.append(m)
-            except (OSError, ValueError):
-                pass
+            except (OSError, ValueError) as e:  # kept in the log text, so that a failing assertion on it says why
+                self.logs.append({"log": "driver", "text": f"reading the node's last words failed: {e!r}"})
         rc = self.proc.wait(timeout=timeout)
         err = self.proc.stderr.read().decode()
         if self.sock is not None:
