@@ -785,8 +785,9 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
         # The reference's try_step returns the refreshed mean EVERY step (particle_filter.rs:299,332,343,496), so the headline
         # step is the one that produces it: rr_pf_step_async_estimate -- the mean of the resampled set accumulated inside the
         # step's own plan kernel and kept on the device (one synchronisation at the end of the K steps).  The multinomial
-        # scheme has no in-step estimate: its step is the plain asynchronous one (the line says which).
-        with_est = args.scheme == "systematic" and n <= 8_388_608  # (the in-step estimate's limit, rr_pf.h)
+        # scheme's estimate is the deferred form: the resampled set's mean is summed by the kernel that draws, searches and
+        # gathers the sources -- the next step's k_step_lazy (the last step's by rr_pf_last_step_estimate's gather).
+        with_est = n <= 8_388_608  # (the in-step estimate's limit, rr_pf.h)
         step_fn = pf.step_async_estimate if with_est else pf.step_async
         for t in range(D):  # device warm-up (see DEVICE_WARMUP_MCL), then time moves on
             step_fn(u, obs_list[t])
@@ -805,9 +806,9 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
         pf.synchronize()
         dt = time.perf_counter() - t0
         extra["headline_step"] = ("rr_pf_step_async_estimate: propagate + weight + resample + the mean try_step returns, every step"
-                                  if with_est else ("rr_pf_step_async: propagate + weight + resample (no per-step estimate in the multinomial scheme)"
-                                                    if args.scheme != "systematic" else
-                                                    "rr_pf_step_async: propagate + weight + resample (the in-step estimate serves up to 8 388 608 particles)"))
+                                  + ("" if args.scheme == "systematic" else " (summed by the next step's draw-and-gather kernel)")
+                                  if with_est else
+                                  "rr_pf_step_async: propagate + weight + resample (the in-step estimate serves up to 8 388 608 particles)")
         if with_est:
             extra["last_step_estimate"] = [float(a) for a in pf.last_step_estimate()]
         est = pf.estimate()

@@ -233,6 +233,7 @@ enum StepSrc {
                     // (mn_guide_search) -- the latency-bound search hides under this kernel's FP64 work instead of being a
                     // launch of its own (k_resample_guide_mn: 17.7 us at 1e6 particles)
 };
+constexpr size_t kEstSlotWords = 4 * (kBlock / rr::kWave);  // doubles per slot tile of the deferred estimate: one quadruple per wave
 struct WindowArgs {
   const double* inbox;         // this rank's inbox [4 fields + tag][n]
   int* err;
@@ -246,6 +247,9 @@ struct WindowArgs {
   uint64_t n_src;
   unsigned int rstep;
   int guide_log2;
+  // every source kind but kSrcWindow: the previous step asked for its estimate in the deferred form (rr::kEstDeferred) -- when its
+  // resample fired (Ctl.pending), this launch adds up the fields of the sources it gathers, per slot tile -> est_partials[tile][4]
+  double* est_partials;
 };
 
 // The multinomial draw of output slot `slot` through the guide table (resample_core.hpp: buckets of the target space, built
@@ -271,7 +275,9 @@ __device__ inline uint64_t mn_guide_search(const Ctl* __restrict__ ctl, const ui
   return j;
 }
 
-template <bool OBS_KERNARG, int SRC, int LIK, bool PACKED = false>
+// EST: a build that can add up the deferred estimate (WindowArgs.est_partials).  A build of its own because the code's mere presence
+// costs the headline kernel 1.5 us at 1e6 x 32 (six more VGPRs live through the observation loop), executed or not.
+template <bool OBS_KERNARG, int SRC, int LIK, bool PACKED = false, bool EST = false>
 __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
                                                      StepParams p, ObsArg obs_arg,
                                                      const double* __restrict__ obs_dev,
@@ -291,6 +297,8 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
   const double* __restrict__ syaw = b.yaw[src];
   const uint64_t n_tiles = (p.n + rr::kResolveSlots - 1) / rr::kResolveSlots;
   double wmax_local = 0.0;
+  bool est_now = false;
+  double est_acc[4] = {0.0, 0.0, 0.0, 0.0};
   const uint64_t tile = blockIdx.x;  // one tile per workgroup: nothing is loop-invariant, so no constant outlives its use
   if (tile < n_tiles) {
     unsigned int idx[rr::kResolveRows];
@@ -374,10 +382,12 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
     }
     // issue every row's loads before the (long) arithmetic of the first row
     double x[rr::kResolveRows], y[rr::kResolveRows], yaw[rr::kResolveRows];
+    est_now = EST && SRC != kSrcWindow && wa.est_partials != nullptr && pending;
+    double v_src[rr::kResolveRows];  // the sources' v: only the estimate reads it (propagate overwrites v)
 #pragma unroll
     for (int r = 0; r < rr::kResolveRows; ++r) {
       const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
-      x[r] = y[r] = yaw[r] = 0.0;
+      x[r] = y[r] = yaw[r] = v_src[r] = 0.0;
       if (k < p.n) {
         const uint64_t j = idx[r];
         if (SRC == kSrcWindow && pending && (pos0 + (uint64_t)r * kBlock + tid < win_lo || pos0 + (uint64_t)r * kBlock + tid >= win_hi)) {
@@ -394,12 +404,25 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
           x[r] = rec.x;
           y[r] = rec.y;
           yaw[r] = rec.z;
+          v_src[r] = rec.w;
         } else {
           x[r] = sx[j];
           y[r] = sy[j];
           yaw[r] = syaw[j];
+          if (EST && est_now) v_src[r] = b.v[src][j];
         }
       }
+    }
+    if (EST && est_now) {  // the mean of the resampled set, before it is propagated: the thread's rows now, the wave's sums at the end
+      double f[4][rr::kResolveRows];
+#pragma unroll
+      for (int r = 0; r < rr::kResolveRows; ++r) {
+        f[0][r] = x[r];
+        f[1][r] = y[r];
+        f[2][r] = yaw[r];
+        f[3][r] = v_src[r];
+      }
+      rr::est_rows_sum<rr::kResolveRows>(f, est_acc);
     }
 #pragma unroll
     for (int r = 0; r < rr::kResolveRows; ++r) {
@@ -437,6 +460,7 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
       }
     }
   }
+  if (EST && est_now) rr::est_wave_store<kBlock>(est_acc, wa.est_partials, tile);
   double m = rr::wave_max(wmax_local);
   if ((tid & 63) == 0) s_wmax[tid >> 6] = m;
   __syncthreads();
@@ -1096,6 +1120,7 @@ __global__ __launch_bounds__(BLOCK) void k_step_small(Bufs b, double* __restrict
       for (int k = 0; k < 4; ++k) est_partials[k] = c_est[k];
       ctl->est_denom = c_den;
       ctl->est_step = (uint64_t)(a.rstep0 + (unsigned int)(resident ? steps_done : a.K) - 1) + 1;
+      ctl->est_kind = rr::kEstPlanTiles;
       if (a.mail_seq) {
         for (int k = 0; k < 4; ++k)
           __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[k]), (uint64_t)__double_as_longlong(c_est[k] / c_den), __ATOMIC_RELAXED,
@@ -1355,6 +1380,27 @@ __global__ __launch_bounds__(kBlock) void k_gather_lidx(Bufs b, const Ctl* __res
   b.yaw[dst][k] = b.yaw[src][j];
   b.v[dst][k] = b.v[src][j];
   lidx[k] = kInPlace;
+}
+
+// The deferred in-step estimate when an accessor moved the particles before the next step did (materialise): the same sums over
+// the live set -- slot k now HOLDS its source's fields --, the same slot tiles, the same order as k_step_lazy (est_slots_partial).
+__global__ __launch_bounds__(kBlock) void k_est_slots(Bufs b, const Ctl* __restrict__ ctl, uint64_t n, double* __restrict__ partials) {
+  if (ctl->est_kind != rr::kEstSlotTiles) return;  // the gate stayed shut: the plan kernel has formed the weighted mean
+  const int cur = ctl->cur, tid = threadIdx.x;
+  const uint64_t tile_base = (uint64_t)blockIdx.x * rr::kResolveSlots;
+  double f[4][rr::kResolveRows];
+#pragma unroll
+  for (int r = 0; r < rr::kResolveRows; ++r) {
+    const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
+    const bool in = k < n;
+    f[0][r] = in ? b.x[cur][k] : 0.0;
+    f[1][r] = in ? b.y[cur][k] : 0.0;
+    f[2][r] = in ? b.yaw[cur][k] : 0.0;
+    f[3][r] = in ? b.v[cur][k] : 0.0;
+  }
+  double acc[4];
+  rr::est_rows_sum<rr::kResolveRows>(f, acc);
+  rr::est_wave_store<kBlock>(acc, partials, blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2111,6 +2157,9 @@ struct rr_pf {
   double* partials = nullptr;
   double* est_partials = nullptr;      // [kFusedMaxTiles][4] per-workgroup sums of the fused per-step estimate
   double* est_partials_host = nullptr; // pinned copy, made when the estimate is read
+  double* est_slot_partials = nullptr; // [ceil(cap / kResolveSlots)][waves][4]: the deferred form's sums per slot tile (rr::kEstDeferred)
+  double* est_slot_partials_host = nullptr;
+  bool est_deferred = false;           // the last plan was asked for the deferred form and nobody has moved the particles yet
   // small particle sets (k_step_small): the step inputs of rr_pf_step_many and its per-step estimates on the device
   bool small_ok = true;  // RR_PF_SMALL=0 at create time: always take the large path
   HostMail* mail = nullptr;  // pinned, host-coherent: where the small kernel leaves the estimate of a synchronous step
@@ -2388,6 +2437,14 @@ void launch_quantize(rr_pf* h, const double* wmax_src, int settle = 0) {
 // make a pending lazy resample real (accessors and the non-fused entry points call this first)
 void launch_guide_search(rr_pf* h, const double* r_explicit_dev, unsigned int* lidx, const GatherArgs& g);
 
+// the deferred in-step estimate of a resample an accessor made real (the next step's k_step_lazy would have summed it on the way)
+static void launch_est_slots(rr_pf* h) {
+  if (!h->est_deferred) return;
+  h->est_deferred = false;
+  hipLaunchKernelGGL(k_est_slots, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b, (const Ctl*)h->ctl, h->n,
+                     h->est_slot_partials);
+}
+
 rr_status materialise(rr_pf* h) {
   if (!h->maybe_pending) return RR_OK;
   if (h->pending_kind == kSrcLidx) {
@@ -2399,6 +2456,7 @@ rr_status materialise(rr_pf* h) {
     hipLaunchKernelGGL(k_gather_lidx, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->lidx, h->n,
                        (const double*)nullptr);
     hipLaunchKernelGGL(k_settle, dim3(1), dim3(1), 0, h->stream, h->ctl);
+    launch_est_slots(h);
     RR_HIP_TRY(hipGetLastError());
     h->maybe_pending = false;
     h->pending_kind = kSrcMarkers;
@@ -2422,6 +2480,7 @@ rr_status materialise(rr_pf* h) {
     hipLaunchKernelGGL(k_resolve_gather, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b,
                        h->ctl, h->markers, h->carry, h->idx, (double*)nullptr, h->n, 0, 1);
     hipLaunchKernelGGL(k_settle, dim3(1), dim3(1), 0, h->stream, h->ctl);
+    launch_est_slots(h);
   }
   RR_HIP_TRY(hipGetLastError());
   h->maybe_pending = false;
@@ -2501,7 +2560,7 @@ void launch_mn_search(rr_pf* h, bool guide, const double* r_explicit_dev, unsign
 // The resample pipeline: integer image -> plan (gate) + CDF -> gather.  Every kernel after the
 // plan decides on the device whether it has anything to do.  mode 0 = gate, 1 = forced.
 rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, const double* r_explicit_dev,
-                          bool lazy = false, int settle = 0, bool want_estimate = false) {
+                          bool lazy = false, int settle = 0, int est_mode = rr::kEstOff) {
   // K2 + fused plan in one launch when every tile's workgroup is resident at once (k_quantize_plan_mark)
   const bool one_launch = scheme == RR_RESAMPLE_SYSTEMATIC && h->n_tiles <= h->grid_capacity && h->n == h->n_global &&
                           rr::spin_permit(h->opt.device, h);
@@ -2525,20 +2584,27 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
   {
     Timed t(h, RR_K_CDF);
     const dim3 grid((unsigned)h->n_tiles), block(rr::kTileBlock);
-    if (sys && fused) {
-      rr::EstArgs ea{};
-      if (want_estimate && lazy) {  // the mean the reference's try_step returns, from inside the plan kernel
-        for (int k = 0; k < 2; ++k) {
-          ea.field[k][0] = h->b.x[k];
-          ea.field[k][1] = h->b.y[k];
-          ea.field[k][2] = h->b.yaw[k];
-          ea.field[k][3] = h->b.v[k];
-        }
-        ea.partials = h->est_partials;
-        ea.ticket = h->est_ticket;
-        ea.want = 1;
+    rr::EstArgs ea{};
+    if (est_mode != rr::kEstOff && lazy && fused) {  // the mean the reference's try_step returns (rr::EstArgs: in the plan / deferred)
+      if (est_mode == rr::kEstDeferred && !h->est_slot_partials)
+        RR_HIP_TRY(hipMalloc(&h->est_slot_partials, (size_t)grid_for(h->cap, rr::kResolveSlots) * kEstSlotWords * sizeof(double)));
+      for (int k = 0; k < 2; ++k) {
+        ea.field[k][0] = h->b.x[k];
+        ea.field[k][1] = h->b.y[k];
+        ea.field[k][2] = h->b.yaw[k];
+        ea.field[k][3] = h->b.v[k];
       }
-      if (one_launch)
+      ea.partials = h->est_partials;
+      ea.ticket = h->est_ticket;
+      ea.want = sys ? est_mode : (int)rr::kEstDeferred;
+      h->est_deferred = ea.want == rr::kEstDeferred;
+    }
+    if (sys && fused) {
+      if (one_launch && ea.want == rr::kEstDeferred)
+        hipLaunchKernelGGL((rr::k_quantize_plan_mark<false, true>), grid, block, 0, h->stream, (const double*)h->w, h->ctl, wmax_source(h),
+                           image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, settle, h->n_tiles, pa, h->markers,
+                           h->carry, ea, rr::plan_giveup_ticks());
+      else if (one_launch)
         hipLaunchKernelGGL(rr::k_quantize_plan_mark<false>, grid, block, 0, h->stream, (const double*)h->w, h->ctl, wmax_source(h),
                            image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, settle, h->n_tiles, pa, h->markers,
                            h->carry, ea, rr::plan_giveup_ticks());
@@ -2552,7 +2618,7 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
     else if (fused)
       hipLaunchKernelGGL(rr::k_plan_cdf, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total,
                          h->tile_q2, h->n_tiles, pa, h->cdf, guide ? (uint64_t*)nullptr : h->cdf_coarse, h->coarse_log2,
-                         guide ? h->guide_markers : (unsigned int*)nullptr, h->guide_carry, h->guide_log2);
+                         guide ? h->guide_markers : (unsigned int*)nullptr, h->guide_carry, h->guide_log2, ea);
     else
       hipLaunchKernelGGL(rr::k_cdf, grid, block, 0, h->stream, h->w, h->ctl, image_args(h), h->tile_total, h->cdf,
                          h->cdf_coarse, h->coarse_log2);
@@ -3009,15 +3075,15 @@ rr_status ensure_scratch(rr_pf* h, size_t doubles_a, size_t doubles_b) {
 // C ABI
 // =============================================================================================
 // one launch of k_step_lazy: the template arguments from run-time facts (ea/eb: dispatch timestamps when profiling)
-template <bool KA, int SRC, int LIK, bool PK = false>
+template <bool KA, int SRC, int LIK, bool PK = false, bool EST = false>
 static void launch_k1_as(rr_pf* h, unsigned grid, size_t lds, hipEvent_t ea, hipEvent_t eb, const StepParams& p, const ObsArg& arg,
                          unsigned int* markers, const unsigned int* carry, unsigned int* idx_out, const WindowArgs& wa) {
   const double* obs_dev = KA ? nullptr : h->obs_dev;
   if (ea)
-    hipExtLaunchKernelGGL((k_step_lazy<KA, SRC, LIK, PK>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl, p, arg,
+    hipExtLaunchKernelGGL((k_step_lazy<KA, SRC, LIK, PK, EST>), dim3(grid), dim3(kBlock), lds, h->stream, ea, eb, 0, h->b, h->w, h->ctl, p, arg,
                           obs_dev, markers, carry, idx_out, wa, h->packed[0], h->packed[1]);
   else
-    hipLaunchKernelGGL((k_step_lazy<KA, SRC, LIK, PK>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg, obs_dev,
+    hipLaunchKernelGGL((k_step_lazy<KA, SRC, LIK, PK, EST>), dim3(grid), dim3(kBlock), lds, h->stream, h->b, h->w, h->ctl, p, arg, obs_dev,
                        markers, carry, idx_out, wa, h->packed[0], h->packed[1]);
 }
 
@@ -3025,9 +3091,16 @@ static void launch_k1(rr_pf* h, bool kernarg, int src, unsigned grid, size_t lds
                       const StepParams& p, const ObsArg& arg, unsigned int* markers, const unsigned int* carry,
                       unsigned int* idx_out, const WindowArgs& wa = WindowArgs{}, bool packed = false) {
   const bool product = p.lik_mode == RR_LIK_PRODUCT;
-#define RR_K1_GO(KA_, SRC_, LIK_) launch_k1_as<KA_, SRC_, LIK_>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa)
-#define RR_K1_GO_PK(KA_, LIK_) launch_k1_as<KA_, kSrcLidx, LIK_, true>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa)
-#define RR_K1_GO_DRAW(KA_, LIK_) launch_k1_as<KA_, kSrcDraw, LIK_, true>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa)
+  const bool est = wa.est_partials != nullptr;  // the builds that add up the deferred estimate (never the window kernels)
+#define RR_K1_GO(KA_, SRC_, LIK_)                                                                                             \
+  ((est && SRC_ != kSrcWindow) ? launch_k1_as<KA_, SRC_, LIK_, false, (SRC_ != kSrcWindow)>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa) \
+                               : launch_k1_as<KA_, SRC_, LIK_>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa))
+#define RR_K1_GO_PK(KA_, LIK_)                                                                                         \
+  (est ? launch_k1_as<KA_, kSrcLidx, LIK_, true, true>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa)         \
+       : launch_k1_as<KA_, kSrcLidx, LIK_, true>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa))
+#define RR_K1_GO_DRAW(KA_, LIK_)                                                                                       \
+  (est ? launch_k1_as<KA_, kSrcDraw, LIK_, true, true>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa)         \
+       : launch_k1_as<KA_, kSrcDraw, LIK_, true>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa))
 #define RR_K1_SRC(SRC_)                                                                                       \
   do {                                                                                                        \
     if (kernarg) product ? RR_K1_GO(true, SRC_, RR_LIK_PRODUCT) : RR_K1_GO(true, SRC_, RR_LIK_FUSED);          \
@@ -3441,6 +3514,8 @@ void rr_pf_destroy(rr_pf* h) {
   (void)hipFree(h->partials);
   (void)hipFree(h->est_partials);
   if (h->est_partials_host) (void)hipHostFree(h->est_partials_host);
+  (void)hipFree(h->est_slot_partials);
+  if (h->est_slot_partials_host) (void)hipHostFree(h->est_slot_partials_host);
   (void)hipFree(h->steps_dev);
   (void)hipFree(h->est_ring);
   if (h->mail) (void)hipHostFree(h->mail);
@@ -3544,8 +3619,9 @@ rr_status rr_pf_resample(rr_pf* h) {
 // want_estimate: the fused systematic step (and the small-set step, either resampler) also leaves the mean of the particle set
 static bool fused_estimate_available(const rr_pf* h) {
   if (small_path(h, 0)) return true;
-  return !h->adaptive && h->opt.resample_scheme == RR_RESAMPLE_SYSTEMATIC && h->n_tiles <= (uint64_t)rr::kFusedMaxTiles &&
-         h->n == h->n_global;
+  if (h->adaptive || h->n_tiles > (uint64_t)rr::kFusedMaxTiles || h->n != h->n_global) return false;
+  // systematic: in the plan kernel or deferred; multinomial: deferred only, through the lazy resample (lidx), one GPU
+  return h->opt.resample_scheme == RR_RESAMPLE_SYSTEMATIC || (h->lidx != nullptr && !h->p2p.ready);
 }
 
 // the adaptive step of a filter of the reference's sizes: one launch of one workgroup (k_mcl_adaptive_small) up to 1 024 candidate
@@ -3599,15 +3675,17 @@ static rr_status step_adaptive_small(rr_pf* h, const StepParams& p, const ObsArg
   return RR_OK;
 }
 
-static rr_status step_async_impl(rr_pf* h, const double control[2], const double* obs, size_t n_obs, bool want_estimate,
+// want_estimate: rr::kEstOff, rr::kEstInPlan (the synchronous caller reads it back at once) or rr::kEstDeferred (see rr::EstArgs)
+static rr_status step_async_impl(rr_pf* h, const double control[2], const double* obs, size_t n_obs, int want_estimate,
                                  uint64_t* mail_seq_out = nullptr) {
   rr_status s = bind(h, /*keep_lazy=*/h && h->adaptive);  // an adaptive filter steps without knowing its current count on the host
   if (s != RR_OK) return s;
   if ((s = validate_control(control)) != RR_OK) return s;
   if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
-  if (small_path(h, n_obs)) return step_small(h, control, obs, n_obs, 1, want_estimate, nullptr);
-  if (want_estimate && (h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC || h->n_tiles > (uint64_t)rr::kFusedMaxTiles))
-    return fail(RR_INVALID_PARAMETER, "the in-step estimate of a large filter needs the systematic scheme");
+  if (small_path(h, n_obs)) return step_small(h, control, obs, n_obs, 1, want_estimate != rr::kEstOff, nullptr);
+  if (want_estimate && !fused_estimate_available(h))
+    return fail(RR_INVALID_PARAMETER, "no in-step estimate for this filter (adaptive, sharded, or beyond 8 388 608 particles)");
+  if (want_estimate == rr::kEstDeferred && h->p2p.ready) want_estimate = rr::kEstInPlan;  // (the window kernels do not sum)
   ObsArg arg;
   bool kernarg;
   if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
@@ -3636,8 +3714,11 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
   const unsigned grid = (unsigned)n_rtiles;  // one tile per workgroup
   {
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
+    WindowArgs wa_est{};  // the deferred estimate of the step before: summed by this launch as it gathers
+    wa_est.est_partials = h->est_deferred ? h->est_slot_partials : nullptr;
+    h->est_deferred = false;
     if (multinomial && h->mn_deferred) {  // ... are still to be drawn: this launch does it for its own slots
-      WindowArgs wa{};
+      WindowArgs wa = wa_est;
       wa.cdf = h->cdf;
       wa.guide = h->guide;
       wa.n_src = h->mn_deferred_args.n_src;
@@ -3646,7 +3727,7 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
       launch_k1(h, kernarg, kSrcDraw, grid, lds, nullptr, nullptr, p, arg, nullptr, nullptr, h->idx, wa, /*packed=*/true);
       h->mn_deferred = false;
     } else if (multinomial) {  // sources of the previous (multinomial) resample are in lidx
-      launch_k1(h, kernarg, kSrcLidx, grid, lds, nullptr, nullptr, p, arg, h->lidx, nullptr, nullptr, WindowArgs{},
+      launch_k1(h, kernarg, kSrcLidx, grid, lds, nullptr, nullptr, p, arg, h->lidx, nullptr, nullptr, wa_est,
                 /*packed=*/h->packed[0] != nullptr);
     } else {
       hipEvent_t ea = nullptr, eb = nullptr;
@@ -3655,7 +3736,7 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
         eb = take_event(h);
         h->events.push_back({RR_K_PROPAGATE_WEIGHT, ea, eb});
       }
-      launch_k1(h, kernarg, kSrcMarkers, grid, lds, ea, eb, p, arg, h->markers, h->carry, h->idx);
+      launch_k1(h, kernarg, kSrcMarkers, grid, lds, ea, eb, p, arg, h->markers, h->carry, h->idx, wa_est);
     }
   }
   RR_HIP_TRY(hipGetLastError());
@@ -3673,7 +3754,7 @@ rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs,
     if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
     return resident_step(h, control, obs, n_obs, nullptr);
   }
-  return step_async_impl(h, control, obs, n_obs, false);
+  return step_async_impl(h, control, obs, n_obs, rr::kEstOff);
 }
 
 // The resident service of a small filter (<= 2048 particles, <= 128 observations per step): idle_us > 0 switches it on --
@@ -3699,23 +3780,45 @@ rr_status rr_pf_resident_stats(const rr_pf* h, uint64_t* launches, uint64_t* ste
 
 rr_status rr_pf_step_async_estimate(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
   if (h && !fused_estimate_available(h))
-    return fail(RR_INVALID_PARAMETER, "the in-step estimate needs the fused systematic step (fixed N, systematic scheme, one shard, "
-                                      "<= 8 388 608 particles); use rr_pf_step / rr_pf_estimate");
-  return step_async_impl(h, control, obs, n_obs, true);
+    return fail(RR_INVALID_PARAMETER, "the in-step estimate needs the fused step (fixed N, one shard, <= 8 388 608 particles); use "
+                                      "rr_pf_step / rr_pf_estimate");
+  // Systematic: in the plan kernel.  The deferred form (rr::EstArgs: the resampled set's mean summed by the kernel that moves the
+  // particles, the next step's k_step_lazy) was measured against it at 1e6 x 32, round 4: the plan kernel gets 1 us shorter, the
+  // step kernel 1.6 us longer (profiles/r04d_deferred_estimate_ab.md) -- RR_PF_EST_DEFER=1 selects it for A/B.  Multinomial: always
+  // deferred, the offspring counts of iid draws do not exist before the draws are searched.
+  const char* e = std::getenv("RR_PF_EST_DEFER");  // (read per call: the tests switch it within one process)
+  const int sys_mode = e && std::atoi(e) != 0 ? (int)rr::kEstDeferred : (int)rr::kEstInPlan;
+  const bool small = h && small_path(h, 0);
+  const int mode = (h && !small && h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC) ? (int)rr::kEstDeferred : sys_mode;
+  return step_async_impl(h, control, obs, n_obs, mode);
 }
 
 rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!out) return fail(RR_INVALID_PARAMETER, "null output");
+  // the deferred form, and no step has come since: the resample is made real here (gather + k_est_slots: the same sums the next
+  // step would have formed)
+  if (h->est_deferred && (s = materialise(h)) != RR_OK) return s;
   if (!h->est_partials_host) RR_HIP_TRY(hipHostMalloc(&h->est_partials_host, (size_t)rr::kFusedMaxTiles * 4 * sizeof(double)));
   RR_HIP_TRY(hipMemcpyAsync(h->est_partials_host, h->est_partials, (size_t)h->n_tiles * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  const uint64_t n_slot_tiles = grid_for(h->n, rr::kResolveSlots);
+  if (h->est_slot_partials) {
+    if (!h->est_slot_partials_host)
+      RR_HIP_TRY(hipHostMalloc(&h->est_slot_partials_host, (size_t)grid_for(h->cap, rr::kResolveSlots) * kEstSlotWords * sizeof(double)));
+    RR_HIP_TRY(hipMemcpyAsync(h->est_slot_partials_host, h->est_slot_partials, (size_t)n_slot_tiles * kEstSlotWords * sizeof(double),
+                              hipMemcpyDeviceToHost, h->stream));
+  }
   if ((s = fetch_ctl(h)) != RR_OK) return s;  // (synchronises the stream)
   if (h->ctl_host->est_step == 0) return fail(RR_INVALID_PARAMETER, "no step has produced an in-step estimate yet");
-  // the tiles' partial sums in tile order (a fixed order: the same bits whichever plan kernel produced them)
+  // the tiles' partial sums in tile order (a fixed order: the same bits whichever kernel produced them)
+  const bool slots = h->ctl_host->est_kind == rr::kEstSlotTiles;
+  if (slots && !h->est_slot_partials) return fail(RR_RUNTIME_ERROR, "the deferred estimate's sums are missing");
+  const double* part = slots ? h->est_slot_partials_host : h->est_partials_host;
+  const uint64_t n_part = slots ? n_slot_tiles * (kBlock / rr::kWave) : h->n_tiles;  // (slot tiles: one entry per wave)
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (uint64_t t = 0; t < h->n_tiles; ++t)
-    for (int k = 0; k < 4; ++k) acc[k] += h->est_partials_host[4 * t + k];
+  for (uint64_t t = 0; t < n_part; ++t)
+    for (int k = 0; k < 4; ++k) acc[k] += part[4 * t + k];
   for (int k = 0; k < 4; ++k) out[k] = acc[k] / h->ctl_host->est_denom;
   return RR_OK;
 }
@@ -3800,10 +3903,10 @@ rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_
     for (int k = 0; k < 4; ++k) out_state[k] = h->mail->est[k];
     return RR_OK;
   }
-  if (h && out_state && fused_estimate_available(h) && !small_path(h, 0)) {
+  if (h && out_state && h->opt.resample_scheme == RR_RESAMPLE_SYSTEMATIC && fused_estimate_available(h) && !small_path(h, 0)) {
     // try_step (particle_filter.rs:488-497): the returned mean comes out of the step's own plan kernel -- one
     // 300-byte read-back instead of a gather + a two-kernel moment reduction
-    rr_status s = step_async_impl(h, control, obs, n_obs, true);
+    rr_status s = step_async_impl(h, control, obs, n_obs, rr::kEstInPlan);
     if (s != RR_OK) return s;
     if (h->p2p.ready) return rr_pf_last_step_estimate(h, out_state);
     if (!h->mail) {
@@ -3819,7 +3922,7 @@ rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_
     return RR_OK;
   }
   uint64_t want = 0;
-  rr_status s = step_async_impl(h, control, obs, n_obs, false, (h && h->adaptive && out_state) ? &want : nullptr);
+  rr_status s = step_async_impl(h, control, obs, n_obs, rr::kEstOff, (h && h->adaptive && out_state) ? &want : nullptr);
   if (s != RR_OK) return s;
   if (!out_state) return rr_pf_synchronize(h);
   if (want) {  // the adaptive step of a small filter has formed the mean itself (k_mcl_adaptive_small): poll the mailbox

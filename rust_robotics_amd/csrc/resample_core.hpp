@@ -76,6 +76,7 @@ struct Ctl {
   uint64_t est_step;      // resample-step counter the in-step estimate belongs to (+1; 0 = none yet)
   double est_denom;       // ... and what the sum of the tiles' partial sums is divided by (N when the resample fired, else T)
   int obs_timeout;        // FastSLAM: a chunk's weight factor did not show up in k_fs1_observe (never seen; reported as an error)
+  int est_kind;           // where the in-step estimate's partial sums are: kEstPlanTiles / kEstSlotTiles (see EstArgs)
   uint64_t n_active;      // KLD-adaptive filters: the CURRENT particle count (k_kld_count sets it; the kernels of such a filter read
                           // their n from here instead of their launch packet, so the host does not have to know it to enqueue a step)
 };
@@ -467,29 +468,6 @@ static __global__ __launch_bounds__(kTileBlock) void k_cdf(const double* __restr
 // CDF.  Workgroup 0 publishes the plan.  Saves one launch and one dependent single-block kernel.
 constexpr int kFusedMaxTiles = 4096;
 
-static __global__ __launch_bounds__(kTileBlock) void k_plan_cdf(const double* __restrict__ w, Ctl* __restrict__ ctl,
-                                                           ImageArgs a, const uint64_t* __restrict__ tile_total,
-                                                           const uint64_t* __restrict__ tile_q2, uint64_t n_tiles,
-                                                           PlanArgs pa, uint64_t* __restrict__ cdf,
-                                                           uint64_t* __restrict__ coarse, int coarse_log2,
-                                                           unsigned int* __restrict__ guide_markers,
-                                                           unsigned int* __restrict__ guide_carry, int guide_log2) {
-  __shared__ uint64_t s4[4 * (kTileBlock / kWave)];
-  __shared__ uint64_t s_w[kTileBlock / kWave];
-  a = image_args_now(a, ctl);  // (Ctl.n_active is only rewritten by a later kernel)
-  if (a.dyn_n) pa.n_global = a.n_global;
-  const TileSums ts = tile_sums(tile_total, tile_q2, n_tiles, s4);
-  const int mode = ctl->image_mode;  // written by k_quantize_reduce; nothing below reads what block 0 writes
-  const int shift = ctl->shift;
-  const int fire = gate_decision(mode, ts, pa);
-  if (blockIdx.x == 0 && threadIdx.x == 0) finalize_plan(ctl, ts.tot, 0, ts.tot, ts.q2, pa);
-  if (!fire) return;
-  const TileScan t = tile_scan(w, a, mode, shift, blockIdx.x, s_w);
-  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
-  store_cdf(t, ts.pre + t.thread_off, i0, a.n, cdf, coarse, coarse_log2);
-  if (guide_markers) mark_guide(t, ts.pre + t.thread_off, i0, a.n, guide_shift(ts.tot, guide_log2), guide_markers, guide_carry);
-}
-
 // ------------------------------------------------------------------------------------------
 // Systematic resampling WITHOUT any search.  Targets are monotone in the slot index, so source j
 // (inclusive CDF C_j) feeds the contiguous slot run [H_{j-1}, H_j), H_j = rr_sys_slots_upto(C_j).
@@ -608,11 +586,22 @@ static __global__ __launch_bounds__(kTileBlock) void k_quantize_reduce_sums(cons
   }
 }
 
+// The in-step estimate (the mean try_step returns, particle_filter.rs:488-497) in two forms:
+//   kEstInPlan   the plan kernel adds offspring_j * field_j (fired) or q_j * field_j (gate shut) over its tile: everything is
+//                known when the plan kernel ends -- the synchronous rr_pf_step, which reads the value back at once;
+//   kEstDeferred fired: nothing here.  The mean of the resampled set is summed by whoever MOVES the particles -- the next
+//                step's k_step_lazy, which holds every slot's source fields in registers before it propagates them, or the
+//                gather of an accessor that comes first (k_est_slots afterwards) -- per slot tile, in one fixed order.  The plan
+//                kernel then neither reads the particle fields (32 MB at 1e6 particles) nor carries the offspring counts to the
+//                end; gate shut: as kEstInPlan (the fields are requested once the decision is known).
+// Ctl.est_kind says which array the host adds up: kEstPlanTiles -> partials[n_tiles][4], kEstSlotTiles -> the slot tiles' array.
+enum : int { kEstOff = 0, kEstInPlan = 1, kEstDeferred = 2 };
+enum : int { kEstPlanTiles = 0, kEstSlotTiles = 1 };
 struct EstArgs {
   const double* field[2][4];  // x, y, yaw, v of both buffer sets
   double* partials;           // [n_tiles][4]
   unsigned int* ticket;       // (unused since round 3)
-  int want;
+  int want;                   // kEstOff / kEstInPlan / kEstDeferred
 };
 
 // The particle fields of this thread's kItems CONSECUTIVE sources (the blocked layout of tile_scan: a lane reads 8 * kItems
@@ -674,9 +663,69 @@ __device__ inline void est_tile_partial(const EstArgs& ea, const TileScan& t, co
 // stream has drained) adds the n_tiles x 4 numbers on the host, in tile order, and divides by Ctl.est_denom.  Round 2 had
 // the last workgroup to arrive do that inside the kernel: a fence, a ticket and a dependent read-back at the tail of
 // every step for a number that is read once in a while.  One thread of the launch records which step the sums belong to.
-__device__ inline void est_publish(Ctl* __restrict__ ctl, double denom, unsigned int rstep) {
+__device__ inline void est_publish(Ctl* __restrict__ ctl, double denom, unsigned int rstep, int kind = kEstPlanTiles) {
   ctl->est_denom = denom;
   ctl->est_step = (uint64_t)rstep + 1;
+  ctl->est_kind = kind;
+}
+
+// The slot-tile form: a workgroup of kBlock threads has the four fields of its kResolveSlots slots (slot = tile base +
+// r * kBlock + tid) in registers.  Per thread the rows in order (est_rows_sum, right after the loads: four doubles live on instead
+// of the fields), per wave ONE four-value reduction at the kernel's end (est_wave_store, wave_sum4) -> partials[tile][wave][0..3];
+// nothing crosses a wave,
+// so no barrier stands between a workgroup's loads and its arithmetic.  Whoever reads the estimate adds the waves' numbers in
+// (tile, wave) order.  ONE definition for every kernel that produces these sums, so that they agree to the bit whoever ran.
+template <int ROWS>
+__device__ inline void est_rows_sum(const double (&f)[4][ROWS], double (&acc)[4]) {
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    acc[k] = 0.0;
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) acc[k] += f[k][r];
+  }
+}
+template <int BLOCK>
+__device__ inline void est_wave_store(const double (&acc)[4], double* __restrict__ partials, uint64_t tile) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const double v = wave_sum4(acc);
+  if (lane >= 12 && lane < 16) partials[(tile * (BLOCK / kWave) + wv) * 4 + wave_sum4_field(lane)] = v;
+}
+
+// multinomial: gate + CDF (+ the guide markers over the target space)
+static __global__ __launch_bounds__(kTileBlock) void k_plan_cdf(const double* __restrict__ w, Ctl* __restrict__ ctl,
+                                                           ImageArgs a, const uint64_t* __restrict__ tile_total,
+                                                           const uint64_t* __restrict__ tile_q2, uint64_t n_tiles,
+                                                           PlanArgs pa, uint64_t* __restrict__ cdf,
+                                                           uint64_t* __restrict__ coarse, int coarse_log2,
+                                                           unsigned int* __restrict__ guide_markers,
+                                                           unsigned int* __restrict__ guide_carry, int guide_log2,
+                                                           EstArgs ea = EstArgs{}) {
+  __shared__ uint64_t s4[4 * (kTileBlock / kWave)];
+  __shared__ uint64_t s_w[kTileBlock / kWave];
+  a = image_args_now(a, ctl);  // (Ctl.n_active is only rewritten by a later kernel)
+  if (a.dyn_n) pa.n_global = a.n_global;
+  const TileSums ts = tile_sums(tile_total, tile_q2, n_tiles, s4);
+  const int mode = ctl->image_mode;  // written by k_quantize_reduce; nothing below reads what block 0 writes
+  const int shift = ctl->shift;
+  const int fire = gate_decision(mode, ts, pa);
+  if (blockIdx.x == 0 && threadIdx.x == 0) finalize_plan(ctl, ts.tot, 0, ts.tot, ts.q2, pa);
+  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
+  // the in-step estimate of the multinomial scheme is always the deferred form (EstArgs): the offspring counts of iid draws are
+  // not known before the draws are searched, which the kernel that moves the particles does
+  if (ea.want && blockIdx.x == 0 && threadIdx.x == 0)
+    est_publish(ctl, fire ? (double)pa.n_global : (double)ts.tot, pa.rstep, fire ? kEstSlotTiles : kEstPlanTiles);
+  if (!fire) {
+    if (ea.want) {  // gate shut: the weighted mean over the integer image, as the systematic plan forms it
+      EstFields ef;
+      est_prefetch(ea, ctl->cur, i0, a.n, ef);
+      const TileScan t = tile_scan(w, a, mode, shift, blockIdx.x, s_w);
+      est_tile_partial(ea, t, nullptr, 0, i0, a.n, ef, blockIdx.x);
+    }
+    return;
+  }
+  const TileScan t = tile_scan(w, a, mode, shift, blockIdx.x, s_w);
+  store_cdf(t, ts.pre + t.thread_off, i0, a.n, cdf, coarse, coarse_log2);
+  if (guide_markers) mark_guide(t, ts.pre + t.thread_off, i0, a.n, guide_shift(ts.tot, guide_log2), guide_markers, guide_carry);
 }
 
 // fused plan + mark (single shard, systematic, n_tiles <= kFusedMaxTiles)
@@ -689,7 +738,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_plan_mark(const double* _
   __shared__ uint64_t s_w[kTileBlock / kWave];
   const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
   EstFields ef;
-  if (ea.want) est_prefetch(ea, ctl->cur, i0, a.n, ef);  // (lazy plans never flip Ctl.cur in this kernel)
+  if (ea.want == kEstInPlan) est_prefetch(ea, ctl->cur, i0, a.n, ef);  // (lazy plans never flip Ctl.cur in this kernel)
   const TileSums ts = tile_sums(tile_total, tile_q2, n_tiles, s4);
   const int mode = ctl->image_mode;
   const int shift = ctl->shift;
@@ -702,16 +751,17 @@ static __global__ __launch_bounds__(kTileBlock) void k_plan_mark(const double* _
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) finalize_plan(ctl, ts.tot, 0, ts.tot, ts.q2, pa);
   if (!fire && !ea.want) return;
+  const bool est_here = ea.want == kEstInPlan || (ea.want == kEstDeferred && !fire);
+  if (ea.want == kEstDeferred && !fire) est_prefetch(ea, ctl->cur, i0, a.n, ef);
   const TileScan t = tile_scan(w, a, mode, shift, blockIdx.x, s_w);
   unsigned int offspring[kItems];
   if (fire) {
     const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
-    mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry, ea.want ? offspring : nullptr);
+    mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry, est_here ? offspring : nullptr);
   }
-  if (ea.want) {
-    est_tile_partial(ea, t, offspring, fire, i0, a.n, ef, blockIdx.x);
-    if (blockIdx.x == 0 && threadIdx.x == 0) est_publish(ctl, fire ? (double)pa.n_global : (double)ts.tot, pa.rstep);
-  }
+  if (est_here) est_tile_partial(ea, t, offspring, fire, i0, a.n, ef, blockIdx.x);
+  if (ea.want && blockIdx.x == 0 && threadIdx.x == 0)
+    est_publish(ctl, fire ? (double)pa.n_global : (double)ts.tot, pa.rstep, est_here ? kEstPlanTiles : kEstSlotTiles);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -828,7 +878,7 @@ __device__ inline void plan_image_tile(typename std::conditional<FS_WEIGHTS, dou
 
 // phase B of the plan for one tile whose image is in `t` (k_plan_mark's second half): FastSLAM rewrites the weights
 // (normalised, or 1/n + markers when the gate fires), PF/MCL marks and adds the tile's share of the estimate
-template <bool FS_WEIGHTS>
+template <bool FS_WEIGHTS, bool DEFER = false>
 __device__ inline void plan_apply_tile(typename std::conditional<FS_WEIGHTS, double*, const double*>::type w, const ImageArgs& a,
                                        int mode, int shift, const TileScan& t, const double (&w_in)[FS_WEIGHTS ? kItems : 1],
                                        const TileSums& ts, int fire, double rho, const PlanArgs& pa, uint64_t tile,
@@ -854,7 +904,7 @@ __device__ inline void plan_apply_tile(typename std::conditional<FS_WEIGHTS, dou
     if (!fire && !ea.want) return;
     if (fire) {
       const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
-      mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry, ea.want ? offspring : nullptr);
+      mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry, (!DEFER && ea.want) ? offspring : nullptr);
     }
   }
 }
@@ -863,7 +913,9 @@ __device__ inline void plan_apply_tile(typename std::conditional<FS_WEIGHTS, dou
 // (fastslam1.rs:196-203), w = 1/n when it fires (:228) -- and are rewritten by the threads that read them.
 // (amdgpu_waves_per_eu(4): at most 128 VGPRs, i.e. two of these 512-thread workgroups per CU -- the 489 workgroups of a
 // 1e6-particle filter must all be on the 256 CUs at once)
-template <bool FS_WEIGHTS>
+// DEFER (PF / MCL): the estimate in its deferred form (EstArgs) as a build of its own -- no offspring counts, no particle fields
+// in flight across the hand-over: the kernel sits at its 128-VGPR cap, and the one build that served both forms spilled
+template <bool FS_WEIGHTS, bool DEFER = false>
 static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_eu(4))) void k_quantize_plan_mark(
     typename std::conditional<FS_WEIGHTS, double*, const double*>::type w, Ctl* __restrict__ ctl,
     const double* __restrict__ wmax_src, ImageArgs a,
@@ -919,7 +971,7 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
   // fields once the flag is up.  Requesting the fields only after the flag for EVERY workgroup was measured too, round 4: the flag
   // then comes 2 us earlier -- the early workgroups' 32 MB of requests no longer stand in the way of the late workgroups' weights and
   // records -- but the sums' read-back and the marking wait behind those requests instead: plan kernel 21.3 -> 22.8 us.)
-  if (!FS_WEIGHTS && ea.want && !last) est_prefetch(ea, cur_after, i0, a.n, ef);
+  if (!FS_WEIGHTS && !DEFER && ea.want && !last) est_prefetch(ea, cur_after, i0, a.n, ef);
   // ---- the last arrival: exclusive prefix per tile and the grand totals, then the state word
   if (last) {
     const int lane = tid & 63, wv = tid >> 6;
@@ -978,7 +1030,7 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
   RR_TL(3);
   const bool gaveup = s_gaveup != 0;
   if (gaveup && !last) return;  // record and ticket are in; the last arrival plans this tile as well
-  if (!FS_WEIGHTS && ea.want && last && !gaveup) est_prefetch(ea, cur_after, i0, a.n, ef);
+  if (!FS_WEIGHTS && !DEFER && ea.want && last && !gaveup) est_prefetch(ea, cur_after, i0, a.n, ef);
   if (tid == 0) {
     asm volatile("" ::: "memory");
     s4[0] = ld_dev(&rec[(uint64_t)blockIdx.x * kRecWords + 3]);
@@ -1015,7 +1067,10 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
   }
   unsigned int offspring[kItems];
   const double denom = fire ? (double)pa.n_global : (double)ts.tot;
-  const bool want_est = !FS_WEIGHTS && ea.want;
+  // the estimate's partial sums are formed here, or (deferred form, gate fired) by whoever moves the particles
+  const bool want_est = !FS_WEIGHTS && ea.want && !(DEFER && fire);
+  const bool late_fields = want_est && DEFER;  // requested now that the decision is known
+  if (DEFER && ea.want && fire && tid == 0 && (gaveup ? last : blockIdx.x == 0)) est_publish(ctl, denom, pa.rstep, kEstSlotTiles);
   if (FS_WEIGHTS ? (!fire && mode != kImageWeights) : (!fire && !want_est)) return;  // nothing to write
   // One tile -- this workgroup's, its image still in registers -- or, when the launch gave up and this workgroup arrived
   // last, every tile one after the other (the serial plan): the same code either way.
@@ -1032,13 +1087,15 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
       if (want_est) est_prefetch(ea, cur_after, j0, a.n, ef);
       __syncthreads();
       ts.pre = s_tile[0];
+    } else if (late_fields) {
+      est_prefetch(ea, cur_after, j0, a.n, ef);
     }
-    plan_apply_tile<FS_WEIGHTS>(w, a, mode, shift, t, w_in, ts, fire, rho, pa, tile, markers, carry, ea, ef, offspring);
+    plan_apply_tile<FS_WEIGHTS, DEFER>(w, a, mode, shift, t, w_in, ts, fire, rho, pa, tile, markers, carry, ea, ef, offspring);
     RR_TL(5);
     if (want_est) est_tile_partial(ea, t, offspring, fire, j0, a.n, ef, tile);
     RR_TL(6);
   }
-  if (want_est && tid == 0 && (gaveup ? last : blockIdx.x == 0)) est_publish(ctl, denom, pa.rstep);
+  if (want_est && tid == 0 && (gaveup ? last : blockIdx.x == 0)) est_publish(ctl, denom, pa.rstep, kEstPlanTiles);
 }
 
 // sharded: the plan is already in Ctl (k_shard_plan); mark this shard's sources.  tile_offset =

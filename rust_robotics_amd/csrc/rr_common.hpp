@@ -219,6 +219,34 @@ __device__ inline double wave_sum(double v) {
   return __longlong_as_double((long long)last_lane_u64(u));
 }
 
+// FOUR floating-point sums of the 64 lanes in a fixed order for little more than the price of one: the lanes of a quad first
+// split the work -- after two exchanges (quad_perm, lane ^ 1 then lane ^ 2) each lane holds its quad's total of ONE of the four
+// values --, then one value per lane goes down the rows (row_shr 4 / 8) and across them (lane ^ 16, lane ^ 32: commutative, so
+// every row ends with the same bits).  7 additions and 6 + 4 lane exchanges instead of 24 and 48.
+// Returns, in lanes 12 .. 15 of every row, the wave's sums of a[0], a[2], a[1], a[3] (wave_sum4_field(lane) names the value).
+template <int CTRL>
+__device__ inline double dpp_f64(double v) {
+  return __longlong_as_double((long long)dpp_u64<CTRL, 0xf>((uint64_t)__double_as_longlong(v)));
+}
+__device__ inline int wave_sum4_field(int lane) { return ((lane & 1) << 1) | ((lane >> 1) & 1); }
+__device__ inline double wave_sum4(const double (&a)[4]) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const bool odd = (lane & 1) != 0, up = (lane & 2) != 0;
+  // lane ^ 1: even lanes go on with a[0], a[1], odd lanes with a[2], a[3]
+  const double keep0 = odd ? a[2] : a[0], keep1 = odd ? a[3] : a[1];
+  const double send0 = odd ? a[0] : a[2], send1 = odd ? a[1] : a[3];
+  const double b0 = keep0 + dpp_f64<0xB1>(send0);  // quad_perm:[1,0,3,2]
+  const double b1 = keep1 + dpp_f64<0xB1>(send1);
+  // lane ^ 2: lanes 0, 1 of the quad go on with the first of their two values, lanes 2, 3 with the second
+  const double keep = up ? b1 : b0, send = up ? b0 : b1;
+  double c = keep + dpp_f64<0x4E>(send);  // quad_perm:[2,3,0,1]
+  c = c + dpp_f64<0x114>(c);              // row_shr:4 (the first quad of a row adds +0)
+  c = c + dpp_f64<0x118>(c);              // row_shr:8: lanes 12 .. 15 hold the row's totals
+  c = c + __shfl_xor(c, 16, kWave);
+  c = c + __shfl_xor(c, 32, kWave);
+  return c;
+}
+
 // HIP's 64-bit shuffles are declared on (unsigned) long long; uint64_t is unsigned long here
 using ull = unsigned long long;
 __device__ inline uint64_t shfl_xor_u64(uint64_t v, int o) { return (uint64_t)__shfl_xor((ull)v, o, kWave); }

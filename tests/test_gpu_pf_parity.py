@@ -363,14 +363,18 @@ def test_trajectory_vs_literal_reference(loc, det, ref):
     assert mism == 0, f"{mism} resample indices differ from the literal reference walk"
 
 
+@pytest.mark.parametrize("scheme,defer", [(1, False), (1, True), (0, False)], ids=["systematic", "systematic-deferred", "multinomial"])
 @pytest.mark.parametrize("mcl", [False, True])
-def test_in_step_estimate_matches_the_accessor_and_the_reference(loc, ref, mcl):
-    """rr_pf_step_async_estimate: the mean try_step returns (particle_filter.rs:496), accumulated inside the plan kernel
-    from the offspring counts (fired) or the integer image of the weights (gate closed), against (a) the lazy accessor
-    (gather + moment kernels) and (b) ref_pf_estimate of the literal restatement on the same particle set."""
+def test_in_step_estimate_matches_the_accessor_and_the_reference(loc, ref, mcl, scheme, defer, monkeypatch):
+    """rr_pf_step_async_estimate: the mean try_step returns (particle_filter.rs:496) -- the resampled set's mean summed by the
+    kernel that moves the particles (fired; here the accessor's gather + k_est_slots, because the value is read every step) or the
+    weighted mean over the integer image formed in the plan kernel (gate closed) -- against (a) the lazy accessor (gather +
+    moment kernels) and (b) ref_pf_estimate of the literal restatement on the same particle set."""
     n, L, T = 20_000, 6, 14
     lms = H.landmarks_grid(L, 3)
-    kw = dict(seed=7, resample_scheme=1)
+    kw = dict(seed=7, resample_scheme=scheme)
+    if defer:
+        monkeypatch.setenv("RR_PF_EST_DEFER", "1")
     if mcl:
         cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.5)
         pf = loc.MonteCarloLocalizer(cfg, **kw)
@@ -392,10 +396,55 @@ def test_in_step_estimate_matches_the_accessor_and_the_reference(loc, ref, mcl):
         ref.ref_pf_estimate(n, dp(x), dp(y), dp(yaw), dp(v), dp(w), dp(est))
         np.testing.assert_allclose(got, est, **TOL)
         # rr_pf_step returns the same number through the same path
-    if not mcl:
-        assert any(fired) and not all(fired), fired
+    assert any(fired), fired
+    if not mcl and scheme == 1:
+        assert not all(fired), fired
     est2 = pf.step([1.0, 0.1], H.observations(lms, H.true_pose(T + 1), 0.5, rng))
     np.testing.assert_allclose(est2, pf.estimate(), rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("scheme,defer", [(1, "1"), (1, "0"), (0, "0")], ids=["systematic-deferred", "systematic-in-plan", "multinomial"])
+@pytest.mark.parametrize("n", [20_000, 300_000])
+def test_deferred_estimate_is_the_same_whoever_moves_the_particles(loc, scheme, defer, n, monkeypatch):
+    """The deferred form of the in-step estimate (rr::EstArgs; always for the multinomial scheme, RR_PF_EST_DEFER=1 for the
+    systematic one): the sums over the resampled set are formed by the NEXT step's k_step_lazy as it gathers its sources, or --
+    when the value is read first -- by the accessor's gather + k_est_slots.  Same slot tiles, same order: the same bits; and
+    asking for the estimate changes nothing about the particles.  (In-plan form: the plan kernel's sums, read now or later.)"""
+    monkeypatch.setenv("RR_PF_EST_DEFER", defer)
+    L, T = 6, 9
+    lms = H.landmarks_grid(L, 3)
+
+    def run(read_when):
+        cfg = loc.ParticleFilterConfig(n_particles=n, range_noise=0.5, resample_threshold=0.5)
+        pf = loc.ParticleFilterLocalizer(cfg, seed=21, resample_scheme=scheme)
+        rng = np.random.default_rng(22)
+        out = []
+        for t in range(T):
+            obs = H.observations(lms, H.true_pose(t + 1), 0.5, rng)
+            obs2 = H.observations(lms, H.true_pose(t + 2), 0.5, np.random.default_rng(1000 + t))
+            if read_when == "never":
+                pf.step_async([1.0, 0.1], obs)
+            else:
+                pf.step_async_estimate([1.0, 0.1], obs)
+            if read_when == "at once":
+                e = pf.last_step_estimate()
+            fired = pf.last_resample_fired() if read_when == "at once" else None
+            pf.step_async([1.0, 0.1], obs2)  # a plain step: leaves the estimate of the step before alone
+            if read_when == "a step later":
+                e = pf.last_step_estimate()
+            out.append((None if read_when == "never" else np.array(e), fired))
+        return out, pf.get_particles_array().copy()
+
+    a, pa = run("at once")
+    b, pb = run("a step later")
+    _, pc = run("never")
+    fired = [f for _, f in a]
+    assert any(fired), fired  # (and at these settings the gate stays shut on some steps: both forms are exercised)
+    for t, ((ea, _), (eb, _)) in enumerate(zip(a, b)):
+        assert_bits_equal(ea, eb, f"step {t} (fired: {fired[t]})")
+    for k in range(5):
+        assert_bits_equal(pa[:, k], pb[:, k], f"particles, column {k}")
+        assert_bits_equal(pa[:, k], pc[:, k], f"particles with and without the estimate, column {k}")
 
 
 @pytest.mark.parametrize("mcl", [False, True])
