@@ -158,12 +158,15 @@ rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_
  * form a node uses when it only publishes every k-th estimate, and what
  * bench.py times.  Fused propagate+weight kernel, no host synchronisation. */
 rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs, size_t n_obs);
-/* rr_pf_step_async that also produces, on the device and inside the step's own plan kernel, the mean
- * try_step returns (:496: the cache refreshed at :343 after a fired resample -- uniform weights over the
- * resampled set -- or at :332 after the update): sum_j offspring_j p_j / N resp. sum_j q_j p_j / T over
- * the integer image of the weights.  No extra launch, no gather, no host synchronisation;
- * rr_pf_last_step_estimate waits for the stream and reads it (one 300-byte copy).  Fused systematic
- * step only (fixed N, one shard); rr_pf_step uses it automatically when it applies. */
+/* rr_pf_step_async that also produces, on the device, the mean try_step returns (:496: the cache refreshed at
+ * :343 after a fired resample -- uniform weights over the resampled set -- or at :332 after the update).
+ * Systematic scheme: inside the step's own plan kernel, sum_j offspring_j p_j / N resp. sum_j q_j p_j / T over the
+ * integer image of the weights.  Multinomial scheme (the resampler the reference's localizers use): the offspring
+ * counts of iid draws do not exist before the draws are searched, so the resampled set's mean is added up by the
+ * kernel that draws, searches and gathers -- the NEXT step's fused kernel, or rr_pf_last_step_estimate's gather
+ * when it is asked first (the same sums in the same order either way).  No extra launch per step, no host
+ * synchronisation; rr_pf_last_step_estimate waits for the stream and reads the last step's value.  Fixed N, one
+ * shard, up to 8 388 608 particles; rr_pf_step uses the systematic form automatically when it applies. */
 rr_status rr_pf_step_async_estimate(rr_pf* h, const double control[2], const double* obs, size_t n_obs);
 rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]);
 /* n_steps steps in one call: controls = n_steps x (v, yaw_rate), obs = n_steps x n_obs x (d, landmark_x, landmark_y) (the

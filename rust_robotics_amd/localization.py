@@ -236,8 +236,9 @@ class ParticleFilterLocalizer:
         self._cache_valid = False
 
     def step_async_estimate(self, control, observations) -> None:
-        """``step_async`` that also leaves the mean ``try_step`` returns (particle_filter.rs:496) on the device,
-        computed inside the step's plan kernel; read it with ``last_step_estimate`` (engine extension)."""
+        """``step_async`` that also leaves the mean ``try_step`` returns (particle_filter.rs:496) on the device --
+        computed inside the step's plan kernel (systematic) or by the kernel that gathers the drawn sources
+        (multinomial); read it with ``last_step_estimate`` (engine extension)."""
         u = _vec(control, 2, "particle filter control input")
         obs = _obs_array(observations)
         _check(self._L.rr_pf_step_async_estimate(self._h, _dp(u), _dp(obs) if obs.size else None, obs.shape[0]))
