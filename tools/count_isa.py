@@ -25,7 +25,7 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "rust_robotics_amd", "csrc")
 OUT = os.path.join(CSRC, "INSTRUCTION_BUDGET.json")
-KERNEL = "k_step_lazyILb1ELi0ELi0ELb0EE"  # <OBS_KERNARG = true, SRC = kSrcMarkers, LIK = RR_LIK_FUSED, PACKED = false>
+KERNEL = "k_step_lazyILb1ELi0ELi0ELb0ELb0EE"  # <OBS_KERNARG = true, SRC = kSrcMarkers, LIK = RR_LIK_FUSED, PACKED = false, EST = false>
 ROWS = 2
 
 
