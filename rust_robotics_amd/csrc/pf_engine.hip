@@ -275,6 +275,56 @@ __device__ inline uint64_t mn_guide_search(const Ctl* __restrict__ ctl, const ui
   return j;
 }
 
+// The multinomial draws of one slot tile (slot = tile_base + r * kBlock + tid), the rows' searches in LOCKSTEP: every dependent
+// read of the chain (guide pair -> CDF probes) is issued for all rows before any of them is waited for.  (mn_guide_search per
+// row: the bracket loop's trip count depends on the data, so the second row's chain only started when the first row's had
+// ended: +2.6 us at 1e6 slots.)  Same indices as mn_guide_search.
+__device__ inline void mn_draw_rows(const Ctl* __restrict__ ctl, const uint64_t* __restrict__ cdf, const unsigned int* __restrict__ guide,
+                                    int guide_log2, uint64_t n_src, uint64_t seed, unsigned int rstep, uint64_t first_gid,
+                                    uint64_t tile_base, uint64_t n, unsigned int (&idx)[rr::kResolveRows]) {
+  const int tid = threadIdx.x;
+  const uint64_t total = ctl->total;
+  const int gs = rr::guide_shift(total, guide_log2);
+  uint64_t target[rr::kResolveRows], lo[rr::kResolveRows], hi[rr::kResolveRows];
+#pragma unroll
+  for (int r = 0; r < rr::kResolveRows; ++r) {
+    const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
+    target[r] = k < n ? rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, first_gid + k, seed, rstep, nullptr, k) : 0ull;
+  }
+#pragma unroll
+  for (int r = 0; r < rr::kResolveRows; ++r) {
+    const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
+    lo[r] = hi[r] = 0;
+    if (k < n) {
+      const uint64_t bucket = target[r] >> gs;
+      const GuidePair g = *reinterpret_cast<const GuidePair*>(guide + bucket);
+      lo[r] = g.lo;
+      hi[r] = bucket < (total >> gs) ? (uint64_t)g.hi : n_src - 1;  // the last bucket ends with the last source
+    }
+  }
+  for (;;) {
+    bool open = false;
+#pragma unroll
+    for (int r = 0; r < rr::kResolveRows; ++r) open |= lo[r] < hi[r];
+    if (!__any(open)) break;
+    uint64_t c[rr::kResolveRows], mid[rr::kResolveRows];
+#pragma unroll
+    for (int r = 0; r < rr::kResolveRows; ++r) {
+      mid[r] = lo[r] + ((hi[r] - lo[r]) >> 1);
+      c[r] = lo[r] < hi[r] ? cdf[mid[r]] : 0ull;
+    }
+#pragma unroll
+    for (int r = 0; r < rr::kResolveRows; ++r) {
+      if (lo[r] < hi[r]) {
+        if (c[r] >= target[r]) hi[r] = mid[r];
+        else lo[r] = mid[r] + 1;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < rr::kResolveRows; ++r) idx[r] = (unsigned int)lo[r];
+}
+
 // EST: a build that can add up the deferred estimate (WindowArgs.est_partials).  A build of its own because the code's mere presence
 // costs the headline kernel 1.5 us at 1e6 x 32 (six more VGPRs live through the observation loop), executed or not.
 template <bool OBS_KERNARG, int SRC, int LIK, bool PACKED = false, bool EST = false>
@@ -319,51 +369,10 @@ __global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restr
         idx[r] = k < p.n ? markers[k] : 0u;  // `markers` is the lidx array here
       }
     } else if (pending && SRC == kSrcDraw) {
-      // the rows' searches in LOCKSTEP: every dependent read of the chain (guide pair -> CDF probes -> source record) is issued
-      // for all rows before any of them is waited for.  (mn_guide_search per row: the bracket loop's trip count depends on the
-      // data, so the second row's chain only started when the first row's had ended.)
-      const uint64_t total = ctl->total;
-      const int gs = rr::guide_shift(total, wa.guide_log2);
-      uint64_t target[rr::kResolveRows], lo[rr::kResolveRows], hi[rr::kResolveRows];
+      mn_draw_rows(ctl, wa.cdf, wa.guide, wa.guide_log2, wa.n_src, p.seed, wa.rstep, p.first_gid, tile_base, p.n, idx);
 #pragma unroll
       for (int r = 0; r < rr::kResolveRows; ++r) {
         const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
-        target[r] = k < p.n ? rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, p.first_gid + k, p.seed, wa.rstep, nullptr, k) : 0ull;
-      }
-#pragma unroll
-      for (int r = 0; r < rr::kResolveRows; ++r) {
-        const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
-        lo[r] = hi[r] = 0;
-        if (k < p.n) {
-          const uint64_t bucket = target[r] >> gs;
-          const GuidePair g = *reinterpret_cast<const GuidePair*>(wa.guide + bucket);
-          lo[r] = g.lo;
-          hi[r] = bucket < (total >> gs) ? (uint64_t)g.hi : wa.n_src - 1;  // the last bucket ends with the last source
-        }
-      }
-      for (;;) {
-        bool open = false;
-#pragma unroll
-        for (int r = 0; r < rr::kResolveRows; ++r) open |= lo[r] < hi[r];
-        if (!__any(open)) break;
-        uint64_t c[rr::kResolveRows], mid[rr::kResolveRows];
-#pragma unroll
-        for (int r = 0; r < rr::kResolveRows; ++r) {
-          mid[r] = lo[r] + ((hi[r] - lo[r]) >> 1);
-          c[r] = lo[r] < hi[r] ? wa.cdf[mid[r]] : 0ull;
-        }
-#pragma unroll
-        for (int r = 0; r < rr::kResolveRows; ++r) {
-          if (lo[r] < hi[r]) {
-            if (c[r] >= target[r]) hi[r] = mid[r];
-            else lo[r] = mid[r] + 1;
-          }
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < rr::kResolveRows; ++r) {
-        const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
-        idx[r] = (unsigned int)lo[r];
         if (k < p.n && idx_out) idx_out[k] = idx[r];
       }
     } else if (pending && SRC == kSrcWindow) {
@@ -583,6 +592,42 @@ __global__ __launch_bounds__(kBlock) void k_resample_guide_mn(Bufs b, const Ctl*
   if (idx_out) idx_out[k] = (unsigned int)j;
 }
 
+// The synchronous try_step of a large multinomial filter (rr_pf_step) needs the resampled set's mean NOW, not when the next step
+// moves the particles: the draws are searched here -- per slot tile, rows in lockstep, exactly k_step_lazy<kSrcDraw>'s search --,
+// the source indices go to `lidx` (the next step reads through them instead of searching again) and the sources' fields, read out
+// of the packed mirror, into the deferred estimate's per-wave sums (rr::est_rows_sum / est_wave_store: the bits
+// rr_pf_step_async_estimate + rr_pf_last_step_estimate produce).
+__global__ __launch_bounds__(kBlock) void k_mn_search_est(const Ctl* __restrict__ ctl, const uint64_t* __restrict__ cdf,
+                                                         const unsigned int* __restrict__ guide, int guide_log2, GatherArgs a,
+                                                         unsigned int* __restrict__ idx_out, unsigned int* __restrict__ lidx_out,
+                                                         const double* __restrict__ pk0, const double* __restrict__ pk1,
+                                                         double* __restrict__ est_partials) {
+  if (!ctl->fired) return;
+  const int tid = threadIdx.x;
+  const uint64_t tile_base = (uint64_t)blockIdx.x * rr::kResolveSlots;
+  unsigned int idx[rr::kResolveRows];
+  mn_draw_rows(ctl, cdf, guide, guide_log2, a.n_src, a.seed, a.rstep, a.first_slot, tile_base, a.n_slots, idx);
+  const double* __restrict__ pk = ctl->cur ? pk1 : pk0;  // (the lazy resample has not flipped Ctl.cur: the sources are the live set)
+  double f[4][rr::kResolveRows];
+#pragma unroll
+  for (int r = 0; r < rr::kResolveRows; ++r) {
+    const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
+    f[0][r] = f[1][r] = f[2][r] = f[3][r] = 0.0;
+    if (k < a.n_slots) {
+      const double4 rec = *reinterpret_cast<const double4*>(pk + 4 * (uint64_t)idx[r]);
+      f[0][r] = rec.x;
+      f[1][r] = rec.y;
+      f[2][r] = rec.z;
+      f[3][r] = rec.w;
+      lidx_out[k] = idx[r];
+      if (idx_out) idx_out[k] = idx[r];
+    }
+  }
+  double acc[4];
+  rr::est_rows_sum<rr::kResolveRows>(f, acc);
+  rr::est_wave_store<kBlock>(acc, est_partials, blockIdx.x);
+}
+
 // sharded adopt: unpack the received n x (x, y, yaw, v) records into the live buffer set (the
 // plan kernel already made it the other one)
 // slots [self_lo, self_hi) are the ones this rank serves to ITSELF: their records are taken straight from the send
@@ -745,6 +790,49 @@ __global__ void k_est_mail(const Ctl* __restrict__ ctl, const double* __restrict
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (k == 0) __hip_atomic_store(&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The same for a filter whose estimate may be in either form (rr::EstArgs; the multinomial scheme): the plan tiles' partial sums in
+// tile order when the gate stayed shut, else the slot tiles' per-wave sums in est_slots_total's order -- kEstChunks chunks of
+// consecutive entries, each added up from its first entry on, then the chunks in order (the host adds them the same way).
+constexpr int kEstChunks = 256;
+__host__ __device__ inline uint64_t est_chunk_len(uint64_t n_part) { return (n_part + kEstChunks - 1) / kEstChunks; }
+__global__ __launch_bounds__(kEstChunks) void k_est_mail_any(const Ctl* __restrict__ ctl, const double* __restrict__ plan_partials,
+                                                             uint64_t n_tiles, const double* __restrict__ slot_partials, uint64_t n_slot_part,
+                                                             HostMail* mail, uint64_t seq) {
+  __shared__ double s_cs[4][kEstChunks];
+  const int c = threadIdx.x;
+  const bool slots = ctl->est_kind == rr::kEstSlotTiles;
+  const double* __restrict__ part = slots ? slot_partials : plan_partials;
+  const uint64_t n_part = slots ? n_slot_part : n_tiles;
+  // (plan tiles: ONE chunk holds everything -- the sequential order of k_est_mail and rr_pf_last_step_estimate)
+  const uint64_t G = slots ? est_chunk_len(n_part) : n_part;
+  const uint64_t i0 = (uint64_t)c * G, i1 = i0 + G < n_part ? i0 + G : n_part;
+  double cs[4] = {0.0, 0.0, 0.0, 0.0};
+  if (slots || c == 0)
+    for (uint64_t i = i0; i < i1; ++i) {
+      const double4 v = *reinterpret_cast<const double4*>(part + 4 * i);
+      cs[0] += v.x;
+      cs[1] += v.y;
+      cs[2] += v.z;
+      cs[3] += v.w;
+    }
+  for (int k = 0; k < 4; ++k) s_cs[k][c] = cs[k];
+  __syncthreads();
+  if (c < 4) {
+    double acc = 0.0;
+    if (slots)
+      for (int q = 0; q < kEstChunks; ++q) acc += s_cs[c][q];
+    else
+      acc = s_cs[c][0];
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[c]), (uint64_t)__double_as_longlong(acc / ctl->est_denom), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (c == 0) __hip_atomic_store(&mail->flags, (uint64_t)(ctl->grid_timeout != 0) | ((uint64_t)(ctl->est_step == 0) << 1), __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (c == 0) __hip_atomic_store(&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // workgroup-wide helpers of the small kernel (kSmallBlock threads); every thread gets the result
@@ -2160,6 +2248,8 @@ struct rr_pf {
   double* est_slot_partials = nullptr; // [ceil(cap / kResolveSlots)][waves][4]: the deferred form's sums per slot tile (rr::kEstDeferred)
   double* est_slot_partials_host = nullptr;
   bool est_deferred = false;           // the last plan was asked for the deferred form and nobody has moved the particles yet
+  bool est_eager = false;              // rr_pf_step of a multinomial filter: search the draws and add up the estimate right after the plan
+  bool est_eager_done = false;         // ... and the launch that did it is in the stream (k_mn_search_est)
   // small particle sets (k_step_small): the step inputs of rr_pf_step_many and its per-step estimates on the device
   bool small_ok = true;  // RR_PF_SMALL=0 at create time: always take the large path
   HostMail* mail = nullptr;  // pinned, host-coherent: where the small kernel leaves the estimate of a synchronous step
@@ -2633,7 +2723,16 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
     g.seed = h->opt.seed;
     g.rstep = h->rstep;
     g.scheme = scheme;
-    if (guide && h->packed[0] && h->mn_defer_ok) {
+    if (guide && h->packed[0] && h->est_eager && h->est_deferred) {
+      // the synchronous try_step: the caller waits for the mean of the resampled set, so the draws are searched now (the next
+      // step reads through lidx) and the sources' fields added up on the way
+      launch_guide_resolve(h);
+      hipLaunchKernelGGL(k_mn_search_est, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, (const Ctl*)h->ctl,
+                         (const uint64_t*)h->cdf, (const unsigned int*)h->guide, h->guide_log2, g, h->idx, h->lidx,
+                         (const double*)h->packed[0], (const double*)h->packed[1], h->est_slot_partials);
+      h->est_deferred = false;
+      h->est_eager_done = true;
+    } else if (guide && h->packed[0] && h->mn_defer_ok) {
       // the draws and their search wait for the kernel that consumes them: the next step's k_step_lazy<kSrcDraw> (or
       // ensure_searched, when an accessor comes first)
       launch_guide_resolve(h);
@@ -3817,8 +3916,18 @@ rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]) {
   const double* part = slots ? h->est_slot_partials_host : h->est_partials_host;
   const uint64_t n_part = slots ? n_slot_tiles * (kBlock / rr::kWave) : h->n_tiles;  // (slot tiles: one entry per wave)
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (uint64_t t = 0; t < n_part; ++t)
-    for (int k = 0; k < 4; ++k) acc[k] += part[4 * t + k];
+  if (slots) {  // est_slots_total: chunks of consecutive entries, then the chunks in order (k_est_mail_any adds them the same way)
+    const uint64_t G = est_chunk_len(n_part);
+    for (int c = 0; c < kEstChunks; ++c) {
+      double cs[4] = {0.0, 0.0, 0.0, 0.0};
+      for (uint64_t t = (uint64_t)c * G; t < std::min<uint64_t>(((uint64_t)c + 1) * G, n_part); ++t)
+        for (int k = 0; k < 4; ++k) cs[k] += part[4 * t + k];
+      for (int k = 0; k < 4; ++k) acc[k] += cs[k];
+    }
+  } else {
+    for (uint64_t t = 0; t < n_part; ++t)
+      for (int k = 0; k < 4; ++k) acc[k] += part[4 * t + k];
+  }
   for (int k = 0; k < 4; ++k) out[k] = acc[k] / h->ctl_host->est_denom;
   return RR_OK;
 }
@@ -3918,6 +4027,30 @@ rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_
     RR_HIP_TRY(hipGetLastError());
     if ((s = await_mail(h, want)) != RR_OK) return s;
     if (h->mail->flags) return rr_pf_last_step_estimate(h, out_state);  // a degraded plan to take note of (fetch_ctl), or no estimate
+    for (int k = 0; k < 4; ++k) out_state[k] = h->mail->est[k];
+    return RR_OK;
+  }
+  if (h && out_state && h->opt.resample_scheme == RR_RESAMPLE_MULTINOMIAL && fused_estimate_available(h) && !small_path(h, 0) &&
+      !h->profiling) {
+    // try_step of a large multinomial filter (the resampler the reference's localizers use): plan, then ONE launch that searches
+    // the draws and adds up the resampled set's mean (k_mn_search_est), then the mailbox -- instead of search + gather + settle +
+    // two moment kernels
+    h->est_eager = true;
+    h->est_eager_done = false;
+    rr_status s = step_async_impl(h, control, obs, n_obs, rr::kEstDeferred);
+    h->est_eager = false;
+    if (s != RR_OK) return s;
+    if (!h->est_eager_done) return rr_pf_last_step_estimate(h, out_state);  // (no guide table / packed mirror: the long way)
+    if (!h->mail) {
+      RR_HIP_TRY(hipHostMalloc(&h->mail, sizeof(HostMail), hipHostMallocDefault));
+      std::memset(h->mail, 0, sizeof(HostMail));
+    }
+    const uint64_t want = ++h->mail_seq;
+    hipLaunchKernelGGL(k_est_mail_any, dim3(1), dim3(kEstChunks), 0, h->stream, (const Ctl*)h->ctl, (const double*)h->est_partials, h->n_tiles,
+                       (const double*)h->est_slot_partials, (uint64_t)grid_for(h->n, rr::kResolveSlots) * (kBlock / rr::kWave), h->mail, want);
+    RR_HIP_TRY(hipGetLastError());
+    if ((s = await_mail(h, want)) != RR_OK) return s;
+    if (h->mail->flags) return rr_pf_last_step_estimate(h, out_state);
     for (int k = 0; k < 4; ++k) out_state[k] = h->mail->est[k];
     return RR_OK;
   }

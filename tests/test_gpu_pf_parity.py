@@ -447,6 +447,37 @@ def test_deferred_estimate_is_the_same_whoever_moves_the_particles(loc, scheme, 
         assert_bits_equal(pa[:, k], pc[:, k], f"particles with and without the estimate, column {k}")
 
 
+@pytest.mark.parametrize("n", [20_000, 300_000])
+@pytest.mark.parametrize("mcl", [False, True])
+def test_try_step_of_a_large_multinomial_filter(loc, mcl, n):
+    """rr_pf_step on the multinomial scheme beyond the one-workgroup sizes: plan, one launch that searches the draws and adds up
+    the resampled set's mean (k_mn_search_est), mailbox.  The value is the one rr_pf_step_async_estimate +
+    rr_pf_last_step_estimate produce, bit for bit (one order of summation whoever runs it), and the trajectories are the same."""
+    L, T = 6, 12
+    lms = H.landmarks_grid(L, 3)
+
+    def make():
+        if mcl:
+            return loc.MonteCarloLocalizer(loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.5), seed=31, resample_scheme=0)
+        return loc.ParticleFilterLocalizer(loc.ParticleFilterConfig(n_particles=n, range_noise=0.5, resample_threshold=0.5), seed=31, resample_scheme=0)
+
+    a, b = make(), make()
+    rng = np.random.default_rng(32)
+    fired = []
+    for t in range(T):
+        obs = H.observations(lms, H.true_pose(t + 1), 0.5, rng)
+        ea = np.array(a.step([1.0, 0.1], obs))
+        b.step_async_estimate([1.0, 0.1], obs)
+        eb = np.array(b.last_step_estimate())
+        fired.append(a.last_resample_fired())
+        assert_bits_equal(ea, eb, f"step {t} (fired: {fired[-1]})")
+        np.testing.assert_allclose(ea, a.estimate(), rtol=1e-11, atol=1e-11)
+    assert any(fired), fired
+    pa, pb = a.get_particles_array(), b.get_particles_array()
+    for k in range(5):
+        assert_bits_equal(pa[:, k], pb[:, k], f"particles, column {k}")
+
+
 @pytest.mark.parametrize("mcl", [False, True])
 def test_one_launch_plan_equals_the_two_kernel_plan(loc, mcl, monkeypatch):
     """k_quantize_plan_mark (tile sums handed over inside one launch: records, two-level ticket, flag) against
