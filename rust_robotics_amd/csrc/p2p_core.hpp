@@ -449,7 +449,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
     }
     const rr_sys_plan plan = rr_sys_plan_make(rho, total, pa.n_global);
     // marker position of global slot s: s + slot_pad (resolve_tile_window); the overhang over the own block is
-    // k_push_window's (see DESIGN.md section 5 for the variant that delivered it from here, and why it lost)
+    // k_push_window's (see docs/DESIGN_NOTES.md section 5 for the variant that delivered it from here, and why it lost)
     mark_sources(t, base + pre + t.thread_off, i0, a.n, plan, total, (uint64_t)0 - slot_pad, markers, carry);
   }
 }

@@ -4522,7 +4522,7 @@ rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
 // particles, or several ranks on one device, take the plan as four launches (WMAX exchange | k_quantize_reduce |
 // k_scan_exchange | k_mark).  Round 2: 4 launches with a full-size resolve pass (k_resolve_push, 7.9 us at 1e6 particles) and
 // a DONE exchange everybody waited in.  (Delivering the overhang from inside the plan kernel, source side, was built and
-// measured in round 3: DESIGN.md section 5 -- it loses to this on every count.)
+// measured in round 3: docs/DESIGN_NOTES.md section 5 -- it loses to this on every count.)
 rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const double* obs, size_t n_obs);
 
 rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {

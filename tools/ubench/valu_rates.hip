@@ -1,6 +1,6 @@
 // valu_rates.hip -- issue cost (cycles per wave-instruction per SIMD) of the VALU instructions the
 // MCL propagate+weight kernel is made of, measured on the machine at hand.  Development tool
-// (DESIGN.md section 4 "instruction budget"); not part of the library.
+// (docs/DESIGN_NOTES.md section 4 "instruction budget"); not part of the library.
 //   hipcc --offload-arch=gfx950 -O3 -o valu_rates valu_rates.hip && ./valu_rates
 #include <hip/hip_runtime.h>
 
