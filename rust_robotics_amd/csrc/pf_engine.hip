@@ -3899,6 +3899,7 @@ rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]) {
   // the deferred form, and no step has come since: the resample is made real here (gather + k_est_slots: the same sums the next
   // step would have formed)
   if (h->est_deferred && (s = materialise(h)) != RR_OK) return s;
+  if (h->est_deferred) launch_est_slots(h);  // (nothing was pending any more: the live set is the resampled set)
   if (!h->est_partials_host) RR_HIP_TRY(hipHostMalloc(&h->est_partials_host, (size_t)rr::kFusedMaxTiles * 4 * sizeof(double)));
   RR_HIP_TRY(hipMemcpyAsync(h->est_partials_host, h->est_partials, (size_t)h->n_tiles * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   const uint64_t n_slot_tiles = grid_for(h->n, rr::kResolveSlots);
