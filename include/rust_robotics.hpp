@@ -119,6 +119,20 @@ class ParticleFilterLocalizer {
     PFState e = try_step({c.v, c.omega}, obs);
     return {e[0], e[1], e[2], e[3]};
   }
+  // engine extensions: the step enqueued without waiting for it (rr_pf_step_async), with the mean try_step returns left on the
+  // device (rr_pf_step_async_estimate; read it with last_step_estimate), and the resident service of small filters
+  // (rr_pf_set_resident: try_step then launches nothing)
+  void try_step_async(const PFControl& u, const PFMeasurement& obs, bool with_estimate = false) {
+    std::vector<double> flat = flatten(obs);
+    check(with_estimate ? rr_pf_step_async_estimate(h_, u.data(), flat.data(), obs.size()) : rr_pf_step_async(h_, u.data(), flat.data(), obs.size()));
+  }
+  PFState last_step_estimate() {
+    PFState e;
+    check(rr_pf_last_step_estimate(h_, e.data()));
+    return e;
+  }
+  void synchronize() { check(rr_pf_synchronize(h_)); }
+  void set_resident(double idle_us) { check(rr_pf_set_resident(h_, idle_us)); }
   PFState estimate() {
     PFState e;
     check(rr_pf_estimate(h_, e.data()));
@@ -231,6 +245,19 @@ class FastSlam1 {
     }
     check(rr_fs1_update(h_, u.data(), f.data(), z.size()));
   }
+  // engine extensions: the update enqueued without waiting (rr_fs1_update_async + synchronize), and the resident service of small
+  // maps (rr_fs1_set_resident: update launches nothing and is answered with the best particle, so best_particle() after it is free)
+  void update_async(const std::array<double, 2>& u, const std::vector<std::tuple<double, double, size_t>>& z) {
+    std::vector<double> f;
+    for (auto& [d, a, id] : z) {
+      f.push_back(d);
+      f.push_back(a);
+      f.push_back((double)id);
+    }
+    check(rr_fs1_update_async(h_, u.data(), f.data(), z.size()));
+  }
+  void synchronize() { check(rr_fs1_synchronize(h_)); }
+  void set_resident(double idle_us) { check(rr_fs1_set_resident(h_, idle_us)); }
   // get_best_particle, fastslam1.rs:269-274
   std::tuple<std::array<double, 3>, double, uint64_t> best_particle() {
     std::array<double, 3> pose;

@@ -185,7 +185,7 @@ class Node {
         else
           st_.localizer = std::make_unique<rr::ParticleFilterLocalizer>(
               rr::ParticleFilterLocalizer::with_initial_state_2d(init, cfg_.filter, cfg_.seed, cfg_.device));
-        if (cfg_.resident_idle_us > 0.0) rr::check(rr_pf_set_resident(st_.localizer->handle(), cfg_.resident_idle_us));
+        if (cfg_.resident_idle_us > 0.0) st_.localizer->set_resident(cfg_.resident_idle_us);
       } catch (const rr::RoboticsError& e) {
         io_->log(LogLevel::kWarn, std::string("failed to initialize PF state: ") + e.what());
         return;

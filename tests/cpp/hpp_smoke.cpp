@@ -123,6 +123,28 @@ int main() {
     }
   }
 
+  // ---- engine extensions through the wrapper: the resident service answers try_step with the launched steps' bits, and the
+  // asynchronous step + last_step_estimate return what try_step returns
+  {
+    rr::ParticleFilterConfig sc;
+    sc.n_particles = 150;
+    sc.range_noise = 0.5;
+    rr::ParticleFilterLocalizer a(sc, 12), b(sc, 12), c(sc, 12);
+    b.set_resident(20000.0);
+    double tr[3] = {0, 0, 0};
+    for (int t = 0; t < 40; ++t) {
+      tr[0] += std::cos(tr[2]) * sc.dt;
+      tr[1] += std::sin(tr[2]) * sc.dt;
+      tr[2] += 0.1 * sc.dt;
+      const rr::PFMeasurement z = observe(tr, rng, 0.5);
+      const rr::PFState ea = a.try_step({1.0, 0.1}, z), eb = b.try_step({1.0, 0.1}, z);
+      c.try_step_async({1.0, 0.1}, z, /*with_estimate=*/true);
+      const rr::PFState ec = c.last_step_estimate();
+      for (int k = 0; k < 4; ++k) REQUIRE(ea[k] == eb[k] && ea[k] == ec[k]);
+    }
+    c.synchronize();
+  }
+
   // ---- fastslam1 / fastslam2
   rr::fastslam1::Params prm;
   prm.first_obs_cov = 10.0;
@@ -130,6 +152,18 @@ int main() {
   for (int t = 0; t < 10; ++t) fs.update({1.0, 0.1}, {{5.0, 0.1, 0}, {7.0, -0.4, 2}});
   auto [pose, w, i] = fs.best_particle();
   REQUIRE(i < 500 && std::isfinite(pose[0]) && w > 0.0);
+  {  // resident service + asynchronous update through the wrapper: the same best particle as the launched updates
+    rr::fastslam1::FastSlam1 fa(100, 3, prm, 10), fb(100, 3, prm, 10);
+    fb.set_resident(20000.0);
+    for (int t = 0; t < 12; ++t) {
+      fa.update_async({1.0, 0.1}, {{5.0, 0.1, 0}, {7.0, -0.4, 2}});
+      fb.update({1.0, 0.1}, {{5.0, 0.1, 0}, {7.0, -0.4, 2}});
+      auto [pa, wa, ia] = fa.best_particle();
+      auto [pb, wb, ib] = fb.best_particle();
+      REQUIRE(ia == ib && wa == wb && pa[0] == pb[0] && pa[1] == pb[1] && pa[2] == pb[2]);
+    }
+    fa.synchronize();
+  }
   auto lms = fs.landmarks_of(i);
   REQUIRE(lms.size() == 18 && lms[2] < 100.0 && lms[6 + 2] == 1000.0);  // landmark 1 never observed: cov stays 1000 I (fastslam1.rs:34-40)
   rr::fastslam2::FastSlam2 f2(400, 2, {}, 3);
