@@ -888,6 +888,11 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
     # times L plus a per-particle count, both read off the ISA and checked against SQ_INSTS_VALU) over the kernel time
     pair_i, part_i = mcl_instruction_budget()
     valu_rate = (pair_i * L + part_i) * n / k1_avg_s if k1_avg_s > 0 else 0.0
+    # the multinomial kernel moves whole 128-byte lines for its 8-byte guide pairs and 32-byte source records (iid draws have no
+    # locality): what binds it is the MEASURED line traffic (PMC), not the algorithmic bytes and not the FP64 pipe
+    line_rate = (traffic / k1_avg_s) if (traffic and k1_avg_s > 0 and args.scheme == "multinomial") else 0.0
+    fracs = {"fp64_valu": valu_rate / FP64_VALU_PEAK, "hbm": achieved / HBM_PEAK, "line_traffic": line_rate / HBM_PEAK}
+    bound = max(fracs, key=fracs.get)
     out = {
         "metric": "particle-landmark updates/sec",
         "value": value,
@@ -915,10 +920,12 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
             # the binding resource of THIS kernel at THIS L: the FP64 vector pipe once its fraction of the issue peak exceeds the
             # HBM fraction (L >= ~16), HBM below that.  achieved / peak / frac stay the HBM figures the contract asks for;
             # binding_frac is the fraction of the binding resource's peak
-            "bound": "fp64_valu" if valu_rate / FP64_VALU_PEAK > achieved / HBM_PEAK else "hbm",
-            "binding_frac": max(valu_rate / FP64_VALU_PEAK, achieved / HBM_PEAK),
+            "bound": bound,
+            "binding_frac": fracs[bound],
             "hbm_frac": achieved / HBM_PEAK,
-            "kernel": "k_step_lazy (propagate + weight + folded resample gather)" if k1_bytes == 72.0 else "k_propagate_weight",
+            "kernel": ("k_step_lazy (propagate + weight + folded resample gather)" if k1_bytes == 72.0 else
+                       "k_step_lazy<kSrcDraw> (multinomial draws + guide-table search + source gather + propagate + weight)"
+                       if (args.scheme == "multinomial" and not ctx.sharded) else "k_propagate_weight"),
             "achieved": achieved / 1e9,
             "peak": HBM_PEAK / 1e9,
             "unit": "GB/s",
@@ -932,7 +939,12 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
             "algorithmic_bytes_per_launch": k1_bytes * n,
             "fp64_valu": {"lane_instr_per_pair": pair_i, "lane_instr_per_particle": part_i, "achieved_lane_instr_per_s": valu_rate,
                           "peak_lane_instr_per_s": FP64_VALU_PEAK, "frac": valu_rate / FP64_VALU_PEAK},
-            "note": ("FP64-VALU bound at L >= ~16 (fp64_valu.frac is the binding fraction).  " +
+            "line_traffic": ({"bytes_per_launch": traffic, "rate_GBps": line_rate / 1e9, "frac_of_hbm_peak": line_rate / HBM_PEAK,
+                              "note": "PMC bytes per launch / kernel time: 10^6 random guide pairs and 10^6 random 32-byte records move a 128-byte line each "
+                                      "(served by L2 and the Infinity Cache; priced against the 8 TB/s HBM peak); profiles/r04_multinomial_ab.md"}
+                             if line_rate else None),
+            "note": (("bound by cache-line traffic: see line_traffic.  " if bound == "line_traffic" else "") +
+                     "FP64-VALU bound at L >= ~16 (fp64_valu.frac is the binding fraction).  " +
                      ("The working set (~90 B/particle) of 1e6 particles is Infinity-Cache resident, so `traffic` is fabric traffic, not DRAM traffic; "
                       if n <= 2_000_000 else "At this size the working set is several times the 256 MB Infinity Cache: `achieved` is a DRAM rate; ") +
                      "the HBM-bound workload of this line is the `fastslam` leg; profiles/r04_mcl_L_sweep.json shows where MCL turns from HBM- to VALU-bound"),

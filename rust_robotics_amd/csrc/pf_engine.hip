@@ -793,10 +793,10 @@ __global__ void k_est_mail(const Ctl* __restrict__ ctl, const double* __restrict
 }
 
 // The same for a filter whose estimate may be in either form (rr::EstArgs; the multinomial scheme): the plan tiles' partial sums in
-// tile order when the gate stayed shut, else the slot tiles' per-wave sums in est_slots_total's order -- kEstChunks chunks of
-// consecutive entries, each added up from its first entry on, then the chunks in order (the host adds them the same way).
+// tile order when the gate stayed shut, else the slot tiles' per-wave sums in est_slots_total's order -- kEstChunks interleaved
+// chunks (chunk c = entries c, c + kEstChunks, c + 2 kEstChunks, ...: the threads of one pass read consecutive entries), each added
+// up from its first entry on, then the chunks in order (the host adds them the same way).
 constexpr int kEstChunks = 256;
-__host__ __device__ inline uint64_t est_chunk_len(uint64_t n_part) { return (n_part + kEstChunks - 1) / kEstChunks; }
 __global__ __launch_bounds__(kEstChunks) void k_est_mail_any(const Ctl* __restrict__ ctl, const double* __restrict__ plan_partials,
                                                              uint64_t n_tiles, const double* __restrict__ slot_partials, uint64_t n_slot_part,
                                                              HostMail* mail, uint64_t seq) {
@@ -806,17 +806,18 @@ __global__ __launch_bounds__(kEstChunks) void k_est_mail_any(const Ctl* __restri
   const double* __restrict__ part = slots ? slot_partials : plan_partials;
   const uint64_t n_part = slots ? n_slot_part : n_tiles;
   // (plan tiles: ONE chunk holds everything -- the sequential order of k_est_mail and rr_pf_last_step_estimate)
-  const uint64_t G = slots ? est_chunk_len(n_part) : n_part;
-  const uint64_t i0 = (uint64_t)c * G, i1 = i0 + G < n_part ? i0 + G : n_part;
+  const uint64_t first = slots ? (uint64_t)c : 0, stride = slots ? (uint64_t)kEstChunks : 1;
   double cs[4] = {0.0, 0.0, 0.0, 0.0};
-  if (slots || c == 0)
-    for (uint64_t i = i0; i < i1; ++i) {
+  if (slots || c == 0) {
+#pragma unroll 8
+    for (uint64_t i = first; i < n_part; i += stride) {
       const double4 v = *reinterpret_cast<const double4*>(part + 4 * i);
       cs[0] += v.x;
       cs[1] += v.y;
       cs[2] += v.z;
       cs[3] += v.w;
     }
+  }
   for (int k = 0; k < 4; ++k) s_cs[k][c] = cs[k];
   __syncthreads();
   if (c < 4) {
@@ -3917,11 +3918,10 @@ rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]) {
   const double* part = slots ? h->est_slot_partials_host : h->est_partials_host;
   const uint64_t n_part = slots ? n_slot_tiles * (kBlock / rr::kWave) : h->n_tiles;  // (slot tiles: one entry per wave)
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  if (slots) {  // est_slots_total: chunks of consecutive entries, then the chunks in order (k_est_mail_any adds them the same way)
-    const uint64_t G = est_chunk_len(n_part);
+  if (slots) {  // est_slots_total: interleaved chunks, then the chunks in order (k_est_mail_any adds them the same way)
     for (int c = 0; c < kEstChunks; ++c) {
       double cs[4] = {0.0, 0.0, 0.0, 0.0};
-      for (uint64_t t = (uint64_t)c * G; t < std::min<uint64_t>(((uint64_t)c + 1) * G, n_part); ++t)
+      for (uint64_t t = (uint64_t)c; t < n_part; t += kEstChunks)
         for (int k = 0; k < 4; ++k) cs[k] += part[4 * t + k];
       for (int k = 0; k < 4; ++k) acc[k] += cs[k];
     }
