@@ -73,6 +73,10 @@ def test_mcl_every_particle_matches_the_literal_reference(det, ref, n, L):
     assert np.count_nonzero(big) > n // 2
     np.testing.assert_allclose(raw[big], wr[big], rtol=1e-6, atol=0.0)
     assert np.all(raw[~big] <= 1e-249)
+    # ... and below it, down to the edge of the normal range, the two still agree in the logarithm (no garbage hides in the mask)
+    tiny = (~big) & (wr > 1e-300) & (raw > 0.0)
+    if np.any(tiny):
+        assert np.max(np.abs(np.log(raw[tiny]) - np.log(wr[tiny]))) < 1e-5, "masked weights disagree"
     ref.ref_pf_normalize(n, dp(wr))  # the reference's serial left-to-right sum (particle_filter.rs:426-439)
     got = pf.get_particles_array()[:, 4]
     np.testing.assert_allclose(got, wr, rtol=1e-6, atol=1e-12)
@@ -132,3 +136,7 @@ def test_fastslam_every_pair_matches_the_literal_reference(det, ref, n):
     big = pw > 1e-250
     assert np.count_nonzero(big) > n // 2
     np.testing.assert_allclose(gp[big, 0], pw[big], rtol=1e-6, atol=0.0)
+    tiny = (~big) & (pw > 1e-300) & (gp[:, 0] > 0.0)
+    if np.any(tiny):
+        assert np.max(np.abs(np.log(gp[tiny, 0]) - np.log(pw[tiny]))) < 1e-5, "masked weights disagree"
+    print(f"weights compared at 1e-6: {np.count_nonzero(big)} of {n}; in the logarithm: {np.count_nonzero(tiny)}")
