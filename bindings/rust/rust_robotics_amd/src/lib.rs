@@ -234,7 +234,7 @@ impl ParticleFilterLocalizer {
     }
 
     /// Engine extension: enqueue one step without waiting for it; the mean `try_step` would return (:496) is
-    /// produced on the device inside the step's own plan kernel (fused systematic step only).
+    /// produced on the device: inside the step's own plan kernel (systematic scheme) or by the kernel that gathers the drawn sources (multinomial).
     pub fn try_step_async(&mut self, control: &PFControl, observations: &PFMeasurement) -> RoboticsResult<()> {
         let flat = flatten(observations);
         check(unsafe { sys::rr_pf_step_async_estimate(self.h, control.as_ptr(), flat.as_ptr(), observations.len()) })
