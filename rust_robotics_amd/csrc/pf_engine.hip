@@ -9,6 +9,13 @@
 // and the resampling CDF is an integer reduce-then-scan whose value is independent of summation order
 // (include/rr_pf_spec.h).
 //
+// One translation unit in five files: this one (handle, launch logic, the C ABI of the unsharded filter) #includes, in place,
+//   pf_kernels_step.inc      the step kernels of the large filters (k_propagate_weight, k_step_lazy, gathers, moments, mailbox)
+//   pf_kernels_small.inc     k_step_small: the one-workgroup step of small sets, K steps per launch, the resident command loop
+//   pf_kernels_adaptive.inc  p2p gather kernels, the KLD-adaptive resample (wide + k_mcl_adaptive_small), sharded multinomial
+//   pf_sharded_api.inc       the C ABI of the sharded filters (RCCL through dlopen, peer-to-peer, multinomial shards)
+// and shares resample_core.hpp / p2p_core.hpp / resident_core.hpp / rr_common.hpp with fs1_engine.hip.
+//
 // Kernels (one HIP stream per filter, no host synchronisation inside a step):
 //  the fused step (rr_pf_step_async, systematic resampling): 2 launches
 //   k_step_lazy            resolve the previous resample's markers, read x,y,yaw through them, propagate, weigh,
@@ -104,2102 +111,12 @@ struct StepParams {
   int dyn_n;  // KLD-adaptive filter: the particle count is Ctl.n_active (k_propagate_weight only)
 };
 
-// ------------------------------------------------------------------------------------------
-// K1: propagate + weight.  One thread per particle; the observation block (d, lx, ly) x n_obs
-// is staged once per workgroup in LDS and read back with wave-uniform addresses (broadcast).
-// Reads x,y,yaw (24 B), writes x,y,yaw,v,w (40 B).  The per-particle maximum weight is reduced
-// across the wave with shuffles, across waves through LDS, and folded into Ctl with one
-// atomicMax per workgroup (bit pattern of a non-negative double is order preserving).
-template <bool PREDICT, bool WEIGHT, bool EXPLICIT_NOISE, bool OBS_KERNARG>
-__global__ __launch_bounds__(kBlock) void k_propagate_weight(Bufs b, double* __restrict__ w,
-                                                            Ctl* __restrict__ ctl, StepParams p,
-                                                            ObsArg obs_arg,
-                                                            const double* __restrict__ obs_dev,
-                                                            const double* __restrict__ nv,
-                                                            const double* __restrict__ nw) {
-  extern __shared__ double s_obs[];
-  __shared__ double s_wmax[kBlock / rr::kWave];
-  const int tid = threadIdx.x;
-  if (WEIGHT) {
-    for (int i = tid; i < 3 * p.n_obs; i += kBlock) s_obs[i] = OBS_KERNARG ? obs_arg.v[i] : obs_dev[i];
-    __syncthreads();
-  }
-  const int cur = ctl->cur;
-  if (p.dyn_n) p.n = ctl->n_active;
-  double* __restrict__ bx = b.x[cur];
-  double* __restrict__ by = b.y[cur];
-  double* __restrict__ byaw = b.yaw[cur];
-  double* __restrict__ bv = b.v[cur];
-  const uint64_t stride = (uint64_t)gridDim.x * kBlock;
-  uint64_t i = (uint64_t)blockIdx.x * kBlock + tid;
-  double wmax_local = 0.0;
-  // grid-stride over the particles with the next particle's state prefetched while the current
-  // one is being computed (the kernel is FP64-VALU bound; this keeps its HBM reads off the
-  // critical path)
-  double x = 0.0, y = 0.0, yaw = 0.0;
-  if (i < p.n) {
-    x = bx[i];
-    y = by[i];
-    if (PREDICT) yaw = byaw[i];
-  }
-  while (i < p.n) {
-    const uint64_t inext = i + stride;
-    double nx = 0.0, ny = 0.0, nyaw = 0.0;
-    if (inext < p.n) {
-      nx = bx[inext];
-      ny = by[inext];
-      if (PREDICT) nyaw = byaw[inext];
-    }
-    if (PREDICT) {
-      double v, a, c;
-      if (EXPLICIT_NOISE) {
-        a = nv[i];
-        c = nw[i];
-      } else {
-        rr_pf_motion_noise(p.seed, p.step, p.first_gid + i, p.sigma_v, p.sigma_w, &a, &c);
-      }
-      rr_pf_propagate_one(&x, &y, &yaw, &v, p.u0, p.u1, p.dt, a, c);
-      bx[i] = x;
-      by[i] = y;
-      byaw[i] = yaw;
-      bv[i] = v;
-    }
-    if (WEIGHT) {
-      const double wgt = p.lik_mode == RR_LIK_PRODUCT ? rr_pf_weight_product(x, y, s_obs, p.n_obs, p.lik)
-                                                      : rr_pf_weight_fused(x, y, s_obs, p.n_obs, p.lik);
-      w[i] = wgt;
-      if (wgt > wmax_local) wmax_local = wgt;  // NaN and negatives drop out
-    }
-    i = inext;
-    x = nx;
-    y = ny;
-    yaw = nyaw;
-  }
-  if (WEIGHT) {
-    double m = rr::wave_max(wmax_local);
-    if ((tid & 63) == 0) s_wmax[tid >> 6] = m;
-    __syncthreads();
-    if (tid == 0) {
-      double bm = s_wmax[0];
-      for (int k = 1; k < kBlock / rr::kWave; ++k) bm = s_wmax[k] > bm ? s_wmax[k] : bm;
-      if (bm > 0.0) rr::atomic_max_u64(&ctl->wmax_bits, rr_d2u(bm));
-      if (blockIdx.x == 0) ctl->weights_uniform = 0;
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// K1 of the fused step (rr_pf_step_async, systematic resampling): propagate + weight with the
-// previous step's resample gather folded into its loads.  If Ctl.pending is set the last plan
-// kernel left markers instead of moved particles: each workgroup resolves the markers of its
-// 512-slot tiles to source indices (running maximum, rr::resolve_tile) and reads x,y,yaw of slot k
-// from particle idx[k] of the live buffer set, writing the propagated particle to slot k of the
-// OTHER set; k_quantize_reduce (next in the stream) then flips Ctl.cur.  Without a pending
-// resample it runs in place.  This removes a whole 72 B/particle pass over HBM per step.
-//
-// Sharded (rr_pf_shard_step_p2p, StepSrc::kSrcWindow): the markers live in the GLOBAL slot index (rr::resolve_tile_window);
-// the own slots inside the window this shard serves are resolved and read exactly as on one GPU, the few outside it were
-// delivered into this rank's inbox by the peer that serves them (k_push_window) -- such a slot waits, bounded, until the seal
-// of the previous step fits its fields (rr::inbox_take).  Round 2 resolved every served slot in a separate launch
-// (k_resolve_push -> lidx, 7.9 us at 1e6 particles) and waited for a DONE message in a fourth one.
-constexpr unsigned int kInPlace = 0xffffffffu;
-constexpr unsigned kPushGrid = 64;  // workgroups of k_push_window (grid-stride over the foreign tiles: usually a handful)
-
-//
-// Shape of the kernel, each point measured at 1e6 x 32 (A/B on one box, tools/ab_bench.sh):
-//  * ONE 512-slot tile per workgroup, no grid-stride loop.  With the loop every polynomial coefficient of log / sincos /
-//    exp was loop-invariant, the compiler kept them all in registers for the whole kernel (128 VGPRs, 106 SGPRs with
-//    spills into VGPR lanes, 4 waves per SIMD); without it they are materialised where they are used: 52 VGPRs,
-//    8 waves per SIMD, 44.7 -> 37.7 us.
-//  * the likelihood form is a template argument (only one form's code and constants in the kernel);
-//  * the weights of the thread's two rows come from ONE pass over the observation block (rr_pf_weight_fused_rows):
-//    half the LDS reads and two independent chains per wave, -3 us;
-//  * the motion noise (a function of seed, step and slot only) is evaluated before the marker / particle loads are
-//    needed, so the kernel's first microseconds are not spent waiting, -1.3 us;
-//  * the weight maximum goes through rr::atomic_max_u64's look-first form: one same-address atomic per workgroup cost
-//    14.6 us of queueing at L = 1 and 2 us at L = 32.
-//  * PACKED (the lazy MULTINOMIAL resample of one GPU: sources are iid draws, so the reads through `lidx` are random):
-//    the kernel also keeps an array-of-structures mirror {x, y, yaw, v} of the set it writes, and reads a source
-//    particle from the mirror of the live set -- one random 32-byte record instead of three random 8-byte words
-//    from three arrays.  The mirror is only ever read while a resample is pending, and a resample only becomes
-//    pending right after a launch of this kernel has written the mirror of the then-live set.
-// where the sources of a pending resample come from
-enum StepSrc {
-  kSrcMarkers = 0,  // one GPU, systematic: slot-run markers, resolved here (rr::resolve_tile)
-  kSrcLidx = 1,     // one GPU, multinomial: the search kernel left one source index per slot
-  kSrcWindow = 2,   // a shard of the peer-to-peer transport: markers over the global slot index (rr::resolve_tile_window);
-                    // own slots outside the window this shard serves were delivered into the inbox by a peer
-  kSrcDraw = 3      // one GPU, multinomial, the search not run yet: this kernel draws and searches for its own slots
-                    // (mn_guide_search) -- the latency-bound search hides under this kernel's FP64 work instead of being a
-                    // launch of its own (k_resample_guide_mn: 17.7 us at 1e6 particles)
-};
-constexpr size_t kEstSlotWords = 4 * (kBlock / rr::kWave);  // doubles per slot tile of the deferred estimate: one quadruple per wave
-struct WindowArgs {
-  const double* inbox;         // this rank's inbox [4 fields + tag][n]
-  int* err;
-  uint64_t pad;                // marker position of global slot s = s + pad
-  uint64_t wait_seq;           // the tag a peer-served slot must carry: the sequence number of the step being consumed
-  uint64_t timeout_ticks;
-  int n_ranks;                 // 0: nothing to wait for (RCCL transport: an earlier kernel of the stream filled the inbox)
-  // kSrcDraw: the pending multinomial resample's CDF, guide table and draw stream
-  const uint64_t* cdf;
-  const unsigned int* guide;
-  uint64_t n_src;
-  unsigned int rstep;
-  int guide_log2;
-  // every source kind but kSrcWindow: the previous step asked for its estimate in the deferred form (rr::kEstDeferred) -- when its
-  // resample fired (Ctl.pending), this launch adds up the fields of the sources it gathers, per slot tile -> est_partials[tile][4]
-  double* est_partials;
-};
-
-// The multinomial draw of output slot `slot` through the guide table (resample_core.hpp: buckets of the target space, built
-// by k_plan_cdf's markers and k_guide_resolve): two adjacent table entries bracket the answer, the CDF is only read inside
-// the bracket -- not at all when a heavy particle spans the whole bucket.  Same index as the lower bound over the whole CDF
-// (tests: identical to the coarse-table kernel and to the literal walk).
-struct __attribute__((packed, aligned(4))) GuidePair {
-  unsigned int lo, hi;
-};
-__device__ inline uint64_t mn_guide_search(const Ctl* __restrict__ ctl, const uint64_t* __restrict__ cdf,
-                                           const unsigned int* __restrict__ guide, int guide_log2, uint64_t target, uint64_t n_src) {
-  const uint64_t total = ctl->total;
-  const int s = rr::guide_shift(total, guide_log2);
-  const uint64_t bucket = target >> s;
-  const GuidePair g = *reinterpret_cast<const GuidePair*>(guide + bucket);
-  const uint64_t hi = bucket < (total >> s) ? (uint64_t)g.hi : n_src - 1;  // the last bucket ends with the last source
-  uint64_t j = g.lo, end = hi;  // the answer lies in [j, end]: no CDF entry is read when the bracket is one source
-  while (j < end) {
-    const uint64_t mid = j + ((end - j) >> 1);
-    if (cdf[mid] >= target) end = mid;
-    else j = mid + 1;
-  }
-  return j;
-}
-
-// The multinomial draws of one slot tile (slot = tile_base + r * kBlock + tid), the rows' searches in LOCKSTEP: every dependent
-// read of the chain (guide pair -> CDF probes) is issued for all rows before any of them is waited for.  (mn_guide_search per
-// row: the bracket loop's trip count depends on the data, so the second row's chain only started when the first row's had
-// ended: +2.6 us at 1e6 slots.)  Same indices as mn_guide_search.
-__device__ inline void mn_draw_rows(const Ctl* __restrict__ ctl, const uint64_t* __restrict__ cdf, const unsigned int* __restrict__ guide,
-                                    int guide_log2, uint64_t n_src, uint64_t seed, unsigned int rstep, uint64_t first_gid,
-                                    uint64_t tile_base, uint64_t n, unsigned int (&idx)[rr::kResolveRows]) {
-  const int tid = threadIdx.x;
-  const uint64_t total = ctl->total;
-  const int gs = rr::guide_shift(total, guide_log2);
-  uint64_t target[rr::kResolveRows], lo[rr::kResolveRows], hi[rr::kResolveRows];
-#pragma unroll
-  for (int r = 0; r < rr::kResolveRows; ++r) {
-    const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
-    target[r] = k < n ? rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, first_gid + k, seed, rstep, nullptr, k) : 0ull;
-  }
-#pragma unroll
-  for (int r = 0; r < rr::kResolveRows; ++r) {
-    const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
-    lo[r] = hi[r] = 0;
-    if (k < n) {
-      const uint64_t bucket = target[r] >> gs;
-      const GuidePair g = *reinterpret_cast<const GuidePair*>(guide + bucket);
-      lo[r] = g.lo;
-      hi[r] = bucket < (total >> gs) ? (uint64_t)g.hi : n_src - 1;  // the last bucket ends with the last source
-    }
-  }
-  for (;;) {
-    bool open = false;
-#pragma unroll
-    for (int r = 0; r < rr::kResolveRows; ++r) open |= lo[r] < hi[r];
-    if (!__any(open)) break;
-    uint64_t c[rr::kResolveRows], mid[rr::kResolveRows];
-#pragma unroll
-    for (int r = 0; r < rr::kResolveRows; ++r) {
-      mid[r] = lo[r] + ((hi[r] - lo[r]) >> 1);
-      c[r] = lo[r] < hi[r] ? cdf[mid[r]] : 0ull;
-    }
-#pragma unroll
-    for (int r = 0; r < rr::kResolveRows; ++r) {
-      if (lo[r] < hi[r]) {
-        if (c[r] >= target[r]) hi[r] = mid[r];
-        else lo[r] = mid[r] + 1;
-      }
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < rr::kResolveRows; ++r) idx[r] = (unsigned int)lo[r];
-}
-
-// EST: a build that can add up the deferred estimate (WindowArgs.est_partials).  A build of its own because the code's mere presence
-// costs the headline kernel 1.5 us at 1e6 x 32 (six more VGPRs live through the observation loop), executed or not.
-template <bool OBS_KERNARG, int SRC, int LIK, bool PACKED = false, bool EST = false>
-__global__ __launch_bounds__(kBlock, 4) void k_step_lazy(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
-                                                     StepParams p, ObsArg obs_arg,
-                                                     const double* __restrict__ obs_dev,
-                                                     unsigned int* __restrict__ markers,
-                                                     const unsigned int* __restrict__ carry,
-                                                     unsigned int* __restrict__ idx_out,
-                                                     WindowArgs wa, double* pk0, double* pk1) {
-  extern __shared__ double s_obs[];
-  __shared__ double s_wmax[kBlock / rr::kWave];
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 3 * p.n_obs; i += kBlock) s_obs[i] = OBS_KERNARG ? obs_arg.v[i] : obs_dev[i];
-  __syncthreads();
-  const int pending = ctl->pending;
-  const int src = ctl->cur, dst = pending ? src ^ 1 : src;
-  const double* __restrict__ sx = b.x[src];
-  const double* __restrict__ sy = b.y[src];
-  const double* __restrict__ syaw = b.yaw[src];
-  const uint64_t n_tiles = (p.n + rr::kResolveSlots - 1) / rr::kResolveSlots;
-  double wmax_local = 0.0;
-  bool est_now = false;
-  double est_acc[4] = {0.0, 0.0, 0.0, 0.0};
-  const uint64_t tile = blockIdx.x;  // one tile per workgroup: nothing is loop-invariant, so no constant outlives its use
-  if (tile < n_tiles) {
-    unsigned int idx[rr::kResolveRows];
-    const uint64_t tile_base = tile * rr::kResolveSlots;
-    double na[rr::kResolveRows], nc[rr::kResolveRows];
-    // The noise of a slot depends on (seed, step, slot) only: evaluate it first, so that this FP64 work runs while
-    // the first dependent loads of the tile (control word, markers) are in flight and the workgroups of a CU, which
-    // all start together, do not all sit in their load prologue at the same time.
-#pragma unroll
-    for (int r = 0; r < rr::kResolveRows; ++r)
-      rr_pf_motion_noise(p.seed, p.step, p.first_gid + tile_base + (uint64_t)r * kBlock + tid, p.sigma_v, p.sigma_w, &na[r], &nc[r]);
-    // kSrcWindow: positions of the window this shard serves, of this tile's slots
-    uint64_t win_lo = 0, win_hi = 0, pos0 = 0;
-    if (pending && SRC == kSrcLidx) {
-#pragma unroll
-      for (int r = 0; r < rr::kResolveRows; ++r) {
-        const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
-        idx[r] = k < p.n ? markers[k] : 0u;  // `markers` is the lidx array here
-      }
-    } else if (pending && SRC == kSrcDraw) {
-      mn_draw_rows(ctl, wa.cdf, wa.guide, wa.guide_log2, wa.n_src, p.seed, wa.rstep, p.first_gid, tile_base, p.n, idx);
-#pragma unroll
-      for (int r = 0; r < rr::kResolveRows; ++r) {
-        const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
-        if (k < p.n && idx_out) idx_out[k] = idx[r];
-      }
-    } else if (pending && SRC == kSrcWindow) {
-      const uint64_t own0 = p.first_gid + wa.pad;  // position of own slot 0: a multiple of kResolveSlots
-      win_lo = ctl->served_first + wa.pad;
-      win_hi = win_lo + ctl->served_count;
-      pos0 = own0 + tile_base;
-      rr::resolve_tile_window(markers, carry, own0 / rr::kResolveSlots + tile, win_lo, win_hi, own0, own0 + p.n, idx);
-      const uint64_t pos1 = pos0 + rr::kResolveSlots < own0 + p.n ? pos0 + rr::kResolveSlots : own0 + p.n;
-      (void)pos1;  // (a slot a peer serves waits for its own delivery below: the seal plane of the inbox)
-    } else if (pending) {
-      rr::resolve_tile(markers, carry, p.n, tile, idx);
-    } else {
-#pragma unroll
-      for (int r = 0; r < rr::kResolveRows; ++r) idx[r] = (unsigned int)(tile_base + (uint64_t)r * kBlock + tid);
-    }
-    // issue every row's loads before the (long) arithmetic of the first row
-    double x[rr::kResolveRows], y[rr::kResolveRows], yaw[rr::kResolveRows];
-    est_now = EST && SRC != kSrcWindow && wa.est_partials != nullptr && pending;
-    double v_src[rr::kResolveRows];  // the sources' v: only the estimate reads it (propagate overwrites v)
-#pragma unroll
-    for (int r = 0; r < rr::kResolveRows; ++r) {
-      const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
-      x[r] = y[r] = yaw[r] = v_src[r] = 0.0;
-      if (k < p.n) {
-        const uint64_t j = idx[r];
-        if (SRC == kSrcWindow && pending && (pos0 + (uint64_t)r * kBlock + tid < win_lo || pos0 + (uint64_t)r * kBlock + tid >= win_hi)) {
-          // delivered by a peer into this rank's inbox [4 fields + tag][n]: wait (bounded) for THIS slot's tag of the step
-          // whose resample is being consumed, then read its fields.  (n_ranks == 0: the RCCL transport -- an earlier kernel
-          // of this stream filled the inbox.)
-          double f[4];
-          (void)rr::inbox_take(wa.inbox, p.n, k, wa.n_ranks > 0 ? wa.wait_seq : (uint64_t)0, wa.timeout_ticks, wa.err, f);
-          x[r] = f[0];
-          y[r] = f[1];
-          yaw[r] = f[2];
-        } else if (PACKED && pending) {
-          const double4 rec = *reinterpret_cast<const double4*>((src ? pk1 : pk0) + 4 * j);
-          x[r] = rec.x;
-          y[r] = rec.y;
-          yaw[r] = rec.z;
-          v_src[r] = rec.w;
-        } else {
-          x[r] = sx[j];
-          y[r] = sy[j];
-          yaw[r] = syaw[j];
-          if (EST && est_now) v_src[r] = b.v[src][j];
-        }
-      }
-    }
-    if (EST && est_now) {  // the mean of the resampled set, before it is propagated: the thread's rows now, the wave's sums at the end
-      double f[4][rr::kResolveRows];
-#pragma unroll
-      for (int r = 0; r < rr::kResolveRows; ++r) {
-        f[0][r] = x[r];
-        f[1][r] = y[r];
-        f[2][r] = yaw[r];
-        f[3][r] = v_src[r];
-      }
-      rr::est_rows_sum<rr::kResolveRows>(f, est_acc);
-    }
-#pragma unroll
-    for (int r = 0; r < rr::kResolveRows; ++r) {
-      const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
-      if (k < p.n) {
-        double v;
-        rr_pf_propagate_one(&x[r], &y[r], &yaw[r], &v, p.u0, p.u1, p.dt, na[r], nc[r]);
-        b.x[dst][k] = x[r];
-        b.y[dst][k] = y[r];
-        b.yaw[dst][k] = yaw[r];
-        b.v[dst][k] = v;
-        if (PACKED) *reinterpret_cast<double4*>((dst ? pk1 : pk0) + 4 * k) = make_double4(x[r], y[r], yaw[r], v);
-        if (SRC == kSrcLidx) {
-          if (pending) markers[k] = kInPlace;
-        } else if (SRC == kSrcMarkers && pending && idx_out) {
-          idx_out[k] = idx[r];
-        }
-      }
-    }
-    double wgt[rr::kResolveRows];
-    if (LIK == RR_LIK_PRODUCT) {
-#pragma unroll
-      for (int r = 0; r < rr::kResolveRows; ++r) wgt[r] = rr_pf_weight_product(x[r], y[r], s_obs, p.n_obs, p.lik);
-    } else {
-      // one pass over the observation block for the thread's rows, independent chains per row (a row past the end
-      // of the set weighs a dummy particle at the origin and stores nothing)
-      rr_pf_weight_fused_rows<rr::kResolveRows>(x, y, s_obs, p.n_obs, p.lik, wgt);
-    }
-#pragma unroll
-    for (int r = 0; r < rr::kResolveRows; ++r) {
-      const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
-      if (k < p.n) {
-        w[k] = wgt[r];
-        if (wgt[r] > wmax_local) wmax_local = wgt[r];
-      }
-    }
-  }
-  if (EST && est_now) rr::est_wave_store<kBlock>(est_acc, wa.est_partials, tile);
-  double m = rr::wave_max(wmax_local);
-  if ((tid & 63) == 0) s_wmax[tid >> 6] = m;
-  __syncthreads();
-  if (tid == 0) {
-    double bm = s_wmax[0];
-    for (int k = 1; k < kBlock / rr::kWave; ++k) bm = s_wmax[k] > bm ? s_wmax[k] : bm;
-    if (bm > 0.0) rr::atomic_max_u64(&ctl->wmax_bits, rr_d2u(bm));
-    if (blockIdx.x == 0) ctl->weights_uniform = 0;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// K5: resample gather.  The plan kernel has already flipped Ctl.cur, so the particles are read
-// from buffer set cur^1 and written to set cur (or to `staging` for the sharded exchange).
-struct GatherArgs {
-  uint64_t n_src;       // CDF entries (particles of this shard)
-  uint64_t first_slot;  // global index of output slot 0 handled here
-  uint64_t n_slots;
-  uint64_t seed;
-  unsigned int rstep;
-  int scheme;
-  int to_staging;  // 1 => write n_slots x (x, y, yaw, v) records to `staging`
-};
-
-__device__ inline void copy_particle(const Bufs& b, int src, int dst, uint64_t j, uint64_t k, bool to_staging,
-                                     double* __restrict__ staging) {
-  const double x = b.x[src][j], y = b.y[src][j], yaw = b.yaw[src][j], v = b.v[src][j];
-  if (to_staging) {  // one contiguous 32-byte record per slot
-    staging[4 * k] = x;
-    staging[4 * k + 1] = y;
-    staging[4 * k + 2] = yaw;
-    staging[4 * k + 3] = v;
-  } else {
-    b.x[dst][k] = x;
-    b.y[dst][k] = y;
-    b.yaw[dst][k] = yaw;
-    b.v[dst][k] = v;
-  }
-}
-
-// Systematic (fastslam1.rs:219-231): the plan kernel left one marker per source with offspring
-// (resample_core.hpp "WITHOUT any search"); resolve them to source indices with a running maximum
-// per 1024-slot tile and move the particles in the same pass.  Reads 4 B marker + 32 B particle,
-// writes 32 B particle (+ 4 B marker clear) per slot; no CDF array, no binary search.
-__global__ __launch_bounds__(kBlock) void k_resolve_gather(Bufs b, const Ctl* __restrict__ ctl,
-                                                          unsigned int* __restrict__ markers,
-                                                          const unsigned int* __restrict__ carry,
-                                                          unsigned int* __restrict__ idx_out,
-                                                          double* __restrict__ staging, uint64_t n_slots,
-                                                          int to_staging, int lazy) {
-  // eager: the plan kernel flipped Ctl.cur already (read cur^1, write cur), runs iff fired;
-  // lazy (materialise a pending resample for an accessor): read cur, write cur^1, k_settle flips
-  if (lazy ? !ctl->pending : !ctl->fired) return;
-  unsigned int idx[rr::kResolveRows];
-  rr::resolve_tile(markers, carry, n_slots, blockIdx.x, idx);
-  const int dst = lazy ? ctl->cur ^ 1 : ctl->cur, src = dst ^ 1;
-  const uint64_t tile_base = (uint64_t)blockIdx.x * rr::kResolveSlots;
-#pragma unroll
-  for (int r = 0; r < rr::kResolveRows; ++r) {
-    const uint64_t k = tile_base + (uint64_t)r * kBlock + threadIdx.x;
-    if (k < n_slots) {
-      copy_particle(b, src, dst, idx[r], k, to_staging != 0, staging);
-      if (idx_out) idx_out[k] = idx[r];
-    }
-  }
-}
-
-__global__ void k_settle(Ctl* ctl) {
-  if (ctl->pending) {
-    ctl->cur ^= 1;
-    ctl->pending = 0;
-  }
-}
-
-// Multinomial (particle_filter.rs:455-470): independent draws, one thread per output slot.  A
-// lower bound over the whole CDF is ~20 DEPENDENT probes of HBM/L2 per draw (137 us for 1e6
-// draws); instead every workgroup stages the coarse table (every 2^coarse_log2-th CDF entry,
-// <= 144 KB: 64-entry windows up to 1.18e6 particles) in LDS, searches that, and finishes inside one
-// 2^coarse_log2-entry window of the full CDF (6 probes over 4 cache lines at 64 entries).
-__global__ __launch_bounds__(1024) void k_resample_gather_mn(Bufs b, const Ctl* __restrict__ ctl,
-                                                              const uint64_t* __restrict__ cdf,
-                                                              const uint64_t* __restrict__ coarse, int coarse_log2,
-                                                              uint64_t n_coarse,
-                                                              const double* __restrict__ r_explicit,
-                                                              unsigned int* __restrict__ idx_out,
-                                                              unsigned int* __restrict__ lidx_out, GatherArgs a) {
-  if (!ctl->fired) return;
-  extern __shared__ uint64_t s_coarse[];
-  for (uint64_t i = threadIdx.x; i < n_coarse; i += blockDim.x) s_coarse[i] = coarse[i];
-  __syncthreads();
-  const int dst = ctl->cur, src = dst ^ 1;
-  // grid-stride: a workgroup stages the coarse table once and serves several blocks of slots
-  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < a.n_slots; k += (uint64_t)gridDim.x * blockDim.x) {
-    const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, a.first_slot + k, a.seed, a.rstep, r_explicit, k);
-    const uint64_t blk = rr_lower_bound_u64(s_coarse, n_coarse, target);  // first window whose last entry >= target
-    const uint64_t lo = blk << coarse_log2;
-    const uint64_t len = lo + (1ull << coarse_log2) <= a.n_src ? (1ull << coarse_log2) : a.n_src - lo;
-    const uint64_t j = lo + rr_lower_bound_u64(cdf + lo, len, target);
-    if (lidx_out) lidx_out[k] = (unsigned int)j;  // lazy: the next propagate kernel reads through it
-    else copy_particle(b, src, dst, j, k, false, nullptr);
-    if (idx_out) idx_out[k] = (unsigned int)j;
-  }
-}
-
-// The same draws through the guide table (mn_guide_search): no LDS table to stage, one draw per thread.
-__global__ __launch_bounds__(kBlock) void k_resample_guide_mn(Bufs b, const Ctl* __restrict__ ctl,
-                                                             const uint64_t* __restrict__ cdf,
-                                                             const unsigned int* __restrict__ guide, int guide_log2,
-                                                             const double* __restrict__ r_explicit,
-                                                             unsigned int* __restrict__ idx_out,
-                                                             unsigned int* __restrict__ lidx_out, GatherArgs a) {
-  if (!ctl->fired) return;
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= a.n_slots) return;
-  const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, a.first_slot + k, a.seed, a.rstep, r_explicit, k);
-  const uint64_t j = mn_guide_search(ctl, cdf, guide, guide_log2, target, a.n_src);
-  const int dst = ctl->cur, src = dst ^ 1;
-  if (lidx_out) lidx_out[k] = (unsigned int)j;  // lazy: the next propagate kernel reads through it
-  else copy_particle(b, src, dst, j, k, false, nullptr);
-  if (idx_out) idx_out[k] = (unsigned int)j;
-}
-
-// The synchronous try_step of a large multinomial filter (rr_pf_step) needs the resampled set's mean NOW, not when the next step
-// moves the particles: the draws are searched here -- per slot tile, rows in lockstep, exactly k_step_lazy<kSrcDraw>'s search --,
-// the source indices go to `lidx` (the next step reads through them instead of searching again) and the sources' fields, read out
-// of the packed mirror, into the deferred estimate's per-wave sums (rr::est_rows_sum / est_wave_store: the bits
-// rr_pf_step_async_estimate + rr_pf_last_step_estimate produce).
-__global__ __launch_bounds__(kBlock) void k_mn_search_est(const Ctl* __restrict__ ctl, const uint64_t* __restrict__ cdf,
-                                                         const unsigned int* __restrict__ guide, int guide_log2, GatherArgs a,
-                                                         unsigned int* __restrict__ idx_out, unsigned int* __restrict__ lidx_out,
-                                                         const double* __restrict__ pk0, const double* __restrict__ pk1,
-                                                         double* __restrict__ est_partials) {
-  if (!ctl->fired) return;
-  const int tid = threadIdx.x;
-  const uint64_t tile_base = (uint64_t)blockIdx.x * rr::kResolveSlots;
-  unsigned int idx[rr::kResolveRows];
-  mn_draw_rows(ctl, cdf, guide, guide_log2, a.n_src, a.seed, a.rstep, a.first_slot, tile_base, a.n_slots, idx);
-  const double* __restrict__ pk = ctl->cur ? pk1 : pk0;  // (the lazy resample has not flipped Ctl.cur: the sources are the live set)
-  double f[4][rr::kResolveRows];
-#pragma unroll
-  for (int r = 0; r < rr::kResolveRows; ++r) {
-    const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
-    f[0][r] = f[1][r] = f[2][r] = f[3][r] = 0.0;
-    if (k < a.n_slots) {
-      const double4 rec = *reinterpret_cast<const double4*>(pk + 4 * (uint64_t)idx[r]);
-      f[0][r] = rec.x;
-      f[1][r] = rec.y;
-      f[2][r] = rec.z;
-      f[3][r] = rec.w;
-      lidx_out[k] = idx[r];
-      if (idx_out) idx_out[k] = idx[r];
-    }
-  }
-  double acc[4];
-  rr::est_rows_sum<rr::kResolveRows>(f, acc);
-  rr::est_wave_store<kBlock>(acc, est_partials, blockIdx.x);
-}
-
-// sharded adopt: unpack the received n x (x, y, yaw, v) records into the live buffer set (the
-// plan kernel already made it the other one)
-// slots [self_lo, self_hi) are the ones this rank serves to ITSELF: their records are taken straight from the send
-// buffer (`in_self`, record 0 = slot self_lo) instead of travelling through a send / receive to the same rank
-__global__ __launch_bounds__(kBlock) void k_adopt(Bufs b, const Ctl* __restrict__ ctl,
-                                                 const double* __restrict__ in, uint64_t n,
-                                                 const double* __restrict__ in_self, uint64_t self_lo, uint64_t self_hi) {
-  if (!ctl->fired) return;
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= n) return;
-  const int dst = ctl->cur;
-  const double* __restrict__ r = (k >= self_lo && k < self_hi) ? in_self + 4 * (k - self_lo) : in + 4 * k;
-  b.x[dst][k] = r[0];
-  b.y[dst][k] = r[1];
-  b.yaw[dst][k] = r[2];
-  b.v[dst][k] = r[3];
-}
-
-// ------------------------------------------------------------------------------------------
-// K7: weighted moments about the shift point p0 = particle 0 of the live set (always inside
-// the cloud, so the one-pass covariance does not cancel): sum w, sum w d, sum w d d^T with
-// d = p - p0.  Grid-stride, 15 accumulators per thread, wave shuffle + LDS, per-block partials
-// combined by k_moments_final in block order.  force_uniform => w_i = 1.
-__global__ __launch_bounds__(kBlock) void k_moments(Bufs b, const double* __restrict__ w,
-                                                   const Ctl* __restrict__ ctl, uint64_t n,
-                                                   int force_uniform, double* __restrict__ partials) {
-  __shared__ double s_acc[kBlock / rr::kWave][kNumMoments];
-  const int cur = ctl->cur;
-  const bool uniform = force_uniform || ctl->weights_uniform;
-  const double p0x = b.x[cur][0], p0y = b.y[cur][0], p0a = b.yaw[cur][0], p0v = b.v[cur][0];
-  double acc[kNumMoments];
-#pragma unroll
-  for (int k = 0; k < kNumMoments; ++k) acc[k] = 0.0;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n;
-       i += (uint64_t)gridDim.x * kBlock) {
-    const double wi = uniform ? 1.0 : w[i];
-    const double d0 = b.x[cur][i] - p0x, d1 = b.y[cur][i] - p0y, d2 = b.yaw[cur][i] - p0a, d3 = b.v[cur][i] - p0v;
-    const double w0 = wi * d0, w1 = wi * d1, w2 = wi * d2, w3 = wi * d3;
-    acc[0] += wi;
-    acc[1] += w0; acc[2] += w1; acc[3] += w2; acc[4] += w3;
-    acc[5] += w0 * d0; acc[6] += w0 * d1; acc[7] += w0 * d2; acc[8] += w0 * d3;
-    acc[9] += w1 * d1; acc[10] += w1 * d2; acc[11] += w1 * d3;
-    acc[12] += w2 * d2; acc[13] += w2 * d3;
-    acc[14] += w3 * d3;
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int k = 0; k < kNumMoments; ++k) {
-    double s = rr::wave_sum(acc[k]);
-    if (lane == 0) s_acc[wv][k] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x < kNumMoments) {
-    double s = 0.0;
-    for (int k = 0; k < kBlock / rr::kWave; ++k) s += s_acc[k][threadIdx.x];
-    partials[(uint64_t)blockIdx.x * kNumMoments + threadIdx.x] = s;
-  }
-}
-
-// Host-visible mailbox of a filter (pinned, host-coherent memory): the synchronous try_step of a small filter reads the
-// estimate the kernel wrote there instead of paying two device-to-host copies and a stream synchronisation (~20 us) for
-// four doubles; the host polls `seq`.
-struct HostMail {
-  double est[4];
-  uint64_t flags;  // k_est_mail: != 0 => Ctl holds something the host has to look at (a degraded plan) -- take the long way
-  uint64_t seq;
-};
-// one wave per moment: lanes stride over the per-block partials (fixed order per lane), then a
-// shuffle tree -- deterministic for a given grid.  mail != null: the estimate (rr_pf_estimate: shift point + first moments / W,
-// formed as compute_moments forms it on the host) also goes to the host mailbox, stamped `seq`; flags != 0 when the weights do
-// not sum to a positive finite number (the host then takes the uniform-weights retry of particle_filter.rs:433-438)
-__global__ __launch_bounds__(kNumMoments * 64) void k_moments_final(Bufs b, Ctl* __restrict__ ctl,
-                                                                   const double* __restrict__ partials,
-                                                                   int n_blocks, HostMail* __restrict__ mail, uint64_t seq) {
-  __shared__ double s_m[kNumMoments];
-  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double s = 0.0;
-  for (int j = lane; j < n_blocks; j += 64) s += partials[j * kNumMoments + k];
-  s = rr::wave_sum(s);
-  if (lane == 0) {
-    ctl->moments[k] = s;
-    s_m[k] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int cur = ctl->cur;
-    const double p0[4] = {b.x[cur][0], b.y[cur][0], b.yaw[cur][0], b.v[cur][0]};
-    for (int q = 0; q < 4; ++q) ctl->shift_point[q] = p0[q];
-    if (mail) {
-      const double W = s_m[0];
-      const bool ok = W > 0.0 && W < INFINITY;
-      for (int q = 0; q < 4; ++q)
-        __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[q]), (uint64_t)__double_as_longlong(p0[q] + s_m[1 + q] / W), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(&mail->flags, (uint64_t)(ok ? 0 : 1) | ((uint64_t)(ctl->grid_timeout != 0) << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// SMALL particle sets: the whole step -- and K of them -- in ONE launch of ONE workgroup.
-// Every caller in the reference runs 100 - 1200 particles (headless_localizers.rs:56, render_gif_particle_filter.rs:77-79,
-// playground/src/localization.rs:58-66, tests/unified_filter_comparison.rs:286-295).  At that size the fused step of the
-// large filters (2 launches, 5 for the multinomial resampler) is nothing but launch latency: 16 us a step for 2 us of work.
-// Here the particles live in REGISTERS from the first step of the launch to the last (thread t owns the R consecutive slots
-// [t R, t R + R), R = 1 / 2 / 4 for N <= 512 / 1024 / 2048), the maximum and the integer sums are workgroup reductions, the
-// resample runs through LDS (systematic: slot-run markers + running maximum, exactly the large kernels' scheme; multinomial:
-// the integer CDF and one binary search per slot), the gather is an LDS round trip, and the mean try_step returns
-// (particle_filter.rs:488-497) is a workgroup sum.  Same per-element arithmetic (include/rr_pf_spec.h), same Philox
-// counters, same integer image: bit-identical to the large path and to the D-spec (tests/test_gpu_small_n.py).
-// rr_pf_step_many hands K controls and observation blocks over in one buffer; the single-step entry points use K = 1 with the
-// observations in the launch packet.
-constexpr uint64_t kSmallMaxParticles = 2048;
-
-struct SmallArgs {
-  uint64_t n;
-  uint64_t seed;
-  unsigned int step0, rstep0;
-  int n_obs, K;
-  int gate, scheme;       // rr_resample_gate, rr_resample_scheme
-  double neff_threshold;  // N * resample_threshold
-  double dt, sigma_v, sigma_w;
-  double u0, u1;          // K == 1: the control (else in steps_in)
-  rr_pf_lik lik;
-  int want_est;
-  int inputs_in_kernarg;  // K == 1 and the observations fit the launch packet
-  uint64_t mail_seq;      // != 0: the last step's estimate also goes to the host mailbox, stamped with this number
-  rr::ResidentArgs res;   // res.on: the kernel stays and serves one step per command of the ring (resident_core.hpp); K is ignored
-};
-
-constexpr int kEstRing = 32;  // per-step estimates of rr_pf_step_many gather in LDS and leave in blocks of this many steps
-
-// The synchronous try_step of a LARGE filter (rr_pf_step, fused systematic step): the step's estimate is the sum of the plan
-// kernel's per-tile partial sums in tile order, divided by Ctl.est_denom -- formed here exactly as rr_pf_last_step_estimate
-// forms it on the host (same order, same operations) and left in the mailbox, so the host polls a stamp instead of copying
-// 16 KB of partial sums and Ctl back behind a stream synchronisation (~20 us of a 70 us synchronous step at 1e6 particles).
-__global__ void k_est_mail(const Ctl* __restrict__ ctl, const double* __restrict__ partials, uint64_t n_tiles,
-                           HostMail* __restrict__ mail, uint64_t seq) {
-  // the sums are serial (tile order), the loads must not be: stage 512 tiles at a time in LDS with all threads
-  constexpr int kStage = 512;
-  __shared__ double s_part[4 * kStage];
-  const int k = threadIdx.x;
-  double acc = 0.0;
-  for (uint64_t t0 = 0; t0 < n_tiles; t0 += kStage) {
-    const uint64_t m = n_tiles - t0 < (uint64_t)kStage ? n_tiles - t0 : (uint64_t)kStage;
-    __syncthreads();
-    for (uint64_t i = threadIdx.x; i < 4 * m; i += blockDim.x) s_part[i] = partials[4 * t0 + i];
-    __syncthreads();
-    if (k < 4)
-      for (uint64_t t = 0; t < m; ++t) acc += s_part[4 * t + k];
-  }
-  if (k < 4) {
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[k]), (uint64_t)__double_as_longlong(acc / ctl->est_denom), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  if (k == 0) __hip_atomic_store(&mail->flags, (uint64_t)(ctl->grid_timeout != 0) | ((uint64_t)(ctl->est_step == 0) << 1), __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_SYSTEM);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (k == 0) __hip_atomic_store(&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// The same for a filter whose estimate may be in either form (rr::EstArgs; the multinomial scheme): the plan tiles' partial sums in
-// tile order when the gate stayed shut, else the slot tiles' per-wave sums in est_slots_total's order -- kEstChunks interleaved
-// chunks (chunk c = entries c, c + kEstChunks, c + 2 kEstChunks, ...: the threads of one pass read consecutive entries), each added
-// up from its first entry on, then the chunks in order (the host adds them the same way).
-constexpr int kEstChunks = 256;
-__global__ __launch_bounds__(kEstChunks) void k_est_mail_any(const Ctl* __restrict__ ctl, const double* __restrict__ plan_partials,
-                                                             uint64_t n_tiles, const double* __restrict__ slot_partials, uint64_t n_slot_part,
-                                                             HostMail* mail, uint64_t seq) {
-  __shared__ double s_cs[4][kEstChunks];
-  const int c = threadIdx.x;
-  const bool slots = ctl->est_kind == rr::kEstSlotTiles;
-  const double* __restrict__ part = slots ? slot_partials : plan_partials;
-  const uint64_t n_part = slots ? n_slot_part : n_tiles;
-  // (plan tiles: ONE chunk holds everything -- the sequential order of k_est_mail and rr_pf_last_step_estimate)
-  const uint64_t first = slots ? (uint64_t)c : 0, stride = slots ? (uint64_t)kEstChunks : 1;
-  double cs[4] = {0.0, 0.0, 0.0, 0.0};
-  if (slots || c == 0) {
-#pragma unroll 8
-    for (uint64_t i = first; i < n_part; i += stride) {
-      const double4 v = *reinterpret_cast<const double4*>(part + 4 * i);
-      cs[0] += v.x;
-      cs[1] += v.y;
-      cs[2] += v.z;
-      cs[3] += v.w;
-    }
-  }
-  for (int k = 0; k < 4; ++k) s_cs[k][c] = cs[k];
-  __syncthreads();
-  if (c < 4) {
-    double acc = 0.0;
-    if (slots)
-      for (int q = 0; q < kEstChunks; ++q) acc += s_cs[c][q];
-    else
-      acc = s_cs[c][0];
-    __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[c]), (uint64_t)__double_as_longlong(acc / ctl->est_denom), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  if (c == 0) __hip_atomic_store(&mail->flags, (uint64_t)(ctl->grid_timeout != 0) | ((uint64_t)(ctl->est_step == 0) << 1), __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_SYSTEM);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (c == 0) __hip_atomic_store(&mail->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// workgroup-wide helpers of the small kernel (kSmallBlock threads); every thread gets the result
-template <int BLOCK>
-__device__ inline double small_block_max(double v, double* s_red) {
-  const int tid = threadIdx.x;
-  const double m = rr::wave_max(v);
-  __syncthreads();
-  if ((tid & 63) == 0) s_red[tid >> 6] = m;
-  __syncthreads();
-  double r = s_red[0];
-#pragma unroll
-  for (int k = 1; k < BLOCK / rr::kWave; ++k) r = s_red[k] > r ? s_red[k] : r;
-  return r;
-}
-// four sums at once (the estimate): DPP inside the waves, one LDS exchange
-template <int BLOCK>
-__device__ inline void small_block_sum4(double (&v)[4], double* s_red4 /* [4][BLOCK / 64] */) {
-  constexpr int W = BLOCK / rr::kWave;
-  const int tid = threadIdx.x;
-  double m[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) m[k] = rr::wave_sum_dpp(v[k]);
-  __syncthreads();
-  if ((tid & 63) == 63) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) s_red4[k * W + (tid >> 6)] = m[k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    double r = 0.0;
-#pragma unroll
-    for (int q = 0; q < W; ++q) r += s_red4[k * W + q];
-    v[k] = r;
-  }
-}
-
-// instrumented build (make timeline): 100 MHz stamps of a resident step's phases, returned in rsp[8 .. 15] (tools/resident_timeline.py)
-#if defined(RR_PLAN_TIMELINE)
-#define RR_RES_TL(K_) do { if (resident && threadIdx.x == 0) res_tl[(K_)] = wall_clock64(); } while (0)
-#else
-#define RR_RES_TL(K_) do { } while (0)
-#endif
-template <int BLOCK, int R, int LIK>
-__global__ __launch_bounds__(BLOCK) void k_step_small(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl, SmallArgs a,
-                                                            ObsArg obs_arg, const double* __restrict__ steps_in,
-                                                            unsigned int* __restrict__ idx_out, double* __restrict__ est_out,
-                                                            double* __restrict__ est_partials, HostMail* mail,
-                                                            rr::ResidentRing* __restrict__ ring) {
-  // [3 n_obs] observations | [4][n] gather fields | [n + 1] markers (u32) or [n] CDF (u64);
-  // resident: [payload_cap] command payload (u0, u1, observations) in front instead of the observations
-  extern __shared__ double s_dyn[];
-  constexpr int W = BLOCK / rr::kWave;
-  __shared__ uint64_t s_u[4 * W];
-  __shared__ double s_red[4 * W];
-  __shared__ unsigned int s_mx[W];
-  __shared__ double s_ring[kEstRing * 4];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint64_t n = a.n;
-  const bool resident = a.res.on != 0;
-  __shared__ int s_hdr[2];
-  double* const s_obs = resident ? s_dyn + 2 : s_dyn;
-  double* const s_f = s_dyn + (resident ? (size_t)a.res.payload_cap : 3 * (size_t)a.n_obs);
-  uint64_t* const s_cdf = reinterpret_cast<uint64_t*>(s_f + 4 * n);
-  unsigned int* const s_mark = reinterpret_cast<unsigned int*>(s_f + 4 * n);
-  const int cur = ctl->cur;
-  const uint64_t k0 = (uint64_t)tid * R;
-  double x[R], y[R], yaw[R], v[R], wgt[R];
-  unsigned int last_idx[R];
-#pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const uint64_t k = k0 + j;
-    x[j] = k < n ? b.x[cur][k] : 0.0;
-    y[j] = k < n ? b.y[cur][k] : 0.0;
-    yaw[j] = k < n ? b.yaw[cur][k] : 0.0;
-    v[j] = k < n ? b.v[cur][k] : 0.0;
-    wgt[j] = 0.0;
-    last_idx[j] = (unsigned int)k;
-  }
-  // what the last step leaves in Ctl (thread 0 writes it once, after the loop)
-  int c_usable = 0, c_mode = rr::kImageUniform, c_shift = 0, c_fired = 0, any_fired = 0;
-  uint64_t c_total = 0;
-  u128 c_q2 = {0, 0};
-  double c_wmax = 0.0, c_rho = 0.0, c_est[4] = {0.0, 0.0, 0.0, 0.0}, c_den = 1.0;
-  rr_sys_plan c_plan = {};
-#if defined(RR_PLAN_TIMELINE)
-  uint64_t res_tl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-  int n_obs = a.n_obs, steps_done = 0, res_guess = 3 + 3 * a.n_obs < 64 ? 3 + 3 * a.n_obs : 64, res_last_op = rr::kResOpNone;
-  const uint64_t res_deadline = resident ? wall_clock64() + a.res.life_ticks : 0;
-  for (int s = 0; resident || s < a.K; ++s) {
-    // ---- inputs of this step
-    double u0 = a.u0, u1 = a.u1;
-    // the step's random numbers are functions of (seed, step counters, slot) alone -- not of the state, not of the inputs: a
-    // resident incarnation draws them BEFORE it waits for the command, in time the host spends turning the last answer around
-    // (the Philox rounds, the logarithm and the sine/cosine of the Box-Muller pair are ~40 % of a small step's dependent chain)
-    double pre_na[R], pre_nc[R], pre_r[R];
-    if (resident) {
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        double dummy;
-        rr_pf_motion_noise(a.seed, a.step0 + (unsigned int)s, k0 + j, a.sigma_v, a.sigma_w, &pre_na[j], &pre_nc[j]);
-        // multinomial: this slot's draw; systematic: the one offset (index 0 of the stream), the same in every slot
-        rr_uniform2(a.seed, RR_STREAM_RESAMPLE, a.rstep0 + (unsigned int)s, a.scheme == RR_RESAMPLE_SYSTEMATIC ? 0ull : k0 + j, &pre_r[j], &dummy);
-      }
-    }
-    RR_RES_TL(0);  // random numbers drawn, about to wait
-    if (resident) {  // wait for the host's next command; anything but a step ends this incarnation
-      res_last_op = rr::resident_fetch<BLOCK>(ring, a.res.first_seq + (uint64_t)s, a.res.idle_ticks, res_deadline, a.res.payload_cap,
-                                              res_guess, s_dyn, s_hdr);
-      if (res_last_op != rr::kResOpStep) break;
-      n_obs = (s_hdr[1] - 2) / 3;
-      u0 = s_dyn[0];
-      u1 = s_dyn[1];
-    } else {
-      __syncthreads();
-      if (a.inputs_in_kernarg) {
-        for (int i = tid; i < 3 * n_obs; i += BLOCK) s_obs[i] = obs_arg.v[i];
-      } else {
-        const double* in = steps_in + (size_t)s * (2 + 3 * (size_t)n_obs);
-        u0 = in[0];
-        u1 = in[1];
-        for (int i = tid; i < 3 * n_obs; i += BLOCK) s_obs[i] = in[2 + i];
-      }
-      __syncthreads();
-    }
-    steps_done = s + 1;
-    RR_RES_TL(1);  // command here
-    // ---- propagate + weight (particle_filter.rs:279-296, :310-329)
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-      double na, nc;
-      if (resident) {
-        na = pre_na[j];
-        nc = pre_nc[j];
-      } else {
-        rr_pf_motion_noise(a.seed, a.step0 + (unsigned int)s, k0 + j, a.sigma_v, a.sigma_w, &na, &nc);
-      }
-      rr_pf_propagate_one(&x[j], &y[j], &yaw[j], &v[j], u0, u1, a.dt, na, nc);
-    }
-    if (LIK == RR_LIK_PRODUCT) {
-#pragma unroll
-      for (int j = 0; j < R; ++j) wgt[j] = rr_pf_weight_product(x[j], y[j], s_obs, n_obs, a.lik);
-    } else {
-      rr_pf_weight_fused_rows<R>(x, y, s_obs, n_obs, a.lik, wgt);
-    }
-    double wl = 0.0;
-#pragma unroll
-    for (int j = 0; j < R; ++j)
-      if (k0 + j < n && wgt[j] > wl) wl = wgt[j];  // NaN and negatives drop out
-    RR_RES_TL(2);  // propagated, weighted
-    const double wmax = small_block_max<BLOCK>(wl, s_red);
-    RR_RES_TL(3);  // maximum
-    // ---- integer image, sums (resample_core.hpp: quantize_reduce_tile / tile_scan)
-    const bool usable = wmax > 0.0 && wmax < INFINITY;
-    const int mode = usable ? (int)rr::kImageWeights : (int)rr::kImageUniform;  // PF / MCL: sum w <= 0 => uniform (:433-438)
-    const int shift = usable ? rr_fix_shift(wmax, n) : 0;
-    uint64_t q[R], c[R], run = 0;
-    u128 q2 = {0, 0};
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-      q[j] = k0 + j >= n ? 0ull : (mode == rr::kImageWeights ? rr_fix_quantize(wgt[j], shift) : 1ull);
-      run += q[j];
-      c[j] = run;
-      u128 sq;
-      rr_mul64wide(q[j], q[j], &sq.hi, &sq.lo);
-      q2 = rr::add128(q2, sq);
-    }
-    const uint64_t incl = rr::wave_scan_u64(run, lane);
-    q2 = rr::wave_sum_u128(q2);
-    __syncthreads();
-    if (lane == 63) s_u[wv] = incl;
-    if (lane == 0) {
-      s_u[W + wv] = q2.hi;
-      s_u[2 * W + wv] = q2.lo;
-    }
-    __syncthreads();
-    uint64_t off = incl - run, total = 0;
-    u128 qq = {0, 0};
-#pragma unroll
-    for (int k = 0; k < W; ++k) {
-      if (k < wv) off += s_u[k];
-      total += s_u[k];
-      qq = rr::add128(qq, u128{s_u[W + k], s_u[2 * W + k]});
-    }
-    rr::TileSums ts;
-    ts.pre = 0;
-    ts.tot = total;
-    ts.q2 = qq;
-    PlanArgs pa{};
-    pa.n_global = n;
-    pa.neff_threshold = a.neff_threshold;
-    pa.gate = a.gate;
-    pa.mode = 0;
-    const int fire = rr::gate_decision(mode, ts, pa);
-    const unsigned int rstep = a.rstep0 + (unsigned int)s;
-    c_usable = usable ? 1 : 0;
-    c_mode = mode;
-    c_shift = shift;
-    c_fired = fire;
-    c_total = total;
-    c_q2 = qq;
-    c_wmax = wmax;
-    double est_acc[4] = {0.0, 0.0, 0.0, 0.0};
-    RR_RES_TL(4);  // integer image, sums, gate
-    if (!fire) {
-      if (a.want_est) {  // sum_j q_j p_j / T  (the cache refreshed at particle_filter.rs:332)
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-          const double cq = (double)q[j];
-          est_acc[0] = rr_fma(cq, x[j], est_acc[0]);
-          est_acc[1] = rr_fma(cq, y[j], est_acc[1]);
-          est_acc[2] = rr_fma(cq, yaw[j], est_acc[2]);
-          est_acc[3] = rr_fma(cq, v[j], est_acc[3]);
-        }
-        c_den = (double)total;
-      }
-    } else {
-      any_fired = 1;
-      unsigned int idx[R];
-      if (a.scheme == RR_RESAMPLE_SYSTEMATIC) {
-        double rho, dummy;
-        if (resident) rho = pre_r[0];
-        else rr_uniform2(a.seed, RR_STREAM_RESAMPLE, rstep, 0, &rho, &dummy);
-        const rr_sys_plan plan = rr_sys_plan_make(rho, total, n);
-        c_rho = rho;
-        c_plan = plan;
-        const rr_sys_inv inv = rr_sys_inv_make(plan, total);
-        __syncthreads();
-        for (uint64_t k = tid; k <= n; k += BLOCK) s_mark[k] = 0;
-        __syncthreads();
-        uint64_t h_run = rr_sys_slots_upto(plan, inv, total, off);
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-          if (q[j] == 0 || k0 + j >= n) continue;
-          const uint64_t h = rr_sys_slots_upto(plan, inv, total, off + c[j]);
-          if (h > h_run) {
-            s_mark[h_run] = (unsigned int)(k0 + j + 1);
-            h_run = h;
-          }
-        }
-        __syncthreads();
-        // running maximum over the slots in slot order: serial inside the thread, DPP across the wave, LDS across waves
-        unsigned int m[R], mrun = 0;
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-          const unsigned int mk = k0 + j < n ? s_mark[k0 + j] : 0u;
-          mrun = mk > mrun ? mk : mrun;
-          m[j] = mrun;
-        }
-        const unsigned int mincl = rr::wave_scan_max_u32(mrun);
-        if (lane == 63) s_mx[wv] = mincl;
-        __syncthreads();
-        unsigned int pre = 0;
-#pragma unroll
-        for (int k = 0; k < W; ++k)
-          if (k < wv) pre = s_mx[k] > pre ? s_mx[k] : pre;
-        // exclusive carry into this thread: the maximum of the lanes before it in the wave and of the waves before that
-        unsigned int before = __shfl_up(mincl, 1, rr::kWave);
-        if (lane == 0) before = 0;
-        before = before > pre ? before : pre;
-#pragma unroll
-        for (int j = 0; j < R; ++j) idx[j] = (m[j] > before ? m[j] : before) - 1u;
-      } else {  // multinomial (particle_filter.rs:455-470; monte_carlo_localization.rs:343-355,387-392)
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < R; ++j)
-          if (k0 + j < n) s_cdf[k0 + j] = off + c[j];
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-          double r, dummy;
-          if (resident) r = pre_r[j];
-          else rr_uniform2(a.seed, RR_STREAM_RESAMPLE, rstep, k0 + j, &r, &dummy);
-          idx[j] = k0 + j < n ? (unsigned int)rr_lower_bound_u64(s_cdf, n, rr_fix_target_multinomial(r, total)) : 0u;
-        }
-      }
-      // ---- gather through LDS (particle_filter.rs:467-469)
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < R; ++j)
-        if (k0 + j < n) {
-          s_f[k0 + j] = x[j];
-          s_f[n + k0 + j] = y[j];
-          s_f[2 * n + k0 + j] = yaw[j];
-          s_f[3 * n + k0 + j] = v[j];
-        }
-      __syncthreads();
-#pragma unroll
-      for (int j = 0; j < R; ++j)
-        if (k0 + j < n) {
-          const unsigned int i = idx[j];
-          x[j] = s_f[i];
-          y[j] = s_f[n + i];
-          yaw[j] = s_f[2 * n + i];
-          v[j] = s_f[3 * n + i];
-          last_idx[j] = i;
-          if (a.want_est) {  // the mean of the resampled set, uniform weights (:343)
-            est_acc[0] += x[j];
-            est_acc[1] += y[j];
-            est_acc[2] += yaw[j];
-            est_acc[3] += v[j];
-          }
-        }
-      c_den = (double)n;
-    }
-    RR_RES_TL(5);  // resampled / gathered
-    if (a.want_est) {
-      small_block_sum4<BLOCK>(est_acc, s_red);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) c_est[k] = est_acc[k];
-      if (est_out) {  // K x 4 estimates: collected in LDS, flushed (coalesced) every kEstRing steps -- no global store per step
-        if (tid == 0) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) s_ring[(s % kEstRing) * 4 + k] = c_est[k] / c_den;
-        }
-        if ((s % kEstRing) == kEstRing - 1 || s == a.K - 1) {
-          __syncthreads();
-          const int s0 = s - (s % kEstRing), cnt = (s - s0 + 1) * 4;
-          if (tid < cnt) est_out[4 * (size_t)s0 + tid] = s_ring[tid];
-        }
-      }
-      if (resident && tid < 4) {  // the step's answer: four self-vouching pairs, no fence, no separate stamp
-        const double e = tid == 0 ? c_est[0] : tid == 1 ? c_est[1] : tid == 2 ? c_est[2] : c_est[3];
-        rr::store_pair_sys(&ring->rsp[tid], (uint64_t)__double_as_longlong(e / c_den), a.res.first_seq + (uint64_t)s);
-      }
-#if defined(RR_PLAN_TIMELINE)
-      if (resident && tid == 0) {  // [6]: the estimate summed and its four pairs issued; [7]: did the resample fire
-        res_tl[6] = wall_clock64();
-        res_tl[7] = (uint64_t)fire;
-        for (int k = 0; k < 8; ++k) rr::store_pair_sys(&ring->rsp[8 + k], res_tl[k], a.res.first_seq + (uint64_t)s);
-      }
-#endif
-    }
-  }
-  if (resident) __syncthreads();
-  // a resident incarnation that served no step leaves the particle set, the weights and Ctl as it found them
-  const bool write_back = !resident || steps_done > 0;
-  // ---- the state after the last step
-#pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const uint64_t k = k0 + j;
-    if (k < n && write_back) {
-      b.x[cur][k] = x[j];
-      b.y[cur][k] = y[j];
-      b.yaw[cur][k] = yaw[j];
-      b.v[cur][k] = v[j];
-      w[k] = wgt[j];
-      if (idx_out && any_fired) idx_out[k] = last_idx[j];
-    }
-  }
-  if (tid == 0 && write_back) {
-    ctl->weights_uniform = c_fired ? 1 : 0;
-    ctl->usable = c_usable;
-    ctl->image_mode = c_mode;
-    ctl->shift = c_shift;
-    ctl->wmax = c_wmax;
-    ctl->pending = 0;
-    PlanArgs pa{};
-    pa.n_global = n;
-    pa.mode = 2;  // sums only: the decision, the plan and the flags are set below
-    rr::finalize_plan(ctl, c_total, 0, c_total, c_q2, pa);
-    ctl->fired = c_fired;
-    ctl->wmax_bits = 0;
-    if (c_fired && a.scheme == RR_RESAMPLE_SYSTEMATIC) {
-      ctl->rho = c_rho;
-      ctl->plan = c_plan;
-      ctl->served_first = 0;
-      ctl->served_count = n;
-    }
-    if (a.want_est) {
-      for (int k = 0; k < 4; ++k) est_partials[k] = c_est[k];
-      ctl->est_denom = c_den;
-      ctl->est_step = (uint64_t)(a.rstep0 + (unsigned int)(resident ? steps_done : a.K) - 1) + 1;
-      ctl->est_kind = rr::kEstPlanTiles;
-      if (a.mail_seq) {
-        for (int k = 0; k < 4; ++k)
-          __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[k]), (uint64_t)__double_as_longlong(c_est[k] / c_den), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&mail->seq, a.mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-      }
-    }
-  }
-  if (resident && tid == 0) {  // EXIT marker: the last command this incarnation consumed (a quit counts), stamped with the launch id
-    const uint64_t consumed = a.res.first_seq + (uint64_t)steps_done - 1 + (res_last_op == rr::kResOpQuit ? 1 : 0);
-    rr::store_pair_sys(&ring->rsp[rr::kResRspExit], consumed, a.res.launch_id);
-  }
-}
-
-// initial clouds
-__global__ __launch_bounds__(kBlock) void k_init(Bufs b, double* __restrict__ w, uint64_t n,
-                                                uint64_t n_global, uint64_t first_gid,
-                                                uint64_t seed, int jitter, double s0, double s1,
-                                                double s2, double s3) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  double x = 0.0, y = 0.0, yaw = 0.0, v = 0.0;
-  if (jitter) {
-    const double st[4] = {s0, s1, s2, s3};
-    rr_pf_init_one(seed, first_gid + i, st, &x, &y, &yaw, &v);
-  }
-  b.x[0][i] = x;
-  b.y[0][i] = y;
-  b.yaw[0][i] = yaw;
-  b.v[0][i] = v;
-  w[i] = 1.0 / (double)n_global;
-}
-
-// AoS (x,y,yaw,v,w) <-> SoA
-__global__ __launch_bounds__(kBlock) void k_pack_aos(Bufs b, const double* __restrict__ w,
-                                                    const Ctl* __restrict__ ctl, uint64_t n,
-                                                    uint64_t n_global, double* __restrict__ out) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const int cur = ctl->cur;
-  double wi;
-  if (ctl->weights_uniform || ctl->image_mode != rr::kImageWeights) wi = 1.0 / (double)n_global;
-  else wi = w[i] / ctl->sum;
-  out[5 * i] = b.x[cur][i];
-  out[5 * i + 1] = b.y[cur][i];
-  out[5 * i + 2] = b.yaw[cur][i];
-  out[5 * i + 3] = b.v[cur][i];
-  out[5 * i + 4] = wi;
-}
-
-__global__ __launch_bounds__(kBlock) void k_unpack_aos(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl,
-                                                      uint64_t n, const double* __restrict__ in) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int cur = ctl->cur;
-  double wi = 0.0;
-  if (i < n) {
-    b.x[cur][i] = in[5 * i];
-    b.y[cur][i] = in[5 * i + 1];
-    b.yaw[cur][i] = in[5 * i + 2];
-    b.v[cur][i] = in[5 * i + 3];
-    wi = in[5 * i + 4];
-    w[i] = wi;
-  }
-  double m = wi > 0.0 ? wi : 0.0;
-  m = rr::wave_max(m);
-  if ((threadIdx.x & 63) == 0 && m > 0.0) rr::atomic_max_u64(&ctl->wmax_bits, rr_d2u(m));
-  if (i == 0) ctl->weights_uniform = 0;
-}
+#include "pf_kernels_step.inc"
+#include "pf_kernels_small.inc"
 
 }  // namespace
 
-// resolve + gather of the slots this rank serves, stored straight into the owners' slabs:
-// global slot s -> rank s / n_local, local index s % n_local, buffer set `Ctl.cur` (every rank
-// flips in lockstep: the gate decision is a function of the global integer sums)
-__global__ __launch_bounds__(kBlock) void k_resolve_gather_p2p(Bufs b, const Ctl* __restrict__ ctl,
-                                                              unsigned int* __restrict__ markers,
-                                                              const unsigned int* __restrict__ carry,
-                                                              P2PPeers peers, uint64_t n_local) {
-  if (!ctl->fired) return;
-  const uint64_t first = ctl->served_first, n_slots = ctl->served_count;
-  const uint64_t tile_base = (uint64_t)blockIdx.x * rr::kResolveSlots;
-  if (tile_base >= n_slots) return;  // uniform per workgroup
-  unsigned int idx[rr::kResolveRows];
-  rr::resolve_tile(markers, carry, n_slots, blockIdx.x, idx);
-  const int dst = ctl->cur, src = dst ^ 1;
-#pragma unroll
-  for (int r = 0; r < rr::kResolveRows; ++r) {
-    const uint64_t k = tile_base + (uint64_t)r * kBlock + threadIdx.x;
-    if (k < n_slots) {
-      const uint64_t s = first + k;
-      const uint64_t d = s / n_local, li = s - d * n_local;
-      const uint64_t j = idx[r];
-      double* __restrict__ out = peers.slab[d] + (size_t)(4 * dst) * n_local;
-      out[li] = b.x[src][j];
-      out[n_local + li] = b.y[src][j];
-      out[2 * n_local + li] = b.yaw[src][j];
-      out[3 * n_local + li] = b.v[src][j];
-    }
-  }
-}
-
-// Sharded lazy resample, phase D: deliver what this shard serves to OTHER ranks.  The window of positions this shard's
-// sources feed, [served_first, +served_count) + pad, sticks out of its own block [own0, own0 + n) on either side by the
-// drift of the cumulative weight across the block boundaries (10^3 - 10^4 slots of 10^6 in steady state, everything in
-// the worst case): those positions are resolved here, tile by tile (grid-stride over the foreign tiles only), and each
-// particle is stored into the owning rank's fine-grained inbox, its four fields and the seal that vouches for them in one go
-// (rr::inbox_put).  Own positions are left to the next step's k_step_lazy.
-__global__ __launch_bounds__(kBlock) void k_push_window(Bufs b, const Ctl* __restrict__ ctl,
-                                                       unsigned int* __restrict__ markers,
-                                                       const unsigned int* __restrict__ carry, P2PPeers peers,
-                                                       uint64_t n_local, uint64_t pad, uint64_t seq) {
-  if (!ctl->fired) return;
-  const uint64_t own0 = (uint64_t)peers.rank * n_local + pad, own1 = own0 + n_local;
-  const uint64_t win_lo = ctl->served_first + pad, win_hi = win_lo + ctl->served_count;
-  const int src = ctl->cur;  // lazy: Ctl.cur flips when the next step settles
-  // foreign positions: left of the own block [l_lo, l_hi), right of it [r_lo, r_hi)
-  const uint64_t S = rr::kResolveSlots;
-  const uint64_t l_lo = win_lo, l_hi = own0 < win_hi ? own0 : win_hi;
-  const uint64_t r_lo = own1 > win_lo ? own1 : win_lo, r_hi = win_hi;
-  const uint64_t lt0 = l_lo / S, n_left = l_lo < l_hi ? (l_hi + S - 1) / S - lt0 : 0;
-  const uint64_t rt0 = r_lo / S, n_right = r_lo < r_hi ? (r_hi + S - 1) / S - rt0 : 0;
-  const uint64_t n_tiles = n_left + n_right;
-  for (uint64_t q = blockIdx.x; q < n_tiles; q += gridDim.x) {
-    const uint64_t tile = q < n_left ? lt0 + q : rt0 + (q - n_left);
-    const uint64_t lo = q < n_left ? l_lo : r_lo, hi = q < n_left ? l_hi : r_hi;  // positions this kernel consumes
-    unsigned int idx[rr::kResolveRows];
-    rr::resolve_tile_window(markers, carry, tile, win_lo, win_hi, lo, hi, idx);
-#pragma unroll
-    for (int r = 0; r < rr::kResolveRows; ++r) {
-      const uint64_t pos = tile * S + (uint64_t)r * kBlock + threadIdx.x;
-      if (pos >= lo && pos < hi) {
-        const uint64_t s = pos - pad;  // global slot
-        const uint64_t d = s / n_local, li = s - d * n_local;
-        const uint64_t j = idx[r];
-        // fine-grained, [4 fields + seal][n_local]: the five words in one go, the seal vouches for them (rr::inbox_put)
-        rr::inbox_put(peers.inbox[d], n_local, li, seq, b.x[src][j], b.y[src][j], b.yaw[src][j], b.v[src][j]);
-      }
-    }
-  }
-}
-
-// RCCL transport, the same overhang into a SEND BUFFER instead of the peers' inboxes: record q (x, y, yaw, v) is the q-th
-// foreign position of the window in ascending order -- left overhang, then right overhang -- which is also ascending
-// destination rank, so the buffer is cut into one contiguous segment per destination.  If the overhang does not fit the
-// buffer (`cap` records) the kernel leaves everything as it is and the host, which learns the size a moment later, grows
-// the buffer and launches it again.
-__global__ __launch_bounds__(kBlock) void k_pack_window(Bufs b, const Ctl* __restrict__ ctl, unsigned int* __restrict__ markers,
-                                                       const unsigned int* __restrict__ carry, int rank, uint64_t n_local,
-                                                       uint64_t pad, double* __restrict__ send, uint64_t cap) {
-  if (!ctl->fired) return;
-  const uint64_t own0 = (uint64_t)rank * n_local + pad, own1 = own0 + n_local;
-  const uint64_t win_lo = ctl->served_first + pad, win_hi = win_lo + ctl->served_count;
-  const int src = ctl->cur;
-  const uint64_t S = rr::kResolveSlots;
-  const uint64_t l_lo = win_lo, l_hi = own0 < win_hi ? own0 : win_hi;
-  const uint64_t r_lo = own1 > win_lo ? own1 : win_lo, r_hi = win_hi;
-  const uint64_t n_lpos = l_lo < l_hi ? l_hi - l_lo : 0, n_rpos = r_lo < r_hi ? r_hi - r_lo : 0;
-  if (n_lpos + n_rpos > cap) return;
-  const uint64_t lt0 = l_lo / S, n_left = n_lpos ? (l_hi + S - 1) / S - lt0 : 0;
-  const uint64_t rt0 = r_lo / S, n_right = n_rpos ? (r_hi + S - 1) / S - rt0 : 0;
-  for (uint64_t q = blockIdx.x; q < n_left + n_right; q += gridDim.x) {
-    const bool left = q < n_left;
-    const uint64_t tile = left ? lt0 + q : rt0 + (q - n_left);
-    const uint64_t lo = left ? l_lo : r_lo, hi = left ? l_hi : r_hi;
-    unsigned int idx[rr::kResolveRows];
-    rr::resolve_tile_window(markers, carry, tile, win_lo, win_hi, lo, hi, idx);
-#pragma unroll
-    for (int r = 0; r < rr::kResolveRows; ++r) {
-      const uint64_t pos = tile * S + (uint64_t)r * kBlock + threadIdx.x;
-      if (pos >= lo && pos < hi) {
-        const uint64_t rec = left ? pos - l_lo : n_lpos + (pos - r_lo);
-        const uint64_t j = idx[r];
-        double* __restrict__ o = send + 4 * rec;
-        o[0] = b.x[src][j];
-        o[1] = b.y[src][j];
-        o[2] = b.yaw[src][j];
-        o[3] = b.v[src][j];
-      }
-    }
-  }
-}
-
-// received records -> this rank's inbox: record q is the q-th own slot OUTSIDE the own window, in ascending order
-// (`below` of them lie below the window, the rest above the `self` slots this rank serves to itself)
-__global__ __launch_bounds__(kBlock) void k_unpack_inbox(const double* __restrict__ recv, uint64_t n_recv, uint64_t below, uint64_t self,
-                                                        uint64_t n, double* __restrict__ inbox) {
-  const uint64_t q = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (q >= n_recv) return;
-  const uint64_t k = q < below ? q : q + self;
-  if (k >= n) return;
-  const double* __restrict__ r = recv + 4 * q;
-  inbox[k] = r[0];
-  inbox[n + k] = r[1];
-  inbox[2 * n + k] = r[2];
-  inbox[3 * n + k] = r[3];
-}
-
-// accessors: make a pending window resample real -- own slots inside the window through the markers, the others out of
-// the inbox (peer-to-peer transport: each as soon as its seal fits); k_settle flips the live set afterwards
-__global__ __launch_bounds__(kBlock) void k_resolve_gather_window(Bufs b, const Ctl* __restrict__ ctl,
-                                                                 unsigned int* __restrict__ markers,
-                                                                 const unsigned int* __restrict__ carry, uint64_t n,
-                                                                 uint64_t first_gid, uint64_t pad,
-                                                                 const double* __restrict__ inbox,
-                                                                 unsigned int* __restrict__ idx_out, uint64_t wait_seq,
-                                                                 uint64_t timeout_ticks, int* __restrict__ err) {
-  if (!ctl->pending) return;
-  const uint64_t own0 = first_gid + pad;
-  const uint64_t win_lo = ctl->served_first + pad, win_hi = win_lo + ctl->served_count;
-  unsigned int idx[rr::kResolveRows];
-  rr::resolve_tile_window(markers, carry, own0 / rr::kResolveSlots + blockIdx.x, win_lo, win_hi, own0, own0 + n, idx);
-  const int src = ctl->cur, dst = src ^ 1;
-#pragma unroll
-  for (int r = 0; r < rr::kResolveRows; ++r) {
-    const uint64_t k = (uint64_t)blockIdx.x * rr::kResolveSlots + (uint64_t)r * kBlock + threadIdx.x;
-    if (k >= n) continue;
-    const uint64_t pos = own0 + k;
-    if (pos < win_lo || pos >= win_hi) {
-      double f[4];
-      (void)rr::inbox_take(inbox, n, k, wait_seq, timeout_ticks, err, f);
-      b.x[dst][k] = f[0];
-      b.y[dst][k] = f[1];
-      b.yaw[dst][k] = f[2];
-      b.v[dst][k] = f[3];
-      if (idx_out) idx_out[k] = kInPlace;
-    } else {
-      const uint64_t j = idx[r];
-      b.x[dst][k] = b.x[src][j];
-      b.y[dst][k] = b.y[src][j];
-      b.yaw[dst][k] = b.yaw[src][j];
-      b.v[dst][k] = b.v[src][j];
-      if (idx_out) idx_out[k] = (unsigned int)j;
-    }
-  }
-}
-
-// make a pending sharded-lazy resample real (accessors): copy the locally-sourced slots, leave
-// the ones a peer stored where they are; k_settle flips the live set afterwards
-__global__ __launch_bounds__(kBlock) void k_gather_lidx(Bufs b, const Ctl* __restrict__ ctl,
-                                                       unsigned int* __restrict__ lidx, uint64_t n,
-                                                       const double* __restrict__ inbox) {
-  if (!ctl->pending) return;
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= n) return;
-  const unsigned int j = lidx[k];
-  const int src = ctl->cur, dst = src ^ 1;
-  if (j == kInPlace) {  // delivered by a peer: take it out of the inbox (multinomial, unsharded: never happens)
-    if (!inbox) return;
-    b.x[dst][k] = inbox[k];
-    b.y[dst][k] = inbox[n + k];
-    b.yaw[dst][k] = inbox[2 * n + k];
-    b.v[dst][k] = inbox[3 * n + k];
-    return;
-  }
-  b.x[dst][k] = b.x[src][j];
-  b.y[dst][k] = b.y[src][j];
-  b.yaw[dst][k] = b.yaw[src][j];
-  b.v[dst][k] = b.v[src][j];
-  lidx[k] = kInPlace;
-}
-
-// The deferred in-step estimate when an accessor moved the particles before the next step did (materialise): the same sums over
-// the live set -- slot k now HOLDS its source's fields --, the same slot tiles, the same order as k_step_lazy (est_slots_partial).
-__global__ __launch_bounds__(kBlock) void k_est_slots(Bufs b, const Ctl* __restrict__ ctl, uint64_t n, double* __restrict__ partials) {
-  if (ctl->est_kind != rr::kEstSlotTiles) return;  // the gate stayed shut: the plan kernel has formed the weighted mean
-  const int cur = ctl->cur, tid = threadIdx.x;
-  const uint64_t tile_base = (uint64_t)blockIdx.x * rr::kResolveSlots;
-  double f[4][rr::kResolveRows];
-#pragma unroll
-  for (int r = 0; r < rr::kResolveRows; ++r) {
-    const uint64_t k = tile_base + (uint64_t)r * kBlock + tid;
-    const bool in = k < n;
-    f[0][r] = in ? b.x[cur][k] : 0.0;
-    f[1][r] = in ? b.y[cur][k] : 0.0;
-    f[2][r] = in ? b.yaw[cur][k] : 0.0;
-    f[3][r] = in ? b.v[cur][k] : 0.0;
-  }
-  double acc[4];
-  rr::est_rows_sum<rr::kResolveRows>(f, acc);
-  rr::est_wave_store<kBlock>(acc, partials, blockIdx.x);
-}
-
-// ------------------------------------------------------------------------------------------
-// KLD-adaptive resampling (monte_carlo_localization.rs:322-385).  The reference draws one
-// particle at a time and stops at the first count that satisfies the KLD bound for the number of
-// bins occupied so far.  Here all max_particles candidate draws are evaluated at once:
-//   k_kld_draw    draw m -> source index (multinomial, as k_resample_gather_mn) and its bin,
-//   k_kld_insert  exact "first draw with this bin" through an open-addressing table keyed by the
-//                 full (x, y, yaw) bin triple: a slot is claimed once (CAS) by some draw, later
-//                 draws compare their bin with the claimant's and keep the minimum draw index,
-//   k_kld_count   one workgroup: occupied-bin count after every draw (scan of the first-occurrence
-//                 flags), running maximum of rr_kld_required, first draw satisfying rr_kld_stop.
-// The new count goes to the host (the only synchronisation of an adaptive step); a plain gather
-// of that many particles follows.
-constexpr unsigned int kKldEmpty = 0xffffffffu;
-
-// ------------------------------------------------------------------------------------------
-// Sharded MULTINOMIAL resample (the resampler MonteCarloLocalizer uses, monte_carlo_localization.rs:322-365,387-392,
-// and particle_filter.rs:441-473).  Draw k belongs to output slot k of the GLOBAL particle index and is a pure
-// function of (seed, resample step, k), so every shard can evaluate all n_global targets; the shard whose CDF
-// interval (base, base + T_local] contains target_k serves slot k.  Unlike the systematic plan the served slots
-// are scattered, so they are COMPACTED in slot order: tiles of 2048 slots that never straddle a destination rank
-// (destination d owns slots [d n_local, (d+1) n_local)), count -> scan -> write.  The send buffer is therefore
-// ordered by global slot, i.e. grouped by destination, and its per-destination counts are row `rank` of the
-// exchange matrix.  Records are 5 doubles: x, y, yaw, v and the destination's LOCAL slot index.
-struct MnSelectArgs {
-  uint64_t n_local, n_global, tiles_per_dest;
-  uint64_t seed;
-  unsigned int rstep;
-  int n_shards;
-};
-
-__device__ inline bool mn_slot_target(const Ctl* __restrict__ ctl, const MnSelectArgs& a, uint64_t tile, int item,
-                                      uint64_t* slot_out, uint64_t* target_out) {
-  const uint64_t d = tile / a.tiles_per_dest, t = tile - d * a.tiles_per_dest;
-  const uint64_t li = t * kTile + (uint64_t)threadIdx.x * rr::kItems + item;
-  if (li >= a.n_local) return false;
-  const uint64_t slot = d * a.n_local + li;
-  double r, dummy;
-  rr_uniform2(a.seed, RR_STREAM_RESAMPLE, a.rstep, slot, &r, &dummy);
-  const uint64_t target = rr_fix_target_multinomial(r, ctl->total);
-  *slot_out = slot;
-  *target_out = target;
-  return target > ctl->base && target <= ctl->base + ctl->total_local;
-}
-
-__global__ __launch_bounds__(rr::kTileBlock) void k_mn_select_count(const Ctl* __restrict__ ctl, MnSelectArgs a,
-                                                           unsigned int* __restrict__ tile_cnt) {
-  __shared__ unsigned int s_c[rr::kTileBlock / rr::kWave];
-  unsigned int c = 0;
-  if (ctl->fired) {
-#pragma unroll
-    for (int j = 0; j < rr::kItems; ++j) {
-      uint64_t slot, target;
-      c += mn_slot_target(ctl, a, blockIdx.x, j, &slot, &target) ? 1u : 0u;
-    }
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, rr::kWave);
-  if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned int t = 0;
-    for (int k = 0; k < rr::kTileBlock / rr::kWave; ++k) t += s_c[k];
-    tile_cnt[blockIdx.x] = t;
-  }
-}
-
-// one workgroup: exclusive scan of the tile counts (in place), counts per destination
-__global__ __launch_bounds__(kScanThreads) void k_mn_select_scan(unsigned int* __restrict__ tile_cnt, uint64_t n_tiles,
-                                                                uint64_t tiles_per_dest, int n_shards,
-                                                                uint64_t* __restrict__ counts_out) {
-  __shared__ uint64_t s_w[kScanThreads / rr::kWave];
-  __shared__ uint64_t s_dest[kMaxP2P + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint64_t per = (n_tiles + kScanThreads - 1) / kScanThreads;
-  const uint64_t lo = (uint64_t)tid * per, hi = lo + per < n_tiles ? lo + per : n_tiles;
-  uint64_t local = 0;
-  for (uint64_t k = lo; k < hi; ++k) local += tile_cnt[k];
-  const uint64_t incl = rr::wave_scan_u64(local, lane);
-  if (lane == 63) s_w[wv] = incl;
-  __syncthreads();
-  uint64_t run = incl - local;
-  for (int k = 0; k < wv; ++k) run += s_w[k];
-  for (uint64_t k = lo; k < hi; ++k) {
-    if (k % tiles_per_dest == 0) s_dest[k / tiles_per_dest] = run;  // first tile of a destination: its block starts here
-    const unsigned int t = tile_cnt[k];
-    tile_cnt[k] = (unsigned int)run;
-    run += t;
-  }
-  if (tid == kScanThreads - 1 || hi == n_tiles) {
-    if (hi == n_tiles && lo < hi) s_dest[n_shards] = run;  // grand total (the thread that owns the last tile)
-  }
-  __syncthreads();
-  if (tid < n_shards) counts_out[tid] = s_dest[tid + 1] - s_dest[tid];
-}
-
-__global__ __launch_bounds__(rr::kTileBlock) void k_mn_select_pack(Bufs b, const Ctl* __restrict__ ctl, MnSelectArgs a,
-                                                          const unsigned int* __restrict__ tile_off,
-                                                          const uint64_t* __restrict__ cdf, uint64_t n_src,
-                                                          double* __restrict__ out) {
-  if (!ctl->fired) return;
-  __shared__ unsigned int s_c[rr::kTileBlock / rr::kWave];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  uint64_t slot[rr::kItems], target[rr::kItems];
-  bool mine[rr::kItems];
-  unsigned int c = 0;
-#pragma unroll
-  for (int j = 0; j < rr::kItems; ++j) {
-    mine[j] = mn_slot_target(ctl, a, blockIdx.x, j, &slot[j], &target[j]);
-    c += mine[j] ? 1u : 0u;
-  }
-  unsigned int incl = c;
-#pragma unroll
-  for (int o = 1; o < rr::kWave; o <<= 1) {
-    const unsigned int t = __shfl_up(incl, o, rr::kWave);
-    if (lane >= o) incl += t;
-  }
-  if (lane == 63) s_c[wv] = incl;
-  __syncthreads();
-  unsigned int pos = tile_off[blockIdx.x] + incl - c;
-  for (int k = 0; k < wv; ++k) pos += s_c[k];
-  const int src = ctl->cur ^ 1;  // the plan kernel has flipped Ctl.cur: the weighted set is the other one
-#pragma unroll
-  for (int j = 0; j < rr::kItems; ++j) {
-    if (!mine[j]) continue;
-    const uint64_t i = rr_lower_bound_u64(cdf, n_src, target[j]);
-    double* __restrict__ o = out + 5 * (uint64_t)pos;
-    o[0] = b.x[src][i];
-    o[1] = b.y[src][i];
-    o[2] = b.yaw[src][i];
-    o[3] = b.v[src][i];
-    o[4] = (double)(slot[j] % a.n_local);
-    ++pos;
-  }
-}
-
-// received records -> the live buffer set, each to the local slot it names
-__global__ __launch_bounds__(kBlock) void k_adopt_records(Bufs b, const Ctl* __restrict__ ctl,
-                                                         const double* __restrict__ in, uint64_t n) {
-  if (!ctl->fired) return;
-  const uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (r >= n) return;
-  const int dst = ctl->cur;
-  const uint64_t k = (uint64_t)in[5 * r + 4];
-  if (k >= n) return;
-  b.x[dst][k] = in[5 * r];
-  b.y[dst][k] = in[5 * r + 1];
-  b.yaw[dst][k] = in[5 * r + 2];
-  b.v[dst][k] = in[5 * r + 3];
-}
-
-__global__ __launch_bounds__(kBlock) void k_kld_draw(Bufs b, const Ctl* __restrict__ ctl,
-                                                    const uint64_t* __restrict__ cdf,
-                                                    const uint64_t* __restrict__ coarse, int coarse_log2,
-                                                    uint64_t n_coarse, const double* __restrict__ r_explicit,
-                                                    unsigned int* __restrict__ idx, int32_t* __restrict__ keys,
-                                                    uint64_t n_src, uint64_t n_draws, uint64_t seed, unsigned int rstep, int dyn_n) {
-  extern __shared__ uint64_t s_coarse[];
-  if (dyn_n) {  // the current particle count lives on the device (Ctl.n_active); the launch was sized for the capacity
-    n_src = ctl->n_active;
-    n_coarse = (n_src + (1ull << coarse_log2) - 1) >> coarse_log2;
-  }
-  for (uint64_t i = threadIdx.x; i < n_coarse; i += kBlock) s_coarse[i] = coarse[i];
-  __syncthreads();
-  const uint64_t m = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (m >= n_draws) return;
-  const int src = ctl->cur ^ 1;  // the plan kernel flipped Ctl.cur already
-  const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, m, seed, rstep, r_explicit, m);
-  const uint64_t blk = rr_lower_bound_u64(s_coarse, n_coarse, target);
-  const uint64_t lo = blk << coarse_log2;
-  const uint64_t len = lo + (1ull << coarse_log2) <= n_src ? (1ull << coarse_log2) : n_src - lo;
-  uint64_t j = lo + rr_lower_bound_u64(cdf + lo, len, target);
-  if (j >= n_src) j = n_src - 1;
-  idx[m] = (unsigned int)j;
-  int32_t xb, yb, ab;
-  rr_kld_bin(b.x[src][j], b.y[src][j], b.yaw[src][j], &xb, &yb, &ab);
-  keys[3 * m] = xb;
-  keys[3 * m + 1] = yb;
-  keys[3 * m + 2] = ab;
-}
-
-__device__ inline uint64_t kld_hash(int32_t a, int32_t b, int32_t c) {
-  uint64_t h = ((uint64_t)(uint32_t)a << 32) | (uint32_t)b;
-  h ^= (uint64_t)(uint32_t)c * 0x9e3779b97f4a7c15ull;
-  h ^= h >> 33;
-  h *= 0xff51afd7ed558ccdull;
-  h ^= h >> 33;
-  h *= 0xc4ceb9fe1a85ec53ull;
-  h ^= h >> 33;
-  return h;
-}
-
-// One lane per DISTINCT value of `slot` among the wave's valid lanes: the lowest such lane (its draw index is the smallest of
-// the group, draw indices ascend with the lane).  A tracking filter's draws fall into a few dozen bins, and same-address
-// atomics are carried out one after the other at the memory side (7.5 ns each): 5000 draws claiming and lowering ~100
-// slots took 36 us; with one atomic per bin and wave, and none when a look shows that nothing would change, 5 us.
-__device__ inline bool wave_first_of_slot(uint32_t slot, bool valid) {
-  const int lane = threadIdx.x & 63;
-  unsigned long long todo = __ballot(valid);
-  bool first = false;
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const uint32_t s_l = (uint32_t)__builtin_amdgcn_readlane((int)slot, leader);
-    const unsigned long long same = __ballot(valid && slot == s_l);
-    if (lane == leader) first = true;
-    todo &= ~same;
-  }
-  return first;
-}
-
-// draw m's bin into the table (all lanes of a wave call this together; valid == false: the lane only takes part in the
-// wave-wide steps)
-__device__ inline void kld_insert_one(uint64_t m, bool valid, const int32_t* __restrict__ keys, unsigned int* __restrict__ table,
-                                      unsigned int* __restrict__ minslot, unsigned int* __restrict__ myslot, uint64_t hash_size) {
-  int32_t a = 0, bb = 0, c = 0;
-  if (valid) {
-    a = keys[3 * m];
-    bb = keys[3 * m + 1];
-    c = keys[3 * m + 2];
-  }
-  uint64_t s = kld_hash(a, bb, c) & (hash_size - 1);
-  // the home slot of a bin is claimed once per wave, not once per draw
-  if (wave_first_of_slot((uint32_t)s, valid) && __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kKldEmpty)
-    (void)atomicCAS(&table[s], kKldEmpty, (unsigned int)m);
-  bool placed = !valid;
-  while (!placed) {
-    unsigned int o = __hip_atomic_load(&table[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (o == kKldEmpty) {
-      o = atomicCAS(&table[s], kKldEmpty, (unsigned int)m);
-      if (o == kKldEmpty) o = (unsigned int)m;
-    }
-    if (o == m || (keys[3 * (uint64_t)o] == a && keys[3 * (uint64_t)o + 1] == bb && keys[3 * (uint64_t)o + 2] == c)) placed = true;
-    else s = (s + 1) & (hash_size - 1);  // another bin lives here: linear probing (the table is at most half full)
-  }
-  if (valid) myslot[m] = (unsigned int)s;
-  // the bin's smallest draw index: the wave's smallest draw of the bin speaks for the wave, and only if a look says it matters
-  if (wave_first_of_slot((uint32_t)s, valid) && __hip_atomic_load(&minslot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > (unsigned int)m)
-    atomicMin(&minslot[s], (unsigned int)m);
-}
-
-__global__ __launch_bounds__(kBlock) void k_kld_insert(const int32_t* __restrict__ keys, unsigned int* __restrict__ table,
-                                                      unsigned int* __restrict__ minslot,
-                                                      unsigned int* __restrict__ myslot, uint64_t n_draws,
-                                                      uint64_t hash_size) {
-  const uint64_t m = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  kld_insert_one(m, m < n_draws, keys, table, minslot, myslot, hash_size);
-}
-
-constexpr int kKldThreads = 1024;
-constexpr uint64_t kKldWipeInKernel = 16384;  // candidate draws up to which k_kld_count wipes the bin table itself
-// One workgroup of kKldThreads: the number of draws the reference's loop makes before it stops (:340-352) -- occupied-bin
-// count after every draw (scan of the first-occurrence flags), running maximum of the KLD bound, first draw that satisfies
-// the stop rule.  Every thread gets the result.  Then the bin table and the first-occurrence slots are wiped for the NEXT
-// resample (both arrays are cleared once when the filter is created).
-__device__ inline uint64_t kld_count_body(unsigned int* __restrict__ minslot, const unsigned int* __restrict__ myslot, uint64_t n_draws,
-                                          const rr_mcl_adaptive& kld, unsigned int* __restrict__ table, uint64_t hash_size) {
-  __shared__ uint64_t s_cnt[kKldThreads / rr::kWave];
-  __shared__ uint64_t s_req[kKldThreads / rr::kWave];
-  __shared__ uint64_t s_stop;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  uint64_t k_carry = 0, req_carry = kld.min_particles;
-  if (tid == 0) s_stop = ~0ull;
-  __syncthreads();
-  for (uint64_t base = 0; base < n_draws; base += kKldThreads) {
-    const uint64_t m = base + tid;
-    // (device-scope load: in the one-launch adaptive step the minima were formed by atomics of this very launch)
-    const uint64_t flag = (m < n_draws && __hip_atomic_load(&minslot[myslot[m]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)m) ? 1ull : 0ull;
-    // occupied bins after draw m
-    uint64_t incl = rr::wave_scan_u64(flag, lane);
-    if (lane == 63) s_cnt[wv] = incl;
-    __syncthreads();
-    uint64_t off = k_carry;
-    for (int q = 0; q < wv; ++q) off += s_cnt[q];
-    const uint64_t k = off + incl;
-    uint64_t chunk_total = 0;
-    for (int q = 0; q < kKldThreads / rr::kWave; ++q) chunk_total += s_cnt[q];
-    // running maximum of the bound (:350: required = required.max(...))
-    uint64_t req = m < n_draws ? rr_kld_required(k, kld.min_particles, kld.max_particles, kld.kld_epsilon, kld.kld_z) : 0;
-#pragma unroll
-    for (int o = 1; o < rr::kWave; o <<= 1) {
-      const uint64_t t = rr::shfl_up_u64(req, o);
-      if (lane >= o && t > req) req = t;
-    }
-    if (lane == 63) s_req[wv] = req;
-    __syncthreads();
-    uint64_t pre = req_carry;
-    for (int q = 0; q < wv; ++q) pre = s_req[q] > pre ? s_req[q] : pre;
-    if (pre > req) req = pre;
-    uint64_t chunk_req = req_carry;
-    for (int q = 0; q < kKldThreads / rr::kWave; ++q) chunk_req = s_req[q] > chunk_req ? s_req[q] : chunk_req;
-    if (m < n_draws && rr_kld_stop(m, req, kld.min_particles)) atomicMin((unsigned long long*)&s_stop, (unsigned long long)m);
-    __syncthreads();
-    if (s_stop != ~0ull) break;  // uniform: read after the barrier
-    k_carry += chunk_total;
-    req_carry = chunk_req;
-    __syncthreads();
-  }
-  const uint64_t n_new = s_stop == ~0ull ? n_draws : s_stop + 1;  // :342: at most max_particles
-  // every read of minslot[] above happened before a barrier all threads have passed (the loop ends with one, or breaks
-  // right after one): the table can go
-  // (one workgroup wipes the slots the draws used; beyond kKldWipeInKernel draws the host wipes both arrays with two wide
-  // memsets behind the launch instead -- 2 x 4 x hash_size bytes through one workgroup would cost more than the step)
-  __syncthreads();
-  if (n_draws <= kKldWipeInKernel) {
-    for (uint64_t m = tid; m < n_draws; m += kKldThreads) {
-      const unsigned int slot = myslot[m];
-      table[slot] = kKldEmpty;
-      minslot[slot] = kKldEmpty;
-    }
-  }
-  (void)hash_size;
-  return n_new;
-}
-
-__global__ __launch_bounds__(kKldThreads) void k_kld_count(unsigned int* __restrict__ minslot,
-                                                          const unsigned int* __restrict__ myslot, uint64_t n_draws,
-                                                          rr_mcl_adaptive kld, uint64_t* __restrict__ out,
-                                                          unsigned int* __restrict__ table, uint64_t hash_size, Bufs b,
-                                                          Ctl* __restrict__ ctl, const unsigned int* __restrict__ idx, int gather) {
-  const uint64_t n_new = kld_count_body(minslot, myslot, n_draws, kld, table, hash_size);
-  const int tid = threadIdx.x;
-  if (tid == 0) out[0] = n_new;
-  if (gather) {  // a filter of the reference's sizes (<= 16 384 candidate draws): k_kld_gather_dyn's work on the way, one launch less
-    const int dst = ctl->cur, src = dst ^ 1;
-    for (uint64_t k = tid; k < n_new; k += kKldThreads) copy_particle(b, src, dst, idx[k], k, false, nullptr);
-    if (tid == 0) ctl->n_active = n_new;  // (nothing in this launch reads it)
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// The adaptive step of a filter of the reference's sizes (MonteCarloLocalizationConfig::default(): 100 - 5 000 particles) in
-// ONE launch of ONE workgroup: propagate + weight (k_propagate_weight), integer image and CDF (k_quantize_reduce, k_plan_cdf,
-// finalize_plan), the max_particles candidate draws and their bins (k_kld_draw), the bin table (k_kld_insert), the stop rule
-// (k_kld_count) and the gather -- six launches of a few microseconds of work each otherwise (36 us a step).  Same
-// per-element arithmetic, same integer sums, same draws: bit-identical to the six kernels (tests/test_gpu_kld_adaptive.py runs
-// both routes).  The particle count comes from Ctl.n_active and goes back there.
-struct AdaptSmallArgs {
-  ImageArgs img;
-  PlanArgs plan;
-  rr_mcl_adaptive kld;
-  uint64_t max_draws;
-  uint64_t hash_size;
-  rr::ResidentArgs res;  // res.on: the kernel stays and serves one step per command of the ring (resident_core.hpp)
-};
-// Resident mode (rr_pf_set_resident on an adaptive filter): the body below runs once per command; the particle set, the CDF and
-// the bin table live in HBM anyway (one workgroup: its writes are its own reads after a barrier), so an incarnation can leave
-// at any command boundary without a write-back.  While it waits it draws the NEXT step's random numbers -- the motion noise of
-// the live particles and the uniforms of all max_particles candidate draws are functions of (seed, counters, index) alone --
-// into `pre` ([cap] noise v | [cap] noise w | [cap] uniforms).
-__global__ __launch_bounds__(kKldThreads) void k_mcl_adaptive_small(Bufs b, double* __restrict__ w, Ctl* __restrict__ ctl, StepParams p,
-                                                                   ObsArg obs_arg, AdaptSmallArgs a, uint64_t* __restrict__ cdf,
-                                                                   unsigned int* __restrict__ idx, int32_t* __restrict__ keys,
-                                                                   unsigned int* __restrict__ table, unsigned int* __restrict__ minslot,
-                                                                   unsigned int* __restrict__ myslot, uint64_t* __restrict__ out,
-                                                                   uint64_t* __restrict__ coarse, int coarse_log2, int front_only,
-                                                                   HostMail* __restrict__ mail, uint64_t mail_seq,
-                                                                   rr::ResidentRing* __restrict__ ring, double* __restrict__ pre,
-                                                                   uint64_t cap) {
-  extern __shared__ double s_dyn_a[];  // [3 n_obs] observations; resident: the command's payload (u0, u1, observations)
-  constexpr int W = kKldThreads / rr::kWave;
-  __shared__ double s_max[W];
-  __shared__ uint64_t s_t[W], s_qh[W], s_ql[W];
-  __shared__ int s_hdr[2];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const bool resident = a.res.on != 0;
-  double* const s_obs = resident ? s_dyn_a + 2 : s_dyn_a;
-  int n_obs = p.n_obs, res_guess = 3 + 3 * p.n_obs < 64 ? 3 + 3 * p.n_obs : 64, res_last_op = rr::kResOpNone, steps_done = 0;
-  double u0 = p.u0, u1 = p.u1;
-  const uint64_t res_deadline = resident ? wall_clock64() + a.res.life_ticks : 0;
-#if defined(RR_PLAN_TIMELINE)
-  uint64_t atl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define RR_ATL(K_) do { __syncthreads(); if (resident && threadIdx.x == 0) { uint64_t t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); atl[(K_)] = t_; } } while (0)
-#else
-#define RR_ATL(K_) do { } while (0)
-#endif
-  for (int s = 0;; ++s) {
-  const unsigned int step = p.step + (unsigned int)s, rstep = a.plan.rstep + (unsigned int)s;
-  const uint64_t n = ctl->n_active;
-  const int cur = ctl->cur;
-  if (resident) {
-    for (uint64_t i = tid; i < n; i += kKldThreads) rr_pf_motion_noise(p.seed, step, p.first_gid + i, p.sigma_v, p.sigma_w, &pre[i], &pre[cap + i]);
-    for (uint64_t m = tid; m < a.max_draws; m += kKldThreads) {
-      double dummy;
-      rr_uniform2(p.seed, RR_STREAM_RESAMPLE, rstep, m, &pre[2 * cap + m], &dummy);
-    }
-    RR_ATL(0);
-    res_last_op = rr::resident_fetch<kKldThreads>(ring, a.res.first_seq + (uint64_t)s, a.res.idle_ticks, res_deadline, a.res.payload_cap,
-                                                  res_guess, s_dyn_a, s_hdr);
-    if (res_last_op != rr::kResOpStep) break;
-    n_obs = (s_hdr[1] - 2) / 3;
-    u0 = s_dyn_a[0];
-    u1 = s_dyn_a[1];
-  } else {
-    for (int i = tid; i < 3 * n_obs; i += kKldThreads) s_obs[i] = obs_arg.v[i];
-    __syncthreads();
-  }
-  steps_done = s + 1;
-  RR_ATL(1);
-  // ---- propagate + weight, in place on the live set (k_propagate_weight<true, true, false>)
-  double wmax_local = 0.0;
-  for (uint64_t i = tid; i < n; i += kKldThreads) {
-    double x = b.x[cur][i], y = b.y[cur][i], yaw = b.yaw[cur][i], v, na, nc;
-    if (resident) {
-      na = pre[i];
-      nc = pre[cap + i];
-    } else {
-      rr_pf_motion_noise(p.seed, step, p.first_gid + i, p.sigma_v, p.sigma_w, &na, &nc);
-    }
-    rr_pf_propagate_one(&x, &y, &yaw, &v, u0, u1, p.dt, na, nc);
-    b.x[cur][i] = x;
-    b.y[cur][i] = y;
-    b.yaw[cur][i] = yaw;
-    b.v[cur][i] = v;
-    const double wgt = p.lik_mode == RR_LIK_PRODUCT ? rr_pf_weight_product(x, y, s_obs, n_obs, p.lik) : rr_pf_weight_fused(x, y, s_obs, n_obs, p.lik);
-    w[i] = wgt;
-    if (wgt > wmax_local) wmax_local = wgt;  // NaN and negatives drop out
-  }
-  {
-    const double m = rr::wave_max(wmax_local);
-    if (lane == 0) s_max[wv] = m;
-  }
-  __syncthreads();
-  double wmax = s_max[0];
-  for (int k = 1; k < W; ++k) wmax = s_max[k] > wmax ? s_max[k] : wmax;
-  RR_ATL(2);
-  // ---- integer image (quantize_reduce_tile; the weights have just been set, so Ctl.weights_uniform does not apply)
-  const bool usable = wmax > 0.0 && wmax < INFINITY;
-  const int mode = usable ? (int)rr::kImageWeights : a.img.degenerate;
-  const int shift = usable ? rr_fix_shift(wmax, n) : 0;
-  // ---- inclusive integer CDF, total and sum of squares
-  uint64_t carry = 0;
-  u128 q2 = {0, 0};
-  for (uint64_t base = 0; base < n; base += kKldThreads) {
-    const uint64_t i = base + tid;
-    const uint64_t q = rr::quantize_at(w, i, n, mode, shift, 0, n);
-    u128 sq;
-    rr_mul64wide(q, q, &sq.hi, &sq.lo);
-    q2 = rr::add128(q2, sq);
-    const uint64_t incl = rr::wave_scan_u64(q, lane);
-    __syncthreads();  // (s_t of the previous chunk has been read)
-    if (lane == 63) s_t[wv] = incl;
-    __syncthreads();
-    uint64_t off = carry, chunk = 0;
-    for (int k = 0; k < W; ++k) {
-      if (k < wv) off += s_t[k];
-      chunk += s_t[k];
-    }
-    if (i < n) {
-      cdf[i] = off + incl;
-      // (store_cdf: every 2^coarse_log2-th entry and the last one -- the table k_kld_draw stages in LDS)
-      if ((((i + 1) & ((1ull << coarse_log2) - 1)) == 0) || i == n - 1) coarse[i >> coarse_log2] = off + incl;
-    }
-    carry += chunk;
-  }
-  q2 = rr::wave_sum_u128(q2);
-  __syncthreads();
-  if (lane == 0) {
-    s_qh[wv] = q2.hi;
-    s_ql[wv] = q2.lo;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    u128 qq = {0, 0};
-    for (int k = 0; k < W; ++k) qq = rr::add128(qq, u128{s_qh[k], s_ql[k]});
-    ctl->weights_uniform = 0;
-    ctl->usable = usable ? 1 : 0;
-    ctl->image_mode = mode;
-    ctl->shift = shift;
-    ctl->wmax = wmax;
-    PlanArgs pa = a.plan;
-    pa.n_global = n;
-    pa.rstep = rstep;
-    rr::finalize_plan(ctl, carry, 0, carry, qq, pa);  // forced, eager: Ctl.cur flips here, the weights become uniform
-  }
-  if (front_only) return;  // (the draws, the table and the count follow as launches of their own; never resident)
-  __syncthreads();
-  RR_ATL(3);
-  // ---- the candidate draws in blocks of kKldThreads, as far as the reference's loop would go (:340-352): a block's draws and
-  // bins (k_kld_draw; the lower bound over the whole CDF is the index its two-level search finds), its entries in the bin
-  // table (k_kld_insert), then the stop rule over the block (k_kld_count: occupied-bin count after every draw, running
-  // maximum of the KLD bound) -- the first block that contains the stopping draw is the last one looked at.  A bin's smallest
-  // draw index can only come from the blocks seen so far, so the flags of a block are final when it has been inserted: the
-  // result is that of all max_particles candidates evaluated at once, for a fifth of the work at the default configuration
-  // (5 000 candidates, a tracking filter stops around 300).
-  __shared__ uint64_t s_cnt[W];
-  __shared__ uint64_t s_req[W];
-  __shared__ uint64_t s_stop;
-  // The FIRST block of draws keeps its bin table in the LDS (the reference's loop stops after a few hundred draws when the filter
-  // tracks, :340-352: the first block is then the only one).  The global table's claim / probe / lower-the-minimum chain is six
-  // dependent device-scope round trips (~7 us of the step); the same chain on ds_ atomics is a few hundred cycles.  The flags
-  // (is draw m the first of its bin?) do not depend on where the table lives.  Only if the loop goes on are the first block's
-  // draws inserted into the global table as well (the later blocks must see their bins).
-  constexpr int kLdsSlots = 2 * kKldThreads;
-  __shared__ int32_t s_keys[3 * kKldThreads];
-  __shared__ unsigned int s_tab[kLdsSlots], s_min[kLdsSlots];
-  const int src = ctl->cur ^ 1;
-  uint64_t k_carry = 0, req_carry = a.kld.min_particles, seen = 0;
-  if (tid == 0) s_stop = ~0ull;
-  for (int q = tid; q < kLdsSlots; q += kKldThreads) {
-    s_tab[q] = kKldEmpty;
-    s_min[q] = kKldEmpty;
-  }
-  __syncthreads();
-  // ... and in SUB-blocks of kKldSub draws (four waves, one per SIMD): a tracking filter stops after 100 - 300 draws, and the
-  // sixteen waves of a full block spend 4 us issuing ~500 instructions per draw for 1 024 candidates of which a quarter matter
-  constexpr int kKldSub = 256;
-  for (uint64_t base = 0; base < a.max_draws;) {
-    const bool in_lds = base < (uint64_t)kKldThreads;
-    const uint64_t span = in_lds ? (uint64_t)kKldSub : (uint64_t)kKldThreads;
-    const uint64_t m = base + tid;
-    const bool valid = (uint64_t)tid < span && m < a.max_draws;
-    int32_t xb = 0, yb = 0, ab = 0;
-    if (valid) {
-      const uint64_t target = rr::resample_target(ctl, RR_RESAMPLE_MULTINOMIAL, m, p.seed, rstep, resident ? pre + 2 * cap : nullptr, m);
-      uint64_t j = rr_lower_bound_u64(cdf, n, target);
-      if (j >= n) j = n - 1;
-      idx[m] = (unsigned int)j;
-      rr_kld_bin(b.x[src][j], b.y[src][j], b.yaw[src][j], &xb, &yb, &ab);
-      if (in_lds) {
-        s_keys[3 * m] = xb;
-        s_keys[3 * m + 1] = yb;
-        s_keys[3 * m + 2] = ab;
-      } else {
-        keys[3 * m] = xb;
-        keys[3 * m + 1] = yb;
-        keys[3 * m + 2] = ab;
-      }
-    }
-    __syncthreads();  // (a probing draw compares with the keys of the draw that owns a slot)
-    uint64_t flag;
-    if (in_lds) {
-      unsigned int sl = (unsigned int)(kld_hash(xb, yb, ab) & (uint64_t)(kLdsSlots - 1));
-      bool placed = !valid;
-      while (!placed) {
-        unsigned int o = s_tab[sl];
-        if (o == kKldEmpty) {
-          o = atomicCAS(&s_tab[sl], kKldEmpty, (unsigned int)m);
-          if (o == kKldEmpty) o = (unsigned int)m;
-        }
-        if (o == (unsigned int)m || (s_keys[3 * o] == xb && s_keys[3 * o + 1] == yb && s_keys[3 * o + 2] == ab)) placed = true;
-        else sl = (sl + 1) & (kLdsSlots - 1);
-      }
-      if (valid) atomicMin(&s_min[sl], (unsigned int)m);
-      __syncthreads();
-      flag = (valid && s_min[sl] == (unsigned int)m) ? 1ull : 0ull;
-    } else {
-      kld_insert_one(m, valid, keys, table, minslot, myslot, a.hash_size);
-      __syncthreads();
-      seen = base + kKldThreads < a.max_draws ? base + kKldThreads : a.max_draws;
-      flag = (valid && __hip_atomic_load(&minslot[myslot[m]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)m) ? 1ull : 0ull;
-    }
-    uint64_t incl = rr::wave_scan_u64(flag, lane);
-    if (lane == 63) s_cnt[wv] = incl;
-    __syncthreads();
-    uint64_t off = k_carry, chunk_total = 0;
-    for (int q = 0; q < W; ++q) {
-      if (q < wv) off += s_cnt[q];
-      chunk_total += s_cnt[q];
-    }
-    const uint64_t k = off + incl;
-    uint64_t req = valid ? rr_kld_required(k, a.kld.min_particles, a.kld.max_particles, a.kld.kld_epsilon, a.kld.kld_z) : 0;
-    req = rr::wave_scan_max_u64(req);  // running maximum inside the wave (:350)
-    if (lane == 63) s_req[wv] = req;
-    __syncthreads();
-    uint64_t pre = req_carry, chunk_req = req_carry;
-    for (int q = 0; q < W; ++q) {
-      if (q < wv) pre = s_req[q] > pre ? s_req[q] : pre;
-      chunk_req = s_req[q] > chunk_req ? s_req[q] : chunk_req;
-    }
-    if (pre > req) req = pre;
-    if (valid && rr_kld_stop(m, req, a.kld.min_particles)) atomicMin((unsigned long long*)&s_stop, (unsigned long long)m);
-    __syncthreads();
-    if (s_stop != ~0ull) break;  // uniform: read after the barrier
-    k_carry += chunk_total;
-    req_carry = chunk_req;
-    base += span;
-    if (in_lds && base == (uint64_t)kKldThreads && base < a.max_draws) {
-      // the loop leaves the LDS table: the global blocks that follow must find the first 1 024 draws' bins
-      const bool v2 = (uint64_t)tid < a.max_draws;
-      if (v2) {
-        keys[3 * tid] = s_keys[3 * tid];
-        keys[3 * tid + 1] = s_keys[3 * tid + 1];
-        keys[3 * tid + 2] = s_keys[3 * tid + 2];
-      }
-      __syncthreads();
-      kld_insert_one((uint64_t)tid, v2, keys, table, minslot, myslot, a.hash_size);
-      seen = (uint64_t)kKldThreads < a.max_draws ? (uint64_t)kKldThreads : a.max_draws;
-    }
-    __syncthreads();
-  }
-  const uint64_t n_new = s_stop == ~0ull ? a.max_draws : s_stop + 1;  // :342: at most max_particles
-  __syncthreads();
-  RR_ATL(4);
-  // the table slots the draws of this step have used go back to empty for the next one (every occupied slot is some draw's)
-  for (uint64_t m = tid; m < seen; m += kKldThreads) {
-    const unsigned int sl = myslot[m];
-    table[sl] = kKldEmpty;
-    minslot[sl] = kKldEmpty;
-  }
-  const int dst = ctl->cur;
-  for (uint64_t k = tid; k < n_new; k += kKldThreads) copy_particle(b, dst ^ 1, dst, idx[k], k, false, nullptr);
-  if (tid == 0) {
-    out[0] = n_new;
-    ctl->n_active = n_new;
-  }
-  RR_ATL(5);
-  if (mail || resident) {
-  // ---- the mean try_step returns (monte_carlo_localization.rs:299-300 after :359-362: uniform weights over the new set), for
-  // the synchronous caller: formed exactly as rr_pf_estimate forms it -- k_moments runs ceil(n / 256) workgroups of four waves
-  // with one particle per thread (n <= 262 144), so this workgroup's chunk c stands for workgroups 4c .. 4c + 3, its wave w for
-  // wave w % 4 of workgroup 4c + w / 4; the workgroup partials are added in k_moments' order and reduced as k_moments_final
-  // does (lane j takes partial j: at most 64 of them for the 16 384 particles this kernel serves) -- and left in the host
-  // mailbox / the resident answer.  flags != 0: weights that do not sum to a positive number: the host takes the long way.
-  __shared__ double s_mom[W][5];
-  __shared__ double s_part[64][5];
-  __syncthreads();  // (the gathered set is complete)
-  const int n_blocks = (int)((n_new + kBlock - 1) / kBlock);
-  const double p0[4] = {b.x[dst][0], b.y[dst][0], b.yaw[dst][0], b.v[dst][0]};
-  for (uint64_t base = 0; base < n_new; base += kKldThreads) {
-    const uint64_t i = base + tid;
-    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if (i < n_new) {
-      const double wi = 1.0;
-      const double d0 = b.x[dst][i] - p0[0], d1 = b.y[dst][i] - p0[1], d2 = b.yaw[dst][i] - p0[2], d3 = b.v[dst][i] - p0[3];
-      acc[0] += wi;
-      acc[1] += wi * d0;
-      acc[2] += wi * d1;
-      acc[3] += wi * d2;
-      acc[4] += wi * d3;
-    }
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      const double sw = rr::wave_sum(acc[k]);
-      if (lane == 0) s_mom[wv][k] = sw;
-    }
-    __syncthreads();
-    if (tid < 5 * (kKldThreads / kBlock)) {  // k_moments: a workgroup's four wave sums, in wave order
-      const int q = tid / 5, k = tid % 5, blk = (int)(base / kBlock) + q;
-      if (blk < n_blocks) {
-        double part = 0.0;
-        for (int r = 0; r < kBlock / rr::kWave; ++r) part += s_mom[(kBlock / rr::kWave) * q + r][k];
-        s_part[blk][k] = part;
-      }
-    }
-    __syncthreads();
-  }
-  if (wv == 0) {
-    double mom[5];
-#pragma unroll
-    for (int k = 0; k < 5; ++k) {
-      double v = 0.0;  // k_moments_final: lane j adds the partials j, j + 64, ... (one here), then the shuffle tree
-      if (lane < n_blocks) v += s_part[lane][k];
-      mom[k] = rr::wave_sum(v);
-    }
-    const double Wt = mom[0];
-    const bool ok = Wt > 0.0 && Wt < INFINITY;
-    const uint64_t flags = (uint64_t)(ok ? 0 : 1) | ((uint64_t)(ctl->grid_timeout != 0) << 1);
-    if (resident) {
-      const uint64_t seq = a.res.first_seq + (uint64_t)s;
-      if (lane < 4) {
-        const double e = lane == 0 ? p0[0] + mom[1] / Wt : lane == 1 ? p0[1] + mom[2] / Wt : lane == 2 ? p0[2] + mom[3] / Wt : p0[3] + mom[4] / Wt;
-        rr::store_pair_sys(&ring->rsp[lane], (uint64_t)__double_as_longlong(e), seq);
-      }
-      if (lane == 4) rr::store_pair_sys(&ring->rsp[rr::kResRspFlags], flags, seq);
-#if defined(RR_PLAN_TIMELINE)
-      if (lane == 0) {
-        { uint64_t t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); atl[6] = t_; }
-        atl[7] = n_new;
-        for (int k = 0; k < 8; ++k) rr::store_pair_sys(&ring->rsp[8 + k], atl[k], seq);
-      }
-#endif
-    } else if (lane == 0) {
-      for (int q = 0; q < 4; ++q)
-        __hip_atomic_store(reinterpret_cast<uint64_t*>(&mail->est[q]), (uint64_t)__double_as_longlong(p0[q] + mom[1 + q] / Wt), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-      __hip_atomic_store(&mail->flags, flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&mail->seq, mail_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
-  }
-  if (!resident) break;
-  __syncthreads();  // (Ctl.n_active, Ctl.cur and the gathered set are read by the next step)
-  }  // for (s)
-  if (resident && tid == 0) {  // EXIT marker (resident_core.hpp)
-    const uint64_t consumed = a.res.first_seq + (uint64_t)steps_done - 1 + (res_last_op == rr::kResOpQuit ? 1 : 0);
-    rr::store_pair_sys(&ring->rsp[rr::kResRspExit], consumed, a.res.launch_id);
-  }
-}
-
-// the first n_new = kld_out[0] draws become the particle set (set cur^1 -> set cur), and n_new becomes the filter's particle
-// count ON THE DEVICE: every later kernel of an adaptive filter reads Ctl.n_active, so the host need not wait for the number
-__global__ __launch_bounds__(kBlock) void k_kld_gather_dyn(Bufs b, Ctl* __restrict__ ctl, const unsigned int* __restrict__ idx,
-                                                          const uint64_t* __restrict__ kld_out) {
-  const uint64_t n_new = kld_out[0];
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const int dst = ctl->cur, src = dst ^ 1;
-  if (k < n_new) copy_particle(b, src, dst, idx[k], k, false, nullptr);
-  if (k == 0) ctl->n_active = n_new;  // (nothing in this launch reads it)
-}
-
-// the first n_new draws become the particle set (set cur^1 -> set cur)
-__global__ __launch_bounds__(kBlock) void k_kld_gather(Bufs b, const Ctl* __restrict__ ctl,
-                                                      const unsigned int* __restrict__ idx, uint64_t n_new) {
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= n_new) return;
-  const int dst = ctl->cur, src = dst ^ 1;
-  copy_particle(b, src, dst, idx[k], k, false, nullptr);
-}
+#include "pf_kernels_adaptive.inc"
 
 // =============================================================================================
 // host side
@@ -4701,547 +2618,4 @@ rr_status rr_pf_p2p_status(rr_pf* h, int32_t* timed_out) {
 // native sharded step: RCCL through dlopen
 }  // extern "C"
 
-#include <dlfcn.h>
-
-extern "C" {
-
-rr_status rr_comm_unique_id(uint8_t out[RR_COMM_UNIQUE_ID_BYTES]) {
-  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
-  rr_status s = rccl_load();
-  if (s != RR_OK) return s;
-  RR_NCCL_TRY(rccl().GetUniqueId(out));
-  return RR_OK;
-}
-
-rr_status rr_comm_create(const uint8_t id[RR_COMM_UNIQUE_ID_BYTES], int32_t rank, int32_t n_ranks, int32_t device,
-                         rr_comm** out) {
-  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
-  *out = nullptr;
-  if (!id || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(RR_INVALID_PARAMETER, "bad communicator arguments");
-  rr_status s = rccl_load();
-  if (s != RR_OK) return s;
-  RR_HIP_TRY(hipSetDevice(device));
-  rr_comm* c = new rr_comm();
-  c->rank = rank;
-  c->n_ranks = n_ranks;
-  c->device = device;
-  ncclUniqueIdPod uid;
-  std::memcpy(uid.internal, id, RR_COMM_UNIQUE_ID_BYTES);
-  int e = rccl().CommInitRank(&c->comm, n_ranks, uid, rank);
-  if (e != 0) {
-    delete c;
-    return fail(RR_RUNTIME_ERROR, std::string("ncclCommInitRank: ") + (rccl().GetErrorString ? rccl().GetErrorString(e) : "error"));
-  }
-  auto bad = [&](hipError_t err) {
-    rr_comm_destroy(c);
-    return fail(RR_RUNTIME_ERROR, std::string("communicator scratch: ") + hipGetErrorString(err));
-  };
-  hipError_t err;
-  if ((err = hipMalloc(&c->d_wmax, sizeof(double))) != hipSuccess) return bad(err);
-  if ((err = hipMalloc(&c->d_sums, 3 * sizeof(uint64_t))) != hipSuccess) return bad(err);
-  if ((err = hipMalloc(&c->d_all, (3 * n_ranks + 1) * sizeof(uint64_t))) != hipSuccess) return bad(err);
-  if ((err = hipHostMalloc(&c->h_all, (3 * n_ranks + 1) * sizeof(uint64_t))) != hipSuccess) return bad(err);
-  if ((err = hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming)) != hipSuccess) return bad(err);
-  if ((err = hipMalloc(&c->d_mom, 21 * (n_ranks + 1) * sizeof(double))) != hipSuccess) return bad(err);
-  if ((err = hipHostMalloc(&c->h_mom, 21 * (n_ranks + 1) * sizeof(double))) != hipSuccess) return bad(err);
-  c->matrix.assign((size_t)n_ranks * n_ranks, 0);
-  *out = c;
-  return RR_OK;
-}
-
-void rr_comm_destroy(rr_comm* c) {
-  if (!c) return;
-  (void)hipSetDevice(c->device);
-  (void)hipDeviceSynchronize();
-  if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
-  (void)hipFree(c->d_wmax);
-  (void)hipFree(c->d_sums);
-  (void)hipFree(c->d_all);
-  if (c->h_all) (void)hipHostFree(c->h_all);
-  if (c->ev_plan) (void)hipEventDestroy(c->ev_plan);
-  (void)hipFree(c->d_send);
-  (void)hipFree(c->d_recv);
-  (void)hipFree(c->d_fsend);
-  (void)hipFree(c->d_frecv);
-  (void)hipFree(c->d_cnt);
-  if (c->h_cnt) (void)hipHostFree(c->h_cnt);
-  (void)hipFree(c->d_mom);
-  if (c->h_mom) (void)hipHostFree(c->h_mom);
-  delete c;
-}
-
-// The systematic sharded step over RCCL, lazy like the peer-to-peer one: k_step_lazy<kSrcWindow> | all-reduce(MAX) |
-// k_quantize_reduce_sums (image + this shard's sums by its last workgroup) | all-gather(sums) | k_mark_plan (gate + plan +
-// window markers) | D2H of the sums + event | k_pack_window | grouped send/recv of the window's overhang only | k_unpack_inbox.  Own slots inside the own window never
-// move (the next step reads them through the markers); the host's one wait -- for the G sums that size the segments --
-// is an EVENT recorded right behind the copy, so it overlaps k_mark and k_pack_window instead of draining the stream.
-// Round 2 propagated with the non-lazy kernel, gathered ALL served slots into a send buffer and adopted all n slots
-// (two 64 MB passes at 1e6 particles) behind a full stream synchronisation: 99 us at world size 1.
-// The step is written as phases with the three exchanges between them, so that the same code runs over RCCL
-// (rr_pf_shard_step) and over plain device copies between shards of ONE process (rr_pf_shard_step_local: the seam that
-// lets a one-GPU box check the segment logic for 2 and 3 shards).
-struct WinPlan {
-  bool fired = false;
-  uint64_t n_send = 0, n_recv = 0, below = 0, self = 0;
-};
-
-static double* win_wmax_slot(rr_comm* c) { return reinterpret_cast<double*>(c->d_all + 3 * (size_t)c->n_ranks); }
-
-static rr_status win_ensure(double** buf, size_t* cap, size_t records) {
-  if (records <= *cap) return RR_OK;
-  if (*buf) RR_HIP_TRY(hipFree(*buf));
-  *buf = nullptr;
-  *cap = 0;
-  const size_t want = records + records / 4 + 1024;
-  RR_HIP_TRY(hipMalloc(buf, want * 4 * sizeof(double)));
-  *cap = want;
-  return RR_OK;
-}
-
-static void win_pack(rr_pf* h, rr_comm* c) {
-  Timed t(h, RR_K_RESAMPLE_GATHER);
-  hipLaunchKernelGGL(k_pack_window, dim3(kPushGrid), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->markers, h->carry, c->rank, h->n, h->slot_pad,
-                     c->d_send, (uint64_t)c->cap_send);
-}
-
-// A: propagate + weight through the window; the local maximum stays in Ctl.wmax_bits
-static rr_status win_phase_a(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
-  rr_status s;
-  if ((s = validate_control(control)) != RR_OK) return s;
-  if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
-  if (h->maybe_pending && !(h->pending_kind == kSrcWindow && h->window_rccl) && (s = materialise(h)) != RR_OK) return s;
-  ObsArg arg;
-  bool kernarg;
-  if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
-  StepParams p = make_params(h, control, (int)n_obs);
-  const size_t lds = 3 * n_obs * sizeof(double);
-  if (lds > 150 * 1024) return fail(RR_INVALID_PARAMETER, "too many observations for one LDS block (max 6400)");
-  if (!h->rccl_inbox) RR_HIP_TRY(hipMalloc(&h->rccl_inbox, 4 * h->n * sizeof(double)));
-  if (!h->wmax_bits_clean) RR_HIP_TRY(hipMemsetAsync(&h->ctl->wmax_bits, 0, sizeof(uint64_t), h->stream));
-  WindowArgs wa{};
-  wa.inbox = h->rccl_inbox;
-  wa.pad = h->slot_pad;
-  wa.n_ranks = 0;  // nothing to wait for inside the kernel
-  {
-    Timed t(h, RR_K_PROPAGATE_WEIGHT);
-    launch_k1(h, kernarg, kSrcWindow, (unsigned)((h->n + rr::kResolveSlots - 1) / rr::kResolveSlots), lds, nullptr, nullptr, p, arg,
-              h->markers, h->carry, nullptr, wa);
-  }
-  RR_HIP_TRY(hipGetLastError());
-  h->step += 1;
-  return RR_OK;
-}
-
-// B: the integer image under the GLOBAL maximum (in the slot behind the gathered sums), local sums -> c->d_sums
-static rr_status win_phase_b(rr_pf* h, rr_comm* c) {
-  Timed t(h, RR_K_QUANTIZE_REDUCE);
-  hipLaunchKernelGGL(rr::k_quantize_reduce_sums, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, (const double*)h->w, h->ctl,
-                     (const double*)win_wmax_slot(c), image_args(h), h->tile_total, h->tile_q2, /*settle=*/1, h->n_tiles, h->grid_ticket,
-                     c->d_sums);
-  RR_HIP_TRY(hipGetLastError());
-  return RR_OK;
-}
-
-// C: gate + plan + markers over the global slot index, the sums on their way to the host, the overhang into the send buffer
-static rr_status win_phase_c(rr_pf* h, rr_comm* c) {
-  const int G = c->n_ranks;
-  PlanArgs pa = plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN);
-  pa.lazy_gather = 1;
-  {
-    Timed t(h, RR_K_CDF);
-    hipLaunchKernelGGL(rr::k_mark_plan, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, (const double*)h->w, h->ctl, image_args(h),
-                       (const uint64_t*)h->tile_total, (const uint64_t*)c->d_all, G, c->rank, pa, h->markers, h->carry, h->slot_pad);
-  }
-  RR_HIP_TRY(hipMemcpyAsync(c->h_all, c->d_all, (3 * (size_t)G + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
-  RR_HIP_TRY(hipEventRecord(c->ev_plan, h->stream));
-  if (G > 1) {
-    rr_status s = win_ensure(&c->d_send, &c->cap_send, std::max<size_t>(65536, h->n / 8));
-    if (s != RR_OK) return s;
-    win_pack(h, c);
-  }
-  RR_HIP_TRY(hipGetLastError());
-  h->wmax_live = false;
-  h->wmax_bits_clean = true;
-  h->rstep += 1;
-  return RR_OK;
-}
-
-// the host's part: gate decision and segment sizes from the G sums (pure integer arithmetic, the same on every rank)
-static rr_status win_host(rr_pf* h, rr_comm* c, WinPlan* out) {
-  const int G = c->n_ranks, r = c->rank;
-  RR_HIP_TRY(hipEventSynchronize(c->ev_plan));
-  const double wmax = rr_u2d(c->h_all[3 * (size_t)G]);
-  const bool usable = wmax > 0.0 && wmax < INFINITY;
-  std::vector<uint64_t> totals(G);
-  uint64_t total = 0;
-  u128 qq = {0, 0};
-  for (int g = 0; g < G; ++g) {
-    totals[g] = c->h_all[3 * g];
-    total += totals[g];
-    qq = rr::add128(qq, u128{c->h_all[3 * g + 1], c->h_all[3 * g + 2]});
-  }
-  const double neff = (usable && total > 0) ? rr_fix_neff(total, qq.hi, qq.lo) : (double)h->n_global;  // (unusable: the uniform image)
-  const double threshold = (double)h->n_global * h->cfg.resample_threshold;
-  *out = WinPlan{};
-  out->fired = h->opt.resample_gate == RR_GATE_ALWAYS || neff < threshold;
-  h->last_migrated = 0;
-  if (!out->fired) {
-    h->maybe_pending = false;
-    h->pending_kind = kSrcMarkers;
-    return RR_OK;
-  }
-  h->maybe_pending = true;
-  h->pending_kind = kSrcWindow;
-  h->window_rccl = true;
-  h->window_seq = 0;
-  out->self = h->n;
-  if (G == 1) return RR_OK;
-  double rho, dummy;
-  rr_uniform2(h->opt.seed, RR_STREAM_RESAMPLE, h->rstep - 1, 0, &rho, &dummy);  // (phase C has advanced the counter)
-  (void)rr_sys_segment_matrix(rho, totals.data(), G, h->n_global, h->n, r, c->matrix.data());
-  const int64_t* M = c->matrix.data();
-  uint64_t migrated = 0;
-  for (int g = 0; g < G; ++g) {
-    if (g != r) {
-      out->n_send += (uint64_t)M[(size_t)r * G + g];
-      out->n_recv += (uint64_t)M[(size_t)g * G + r];
-      if (g < r) out->below += (uint64_t)M[(size_t)g * G + r];
-    }
-    for (int d = 0; d < G; ++d)
-      if (g != d) migrated += (uint64_t)M[(size_t)g * G + d];
-  }
-  h->last_migrated = migrated;
-  out->self = (uint64_t)M[(size_t)r * G + r];
-  if (out->n_recv + out->self != h->n) return fail(RR_RUNTIME_ERROR, "segment plan does not cover this shard's slots exactly once");
-  rr_status s;
-  if (out->n_send > c->cap_send) {  // the overhang did not fit: the kernel left everything in place
-    if ((s = win_ensure(&c->d_send, &c->cap_send, out->n_send)) != RR_OK) return s;
-    win_pack(h, c);
-    RR_HIP_TRY(hipGetLastError());
-  }
-  return win_ensure(&c->d_recv, &c->cap_recv, out->n_recv);
-}
-
-// D: what the peers served for this shard's slots -> the inbox
-static rr_status win_phase_d(rr_pf* h, rr_comm* c, const WinPlan& w) {
-  if (!w.fired || !w.n_recv) return RR_OK;
-  hipLaunchKernelGGL(k_unpack_inbox, dim3(grid_for(w.n_recv, kBlock)), dim3(kBlock), 0, h->stream, (const double*)c->d_recv, w.n_recv, w.below,
-                     w.self, h->n, h->rccl_inbox);
-  RR_HIP_TRY(hipGetLastError());
-  return RR_OK;
-}
-
-static rr_status shard_step_rccl_window(rr_pf* h, rr_comm* c, const double control[2], const double* obs, size_t n_obs) {
-  rr_status s;
-  Rccl& R = rccl();
-  const int G = c->n_ranks, r = c->rank;
-  if ((s = win_phase_a(h, control, obs, n_obs)) != RR_OK) return s;
-  RR_NCCL_TRY(R.AllReduce(&h->ctl->wmax_bits, win_wmax_slot(c), 1, kNcclFloat64, kNcclMax, c->comm, h->stream));  // (doubles >= 0)
-  if ((s = win_phase_b(h, c)) != RR_OK) return s;
-  RR_NCCL_TRY(R.AllGather(c->d_sums, c->d_all, 3, kNcclUint64, c->comm, h->stream));
-  if ((s = win_phase_c(h, c)) != RR_OK) return s;
-  WinPlan w;
-  if ((s = win_host(h, c, &w)) != RR_OK) return s;
-  if (w.fired && (w.n_send || w.n_recv)) {
-    const int64_t* M = c->matrix.data();
-    RR_NCCL_TRY(R.GroupStart());
-    uint64_t so = 0, ro = 0;
-    for (int g = 0; g < G; ++g) {
-      if (g == r) continue;
-      const uint64_t ns = (uint64_t)M[(size_t)r * G + g], nr = (uint64_t)M[(size_t)g * G + r];
-      if (ns) RR_NCCL_TRY(R.Send(c->d_send + 4 * so, 4 * ns, kNcclFloat64, g, c->comm, h->stream));
-      if (nr) RR_NCCL_TRY(R.Recv(c->d_recv + 4 * ro, 4 * nr, kNcclFloat64, g, c->comm, h->stream));
-      so += ns;
-      ro += nr;
-    }
-    RR_NCCL_TRY(R.GroupEnd());
-  }
-  return win_phase_d(h, c, w);
-}
-
-rr_status rr_pf_shard_step(rr_pf* h, rr_comm* c, const double control[2], const double* obs, size_t n_obs) {
-  rr_status s = bind(h);
-  if (s != RR_OK) return s;
-  if (!c) return fail(RR_INVALID_PARAMETER, "null communicator");
-  if (h->n_global != h->n * (uint64_t)c->n_ranks || h->opt.first_global_index != h->n * (uint64_t)c->rank)
-    return fail(RR_INVALID_PARAMETER, "shard geometry does not match the communicator (equal blocks, rank * n_local)");
-  static const bool eager = [] { const char* e = std::getenv("RR_PF_RCCL_EAGER"); return e && std::atoi(e) != 0; }();
-  if (h->opt.resample_scheme == RR_RESAMPLE_SYSTEMATIC && !eager) return shard_step_rccl_window(h, c, control, obs, n_obs);
-  Rccl& R = rccl();
-  // A: propagate + weight, local maximum
-  if ((s = rr_pf_shard_propagate_weight(h, control, obs, n_obs, c->d_wmax)) != RR_OK) return s;
-  RR_NCCL_TRY(R.AllReduce(c->d_wmax, c->d_wmax, 1, kNcclFloat64, kNcclMax, c->comm, h->stream));
-  // B: integer image under the global maximum, local sums
-  if ((s = rr_pf_shard_quantize(h, c->d_wmax, c->d_sums)) != RR_OK) return s;
-  RR_NCCL_TRY(R.AllGather(c->d_sums, c->d_all, 3, kNcclUint64, c->comm, h->stream));
-  // C: plan + local marking; the G totals come back to the host to size the segments
-  if ((s = rr_pf_shard_cdf(h, c->d_all, c->n_ranks, c->rank)) != RR_OK) return s;
-  RR_HIP_TRY(hipMemcpyAsync(c->h_all, c->d_all, 3 * c->n_ranks * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
-  rr_pf_shard_plan plan;
-  if ((s = rr_pf_shard_get_plan(h, &plan)) != RR_OK) return s;  // synchronises the stream
-  if (!plan.fired) {
-    h->last_migrated = 0;
-    return RR_OK;
-  }
-  const int G = c->n_ranks, r = c->rank;
-  if (h->opt.resample_scheme == RR_RESAMPLE_MULTINOMIAL) {
-    // scattered served slots: every rank counts what it serves per destination, the counts are all-gathered into
-    // the exchange matrix, records (x, y, yaw, v, local slot) travel in one grouped send/recv
-    if (!c->d_cnt) {
-      RR_HIP_TRY(hipMalloc(&c->d_cnt, ((size_t)G + (size_t)G * G) * sizeof(uint64_t)));
-      RR_HIP_TRY(hipHostMalloc(&c->h_cnt, (size_t)G * G * sizeof(uint64_t)));
-    }
-    if ((s = rr_pf_shard_select(h, G, c->d_cnt)) != RR_OK) return s;
-    RR_NCCL_TRY(R.AllGather(c->d_cnt, c->d_cnt + G, G, kNcclUint64, c->comm, h->stream));
-    RR_HIP_TRY(hipMemcpyAsync(c->h_cnt, c->d_cnt + G, (size_t)G * G * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
-    RR_HIP_TRY(hipStreamSynchronize(h->stream));
-    uint64_t n_send = 0, n_recv = 0, migrated = 0;
-    for (int g = 0; g < G; ++g) {
-      n_send += c->h_cnt[(size_t)r * G + g];
-      n_recv += c->h_cnt[(size_t)g * G + r];
-      for (int d = 0; d < G; ++d)
-        if (g != d) migrated += c->h_cnt[(size_t)g * G + d];
-    }
-    h->last_migrated = migrated;
-    if (n_recv != h->n) return fail(RR_RUNTIME_ERROR, "multinomial exchange does not cover this shard's slots exactly once");
-    auto ensure = [&](double** buf, size_t* cap, size_t need) -> rr_status {
-      if (need <= *cap) return RR_OK;
-      if (*buf) RR_HIP_TRY(hipFree(*buf));
-      *buf = nullptr;
-      *cap = 0;
-      RR_HIP_TRY(hipMalloc(buf, (need + need / 4 + 1024) * sizeof(double)));
-      *cap = need + need / 4 + 1024;
-      return RR_OK;
-    };
-    if ((s = ensure(&c->d_fsend, &c->cap_fsend, 5 * n_send)) != RR_OK) return s;
-    if ((s = ensure(&c->d_frecv, &c->cap_frecv, 5 * h->n)) != RR_OK) return s;
-    if ((s = rr_pf_shard_pack_selected(h, G, c->d_fsend)) != RR_OK) return s;
-    RR_NCCL_TRY(R.GroupStart());
-    uint64_t so = 0, ro = 0;
-    for (int g = 0; g < G; ++g) {
-      const uint64_t ns = c->h_cnt[(size_t)r * G + g], nr = c->h_cnt[(size_t)g * G + r];
-      if (ns) RR_NCCL_TRY(R.Send(c->d_fsend + 5 * so, 5 * ns, kNcclFloat64, g, c->comm, h->stream));
-      if (nr) RR_NCCL_TRY(R.Recv(c->d_frecv + 5 * ro, 5 * nr, kNcclFloat64, g, c->comm, h->stream));
-      so += ns;
-      ro += nr;
-    }
-    RR_NCCL_TRY(R.GroupEnd());
-    return rr_pf_shard_adopt_records(h, c->d_frecv, h->n);
-  }
-  std::vector<uint64_t> totals(G);
-  for (int g = 0; g < G; ++g) totals[g] = c->h_all[3 * g];
-  const uint64_t first = rr_sys_segment_matrix(plan.rho, totals.data(), G, h->n_global, h->n, r, c->matrix.data());
-  const int64_t* M = c->matrix.data();
-  uint64_t n_send = 0, n_recv = 0, migrated = 0;
-  for (int g = 0; g < G; ++g) {
-    n_send += (uint64_t)M[(size_t)r * G + g];
-    n_recv += (uint64_t)M[(size_t)g * G + r];
-    for (int d = 0; d < G; ++d)
-      if (g != d) migrated += (uint64_t)M[(size_t)g * G + d];
-  }
-  h->last_migrated = migrated;
-  if (n_recv != h->n) return fail(RR_RUNTIME_ERROR, "segment plan does not cover this shard's slots exactly once");
-  if (n_send > c->cap_send) {
-    if (c->d_send) RR_HIP_TRY(hipFree(c->d_send));
-    c->d_send = nullptr;
-    c->cap_send = 0;
-    RR_HIP_TRY(hipMalloc(&c->d_send, (n_send + n_send / 4 + 1024) * 4 * sizeof(double)));
-    c->cap_send = n_send + n_send / 4 + 1024;
-  }
-  if (h->n > c->cap_recv) {
-    if (c->d_recv) RR_HIP_TRY(hipFree(c->d_recv));
-    c->d_recv = nullptr;
-    RR_HIP_TRY(hipMalloc(&c->d_recv, h->n * 4 * sizeof(double)));
-    c->cap_recv = h->n;
-  }
-  // D: gather what the served slots need into one contiguous buffer, exchange the segments
-  if ((s = rr_pf_shard_gather_slots(h, first, n_send, c->d_send)) != RR_OK) return s;
-  // (what this rank serves to itself -- nearly everything: systematic resampling moves particles by a boundary's drift --
-  // does not go through a send / receive to the same rank: k_adopt reads it where the gather left it)
-  RR_NCCL_TRY(R.GroupStart());
-  uint64_t so = 0, ro = 0, self_so = 0, self_lo = 0, self_hi = 0;
-  for (int g = 0; g < G; ++g) {
-    const uint64_t ns = (uint64_t)M[(size_t)r * G + g], nr = (uint64_t)M[(size_t)g * G + r];
-    if (g == r) {
-      self_so = so;
-      self_lo = ro;
-      self_hi = ro + nr;  // (ns == nr for g == r)
-    } else {
-      if (ns) RR_NCCL_TRY(R.Send(c->d_send + 4 * so, 4 * ns, kNcclFloat64, g, c->comm, h->stream));
-      if (nr) RR_NCCL_TRY(R.Recv(c->d_recv + 4 * ro, 4 * nr, kNcclFloat64, g, c->comm, h->stream));
-    }
-    so += ns;
-    ro += nr;
-  }
-  RR_NCCL_TRY(R.GroupEnd());
-  // E: adopt
-  return shard_adopt_with_self(h, c->d_recv, c->d_send + 4 * self_so, self_lo, self_hi);
-}
-
-uint64_t rr_pf_shard_last_migrated(const rr_pf* h) { return h ? h->last_migrated : 0; }
-
-rr_status rr_comm_create_local(int32_t rank, int32_t n_ranks, int32_t device, rr_comm** out) {
-  if (!out) return fail(RR_INVALID_PARAMETER, "null output");
-  *out = nullptr;
-  if (n_ranks <= 0 || n_ranks > kMaxP2P || rank < 0 || rank >= n_ranks) return fail(RR_INVALID_PARAMETER, "bad rank layout (1..16 ranks)");
-  RR_HIP_TRY(hipSetDevice(device));
-  rr_comm* c = new rr_comm();
-  c->rank = rank;
-  c->n_ranks = n_ranks;
-  c->device = device;
-  auto bad = [&](hipError_t err) {
-    rr_comm_destroy(c);
-    return fail(RR_RUNTIME_ERROR, std::string("communicator scratch: ") + hipGetErrorString(err));
-  };
-  hipError_t err;
-  if ((err = hipMalloc(&c->d_wmax, sizeof(double))) != hipSuccess) return bad(err);
-  if ((err = hipMalloc(&c->d_sums, 3 * sizeof(uint64_t))) != hipSuccess) return bad(err);
-  if ((err = hipMalloc(&c->d_all, (3 * n_ranks + 1) * sizeof(uint64_t))) != hipSuccess) return bad(err);
-  if ((err = hipHostMalloc(&c->h_all, (3 * n_ranks + 1) * sizeof(uint64_t))) != hipSuccess) return bad(err);
-  if ((err = hipEventCreateWithFlags(&c->ev_plan, hipEventDisableTiming)) != hipSuccess) return bad(err);
-  c->matrix.assign((size_t)n_ranks * n_ranks, 0);
-  *out = c;
-  return RR_OK;
-}
-
-rr_status rr_pf_shard_step_local(rr_pf* const* hs, rr_comm* const* cs, int32_t n_ranks, const double control[2], const double* obs,
-                                 size_t n_obs) {
-  if (!hs || !cs || n_ranks <= 0 || n_ranks > kMaxP2P) return fail(RR_INVALID_PARAMETER, "bad shard list");
-  const int G = n_ranks;
-  rr_status s;
-  for (int g = 0; g < G; ++g) {
-    if (!hs[g] || !cs[g] || cs[g]->n_ranks != G || cs[g]->rank != g) return fail(RR_INVALID_PARAMETER, "shard / communicator list does not match the rank layout");
-    if (hs[g]->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC) return fail(RR_INVALID_PARAMETER, "systematic shards only");
-    if (hs[g]->n_global != hs[g]->n * (uint64_t)G || hs[g]->opt.first_global_index != hs[g]->n * (uint64_t)g)
-      return fail(RR_INVALID_PARAMETER, "shard geometry does not match the rank layout (equal blocks, rank * n_local)");
-  }
-  // A, then the all-reduce(MAX) by hand
-  uint64_t wmax_bits = 0;
-  for (int g = 0; g < G; ++g) {
-    if ((s = bind(hs[g])) != RR_OK) return s;
-    if ((s = win_phase_a(hs[g], control, obs, n_obs)) != RR_OK) return s;
-  }
-  for (int g = 0; g < G; ++g) {
-    if ((s = bind(hs[g])) != RR_OK) return s;
-    uint64_t b = 0;
-    RR_HIP_TRY(hipMemcpyAsync(&b, &hs[g]->ctl->wmax_bits, sizeof b, hipMemcpyDeviceToHost, hs[g]->stream));
-    RR_HIP_TRY(hipStreamSynchronize(hs[g]->stream));
-    if (rr_u2d(b) > rr_u2d(wmax_bits)) wmax_bits = b;
-  }
-  // B, then the all-gather by hand
-  std::vector<uint64_t> all(3 * (size_t)G + 1);
-  for (int g = 0; g < G; ++g) {
-    if ((s = bind(hs[g])) != RR_OK) return s;
-    RR_HIP_TRY(hipMemcpyAsync(win_wmax_slot(cs[g]), &wmax_bits, sizeof wmax_bits, hipMemcpyHostToDevice, hs[g]->stream));
-    if ((s = win_phase_b(hs[g], cs[g])) != RR_OK) return s;
-    RR_HIP_TRY(hipMemcpyAsync(&all[3 * (size_t)g], cs[g]->d_sums, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost, hs[g]->stream));
-    RR_HIP_TRY(hipStreamSynchronize(hs[g]->stream));
-  }
-  std::vector<WinPlan> plans(G);
-  for (int g = 0; g < G; ++g) {
-    if ((s = bind(hs[g])) != RR_OK) return s;
-    RR_HIP_TRY(hipMemcpyAsync(cs[g]->d_all, all.data(), 3 * (size_t)G * sizeof(uint64_t), hipMemcpyHostToDevice, hs[g]->stream));
-    if ((s = win_phase_c(hs[g], cs[g])) != RR_OK) return s;
-    if ((s = win_host(hs[g], cs[g], &plans[g])) != RR_OK) return s;
-    RR_HIP_TRY(hipStreamSynchronize(hs[g]->stream));  // the send buffer is complete
-  }
-  // the exchange: segment (src -> dst) = M[src][dst] records, the src's send buffer and the dst's receive buffer both in rank order
-  for (int d = 0; d < G; ++d) {
-    if (!plans[d].fired) continue;
-    if ((s = bind(hs[d])) != RR_OK) return s;
-    const int64_t* M = cs[d]->matrix.data();
-    uint64_t ro = 0;
-    for (int g = 0; g < G; ++g) {
-      if (g == d) continue;
-      const uint64_t nr = (uint64_t)M[(size_t)g * G + d];
-      uint64_t so = 0;  // offset of the (g -> d) segment in g's send buffer
-      for (int q = 0; q < d; ++q)
-        if (q != g) so += (uint64_t)M[(size_t)g * G + q];
-      if (nr) RR_HIP_TRY(hipMemcpyAsync(cs[d]->d_recv + 4 * ro, cs[g]->d_send + 4 * so, 4 * nr * sizeof(double), hipMemcpyDeviceToDevice, hs[d]->stream));
-      ro += nr;
-    }
-    if ((s = win_phase_d(hs[d], cs[d], plans[d])) != RR_OK) return s;
-    RR_HIP_TRY(hipStreamSynchronize(hs[d]->stream));
-  }
-  return RR_OK;
-}
-
-rr_status rr_pf_shard_estimate(rr_pf* h, rr_comm* c, double est[4], double cov[16]) {
-  rr_status s = bind(h);
-  if (s != RR_OK) return s;
-  if (!c) return fail(RR_INVALID_PARAMETER, "null communicator");
-  double e[4], cv[16];
-  if ((s = materialise(h)) != RR_OK) return s;
-  if ((s = compute_moments(h, e, cv)) != RR_OK) return s;
-  // weight share of this shard: 1/G after a resample, T_local / T otherwise
-  if ((s = fetch_ctl(h)) != RR_OK) return s;
-  const Ctl& k = *h->ctl_host;
-  double share = 1.0 / c->n_ranks;
-  if (!k.weights_uniform && k.total > 0) share = (double)k.total_local / (double)k.total;
-  double* rec = c->h_mom + 21 * (size_t)c->n_ranks;
-  rec[0] = share;
-  std::memcpy(rec + 1, e, sizeof e);
-  std::memcpy(rec + 5, cv, sizeof cv);
-  double* d_rec = c->d_mom + 21 * (size_t)c->n_ranks;
-  RR_HIP_TRY(hipMemcpyAsync(d_rec, rec, 21 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  RR_NCCL_TRY(rccl().AllGather(d_rec, c->d_mom, 21, kNcclFloat64, c->comm, h->stream));
-  RR_HIP_TRY(hipMemcpyAsync(c->h_mom, c->d_mom, 21 * (size_t)c->n_ranks * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  RR_HIP_TRY(hipStreamSynchronize(h->stream));
-  double W = 0.0, mean[4] = {0, 0, 0, 0};
-  for (int g = 0; g < c->n_ranks; ++g) {
-    const double* a = c->h_mom + 21 * (size_t)g;
-    W += a[0];
-    for (int q = 0; q < 4; ++q) mean[q] += a[0] * a[1 + q];
-  }
-  for (int q = 0; q < 4; ++q) mean[q] /= W;
-  if (est) std::memcpy(est, mean, sizeof mean);
-  if (cov) {
-    for (int q = 0; q < 16; ++q) cov[q] = 0.0;
-    for (int g = 0; g < c->n_ranks; ++g) {
-      const double* a = c->h_mom + 21 * (size_t)g;
-      for (int i = 0; i < 4; ++i)
-        for (int j = 0; j < 4; ++j) cov[4 * i + j] += a[0] * (a[5 + 4 * i + j] + (a[1 + i] - mean[i]) * (a[1 + j] - mean[j]));
-    }
-    for (int q = 0; q < 16; ++q) cov[q] /= W;
-  }
-  return RR_OK;
-}
-
-rr_status rr_pf_profile_enable(rr_pf* h, int32_t enable) {
-  rr_status s = bind(h);
-  if (s != RR_OK) return s;
-  RR_HIP_TRY(hipStreamSynchronize(h->stream));
-  drain_events(h);
-  h->profiling = enable != 0;
-  h->profile_dispatch_only = enable == 2;  // 2 = only the propagate+weight kernel, timed by its own dispatch packet
-  return RR_OK;
-}
-
-rr_status rr_pf_profile_read(rr_pf* h, int32_t kernel_id, uint64_t* launches, double* total_ms) {
-  rr_status s = bind(h);
-  if (s != RR_OK) return s;
-  if (kernel_id < 0 || kernel_id >= RR_K_COUNT) return fail(RR_INVALID_PARAMETER, "kernel id out of range");
-  RR_HIP_TRY(hipStreamSynchronize(h->stream));
-  drain_events(h);
-  if (launches) *launches = h->prof_launches[kernel_id];
-  if (total_ms) *total_ms = h->prof_ms[kernel_id];
-  return RR_OK;
-}
-
-rr_status rr_pf_profile_reset(rr_pf* h) {
-  rr_status s = bind(h);
-  if (s != RR_OK) return s;
-  RR_HIP_TRY(hipStreamSynchronize(h->stream));
-  drain_events(h);
-  for (int k = 0; k < RR_K_COUNT; ++k) {
-    h->prof_launches[k] = 0;
-    h->prof_ms[k] = 0.0;
-  }
-  return RR_OK;
-}
-
-const char* rr_pf_kernel_name(int32_t kernel_id) {
-  return kernel_id >= 0 && kernel_id < RR_K_COUNT ? kKernelNames[kernel_id] : "";
-}
-
-}  // extern "C"
+#include "pf_sharded_api.inc"
