@@ -8,6 +8,9 @@
 // touching 64 consecutive particles of one landmark field is one coalesced 512-byte access, the
 // observation list is wave-uniform (LDS), and the systematic resample is a monotone plane gather.
 //
+// One translation unit in two files: the kernels are in fs1_kernels.inc (#included below, in place); this file holds the handle,
+// the launch logic and the C ABI.
+//
 // Kernels of one update (rr_fs1_update_async): 3 launches (round 2: 5)
 //   k_fs1_resolve_predict   the last plan's markers -> idx[] (the update reads every observed landmark through it: lazy
 //                      gather) and the pose planes moved through it                   48 B / particle
@@ -49,972 +52,7 @@ using rr::kTile;
 using rr::PlanArgs;
 
 namespace {
-
-constexpr int kMaxChunks = 64;
-constexpr int kPlanesPerThread = 8;  // planes one gather thread copies for its output slot
-// sharded lazy resample: idx[p] == kInPlace => a peer has delivered slot p's particle into this rank's
-// fine-grained inbox (k_fs1_push); the consuming kernels then read slot p of the inbox instead
-constexpr unsigned int kInPlace = 0xffffffffu;
-
-struct Planes {
-  double* s[2];         // [(3 + 6L) * N]: planes 0..2 = x, y, yaw; plane 3 + l*6 + f = landmark l field f
-  const double* inbox;  // sharded: fine-grained mirror of one set where peers deliver cross-rank particles (else null)
-};
-
-// LAZY: consume a pending resample -- read the pose of slot p from particle idx[p] of the live
-// set and write the predicted pose to slot p of the OTHER set (k_quantize_reduce flips Ctl.cur
-// afterwards).  Otherwise in place.
-template <bool EXPLICIT, bool LAZY>
-__global__ __launch_bounds__(kBlock) void k_fs1_predict(Planes pl, const Ctl* __restrict__ ctl, uint64_t n,
-                                                       double u0, double u1, rr_fs1_model m, uint64_t seed,
-                                                       unsigned int step, const double* __restrict__ z0,
-                                                       const double* __restrict__ z1,
-                                                       const unsigned int* __restrict__ idx, uint64_t gid0) {
-  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= n) return;
-  const bool pending = LAZY && ctl->pending;
-  double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
-  const unsigned int ji = pending ? idx[p] : (unsigned int)p;
-  const bool inplace = pending && ji == kInPlace;
-  const double* __restrict__ src = inplace ? pl.inbox : pl.s[ctl->cur];
-  const uint64_t j = inplace ? p : ji;
-  double x = src[j], y = src[n + j], yaw = src[2 * n + j];
-  double a, b;
-  if (EXPLICIT) {
-    a = z0[p];
-    b = z1[p];
-  } else {
-    rr_fs1_motion_noise(seed, step, gid0 + p, &a, &b);
-  }
-  rr_fs1_predict_one(&x, &y, &yaw, u0, u1, a, b, m);
-  dst[p] = x;
-  dst[n + p] = y;
-  dst[2 * n + p] = yaw;
-}
-
-// observations of an update staged through the first kernel (k_fs1_resolve_predict)
-constexpr int kZStagePerThread = 4;              // words one thread of the staging workgroup carries
-constexpr int kZStageWords = kZStagePerThread * kBlock;  // 1024 doubles = 341 observations; more: hipMemcpyAsync as before
-constexpr int kZRing = 32;                       // pinned slots: the host runs at most this many updates ahead of the device
-struct ZStage {
-  const double* host;  // pinned, device-visible: 3 * n_z doubles of this update
-  double* dev;         // where k_fs1_observe reads them
-  uint64_t* done;      // pinned: sequence number of the last slot the device has consumed
-  uint64_t seq;
-  int words;           // 0: nothing to stage
-};
-
-// The same with the resample plan's markers resolved on the way (single GPU, FastSLAM 1.0): the plan kernel leaves markers,
-// the first kernel of the NEXT update turns them into source indices (running maximum per 2048 slots, rr::resolve_tile), keeps
-// them in idx[] for k_fs1_observe / k_fs1_gather and moves the poses through them -- one launch instead of k_fs1_resolve at
-// the end of an update and k_fs1_predict at the start of the next.
-__global__ __launch_bounds__(kBlock) void k_fs1_resolve_predict(Planes pl, const Ctl* __restrict__ ctl, uint64_t n, double u0, double u1,
-                                                               rr_fs1_model m, uint64_t seed, unsigned int step,
-                                                               unsigned int* __restrict__ markers, const unsigned int* __restrict__ carry,
-                                                               unsigned int* __restrict__ idx, uint64_t gid0, ZStage zs, int resolve) {
-  // The update's observations come along: the host has left them in a pinned slot, the last workgroup reads them over the
-  // bus while it does its share of the poses and leaves them in device memory for k_fs1_observe -- no H2D copy operation in
-  // the stream (4.7 us blit kernel + a boundary per update at 200 observations; they do not fit a kernel argument).
-  const bool stager = zs.words > 0 && blockIdx.x == gridDim.x - 1;
-  double zv[kZStagePerThread];
-  if (stager) {
-#pragma unroll
-    for (int k = 0; k < kZStagePerThread; ++k) {
-      const int i = k * kBlock + (int)threadIdx.x;
-      zv[k] = i < zs.words ? rr::ld_sys(zs.host + i) : 0.0;
-    }
-  }
-  const bool pending = ctl->pending != 0;  // uniform
-  unsigned int from[rr::kResolveRows];
-  if (pending && resolve) {
-    rr::resolve_tile(markers, carry, n, blockIdx.x, from);
-  } else if (pending) {  // an accessor has had the markers resolved already (k_fs1_resolve)
-#pragma unroll
-    for (int r = 0; r < rr::kResolveRows; ++r) {
-      const uint64_t p = (uint64_t)blockIdx.x * rr::kResolveSlots + (uint64_t)r * kBlock + threadIdx.x;
-      from[r] = p < n ? idx[p] : 0u;
-    }
-  }
-  const double* __restrict__ src = pl.s[ctl->cur];
-  double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
-  double x[rr::kResolveRows], y[rr::kResolveRows], yaw[rr::kResolveRows];
-#pragma unroll
-  for (int r = 0; r < rr::kResolveRows; ++r) {  // every row's loads first
-    const uint64_t p = (uint64_t)blockIdx.x * rr::kResolveSlots + (uint64_t)r * kBlock + threadIdx.x;
-    x[r] = y[r] = yaw[r] = 0.0;
-    if (p < n) {
-      const uint64_t j = pending ? (uint64_t)from[r] : p;
-      if (pending && resolve) idx[p] = from[r];
-      x[r] = src[j];
-      y[r] = src[n + j];
-      yaw[r] = src[2 * n + j];
-    }
-  }
-#pragma unroll
-  for (int r = 0; r < rr::kResolveRows; ++r) {
-    const uint64_t p = (uint64_t)blockIdx.x * rr::kResolveSlots + (uint64_t)r * kBlock + threadIdx.x;
-    if (p < n) {
-      double a, b;
-      rr_fs1_motion_noise(seed, step, gid0 + p, &a, &b);
-      rr_fs1_predict_one(&x[r], &y[r], &yaw[r], u0, u1, a, b, m);
-      dst[p] = x[r];
-      dst[n + p] = y[r];
-      dst[2 * n + p] = yaw[r];
-    }
-  }
-  if (stager) {
-#pragma unroll
-    for (int k = 0; k < kZStagePerThread; ++k) {
-      const int i = k * kBlock + (int)threadIdx.x;
-      if (i < zs.words) zs.dev[i] = zv[k];
-    }
-    __syncthreads();  // every thread's loads of the slot have returned (their values have been stored)
-    if (threadIdx.x == 0) rr::st_sys_u64(zs.done, zs.seq);  // the host may reuse the slot
-  }
-}
-
-// FastSLAM 2.0 (fastslam2.rs:339-358): the pose is not pushed through the noisy motion model but
-// SAMPLED from the proposal that fuses the motion prior with the first observation of the step --
-// per particle a 3x3 prior, a 2x2 innovation covariance, two 3x3 inverses, a Cholesky factor and
-// three normals (rr_fs2_predict_one).  Reads the six planes of the first observation's landmark;
-// LAZY as in k_fs1_predict.  noise (EXPLICIT): 3 unit normals per particle, [3p + k].
-template <bool EXPLICIT, bool LAZY>
-__global__ __launch_bounds__(kBlock) void k_fs2_predict(Planes pl, const Ctl* __restrict__ ctl, uint64_t n, double u0,
-                                                       double u1, rr_fs2_model m, uint64_t seed, unsigned int step,
-                                                       const double* __restrict__ noise,
-                                                       const unsigned int* __restrict__ idx, uint64_t gid0, int has_obs,
-                                                       double zd, double za, uint64_t id0) {
-  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= n) return;
-  const bool pending = LAZY && ctl->pending;
-  double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
-  const unsigned int ji = pending ? idx[p] : (unsigned int)p;
-  const bool inplace = pending && ji == kInPlace;
-  const double* __restrict__ src = inplace ? pl.inbox : pl.s[ctl->cur];
-  const uint64_t j = inplace ? p : ji;
-  double pose[3] = {src[j], src[n + j], src[2 * n + j]};
-  double lm[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-  if (has_obs) {
-    const double* in = src + (3 + id0 * 6) * n + j;
-#pragma unroll
-    for (int f = 0; f < 6; ++f) lm[f] = in[f * n];
-  }
-  double z[3];
-  if (EXPLICIT) {
-    z[0] = noise[3 * p];
-    z[1] = noise[3 * p + 1];
-    z[2] = noise[3 * p + 2];
-  } else {
-    rr_fs2_noise(seed, step, gid0 + p, z);
-  }
-  rr_fs2_predict_one(pose, u0, u1, has_obs, zd, za, lm, z, m);
-  dst[p] = pose[0];
-  dst[n + p] = pose[1];
-  dst[2 * n + p] = pose[2];
-}
-
-// (particle, observation chunk).  blockIdx.y = chunk.  The chunk's observations are staged in
-// LDS and read back with wave-uniform addresses; each update loads the 6 planes of the observed
-// landmark for 64 consecutive particles (coalesced), runs the 2x2 EKF of rr_fs1_update_one and
-// stores the six fields back (a field the update left alone is rewritten with the same bits).
-// SEQ (a landmark id repeats inside the step; host side: one chunk, in place, nothing pending): the
-// second update of a landmark must see the first one's result (fastslam1.rs:250-256 runs the
-// observations one after the other), so every update loads its planes only after the previous
-// update's stores -- no software pipeline, no restrict-qualified alias of the live set.
-// VAR: tuning variants of the same arithmetic (RR_FS1_VARIANT; identical results):
-//   bit 0  non-temporal stores while a pending resample is being consumed (separate read and write streams)
-//   bit 1  non-temporal loads on that path as well
-//   bit 2  no software pipeline (loads at the top of each update)
-//   bit 3  register budget for 4 waves per SIMD instead of 3
-// (The memory pattern alone -- same grid, same pipeline, synthetic arithmetic -- is tools/ubench/plane_layout.hip: 5.2-5.4 TB/s
-// whether 0 or 300 FMAs sit between a wave's loads and its stores; this kernel runs at 5.25 TB/s.)
-constexpr int kObsNtStore = 1, kObsNtLoad = 2, kObsNoPipe = 4, kObsFourWaves = 8;
-constexpr uint64_t kNoFactor = 0x7FF45EA1ED000001ull;  // "no factor here yet": a signalling NaN (k_fs1_observe)
-// ASSUMPTION: the closing chunk's workgroups of a particle block may wait for the factors of the block's other
-// chunks because those have LOWER workgroup indices in the same one-dimensional launch and the hardware dispatches a grid's
-// workgroups in ascending index order (round-robin over the XCDs): whoever is waited for has at least been handed to a CU
-// before the waiter exists.  HIP does not promise that order.  The wait is therefore bounded: after kFactorWaitTicks the weight
-// of the particle is NaN and Ctl.obs_timeout is latched -- every later accessor and synchronous call of the handle reports
-// RR_RUNTIME_ERROR ("a chunk's weight factor did not arrive") instead of returning numbers.  Never observed (the soak runs of
-// rounds 2-4: > 10^7 launches); a handle that must not depend on the assumption takes obs_chunks = 1 (rr_fs1_options).
-constexpr uint64_t kFactorWaitTicks = 200000000ull;    // 2 s of the 100 MHz wall clock
-
-__global__ __launch_bounds__(kBlock) void k_fs1_no_factors(uint64_t* __restrict__ partial, uint64_t words) {
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < words; i += (uint64_t)gridDim.x * kBlock) partial[i] = kNoFactor;
-}
-
-template <bool LAZY, bool SEQ, int VAR>
-__global__ __launch_bounds__(kBlock, (VAR & kObsFourWaves) ? 4 : 1) void k_fs1_observe(
-    Planes pl, double* __restrict__ pw, Ctl* __restrict__ ctl, uint64_t n, const double* __restrict__ z, int n_z, int chunk_len,
-    int n_chunks, rr_fs1_model m, double* partial /* written by the other chunks while the closing one reads */,
-    const unsigned int* __restrict__ idx, unsigned int n_pblocks) {
-  extern __shared__ double s_z[];
-  __shared__ double s_wmax[kBlock / rr::kWave];
-  // Dispatch order (one-dimensional grid of n_pblocks x n_chunks workgroups): chunk by chunk, a chunk's particle blocks side
-  // by side -- the order the memory system likes (block by block, all chunks of a block side by side: 20 % slower; bands of
-  // blocks, each band chunk by chunk: no better, RR_FS1_BANDS experiment of round 3).  A block's last chunk is therefore
-  // dispatched after its other chunks; it forms the block's weights (below).
-  const int chunk = (int)(blockIdx.x / n_pblocks);
-  const unsigned int pblock = blockIdx.x % n_pblocks;
-  const int k0 = chunk * chunk_len;
-  const int k1 = min(k0 + chunk_len, n_z);
-  for (int i = threadIdx.x; i < 3 * (k1 - k0); i += kBlock) s_z[i] = z[3 * k0 + i];
-  __syncthreads();
-  const uint64_t p = (uint64_t)pblock * kBlock + threadIdx.x;
-  double acc = 0.0;
-  if (p < n) {
-    // LAZY + pending: the maps of slot p still sit at particle idx[p] of the live set; every observed
-    // landmark is read from there and written (all six fields) to slot p of the other set, which
-    // folds the resample gather of the observed landmarks into this kernel's own traffic.  The
-    // pose was already moved by k_fs1_predict<LAZY>.
-    const bool pending = LAZY && ctl->pending;
-    const bool nt_st = pending && (VAR & kObsNtStore), nt_ld = pending && (VAR & kObsNtLoad);
-    double* __restrict__ dst = pl.s[pending ? ctl->cur ^ 1 : ctl->cur];
-    const unsigned int ji = pending ? idx[p] : (unsigned int)p;
-    const bool inplace = pending && ji == kInPlace;
-    const double* src = inplace ? pl.inbox : pl.s[ctl->cur];
-    const uint64_t j = inplace ? p : ji;
-    const double px = dst[p], py = dst[n + p], pyaw = dst[2 * n + p];
-    acc = chunk == 0 ? pw[p] : 1.0;
-    const int nk = k1 - k0;
-    auto load6 = [&](const double* in, double* v) {
-      if (nt_ld) {
-#pragma unroll
-        for (int f = 0; f < 6; ++f) v[f] = __builtin_nontemporal_load(in + f * n);
-      } else {
-#pragma unroll
-        for (int f = 0; f < 6; ++f) v[f] = in[f * n];
-      }
-    };
-    auto store6 = [&](double* out, const double* v) {
-      if (nt_st) {
-#pragma unroll
-        for (int f = 0; f < 6; ++f) __builtin_nontemporal_store(v[f], out + f * n);
-      } else {
-#pragma unroll
-        for (int f = 0; f < 6; ++f) out[f * n] = v[f];
-      }
-    };
-    if (SEQ) {
-      double* live = pl.s[ctl->cur];
-      for (int k = 0; k < nk; ++k) {
-        const double zd = s_z[3 * k], za = s_z[3 * k + 1];
-        double* io = live + (3 + (uint64_t)s_z[3 * k + 2] * 6) * n + p;
-        double e[6];
-#pragma unroll
-        for (int f = 0; f < 6; ++f) e[f] = io[f * n];
-        acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
-#pragma unroll
-        for (int f = 0; f < 6; ++f) io[f * n] = e[f];
-      }
-    } else if (VAR & kObsNoPipe) {
-      for (int k = 0; k < nk; ++k) {
-        const double zd = s_z[3 * k], za = s_z[3 * k + 1];
-        const uint64_t id = (uint64_t)s_z[3 * k + 2];
-        double e[6];
-        load6(src + (3 + id * 6) * n + j, e);
-        acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
-        store6(dst + (3 + id * 6) * n + p, e);
-      }
-    } else {
-      // software pipeline: the six plane loads of observation k+1 are issued before the FP64
-      // instructions of update k, so two updates' worth of HBM requests are in flight per wave
-      double nxt[6];
-      if (nk > 0) load6(src + (3 + (uint64_t)s_z[2] * 6) * n + j, nxt);
-      for (int k = 0; k < nk; ++k) {
-        const double zd = s_z[3 * k], za = s_z[3 * k + 1];
-        const uint64_t id = (uint64_t)s_z[3 * k + 2];
-        double e[6];
-#pragma unroll
-        for (int f = 0; f < 6; ++f) e[f] = nxt[f];
-        if (k + 1 < nk) load6(src + (3 + (uint64_t)s_z[3 * k + 5] * 6) * n + j, nxt);
-        acc *= rr_fs1_update_one(px, py, pyaw, zd, za, e, m);
-        store6(dst + (3 + id * 6) * n + p, e);
-      }
-    }
-  }
-  // The weight is the product of the chunks' factors in chunk order (the D-spec's).  The LAST chunk's workgroup of a
-  // particle block forms it: the other chunks leave their factor in `partial` and are done -- no wait, no ticket, nothing at
-  // their end -- and the last chunk, dispatched after the others, reads the factors back when its own updates are through.
-  // A factor that has not landed yet shows as kNoFactor, a signalling-NaN pattern no arithmetic produces (results are quiet
-  // NaNs); the reader looks again (bounded: Ctl.obs_timeout) and puts the pattern back for the next update.  No
-  // k_fs1_combine launch (round 2: 10.8 - 12.5 us + a launch boundary at 1e5 particles x 25 chunks).
-  const bool closing = chunk == n_chunks - 1;  // uniform per workgroup
-  if (!closing) {
-    if (p < n) rr::st_dev(reinterpret_cast<uint64_t*>(&partial[(uint64_t)chunk * n + p]), rr_d2u(acc));  // device scope: read from any XCD
-  } else if (n_chunks > 1) {
-    if (p < n) {
-      double w = 1.0;
-      constexpr int kBatch = 16;  // loads in flight
-      for (int c0 = 0; c0 < n_chunks - 1; c0 += kBatch) {
-        uint64_t f[kBatch];
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k)
-          f[k] = c0 + k < n_chunks - 1 ? rr::ld_dev(reinterpret_cast<const uint64_t*>(&partial[(uint64_t)(c0 + k) * n + p])) : rr_d2u(1.0);
-#pragma unroll
-        for (int k = 0; k < kBatch; ++k) {
-          if (c0 + k >= n_chunks - 1) continue;  // a chunk past the end contributes an exact factor 1
-          uint64_t* slot = reinterpret_cast<uint64_t*>(&partial[(uint64_t)(c0 + k) * n + p]);
-          if (f[k] == kNoFactor) {
-            const uint64_t t0 = wall_clock64();
-            while ((f[k] = rr::ld_dev(slot)) == kNoFactor) {
-              __builtin_amdgcn_s_sleep(8);
-              if (wall_clock64() - t0 > kFactorWaitTicks) {
-                ctl->obs_timeout = 1;
-                break;
-              }
-            }
-          }
-          rr::st_dev(slot, kNoFactor);
-          w = (c0 + k == 0) ? rr_u2d(f[k]) : w * rr_u2d(f[k]);
-        }
-      }
-      acc = w * acc;  // this chunk's own factor is the last one
-      pw[p] = acc;
-    }
-  } else if (p < n) {
-    pw[p] = acc;
-  }
-  if (closing) {
-    double mx = acc > 0.0 ? acc : 0.0;
-    mx = rr::wave_max(mx);
-    if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = mx;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      double bm = s_wmax[0];
-      for (int k = 1; k < kBlock / rr::kWave; ++k) bm = s_wmax[k] > bm ? s_wmax[k] : bm;
-      if (bm > 0.0) rr::atomic_max_u64(&ctl->wmax_bits, rr_d2u(bm));
-    }
-  }
-}
-
-// max only (after set_state)
-__global__ __launch_bounds__(kBlock) void k_fs1_wmax(const double* __restrict__ pw, Ctl* __restrict__ ctl, uint64_t n) {
-  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  double w = p < n ? pw[p] : 0.0;
-  double mx = w > 0.0 ? w : 0.0;
-  mx = rr::wave_max(mx);
-  if ((threadIdx.x & 63) == 0 && mx > 0.0) rr::atomic_max_u64(&ctl->wmax_bits, rr_d2u(mx));
-}
-
-// fastslam1.rs:196-203 when no resample follows: w /= sum iff the sum is positive
-__global__ __launch_bounds__(kBlock) void k_fs1_normalize(double* __restrict__ pw, const Ctl* __restrict__ ctl, uint64_t n) {
-  if (ctl->fired || ctl->image_mode != rr::kImageWeights) return;
-  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p < n) pw[p] = pw[p] / ctl->sum;
-}
-
-// Single-GPU plan, fused (the MCL engine's k_plan_mark shape, resample_core.hpp): every workgroup re-derives its tile
-// offset and the grand totals from the tile totals, takes the gate decision (fastslam1.rs:262-265) and then either
-// normalises its tile's weights (:196-203, gate shut) or marks the slot run each of its sources feeds (:205-234) and
-// sets the weights to 1/n (:228).  One launch instead of k_scan_tiles + k_cdf + k_fs1_normalize + k_fs1_indices, no
-// CDF array, no per-slot binary search.  k_fs1_resolve turns the markers into idx[] (running maximum per 512 slots).
-__global__ __launch_bounds__(rr::kTileBlock) void k_fs1_plan(double* pw /* read (tile_scan) and rewritten: no restrict */, Ctl* __restrict__ ctl, ImageArgs a,
-                                                    const uint64_t* __restrict__ tile_total,
-                                                    const uint64_t* __restrict__ tile_q2, uint64_t n_tiles, PlanArgs pa,
-                                                    unsigned int* __restrict__ markers, unsigned int* __restrict__ carry) {
-  __shared__ uint64_t s4[4 * (rr::kTileBlock / rr::kWave)];
-  __shared__ uint64_t s_w[rr::kTileBlock / rr::kWave];
-  const rr::TileSums ts = rr::tile_sums(tile_total, tile_q2, n_tiles, s4);
-  const int mode = ctl->image_mode;
-  const int shift = ctl->shift;
-  const int fire = rr::gate_decision(mode, ts, pa);
-  double rho = pa.rho_override;
-  if (rho != rho) {
-    double dummy;
-    rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
-  }
-  if (blockIdx.x == 0 && threadIdx.x == 0) rr::finalize_plan(ctl, ts.tot, 0, ts.tot, ts.q2, pa);
-  const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * rr::kItems;
-  if (!fire) {
-    if (mode != rr::kImageWeights) return;  // all-zero weights stay untouched (fastslam1.rs:198-202)
-    const double sum = rr_fix_total_to_double(ts.tot, shift);
-#pragma unroll
-    for (int j = 0; j < rr::kItems; ++j)
-      if (i0 + j < a.n) pw[i0 + j] = pw[i0 + j] / sum;
-    return;
-  }
-  const rr_sys_plan plan = rr_sys_plan_make(rho, ts.tot, pa.n_global);
-  const rr::TileScan t = rr::tile_scan(pw, a, mode, shift, blockIdx.x, s_w);  // reads this tile's weights ...
-  rr::mark_sources(t, ts.pre + t.thread_off, i0, a.n, plan, ts.tot, 0, markers, carry);
-  const double w_new = 1.0 / (double)pa.n_global;
-#pragma unroll
-  for (int j = 0; j < rr::kItems; ++j)
-    if (i0 + j < a.n) pw[i0 + j] = w_new;  // ... before the same threads overwrite them
-}
-
-__global__ __launch_bounds__(kBlock) void k_fs1_resolve(const Ctl* __restrict__ ctl, unsigned int* __restrict__ markers,
-                                                       const unsigned int* __restrict__ carry, uint64_t n,
-                                                       unsigned int* __restrict__ idx) {
-  if (!ctl->fired) return;
-  unsigned int src[rr::kResolveRows];
-  rr::resolve_tile(markers, carry, n, blockIdx.x, src);
-#pragma unroll
-  for (int r = 0; r < rr::kResolveRows; ++r) {
-    const uint64_t k = (uint64_t)blockIdx.x * rr::kResolveSlots + (uint64_t)r * kBlock + threadIdx.x;
-    if (k < n) idx[k] = src[r];
-  }
-}
-
-// sharded variants.  Slots this shard serves: [first, first + n_served) with
-// first = slots_upto(base), n_served = slots_upto(base + T_local) - first (device-side only).
-__device__ inline void served_range(const Ctl* ctl, uint64_t* first, uint64_t* n_served) {
-  *first = ctl->served_first;
-  *n_served = ctl->served_count;
-}
-
-// remote-owned served slots are the two ends of the served range: k in [0, lead) and
-// [tail_start, n_served), with lead / tail_start = where this rank's own slots begin / end in
-// served-slot coordinates
-struct ServedSplit {
-  uint64_t first, n_served, lead, tail_start, n_remote;
-};
-__device__ inline ServedSplit served_split(const Ctl* ctl, uint64_t own_first, uint64_t n_local) {
-  ServedSplit v;
-  served_range(ctl, &v.first, &v.n_served);
-  const uint64_t end = v.first + v.n_served;
-  const uint64_t lo = own_first < v.first ? v.first : (own_first > end ? end : own_first);
-  const uint64_t own_end = own_first + n_local;
-  const uint64_t hi = own_end < v.first ? v.first : (own_end > end ? end : own_end);
-  v.lead = lo - v.first;
-  v.tail_start = hi - v.first;
-  v.n_remote = v.lead + (v.n_served - v.tail_start);
-  return v;
-}
-
-// workgroups [0, own_blocks): one thread per OWN slot -- its local source if this shard serves
-// it, kInPlace if a peer does.  Workgroups beyond: the sources of the served slots that belong to
-// peers (ridx, grid-stride; there are few in steady state).
-__global__ __launch_bounds__(kBlock) void k_fs1_indices_sharded(const Ctl* __restrict__ ctl,
-                                                               const uint64_t* __restrict__ cdf, uint64_t n,
-                                                               uint64_t own_first, unsigned int own_blocks,
-                                                               unsigned int* __restrict__ idx,
-                                                               unsigned int* __restrict__ ridx) {
-  if (!ctl->fired) return;
-  const rr_sys_plan plan = ctl->plan;
-  const ServedSplit v = served_split(ctl, own_first, n);
-  if (blockIdx.x < own_blocks) {
-    const uint64_t li = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-    if (li >= n) return;
-    const uint64_t s = own_first + li;
-    idx[li] = (s >= v.first && s < v.first + v.n_served) ? (unsigned int)rr_lower_bound_u64(cdf, n, rr_sys_target(plan, s))
-                                                         : kInPlace;
-    return;
-  }
-  const uint64_t stride = (uint64_t)(gridDim.x - own_blocks) * kBlock;
-  for (uint64_t r = (uint64_t)(blockIdx.x - own_blocks) * kBlock + threadIdx.x; r < v.n_remote; r += stride) {
-    const uint64_t k = r < v.lead ? r : v.tail_start + (r - v.lead);
-    ridx[r] = (unsigned int)rr_lower_bound_u64(cdf, n, rr_sys_target(plan, v.first + k));
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_fs1_uniform_weights(const Ctl* __restrict__ ctl, double* __restrict__ pw,
-                                                               uint64_t n, uint64_t n_global) {
-  if (!ctl->fired) return;
-  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p < n) pw[p] = 1.0 / (double)n_global;  // fastslam1.rs:228
-}
-
-// the served slots that belong to peers: all planes of the source particle into slot li of the
-// owner's fine-grained inbox (the owner's idx says kInPlace)
-__global__ __launch_bounds__(kBlock) void k_fs1_push(Planes pl, const Ctl* __restrict__ ctl,
-                                                    const unsigned int* __restrict__ ridx, uint64_t n_local,
-                                                    uint64_t own_first, uint64_t n_planes, rr::P2PPeers peers) {
-  if (!ctl->fired) return;
-  const ServedSplit v = served_split(ctl, own_first, n_local);
-  const int cur = ctl->cur;  // lazy: not flipped yet
-  const double* __restrict__ in = pl.s[cur];
-  const uint64_t p0 = (uint64_t)blockIdx.y * kPlanesPerThread;
-  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < v.n_remote; r += (uint64_t)gridDim.x * kBlock) {
-    const uint64_t k = r < v.lead ? r : v.tail_start + (r - v.lead);
-    const uint64_t s = v.first + k;
-    const uint64_t d = s / n_local, li = s - d * n_local;
-    const uint64_t j = ridx[r];
-    double* __restrict__ out = peers.inbox[d];  // fine-grained, [plane][n_local]
-    double val[kPlanesPerThread];
-#pragma unroll
-    for (int q = 0; q < kPlanesPerThread; ++q)
-      if (p0 + q < n_planes) val[q] = in[(p0 + q) * n_local + j];
-#pragma unroll
-    for (int q = 0; q < kPlanesPerThread; ++q)
-      if (p0 + q < n_planes) out[(p0 + q) * n_local + li] = val[q];
-  }
-}
-
-__global__ __launch_bounds__(kBlock) void k_fs1_indices(const Ctl* __restrict__ ctl, const uint64_t* __restrict__ cdf,
-                                                       uint64_t n, unsigned int* __restrict__ idx,
-                                                       double* __restrict__ pw) {
-  if (!ctl->fired) return;
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= n) return;
-  const uint64_t target = rr_sys_target(ctl->plan, k);
-  idx[k] = (unsigned int)rr_lower_bound_u64(cdf, n, target);
-  pw[k] = 1.0 / (double)n;  // fastslam1.rs:228
-}
-
-// blockIdx.y selects a group of kPlanesPerThread planes; indices are non-decreasing, so each
-// plane is read almost sequentially.  mode 0 (eager): the plan kernel flipped Ctl.cur already --
-// read set cur^1, write set cur, runs iff fired.  mode 1 (lazy): a pending resample is being
-// consumed -- read set cur, write set cur^1, runs iff pending (a settle flips afterwards).
-// plane_list != nullptr restricts the copy to the listed planes (the landmarks a lazy observe
-// did not touch).
-__global__ __launch_bounds__(kBlock) void k_fs1_gather(Planes pl, const Ctl* __restrict__ ctl,
-                                                      const unsigned int* __restrict__ idx, uint64_t n,
-                                                      uint64_t n_planes, int lazy,
-                                                      const unsigned int* __restrict__ plane_list) {
-  if (lazy ? !ctl->pending : !ctl->fired) return;
-  const uint64_t k = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (k >= n) return;
-  const int cur = ctl->cur;
-  const double* in = pl.s[lazy ? cur : cur ^ 1];
-  double* __restrict__ out = pl.s[lazy ? cur ^ 1 : cur];
-  uint64_t j = idx[k];
-  if (lazy && idx[k] == kInPlace) {  // sharded: delivered by a peer -- take it out of the inbox
-    in = pl.inbox;
-    j = k;
-  }
-  const uint64_t p0 = (uint64_t)blockIdx.y * kPlanesPerThread;
-  double v[kPlanesPerThread];
-  uint64_t pid[kPlanesPerThread];
-#pragma unroll
-  for (int q = 0; q < kPlanesPerThread; ++q) {
-    pid[q] = p0 + q < n_planes ? (plane_list ? plane_list[p0 + q] : p0 + q) : 0;
-    if (p0 + q < n_planes) v[q] = in[pid[q] * n + j];
-  }
-#pragma unroll
-  for (int q = 0; q < kPlanesPerThread; ++q)
-    if (p0 + q < n_planes) out[pid[q] * n + k] = v[q];
-}
-
-// ---- RCCL / host-orchestrated transport (rr_fs1_shard_update): whole particles that cross ranks travel
-// as one contiguous block per (source, destination) pair, laid out [plane][count] so that both the
-// packing reads (non-decreasing source indices along a plane) and the unpacking writes are coalesced.
-// ChunkTable: start[g] .. start[g + 1] = the block of rank g in remote-slot order (ascending global
-// slot, this rank's own slots left out); first_local[g] = local slot the block of SOURCE g starts at.
-struct ChunkTable {
-  uint64_t start[rr::kMaxP2P + 1];
-  uint64_t first_local[rr::kMaxP2P];
-  int n_ranks;
-};
-
-__device__ inline int chunk_of(const ChunkTable& t, uint64_t r) {
-  int g = 0;
-  while (g + 1 < t.n_ranks && r >= t.start[g + 1]) ++g;
-  return g;
-}
-
-// served slots that belong to peers -> send buffer.  ridx[r] = local source of remote slot r (k_fs1_indices_sharded).
-__global__ __launch_bounds__(kBlock) void k_fs1_pack(Planes pl, const Ctl* __restrict__ ctl,
-                                                    const unsigned int* __restrict__ ridx, uint64_t n_local,
-                                                    uint64_t n_planes, ChunkTable t, double* __restrict__ out) {
-  if (!ctl->fired) return;
-  const double* __restrict__ in = pl.s[ctl->cur];  // lazy: not flipped yet
-  const uint64_t n_remote = t.start[t.n_ranks];
-  const uint64_t p0 = (uint64_t)blockIdx.y * kPlanesPerThread;
-  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n_remote; r += (uint64_t)gridDim.x * kBlock) {
-    const int g = chunk_of(t, r);
-    const uint64_t cnt = t.start[g + 1] - t.start[g], k = r - t.start[g];
-    const uint64_t j = ridx[r];
-    double* __restrict__ o = out + t.start[g] * n_planes + k;
-    double val[kPlanesPerThread];
-#pragma unroll
-    for (int q = 0; q < kPlanesPerThread; ++q)
-      if (p0 + q < n_planes) val[q] = in[(p0 + q) * n_local + j];
-#pragma unroll
-    for (int q = 0; q < kPlanesPerThread; ++q)
-      if (p0 + q < n_planes) o[(p0 + q) * cnt] = val[q];
-  }
-}
-
-// receive buffer -> this rank's inbox (the owner's idx says kInPlace for exactly these slots)
-__global__ __launch_bounds__(kBlock) void k_fs1_unpack(double* __restrict__ inbox, const Ctl* __restrict__ ctl,
-                                                      uint64_t n_local, uint64_t n_planes, ChunkTable t,
-                                                      const double* __restrict__ in) {
-  if (!ctl->fired) return;
-  const uint64_t n_remote = t.start[t.n_ranks];
-  const uint64_t p0 = (uint64_t)blockIdx.y * kPlanesPerThread;
-  for (uint64_t r = (uint64_t)blockIdx.x * kBlock + threadIdx.x; r < n_remote; r += (uint64_t)gridDim.x * kBlock) {
-    const int g = chunk_of(t, r);
-    const uint64_t cnt = t.start[g + 1] - t.start[g], k = r - t.start[g];
-    const uint64_t li = t.first_local[g] + k;
-    const double* __restrict__ i0 = in + t.start[g] * n_planes + k;
-#pragma unroll
-    for (int q = 0; q < kPlanesPerThread; ++q)
-      if (p0 + q < n_planes) inbox[(p0 + q) * n_local + li] = i0[(p0 + q) * cnt];
-  }
-}
-
-__global__ void k_fs1_settle(Ctl* ctl) {
-  if (ctl->pending) {
-    ctl->cur ^= 1;
-    ctl->pending = 0;
-  }
-}
-
-// arg max of the weight with ties -> highest index (fastslam1.rs:269-274, Q14): the key (weight bits, index) is order
-// preserving for non-negative doubles.  ONE launch: every workgroup leaves its best key, the workgroup that takes the last
-// ticket picks the best of those and leaves index, pose and weight of that particle in Ctl and in the handle's
-// host-visible mailbox (pinned memory; the host polls its stamp -- no device-to-host copies, no stream synchronisation).
-// Round 2: two launches, a read-back of Ctl and four 8-byte copies behind a second synchronisation -- 95 us per call, more
-// than the reference spends on a whole update of its 100 particles.
-struct BestMail {
-  uint64_t index;
-  double pose[3];
-  double weight;
-  uint64_t flags;  // != 0: Ctl holds something the host has to look at (obs_timeout, grid_timeout)
-  uint64_t seq;    // stamped last
-};
-__global__ __launch_bounds__(kBlock) void k_fs1_best(const double* __restrict__ pw, uint64_t n, const double* __restrict__ planes0,
-                                                    const double* __restrict__ planes1, Ctl* __restrict__ ctl,
-                                                    uint64_t* __restrict__ part_bits, uint64_t* __restrict__ part_idx,
-                                                    unsigned int* __restrict__ ticket, BestMail* __restrict__ mail, uint64_t seq,
-                                                    const unsigned int* __restrict__ idx) {
-  __shared__ uint64_t s_b[kBlock / rr::kWave], s_i[kBlock / rr::kWave];
-  __shared__ int s_last;
-  auto better = [](uint64_t ob, uint64_t oi, uint64_t bb, uint64_t bi) { return ob > bb || (ob == bb && oi > bi); };
-  auto wave_best = [&](uint64_t& bb, uint64_t& bi) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const uint64_t ob = rr::shfl_xor_u64(bb, o), oi = rr::shfl_xor_u64(bi, o);
-      if (better(ob, oi, bb, bi)) {
-        bb = ob;
-        bi = oi;
-      }
-    }
-  };
-  auto block_best = [&](uint64_t& bb, uint64_t& bi) {  // thread 0 ends up with the workgroup's best
-    wave_best(bb, bi);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
-      s_b[threadIdx.x >> 6] = bb;
-      s_i[threadIdx.x >> 6] = bi;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-      for (int k = 1; k < kBlock / rr::kWave; ++k)
-        if (better(s_b[k], s_i[k], bb, bi)) {
-          bb = s_b[k];
-          bi = s_i[k];
-        }
-  };
-  uint64_t bb = 0, bi = 0;  // (an empty share ranks lowest: key (0, 0))
-  for (uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x; p < n; p += (uint64_t)gridDim.x * kBlock) {
-    const double w = pw[p];
-    const uint64_t b = w > 0.0 ? rr_d2u(w) : 0ull;  // NaN / negative weights rank lowest
-    if (better(b, p, bb, bi) || (b == bb && p == bi)) {
-      bb = b;
-      bi = p;
-    }
-  }
-  block_best(bb, bi);
-  if (threadIdx.x == 0) {
-    rr::st_dev(&part_bits[blockIdx.x], bb);
-    rr::st_dev(&part_idx[blockIdx.x], bi);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned int before = atomicAdd(ticket, 1u);
-    s_last = before == gridDim.x - 1 ? 1 : 0;
-    if (s_last) *ticket = 0;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  bb = 0;
-  bi = 0;
-  for (unsigned int k = threadIdx.x; k < gridDim.x; k += kBlock) {
-    const uint64_t ob = rr::ld_dev(&part_bits[k]), oi = rr::ld_dev(&part_idx[k]);
-    if (better(ob, oi, bb, bi)) {
-      bb = ob;
-      bi = oi;
-    }
-  }
-  block_best(bb, bi);
-  if (threadIdx.x == 0) {
-    // a pending (lazy) resample has set the weights already; the particle of slot bi still sits at its source in the live set
-    const double* __restrict__ live = ctl->cur ? planes1 : planes0;
-    const uint64_t j = (idx && ctl->pending) ? (uint64_t)idx[bi] : bi;
-    const double x = live[j], y = live[n + j], yaw = live[2 * n + j], w = pw[bi];
-    ctl->best_bits = bb;
-    ctl->best_index = bi;
-    if (mail) {
-      rr::st_sys_u64(&mail->index, bi);
-      rr::st_sys(&mail->pose[0], x);
-      rr::st_sys(&mail->pose[1], y);
-      rr::st_sys(&mail->pose[2], yaw);
-      rr::st_sys(&mail->weight, w);
-      rr::st_sys_u64(&mail->flags, (uint64_t)(ctl->obs_timeout != 0) | ((uint64_t)(ctl->grid_timeout != 0) << 1));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stamp goes last
-      rr::st_sys_u64(&mail->seq, seq);
-    }
-  }
-}
-
-// "everything before me in this stream is done, and this is what Ctl has to report": the stamp of a synchronous call
-// (rr_fs1_update, rr_fs1_synchronize) -- the host polls the mailbox instead of copying Ctl back behind a stream synchronisation
-__global__ void k_fs1_stamp(const Ctl* __restrict__ ctl, BestMail* __restrict__ mail, uint64_t seq) {
-  rr::st_sys_u64(&mail->flags, (uint64_t)(ctl->obs_timeout != 0) | ((uint64_t)(ctl->grid_timeout != 0) << 1));
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  rr::st_sys_u64(&mail->seq, seq);
-}
-
-// ------------------------------------------------------------------------------------------
-// RESIDENT update of a small particle set (rr_fs1_set_resident; resident_core.hpp): fastslam_update (fastslam1.rs:237-266)
-// followed by get_best_particle (:269-274) -- the loop every FastSLAM caller in the reference runs, at its sizes (100
-// particles x 8 landmarks: render_gif_slam.rs:166-200) -- for ONE workgroup that stays on the device and takes one update per
-// command of the ring: (u0, u1, chunk length, n_z x (distance, angle, landmark id)).  The general path spends three
-// launches on an update and a fourth on the best particle (19 + 17 us for a few microseconds of work); here a thread owns a
-// particle, the poses, weights and maps stay where they are (HBM / L2: one workgroup reads its own writes after a barrier),
-// and the resample gather is EAGER, so an incarnation can leave at any command boundary with nothing pending.
-// Same per-element arithmetic (rr_fs1_predict_one, rr_fs1_update_one), the weight as the left-to-right product of the
-// observation chunks' factors (choose_chunks' plan, handed over by the host), the same integer image, gate, systematic plan
-// and tie rule: bit-identical to the launched path (tests/test_gpu_fs1_resident.py).
-struct Fs1SmallArgs {
-  uint64_t n, L, n_global, gid0;
-  uint64_t seed;
-  unsigned int step0, rstep0;
-  rr_fs1_model m;
-  PlanArgs plan;  // mode 0, N_eff gate against NTH, systematic, eager gather
-  rr::ResidentArgs res;
-};
-constexpr int kFs1ResMaxObs = 64;
-constexpr int kFs1ResPayload = 3 + 3 * kFs1ResMaxObs;
-constexpr int kFs1RspIndex = 6;  // rsp[0..2] pose, [3] weight, [4] flags, [5] EXIT marker, [6] index of the best particle
-
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void k_fs1_small(Planes pl, double* __restrict__ pw, Ctl* __restrict__ ctl, Fs1SmallArgs a,
-                                                    unsigned int* __restrict__ idx_out, rr::ResidentRing* __restrict__ ring) {
-  constexpr int W = BLOCK / rr::kWave;
-  __shared__ double s_pay[kFs1ResPayload + 1];
-  __shared__ int s_hdr[2];
-  __shared__ double s_red[W];
-  __shared__ uint64_t s_u[3 * W];
-  __shared__ uint64_t s_bb[W], s_bi[W];
-  __shared__ unsigned int s_mx[W];
-  __shared__ unsigned int s_mark[BLOCK + 1];
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const uint64_t n = a.n, p = (uint64_t)tid;
-  const bool mine = p < n;
-  int res_guess = 28, res_last_op = rr::kResOpNone, steps_done = 0;
-  const uint64_t deadline = wall_clock64() + a.res.life_ticks;
-  for (int s = 0;; ++s) {
-    // ---- the update's motion noise does not depend on the command: drawn before the wait
-    double na = 0.0, nb = 0.0;
-    if (mine) rr_fs1_motion_noise(a.seed, a.step0 + (unsigned int)s, a.gid0 + p, &na, &nb);
-    double rho, rho_dummy;
-    rr_uniform2(a.plan.seed, RR_STREAM_RESAMPLE, a.rstep0 + (unsigned int)s, 0, &rho, &rho_dummy);
-    res_last_op = rr::resident_fetch<BLOCK>(ring, a.res.first_seq + (uint64_t)s, a.res.idle_ticks, deadline, kFs1ResPayload, res_guess, s_pay, s_hdr);
-    if (res_last_op != rr::kResOpStep) break;
-    steps_done = s + 1;
-    const int n_z = (s_hdr[1] - 3) / 3;
-    const double u0 = s_pay[0], u1 = s_pay[1];
-    const int chunk_len = (int)s_pay[2];
-    const double* s_z = s_pay + 3;
-    const int cur = ctl->cur;
-    double* __restrict__ live = pl.s[cur];
-    // ---- predict_particle (fastslam1.rs:123-137)
-    double px = 0.0, py = 0.0, pyaw = 0.0, w = 0.0;
-    if (mine) {
-      px = live[p];
-      py = live[n + p];
-      pyaw = live[2 * n + p];
-      rr_fs1_predict_one(&px, &py, &pyaw, u0, u1, na, nb, a.m);
-      live[p] = px;
-      live[n + p] = py;
-      live[2 * n + p] = pyaw;
-      // ---- update_landmark per observation (:140-183); the weight: chunk factors multiplied left to right (k_fs1_observe)
-      double total_w = pw[p];  // (no observation: the weight stays as it is)
-      for (int k0 = 0, c = 0; k0 < n_z; k0 += chunk_len, ++c) {
-        double acc = c == 0 ? total_w : 1.0;
-        const int k1 = k0 + chunk_len < n_z ? k0 + chunk_len : n_z;
-        for (int k = k0; k < k1; ++k) {
-          double* io = live + (3 + (uint64_t)s_z[3 * k + 2] * 6) * n + p;
-          double e[6];
-#pragma unroll
-          for (int f = 0; f < 6; ++f) e[f] = io[f * n];
-          acc *= rr_fs1_update_one(px, py, pyaw, s_z[3 * k], s_z[3 * k + 1], e, a.m);
-#pragma unroll
-          for (int f = 0; f < 6; ++f) io[f * n] = e[f];
-        }
-        total_w = c == 0 ? acc : total_w * acc;
-      }
-      w = total_w;
-    }
-    // ---- maximum, integer image, sums (k_quantize_plan_mark<true>'s phase A)
-    double wl = w > 0.0 ? w : 0.0;
-    wl = rr::wave_max(wl);
-    __syncthreads();
-    if (lane == 0) s_red[wv] = wl;
-    __syncthreads();
-    double wmax = s_red[0];
-#pragma unroll
-    for (int k = 1; k < W; ++k) wmax = s_red[k] > wmax ? s_red[k] : wmax;
-    const bool usable = wmax > 0.0 && wmax < INFINITY;
-    const int mode = usable ? (int)rr::kImageWeights : (int)rr::kImageLast;
-    const int shift = usable ? rr_fix_shift(wmax, a.n_global) : 0;
-    const uint64_t q = !mine ? 0ull : (mode == rr::kImageWeights ? rr_fix_quantize(w, shift) : (a.gid0 + p == a.n_global - 1 ? 1ull : 0ull));
-    rr::u128 q2;
-    rr_mul64wide(q, q, &q2.hi, &q2.lo);
-    const uint64_t incl = rr::wave_scan_u64(q, lane);
-    q2 = rr::wave_sum_u128(q2);
-    __syncthreads();
-    if (lane == 63) s_u[wv] = incl;
-    if (lane == 0) {
-      s_u[W + wv] = q2.hi;
-      s_u[2 * W + wv] = q2.lo;
-    }
-    __syncthreads();
-    uint64_t off = incl - q, total = 0;
-    rr::u128 qq = {0, 0};
-#pragma unroll
-    for (int k = 0; k < W; ++k) {
-      if (k < wv) off += s_u[k];
-      total += s_u[k];
-      qq = rr::add128(qq, rr::u128{s_u[W + k], s_u[2 * W + k]});
-    }
-    rr::TileSums ts;
-    ts.pre = 0;
-    ts.tot = total;
-    ts.q2 = qq;
-    PlanArgs pa = a.plan;
-    pa.rstep = a.rstep0 + (unsigned int)s;
-    const int fire = rr::gate_decision(mode, ts, pa);
-    if (tid == 0) {  // what the plan kernel's first workgroup leaves in Ctl
-      ctl->usable = usable ? 1 : 0;
-      ctl->image_mode = mode;
-      ctl->shift = shift;
-      ctl->wmax = wmax;
-      rr::finalize_plan(ctl, total, 0, total, qq, pa);  // eager: Ctl.cur flips here when the gate fires
-    }
-    int cur_now = cur;
-    if (!fire) {  // fastslam1.rs:196-203: w /= sum iff the sum is positive (all-zero weights stay untouched)
-      if (mode == rr::kImageWeights) w = w / rr_fix_total_to_double(total, shift);
-      if (mine) pw[p] = w;
-    } else {  // fastslam1.rs:205-234: systematic walk -> slot-run markers -> running maximum, then every plane moves
-      const rr_sys_plan plan = rr_sys_plan_make(rho, total, a.n_global);
-      const rr_sys_inv inv = rr_sys_inv_make(plan, total);
-      __syncthreads();
-      for (uint64_t k = tid; k <= n; k += BLOCK) s_mark[k] = 0;
-      __syncthreads();
-      if (mine && q != 0) {
-        const uint64_t h0 = rr_sys_slots_upto(plan, inv, total, off), h1 = rr_sys_slots_upto(plan, inv, total, off + q);
-        if (h1 > h0) s_mark[h0] = (unsigned int)(p + 1);
-      }
-      __syncthreads();
-      const unsigned int mk = mine ? s_mark[p] : 0u;
-      const unsigned int mincl = rr::wave_scan_max_u32(mk);
-      if (lane == 63) s_mx[wv] = mincl;
-      __syncthreads();
-      unsigned int pre = 0;
-#pragma unroll
-      for (int k = 0; k < W; ++k)
-        if (k < wv) pre = s_mx[k] > pre ? s_mx[k] : pre;
-      const unsigned int src_i = (mincl > pre ? mincl : pre) - 1u;
-      double* __restrict__ dst = pl.s[cur ^ 1];
-      if (mine) {
-        const uint64_t planes = 3 + 6 * a.L;
-        for (uint64_t f = 0; f < planes; ++f) dst[f * n + p] = live[f * n + src_i];
-        w = 1.0 / (double)a.n_global;
-        pw[p] = w;
-        if (idx_out) idx_out[p] = src_i;
-      }
-      cur_now = cur ^ 1;
-    }
-    // ---- get_best_particle (fastslam1.rs:269-274): arg max of the weight, ties -> the highest index
-    uint64_t bb = mine && w > 0.0 ? rr_d2u(w) : 0ull, bi = mine ? p : 0ull;
-    auto better = [](uint64_t ob, uint64_t oi, uint64_t b0, uint64_t i0) { return ob > b0 || (ob == b0 && oi > i0); };
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const uint64_t ob = rr::shfl_xor_u64(bb, o), oi = rr::shfl_xor_u64(bi, o);
-      if (better(ob, oi, bb, bi)) {
-        bb = ob;
-        bi = oi;
-      }
-    }
-    __syncthreads();  // (the gathered planes are complete, s_mark is free)
-    if (lane == 0) {
-      s_bb[wv] = bb;
-      s_bi[wv] = bi;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      for (int k = 1; k < W; ++k)
-        if (better(s_bb[k], s_bi[k], bb, bi)) {
-          bb = s_bb[k];
-          bi = s_bi[k];
-        }
-      const double* __restrict__ now = pl.s[cur_now];
-      const uint64_t seq = a.res.first_seq + (uint64_t)s;
-      ctl->best_bits = bb;
-      ctl->best_index = bi;
-      rr::store_pair_sys(&ring->rsp[0], rr_d2u(now[bi]), seq);
-      rr::store_pair_sys(&ring->rsp[1], rr_d2u(now[n + bi]), seq);
-      rr::store_pair_sys(&ring->rsp[2], rr_d2u(now[2 * n + bi]), seq);
-      rr::store_pair_sys(&ring->rsp[3], rr_d2u(pw[bi]), seq);
-      rr::store_pair_sys(&ring->rsp[rr::kResRspFlags], 0ull, seq);
-      rr::store_pair_sys(&ring->rsp[kFs1RspIndex], bi, seq);
-    }
-    __syncthreads();  // (Ctl.cur and the weights are read by the next command)
-  }
-  if (tid == 0) {  // EXIT marker: the last command consumed (a quit counts), stamped with the launch id
-    const uint64_t consumed = a.res.first_seq + (uint64_t)steps_done - 1 + (res_last_op == rr::kResOpQuit ? 1 : 0);
-    rr::store_pair_sys(&ring->rsp[rr::kResRspExit], consumed, a.res.launch_id);
-  }
-}
-
-// host layouts <-> planes.  tmp holds the AoS image on the device.
-__global__ __launch_bounds__(kBlock) void k_fs1_init(Planes pl, double* __restrict__ pw, uint64_t n, uint64_t L,
-                                                    double w0, double cov0) {
-  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  const uint64_t n_planes = 3 + 6 * L;
-  if (t >= n_planes * n) return;
-  const uint64_t plane = t / n, p = t % n;
-  double v = 0.0;
-  if (plane >= 3) {
-    const int f = (int)((plane - 3) % 6);
-    if (f == 2 || f == 5) v = cov0;
-  }
-  pl.s[0][t] = v;
-  if (plane == 0) pw[p] = w0;
-}
-
-// maps AoS [p][l][6] -> planes (dir = 0) or back (dir = 1); one thread per (p, l)
-__global__ __launch_bounds__(kBlock) void k_fs1_maps_transpose(double* __restrict__ planes, double* __restrict__ aos,
-                                                              uint64_t n, uint64_t L, int dir) {
-  const uint64_t t = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (t >= n * L) return;
-  const uint64_t l = t / n, p = t % n;  // consecutive threads -> consecutive particles: plane side coalesced
-  double* a = aos + (p * L + l) * 6;
-  double* b = planes + (3 + l * 6) * n + p;
-#pragma unroll
-  for (int f = 0; f < 6; ++f) {
-    if (dir == 0) b[f * n] = a[f];
-    else a[f] = b[f * n];
-  }
-}
-
-// poses N x (w, x, y, yaw) <-> weight array + pose planes
-__global__ __launch_bounds__(kBlock) void k_fs1_poses(double* __restrict__ planes, double* __restrict__ pw,
-                                                     double* __restrict__ aos, uint64_t n, int dir) {
-  const uint64_t p = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (p >= n) return;
-  if (dir == 0) {
-    pw[p] = aos[4 * p];
-    planes[p] = aos[4 * p + 1];
-    planes[n + p] = aos[4 * p + 2];
-    planes[2 * n + p] = aos[4 * p + 3];
-  } else {
-    aos[4 * p] = pw[p];
-    aos[4 * p + 1] = planes[p];
-    aos[4 * p + 2] = planes[n + p];
-    aos[4 * p + 3] = planes[2 * n + p];
-  }
-}
-
-__global__ void k_fs1_one_landmarks(const double* __restrict__ planes, uint64_t n, uint64_t L, uint64_t p,
-                                    double* __restrict__ out) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 6 * L) return;
-  out[t] = planes[(3 + t) * n + p];  // t = l*6 + f
-}
-
+#include "fs1_kernels.inc"
 }  // namespace
 
 // =============================================================================================
