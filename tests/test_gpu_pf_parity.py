@@ -404,7 +404,7 @@ def test_in_step_estimate_matches_the_accessor_and_the_reference(loc, ref, mcl, 
 
 
 @pytest.mark.parametrize("scheme,defer", [(1, "1"), (1, "0"), (0, "0")], ids=["systematic-deferred", "systematic-in-plan", "multinomial"])
-@pytest.mark.parametrize("n", [20_000, 300_000])
+@pytest.mark.parametrize("n", [2_049, 20_000, 70_001, 300_000])  # (2 049: the smallest set the one-workgroup kernel does not take)
 def test_deferred_estimate_is_the_same_whoever_moves_the_particles(loc, scheme, defer, n, monkeypatch):
     """The deferred form of the in-step estimate (rr::EstArgs; always for the multinomial scheme, RR_PF_EST_DEFER=1 for the
     systematic one): the sums over the resampled set are formed by the NEXT step's k_step_lazy as it gathers its sources, or --
@@ -447,7 +447,7 @@ def test_deferred_estimate_is_the_same_whoever_moves_the_particles(loc, scheme, 
         assert_bits_equal(pa[:, k], pc[:, k], f"particles with and without the estimate, column {k}")
 
 
-@pytest.mark.parametrize("n", [20_000, 300_000])
+@pytest.mark.parametrize("n", [2_049, 20_000, 70_001, 300_000])
 @pytest.mark.parametrize("mcl", [False, True])
 def test_try_step_of_a_large_multinomial_filter(loc, mcl, n):
     """rr_pf_step on the multinomial scheme beyond the one-workgroup sizes: plan, one launch that searches the draws and adds up
