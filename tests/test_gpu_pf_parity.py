@@ -478,6 +478,33 @@ def test_try_step_of_a_large_multinomial_filter(loc, mcl, n):
         assert_bits_equal(pa[:, k], pb[:, k], f"particles, column {k}")
 
 
+@pytest.mark.parametrize("scheme", [1, 0], ids=["systematic", "multinomial"])
+@pytest.mark.parametrize("mcl", [False, True])
+def test_estimate_forms_without_observations_and_with_vanishing_weights(loc, mcl, scheme):
+    """The reference's edge cases through the in-step estimate and the synchronous try_step of a large filter: a step without
+    observations is a pure prediction with uniform weights (particle_filter.rs:317-331), and observations so far away that every
+    weight underflows take the uniform fallback (:433-438) -- the returned mean is the accessor's either way."""
+    n = 50_000
+    lms = H.landmarks_grid(4, 3)
+    if mcl:
+        pf = loc.MonteCarloLocalizer(loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.05), seed=41, resample_scheme=scheme)
+    else:
+        pf = loc.ParticleFilterLocalizer(loc.ParticleFilterConfig(n_particles=n, range_noise=0.05, resample_threshold=0.5), seed=41, resample_scheme=scheme)
+    rng = np.random.default_rng(42)
+    far = np.array([[1.0e4, 0.0, 0.0], [2.0e4, 5.0, 5.0]])  # ranges no particle is anywhere near: every likelihood is exactly 0
+    for t in range(9):
+        obs = [np.zeros((0, 3)), H.observations(lms, H.true_pose(t + 1), 0.05, rng), far][t % 3]
+        if t % 2:
+            pf.step_async_estimate([1.0, 0.1], obs)
+            e = np.array(pf.last_step_estimate())
+        else:
+            e = np.array(pf.step([1.0, 0.1], obs))
+        assert np.all(np.isfinite(e)), (t, e)
+        np.testing.assert_allclose(e, pf.estimate(), rtol=1e-10, atol=1e-10, err_msg=f"step {t}")
+        w = pf.get_particles_array()[:, 4]
+        assert abs(w.sum() - 1.0) < 1e-9 and np.all(w >= 0.0)
+
+
 @pytest.mark.parametrize("mcl", [False, True])
 def test_one_launch_plan_equals_the_two_kernel_plan(loc, mcl, monkeypatch):
     """k_quantize_plan_mark (tile sums handed over inside one launch: records, two-level ticket, flag) against
