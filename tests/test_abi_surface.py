@@ -173,3 +173,19 @@ def test_instruction_budget_is_reproducible_from_the_isa():
     want = json.load(open(os.path.join(root, "rust_robotics_amd", "csrc", "INSTRUCTION_BUDGET.json")))
     assert abs(got - want["per_pair"]) < 1e-3, (got, want["per_pair"], "run `python tools/count_isa.py --write`")
     assert "tools/count_isa.py" in want["source"]
+
+
+def test_every_part_of_the_translation_units_is_a_build_dependency():
+    """pf_engine.hip / fs1_engine.hip #include their kernels as .inc parts: each part, and every shared header, must be listed in
+    the Makefile's HDRS (an edit that does not rebuild the library would ship a stale .so to the GPU box), and must be included."""
+    import glob
+    import re
+
+    csrc = os.path.join(ROOT, "rust_robotics_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    hdrs = set(re.search(r"^HDRS\s*:=\s*(.*)$", mk, flags=re.M).group(1).split())
+    parts = {os.path.basename(f) for f in glob.glob(os.path.join(csrc, "*.inc")) + glob.glob(os.path.join(csrc, "*.hpp"))}
+    assert parts <= hdrs, f"not a build dependency: {sorted(parts - hdrs)}"
+    sources = "".join(open(os.path.join(csrc, f)).read() for f in ("pf_engine.hip", "fs1_engine.hip"))
+    for p in parts:
+        assert f'#include "{p}"' in sources or p.endswith(".hpp"), f"{p} is not included by any translation unit"
