@@ -790,7 +790,8 @@ __device__ inline void st_dev(double* p, double v) { st_dev(reinterpret_cast<uin
 //                          2 * epoch + 1 = GIVEN UP: a waiting workgroup ran out of patience before that.
 // Waiting in a kernel for OTHER workgroups of the same kernel only works if all of them are on the device at once.  The
 // host launches this kernel when an idle device holds the whole grid (occupancy query, one such kernel per process at a
-// time: rr::spin_permit) -- but another PROCESS on the same GPU can keep some workgroups off the CUs while the ones that
+// time: rr::spin_permit; hipLaunchCooperativeKernel makes the same check and costs 17 us more per launch on this runtime --
+// measured, round 4: step 49.8 -> 67.8 us) -- but another PROCESS on the same GPU can keep some workgroups off the CUs while the ones that
 // run hold their slots and spin (two such kernels of two processes can do that to each other).  So the wait is bounded
 // (`giveup_ticks` of the 100 MHz wall clock, default 2 ms -- a healthy launch waits ~5 us), and when it runs out the
 // launch DEGRADES instead of failing: whoever is first moves the state word from an older epoch to RAISED (the last
