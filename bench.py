@@ -775,6 +775,9 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
             # every rank steps its own, independent filter (NO exchange, NOT one sharded filter) and the line
             # says so in config.sharding -- the number is an upper bound for the sharded step, not a measurement of it.
             res = replicas_fallback(ctx, n, L, K, W, obs_list[:W + 2 * K + EXTRA_WARMUP], scheme, lik, str(e))
+        extra["headline_step"] = ("sharded rr_pf_shard_step[_p2p]: propagate + weight + global resample -- the PLAIN step (the mean is formed when an "
+                                  "accessor asks: local moments + one all-reduce); the N = 1 line's `plain_async_step` is its single-GPU counterpart, "
+                                  "its `value` additionally produces the mean every step")
     else:
         import rust_robotics_amd.localization as loc
 
