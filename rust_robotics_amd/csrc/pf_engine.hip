@@ -1835,12 +1835,17 @@ rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]) {
   const double* part = slots ? h->est_slot_partials_host : h->est_partials_host;
   const uint64_t n_part = slots ? n_slot_tiles * (kBlock / rr::kWave) : h->n_tiles;  // (slot tiles: one entry per wave)
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  if (slots) {  // est_slots_total: interleaved chunks, then the chunks in order (k_est_mail_any adds them the same way)
-    for (int c = 0; c < kEstChunks; ++c) {
-      double cs[4] = {0.0, 0.0, 0.0, 0.0};
+  if (slots) {  // est_slots_total: the three-level order of k_est_mail_any (chunks, groups of chunks, the groups in order)
+    static thread_local std::vector<double> cs;
+    cs.assign((size_t)4 * kEstChunks, 0.0);
+    for (int c = 0; c < kEstChunks; ++c)
       for (uint64_t t = (uint64_t)c; t < n_part; t += kEstChunks)
-        for (int k = 0; k < 4; ++k) cs[k] += part[4 * t + k];
-      for (int k = 0; k < 4; ++k) acc[k] += cs[k];
+        for (int k = 0; k < 4; ++k) cs[(size_t)4 * c + k] += part[4 * t + k];
+    for (int g = 0; g < kEstGroups; ++g) {
+      double gs[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int c = g; c < kEstChunks; c += kEstGroups)
+        for (int k = 0; k < 4; ++k) gs[k] += cs[(size_t)4 * c + k];
+      for (int k = 0; k < 4; ++k) acc[k] += gs[k];
     }
   } else {
     for (uint64_t t = 0; t < n_part; ++t)
