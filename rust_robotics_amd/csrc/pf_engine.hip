@@ -1847,9 +1847,13 @@ rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]) {
         for (int k = 0; k < 4; ++k) gs[k] += cs[(size_t)4 * c + k];
       for (int k = 0; k < 4; ++k) acc[k] += gs[k];
     }
-  } else {
-    for (uint64_t t = 0; t < n_part; ++t)
-      for (int k = 0; k < 4; ++k) acc[k] += part[4 * t + k];
+  } else {  // est_plan_total's order: interleaved chunks of tiles, then the chunks in order
+    double cs[kEstPlanChunks][4] = {};
+    for (int c = 0; c < kEstPlanChunks; ++c)
+      for (uint64_t t = (uint64_t)c; t < n_part; t += kEstPlanChunks)
+        for (int k = 0; k < 4; ++k) cs[c][k] += part[4 * t + k];
+    for (int c = 0; c < kEstPlanChunks; ++c)
+      for (int k = 0; k < 4; ++k) acc[k] += cs[c][k];
   }
   for (int k = 0; k < 4; ++k) out[k] = acc[k] / h->ctl_host->est_denom;
   return RR_OK;
