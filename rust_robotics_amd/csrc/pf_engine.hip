@@ -1943,7 +1943,10 @@ rr_status rr_pf_step(rr_pf* h, const double control[2], const double* obs, size_
     // try_step (particle_filter.rs:488-497): the returned mean comes out of the step's own plan kernel -- one
     // 300-byte read-back instead of a gather + a two-kernel moment reduction.  (k_est_mail as the closing act of the plan kernel
     // itself -- device-scope partial sums, a second arrival ticket, the last workgroup adds and posts -- was measured, round 4:
-    // 71.9 - 73.7 us per synchronous step against 69.7 - 70.1 with the separate launch, whose dispatch overlaps the plan kernel.)
+    // 71.9 - 73.7 us per synchronous step against 69.7 - 70.1 with the separate launch, whose dispatch overlaps the plan kernel.
+    // So was the opposite: every workgroup of the plan kernel storing its four sums straight into pinned host memory as
+    // self-vouching {bits, seq} pairs, the host polling and adding them -- 2 000 sixteen-byte writes over the link and 489 freshly
+    // invalidated lines on the host: 70.5 - 70.9 us against 67.6 - 68.6 with k_est_mail.)
     rr_status s = step_async_impl(h, control, obs, n_obs, rr::kEstInPlan);
     if (s != RR_OK) return s;
     if (h->p2p.ready) return rr_pf_last_step_estimate(h, out_state);
