@@ -1262,14 +1262,12 @@ static rr_status resident_await(rr_pf* h, uint64_t seq, double out[4]) {
   rr_pf::Resident& r = h->res;
   const auto t0 = std::chrono::steady_clock::now();
   for (unsigned spins = 0;; ++spins) {
-    uint64_t e[4];
-    if (rr::ring_take(&r.ring->rsp[3], seq, &e[3]) && rr::ring_take(&r.ring->rsp[2], seq, &e[2]) && rr::ring_take(&r.ring->rsp[1], seq, &e[1]) &&
-        rr::ring_take(&r.ring->rsp[0], seq, &e[0])) {
+    uint64_t e[4], flags = 0;
+    // (the adaptive kernel vouches for its estimate with a flags pair: part of the answer, waited for under the same bound)
+    if ((!h->adaptive || rr::ring_take(&r.ring->rsp[rr::kResRspFlags], seq, &flags)) && rr::ring_take(&r.ring->rsp[3], seq, &e[3]) &&
+        rr::ring_take(&r.ring->rsp[2], seq, &e[2]) && rr::ring_take(&r.ring->rsp[1], seq, &e[1]) && rr::ring_take(&r.ring->rsp[0], seq, &e[0])) {
       r.pending = false;
-      if (h->adaptive) {  // (the adaptive kernel vouches for its estimate: flags != 0 => form it the long way)
-        uint64_t flags = 0;
-        while (!rr::ring_take(&r.ring->rsp[rr::kResRspFlags], seq, &flags)) {
-        }
+      if (h->adaptive) {  // flags != 0 => form the estimate the long way
         if (flags != 0) {
           if (!out) return RR_OK;
           rr_status s = bind(h);  // parks the kernel, refreshes the host's particle count
