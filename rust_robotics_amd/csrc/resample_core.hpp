@@ -914,6 +914,33 @@ __device__ inline void plan_apply_tile(typename std::conditional<FS_WEIGHTS, dou
 // (fastslam1.rs:196-203), w = 1/n when it fires (:228) -- and are rewritten by the threads that read them.
 // (amdgpu_waves_per_eu(4): at most 128 VGPRs, i.e. two of these 512-thread workgroups per CU -- the 489 workgroups of a
 // 1e6-particle filter must all be on the 256 CUs at once)
+// the serial plan of a launch that gave up (k_quantize_plan_mark): every tile by ONE workgroup
+template <bool FS_WEIGHTS, bool DEFER>
+__device__ __attribute__((noinline)) void plan_serial(typename std::conditional<FS_WEIGHTS, double*, const double*>::type w, ImageArgs a, int mode,
+                                                       int shift, int fire, double rho, PlanArgs pa, uint64_t n_tiles, const uint64_t* rec,
+                                                       unsigned int* markers, unsigned int* carry, EstArgs ea, bool want_est, int cur_after,
+                                                       TileSums ts /* the grand totals; .pre per tile below */, uint64_t* s_w, uint64_t* s4,
+                                                       uint64_t* s_tile) {
+  const int tid = threadIdx.x;
+  TileScan t;
+  EstFields ef;
+  double w_in[FS_WEIGHTS ? kItems : 1];
+  unsigned int offspring[kItems];
+  for (uint64_t tile = 0; tile < n_tiles; ++tile) {
+    const uint64_t j0 = tile * kTile + (uint64_t)tid * kItems;
+    __syncthreads();
+    uint64_t tt;
+    u128 qq;
+    plan_image_tile<FS_WEIGHTS>(w, a, mode, shift, tile, s_w, s4, t, w_in, &tt, &qq);
+    if (tid == 0) s_tile[0] = ld_dev(&rec[tile * kRecWords + 3]);
+    if (want_est) est_prefetch(ea, cur_after, j0, a.n, ef);
+    __syncthreads();
+    ts.pre = s_tile[0];
+    plan_apply_tile<FS_WEIGHTS, DEFER>(w, a, mode, shift, t, w_in, ts, fire, rho, pa, tile, markers, carry, ea, ef, offspring);
+    if (want_est) est_tile_partial(ea, t, offspring, fire, j0, a.n, ef, tile);
+  }
+}
+
 // DEFER (PF / MCL): the estimate in its deferred form (EstArgs) as a build of its own -- no offspring counts, no particle fields
 // in flight across the hand-over: the kernel sits at its 128-VGPR cap, and the one build that served both forms spilled
 template <bool FS_WEIGHTS, bool DEFER = false>
@@ -1073,28 +1100,18 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
   const bool late_fields = want_est && DEFER;  // requested now that the decision is known
   if (DEFER && ea.want && fire && tid == 0 && (gaveup ? last : blockIdx.x == 0)) est_publish(ctl, denom, pa.rstep, kEstSlotTiles);
   if (FS_WEIGHTS ? (!fire && mode != kImageWeights) : (!fire && !want_est)) return;  // nothing to write
-  // One tile -- this workgroup's, its image still in registers -- or, when the launch gave up and this workgroup arrived
-  // last, every tile one after the other (the serial plan): the same code either way.
-  uint64_t tile = gaveup ? 0 : blockIdx.x;
-  const uint64_t tile_end = gaveup ? n_tiles : tile + 1;
-  for (; tile < tile_end; ++tile) {
-    const uint64_t j0 = tile * kTile + (uint64_t)tid * kItems;
-    if (gaveup) {
-      __syncthreads();
-      uint64_t tt;
-      u128 qq;
-      plan_image_tile<FS_WEIGHTS>(w, a, mode, shift, tile, s_w, s4, t, w_in, &tt, &qq);
-      if (tid == 0) s_tile[0] = ld_dev(&rec[tile * kRecWords + 3]);
-      if (want_est) est_prefetch(ea, cur_after, j0, a.n, ef);
-      __syncthreads();
-      ts.pre = s_tile[0];
-    } else if (late_fields) {
-      est_prefetch(ea, cur_after, j0, a.n, ef);
-    }
-    plan_apply_tile<FS_WEIGHTS, DEFER>(w, a, mode, shift, t, w_in, ts, fire, rho, pa, tile, markers, carry, ea, ef, offspring);
+  if (!gaveup) {
+    // One tile -- this workgroup's, its image still in registers.  (Straight-line code: as ONE loop with the serial plan below,
+    // the tile's image, weights and fields were loop-carried values of a kernel that sits at its 128-VGPR cap.)
+    if (late_fields) est_prefetch(ea, cur_after, i0, a.n, ef);
+    plan_apply_tile<FS_WEIGHTS, DEFER>(w, a, mode, shift, t, w_in, ts, fire, rho, pa, blockIdx.x, markers, carry, ea, ef, offspring);
     RR_TL(5);
-    if (want_est) est_tile_partial(ea, t, offspring, fire, j0, a.n, ef, tile);
+    if (want_est) est_tile_partial(ea, t, offspring, fire, i0, a.n, ef, blockIdx.x);
     RR_TL(6);
+  } else {
+    // The launch gave up and this workgroup arrived last: every tile, one after the other (the serial plan) -- the same functions,
+    // behind a real call, so that the loop's live values are not the straight path's register pressure.
+    plan_serial<FS_WEIGHTS, DEFER>(w, a, mode, shift, fire, rho, pa, n_tiles, rec, markers, carry, ea, want_est, cur_after, ts, s_w, s4, s_tile);
   }
   if (want_est && tid == 0 && (gaveup ? last : blockIdx.x == 0)) est_publish(ctl, denom, pa.rstep, kEstPlanTiles);
 }
