@@ -210,6 +210,8 @@ def lib() -> C.CDLL:
     proto("rr_pf_shard_step_p2p", st, [H, P, P, sz])
     proto("rr_pf_shard_step_p2p_unfused", st, [H, P, P, sz])
     proto("rr_pf_p2p_status", st, [H, C.POINTER(i32)])
+    proto("rr_pf_shard_want_estimate", st, [H, i32])
+    proto("rr_pf_shard_last_estimate_sums", st, [H, P, P])
     proto("rr_sys_segment_matrix", u64, [d, C.POINTER(u64), i32, u64, u64, i32, C.POINTER(C.c_int64)])
     FP, FO = C.POINTER(Fs1Params), C.POINTER(Fs1Options)
     proto("rr_fs1_params_default", None, [FP])

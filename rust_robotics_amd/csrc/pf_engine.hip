@@ -166,6 +166,7 @@ struct rr_pf {
   double* est_slot_partials = nullptr; // [ceil(cap / kResolveSlots)][waves][4]: the deferred form's sums per slot tile (rr::kEstDeferred)
   double* est_slot_partials_host = nullptr;
   bool est_deferred = false;           // the last plan was asked for the deferred form and nobody has moved the particles yet
+  bool shard_est = false;              // rr_pf_shard_want_estimate: every peer-to-peer shard step leaves this shard's part of the mean
   bool est_eager = false;              // rr_pf_step of a multinomial filter: search the draws and add up the estimate right after the plan
   bool est_eager_done = false;         // ... and the launch that did it is in the stream (k_mn_search_est)
   // small particle sets (k_step_small): the step inputs of rr_pf_step_many and its per-step estimates on the device
@@ -450,7 +451,7 @@ static void launch_est_slots(rr_pf* h) {
   if (!h->est_deferred) return;
   h->est_deferred = false;
   hipLaunchKernelGGL(k_est_slots, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b, (const Ctl*)h->ctl, h->n,
-                     h->est_slot_partials);
+                     h->est_slot_partials, h->p2p.ready ? 1 : 0);
 }
 
 rr_status materialise(rr_pf* h) {
@@ -478,6 +479,7 @@ rr_status materialise(rr_pf* h) {
                        (const double*)(via_p2p ? h->p2p.inbox : h->rccl_inbox), h->idx, via_p2p ? h->window_seq : (uint64_t)0,
                        via_p2p ? h->p2p.peers.timeout_ticks : (uint64_t)0, via_p2p ? h->p2p.err : (int*)nullptr);
     hipLaunchKernelGGL(k_settle, dim3(1), dim3(1), 0, h->stream, h->ctl);
+    launch_est_slots(h);
     RR_HIP_TRY(hipGetLastError());
     h->maybe_pending = false;
     h->pending_kind = kSrcMarkers;
@@ -1108,10 +1110,10 @@ static void launch_k1(rr_pf* h, bool kernarg, int src, unsigned grid, size_t lds
                       const StepParams& p, const ObsArg& arg, unsigned int* markers, const unsigned int* carry,
                       unsigned int* idx_out, const WindowArgs& wa = WindowArgs{}, bool packed = false) {
   const bool product = p.lik_mode == RR_LIK_PRODUCT;
-  const bool est = wa.est_partials != nullptr;  // the builds that add up the deferred estimate (never the window kernels)
+  const bool est = wa.est_partials != nullptr;  // the builds that add up the deferred estimate
 #define RR_K1_GO(KA_, SRC_, LIK_)                                                                                             \
-  ((est && SRC_ != kSrcWindow) ? launch_k1_as<KA_, SRC_, LIK_, false, (SRC_ != kSrcWindow)>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa) \
-                               : launch_k1_as<KA_, SRC_, LIK_>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa))
+  (est ? launch_k1_as<KA_, SRC_, LIK_, false, true>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa) \
+       : launch_k1_as<KA_, SRC_, LIK_>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa))
 #define RR_K1_GO_PK(KA_, LIK_)                                                                                         \
   (est ? launch_k1_as<KA_, kSrcLidx, LIK_, true, true>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa)         \
        : launch_k1_as<KA_, kSrcLidx, LIK_, true>(h, grid, lds, ea, eb, p, arg, markers, carry, idx_out, wa))
@@ -1808,6 +1810,22 @@ rr_status rr_pf_step_async_estimate(rr_pf* h, const double control[2], const dou
   return step_async_impl(h, control, obs, n_obs, mode);
 }
 
+// est_slots_total on the host: the three-level order of k_est_mail_any (interleaved chunks, groups of chunks, the groups in order)
+static void est_slots_total_host(const double* part, uint64_t n_part, double acc[4]) {
+  static thread_local std::vector<double> cs;
+  cs.assign((size_t)4 * kEstChunks, 0.0);
+  for (int k = 0; k < 4; ++k) acc[k] = 0.0;
+  for (int c = 0; c < kEstChunks; ++c)
+    for (uint64_t t = (uint64_t)c; t < n_part; t += kEstChunks)
+      for (int k = 0; k < 4; ++k) cs[(size_t)4 * c + k] += part[4 * t + k];
+  for (int g = 0; g < kEstGroups; ++g) {
+    double gs[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c = g; c < kEstChunks; c += kEstGroups)
+      for (int k = 0; k < 4; ++k) gs[k] += cs[(size_t)4 * c + k];
+    for (int k = 0; k < 4; ++k) acc[k] += gs[k];
+  }
+}
+
 rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
@@ -1833,18 +1851,8 @@ rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]) {
   const double* part = slots ? h->est_slot_partials_host : h->est_partials_host;
   const uint64_t n_part = slots ? n_slot_tiles * (kBlock / rr::kWave) : h->n_tiles;  // (slot tiles: one entry per wave)
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  if (slots) {  // est_slots_total: the three-level order of k_est_mail_any (chunks, groups of chunks, the groups in order)
-    static thread_local std::vector<double> cs;
-    cs.assign((size_t)4 * kEstChunks, 0.0);
-    for (int c = 0; c < kEstChunks; ++c)
-      for (uint64_t t = (uint64_t)c; t < n_part; t += kEstChunks)
-        for (int k = 0; k < 4; ++k) cs[(size_t)4 * c + k] += part[4 * t + k];
-    for (int g = 0; g < kEstGroups; ++g) {
-      double gs[4] = {0.0, 0.0, 0.0, 0.0};
-      for (int c = g; c < kEstChunks; c += kEstGroups)
-        for (int k = 0; k < 4; ++k) gs[k] += cs[(size_t)4 * c + k];
-      for (int k = 0; k < 4; ++k) acc[k] += gs[k];
-    }
+  if (slots) {
+    est_slots_total_host(part, n_part, acc);
   } else {  // est_plan_total's order: interleaved chunks of tiles, then the chunks in order
     double cs[kEstPlanChunks][4] = {};
     for (int c = 0; c < kEstPlanChunks; ++c)
@@ -2486,6 +2494,9 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   wa.wait_seq = h->window_seq;  // the step whose resample this launch consumes (its deliveries carry that seal)
   wa.timeout_ticks = h->p2p.peers.timeout_ticks;
   wa.n_ranks = h->p2p.peers.n_ranks;
+  // rr_pf_shard_want_estimate: this launch adds up the fields of the sources of its own slots (the step before's resample)
+  wa.est_partials = h->est_deferred ? h->est_slot_partials : nullptr;
+  h->est_deferred = false;
   const uint64_t seq = ++h->p2p.seq;
   uint64_t* gathered = h->p2p.gathered();
   // A: propagate + weight through the window
@@ -2557,6 +2568,40 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   h->pending_kind = kSrcWindow;
   h->window_seq = seq;
   h->window_rccl = false;
+  h->est_deferred = h->shard_est;  // (whoever moves the particles next adds up this shard's part of the step's mean)
+  return RR_OK;
+}
+
+// The mean try_step returns, for a filter sharded over the peer-to-peer transport: with want != 0 every rr_pf_shard_step_p2p leaves
+// THIS shard's part -- the sums of the four fields over the sources of its own output slots (deferred form of the in-step
+// estimate: added up by the next step's kernel as it moves the particles, rr::EstArgs) -- and rr_pf_shard_last_estimate_sums
+// returns them with the denominator N; the mean is the sum of the shards' sums over N (one all-reduce of four doubles, whenever
+// the caller wants the value).  Defined for steps whose resample fired (MonteCarloLocalizer: every step).
+rr_status rr_pf_shard_want_estimate(rr_pf* h, int32_t want) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (want && !h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_p2p_connect first");
+  if (want && !h->est_slot_partials)
+    RR_HIP_TRY(hipMalloc(&h->est_slot_partials, (size_t)grid_for(h->cap, rr::kResolveSlots) * kEstSlotWords * sizeof(double)));
+  h->shard_est = want != 0;  // (want == 0: later steps leave no sums; the last step's stay readable, also after one more step)
+  return RR_OK;
+}
+
+rr_status rr_pf_shard_last_estimate_sums(rr_pf* h, double out_sums[4], double* out_denom) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out_sums || !out_denom) return fail(RR_INVALID_PARAMETER, "null output");
+  if (!h->est_slot_partials || !h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_shard_want_estimate first");
+  if (h->est_deferred && (s = materialise(h)) != RR_OK) return s;  // nobody has moved the particles yet: gather + k_est_slots
+  if (h->est_deferred) launch_est_slots(h);
+  const uint64_t n_part = (uint64_t)grid_for(h->n, rr::kResolveSlots) * (kBlock / rr::kWave);
+  if (!h->est_slot_partials_host)
+    RR_HIP_TRY(hipHostMalloc(&h->est_slot_partials_host, (size_t)grid_for(h->cap, rr::kResolveSlots) * kEstSlotWords * sizeof(double)));
+  RR_HIP_TRY(hipMemcpyAsync(h->est_slot_partials_host, h->est_slot_partials, (size_t)n_part * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  if (!h->ctl_host->fired) return fail(RR_INVALID_PARAMETER, "the last step's gate stayed shut: no resampled set to take the mean of");
+  est_slots_total_host(h->est_slot_partials_host, n_part, out_sums);
+  *out_denom = (double)h->n_global;
   return RR_OK;
 }
 
@@ -2613,6 +2658,10 @@ rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const 
   // exchange 3: every rank has finished writing into everybody's slab
   hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PDone, seq,
                      (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+  if (h->shard_est) {  // rr_pf_shard_want_estimate: the resampled set is in place (eager gather): this shard's part of its mean
+    h->est_deferred = true;
+    launch_est_slots(h);
+  }
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
 }

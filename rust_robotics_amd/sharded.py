@@ -490,6 +490,17 @@ class P2PShard:
         self._check(self.L.rr_pf_p2p_status(self.h, C.byref(out)))
         return bool(out.value)
 
+    def want_estimate(self, on: bool = True) -> None:
+        """rr_pf_shard_want_estimate: every step leaves this shard's part of the mean try_step returns (the sums of x, y, yaw, v
+        over the sources of the shard's own output slots, added up by the kernel that moves the particles)."""
+        self._check(self.L.rr_pf_shard_want_estimate(self.h, 1 if on else 0))
+
+    def estimate_sums(self):
+        """(sums[4], N) of the last step: the mean is the sum of every shard's sums over N (one all-reduce of four doubles)."""
+        sums, den = np.empty(4), C.c_double()
+        self._check(self.L.rr_pf_shard_last_estimate_sums(self.h, sums.ctypes.data_as(C.POINTER(C.c_double)), C.byref(den)))
+        return sums, den.value
+
     def particles(self) -> np.ndarray:
         out = np.empty((self.n_local, 5))
         self._check(self.L.rr_pf_get_particles(self.h, out.ctypes.data_as(C.POINTER(C.c_double))))
@@ -815,6 +826,23 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
 
     shard = p2p if use_p2p else ref
     log("timed region on " + ("the peer-to-peer transport" if use_p2p else f"the {ref_kind} transport"))
+    # the reference's try_step returns the mean every step: over the peer-to-peer transport every step leaves this shard's part of
+    # it (the sums over the sources of its own slots, added up by the kernel that moves the particles); the all-reduce of the four
+    # doubles is only done when somebody wants the value -- below, once, after the timed steps
+    est_every_step = False
+    if use_p2p:
+        ok = True
+        try:
+            p2p.want_estimate(True)
+        except RoboticsError as e:
+            ok = False
+            log(f"rr_pf_shard_want_estimate failed on this rank: {e}")
+        est_every_step = agree(ok)
+        if not est_every_step:
+            try:
+                p2p.want_estimate(False)
+            except RoboticsError:
+                pass
     if not validated_ref and not use_p2p:  # no validation ran on it: the reference transport has not seen the first V steps yet
         for t in range(V):
             ref.step(u, obs_list[t])
@@ -830,7 +858,23 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
             seconds = timed_region(shard)
             notes.append(f"timed region repeated on the {ref_kind} transport")
     if use_p2p:
-        est, _ = p2p.local_moments()  # local estimate of this rank's block (all blocks are samples of the same posterior)
+        est, ok = None, False
+        if est_every_step:
+            try:
+                sums, den = p2p.estimate_sums()
+                ok = True
+            except RoboticsError as e:
+                log(f"rr_pf_shard_last_estimate_sums failed on this rank: {e}")
+                sums, den = np.zeros(4), 1.0
+            if agree(ok):
+                tot = torch.tensor(sums, dtype=torch.float64)
+                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+                est = (tot / den).numpy()
+            else:
+                est_every_step = False
+            p2p.want_estimate(False)  # (the instrumented continuation below times the kernels of the plain step)
+        if est is None:
+            est, _ = p2p.local_moments()  # local estimate of this rank's block (all blocks are samples of the same posterior)
         moved = -1
     else:
         est, _ = shard.estimate()
@@ -852,4 +896,4 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
         dist.destroy_process_group()
     return dict(seconds=seconds, seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est], dominant=None,
                 migrated_particles_last_step=moved, transport="p2p (xGMI, device-initiated)" if use_p2p else ref_kind,
-                transport_note="; ".join(notes), p2p_timed_out=bool(timed_out))
+                transport_note="; ".join(notes), p2p_timed_out=bool(timed_out), estimate_every_step=bool(est_every_step))

@@ -58,6 +58,69 @@ def run_in_process(world, n_local, steps=10, mode="fused"):
     print("P2P_LOCAL_OK")
 
 
+def run_estimate_in_process(world, n_local, steps=12, mode="fused"):
+    """rr_pf_shard_want_estimate: the shards' sums of the resampled set's fields divided by N, against the unsharded filter's
+    in-step estimate (its deferred form: the same slot tiles at world size 1, hence the same bits there).  Read at once (the
+    accessor's gather + k_est_slots add the sums up) and read a step later (the next step's k_step_lazy<kSrcWindow, EST> has,
+    while it moved the particles)."""
+    import rust_robotics_amd.localization as loc
+    from rust_robotics_amd import _ffi
+    from rust_robotics_amd.sharded import P2PShard
+
+    os.environ["RR_PF_EST_DEFER"] = "1"
+    kw = dict(range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))
+    shards = [P2PShard(g, world, 0, n_local, seed=42, **kw) for g in range(world)]
+    P2PShard.link_local(shards)
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=n_local * world, max_particles=n_local * world, **kw)
+    ref = loc.MonteCarloLocalizer(cfg, seed=42, resample_scheme=_ffi.RR_RESAMPLE_SYSTEMATIC)
+    rng = np.random.default_rng(43)
+
+    def step_all(obs, want):
+        for s in shards:
+            s.want_estimate(want)
+            (s.step if mode == "fused" else s.step_unfused)([1.0, 0.1], obs)
+
+    def mean_of_shards():
+        sums = [s.estimate_sums() for s in shards]
+        assert all(den == n_local * world for _, den in sums)
+        return np.sum([a for a, _ in sums], axis=0) / sums[0][1]
+
+    def check(got, want, what):
+        if world == 1:
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (what, got, want)
+        np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-11, err_msg=what)
+
+    t = 0
+    while t < steps:
+        obs = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng)
+        step_all(obs, True)
+        ref.step_async_estimate([1.0, 0.1], obs)
+        want = np.array(ref.last_step_estimate())
+        t += 1
+        if t % 3 == 0:  # one more step on both sides -- a plain one -- before the value of the step before is read
+            obs2 = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng)
+            step_all(obs2, False)
+            ref.step_async([1.0, 0.1], obs2)
+            t += 1
+            check(mean_of_shards(), want, f"step {t - 1}, read a step later")
+        else:
+            check(mean_of_shards(), want, f"step {t}, read at once")
+    exp = ref.get_particles_array()
+    for g, s in enumerate(shards):
+        assert not s.timed_out()
+        assert np.array_equal(s.particles().view(np.uint64), exp[g * n_local:(g + 1) * n_local].view(np.uint64)), f"rank {g} differs"
+        s.close()
+    print("P2P_EST_OK")
+
+
+@pytest.mark.parametrize("world,n_local,mode", [(1, 5000, "fused"), (2, 6000, "fused"), (3, 4100, "fused"), (2, 6000, "unfused"), (1, 300_000, "fused")])
+def test_in_process_shards_leave_their_part_of_the_mean(world, n_local, mode):
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); from tests.test_gpu_p2p import run_estimate_in_process; run_estimate_in_process({world}, {n_local}, mode={mode!r})"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="8"))
+    assert r.returncode == 0 and "P2P_EST_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 @pytest.mark.parametrize("world,n_local,mode", [(1, 5000, "fused"), (2, 6000, "fused"), (3, 4100, "fused"),
                                                 (2, 6000, "unfused"), (3, 4100, "mixed"), (2, 700_000, "fused")])
 def test_in_process_shards_equal_unsharded(world, n_local, mode):
