@@ -24,10 +24,20 @@ def mcl(kind, dist, rank, world, n, steps):
         shard = NativeShard(rank, world, rank, n, gloo_exchange(dist), **kw)
     dist.barrier()
     rng = np.random.default_rng(43)
+    if kind == "p2p":
+        shard.want_estimate(True)  # every step leaves this shard's part of the mean try_step returns
     for t in range(steps):
         shard.step([1.0, 0.1], H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng))
     if kind == "p2p":
         assert not shard.timed_out(), "a peer wait timed out"
+        # ... the shards' sums over N = the mean of the resampled set, whose slots came from both devices
+        import torch
+
+        sums, den = shard.estimate_sums()
+        tot = torch.tensor(sums, dtype=torch.float64)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        whole = unsharded(n * world, steps)
+        np.testing.assert_allclose((tot / den).numpy(), whole[:, :4].mean(axis=0), rtol=1e-10, atol=1e-10)
     got = shard.particles()
     exp = unsharded(n * world, steps)[rank * n:(rank + 1) * n]
     assert np.array_equal(got.view(np.uint64), exp.view(np.uint64)), f"{kind} shard differs from the unsharded engine"
