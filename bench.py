@@ -776,7 +776,7 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
             # says so in config.sharding -- the number is an upper bound for the sharded step, not a measurement of it.
             res = replicas_fallback(ctx, n, L, K, W, obs_list[:W + 2 * K + EXTRA_WARMUP], scheme, lik, str(e))
         extra["headline_step"] = (
-            "sharded rr_pf_shard_step_p2p + rr_pf_shard_want_estimate: propagate + weight + global resample, every shard leaving its part of the mean "
+            "sharded rr_pf_shard_step_p2p / rr_pf_shard_step + rr_pf_shard_want_estimate: propagate + weight + global resample, every shard leaving its part of the mean "
             "try_step returns every step (the sums over the sources of its own slots, added up by the kernel that moves the particles; one all-reduce of "
             "four doubles when the value is read) -- the counterpart of the N = 1 line's `value`"
             if res.get("estimate_every_step") else

@@ -360,8 +360,8 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
 /* the same step with an eager gather of ALL slots into their owners' slabs and a separate tile-scan
  * launch: the plain statement of the protocol, kept for A/B measurement */
 rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const double* obs, size_t n_obs);
-/* The mean try_step returns, for a filter sharded over the peer-to-peer transport.  want != 0: every rr_pf_shard_step_p2p
- * leaves THIS shard's part of it -- the sums of x, y, yaw, v over the sources of the shard's own output slots, added up by
+/* The mean try_step returns, for a sharded filter (systematic scheme; the peer-to-peer transport and the native RCCL
+ * step).  want != 0: every rr_pf_shard_step_p2p / rr_pf_shard_step leaves THIS shard's part of it -- the sums of x, y, yaw, v over the sources of the shard's own output slots, added up by
  * the kernel that moves the particles (the next step's, or the accessor's gather when the value is read first; the deferred
  * form of rr_pf_step_async_estimate).  rr_pf_shard_last_estimate_sums returns the four sums and the denominator N: the mean
  * is the sum of every shard's sums divided by N (one all-reduce of four doubles whenever the caller wants the value).

@@ -166,7 +166,8 @@ struct rr_pf {
   double* est_slot_partials = nullptr; // [ceil(cap / kResolveSlots)][waves][4]: the deferred form's sums per slot tile (rr::kEstDeferred)
   double* est_slot_partials_host = nullptr;
   bool est_deferred = false;           // the last plan was asked for the deferred form and nobody has moved the particles yet
-  bool shard_est = false;              // rr_pf_shard_want_estimate: every peer-to-peer shard step leaves this shard's part of the mean
+  bool shard_est = false;              // rr_pf_shard_want_estimate: every window step of this shard leaves its part of the mean
+  bool shard_est_ever = false;         // ... has been asked for at some point (k_est_slots then trusts the caller about Ctl.fired)
   bool est_eager = false;              // rr_pf_step of a multinomial filter: search the draws and add up the estimate right after the plan
   bool est_eager_done = false;         // ... and the launch that did it is in the stream (k_mn_search_est)
   // small particle sets (k_step_small): the step inputs of rr_pf_step_many and its per-step estimates on the device
@@ -451,7 +452,7 @@ static void launch_est_slots(rr_pf* h) {
   if (!h->est_deferred) return;
   h->est_deferred = false;
   hipLaunchKernelGGL(k_est_slots, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b, (const Ctl*)h->ctl, h->n,
-                     h->est_slot_partials, h->p2p.ready ? 1 : 0);
+                     h->est_slot_partials, h->shard_est_ever ? 1 : 0);
 }
 
 rr_status materialise(rr_pf* h) {
@@ -2580,10 +2581,12 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
 rr_status rr_pf_shard_want_estimate(rr_pf* h, int32_t want) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
-  if (want && !h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_p2p_connect first");
+  if (want && h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC)
+    return fail(RR_INVALID_PARAMETER, "the sharded estimate serves the systematic scheme (the window steps: rr_pf_shard_step_p2p, rr_pf_shard_step)");
   if (want && !h->est_slot_partials)
     RR_HIP_TRY(hipMalloc(&h->est_slot_partials, (size_t)grid_for(h->cap, rr::kResolveSlots) * kEstSlotWords * sizeof(double)));
   h->shard_est = want != 0;  // (want == 0: later steps leave no sums; the last step's stay readable, also after one more step)
+  if (want) h->shard_est_ever = true;
   return RR_OK;
 }
 
@@ -2591,7 +2594,7 @@ rr_status rr_pf_shard_last_estimate_sums(rr_pf* h, double out_sums[4], double* o
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!out_sums || !out_denom) return fail(RR_INVALID_PARAMETER, "null output");
-  if (!h->est_slot_partials || !h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_shard_want_estimate first");
+  if (!h->est_slot_partials || !h->shard_est_ever) return fail(RR_INVALID_PARAMETER, "call rr_pf_shard_want_estimate first");
   if (h->est_deferred && (s = materialise(h)) != RR_OK) return s;  // nobody has moved the particles yet: gather + k_est_slots
   if (h->est_deferred) launch_est_slots(h);
   const uint64_t n_part = (uint64_t)grid_for(h->n, rr::kResolveSlots) * (kBlock / rr::kWave);

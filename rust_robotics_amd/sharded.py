@@ -343,6 +343,16 @@ class NativeShard:
     def migrated(self) -> int:
         return int(self.L.rr_pf_shard_last_migrated(self.h))
 
+    def want_estimate(self, on: bool = True) -> None:
+        """rr_pf_shard_want_estimate (systematic shards): every step leaves this shard's part of the mean try_step returns."""
+        self._check(self.L.rr_pf_shard_want_estimate(self.h, 1 if on else 0))
+
+    def estimate_sums(self):
+        """(sums[4], N) of the last step: the mean is the sum of every shard's sums over N."""
+        sums, den = np.empty(4), C.c_double()
+        self._check(self.L.rr_pf_shard_last_estimate_sums(self.h, sums.ctypes.data_as(C.POINTER(C.c_double)), C.byref(den)))
+        return sums, den.value
+
     def synchronize(self) -> None:
         self._check(self.L.rr_pf_synchronize(self.h))
 
@@ -414,6 +424,19 @@ class LocalWindowShards:
         out = np.empty((self.n_local, 5))
         self._check(self.L.rr_pf_get_particles(C.c_void_p(self.hs[g]), out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
+
+    def want_estimate(self, on: bool = True) -> None:
+        for g in range(self.world):
+            self._check(self.L.rr_pf_shard_want_estimate(C.c_void_p(self.hs[g]), 1 if on else 0))
+
+    def estimate(self) -> np.ndarray:
+        """the mean of the last step's resampled set: the shards' sums (rr_pf_shard_last_estimate_sums) over N"""
+        total, den = np.zeros(4), C.c_double()
+        for g in range(self.world):
+            sums = np.empty(4)
+            self._check(self.L.rr_pf_shard_last_estimate_sums(C.c_void_p(self.hs[g]), sums.ctypes.data_as(C.POINTER(C.c_double)), C.byref(den)))
+            total += sums
+        return total / den.value
 
     def migrated(self) -> int:
         return int(self.L.rr_pf_shard_last_migrated(C.c_void_p(self.hs[0])))
@@ -830,17 +853,17 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     # it (the sums over the sources of its own slots, added up by the kernel that moves the particles); the all-reduce of the four
     # doubles is only done when somebody wants the value -- below, once, after the timed steps
     est_every_step = False
-    if use_p2p:
+    if not multinomial and hasattr(shard, "want_estimate"):  # (the peer-to-peer and the native RCCL transport)
         ok = True
         try:
-            p2p.want_estimate(True)
+            shard.want_estimate(True)
         except RoboticsError as e:
             ok = False
             log(f"rr_pf_shard_want_estimate failed on this rank: {e}")
         est_every_step = agree(ok)
         if not est_every_step:
             try:
-                p2p.want_estimate(False)
+                shard.want_estimate(False)
             except RoboticsError:
                 pass
     if not validated_ref and not use_p2p:  # no validation ran on it: the reference transport has not seen the first V steps yet
@@ -857,27 +880,33 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
             use_p2p, shard = False, ref
             seconds = timed_region(shard)
             notes.append(f"timed region repeated on the {ref_kind} transport")
+    est, ok = None, False
+    if est_every_step and not timed_out:
+        try:
+            sums, den = shard.estimate_sums()
+            ok = True
+        except RoboticsError as e:
+            log(f"rr_pf_shard_last_estimate_sums failed on this rank: {e}")
+            sums, den = np.zeros(4), 1.0
+        if agree(ok):
+            tot = torch.tensor(sums, dtype=torch.float64)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            est = (tot / den).numpy()
+        else:
+            est_every_step = False
+        try:
+            shard.want_estimate(False)  # (the instrumented continuation below times the kernels of the plain step)
+        except RoboticsError:
+            pass
+    elif est_every_step:
+        est_every_step = False  # (the region was repeated on the reference transport without it)
     if use_p2p:
-        est, ok = None, False
-        if est_every_step:
-            try:
-                sums, den = p2p.estimate_sums()
-                ok = True
-            except RoboticsError as e:
-                log(f"rr_pf_shard_last_estimate_sums failed on this rank: {e}")
-                sums, den = np.zeros(4), 1.0
-            if agree(ok):
-                tot = torch.tensor(sums, dtype=torch.float64)
-                dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-                est = (tot / den).numpy()
-            else:
-                est_every_step = False
-            p2p.want_estimate(False)  # (the instrumented continuation below times the kernels of the plain step)
         if est is None:
             est, _ = p2p.local_moments()  # local estimate of this rank's block (all blocks are samples of the same posterior)
         moved = -1
     else:
-        est, _ = shard.estimate()
+        if est is None:
+            est, _ = shard.estimate()
         moved = shard.migrated()
     shard.profile(True)
     t1 = time.perf_counter()

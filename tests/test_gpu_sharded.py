@@ -137,3 +137,53 @@ def test_rccl_window_step_in_process_equals_unsharded(world, n_local, peaked):
                 assert bad.size == 0, f"step {t} shard {g}: {bad.size} of {n_local} particles differ, first {bad[:6]}, last {bad[-3:]}"
     assert moved > 0, "no particle ever crossed a shard boundary: the exchange was not exercised"
     sh.close()
+
+
+@pytest.mark.parametrize("world,n_local", [(1, 20_000), (2, 6000), (3, 4100), (2, 300_000)])
+def test_rccl_window_step_leaves_the_shards_part_of_the_mean(world, n_local, monkeypatch):
+    """rr_pf_shard_want_estimate on the RCCL transport's window step (the loopback seam): the shards' sums over N against the
+    unsharded filter's in-step estimate in its deferred form -- the same slot tiles at world size 1, so the same bits there --
+    read at once (accessor's gather + k_est_slots) and a step later (the next step's k_step_lazy<kSrcWindow, EST>)."""
+    import math
+
+    import numpy as np
+
+    import rust_robotics_amd.localization as loc
+    from rust_robotics_amd import _ffi
+    from rust_robotics_amd.sharded import LocalWindowShards
+    from tests import helpers as H
+
+    monkeypatch.setenv("RR_PF_EST_DEFER", "1")
+    kw = dict(seed=42, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=n_local * world, max_particles=n_local * world, range_noise=0.5, velocity_noise=0.3,
+                                           yaw_rate_noise=math.radians(5.0))
+    ref = loc.MonteCarloLocalizer(cfg, seed=42, resample_scheme=_ffi.RR_RESAMPLE_SYSTEMATIC)
+    sh = LocalWindowShards(world, n_local, **kw)
+    rng = np.random.default_rng(43)
+
+    def check(got, want, what):
+        if world == 1:
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (what, got, want)
+        np.testing.assert_allclose(got, want, rtol=1e-11, atol=1e-11, err_msg=what)
+
+    t = 0
+    while t < 10:
+        obs = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng)
+        sh.want_estimate(True)
+        sh.step([1.0, 0.1], obs)
+        ref.step_async_estimate([1.0, 0.1], obs)
+        want = np.array(ref.last_step_estimate())
+        t += 1
+        if t % 3 == 0:
+            obs2 = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng)
+            sh.want_estimate(False)
+            sh.step([1.0, 0.1], obs2)
+            ref.step_async([1.0, 0.1], obs2)
+            t += 1
+            check(sh.estimate(), want, f"step {t - 1}, read a step later")
+        else:
+            check(sh.estimate(), want, f"step {t}, read at once")
+    exp = ref.get_particles_array()
+    for g in range(world):
+        assert np.array_equal(sh.particles(g).view(np.uint64), exp[g * n_local:(g + 1) * n_local].view(np.uint64)), f"shard {g}"
+    sh.close()
