@@ -425,6 +425,10 @@ class LocalWindowShards:
         self._check(self.L.rr_pf_get_particles(C.c_void_p(self.hs[g]), out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
+    def synchronize(self) -> None:
+        for g in range(self.world):
+            self._check(self.L.rr_pf_synchronize(C.c_void_p(self.hs[g])))
+
     def want_estimate(self, on: bool = True) -> None:
         for g in range(self.world):
             self._check(self.L.rr_pf_shard_want_estimate(C.c_void_p(self.hs[g]), 1 if on else 0))

