@@ -1369,9 +1369,110 @@ def main():
         emit(out)
 
 
+HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data")
+LINE_LIMIT = 3500  # bytes: the driver keeps a short tail of stdout; round 4's 24.7 KB line fell off it (BENCH_r04.json parsed: null)
+
+
+def _num(v, digits=6):
+    """numbers of the compact line carry 6 significant digits; everything else passes through"""
+    if isinstance(v, float) and math.isfinite(v):
+        return float(f"{v:.{digits}g}")
+    return v
+
+
+def _short(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[: n - 3] + "..."
+
+
+def _compact_roofline(r):
+    if not isinstance(r, dict):
+        return None
+    out = {k: _num(r[k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "binding_frac", "traffic", "avg_kernel_ms",
+                                   "algorithmic_bytes_per_launch") if k in r}
+    if "kernel" in out:
+        out["kernel"] = _short(str(out["kernel"]).split(" ")[0], 40)
+    return out
+
+
+def _compact_cpu(c):
+    if not isinstance(c, dict):
+        return None
+    out = {k: _num(c[k]) for k in ("value", "unit", "cores", "kind") if k in c}
+    if "sample" in c:
+        out["sample"] = _short(c["sample"], 330)
+    host = c.get("host")
+    if isinstance(host, dict):
+        out["host"] = _short(f"{host.get('cpu_model', '?')}, {host.get('nproc', '?')} hw threads, {host.get('threads', '?')} used", 90)
+    return out
+
+
+def _leg_row(leg):
+    """[ms_per_step, roofline fraction of the leg's dominant kernel (HBM), fraction of its binding resource]"""
+    if not isinstance(leg, dict):
+        return None
+    if "error" in leg:
+        return {"error": _short(leg["error"], 80)}
+    r = leg.get("roofline") if isinstance(leg.get("roofline"), dict) else {}
+    return [_num(leg.get("ms_per_step"), 5), _num(r.get("frac"), 4), _num(r.get("binding_frac", r.get("frac")), 4)]
+
+
+def compact_line(out):
+    """The line the driver parses: the contract's headline fields, `roofline`, `cpu_baseline`, and one short row per extra
+    leg.  Every leg in full goes out as its own earlier JSON line and into bench_legs.json (emit)."""
+    line = {k: _num(out[k], 9) for k in HEADLINE_KEYS if k in out}
+    cfg = out.get("config")
+    if isinstance(cfg, dict):
+        line["config"] = {k: (_short(v, 200) if isinstance(v, str) else v) for k, v in cfg.items()}
+    if "roofline" in out:
+        line["roofline"] = _compact_roofline(out["roofline"])
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = _compact_cpu(out["cpu_baseline"])
+    for k in ("device_warmup_steps", "ms_per_step_cold", "deadline_exceeded", "error"):
+        if k in out:
+            line[k] = _num(out[k], 5)
+    legs = {}
+    for name, leg in out.items():
+        if not isinstance(leg, dict) or name in ("config", "roofline", "cpu_baseline", "kernel_ms_avg", "index_parity"):
+            continue
+        if "ms_per_step" in leg or "error" in leg:
+            legs[name] = _leg_row(leg)
+        else:  # a group of legs (sharded_world1: {p2p, rccl}; small_n: {rows})
+            for sub, v in leg.items():
+                if isinstance(v, dict) and ("ms_per_step" in v or "error" in v):
+                    legs[f"{name}.{sub}"] = _leg_row(v)
+    if legs:
+        line["legs"] = legs
+        line["legs_columns"] = ["ms_per_step", "hbm_frac", "binding_frac"]
+    for k in ("strong_scaling_ceiling", "weak_scaling_ceiling"):
+        if k in out:
+            line[k] = out[k]
+    if legs:
+        line["full"] = "bench_legs.json; every leg also as its own JSON line above this one"
+    data = json.dumps(line)
+    while len(data) > LINE_LIMIT:  # never again a line the driver cannot read: shed the optional parts, longest first
+        for k in ("legs", "cpu_baseline.sample", "config.workload", "roofline"):
+            if "." in k:
+                a, b = k.split(".")
+                if isinstance(line.get(a), dict) and isinstance(line[a].get(b), str) and len(line[a][b]) > 60:
+                    line[a][b] = _short(line[a][b], 60)
+                    break
+            elif k in line and k == "legs":
+                line.pop("legs")
+                line.pop("legs_columns", None)
+                break
+        else:
+            line = {k: line[k] for k in HEADLINE_KEYS if k in line}
+            data = json.dumps(line)
+            break
+        data = json.dumps(line)
+    return data
+
+
 def emit(out):
-    """ONE JSON line, last on stdout: native libraries (RCCL's version banner) write through C
-    stdio, so drain that buffer first."""
+    """Last on stdout: ONE compact JSON line (compact_line, < LINE_LIMIT bytes) with the contract's fields.  Before it, every
+    extra leg in full as its own JSON line ({"leg": name, ...}), and the whole record in bench_legs.json.  Native libraries
+    (RCCL's version banner) write through C stdio, so drain that buffer first."""
     import ctypes
 
     try:
@@ -1379,7 +1480,22 @@ def emit(out):
     except Exception:
         pass
     _OUT["emitted"] = True
-    data = (json.dumps(out) + "\n").encode()
+    chunks = []
+    head = {k: v for k, v in out.items() if not (isinstance(v, dict) and k not in ("config", "roofline", "cpu_baseline", "kernel_ms_avg",
+                                                                                 "index_parity", "plain_async_step",
+                                                                                 "synchronous_try_step"))}
+    if len(out) > len(head):
+        chunks.append(json.dumps({"leg": "headline", **head}))
+        for k, v in out.items():
+            if k not in head:
+                chunks.append(json.dumps({"leg": k, **v}))
+    try:
+        with open(os.environ.get("RR_BENCH_LEGS_FILE", os.path.join(ROOT, "bench_legs.json")), "w") as f:
+            json.dump(out, f, indent=1)
+    except OSError:
+        pass
+    chunks.append(compact_line(out))
+    data = ("\n".join(chunks) + "\n").encode()
     if _OUT["fd"] is None:
         sys.stdout.write(data.decode())
         sys.stdout.flush()

@@ -69,3 +69,48 @@ def test_deadline_prints_the_headline_and_leaves():
     assert "deadline of" in r.stderr
     r = _run_snippet(code % "None", {"RR_BENCH_DEADLINE_S": "0.5"})
     assert r.returncode != 0 and r.stdout == ""
+
+
+def test_the_last_line_is_short_enough_for_the_driver_and_carries_the_contract(tmp_path):
+    """Round 4's line was 24.7 KB and the driver's record came back `parsed: null`.  The last stdout line is now a compact
+    one (< 4 KB) with the contract's fields, `roofline` and `cpu_baseline`; the full legs are earlier lines and a file.
+    Input: round 4's own full record (profiles/r04g_bench_driver_command.json)."""
+    import json
+
+    legs_file = tmp_path / "legs.json"
+    r = _run_snippet("import json, bench\n"
+                     "bench.claim_stdout()\n"
+                     "bench.emit(json.load(open('profiles/r04g_bench_driver_command.json')))\n", {"RR_BENCH_LEGS_FILE": str(legs_file)})
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    last = lines[-1]
+    assert len(last) < 4096, len(last)
+    line = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["config"]["workload"].startswith("fixed-N MCL (BASELINE.json configs[1])")
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in line["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-5
+    full = json.load(open(legs_file))
+    assert abs(line["value"] / full["value"] - 1) < 1e-8 and abs(line["ms_per_step"] / full["ms_per_step"] - 1) < 1e-8
+    assert line["legs"]["fastslam"][0] == pytest.approx(full["fastslam"]["ms_per_step"], rel=1e-4)
+    # every earlier line is a leg in full, each of them JSON on its own
+    named = [json.loads(l)["leg"] for l in lines[:-1]]
+    assert named[0] == "headline" and "fastslam" in named and "mcl_multinomial" in named
+
+
+def test_an_oversized_record_still_yields_a_parseable_line():
+    import json
+
+    import bench
+
+    big = {"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0,
+           "config": {"workload": "w" * 5000}, "cpu_baseline": {"value": 1.0, "cores": 1, "kind": "port", "sample": "s" * 9000}}
+    for i in range(400):
+        big[f"leg{i}"] = {"ms_per_step": 0.1 * i, "roofline": {"frac": 0.5}}
+    s = bench.compact_line(big)
+    assert len(s) <= bench.LINE_LIMIT and json.loads(s)["value"] == 1.0
