@@ -1444,6 +1444,8 @@ def compact_line(out):
     if legs:
         line["legs"] = legs
         line["legs_columns"] = ["ms_per_step", "hbm_frac", "binding_frac"]
+    if isinstance(out.get("sharded"), dict):
+        line["sharded"] = {k: out["sharded"].get(k) for k in ("transport", "p2p_timed_out") if k in out["sharded"]}
     for k in ("strong_scaling_ceiling", "weak_scaling_ceiling"):
         if k in out:
             line[k] = out[k]

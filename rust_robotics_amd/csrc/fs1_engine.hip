@@ -1276,7 +1276,6 @@ rr_status rr_fs1_shard_update_p2p(rr_fs1* h, const double u[2], const double* z,
   bool dup;
   if ((s = validate_z(h, z, n_z, &dup)) != RR_OK) return s;
   const uint64_t seq = ++h->p2p.seq;
-  uint64_t* gathered = h->p2p.gathered();
   uint64_t* local3 = h->p2p.local3();
   // local part, exactly as rr_fs1_update_async: predict + per-observation EKF, reading the previous
   // resample's survivors through idx (kInPlace = stored by a peer) unless a landmark repeats
@@ -1293,7 +1292,7 @@ rr_status rr_fs1_shard_update_p2p(rr_fs1* h, const double u[2], const double* z,
   PlanArgs pa = plan_args(h, 0, NAN, /*lazy=*/true);
   // exchange 1: global maximum -> Ctl.wmax
   hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PWmax, seq,
-                     (const uint64_t*)&h->ctl->wmax_bits, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+                     (const uint64_t*)&h->ctl->wmax_bits, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_QUANTIZE_REDUCE);
     hipLaunchKernelGGL(rr::k_quantize_reduce, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->pw, h->ctl,
@@ -1303,7 +1302,7 @@ rr_status rr_fs1_shard_update_p2p(rr_fs1* h, const double u[2], const double* z,
   {
     rr::ScopedTimer t(h->prof, h->stream, RR_FK_SCAN_TILES);
     hipLaunchKernelGGL(rr::k_scan_exchange, dim3(1), dim3(kScanThreads), 0, h->stream, h->p2p.peers, seq, h->tile_total,
-                       (const uint64_t*)h->tile_q2, h->n_tiles, gathered, h->ctl, pa, h->p2p.err);
+                       (const uint64_t*)h->tile_q2, h->n_tiles, h->ctl, pa, h->p2p.err);
   }
   h->wmax_live = false;
   h->wmax_bits_clean = false;  // a peer wait that gave up skips finalize_plan: do not rely on the zeroed accumulator here
@@ -1330,7 +1329,7 @@ rr_status rr_fs1_shard_update_p2p(rr_fs1* h, const double u[2], const double* z,
   }
   // exchange 3: everybody has finished writing into everybody's slab
   hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PDone, seq,
-                     (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+                     (const uint64_t*)local3, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
   RR_HIP_TRY(hipGetLastError());
   h->maybe_pending = true;  // the next update reads through idx (or an accessor materialises)
   h->rstep += 1;

@@ -55,13 +55,20 @@ __device__ inline P2PSlot* p2p_slot(P2PMailbox* m, int kind, int idx) {
 
 // One exchange round, executed block-uniformly by a workgroup of >= 64 threads (thread g < n_ranks
 // talks to peer g).  payload (valid in every thread g < n_ranks): kind WMAX -> {bits of the local
-// max weight}, SUMS -> {T, q2_hi, q2_lo}, DONE -> nothing.  gathered[g*3..] receives every rank's
-// payload.  Post-processing by thread 0: WMAX -> *wmax_out = global max; SUMS -> finalize_plan with
+// max weight}, SUMS -> {T, q2_hi, q2_lo}, DONE -> nothing.  Every rank's payload is collected in LDS
+// (gathered[g*3..]).  Post-processing by thread 0: WMAX -> *wmax_out = global max; SUMS -> finalize_plan with
 // the global totals (what k_shard_plan does in the RCCL path).
+// (Until round 5 the payloads were collected in a scratch array in DEVICE memory, with ordinary stores and loads.  Inside
+// k_shard_plan_mark two DIFFERENT workgroups run an exchange in one launch -- workgroup 0 the maxima, the last arrival the sums --
+// normally on two XCDs, each with an L2 of its own: two dirty copies of the same words.  When a kernel boundary of ANOTHER stream
+// wrote both L2s back and invalidated them between the last arrival's store and its own load, the load came back with workgroup
+// 0's maximum instead of the sum just stored -- T = the bit pattern of w_max, a wrong resample, ~1 in 150 runs of a 5 000-particle
+// shard stepping beside another filter: tools/soak_shard_estimate.py, profiles/r05_shard_race.md.  Nothing that only one
+// workgroup needs has any business in device memory.)
 __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t seq, uint64_t v0, uint64_t v1, uint64_t v2,
-                                    uint64_t* __restrict__ gathered, Ctl* __restrict__ ctl, double* __restrict__ wmax_out,
-                                    const PlanArgs& pa, int* __restrict__ err) {
+                                    Ctl* __restrict__ ctl, double* __restrict__ wmax_out, const PlanArgs& pa, int* __restrict__ err) {
   __shared__ int s_bad;
+  __shared__ uint64_t gathered[3 * kMaxP2P];
   const int g = threadIdx.x;
   // once a wait has given up, every later exchange of this filter gives up at once (the host
   // reads the flag with rr_pf_p2p_status); only the first one costs the timeout
@@ -143,12 +150,11 @@ __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t se
 
 // stand-alone exchange (one workgroup of 64): payload from device memory written by the previous kernel
 static __global__ void k_p2p_exchange(P2PPeers peers, int kind, uint64_t seq, const uint64_t* __restrict__ payload,
-                                      uint64_t* __restrict__ gathered, Ctl* __restrict__ ctl,
-                                      double* __restrict__ wmax_out, PlanArgs pa, int* __restrict__ err) {
+                                      Ctl* __restrict__ ctl, double* __restrict__ wmax_out, PlanArgs pa, int* __restrict__ err) {
   uint64_t v0 = 0, v1 = 0, v2 = 0;
   if (kind == kP2PWmax) v0 = payload[0];
   if (kind == kP2PSums) { v0 = payload[0]; v1 = payload[1]; v2 = payload[2]; }
-  p2p_exchange(peers, kind, seq, v0, v1, v2, gathered, ctl, wmax_out, pa, err);
+  p2p_exchange(peers, kind, seq, v0, v1, v2, ctl, wmax_out, pa, err);
 }
 
 // k_scan_tiles + the SUMS exchange in one single-workgroup launch: exclusive scan of the tile
@@ -156,8 +162,7 @@ static __global__ void k_p2p_exchange(P2PPeers peers, int kind, uint64_t seq, co
 static __global__ __launch_bounds__(kScanThreads) void k_scan_exchange(P2PPeers peers, uint64_t seq,
                                                                       uint64_t* __restrict__ tile_total,
                                                                       const uint64_t* __restrict__ tile_q2,
-                                                                      uint64_t n_tiles, uint64_t* __restrict__ gathered,
-                                                                      Ctl* __restrict__ ctl, PlanArgs pa,
+                                                                      uint64_t n_tiles, Ctl* __restrict__ ctl, PlanArgs pa,
                                                                       int* __restrict__ err) {
   __shared__ uint64_t s_pay[3];
   uint64_t total = 0;
@@ -170,7 +175,7 @@ static __global__ __launch_bounds__(kScanThreads) void k_scan_exchange(P2PPeers 
     s_pay[2] = qq.lo;
   }
   __syncthreads();
-  p2p_exchange(peers, kP2PSums, seq, s_pay[0], s_pay[1], s_pay[2], gathered, ctl, &ctl->wmax, pa, err);
+  p2p_exchange(peers, kP2PSums, seq, s_pay[0], s_pay[1], s_pay[2], ctl, &ctl->wmax, pa, err);
 }
 
 // Inbox traffic goes around every cache: system-scope (sc0 sc1) stores on the delivering side, system-scope loads on the
@@ -299,8 +304,11 @@ __device__ inline bool wait_flag(const uint64_t* flag, uint64_t epoch, uint64_t 
 static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
     P2PPeers peers, uint64_t seq, const double* __restrict__ w, Ctl* __restrict__ ctl, ImageArgs a, uint64_t* __restrict__ rec,
     unsigned int* __restrict__ ticket, uint64_t epoch, int settle, uint64_t n_tiles, PlanArgs pa,
-    unsigned int* __restrict__ markers, unsigned int* __restrict__ carry, uint64_t* __restrict__ gathered,
-    int* __restrict__ err, uint64_t slot_pad) {
+    unsigned int* __restrict__ markers, unsigned int* __restrict__ carry, int* __restrict__ err, uint64_t slot_pad
+#if defined(RR_DEBUG_TRACE)
+    , uint64_t* trace
+#endif
+    ) {
   constexpr int W = kTileBlock / kWave;
   __shared__ uint64_t s4[4 * W];
   __shared__ uint64_t s_w[W];
@@ -316,11 +324,19 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
   // ---- 0: the global maximum
   if (blockIdx.x == 0) {
     const uint64_t local_bits = ctl->wmax_bits;
-    p2p_exchange(peers, kP2PWmax, seq, local_bits, 0, 0, gathered, ctl, &s_wmax, pa, err);  // thread 0 leaves the maximum in s_wmax
+    p2p_exchange(peers, kP2PWmax, seq, local_bits, 0, 0, ctl, &s_wmax, pa, err);  // thread 0 leaves the maximum in s_wmax
     if (tid == 0) {
       st_dev(&head0[0], rr_d2u(s_wmax));
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       st_dev(&head0[1], epoch);
+#if defined(RR_DEBUG_TRACE)
+      if (trace) {
+        trace[10] = local_bits;
+        trace[11] = rr_d2u(s_wmax);
+        trace[12] = seq;
+        trace[13] = epoch;
+      }
+#endif
     }
   }
   if (tid == 0) {
@@ -416,8 +432,27 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
       ctl->total_local = tt;
     }
     __syncthreads();
-    p2p_exchange(peers, kP2PSums, seq, s_pay[0], s_pay[1], s_pay[2], gathered, ctl, &ctl->wmax, pa, err);
+    p2p_exchange(peers, kP2PSums, seq, s_pay[0], s_pay[1], s_pay[2], ctl, &ctl->wmax, pa, err);
     if (tid == 0) {  // finalize_plan has run in this thread: Ctl holds base, the global totals, the gate decision
+#if defined(RR_DEBUG_TRACE)
+      if (trace) {
+        trace[14] = s_pay[0];
+        trace[15] = ctl->total;
+        trace[16] = (uint64_t)ctl->fired;
+        trace[17] = (uint64_t)ctl->pending;
+        trace[18] = (uint64_t)ctl->cur;
+        trace[19] = ctl->base;
+        trace[20] = ctl->q2_lo;
+        trace[21] = ctl->served_first;
+        trace[22] = ctl->served_count;
+        trace[23] = (uint64_t)(unsigned int)ctl->shift;
+        trace[24] = (uint64_t)blockIdx.x;
+        trace[25] = rr_d2u(wmax);
+        trace[26] = rr_d2u(ctl->rho);
+        trace[27] = (uint64_t)ctl->image_mode;
+        trace[28] = wall_clock64();
+      }
+#endif
       st_dev(&head1[0], ctl->base);
       st_dev(&head1[1], ctl->total);
       st_dev(&head1[2], ctl->q2_hi);
@@ -440,6 +475,10 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
   __syncthreads();
   const uint64_t pre = s4[0], base = s4[1], total = s4[2];
   const bool fired = s4[3] != 0;
+#if defined(RR_DEBUG_TRACE)
+  if (trace && tid == 0 && blockIdx.x < 3) trace[32 + 4 * blockIdx.x] = pre, trace[33 + 4 * blockIdx.x] = base, trace[34 + 4 * blockIdx.x] = total,
+                                           trace[35 + 4 * blockIdx.x] = (uint64_t)fired | ((uint64_t)(unsigned int)shift << 8) | ((uint64_t)mode << 40);
+#endif
   if (fired) {
     // ---- B: k_mark
     double rho = pa.rho_override;
@@ -465,11 +504,10 @@ struct P2PState {
   void* opened[3 * kMaxP2P] = {};  // IPC mappings to close
   int n_opened = 0;
   uint64_t seq = 0;
-  uint64_t* scratch = nullptr;  // [kMaxP2P][3] gathered records + [4] local payload
+  uint64_t* scratch = nullptr;  // [4] local payload of the stand-alone exchanges (behind 3 * kMaxP2P words no longer used)
   int* err = nullptr;           // device: set when a wait timed out
   int* err_host = nullptr;
 
-  uint64_t* gathered() const { return scratch; }
   uint64_t* local3() const { return scratch + 3 * kMaxP2P; }
 
   void teardown() {

@@ -122,7 +122,14 @@ struct StepParams {
 // host side
 // =============================================================================================
 
+#if defined(RR_DEBUG_TRACE)
+constexpr int kDbgWords = 48;
+#endif
 struct rr_pf {
+#if defined(RR_DEBUG_TRACE)
+  uint64_t* dbg_trace = nullptr;  // [dbg_cap][kDbgWords] (instrumented build)
+  uint32_t dbg_cap = 0;
+#endif
   rr_pf_config cfg;
   rr_pf_options opt;
   uint64_t n = 0, n_global = 0;
@@ -1735,6 +1742,9 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
     WindowArgs wa_est{};  // the deferred estimate of the step before: summed by this launch as it gathers
     wa_est.est_partials = h->est_deferred ? h->est_slot_partials : nullptr;
     h->est_deferred = false;
+#if defined(RR_DEBUG_TRACE)
+    wa_est.trace = h->dbg_trace ? h->dbg_trace + (size_t)(h->step % h->dbg_cap) * kDbgWords : nullptr;
+#endif
     if (multinomial && h->mn_deferred) {  // ... are still to be drawn: this launch does it for its own slots
       WindowArgs wa = wa_est;
       wa.cdf = h->cdf;
@@ -1761,6 +1771,13 @@ static rr_status step_async_impl(rr_pf* h, const double control[2], const double
   h->step += 1;
   h->maybe_pending = false;  // consumed (k_quantize_reduce settles Ctl.cur)
   h->pending_kind = kSrcMarkers;
+#if defined(RR_DEBUG_TRACE)
+  if (h->dbg_trace) {  // the unsharded filter of the hunt: Ctl as the plan leaves it (first 112 bytes: the ints, the integer sums, wmax .. rho)
+    const rr_status rs = launch_resample(h, 0, h->opt.resample_scheme, NAN, nullptr, /*lazy=*/true, /*settle=*/1, want_estimate);
+    RR_HIP_TRY(hipMemcpyAsync(h->dbg_trace + (size_t)((h->step - 1) % h->dbg_cap) * kDbgWords + 14, h->ctl, 112, hipMemcpyDeviceToDevice, h->stream));
+    return rs;
+  }
+#endif
   return launch_resample(h, 0, h->opt.resample_scheme, NAN, nullptr, /*lazy=*/true, /*settle=*/1, want_estimate);
 }
 
@@ -2498,8 +2515,11 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   // rr_pf_shard_want_estimate: this launch adds up the fields of the sources of its own slots (the step before's resample)
   wa.est_partials = h->est_deferred ? h->est_slot_partials : nullptr;
   h->est_deferred = false;
+#if defined(RR_DEBUG_TRACE)
+  uint64_t* const dbg = h->dbg_trace ? h->dbg_trace + (size_t)(h->step % h->dbg_cap) * kDbgWords : nullptr;
+  wa.trace = dbg;
+#endif
   const uint64_t seq = ++h->p2p.seq;
-  uint64_t* gathered = h->p2p.gathered();
   // A: propagate + weight through the window
   const uint64_t n_rtiles = (h->n + rr::kResolveSlots - 1) / rr::kResolveSlots;
   const unsigned grid = (unsigned)n_rtiles;  // one tile per workgroup
@@ -2534,18 +2554,22 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
     Timed t(h, RR_K_CDF);
     hipLaunchKernelGGL(rr::k_shard_plan_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->p2p.peers, seq,
                        (const double*)h->w, h->ctl, image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, /*settle=*/1,
-                       h->n_tiles, pa, h->markers, h->carry, gathered, h->p2p.err, h->slot_pad);
+                       h->n_tiles, pa, h->markers, h->carry, h->p2p.err, h->slot_pad
+#if defined(RR_DEBUG_TRACE)
+                       , dbg
+#endif
+                       );
   } else {
     // exchange 1: global maximum -> Ctl.wmax
     hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PWmax, seq,
-                       (const uint64_t*)&h->ctl->wmax_bits, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+                       (const uint64_t*)&h->ctl->wmax_bits, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
     // B: integer image under the global maximum (settles the resample K1 consumed)
     launch_quantize(h, (const double*)&h->ctl->wmax, /*settle=*/1);
     // tile scan + exchange 2: every rank's sums -> gate, base, plan in Ctl
     {
       Timed t(h, RR_K_SCAN_TILES);
       hipLaunchKernelGGL(rr::k_scan_exchange, dim3(1), dim3(kScanThreads), 0, h->stream, h->p2p.peers, seq, h->tile_total,
-                         (const uint64_t*)h->tile_q2, h->n_tiles, gathered, h->ctl, pa, h->p2p.err);
+                         (const uint64_t*)h->tile_q2, h->n_tiles, h->ctl, pa, h->p2p.err);
     }
     // C: mark this shard's sources
     {
@@ -2608,6 +2632,42 @@ rr_status rr_pf_shard_last_estimate_sums(rr_pf* h, double out_sums[4], double* o
   return RR_OK;
 }
 
+#if defined(RR_DEBUG_TRACE)
+// instrumented build only (make -C csrc trace): what the step kernels saw, kDbgWords words per step in a ring of cap_steps
+rr_status rr_pf_debug_trace(rr_pf* h, uint32_t cap_steps) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  RR_HIP_TRY(hipMalloc(&h->dbg_trace, (size_t)cap_steps * kDbgWords * sizeof(uint64_t)));
+  RR_HIP_TRY(hipMemset(h->dbg_trace, 0, (size_t)cap_steps * kDbgWords * sizeof(uint64_t)));
+  h->dbg_cap = cap_steps;
+  return RR_OK;
+}
+rr_status rr_pf_debug_trace_read(rr_pf* h, uint64_t* out, uint64_t cap_words) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!h->dbg_trace) return fail(RR_INVALID_PARAMETER, "no trace");
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  RR_HIP_TRY(hipMemcpy(out, h->dbg_trace, (size_t)std::min<uint64_t>(cap_words, (uint64_t)h->dbg_cap * kDbgWords) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return RR_OK;
+}
+#endif
+
+// Diagnostics (not part of include/rr_pf.h; tools/soak_shard_estimate.py): the per-wave sums of the deferred estimate as they
+// stand in device memory once the stream has drained -- a second, independent read of what rr_pf_last_step_estimate /
+// rr_pf_shard_last_estimate_sums add up.
+rr_status rr_pf_debug_est_slot_partials(rr_pf* h, double* out, uint64_t cap_doubles, uint64_t* n_doubles) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!out || !n_doubles) return fail(RR_INVALID_PARAMETER, "null output");
+  if (!h->est_slot_partials) return fail(RR_INVALID_PARAMETER, "no deferred estimate has been asked for");
+  const uint64_t n = (uint64_t)grid_for(h->n, rr::kResolveSlots) * kEstSlotWords;
+  if (n > cap_doubles) return fail(RR_INVALID_PARAMETER, "output too small");
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  RR_HIP_TRY(hipMemcpy(out, h->est_slot_partials, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  *n_doubles = n;
+  return RR_OK;
+}
+
 // The same step with every phase as its own launch (three exchange kernels, eager gather): kept as
 // the plain statement of the protocol and for A/B measurement.
 rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
@@ -2615,7 +2675,6 @@ rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const 
   if (s != RR_OK) return s;
   if (!h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_p2p_connect first");
   const uint64_t seq = ++h->p2p.seq;
-  uint64_t* gathered = h->p2p.gathered();
   uint64_t* local3 = h->p2p.local3();
   // A: propagate + weight; the local maximum stays in Ctl.wmax_bits
   if ((s = materialise(h)) != RR_OK) return s;
@@ -2630,7 +2689,7 @@ rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const 
   PlanArgs pa = plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN);
   // exchange 1: global maximum -> Ctl.wmax (k_quantize_reduce reads it from there)
   hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PWmax, seq,
-                     (const uint64_t*)&h->ctl->wmax_bits, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+                     (const uint64_t*)&h->ctl->wmax_bits, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
   // B: integer image under the global maximum, local sums -> local3
   launch_quantize(h, (const double*)&h->ctl->wmax);
   {
@@ -2640,7 +2699,7 @@ rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const 
   }
   // exchange 2: every rank's sums -> plan (gate, base, systematic plan) in Ctl
   hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PSums, seq,
-                     (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+                     (const uint64_t*)local3, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
   // C: mark this shard's sources
   {
     Timed t(h, RR_K_CDF);
@@ -2660,7 +2719,7 @@ rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const 
   }
   // exchange 3: every rank has finished writing into everybody's slab
   hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PDone, seq,
-                     (const uint64_t*)local3, gathered, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+                     (const uint64_t*)local3, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
   if (h->shard_est) {  // rr_pf_shard_want_estimate: the resampled set is in place (eager gather): this shard's part of its mean
     h->est_deferred = true;
     launch_est_slots(h);

@@ -170,8 +170,7 @@ def test_rccl_window_step_leaves_the_shards_part_of_the_mean(world, n_local, mon
     while t < 10:
         obs = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng)
         sh.want_estimate(True)
-        sh.step([1.0, 0.1], obs)
-        sh.synchronize()  # (the unsharded reference steps next, in its own stream: one after the other -- see tests/test_gpu_p2p.py)
+        sh.step([1.0, 0.1], obs)  # (no host wait: the unsharded reference steps next, in its own stream, beside the shards)
         ref.step_async_estimate([1.0, 0.1], obs)
         want = np.array(ref.last_step_estimate())
         t += 1
@@ -179,7 +178,6 @@ def test_rccl_window_step_leaves_the_shards_part_of_the_mean(world, n_local, mon
             obs2 = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng)
             sh.want_estimate(False)
             sh.step([1.0, 0.1], obs2)
-            sh.synchronize()
             ref.step_async([1.0, 0.1], obs2)
             t += 1
             check(sh.estimate(), want, f"step {t - 1}, read a step later")
