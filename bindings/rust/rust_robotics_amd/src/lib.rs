@@ -14,6 +14,7 @@
 use nalgebra::{DMatrix, Matrix4, Vector2, Vector4};
 use rust_robotics_amd_sys as sys;
 use rust_robotics_core::{ControlInput, Obstacles, Point2D, RoboticsError, RoboticsResult, State2D, StateEstimator};
+use std::cell::OnceCell;
 use std::ffi::CStr;
 
 /// Particle, particle_filter.rs:25-32 (same fields, same order: `rr_pf_get_particles` fills a slice of these directly)
@@ -78,8 +79,11 @@ impl ParticleFilterConfig {
 pub struct ParticleFilterLocalizer {
     h: *mut sys::rr_pf,
     state_estimate: PFState,
-    covariance: Matrix4<f64>,
-    covariance_dyn: DMatrix<f64>,
+    /// The covariance of the current particle set, computed on the device the first time somebody asks after a change
+    /// (`calc_covariance`, `StateEstimator::get_covariance`, both through `&self`) and dropped by everything that moves or
+    /// reweights the particles.  The reference recomputes it inside every step (particle_filter.rs:299,332,343); a caller
+    /// ported from it therefore never reads the covariance of an earlier step, and a caller that never asks never pays.
+    covariance: OnceCell<(Matrix4<f64>, DMatrix<f64>)>,
     particles: Vec<Particle>,   // host mirror behind get_particles (filled on demand)
     landmarks: Vec<Point2D>,    // set_landmarks* only stores them, as the reference does (particle_filter.rs:216-220, Q19)
 }
@@ -108,7 +112,7 @@ impl ParticleFilterLocalizer {
     }
 
     fn from_handle(h: *mut sys::rr_pf) -> RoboticsResult<Self> {
-        let mut s = Self { h, state_estimate: PFState::zeros(), covariance: Matrix4::zeros(), covariance_dyn: DMatrix::zeros(4, 4),
+        let mut s = Self { h, state_estimate: PFState::zeros(), covariance: OnceCell::new(),
                            particles: Vec::new(), landmarks: Vec::new() };
         s.refresh_cache()?;
         Ok(s)
@@ -184,6 +188,7 @@ impl ParticleFilterLocalizer {
         let mut out = [0.0f64; 4];
         check(unsafe { sys::rr_pf_step(self.h, u.as_ptr(), flat.as_ptr(), observations.len(), out.as_mut_ptr()) })?;
         self.state_estimate = PFState::from_column_slice(&out);
+        self.covariance.take();  // stale from here on: recomputed at the next calc_covariance / get_covariance
         Ok(State2D::new(out[0], out[1], out[2], out[3]))
     }
 
@@ -223,20 +228,25 @@ impl ParticleFilterLocalizer {
         let flat = flatten(observations);
         let mut out = [0.0f64; 4];
         check(unsafe { sys::rr_pf_step(self.h, control.as_ptr(), flat.as_ptr(), observations.len(), out.as_mut_ptr()) })?;
-        self.state_estimate = PFState::from_column_slice(&out);  // (the covariance cache is refreshed by refresh_covariance / the trait's get_covariance path)
+        self.state_estimate = PFState::from_column_slice(&out);
+        self.covariance.take();  // stale from here on: recomputed at the next calc_covariance / get_covariance
         Ok(self.state_estimate)
     }
 
-    /// Bring the covariance cache up to date (calc_covariance / StateEstimator::get_covariance read it through `&self`): the
-    /// reference recomputes it inside every step (particle_filter.rs:299,332,343); here it is two small kernels on request.
+    /// Compute the covariance now instead of at the first `calc_covariance` / `get_covariance` (two small kernels and a
+    /// 128-byte copy); an error of the device surfaces here as a `RoboticsResult` instead of a panic there.
     pub fn refresh_covariance(&mut self) -> RoboticsResult<()> {
-        self.refresh_cache()
+        self.covariance.take();
+        let c = self.read_covariance()?;
+        let _ = self.covariance.set(c);
+        Ok(())
     }
 
     /// Engine extension: enqueue one step without waiting for it; the mean `try_step` would return (:496) is
     /// produced on the device: inside the step's own plan kernel (systematic scheme) or by the kernel that gathers the drawn sources (multinomial).
     pub fn try_step_async(&mut self, control: &PFControl, observations: &PFMeasurement) -> RoboticsResult<()> {
         let flat = flatten(observations);
+        self.covariance.take();
         check(unsafe { sys::rr_pf_step_async_estimate(self.h, control.as_ptr(), flat.as_ptr(), observations.len()) })
     }
 
@@ -274,7 +284,7 @@ impl ParticleFilterLocalizer {
 
     /// calc_covariance, :363-365
     pub fn calc_covariance(&self) -> Matrix4<f64> {
-        self.covariance
+        self.covariance_pair().0
     }
 
     pub fn particle_count(&self) -> usize {
@@ -286,15 +296,24 @@ impl ParticleFilterLocalizer {
         check(unsafe { sys::rr_pf_set_range_noise(self.h, range_noise) })
     }
 
+    /// the mean of the current set now (one small kernel); the covariance is left for whoever asks (covariance_pair)
     fn refresh_cache(&mut self) -> RoboticsResult<()> {
         let mut e = [0.0f64; 4];
-        let mut c = [0.0f64; 16];
         check(unsafe { sys::rr_pf_estimate(self.h, e.as_mut_ptr()) })?;
-        check(unsafe { sys::rr_pf_covariance(self.h, c.as_mut_ptr()) })?;
         self.state_estimate = PFState::from_column_slice(&e);
-        self.covariance = Matrix4::from_row_slice(&c);
-        self.covariance_dyn = DMatrix::from_row_slice(4, 4, &c);
+        self.covariance.take();
         Ok(())
+    }
+
+    fn read_covariance(&self) -> RoboticsResult<(Matrix4<f64>, DMatrix<f64>)> {
+        let mut c = [0.0f64; 16];
+        check(unsafe { sys::rr_pf_covariance(self.h, c.as_mut_ptr()) })?;
+        Ok((Matrix4::from_row_slice(&c), DMatrix::from_row_slice(4, 4, &c)))
+    }
+
+    /// the cached covariance, computed on first use after a change (`OnceCell::get_or_init` hands out `&` through `&self`)
+    fn covariance_pair(&self) -> &(Matrix4<f64>, DMatrix<f64>) {
+        self.covariance.get_or_init(|| self.read_covariance().expect("particle filter moments failed on the device"))
     }
 }
 
@@ -315,7 +334,7 @@ impl StateEstimator for ParticleFilterLocalizer {
         &self.state_estimate
     }
     fn get_covariance(&self) -> Option<&DMatrix<f64>> {
-        Some(&self.covariance_dyn)
+        Some(&self.covariance_pair().1)
     }
 }
 
