@@ -425,7 +425,7 @@ def require_devices(ctx):
 
 
 # ------------------------------------------------------------------------------------------------------
-def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True):
+def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True, device_warmup=None, label="configs[2]"):
     """BASELINE.json configs[2]: FastSLAM 1.0, 100 000 particles x 200 landmarks, every landmark observed
     every step, EKF branch (first_obs_cov = 0.5 initialises the maps on the first, untimed, step),
     N_eff threshold N/1.5 so that resampling triggers data-dependently."""
@@ -444,7 +444,7 @@ def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True):
         prm.first_obs_cov = 0.5
         prm.nth = n / 1.5 * float(os.environ.get("RR_BENCH_NTH_SCALE", "1"))  # development knob: 0 = never resample, 10 = every step
         f = fs.FastSlam1(n, L, params=prm, seed=2, obs_chunks=int(os.environ.get("RR_BENCH_OBS_CHUNKS", "0")))  # 0 = the engine's own choice
-    D = DEVICE_WARMUP_FS
+    D = DEVICE_WARMUP_FS if device_warmup is None else device_warmup
     zs = [np.array(fs.get_observations(H.true_pose(t + 1, v=0.5), [tuple(p) for p in lms], seed=2, step=t)).reshape(-1, 3)
           for t in range(D + 2 * K + W)]
     u = [0.5, 0.1]
@@ -489,7 +489,7 @@ def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True):
         "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": (f"FastSLAM 2.0 (the configs[2] shape with the proposal of fastslam2.rs): " if v2 else
-                                "FastSLAM 1.0 (BASELINE.json configs[2]): ") +
+                                f"FastSLAM 1.0 (BASELINE.json {label}): ") +
                                f"{n} particles x {L} landmarks, all observed, 2x2 EKF branch, N_eff-gated systematic resample",
                    "particles_per_gpu": n, "landmarks": L},
         "roofline": {"bound": "hbm", "kernel": "k_fs1_observe", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
@@ -509,7 +509,7 @@ def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True):
         "kernel_launches": {k: v[0] for k, v in prof.items() if v[0]},
         "ms_per_step_instrumented": dt_i / K * 1e3,
         "obs_chunks": chunks,
-        "device_warmup_steps": DEVICE_WARMUP_FS,
+        "device_warmup_steps": D,
         "best_particle": {"index": i, "weight": w, "pose": [float(a) for a in pose]},
     }
     if with_cpu:
@@ -796,6 +796,21 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
         # gathers the sources -- the next step's k_step_lazy (the last step's by rr_pf_last_step_estimate's gather).
         with_est = n <= 8_388_608  # (the in-step estimate's limit, rr_pf.h)
         step_fn = pf.step_async_estimate if with_est else pf.step_async
+        if D and getattr(args, "cold_first", False):
+            # COLD: the same W + K steps with nothing but the command line's warm-up before them -- the first work this process
+            # gives the device (a filter of its own, so that the hot measurement below starts from the same state as ever)
+            pc = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=ctx.local_rank,
+                                                            resample_scheme=scheme, likelihood_mode=lik)
+            fn_c = pc.step_async_estimate if with_est else pc.step_async
+            for t in range(W):
+                fn_c(u, obs_list[t])
+            pc.synchronize()
+            t0 = time.perf_counter()
+            for t in range(W, W + K):
+                fn_c(u, obs_list[t])
+            pc.synchronize()
+            extra["ms_per_step_cold"] = (time.perf_counter() - t0) / K * 1e3
+            del pc
         for t in range(D):  # device warm-up (see DEVICE_WARMUP_MCL), then time moves on
             step_fn(u, obs_list[t])
             # in blocks with a synchronisation in between, the shape of the timed region: a thousand steps enqueued in one go leave
@@ -1282,7 +1297,9 @@ def main():
         return
 
     log(f"headline leg: MCL {n} particles/GPU x {L} landmarks, world {ctx.world}")
+    args.cold_first = True  # the headline leg also reports the cold number (device_warmup_steps: 0) beside the hot one
     out = leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=not args.no_breakdown)
+    args.cold_first = False
     if ctx.rank == 0:
         _OUT["partial"] = out
     log("headline leg done")
@@ -1338,6 +1355,16 @@ def main():
                                                                "headline_step", "plain_async_step", "cpu_baseline", "device_warmup_steps") if k in leg}
             except Exception as e:  # noqa: BLE001
                 out["mcl_config5_full"] = {"error": f"{type(e).__name__}: {e}"}
+            # configs[3] at FULL size on this one GPU (1e6 x 200: 19.3 GB of maps in two sets): the denominator of the FastSLAM
+            # strong-scaling arithmetic (">= 6x at 8 GPUs")
+            try:
+                log("extra leg fastslam_config4_full (configs[3] unsharded)")
+                leg = leg_fastslam(args, 1_000_000, 200, 10, 2, with_cpu=False, breakdown=False, device_warmup=10,
+                                   label="configs[3], all 1e6 particles on ONE GPU")
+                out["fastslam_config4_full"] = {k: leg[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernel_ms_avg",
+                                                                    "obs_chunks", "device_warmup_steps") if k in leg}
+            except Exception as e:  # noqa: BLE001
+                out["fastslam_config4_full"] = {"error": f"{type(e).__name__}: {e}"}
             # the sharded step at world size 1, both transports: what a rank of the 8-GPU run pays before any cross-device latency
             # (weak-scaling ceiling = 8 x unsharded step / this)
             if not args.no_sharded_world1:
@@ -1345,6 +1372,23 @@ def main():
                 out["sharded_world1_config5_shape"] = leg_sharded_world1(args, 2_000_000, 64, K, W, transports=(("p2p", "p2p-only"),),
                                                                          what="BASELINE.json configs[4] per-GPU shape: 2e6 particles x 64 landmarks")
                 out["fastslam_sharded_world1_config4_shape"] = leg_fastslam_sharded_world1(125_000, 200)
+
+                def ms(*path):
+                    d = out
+                    for k in path:
+                        d = d.get(k) if isinstance(d, dict) else None
+                    return d.get("ms_per_step") if isinstance(d, dict) else None
+
+                def ratio(a, b, scale=1.0):
+                    return round(scale * a / b, 3) if a and b else None
+
+                # what 8 GPUs can reach BEFORE any cross-device latency (everything measured on this one GPU, world size 1):
+                # weak: 8 x the unsharded step / the sharded step of the same per-GPU shape; strong: the full problem on one GPU / the
+                # sharded step of its 1/8 shape
+                out["weak_scaling_ceiling"] = {"configs[1] p2p": ratio(out.get("ms_per_step"), ms("sharded_world1", "p2p"), 8.0),
+                                               "configs[1] rccl": ratio(out.get("ms_per_step"), ms("sharded_world1", "rccl"), 8.0)}
+                out["strong_scaling_ceiling"] = {"configs[3] p2p": ratio(ms("fastslam_config4_full"), ms("fastslam_sharded_world1_config4_shape")),
+                                                 "configs[4] p2p": ratio(ms("mcl_config5_full"), ms("sharded_world1_config5_shape", "p2p"))}
         elif ctx.world == 8 or args.all_legs:
             per_gpu = 1_000_000 // 8 if ctx.world == 8 else 125_000
             # the extra legs never take the headline down with them: an exception becomes an "error" entry
