@@ -127,6 +127,10 @@ rr_status rr_fs1_get_counters(rr_fs1* h, uint32_t* step, uint32_t* resample_step
 /* one-launch resample plan of this handle: launches that degraded to the serial plan because the device did not run all
  * of their workgroups at once (rr_pf_plan_stats in rr_pf.h tells the story), and whether the handle still uses it */
 rr_status rr_fs1_plan_stats(rr_fs1* h, uint64_t* giveups, int32_t* one_launch_enabled);
+/* the observation kernel's in-kernel hand-over of the chunks' weight factors (fastslam1.rs:250-256 `weight *=`, chunked): host looks
+ * at the device that found a closing workgroup had given up waiting for a factor -- the weights were then formed by the follow-up
+ * kernel, same bits, no error -- and whether the handle still waits inside the kernel (0 after the first give-up) */
+rr_status rr_fs1_observe_stats(rr_fs1* h, uint64_t* giveups, int32_t* in_kernel_wait_enabled);
 
 /* ---- sharded FastSLAM: contiguous particle blocks over the GPUs of a node, each
  * particle's whole map moves with it.  Peer-to-peer transport only (include/rr_pf.h "peer-to-peer

@@ -250,6 +250,7 @@ def lib() -> C.CDLL:
     proto("rr_fs1_get_fixed_sums", st, [H, C.POINTER(PfFixedSums)])
     proto("rr_fs1_get_counters", st, [H, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32)])
     proto("rr_fs1_plan_stats", st, [H, C.POINTER(u64), C.POINTER(i32)])
+    proto("rr_fs1_observe_stats", st, [H, C.POINTER(u64), C.POINTER(i32)])
     proto("rr_fs1_p2p_export", st, [H, U8])
     proto("rr_fs1_p2p_connect", st, [H, U8, i32, i32])
     proto("rr_fs1_p2p_connect_local", st, [C.POINTER(H), i32])

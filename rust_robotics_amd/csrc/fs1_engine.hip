@@ -84,6 +84,8 @@ struct rr_fs1 {
   uint64_t grid_epoch = 0;
   uint64_t grid_capacity = ~0ull;
   uint64_t plan_giveups = 0;  // launches of the one-launch plan that degraded to the serial plan
+  uint64_t obs_giveups = 0;   // host looks at Ctl that found k_fs1_observe's closing chunk had given up waiting (k_fs1_combine repaired it)
+  bool obs_two_launch = false;  // ... after which the handle forms the weights in k_fs1_combine for good (no wait inside the observe kernel)
   unsigned int* markers = nullptr;  // n + kResolveSlots, zero between resamples (fused single-GPU plan)
   unsigned int* carry = nullptr;    // one per kResolveSlots slots
   unsigned int* ridx = nullptr;  // sharded: sources of the served slots that belong to peers (allocated on connect)
@@ -339,6 +341,16 @@ rr_status launch_motion(rr_fs1* h, const double u[2], const double* z, size_t n_
   return launch_predict<false, LAZY>(h, u, z, n_z);
 }
 
+// how long k_fs1_observe's closing chunk waits for a factor before it leaves the weight to k_fs1_combine, in ticks of the
+// 100 MHz wall clock: RR_FS1_FACTOR_WAIT_US, default 2 s (0: never wait -- the test hook that exercises the degrade path)
+static uint64_t factor_wait_ticks() {
+  static const uint64_t ticks = [] {
+    const char* e = std::getenv("RR_FS1_FACTOR_WAIT_US");
+    return e ? (uint64_t)(std::max(0.0, std::atof(e)) * 100.0) : kFactorWaitTicksDefault;
+  }();
+  return ticks;
+}
+
 int choose_chunks(const rr_fs1* h, size_t n_z, bool dup) {
   if (dup || n_z <= 1) return 1;
   int want = h->opt.obs_chunks;
@@ -430,9 +442,17 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool 
     const unsigned int* a_idx = h->idx;
     unsigned int a_pblocks = grid.x;
     const dim3 grid_l((unsigned int)((uint64_t)a_pblocks * (uint64_t)chunks));
-    void* args[] = {&a_pl, &a_pw, &a_ctl, &a_n, &a_z, &a_nz, &a_len, &a_chunks, &a_m, &a_partial, &a_idx, &a_pblocks};
+    uint64_t a_wait = h->obs_two_launch ? 0ull : factor_wait_ticks();
+    void* args[] = {&a_pl, &a_pw, &a_ctl, &a_n, &a_z, &a_nz, &a_len, &a_chunks, &a_m, &a_partial, &a_idx, &a_pblocks, &a_wait};
     if (ea && !dup) RR_HIP_TRY(hipExtLaunchKernel(kfn, grid_l, dim3(kBlock), args, lds, h->stream, ea, eb, 0));
     else RR_HIP_TRY(hipLaunchKernel(kfn, grid_l, dim3(kBlock), args, lds, h->stream));
+  }
+  if (chunks > 1) {
+    // the closing chunk's degrade path (fs1_kernels.inc): a no-op launch unless a closing workgroup gave up waiting (or the
+    // handle has left the in-kernel wait after an earlier give-up)
+    rr::ScopedTimer t(h->prof, h->stream, RR_FK_COMBINE);
+    hipLaunchKernelGGL(k_fs1_combine, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pw, h->ctl, h->n, h->partial, chunks,
+                       h->obs_two_launch ? 1 : 0);
   }
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
@@ -561,8 +581,15 @@ rr_status fetch_ctl(rr_fs1* h) {
   RR_HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
   rr::spin_release(h->opt.device, h);
-  if (h->ctl_host->obs_timeout)
-    return fail(RR_RUNTIME_ERROR, "k_fs1_observe: a chunk's weight factor did not arrive within 2 s; the weights of this update are not valid");
+  if (h->ctl_host->obs_timeout) {
+    // closing workgroups of k_fs1_observe gave up waiting for a chunk's factor (workgroups not dispatched in ascending order, or
+    // kept off the device by another process); k_fs1_combine has formed those weights since -- same bits.  This handle forms
+    // its weights there from now on (fs1_kernels.inc)
+    h->obs_giveups += 1;
+    h->obs_two_launch = true;
+    RR_HIP_TRY(hipMemsetAsync(&h->ctl->obs_timeout, 0, sizeof(int), h->stream));
+    h->ctl_host->obs_timeout = 0;
+  }
   if (h->ctl_host->grid_timeout) {
     // launches of the one-launch plan degraded to the serial plan (another process kept workgroups off the device): same
     // results; this handle takes the multi-launch plan from now on (resample_core.hpp, k_quantize_plan_mark)
@@ -1604,6 +1631,15 @@ rr_status rr_fs1_plan_stats(rr_fs1* h, uint64_t* giveups, int32_t* one_launch_en
   if ((s = fetch_ctl(h)) != RR_OK) return s;
   if (giveups) *giveups = h->plan_giveups;
   if (one_launch_enabled) *one_launch_enabled = (h->grid_capacity != 0 && h->grid_capacity != ~0ull) ? 1 : 0;
+  return RR_OK;
+}
+
+rr_status rr_fs1_observe_stats(rr_fs1* h, uint64_t* giveups, int32_t* in_kernel_wait_enabled) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if ((s = fetch_ctl(h)) != RR_OK) return s;
+  if (giveups) *giveups = h->obs_giveups;
+  if (in_kernel_wait_enabled) *in_kernel_wait_enabled = h->obs_two_launch ? 0 : 1;
   return RR_OK;
 }
 

@@ -216,6 +216,14 @@ class FastSlam1:
         _check(self._L.rr_fs1_plan_stats(self._h, C.byref(g), C.byref(e)))
         return g.value, bool(e.value)
 
+    def observe_stats(self) -> Tuple[int, bool]:
+        """(host looks at the device that found a closing workgroup of the observation kernel had given up waiting for a chunk's
+        weight factor -- the follow-up kernel formed those weights, same bits --, whether the handle still waits inside the
+        kernel) -- ``rr_fs1_observe_stats``"""
+        g, e = C.c_uint64(), C.c_int32()
+        _check(self._L.rr_fs1_observe_stats(self._h, C.byref(g), C.byref(e)))
+        return g.value, bool(e.value)
+
     # ---- measurement hooks
     def profile_enable(self, on) -> None:
         """False/0 off; True/1 HIP events around every launch; 2 only k_fs1_observe, timed by the

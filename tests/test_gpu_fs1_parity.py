@@ -284,7 +284,11 @@ def test_trajectory_bit_exact_vs_det(fs, det, chunks, read_every, n_observed):
     """read_every > 1 leaves several updates between accessor calls, so the resample gathers are
     consumed lazily by the next update's own loads; n_observed < L exercises the separate gather of
     the unobserved landmarks' planes."""
-    n, L, T = 2000, 24, 12
+    trajectory_vs_det(fs, det, chunks, read_every, n_observed)
+
+
+def trajectory_vs_det(fs, det, chunks, read_every, n_observed, n=2000):
+    L, T = 24, 12
     lms = scene(L, 41)
     prm = fs.default_params()
     prm.first_obs_cov = 2.0   # reach the EKF branch through updates alone
@@ -318,6 +322,40 @@ def test_trajectory_bit_exact_vs_det(fs, det, chunks, read_every, n_observed):
     pose, w, i = f.best_particle()
     assert i == det.det_fs1_best_particle(n, dp(pw))
     assert np.hypot(*(pose[:2] - H.true_pose(T)[:2])) < 2.0
+    return f
+
+
+def degrade_in_process():
+    """(fresh interpreter, RR_FS1_FACTOR_WAIT_US=0) the closing chunk of k_fs1_observe never waits: a factor that is not there at
+    its first look makes it leave the weight to k_fs1_combine"""
+    from rust_robotics_amd.slam import fastslam1
+
+    gave_up = 0
+    for chunks, read_every, n_observed, n in ((3, 5, 17, 2000), (6, 1, 24, 40_000), (0, 4, 24, 2000)):
+        f = trajectory_vs_det(fastslam1, oracle.det(), chunks, read_every, n_observed, n=n)
+        g, waits = f.observe_stats()
+        assert g == 0 or not waits, "a handle that has given up once forms its weights in the follow-up kernel from then on"
+        gave_up += g
+    assert gave_up >= 1, "no closing workgroup ever found a factor missing: the degrade path did not run"
+    print("OBSERVE_DEGRADE_OK", gave_up)
+
+
+def test_observe_degrades_when_a_chunk_factor_does_not_arrive(fs):
+    """k_fs1_observe's closing chunk waits (bounded) for the other chunks' weight factors, which rests on workgroups being
+    dispatched in ascending order (fs1_kernels.inc).  With the wait set to zero every factor that is late is a miss: the closing
+    workgroup must leave the weight to k_fs1_combine, the results -- poses, maps, weights, gate decisions, resample indices over
+    whole trajectories -- must stay bit-identical to the deterministic specification, no call may fail, and the handle must count
+    the give-up and stop waiting inside the kernel (the reference's left-to-right `weight *=`,
+    fastslam1.rs:250-256, is what the chunk order preserves)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"import sys; sys.path.insert(0, {root!r}); from tests.test_gpu_fs1_parity import degrade_in_process; degrade_in_process()"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, PYTHONPATH=root, RR_FS1_FACTOR_WAIT_US="0"))
+    assert r.returncode == 0 and "OBSERVE_DEGRADE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
 @pytest.mark.parametrize("algorithm", [1, 2])
