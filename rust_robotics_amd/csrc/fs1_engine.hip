@@ -443,7 +443,8 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool 
     unsigned int a_pblocks = grid.x;
     const dim3 grid_l((unsigned int)((uint64_t)a_pblocks * (uint64_t)chunks));
     uint64_t a_wait = h->obs_two_launch ? 0ull : factor_wait_ticks();
-    void* args[] = {&a_pl, &a_pw, &a_ctl, &a_n, &a_z, &a_nz, &a_len, &a_chunks, &a_m, &a_partial, &a_idx, &a_pblocks, &a_wait};
+    int a_latch = h->obs_two_launch ? 0 : 1;
+    void* args[] = {&a_pl, &a_pw, &a_ctl, &a_n, &a_z, &a_nz, &a_len, &a_chunks, &a_m, &a_partial, &a_idx, &a_pblocks, &a_wait, &a_latch};
     if (ea && !dup) RR_HIP_TRY(hipExtLaunchKernel(kfn, grid_l, dim3(kBlock), args, lds, h->stream, ea, eb, 0));
     else RR_HIP_TRY(hipLaunchKernel(kfn, grid_l, dim3(kBlock), args, lds, h->stream));
   }
