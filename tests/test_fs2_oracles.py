@@ -178,3 +178,21 @@ def test_reference_landmark_convergence(ref):
     w = pw[init]
     mx, my = (np.average(e[init, 0], weights=w), np.average(e[init, 1], weights=w)) if w.sum() > 0 else (e[init, 0].mean(), e[init, 1].mean())
     assert math.hypot(mx - 5.0, my - 5.0) < 6.0
+
+
+def test_reference_seeded_tests_replayed_through_the_literal_restatement():
+    """fastslam2.rs:443-456 (StdRng seed 7: 20 particles, 3 landmarks, 5 updates, the truth standing still) and :491-545 (StdRng
+    seed 17: 120 particles, one landmark at (5, 5), 60 updates along a straight line, `lm_err < 6.0`) with the reference's own
+    random stream (oracle/rand_rs.py: rand 0.9 StdRng, rand_distr 0.5.1 StandardNormal / Uniform restated and checked against their
+    published vectors in tests/test_rand_port.py), consumed in the reference's order (tests/fs2_replay.py)."""
+    from tests import fs2_replay as RP
+
+    e = RP.LiteralEngine(20, 3)
+    fired, _ = RP.replay(e, 7, 20, [(10.0, 0.0), (0.0, 10.0), (10.0, 10.0)], np.zeros(3), [1.0, 0.1], 5, truth_moves=False)
+    w, maps = e.state()
+    assert len(w) == 20 and np.all(np.isfinite(w)) and np.all(np.isfinite(maps)) and len(fired) == 5
+    e = RP.LiteralEngine(120, 1)
+    fired, _ = RP.replay(e, 17, 120, [(5.0, 5.0)], np.array([0.0, 0.0, math.pi / 4]), [0.5, 0.0], 60, truth_moves=True)
+    err = RP.landmark_error(e, (5.0, 5.0))
+    assert err < 6.0, f"landmark estimate should converge: err={err}"
+    assert any(fired)

@@ -179,3 +179,30 @@ def test_duplicate_observations_and_parameter_validation(fs2, det):
         fs2.FastSlam2(10, 2, params=bad)
     with pytest.raises(RoboticsError):
         f.update([1.0, 0.1], [(1.0, 0.0, L)])  # landmark id out of range
+
+
+def test_reference_seeded_tests_replayed_on_the_gpu(fs2):
+    """The same two seeded tests (fastslam2.rs:443-456 seed 7, :491-545 seed 17 with `lm_err < 6.0`) on the GPU, through the
+    explicit-noise seams, next to the literal restatement fed the identical stream: the reference's own assertions hold on both,
+    the gate decisions agree step for step, and the two engines end within 1e-6 of each other (weights, landmark means and
+    covariances of every particle) -- the only numeric assertions the reference holds for this path, run with its own seeds."""
+    from tests import fs2_replay as RP
+
+    cases = [(7, 20, [(10.0, 0.0), (0.0, 10.0), (10.0, 10.0)], np.zeros(3), [1.0, 0.1], 5, False),
+             (17, 120, [(5.0, 5.0)], np.array([0.0, 0.0, math.pi / 4]), [0.5, 0.0], 60, True)]
+    for seed, n, lms, x0, u, steps, moves in cases:
+        g, lit = RP.GpuEngine(fs2, n, len(lms)), RP.LiteralEngine(n, len(lms))
+        fg, rg = RP.replay(g, seed, n, lms, x0.copy(), u, steps, moves)
+        fl, rl = RP.replay(lit, seed, n, lms, x0.copy(), u, steps, moves)
+        assert fg == fl, "the N_eff gate decided differently somewhere along the trajectory"
+        assert rg.next_u64() == rl.next_u64(), "the two replays consumed different amounts of the random stream"
+        wg, mg = g.state()
+        wl, ml = lit.state()
+        assert len(wg) == n and np.all(np.isfinite(wg)) and np.all(np.isfinite(mg))
+        np.testing.assert_allclose(wg, wl, **TOL)
+        np.testing.assert_allclose(mg, ml, **TOL)
+        if seed == 17:
+            assert any(fg)
+            for e in (g, lit):
+                err = RP.landmark_error(e, (5.0, 5.0))
+                assert err < 6.0, f"landmark estimate should converge: err={err}"
