@@ -84,7 +84,7 @@ rr_status rr_fs1_best_particle(rr_fs1* h, double out_pose[3], double* out_weight
  * 64 observations per update) launch nothing -- ONE kernel of one
  * workgroup stays on the device, takes each update's control and observations from a pinned command block and answers with
  * the best particle of the updated set in a pinned response block, so the rr_fs1_best_particle that follows an update is
- * free.  It leaves by itself after idle_us microseconds without an update and after max(100 ms, 20 idle_us) in any case; every
+ * free.  It leaves by itself after idle_us microseconds without an update and after max(100 ms, 20 idle_us) in any case (idle_us <= 0.5 s); every
  * other entry point asks it to leave first.  Same bits as the launched update.  0 switches the service off (the default). */
 rr_status rr_fs1_set_resident(rr_fs1* h, double idle_us);
 /* incarnations of the resident kernel launched so far and updates served by them */

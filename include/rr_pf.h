@@ -185,7 +185,7 @@ rr_status rr_pf_step_many(rr_pf* h, const double* controls, const double* obs, s
  * step's control and observations from a pinned command block and leaves the estimate in a pinned response block the
  * host polls.  A synchronous step then costs its arithmetic plus two trips over the host link instead of a launch and a
  * completion wait.  The kernel leaves by itself after idle_us microseconds without a step (the next step starts it again:
- * nothing is lost, that step just pays a launch) and after max(100 ms, 20 idle_us) in any case, so work queued behind it is
+ * nothing is lost, that step just pays a launch) and after max(100 ms, 20 idle_us) in any case (idle_us <= 0.5 s), so work queued behind it is
  * delayed, never blocked; every other entry point of the handle asks it to leave before it touches the particle set.  Same
  * kernel code, same bits as the launched step.  While it runs it holds one workgroup's registers and LDS of one compute unit.
  * idle_us == 0 switches the service off (the default; RR_PF_RESIDENT_US=<us> at create time switches it on). */

@@ -9,6 +9,7 @@
 // PF_RESIDENT_IDLE_US, PF_LOG_INTERVAL_S, PF_TRANSPORT, PF_PIN_TO_GPU_NUMA; PF_LOCALIZER=mcl (+ PF_MIN_PARTICLES, PF_MAX_PARTICLES): the
 // MonteCarloLocalizer with its KLD-adaptive particle count instead of the ParticleFilterLocalizer.
 //   pf_localizer_node --self-test   the reference node's own unit tests (main.rs:303-384) on this node's helpers; no GPU
+#include <csignal>
 #include <sched.h>
 
 #include <cstdio>
@@ -52,6 +53,9 @@ static int self_test();
 int main(int argc, char** argv) {
   using namespace pfnode;
   if (argc > 1 && std::string(argv[1]) == "--self-test") return self_test();
+  // a peer that hangs up must end this node through the transport's "peer is gone" path (a closing log line, the resident kernel
+  // parked), not through SIGPIPE's default action
+  std::signal(SIGPIPE, SIG_IGN);
   try {
     Settings settings = Settings::from_env();
     std::unique_ptr<Transport> io;

@@ -46,6 +46,15 @@ inline std::string topic_from_env(const char* key, const char* fallback) {
   if (a == std::string::npos) return fallback;
   return s;
 }
+// a whole number from the environment: NaN, negative or absurdly large values (a cast of which is undefined) fall back
+inline uint64_t count_from_env(const char* key, uint64_t fallback, uint64_t max = (uint64_t)1 << 40) {
+  const char* v = std::getenv(key);
+  if (!v || !*v) return fallback;
+  char* end = nullptr;
+  const double x = std::strtod(v, &end);
+  if (end == v || !(x >= 0.0) || !(x <= (double)max)) return fallback;
+  return (uint64_t)x;
+}
 inline double number_from_env(const char* key, double fallback) {
   const char* v = std::getenv(key);
   if (!v || !*v) return fallback;
@@ -107,21 +116,21 @@ struct Settings {
     s.topics.output_odom = topic_from_env("PF_OUTPUT_ODOM_TOPIC", kDefaultOutputOdomTopic);
     s.topics.output_pose = topic_from_env("PF_OUTPUT_POSE_TOPIC", kDefaultOutputPoseTopic);
     // ParticleFilterConfig::default() (particle_filter.rs:67-78) unless the environment says otherwise
-    s.filter.n_particles = (uint64_t)number_from_env("PF_PARTICLES", (double)s.filter.n_particles);
+    s.filter.n_particles = count_from_env("PF_PARTICLES", s.filter.n_particles);
     s.filter.resample_threshold = number_from_env("PF_RESAMPLE_THRESHOLD", s.filter.resample_threshold);
     s.filter.range_noise = number_from_env("PF_RANGE_NOISE", s.filter.range_noise);
     s.filter.velocity_noise = number_from_env("PF_VELOCITY_NOISE", s.filter.velocity_noise);
     s.filter.yaw_rate_noise = number_from_env("PF_YAW_RATE_NOISE", s.filter.yaw_rate_noise);
     s.filter.dt = number_from_env("PF_DT", s.filter.dt);
     s.use_mcl = topic_from_env("PF_LOCALIZER", "pf") == "mcl";
-    s.mcl.min_particles = (uint64_t)number_from_env("PF_MIN_PARTICLES", (double)s.mcl.min_particles);
-    s.mcl.max_particles = (uint64_t)number_from_env("PF_MAX_PARTICLES", (double)s.mcl.max_particles);
+    s.mcl.min_particles = count_from_env("PF_MIN_PARTICLES", s.mcl.min_particles);
+    s.mcl.max_particles = count_from_env("PF_MAX_PARTICLES", s.mcl.max_particles);
     s.mcl.range_noise = s.filter.range_noise;
     s.mcl.velocity_noise = s.filter.velocity_noise;
     s.mcl.yaw_rate_noise = s.filter.yaw_rate_noise;
     s.mcl.dt = s.filter.dt;
-    s.seed = (uint64_t)number_from_env("PF_SEED", 0.0);
-    s.device = (int)number_from_env("PF_DEVICE", 0.0);
+    s.seed = count_from_env("PF_SEED", 0, (uint64_t)1 << 53);
+    s.device = (int)count_from_env("PF_DEVICE", 0, 63);
     s.resident_idle_us = number_from_env("PF_RESIDENT_IDLE_US", s.resident_idle_us);
     s.log_interval_s = number_from_env("PF_LOG_INTERVAL_S", kLogIntervalSeconds);
     return s;

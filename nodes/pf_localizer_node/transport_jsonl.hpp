@@ -151,8 +151,11 @@ inline bool decode_input(const std::string& line, const Topics& topics, Input* o
   const std::string topic = str("topic");
   Stamp stamp;
   if (const auto* st = arr("stamp", 2)) {
-    stamp.sec = (int32_t)(*st)[0];
-    stamp.nanosec = (uint32_t)(*st)[1];
+    // (a cast of a NaN, negative or huge double is undefined: range first)
+    const double sec = (*st)[0], nsec = (*st)[1];
+    if (!(sec >= -2147483648.0 && sec <= 2147483647.0) || !(nsec >= 0.0 && nsec < 4294967296.0)) throw std::runtime_error("stamp out of range");
+    stamp.sec = (int32_t)sec;
+    stamp.nanosec = (uint32_t)nsec;
   }
   if (topic == topics.input_ranges) {
     out->kind = Input::kLandmarkRanges;
@@ -273,6 +276,10 @@ class JsonLinesTransport : public Transport {
         buf_.erase(0, nl + 1);
         return true;
       }
+      if (buf_.size() > kMaxLineBytes) {  // a peer that never sends a newline must not grow this process without bound
+        log(LogLevel::kWarn, "input line longer than 1 MiB dropped");
+        buf_.clear();
+      }
       char chunk[4096];
       const ssize_t got = ::read(in_fd_, chunk, sizeof chunk);
       if (got < 0 && errno == EINTR) continue;
@@ -285,6 +292,7 @@ class JsonLinesTransport : public Transport {
       buf_.append(chunk, (size_t)got);
     }
   }
+  static constexpr size_t kMaxLineBytes = 1u << 20;
   static void write_all(int fd, const std::string& s) {
     size_t off = 0;
     while (off < s.size()) {

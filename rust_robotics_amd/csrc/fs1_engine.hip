@@ -932,7 +932,9 @@ static rr_status fs1_resident_launch(rr_fs1* h, uint64_t first_seq, unsigned int
 
 static rr_status fs1_resident_await(rr_fs1* h, uint64_t seq) {
   rr_fs1::Resident& r = h->res;
-  const auto t0 = std::chrono::steady_clock::now();
+  auto t0 = std::chrono::steady_clock::now();
+  const long long patience_ms = 2000 + (long long)(r.life_us / 1000.0);  // (see resident_await, pf_engine.hip)
+  int gave_up = 0;
   for (unsigned spins = 0;; ++spins) {
     uint64_t e[5], flags;
     if (rr::ring_take(&r.ring->rsp[kFs1RspIndex], seq, &e[4]) && rr::ring_take(&r.ring->rsp[rr::kResRspFlags], seq, &flags) &&
@@ -954,11 +956,16 @@ static rr_status fs1_resident_await(rr_fs1* h, uint64_t seq) {
       }
       continue;
     }
-    if ((spins & 1023u) == 1023u && std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > 2000) {
+    if ((spins & 1023u) == 1023u && std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > patience_ms) {
+      // once the stream has drained the incarnation has either answered (next turn of the loop: the update WAS applied and is
+      // reported as such) or left without the command (EXIT marker above: relaunched); an error only after two such rounds
       (void)hipStreamSynchronize(h->stream);
-      r.live = false;
-      r.pending = false;
-      return fail(RR_RUNTIME_ERROR, "the resident FastSLAM kernel did not answer");
+      if (++gave_up > 2) {
+        r.live = false;
+        r.pending = false;
+        return fail(RR_RUNTIME_ERROR, "the resident FastSLAM kernel did not answer");
+      }
+      t0 = std::chrono::steady_clock::now();
     }
   }
 }
@@ -1017,7 +1024,7 @@ rr_status fs1_resident_park(rr_fs1* h) {
 rr_status rr_fs1_set_resident(rr_fs1* h, double idle_us) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
-  if (!(idle_us >= 0.0) || !(idle_us <= 1e7)) return fail(RR_INVALID_PARAMETER, "resident idle time must lie in [0, 1e7] microseconds");
+  if (!(idle_us >= 0.0) || !(idle_us <= 5e5)) return fail(RR_INVALID_PARAMETER, "resident idle time must lie in [0, 5e5] microseconds");
   h->res.enabled = idle_us > 0.0;
   h->res.idle_us = idle_us;
   h->res.life_us = std::max(100000.0, 20.0 * idle_us);

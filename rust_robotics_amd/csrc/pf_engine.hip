@@ -173,6 +173,7 @@ struct rr_pf {
   double* est_slot_partials = nullptr; // [ceil(cap / kResolveSlots)][waves][4]: the deferred form's sums per slot tile (rr::kEstDeferred)
   double* est_slot_partials_host = nullptr;
   bool est_deferred = false;           // the last plan was asked for the deferred form and nobody has moved the particles yet
+  uint64_t shard_est_stamp = 0;        // rr_pf_shard_want_estimate: the resample step (rstep, 1-based) whose sums were asked for last
   bool shard_est = false;              // rr_pf_shard_want_estimate: every window step of this shard leaves its part of the mean
   bool shard_est_ever = false;         // ... has been asked for at some point (k_est_slots then trusts the caller about Ctl.fired)
   bool est_eager = false;              // rr_pf_step of a multinomial filter: search the draws and add up the estimate right after the plan
@@ -451,6 +452,12 @@ void launch_quantize(rr_pf* h, const double* wmax_src, int settle = 0) {
                      wmax_src, image_args(h), h->tile_total, h->tile_q2, settle);
 }
 
+// the deferred estimate's per-wave sums, and behind them ONE word: the resample step a shard's sums belong to (WindowArgs.est_stamp)
+static size_t est_slot_bytes(const rr_pf* h) { return ((size_t)grid_for(h->cap, rr::kResolveSlots) * kEstSlotWords + 1) * sizeof(double); }
+static uint64_t* est_stamp_slot(const rr_pf* h) {
+  return h->est_slot_partials ? reinterpret_cast<uint64_t*>(h->est_slot_partials + (size_t)grid_for(h->cap, rr::kResolveSlots) * kEstSlotWords) : nullptr;
+}
+
 // make a pending lazy resample real (accessors and the non-fused entry points call this first)
 void launch_guide_search(rr_pf* h, const double* r_explicit_dev, unsigned int* lidx, const GatherArgs& g);
 
@@ -459,7 +466,7 @@ static void launch_est_slots(rr_pf* h) {
   if (!h->est_deferred) return;
   h->est_deferred = false;
   hipLaunchKernelGGL(k_est_slots, dim3(grid_for(h->n, rr::kResolveSlots)), dim3(kBlock), 0, h->stream, h->b, (const Ctl*)h->ctl, h->n,
-                     h->est_slot_partials, h->shard_est_ever ? 1 : 0);
+                     h->est_slot_partials, h->shard_est_ever ? 1 : 0, est_stamp_slot(h), h->shard_est_stamp);
 }
 
 rr_status materialise(rr_pf* h) {
@@ -605,7 +612,7 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
     rr::EstArgs ea{};
     if (est_mode != rr::kEstOff && lazy && fused) {  // the mean the reference's try_step returns (rr::EstArgs: in the plan / deferred)
       if (est_mode == rr::kEstDeferred && !h->est_slot_partials)
-        RR_HIP_TRY(hipMalloc(&h->est_slot_partials, (size_t)grid_for(h->cap, rr::kResolveSlots) * kEstSlotWords * sizeof(double)));
+        RR_HIP_TRY(hipMalloc(&h->est_slot_partials, est_slot_bytes(h)));
       for (int k = 0; k < 2; ++k) {
         ea.field[k][0] = h->b.x[k];
         ea.field[k][1] = h->b.y[k];
@@ -1270,7 +1277,9 @@ static rr_status resident_launch(rr_pf* h, uint64_t first_seq, unsigned int step
 // of life) is replaced; the command is still in the ring.
 static rr_status resident_await(rr_pf* h, uint64_t seq, double out[4]) {
   rr_pf::Resident& r = h->res;
-  const auto t0 = std::chrono::steady_clock::now();
+  auto t0 = std::chrono::steady_clock::now();
+  const long long patience_ms = 2000 + (long long)(r.life_us / 1000.0);
+  int gave_up = 0;
   for (unsigned spins = 0;; ++spins) {
     uint64_t e[4], flags = 0;
     // (the adaptive kernel vouches for its estimate with a flags pair: part of the answer, waited for under the same bound)
@@ -1300,11 +1309,21 @@ static rr_status resident_await(rr_pf* h, uint64_t seq, double out[4]) {
       continue;  // (consumed >= seq: the answer is on its way)
     }
     if ((spins & 1023u) == 1023u &&
-        std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > 2000) {
+        std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > patience_ms) {
+      // No answer within the bound.  The (re)launched kernel may simply not have had its turn yet -- queued behind another
+      // handle's resident kernel on a shared hardware queue, which may live for its whole life_us -- so the bound covers the
+      // longest life a resident kernel can have (rr_pf_set_resident caps it).  Past that: wait for the stream, after which the
+      // incarnation has either taken the command (the answer is in the ring: the loop's next turn returns it, the step WAS
+      // applied and is reported as such) or left without it (EXIT marker, consumed < seq: relaunched by the branch above, the
+      // command is still in the ring).  Only a kernel that neither answers nor leaves twice in a row is an error -- never a
+      // failure reported for a step the device went on to apply.
       (void)hipStreamSynchronize(h->stream);
-      r.live = false;
-      r.pending = false;
-      return fail(RR_RUNTIME_ERROR, "the resident step kernel did not answer");
+      if (++gave_up > 2) {
+        r.live = false;
+        r.pending = false;
+        return fail(RR_RUNTIME_ERROR, "the resident step kernel did not answer");
+      }
+      t0 = std::chrono::steady_clock::now();
     }
   }
 }
@@ -1799,7 +1818,8 @@ rr_status rr_pf_step_async(rr_pf* h, const double control[2], const double* obs,
 rr_status rr_pf_set_resident(rr_pf* h, double idle_us) {
   rr_status s = bind(h);  // (parks a live kernel)
   if (s != RR_OK) return s;
-  if (!(idle_us >= 0.0) || !(idle_us <= 1e7)) return fail(RR_INVALID_PARAMETER, "resident idle time must lie in [0, 1e7] microseconds");
+  // (<= 0.5 s idle, hence <= 10 s of life: what a host that waits for an answer has to be prepared to sit out, resident_await)
+  if (!(idle_us >= 0.0) || !(idle_us <= 5e5)) return fail(RR_INVALID_PARAMETER, "resident idle time must lie in [0, 5e5] microseconds");
   h->res.enabled = idle_us > 0.0;
   h->res.idle_us = idle_us;
   h->res.life_us = std::max(100000.0, 20.0 * idle_us);
@@ -1857,7 +1877,7 @@ rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]) {
   const uint64_t n_slot_tiles = grid_for(h->n, rr::kResolveSlots);
   if (h->est_slot_partials) {
     if (!h->est_slot_partials_host)
-      RR_HIP_TRY(hipHostMalloc(&h->est_slot_partials_host, (size_t)grid_for(h->cap, rr::kResolveSlots) * kEstSlotWords * sizeof(double)));
+      RR_HIP_TRY(hipHostMalloc(&h->est_slot_partials_host, est_slot_bytes(h)));
     RR_HIP_TRY(hipMemcpyAsync(h->est_slot_partials_host, h->est_slot_partials, (size_t)n_slot_tiles * kEstSlotWords * sizeof(double),
                               hipMemcpyDeviceToHost, h->stream));
   }
@@ -2514,6 +2534,8 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   wa.n_ranks = h->p2p.peers.n_ranks;
   // rr_pf_shard_want_estimate: this launch adds up the fields of the sources of its own slots (the step before's resample)
   wa.est_partials = h->est_deferred ? h->est_slot_partials : nullptr;
+  wa.est_stamp_slot = h->est_deferred ? est_stamp_slot(h) : nullptr;
+  wa.est_stamp = h->shard_est_stamp;
   h->est_deferred = false;
 #if defined(RR_DEBUG_TRACE)
   uint64_t* const dbg = h->dbg_trace ? h->dbg_trace + (size_t)(h->step % h->dbg_cap) * kDbgWords : nullptr;
@@ -2594,6 +2616,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   h->window_seq = seq;
   h->window_rccl = false;
   h->est_deferred = h->shard_est;  // (whoever moves the particles next adds up this shard's part of the step's mean)
+  if (h->shard_est) h->shard_est_stamp = h->rstep;
   return RR_OK;
 }
 
@@ -2607,8 +2630,10 @@ rr_status rr_pf_shard_want_estimate(rr_pf* h, int32_t want) {
   if (s != RR_OK) return s;
   if (want && h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC)
     return fail(RR_INVALID_PARAMETER, "the sharded estimate serves the systematic scheme (the window steps: rr_pf_shard_step_p2p, rr_pf_shard_step)");
-  if (want && !h->est_slot_partials)
-    RR_HIP_TRY(hipMalloc(&h->est_slot_partials, (size_t)grid_for(h->cap, rr::kResolveSlots) * kEstSlotWords * sizeof(double)));
+  if (want && !h->est_slot_partials) {
+    RR_HIP_TRY(hipMalloc(&h->est_slot_partials, est_slot_bytes(h)));
+    RR_HIP_TRY(hipMemsetAsync(est_stamp_slot(h), 0, sizeof(uint64_t), h->stream));  // (no step's sums yet: stamps start at 1)
+  }
   h->shard_est = want != 0;  // (want == 0: later steps leave no sums; the last step's stay readable, also after one more step)
   if (want) h->shard_est_ever = true;
   return RR_OK;
@@ -2623,10 +2648,16 @@ rr_status rr_pf_shard_last_estimate_sums(rr_pf* h, double out_sums[4], double* o
   if (h->est_deferred) launch_est_slots(h);
   const uint64_t n_part = (uint64_t)grid_for(h->n, rr::kResolveSlots) * (kBlock / rr::kWave);
   if (!h->est_slot_partials_host)
-    RR_HIP_TRY(hipHostMalloc(&h->est_slot_partials_host, (size_t)grid_for(h->cap, rr::kResolveSlots) * kEstSlotWords * sizeof(double)));
+    RR_HIP_TRY(hipHostMalloc(&h->est_slot_partials_host, est_slot_bytes(h)));
   RR_HIP_TRY(hipMemcpyAsync(h->est_slot_partials_host, h->est_slot_partials, (size_t)n_part * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  uint64_t* const stamp_host = reinterpret_cast<uint64_t*>(h->est_slot_partials_host + (size_t)grid_for(h->cap, rr::kResolveSlots) * kEstSlotWords);
+  RR_HIP_TRY(hipMemcpyAsync(stamp_host, est_stamp_slot(h), sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
   if ((s = fetch_ctl(h)) != RR_OK) return s;
-  if (!h->ctl_host->fired) return fail(RR_INVALID_PARAMETER, "the last step's gate stayed shut: no resampled set to take the mean of");
+  // The sums carry the resample step they were formed for (written by the kernel that formed them, only when that step's gate
+  // fired).  Asked for was step shard_est_stamp -- the last step taken with rr_pf_shard_want_estimate on, however many plain
+  // steps followed (the live Ctl.fired belongs to the LATEST step, not to that one).
+  if (*stamp_host != h->shard_est_stamp)
+    return fail(RR_INVALID_PARAMETER, "the gate of the step whose estimate was asked for stayed shut: no resampled set to take the mean of");
   est_slots_total_host(h->est_slot_partials_host, n_part, out_sums);
   *out_denom = (double)h->n_global;
   return RR_OK;
@@ -2722,6 +2753,7 @@ rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const 
                      (const uint64_t*)local3, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
   if (h->shard_est) {  // rr_pf_shard_want_estimate: the resampled set is in place (eager gather): this shard's part of its mean
     h->est_deferred = true;
+    h->shard_est_stamp = h->rstep;
     launch_est_slots(h);
   }
   RR_HIP_TRY(hipGetLastError());

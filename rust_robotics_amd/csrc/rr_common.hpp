@@ -150,7 +150,8 @@ constexpr int kWave = 64;
 // step -- instead of __shfl (ds_bpermute_b32 through the LDS crossbar, ~100+ cycles a step, and the steps depend on each
 // other): row_shr 1 / 2 / 4 / 8 give an inclusive scan inside each row of 16 lanes, row_bcast:15 (rows 1, 3) and
 // row_bcast:31 (rows 2, 3) carry it across the rows.  Lane 63 ends up with the reduction of the whole wave.
-// (Floating-point SUMS keep their fixed __shfl_xor butterfly: their value depends on the order.)
+// (Floating-point sums take the same lane movements in one FIXED order -- wave_sum_dpp, wave_sum4 below -- since round 4; their
+// value depends on the order, which is therefore part of the deterministic specification's GPU side.)
 template <int CTRL, int ROW_MASK>
 __device__ inline unsigned int dpp_u32(unsigned int v) {  // lanes without a source lane (or outside ROW_MASK) read 0
   return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);

@@ -90,3 +90,30 @@ class DetPF:
         cov = np.empty(16)
         self.det.det_pf_moments(self.n, dp(self.x), dp(self.y), dp(self.yaw), dp(self.v), dp(self.w), self.s, dp(est), dp(cov))
         return est, cov.reshape(4, 4)
+
+
+def unified_sim_data():
+    """`generate_sim_data` of rust_robotics_localization/tests/unified_filter_comparison.rs:67-121 with the reference's own stream
+    (StdRng::seed_from_u64(42) through oracle/rand_rs.py): per step one normal each for the velocity and yaw-rate input noise
+    (sigma 0.3, 5 deg), the x and y position observation (0.5, 0.5) and the four landmark ranges (0.5, clamped at 0), in that
+    order.  Returns (ground truth [100][4], noisy controls [100][2], landmark observations [100][4][3] = (d, lx, ly))."""
+    from oracle import rand_rs as R
+
+    rng = R.StdRng.seed_from_u64(42)
+    lms = [(10.0, 0.0), (0.0, 15.0), (-5.0, 20.0), (10.0, 10.0)]
+    x = np.zeros(4)
+    truth, controls, lm_obs = [], [], []
+    for _ in range(100):
+        yaw = x[2]
+        x = np.array([x[0] + 0.1 * 1.0 * math.cos(yaw), x[1] + 0.1 * 1.0 * math.sin(yaw), x[2] + 0.1 * 0.1, 1.0])
+        u = (1.0 + R.normal(rng, 0.0, 0.3), 0.1 + R.normal(rng, 0.0, math.radians(5.0)))
+        R.normal(rng, 0.0, 0.5)  # the position observation of the Kalman-family filters (x, then y): drawn, not used here
+        R.normal(rng, 0.0, 0.5)
+        obs = []
+        for lx, ly in lms:
+            d_true = math.sqrt((x[0] - lx) ** 2 + (x[1] - ly) ** 2)
+            obs.append((max(d_true + R.normal(rng, 0.0, 0.5), 0.0), lx, ly))
+        truth.append(x)
+        controls.append(u)
+        lm_obs.append(obs)
+    return np.array(truth), np.array(controls), np.array(lm_obs)

@@ -149,6 +149,49 @@ def test_in_process_shards_multi_launch_plan(world, n_local, mode):
     assert r.returncode == 0 and "P2P_LOCAL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+def test_shard_estimate_says_which_step_it_belongs_to():
+    """rr_pf_shard_last_estimate_sums returns the sums of the LAST STEP TAKEN WITH rr_pf_shard_want_estimate ON, validated by a stamp
+    the summing kernel leaves behind the sums -- not by the live Ctl.fired, which belongs to the latest step.  (a) a step
+    whose resample fired, then a plain step whose gate stays shut (no observation: the weights stay uniform, N_eff = N): the first
+    step's sums are still returned, and equal the unsharded filter's estimate of that step bit for bit; (b) a step whose own gate
+    stays shut: an error that says so, whether it is read at once or a step later."""
+    import rust_robotics_amd.localization as loc
+    from rust_robotics_amd import _ffi
+    from rust_robotics_amd.sharded import P2PShard
+
+    os.environ["RR_PF_EST_DEFER"] = "1"
+    n, kw = 6000, dict(range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))
+    rng = np.random.default_rng(3)
+    obs = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(1), 0.5, rng)
+    none = np.zeros((0, 3))
+    for read_later in (False, True):
+        s = P2PShard(0, 1, 0, n, seed=9, gate=_ffi.RR_GATE_NEFF, resample_threshold=1.0, **kw)
+        P2PShard.link_local([s])
+        ref = loc.ParticleFilterLocalizer(loc.ParticleFilterConfig(n_particles=n, resample_threshold=1.0, **kw), seed=9,
+                                          resample_scheme=_ffi.RR_RESAMPLE_SYSTEMATIC)
+        # (a)
+        s.want_estimate(True)
+        s.step([1.0, 0.1], obs)
+        ref.step_async_estimate([1.0, 0.1], obs)
+        want = np.array(ref.last_step_estimate())
+        s.want_estimate(False)
+        s.step([1.0, 0.1], none)  # gate shut: uniform weights
+        s.synchronize()
+        sums, den = s.estimate_sums()
+        assert den == n and np.array_equal((sums / den).view(np.uint64), want.view(np.uint64)), (sums / den, want)
+        # (b)
+        s.want_estimate(True)
+        s.step([1.0, 0.1], none)
+        if read_later:
+            s.want_estimate(False)
+            s.step([1.0, 0.1], obs)
+        with pytest.raises(Exception) as ei:
+            s.estimate_sums()
+        assert "stayed shut" in str(ei.value)
+        assert not s.timed_out()
+        s.close()
+
+
 @pytest.mark.parametrize("plain", ["0", "1"])
 def test_sharded_steps_beside_another_filter(plain):
     """tools/soak_shard_estimate.py as a regression: a world-size-1 shard of 5 000 particles and an unsharded filter step side by
