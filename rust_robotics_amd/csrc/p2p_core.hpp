@@ -11,16 +11,16 @@
 #include <string>
 
 #include "resample_core.hpp"
+#include "resident_core.hpp"
 #include "rr_common.hpp"
 
 namespace rr {
 
 // ------------------------------------------------------------------------------------------
 // Device-initiated exchange over xGMI: no host code and no collective library inside a step.
-// Every rank owns a fine-grained mailbox that the peers write 32-byte records into
-// {payload[3], seq}; k_p2p_exchange (one workgroup, one thread per peer) publishes this rank's
-// record to every peer with system-scope release and waits, bounded, for every peer's record
-// with system-scope acquire.  Particles that cross ranks at resample time are delivered into the
+// Every rank owns a fine-grained mailbox that the peers write their records into (WMAX / SUMS: self-vouching
+// 16-byte pairs, P2PPairSlot; DONE: a release-stamped slot); k_p2p_exchange (one workgroup, one thread per peer)
+// publishes this rank's record to every peer and waits, bounded, for every peer's record.  Particles that cross ranks at resample time are delivered into the
 // owning rank's INBOX: a fine-grained (uncached, device-coherent) mirror of one buffer set, the
 // kind of memory RCCL uses for its own peer-written buffers -- a store from a remote kernel is
 // visible to a later local kernel without any assumption about what either GPU's L2 still holds.
@@ -34,9 +34,19 @@ struct P2PSlot {
   uint64_t v[3];
   uint64_t seq;
 };
+// WMAX / SUMS records vouch for themselves (round 5): each payload word travels as ONE 16-byte store {word, seq ^ mix(word)}
+// (MailPair, resident_core.hpp: the same store the resident service answers the host with).  The sender stores and is done -- no
+// wait for the words' acknowledgement before a separate stamp; the reader polls the pairs themselves and has the payload the moment
+// the last one fits -- no second round trip for it.  mix is one-to-one, so a pair torn in flight (it is a single aligned 16-byte
+// transaction; nothing promises that on every fabric) fits only if the word is the one the tag was made for.  Two round trips less per
+// exchange: at world size 1 the sharded plan kernel went from 21.7 to ~17 us (profiles/r05g_*).
+struct alignas(64) P2PPairSlot {
+  MailPair p[3];
+};
+__device__ inline uint64_t p2p_tag(uint64_t seq, uint64_t word) { return seq ^ (word * 0x9E3779B97F4A7C15ull); }
 struct P2PMailbox {
-  P2PSlot wmax[kMaxP2P];
-  P2PSlot sums[kMaxP2P];
+  P2PPairSlot wmax[kMaxP2P];
+  P2PPairSlot sums[kMaxP2P];
   P2PSlot done[kMaxP2P];
 };
 struct P2PPeers {
@@ -49,9 +59,7 @@ struct P2PPeers {
 };
 enum { kP2PWmax = 0, kP2PSums = 1, kP2PDone = 2 };
 
-__device__ inline P2PSlot* p2p_slot(P2PMailbox* m, int kind, int idx) {
-  return kind == kP2PWmax ? &m->wmax[idx] : (kind == kP2PSums ? &m->sums[idx] : &m->done[idx]);
-}
+__device__ inline P2PPairSlot* p2p_pairs(P2PMailbox* m, int kind, int idx) { return kind == kP2PWmax ? &m->wmax[idx] : &m->sums[idx]; }
 
 // One exchange round, executed block-uniformly by a workgroup of >= 64 threads (thread g < n_ranks
 // talks to peer g).  payload (valid in every thread g < n_ranks): kind WMAX -> {bits of the local
@@ -74,50 +82,67 @@ __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t se
   // reads the flag with rr_pf_p2p_status); only the first one costs the timeout
   if (g == 0) s_bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
-  if (g < peers.n_ranks && !s_bad) {
-    P2PSlot* out = p2p_slot(peers.mbox[g], kind, peers.rank);
-    __hip_atomic_store(&out->v[0], v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&out->v[1], v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(&out->v[2], v2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (kind == kP2PDone) {
-      // DONE of the eager / FastSLAM protocols vouches for bulk data written with ORDINARY stores by other workgroups and
-      // earlier kernels: a full system-scope release (L2 write-back) has to come first
-      __atomic_thread_fence(__ATOMIC_SEQ_CST);
-      __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    } else {
-      // WMAX / SUMS carry nothing but their own three words, and those are system-scope (write-through) stores: once they
-      // are acknowledged they are in the peer's memory, and the stamp may follow -- no cache maintenance at all.  (The fence
-      // this replaces wrote the whole L2 back twice per step: ~2 us per exchange at 1e6 particles.)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __hip_atomic_store(&out->seq, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    P2PSlot* in = p2p_slot(peers.mbox[peers.rank], kind, g);
+  if (g < peers.n_ranks && !s_bad && kind != kP2PDone) {
+    // WMAX (one word) / SUMS (three): self-vouching pairs, see P2PPairSlot
+    const int n_words = kind == kP2PWmax ? 1 : 3;
+    const uint64_t v[3] = {v0, v1, v2};
+    P2PPairSlot* out = p2p_pairs(peers.mbox[g], kind, peers.rank);
+    for (int k = 0; k < n_words; ++k) store_pair_sys(&out->p[k], v[k], p2p_tag(seq, v[k]));
+    const P2PPairSlot* in = p2p_pairs(peers.mbox[peers.rank], kind, g);
     const uint64_t t0 = wall_clock64();  // 100 MHz
-    bool ok = true;
-    // (the payload is read with system-scope loads below, which bypass the caches: no acquire -- no invalidate -- needed
-    // for WMAX / SUMS; the loads are issued after the stamp has been seen, and a wave's loads return in order)
-    while ((kind == kP2PDone ? __hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM)
-                             : __hip_atomic_load(&in->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) < seq) {
-      __builtin_amdgcn_s_sleep(8);
+    uint64_t got[3] = {0, 0, 0}, tag[3] = {0, 0, 0};
+    bool ok = false;
+    for (;;) {
+      bool all = true;
+      for (int k = 0; k < n_words; ++k) {
+        load_pair_sys(&in->p[k], got[k], tag[k]);
+        all &= tag[k] == p2p_tag(seq, got[k]);
+      }
+      if (all) {
+        ok = true;
+        break;
+      }
       // a peer is gone: do not hang the device.  The first exchanges of a filter get ten times the
       // budget -- process start-up and code-object loading skew the ranks by far more than a step does
+      if (wall_clock64() - t0 > (seq <= 3 ? 10 * peers.timeout_ticks : peers.timeout_ticks)) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    if (!ok) {
+      uint64_t* d = reinterpret_cast<uint64_t*>(err) + 1;  // (the flag's allocation has room for this: P2PState::local_setup)
+      d[0] = (uint64_t)g;
+      d[1] = seq;
+      d[2] = tag[0] ^ (got[0] * 0x9E3779B97F4A7C15ull);  // the sequence number the first pair that IS there vouches for
+      d[3] = seq;                                          // (this rank's own record went out before the wait)
+      atomicExch(&s_bad, 1);
+    } else {
+      gathered[3 * g] = got[0];
+      gathered[3 * g + 1] = got[1];
+      gathered[3 * g + 2] = got[2];
+    }
+  } else if (g < peers.n_ranks && !s_bad) {
+    // DONE of the eager / FastSLAM protocols vouches for bulk data written with ORDINARY stores by other workgroups and
+    // earlier kernels: a full system-scope release (L2 write-back) has to come first, the stamp is a release store and the
+    // wait an acquire
+    P2PSlot* out = &peers.mbox[g]->done[peers.rank];
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
+    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    P2PSlot* in = &peers.mbox[peers.rank]->done[g];
+    const uint64_t t0 = wall_clock64();
+    bool ok = true;
+    while (__hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+      __builtin_amdgcn_s_sleep(8);
       if (wall_clock64() - t0 > (seq <= 3 ? 10 * peers.timeout_ticks : peers.timeout_ticks)) {
         ok = false;
         break;
       }
     }
-    asm volatile("" ::: "memory");
     if (!ok) {
-      uint64_t* d = reinterpret_cast<uint64_t*>(err) + 1;  // (the flag's allocation has room for this: P2PState::local_setup)
+      uint64_t* d = reinterpret_cast<uint64_t*>(err) + 1;
       d[0] = (uint64_t)g;
       d[1] = seq;
       d[2] = __hip_atomic_load(&in->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       d[3] = __hip_atomic_load(&out->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       atomicExch(&s_bad, 1);
-    } else {
-      gathered[3 * g] = __hip_atomic_load(&in->v[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      gathered[3 * g + 1] = __hip_atomic_load(&in->v[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      gathered[3 * g + 2] = __hip_atomic_load(&in->v[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   __threadfence_block();
