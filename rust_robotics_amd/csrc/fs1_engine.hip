@@ -526,7 +526,7 @@ rr_status launch_plan_fused(rr_fs1* h, int settle) {
       if (std::atoi(e) == 0) h->grid_capacity = 0;
     }
     if (h->grid_capacity) {
-      const size_t rec_bytes = (size_t)(rr::kTileBlock + 1) * rr::kRecWords * sizeof(uint64_t);
+      const size_t rec_bytes = rr::kPlanRecBytes;
       RR_HIP_TRY(hipMalloc(&h->grid_rec, rec_bytes));
       RR_HIP_TRY(hipMemsetAsync(h->grid_rec, 0, rec_bytes, h->stream));
       RR_HIP_TRY(hipMalloc(&h->grid_ticket, rr::kTicketWords * sizeof(unsigned int)));

@@ -312,17 +312,25 @@ __device__ inline bool inbox_take(const double* inbox, uint64_t n_local, uint64_
 //   the last arrival scans the records (prefix per tile, this shard's sums), settles Ctl as k_quantize_reduce would,
 //   trades the sums with the peers (p2p_exchange -> finalize_plan: gate, base, plan) and raises flag 1;
 //   every workgroup reads its prefix, the base and the global totals and marks its sources exactly as k_mark does.
-// rec layout: [n_tiles][kRecWords], then head0 {wmax bits, flag 0}, then head1 {base, T, q2_hi, q2_lo, flag 1}.
+// rec layout: [n_tiles][kRecWords] input records; everything handed BACK (the global maximum; every tile's prefix, the base, the
+// global total, the gate decision) travels as self-vouching pairs (resample_core.hpp, TagPair / plan_pairs).
 // All workgroups must be resident at once (host: n_tiles <= grid capacity).  A local wait is bounded by twelve peer
 // time-outs (the first exchanges of a filter are allowed ten); giving up sets *err like a peer time-out does.
-constexpr int kShardHeadWords = 8;
 __device__ inline bool wait_flag(const uint64_t* flag, uint64_t epoch, uint64_t limit_ticks) {
   const uint64_t t0 = wall_clock64();
   while (ld_dev(flag) != epoch) {
     __builtin_amdgcn_s_sleep(1);
     if (wall_clock64() - t0 > limit_ticks) return false;
   }
-  asm volatile("" ::: "memory");
+  return true;
+}
+template <int N>
+__device__ inline bool wait_pairs(const TagPair* const (&p)[N], uint64_t epoch, uint64_t limit_ticks, uint64_t (&word)[N]) {
+  const uint64_t t0 = wall_clock64();
+  while (!take_pairs<N>(p, epoch, word)) {
+    __builtin_amdgcn_s_sleep(1);
+    if (wall_clock64() - t0 > limit_ticks) return false;
+  }
   return true;
 }
 
@@ -341,8 +349,9 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
   __shared__ double s_wmax;
   __shared__ int s_last;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  uint64_t* const head0 = rec + n_tiles * kRecWords;
-  uint64_t* const head1 = head0 + 2;
+  TagPair* const pp = plan_pairs(rec);  // [tile]: its exclusive prefix; [kTileBlock + 0 .. 2]: base, global total, gate decision; [+ 5]: the global maximum
+  uint64_t* const flag0 = rec + n_tiles * kRecWords;  // the two state words of the launch (= epoch when raised)
+  uint64_t* const flag1 = flag0 + 1;
   const uint64_t limit = 12 * peers.timeout_ticks;
   // reads of Ctl that the last arrival's settle / finalize could race with come first (they precede this workgroup's ticket)
   const bool forced_uniform = a.honour_uniform_flag && ctl->weights_uniform;
@@ -351,9 +360,8 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
     const uint64_t local_bits = ctl->wmax_bits;
     p2p_exchange(peers, kP2PWmax, seq, local_bits, 0, 0, ctl, &s_wmax, pa, err);  // thread 0 leaves the maximum in s_wmax
     if (tid == 0) {
-      st_dev(&head0[0], rr_d2u(s_wmax));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      st_dev(&head0[1], epoch);
+      put_pair(&pp[kTileBlock + 5], rr_d2u(s_wmax), epoch);  // vouches for itself (resample_core.hpp, TagPair): the flag follows at once
+      st_dev(flag0, epoch);
 #if defined(RR_DEBUG_TRACE)
       if (trace) {
         trace[10] = local_bits;
@@ -365,8 +373,10 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
     }
   }
   if (tid == 0) {
-    if (!wait_flag(&head0[1], epoch, limit)) (void)atomicCAS(err, 0, kGaveUpPlanFlag);
-    s_wmax = rr_u2d(ld_dev(&head0[0]));
+    const TagPair* const want[1] = {&pp[kTileBlock + 5]};
+    uint64_t got[1] = {0};
+    if (!wait_flag(flag0, epoch, limit) || !wait_pairs<1>(want, epoch, limit, got)) (void)atomicCAS(err, 0, kGaveUpPlanFlag);
+    s_wmax = rr_u2d(got[0]);
   }
   __syncthreads();
   const double wmax = s_wmax;
@@ -434,7 +444,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
     __syncthreads();
     uint64_t wave_off = 0;
     for (int k = 0; k < wv; ++k) wave_off += s_w[k];
-    if ((uint64_t)tid < n_tiles) st_dev(&rec[(uint64_t)tid * kRecWords + 3], wave_off + inc - tk);
+    if ((uint64_t)tid < n_tiles) put_pair(&pp[tid], wave_off + inc - tk, epoch);
     if (tid == 0) {
       uint64_t tt = 0;
       u128 qq = {0, 0};
@@ -478,24 +488,22 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
         trace[28] = wall_clock64();
       }
 #endif
-      st_dev(&head1[0], ctl->base);
-      st_dev(&head1[1], ctl->total);
-      st_dev(&head1[2], ctl->q2_hi);
-      st_dev(&head1[3], ctl->q2_lo);
-      st_dev(&head1[4], (uint64_t)ctl->fired);
+      put_pair(&pp[kTileBlock + 0], ctl->base, epoch);
+      put_pair(&pp[kTileBlock + 1], ctl->total, epoch);
+      put_pair(&pp[kTileBlock + 2], (uint64_t)ctl->fired, epoch);
+      st_dev(flag1, epoch);  // (right behind the pairs, not after their acknowledgement: they vouch for themselves)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) st_dev(&head1[5], epoch);
   }
-  // ---- everybody: flag 1, then the workgroup's prefix, the base and the global totals
+  // ---- everybody: this tile's prefix, the base, the global total and the gate decision, as soon as they vouch for this launch
   if (tid == 0) {
-    const bool ok = wait_flag(&head1[5], epoch, limit);
+    const TagPair* const want[4] = {&pp[blockIdx.x], &pp[kTileBlock + 0], &pp[kTileBlock + 1], &pp[kTileBlock + 2]};
+    uint64_t got[4] = {0, 0, 0, 0};
+    const bool ok = wait_flag(flag1, epoch, limit) && wait_pairs<4>(want, epoch, limit, got);
     if (!ok) (void)atomicCAS(err, 0, kGaveUpPlanFlag);
-    s4[0] = ld_dev(&rec[(uint64_t)blockIdx.x * kRecWords + 3]);
-    s4[1] = ld_dev(&head1[0]);
-    s4[2] = ld_dev(&head1[1]);
-    s4[3] = ok ? ld_dev(&head1[4]) : 0;  // gave up: as if the gate were shut -- nothing is marked with unknown sums
+    s4[0] = got[0];
+    s4[1] = got[1];
+    s4[2] = got[2];
+    s4[3] = ok ? got[3] : 0;  // gave up: as if the gate were shut -- nothing is marked with unknown sums
   }
   __syncthreads();
   const uint64_t pre = s4[0], base = s4[1], total = s4[2];

@@ -1054,8 +1054,7 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
     if (const char* e = std::getenv("RR_PF_FUSED_PLAN")) {
       if (std::atoi(e) == 0) h->grid_capacity = 0;
     }
-    const size_t rec_bytes = (size_t)(rr::kTileBlock + 1) * rr::kRecWords * sizeof(uint64_t) + 16 * sizeof(uint64_t) +
-                             (size_t)rr::kTileBlock * rr::kTimelineWords * sizeof(uint64_t);  // records, heads, (instrumented build) stamps
+    const size_t rec_bytes = rr::kPlanRecBytes;  // records, heads, (instrumented build) stamps, the self-vouching pairs
     RR_TRY_OR_CLEAN(hipMalloc(&h->grid_rec, rec_bytes));
     RR_TRY_OR_CLEAN(hipMemsetAsync(h->grid_rec, 0, rec_bytes, h->stream));
     RR_TRY_OR_CLEAN(hipMalloc(&h->grid_ticket, rr::kTicketWords * sizeof(unsigned int)));

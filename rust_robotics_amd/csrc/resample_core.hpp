@@ -779,7 +779,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_plan_mark(const double* _
 // the same trick is not worth it between k_step_lazy and this kernel.
 // Reads of Ctl that the settle / finalize writes of workgroup 0 could race with happen before the ticket is taken;
 // workgroup 0 writes after it has seen the flag, i.e. after every workgroup has arrived.
-constexpr int kRecWords = 4;  // total, q2_hi, q2_lo, exclusive prefix (written back by the last arrival)
+constexpr int kRecWords = 4;  // a tile's record: total, q2_hi, q2_lo (+ 1 spare word)
 // rec layout: [n_tiles][kRecWords] records, then kRecWords words {grand total, q2_hi, q2_lo, state}
 __device__ inline uint64_t ld_dev(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_dev(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -803,11 +803,51 @@ __device__ inline void st_dev(double* p, double v) { st_dev(reinterpret_cast<uin
 // which (a) makes every later launch of the kernel skip the wait outright (serial plan at once, no 2 ms each) until (b) the
 // host sees it at its next read of Ctl and moves the handle to the multi-launch plan for good.  Nothing is reported as an
 // error: the results are those of the undisturbed filter.
+// ---- the OUTPUT side of the hand-over (round 5): what the last arrival hands back -- every tile's exclusive prefix and the grand
+// totals -- travels as self-vouching pairs {word, epoch ^ mix(word)}.  The last arrival stores them and is done with them: no wait
+// for their acknowledgement before a flag; a waiting workgroup polls ITS OWN prefix pair and the three totals (four pairs, one
+// round trip per look) and has the numbers the moment they fit -- no flag to see first and no second round trip for what it
+// announces.  mix is one-to-one, so a pair of which only half has arrived does not fit, nor does anything an earlier launch
+// left (other epoch).  What that buys: the last arrival stores the pairs and moves the state word at once, without waiting
+// for the pairs' acknowledgement first; a waiter that sees RAISED reads its pairs and looks again should one be late.
+// (Waiters polling the PAIRS instead of the state word -- no flag hop at all -- was built and measured, round 5: +1 us per step with
+// shared totals, +4.4 us with one 64-byte record per tile: the polling traffic of 489 workgroups stands in the way of the very
+// stores it waits for.  profiles/r05h_plan_handover_ab.md)
+struct alignas(16) TagPair {
+  uint64_t bits, tag;
+};
+__device__ inline uint64_t pair_tag(uint64_t epoch, uint64_t word) { return epoch ^ (word * 0x9E3779B97F4A7C15ull); }
+__device__ inline void put_pair(TagPair* p, uint64_t word, uint64_t epoch) {
+  st_dev(&p->bits, word);
+  st_dev(&p->tag, pair_tag(epoch, word));
+}
+// rec layout in words: [kTileBlock + 1][kRecWords] records and head | 16 spare | (instrumented build) kTileBlock x kTimelineWords
+// stamps | pairs: kTileBlock prefixes, then kPlanTotals shared words (totals; the sharded plan's base, gate decision, global maximum)
+constexpr int kTimelineWords = 8;
+constexpr int kPlanTotals = 8;
+constexpr size_t kPlanPairsWord = (size_t)(kTileBlock + 1) * kRecWords + 16 + (size_t)kTileBlock * kTimelineWords;
+constexpr size_t kPlanRecBytes = kPlanPairsWord * sizeof(uint64_t) + (size_t)(kTileBlock + kPlanTotals) * sizeof(TagPair);
+static_assert(kPlanPairsWord % 2 == 0, "the pairs are 16-byte aligned");
+__device__ inline TagPair* plan_pairs(uint64_t* rec) { return reinterpret_cast<TagPair*>(rec + kPlanPairsWord); }
+// up to four pairs in one round trip; true when every one of them vouches for `epoch` (word[k] then holds pair k's word)
+template <int N>
+__device__ inline bool take_pairs(const TagPair* const (&p)[N], uint64_t epoch, uint64_t (&word)[N]) {
+  uint64_t tag[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    word[k] = ld_dev(&p[k]->bits);
+    tag[k] = ld_dev(&p[k]->tag);
+  }
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < N; ++k) ok &= tag[k] == pair_tag(epoch, word[k]);
+  return ok;
+}
+
 constexpr uint64_t kPlanGiveupTicksDefault = 200000;  // 2 ms
 // Instrumented build (make -C csrc timeline: -DRR_PLAN_TIMELINE, a separate .so for tools/plan_timeline.py): thread 0 of
 // every workgroup stamps the 100 MHz wall clock at the kernel's stations into the words behind the records:
-//   0 start, 1 record stored, 2 ticket taken, 3 state word seen / decided, 4 sums read, 5 markers written (6 estimate partial)
-constexpr int kTimelineWords = 8;
+//   0 start, 1 record stored, 2 ticket taken, 3 sums seen (the pairs fit) / decided, 4 = 3, 5 markers written (6 estimate partial)
 #if defined(RR_PLAN_TIMELINE)
 #define RR_TL(K_) do { if (threadIdx.x == 0) tl[(uint64_t)blockIdx.x * kTimelineWords + (K_)] = wall_clock64(); } while (0)
 #else
@@ -932,7 +972,7 @@ __device__ __attribute__((noinline)) void plan_serial(typename std::conditional<
     uint64_t tt;
     u128 qq;
     plan_image_tile<FS_WEIGHTS>(w, a, mode, shift, tile, s_w, s4, t, w_in, &tt, &qq);
-    if (tid == 0) s_tile[0] = ld_dev(&rec[tile * kRecWords + 3]);
+    if (tid == 0) s_tile[0] = ld_dev(&plan_pairs(const_cast<uint64_t*>(rec))[tile].bits);
     if (want_est) est_prefetch(ea, cur_after, j0, a.n, ef);
     __syncthreads();
     ts.pre = s_tile[0];
@@ -954,9 +994,11 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
   __shared__ uint64_t s4[4 * W];
   __shared__ uint64_t s_w[W];
   __shared__ uint64_t s_tile[3];
+  __shared__ uint64_t s_sum[4];  // this tile's exclusive prefix, T, q2_hi, q2_lo
   __shared__ int s_last;
   __shared__ int s_gaveup;
   const int tid = threadIdx.x;
+  TagPair* const pp = plan_pairs(rec);
 #if defined(RR_PLAN_TIMELINE)
   uint64_t* const tl = rec + (kTileBlock + 1) * kRecWords + 16;  // (behind the records and the heads: sized by the host)
 #endif
@@ -983,9 +1025,11 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
       st_dev(&r[0], tt);
       st_dev(&r[1], qq.hi);
       st_dev(&r[2], qq.lo);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // acknowledged at device scope before the ticket says so
-      RR_TL(1);
-      s_last = last_arrival(ticket, blockIdx.x, (unsigned int)n_tiles, /*fence=*/false) ? 1 : 0;
+      // acknowledged at device scope before the ticket says so.  (The records as self-vouching pairs and the ticket taken at once,
+      // the last arrival looking again at a late one, was measured in round 5: the gain of the hand-BACK's pairs, -1 us, was gone
+      // again -- twice the loads in the last arrival's scan; profiles/r05h_plan_handover_ab.md)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      RR_TL(1);      s_last = last_arrival(ticket, blockIdx.x, (unsigned int)n_tiles, /*fence=*/false) ? 1 : 0;
       s_gaveup = 0;
       RR_TL(2);
     }
@@ -1022,7 +1066,7 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
     __syncthreads();
     uint64_t wave_off = 0;
     for (int k = 0; k < wv; ++k) wave_off += s_w[k];
-    if ((uint64_t)tid < n_tiles) st_dev(&rec[(uint64_t)tid * kRecWords + 3], wave_off + inc - tk);
+    const uint64_t my_pre = wave_off + inc - tk;
     if (tid == 0) {
       uint64_t tt = 0;
       u128 qq = {0, 0};
@@ -1030,15 +1074,25 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
         tt += s_w[k];
         qq = add128(qq, u128{s4[k], s4[W + k]});
       }
-      st_dev(&head[0], tt);
-      st_dev(&head[1], qq.hi);
-      st_dev(&head[2], qq.lo);
+      s_sum[1] = tt;
+      s_sum[2] = qq.hi;
+      s_sum[3] = qq.lo;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();  // every prefix is acknowledged
+    if ((uint64_t)tid == (uint64_t)blockIdx.x) s_sum[0] = my_pre;
+    if ((uint64_t)tid < n_tiles) put_pair(&pp[tid], my_pre, epoch);  // every tile's prefix, vouching for itself
+    if (tid == 0) {
+      put_pair(&pp[kTileBlock + 0], s_sum[1], epoch);
+      put_pair(&pp[kTileBlock + 1], s_sum[2], epoch);
+      put_pair(&pp[kTileBlock + 2], s_sum[3], epoch);
+    }
+    // The state word goes out right behind the pairs -- NOT after their acknowledgement (1.2 us of every workgroup's wait until round
+    // 5): a waiter that sees RAISED reads its pairs and, should one not have landed yet, looks again.
+    __syncthreads();  // (every thread's pair stores are issued)
     if (tid == 0) s_gaveup = (int)(plan_state_decide(&head[3], epoch, serial_only ? 1 : 0, /*guess_previous=*/true) & 1);
   } else if (tid == 0) {
-    // ---- everybody else: one thread waits for the state word of this launch
+    // ---- everybody else: one thread waits for the state word of this launch (ONE word for everybody: looking at more than that
+    // while waiting -- the pairs themselves, shared or one record per tile -- was measured and is slower: +1 / +4.4 us per step),
+    // then takes this tile's prefix and the totals, each of which vouches for itself
     if (serial_only) {
       s_gaveup = 1;
     } else {
@@ -1052,6 +1106,15 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
         __builtin_amdgcn_s_sleep(1);
       }
       s_gaveup = (int)(st & 1);
+      if (!(st & 1)) {
+        const TagPair* const want[4] = {&pp[blockIdx.x], &pp[kTileBlock + 0], &pp[kTileBlock + 1], &pp[kTileBlock + 2]};
+        uint64_t got[4];
+        while (!take_pairs<4>(want, epoch, got)) __builtin_amdgcn_s_sleep(1);  // (stores issued before the state word moved: they land)
+        s_sum[0] = got[0];
+        s_sum[1] = got[1];
+        s_sum[2] = got[2];
+        s_sum[3] = got[3];
+      }
     }
   }
   __syncthreads();
@@ -1059,22 +1122,15 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
   const bool gaveup = s_gaveup != 0;
   if (gaveup && !last) return;  // record and ticket are in; the last arrival plans this tile as well
   if (!FS_WEIGHTS && !DEFER && ea.want && last && !gaveup) est_prefetch(ea, cur_after, i0, a.n, ef);
-  if (tid == 0) {
-    asm volatile("" ::: "memory");
-    s4[0] = ld_dev(&rec[(uint64_t)blockIdx.x * kRecWords + 3]);
-    s4[1] = ld_dev(&head[0]);
-    s4[2] = ld_dev(&head[1]);
-    s4[3] = ld_dev(&head[2]);
-  }
-  __syncthreads();
   RR_TL(4);
   TileSums ts;
-  ts.pre = s4[0];
-  ts.tot = s4[1];
-  ts.q2 = u128{s4[2], s4[3]};
-  // ---- what k_quantize_reduce's and k_plan_mark's first threads leave in Ctl: workgroup 0 after it has seen the sums,
-  // i.e. after every workgroup has arrived (and read what it needs of Ctl); the last arrival when the launch gave up
-  if (tid == 0 && (gaveup ? last : blockIdx.x == 0)) {
+  ts.pre = s_sum[0];
+  ts.tot = s_sum[1];
+  ts.q2 = u128{s_sum[2], s_sum[3]};
+  // ---- what k_quantize_reduce's and k_plan_mark's first threads leave in Ctl: the LAST ARRIVAL, whatever the launch's outcome --
+  // every workgroup has arrived by then (and read what it needs of Ctl), and it is the one party that knows the launch's ONE
+  // answer (a waiter that went by the pairs does not, and two writers would settle twice)
+  if (tid == 0 && last) {
     if (settle && ctl->pending) {
       ctl->cur ^= 1;
       ctl->pending = 0;
@@ -1098,7 +1154,7 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
   // the estimate's partial sums are formed here, or (deferred form, gate fired) by whoever moves the particles
   const bool want_est = !FS_WEIGHTS && ea.want && !(DEFER && fire);
   const bool late_fields = want_est && DEFER;  // requested now that the decision is known
-  if (DEFER && ea.want && fire && tid == 0 && (gaveup ? last : blockIdx.x == 0)) est_publish(ctl, denom, pa.rstep, kEstSlotTiles);
+  if (DEFER && ea.want && fire && tid == 0 && last) est_publish(ctl, denom, pa.rstep, kEstSlotTiles);
   if (FS_WEIGHTS ? (!fire && mode != kImageWeights) : (!fire && !want_est)) return;  // nothing to write
   if (!gaveup) {
     // One tile -- this workgroup's, its image still in registers.  (Straight-line code: as ONE loop with the serial plan below,
@@ -1110,10 +1166,13 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
     RR_TL(6);
   } else {
     // The launch gave up and this workgroup arrived last: every tile, one after the other (the serial plan) -- the same functions,
-    // behind a real call, so that the loop's live values are not the straight path's register pressure.
+    // behind a real call, so that the loop's live values are not the straight path's register pressure.  (Tiles whose workgroups
+    // had gone by the pairs before somebody gave up are marked twice, with the same values.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's own prefix pairs are read back below
+    __syncthreads();
     plan_serial<FS_WEIGHTS, DEFER>(w, a, mode, shift, fire, rho, pa, n_tiles, rec, markers, carry, ea, want_est, cur_after, ts, s_w, s4, s_tile);
   }
-  if (want_est && tid == 0 && (gaveup ? last : blockIdx.x == 0)) est_publish(ctl, denom, pa.rstep, kEstPlanTiles);
+  if (want_est && tid == 0 && last) est_publish(ctl, denom, pa.rstep, kEstPlanTiles);
 }
 
 // sharded: the plan is already in Ctl (k_shard_plan); mark this shard's sources.  tile_offset =
