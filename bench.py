@@ -810,7 +810,7 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
                 fn_c(u, obs_list[t])
             pc.synchronize()
             extra["ms_per_step_cold"] = (time.perf_counter() - t0) / K * 1e3
-            del pc
+            del fn_c, pc  # (the bound method holds the filter too: both, or it lives on beside the hot one)
         for t in range(D):  # device warm-up (see DEVICE_WARMUP_MCL), then time moves on
             step_fn(u, obs_list[t])
             # in blocks with a synchronisation in between, the shape of the timed region: a thousand steps enqueued in one go leave
@@ -874,13 +874,19 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
         if n <= 4_000_000:
             for t in range(5):
                 pf.step(u, obs_list[W + 4 * K + t])
-            t1 = time.perf_counter()
-            for t in range(K):
+            per = []
+            for t in range(K):  # (every step is a host round trip of its own, so each one is timed by itself)
+                t1 = time.perf_counter()
                 pf.step(u, obs_list[W + 4 * K + 5 + t])
-            t_sync = (time.perf_counter() - t1) / K
+                per.append(time.perf_counter() - t1)
+            t_sync = float(np.mean(per))
             extra["synchronous_try_step"] = {"ms_per_step": t_sync * 1e3, "value": float(n) * L / t_sync,
+                                             "median_ms": float(np.median(per)) * 1e3, "max_ms": float(np.max(per)) * 1e3,
                                              "note": "rr_pf_step: one host round trip per step, the mean of the resampled set returned every step" +
-                                                     ("" if with_est else " (multinomial: the pending draws are searched, gathered and averaged by extra launches)")}
+                                                     ("" if with_est else " (multinomial: the pending draws are searched, gathered and averaged by extra launches)") +
+                                                     "; mean of the K steps (median_ms / max_ms beside it: the HIP runtime stalls ONCE for ~0.45 ms at some launch "
+                                                     "count of a process -- build_ab/stall_probe.py: one step of 600 --, and with K = 20 that one step is 22 us of the mean "
+                                                     "when it falls into this window)"}
         if with_cpu and n <= 4_000_000:  # (checker use of the oracle: part of the cpu_baseline leg)
             pf2 = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=ctx.local_rank,
                                                              resample_scheme=scheme, likelihood_mode=lik, record_indices=True)
@@ -1297,7 +1303,7 @@ def main():
         return
 
     log(f"headline leg: MCL {n} particles/GPU x {L} landmarks, world {ctx.world}")
-    args.cold_first = True  # the headline leg also reports the cold number (device_warmup_steps: 0) beside the hot one
+    args.cold_first = os.environ.get("RR_BENCH_NO_COLD") is None  # the headline leg also reports the cold number (device_warmup_steps: 0) beside the hot one
     out = leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=not args.no_breakdown)
     args.cold_first = False
     if ctx.rank == 0:
@@ -1458,7 +1464,10 @@ def _leg_row(leg):
     if "error" in leg:
         return {"error": _short(leg["error"], 80)}
     r = leg.get("roofline") if isinstance(leg.get("roofline"), dict) else {}
-    return [_num(leg.get("ms_per_step"), 5), _num(r.get("frac"), 4), _num(r.get("binding_frac", r.get("frac")), 4)]
+    row = [_num(leg.get("ms_per_step"), 5), _num(r.get("frac"), 4), _num(r.get("binding_frac", r.get("frac")), 4)]
+    if "median_ms" in leg:  # (legs timed step by step: the median beside the mean)
+        row.append({"median_ms": _num(leg["median_ms"], 5), "max_ms": _num(leg.get("max_ms"), 4)})
+    return row
 
 
 def compact_line(out):
