@@ -885,7 +885,7 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
                                              "note": "rr_pf_step: one host round trip per step, the mean of the resampled set returned every step" +
                                                      ("" if with_est else " (multinomial: the pending draws are searched, gathered and averaged by extra launches)") +
                                                      "; mean of the K steps (median_ms / max_ms beside it: the HIP runtime stalls ONCE for ~0.45 ms at some launch "
-                                                     "count of a process -- build_ab/stall_probe.py: one step of 600 --, and with K = 20 that one step is 22 us of the mean "
+                                                     "count of a process -- tools/stall_probe.py: one step of 600 --, and with K = 20 that one step is 22 us of the mean "
                                                      "when it falls into this window)"}
         if with_cpu and n <= 4_000_000:  # (checker use of the oracle: part of the cpu_baseline leg)
             pf2 = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=ctx.local_rank,
