@@ -20,8 +20,8 @@ namespace rr {
 // Device-initiated exchange over xGMI: no host code and no collective library inside a step.
 // Every rank owns a fine-grained mailbox that the peers write their records into (WMAX / SUMS: self-vouching
 // 16-byte pairs, P2PPairSlot; DONE: a release-stamped slot); k_p2p_exchange (one workgroup, one thread per peer)
-// publishes this rank's record to every peer and waits, bounded, for every peer's record.  Particles that cross ranks at resample time are delivered into the
-// owning rank's INBOX: a fine-grained (uncached, device-coherent) mirror of one buffer set, the
+// publishes this rank's record to every peer and waits, bounded, for every peer's record.  Particles that cross
+// ranks at resample time are delivered into the owning rank's INBOX: a fine-grained (uncached, device-coherent) mirror of one buffer set, the
 // kind of memory RCCL uses for its own peer-written buffers -- a store from a remote kernel is
 // visible to a later local kernel without any assumption about what either GPU's L2 still holds.
 // The consumer reads an "in place" slot from its inbox instead of its slab.
@@ -38,8 +38,10 @@ struct P2PSlot {
 // (MailPair, resident_core.hpp: the same store the resident service answers the host with).  The sender stores and is done -- no
 // wait for the words' acknowledgement before a separate stamp; the reader polls the pairs themselves and has the payload the moment
 // the last one fits -- no second round trip for it.  mix is one-to-one, so a pair torn in flight (it is a single aligned 16-byte
-// transaction; nothing promises that on every fabric) fits only if the word is the one the tag was made for.  Two round trips less per
-// exchange: at world size 1 the sharded plan kernel went from 21.7 to ~17 us (profiles/r05g_*).
+// transaction; nothing promises that on every fabric) fits only if the word is the one the tag was made for.  Only n_ranks threads of
+// ONE workgroup poll here, so looking at the pairs directly costs nothing (489 workgroups doing the same inside the plan kernels is
+// another matter: resample_core.hpp).  Measured at world size 1, two builds alternating on one box: 56.8 -> 56.1 us per sharded step
+// (profiles/r05g_ab_shard_exchange_pairs.log).
 struct alignas(64) P2PPairSlot {
   MailPair p[3];
 };
