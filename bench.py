@@ -828,7 +828,8 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
         pf.synchronize()
         dt = time.perf_counter() - t0
         extra["headline_step"] = ("rr_pf_step_async_estimate: propagate + weight + resample + the mean try_step returns, every step"
-                                  + ("" if args.scheme == "systematic" else " (summed by the next step's draw-and-gather kernel)")
+                                  + (" (summed by the next step's kernel as it moves the particles; RR_PF_EST_DEFER=0: inside the plan kernel)"
+                                     if args.scheme == "systematic" else " (summed by the next step's draw-and-gather kernel)")
                                   if with_est else
                                   "rr_pf_step_async: propagate + weight + resample (the in-step estimate serves up to 8 388 608 particles)")
         if with_est:
@@ -907,14 +908,16 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
         dominant = None  # this path does not stamp its dispatches (multinomial): fall back to the instrumented re-run
     k1_n, k1_ms = dominant or kern["k_propagate_weight"]
     k1_avg_s = (k1_ms / max(k1_n, 1)) * 1e-3
-    k1_bytes = K1_BYTES[args.scheme] if not ctx.sharded else 64.0
+    # the systematic headline's step kernel is the EST build when the estimate is deferred (the default): it also reads the sources' v
+    est_build = (not ctx.sharded) and args.scheme == "systematic" and n <= 8_388_608 and os.environ.get("RR_PF_EST_DEFER", "1") != "0"
+    k1_bytes = (K1_BYTES[args.scheme] + (8.0 if est_build else 0.0)) if not ctx.sharded else 64.0
     achieved = k1_bytes * n / k1_avg_s if k1_avg_s > 0 else 0.0
     step_kernel_ms = {k: (v[1] / max(v[0], 1)) for k, v in kern.items() if v[0]}
     traffic, traffic_src = measured_traffic("k_step_lazy", getattr(args, "traffic_key", "mcl" if (n, L, args.scheme) == (1_000_000, 32, "systematic") else
                                                                    f"mcl_{n}x{L}_{args.scheme}"))
     # FP64-VALU side of the same kernel: f64-rate lane-instructions per particle (a per-pair count
     # times L plus a per-particle count, both read off the ISA and checked against SQ_INSTS_VALU) over the kernel time
-    pair_i, part_i = mcl_instruction_budget()
+    pair_i, part_i = mcl_instruction_budget(est=est_build)
     valu_rate = (pair_i * L + part_i) * n / k1_avg_s if k1_avg_s > 0 else 0.0
     # the multinomial kernel moves whole 128-byte lines for its 8-byte guide pairs and 32-byte source records (iid draws have no
     # locality): what binds it is the MEASURED line traffic (PMC), not the algorithmic bytes and not the FP64 pipe
@@ -951,7 +954,8 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
             "bound": bound,
             "binding_frac": fracs[bound],
             "hbm_frac": achieved / HBM_PEAK,
-            "kernel": ("k_step_lazy (propagate + weight + folded resample gather)" if k1_bytes == 72.0 else
+            "kernel": ("k_step_lazy<EST> (propagate + weight + folded resample gather + the mean of the resampled set it moves)" if k1_bytes == 80.0 else
+                       "k_step_lazy (propagate + weight + folded resample gather)" if k1_bytes == 72.0 else
                        "k_step_lazy<kSrcDraw> (multinomial draws + guide-table search + source gather + propagate + weight)"
                        if (args.scheme == "multinomial" and not ctx.sharded) else "k_propagate_weight"),
             "achieved": achieved / 1e9,
@@ -1203,11 +1207,14 @@ def leg_sharded_world1(args, n, L, K, W, transports=(("p2p", "p2p-only"), ("rccl
     return out
 
 
-def mcl_instruction_budget():
+def mcl_instruction_budget(est=False):
     """(f64-rate lane-instructions per particle-landmark pair, per particle) of k_step_lazy, maintained next to the kernel
-    (rust_robotics_amd/csrc/INSTRUCTION_BUDGET.json, written from the ISA dump by tools/count_isa.py)."""
+    (rust_robotics_amd/csrc/INSTRUCTION_BUDGET.json, written from the ISA dump by tools/count_isa.py); est: the EST build (the
+    step kernel that also adds up the deferred in-step estimate of the step before -- the headline's since round 5)."""
     try:
         d = json.load(open(os.path.join(ROOT, "rust_robotics_amd", "csrc", "INSTRUCTION_BUDGET.json")))
+        if est and isinstance(d.get("est"), dict) and d["est"].get("per_particle"):
+            d = d["est"]
         return float(d["per_pair"]), float(d["per_particle"])
     except Exception:
         return 19.0, 530.0  # round-1 ISA count

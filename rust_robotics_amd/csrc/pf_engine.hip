@@ -1836,12 +1836,17 @@ rr_status rr_pf_step_async_estimate(rr_pf* h, const double control[2], const dou
   if (h && !fused_estimate_available(h))
     return fail(RR_INVALID_PARAMETER, "the in-step estimate needs the fused step (fixed N, one shard, <= 8 388 608 particles); use "
                                       "rr_pf_step / rr_pf_estimate");
-  // Systematic: in the plan kernel.  The deferred form (rr::EstArgs: the resampled set's mean summed by the kernel that moves the
-  // particles, the next step's k_step_lazy) was measured against it at 1e6 x 32, round 4: the plan kernel gets 1 us shorter, the
-  // step kernel 1.6 us longer (profiles/r04d_deferred_estimate_ab.md) -- RR_PF_EST_DEFER=1 selects it for A/B.  Multinomial: always
-  // deferred, the offspring counts of iid draws do not exist before the draws are searched.
+  // The DEFERRED form (rr::EstArgs: the resampled set's mean summed by the kernel that moves the particles, i.e. the next step's
+  // k_step_lazy<., EST>, or by the accessor's gather + k_est_slots when the value is read before another step has come) for both
+  // schemes.  Multinomial: the only form there is (the offspring counts of iid draws do not exist before the draws are searched).
+  // Systematic: since round 5, when the EST build of the step kernel was given the register budget of the plain one (64 VGPRs,
+  // pf_kernels_step.inc: step_blocks_per_cu) -- 47.4 against the in-plan form's 48.5 us per step at 1e6 x 32, one box, alternating
+  // (profiles/r05l_launch_bounds_ab.md; round 4, with the EST build at 93 VGPRs, the deferred form lost by 0.5 us).  What it costs: a
+  // caller that reads the value right after the step (no other step in between) pays the accessor's gather, ~25 us at 1e6 particles,
+  // where the in-plan form pays a 16 KB copy -- the synchronous rr_pf_step, whose caller always does, keeps the in-plan form;
+  // RR_PF_EST_DEFER=0 selects it for rr_pf_step_async_estimate too.  Same value either way to 1e-11 (another order of summation).
   const char* e = std::getenv("RR_PF_EST_DEFER");  // (read per call: the tests switch it within one process)
-  const int sys_mode = e && std::atoi(e) != 0 ? (int)rr::kEstDeferred : (int)rr::kEstInPlan;
+  const int sys_mode = e && std::atoi(e) == 0 ? (int)rr::kEstInPlan : (int)rr::kEstDeferred;
   const bool small = h && small_path(h, 0);
   const int mode = (h && !small && h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC) ? (int)rr::kEstDeferred : sys_mode;
   return step_async_impl(h, control, obs, n_obs, mode);

@@ -373,8 +373,7 @@ def test_in_step_estimate_matches_the_accessor_and_the_reference(loc, ref, mcl, 
     n, L, T = 20_000, 6, 14
     lms = H.landmarks_grid(L, 3)
     kw = dict(seed=7, resample_scheme=scheme)
-    if defer:
-        monkeypatch.setenv("RR_PF_EST_DEFER", "1")
+    monkeypatch.setenv("RR_PF_EST_DEFER", "1" if defer else "0")  # (the systematic scheme's default is the deferred form since round 5)
     if mcl:
         cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.5)
         pf = loc.MonteCarloLocalizer(cfg, **kw)

@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "rust_robotics_amd", "csrc")
 OUT = os.path.join(CSRC, "INSTRUCTION_BUDGET.json")
 KERNEL = "k_step_lazyILb1ELi0ELi0ELb0ELb0EE"  # <OBS_KERNARG = true, SRC = kSrcMarkers, LIK = RR_LIK_FUSED, PACKED = false, EST = false>
+KERNEL_EST = "k_step_lazyILb1ELi0ELi0ELb0ELb1EE"  # ... EST = true: the build that also adds up the deferred in-step estimate (--est)
 ROWS = 2
 
 
@@ -46,7 +47,10 @@ def isa():
         return open(out).read()
 
 
-def kernel_body(text):
+def kernel_body(text, kernel=None):
+    global KERNEL
+    if kernel:
+        KERNEL = kernel
     start = None
     lines = text.splitlines()
     for i, ln in enumerate(lines):
@@ -79,8 +83,10 @@ def main():
     ap.add_argument("--write", action="store_true")
     ap.add_argument("--sq-insts-valu-per-wave", type=float, default=None)
     ap.add_argument("--landmarks", type=int, default=32)
+    ap.add_argument("--est", action="store_true", help="count the EST build (the headline step since round 5: the deferred in-step estimate); "
+                                                       "--write then fills the JSON's \"est\" entry")
     args = ap.parse_args()
-    body = kernel_body(isa())
+    body = kernel_body(isa(), KERNEL_EST if args.est else None)
     cand = [(a, b) for a, b in loops(body) if any("v_rsq_f64" in ln for ln in body[a:b + 1])]
     if not cand:
         sys.exit("no loop with v_rsq_f64 in the kernel")
@@ -105,13 +111,20 @@ def main():
           f"({pairs // ROWS} observations x {ROWS} rows) -> per_pair = {per_pair:.4f}")
     print("  " + ", ".join(f"{k} {v}" for k, v in sorted(ops.items(), key=lambda kv: -kv[1])))
     old = json.load(open(OUT)) if os.path.exists(OUT) else {}
-    per_particle = old.get("per_particle")
-    src_pp = old.get("per_particle_source", "previous value")
+    old_entry = old.get("est", {}) if args.est else old
+    per_particle = old_entry.get("per_particle")
+    src_pp = old_entry.get("per_particle_source", "previous value")
     if args.sq_insts_valu_per_wave is not None:
         per_particle = args.sq_insts_valu_per_wave / ROWS - args.landmarks * per_pair
         src_pp = f"SQ_INSTS_VALU per wave {args.sq_insts_valu_per_wave:g} (rocprofv3 --pmc) / {ROWS} rows - {args.landmarks} x per_pair"
         print(f"per_particle = {per_particle:.1f}  ({src_pp})")
-    if args.write:
+    if args.write and args.est:
+        old["est"] = {"kernel": "k_step_lazy<true, kSrcMarkers, RR_LIK_FUSED, false, EST> (the same + the deferred in-step estimate of the step before)",
+                      "per_pair": round(per_pair, 4), "per_particle": per_particle,
+                      "source": f"tools/count_isa.py --est: {n_valu} VALU instructions for {pairs} pairs in the pair loop", "per_particle_source": src_pp}
+        json.dump(old, open(OUT, "w"), indent=2)
+        print("wrote", OUT, "(est)")
+    elif args.write:
         d = {"kernel": "k_step_lazy<true, kSrcMarkers, RR_LIK_FUSED> (MCL propagate + weight, 10^6 particles x 32 landmarks)",
              "per_pair": round(per_pair, 4), "per_particle": per_particle,
              "source": f"tools/count_isa.py: per_pair = VALU instructions of the pair loop in the gfx950 ISA ({n_valu} for {pairs} pairs: "
@@ -119,6 +132,8 @@ def main():
              "per_particle_source": src_pp}
         if "measured_issue_rate" in old:
             d["measured_issue_rate"] = old["measured_issue_rate"]
+        if "est" in old:
+            d["est"] = old["est"]
         json.dump(d, open(OUT, "w"), indent=2)
         print("wrote", OUT)
 
