@@ -171,7 +171,7 @@ struct rr_pf {
   double* est_partials = nullptr;      // [kFusedMaxTiles][4] per-workgroup sums of the fused per-step estimate
   double* est_partials_host = nullptr; // pinned copy, made when the estimate is read
   double* est_slot_partials = nullptr; // [ceil(cap / kResolveSlots)][waves][4]: the deferred form's sums per slot tile (rr::kEstDeferred)
-  double* est_slot_partials_host = nullptr;
+  double* est_total_dev = nullptr;     // [4]: the slot tiles' sums added up on the device for an accessor (k_est_slots_total)
   bool est_deferred = false;           // the last plan was asked for the deferred form and nobody has moved the particles yet
   uint64_t shard_est_stamp = 0;        // rr_pf_shard_want_estimate: the resample step (rstep, 1-based) whose sums were asked for last
   bool shard_est = false;              // rr_pf_shard_want_estimate: every window step of this shard leaves its part of the mean
@@ -1558,7 +1558,7 @@ void rr_pf_destroy(rr_pf* h) {
   (void)hipFree(h->est_partials);
   if (h->est_partials_host) (void)hipHostFree(h->est_partials_host);
   (void)hipFree(h->est_slot_partials);
-  if (h->est_slot_partials_host) (void)hipHostFree(h->est_slot_partials_host);
+  (void)hipFree(h->est_total_dev);
   (void)hipFree(h->steps_dev);
   (void)hipFree(h->est_ring);
   if (h->mail) (void)hipHostFree(h->mail);
@@ -1852,20 +1852,15 @@ rr_status rr_pf_step_async_estimate(rr_pf* h, const double control[2], const dou
   return step_async_impl(h, control, obs, n_obs, mode);
 }
 
-// est_slots_total on the host: the three-level order of k_est_mail_any (interleaved chunks, groups of chunks, the groups in order)
-static void est_slots_total_host(const double* part, uint64_t n_part, double acc[4]) {
-  static thread_local std::vector<double> cs;
-  cs.assign((size_t)4 * kEstChunks, 0.0);
-  for (int k = 0; k < 4; ++k) acc[k] = 0.0;
-  for (int c = 0; c < kEstChunks; ++c)
-    for (uint64_t t = (uint64_t)c; t < n_part; t += kEstChunks)
-      for (int k = 0; k < 4; ++k) cs[(size_t)4 * c + k] += part[4 * t + k];
-  for (int g = 0; g < kEstGroups; ++g) {
-    double gs[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int c = g; c < kEstChunks; c += kEstGroups)
-      for (int k = 0; k < 4; ++k) gs[k] += cs[(size_t)4 * c + k];
-    for (int k = 0; k < 4; ++k) acc[k] += gs[k];
-  }
+// The slot tiles' sums of the deferred estimate, added up ON THE DEVICE by k_est_slots_total (the three-level order of k_est_mail_any:
+// the same bits as the synchronous step's mailbox kernel): the host fetches four doubles, and the stamp behind the sums if asked.
+static rr_status est_slots_total(rr_pf* h, uint64_t n_part, double acc[4], uint64_t* stamp) {
+  if (!h->est_total_dev) RR_HIP_TRY(hipMalloc(&h->est_total_dev, 4 * sizeof(double)));
+  hipLaunchKernelGGL(k_est_slots_total, dim3(1), dim3(kEstChunks), 0, h->stream, (const double*)h->est_slot_partials, n_part, h->est_total_dev);
+  RR_HIP_TRY(hipGetLastError());
+  RR_HIP_TRY(hipMemcpyAsync(acc, h->est_total_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (stamp) RR_HIP_TRY(hipMemcpyAsync(stamp, est_stamp_slot(h), sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  return RR_OK;  // (the caller's fetch_ctl waits for the stream)
 }
 
 rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]) {
@@ -1879,23 +1874,18 @@ rr_status rr_pf_last_step_estimate(rr_pf* h, double out[4]) {
   if (!h->est_partials_host) RR_HIP_TRY(hipHostMalloc(&h->est_partials_host, (size_t)rr::kFusedMaxTiles * 4 * sizeof(double)));
   RR_HIP_TRY(hipMemcpyAsync(h->est_partials_host, h->est_partials, (size_t)h->n_tiles * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   const uint64_t n_slot_tiles = grid_for(h->n, rr::kResolveSlots);
-  if (h->est_slot_partials) {
-    if (!h->est_slot_partials_host)
-      RR_HIP_TRY(hipHostMalloc(&h->est_slot_partials_host, est_slot_bytes(h)));
-    RR_HIP_TRY(hipMemcpyAsync(h->est_slot_partials_host, h->est_slot_partials, (size_t)n_slot_tiles * kEstSlotWords * sizeof(double),
-                              hipMemcpyDeviceToHost, h->stream));
-  }
+  double slot_total[4] = {0.0, 0.0, 0.0, 0.0};
+  if (h->est_slot_partials && (s = est_slots_total(h, n_slot_tiles * (kBlock / rr::kWave), slot_total, nullptr)) != RR_OK) return s;
   if ((s = fetch_ctl(h)) != RR_OK) return s;  // (synchronises the stream)
   if (h->ctl_host->est_step == 0) return fail(RR_INVALID_PARAMETER, "no step has produced an in-step estimate yet");
-  // the tiles' partial sums in tile order (a fixed order: the same bits whichever kernel produced them)
   const bool slots = h->ctl_host->est_kind == rr::kEstSlotTiles;
   if (slots && !h->est_slot_partials) return fail(RR_RUNTIME_ERROR, "the deferred estimate's sums are missing");
-  const double* part = slots ? h->est_slot_partials_host : h->est_partials_host;
-  const uint64_t n_part = slots ? n_slot_tiles * (kBlock / rr::kWave) : h->n_tiles;  // (slot tiles: one entry per wave)
   double acc[4] = {0.0, 0.0, 0.0, 0.0};
   if (slots) {
-    est_slots_total_host(part, n_part, acc);
-  } else {  // est_plan_total's order: interleaved chunks of tiles, then the chunks in order
+    for (int k = 0; k < 4; ++k) acc[k] = slot_total[k];
+  } else {  // the plan tiles' partial sums in est_plan_total's order: interleaved chunks of tiles, then the chunks in order
+    const double* part = h->est_partials_host;
+    const uint64_t n_part = h->n_tiles;
     double cs[kEstPlanChunks][4] = {};
     for (int c = 0; c < kEstPlanChunks; ++c)
       for (uint64_t t = (uint64_t)c; t < n_part; t += kEstPlanChunks)
@@ -2651,18 +2641,14 @@ rr_status rr_pf_shard_last_estimate_sums(rr_pf* h, double out_sums[4], double* o
   if (h->est_deferred && (s = materialise(h)) != RR_OK) return s;  // nobody has moved the particles yet: gather + k_est_slots
   if (h->est_deferred) launch_est_slots(h);
   const uint64_t n_part = (uint64_t)grid_for(h->n, rr::kResolveSlots) * (kBlock / rr::kWave);
-  if (!h->est_slot_partials_host)
-    RR_HIP_TRY(hipHostMalloc(&h->est_slot_partials_host, est_slot_bytes(h)));
-  RR_HIP_TRY(hipMemcpyAsync(h->est_slot_partials_host, h->est_slot_partials, (size_t)n_part * 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  uint64_t* const stamp_host = reinterpret_cast<uint64_t*>(h->est_slot_partials_host + (size_t)grid_for(h->cap, rr::kResolveSlots) * kEstSlotWords);
-  RR_HIP_TRY(hipMemcpyAsync(stamp_host, est_stamp_slot(h), sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  uint64_t stamp = 0;
+  if ((s = est_slots_total(h, n_part, out_sums, &stamp)) != RR_OK) return s;
   if ((s = fetch_ctl(h)) != RR_OK) return s;
   // The sums carry the resample step they were formed for (written by the kernel that formed them, only when that step's gate
   // fired).  Asked for was step shard_est_stamp -- the last step taken with rr_pf_shard_want_estimate on, however many plain
   // steps followed (the live Ctl.fired belongs to the LATEST step, not to that one).
-  if (*stamp_host != h->shard_est_stamp)
+  if (stamp != h->shard_est_stamp)
     return fail(RR_INVALID_PARAMETER, "the gate of the step whose estimate was asked for stayed shut: no resampled set to take the mean of");
-  est_slots_total_host(h->est_slot_partials_host, n_part, out_sums);
   *out_denom = (double)h->n_global;
   return RR_OK;
 }
