@@ -98,10 +98,11 @@ DEVICE_WARMUP_FS = 60
 FS1_BYTES_PER_UPDATE = 96.0  # k_fs1_observe: read 48 B + write 48 B per (particle, observed landmark), EKF branch
 
 
-def measured_traffic(kernel_prefix, workload):
+def measured_traffic(kernel_prefix, workload, est=None):
     """HBM bytes per launch of `kernel_prefix` from the committed PMC passes (separate rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE runs, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    Newest round first; None if no file has the row."""
+    Newest round first; None if no file has the row.  `est`: of k_step_lazy's instantiations the one whose last template
+    argument (EST: the build that also adds up the deferred estimate) is this."""
     import csv
     import glob
 
@@ -109,6 +110,8 @@ def measured_traffic(kernel_prefix, workload):
     for name, wl in [(f, workload) for f in newest] + [("r01f_pmc_hbm_traffic_fastslam_timed_region.csv", workload + "_timed_region")]:
         try:
             rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", name))) if r["workload"] == wl and r["kernel"].startswith(kernel_prefix)]
+            if est is not None and any(r["kernel"].endswith((",true>", ",false>")) for r in rows):
+                rows = [r for r in rows if r["kernel"].endswith(",true>" if est else ",false>")]
             if rows:  # several instantiations of one kernel in a run (a warm-up variant): the one that did the timed launches
                 r = max(rows, key=lambda q: int(q["dispatches"]))
                 return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6, "profiles/" + name
@@ -914,7 +917,8 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
     achieved = k1_bytes * n / k1_avg_s if k1_avg_s > 0 else 0.0
     step_kernel_ms = {k: (v[1] / max(v[0], 1)) for k, v in kern.items() if v[0]}
     traffic, traffic_src = measured_traffic("k_step_lazy", getattr(args, "traffic_key", "mcl" if (n, L, args.scheme) == (1_000_000, 32, "systematic") else
-                                                                   f"mcl_{n}x{L}_{args.scheme}"))
+                                                                   f"mcl_{n}x{L}_{args.scheme}"),
+                                              est=est_build if args.scheme == "systematic" else None)
     # FP64-VALU side of the same kernel: f64-rate lane-instructions per particle (a per-pair count
     # times L plus a per-particle count, both read off the ISA and checked against SQ_INSTS_VALU) over the kernel time
     pair_i, part_i = mcl_instruction_budget(est=est_build)
