@@ -63,9 +63,9 @@ enum { kP2PWmax = 0, kP2PSums = 1, kP2PDone = 2 };
 
 __device__ inline P2PPairSlot* p2p_pairs(P2PMailbox* m, int kind, int idx) { return kind == kP2PWmax ? &m->wmax[idx] : &m->sums[idx]; }
 
-// One exchange round, executed block-uniformly by a workgroup of >= 64 threads (thread g < n_ranks
-// talks to peer g).  payload (valid in every thread g < n_ranks): kind WMAX -> {bits of the local
-// max weight}, SUMS -> {T, q2_hi, q2_lo}, DONE -> nothing.  Every rank's payload is collected in LDS
+// One exchange round, executed block-uniformly by a workgroup of >= 64 threads (WMAX / DONE: thread g < n_ranks
+// talks to peer g; SUMS: thread 3 g + k trades word k with peer g).  payload (valid in every thread of the first
+// wave): kind WMAX -> {bits of the local max weight}, SUMS -> {T, q2_hi, q2_lo}, DONE -> nothing.  Every rank's payload is collected in LDS
 // (gathered[g*3..]).  Post-processing by thread 0: WMAX -> *wmax_out = global max; SUMS -> finalize_plan with
 // the global totals (what k_shard_plan does in the RCCL path).
 // (Until round 5 the payloads were collected in a scratch array in DEVICE memory, with ordinary stores and loads.  Inside
@@ -75,53 +75,60 @@ __device__ inline P2PPairSlot* p2p_pairs(P2PMailbox* m, int kind, int idx) { ret
 // 0's maximum instead of the sum just stored -- T = the bit pattern of w_max, a wrong resample, ~1 in 150 runs of a 5 000-particle
 // shard stepping beside another filter: tools/soak_shard_estimate.py, profiles/r05_shard_race.md.  Nothing that only one
 // workgroup needs has any business in device memory.)
+// `totals` (SUMS, optional, LDS): thread 0 leaves the global total, this rank's base, its local total and the squares' sum there
+// INSTEAD of running finalize_plan -- the caller has something more urgent to do with them first (k_shard_plan_mark: tell the
+// waiting workgroups) and finalizes afterwards; ok = 0 when the exchange gave up.
+struct P2PSumsTotals {
+  uint64_t total, base, local;
+  u128 q2;
+  int ok;
+};
 __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t seq, uint64_t v0, uint64_t v1, uint64_t v2,
-                                    Ctl* __restrict__ ctl, double* __restrict__ wmax_out, const PlanArgs& pa, int* __restrict__ err) {
-  __shared__ int s_bad;
+                                    Ctl* __restrict__ ctl, double* __restrict__ wmax_out, const PlanArgs& pa, int* __restrict__ err,
+                                    P2PSumsTotals* totals = nullptr) {
   __shared__ uint64_t gathered[3 * kMaxP2P];
   const int g = threadIdx.x;
-  // once a wait has given up, every later exchange of this filter gives up at once (the host
-  // reads the flag with rr_pf_p2p_status); only the first one costs the timeout
-  if (g == 0) s_bad = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (g < peers.n_ranks && !s_bad && kind != kP2PDone) {
-    // WMAX (one word) / SUMS (three): self-vouching pairs, see P2PPairSlot
-    const int n_words = kind == kP2PWmax ? 1 : 3;
-    const uint64_t v[3] = {v0, v1, v2};
-    P2PPairSlot* out = p2p_pairs(peers.mbox[g], kind, peers.rank);
-    for (int k = 0; k < n_words; ++k) store_pair_sys(&out->p[k], v[k], p2p_tag(seq, v[k]));
-    const P2PPairSlot* in = p2p_pairs(peers.mbox[peers.rank], kind, g);
+  const int n_words = kind == kP2PWmax ? 1 : 3;
+  // a peer is gone: do not hang the device.  The first exchanges of a filter get ten times the
+  // budget -- process start-up and code-object loading skew the ranks by far more than a step does
+  const uint64_t patience = seq <= 3 ? 10 * peers.timeout_ticks : peers.timeout_ticks;
+  // Once a wait has given up, every later exchange of this filter gives up at once (the host reads the flag with
+  // rr_pf_p2p_status); only the first one costs the time-out.  The flag is looked at when a record is NOT there at the first
+  // look -- not up front, where it was a device-scope round trip and a barrier on the critical path of every exchange.
+  bool bad = false;
+  if (kind != kP2PDone && g < n_words * peers.n_ranks) {
+    // WMAX (one word) / SUMS (three): self-vouching pairs, see P2PPairSlot.  One LANE per pair -- thread 3 r + k sends word k to
+    // rank r and waits for word k of rank r -- so that a look at a peer's record is one round trip to the mailbox, not three one
+    // after the other (a pair is read by ONE instruction that waits for its answer; until round 5 one thread per peer read the three
+    // pairs of a SUMS record in turn: tools/shard_plan_timeline.py)
+    const int r = g / n_words, k = g - r * n_words;
+    const uint64_t mine = k == 0 ? v0 : (k == 1 ? v1 : v2);
+    store_pair_sys(&p2p_pairs(peers.mbox[r], kind, peers.rank)->p[k], mine, p2p_tag(seq, mine));
+    const MailPair* in = &p2p_pairs(peers.mbox[peers.rank], kind, r)->p[k];
     const uint64_t t0 = wall_clock64();  // 100 MHz
-    uint64_t got[3] = {0, 0, 0}, tag[3] = {0, 0, 0};
-    bool ok = false;
-    for (;;) {
-      bool all = true;
-      for (int k = 0; k < n_words; ++k) {
-        load_pair_sys(&in->p[k], got[k], tag[k]);
-        all &= tag[k] == p2p_tag(seq, got[k]);
-      }
-      if (all) {
-        ok = true;
+    uint64_t got = 0, tag = 0;
+    for (unsigned looks = 0;; ++looks) {
+      load_pair_sys(in, got, tag);
+      if (tag == p2p_tag(seq, got)) break;
+      if (looks == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        bad = true;  // (the transport gave up earlier)
         break;
       }
-      // a peer is gone: do not hang the device.  The first exchanges of a filter get ten times the
-      // budget -- process start-up and code-object loading skew the ranks by far more than a step does
-      if (wall_clock64() - t0 > (seq <= 3 ? 10 * peers.timeout_ticks : peers.timeout_ticks)) break;
+      if (wall_clock64() - t0 > patience) {
+        bad = true;
+        if (atomicCAS(err, 0, kind == kP2PWmax ? kGaveUpWmax : kGaveUpSums) == 0) {  // the FIRST give-up names the wait and says what it saw
+          uint64_t* d = reinterpret_cast<uint64_t*>(err) + 1;  // (the flag's allocation has room for this: P2PState::local_setup)
+          d[0] = (uint64_t)r;
+          d[1] = seq;
+          d[2] = tag ^ (got * 0x9E3779B97F4A7C15ull);  // the sequence number the pair that IS there vouches for
+          d[3] = seq;                                   // (this rank's own record went out before the wait)
+        }
+        break;
+      }
       __builtin_amdgcn_s_sleep(8);
     }
-    if (!ok) {
-      uint64_t* d = reinterpret_cast<uint64_t*>(err) + 1;  // (the flag's allocation has room for this: P2PState::local_setup)
-      d[0] = (uint64_t)g;
-      d[1] = seq;
-      d[2] = tag[0] ^ (got[0] * 0x9E3779B97F4A7C15ull);  // the sequence number the first pair that IS there vouches for
-      d[3] = seq;                                          // (this rank's own record went out before the wait)
-      atomicExch(&s_bad, 1);
-    } else {
-      gathered[3 * g] = got[0];
-      gathered[3 * g + 1] = got[1];
-      gathered[3 * g + 2] = got[2];
-    }
-  } else if (g < peers.n_ranks && !s_bad) {
+    if (!bad) gathered[3 * r + k] = got;
+  } else if (kind == kP2PDone && g < peers.n_ranks) {
     // DONE of the eager / FastSLAM protocols vouches for bulk data written with ORDINARY stores by other workgroups and
     // earlier kernels: a full system-scope release (L2 write-back) has to come first, the stamp is a release store and the
     // wait an acquire
@@ -130,30 +137,31 @@ __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t se
     __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     P2PSlot* in = &peers.mbox[peers.rank]->done[g];
     const uint64_t t0 = wall_clock64();
-    bool ok = true;
-    while (__hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
-      __builtin_amdgcn_s_sleep(8);
-      if (wall_clock64() - t0 > (seq <= 3 ? 10 * peers.timeout_ticks : peers.timeout_ticks)) {
-        ok = false;
+    for (unsigned looks = 0; __hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq; ++looks) {
+      if (looks == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        bad = true;
         break;
       }
-    }
-    if (!ok) {
-      uint64_t* d = reinterpret_cast<uint64_t*>(err) + 1;
-      d[0] = (uint64_t)g;
-      d[1] = seq;
-      d[2] = __hip_atomic_load(&in->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      d[3] = __hip_atomic_load(&out->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      atomicExch(&s_bad, 1);
+      if (wall_clock64() - t0 > patience) {
+        bad = true;
+        if (atomicCAS(err, 0, kGaveUpRecord) == 0) {
+          uint64_t* d = reinterpret_cast<uint64_t*>(err) + 1;
+          d[0] = (uint64_t)g;
+          d[1] = seq;
+          d[2] = __hip_atomic_load(&in->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          d[3] = __hip_atomic_load(&out->seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
     }
   }
-  __threadfence_block();
-  __syncthreads();
+  const int any_bad = __syncthreads_or(bad ? 1 : 0);  // (also: gathered[] is complete for thread 0)
   if (g != 0) return;
-  if (s_bad) {
-    (void)atomicCAS(err, 0, kind == kP2PWmax ? kGaveUpWmax : (kind == kP2PSums ? kGaveUpSums : kGaveUpRecord));  // the FIRST give-up names the wait
+  if (any_bad) {
     ctl->fired = 0;  // nothing downstream may act on incomplete data
     if (kind == kP2PWmax) *wmax_out = 0.0;
+    if (totals) totals->ok = 0;
     return;
   }
   if (kind == kP2PWmax) {
@@ -171,7 +179,15 @@ __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t se
       total += gathered[3 * k];
       qq = add128(qq, u128{gathered[3 * k + 1], gathered[3 * k + 2]});
     }
-    finalize_plan(ctl, total, base, gathered[3 * peers.rank], qq, pa);
+    if (totals) {
+      totals->total = total;
+      totals->base = base;
+      totals->local = gathered[3 * peers.rank];
+      totals->q2 = qq;
+      totals->ok = 1;
+    } else {
+      finalize_plan(ctl, total, base, gathered[3 * peers.rank], qq, pa);
+    }
   }
 }
 
@@ -339,12 +355,14 @@ __device__ inline bool wait_pairs(const TagPair* const (&p)[N], uint64_t epoch, 
 static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
     P2PPeers peers, uint64_t seq, const double* __restrict__ w, Ctl* __restrict__ ctl, ImageArgs a, uint64_t* __restrict__ rec,
     unsigned int* __restrict__ ticket, uint64_t epoch, int settle, uint64_t n_tiles, PlanArgs pa,
-    unsigned int* __restrict__ markers, unsigned int* __restrict__ carry, int* __restrict__ err, uint64_t slot_pad
+    unsigned int* __restrict__ markers, unsigned int* __restrict__ carry, int* __restrict__ err, uint64_t slot_pad, int wmax_posted
 #if defined(RR_DEBUG_TRACE)
     , uint64_t* trace
 #endif
     ) {
   constexpr int W = kTileBlock / kWave;
+  __shared__ uint64_t s_posted[kMaxP2P];
+  __shared__ P2PSumsTotals s_tot;
   __shared__ uint64_t s4[4 * W];
   __shared__ uint64_t s_w[W];
   __shared__ uint64_t s_pay[3];
@@ -355,32 +373,84 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
   uint64_t* const flag0 = rec + n_tiles * kRecWords;  // the two state words of the launch (= epoch when raised)
   uint64_t* const flag1 = flag0 + 1;
   const uint64_t limit = 12 * peers.timeout_ticks;
+#if defined(RR_PLAN_TIMELINE)
+  // instrumented build (tools/shard_plan_timeline.py): 0 start, 1 the global maximum known, 2 record stored, 3 ticket taken,
+  // 4 prefix + totals seen, 5 markers written; the last arrival alone: 6 records scanned (before the SUMS exchange), 7 sums traded
+  uint64_t* const tl = rec + (kTileBlock + 1) * kRecWords + 16;
+#endif
+  RR_TL(0);
   // reads of Ctl that the last arrival's settle / finalize could race with come first (they precede this workgroup's ticket)
   const bool forced_uniform = a.honour_uniform_flag && ctl->weights_uniform;
   // ---- 0: the global maximum
-  if (blockIdx.x == 0) {
-    const uint64_t local_bits = ctl->wmax_bits;
-    p2p_exchange(peers, kP2PWmax, seq, local_bits, 0, 0, ctl, &s_wmax, pa, err);  // thread 0 leaves the maximum in s_wmax
-    if (tid == 0) {
-      put_pair(&pp[kTileBlock + 5], rr_d2u(s_wmax), epoch);  // vouches for itself (resample_core.hpp, TagPair): the flag follows at once
-      st_dev(flag0, epoch);
-#if defined(RR_DEBUG_TRACE)
-      if (trace) {
-        trace[10] = local_bits;
-        trace[11] = rr_d2u(s_wmax);
-        trace[12] = seq;
-        trace[13] = epoch;
+  if (wmax_posted) {
+    // RR_P2P_WMAX_EARLY=1 (off by default, pf_engine.hip: rr_pf_shard_step_p2p): the ranks' maxima are already on their way, or
+    // here -- the last workgroup of every rank's STEP kernel sent its shard's maximum to every mailbox as it finished
+    // (k_step_lazy<kSrcWindow>, WindowArgs.post_peers).  Every workgroup takes them from this rank's own mailbox itself -- n_ranks
+    // self-vouching pairs, one round trip to local memory -- instead of workgroup 0 opening the launch with an exchange (store,
+    // fabric, poll) and a flag for the others to wait on.  This kernel gets 1.65 us shorter by it and the step kernel as much
+    // longer (profiles/r05o_wmax_early.md).  (The records cannot be overwritten while somebody still reads them: a rank sends the
+    // next maximum after its plan kernel has traded the SUMS of this sequence number, which every rank posts only after ALL its
+    // workgroups have passed this point -- they need the maximum to form the records the last arrival adds up.)
+    if (tid < peers.n_ranks) {
+      const P2PPairSlot* in = &peers.mbox[peers.rank]->wmax[tid];
+      uint64_t got = 0, tag = 0;
+      bool ok = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;  // (a transport that gave up stays down)
+      const uint64_t t0 = wall_clock64();
+      while (ok) {
+        load_pair_sys(&in->p[0], got, tag);
+        if (tag == p2p_tag(seq, got)) break;
+        if (wall_clock64() - t0 > (seq <= 3 ? 10 * peers.timeout_ticks : peers.timeout_ticks)) {
+          ok = false;
+          if (atomicCAS(err, 0, kGaveUpWmax) == 0) {  // the first give-up names the wait and says what it saw
+            uint64_t* d = reinterpret_cast<uint64_t*>(err) + 1;
+            d[0] = (uint64_t)tid;
+            d[1] = seq;
+            d[2] = tag ^ (got * 0x9E3779B97F4A7C15ull);
+            d[3] = seq;
+          }
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
       }
+      s_posted[tid] = ok ? got : ~0ull;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double m = 0.0;
+      bool ok = true;
+      for (int k = 0; k < peers.n_ranks; ++k) {
+        ok &= s_posted[k] != ~0ull;
+        const double wk = rr_u2d(s_posted[k]);
+        if (wk > m) m = wk;
+      }
+      s_wmax = ok ? m : 0.0;  // (gave up: the SUMS exchange below sees the flag, shuts the gate, and nothing is marked)
+    }
+  } else {
+    if (blockIdx.x == 0) {
+      const uint64_t local_bits = ctl->wmax_bits;
+      p2p_exchange(peers, kP2PWmax, seq, local_bits, 0, 0, ctl, &s_wmax, pa, err);  // thread 0 leaves the maximum in s_wmax
+      if (tid == 0) {
+        put_pair(&pp[kTileBlock + 5], rr_d2u(s_wmax), epoch);  // vouches for itself (resample_core.hpp, TagPair): the flag follows at once
+        st_dev(flag0, epoch);
+#if defined(RR_DEBUG_TRACE)
+        if (trace) {
+          trace[10] = local_bits;
+          trace[11] = rr_d2u(s_wmax);
+          trace[12] = seq;
+          trace[13] = epoch;
+        }
 #endif
+      }
+    }
+    if (tid == 0) {
+      const TagPair* const want[1] = {&pp[kTileBlock + 5]};
+      uint64_t got[1] = {0};
+      if (!wait_flag(flag0, epoch, limit) || !wait_pairs<1>(want, epoch, limit, got)) (void)atomicCAS(err, 0, kGaveUpPlanFlag);
+      s_wmax = rr_u2d(got[0]);
     }
   }
-  if (tid == 0) {
-    const TagPair* const want[1] = {&pp[kTileBlock + 5]};
-    uint64_t got[1] = {0};
-    if (!wait_flag(flag0, epoch, limit) || !wait_pairs<1>(want, epoch, limit, got)) (void)atomicCAS(err, 0, kGaveUpPlanFlag);
-    s_wmax = rr_u2d(got[0]);
-  }
   __syncthreads();
+  RR_TL(1);
   const double wmax = s_wmax;
   // ---- A: the integer image of this tile (k_quantize_plan_mark, phase A)
   const bool usable = !forced_uniform && wmax > 0.0 && wmax < INFINITY;
@@ -422,7 +492,9 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
     st_dev(&r[1], qq.hi);
     st_dev(&r[2], qq.lo);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RR_TL(2);
     s_last = last_arrival(ticket, blockIdx.x, (unsigned int)n_tiles, /*fence=*/false) ? 1 : 0;
+    RR_TL(3);
   }
   __syncthreads();
   // ---- the last arrival: prefixes, this shard's sums, Ctl, the exchange with the peers, flag 1
@@ -469,33 +541,49 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
       ctl->total_local = tt;
     }
     __syncthreads();
-    p2p_exchange(peers, kP2PSums, seq, s_pay[0], s_pay[1], s_pay[2], ctl, &ctl->wmax, pa, err);
-    if (tid == 0) {  // finalize_plan has run in this thread: Ctl holds base, the global totals, the gate decision
-#if defined(RR_DEBUG_TRACE)
-      if (trace) {
-        trace[14] = s_pay[0];
-        trace[15] = ctl->total;
-        trace[16] = (uint64_t)ctl->fired;
-        trace[17] = (uint64_t)ctl->pending;
-        trace[18] = (uint64_t)ctl->cur;
-        trace[19] = ctl->base;
-        trace[20] = ctl->q2_lo;
-        trace[21] = ctl->served_first;
-        trace[22] = ctl->served_count;
-        trace[23] = (uint64_t)(unsigned int)ctl->shift;
-        trace[24] = (uint64_t)blockIdx.x;
-        trace[25] = rr_d2u(wmax);
-        trace[26] = rr_d2u(ctl->rho);
-        trace[27] = (uint64_t)ctl->image_mode;
-        trace[28] = wall_clock64();
-      }
-#endif
-      put_pair(&pp[kTileBlock + 0], ctl->base, epoch);
-      put_pair(&pp[kTileBlock + 1], ctl->total, epoch);
-      put_pair(&pp[kTileBlock + 2], (uint64_t)ctl->fired, epoch);
+    RR_TL(6);
+    p2p_exchange(peers, kP2PSums, seq, s_pay[0], s_pay[1], s_pay[2], ctl, &ctl->wmax, pa, err, &s_tot);
+    RR_TL(7);
+    if (tid == 0) {
+      // What everybody is waiting for goes out FIRST: this rank's base, the global total, the gate's decision.  What finalize_plan
+      // leaves in Ctl -- the sums, the plan, the served range: a 64-bit division, two 128-bit slot counts -- is for LATER kernels
+      // and follows below, while the other workgroups mark (until round 5 it came first: 2.1 us of one thread on everybody's
+      // critical path, tools/shard_plan_timeline.py).
+      TileSums ts;
+      ts.pre = 0;
+      ts.tot = s_tot.total;
+      ts.q2 = s_tot.q2;
+      const int fire = s_tot.ok ? gate_decision(mode, ts, pa) : 0;  // (gave up: Ctl.fired is 0, nothing is marked)
+      put_pair(&pp[kTileBlock + 0], s_tot.base, epoch);
+      put_pair(&pp[kTileBlock + 1], s_tot.total, epoch);
+      put_pair(&pp[kTileBlock + 2], (uint64_t)fire, epoch);
       st_dev(flag1, epoch);  // (right behind the pairs, not after their acknowledgement: they vouch for themselves)
     }
   }
+  // the plan's one uniform: drawn while this workgroup has nothing to do but wait; the last arrival draws it now that everybody
+  // has been told, and leaves in Ctl what later kernels need
+  double rho = s_last ? plan_rho(pa) : plan_rho_early(pa);
+  if (s_last && tid == 0 && s_tot.ok) finalize_plan(ctl, s_tot.total, s_tot.base, s_tot.local, s_tot.q2, pa, rho, mode, shift);
+#if defined(RR_DEBUG_TRACE)
+  if (s_last && tid == 0 && trace) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    trace[14] = s_pay[0];
+    trace[15] = ctl->total;
+    trace[16] = (uint64_t)ctl->fired;
+    trace[17] = (uint64_t)ctl->pending;
+    trace[18] = (uint64_t)ctl->cur;
+    trace[19] = ctl->base;
+    trace[20] = ctl->q2_lo;
+    trace[21] = ctl->served_first;
+    trace[22] = ctl->served_count;
+    trace[23] = (uint64_t)(unsigned int)ctl->shift;
+    trace[24] = (uint64_t)blockIdx.x;
+    trace[25] = rr_d2u(wmax);
+    trace[26] = rr_d2u(ctl->rho);
+    trace[27] = (uint64_t)ctl->image_mode;
+    trace[28] = wall_clock64();
+  }
+#endif
   // ---- everybody: this tile's prefix, the base, the global total and the gate decision, as soon as they vouch for this launch
   if (tid == 0) {
     const TagPair* const want[4] = {&pp[blockIdx.x], &pp[kTileBlock + 0], &pp[kTileBlock + 1], &pp[kTileBlock + 2]};
@@ -508,6 +596,7 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
     s4[3] = ok ? got[3] : 0;  // gave up: as if the gate were shut -- nothing is marked with unknown sums
   }
   __syncthreads();
+  RR_TL(4);
   const uint64_t pre = s4[0], base = s4[1], total = s4[2];
   const bool fired = s4[3] != 0;
 #if defined(RR_DEBUG_TRACE)
@@ -516,16 +605,12 @@ static __global__ __launch_bounds__(kTileBlock) void k_shard_plan_mark(
 #endif
   if (fired) {
     // ---- B: k_mark
-    double rho = pa.rho_override;
-    if (rho != rho) {
-      double dummy;
-      rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
-    }
     const rr_sys_plan plan = rr_sys_plan_make(rho, total, pa.n_global);
     // marker position of global slot s: s + slot_pad (resolve_tile_window); the overhang over the own block is
     // k_push_window's (see docs/DESIGN_NOTES.md section 5 for the variant that delivered it from here, and why it lost)
     mark_sources(t, base + pre + t.thread_off, i0, a.n, plan, total, (uint64_t)0 - slot_pad, markers, carry);
   }
+  RR_TL(5);
 }
 
 // ---- host side: what a handle owns for the transport
@@ -542,6 +627,9 @@ struct P2PState {
   uint64_t* scratch = nullptr;  // [4] local payload of the stand-alone exchanges (behind 3 * kMaxP2P words no longer used)
   int* err = nullptr;           // device: set when a wait timed out
   int* err_host = nullptr;
+  P2PPeers* peers_dev = nullptr;       // `peers` in device memory, for the kernel that posts a record without being handed the struct
+                                       // (k_step_lazy<kSrcWindow>: WindowArgs.post_peers)
+  unsigned int* post_ticket = nullptr; // kTicketWords: "the last workgroup of the step kernel" (zero between launches)
 
   uint64_t* local3() const { return scratch + 3 * kMaxP2P; }
 
@@ -553,6 +641,10 @@ struct P2PState {
     inbox = nullptr;
     (void)hipFree(scratch);
     (void)hipFree(err);
+    (void)hipFree(peers_dev);
+    (void)hipFree(post_ticket);
+    peers_dev = nullptr;
+    post_ticket = nullptr;
     if (err_host) (void)hipHostFree(err_host);
     mbox = nullptr;
     scratch = nullptr;
@@ -590,7 +682,17 @@ struct P2PState {
     RR_HIP_TRY(hipMalloc(&err, 64));  // the flag + 7 words of detail a give-up leaves behind (kP2PErrWords)
     RR_HIP_TRY(hipMemset(err, 0, 64));
     RR_HIP_TRY(hipHostMalloc(&err_host, 64));
+    RR_HIP_TRY(hipMalloc(&peers_dev, sizeof(P2PPeers)));
+    RR_HIP_TRY(hipMalloc(&post_ticket, kTicketWords * sizeof(unsigned int)));
+    RR_HIP_TRY(hipMemset(post_ticket, 0, kTicketWords * sizeof(unsigned int)));
     RR_HIP_TRY(hipDeviceSynchronize());
+    return RR_OK;
+  }
+
+  // the connection is made: `peers` goes to device memory as well (synchronous: nothing of this handle runs yet)
+  rr_status publish_peers() {
+    RR_HIP_TRY(hipMemcpy(peers_dev, &peers, sizeof(P2PPeers), hipMemcpyHostToDevice));
+    RR_HIP_TRY(hipMemset(post_ticket, 0, kTicketWords * sizeof(unsigned int)));
     return RR_OK;
   }
 
@@ -649,6 +751,7 @@ struct P2PState {
     }
     p.timeout_ticks = timeout_ticks_from_env();
     peers = p;
+    if ((s = publish_peers()) != RR_OK) return s;
     ready = true;
     seq = 0;
     return RR_OK;
@@ -718,6 +821,7 @@ inline rr_status p2p_link_local(P2PState* const* states, double* const* slabs, c
     }
     p.timeout_ticks = P2PState::timeout_ticks_from_env();
     states[g]->peers = p;
+    if (rr_status s = states[g]->publish_peers(); s != RR_OK) return s;
     states[g]->ready = true;
     states[g]->seq = 0;
     states[g]->n_sharing = 0;

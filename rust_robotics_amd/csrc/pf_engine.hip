@@ -1857,9 +1857,11 @@ rr_status rr_pf_step_async_estimate(rr_pf* h, const double control[2], const dou
 static rr_status est_slots_total(rr_pf* h, uint64_t n_part, double acc[4], uint64_t* stamp) {
   if (!h->est_total_dev) RR_HIP_TRY(hipMalloc(&h->est_total_dev, 4 * sizeof(double)));
   hipLaunchKernelGGL(k_est_slots_total, dim3(1), dim3(kEstChunks), 0, h->stream, (const double*)h->est_slot_partials, n_part, h->est_total_dev);
-  RR_HIP_TRY(hipGetLastError());
-  RR_HIP_TRY(hipMemcpyAsync(acc, h->est_total_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  if (stamp) RR_HIP_TRY(hipMemcpyAsync(stamp, est_stamp_slot(h), sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+  hipError_t copies = hipGetLastError();
+  if (copies == hipSuccess) copies = hipMemcpyAsync(acc, h->est_total_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+  if (copies == hipSuccess && stamp) copies = hipMemcpyAsync(stamp, est_stamp_slot(h), sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream);
+  if (copies != hipSuccess) (void)hipStreamSynchronize(h->stream);  // (acc / stamp are the caller's locals: nothing may still be on its way there)
+  RR_HIP_TRY(copies);
   return RR_OK;  // (the caller's fetch_ctl waits for the stream)
 }
 
@@ -2536,6 +2538,33 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   wa.trace = dbg;
 #endif
   const uint64_t seq = ++h->p2p.seq;
+  if (h->shard_capacity == ~0ull) {  // every workgroup of k_shard_plan_mark resident at once?
+    int per_cu = 0, dev_cus = 0;
+    RR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rr::k_shard_plan_mark, rr::kTileBlock, 0));
+    RR_HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
+    h->dev_cus = dev_cus;
+    h->shard_capacity = h->grid_capacity ? std::min<uint64_t>((uint64_t)per_cu * (uint64_t)dev_cus, (uint64_t)rr::kTileBlock) : 0;
+  }
+  // Ranks that share this device (a test rig: several shards of one filter on one GPU) run their kernels beside this one's;
+  // a plan kernel that spins on every CU would leave a peer's exchange workgroup -- the one it is waiting for -- nowhere to
+  // go (seen as stalls of seconds with two 1e6-particle shards on one device).  All sharers together keep to one
+  // workgroup per CU.
+  const uint64_t fused_cap = h->p2p.n_sharing > 1 ? std::min<uint64_t>(h->shard_capacity, (uint64_t)h->dev_cus / (uint64_t)h->p2p.n_sharing)
+                                                  : h->shard_capacity;
+  const bool fused_plan = h->n_tiles <= fused_cap && rr::spin_permit(h->opt.device, h);
+  // RR_P2P_WMAX_EARLY=1: the last workgroup of the step kernel sends this shard's weight maximum to the ranks' mailboxes as it
+  // finishes (WindowArgs.post_peers) and the one-launch plan's workgroups take the records from their own mailbox, instead of the
+  // plan kernel's first workgroup opening with an exchange and a flag.  Measured at world size 1 (round 5,
+  // profiles/r05o_wmax_early.md): the plan kernel gets 1.65 us shorter and the step kernel as much longer -- "everybody has
+  // finished" costs the step kernel's tail the hand-overs the plan kernel saves -- 52.85 against 52.86 us per step.  Off by default;
+  // kept, with its tests, for the first run on a real fabric, where the record's flight would overlap the kernel boundary.
+  const char* const early_env = std::getenv("RR_P2P_WMAX_EARLY");  // (read per call: the tests switch it within one process)
+  const bool post_wmax = fused_plan && early_env && std::atoi(early_env) != 0;
+  if (post_wmax) {
+    wa.post_peers = h->p2p.peers_dev;
+    wa.post_ticket = h->p2p.post_ticket;
+    wa.post_seq = seq;
+  }
   // A: propagate + weight through the window
   const uint64_t n_rtiles = (h->n + rr::kResolveSlots - 1) / rr::kResolveSlots;
   const unsigned grid = (unsigned)n_rtiles;  // one tile per workgroup
@@ -2552,25 +2581,12 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   h->step += 1;
   PlanArgs pa = plan_args(h, 0, RR_RESAMPLE_SYSTEMATIC, NAN);
   pa.lazy_gather = 1;
-  if (h->shard_capacity == ~0ull) {  // every workgroup of k_shard_plan_mark resident at once?
-    int per_cu = 0, dev_cus = 0;
-    RR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rr::k_shard_plan_mark, rr::kTileBlock, 0));
-    RR_HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
-    h->dev_cus = dev_cus;
-    h->shard_capacity = h->grid_capacity ? std::min<uint64_t>((uint64_t)per_cu * (uint64_t)dev_cus, (uint64_t)rr::kTileBlock) : 0;
-  }
-  // Ranks that share this device (a test rig: several shards of one filter on one GPU) run their kernels beside this one's;
-  // a plan kernel that spins on every CU would leave a peer's exchange workgroup -- the one it is waiting for -- nowhere to
-  // go (seen as stalls of seconds with two 1e6-particle shards on one device).  All sharers together keep to one
-  // workgroup per CU.
-  const uint64_t fused_cap = h->p2p.n_sharing > 1 ? std::min<uint64_t>(h->shard_capacity, (uint64_t)h->dev_cus / (uint64_t)h->p2p.n_sharing)
-                                                  : h->shard_capacity;
-  if (h->n_tiles <= fused_cap && rr::spin_permit(h->opt.device, h)) {
+  if (fused_plan) {
     // exchange 1 + B + exchange 2 + C in one launch (k_shard_plan_mark)
     Timed t(h, RR_K_CDF);
     hipLaunchKernelGGL(rr::k_shard_plan_mark, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->p2p.peers, seq,
                        (const double*)h->w, h->ctl, image_args(h), h->grid_rec, h->grid_ticket, ++h->grid_epoch, /*settle=*/1,
-                       h->n_tiles, pa, h->markers, h->carry, h->p2p.err, h->slot_pad
+                       h->n_tiles, pa, h->markers, h->carry, h->p2p.err, h->slot_pad, post_wmax ? 1 : 0
 #if defined(RR_DEBUG_TRACE)
                        , dbg
 #endif

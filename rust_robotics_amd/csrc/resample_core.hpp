@@ -191,18 +191,41 @@ struct PlanArgs {
                             // reads them through the resolved indices.  0 => a gather kernel follows: flip now
 };
 
+// the systematic plan's one uniform: the caller's override, or the first draw of the resample step's Philox stream.  It depends on
+// nothing a plan kernel waits for -- the one-launch plans draw it BEFORE their waits (plan_rho_early) instead of after
+__device__ inline double plan_rho(const PlanArgs& a) {
+  double rho = a.rho_override;
+  if (rho != rho) {
+    double dummy;
+    rr_uniform2(a.seed, RR_STREAM_RESAMPLE, a.rstep, 0, &rho, &dummy);
+  }
+  return rho;
+}
+__device__ inline double plan_rho_early(const PlanArgs& a) {
+  // (the same in every lane: it waits in scalar registers, and the empty asm keeps it where it is -- the compiler would sink the
+  // draw to its first use, behind the wait)
+  const uint64_t bits = rr_d2u(plan_rho(a));
+  unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)bits), hi = __builtin_amdgcn_readfirstlane((unsigned int)(bits >> 32));
+  asm volatile("" : "+s"(lo), "+s"(hi));
+  return rr_u2d((uint64_t)lo | ((uint64_t)hi << 32));
+}
+
+// rho_known / image_known, shift_known: what the caller already holds of the plan's uniform and of Ctl.image_mode / Ctl.shift (the
+// last arrival of a one-launch plan, which has the launch's end waiting for it: no second Philox draw, no round trip to Ctl for two
+// words it wrote itself a moment ago); NaN / -1: drawn / read here.
 __device__ inline void finalize_plan(Ctl* ctl, uint64_t total_global, uint64_t base, uint64_t total_local, u128 q2,
-                                     const PlanArgs& a) {
+                                     const PlanArgs& a, double rho_known = NAN, int image_known = -1, int shift_known = 0) {
   ctl->total_local = total_local;
   ctl->total = total_global;
   ctl->base = base;
   ctl->q2_hi = q2.hi;
   ctl->q2_lo = q2.lo;
+  const int image_mode = image_known >= 0 ? image_known : ctl->image_mode;
   double neff, sum;
-  if (ctl->image_mode == kImageWeights && total_global > 0) {
-    sum = rr_fix_total_to_double(total_global, ctl->shift);
+  if (image_mode == kImageWeights && total_global > 0) {
+    sum = rr_fix_total_to_double(total_global, image_known >= 0 ? shift_known : ctl->shift);
     neff = rr_fix_neff(total_global, q2.hi, q2.lo);
-  } else if (ctl->image_mode == kImageUniform) {  // T = N, N_eff = N
+  } else if (image_mode == kImageUniform) {  // T = N, N_eff = N
     sum = 1.0;
     neff = (double)a.n_global;
   } else {  // all-zero weights: fastslam1.rs:186-193 gives N_eff = 0
@@ -226,17 +249,21 @@ __device__ inline void finalize_plan(Ctl* ctl, uint64_t total_global, uint64_t b
     if (a.set_uniform_on_fire) ctl->weights_uniform = 1;
   }
   if (fire && a.scheme == RR_RESAMPLE_SYSTEMATIC) {
-    double rho = a.rho_override;
-    if (rho != rho) {
-      double dummy;
-      rr_uniform2(a.seed, RR_STREAM_RESAMPLE, a.rstep, 0, &rho, &dummy);
-    }
+    const double rho = rho_known == rho_known ? rho_known : plan_rho(a);
     ctl->rho = rho;
     const rr_sys_plan plan = rr_sys_plan_make(rho, total_global, a.n_global);
     ctl->plan = plan;
-    const uint64_t first = rr_sys_slots_upto_exact(plan, total_global, base);
-    ctl->served_first = first;
-    ctl->served_count = rr_sys_slots_upto_exact(plan, total_global, base + total_local) - first;
+    if (base == 0 && total_local == total_global && plan.offs < total_global) {
+      // One shard holds everything: the served range is all n slots, and no 128-bit arithmetic is needed to know it -- slots_upto(0)
+      // = 0, and slots_upto(T) = floor((T n - offs) / T) + 1 capped at n = n because offs = (rho 2^53) T >> 53 < T.  (This thread
+      // has the end of the launch waiting for it when it is the last arrival of a one-launch plan: 0.7 us, round 5.)
+      ctl->served_first = 0;
+      ctl->served_count = a.n_global;
+    } else {
+      const uint64_t first = rr_sys_slots_upto_exact(plan, total_global, base);
+      ctl->served_first = first;
+      ctl->served_count = rr_sys_slots_upto_exact(plan, total_global, base + total_local) - first;
+    }
   }
 }
 
@@ -1044,6 +1071,10 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
   // then comes 2 us earlier -- the early workgroups' 32 MB of requests no longer stand in the way of the late workgroups' weights and
   // records -- but the sums' read-back and the marking wait behind those requests instead: plan kernel 21.3 -> 22.8 us.)
   if (!FS_WEIGHTS && !DEFER && ea.want && !last) est_prefetch(ea, cur_after, i0, a.n, ef);
+  // the plan's one uniform, drawn while this workgroup has nothing to do but wait (the last arrival, for whom everybody waits,
+  // draws it once the sums are out)
+  double rho = NAN;
+  if (!last) rho = plan_rho_early(pa);
   // ---- the last arrival: exclusive prefix per tile and the grand totals, then the state word
   if (last) {
     const int lane = tid & 63, wv = tid >> 6;
@@ -1139,16 +1170,14 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
     ctl->image_mode = mode;
     ctl->shift = shift;
     ctl->wmax = wmax;
-    finalize_plan(ctl, ts.tot, 0, ts.tot, ts.q2, pa);
     if (gaveup) ctl->grid_timeout += 1;
+  }
+  if (last) {
+    rho = plan_rho(pa);  // (every thread: the marking below needs it; finalize_plan takes it instead of drawing it again)
+    if (tid == 0) finalize_plan(ctl, ts.tot, 0, ts.tot, ts.q2, pa, rho, mode, shift);
   }
   // ---- B: plan_mark_tile from here on
   const int fire = gate_decision(mode, ts, pa);
-  double rho = pa.rho_override;
-  if (rho != rho) {
-    double dummy;
-    rr_uniform2(pa.seed, RR_STREAM_RESAMPLE, pa.rstep, 0, &rho, &dummy);
-  }
   unsigned int offspring[kItems];
   const double denom = fire ? (double)pa.n_global : (double)ts.tot;
   // the estimate's partial sums are formed here, or (deferred form, gate fired) by whoever moves the particles

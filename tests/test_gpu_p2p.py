@@ -42,8 +42,10 @@ def run_in_process(world, n_local, steps=10, mode="fused"):
     rng = np.random.default_rng(43)
     for t in range(steps):
         obs = H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.5, rng)
-        fused = mode == "fused" or (mode == "mixed" and t % 3 != 2)
-        for s in shards:  # every shard's step is only enqueued; the device-side waits pair them up
+        fused = mode in ("fused", "wmax_mixed") or (mode == "mixed" and t % 3 != 2)
+        for g, s in enumerate(shards):  # every shard's step is only enqueued; the device-side waits pair them up
+            if mode == "wmax_mixed":  # who sends the shard's weight maximum -- the step kernel's last workgroup or the plan kernel's
+                os.environ["RR_P2P_WMAX_EARLY"] = str((t + g) % 2)  # first -- changes from step to step and from rank to rank
             (s.step if fused else s.step_unfused)([1.0, 0.1], obs)
         if mode == "mixed" and t == steps // 2:
             for s in shards:
@@ -135,6 +137,19 @@ def test_in_process_shards_equal_unsharded(world, n_local, mode):
     code = f"import sys; sys.path.insert(0, {ROOT!r}); from tests.test_gpu_p2p import run_in_process; run_in_process({world}, {n_local}, mode={mode!r})"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
                        env=dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="8"))
+    assert r.returncode == 0 and "P2P_LOCAL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+@pytest.mark.parametrize("world,n_local,mode,early", [(2, 6000, "fused", "1"), (3, 4100, "mixed", "1"), (1, 300_000, "fused", "1"),
+                                                      (3, 4100, "wmax_mixed", "0"), (2, 700_000, "wmax_mixed", "0")])
+def test_in_process_shards_either_sender_of_the_weight_maximum(world, n_local, mode, early):
+    """The one-launch plan of a shard needs the ranks' weight maxima first.  Default: the plan kernel's first workgroup runs an
+    exchange and raises a flag for the others.  RR_P2P_WMAX_EARLY=1 (round 5; no gain at world size 1, kept for a real fabric):
+    the LAST workgroup of every rank's step kernel sends its shard's maximum as it finishes and the plan kernel's workgroups take
+    the records from their own mailbox.  Both, and any mixture over steps and ranks, give the unsharded filter's bits."""
+    code = f"import sys; sys.path.insert(0, {ROOT!r}); from tests.test_gpu_p2p import run_in_process; run_in_process({world}, {n_local}, mode={mode!r})"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="8", RR_P2P_WMAX_EARLY=early))
     assert r.returncode == 0 and "P2P_LOCAL_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
