@@ -256,7 +256,8 @@ __device__ inline void finalize_plan(Ctl* ctl, uint64_t total_global, uint64_t b
     if (base == 0 && total_local == total_global && plan.offs < total_global) {
       // One shard holds everything: the served range is all n slots, and no 128-bit arithmetic is needed to know it -- slots_upto(0)
       // = 0, and slots_upto(T) = floor((T n - offs) / T) + 1 capped at n = n because offs = (rho 2^53) T >> 53 < T.  (This thread
-      // has the end of the launch waiting for it when it is the last arrival of a one-launch plan: 0.7 us, round 5.)
+      // has the end of the launch waiting for it when it is the last arrival of a one-launch plan: its workgroup finished 1.7 us
+      // behind the others, 1.1 us now -- profiles/r05o_wmax_early.md.)
       ctl->served_first = 0;
       ctl->served_count = a.n_global;
     } else {
