@@ -61,6 +61,20 @@ struct P2PPeers {
 };
 enum { kP2PWmax = 0, kP2PSums = 1, kP2PDone = 2 };
 
+// A record's pair and the transport's give-up flag in ONE round trip: the flag's load (device scope) is issued first and waited for
+// together with the pair's (system scope).
+__device__ inline void load_pair_and_flag(const MailPair* p, const int* flag, uint64_t& bits, uint64_t& tag, int& flag_value) {
+  res_u4 v;
+  int f;
+  asm volatile("global_load_dword %1, %3, off sc1\n\tglobal_load_dwordx4 %0, %2, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+               : "=&v"(v), "=&v"(f)
+               : "v"(p), "v"(flag)
+               : "memory");
+  bits = (uint64_t)v.x | ((uint64_t)v.y << 32);
+  tag = (uint64_t)v.z | ((uint64_t)v.w << 32);
+  flag_value = f;
+}
+
 __device__ inline P2PPairSlot* p2p_pairs(P2PMailbox* m, int kind, int idx) { return kind == kP2PWmax ? &m->wmax[idx] : &m->sums[idx]; }
 
 // One exchange round, executed block-uniformly by a workgroup of >= 64 threads (WMAX / DONE: thread g < n_ranks
@@ -93,8 +107,9 @@ __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t se
   // budget -- process start-up and code-object loading skew the ranks by far more than a step does
   const uint64_t patience = seq <= 3 ? 10 * peers.timeout_ticks : peers.timeout_ticks;
   // Once a wait has given up, every later exchange of this filter gives up at once (the host reads the flag with
-  // rr_pf_p2p_status); only the first one costs the time-out.  The flag is looked at when a record is NOT there at the first
-  // look -- not up front, where it was a device-scope round trip and a barrier on the critical path of every exchange.
+  // rr_pf_p2p_status); only the first one costs the time-out.  The flag travels with the first look at the peer's record -- one
+  // round trip for both; up front, as until round 5, it was a device-scope round trip and a barrier on the critical path of every
+  // exchange.
   bool bad = false;
   if (kind != kP2PDone && g < n_words * peers.n_ranks) {
     // WMAX (one word) / SUMS (three): self-vouching pairs, see P2PPairSlot.  One LANE per pair -- thread 3 r + k sends word k to
@@ -107,13 +122,10 @@ __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t se
     const MailPair* in = &p2p_pairs(peers.mbox[peers.rank], kind, r)->p[k];
     const uint64_t t0 = wall_clock64();  // 100 MHz
     uint64_t got = 0, tag = 0;
-    for (unsigned looks = 0;; ++looks) {
-      load_pair_sys(in, got, tag);
-      if (tag == p2p_tag(seq, got)) break;
-      if (looks == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-        bad = true;  // (the transport gave up earlier)
-        break;
-      }
+    int dead = 0;
+    load_pair_and_flag(in, err, got, tag, dead);
+    if (dead) bad = true;  // (the transport gave up earlier: whatever the record says)
+    while (!bad && tag != p2p_tag(seq, got)) {
       if (wall_clock64() - t0 > patience) {
         bad = true;
         if (atomicCAS(err, 0, kind == kP2PWmax ? kGaveUpWmax : kGaveUpSums) == 0) {  // the FIRST give-up names the wait and says what it saw
@@ -126,6 +138,7 @@ __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t se
         break;
       }
       __builtin_amdgcn_s_sleep(8);
+      load_pair_sys(in, got, tag);
     }
     if (!bad) gathered[3 * r + k] = got;
   } else if (kind == kP2PDone && g < peers.n_ranks) {
@@ -137,11 +150,8 @@ __device__ inline void p2p_exchange(const P2PPeers& peers, int kind, uint64_t se
     __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     P2PSlot* in = &peers.mbox[peers.rank]->done[g];
     const uint64_t t0 = wall_clock64();
-    for (unsigned looks = 0; __hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq; ++looks) {
-      if (looks == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-        bad = true;
-        break;
-      }
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) bad = true;  // (not a hot path: asked up front)
+    while (!bad && __hip_atomic_load(&in->seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
       if (wall_clock64() - t0 > patience) {
         bad = true;
         if (atomicCAS(err, 0, kGaveUpRecord) == 0) {
