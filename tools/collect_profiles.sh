@@ -56,6 +56,9 @@ python tools/summarize_rocprof.py sq "$(find_csv fs1_sq counter_collection)" > "
 if [ -f "$REPO/rust_robotics_amd/librust_robotics_amd_timeline.so" ]; then
   RR_AMD_LIBRARY="$REPO/rust_robotics_amd/librust_robotics_amd_timeline.so" python tools/plan_timeline.py "$OUT/${TAG}_plan_kernel_timeline.json" > /dev/null 2> "$OUT/plan_timeline.err"
 fi
+if [ -f "$REPO/rust_robotics_amd/librust_robotics_amd_timeline.so" ]; then  # ... and of a shard's (k_shard_plan_mark, world size 1)
+  RR_AMD_LIBRARY="$REPO/rust_robotics_amd/librust_robotics_amd_timeline.so" python tools/shard_plan_timeline.py "$OUT/${TAG}_shard_plan_timeline.json" > /dev/null 2> "$OUT/shard_plan_timeline.err"
+fi
 if [ -f "$REPO/rust_robotics_amd/librust_robotics_amd_timeline.so" ]; then
   RR_AMD_LIBRARY="$REPO/rust_robotics_amd/librust_robotics_amd_timeline.so" python tools/resident_timeline.py > "$OUT/${TAG}_resident_step_timeline.json" 2> "$OUT/resident_timeline.err"
 fi
