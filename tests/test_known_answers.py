@@ -156,3 +156,24 @@ def test_KA7_underflow_bound(ref):
         w = np.empty(1)
         ref.ref_pf_update_raw(1, dp(x), dp(y), dp(w), dp(obs), 64, 0.2)
         assert (w[0] == 0.0) == zero, (ss, w[0])
+
+
+def test_a_single_shard_serves_all_slots(tmp_path):
+    """finalize_plan (csrc/resample_core.hpp) does not evaluate rr_sys_slots_upto_exact for a shard that holds everything: it
+    writes served range [0, n).  tests/c/served_range.c checks that identity against the exact function on the host -- edge cases
+    up to T = 2^64 - 1, n = 2^31 - 1 and three million random plans (include/rr_pf_spec.h: the same code the kernels run)."""
+    import os
+    import shutil
+    import subprocess
+
+    import pytest
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "served_range")
+    r = subprocess.run(["gcc", "-std=c11", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "c", "served_range.c"),
+                        "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "SERVED_RANGE_OK" in r.stdout, r.stdout[-1500:]
