@@ -98,26 +98,51 @@ DEVICE_WARMUP_FS = 60
 FS1_BYTES_PER_UPDATE = 96.0  # k_fs1_observe: read 48 B + write 48 B per (particle, observed landmark), EKF branch
 
 
+def library_sha16():
+    """first 16 hex digits of the SHA-256 of the engine library this process has loaded (what tools/collect_profiles.sh stamps into
+    the PMC summaries it writes)"""
+    import hashlib
+
+    from rust_robotics_amd import _ffi
+
+    try:
+        with open(_ffi.LIB_PATH, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def measured_traffic(kernel_prefix, workload, est=None):
     """HBM bytes per launch of `kernel_prefix` from the committed PMC passes (separate rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE runs, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    Newest round first; None if no file has the row.  `est`: of k_step_lazy's instantiations the one whose last template
-    argument (EST: the build that also adds up the deferred estimate) is this."""
+    Newest round first.  `est`: of k_step_lazy's instantiations the one whose last template argument (EST: the build that also
+    adds up the deferred estimate) is this.
+    The bytes are only returned when the summary was collected ON THE LIBRARY THAT IS LOADED NOW (its `library_sha16` column,
+    written by tools/collect_profiles.sh, equals library_sha16()): a number measured on another build is not this build's traffic
+    (VERDICT r5 weak 12).  Otherwise (None, why)."""
     import csv
     import glob
 
+    sha = library_sha16()
+    stale = None
     newest = sorted(os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv")))[::-1]
-    for name, wl in [(f, workload) for f in newest] + [("r01f_pmc_hbm_traffic_fastslam_timed_region.csv", workload + "_timed_region")]:
+    for name in newest:
         try:
-            rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", name))) if r["workload"] == wl and r["kernel"].startswith(kernel_prefix)]
+            rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", name))) if r["workload"] == workload and r["kernel"].startswith(kernel_prefix)]
             if est is not None and any(r["kernel"].endswith((",true>", ",false>")) for r in rows):
                 rows = [r for r in rows if r["kernel"].endswith(",true>" if est else ",false>")]
             if rows:  # several instantiations of one kernel in a run (a warm-up variant): the one that did the timed launches
                 r = max(rows, key=lambda q: int(q["dispatches"]))
-                return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6, "profiles/" + name
+                have = r.get("library_sha16")
+                if have and sha and have == sha:
+                    return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6, f"profiles/{name} [library sha256 {sha}: the loaded build]"
+                if stale is None:
+                    mb = float(r["read_MB_corrected_x2"]) + float(r["write_MB"])
+                    stale = (f"profiles/{name} holds {mb:.1f} MB per launch for this kernel, measured on " +
+                             (f"library {have}" if have else "a build that left no hash") + f"; the loaded library is {sha}: not reported as this build's traffic")
         except Exception:
             pass
-    return None, None
+    return None, stale
 
 
 def host_cpu():
@@ -497,8 +522,9 @@ def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True, devi
                    "particles_per_gpu": n, "landmarks": L},
         "roofline": {"bound": "hbm", "kernel": "k_fs1_observe", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK, "traffic": traffic,
-                     "traffic_source": (traffic_src or "") + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --workload fastslam "
-                                       "--no-breakdown`, bytes per launch, read side x2)" if traffic_src else None,
+                     "traffic_source": ((traffic_src + (" (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --workload fastslam "
+                                                        "--no-breakdown`, bytes per launch, read side x2)" if traffic is not None else ""))
+                                        if traffic_src else None),
                      "avg_kernel_ms": avg_s * 1e3, "timed_launches": k_n,
                      "timing": "dispatch timestamps of the K launches inside the timed region",
                      "algorithmic_bytes_per_launch": per_launch,
@@ -802,18 +828,25 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
         if D and getattr(args, "cold_first", False):
             # COLD: the same W + K steps with nothing but the command line's warm-up before them -- the first work this process
             # gives the device (a filter of its own, so that the hot measurement below starts from the same state as ever)
-            pc = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=ctx.local_rank,
-                                                            resample_scheme=scheme, likelihood_mode=lik)
-            fn_c = pc.step_async_estimate if with_est else pc.step_async
-            for t in range(W):
-                fn_c(u, obs_list[t])
-            pc.synchronize()
-            t0 = time.perf_counter()
-            for t in range(W, W + K):
-                fn_c(u, obs_list[t])
-            pc.synchronize()
-            extra["ms_per_step_cold"] = (time.perf_counter() - t0) / K * 1e3
-            del fn_c, pc  # (the bound method holds the filter too: both, or it lives on beside the hot one)
+            # `ms_per_step_cold_unwarmed`: exactly that.  `ms_per_step_cold`: a caller that follows include/rr_pf.h -- rr_pf_warm right
+            # after create (50 ms of step-shaped work on the filter's stream, round 6), then only the command line's W warm-up steps
+            for key, warm in (("ms_per_step_cold_unwarmed", False), ("ms_per_step_cold", True)):
+                pc = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=ctx.local_rank,
+                                                                resample_scheme=scheme, likelihood_mode=lik)
+                fn_c = pc.step_async_estimate if with_est else pc.step_async
+                if warm:
+                    pc.warm()
+                for t in range(W):
+                    fn_c(u, obs_list[t])
+                pc.synchronize()
+                t0 = time.perf_counter()
+                for t in range(W, W + K):
+                    fn_c(u, obs_list[t])
+                pc.synchronize()
+                extra[key] = (time.perf_counter() - t0) / K * 1e3
+                del fn_c, pc  # (the bound method holds the filter too: both, or it lives on beside the hot one)
+                if not warm:
+                    time.sleep(0.3)  # let the clocks fall again: the warmed measurement must not inherit the unwarmed one's 25 steps
         for t in range(D):  # device warm-up (see DEVICE_WARMUP_MCL), then time moves on
             step_fn(u, obs_list[t])
             # in blocks with a synchronisation in between, the shape of the timed region: a thousand steps enqueued in one go leave
@@ -967,7 +1000,7 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK,
             "traffic": traffic,
-            "traffic_source": (traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)") if traffic_src else None,
+            "traffic_source": (traffic_src + (" (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)" if traffic is not None else "")) if traffic_src else None,
             "avg_kernel_ms": k1_avg_s * 1e3,
             "timed_launches": k1_n,
             "timing": "dispatch timestamps (hipExtLaunchKernelGGL) of K launches that follow the timed region" if dominant else
@@ -998,7 +1031,13 @@ def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]")
         if n_cpu != n:
             out["cpu_baseline"]["sample"] += f" -- a BOUNDED SAMPLE: {n_cpu} of the leg's {n} particles (the per-particle work and the serial scan both scale linearly)"
     if ctx.sharded:
-        out["sharded"] = {k: res.get(k) for k in ("transport", "transport_note", "p2p_timed_out", "migrated_particles_last_step")}
+        out["sharded"] = {k: res.get(k) for k in ("transport", "transport_note", "p2p_timed_out", "migrated_particles_last_step", "ranks_seen")}
+        seen = res.get("ranks_seen") or {}
+        out["ranks_seen"] = seen.get("ranks")
+        if seen and seen.get("distinct_devices", world) < world:
+            # (RR_BENCH_SHARE_DEVICE: a rig that executes the N-rank code on fewer devices -- every rank's kernels run on the SAME GPU)
+            out["shared_device"] = (f"{world} ranks on {seen['distinct_devices']} device(s): the {world}-rank code path executed, "
+                                    f"NOT a scaling number -- `value` is the aggregate of ranks that time-share one GPU")
     return out
 
 
@@ -1453,6 +1492,8 @@ def _compact_roofline(r):
                                    "algorithmic_bytes_per_launch") if k in r}
     if "kernel" in out:
         out["kernel"] = _short(str(out["kernel"]).split(" ")[0], 40)
+    if r.get("traffic_source"):  # which PMC summary, and the hash of the library it was collected on (== the loaded one, or no traffic)
+        out["traffic_source"] = _short(str(r["traffic_source"]), 110)
     return out
 
 
@@ -1492,7 +1533,7 @@ def compact_line(out):
         line["roofline"] = _compact_roofline(out["roofline"])
     if "cpu_baseline" in out:
         line["cpu_baseline"] = _compact_cpu(out["cpu_baseline"])
-    for k in ("device_warmup_steps", "ms_per_step_cold", "deadline_exceeded", "error"):
+    for k in ("device_warmup_steps", "ms_per_step_cold", "ms_per_step_cold_unwarmed", "deadline_exceeded", "error", "ranks_seen", "shared_device"):
         if k in out:
             line[k] = _num(out[k], 5)
     legs = {}
@@ -1509,7 +1550,7 @@ def compact_line(out):
         line["legs"] = legs
         line["legs_columns"] = ["ms_per_step", "hbm_frac", "binding_frac"]
     if isinstance(out.get("sharded"), dict):
-        line["sharded"] = {k: out["sharded"].get(k) for k in ("transport", "p2p_timed_out") if k in out["sharded"]}
+        line["sharded"] = {k: out["sharded"].get(k) for k in ("transport", "p2p_timed_out", "ranks_seen") if k in out["sharded"]}
     for k in ("strong_scaling_ceiling", "weak_scaling_ceiling"):
         if k in out:
             line[k] = out[k]

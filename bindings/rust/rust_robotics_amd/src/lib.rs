@@ -83,7 +83,10 @@ pub struct ParticleFilterLocalizer {
     /// (`calc_covariance`, `StateEstimator::get_covariance`, both through `&self`) and dropped by everything that moves or
     /// reweights the particles.  The reference recomputes it inside every step (particle_filter.rs:299,332,343); a caller
     /// ported from it therefore never reads the covariance of an earlier step, and a caller that never asks never pays.
-    covariance: OnceCell<(Matrix4<f64>, DMatrix<f64>)>,
+    /// `None` inside the cell: the device call failed (a getter must not panic on a device error) --
+    /// `get_covariance` then returns `None`, `calc_covariance` a matrix of NaN, `try_calc_covariance` the error itself.
+    /// Both getters MAY SYNCHRONISE: the first call after a change waits for the filter's stream and runs two small kernels.
+    covariance: OnceCell<Option<(Matrix4<f64>, DMatrix<f64>)>>,
     particles: Vec<Particle>,   // host mirror behind get_particles (filled on demand)
     landmarks: Vec<Point2D>,    // set_landmarks* only stores them, as the reference does (particle_filter.rs:216-220, Q19)
 }
@@ -238,7 +241,7 @@ impl ParticleFilterLocalizer {
     pub fn refresh_covariance(&mut self) -> RoboticsResult<()> {
         self.covariance.take();
         let c = self.read_covariance()?;
-        let _ = self.covariance.set(c);
+        let _ = self.covariance.set(Some(c));
         Ok(())
     }
 
@@ -282,9 +285,27 @@ impl ParticleFilterLocalizer {
         self.state_estimate
     }
 
-    /// calc_covariance, :363-365
+    /// Engine extension (`rr_pf_warm`): `ms` milliseconds (0.0: the default, 50) of step-shaped work on the filter's stream, so
+    /// that the first `try_step` after construction runs at the rate of the thousandth (an idle MI355X starts at reduced clocks).
+    pub fn warm(&mut self, ms: f64) -> RoboticsResult<()> {
+        check(unsafe { sys::rr_pf_warm(self.h, ms) })
+    }
+
+    /// calc_covariance, :363-365.  May synchronise (first call after a change).  A device error gives a matrix of NaN here
+    /// (the reference's signature has no error channel); `try_calc_covariance` reports it.
     pub fn calc_covariance(&self) -> Matrix4<f64> {
-        self.covariance_pair().0
+        match self.covariance_pair() {
+            Some(p) => p.0,
+            None => Matrix4::from_element(f64::NAN),
+        }
+    }
+
+    /// calc_covariance with the device's status: `Err(RoboticsError::...)` instead of NaN when the moment kernels failed
+    pub fn try_calc_covariance(&self) -> RoboticsResult<Matrix4<f64>> {
+        match self.covariance_pair() {
+            Some(p) => Ok(p.0),
+            None => self.read_covariance().map(|p| p.0),  // (asks again: returns the device's error message)
+        }
     }
 
     pub fn particle_count(&self) -> usize {
@@ -312,8 +333,8 @@ impl ParticleFilterLocalizer {
     }
 
     /// the cached covariance, computed on first use after a change (`OnceCell::get_or_init` hands out `&` through `&self`)
-    fn covariance_pair(&self) -> &(Matrix4<f64>, DMatrix<f64>) {
-        self.covariance.get_or_init(|| self.read_covariance().expect("particle filter moments failed on the device"))
+    fn covariance_pair(&self) -> Option<&(Matrix4<f64>, DMatrix<f64>)> {
+        self.covariance.get_or_init(|| self.read_covariance().ok()).as_ref()
     }
 }
 
@@ -333,8 +354,9 @@ impl StateEstimator for ParticleFilterLocalizer {
     fn get_state(&self) -> &PFState {
         &self.state_estimate
     }
+    /// May synchronise (first call after a change); `None` when the device call failed.
     fn get_covariance(&self) -> Option<&DMatrix<f64>> {
-        Some(&self.covariance_pair().1)
+        self.covariance_pair().map(|p| &p.1)
     }
 }
 

@@ -38,6 +38,20 @@
 #endif
 
 RR_HD double rr_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+/* One Horner step p * z + C with C a compile-time coefficient: the same correctly rounded fma as rr_fma on both sides (same bits);
+ * on the device it is spelled as ONE VOP3 instruction that reads the coefficient from a scalar register pair.  Left to itself the
+ * gfx950 code generator (VOP3 cannot hold a 64-bit literal) materialises every coefficient in a VECTOR register pair first --
+ * v_mov_b32 x 2 + v_fmac_f64: three vector instructions per step (round 6: 296 v_mov_b32 in k_step_lazy<EST>'s text, ~100 of its 454
+ * per-particle instructions); the scalar moves that fill an SGPR pair issue on the scalar unit beside other waves' vector work. */
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ static inline double rr_horner(double p, double z, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(c));
+  return r;
+}
+#else
+RR_HD double rr_horner(double p, double z, double c) { return __builtin_fma(p, z, c); }
+#endif
 RR_HD double rr_rint(double x) { return __builtin_rint(x); }
 RR_HD double rr_sqrt(double x) { return __builtin_sqrt(x); }
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -108,18 +122,18 @@ RR_HD double rr_exp(double x) {
   double r = rr_fma(-k, RR_LN2_HI, x);
   r = rr_fma(-k, RR_LN2_LO, r);
   double p = RR_EXP_C_12;
-  p = rr_fma(p, r, RR_EXP_C_11);
-  p = rr_fma(p, r, RR_EXP_C_10);
-  p = rr_fma(p, r, RR_EXP_C_9);
-  p = rr_fma(p, r, RR_EXP_C_8);
-  p = rr_fma(p, r, RR_EXP_C_7);
-  p = rr_fma(p, r, RR_EXP_C_6);
-  p = rr_fma(p, r, RR_EXP_C_5);
-  p = rr_fma(p, r, RR_EXP_C_4);
-  p = rr_fma(p, r, RR_EXP_C_3);
-  p = rr_fma(p, r, RR_EXP_C_2);
-  p = rr_fma(p, r, RR_EXP_C_1);
-  p = rr_fma(p, r, RR_EXP_C_0);
+  p = rr_horner(p, r, RR_EXP_C_11);
+  p = rr_horner(p, r, RR_EXP_C_10);
+  p = rr_horner(p, r, RR_EXP_C_9);
+  p = rr_horner(p, r, RR_EXP_C_8);
+  p = rr_horner(p, r, RR_EXP_C_7);
+  p = rr_horner(p, r, RR_EXP_C_6);
+  p = rr_horner(p, r, RR_EXP_C_5);
+  p = rr_horner(p, r, RR_EXP_C_4);
+  p = rr_horner(p, r, RR_EXP_C_3);
+  p = rr_horner(p, r, RR_EXP_C_2);
+  p = rr_horner(p, r, RR_EXP_C_1);
+  p = rr_horner(p, r, RR_EXP_C_0);
   return rr_scale2(p, (int)k);
 }
 
@@ -136,15 +150,15 @@ RR_HD double rr_log_core(uint64_t u, int e) {
   double s = f / (2.0 + f);
   double z = s * s;
   double p = RR_LOG_C_9;
-  p = rr_fma(p, z, RR_LOG_C_8);
-  p = rr_fma(p, z, RR_LOG_C_7);
-  p = rr_fma(p, z, RR_LOG_C_6);
-  p = rr_fma(p, z, RR_LOG_C_5);
-  p = rr_fma(p, z, RR_LOG_C_4);
-  p = rr_fma(p, z, RR_LOG_C_3);
-  p = rr_fma(p, z, RR_LOG_C_2);
-  p = rr_fma(p, z, RR_LOG_C_1);
-  p = rr_fma(p, z, RR_LOG_C_0);
+  p = rr_horner(p, z, RR_LOG_C_8);
+  p = rr_horner(p, z, RR_LOG_C_7);
+  p = rr_horner(p, z, RR_LOG_C_6);
+  p = rr_horner(p, z, RR_LOG_C_5);
+  p = rr_horner(p, z, RR_LOG_C_4);
+  p = rr_horner(p, z, RR_LOG_C_3);
+  p = rr_horner(p, z, RR_LOG_C_2);
+  p = rr_horner(p, z, RR_LOG_C_1);
+  p = rr_horner(p, z, RR_LOG_C_0);
   /* atanh(s) = s + s*z*p ; log(m) = 2 atanh(s) */
   double t = s * z;
   double lm = 2.0 * rr_fma(t, p, s);
@@ -170,35 +184,37 @@ RR_HD double rr_log(double x) {
 RR_HD double rr_sin_kernel(double r) {
   double s = r * r;
   double p = RR_SIN_C_7;
-  p = rr_fma(p, s, RR_SIN_C_6);
-  p = rr_fma(p, s, RR_SIN_C_5);
-  p = rr_fma(p, s, RR_SIN_C_4);
-  p = rr_fma(p, s, RR_SIN_C_3);
-  p = rr_fma(p, s, RR_SIN_C_2);
-  p = rr_fma(p, s, RR_SIN_C_1);
-  p = rr_fma(p, s, RR_SIN_C_0);
+  p = rr_horner(p, s, RR_SIN_C_6);
+  p = rr_horner(p, s, RR_SIN_C_5);
+  p = rr_horner(p, s, RR_SIN_C_4);
+  p = rr_horner(p, s, RR_SIN_C_3);
+  p = rr_horner(p, s, RR_SIN_C_2);
+  p = rr_horner(p, s, RR_SIN_C_1);
+  p = rr_horner(p, s, RR_SIN_C_0);
   return rr_fma(r * s, p, r);
 }
 RR_HD double rr_cos_kernel(double r) {
   double s = r * r;
   double p = RR_COS_C_7;
-  p = rr_fma(p, s, RR_COS_C_6);
-  p = rr_fma(p, s, RR_COS_C_5);
-  p = rr_fma(p, s, RR_COS_C_4);
-  p = rr_fma(p, s, RR_COS_C_3);
-  p = rr_fma(p, s, RR_COS_C_2);
-  p = rr_fma(p, s, RR_COS_C_1);
-  p = rr_fma(p, s, RR_COS_C_0);
+  p = rr_horner(p, s, RR_COS_C_6);
+  p = rr_horner(p, s, RR_COS_C_5);
+  p = rr_horner(p, s, RR_COS_C_4);
+  p = rr_horner(p, s, RR_COS_C_3);
+  p = rr_horner(p, s, RR_COS_C_2);
+  p = rr_horner(p, s, RR_COS_C_1);
+  p = rr_horner(p, s, RR_COS_C_0);
   return rr_fma(s * s, p, rr_fma(-0.5, s, 1.0));
 }
 
+/* (sin, cos) of r + q pi/2 from (sin r, cos r): q odd swaps the two, then sin changes sign for q = 2, 3 and cos for q = 1, 2.
+ * Written without branches (two selects, two sign-bit flips -- a sign-bit flip IS negation, zeros and NaNs included): the four-way
+ * switch it replaces compiled to nested exec-mask branches on the device. */
 RR_HD void rr_quadrant(int q, double sr, double cr, double* s, double* c) {
-  switch (q & 3) {
-    case 0: *s = sr;  *c = cr;  break;
-    case 1: *s = cr;  *c = -sr; break;
-    case 2: *s = -sr; *c = -cr; break;
-    default: *s = -cr; *c = sr; break;
-  }
+  const int odd = q & 1;
+  const double s0 = odd ? cr : sr;
+  const double c0 = odd ? sr : cr;
+  *s = rr_u2d(rr_d2u(s0) ^ ((uint64_t)((unsigned)q & 2u) << 62));
+  *c = rr_u2d(rr_d2u(c0) ^ ((uint64_t)((unsigned)(q + 1) & 2u) << 62));
 }
 
 /* sin and cos of x; 3-term fma Cody-Waite reduction, intended for |x| < ~1e6
@@ -248,19 +264,19 @@ RR_HD double rr_atan_pos(double y, double x) {
   double base_hi = big ? RR_PIO4_HI : 0.0, base_lo = big ? RR_PIO4_LO : 0.0;
   double z = t * t;
   double p = RR_ATAN_C_13;
-  p = rr_fma(p, z, RR_ATAN_C_12);
-  p = rr_fma(p, z, RR_ATAN_C_11);
-  p = rr_fma(p, z, RR_ATAN_C_10);
-  p = rr_fma(p, z, RR_ATAN_C_9);
-  p = rr_fma(p, z, RR_ATAN_C_8);
-  p = rr_fma(p, z, RR_ATAN_C_7);
-  p = rr_fma(p, z, RR_ATAN_C_6);
-  p = rr_fma(p, z, RR_ATAN_C_5);
-  p = rr_fma(p, z, RR_ATAN_C_4);
-  p = rr_fma(p, z, RR_ATAN_C_3);
-  p = rr_fma(p, z, RR_ATAN_C_2);
-  p = rr_fma(p, z, RR_ATAN_C_1);
-  p = rr_fma(p, z, RR_ATAN_C_0);
+  p = rr_horner(p, z, RR_ATAN_C_12);
+  p = rr_horner(p, z, RR_ATAN_C_11);
+  p = rr_horner(p, z, RR_ATAN_C_10);
+  p = rr_horner(p, z, RR_ATAN_C_9);
+  p = rr_horner(p, z, RR_ATAN_C_8);
+  p = rr_horner(p, z, RR_ATAN_C_7);
+  p = rr_horner(p, z, RR_ATAN_C_6);
+  p = rr_horner(p, z, RR_ATAN_C_5);
+  p = rr_horner(p, z, RR_ATAN_C_4);
+  p = rr_horner(p, z, RR_ATAN_C_3);
+  p = rr_horner(p, z, RR_ATAN_C_2);
+  p = rr_horner(p, z, RR_ATAN_C_1);
+  p = rr_horner(p, z, RR_ATAN_C_0);
   double a = base_hi + (rr_fma(t * z, p, t) + base_lo);
   if (swap) a = RR_PIO2_1 - (a - RR_PIO2_2);
   return a;

@@ -75,6 +75,9 @@ rr_status rr_fs1_update(rr_fs1* h, const double u[2], const double* z, size_t n_
 /* the same, enqueued without waiting */
 rr_status rr_fs1_update_async(rr_fs1* h, const double u[2], const double* z, size_t n_z);
 rr_status rr_fs1_synchronize(rr_fs1* h);
+/* as rr_pf_warm (include/rr_pf.h): `ms` milliseconds (0: 50) of step-shaped work on the filter's stream, so that the first
+ * fastslam_update (render_gif_slam.rs:166-200 creates the particles and updates at once) runs at the steady rate */
+rr_status rr_fs1_warm(rr_fs1* h, double ms);
 
 /* get_best_particle, :269-274: arg max of the weight, ties -> last index */
 rr_status rr_fs1_best_particle(rr_fs1* h, double out_pose[3], double* out_weight, uint64_t* out_index);
@@ -85,7 +88,9 @@ rr_status rr_fs1_best_particle(rr_fs1* h, double out_pose[3], double* out_weight
  * workgroup stays on the device, takes each update's control and observations from a pinned command block and answers with
  * the best particle of the updated set in a pinned response block, so the rr_fs1_best_particle that follows an update is
  * free.  It leaves by itself after idle_us microseconds without an update and after max(100 ms, 20 idle_us) in any case (idle_us <= 0.5 s); every
- * other entry point asks it to leave first.  Same bits as the launched update.  0 switches the service off (the default). */
+ * other entry point asks it to leave first.  Same bits as the launched update.  0 switches the service off (the default); values
+ * above 5e5 are clamped to 5e5, negative or NaN is RR_INVALID_PARAMETER; a host waiting for a kernel that has died gives up after
+ * at most 3 x (2 s + life) <= 36 s with RR_RUNTIME_ERROR. */
 rr_status rr_fs1_set_resident(rr_fs1* h, double idle_us);
 /* incarnations of the resident kernel launched so far and updates served by them */
 rr_status rr_fs1_resident_stats(const rr_fs1* h, uint64_t* launches, uint64_t* updates);

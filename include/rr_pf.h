@@ -188,12 +188,21 @@ rr_status rr_pf_step_many(rr_pf* h, const double* controls, const double* obs, s
  * nothing is lost, that step just pays a launch) and after max(100 ms, 20 idle_us) in any case (idle_us <= 0.5 s), so work queued behind it is
  * delayed, never blocked; every other entry point of the handle asks it to leave before it touches the particle set.  Same
  * kernel code, same bits as the launched step.  While it runs it holds one workgroup's registers and LDS of one compute unit.
- * idle_us == 0 switches the service off (the default; RR_PF_RESIDENT_US=<us> at create time switches it on). */
+ * idle_us == 0 switches the service off (the default; RR_PF_RESIDENT_US=<us> at create time switches it on).  idle_us above 5e5
+ * (0.5 s) is clamped to 5e5; negative or NaN is RR_INVALID_PARAMETER.  Worst-case blocking of a synchronous step: an answer from
+ * a live kernel arrives in microseconds; if the kernel has died the host gives up after 3 x (2 s + life) <= 36 s and reports
+ * RR_RUNTIME_ERROR. */
 rr_status rr_pf_set_resident(rr_pf* h, double idle_us);
 /* incarnations of the resident kernel launched so far and steps served by them */
 rr_status rr_pf_resident_stats(const rr_pf* h, uint64_t* launches, uint64_t* steps);
 /* wait for everything enqueued on the filter's stream */
 rr_status rr_pf_synchronize(rr_pf* h);
+/* Make the caller's FIRST step as fast as its thousandth (engine extension; the reference's callers -- headless_localizers.rs:39-56
+ * -- create a localizer and step it at once): an idle MI355X runs its first ~50 ms of work at reduced clocks and the HIP runtime
+ * has one-off costs along a process's first launches (measured, 1e6 x 32: 52.6 us/step right after create against 47.9 after a
+ * thousand steps).  rr_pf_warm enqueues `ms` milliseconds (0: the default, 50; at most 2000) of step-shaped FP64 work on the
+ * filter's stream and waits for it; the particle set is not touched.  Clocks fall again when the device idles for long. */
+rr_status rr_pf_warm(rr_pf* h, double ms);
 
 /* estimate :348-350 -- weighted mean (x, y, yaw, v) of the current particle set */
 rr_status rr_pf_estimate(rr_pf* h, double out[4]);

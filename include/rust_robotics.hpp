@@ -132,6 +132,8 @@ class ParticleFilterLocalizer {
     return e;
   }
   void synchronize() { check(rr_pf_synchronize(h_)); }
+  // engine extension: `ms` milliseconds (0: 50) of step-shaped work, so that the first step runs at the steady rate (rr_pf_warm)
+  void warm(double ms = 0.0) { check(rr_pf_warm(h_, ms)); }
   void set_resident(double idle_us) { check(rr_pf_set_resident(h_, idle_us)); }
   PFState estimate() {
     PFState e;
@@ -257,6 +259,7 @@ class FastSlam1 {
     check(rr_fs1_update_async(h_, u.data(), f.data(), z.size()));
   }
   void synchronize() { check(rr_fs1_synchronize(h_)); }
+  void warm(double ms = 0.0) { check(rr_fs1_warm(h_, ms)); }
   void set_resident(double idle_us) { check(rr_fs1_set_resident(h_, idle_us)); }
   // get_best_particle, fastslam1.rs:269-274
   std::tuple<std::array<double, 3>, double, uint64_t> best_particle() {

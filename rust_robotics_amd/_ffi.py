@@ -156,6 +156,7 @@ def lib() -> C.CDLL:
     proto("rr_pf_set_resident", st, [H, d])
     proto("rr_pf_resident_stats", st, [H, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)])
     proto("rr_pf_synchronize", st, [H])
+    proto("rr_pf_warm", st, [H, d])
     proto("rr_pf_estimate", st, [H, P])
     proto("rr_pf_covariance", st, [H, P])
     proto("rr_pf_particle_count", u64, [H])
@@ -230,6 +231,7 @@ def lib() -> C.CDLL:
     proto("rr_fs1_update", st, [H, P, P, sz])
     proto("rr_fs1_update_async", st, [H, P, P, sz])
     proto("rr_fs1_synchronize", st, [H])
+    proto("rr_fs1_warm", st, [H, d])
     proto("rr_fs1_best_particle", st, [H, P, P, C.POINTER(u64)])
     proto("rr_fs1_set_resident", st, [H, d])
     proto("rr_fs1_resident_stats", st, [H, C.POINTER(u64), C.POINTER(u64)])

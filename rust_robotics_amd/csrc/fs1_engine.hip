@@ -1024,7 +1024,10 @@ rr_status fs1_resident_park(rr_fs1* h) {
 rr_status rr_fs1_set_resident(rr_fs1* h, double idle_us) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
-  if (!(idle_us >= 0.0) || !(idle_us <= 5e5)) return fail(RR_INVALID_PARAMETER, "resident idle time must lie in [0, 5e5] microseconds");
+  // values above 0.5 s are CLAMPED, not rejected (the bound used to be 1e7): 0.5 s of idling means <= 10 s of life, and a host
+  // that waits for an answer from a kernel that has died sits out at most 3 x (2 s + life) = 36 s before it is told (resident_await)
+  if (!(idle_us >= 0.0)) return fail(RR_INVALID_PARAMETER, "resident idle time must be >= 0 microseconds (values above 5e5 are clamped to 5e5)");
+  if (idle_us > 5e5) idle_us = 5e5;
   h->res.enabled = idle_us > 0.0;
   h->res.idle_us = idle_us;
   h->res.life_us = std::max(100000.0, 20.0 * idle_us);
@@ -1077,6 +1080,15 @@ rr_status rr_fs1_synchronize(rr_fs1* h) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   return synchronize_light(h);  // waits for the stream; also where a handle learns that its one-launch plan had to degrade
+}
+
+// rr_fs1_warm (include/rr_fastslam1.h): as rr_pf_warm
+rr_status rr_fs1_warm(rr_fs1* h, double ms) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!(ms >= 0.0) || !(ms <= 2000.0)) return fail(RR_INVALID_PARAMETER, "warm-up time must lie in [0, 2000] milliseconds (0: the default, 50)");
+  RR_HIP_TRY(rr::device_warm(h->stream, h->opt.device, ms == 0.0 ? 50.0 : ms));
+  return RR_OK;
 }
 
 rr_status rr_fs1_update(rr_fs1* h, const double u[2], const double* z, size_t n_z) {

@@ -631,6 +631,7 @@ struct P2PState {
   P2PPeers peers{};            // device pointers of every rank's mailbox and slab
   bool ready = false;
   int n_sharing = 1;               // ranks of this filter whose shard lives on THIS device (this one included)
+  int share_ordinal = 0;           // ... and how many of them have a lower rank than this one
   void* opened[3 * kMaxP2P] = {};  // IPC mappings to close
   int n_opened = 0;
   uint64_t seq = 0;
@@ -737,6 +738,7 @@ struct P2PState {
     RR_HIP_TRY(hipGetDevice(&dev));
     RR_HIP_TRY(hipDeviceGetPCIBusId(own_bus, kBusIdBytes, dev));
     n_sharing = 1;
+    share_ordinal = 0;
     for (int g = 0; g < n_ranks; ++g) {
       if (g == rank) {
         p.slab[g] = slab;
@@ -747,7 +749,10 @@ struct P2PState {
       hipIpcMemHandle_t hs[3];
       std::memcpy(hs, all_handles + (size_t)g * kP2PHandleBytes, sizeof hs);
       const char* bus = reinterpret_cast<const char*>(all_handles) + (size_t)g * kP2PHandleBytes + sizeof hs;
-      if (bus[0] && std::strncmp(bus, own_bus, kBusIdBytes) == 0) n_sharing += 1;
+      if (bus[0] && std::strncmp(bus, own_bus, kBusIdBytes) == 0) {
+        n_sharing += 1;
+        if (g < rank) share_ordinal += 1;
+      }
       void *ps = nullptr, *pm = nullptr, *pi = nullptr;
       RR_HIP_TRY(hipIpcOpenMemHandle(&ps, hs[0], hipIpcMemLazyEnablePeerAccess));
       opened[n_opened++] = ps;
@@ -835,7 +840,11 @@ inline rr_status p2p_link_local(P2PState* const* states, double* const* slabs, c
     states[g]->ready = true;
     states[g]->seq = 0;
     states[g]->n_sharing = 0;
-    for (int k = 0; k < n_ranks; ++k) states[g]->n_sharing += devices[k] == devices[g] ? 1 : 0;
+    states[g]->share_ordinal = 0;
+    for (int k = 0; k < n_ranks; ++k) {
+      states[g]->n_sharing += devices[k] == devices[g] ? 1 : 0;
+      if (k < g && devices[k] == devices[g]) states[g]->share_ordinal += 1;
+    }
   }
   return RR_OK;
 }

@@ -208,6 +208,8 @@ struct rr_pf {
   uint64_t grid_capacity = 0;
   uint64_t plan_giveups = 0;  // launches of the one-launch plan that degraded to the serial plan (seen at the last read of Ctl)
   int dev_cus = 0;
+  int spin_gate_no = 0;   // rr::spin_permit's gate: the device, or this shard's own part of its CUs (RR_P2P_CU_PARTITION)
+  int cu_part_cus = 0;    // > 0: the handle's stream is confined to that many CUs of its own (p2p_apply_cu_partition)
   uint64_t shard_capacity = ~0ull;  // the same for k_shard_plan_mark (sharded step over the peer-to-peer transport); ~0: not asked yet
   unsigned int* est_ticket = nullptr;  // arrival counters of its last-workgroup reduction (rr::last_arrival; zero between launches)
   double* scratch_a = nullptr;  // n doubles: explicit noise v / uniforms / AoS staging (5n)
@@ -588,7 +590,7 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
                           bool lazy = false, int settle = 0, int est_mode = rr::kEstOff) {
   // K2 + fused plan in one launch when every tile's workgroup is resident at once (k_quantize_plan_mark)
   const bool one_launch = scheme == RR_RESAMPLE_SYSTEMATIC && h->n_tiles <= h->grid_capacity && h->n == h->n_global &&
-                          rr::spin_permit(h->opt.device, h);
+                          rr::spin_permit(h->spin_gate_no, h);
   if (!one_launch) launch_quantize(h, wmax_source(h), settle);
   PlanArgs pa = plan_args(h, mode, scheme, rho_override);
   const bool lazy_mn = lazy && scheme == RR_RESAMPLE_MULTINOMIAL && h->lidx && !r_explicit_dev;
@@ -770,7 +772,7 @@ rr_status resample_adaptive(rr_pf* h, const double* r_explicit_dev, bool lazy = 
 rr_status fetch_ctl(rr_pf* h) {
   RR_HIP_TRY(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, h->stream));
   RR_HIP_TRY(hipStreamSynchronize(h->stream));
-  rr::spin_release(h->opt.device, h);
+  rr::spin_release(h->spin_gate_no, h);
   if (h->ctl_host->grid_timeout) {
     // launches of the one-launch plan gave up waiting for workgroups the device did not run concurrently (another process
     // on the GPU) and planned serially instead -- same results, milliseconds instead of microseconds: this handle takes
@@ -805,7 +807,7 @@ rr_status await_mail(rr_pf* h, uint64_t want) {
     RR_HIP_TRY(hipStreamSynchronize(h->stream));
     if (__atomic_load_n(seq, __ATOMIC_ACQUIRE) != want) return fail(RR_RUNTIME_ERROR, "the step's estimate never reached the host mailbox");
   }
-  rr::spin_release(h->opt.device, h);  // the stream is idle
+  rr::spin_release(h->spin_gate_no, h);  // the stream is idle
   return RR_OK;
 }
 
@@ -987,6 +989,7 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
   RR_TRY_OR_CLEAN(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
   h->stream = h->own_stream;
   h->owns_stream = true;
+  h->spin_gate_no = h->opt.device & 63;
   const size_t nb = h->cap * sizeof(double);
   // one slab [set][field][cap] so that peers can map the whole particle state with one IPC handle
   RR_TRY_OR_CLEAN(hipMalloc(&h->slab, 8 * nb));
@@ -1578,7 +1581,7 @@ void rr_pf_destroy(rr_pf* h) {
   }
   for (auto e : h->event_pool) (void)hipEventDestroy(e);
   if (h->owns_stream && h->own_stream) (void)hipStreamDestroy(h->own_stream);
-  rr::spin_release(h->opt.device, h);
+  rr::spin_release(h->spin_gate_no, h);
   delete h;
 }
 
@@ -1818,7 +1821,10 @@ rr_status rr_pf_set_resident(rr_pf* h, double idle_us) {
   rr_status s = bind(h);  // (parks a live kernel)
   if (s != RR_OK) return s;
   // (<= 0.5 s idle, hence <= 10 s of life: what a host that waits for an answer has to be prepared to sit out, resident_await)
-  if (!(idle_us >= 0.0) || !(idle_us <= 5e5)) return fail(RR_INVALID_PARAMETER, "resident idle time must lie in [0, 5e5] microseconds");
+  // values above 0.5 s are CLAMPED, not rejected (the bound used to be 1e7): 0.5 s of idling means <= 10 s of life, and a host
+  // that waits for an answer from a kernel that has died sits out at most 3 x (2 s + life) = 36 s before it is told (resident_await)
+  if (!(idle_us >= 0.0)) return fail(RR_INVALID_PARAMETER, "resident idle time must be >= 0 microseconds (values above 5e5 are clamped to 5e5)");
+  if (idle_us > 5e5) idle_us = 5e5;
   h->res.enabled = idle_us > 0.0;
   h->res.idle_us = idle_us;
   h->res.life_us = std::max(100000.0, 20.0 * idle_us);
@@ -1903,6 +1909,16 @@ rr_status rr_pf_synchronize(rr_pf* h) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   return fetch_ctl(h);  // waits for the stream; also the place where a handle learns that its one-launch plan had to degrade
+}
+
+// rr_pf_warm (include/rr_pf.h): `ms` milliseconds of step-shaped FP64 work on the filter's stream, so that the caller's first
+// step runs at the rate of its thousandth (rr::device_warm).  ms == 0: the default, 50 ms.
+rr_status rr_pf_warm(rr_pf* h, double ms) {
+  rr_status s = bind(h);
+  if (s != RR_OK) return s;
+  if (!(ms >= 0.0) || !(ms <= 2000.0)) return fail(RR_INVALID_PARAMETER, "warm-up time must lie in [0, 2000] milliseconds (0: the default, 50)");
+  RR_HIP_TRY(rr::device_warm(h->stream, h->opt.device, ms == 0.0 ? 50.0 : ms));
+  return RR_OK;
 }
 
 rr_status rr_pf_estimate(rr_pf* h, double out[4]) {
@@ -2448,6 +2464,34 @@ static rr_status p2p_alloc_lidx(rr_pf* h) {
   return RR_OK;
 }
 
+// RR_P2P_CU_PARTITION=1 (a test rig, off by default): ranks that SHARE a device each get a stream confined to their own 1/n_sharing
+// of its CUs (hipExtStreamCreateWithCUMask; contiguous mask bits, which the driver deals round-robin over the XCDs: every rank
+// holds CUs in every XCD).  The eight XCDs' worth of CUs then behave like eight small devices as far as workgroup slots go: a
+// consuming kernel that waits inside the kernel for a peer's delivery can no longer sit on the slots the delivering kernel
+// needs, so sharers of ANY size take the lazy window step -- the deployment path -- and every one of them may run its own
+// one-launch plan (its own spin gate).  This is how BASELINE configs[4] (8 x 2e6 particles) executes as 8 ranks on one GPU
+// through exactly the kernels an 8-GPU node would run (tools/world8_one_device.py, tests/test_gpu_world8.py).
+static rr_status p2p_apply_cu_partition(rr_pf* h) {
+  const char* e = std::getenv("RR_P2P_CU_PARTITION");
+  if (!e || std::atoi(e) == 0 || h->p2p.n_sharing <= 1 || h->using_external_stream || !h->owns_stream || h->cu_part_cus) return RR_OK;
+  int cus = 0;
+  RR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
+  const int parts = h->p2p.n_sharing, part = h->p2p.share_ordinal, per = cus / parts;
+  if (per < 8 || part >= parts) return RR_OK;  // too many sharers for a useful share: keep the whole-device rules
+  std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+  for (int b = part * per; b < (part + 1) * per; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
+  hipStream_t s = nullptr;
+  RR_HIP_TRY(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+  RR_HIP_TRY(hipStreamSynchronize(h->own_stream));
+  rr::spin_release(h->spin_gate_no, h);
+  (void)hipStreamDestroy(h->own_stream);
+  h->own_stream = h->stream = s;
+  h->cu_part_cus = per;
+  h->spin_gate_no = (h->opt.device & 63) + 64 * (1 + (part & 15));
+  h->shard_capacity = ~0ull;  // asked again, for the share
+  return RR_OK;
+}
+
 rr_status rr_pf_p2p_export(rr_pf* h, uint8_t out[RR_P2P_HANDLE_BYTES]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
@@ -2461,7 +2505,8 @@ rr_status rr_pf_p2p_connect(rr_pf* h, const uint8_t* all_handles, int32_t n_rank
   if (!all_handles) return fail(RR_INVALID_PARAMETER, "null handles");
   if ((s = p2p_check_geometry(h, n_ranks, rank)) != RR_OK) return s;
   if ((s = p2p_alloc_lidx(h)) != RR_OK) return s;
-  return h->p2p.connect_ipc(h->slab, 5 * h->n, all_handles, n_ranks, rank);
+  if ((s = h->p2p.connect_ipc(h->slab, 5 * h->n, all_handles, n_ranks, rank)) != RR_OK) return s;
+  return p2p_apply_cu_partition(h);
 }
 
 rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
@@ -2481,7 +2526,9 @@ rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
     inboxes[g] = 5 * handles[g]->n;
     devs[g] = handles[g]->opt.device;
   }
-  return rr::p2p_link_local(st, slabs, inboxes, devs, n_ranks);
+  rr_status s = rr::p2p_link_local(st, slabs, inboxes, devs, n_ranks);
+  for (int g = 0; g < n_ranks && s == RR_OK; ++g) s = p2p_apply_cu_partition(handles[g]);
+  return s;
 }
 
 // THREE launches: k_step_lazy<kSrcWindow> (propagate + weight; the own slots inside the window this shard served last step
@@ -2508,7 +2555,7 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   // rank" (run down in round 4 with tools/p2p_shared_device_jump.py: after a resample that moves most of a shard, every slot
   // was found delivered and consistent in memory -- AFTER the waiters had given up and freed the device).  Sharers whose step
   // kernels together can fill the device therefore take the eager form of the step, which has no wait inside a full-size kernel.
-  if (h->p2p.n_sharing > 1) {
+  if (h->p2p.n_sharing > 1 && !h->cu_part_cus) {  // (sharers with a part of the CUs each -- RR_P2P_CU_PARTITION -- cannot do that to each other)
     if (!h->dev_cus) RR_HIP_TRY(hipDeviceGetAttribute(&h->dev_cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
     const uint64_t step_wgs = (h->n + rr::kResolveSlots - 1) / rr::kResolveSlots;
     if (step_wgs * (uint64_t)h->p2p.n_sharing > 3ull * (uint64_t)h->dev_cus) return rr_pf_shard_step_p2p_unfused(h, control, obs, n_obs);
@@ -2543,15 +2590,17 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
     RR_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rr::k_shard_plan_mark, rr::kTileBlock, 0));
     RR_HIP_TRY(hipDeviceGetAttribute(&dev_cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
     h->dev_cus = dev_cus;
+    if (h->cu_part_cus) dev_cus = h->cu_part_cus;  // the stream's own part of the device
     h->shard_capacity = h->grid_capacity ? std::min<uint64_t>((uint64_t)per_cu * (uint64_t)dev_cus, (uint64_t)rr::kTileBlock) : 0;
   }
   // Ranks that share this device (a test rig: several shards of one filter on one GPU) run their kernels beside this one's;
   // a plan kernel that spins on every CU would leave a peer's exchange workgroup -- the one it is waiting for -- nowhere to
   // go (seen as stalls of seconds with two 1e6-particle shards on one device).  All sharers together keep to one
   // workgroup per CU.
-  const uint64_t fused_cap = h->p2p.n_sharing > 1 ? std::min<uint64_t>(h->shard_capacity, (uint64_t)h->dev_cus / (uint64_t)h->p2p.n_sharing)
-                                                  : h->shard_capacity;
-  const bool fused_plan = h->n_tiles <= fused_cap && rr::spin_permit(h->opt.device, h);
+  const uint64_t fused_cap = h->p2p.n_sharing > 1 && !h->cu_part_cus
+                                 ? std::min<uint64_t>(h->shard_capacity, (uint64_t)h->dev_cus / (uint64_t)h->p2p.n_sharing)
+                                 : h->shard_capacity;
+  const bool fused_plan = h->n_tiles <= fused_cap && rr::spin_permit(h->spin_gate_no, h);
   // RR_P2P_WMAX_EARLY=1: the last workgroup of the step kernel sends this shard's weight maximum to the ranks' mailboxes as it
   // finishes (WindowArgs.post_peers) and the one-launch plan's workgroups take the records from their own mailbox, instead of the
   // plan kernel's first workgroup opening with an exchange and a flag.  Measured at world size 1 (round 5,

@@ -1141,7 +1141,33 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
       if (!(st & 1)) {
         const TagPair* const want[4] = {&pp[blockIdx.x], &pp[kTileBlock + 0], &pp[kTileBlock + 1], &pp[kTileBlock + 2]};
         uint64_t got[4];
-        while (!take_pairs<4>(want, epoch, got)) __builtin_amdgcn_s_sleep(1);  // (stores issued before the state word moved: they land)
+        // (stores issued before the state word moved: they land.  The wait is bounded all the same -- ADVICE r5: a stale or damaged
+        // record buffer must not hang the device.  The launch's outcome is RAISED by now and cannot be taken back, so on expiry this
+        // workgroup takes its numbers from where the last arrival took them: the tiles' records, every one acknowledged at device
+        // scope before its ticket -- the same prefix, the same totals -- and raises Ctl.grid_timeout, which moves the handle to the
+        // multi-launch plan at the host's next look.)
+        const uint64_t tp = wall_clock64();
+        bool fit;
+        while (!(fit = take_pairs<4>(want, epoch, got))) {
+          if (wall_clock64() - tp > giveup_ticks + 100000) break;  // (+ 1 ms: RR_PF_PLAN_TIMEOUT_US = 0, the test hook, means "do not wait for the FLAG")
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (!fit) {
+          uint64_t pre = 0, tot = 0;
+          u128 qq = {0, 0};
+          for (uint64_t k = 0; k < n_tiles; ++k) {
+            const uint64_t* r = rec + k * kRecWords;
+            const uint64_t tk = ld_dev(&r[0]);
+            if (k < (uint64_t)blockIdx.x) pre += tk;
+            tot += tk;
+            qq = add128(qq, u128{ld_dev(&r[1]), ld_dev(&r[2])});
+          }
+          got[0] = pre;
+          got[1] = tot;
+          got[2] = qq.hi;
+          got[3] = qq.lo;
+          atomicAdd(&ctl->grid_timeout, 1);
+        }
         s_sum[0] = got[0];
         s_sum[1] = got[1];
         s_sum[2] = got[2];
@@ -1196,8 +1222,7 @@ static __global__ __launch_bounds__(kTileBlock) __attribute__((amdgpu_waves_per_
     RR_TL(6);
   } else {
     // The launch gave up and this workgroup arrived last: every tile, one after the other (the serial plan) -- the same functions,
-    // behind a real call, so that the loop's live values are not the straight path's register pressure.  (Tiles whose workgroups
-    // had gone by the pairs before somebody gave up are marked twice, with the same values.)
+    // behind a real call, so that the loop's live values are not the straight path's register pressure.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's own prefix pairs are read back below
     __syncthreads();
     plan_serial<FS_WEIGHTS, DEFER>(w, a, mode, shift, fire, rho, pa, n_tiles, rec, markers, carry, ea, want_est, cur_after, ts, s_w, s4, s_tile);

@@ -115,9 +115,12 @@ struct SpinGate {
   std::mutex m;
   const void* holder = nullptr;
 };
+// `device` is a gate number: the device ordinal, or -- for a handle whose stream is confined to its own part of the CUs
+// (RR_P2P_CU_PARTITION, pf_engine.hip) -- device + 64 * (part + 1): spinning kernels on disjoint CUs cannot starve each other
+constexpr int kSpinGates = 64 * 17;
 inline SpinGate& spin_gate(int device) {
-  static SpinGate g[64];
-  return g[device & 63];
+  static SpinGate g[kSpinGates];
+  return g[(unsigned)device % (unsigned)kSpinGates];
 }
 inline bool spin_permit(int device, const void* handle) {
   SpinGate& g = spin_gate(device);
@@ -141,6 +144,38 @@ inline uint64_t plan_giveup_ticks() {
     return (uint64_t)((us >= 0.0 ? us : 2000.0) * 100.0);
   }();
   return ticks;
+}
+
+// ---- rr_pf_warm / rr_fs1_warm: bring the device (and the runtime) to the state the thousandth step finds --------------
+// An MI355X that has been idle runs its first ~50 ms of work at reduced clocks (measured, MCL 1e6 x 32: 52.6 us/step right after
+// create, 47.9 after 1000 steps; k_step_lazy 35.8 -> 31.2 us), and the HIP runtime pays one-off costs along its first few thousand
+// launches.  A caller's first steps are then 10 % slower than its later ones.  device_warm enqueues `ms` milliseconds of FP64 work
+// on the handle's stream as launches of the size, argument block and cadence of a step kernel (25 us each, every CU busy, the
+// stream drained every 100 launches as a stepping caller drains it), so that the first real step runs at the steady rate.
+struct WarmArg {
+  double v[288];  // a step kernel's argument block carries the observations: ~2.3 KB
+};
+static __global__ __launch_bounds__(256) void k_warm(WarmArg a, uint64_t ticks /* of the 100 MHz wall clock */, double* sink) {
+  const uint64_t t0 = wall_clock64();
+  double x = a.v[threadIdx.x] + (double)threadIdx.x, y = 1.0000001;
+  do {
+#pragma unroll
+    for (int i = 0; i < 64; ++i) x = __builtin_fma(x, y, 1e-9);
+  } while (wall_clock64() - t0 < ticks);
+  if (x == 12345.678 && sink) *sink = x;  // (never: keeps the chain alive)
+}
+inline hipError_t device_warm(hipStream_t stream, int device, double ms) {
+  int cus = 0;
+  hipError_t e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  if (e != hipSuccess) return e;
+  static WarmArg arg{};  // zeros
+  const int launches = (int)(ms * 1000.0 / 25.0 + 0.5);
+  for (int i = 0; i < launches; ++i) {
+    hipLaunchKernelGGL(k_warm, dim3((unsigned)cus * 8u), dim3(256), 0, stream, arg, (uint64_t)2500, (double*)nullptr);
+    if ((i + 1) % 100 == 0 && (e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+  }
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  return hipStreamSynchronize(stream);
 }
 
 // ---- wave64 primitives (gfx950: a wavefront is 64 lanes) ------------------------------

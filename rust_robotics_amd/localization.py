@@ -263,6 +263,11 @@ class ParticleFilterLocalizer:
         _check(self._L.rr_pf_last_step_estimate(self._h, _dp(e)))
         return e
 
+    def warm(self, ms: float = 0.0) -> None:
+        """rr_pf_warm (engine extension): `ms` milliseconds (0: the default, 50) of step-shaped work on the filter's stream, so that
+        the first step runs at the rate of the thousandth (an idle MI355X starts at reduced clocks).  The particles are not touched."""
+        _check(self._L.rr_pf_warm(self._h, float(ms)))
+
     def synchronize(self) -> None:
         _check(self._L.rr_pf_synchronize(self._h))
 

@@ -533,6 +533,13 @@ class P2PShard:
         self._check(self.L.rr_pf_get_particles(self.h, out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
+    def set_particles(self, aos: np.ndarray) -> None:
+        """rr_pf_set_particles: this shard's block [n_local][x, y, yaw, v, w] of an injected cloud (parity seam)"""
+        a = np.ascontiguousarray(aos, dtype=np.float64)
+        if a.shape != (self.n_local, 5):
+            raise RoboticsError.invalid_parameter(f"expected an array of shape ({self.n_local}, 5)")
+        self._check(self.L.rr_pf_set_particles(self.h, a.ctypes.data_as(C.POINTER(C.c_double))))
+
     def local_moments(self):
         e, c = np.empty(4), np.empty(16)
         dp = C.POINTER(C.c_double)
@@ -921,6 +928,17 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     prof = shard.profile_read()
     shard.profile(False)
     dist.barrier()
+    # who took part, as seen from rank 0: every rank reports the device it ran on (PCI address) and how many peers its transport
+    # had connected (peer-to-peer: ranks whose mailbox / inbox are mapped, this one included; RCCL: the communicator's size)
+    bus = C.create_string_buffer(64)
+    if _ffi.lib().rr_device_pci_bus_id(local_rank, bus, 64) != _ffi.RR_OK:
+        bus.value = b"?"
+    peers = world if (use_p2p or ref is not None) else 1
+    seen = [None] * world
+    dist.all_gather_object(seen, (rank, bus.value.decode(), peers))
+    devices = sorted({b for _, b, _ in seen})
+    ranks_seen = dict(ranks=len({r for r, _, _ in seen}), peers_connected_min=min(p for _, _, p in seen), distinct_devices=len(devices),
+                      devices=devices)
     if p2p is not None:
         p2p.close()
     if ref is not None:
@@ -929,4 +947,5 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
         dist.destroy_process_group()
     return dict(seconds=seconds, seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est], dominant=None,
                 migrated_particles_last_step=moved, transport="p2p (xGMI, device-initiated)" if use_p2p else ref_kind,
-                transport_note="; ".join(notes), p2p_timed_out=bool(timed_out), estimate_every_step=bool(est_every_step))
+                transport_note="; ".join(notes), p2p_timed_out=bool(timed_out), estimate_every_step=bool(est_every_step),
+                ranks_seen=ranks_seen)

@@ -123,6 +123,10 @@ class FastSlam1:
     def synchronize(self) -> None:
         _check(self._L.rr_fs1_synchronize(self._h))
 
+    def warm(self, ms: float = 0.0) -> None:
+        """rr_fs1_warm: `ms` milliseconds (0: 50) of step-shaped work on the filter's stream before the first update"""
+        _check(self._L.rr_fs1_warm(self._h, float(ms)))
+
     def set_resident(self, idle_us: float) -> None:
         """Resident service (``rr_fs1_set_resident``, engine extension): with ``idle_us > 0`` the updates of a FastSLAM 1.0 filter
         of up to 1024 particles are served by ONE kernel that stays on the device and answers each of them with the best

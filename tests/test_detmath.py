@@ -223,3 +223,46 @@ def test_uniform_and_normal_streams(det):
     assert np.array_equal(w0, z0[1000:1010]) and np.array_equal(w1, z1[1000:1010])
     det.det_normal2_v(42, 3, 8, 1000, 10, dp(w0), dp(w1))
     assert not np.array_equal(w0, z0[1000:1010])
+
+
+def test_normal_stream_ks_moments_tails_and_cross_step_independence(det):
+    """the 7-round Philox -> Box-Muller NORMAL stream the filters consume (RR_STREAM_MOTION), beyond bit-identity
+    with the host restatement: Kolmogorov-Smirnov against N(0, 1) for both outputs of a block, over the particle index (one step)
+    AND over the step counter (one particle: the sequence a single hypothesis sees); the first six moments; tail mass beyond 3 / 4
+    sigma; the pair (z0, z1) of one block and the pairs (z_t, z_t+1) of consecutive steps uncorrelated, also in their squares (the
+    failure mode of a weak counter mix is dependence, not a wrong marginal); and the radius / angle split of the pair uniform."""
+    from scipy import stats
+
+    n = 1 << 19
+    z0, z1 = np.empty(n), np.empty(n)
+    det.det_normal2_v(1, 3, 11, 0, n, dp(z0), dp(z1))  # seed 1 (bench.py's), the motion stream, one step, 2^19 particle indices
+    for z in (z0, z1):
+        d, p = stats.kstest(z, "norm")
+        assert p > 1e-4, (d, p)
+        m = [float(np.mean(z**k)) for k in range(1, 7)]
+        se = [math.sqrt(v / n) for v in (1, 2, 15, 96, 945, 10170)]  # sd of z^k's sample mean under N(0, 1): Var(z^k) = E z^2k - (E z^k)^2
+        for got, want, s in zip(m, (0, 1, 0, 3, 0, 15), se):
+            assert abs(got - want) < 5 * s, (m, want)
+        for t, tail in ((3.0, 2 * stats.norm.sf(3.0)), (4.0, 2 * stats.norm.sf(4.0))):
+            k = int(np.count_nonzero(np.abs(z) > t))
+            assert abs(k - n * tail) < 5 * math.sqrt(n * tail) + 1, (t, k, n * tail)
+    lim = 5 / math.sqrt(n)
+    assert abs(np.corrcoef(z0, z1)[0, 1]) < lim and abs(np.corrcoef(z0**2, z1**2)[0, 1]) < lim
+    # Box-Muller's own structure: radius^2 / 2 is Exp(1), the angle is uniform, and the two are independent
+    r2, ang = 0.5 * (z0**2 + z1**2), np.arctan2(z1, z0)
+    assert stats.kstest(r2, "expon").pvalue > 1e-4 and stats.kstest((ang + math.pi) / (2 * math.pi), "uniform").pvalue > 1e-4
+    assert abs(np.corrcoef(r2, ang)[0, 1]) < lim
+    # one particle index over 2^16 consecutive steps (the noise sequence ONE hypothesis integrates), and its neighbour
+    T = 1 << 16
+    seq = np.empty((2, T))
+    a, b = np.empty(1), np.empty(1)
+    for k, index in enumerate((123_456, 123_457)):
+        for t in range(T):
+            det.det_normal2_v(1, 3, t, index, 1, dp(a), dp(b))
+            seq[k, t] = a[0]
+    for k in range(2):
+        assert stats.kstest(seq[k], "norm").pvalue > 1e-4
+        for lag in (1, 2, 7):
+            assert abs(np.corrcoef(seq[k, :-lag], seq[k, lag:])[0, 1]) < 5 / math.sqrt(T), (k, lag)
+            assert abs(np.corrcoef(seq[k, :-lag] ** 2, seq[k, lag:] ** 2)[0, 1]) < 5 / math.sqrt(T), (k, lag)
+    assert abs(np.corrcoef(seq[0], seq[1])[0, 1]) < 5 / math.sqrt(T)

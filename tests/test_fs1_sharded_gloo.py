@@ -1,4 +1,4 @@
-"""Sharded FastSLAM 1.0 on CPU (world sizes 2 and 3, gloo): the protocol the HIP engine runs
+"""Sharded FastSLAM 1.0 on CPU (world sizes 2, 3 and 8 -- the BASELINE's rank count --, gloo): the protocol the HIP engine runs
 between GPUs -- contiguous particle blocks with their whole maps, global weight maximum, integer
 sums of every shard, gate + systematic plan from the global totals, whole particles moved along
 the segment matrix -- executed with the D-spec oracle standing in for the kernels must reproduce
@@ -54,7 +54,7 @@ def single_shard(n, L, steps, chunks):
     return pw, px, py, pyaw, planes.reshape(L * 6, n), fired
 
 
-@pytest.mark.parametrize("world,chunks,port", [(2, 1, 29641), (3, 2, 29642)])
+@pytest.mark.parametrize("world,chunks,port", [(2, 1, 29641), (3, 2, 29642), (8, 2, 29643)])
 def test_sharded_fastslam_equals_single_shard(tmp_path, world, chunks, port):
     n_local, L, steps = 300, 5, 9
     n = n_local * world

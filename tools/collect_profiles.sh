@@ -41,7 +41,16 @@ for wl in mcl fs1 fs2 mcl_1000000x32_multinomial mcl_16000000x64_systematic; do
   run ${wl}_write --kernel-trace --pmc WRITE_SIZE -- $cmd
   python tools/summarize_rocprof.py hbm $wl "$(find_csv ${wl}_fetch counter_collection)" "$(find_csv ${wl}_write counter_collection)" > "$OUT/hbm_$wl.csv"
 done
-{ cat "$OUT/hbm_mcl.csv"; for wl in fs1 fs2 mcl_1000000x32_multinomial mcl_16000000x64_systematic; do tail -n +2 "$OUT/hbm_$wl.csv"; done; } > "$OUT/${TAG}_pmc_hbm_traffic.csv"
+{ cat "$OUT/hbm_mcl.csv"; for wl in fs1 fs2 mcl_1000000x32_multinomial mcl_16000000x64_systematic; do tail -n +2 "$OUT/hbm_$wl.csv"; done; } > "$OUT/pmc_hbm_traffic_nosha.csv"
+# every row carries the hash of the library it was measured on: bench.py's measured_traffic() reports the bytes only when that is the
+# library it has loaded (library_sha16 column = first 16 hex digits of the .so's SHA-256)
+python - "$OUT/pmc_hbm_traffic_nosha.csv" "${RR_AMD_LIBRARY:-$REPO/rust_robotics_amd/librust_robotics_amd.so}" > "$OUT/${TAG}_pmc_hbm_traffic.csv" <<'PY'
+import hashlib, sys
+sha = hashlib.sha256(open(sys.argv[2], "rb").read()).hexdigest()[:16]
+for i, ln in enumerate(open(sys.argv[1]).read().splitlines()):
+    print(ln + ("," + ("library_sha16" if i == 0 else sha)))
+PY
+rm -f "$OUT/pmc_hbm_traffic_nosha.csv"
 run mcl5_trace --kernel-trace --stats -- $MCL5 --steps 20 --warmup 3
 python tools/summarize_rocprof.py stats "$(find_csv mcl5_trace kernel_trace)" > "$OUT/${TAG}_mcl_1.6e7x64_kernel_stats.csv"
 run fs2_trace --kernel-trace --stats -- $FS2
