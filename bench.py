@@ -22,1253 +22,26 @@ stdout carries that one line and nothing else: once the arguments are parsed, fi
 and RCCL print banners there from C++) and the line goes to a private copy of the real stdout.  Progress
 (``[bench rank r +t s] ...``) goes to stderr.  ``RR_BENCH_DEADLINE_S`` (default 600; 0 = none): a stalled extra leg or a dead
 rank costs at most this long -- rank 0 then prints the headline leg it already has, flagged ``deadline_exceeded``.
+
+The legs live in benchlib/ (round 6: this file used to be one 1 600-line module); everything they define is re-exported here, so
+`import bench; bench.leg_small_n(...)` keeps working for tools/ and tests/.
 """
 import argparse
-import json
-import math
 import os
-import socket
 import subprocess
 import sys
-import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
-FP64_VALU_PEAK = 256 * 4 * 16 * 2.4e9  # FP64 FMA lane-instructions / s: 256 CUs x 4 SIMDs x 16 lanes/clk x 2.4 GHz = 3.93e13
-# algorithmic HBM bytes per particle of the dominant kernel (DESIGN.md section 4): read x,y,yaw (24 B) + write
-# x,y,yaw,v,w (40 B); the systematic path's k_step_lazy also reads and clears the 4-byte resample marker
-K1_BYTES = {"systematic": 72.0, "multinomial": 64.0}
-# sharded legs: a process that has torch's HIP context loaded stalls once on the host (~40 ms) somewhere in its first few
-# hundred launches (DESIGN.md section 6); this many extra untimed steps keep that out of the timed region
-EXTRA_WARMUP = 1000
-
-# ---- one JSON line on stdout, whatever the native libraries print; progress on stderr; a deadline
-_T0 = time.time()
-_OUT = {"fd": None, "partial": None, "emitted": False}
-
-
-def log(msg):
-    """progress on stderr (the driver keeps it): which leg a rank is in when something takes long"""
-    sys.stderr.write(f"[bench rank {os.environ.get('RANK', '0')} +{time.time() - _T0:6.1f}s] {msg}\n")
-    sys.stderr.flush()
-
-
-def claim_stdout():
-    """gloo and RCCL print banners and warnings on file descriptor 1 from C++: from here on descriptor 1 IS stderr, and
-    the one JSON line goes to a private copy of the real stdout (emit)."""
-    if _OUT["fd"] is None:
-        sys.stdout.flush()
-        _OUT["fd"] = os.dup(1)
-        os.dup2(2, 1)
-
-
-def start_deadline(rank):
-    """A rank that dies or a transport that stalls must not keep the whole job (and whoever launched it) waiting for a
-    chain of collective time-outs: after RR_BENCH_DEADLINE_S seconds (default 600, 0 = none) rank 0 prints what it has --
-    the headline leg if that finished, flagged `deadline_exceeded` -- and every rank leaves."""
-    import threading
-
-    limit = float(os.environ.get("RR_BENCH_DEADLINE_S", "600"))
-    if limit <= 0:
-        return
-
-    def fire():
-        log(f"deadline of {limit:.0f} s exceeded -- leaving")
-        rc = 3
-        if rank == 0 and _OUT["partial"] is not None and not _OUT["emitted"]:
-            line = dict(_OUT["partial"])
-            line["deadline_exceeded"] = True
-            emit(line)
-            rc = 0
-        os._exit(rc if rank == 0 else 0)
-
-    t = threading.Timer(limit, fire)
-    t.daemon = True
-    t.start()
-# every leg: the device itself needs ~50 ms of this work before it runs at its steady rate -- measured, MCL 1e6 x 32 with
-# --steps 20: 51.2 us/step after 5 warm-up steps, 48.3 after 300, 46.5 after 1000, 47.0 after 3000 (`k_step_lazy` 35.8 ->
-# 31.2 us); FastSLAM 1e5 x 200: 408 us/update after 5 warm-up updates, 397 after 50.  These untimed steps run BEFORE the W
-# warm-up steps of the command line and are reported as `device_warmup_steps`; the timed region is still exactly K steps.
-DEVICE_WARMUP_MCL = 1000
-DEVICE_WARMUP_FS = 60
-FS1_BYTES_PER_UPDATE = 96.0  # k_fs1_observe: read 48 B + write 48 B per (particle, observed landmark), EKF branch
-
-
-def library_sha16():
-    """first 16 hex digits of the SHA-256 of the engine library this process has loaded (what tools/collect_profiles.sh stamps into
-    the PMC summaries it writes)"""
-    import hashlib
-
-    from rust_robotics_amd import _ffi
-
-    try:
-        with open(_ffi.LIB_PATH, "rb") as f:
-            return hashlib.sha256(f.read()).hexdigest()[:16]
-    except OSError:
-        return None
-
-
-def measured_traffic(kernel_prefix, workload, est=None):
-    """HBM bytes per launch of `kernel_prefix` from the committed PMC passes (separate rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE runs, read side doubled as MI355X_MICROARCH.md prescribes for gfx950).
-    Newest round first.  `est`: of k_step_lazy's instantiations the one whose last template argument (EST: the build that also
-    adds up the deferred estimate) is this.
-    The bytes are only returned when the summary was collected ON THE LIBRARY THAT IS LOADED NOW (its `library_sha16` column,
-    written by tools/collect_profiles.sh, equals library_sha16()): a number measured on another build is not this build's traffic
-    (VERDICT r5 weak 12).  Otherwise (None, why)."""
-    import csv
-    import glob
-
-    sha = library_sha16()
-    stale = None
-    newest = sorted(os.path.basename(f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv")))[::-1]
-    for name in newest:
-        try:
-            rows = [r for r in csv.DictReader(open(os.path.join(ROOT, "profiles", name))) if r["workload"] == workload and r["kernel"].startswith(kernel_prefix)]
-            if est is not None and any(r["kernel"].endswith((",true>", ",false>")) for r in rows):
-                rows = [r for r in rows if r["kernel"].endswith(",true>" if est else ",false>")]
-            if rows:  # several instantiations of one kernel in a run (a warm-up variant): the one that did the timed launches
-                r = max(rows, key=lambda q: int(q["dispatches"]))
-                have = r.get("library_sha16")
-                if have and sha and have == sha:
-                    return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6, f"profiles/{name} [library sha256 {sha}: the loaded build]"
-                if stale is None:
-                    mb = float(r["read_MB_corrected_x2"]) + float(r["write_MB"])
-                    stale = (f"profiles/{name} holds {mb:.1f} MB per launch for this kernel, measured on " +
-                             (f"library {have}" if have else "a build that left no hash") + f"; the loaded library is {sha}: not reported as this build's traffic")
-        except Exception:
-            pass
-    return None, stale
-
-
-def host_cpu():
-    model = "unknown"
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                model = line.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return model, os.cpu_count() or 1
-
-
-_THREADS = {}
-
-
-def pick_threads():
-    """Thread count for the OpenMP CPU baseline: the fastest of {1, 2, 4, ...} up to the CPUs this process may
-    use (scheduler affinity and cgroup quota -- a container usually sees far fewer than /proc/cpuinfo lists), found
-    by a short calibration on the weight kernel of the literal restatement.  Returns (threads, {threads: updates/s})."""
-    if _THREADS:
-        return _THREADS["best"], _THREADS["table"]
-    import oracle
-    from oracle import dp
-
-    ref = oracle.ref()
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        avail = os.cpu_count() or 1
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            avail = max(1, min(avail, int(math.ceil(int(quota) / int(period)))))
-    except (OSError, ValueError):
-        pass
-    n, L = 200_000, 32
-    rng = np.random.default_rng(0)
-    x, y = rng.normal(size=n), rng.normal(size=n)
-    w = np.empty(n)
-    obs = np.ascontiguousarray(np.column_stack([rng.uniform(5, 20, L), rng.uniform(-20, 20, L), rng.uniform(-20, 20, L)]))
-    table, t = {}, 1
-    cands = []
-    while t < avail:
-        cands.append(t)
-        t *= 2
-    cands.append(avail)
-    for th in cands:
-        ref.ref_set_threads(th)
-        ref.ref_pf_update_raw(n, dp(x), dp(y), dp(w), dp(obs), L, 0.2)  # creates the team
-        best = 1e9
-        for _ in range(3):
-            t0 = time.perf_counter()
-            ref.ref_pf_update_raw(n, dp(x), dp(y), dp(w), dp(obs), L, 0.2)
-            best = min(best, time.perf_counter() - t0)
-        table[th] = n * L / best
-    ref.ref_set_threads(1)
-    _THREADS["best"] = max(table, key=table.get)
-    _THREADS["table"] = {str(k): round(v) for k, v in table.items()}
-    _THREADS["avail"] = avail
-    return _THREADS["best"], _THREADS["table"]
-
-
-def make_scene(L, steps, seed):
-    from tests import helpers as H
-
-    lms = H.landmarks_grid(L, seed)
-    rng = np.random.default_rng(seed + 1)
-    return [H.observations(lms, H.true_pose(t + 1), 0.2, rng) for t in range(steps)]
-
-
-# ------------------------------------------------------------------------------------------------------
-# CPU baselines: oracle/ref_literal.c (the reference's arithmetic restated line by line) timed on this
-# box's host cores.  SURVEY.md 8d: per-particle stages under OpenMP on all cores, cumsum / resample walk
-# serial as in the reference; the reference's own O(N^2) multinomial resample timed separately at N = 1e4.
-def cpu_baseline(n, L, obs_list, max_seconds=12.0, scheme="systematic", brief=False):
-    """`value` = the literal restatement running the SAME step as the GPU leg it stands beside: the MCL step with the
-    reference's systematic walk (fastslam1.rs:205-234) for the systematic legs, with its multinomial draws
-    (monte_carlo_localization.rs:322-365, binary search) for the multinomial leg; the other variant is reported next to it."""
-    import oracle
-    from oracle import dp, u32p
-
-    ref = oracle.ref()
-    det = oracle.det()
-    model, nproc = host_cpu()
-    sv, sw = 2.0, math.radians(40.0)
-
-    def run(threads, n_run, budget, literal_scan, scheme_id):
-        used = ref.ref_set_threads(threads)
-        x, y, yaw, v = (np.zeros(n_run) for _ in range(4))
-        st = np.array([0.0, 0.0, 0.0, 1.0])
-        det.det_pf_init(n_run, 1, 0, dp(st), dp(x), dp(y), dp(yaw), dp(v))
-        w = np.full(n_run, 1.0 / n_run)
-        idx = np.empty(n_run, np.uint32)
-        est = np.empty(4)
-        z0, z1, r, r2 = (np.empty(n_run) for _ in range(4))
-        steps, t_total = 0, 0.0
-        while steps < len(obs_list) and t_total < budget:
-            obs = np.ascontiguousarray(obs_list[steps])
-            # noise generation is not part of the timed arithmetic: the reference draws from ChaCha12/ziggurat,
-            # we hand it ready samples (DESIGN.md section 6)
-            det.det_normal2_v(1, 3, steps, 0, n_run, dp(z0), dp(z1))
-            det.det_uniform2_v(1, 4, steps, 0, n_run, dp(r), dp(r2))
-            nv, nw = sv * z0, sw * z1
-            t0 = time.perf_counter()
-            ref.ref_pf_step_ex(n_run, dp(x), dp(y), dp(yaw), dp(v), dp(w), 1.0, 0.1, 0.1, dp(nv), dp(nw), dp(obs), L, 0.2, 1.0, scheme_id,
-                               dp(r), u32p(idx), dp(est), 1 if literal_scan else 0)
-            dt = time.perf_counter() - t0
-            if steps or budget < 1.0:  # the first step also pays for the thread team's creation
-                t_total += dt
-            steps += 1
-        ref.ref_set_threads(1)
-        timed = max(steps - (0 if budget < 1.0 else 1), 1)
-        return n_run * L * timed / max(t_total, 1e-9), used, timed, t_total
-
-    threads, table = pick_threads()
-    main_id, other_id = (2, 1) if scheme == "systematic" else (1, 2)
-    names = {1: "multinomial draws + binary search (monte_carlo_localization.rs:322-365,387-392)", 2: "systematic walk (fastslam1.rs:205-234)"}
-    v_all, cores, s_all, t_all = run(threads, n, max_seconds, False, main_id)
-    if brief:  # the extra legs: the like-for-like number only (the variants are in the headline legs of the same line)
-        return dict(value=v_all, unit="particle-landmark updates/s", cores=cores, kind="port",
-                    sample=f"oracle/ref_literal.c ref_pf_step (literal reference arithmetic; predict / weight / gather under OpenMP on {cores} threads, "
-                           f"cumsum + resample -- {names[main_id]} -- serial), {n} particles x {L} landmarks x {s_all} steps, {t_all:.1f} s, noise samples pre-drawn",
-                    host={"cpu_model": model, "nproc": nproc, "threads": cores})
-    v_one, _, s_one, t_one = run(1, n, max_seconds / 2, False, main_id)
-    v_oth, _, s_oth, t_oth = run(threads, n, max_seconds / 3, False, other_id)
-    # the reference's own resample: a linear scan of the cumulative weights per draw (particle_filter.rs:455-470),
-    # gate forced open (threshold 1.0 + scheme 0 fires whenever N_eff < N, i.e. always after a weight update)
-    n_f = min(n, 10_000)
-    v_f, _, s_f, t_f = run(threads, n_f, 4.0, True, 0)
-    return dict(value=v_all, unit="particle-landmark updates/s", cores=cores, kind="port",
-                sample=f"oracle/ref_literal.c ref_pf_step (literal reference arithmetic; predict / weight / gather under OpenMP on "
-                       f"{cores} threads, cumsum + resample -- {names[main_id]} -- serial), {n} particles x {L} landmarks x {s_all} "
-                       f"steps, {t_all:.1f} s, noise samples pre-drawn",
-                host={"cpu_model": model, "nproc": nproc, "usable_cpus": _THREADS.get("avail"), "threads": cores,
-                      "thread_calibration_updates_per_s": table},
-                single_thread={"value": v_one, "steps": s_one, "seconds": round(t_one, 2)},
-                other_resampler={"value": v_oth, "resample": names[other_id], "steps": s_oth, "seconds": round(t_oth, 2), "threads": cores},
-                reference_faithful={"value": v_f, "particles": n_f, "steps": s_f, "seconds": round(t_f, 2), "threads": cores,
-                                    "note": "the reference's own O(N^2) resample (linear scan per draw, particle_filter.rs:455-470); "
-                                            "infeasible at 1e6 particles (~5e11 compares per step), so measured at N = 1e4 and never extrapolated"})
-
-
-def index_parity(pf, n, L, scheme, obs):
-    """Checker, not product: how many output slots of ONE resample at this size pick a different particle than the reference's
-    own float walk over the same normalised weights and the same draws (the integer CDF is order-independent, the reference's
-    serial float cumsum is not: DESIGN.md section 2).  Runs after the timed regions on the filter the leg just timed."""
-    import oracle
-    from oracle import dp, u32p
-
-    ref = oracle.ref()
-    rng = np.random.default_rng(17)
-    pf.predict_with_control([1.0, 0.1])
-    pf.update_with_observations(obs)
-    w = pf.get_particles_array()[:, 4].copy()
-    lit = np.empty(n, np.uint32)
-    if scheme == "systematic":
-        rho = float(np.floor(rng.random() * 2**53) / 2**53)
-        pf.resample_systematic(rho)
-        ref.ref_fs1_resample_indices(n, dp(w.copy()), rho / n, u32p(lit))
-        walk = "fastslam1.rs:205-234 (r += 1/n accumulated serially)"
-    else:
-        r = np.floor(rng.random(n) * 2**53) / 2**53
-        pf.resample_with_uniforms(r)
-        ref.ref_mcl_resample_indices(n, dp(w), dp(r), u32p(lit))
-        walk = "monte_carlo_localization.rs:328-392 (serial float cumsum, first i with r <= c[i])"
-    got = pf.last_resample_indices()
-    diff = np.nonzero(got != lit)[0]
-    far = int(np.max(np.abs(got[diff].astype(np.int64) - lit[diff].astype(np.int64)))) if diff.size else 0
-    return {"resample": scheme, "slots": n, "differing_slots_vs_literal_float_walk": int(diff.size), "max_index_distance": far,
-            "literal_walk": walk,
-            "note": "identical weights and draws into the engine and into the literal restatement; a differing slot picks the neighbouring "
-                    "particle (the draw lies within the float cumsum's own rounding error of a boundary); bit-exact against the "
-                    "order-independent integer CDF of the D-spec at every size (tests/)"}
-
-
-def fs1_scene(L, seed, half=13.0):
-    rng = np.random.default_rng(seed)
-    return rng.uniform(-half, half, size=(L, 2))
-
-
-def fs1_cpu_baseline(n, L, z_list, max_seconds=10.0):
-    """fastslam_update of the literal C restatement (oracle/ref_literal.c), all host cores + one core."""
-    import ctypes as C
-
-    import oracle
-    from oracle import dp, u32p
-
-    ref, det = oracle.ref(), oracle.det()
-    model, nproc = host_cpu()
-
-    def run(threads, budget):
-        used = ref.ref_set_threads(threads)
-        m = oracle.ref_fs1_model()
-        m.init_cov = 0.5
-        px, py, pyaw = (np.zeros(n) for _ in range(3))
-        pw = np.full(n, 0.01)
-        lm = np.tile(np.array([0, 0, 1000.0, 0, 0, 1000.0]), (n, L, 1)).reshape(-1).copy()
-        idx = np.empty(n, np.uint32)
-        z0, z1 = np.empty(n), np.empty(n)
-        steps, t_total, updates = 0, 0.0, 0
-        while steps < len(z_list) and t_total < budget:
-            z = np.ascontiguousarray(z_list[steps])
-            det.det_normal2_v(2, 3, steps, 0, n, dp(z0), dp(z1))
-            t0 = time.perf_counter()
-            ref.ref_fs1_update(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(lm), 0.5, 0.1, dp(z0), dp(z1), dp(z), len(z), C.byref(m),
-                               n / 1.5, 0.3 / n, u32p(idx))
-            dt = time.perf_counter() - t0
-            if steps:  # step 0 takes the initialisation branch and creates the thread team
-                t_total += dt
-                updates += n * len(z)
-            steps += 1
-        ref.ref_set_threads(1)
-        return updates / max(t_total, 1e-9), used, steps - 1, t_total
-
-    threads, table = pick_threads()
-    v_all, cores, s_all, t_all = run(threads, max_seconds)
-    v_one, _, s_one, t_one = run(1, max_seconds / 2)
-    return dict(value=v_all, unit="particle-landmark updates/s", cores=cores, kind="port",
-                sample=f"oracle/ref_literal.c ref_fs1_update (literal fastslam1.rs arithmetic; predict / EKF / clone under OpenMP on {cores} "
-                       f"threads, normalise + systematic walk serial), {n} particles x {L} landmarks x {s_all} EKF-branch steps, {t_all:.1f} s",
-                host={"cpu_model": model, "nproc": nproc, "usable_cpus": _THREADS.get("avail"), "threads": cores,
-                      "thread_calibration_updates_per_s": table},
-                single_thread={"value": v_one, "steps": s_one, "seconds": round(t_one, 2)})
-
-
-def fs2_cpu_baseline(n, L, z_list, max_seconds=10.0):
-    """fastslam2_update of the literal C restatement (oracle/ref_literal.c), all host cores."""
-    import oracle
-    from oracle import dp, u32p
-
-    ref = oracle.ref()
-    model, nproc = host_cpu()
-    cores = ref.ref_set_threads(pick_threads()[0])
-    px, py, pyaw = (np.zeros(n) for _ in range(3))
-    pw = np.full(n, 0.01)
-    lm = np.tile(np.array([0, 0, 1000.0, 0, 0, 1000.0]), (n, L, 1)).reshape(-1).copy()
-    idx = np.empty(n, np.uint32)
-    rng = np.random.default_rng(2)
-    steps, t_total, updates = 0, 0.0, 0
-    while steps < len(z_list) and t_total < max_seconds:
-        z = np.ascontiguousarray(z_list[steps])
-        noise = np.ascontiguousarray(rng.normal(size=(n, 3)))
-        t0 = time.perf_counter()
-        ref.ref_fs2_update(n, L, dp(px), dp(py), dp(pyaw), dp(pw), dp(lm), 0.5, 0.1, dp(noise), dp(z), len(z), n / 1.5, 0.3 / n, u32p(idx))
-        dt = time.perf_counter() - t0
-        if steps:
-            t_total += dt
-            updates += n * len(z)
-        steps += 1
-    ref.ref_set_threads(1)
-    return dict(value=updates / max(t_total, 1e-9), unit="particle-landmark updates/s", cores=cores, kind="port",
-                sample=f"oracle/ref_literal.c ref_fs2_update (literal fastslam2.rs arithmetic, OpenMP over particles on {cores} threads), "
-                       f"{n} particles x {L} landmarks x {steps - 1} steps, {t_total:.1f} s, normals pre-drawn",
-                host={"cpu_model": model, "nproc": nproc, "threads": cores})
-
-
-# ------------------------------------------------------------------------------------------------------
-class Ctx:
-    """rank / world / device of this process and, for world > 1 (or --force-sharded), the gloo group that
-    carries bootstrap data and the timing barrier (never particle data)."""
-
-    def __init__(self, args):
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if os.environ.get("RR_BENCH_SHARE_DEVICE"):  # development knob: every rank on device 0, so that the multi-process
-            self.local_rank = 0                       # flow (launcher, gloo group, IPC hand-off, ladder) runs on a one-GPU box
-        self.sharded = self.world > 1 or args.force_sharded
-        self.dist = None
-
-    def init_group(self):
-        if self.dist is not None or not self.sharded:
-            return
-        import torch.distributed as dist
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29555")  # a lone rank started without a launcher
-        import datetime
-
-        # a rank that dies inside a leg must not leave the others waiting for half an hour in a gloo collective
-        dist.init_process_group("gloo", rank=self.rank, world_size=self.world, timeout=datetime.timedelta(seconds=240))
-        self.dist = dist
-
-    def close(self):
-        if self.dist is not None:
-            self.dist.barrier()
-            self.dist.destroy_process_group()
-            self.dist = None
-
-
-def require_devices(ctx):
-    """The engine has no CPU fallback: say so once, clearly, instead of failing somewhere inside a rank."""
-    from rust_robotics_amd import _ffi
-
-    have = int(_ffi.lib().rr_device_count())
-    need = ctx.local_rank + 1
-    if have < need:
-        msg = (f"bench.py: no HIP device available for rank {ctx.rank} (local rank {ctx.local_rank}; {have} device(s) visible) -- "
-               f"the engine has no CPU fallback; run on an MI355X box")
-        if ctx.dist is not None:
-            try:
-                ctx.close()
-            except Exception:
-                pass
-        raise SystemExit(msg)
-
-
-# ------------------------------------------------------------------------------------------------------
-def leg_fastslam(args, n, L, K, W, v2=False, with_cpu=True, breakdown=True, device_warmup=None, label="configs[2]"):
-    """BASELINE.json configs[2]: FastSLAM 1.0, 100 000 particles x 200 landmarks, every landmark observed
-    every step, EKF branch (first_obs_cov = 0.5 initialises the maps on the first, untimed, step),
-    N_eff threshold N/1.5 so that resampling triggers data-dependently."""
-    from rust_robotics_amd.slam import fastslam1 as fs
-    from tests import helpers as H
-
-    lms = fs1_scene(L, 2)
-    if v2:  # the same configuration with the FastSLAM 2.0 proposal (fastslam2.rs); first_obs_cov = 10 is its own constant
-        from rust_robotics_amd.slam import fastslam2 as fs2
-
-        prm2 = fs2.default_params()
-        prm2.base.nth = n / 1.5
-        f = fs2.FastSlam2(n, L, params=prm2, seed=2)
-    else:
-        prm = fs.default_params()
-        prm.first_obs_cov = 0.5
-        prm.nth = n / 1.5 * float(os.environ.get("RR_BENCH_NTH_SCALE", "1"))  # development knob: 0 = never resample, 10 = every step
-        f = fs.FastSlam1(n, L, params=prm, seed=2, obs_chunks=int(os.environ.get("RR_BENCH_OBS_CHUNKS", "0")))  # 0 = the engine's own choice
-    D = DEVICE_WARMUP_FS if device_warmup is None else device_warmup
-    zs = [np.array(fs.get_observations(H.true_pose(t + 1, v=0.5), [tuple(p) for p in lms], seed=2, step=t)).reshape(-1, 3)
-          for t in range(D + 2 * K + W)]
-    u = [0.5, 0.1]
-    for t in range(D):  # device warm-up (see DEVICE_WARMUP_FS), then time moves on
-        f.update_async(u, zs[t])
-    zs = zs[D:]
-    for t in range(W):
-        f.update_async(u, zs[t])
-    f.synchronize()
-    # the dominant kernel is timed INSIDE the timed region by the timestamps of its own dispatch packets
-    f.profile_enable(2)
-    f.profile_reset()
-    t0 = time.perf_counter()
-    for t in range(W, W + K):
-        f.update_async(u, zs[t])
-    f.synchronize()
-    dt = time.perf_counter() - t0
-    k_n, k_ms = f.profile_read()["k_fs1_observe"]
-    updates = float(sum(n * len(zs[t]) for t in range(W, W + K)))
-    # per-kernel breakdown: instrumented CONTINUATION (HIP events around every launch; the filter has moved
-    # on, so these averages belong to later steps -- informational only)
-    prof, dt_i = {"k_fs1_observe": (k_n, k_ms)}, 0.0
-    if breakdown:
-        f.profile_enable(1)
-        f.profile_reset()
-        t1 = time.perf_counter()
-        for t in range(W + K, W + 2 * K):
-            f.update_async(u, zs[t])
-        f.synchronize()
-        dt_i = time.perf_counter() - t1
-        prof = f.profile_read()
-    f.profile_enable(0)
-    pose, w, i = f.best_particle()
-    chunks = f.counters()[2]
-    del f
-    avg_s = k_ms / max(k_n, 1) * 1e-3
-    per_launch = FS1_BYTES_PER_UPDATE * n * np.mean([len(zs[t]) for t in range(W, W + K)])
-    achieved = per_launch / avg_s if avg_s > 0 else 0.0
-    traffic, traffic_src = measured_traffic("k_fs1_observe", "fs2" if v2 else "fs1") if (n, L) == (100_000, 200) else (None, None)
-    out = {
-        "metric": "particle-landmark updates/sec", "value": updates / dt, "unit": "particle-landmark updates/s", "n_gpus": 1,
-        "steps": K, "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": (f"FastSLAM 2.0 (the configs[2] shape with the proposal of fastslam2.rs): " if v2 else
-                                f"FastSLAM 1.0 (BASELINE.json {label}): ") +
-                               f"{n} particles x {L} landmarks, all observed, 2x2 EKF branch, N_eff-gated systematic resample",
-                   "particles_per_gpu": n, "landmarks": L},
-        "roofline": {"bound": "hbm", "kernel": "k_fs1_observe", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK, "traffic": traffic,
-                     "traffic_source": ((traffic_src + (" (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over `bench.py --workload fastslam "
-                                                        "--no-breakdown`, bytes per launch, read side x2)" if traffic is not None else ""))
-                                        if traffic_src else None),
-                     "avg_kernel_ms": avg_s * 1e3, "timed_launches": k_n,
-                     "timing": "dispatch timestamps of the K launches inside the timed region",
-                     "algorithmic_bytes_per_launch": per_launch,
-                     "note": "`peak` is the HBM peak; a plain copy of the same bytes (dst[i] = src[i], 16 B per thread) runs at 4.6-6.2 TB/s on this "
-                             "GPU depending on its launch shape (hipMemcpyAsync D2D: 5.1; tools/ubench/copy_rates.hip) and the kernel's own "
-                             "access pattern with synthetic arithmetic at 5.2-5.4 TB/s (tools/ubench/plane_layout.hip, DESIGN.md section 4)"
-                             + ("; FastSLAM 2.0 on this trajectory resamples to few distinct ancestors, so lanes share source lines and the "
-                                "launch READS 0.74 GB instead of the algorithmic 0.96 GB (rocprofv3 FETCH_SIZE, DESIGN.md section 6): "
-                                "`frac` is by algorithmic bytes, the moved bytes correspond to ~5.5 TB/s" if v2 else "")},
-        "kernel_ms_avg": {k: v[1] / max(v[0], 1) for k, v in prof.items() if v[0]},
-        "kernel_launches": {k: v[0] for k, v in prof.items() if v[0]},
-        "ms_per_step_instrumented": dt_i / K * 1e3,
-        "obs_chunks": chunks,
-        "device_warmup_steps": D,
-        "best_particle": {"index": i, "weight": w, "pose": [float(a) for a in pose]},
-    }
-    if with_cpu:
-        # FastSLAM 1.0: the literal restatement at the FULL particle count (1e5 x 200: ~2 GB of host memory for the maps and the
-        # clone buffer of the resample); FastSLAM 2.0 (not a BASELINE config) keeps the 20 000-particle sample
-        out["cpu_baseline"] = fs2_cpu_baseline(min(n, 20000), L, zs) if v2 else fs1_cpu_baseline(n, L, zs)
-    return out
-
-
-def leg_fastslam_sharded(ctx, n, L, K, W):
-    """BASELINE.json configs[3] shape: FastSLAM 1.0 sharded over the GPUs of a node (125 000 particles x 200
-    landmarks per GPU at 8 GPUs = 1e6 x 200), weak scaling.  Transport ladder as for MCL: the peer-to-peer
-    transport (rr_fs1_shard_update_p2p) is timed iff it connects and reproduces its block of the unsharded
-    filter bit for bit on this machine; otherwise the RCCL transport (rr_fs1_shard_update: all-reduce MAX,
-    all-gather of the integer sums, grouped send/recv of whole particles) -- itself validated the same way."""
-    import torch
-
-    from rust_robotics_amd.sharded import gloo_allgather, gloo_exchange
-    from rust_robotics_amd.slam import fastslam1 as fs
-    from tests import helpers as H
-
-    dist = ctx.dist
-    rank, world, local_rank = ctx.rank, ctx.world, ctx.local_rank
-    u = [0.5, 0.1]
-    notes = []
-
-    def agree(ok):
-        t = torch.tensor([1 if ok else 0], dtype=torch.int32)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
-        return bool(t.item())
-
-    def observations(lms, steps, seed):
-        return [np.array(fs.get_observations(H.true_pose(t + 1, v=0.5), [tuple(p) for p in lms], seed=seed, step=t)).reshape(-1, 3)
-                for t in range(steps)]
-
-    def params(n_local):
-        prm = fs.default_params()
-        prm.first_obs_cov = 0.5
-        prm.nth = n_local * world / 1.5
-        prm.initial_weight = 1.0 / (n_local * world)
-        return prm
-
-    def make(kind, n_local, Lm, chunks):
-        f = fs.ShardedFastSlam1(rank, world, n_local, Lm, device=local_rank, params=params(n_local), seed=2, obs_chunks=chunks)
-        if kind == "p2p":
-            f.connect_ipc(gloo_allgather(dist))
-        else:
-            f.connect_rccl(gloo_exchange(dist))
-        return f
-
-    def attempt(kind, *a):
-        obj, err = None, None
-        try:
-            obj = make(kind, *a)
-        except Exception as e:  # noqa: BLE001 -- any failure means "next rung of the ladder"
-            err = f"{type(e).__name__}: {e}"
-        if agree(obj is not None):
-            return obj
-        notes.append(f"{kind} transport unavailable" + (f" ({err})" if err else " (failed on another rank)"))
-        if obj is not None:
-            obj.close()
-        return None
-
-    # run-time validation of the cross-GPU hand-off on a small filter
-    nv, Lv, Sv = 4096, 8, 8
-    zv = observations(fs1_scene(Lv, 3), Sv, 3)
-
-    def validate(fv):
-        ok = True
-        try:
-            for z in zv:
-                fv.update_async(u, z)
-            fv.synchronize()
-            ok = not fv.timed_out()
-        except Exception:  # a latched peer-wait timeout surfaces as an error
-            ok = False
-        if ok:
-            whole = fs.FastSlam1(nv * world, Lv, params=params(nv), seed=2, device=local_rank, obs_chunks=2)
-            for z in zv:
-                whole.update_async(u, z)
-            ep, em = whole.get_state()
-            gp, gm = fv.get_state()
-            sl = slice(rank * nv, (rank + 1) * nv)
-            ok = np.array_equal(gp.view(np.uint64), ep[sl].view(np.uint64)) and np.array_equal(gm.view(np.uint64), em[sl].view(np.uint64))
-            del whole
-        return agree(ok)
-
-    kind = None
-    for cand in (("p2p", "rccl") if ctx_transport(ctx) == "auto" else (ctx_transport(ctx),)):
-        log(f"fastslam sharded: trying the {cand} transport")
-        fv = attempt(cand, nv, Lv, 2)
-        if fv is None:
-            continue
-        dist.barrier()
-        good = validate(fv)
-        if good:
-            # host-runtime warm-up: in a process that has torch's HIP context loaded, the first ~50 updates of the first
-            # big filter are enqueued at ~0.85 ms each instead of ~0.05 ms (DESIGN.md section 6); spend them here
-            for k in range(96):
-                fv.update_async(u, zv[k % Sv])
-            fv.synchronize()
-        dist.barrier()
-        fv.close()
-        notes.append(f"{cand} transport " + ("validated bit-identical to the unsharded filter" if good else "FAILED validation against the unsharded filter"))
-        if good:
-            kind = cand
-            break
-    if kind is None:
-        return {"error": "sharded FastSLAM: no transport reproduced the unsharded filter on this machine", "transport_note": "; ".join(notes)}
-
-    log(f"fastslam sharded: {kind} transport validated, timing {n} particles x {L} landmarks per GPU")
-    f = attempt(kind, n, L, 0)
-    if f is None:
-        return {"error": "sharded FastSLAM: the validated transport could not be set up at full size", "transport_note": "; ".join(notes)}
-    zs = observations(fs1_scene(L, 2), 2 * K + W, 2)
-    # From here to the end every rank runs the SAME sequence of collectives whatever happens on its device: an error of one
-    # rank (a latched peer-wait time-out surfaces as an exception of synchronize / update_async) is remembered, not raised,
-    # and the ranks decide together at the end -- a rank that left early would leave the others in a barrier.
-    trouble = []
-
-    def quiet(fn, *a):
-        try:
-            return fn(*a)
-        except Exception as e:  # noqa: BLE001
-            if not trouble:
-                trouble.append(f"rank {rank}: {type(e).__name__}: {e}")
-            return None
-
-    def fence():
-        quiet(f.synchronize)
-        torch.cuda.synchronize()
-        dist.barrier()
-        quiet(f.synchronize)
-        torch.cuda.synchronize()
-
-    for t in range(W):
-        quiet(f.update_async, u, zs[t])
-    fence()
-    if not agree(not trouble and not quiet(f.timed_out)):  # do not spend K steps on a transport that is already dead
-        note = "; ".join(notes + trouble + ["a peer wait gave up during the warm-up steps at full size"])
-        quiet(f.close)
-        return {"error": "sharded FastSLAM: the transport failed at full size", "transport_note": note}
-    quiet(f.profile_enable, 2)  # k_fs1_observe timed by its own dispatch timestamps, inside the timed region
-    quiet(f.profile_reset)
-    t0 = time.perf_counter()
-    for t in range(W, W + K):
-        quiet(f.update_async, u, zs[t])
-    fence()
-    dt = time.perf_counter() - t0
-    dom = (quiet(f.profile_read) or {}).get("k_fs1_observe", (0, 0.0))
-    tmax = torch.tensor([dt], dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    timed_out = bool(quiet(f.timed_out))
-    quiet(f.profile_enable, 1)
-    quiet(f.profile_reset)
-    t1 = time.perf_counter()
-    for t in range(W + K, W + 2 * K):
-        quiet(f.update_async, u, zs[t])
-    quiet(f.synchronize)
-    dt_i = time.perf_counter() - t1
-    prof = quiet(f.profile_read) or {}
-    quiet(f.profile_enable, 0)
-    chunks = (quiet(f.counters) or (0, 0, 0))[2]
-    dist.barrier()
-    quiet(f.close)
-    if not agree(not trouble and not timed_out):
-        return {"error": "sharded FastSLAM: the transport failed inside the timed region",
-                "transport_note": "; ".join(notes + trouble + (["a peer wait gave up"] if timed_out else []))}
-    seconds = float(tmax.item())
-    updates = float(sum(n * world * len(zs[t]) for t in range(W, W + K)))
-    k_n, k_ms = dom
-    avg_s = k_ms / max(k_n, 1) * 1e-3
-    per_launch = FS1_BYTES_PER_UPDATE * n * np.mean([len(zs[t]) for t in range(W, W + K)])
-    achieved = per_launch / avg_s if avg_s > 0 else 0.0
-    return {
-        "metric": "particle-landmark updates/sec", "value": updates / seconds, "unit": "particle-landmark updates/s", "n_gpus": world,
-        "steps": K, "warmup": W, "ms_per_step": seconds / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"FastSLAM 1.0 sharded (BASELINE.json configs[3] shape): {n} particles x {L} landmarks per GPU, "
-                               f"{n * world} particles over {world} GPU(s), all landmarks observed, 2x2 EKF branch, N_eff-gated "
-                               f"global systematic resample", "particles_per_gpu": n, "landmarks": L,
-                   "transport": ("p2p (xGMI, device-initiated)" if kind == "p2p" else "RCCL (all-reduce MAX, all-gather sums, grouped send/recv of whole particles)"),
-                   "transport_note": "; ".join(notes)},
-        "roofline": {"bound": "hbm", "kernel": "k_fs1_observe", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK, "traffic": None, "avg_kernel_ms": avg_s * 1e3,
-                     "algorithmic_bytes_per_launch": per_launch},
-        "kernel_ms_avg": {k: v[1] / max(v[0], 1) for k, v in prof.items() if v[0]},
-        "kernel_launches": {k: v[0] for k, v in prof.items() if v[0]},
-        "ms_per_step_instrumented": dt_i / K * 1e3, "obs_chunks": chunks, "p2p_timed_out": bool(timed_out),
-    }
-
-
-_TRANSPORT = {"value": "auto"}
-
-
-def ctx_transport(ctx):
-    t = _TRANSPORT["value"]
-    return {"auto": "auto", "p2p": "p2p", "p2p-only": "p2p", "rccl": "rccl", "torch": "rccl"}[t]
-
-
-def replicas_fallback(ctx, n, L, K, W, obs_list, scheme, lik, reason):
-    import torch
-
-    import rust_robotics_amd.localization as loc
-
-    dist = ctx.dist
-    cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
-    pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1 + ctx.rank, device=ctx.local_rank,
-                                                    resample_scheme=scheme, likelihood_mode=lik)
-    u = [1.0, 0.1]
-
-    def fence():
-        pf.synchronize()
-        torch.cuda.synchronize()
-        dist.barrier()
-        pf.synchronize()
-        torch.cuda.synchronize()
-
-    W0 = max(len(obs_list) - 2 * K, W)  # W + 76: host-runtime warm-up of a process that has torch's HIP context loaded (DESIGN.md section 6)
-    for t in range(W0):
-        pf.step_async(u, obs_list[t])
-    fence()
-    t0 = time.perf_counter()
-    for t in range(W0, W0 + K):
-        pf.step_async(u, obs_list[t])
-    fence()
-    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    pf.profile_enable(1)
-    pf.profile_reset()
-    t1 = time.perf_counter()
-    for t in range(W0 + K, W0 + 2 * K):
-        pf.step_async(u, obs_list[t])
-    pf.synchronize()
-    dt_instr = time.perf_counter() - t1
-    prof = pf.profile_read()
-    pf.profile_enable(0)
-    est = pf.estimate()
-    dist.barrier()
-    return dict(seconds=float(tmax.item()), seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est],
-                dominant=None, transport="NONE -- independent replicas, no exchange",
-                transport_note="SHARDING FAILED: " + reason, p2p_timed_out=False, migrated_particles_last_step=0)
-
-
-def leg_mcl(args, ctx, n, L, K, W, with_cpu, breakdown=True, label="configs[1]"):
-    """Fixed-N MCL: n particles per GPU x L landmarks, propagate + weight + resample every step."""
-    world = ctx.world
-    # time only moves forward for every filter: W warm-up + K timed + K estimate-every-step + K dispatch-stamped + K breakdown
-    # steps; the sharded legs also validate (12 steps) and warm up 64 steps longer
-    # (the sharded legs warm up EXTRA_WARMUP steps + settle blocks inside bench_sharded; ~50 ms of work is what the device needs)
-    D = 0 if ctx.sharded else (DEVICE_WARMUP_MCL if n <= 2_000_000 else 60)
-    obs_list = make_scene(L, D + W + 5 * K + 8 + (EXTRA_WARMUP if ctx.sharded else 0), seed=1)
-    scheme = 1 if args.scheme == "systematic" else 0
-    lik = 0 if args.likelihood == "fused" else 1
-    extra = {}
-    if ctx.sharded:
-        from rust_robotics_amd import sharded
-
-        try:
-            res = sharded.bench_sharded(ctx.rank, world, ctx.local_rank, n, L, K, W, obs_list[:W + 2 * K + EXTRA_WARMUP], scheme, lik, args.transport)
-        except RuntimeError as e:
-            # no sharded transport works on this machine.  Last resort so that the run still leaves a line:
-            # every rank steps its own, independent filter (NO exchange, NOT one sharded filter) and the line
-            # says so in config.sharding -- the number is an upper bound for the sharded step, not a measurement of it.
-            res = replicas_fallback(ctx, n, L, K, W, obs_list[:W + 2 * K + EXTRA_WARMUP], scheme, lik, str(e))
-        extra["headline_step"] = (
-            "sharded rr_pf_shard_step_p2p / rr_pf_shard_step + rr_pf_shard_want_estimate: propagate + weight + global resample, every shard leaving its part of the mean "
-            "try_step returns every step (the sums over the sources of its own slots, added up by the kernel that moves the particles; one all-reduce of "
-            "four doubles when the value is read) -- the counterpart of the N = 1 line's `value`"
-            if res.get("estimate_every_step") else
-            "sharded rr_pf_shard_step: propagate + weight + global resample -- the PLAIN step (the mean is formed when an accessor asks: local moments + "
-            "one all-reduce); the N = 1 line's `plain_async_step` is its single-GPU counterpart")
-    else:
-        import rust_robotics_amd.localization as loc
-
-        cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
-        pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=ctx.local_rank,
-                                                        resample_scheme=scheme, likelihood_mode=lik)
-        u = [1.0, 0.1]
-        # The reference's try_step returns the refreshed mean EVERY step (particle_filter.rs:299,332,343,496), so the headline
-        # step is the one that produces it: rr_pf_step_async_estimate -- the mean of the resampled set accumulated inside the
-        # step's own plan kernel and kept on the device (one synchronisation at the end of the K steps).  The multinomial
-        # scheme's estimate is the deferred form: the resampled set's mean is summed by the kernel that draws, searches and
-        # gathers the sources -- the next step's k_step_lazy (the last step's by rr_pf_last_step_estimate's gather).
-        with_est = n <= 8_388_608  # (the in-step estimate's limit, rr_pf.h)
-        step_fn = pf.step_async_estimate if with_est else pf.step_async
-        if D and getattr(args, "cold_first", False):
-            # COLD: the same W + K steps with nothing but the command line's warm-up before them -- the first work this process
-            # gives the device (a filter of its own, so that the hot measurement below starts from the same state as ever)
-            # `ms_per_step_cold_unwarmed`: exactly that.  `ms_per_step_cold`: a caller that follows include/rr_pf.h -- rr_pf_warm right
-            # after create (50 ms of step-shaped work on the filter's stream, round 6), then only the command line's W warm-up steps
-            for key, warm in (("ms_per_step_cold_unwarmed", False), ("ms_per_step_cold", True)):
-                pc = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=ctx.local_rank,
-                                                                resample_scheme=scheme, likelihood_mode=lik)
-                fn_c = pc.step_async_estimate if with_est else pc.step_async
-                if warm:
-                    pc.warm()
-                for t in range(W):
-                    fn_c(u, obs_list[t])
-                pc.synchronize()
-                t0 = time.perf_counter()
-                for t in range(W, W + K):
-                    fn_c(u, obs_list[t])
-                pc.synchronize()
-                extra[key] = (time.perf_counter() - t0) / K * 1e3
-                del fn_c, pc  # (the bound method holds the filter too: both, or it lives on beside the hot one)
-                if not warm:
-                    time.sleep(0.3)  # let the clocks fall again: the warmed measurement must not inherit the unwarmed one's 25 steps
-        for t in range(D):  # device warm-up (see DEVICE_WARMUP_MCL), then time moves on
-            step_fn(u, obs_list[t])
-            # in blocks with a synchronisation in between, the shape of the timed region: a thousand steps enqueued in one go leave
-            # the host ~40 ms ahead of the device, and one run in five then paid a ~0.45 ms stall of the runtime somewhere in the
-            # 20 steps that follow (measured with the driver's --steps 20: 75 instead of 53 us/step); in blocks: none in 300 blocks
-            if (t + 1) % 50 == 0:
-                pf.synchronize()
-        obs_list = obs_list[D:]
-        for t in range(W):
-            step_fn(u, obs_list[t])
-        pf.synchronize()
-        t0 = time.perf_counter()
-        for t in range(W, W + K):
-            step_fn(u, obs_list[t])
-        pf.synchronize()
-        dt = time.perf_counter() - t0
-        extra["headline_step"] = ("rr_pf_step_async_estimate: propagate + weight + resample + the mean try_step returns, every step"
-                                  + (" (summed by the next step's kernel as it moves the particles; RR_PF_EST_DEFER=0: inside the plan kernel)"
-                                     if args.scheme == "systematic" else " (summed by the next step's draw-and-gather kernel)")
-                                  if with_est else
-                                  "rr_pf_step_async: propagate + weight + resample (the in-step estimate serves up to 8 388 608 particles)")
-        if with_est:
-            extra["last_step_estimate"] = [float(a) for a in pf.last_step_estimate()]
-        est = pf.estimate()
-        # the same K steps again WITHOUT the per-step estimate (what a node that publishes every k-th estimate runs)
-        if with_est:
-            for t in range(W + K, W + K + min(W, 10)):
-                pf.step_async(u, obs_list[t])
-            pf.synchronize()
-            t1 = time.perf_counter()
-            for t in range(W + K + min(W, 10), W + 2 * K):
-                pf.step_async(u, obs_list[t])
-            pf.synchronize()
-            t_plain = (time.perf_counter() - t1) / max(K - min(W, 10), 1)
-            extra["plain_async_step"] = {"ms_per_step": t_plain * 1e3, "value": float(n) * L / t_plain,
-                                         "note": "rr_pf_step_async: the step without the per-step estimate"}
-        # roofline kernel: the NEXT K steps (the filter resamples every step, so the work per step is stationary) in
-        # which ONLY the propagate+weight kernel is timed, by the start/stop timestamps of its own dispatch packets
-        # (hipExtLaunchKernelGGL on the filter's stream): no event packets in the stream, the kernel runs as in the
-        # timed loop.  Kept out of the timed region because the stamped launch costs the host ~3 us per step.
-        pf.profile_enable(2)
-        pf.profile_reset()
-        for t in range(W + 2 * K, W + 3 * K):
-            step_fn(u, obs_list[t])
-        pf.synchronize()
-        dominant = pf.profile_read()["k_propagate_weight"]
-        # per-kernel breakdown: an instrumented re-run of K steps with HIP events around every launch (adds
-        # ~3 us per launch; informational, kept out of `value` and of `roofline`)
-        prof, dt_instr = {"k_propagate_weight": dominant}, 0.0
-        if breakdown:
-            pf.profile_enable(1)
-            pf.profile_reset()
-            t1 = time.perf_counter()
-            for t in range(W + 3 * K, W + 4 * K):
-                step_fn(u, obs_list[t])
-            pf.synchronize()
-            dt_instr = time.perf_counter() - t1
-            prof = pf.profile_read()
-        pf.profile_enable(0)
-        # the SYNCHRONOUS try_step (rr_pf_step: the estimate comes back to the host every step -- what the reference's callers do,
-        # particle_filter.rs:488-497 / monte_carlo_localization.rs:291-300), over the same K steps' worth of inputs, outside `value`
-        if n <= 4_000_000:
-            for t in range(5):
-                pf.step(u, obs_list[W + 4 * K + t])
-            per = []
-            for t in range(K):  # (every step is a host round trip of its own, so each one is timed by itself)
-                t1 = time.perf_counter()
-                pf.step(u, obs_list[W + 4 * K + 5 + t])
-                per.append(time.perf_counter() - t1)
-            t_sync = float(np.mean(per))
-            extra["synchronous_try_step"] = {"ms_per_step": t_sync * 1e3, "value": float(n) * L / t_sync,
-                                             "median_ms": float(np.median(per)) * 1e3, "max_ms": float(np.max(per)) * 1e3,
-                                             "note": "rr_pf_step: one host round trip per step, the mean of the resampled set returned every step" +
-                                                     ("" if with_est else " (multinomial: the pending draws are searched, gathered and averaged by extra launches)") +
-                                                     "; mean of the K steps (median_ms / max_ms beside it: the HIP runtime stalls ONCE for ~0.45 ms at some launch "
-                                                     "count of a process -- tools/stall_probe.py: one step of 600 --, and with K = 20 that one step is 22 us of the mean "
-                                                     "when it falls into this window)"}
-        if with_cpu and n <= 4_000_000:  # (checker use of the oracle: part of the cpu_baseline leg)
-            pf2 = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=ctx.local_rank,
-                                                             resample_scheme=scheme, likelihood_mode=lik, record_indices=True)
-            for t in range(3):
-                pf2.step_async(u, obs_list[t])
-            extra["index_parity"] = index_parity(pf2, n, L, args.scheme, obs_list[3])
-            del pf2
-        del pf
-        res = dict(seconds=dt, seconds_instrumented=dt_instr, kernels=prof, estimate=[float(a) for a in est], dominant=dominant)
-
-    if ctx.rank != 0:
-        return None
-    total_updates = float(n) * world * L * K
-    value = total_updates / res["seconds"]
-    kern = res["kernels"]
-    dominant = res.get("dominant")
-    if dominant and not dominant[0]:
-        dominant = None  # this path does not stamp its dispatches (multinomial): fall back to the instrumented re-run
-    k1_n, k1_ms = dominant or kern["k_propagate_weight"]
-    k1_avg_s = (k1_ms / max(k1_n, 1)) * 1e-3
-    # the systematic headline's step kernel is the EST build when the estimate is deferred (the default): it also reads the sources' v
-    est_build = (not ctx.sharded) and args.scheme == "systematic" and n <= 8_388_608 and os.environ.get("RR_PF_EST_DEFER", "1") != "0"
-    k1_bytes = (K1_BYTES[args.scheme] + (8.0 if est_build else 0.0)) if not ctx.sharded else 64.0
-    achieved = k1_bytes * n / k1_avg_s if k1_avg_s > 0 else 0.0
-    step_kernel_ms = {k: (v[1] / max(v[0], 1)) for k, v in kern.items() if v[0]}
-    traffic, traffic_src = measured_traffic("k_step_lazy", getattr(args, "traffic_key", "mcl" if (n, L, args.scheme) == (1_000_000, 32, "systematic") else
-                                                                   f"mcl_{n}x{L}_{args.scheme}"),
-                                              est=est_build if args.scheme == "systematic" else None)
-    # FP64-VALU side of the same kernel: f64-rate lane-instructions per particle (DESIGN.md section 4: a per-pair count
-    # times L plus a per-particle count, both read off the ISA and checked against SQ_INSTS_VALU) over the kernel time
-    pair_i, part_i = mcl_instruction_budget(est=est_build)
-    valu_rate = (pair_i * L + part_i) * n / k1_avg_s if k1_avg_s > 0 else 0.0
-    # the multinomial kernel moves whole 128-byte lines for its 8-byte guide pairs and 32-byte source records (iid draws have no
-    # locality): what binds it is the MEASURED line traffic (PMC), not the algorithmic bytes and not the FP64 pipe
-    line_rate = (traffic / k1_avg_s) if (traffic and k1_avg_s > 0 and args.scheme == "multinomial") else 0.0
-    fracs = {"fp64_valu": valu_rate / FP64_VALU_PEAK, "hbm": achieved / HBM_PEAK, "line_traffic": line_rate / HBM_PEAK}
-    bound = max(fracs, key=fracs.get)
-    out = {
-        "metric": "particle-landmark updates/sec",
-        "value": value,
-        "unit": "particle-landmark updates/s",
-        "n_gpus": world,
-        "steps": K,
-        "warmup": W,
-        "ms_per_step": res["seconds"] / K * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "f64",
-        "data": "synthetic",
-        "config": {
-            "workload": f"fixed-N MCL (BASELINE.json {label}): {n} particles/GPU x {L} landmarks, "
-                        f"propagate+weight+{args.scheme} resample every step, likelihood={args.likelihood}",
-            "particles_per_gpu": n,
-            "landmarks": L,
-            "resample": args.scheme,
-            "sharding": "none" if not ctx.sharded else
-                        (f"{res.get('transport')} ({res.get('transport_note')})" if str(res.get("transport", "")).startswith("NONE") else
-                         f"contiguous particle blocks over {world} GPUs; transport {res.get('transport')} ({res.get('transport_note')})"),
-        },
-        "roofline": {
-            # the binding resource of THIS kernel at THIS L: the FP64 vector pipe once its fraction of the issue peak exceeds the
-            # HBM fraction (L >= ~16), HBM below that.  achieved / peak / frac stay the HBM figures the contract asks for;
-            # binding_frac is the fraction of the binding resource's peak
-            "bound": bound,
-            "binding_frac": fracs[bound],
-            "hbm_frac": achieved / HBM_PEAK,
-            "kernel": ("k_step_lazy<EST> (propagate + weight + folded resample gather + the mean of the resampled set it moves)" if k1_bytes == 80.0 else
-                       "k_step_lazy (propagate + weight + folded resample gather)" if k1_bytes == 72.0 else
-                       "k_step_lazy<kSrcDraw> (multinomial draws + guide-table search + source gather + propagate + weight)"
-                       if (args.scheme == "multinomial" and not ctx.sharded) else "k_propagate_weight"),
-            "achieved": achieved / 1e9,
-            "peak": HBM_PEAK / 1e9,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK,
-            "traffic": traffic,
-            "traffic_source": (traffic_src + (" (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, bytes per launch)" if traffic is not None else "")) if traffic_src else None,
-            "avg_kernel_ms": k1_avg_s * 1e3,
-            "timed_launches": k1_n,
-            "timing": "dispatch timestamps (hipExtLaunchKernelGGL) of K launches that follow the timed region" if dominant else
-                      "HIP events in an instrumented re-run of the K steps",
-            "algorithmic_bytes_per_launch": k1_bytes * n,
-            "fp64_valu": {"lane_instr_per_pair": pair_i, "lane_instr_per_particle": part_i, "achieved_lane_instr_per_s": valu_rate,
-                          "peak_lane_instr_per_s": FP64_VALU_PEAK, "frac": valu_rate / FP64_VALU_PEAK},
-            "line_traffic": ({"bytes_per_launch": traffic, "rate_GBps": line_rate / 1e9, "frac_of_hbm_peak": line_rate / HBM_PEAK,
-                              "note": "PMC bytes per launch / kernel time: 10^6 random guide pairs and 10^6 random 32-byte records move a 128-byte line each "
-                                      "(served by L2 and the Infinity Cache; priced against the 8 TB/s HBM peak); profiles/r04_multinomial_ab.md"}
-                             if line_rate else None),
-            "note": (("bound by cache-line traffic: see line_traffic.  " if bound == "line_traffic" else "") +
-                     "FP64-VALU bound at L >= ~16 (fp64_valu.frac is the binding fraction).  " +
-                     ("The working set (~90 B/particle) of 1e6 particles is Infinity-Cache resident, so `traffic` is fabric traffic, not DRAM traffic; "
-                      if n <= 2_000_000 else "At this size the working set is several times the 256 MB Infinity Cache: `achieved` is a DRAM rate; ") +
-                     "the HBM-bound workload of this line is the `fastslam` leg; profiles/r04_mcl_L_sweep.json shows where MCL turns from HBM- to VALU-bound"),
-        },
-        "kernel_ms_avg": step_kernel_ms,
-        "device_warmup_steps": (EXTRA_WARMUP if ctx.sharded else D),
-        "ms_per_step_instrumented": res.get("seconds_instrumented", 0.0) / K * 1e3,
-        "estimate": res.get("estimate"),
-    }
-    out.update(extra)
-    if with_cpu:
-        n_cpu = getattr(args, "cpu_particles", None) or n
-        out["cpu_baseline"] = cpu_baseline(n_cpu, L, obs_list, max_seconds=getattr(args, "cpu_seconds", 12.0), scheme=args.scheme,
-                                           brief=getattr(args, "cpu_brief", False))
-        if n_cpu != n:
-            out["cpu_baseline"]["sample"] += f" -- a BOUNDED SAMPLE: {n_cpu} of the leg's {n} particles (the per-particle work and the serial scan both scale linearly)"
-    if ctx.sharded:
-        out["sharded"] = {k: res.get(k) for k in ("transport", "transport_note", "p2p_timed_out", "migrated_particles_last_step", "ranks_seen")}
-        seen = res.get("ranks_seen") or {}
-        out["ranks_seen"] = seen.get("ranks")
-        if seen and seen.get("distinct_devices", world) < world:
-            # (RR_BENCH_SHARE_DEVICE: a rig that executes the N-rank code on fewer devices -- every rank's kernels run on the SAME GPU)
-            out["shared_device"] = (f"{world} ranks on {seen['distinct_devices']} device(s): the {world}-rank code path executed, "
-                                    f"NOT a scaling number -- `value` is the aggregate of ranks that time-share one GPU")
-    return out
-
-
-SMALL_ROWS = [
-    # (key, particles, landmarks [x, y], config overrides, initial state, exact observations?, where the reference runs this size)
-    ("100x3", 100, [(5.0, 0.0), (0.0, 5.0), (5.0, 5.0)], {}, (0.0, 0.0, 0.0, 0.0), True,
-     "headless_localizers.rs:29-56: ParticleFilterConfig::default() -- 100 particles, 3 landmarks, exact ranges, try_step_state every step"),
-    ("120x5", 120, [(2.0, 2.0), (10.0, 2.0), (2.0, 8.0), (10.0, 8.0), (6.0, 5.0)], {"range_noise": 0.25}, (5.0, 5.0, 0.0, 0.0), False,
-     "rust_robotics_playground/src/localization.rs:50-66: 120 particles, 5 landmarks, range_noise 0.25"),
-    ("150x5", 150, [(2.0, 2.0), (10.0, 2.0), (2.0, 8.0), (10.0, 8.0), (6.0, 5.0)], {"range_noise": 0.25}, (5.0, 5.0, 0.0, 0.0), False,
-     "render_gif_particle_filter.rs:25-40: 150 particles, 5 landmarks, range_noise 0.25"),
-    ("1000x4", 1000, [(10.0, 0.0), (0.0, 15.0), (-5.0, 20.0), (10.0, 10.0)], {"range_noise": 0.5, "velocity_noise": 0.3, "yaw_rate_noise": math.radians(5.0)},
-     (0.0, 0.0, 0.0, 0.0), False, "BASELINE.json configs[0] / tests/unified_filter_comparison.rs:43,278-285: 1 000 particles, 4 landmarks"),
-]
-
-
-def pin_to_gpu_numa_node(device=0):
-    """The synchronous step is two trips over the host link: keep this process on the NUMA node the GPU hangs off (what
-    nodes/pf_localizer_node does at start).  Returns the cpulist it pinned to, or None."""
-    import ctypes as C
-
-    from rust_robotics_amd import _ffi
-
-    try:
-        buf = C.create_string_buffer(64)
-        if _ffi.lib().rr_device_pci_bus_id(device, buf, 64) != 0:
-            return None
-        cpulist = open(f"/sys/bus/pci/devices/{buf.value.decode()}/local_cpulist").read().strip()
-        cpus = set()
-        for part in cpulist.split(","):
-            a, _, b = part.partition("-")
-            cpus.update(range(int(a), int(b or a) + 1))
-        cpus &= os.sched_getaffinity(0)
-        if not cpus:
-            return None
-        os.sched_setaffinity(0, cpus)
-        return cpulist
-    except Exception:  # noqa: BLE001 -- a measurement nicety, never a failure
-        return None
-
-
-def leg_small_n(with_cpu):
-    """The sizes the reference's own callers run (SMALL_ROWS: 100 - 1 000 particles, 3 - 5 landmarks), ParticleFilterLocalizer
-    semantics (multinomial resample behind the N_eff gate, particle_filter.rs:337-345,441-473), through the entry point those
-    callers use -- the SYNCHRONOUS try_step -- in both of its forms: one launch of one workgroup per step (k_step_small + host
-    mailbox) and the resident service (rr_pf_set_resident: the kernel stays, steps travel through pinned memory); beside them
-    the asynchronous and the batched forms, and the literal restatement of the reference's try_step loop (cache refreshes
-    included) on ONE host core, timed inside C.  Calls go through ctypes with prebuilt argument pointers (~1 us of call overhead
-    stays in every GPU number)."""
-    import ctypes as C
-
-    import rust_robotics_amd.localization as loc
-    from rust_robotics_amd import _ffi
-
-    lib = _ffi.lib()
-    K = 2000
-    pinned = pin_to_gpu_numa_node(0)
-    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
-    out = {"steps": K, "unit_rows": "microseconds per step", "host_pinned_to_cpus": pinned, "rows": {}}
-
-    for key, n, lms, over, init, exact, where in SMALL_ROWS:
-        L = len(lms)
-        cfg = loc.ParticleFilterConfig(n_particles=n, **over)
-        rng = np.random.default_rng(42)
-        truth = np.array(init[:3], dtype=np.float64)
-        obs = np.empty((K, L, 3))
-        for t in range(K):
-            truth += [math.cos(truth[2]) * 0.1, math.sin(truth[2]) * 0.1, 0.01]
-            for q, (lx, ly) in enumerate(lms):
-                d = math.hypot(truth[0] - lx, truth[1] - ly)
-                obs[t, q] = (d if exact else max(d + rng.normal(0.0, cfg.range_noise), 0.0), lx, ly)
-        u = np.tile([1.0, 0.1], (K, 1))
-        est = np.empty(4)
-
-        def fresh(resident_us=0.0):
-            pf = loc.ParticleFilterLocalizer.with_initial_state(list(init), cfg, seed=42)
-            if resident_us:
-                pf.set_resident(resident_us)
-            return pf
-
-        def best_of(make, body, reps=3):
-            """body(pf) -> microseconds per step, measured around its own loop (argument pointers are built outside it)"""
-            best = None
-            for _ in range(reps):
-                pf = make()
-                for t in range(300):  # warm: clocks, code, the resident incarnation
-                    lib.rr_pf_step(pf._h, dp(u[t]), dp(obs[t]), L, dp(est))
-                dt = body(pf)
-                best = dt if best is None else min(best, dt)
-                del pf
-            return best
-
-        def sync_loop(pf):
-            h, e = pf._h, dp(est)
-            ptrs = [(dp(u[t]), dp(obs[t])) for t in range(K)]
-            t0 = time.perf_counter()
-            for up, op in ptrs:
-                lib.rr_pf_step(h, up, op, L, e)
-            return (time.perf_counter() - t0) / K * 1e6
-
-        def async_loop(pf):
-            h = pf._h
-            ptrs = [(dp(u[t]), dp(obs[t])) for t in range(K)]
-            t0 = time.perf_counter()
-            for up, op in ptrs:
-                lib.rr_pf_step_async(h, up, op, L)
-            pf.synchronize()
-            return (time.perf_counter() - t0) / K * 1e6
-
-        def many_loop(pf):
-            t0 = time.perf_counter()
-            pf.step_many(u, obs)
-            return (time.perf_counter() - t0) / K * 1e6
-
-        row = {"config": where, "particles": n, "landmarks": L}
-        row["try_step, launched (one launch + mailbox per step)"] = best_of(fresh, sync_loop)
-        row["try_step, resident service"] = best_of(lambda: fresh(5000.0), sync_loop)
-        row["step_async, launched"] = best_of(fresh, async_loop)
-        row["step_many (one launch for all steps, estimates read back at the end)"] = best_of(fresh, many_loop)
-        if with_cpu:
-            import oracle
-            from oracle import dp as odp, u32p
-
-            ref, det = oracle.ref(), oracle.det()
-            ref.ref_set_threads(1)
-            x, y, yaw, v = (np.full(n, init[k]) for k in range(4))
-            w = np.full(n, 1.0 / n)
-            idx, est_k = np.empty(n, np.uint32), np.empty((K, 4))
-            nv, nw, r = np.empty((K, n)), np.empty((K, n)), np.empty((K, n))
-            z0, z1, r2 = np.empty(n), np.empty(n), np.empty(n)
-            for t in range(K):
-                det.det_normal2_v(42, 3, t, 0, n, odp(z0), odp(z1))
-                det.det_uniform2_v(42, 4, t, 0, n, odp(r[t]), odp(r2))
-                nv[t], nw[t] = cfg.velocity_noise * z0, cfg.yaw_rate_noise * z1
-            best = None
-            for _ in range(3):
-                for arr, k in ((x, 0), (y, 1), (yaw, 2), (v, 3)):
-                    arr[:] = init[k]
-                w[:] = 1.0 / n
-                sec = ref.ref_pf_try_step_loop(n, odp(x), odp(y), odp(yaw), odp(v), odp(w), odp(u), cfg.dt, odp(nv), odp(nw), odp(obs), L, cfg.range_noise,
-                                               cfg.resample_threshold, 0, odp(r), u32p(idx), K, odp(est_k), 1, 1)
-                best = sec if best is None else min(best, sec)
-            row["cpu: the reference's try_step loop, one core"] = best / K * 1e6
-        out["rows"][key] = row
-
-    head = out["rows"]["1000x4"]
-    batched = head["step_many (one launch for all steps, estimates read back at the end)"]
-    out["config"] = {"workload": "particle filter at the reference's own sizes (BASELINE.json configs[0] = row 1000x4): multinomial resample behind "
-                                 "the N_eff gate, synchronous try_step", "particles": 1000, "landmarks": 4}
-    out["value"] = 1000 * 4 / (batched * 1e-6)
-    out["unit"] = "particle-landmark updates/s"
-    out["note"] = ("value = rr_pf_step_many at 1000 x 4 with the per-step estimates (a single workgroup on one of 256 CUs: the work of a step does not "
-                   "fill more); the rows are what a caller of try_step sees per step")
-    if with_cpu:
-        model, nproc = host_cpu()
-        cpu_us = head["cpu: the reference's try_step loop, one core"]
-        out["cpu_baseline"] = {"value": 1000 * 4 / (cpu_us * 1e-6), "unit": "particle-landmark updates/s", "cores": 1, "kind": "port", "us_per_step": cpu_us,
-                               "sample": f"oracle/ref_literal.c ref_pf_try_step_loop: try_step as the reference runs it -- predict, update, its O(N^2) linear-scan "
-                                         f"resample behind the N_eff gate (particle_filter.rs:455-470) and refresh_cache (mean + covariance) after predict, update and "
-                                         f"resample (:299,332,343) -- {K} steps per row on one core ({model}), timed inside C, noise samples pre-drawn (the reference's "
-                                         f"RNG is not in the loop: a lower bound of its cost)"}
-    return out
-
-
-def leg_fastslam_sharded_world1(n, L):
-    """BASELINE.json configs[3] per-GPU shape (125 000 particles x 200 landmarks) through the sharded FastSLAM update with ONE
-    rank, in a process of its own like the MCL world-1 legs."""
-    log("extra leg fastslam_sharded_world1")
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR")}
-    env["MASTER_PORT"] = str(free_port())
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-sharded", "--workload", "fastslam", "--particles", str(n), "--landmarks", str(L),
-           "--no-cpu-baseline"]
-    try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        if r.returncode != 0 or not lines:
-            raise RuntimeError(f"rc {r.returncode}: {r.stderr[-400:]}")
-        d = json.loads(lines[-1])
-        return {k: d[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "kernel_ms_avg", "obs_chunks") if k in d}
-    except Exception as e:  # noqa: BLE001
-        return {"error": f"{type(e).__name__}: {e}"}
-
-
-def leg_sharded_world1(args, n, L, K, W, transports=(("p2p", "p2p-only"), ("rccl", "rccl")), what=None):
-    """The sharded MCL step with ONE rank, once per transport: the peer-to-peer transport (validated against the unsharded
-    filter first, as in the multi-GPU run) and the native RCCL transport (a one-rank communicator: RCCL really called).
-    Each in a process of its own (`bench.py --force-sharded --transport ...`): the sharded legs need torch.distributed, and
-    torch's bundled HIP runtime has to be the first one a process loads."""
-    out = {}
-    for name, transport in transports:
-        log(f"extra leg sharded_world1 / {name} ({n} x {L})")
-        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR")}
-        env["MASTER_PORT"] = str(free_port())
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--force-sharded", "--transport", transport, "--no-extra-legs",
-               "--no-cpu-baseline", "--steps", str(K), "--warmup", str(W), "--particles", str(n), "--landmarks", str(L), "--likelihood", args.likelihood]
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
-            lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            if r.returncode != 0 or not lines:
-                raise RuntimeError(f"rc {r.returncode}: {r.stderr[-400:]}")
-            d = json.loads(lines[-1])
-            out[name] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "sharding": d["config"]["sharding"],
-                         "kernel_ms_avg": d.get("kernel_ms_avg"), "steps": d["steps"], "warmup": d["warmup"], "roofline": d.get("roofline")}
-        except Exception as e:  # noqa: BLE001
-            out[name] = {"error": f"{type(e).__name__}: {e}"}
-    if what:
-        out["workload"] = what
-    out["note"] = ("world size 1 on this GPU: every exchange talks to itself, so this is the per-rank cost of the sharded step before any "
-                   "cross-device latency (weak-scaling ceiling at 8 GPUs = 8 x plain_async_step / this)")
-    return out
-
-
-def mcl_instruction_budget(est=False):
-    """(f64-rate lane-instructions per particle-landmark pair, per particle) of k_step_lazy, maintained next to the kernel
-    (rust_robotics_amd/csrc/INSTRUCTION_BUDGET.json, written from the ISA dump by tools/count_isa.py); est: the EST build (the
-    step kernel that also adds up the deferred in-step estimate of the step before -- the headline's since round 5)."""
-    try:
-        d = json.load(open(os.path.join(ROOT, "rust_robotics_amd", "csrc", "INSTRUCTION_BUDGET.json")))
-        if est and isinstance(d.get("est"), dict) and d["est"].get("per_particle"):
-            d = d["est"]
-        return float(d["per_pair"]), float(d["per_particle"])
-    except Exception:
-        return 19.0, 530.0  # round-1 ISA count
-
-
-def free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    return port
+from benchlib.common import *  # noqa: E402,F401,F403
+from benchlib.common import _OUT, _TRANSPORT, BENCH_PY  # noqa: E402,F401
+from benchlib.cpu_baselines import *  # noqa: E402,F401,F403
+from benchlib.legs_fastslam import *  # noqa: E402,F401,F403
+from benchlib.legs_mcl import *  # noqa: E402,F401,F403
+from benchlib.legs_small import *  # noqa: E402,F401,F403
+from benchlib.line import *  # noqa: E402,F401,F403
+from benchlib.line import _compact_cpu, _compact_roofline, _leg_row, _num, _short  # noqa: E402,F401
 
 
 def self_launch(n):
@@ -1277,7 +50,7 @@ def self_launch(n):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: hipIpcGetMemHandle and RCCL need it on this host driver
     env.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(free_port()), BENCH_PY] + sys.argv[1:]
     sys.stderr.write("bench.py: no launcher detected (WORLD_SIZE unset); starting " + " ".join(cmd[1:8]) + " ...\n")
     sys.stderr.flush()
     raise SystemExit(subprocess.call(cmd, env=env))
@@ -1428,6 +201,10 @@ def main():
                 out["sharded_world1_config5_shape"] = leg_sharded_world1(args, 2_000_000, 64, K, W, transports=(("p2p", "p2p-only"),),
                                                                          what="BASELINE.json configs[4] per-GPU shape: 2e6 particles x 64 landmarks")
                 out["fastslam_sharded_world1_config4_shape"] = leg_fastslam_sharded_world1(125_000, 200)
+                # the reference's own PF / MCL resampler, sharded: peer-to-peer (round 6: every served slot stored straight into its
+                # owner's slab) against the RCCL all-to-all form
+                out["sharded_world1_multinomial"] = leg_sharded_world1(args, n, L, K, W, scheme="multinomial",
+                                                                       what="configs[1] shape, MULTINOMIAL resampling (particle_filter.rs:441-473)")
 
                 def ms(*path):
                     d = out
@@ -1467,147 +244,6 @@ def main():
     ctx.close()
     if ctx.rank == 0:
         emit(out)
-
-
-HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-                 "dtype", "data")
-LINE_LIMIT = 3500  # bytes: the driver keeps a short tail of stdout; round 4's 24.7 KB line fell off it (BENCH_r04.json parsed: null)
-
-
-def _num(v, digits=6):
-    """numbers of the compact line carry 6 significant digits; everything else passes through"""
-    if isinstance(v, float) and math.isfinite(v):
-        return float(f"{v:.{digits}g}")
-    return v
-
-
-def _short(s, n):
-    return s if not isinstance(s, str) or len(s) <= n else s[: n - 3] + "..."
-
-
-def _compact_roofline(r):
-    if not isinstance(r, dict):
-        return None
-    out = {k: _num(r[k]) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "binding_frac", "traffic", "avg_kernel_ms",
-                                   "algorithmic_bytes_per_launch") if k in r}
-    if "kernel" in out:
-        out["kernel"] = _short(str(out["kernel"]).split(" ")[0], 40)
-    if r.get("traffic_source"):  # which PMC summary, and the hash of the library it was collected on (== the loaded one, or no traffic)
-        out["traffic_source"] = _short(str(r["traffic_source"]), 110)
-    return out
-
-
-def _compact_cpu(c):
-    if not isinstance(c, dict):
-        return None
-    out = {k: _num(c[k]) for k in ("value", "unit", "cores", "kind") if k in c}
-    if "sample" in c:
-        out["sample"] = _short(c["sample"], 330)
-    host = c.get("host")
-    if isinstance(host, dict):
-        out["host"] = _short(f"{host.get('cpu_model', '?')}, {host.get('nproc', '?')} hw threads, {host.get('threads', '?')} used", 90)
-    return out
-
-
-def _leg_row(leg):
-    """[ms_per_step, roofline fraction of the leg's dominant kernel (HBM), fraction of its binding resource]"""
-    if not isinstance(leg, dict):
-        return None
-    if "error" in leg:
-        return {"error": _short(leg["error"], 80)}
-    r = leg.get("roofline") if isinstance(leg.get("roofline"), dict) else {}
-    row = [_num(leg.get("ms_per_step"), 5), _num(r.get("frac"), 4), _num(r.get("binding_frac", r.get("frac")), 4)]
-    if "median_ms" in leg:  # (legs timed step by step: the median beside the mean)
-        row.append({"median_ms": _num(leg["median_ms"], 5), "max_ms": _num(leg.get("max_ms"), 4)})
-    return row
-
-
-def compact_line(out):
-    """The line the driver parses: the contract's headline fields, `roofline`, `cpu_baseline`, and one short row per extra
-    leg.  Every leg in full goes out as its own earlier JSON line and into bench_legs.json (emit)."""
-    line = {k: _num(out[k], 9) for k in HEADLINE_KEYS if k in out}
-    cfg = out.get("config")
-    if isinstance(cfg, dict):
-        line["config"] = {k: (_short(v, 200) if isinstance(v, str) else v) for k, v in cfg.items()}
-    if "roofline" in out:
-        line["roofline"] = _compact_roofline(out["roofline"])
-    if "cpu_baseline" in out:
-        line["cpu_baseline"] = _compact_cpu(out["cpu_baseline"])
-    for k in ("device_warmup_steps", "ms_per_step_cold", "ms_per_step_cold_unwarmed", "deadline_exceeded", "error", "ranks_seen", "shared_device"):
-        if k in out:
-            line[k] = _num(out[k], 5)
-    legs = {}
-    for name, leg in out.items():
-        if not isinstance(leg, dict) or name in ("config", "roofline", "cpu_baseline", "kernel_ms_avg", "index_parity"):
-            continue
-        if "ms_per_step" in leg or "error" in leg:
-            legs[name] = _leg_row(leg)
-        else:  # a group of legs (sharded_world1: {p2p, rccl}; small_n: {rows})
-            for sub, v in leg.items():
-                if isinstance(v, dict) and ("ms_per_step" in v or "error" in v):
-                    legs[f"{name}.{sub}"] = _leg_row(v)
-    if legs:
-        line["legs"] = legs
-        line["legs_columns"] = ["ms_per_step", "hbm_frac", "binding_frac"]
-    if isinstance(out.get("sharded"), dict):
-        line["sharded"] = {k: out["sharded"].get(k) for k in ("transport", "p2p_timed_out", "ranks_seen") if k in out["sharded"]}
-    for k in ("strong_scaling_ceiling", "weak_scaling_ceiling"):
-        if k in out:
-            line[k] = out[k]
-    if legs:
-        line["full"] = "bench_legs.json; every leg also as its own JSON line above this one"
-    data = json.dumps(line)
-    while len(data) > LINE_LIMIT:  # never again a line the driver cannot read: shed the optional parts, longest first
-        for k in ("legs", "cpu_baseline.sample", "config.workload", "roofline"):
-            if "." in k:
-                a, b = k.split(".")
-                if isinstance(line.get(a), dict) and isinstance(line[a].get(b), str) and len(line[a][b]) > 60:
-                    line[a][b] = _short(line[a][b], 60)
-                    break
-            elif k in line and k == "legs":
-                line.pop("legs")
-                line.pop("legs_columns", None)
-                break
-        else:
-            line = {k: line[k] for k in HEADLINE_KEYS if k in line}
-            data = json.dumps(line)
-            break
-        data = json.dumps(line)
-    return data
-
-
-def emit(out):
-    """Last on stdout: ONE compact JSON line (compact_line, < LINE_LIMIT bytes) with the contract's fields.  Before it, every
-    extra leg in full as its own JSON line ({"leg": name, ...}), and the whole record in bench_legs.json.  Native libraries
-    (RCCL's version banner) write through C stdio, so drain that buffer first."""
-    import ctypes
-
-    try:
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    _OUT["emitted"] = True
-    chunks = []
-    head = {k: v for k, v in out.items() if not (isinstance(v, dict) and k not in ("config", "roofline", "cpu_baseline", "kernel_ms_avg",
-                                                                                 "index_parity", "plain_async_step",
-                                                                                 "synchronous_try_step"))}
-    if len(out) > len(head):
-        chunks.append(json.dumps({"leg": "headline", **head}))
-        for k, v in out.items():
-            if k not in head:
-                chunks.append(json.dumps({"leg": k, **v}))
-    try:
-        with open(os.environ.get("RR_BENCH_LEGS_FILE", os.path.join(ROOT, "bench_legs.json")), "w") as f:
-            json.dump(out, f, indent=1)
-    except OSError:
-        pass
-    chunks.append(compact_line(out))
-    data = ("\n".join(chunks) + "\n").encode()
-    if _OUT["fd"] is None:
-        sys.stdout.write(data.decode())
-        sys.stdout.flush()
-    else:
-        os.write(_OUT["fd"], data)
 
 
 if __name__ == "__main__":

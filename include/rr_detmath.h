@@ -38,19 +38,73 @@
 #endif
 
 RR_HD double rr_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-/* One Horner step p * z + C with C a compile-time coefficient: the same correctly rounded fma as rr_fma on both sides (same bits);
- * on the device it is spelled as ONE VOP3 instruction that reads the coefficient from a scalar register pair.  Left to itself the
- * gfx950 code generator (VOP3 cannot hold a 64-bit literal) materialises every coefficient in a VECTOR register pair first --
- * v_mov_b32 x 2 + v_fmac_f64: three vector instructions per step (round 6: 296 v_mov_b32 in k_step_lazy<EST>'s text, ~100 of its 454
- * per-particle instructions); the scalar moves that fill an SGPR pair issue on the scalar unit beside other waves' vector work. */
+/* One Horner step p * z + C with C a compile-time coefficient: the same correctly rounded fma as rr_fma on both sides (same bits).
+ * On the device it is spelled so that the COEFFICIENT never occupies a vector register.  Left to itself the gfx950 code generator
+ * (VOP3 cannot hold a 64-bit literal) materialises every literal coefficient in a VECTOR register pair first -- v_mov_b32 x 2 +
+ * v_fmac_f64: three vector instructions per step (round 6: 296 v_mov_b32 in k_step_lazy<EST>'s text, ~100 of its 454 per-particle
+ * instructions).  Here the two halves go into VCC by scalar moves and ONE v_fma_f64 reads VCC as its addend, all inside one asm
+ * statement: the scalar unit issues beside other waves' vector work, and the coefficient lives for exactly these three
+ * instructions.  That last point is the whole difficulty -- every form that let the compiler SEE a coefficient in scalar registers
+ * lost (read off the ISA / measured on the MI355X, round 6): a v_fma_f64 asm with an "s" operand, or s_mov_b32 asm feeding a
+ * builtin fma, or a __constant__ table read by s_load_dwordx16 -- the scheduler hoists the scalar moves / loads to the top of the
+ * kernel, ~100 SGPRs spill into VGPR lanes (v_writelane / v_readlane), the 64-VGPR builds spill to scratch, and
+ * k_step_lazy<EST> went from 33.8 to 40.4 us; with a dependency token pinning the moves behind the polynomial's argument the
+ * compiler copied the SGPRs back into VGPRs to use v_fmac. */
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ static inline double rr_horner(double p, double z, double c) {
-  double r;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(z), "s"(c));
-  return r;
+template <unsigned long long BITS>
+__device__ static inline double rr_horner_vcc(double p, double z) {
+  asm("s_mov_b32 vcc_lo, %2\n\ts_mov_b32 vcc_hi, %3\n\tv_fma_f64 %0, %0, %1, vcc"
+      : "+v"(p)
+      : "v"(z), "n"((unsigned int)(BITS & 0xffffffffull)), "n"((unsigned int)(BITS >> 32))
+      : "vcc");
+  return p;
 }
+#define RR_POLY_TOKEN(tok, z) ((void)0)
+#define RR_HORNER_ASM(p, z, C) rr_horner_vcc<__builtin_bit_cast(unsigned long long, (double)(C))>((p), (z))
 #else
-RR_HD double rr_horner(double p, double z, double c) { return __builtin_fma(p, z, c); }
+#define RR_POLY_TOKEN(tok, z) ((void)0)
+#define RR_HORNER_ASM(p, z, C) __builtin_fma((p), (z), (C))
+#endif
+#define RR_HORNER_PLAIN(p, z, C) __builtin_fma((p), (z), (C))
+#ifndef RR_ASM_EXP
+#define RR_ASM_EXP 1
+#endif
+#ifndef RR_ASM_LOG
+#define RR_ASM_LOG 1
+#endif
+#ifndef RR_ASM_SIN
+#define RR_ASM_SIN 1
+#endif
+#ifndef RR_ASM_COS
+#define RR_ASM_COS 1
+#endif
+#ifndef RR_ASM_ATAN
+#define RR_ASM_ATAN 1
+#endif
+#if RR_ASM_EXP
+#define RR_HORNER_EXP RR_HORNER_ASM
+#else
+#define RR_HORNER_EXP RR_HORNER_PLAIN
+#endif
+#if RR_ASM_LOG
+#define RR_HORNER_LOG RR_HORNER_ASM
+#else
+#define RR_HORNER_LOG RR_HORNER_PLAIN
+#endif
+#if RR_ASM_SIN
+#define RR_HORNER_SIN RR_HORNER_ASM
+#else
+#define RR_HORNER_SIN RR_HORNER_PLAIN
+#endif
+#if RR_ASM_COS
+#define RR_HORNER_COS RR_HORNER_ASM
+#else
+#define RR_HORNER_COS RR_HORNER_PLAIN
+#endif
+#if RR_ASM_ATAN
+#define RR_HORNER_ATAN RR_HORNER_ASM
+#else
+#define RR_HORNER_ATAN RR_HORNER_PLAIN
 #endif
 RR_HD double rr_rint(double x) { return __builtin_rint(x); }
 RR_HD double rr_sqrt(double x) { return __builtin_sqrt(x); }
@@ -121,19 +175,20 @@ RR_HD double rr_exp(double x) {
   double k = rr_rint(x * RR_LOG2E);
   double r = rr_fma(-k, RR_LN2_HI, x);
   r = rr_fma(-k, RR_LN2_LO, r);
+  RR_POLY_TOKEN(tok, r);
   double p = RR_EXP_C_12;
-  p = rr_horner(p, r, RR_EXP_C_11);
-  p = rr_horner(p, r, RR_EXP_C_10);
-  p = rr_horner(p, r, RR_EXP_C_9);
-  p = rr_horner(p, r, RR_EXP_C_8);
-  p = rr_horner(p, r, RR_EXP_C_7);
-  p = rr_horner(p, r, RR_EXP_C_6);
-  p = rr_horner(p, r, RR_EXP_C_5);
-  p = rr_horner(p, r, RR_EXP_C_4);
-  p = rr_horner(p, r, RR_EXP_C_3);
-  p = rr_horner(p, r, RR_EXP_C_2);
-  p = rr_horner(p, r, RR_EXP_C_1);
-  p = rr_horner(p, r, RR_EXP_C_0);
+  p = RR_HORNER_EXP(p, r, RR_EXP_C_11);
+  p = RR_HORNER_EXP(p, r, RR_EXP_C_10);
+  p = RR_HORNER_EXP(p, r, RR_EXP_C_9);
+  p = RR_HORNER_EXP(p, r, RR_EXP_C_8);
+  p = RR_HORNER_EXP(p, r, RR_EXP_C_7);
+  p = RR_HORNER_EXP(p, r, RR_EXP_C_6);
+  p = RR_HORNER_EXP(p, r, RR_EXP_C_5);
+  p = RR_HORNER_EXP(p, r, RR_EXP_C_4);
+  p = RR_HORNER_EXP(p, r, RR_EXP_C_3);
+  p = RR_HORNER_EXP(p, r, RR_EXP_C_2);
+  p = RR_HORNER_EXP(p, r, RR_EXP_C_1);
+  p = RR_HORNER_EXP(p, r, RR_EXP_C_0);
   return rr_scale2(p, (int)k);
 }
 
@@ -149,16 +204,17 @@ RR_HD double rr_log_core(uint64_t u, int e) {
   double f = m - 1.0;
   double s = f / (2.0 + f);
   double z = s * s;
+  RR_POLY_TOKEN(tok, z);
   double p = RR_LOG_C_9;
-  p = rr_horner(p, z, RR_LOG_C_8);
-  p = rr_horner(p, z, RR_LOG_C_7);
-  p = rr_horner(p, z, RR_LOG_C_6);
-  p = rr_horner(p, z, RR_LOG_C_5);
-  p = rr_horner(p, z, RR_LOG_C_4);
-  p = rr_horner(p, z, RR_LOG_C_3);
-  p = rr_horner(p, z, RR_LOG_C_2);
-  p = rr_horner(p, z, RR_LOG_C_1);
-  p = rr_horner(p, z, RR_LOG_C_0);
+  p = RR_HORNER_LOG(p, z, RR_LOG_C_8);
+  p = RR_HORNER_LOG(p, z, RR_LOG_C_7);
+  p = RR_HORNER_LOG(p, z, RR_LOG_C_6);
+  p = RR_HORNER_LOG(p, z, RR_LOG_C_5);
+  p = RR_HORNER_LOG(p, z, RR_LOG_C_4);
+  p = RR_HORNER_LOG(p, z, RR_LOG_C_3);
+  p = RR_HORNER_LOG(p, z, RR_LOG_C_2);
+  p = RR_HORNER_LOG(p, z, RR_LOG_C_1);
+  p = RR_HORNER_LOG(p, z, RR_LOG_C_0);
   /* atanh(s) = s + s*z*p ; log(m) = 2 atanh(s) */
   double t = s * z;
   double lm = 2.0 * rr_fma(t, p, s);
@@ -183,26 +239,28 @@ RR_HD double rr_log(double x) {
 /* ------------------------------------------------------------------ sin/cos kernels, |r| <= pi/4 */
 RR_HD double rr_sin_kernel(double r) {
   double s = r * r;
+  RR_POLY_TOKEN(tok, s);
   double p = RR_SIN_C_7;
-  p = rr_horner(p, s, RR_SIN_C_6);
-  p = rr_horner(p, s, RR_SIN_C_5);
-  p = rr_horner(p, s, RR_SIN_C_4);
-  p = rr_horner(p, s, RR_SIN_C_3);
-  p = rr_horner(p, s, RR_SIN_C_2);
-  p = rr_horner(p, s, RR_SIN_C_1);
-  p = rr_horner(p, s, RR_SIN_C_0);
+  p = RR_HORNER_SIN(p, s, RR_SIN_C_6);
+  p = RR_HORNER_SIN(p, s, RR_SIN_C_5);
+  p = RR_HORNER_SIN(p, s, RR_SIN_C_4);
+  p = RR_HORNER_SIN(p, s, RR_SIN_C_3);
+  p = RR_HORNER_SIN(p, s, RR_SIN_C_2);
+  p = RR_HORNER_SIN(p, s, RR_SIN_C_1);
+  p = RR_HORNER_SIN(p, s, RR_SIN_C_0);
   return rr_fma(r * s, p, r);
 }
 RR_HD double rr_cos_kernel(double r) {
   double s = r * r;
+  RR_POLY_TOKEN(tok, s);
   double p = RR_COS_C_7;
-  p = rr_horner(p, s, RR_COS_C_6);
-  p = rr_horner(p, s, RR_COS_C_5);
-  p = rr_horner(p, s, RR_COS_C_4);
-  p = rr_horner(p, s, RR_COS_C_3);
-  p = rr_horner(p, s, RR_COS_C_2);
-  p = rr_horner(p, s, RR_COS_C_1);
-  p = rr_horner(p, s, RR_COS_C_0);
+  p = RR_HORNER_COS(p, s, RR_COS_C_6);
+  p = RR_HORNER_COS(p, s, RR_COS_C_5);
+  p = RR_HORNER_COS(p, s, RR_COS_C_4);
+  p = RR_HORNER_COS(p, s, RR_COS_C_3);
+  p = RR_HORNER_COS(p, s, RR_COS_C_2);
+  p = RR_HORNER_COS(p, s, RR_COS_C_1);
+  p = RR_HORNER_COS(p, s, RR_COS_C_0);
   return rr_fma(s * s, p, rr_fma(-0.5, s, 1.0));
 }
 
@@ -263,20 +321,21 @@ RR_HD double rr_atan_pos(double y, double x) {
   double t = (big ? num - den : num) / (big ? num + den : den);
   double base_hi = big ? RR_PIO4_HI : 0.0, base_lo = big ? RR_PIO4_LO : 0.0;
   double z = t * t;
+  RR_POLY_TOKEN(tok, z);
   double p = RR_ATAN_C_13;
-  p = rr_horner(p, z, RR_ATAN_C_12);
-  p = rr_horner(p, z, RR_ATAN_C_11);
-  p = rr_horner(p, z, RR_ATAN_C_10);
-  p = rr_horner(p, z, RR_ATAN_C_9);
-  p = rr_horner(p, z, RR_ATAN_C_8);
-  p = rr_horner(p, z, RR_ATAN_C_7);
-  p = rr_horner(p, z, RR_ATAN_C_6);
-  p = rr_horner(p, z, RR_ATAN_C_5);
-  p = rr_horner(p, z, RR_ATAN_C_4);
-  p = rr_horner(p, z, RR_ATAN_C_3);
-  p = rr_horner(p, z, RR_ATAN_C_2);
-  p = rr_horner(p, z, RR_ATAN_C_1);
-  p = rr_horner(p, z, RR_ATAN_C_0);
+  p = RR_HORNER_ATAN(p, z, RR_ATAN_C_12);
+  p = RR_HORNER_ATAN(p, z, RR_ATAN_C_11);
+  p = RR_HORNER_ATAN(p, z, RR_ATAN_C_10);
+  p = RR_HORNER_ATAN(p, z, RR_ATAN_C_9);
+  p = RR_HORNER_ATAN(p, z, RR_ATAN_C_8);
+  p = RR_HORNER_ATAN(p, z, RR_ATAN_C_7);
+  p = RR_HORNER_ATAN(p, z, RR_ATAN_C_6);
+  p = RR_HORNER_ATAN(p, z, RR_ATAN_C_5);
+  p = RR_HORNER_ATAN(p, z, RR_ATAN_C_4);
+  p = RR_HORNER_ATAN(p, z, RR_ATAN_C_3);
+  p = RR_HORNER_ATAN(p, z, RR_ATAN_C_2);
+  p = RR_HORNER_ATAN(p, z, RR_ATAN_C_1);
+  p = RR_HORNER_ATAN(p, z, RR_ATAN_C_0);
   double a = base_hi + (rr_fma(t * z, p, t) + base_lo);
   if (swap) a = RR_PIO2_1 - (a - RR_PIO2_2);
   return a;

@@ -364,7 +364,11 @@ rr_status rr_pf_p2p_export(rr_pf* h, uint8_t out[RR_P2P_HANDLE_BYTES]);
 rr_status rr_pf_p2p_connect(rr_pf* h, const uint8_t* all_handles, int32_t n_ranks, int32_t rank);
 /* all shards in THIS process (one or several devices with peer access): handles[g] is rank g */
 rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks);
-/* one sharded step, fully asynchronous (nothing is waited for on the host) */
+/* one sharded step, fully asynchronous (nothing is waited for on the host).  Shards created with RR_RESAMPLE_MULTINOMIAL -- the
+ * resampler the reference's ParticleFilterLocalizer and MonteCarloLocalizer really use (particle_filter.rs:441-473,
+ * monte_carlo_localization.rs:322-365) -- take the same entry point: iid draws scatter the slots a shard serves over all ranks,
+ * so every draw is searched by the shard whose interval of the global CDF holds it and its source is stored straight into the
+ * owning rank's slab, with a DONE exchange behind the stores (no window, nothing lazy; rr_pf_shard_want_estimate is not offered) */
 rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* obs, size_t n_obs);
 /* the same step with an eager gather of ALL slots into their owners' slabs and a separate tile-scan
  * launch: the plain statement of the protocol, kept for A/B measurement */
@@ -380,6 +384,12 @@ rr_status rr_pf_shard_last_estimate_sums(rr_pf* h, double out_sums[4], double* o
 /* synchronises and reports whether any wait gave up (a peer did not answer within 2 s; every
  * later exchange of the filter then returns at once and the resample is skipped) */
 rr_status rr_pf_p2p_status(rr_pf* h, int32_t* timed_out);
+/* How this shard is wired (no synchronisation): out[0] = ranks of the filter, out[1] = how many of them live on this shard's
+ * device (1 in the deployment; > 1 on a test rig), out[2] = CUs of the device this shard's stream is confined to (0: all of them;
+ * > 0 with RR_P2P_CU_PARTITION=1 among sharers of one device: each then runs the lazy window step as on a device of its own),
+ * out[3] = form of the last rr_pf_shard_step_p2p: 1 the lazy window step (k_step_lazy<kSrcWindow> | plan | k_push_window -- the
+ * deployment path), 2 the eager step (sharers of one device whose step kernels could fill it), 0 none yet. */
+rr_status rr_pf_p2p_topology(rr_pf* h, int32_t out[4]);
 
 /* ---- native sharded step: the phases above driven from inside the library with RCCL called
  * directly (librccl is dlopen'ed on first use, so single-GPU users never load it).  One

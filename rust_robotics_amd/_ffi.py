@@ -126,7 +126,12 @@ def lib() -> C.CDLL:
     st = C.c_int
 
     def proto(name, res, args):
-        f = getattr(L, name)
+        try:
+            f = getattr(L, name)
+        except AttributeError:
+            if os.environ.get("RR_AMD_LIBRARY"):  # an OLDER build loaded for an A/B run (tools/ab_bench.sh): entry points added since
+                return                            # are simply absent -- calling one raises AttributeError at the call site
+            raise
         f.restype = res
         f.argtypes = args
 
@@ -211,6 +216,7 @@ def lib() -> C.CDLL:
     proto("rr_pf_shard_step_p2p", st, [H, P, P, sz])
     proto("rr_pf_shard_step_p2p_unfused", st, [H, P, P, sz])
     proto("rr_pf_p2p_status", st, [H, C.POINTER(i32)])
+    proto("rr_pf_p2p_topology", st, [H, C.POINTER(i32)])
     proto("rr_pf_shard_want_estimate", st, [H, i32])
     proto("rr_pf_shard_last_estimate_sums", st, [H, P, P])
     proto("rr_sys_segment_matrix", u64, [d, C.POINTER(u64), i32, u64, u64, i32, C.POINTER(C.c_int64)])

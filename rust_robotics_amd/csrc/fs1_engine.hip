@@ -65,6 +65,7 @@ struct rr_fs1 {
   uint64_t n = 0, L = 0, n_planes = 0, n_tiles = 0;
   uint64_t n_global = 0, gid0 = 0;  // sharding: particles over all shards, global index of local particle 0
   hipStream_t stream = nullptr;
+  bool cu_partitioned = false;  // RR_P2P_CU_PARTITION: the stream was re-created with this shard's share of the device's CUs
   Planes pl{};
   double* slab = nullptr;  // [set][plane][n]
   rr::P2PState p2p;
@@ -1267,11 +1268,36 @@ static rr_status fs1_alloc_ridx(rr_fs1* h) {
   return RR_OK;
 }
 
+// RR_P2P_CU_PARTITION=1 (a test rig, as in pf_engine.hip): shards that SHARE a device each get a stream of their own 1/n of its CUs.
+// A FastSLAM shard waits for its peers only in the one-workgroup exchange kernels, so it needs no CUs of its own to make progress --
+// what it needs is a hardware queue of its own (a spinning exchange kernel must never sit in front of the kernel it waits for), and a
+// stream created with a CU mask gets a dedicated one.  Eight shards of one process were seen to give up an exchange without it
+// (round 6, tests/test_gpu_world8.py).
+static rr_status fs1_apply_cu_partition(rr_fs1* h) {
+  const char* e = std::getenv("RR_P2P_CU_PARTITION");
+  if (!e || std::atoi(e) == 0 || h->p2p.n_sharing <= 1 || h->cu_partitioned) return RR_OK;
+  int cus = 0;
+  RR_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
+  const int parts = h->p2p.n_sharing, part = h->p2p.share_ordinal, per = cus / parts;
+  if (per < 8 || part >= parts) return RR_OK;
+  std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+  for (int b = part * per; b < (part + 1) * per; ++b) mask[(size_t)b / 32] |= 1u << (b % 32);
+  hipStream_t s = nullptr;
+  RR_HIP_TRY(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+  RR_HIP_TRY(hipStreamSynchronize(h->stream));
+  (void)hipStreamDestroy(h->stream);
+  h->stream = s;
+  h->cu_partitioned = true;
+  return RR_OK;
+}
+
 rr_status rr_fs1_p2p_export(rr_fs1* h, uint8_t out[RR_P2P_HANDLE_BYTES]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!out) return fail(RR_INVALID_PARAMETER, "null output");
-  return h->p2p.export_handles(h->slab, h->n_planes * h->n, out);
+  // (no slab: a FastSLAM shard's peers deliver into its INBOX only -- k_fs1_push; at BASELINE configs[3] the slab is 2.4 GB per rank,
+  // beyond what hipIpc maps on this driver, the inbox 1.2 GB)
+  return h->p2p.export_handles(nullptr, h->n_planes * h->n, out);
 }
 
 rr_status rr_fs1_p2p_connect(rr_fs1* h, const uint8_t* all_handles, int32_t n_ranks, int32_t rank) {
@@ -1282,7 +1308,7 @@ rr_status rr_fs1_p2p_connect(rr_fs1* h, const uint8_t* all_handles, int32_t n_ra
   if ((s = fs1_alloc_ridx(h)) != RR_OK) return s;
   if ((s = h->p2p.connect_ipc(h->slab, h->n_planes * h->n, all_handles, n_ranks, rank)) != RR_OK) return s;
   h->pl.inbox = h->p2p.inbox;
-  return RR_OK;
+  return fs1_apply_cu_partition(h);
 }
 
 rr_status rr_fs1_p2p_connect_local(rr_fs1* const* handles, int32_t n_ranks) {
@@ -1305,7 +1331,8 @@ rr_status rr_fs1_p2p_connect_local(rr_fs1* const* handles, int32_t n_ranks) {
   rr_status s = rr::p2p_link_local(st, slabs, inboxes, devs, n_ranks);
   if (s != RR_OK) return s;
   for (int g = 0; g < n_ranks; ++g) handles[g]->pl.inbox = handles[g]->p2p.inbox;
-  return RR_OK;
+  for (int g = 0; g < n_ranks && s == RR_OK; ++g) s = fs1_apply_cu_partition(handles[g]);
+  return s;
 }
 
 rr_status rr_fs1_p2p_status(rr_fs1* h, int32_t* timed_out) {

@@ -707,14 +707,23 @@ struct P2PState {
     return RR_OK;
   }
 
-  rr_status export_handles(double* slab, size_t inbox_doubles_, uint8_t out[kP2PHandleBytes]) {
+  rr_status export_handles(double* slab, size_t inbox_doubles_, uint8_t out[kP2PHandleBytes], size_t slab_bytes = 0) {
     const bool again = mbox != nullptr;
     rr_status s = local_setup(inbox_doubles_);
     if (s != RR_OK) return s;
     if (again && (s = reset_records()) != RR_OK) return s;
     static_assert(3 * sizeof(hipIpcMemHandle_t) <= kP2PHandleBytes, "handle blob too small");
+    // An allocation of 2 GiB or more must not go through hipIpc on this driver (ROCm 7.2, dmabuf IPC): hipIpcOpenMemHandle of the
+    // importing rank does not return (round 6, tools/ipc_connect_probe.py: 2 processes x a 2.4 GB slab hung for minutes; 1.2 GB
+    // opens in 0.1 s).  FastSLAM shards therefore export no slab at all (slab == nullptr: their peers only ever write the inbox),
+    // and an inbox or slab that large is refused here with a message instead of a hang there.
+    constexpr size_t kIpcMaxBytes = (size_t)1 << 31;
+    if (inbox_doubles_ * sizeof(double) >= kIpcMaxBytes || slab_bytes >= kIpcMaxBytes)
+      return fail(RR_INVALID_PARAMETER, "peer-to-peer transport: this shard's inbox / state slab is 2 GiB or larger, which hipIpc cannot map on this "
+                                        "driver (the importing rank would hang): use more ranks (smaller shards) or the RCCL transport");
     hipIpcMemHandle_t hs[3];
-    RR_HIP_TRY(hipIpcGetMemHandle(&hs[0], slab));
+    std::memset(hs, 0, sizeof hs);
+    if (slab) RR_HIP_TRY(hipIpcGetMemHandle(&hs[0], slab));
     RR_HIP_TRY(hipIpcGetMemHandle(&hs[1], mbox));
     RR_HIP_TRY(hipIpcGetMemHandle(&hs[2], inbox));
     std::memset(out, 0, kP2PHandleBytes);
@@ -754,8 +763,11 @@ struct P2PState {
         if (g < rank) share_ordinal += 1;
       }
       void *ps = nullptr, *pm = nullptr, *pi = nullptr;
-      RR_HIP_TRY(hipIpcOpenMemHandle(&ps, hs[0], hipIpcMemLazyEnablePeerAccess));
-      opened[n_opened++] = ps;
+      static const hipIpcMemHandle_t kNoHandle{};
+      if (std::memcmp(&hs[0], &kNoHandle, sizeof kNoHandle) != 0) {  // (FastSLAM shards export no slab: nobody writes a peer's planes)
+        RR_HIP_TRY(hipIpcOpenMemHandle(&ps, hs[0], hipIpcMemLazyEnablePeerAccess));
+        opened[n_opened++] = ps;
+      }
       RR_HIP_TRY(hipIpcOpenMemHandle(&pm, hs[1], hipIpcMemLazyEnablePeerAccess));
       opened[n_opened++] = pm;
       RR_HIP_TRY(hipIpcOpenMemHandle(&pi, hs[2], hipIpcMemLazyEnablePeerAccess));

@@ -210,6 +210,8 @@ struct rr_pf {
   int dev_cus = 0;
   int spin_gate_no = 0;   // rr::spin_permit's gate: the device, or this shard's own part of its CUs (RR_P2P_CU_PARTITION)
   int cu_part_cus = 0;    // > 0: the handle's stream is confined to that many CUs of its own (p2p_apply_cu_partition)
+  bool mn_push_lds_set = false;  // k_mn_push_p2p's dynamic-LDS limit has been raised on this handle's device
+  int p2p_last_form = 0;  // rr_pf_p2p_topology: 1 = the last rr_pf_shard_step_p2p took the lazy window step, 2 = the eager step
   uint64_t shard_capacity = ~0ull;  // the same for k_shard_plan_mark (sharded step over the peer-to-peer transport); ~0: not asked yet
   unsigned int* est_ticket = nullptr;  // arrival counters of its last-workgroup reduction (rr::last_arrival; zero between launches)
   double* scratch_a = nullptr;  // n doubles: explicit noise v / uniforms / AoS staging (5n)
@@ -2452,8 +2454,7 @@ static rr_status p2p_check_geometry(const rr_pf* h, int n_ranks, int rank) {
     return fail(RR_INVALID_PARAMETER, "peer-to-peer transport supports 1..16 ranks");
   if (h->n_global != h->n * (uint64_t)n_ranks || h->opt.first_global_index != h->n * (uint64_t)rank)
     return fail(RR_INVALID_PARAMETER, "shard geometry does not match the rank layout (equal blocks, rank * n_local)");
-  if (h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC)
-    return fail(RR_INVALID_PARAMETER, "sharded resampling is systematic only");
+  // (both schemes: the systematic shards take the window step, the multinomial ones shard_step_p2p_multinomial)
   return RR_OK;
 }
 
@@ -2496,7 +2497,7 @@ rr_status rr_pf_p2p_export(rr_pf* h, uint8_t out[RR_P2P_HANDLE_BYTES]) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!out) return fail(RR_INVALID_PARAMETER, "null output");
-  return h->p2p.export_handles(h->slab, 5 * h->n, out);  // inbox: 4 fields + the seal plane
+  return h->p2p.export_handles(h->slab, 5 * h->n, out, 8 * h->cap * sizeof(double));  // inbox: 4 fields + the seal plane
 }
 
 rr_status rr_pf_p2p_connect(rr_pf* h, const uint8_t* all_handles, int32_t n_ranks, int32_t rank) {
@@ -2542,10 +2543,77 @@ rr_status rr_pf_p2p_connect_local(rr_pf* const* handles, int32_t n_ranks) {
 // measured in round 3: docs/DESIGN_NOTES.md section 5 -- it loses to this on every count.)
 rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const double* obs, size_t n_obs);
 
+// MULTINOMIAL shards over the peer-to-peer transport (round 6): the resampler the reference's ParticleFilterLocalizer and
+// MonteCarloLocalizer really use (particle_filter.rs:441-473, monte_carlo_localization.rs:322-365, :387-392), sharded without a
+// collective library and without the host in the step.  iid draws scatter the slots a shard serves over all ranks, so there is
+// no window and nothing lazy: propagate + weight | WMAX exchange | integer image | tile scan + SUMS exchange (gate, base, totals)
+// | local slice of the global CDF | k_mn_push_p2p: every draw that falls into this shard's CDF interval is searched here and its
+// source stored straight into the owning rank's slab | DONE exchange.  Every shard evaluates all N draws (a Philox block and a
+// comparison each), searches N / G of them on average and moves as many particles -- nearly all of them across ranks: that is
+// what iid draws cost on any transport.  The RCCL form of the same step (rr_pf_shard_step: count, scan, pack, all-to-all, adopt,
+// two host round trips) measured 0.30 ms per step at world size 1.
+static rr_status shard_step_p2p_multinomial(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
+  rr_status s;
+  if ((s = validate_control(control)) != RR_OK) return s;
+  if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
+  if ((s = materialise(h)) != RR_OK) return s;
+  const uint64_t seq = ++h->p2p.seq;
+  ObsArg arg;
+  bool kernarg;
+  if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
+  StepParams p = make_params(h, control, (int)n_obs);
+  if ((s = launch_pw<true, true, false>(h, p, arg, kernarg)) != RR_OK) return s;
+  h->step += 1;
+  PlanArgs pa = plan_args(h, 0, RR_RESAMPLE_MULTINOMIAL, NAN);
+  // exchange 1: global maximum -> Ctl.wmax
+  hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PWmax, seq,
+                     (const uint64_t*)&h->ctl->wmax_bits, h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+  // integer image under the global maximum; tile scan + exchange 2: every rank's sums -> gate, base, totals in Ctl
+  launch_quantize(h, (const double*)&h->ctl->wmax);
+  {
+    Timed t(h, RR_K_SCAN_TILES);
+    hipLaunchKernelGGL(rr::k_scan_exchange, dim3(1), dim3(kScanThreads), 0, h->stream, h->p2p.peers, seq, h->tile_total,
+                       (const uint64_t*)h->tile_q2, h->n_tiles, h->ctl, pa, h->p2p.err);
+  }
+  {
+    Timed t(h, RR_K_CDF);
+    hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl, image_args(h),
+                       h->tile_total, h->cdf, h->cdf_coarse, h->coarse_log2);  // (+ the coarse table the push kernel stages in LDS)
+  }
+  h->wmax_live = false;
+  h->wmax_bits_clean = false;  // (a peer wait that gave up skips finalize_plan: do not rely on the zeroed accumulator)
+  MnSelectArgs a{};
+  a.n_local = h->n;
+  a.n_global = h->n_global;
+  a.tiles_per_dest = (h->n + kTile - 1) / kTile;
+  a.seed = h->opt.seed;
+  a.rstep = h->rstep;  // the resample being planned: the draws of THIS resample step
+  a.n_shards = h->p2p.peers.n_ranks;
+  h->rstep += 1;
+  {
+    Timed t(h, RR_K_RESAMPLE_GATHER);
+    const uint64_t push_tiles = a.tiles_per_dest * (uint64_t)a.n_shards;
+    const size_t lds = h->n_coarse * sizeof(uint64_t);
+    if (!h->mn_push_lds_set) {  // (per handle: the attribute belongs to the handle's device)
+      RR_HIP_TRY(hipFuncSetAttribute((const void*)k_mn_push_p2p, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+      h->mn_push_lds_set = true;
+    }
+    hipLaunchKernelGGL(k_mn_push_p2p, dim3((unsigned)std::min<uint64_t>(push_tiles, (uint64_t)h->mn_grid)), dim3(rr::kTileBlock), lds, h->stream,
+                       h->b, h->ctl, a, (const uint64_t*)h->cdf, h->n, (const uint64_t*)h->cdf_coarse, h->coarse_log2, h->n_coarse, h->p2p.peers);
+  }
+  // exchange 3: every rank has finished writing into everybody's slab
+  hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PDone, seq,
+                     (const uint64_t*)h->p2p.local3(), h->ctl, &h->ctl->wmax, pa, h->p2p.err);
+  RR_HIP_TRY(hipGetLastError());
+  h->p2p_last_form = 2;
+  return RR_OK;
+}
+
 rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_p2p_connect first");
+  if (h->opt.resample_scheme == RR_RESAMPLE_MULTINOMIAL) return shard_step_p2p_multinomial(h, control, obs, n_obs);
   if ((s = validate_control(control)) != RR_OK) return s;
   if ((s = validate_obs(obs, n_obs)) != RR_OK) return s;
   // Ranks that SHARE a device (a test rig; one rank per GPU is the deployment): this step's k_step_lazy waits, inside the
@@ -2558,8 +2626,12 @@ rr_status rr_pf_shard_step_p2p(rr_pf* h, const double control[2], const double* 
   if (h->p2p.n_sharing > 1 && !h->cu_part_cus) {  // (sharers with a part of the CUs each -- RR_P2P_CU_PARTITION -- cannot do that to each other)
     if (!h->dev_cus) RR_HIP_TRY(hipDeviceGetAttribute(&h->dev_cus, hipDeviceAttributeMultiprocessorCount, h->opt.device));
     const uint64_t step_wgs = (h->n + rr::kResolveSlots - 1) / rr::kResolveSlots;
-    if (step_wgs * (uint64_t)h->p2p.n_sharing > 3ull * (uint64_t)h->dev_cus) return rr_pf_shard_step_p2p_unfused(h, control, obs, n_obs);
+    if (step_wgs * (uint64_t)h->p2p.n_sharing > 3ull * (uint64_t)h->dev_cus) {
+      h->p2p_last_form = 2;
+      return rr_pf_shard_step_p2p_unfused(h, control, obs, n_obs);
+    }
   }
+  h->p2p_last_form = 1;
   if (h->maybe_pending && (h->pending_kind != kSrcWindow || h->window_rccl) && (s = materialise(h)) != RR_OK) return s;
   ObsArg arg;
   bool kernarg;
@@ -2760,6 +2832,7 @@ rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const 
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   if (!h->p2p.ready) return fail(RR_INVALID_PARAMETER, "call rr_pf_p2p_connect first");
+  if (h->opt.resample_scheme == RR_RESAMPLE_MULTINOMIAL) return shard_step_p2p_multinomial(h, control, obs, n_obs);  // (its only form)
   const uint64_t seq = ++h->p2p.seq;
   uint64_t* local3 = h->p2p.local3();
   // A: propagate + weight; the local maximum stays in Ctl.wmax_bits
@@ -2812,6 +2885,15 @@ rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const 
     launch_est_slots(h);
   }
   RR_HIP_TRY(hipGetLastError());
+  return RR_OK;
+}
+
+rr_status rr_pf_p2p_topology(rr_pf* h, int32_t out[4]) {
+  if (!h || !out) return fail(RR_INVALID_PARAMETER, "null argument");
+  out[0] = h->p2p.ready ? h->p2p.peers.n_ranks : 0;
+  out[1] = h->p2p.n_sharing;
+  out[2] = h->cu_part_cus;
+  out[3] = h->p2p_last_form;
   return RR_OK;
 }
 

@@ -463,14 +463,17 @@ class P2PShard:
 
     def __init__(self, rank: int, world: int, device: int, n_local: int, *, seed: int, range_noise=0.2,
                  velocity_noise=2.0, yaw_rate_noise=math.radians(40.0), dt=0.1, gate=_ffi.RR_GATE_ALWAYS,
-                 resample_threshold=1.0, likelihood_mode=_ffi.RR_LIK_FUSED, initial_state=None):
+                 resample_threshold=1.0, likelihood_mode=_ffi.RR_LIK_FUSED, initial_state=None,
+                 scheme=_ffi.RR_RESAMPLE_SYSTEMATIC):
+        """scheme: RR_RESAMPLE_SYSTEMATIC (the window step) or RR_RESAMPLE_MULTINOMIAL (the reference's own PF / MCL resampler:
+        every draw searched by the shard whose CDF interval holds it, the source stored straight into the owner's slab)"""
         L = _ffi.lib()
         self.L, self.rank, self.world, self.n_local = L, rank, world, n_local
         cfg = _ffi.PfConfig(n_local, resample_threshold, range_noise, velocity_noise, yaw_rate_noise, dt)
         opt = _ffi.PfOptions()
         L.rr_pf_options_default(C.byref(opt))
         opt.device, opt.seed = device, seed
-        opt.resample_scheme, opt.resample_gate, opt.likelihood_mode = _ffi.RR_RESAMPLE_SYSTEMATIC, gate, likelihood_mode
+        opt.resample_scheme, opt.resample_gate, opt.likelihood_mode = scheme, gate, likelihood_mode
         opt.first_global_index, opt.n_global = rank * n_local, n_local * world
         self.h = C.c_void_p()
         if initial_state is None:
@@ -516,6 +519,12 @@ class P2PShard:
         out = C.c_int32()
         self._check(self.L.rr_pf_p2p_status(self.h, C.byref(out)))
         return bool(out.value)
+
+    def topology(self) -> dict:
+        """rr_pf_p2p_topology: ranks, ranks sharing this device, CUs the stream is confined to (0: all), form of the last step"""
+        out = (C.c_int32 * 4)()
+        self._check(self.L.rr_pf_p2p_topology(self.h, out))
+        return dict(n_ranks=out[0], n_sharing=out[1], cu_partition_cus=out[2], last_step={0: "none", 1: "lazy", 2: "eager"}[out[3]])
 
     def want_estimate(self, on: bool = True) -> None:
         """rr_pf_shard_want_estimate: every step leaves this shard's part of the mean try_step returns (the sums of x, y, yaw, v
@@ -656,9 +665,8 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     import torch
     import torch.distributed as dist
 
-    multinomial = scheme != _ffi.RR_RESAMPLE_SYSTEMATIC
-    if multinomial and transport in ("auto", "p2p", "p2p-only"):
-        transport = "rccl"  # iid draws scatter the served slots over all ranks: all-to-all exchange, RCCL / torch transports only
+    multinomial = scheme != _ffi.RR_RESAMPLE_SYSTEMATIC  # (iid draws: the peer-to-peer transport stores every served slot straight
+    # into its owner's slab -- rr_pf_shard_step_p2p of multinomial shards, round 6; RCCL / torch move them in an all-to-all)
     own_group = not dist.is_initialized()  # bench.py keeps one gloo group for all its legs
     if own_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -720,7 +728,7 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     p2p, use_p2p = None, False
     if transport in ("auto", "p2p", "p2p-only"):
         def make_p2p():
-            s = P2PShard(rank, world, local_rank, n_local, **kw)
+            s = P2PShard(rank, world, local_rank, n_local, **kw)  # (kw carries the scheme of multinomial shards)
             s.connect_ipc(gloo_allgather(dist))
             return s
 
@@ -729,12 +737,12 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
     # UNSHARDED filter of all n_local * world particles on every rank (systematic shards; it fits one GPU up to tens of millions
     # of particles) -- both native transports share the window kernels, so agreeing with each other would not be enough
     validated_ref = False
-    if (ref is not None or p2p is not None) and not multinomial and n_local * world <= (1 << 25):
+    if (ref is not None or p2p is not None) and n_local * world <= (1 << 25):
         import rust_robotics_amd.localization as loc
 
         cfg = loc.MonteCarloLocalizationConfig(min_particles=n_local * world, max_particles=n_local * world)
         whole = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=local_rank,
-                                                           resample_scheme=_ffi.RR_RESAMPLE_SYSTEMATIC, likelihood_mode=lik)
+                                                           resample_scheme=scheme, likelihood_mode=lik)
         alive = True
         for t in range(V):
             if p2p is not None and alive:

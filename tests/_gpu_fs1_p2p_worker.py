@@ -31,12 +31,24 @@ def main():
     from tests import helpers as H
     from tests.test_gpu_fs1_sharded import SEED, check, scenario
 
+    import datetime
+    import faulthandler
+    import time
+
     n_local, steps = int(sys.argv[1]), int(sys.argv[2])
     L = int(sys.argv[3]) if len(sys.argv) > 3 else 7
     big = L >= 100
     chunks = 0 if big else 2
-    dist.init_process_group("gloo")
+    # a rank that stops must say WHERE, and must not keep the others in a collective for gloo's default half hour
+    faulthandler.dump_traceback_later(int(os.environ.get("RR_WORKER_DUMP_AFTER_S", "420")), exit=True)
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=int(os.environ.get("RR_WORKER_GLOO_TIMEOUT_S", "480"))))
     rank, world = dist.get_rank(), dist.get_world_size()
+    t_start = time.time()
+
+    def log(msg):
+        sys.stderr.write(f"[fs1 p2p worker rank {rank} +{time.time() - t_start:6.1f}s] {msg}\n")
+        sys.stderr.flush()
+
     n = n_local * world
     if big:
         lms = np.random.default_rng(61).uniform(-13.0, 13.0, size=(L, 2))
@@ -55,28 +67,37 @@ def main():
         shard = ShardedFastSlam1(rank, world, n_local, L, params=prm, seed=SEED, obs_chunks=chunks)
         shard.set_state(poses[sl], maps[sl])
         u = [1.0, 0.1]
+    log("shard created")
     shard.connect_ipc(gloo_allgather(dist))
+    log("peers mapped")
     dist.barrier()
     for z in zs:
         shard.update_async(u, z)
+    log("updates enqueued")
     assert not shard.timed_out(), "a peer wait timed out"
+    log("updates done, no give-up")
     got = shard.get_state()
+    log("state read back")
     if big:
         mine = digest(*got)
         del got
         dist.barrier()
-        del shard  # (its 3.6 GB back before rank 0 puts 19.3 GB beside the other shards)
+        log("closing the shard")
+        shard.close()  # (its 3.6 GB back before rank 0 puts 19.3 GB beside the other shards)
         shard = None
+        log("shard closed")
         digests = [None] * world
         dist.all_gather_object(digests, mine)
         if rank == 0:
             whole = fs.FastSlam1(n, L, params=params(), seed=8, obs_chunks=chunks)
+            log("unsharded filter created")
             fired = []
             for z in zs:
                 whole.update(u, z)
                 fired.append(bool(whole.last_resample_fired()))
             ep, em = whole.get_state()
             whole.close()
+            log("unsharded filter done")
             assert any(fired), fired
             for g in range(world):
                 sl = slice(g * n_local, (g + 1) * n_local)

@@ -39,6 +39,10 @@ def main():
         shard.step([1.0, 0.1], obs[t])
     assert not shard.timed_out(), "a peer wait timed out"
     got = shard.particles()
+    if rank == 0:
+        print("P2P_TOPOLOGY", shard.topology(), flush=True)
+    if os.environ.get("RR_P2P_CU_PARTITION", "0") not in ("", "0") and world > 1:
+        assert shard.topology()["cu_partition_cus"] > 0 and shard.topology()["last_step"] == "lazy", shard.topology()
     dist.barrier()  # every rank's shard is done before anybody puts the unsharded filter of ALL particles beside it
     if peaked:
         cfg = loc.MonteCarloLocalizationConfig(min_particles=n * world, max_particles=n * world)

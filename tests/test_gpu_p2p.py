@@ -60,6 +60,58 @@ def run_in_process(world, n_local, steps=10, mode="fused"):
     print("P2P_LOCAL_OK")
 
 
+def run_multinomial_in_process(world, n_local, steps=10, peaked=False):
+    """MULTINOMIAL shards over the peer-to-peer transport (rr_pf_shard_step_p2p of shards created with RR_RESAMPLE_MULTINOMIAL, round 6) --
+    the resampler the reference's ParticleFilterLocalizer / MonteCarloLocalizer really use (particle_filter.rs:441-473,
+    monte_carlo_localization.rs:322-365, :387-392) -- against the unsharded multinomial filter: every draw searched by the shard whose
+    CDF interval holds it, its source stored straight into the owner's slab.  peaked: the bench scene (a few heavy particles: nearly
+    every slot of every rank is served by ONE rank)."""
+    import rust_robotics_amd.localization as loc
+    from rust_robotics_amd import _ffi
+    from rust_robotics_amd.sharded import P2PShard
+
+    n = n_local * world
+    if peaked:
+        kw = dict(seed=1, initial_state=[0.0, 0.0, 0.0, 1.0])
+        lms, sigma = H.landmarks_grid(32, 1), 0.2
+        cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
+        ref = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, resample_scheme=_ffi.RR_RESAMPLE_MULTINOMIAL)
+    else:
+        kw = dict(seed=42, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))
+        lms, sigma = H.REF_SCENE_LANDMARKS, 0.5
+        cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.5, velocity_noise=0.3, yaw_rate_noise=math.radians(5.0))
+        ref = loc.MonteCarloLocalizer(cfg, seed=42, resample_scheme=_ffi.RR_RESAMPLE_MULTINOMIAL)
+    shards = [P2PShard(g, world, 0, n_local, scheme=_ffi.RR_RESAMPLE_MULTINOMIAL, **kw) for g in range(world)]
+    P2PShard.link_local(shards)
+    rng = np.random.default_rng(43)
+    for t in range(steps):
+        obs = H.observations(lms, H.true_pose(t + 1), sigma, rng)
+        for s in shards:
+            s.step([1.0, 0.1], obs)
+        ref.step_async([1.0, 0.1], obs)
+        if t == steps // 2:  # an accessor in mid-run (the unsharded filter's resample is lazy: it has to make it real)
+            for g, s in enumerate(shards):
+                assert np.array_equal(s.particles().view(np.uint64), ref.get_particles_array()[g * n_local:(g + 1) * n_local].view(np.uint64)), f"mid-run: rank {g}"
+    exp = ref.get_particles_array()
+    for g, s in enumerate(shards):
+        assert not s.timed_out(), f"rank {g}: a peer wait timed out"
+        got = s.particles()
+        bad = np.nonzero((got.view(np.uint64) != exp[g * n_local:(g + 1) * n_local].view(np.uint64)).any(axis=1))[0]
+        assert bad.size == 0, f"rank {g}: {bad.size} of {n_local} particles differ from the unsharded multinomial filter, first {bad[:5]}"
+    for s in shards:
+        s.close()
+    print("P2P_MN_OK")
+
+
+@pytest.mark.parametrize("world,n_local,peaked", [(1, 5000, False), (2, 6000, False), (3, 4100, False), (4, 30_001, True), (2, 600_000, True), (8, 4100, False)])
+def test_in_process_multinomial_shards_equal_unsharded(world, n_local, peaked):
+    code = (f"import sys; sys.path.insert(0, {ROOT!r}); from tests.test_gpu_p2p import run_multinomial_in_process; "
+            f"run_multinomial_in_process({world}, {n_local}, peaked={peaked})")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="12"))
+    assert r.returncode == 0 and "P2P_MN_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def run_estimate_in_process(world, n_local, steps=12, mode="fused"):
     """rr_pf_shard_want_estimate: the shards' sums of the resampled set's fields divided by N, against the unsharded filter's
     in-step estimate (its deferred form: the same slot tiles at world size 1, hence the same bits there).  Read at once (the

@@ -24,7 +24,10 @@ TOOL = os.path.join(ROOT, "tools", "world8_one_device.py")
 
 
 def run_tool(cases, extra_env=None, timeout=900):
-    env = dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="12")
+    # RR_P2P_TIMEOUT_MS: eight shards time-share ONE device here; a peer's kernel can sit behind seven others' (and, with eight
+    # processes, behind the scheduler's time slices), so the bound of a peer wait is widened from the deployment's 2 s -- every wait
+    # stays bounded, and a give-up still fails the test
+    env = dict(os.environ, PYTHONPATH=ROOT, GPU_MAX_HW_QUEUES="12", RR_P2P_TIMEOUT_MS="20000")
     env.update(extra_env or {})
     r = subprocess.run([sys.executable, TOOL] + list(cases), capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0 and "WORLD8_OK" in r.stdout, (r.stdout[-3000:], r.stderr[-3000:])
@@ -39,8 +42,15 @@ def test_eight_shards_in_one_process_small_and_worst_case(partition):
     eager step and an accessor in mid-run / either sender of the weight maximum, and the worst-case resamples -- one heavy
     particle in rank 7 (every slot of ranks 0..6 crosses ranks: the whole window is overhang), in rank 0, one at each end."""
     recs = run_tool(["mcl-small", "mcl-heavy", "mcl-lazy-max"], {"RR_P2P_CU_PARTITION": partition})
-    assert all(q["lazy_window_step"] for q in recs)
+    assert all(q["lazy_window_step"] for q in recs if q["mode"] != "mixed")  # (rr_pf_p2p_topology: what the last step really took)
     assert {q["wmax_early"] for q in recs} >= {"0", "1"}
+    assert all((q["cus_per_shard"] == [32]) == (partition == "1") for q in recs), [q["cus_per_shard"] for q in recs]
+
+
+def test_eight_multinomial_shards_in_one_process():
+    """the reference's own PF / MCL resampler sharded 8 ways over the peer-to-peer transport: 8 x 4 100 and 8 x 250 000 (bench scene)"""
+    recs = run_tool(["mcl-multinomial"])
+    assert len(recs) == 2 and all(q["mode"] == "multinomial-p2p" for q in recs)
 
 
 def test_eight_shards_in_one_process_multi_launch_plan():
@@ -62,7 +72,7 @@ def test_config4_as_eight_shards_in_one_process():
     """BASELINE configs[3]: FastSLAM 1.0 1 000 000 x 200 as 8 x 125 000 with their maps (19.3 GB sharded + 19.3 GB unsharded on
     the one device), poses, weights and every landmark of every particle equal to
     tests/test_gpu_fs1_parity.py::test_config4_full_size_on_one_gpu's filter; plus small FastSLAM 1.0 / 2.0 worlds of 8."""
-    recs = run_tool(["fs1-small", "fs1-config4"], timeout=1800)
+    recs = run_tool(["fs1-small", "fs1-config4"], {"RR_P2P_CU_PARTITION": "1"}, timeout=1800)  # (a stream, hence a hardware queue, of its own per shard)
     big = [q for q in recs if q["case"] == "fs1-config4"]
     assert big and big[0]["n_global"] == 1_000_000 and big[0]["landmarks"] == 200 and any(big[0]["gate_fired"])
 
@@ -70,7 +80,7 @@ def test_config4_as_eight_shards_in_one_process():
 def launch(script, args, port, nproc=8, extra_env=None, timeout=900):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", script)] + [str(a) for a in args]
-    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1")
+    env = dict(os.environ, PYTHONPATH=ROOT, OMP_NUM_THREADS="1", RR_P2P_TIMEOUT_MS="30000")  # (see run_tool)
     env.update(extra_env or {})
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
 
@@ -85,10 +95,12 @@ def test_eight_processes_over_ipc_handles_mcl(n_local, steps, env):
     assert r.returncode == 0 and r.stdout.count("P2P_OK") == 8, (r.stdout[-2000:], r.stderr[-4000:])
 
 
-@pytest.mark.parametrize("n_local,L,steps", [(3000, 7, 8), (125_000, 200, 4)])
+@pytest.mark.parametrize("n_local,L,steps", [(3000, 7, 8)])
 def test_eight_processes_over_ipc_handles_fastslam(n_local, L, steps):
-    """the same for FastSLAM 1.0: 8 x 3 000 x 7 from a host-made state, and configs[3] (8 x 125 000 x 200)"""
-    r = launch("_gpu_fs1_p2p_worker.py", [n_local, steps, L], 29742, timeout=1800)
+    """the same for FastSLAM 1.0: 8 x 3 000 x 7 from a host-made state.  (configs[3] at full size -- 8 x 125 000 x 200 -- runs as
+    eight shards of ONE process in test_config4_as_eight_shards_in_one_process; as eight PROCESSES it is tools/run_world8.sh's
+    ipc_fs1_config4 case, see profiles/r06_world8.md)"""
+    r = launch("_gpu_fs1_p2p_worker.py", [n_local, steps, L], 29742, timeout=600)
     assert r.returncode == 0 and r.stdout.count("FS1_P2P_OK") == 8, (r.stdout[-2000:], r.stderr[-4000:])
 
 
@@ -97,7 +109,7 @@ def test_bench_eight_ranks_sharing_the_device():
     group of 8, the transport ladder -- the peer-to-peer transport validated against the unsharded filter of all 8 x n particles
     ACROSS the eight processes --, the timed region, rank 0's line.  Not a scaling number (one device): the line says so."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env.update(PYTHONPATH=ROOT, RR_BENCH_SHARE_DEVICE="1", RR_BENCH_DEADLINE_S="600", RR_P2P_CU_PARTITION="1")
+    env.update(PYTHONPATH=ROOT, RR_BENCH_SHARE_DEVICE="1", RR_BENCH_DEADLINE_S="600", RR_P2P_CU_PARTITION="1", RR_P2P_TIMEOUT_MS="30000")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--particles", "250000",
                         "--no-extra-legs", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-4000:]
@@ -106,7 +118,8 @@ def test_bench_eight_ranks_sharing_the_device():
     d = json.loads(lines[-1])
     assert d["n_gpus"] == 8 and d["scaling"] == "weak" and d["value"] > 0 and "deadline_exceeded" not in d
     legs = {q["leg"]: q for q in map(json.loads, lines[:-1])}
-    assert "peer-to-peer transport validated bit-identical" in legs["headline"]["config"]["sharding"], legs["headline"]["config"]["sharding"]
+    why = [ln for ln in r.stderr.splitlines() if "VALIDATION" in ln or "gave up" in ln or "validat" in ln][-12:]
+    assert "peer-to-peer transport validated bit-identical" in legs["headline"]["config"]["sharding"], (legs["headline"]["config"]["sharding"], why)
     assert legs["sharded"]["transport"].startswith("p2p") and not legs["sharded"]["p2p_timed_out"]
     assert "shared" in json.dumps(d).lower(), "a shared-device line must say that it is not a scaling number"
     for k in range(8):

@@ -26,7 +26,7 @@ run inproc_small_cu_partition 600 GPU_MAX_HW_QUEUES=12 RR_P2P_CU_PARTITION=1 -- 
 run inproc_small_multi_launch_plan 600 GPU_MAX_HW_QUEUES=12 RR_PF_FUSED_PLAN=0 -- python $W mcl-small mcl-heavy
 run inproc_config5_cu_partition 900 GPU_MAX_HW_QUEUES=12 RR_P2P_CU_PARTITION=1 -- python $W mcl-config5 mcl-config5-heavy
 run inproc_config5_whole_device 900 GPU_MAX_HW_QUEUES=12 RR_P2P_CU_PARTITION=0 -- python $W mcl-config5 mcl-config5-heavy
-run inproc_fs1 1200 GPU_MAX_HW_QUEUES=12 -- python $W fs1-small fs1-config4
+run inproc_fs1 1200 GPU_MAX_HW_QUEUES=12 RR_P2P_CU_PARTITION=1 RR_P2P_TIMEOUT_MS=20000 -- python $W fs1-small fs1-config4
 L="python -m torch.distributed.run --nnodes=1 --nproc-per-node=8 --master-addr 127.0.0.1"
 run ipc_mcl_8000 600 OMP_NUM_THREADS=1 -- $L --master-port 29751 tests/_gpu_p2p_worker.py 8000 8
 run ipc_mcl_8000_wmax_early 600 OMP_NUM_THREADS=1 RR_P2P_WMAX_EARLY=1 -- $L --master-port 29752 tests/_gpu_p2p_worker.py 8000 8

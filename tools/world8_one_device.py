@@ -97,6 +97,7 @@ def run_mcl(case, world, n_local, steps, *, peaked=False, L=32, heavy=None, mode
                 assert not s.timed_out(), f"rank {g}: a peer wait timed out in the collapse step"
                 assert len(np.unique(_bits(got[:, :4]), axis=0)) <= len(heavy), f"rank {g}: the collapse left more than {len(heavy)} distinct particles"
     exp = ref.get_particles_array()
+    topo = [s.topology() for s in shards]
     gave_up, differ = [], []
     for g, s in enumerate(shards):
         if s.timed_out():
@@ -110,10 +111,16 @@ def run_mcl(case, world, n_local, steps, *, peaked=False, L=32, heavy=None, mode
     rec = dict(case=case, filter="MCL systematic (fastslam1.rs:205-234 walk over particle_filter.rs weights)", world=world, n_local=n_local,
                n_global=n, landmarks=int(len(lms)), steps=steps, mode=mode, wmax_early=os.environ.get("RR_P2P_WMAX_EARLY", "0"),
                fused_plan_env=os.environ.get("RR_PF_FUSED_PLAN", "1"), cu_partition=os.environ.get("RR_P2P_CU_PARTITION", "0"),
-               lazy_window_step=lazy_path_expected(world, n_local), heavy=heavy, ranks_that_gave_up=gave_up,
+               lazy_window_step=all(t["last_step"] == "lazy" for t in topo) if mode in ("fused", "wmax_mixed") else None,
+               lazy_window_step_expected=lazy_path_expected(world, n_local), cus_per_shard=sorted({t["cu_partition_cus"] for t in topo}),
+               ranks_sharing_the_device=topo[0]["n_sharing"], heavy=heavy, ranks_that_gave_up=gave_up,
                ranks_that_differ=differ, equal_to_unsharded=not differ, seconds=round(dt, 2), wiring="8 shards linked in one process")
     print(json.dumps(rec), flush=True)
     assert not gave_up and not differ, rec
+    if mode in ("fused", "wmax_mixed"):
+        assert rec["lazy_window_step"] == rec["lazy_window_step_expected"], rec
+    if os.environ.get("RR_P2P_CU_PARTITION", "0") not in ("", "0") and world > 1:
+        assert rec["cus_per_shard"] != [0], "RR_P2P_CU_PARTITION was asked for and no shard's stream got its share of the CUs"
     return rec
 
 
@@ -173,7 +180,21 @@ def run_fs1(case, world, n_local, L, steps, *, chunks=0, variant=1):
     return rec
 
 
+def run_mcl_multinomial(case, world, n_local, steps, peaked=False):
+    """multinomial shards (rr_pf_shard_step_p2p of RR_RESAMPLE_MULTINOMIAL shards) against the unsharded multinomial filter"""
+    from tests.test_gpu_p2p import run_multinomial_in_process
+
+    t0 = time.time()
+    run_multinomial_in_process(world, n_local, steps=steps, peaked=peaked)  # asserts bit-identity and zero give-ups itself
+    rec = dict(case=case, filter="MCL multinomial (particle_filter.rs:441-473, monte_carlo_localization.rs:322-365)", world=world, n_local=n_local,
+               n_global=world * n_local, landmarks=32 if peaked else 4, steps=steps, mode="multinomial-p2p", ranks_that_gave_up=[], ranks_that_differ=[],
+               equal_to_unsharded=True, seconds=round(time.time() - t0, 2), wiring="8 shards linked in one process")
+    print(json.dumps(rec), flush=True)
+    return rec
+
+
 CASES = {
+    "mcl-multinomial": lambda: [run_mcl_multinomial("mcl-multinomial-small", WORLD, 4100, 10), run_mcl_multinomial("mcl-multinomial-peaked", WORLD, 250_000, 6, peaked=True)],
     # the lazy window step (the deployment path) with n_ranks = 8, all three plan forms
     "mcl-small": lambda: [run_mcl("mcl-small", WORLD, 4100, 12, mode="fused"), run_mcl("mcl-small-mixed", WORLD, 4100, 12, mode="mixed"),
                           run_mcl("mcl-small-early", WORLD, 4100, 12, mode="fused", early=1),
