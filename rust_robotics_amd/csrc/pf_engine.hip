@@ -2592,13 +2592,12 @@ static rr_status shard_step_p2p_multinomial(rr_pf* h, const double control[2], c
   h->rstep += 1;
   {
     Timed t(h, RR_K_RESAMPLE_GATHER);
-    const uint64_t push_tiles = a.tiles_per_dest * (uint64_t)a.n_shards;
     const size_t lds = h->n_coarse * sizeof(uint64_t);
     if (!h->mn_push_lds_set) {  // (per handle: the attribute belongs to the handle's device)
       RR_HIP_TRY(hipFuncSetAttribute((const void*)k_mn_push_p2p, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       h->mn_push_lds_set = true;
     }
-    hipLaunchKernelGGL(k_mn_push_p2p, dim3((unsigned)std::min<uint64_t>(push_tiles, (uint64_t)h->mn_grid)), dim3(rr::kTileBlock), lds, h->stream,
+    hipLaunchKernelGGL(k_mn_push_p2p, dim3((unsigned)std::min<uint64_t>(grid_for(h->n_global, 1024), (uint64_t)h->mn_grid)), dim3(1024), lds, h->stream,
                        h->b, h->ctl, a, (const uint64_t*)h->cdf, h->n, (const uint64_t*)h->cdf_coarse, h->coarse_log2, h->n_coarse, h->p2p.peers);
   }
   // exchange 3: every rank has finished writing into everybody's slab

@@ -146,6 +146,24 @@ inline uint64_t plan_giveup_ticks() {
   return ticks;
 }
 
+// ---- RR_DEBUG_POISON_ALLOC=1: every device allocation of the engine is filled with 0xA5 before anybody uses it -------------------
+// hipMalloc does not promise zeroed memory, and in practice returns zeros on a fresh box and whatever an earlier PROCESS left on a
+// used one -- a read of something the engine never wrote passes every test on the former and fails somewhere, sometimes, on the
+// latter (round 6: the unsharded 2e6-particle reference filter of ONE of eight processes sharing a device came out different, and
+// only when other tests had run before).  With the switch on, the whole GPU suite runs against poisoned allocations
+// (tests/test_gpu_poison.py); a buffer the engine reads before it writes shows as a parity failure, deterministically.
+inline hipError_t dev_malloc_checked(void** p, size_t bytes) {
+  static const bool poison = [] { const char* e = std::getenv("RR_DEBUG_POISON_ALLOC"); return e && std::atoi(e) != 0; }();
+  hipError_t e = hipMalloc(p, bytes);
+  if (e == hipSuccess && poison && bytes) {
+    e = hipMemset(*p, 0xA5, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  return e;
+}
+template <class T>
+inline hipError_t dev_malloc_checked(T** p, size_t bytes) { return dev_malloc_checked(reinterpret_cast<void**>(p), bytes); }
+
 // ---- rr_pf_warm / rr_fs1_warm: bring the device (and the runtime) to the state the thousandth step finds --------------
 // An MI355X that has been idle runs its first ~50 ms of work at reduced clocks (measured, MCL 1e6 x 32: 52.6 us/step right after
 // create, 47.9 after 1000 steps; k_step_lazy 35.8 -> 31.2 us), and the HIP runtime pays one-off costs along its first few thousand
@@ -327,3 +345,6 @@ __device__ inline u128 wave_sum_u128(u128 v) {
 }
 
 }  // namespace rr
+
+// every hipMalloc of the engine's translation units (this header comes first in all of them) goes through the checked allocator
+#define hipMalloc(p, n) rr::dev_malloc_checked((p), (n))

@@ -752,8 +752,18 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
             whole.step_async(u, obs_list[t])
             if t == 0 and p2p is not None:  # a dead transport shows on the first exchange: stop before it costs more
                 alive = agree(not p2p.timed_out())
-        exp = np.ascontiguousarray(whole.get_particles_array()[rank * n_local:(rank + 1) * n_local]).view(np.uint64)
-        del whole
+        whole_all = np.ascontiguousarray(whole.get_particles_array())
+        exp = np.ascontiguousarray(whole_all[rank * n_local:(rank + 1) * n_local]).view(np.uint64)
+        # every rank ran the SAME unsharded filter: if their results differ from each other, the reference is at fault, not a transport
+        import hashlib
+
+        digests = [None] * world
+        dist.all_gather_object(digests, hashlib.blake2b(memoryview(whole_all).cast("B"), digest_size=12).hexdigest())
+        if len(set(digests)) > 1:
+            odd = [g for g in range(world) if digests[g] != max(set(digests), key=digests.count)]
+            notes.append(f"THE UNSHARDED REFERENCE FILTER DIFFERS BETWEEN RANKS (ranks {odd} against the majority): a validation failure on those ranks is the reference's")
+            log(notes[-1])
+        del whole, whole_all
 
         def check(name, shard, dead):
             if dead:
@@ -767,6 +777,13 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
                     cols = [int(np.count_nonzero(got[:, k] != exp[:, k])) for k in range(got.shape[1])]
                     why = (f"rank {rank}: {bad.size} of {n_local} particles differ; rows first {bad[:4].tolist()} last {bad[-4:].tolist()}, "
                            f"per column {cols}")
+                    try:  # is what was read stable?  (a second read after a full synchronisation: the same / now equal to the reference)
+                        shard.synchronize()
+                        again = np.ascontiguousarray(shard.particles()).view(np.uint64)
+                        why += f"; a second read {'repeats the first' if np.array_equal(again, got) else 'DIFFERS from the first'}" + \
+                               (" and now EQUALS the reference" if np.array_equal(again, exp) else "")
+                    except Exception as e:  # noqa: BLE001
+                        why += f"; second read failed: {e}"
                     log(f"VALIDATION MISMATCH ({name}): " + why)  # every rank says what it saw (stderr)
             ok = agree(same)
             notes.append(f"{name} validated bit-identical to the unsharded filter of all particles over {V} steps" if ok else

@@ -112,6 +112,12 @@ def test_bench_eight_ranks_sharing_the_device():
     env.update(PYTHONPATH=ROOT, RR_BENCH_SHARE_DEVICE="1", RR_BENCH_DEADLINE_S="600", RR_P2P_CU_PARTITION="1", RR_P2P_TIMEOUT_MS="30000")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--particles", "250000",
                         "--no-extra-legs", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    try:  # (the ranks' progress and, after a failed validation, what every rank saw: readable after the run)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "test_bench_eight_ranks.stderr.txt"), "w") as f:
+            f.write(r.stderr)
+    except OSError:
+        pass
     assert r.returncode == 0, r.stderr[-4000:]
     lines = r.stdout.splitlines()
     assert all(ln.startswith("{") for ln in lines) and len(lines[-1]) < 4096, r.stdout[:2000]
