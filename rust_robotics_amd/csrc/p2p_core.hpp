@@ -704,6 +704,7 @@ struct P2PState {
   rr_status publish_peers() {
     RR_HIP_TRY(hipMemcpy(peers_dev, &peers, sizeof(P2PPeers), hipMemcpyHostToDevice));
     RR_HIP_TRY(hipMemset(post_ticket, 0, kTicketWords * sizeof(unsigned int)));
+    RR_HIP_TRY(hipDeviceSynchronize());  // (a hipMemset may return before it has run, and the shard's stream does not wait for the null stream)
     return RR_OK;
   }
 

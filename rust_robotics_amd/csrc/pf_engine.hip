@@ -1037,7 +1037,7 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
                                h->n > kSmallMaxParticles;
   if (opt.resample_scheme == RR_RESAMPLE_MULTINOMIAL && !kld) {  // the fused step resamples lazily through lidx
     RR_TRY_OR_CLEAN(hipMalloc(&h->lidx, h->n * sizeof(unsigned int)));
-    RR_TRY_OR_CLEAN(hipMemset(h->lidx, 0xff, h->n * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(rr::memset_on(h->stream, h->lidx, 0xff, h->n * sizeof(unsigned int)));
     if (h->n == h->n_global && !std::getenv("RR_MN_NO_PACKED")) {
       for (int k = 0; k < 2; ++k) RR_TRY_OR_CLEAN(hipMalloc(&h->packed[k], 4 * h->n * sizeof(double)));
     }
@@ -1046,7 +1046,10 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
     // (+ one tile of padding in front of a shard's own block, peer-to-peer transport: rr::resolve_tile_window)
     const size_t nm = (size_t)std::max<uint64_t>(n_global, h->cap) + 3 * (size_t)rr::kResolveSlots;
     RR_TRY_OR_CLEAN(hipMalloc(&h->markers, nm * sizeof(unsigned int)));
-    RR_TRY_OR_CLEAN(hipMemset(h->markers, 0, nm * sizeof(unsigned int)));
+    // ON THE FILTER'S STREAM (rr::memset_on): a hipMemset goes to the null stream and returns before it has run, and this stream
+    // is a non-blocking one -- the first plan then marked into whatever an earlier tenant had left (round 6's "the unsharded
+    // reference filter differs between ranks"; with poisoned allocations: wild source indices, a memory fault)
+    RR_TRY_OR_CLEAN(rr::memset_on(h->stream, h->markers, 0, nm * sizeof(unsigned int)));
     RR_TRY_OR_CLEAN(hipMalloc(&h->carry, (nm / rr::kResolveSlots + 2) * sizeof(unsigned int)));
   }
   RR_TRY_OR_CLEAN(hipMalloc(&h->partials, (size_t)kMomentBlocks * kNumMoments * sizeof(double)));
@@ -2461,7 +2464,7 @@ static rr_status p2p_check_geometry(const rr_pf* h, int n_ranks, int rank) {
 static rr_status p2p_alloc_lidx(rr_pf* h) {
   if (h->lidx) return RR_OK;
   RR_HIP_TRY(hipMalloc(&h->lidx, h->n * sizeof(unsigned int)));
-  RR_HIP_TRY(hipMemset(h->lidx, 0xff, h->n * sizeof(unsigned int)));  // kInPlace everywhere
+  RR_HIP_TRY(rr::memset_on(h->stream, h->lidx, 0xff, h->n * sizeof(unsigned int)));  // kInPlace everywhere
   return RR_OK;
 }
 
@@ -2795,7 +2798,7 @@ rr_status rr_pf_debug_trace(rr_pf* h, uint32_t cap_steps) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
   RR_HIP_TRY(hipMalloc(&h->dbg_trace, (size_t)cap_steps * kDbgWords * sizeof(uint64_t)));
-  RR_HIP_TRY(hipMemset(h->dbg_trace, 0, (size_t)cap_steps * kDbgWords * sizeof(uint64_t)));
+  RR_HIP_TRY(rr::memset_on(h->stream, h->dbg_trace, 0, (size_t)cap_steps * kDbgWords * sizeof(uint64_t)));
   h->dbg_cap = cap_steps;
   return RR_OK;
 }

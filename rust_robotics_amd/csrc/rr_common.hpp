@@ -153,16 +153,34 @@ inline uint64_t plan_giveup_ticks() {
 // only when other tests had run before).  With the switch on, the whole GPU suite runs against poisoned allocations
 // (tests/test_gpu_poison.py); a buffer the engine reads before it writes shows as a parity failure, deterministically.
 inline hipError_t dev_malloc_checked(void** p, size_t bytes) {
-  static const bool poison = [] { const char* e = std::getenv("RR_DEBUG_POISON_ALLOC"); return e && std::atoi(e) != 0; }();
+  // 1: the byte 0xA5 (a huge integer, a denormal-sized negative double); any other value: that byte (0x3f: doubles of ~5e-4 and
+  // integers of ~1e9; 0xff: NaNs and all-ones markers; 0x01: small counters) -- what a stale tenant left looks like SOMETHING
+  static const int poison = [] { const char* e = std::getenv("RR_DEBUG_POISON_ALLOC"); return e ? (int)std::strtol(e, nullptr, 0) : 0; }();
   hipError_t e = hipMalloc(p, bytes);
   if (e == hipSuccess && poison && bytes) {
-    e = hipMemset(*p, 0xA5, bytes);
-    if (e == hipSuccess) e = hipDeviceSynchronize();
+    // on a stream of its own that waits for nobody: the null stream would wait for every blocking stream of the process -- among
+    // them a linked shard's step that waits, on the device, for the very shard this allocation belongs to (in-process worlds)
+    hipStream_t s = nullptr;
+    e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemsetAsync(*p, poison == 1 ? 0xA5 : (poison & 0xff), bytes, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (s) (void)hipStreamDestroy(s);
   }
   return e;
 }
 template <class T>
 inline hipError_t dev_malloc_checked(T** p, size_t bytes) { return dev_malloc_checked(reinterpret_cast<void**>(p), bytes); }
+
+// ---- fills that are DONE when the call returns ------------------------------------------------------------------------------------
+// hipMemset(device memory) is queued on the NULL stream and may return before it has run (CUDA's rule, and this runtime's: seen in
+// round 6 as a first resample plan that marked into an earlier tenant's bytes).  Every stream of the engine is a non-blocking one,
+// which the null stream does not order itself against -- so a plain hipMemset at create time is a race with the filter's first
+// kernels.  memset_on fills on the stream whose kernels will use the memory and waits for it: ordered for that stream by
+// construction, and finished for everybody else (a peer that maps the memory through hipIpc, another shard of the process).
+inline hipError_t memset_on(hipStream_t s, void* p, int value, size_t bytes) {
+  hipError_t e = hipMemsetAsync(p, value, bytes, s);
+  return e == hipSuccess ? hipStreamSynchronize(s) : e;
+}
 
 // ---- rr_pf_warm / rr_fs1_warm: bring the device (and the runtime) to the state the thousandth step finds --------------
 // An MI355X that has been idle runs its first ~50 ms of work at reduced clocks (measured, MCL 1e6 x 32: 52.6 us/step right after

@@ -647,6 +647,56 @@ class TorchShard:
         self.hs.close()
 
 
+def _diagnose_reference_split(rank, world, dist, digests, odd, whole, whole_all, cfg, scheme, lik, device, u, obs, log):
+    """The same unsharded filter, the same inputs, different particles on some ranks (round 6: eight processes on one device):
+    say what differs -- which rows, which counters -- and replay the filter step by step, alone, to see whether it repeats."""
+    import hashlib
+
+    import rust_robotics_amd.localization as loc
+
+    major = max(set(digests), key=digests.count)
+    src = digests.index(major)
+    path = f"/tmp/rr_reference_split_{os.environ.get('MASTER_PORT', '0')}.npy"
+    if rank == src:
+        np.save(path, whole_all)
+    dist.barrier()
+    try:
+        fs = whole.fixed_sums()
+        finger = dict(counters=list(whole.counters()), n_eff=whole.n_eff(), plan=list(whole.plan_stats()),
+                      sums={k: int(getattr(fs, k)) for k, _ in fs._fields_ if isinstance(getattr(fs, k), int)})
+    except Exception as e:  # noqa: BLE001
+        finger = dict(error=str(e))
+    what = dict(rank=rank, odd=rank in odd, finger=finger)
+    if rank in odd:
+        ref = np.load(path)
+        a, b = whole_all.view(np.uint64), ref.view(np.uint64)
+        bad = np.flatnonzero((a != b).any(axis=1))
+        what.update(differing=int(bad.size), of=int(a.shape[0]), first=int(bad[0]), last=int(bad[-1]),
+                    runs=int(np.flatnonzero(np.diff(bad) > 1).size + 1),
+                    per_column=[int(np.count_nonzero(a[:, k] != b[:, k])) for k in range(a.shape[1])],
+                    same_multiset_of_v=bool(np.array_equal(np.sort(whole_all[:, 3]), np.sort(ref[:, 3]))),
+                    max_abs=[float(np.nanmax(np.abs(whole_all[:, k] - ref[:, k]))) for k in range(a.shape[1])])
+    dist.barrier()
+    if rank == src:
+        os.unlink(path)
+    # the replay: alone (rank after rank would take long: all ranks at once, but synchronised after every step)
+    per_step = []
+    replay = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=device, resample_scheme=scheme, likelihood_mode=lik)
+    for t in range(len(obs)):
+        replay.step_async(u, obs[t])
+        per_step.append(hashlib.blake2b(memoryview(np.ascontiguousarray(replay.get_particles_array())).cast("B"), digest_size=6).hexdigest())
+    final = hashlib.blake2b(memoryview(np.ascontiguousarray(replay.get_particles_array())).cast("B"), digest_size=12).hexdigest()
+    what.update(replay_equals_majority=final == major, replay_equals_own_first_pass=final == digests[rank], replay_per_step=per_step)
+    del replay
+    everything = [None] * world
+    dist.all_gather_object(everything, what)
+    if rank == 0:
+        import json
+
+        for w in everything:
+            log("REFERENCE SPLIT " + json.dumps(w))
+
+
 def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, lik, transport="auto"):
     """bench.py's N > 1 leg: weak scaling, n_local particles per GPU, barrier + synchronize on
     both sides of the K timed steps, MAX over ranks.  torch.distributed (gloo) only bootstraps
@@ -763,6 +813,22 @@ def bench_sharded(rank, world, local_rank, n_local, L, K, W, obs_list, scheme, l
             odd = [g for g in range(world) if digests[g] != max(set(digests), key=digests.count)]
             notes.append(f"THE UNSHARDED REFERENCE FILTER DIFFERS BETWEEN RANKS (ranks {odd} against the majority): a validation failure on those ranks is the reference's")
             log(notes[-1])
+            _diagnose_reference_split(rank, world, dist, digests, odd, whole, whole_all, cfg, scheme, lik, local_rank, u, obs_list[:V], log)
+        reps = int(os.environ.get("RR_BENCH_VALIDATE_REPEAT", "0"))  # the hunt: the same unsharded filter again, on every rank at once
+        for rep in range(reps):
+            again = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=1, device=local_rank, resample_scheme=scheme, likelihood_mode=lik)
+            dist.barrier()
+            for t in range(V):
+                again.step_async(u, obs_list[t])
+            arr = np.ascontiguousarray(again.get_particles_array())
+            ds = [None] * world
+            dist.all_gather_object(ds, hashlib.blake2b(memoryview(arr).cast("B"), digest_size=12).hexdigest())
+            if rank == 0:
+                log(f"VALIDATE_REPEAT {rep}: " + ("all ranks equal" if len(set(ds)) == 1 else f"SPLIT {ds}") + f"; equal to the first pass's majority: {ds.count(max(set(digests), key=digests.count))} of {world}")
+            if len(set(ds)) > 1:
+                _diagnose_reference_split(rank, world, dist, ds, [g for g in range(world) if ds[g] != max(set(ds), key=ds.count)], again, arr, cfg, scheme, lik,
+                                          local_rank, u, obs_list[:V], log)
+            del again, arr
         del whole, whole_all
 
         def check(name, shard, dead):

@@ -81,6 +81,27 @@ def test_product_never_imports_the_oracle():
                 assert "ref_literal" not in text and "det_spec" not in text.replace("det_spec.c)", ""), f
 
 
+def test_no_plain_hipmemset_in_the_engine():
+    """hipMemset(device memory) returns before it has run (tools/ubench/memset_sync_probe.hip, profiles/r06o_*) and the engine's
+    streams are non-blocking ones: a plain hipMemset is a race with the next kernel.  Fills go through rr::memset_on / hipMemsetAsync
+    on the consumer's stream; the transport's set-up (p2p_core.hpp) may use hipMemset only with a hipDeviceSynchronize behind it."""
+    import re
+
+    csrc = os.path.join(ROOT, "rust_robotics_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".hpp", ".inc", ".h")):
+            continue
+        text = open(os.path.join(csrc, f)).read()
+        code = re.sub(r"//[^\n]*", "", text)
+        hits = [m.start() for m in re.finditer(r"\bhipMemset\(", code)]
+        if f in ("p2p_core.hpp", "selftest.hip"):  # every one of them is followed, in the same function, by a device-wide synchronisation
+            for at in hits:
+                end = code.find("\n  }\n", at)
+                assert "hipDeviceSynchronize()" in code[at:end if end > 0 else len(code)], (f, code[at:at + 80])
+        else:
+            assert not hits, (f, [code[at:at + 80] for at in hits])
+
+
 def test_mirror_exposes_reference_names():
     import rust_robotics_amd.localization as loc
 
