@@ -234,6 +234,7 @@ struct rr_pf {
   int shard_plan_shards = 0;   // as passed to rr_pf_shard_cdf
   int shard_select_shards = 0; // as passed to rr_pf_shard_select (0: not selected yet)
   unsigned int* mn_tile_cnt = nullptr;  // sharded multinomial: selected slots per (destination, tile), scanned in place
+  double* mn_records = nullptr;         // multinomial shards, peer-to-peer: the weighted particles as {x, y, yaw, v} records (k_mn_push_p2p's source)
   uint64_t mn_tiles = 0;
   rr::P2PState p2p;  // device-initiated exchange over xGMI (rr_pf_p2p_*)
   bool maybe_pending = false;    // a lazy resample plan was launched and nothing has consumed its markers yet
@@ -392,7 +393,7 @@ rr_status stage_obs(rr_pf* h, const double* obs, size_t n_obs, ObsArg* arg, bool
 }
 
 template <bool PREDICT, bool WEIGHT, bool EXPLICIT>
-rr_status launch_pw(rr_pf* h, const StepParams& p, const ObsArg& arg, bool kernarg) {
+rr_status launch_pw(rr_pf* h, const StepParams& p, const ObsArg& arg, bool kernarg, double* packed = nullptr) {
   // grid-stride kernel: at most k1_blocks_per_cu workgroups per CU (256 CUs)
   const unsigned grid = std::min<unsigned>(grid_for(h->adaptive ? h->cap : h->n, kBlock), (unsigned)(256 * h->k1_blocks_per_cu));
   const size_t lds = WEIGHT ? 3 * (size_t)p.n_obs * sizeof(double) : 0;
@@ -408,11 +409,11 @@ rr_status launch_pw(rr_pf* h, const StepParams& p, const ObsArg& arg, bool kerna
     Timed t(h, RR_K_PROPAGATE_WEIGHT);
     if (kernarg)
       hipLaunchKernelGGL((k_propagate_weight<PREDICT, WEIGHT, EXPLICIT, true>), dim3(grid), dim3(kBlock), lds,
-                         h->stream, h->b, h->w, h->ctl, p, arg, (const double*)nullptr, h->scratch_a, h->scratch_b);
+                         h->stream, h->b, h->w, h->ctl, p, arg, (const double*)nullptr, h->scratch_a, h->scratch_b, packed);
     else
       hipLaunchKernelGGL((k_propagate_weight<PREDICT, WEIGHT, EXPLICIT, false>), dim3(grid), dim3(kBlock), lds,
                          h->stream, h->b, h->w, h->ctl, p, arg, (const double*)h->obs_dev, h->scratch_a,
-                         h->scratch_b);
+                         h->scratch_b, packed);
   }
   RR_HIP_TRY(hipGetLastError());
   return RR_OK;
@@ -567,9 +568,9 @@ rr_status ensure_guide(rr_pf* h) {
 }
 
 // the multinomial draws -> source indices (and, unless lidx is given, the particles themselves)
-void launch_guide_resolve(rr_pf* h) {
+void launch_guide_resolve(rr_pf* h, int local = 0) {
   hipLaunchKernelGGL(rr::k_guide_resolve, dim3((unsigned)((((size_t)1 << h->guide_log2) + rr::kResolveSlots) / rr::kResolveSlots)),
-                     dim3(kBlock), 0, h->stream, h->ctl, h->guide_markers, h->guide_carry, h->guide, h->guide_log2);
+                     dim3(kBlock), 0, h->stream, h->ctl, h->guide_markers, h->guide_carry, h->guide, h->guide_log2, local);
 }
 void launch_guide_search(rr_pf* h, const double* r_explicit_dev, unsigned int* lidx, const GatherArgs& g) {
   hipLaunchKernelGGL(k_resample_guide_mn, dim3(grid_for(g.n_slots, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->ctl, h->cdf,
@@ -1571,6 +1572,7 @@ void rr_pf_destroy(rr_pf* h) {
   (void)hipFree(h->est_ring);
   if (h->mail) (void)hipHostFree(h->mail);
   (void)hipFree(h->mn_tile_cnt);
+  (void)hipFree(h->mn_records);
   (void)hipFree(h->est_ticket);
   (void)hipFree(h->rccl_inbox);
   (void)hipFree(h->grid_rec);
@@ -2565,7 +2567,11 @@ static rr_status shard_step_p2p_multinomial(rr_pf* h, const double control[2], c
   bool kernarg;
   if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
   StepParams p = make_params(h, control, (int)n_obs);
-  if ((s = launch_pw<true, true, false>(h, p, arg, kernarg)) != RR_OK) return s;
+  // (the propagated particles once more as 32-byte records: what k_mn_push_p2p gathers from -- one cache line per draw, not four)
+  if (!h->mn_records) RR_HIP_TRY(hipMalloc(&h->mn_records, 4 * h->cap * sizeof(double)));
+  if ((s = ensure_guide(h)) != RR_OK) return s;  // (first step only: allocates and waits once; RR_MN_GUIDE=0: the LDS coarse table instead)
+  const bool guided = h->guide_log2 > 0;
+  if ((s = launch_pw<true, true, false>(h, p, arg, kernarg, h->mn_records)) != RR_OK) return s;
   h->step += 1;
   PlanArgs pa = plan_args(h, 0, RR_RESAMPLE_MULTINOMIAL, NAN);
   // exchange 1: global maximum -> Ctl.wmax
@@ -2581,8 +2587,10 @@ static rr_status shard_step_p2p_multinomial(rr_pf* h, const double control[2], c
   {
     Timed t(h, RR_K_CDF);
     hipLaunchKernelGGL(rr::k_cdf, dim3((unsigned)h->n_tiles), dim3(rr::kTileBlock), 0, h->stream, h->w, h->ctl, image_args(h),
-                       h->tile_total, h->cdf, h->cdf_coarse, h->coarse_log2);  // (+ the coarse table the push kernel stages in LDS)
+                       h->tile_total, h->cdf, h->cdf_coarse, h->coarse_log2,  // (+ the coarse table the unguided push kernel stages in LDS)
+                       guided ? h->guide_markers : (unsigned int*)nullptr, h->guide_carry, h->guide_log2);
   }
+  if (guided) launch_guide_resolve(h, /*local=*/1);
   h->wmax_live = false;
   h->wmax_bits_clean = false;  // (a peer wait that gave up skips finalize_plan: do not rely on the zeroed accumulator)
   MnSelectArgs a{};
@@ -2596,12 +2604,18 @@ static rr_status shard_step_p2p_multinomial(rr_pf* h, const double control[2], c
   {
     Timed t(h, RR_K_RESAMPLE_GATHER);
     const size_t lds = h->n_coarse * sizeof(uint64_t);
+    if (guided) {
+      hipLaunchKernelGGL(k_mn_push_p2p_guided, dim3((unsigned)std::min<uint64_t>(grid_for(h->n_global, 256 * kMnPushRows), 256ull * 8)), dim3(256), 0, h->stream,
+                         (const double*)h->mn_records, h->ctl, a, (const uint64_t*)h->cdf, h->n, (const unsigned int*)h->guide, h->guide_log2, h->p2p.peers);
+    } else {
     if (!h->mn_push_lds_set) {  // (per handle: the attribute belongs to the handle's device)
       RR_HIP_TRY(hipFuncSetAttribute((const void*)k_mn_push_p2p, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
       h->mn_push_lds_set = true;
     }
     hipLaunchKernelGGL(k_mn_push_p2p, dim3((unsigned)std::min<uint64_t>(grid_for(h->n_global, 1024), (uint64_t)h->mn_grid)), dim3(1024), lds, h->stream,
-                       h->b, h->ctl, a, (const uint64_t*)h->cdf, h->n, (const uint64_t*)h->cdf_coarse, h->coarse_log2, h->n_coarse, h->p2p.peers);
+                       (const double*)h->mn_records, h->ctl, a, (const uint64_t*)h->cdf, h->n, (const uint64_t*)h->cdf_coarse, h->coarse_log2, h->n_coarse,
+                       h->p2p.peers);
+    }
   }
   // exchange 3: every rank has finished writing into everybody's slab
   hipLaunchKernelGGL(rr::k_p2p_exchange, dim3(1), dim3(64), 0, h->stream, h->p2p.peers, (int)rr::kP2PDone, seq,

@@ -480,7 +480,8 @@ __device__ inline void mark_guide(const TileScan& t, uint64_t off, uint64_t i0, 
 static __global__ __launch_bounds__(kTileBlock) void k_cdf(const double* __restrict__ w, const Ctl* __restrict__ ctl,
                                                       ImageArgs a, const uint64_t* __restrict__ tile_offset,
                                                       uint64_t* __restrict__ cdf, uint64_t* __restrict__ coarse,
-                                                      int coarse_log2) {
+                                                      int coarse_log2, unsigned int* __restrict__ guide_markers = nullptr,
+                                                      unsigned int* __restrict__ guide_carry = nullptr, int guide_log2 = 0) {
   if (!ctl->fired) return;
   a = image_args_now(a, ctl);
   __shared__ uint64_t s_w[kTileBlock / kWave];
@@ -488,6 +489,10 @@ static __global__ __launch_bounds__(kTileBlock) void k_cdf(const double* __restr
   const uint64_t off = ctl->base + tile_offset[blockIdx.x] + t.thread_off;
   const uint64_t i0 = (uint64_t)blockIdx.x * kTile + (uint64_t)threadIdx.x * kItems;
   store_cdf(t, off, i0, a.n, cdf, coarse, coarse_log2);
+  // a shard's guide table (multinomial shards over the peer-to-peer transport) buckets the shard's OWN interval of the target space:
+  // targets relative to Ctl.base, bucket width from Ctl.total_local -- the single-shard table of k_plan_cdf with base 0
+  if (guide_markers)
+    mark_guide(t, tile_offset[blockIdx.x] + t.thread_off, i0, a.n, guide_shift(ctl->total_local, guide_log2), guide_markers, guide_carry);
 }
 
 // K3+K4 fused (single shard, n_tiles <= kFusedMaxTiles): every workgroup re-derives its tile
@@ -1367,9 +1372,9 @@ __device__ inline void resolve_tile_window(unsigned int* __restrict__ markers, c
 // guide markers -> guide table (and the markers are cleared for the next step)
 static __global__ __launch_bounds__(kBlock) void k_guide_resolve(const Ctl* __restrict__ ctl, unsigned int* __restrict__ markers,
                                                             const unsigned int* __restrict__ carry,
-                                                            unsigned int* __restrict__ guide, int guide_log2) {
+                                                            unsigned int* __restrict__ guide, int guide_log2, int local = 0) {
   if (!ctl->fired) return;
-  const uint64_t total = ctl->total;
+  const uint64_t total = local ? ctl->total_local : ctl->total;  // local: a shard's table over its own interval (k_cdf)
   const uint64_t n_buckets = (total >> guide_shift(total, guide_log2)) + 1;
   if ((uint64_t)blockIdx.x * kResolveSlots >= n_buckets) return;
   unsigned int idx[kResolveRows];
