@@ -69,12 +69,21 @@ FS1_BYTES_PER_UPDATE = 96.0  # k_fs1_observe: read 48 B + write 48 B per (partic
 
 
 def library_sha16():
-    """first 16 hex digits of the SHA-256 of the engine library this process has loaded (what tools/collect_profiles.sh stamps into
-    the PMC summaries it writes)"""
+    """What identifies the build of the engine library this process has loaded (what tools/collect_profiles.sh stamps into the PMC
+    summaries it writes): the first 16 hex digits of the SHA-256 over the library's SOURCES, which the library itself reports
+    (rr_version: "... sources <hash>", csrc/Makefile) -- two builds of the same sources are not the same bytes, but they are the
+    same kernels.  A library that does not say (an older build loaded for an A/B): the hash of the file."""
     import hashlib
+    import re
 
     from rust_robotics_amd import _ffi
 
+    try:
+        m = re.search(r"sources ([0-9a-f]{16})\)", _ffi.lib().rr_version().decode())
+        if m:
+            return m.group(1)
+    except Exception:  # noqa: BLE001
+        pass
     try:
         with open(_ffi.LIB_PATH, "rb") as f:
             return hashlib.sha256(f.read()).hexdigest()[:16]
@@ -105,7 +114,7 @@ def measured_traffic(kernel_prefix, workload, est=None):
                 r = max(rows, key=lambda q: int(q["dispatches"]))
                 have = r.get("library_sha16")
                 if have and sha and have == sha:
-                    return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6, f"profiles/{name} [library sha256 {sha}: the loaded build]"
+                    return (float(r["read_MB_corrected_x2"]) + float(r["write_MB"])) * 1e6, f"profiles/{name} [library sources sha256 {sha}: the loaded build's]"
                 if stale is None:
                     mb = float(r["read_MB_corrected_x2"]) + float(r["write_MB"])
                     stale = (f"profiles/{name} holds {mb:.1f} MB per launch for this kernel, measured on " +

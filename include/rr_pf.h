@@ -43,7 +43,8 @@ typedef enum rr_status {
 
 /* message of the last failing call on this thread ("" if none) */
 const char* rr_last_error(void);
-/* library version string, e.g. "rust_robotics_amd 0.1.0 (gfx950)" */
+/* library version string, e.g. "rust_robotics_amd 0.1.0 (gfx950; sources 3547923a74322cb8)": the hash is the first 16 hex digits of the
+ * SHA-256 over the sources the library was built from (csrc/Makefile) */
 const char* rr_version(void);
 /* number of visible HIP devices (0 if none / runtime unusable) */
 int rr_device_count(void);

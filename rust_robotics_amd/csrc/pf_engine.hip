@@ -1438,7 +1438,10 @@ static rr_status step_small(rr_pf* h, const double* controls, const double* obs,
 extern "C" {
 
 const char* rr_last_error(void) { return rr::last_error_slot().c_str(); }
-const char* rr_version(void) { return "rust_robotics_amd 0.1.0 (gfx950)"; }
+#ifndef RR_SOURCE_SHA16
+#define RR_SOURCE_SHA16 "unknown"  // (csrc/Makefile passes the hash of the sources; a build by hand does not know it)
+#endif
+const char* rr_version(void) { return "rust_robotics_amd 0.1.0 (gfx950; sources " RR_SOURCE_SHA16 ")"; }
 int rr_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -44,9 +44,12 @@ done
 { cat "$OUT/hbm_mcl.csv"; for wl in fs1 fs2 mcl_1000000x32_multinomial mcl_16000000x64_systematic; do tail -n +2 "$OUT/hbm_$wl.csv"; done; } > "$OUT/pmc_hbm_traffic_nosha.csv"
 # every row carries the hash of the library it was measured on: bench.py's measured_traffic() reports the bytes only when that is the
 # library it has loaded (library_sha16 column = first 16 hex digits of the .so's SHA-256)
-python - "$OUT/pmc_hbm_traffic_nosha.csv" "${RR_AMD_LIBRARY:-$REPO/rust_robotics_amd/librust_robotics_amd.so}" > "$OUT/${TAG}_pmc_hbm_traffic.csv" <<'PY'
-import hashlib, sys
-sha = hashlib.sha256(open(sys.argv[2], "rb").read()).hexdigest()[:16]
+# (library_sha16 = the hash of the library's SOURCES as the library reports it, benchlib.common.library_sha16: builds are not
+# bit-reproducible, sources are)
+PYTHONPATH="$REPO" python - "$OUT/pmc_hbm_traffic_nosha.csv" > "$OUT/${TAG}_pmc_hbm_traffic.csv" <<'PY'
+import sys
+from benchlib.common import library_sha16
+sha = library_sha16()
 for i, ln in enumerate(open(sys.argv[1]).read().splitlines()):
     print(ln + ("," + ("library_sha16" if i == 0 else sha)))
 PY
