@@ -228,7 +228,7 @@ rr_status ensure_z_dev(rr_fs1* h, size_t n_z) {
   h->z_dev = nullptr;
   h->z_cap = 0;
   const size_t cap = std::max<size_t>(n_z, 64);
-  RR_HIP_TRY(hipMalloc(&h->z_dev, 3 * cap * sizeof(double)));
+  RR_HIP_TRY(rr::dev_malloc(&h->z_dev, 3 * cap * sizeof(double)));
   h->z_cap = cap;
   return RR_OK;
 }
@@ -434,7 +434,7 @@ rr_status launch_observe(rr_fs1* h, const double* z, size_t n_z, bool dup, bool 
       if (h->partial) RR_HIP_TRY(hipFree(h->partial));
       h->partial = nullptr;
       h->partial_chunks = 0;
-      RR_HIP_TRY(hipMalloc(&h->partial, (size_t)chunks * h->n * sizeof(double)));
+      RR_HIP_TRY(rr::dev_malloc(&h->partial, (size_t)chunks * h->n * sizeof(double)));
       h->partial_chunks = chunks;
       hipLaunchKernelGGL(k_fs1_no_factors, dim3(1024), dim3(kBlock), 0, h->stream, reinterpret_cast<uint64_t*>(h->partial),
                          (uint64_t)chunks * h->n);  // every slot reads "no factor yet" between updates
@@ -528,9 +528,9 @@ rr_status launch_plan_fused(rr_fs1* h, int settle) {
     }
     if (h->grid_capacity) {
       const size_t rec_bytes = rr::kPlanRecBytes;
-      RR_HIP_TRY(hipMalloc(&h->grid_rec, rec_bytes));
+      RR_HIP_TRY(rr::dev_malloc(&h->grid_rec, rec_bytes));
       RR_HIP_TRY(hipMemsetAsync(h->grid_rec, 0, rec_bytes, h->stream));
-      RR_HIP_TRY(hipMalloc(&h->grid_ticket, rr::kTicketWords * sizeof(unsigned int)));
+      RR_HIP_TRY(rr::dev_malloc(&h->grid_ticket, rr::kTicketWords * sizeof(unsigned int)));
       RR_HIP_TRY(hipMemsetAsync(h->grid_ticket, 0, rr::kTicketWords * sizeof(unsigned int), h->stream));
     }
   }
@@ -607,7 +607,7 @@ rr_status ensure_mailbox(rr_fs1* h) {
   if (h->best_mail) return RR_OK;
   RR_HIP_TRY(hipHostMalloc(&h->best_mail, sizeof(BestMail), hipHostMallocDefault));
   std::memset(h->best_mail, 0, sizeof(BestMail));
-  RR_HIP_TRY(hipMalloc(&h->best_ticket, sizeof(unsigned int)));
+  RR_HIP_TRY(rr::dev_malloc(&h->best_ticket, sizeof(unsigned int)));
   RR_HIP_TRY(hipMemsetAsync(h->best_ticket, 0, sizeof(unsigned int), h->stream));
   return RR_OK;
 }
@@ -637,12 +637,12 @@ rr_status synchronize_light(rr_fs1* h) {
 }
 
 rr_status ensure_pose_stage(rr_fs1* h) {
-  if (!h->pose_stage) RR_HIP_TRY(hipMalloc(&h->pose_stage, 4 * h->n * sizeof(double)));
+  if (!h->pose_stage) RR_HIP_TRY(rr::dev_malloc(&h->pose_stage, 4 * h->n * sizeof(double)));
   return RR_OK;
 }
 
 rr_status ensure_noise(rr_fs1* h) {
-  if (!h->noise) RR_HIP_TRY(hipMalloc(&h->noise, 3 * h->n * sizeof(double)));  // FastSLAM 2.0 draws three normals
+  if (!h->noise) RR_HIP_TRY(rr::dev_malloc(&h->noise, 3 * h->n * sizeof(double)));  // FastSLAM 2.0 draws three normals
   return RR_OK;
 }
 
@@ -715,21 +715,21 @@ rr_status rr_fs1_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs1
   } while (0)
   RR_TRY_OR_CLEAN(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   const size_t state_bytes = h->n_planes * h->n * sizeof(double);
-  RR_TRY_OR_CLEAN(hipMalloc(&h->slab, 2 * state_bytes));  // one slab: peers map the whole state with one IPC handle
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->slab, 2 * state_bytes));  // one slab: peers map the whole state with one IPC handle
   h->pl.s[0] = h->slab;
   h->pl.s[1] = h->slab + h->n_planes * h->n;
-  RR_TRY_OR_CLEAN(hipMalloc(&h->pw, h->n * sizeof(double)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->cdf, h->n * sizeof(uint64_t)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->tile_total, h->n_tiles * sizeof(uint64_t)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->tile_q2, 2 * h->n_tiles * sizeof(uint64_t)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->idx, h->n * sizeof(unsigned int)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->markers, (h->n + rr::kResolveSlots) * sizeof(unsigned int)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->pw, h->n * sizeof(double)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->cdf, h->n * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->tile_total, h->n_tiles * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->tile_q2, 2 * h->n_tiles * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->idx, h->n * sizeof(unsigned int)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->markers, (h->n + rr::kResolveSlots) * sizeof(unsigned int)));
   RR_TRY_OR_CLEAN(hipMemsetAsync(h->markers, 0, (h->n + rr::kResolveSlots) * sizeof(unsigned int), h->stream));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->carry, (h->n / rr::kResolveSlots + 2) * sizeof(unsigned int)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->part_bits, 1024 * sizeof(uint64_t)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->part_idx, 1024 * sizeof(uint64_t)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->plane_list, (h->n_planes + 1) * sizeof(unsigned int)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->ctl, sizeof(Ctl)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->carry, (h->n / rr::kResolveSlots + 2) * sizeof(unsigned int)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->part_bits, 1024 * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->part_idx, 1024 * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->plane_list, (h->n_planes + 1) * sizeof(unsigned int)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->ctl, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipHostMalloc(&h->ctl_host, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipMemsetAsync(h->ctl, 0, sizeof(Ctl), h->stream));
   hipLaunchKernelGGL(k_fs1_init, dim3(grid_for(h->n_planes * h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl, h->pw,
@@ -1264,7 +1264,7 @@ static rr_status fs1_check_geometry(const rr_fs1* h, int n_ranks, int rank) {
 
 static rr_status fs1_alloc_ridx(rr_fs1* h) {
   if (h->ridx) return RR_OK;
-  RR_HIP_TRY(hipMalloc(&h->ridx, h->n_global * sizeof(unsigned int)));  // worst case: every slot of every peer
+  RR_HIP_TRY(rr::dev_malloc(&h->ridx, h->n_global * sizeof(unsigned int)));  // worst case: every slot of every peer
   return RR_OK;
 }
 
@@ -1553,7 +1553,7 @@ rr_status rr_fs1_shard_unpack(rr_fs1* h, const int64_t* matrix, int32_t n_shards
   if (rt.start[n_shards] == 0) return RR_OK;
   if (!d_recv) return fail(RR_INVALID_PARAMETER, "null receive buffer");
   if (!h->pl.inbox) {  // no peer-to-peer connection: a plain device mirror of one buffer set serves as the inbox
-    RR_HIP_TRY(hipMalloc(&h->own_inbox, h->n_planes * h->n * sizeof(double)));
+    RR_HIP_TRY(rr::dev_malloc(&h->own_inbox, h->n_planes * h->n * sizeof(double)));
     h->pl.inbox = h->own_inbox;
   }
   rr::ScopedTimer t(h->prof, h->stream, RR_FK_GATHER);
@@ -1605,7 +1605,7 @@ rr_status rr_fs1_shard_update(rr_fs1* h, rr_comm* c, const double u[2], const do
     *buf = nullptr;
     *cap = 0;
     const size_t want = need + need / 4 + 4096;
-    RR_HIP_TRY(hipMalloc(buf, want * sizeof(double)));
+    RR_HIP_TRY(rr::dev_malloc(buf, want * sizeof(double)));
     *cap = want;
     return RR_OK;
   };

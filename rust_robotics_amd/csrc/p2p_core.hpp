@@ -689,12 +689,12 @@ struct P2PState {
     RR_HIP_TRY(hipMemset(inbox, 0, inbox_doubles * sizeof(double)));  // the engines' seal planes must not hold an earlier filter's seals
     RR_HIP_TRY(hipExtMallocWithFlags((void**)&mbox, sizeof(P2PMailbox), hipDeviceMallocFinegrained));
     RR_HIP_TRY(hipMemset(mbox, 0, sizeof(P2PMailbox)));
-    RR_HIP_TRY(hipMalloc(&scratch, (3 * kMaxP2P + 4) * sizeof(uint64_t)));
-    RR_HIP_TRY(hipMalloc(&err, 64));  // the flag + 7 words of detail a give-up leaves behind (kP2PErrWords)
+    RR_HIP_TRY(rr::dev_malloc(&scratch, (3 * kMaxP2P + 4) * sizeof(uint64_t)));
+    RR_HIP_TRY(rr::dev_malloc(&err, 64));  // the flag + 7 words of detail a give-up leaves behind (kP2PErrWords)
     RR_HIP_TRY(hipMemset(err, 0, 64));
     RR_HIP_TRY(hipHostMalloc(&err_host, 64));
-    RR_HIP_TRY(hipMalloc(&peers_dev, sizeof(P2PPeers)));
-    RR_HIP_TRY(hipMalloc(&post_ticket, kTicketWords * sizeof(unsigned int)));
+    RR_HIP_TRY(rr::dev_malloc(&peers_dev, sizeof(P2PPeers)));
+    RR_HIP_TRY(rr::dev_malloc(&post_ticket, kTicketWords * sizeof(unsigned int)));
     RR_HIP_TRY(hipMemset(post_ticket, 0, kTicketWords * sizeof(unsigned int)));
     RR_HIP_TRY(hipDeviceSynchronize());
     return RR_OK;

@@ -384,7 +384,7 @@ rr_status stage_obs(rr_pf* h, const double* obs, size_t n_obs, ObsArg* arg, bool
     if (h->obs_dev) RR_HIP_TRY(hipFree(h->obs_dev));
     h->obs_dev = nullptr;
     h->obs_cap = 0;
-    RR_HIP_TRY(hipMalloc(&h->obs_dev, 3 * n_obs * sizeof(double)));
+    RR_HIP_TRY(rr::dev_malloc(&h->obs_dev, 3 * n_obs * sizeof(double)));
     h->obs_cap = n_obs;
   }
   // pageable source: HIP stages it before returning, so the caller's buffer may be reused
@@ -546,9 +546,9 @@ rr_status ensure_guide(rr_pf* h) {
   const unsigned int one = 1;  // bucket 0 starts at source 0; no source ever writes carry[0]
   const auto make = [&]() -> hipError_t {
     hipError_t e;
-    if ((e = hipMalloc(&h->guide, nb * sizeof(unsigned int))) != hipSuccess) return e;
-    if ((e = hipMalloc(&h->guide_markers, nb * sizeof(unsigned int))) != hipSuccess) return e;
-    if ((e = hipMalloc(&h->guide_carry, nc * sizeof(unsigned int))) != hipSuccess) return e;
+    if ((e = rr::dev_malloc(&h->guide, nb * sizeof(unsigned int))) != hipSuccess) return e;
+    if ((e = rr::dev_malloc(&h->guide_markers, nb * sizeof(unsigned int))) != hipSuccess) return e;
+    if ((e = rr::dev_malloc(&h->guide_carry, nc * sizeof(unsigned int))) != hipSuccess) return e;
     if ((e = hipMemsetAsync(h->guide, 0, nb * sizeof(unsigned int), h->stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(h->guide_markers, 0, nb * sizeof(unsigned int), h->stream)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(h->guide_carry, 0, nc * sizeof(unsigned int), h->stream)) != hipSuccess) return e;
@@ -617,7 +617,7 @@ rr_status launch_resample(rr_pf* h, int mode, int scheme, double rho_override, c
     rr::EstArgs ea{};
     if (est_mode != rr::kEstOff && lazy && fused) {  // the mean the reference's try_step returns (rr::EstArgs: in the plan / deferred)
       if (est_mode == rr::kEstDeferred && !h->est_slot_partials)
-        RR_HIP_TRY(hipMalloc(&h->est_slot_partials, est_slot_bytes(h)));
+        RR_HIP_TRY(rr::dev_malloc(&h->est_slot_partials, est_slot_bytes(h)));
       for (int k = 0; k < 2; ++k) {
         ea.field[k][0] = h->b.x[k];
         ea.field[k][1] = h->b.y[k];
@@ -995,15 +995,15 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
   h->spin_gate_no = h->opt.device & 63;
   const size_t nb = h->cap * sizeof(double);
   // one slab [set][field][cap] so that peers can map the whole particle state with one IPC handle
-  RR_TRY_OR_CLEAN(hipMalloc(&h->slab, 8 * nb));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->slab, 8 * nb));
   for (int k = 0; k < 2; ++k) {
     h->b.x[k] = h->slab + (size_t)(4 * k + 0) * h->cap;
     h->b.y[k] = h->slab + (size_t)(4 * k + 1) * h->cap;
     h->b.yaw[k] = h->slab + (size_t)(4 * k + 2) * h->cap;
     h->b.v[k] = h->slab + (size_t)(4 * k + 3) * h->cap;
   }
-  RR_TRY_OR_CLEAN(hipMalloc(&h->w, nb));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->cdf, h->cap * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->w, nb));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->cdf, h->cap * sizeof(uint64_t)));
   if (const char* e = std::getenv("RR_MN_COARSE_LOG2")) h->coarse_log2 = std::max(4, std::min(16, std::atoi(e)));
   if (const char* e = std::getenv("RR_MN_BLOCK")) h->mn_block = std::max(64, std::min(1024, std::atoi(e) / 64 * 64));
   while (((h->cap + (1ull << h->coarse_log2) - 1) >> h->coarse_log2) > 18432) h->coarse_log2 += 1;  // <= 144 KB of LDS
@@ -1018,43 +1018,43 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
     // 1024 workgroups of 256 threads 51.1 us -- the search is bound by its random 8-byte requests, a finer table saves two of them
     if (!std::getenv("RR_MN_GRID")) h->mn_grid = 256 * (int)std::max<size_t>(1, std::min<size_t>(4, (144 * 1024) / std::max<size_t>(lds, 1)));
   }
-  RR_TRY_OR_CLEAN(hipMalloc(&h->cdf_coarse, (((h->cap + (1ull << h->coarse_log2) - 1) >> h->coarse_log2) + 1) * sizeof(uint64_t)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->tile_total, cap_tiles * sizeof(uint64_t)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->tile_q2, 2 * cap_tiles * sizeof(uint64_t)));
-  if (opt.record_indices) RR_TRY_OR_CLEAN(hipMalloc(&h->idx, h->cap * sizeof(unsigned int)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->cdf_coarse, (((h->cap + (1ull << h->coarse_log2) - 1) >> h->coarse_log2) + 1) * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->tile_total, cap_tiles * sizeof(uint64_t)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->tile_q2, 2 * cap_tiles * sizeof(uint64_t)));
+  if (opt.record_indices) RR_TRY_OR_CLEAN(rr::dev_malloc(&h->idx, h->cap * sizeof(unsigned int)));
   if (kld) {
     h->kld_hash_size = 2;
     while (h->kld_hash_size < 2 * h->cap) h->kld_hash_size *= 2;  // at most half full
-    RR_TRY_OR_CLEAN(hipMalloc(&h->kld_keys, 3 * h->cap * sizeof(int32_t)));
-    RR_TRY_OR_CLEAN(hipMalloc(&h->kld_table, h->kld_hash_size * sizeof(unsigned int)));
-    RR_TRY_OR_CLEAN(hipMalloc(&h->kld_minslot, h->kld_hash_size * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(rr::dev_malloc(&h->kld_keys, 3 * h->cap * sizeof(int32_t)));
+    RR_TRY_OR_CLEAN(rr::dev_malloc(&h->kld_table, h->kld_hash_size * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(rr::dev_malloc(&h->kld_minslot, h->kld_hash_size * sizeof(unsigned int)));
     RR_TRY_OR_CLEAN(hipMemsetAsync(h->kld_table, 0xff, h->kld_hash_size * sizeof(unsigned int), h->stream));  // (k_kld_count keeps them clean)
     RR_TRY_OR_CLEAN(hipMemsetAsync(h->kld_minslot, 0xff, h->kld_hash_size * sizeof(unsigned int), h->stream));
-    RR_TRY_OR_CLEAN(hipMalloc(&h->kld_myslot, h->cap * sizeof(unsigned int)));
-    RR_TRY_OR_CLEAN(hipMalloc(&h->kld_out, 2 * sizeof(uint64_t)));
+    RR_TRY_OR_CLEAN(rr::dev_malloc(&h->kld_myslot, h->cap * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(rr::dev_malloc(&h->kld_out, 2 * sizeof(uint64_t)));
     RR_TRY_OR_CLEAN(hipHostMalloc(&h->kld_out_host, 2 * sizeof(uint64_t)));
   }
   const bool guide_at_create = opt.resample_scheme == RR_RESAMPLE_MULTINOMIAL && !kld && h->n == h->n_global && cap_tiles <= (uint64_t)rr::kFusedMaxTiles &&
                                h->n > kSmallMaxParticles;
   if (opt.resample_scheme == RR_RESAMPLE_MULTINOMIAL && !kld) {  // the fused step resamples lazily through lidx
-    RR_TRY_OR_CLEAN(hipMalloc(&h->lidx, h->n * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(rr::dev_malloc(&h->lidx, h->n * sizeof(unsigned int)));
     RR_TRY_OR_CLEAN(rr::memset_on(h->stream, h->lidx, 0xff, h->n * sizeof(unsigned int)));
     if (h->n == h->n_global && !std::getenv("RR_MN_NO_PACKED")) {
-      for (int k = 0; k < 2; ++k) RR_TRY_OR_CLEAN(hipMalloc(&h->packed[k], 4 * h->n * sizeof(double)));
+      for (int k = 0; k < 2; ++k) RR_TRY_OR_CLEAN(rr::dev_malloc(&h->packed[k], 4 * h->n * sizeof(double)));
     }
   }
   {
     // (+ one tile of padding in front of a shard's own block, peer-to-peer transport: rr::resolve_tile_window)
     const size_t nm = (size_t)std::max<uint64_t>(n_global, h->cap) + 3 * (size_t)rr::kResolveSlots;
-    RR_TRY_OR_CLEAN(hipMalloc(&h->markers, nm * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(rr::dev_malloc(&h->markers, nm * sizeof(unsigned int)));
     // ON THE FILTER'S STREAM (rr::memset_on): a hipMemset goes to the null stream and returns before it has run, and this stream
     // is a non-blocking one -- the first plan then marked into whatever an earlier tenant had left (round 6's "the unsharded
     // reference filter differs between ranks"; with poisoned allocations: wild source indices, a memory fault)
     RR_TRY_OR_CLEAN(rr::memset_on(h->stream, h->markers, 0, nm * sizeof(unsigned int)));
-    RR_TRY_OR_CLEAN(hipMalloc(&h->carry, (nm / rr::kResolveSlots + 2) * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(rr::dev_malloc(&h->carry, (nm / rr::kResolveSlots + 2) * sizeof(unsigned int)));
   }
-  RR_TRY_OR_CLEAN(hipMalloc(&h->partials, (size_t)kMomentBlocks * kNumMoments * sizeof(double)));
-  RR_TRY_OR_CLEAN(hipMalloc(&h->est_partials, (size_t)rr::kFusedMaxTiles * 4 * sizeof(double)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->partials, (size_t)kMomentBlocks * kNumMoments * sizeof(double)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->est_partials, (size_t)rr::kFusedMaxTiles * 4 * sizeof(double)));
   {
     int per_cu = 0, dev_cus = 0;
     RR_TRY_OR_CLEAN(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rr::k_quantize_plan_mark<false>, rr::kTileBlock, 0));
@@ -1064,15 +1064,15 @@ rr_status create_common(const rr_pf_config* cfg_in, const rr_pf_options* opt_in,
       if (std::atoi(e) == 0) h->grid_capacity = 0;
     }
     const size_t rec_bytes = rr::kPlanRecBytes;  // records, heads, (instrumented build) stamps, the self-vouching pairs
-    RR_TRY_OR_CLEAN(hipMalloc(&h->grid_rec, rec_bytes));
+    RR_TRY_OR_CLEAN(rr::dev_malloc(&h->grid_rec, rec_bytes));
     RR_TRY_OR_CLEAN(hipMemsetAsync(h->grid_rec, 0, rec_bytes, h->stream));
-    RR_TRY_OR_CLEAN(hipMalloc(&h->grid_ticket, rr::kTicketWords * sizeof(unsigned int)));
+    RR_TRY_OR_CLEAN(rr::dev_malloc(&h->grid_ticket, rr::kTicketWords * sizeof(unsigned int)));
     RR_TRY_OR_CLEAN(hipMemsetAsync(h->grid_ticket, 0, rr::kTicketWords * sizeof(unsigned int), h->stream));
   }
-  RR_TRY_OR_CLEAN(hipMalloc(&h->est_ticket, rr::kTicketWords * sizeof(unsigned int)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->est_ticket, rr::kTicketWords * sizeof(unsigned int)));
   RR_TRY_OR_CLEAN(hipMemsetAsync(h->est_ticket, 0, rr::kTicketWords * sizeof(unsigned int), h->stream));
   h->slot_pad = (rr::kResolveSlots - h->opt.first_global_index % rr::kResolveSlots) % rr::kResolveSlots;
-  RR_TRY_OR_CLEAN(hipMalloc(&h->ctl, sizeof(Ctl)));
+  RR_TRY_OR_CLEAN(rr::dev_malloc(&h->ctl, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipHostMalloc(&h->ctl_host, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipMemsetAsync(h->ctl, 0, sizeof(Ctl), h->stream));
   hipLaunchKernelGGL(k_init, dim3(grid_for(h->n, kBlock)), dim3(kBlock), 0, h->stream, h->b, h->w, h->n, h->n_global,
@@ -1105,9 +1105,9 @@ rr_status ensure_scratch(rr_pf* h, size_t doubles_a, size_t doubles_b) {
   static_assert(sizeof(double) == 8, "");
   if (doubles_a) {
     size_t want = std::max<size_t>(doubles_a, 5 * h->cap);
-    if (!h->scratch_a) RR_HIP_TRY(hipMalloc(&h->scratch_a, want * sizeof(double)));
+    if (!h->scratch_a) RR_HIP_TRY(rr::dev_malloc(&h->scratch_a, want * sizeof(double)));
   }
-  if (doubles_b && !h->scratch_b) RR_HIP_TRY(hipMalloc(&h->scratch_b, h->cap * sizeof(double)));
+  if (doubles_b && !h->scratch_b) RR_HIP_TRY(rr::dev_malloc(&h->scratch_b, h->cap * sizeof(double)));
   return RR_OK;
 }
 
@@ -1415,7 +1415,7 @@ static rr_status step_small(rr_pf* h, const double* controls, const double* obs,
       if (h->steps_dev) RR_HIP_TRY(hipFree(h->steps_dev));
       h->steps_dev = nullptr;
       h->steps_cap = 0;
-      RR_HIP_TRY(hipMalloc(&h->steps_dev, (K * per + K * per / 2) * sizeof(double)));
+      RR_HIP_TRY(rr::dev_malloc(&h->steps_dev, (K * per + K * per / 2) * sizeof(double)));
       h->steps_cap = K * per + K * per / 2;
     }
     // pageable source: HIP stages it before returning, so steps_host may be reused by the next call
@@ -1871,7 +1871,7 @@ rr_status rr_pf_step_async_estimate(rr_pf* h, const double control[2], const dou
 // The slot tiles' sums of the deferred estimate, added up ON THE DEVICE by k_est_slots_total (the three-level order of k_est_mail_any:
 // the same bits as the synchronous step's mailbox kernel): the host fetches four doubles, and the stamp behind the sums if asked.
 static rr_status est_slots_total(rr_pf* h, uint64_t n_part, double acc[4], uint64_t* stamp) {
-  if (!h->est_total_dev) RR_HIP_TRY(hipMalloc(&h->est_total_dev, 4 * sizeof(double)));
+  if (!h->est_total_dev) RR_HIP_TRY(rr::dev_malloc(&h->est_total_dev, 4 * sizeof(double)));
   hipLaunchKernelGGL(k_est_slots_total, dim3(1), dim3(kEstChunks), 0, h->stream, (const double*)h->est_slot_partials, n_part, h->est_total_dev);
   hipError_t copies = hipGetLastError();
   if (copies == hipSuccess) copies = hipMemcpyAsync(acc, h->est_total_dev, 4 * sizeof(double), hipMemcpyDeviceToHost, h->stream);
@@ -1963,7 +1963,7 @@ rr_status rr_pf_step_many(rr_pf* h, const double* controls, const double* obs, s
         if (h->est_ring) RR_HIP_TRY(hipFree(h->est_ring));
         h->est_ring = nullptr;
         h->est_ring_cap = 0;
-        RR_HIP_TRY(hipMalloc(&h->est_ring, 4 * n_steps * sizeof(double)));
+        RR_HIP_TRY(rr::dev_malloc(&h->est_ring, 4 * n_steps * sizeof(double)));
         h->est_ring_cap = 4 * n_steps;
       }
       ring = h->est_ring;
@@ -2384,7 +2384,7 @@ rr_status rr_pf_shard_select(rr_pf* h, int32_t n_shards, uint64_t* d_counts_out)
     if (h->mn_tile_cnt) RR_HIP_TRY(hipFree(h->mn_tile_cnt));
     h->mn_tile_cnt = nullptr;
     h->mn_tiles = 0;
-    RR_HIP_TRY(hipMalloc(&h->mn_tile_cnt, n_tiles * sizeof(unsigned int)));
+    RR_HIP_TRY(rr::dev_malloc(&h->mn_tile_cnt, n_tiles * sizeof(unsigned int)));
     h->mn_tiles = n_tiles;
   }
   Timed t(h, RR_K_RESAMPLE_GATHER);
@@ -2468,7 +2468,7 @@ static rr_status p2p_check_geometry(const rr_pf* h, int n_ranks, int rank) {
 
 static rr_status p2p_alloc_lidx(rr_pf* h) {
   if (h->lidx) return RR_OK;
-  RR_HIP_TRY(hipMalloc(&h->lidx, h->n * sizeof(unsigned int)));
+  RR_HIP_TRY(rr::dev_malloc(&h->lidx, h->n * sizeof(unsigned int)));
   RR_HIP_TRY(rr::memset_on(h->stream, h->lidx, 0xff, h->n * sizeof(unsigned int)));  // kInPlace everywhere
   return RR_OK;
 }
@@ -2554,12 +2554,14 @@ rr_status rr_pf_shard_step_p2p_unfused(rr_pf* h, const double control[2], const 
 // MULTINOMIAL shards over the peer-to-peer transport (round 6): the resampler the reference's ParticleFilterLocalizer and
 // MonteCarloLocalizer really use (particle_filter.rs:441-473, monte_carlo_localization.rs:322-365, :387-392), sharded without a
 // collective library and without the host in the step.  iid draws scatter the slots a shard serves over all ranks, so there is
-// no window and nothing lazy: propagate + weight | WMAX exchange | integer image | tile scan + SUMS exchange (gate, base, totals)
-// | local slice of the global CDF | k_mn_push_p2p: every draw that falls into this shard's CDF interval is searched here and its
-// source stored straight into the owning rank's slab | DONE exchange.  Every shard evaluates all N draws (a Philox block and a
+// no window and nothing lazy: propagate + weight (the propagated particles also as 32-byte records) | WMAX exchange | integer image |
+// tile scan + SUMS exchange (gate, base, totals) | local slice of the global CDF + the markers of the shard's guide table |
+// k_guide_resolve(local) | k_mn_push_p2p_guided: every draw that falls into this shard's CDF interval is searched here (guide pair,
+// one or two CDF probes) and its source record stored straight into the owning rank's slab | DONE exchange.  Every shard evaluates all N draws (a Philox block and a
 // comparison each), searches N / G of them on average and moves as many particles -- nearly all of them across ranks: that is
-// what iid draws cost on any transport.  The RCCL form of the same step (rr_pf_shard_step: count, scan, pack, all-to-all, adopt,
-// two host round trips) measured 0.30 ms per step at world size 1.
+// what iid draws cost on any transport.  World size 1, 1e6 x 32: 0.097 ms per step (first form, binary search over the whole CDF and
+// four planes per gathered source: 0.21); the RCCL form of the same step (rr_pf_shard_step: count, scan, pack, all-to-all, adopt,
+// two host round trips): 0.30.
 static rr_status shard_step_p2p_multinomial(rr_pf* h, const double control[2], const double* obs, size_t n_obs) {
   rr_status s;
   if ((s = validate_control(control)) != RR_OK) return s;
@@ -2571,7 +2573,7 @@ static rr_status shard_step_p2p_multinomial(rr_pf* h, const double control[2], c
   if ((s = stage_obs(h, obs, n_obs, &arg, &kernarg)) != RR_OK) return s;
   StepParams p = make_params(h, control, (int)n_obs);
   // (the propagated particles once more as 32-byte records: what k_mn_push_p2p gathers from -- one cache line per draw, not four)
-  if (!h->mn_records) RR_HIP_TRY(hipMalloc(&h->mn_records, 4 * h->cap * sizeof(double)));
+  if (!h->mn_records) RR_HIP_TRY(rr::dev_malloc(&h->mn_records, 4 * h->cap * sizeof(double)));
   if ((s = ensure_guide(h)) != RR_OK) return s;  // (first step only: allocates and waits once; RR_MN_GUIDE=0: the LDS coarse table instead)
   const bool guided = h->guide_log2 > 0;
   if ((s = launch_pw<true, true, false>(h, p, arg, kernarg, h->mn_records)) != RR_OK) return s;
@@ -2610,14 +2612,14 @@ static rr_status shard_step_p2p_multinomial(rr_pf* h, const double control[2], c
     if (guided) {
       hipLaunchKernelGGL(k_mn_push_p2p_guided, dim3((unsigned)std::min<uint64_t>(grid_for(h->n_global, 256 * kMnPushRows), 256ull * 8)), dim3(256), 0, h->stream,
                          (const double*)h->mn_records, h->ctl, a, (const uint64_t*)h->cdf, h->n, (const unsigned int*)h->guide, h->guide_log2, h->p2p.peers);
-    } else {
-    if (!h->mn_push_lds_set) {  // (per handle: the attribute belongs to the handle's device)
-      RR_HIP_TRY(hipFuncSetAttribute((const void*)k_mn_push_p2p, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      h->mn_push_lds_set = true;
-    }
-    hipLaunchKernelGGL(k_mn_push_p2p, dim3((unsigned)std::min<uint64_t>(grid_for(h->n_global, 1024), (uint64_t)h->mn_grid)), dim3(1024), lds, h->stream,
-                       (const double*)h->mn_records, h->ctl, a, (const uint64_t*)h->cdf, h->n, (const uint64_t*)h->cdf_coarse, h->coarse_log2, h->n_coarse,
-                       h->p2p.peers);
+    } else {  // RR_MN_GUIDE=0: the coarse table of the CDF staged in LDS, one 1024-thread workgroup per CU
+      if (!h->mn_push_lds_set) {  // (per handle: the attribute belongs to the handle's device)
+        RR_HIP_TRY(hipFuncSetAttribute((const void*)k_mn_push_p2p, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        h->mn_push_lds_set = true;
+      }
+      hipLaunchKernelGGL(k_mn_push_p2p, dim3((unsigned)std::min<uint64_t>(grid_for(h->n_global, 1024), (uint64_t)h->mn_grid)), dim3(1024), lds, h->stream,
+                         (const double*)h->mn_records, h->ctl, a, (const uint64_t*)h->cdf, h->n, (const uint64_t*)h->cdf_coarse, h->coarse_log2,
+                         h->n_coarse, h->p2p.peers);
     }
   }
   // exchange 3: every rank has finished writing into everybody's slab
@@ -2781,7 +2783,7 @@ rr_status rr_pf_shard_want_estimate(rr_pf* h, int32_t want) {
   if (want && h->opt.resample_scheme != RR_RESAMPLE_SYSTEMATIC)
     return fail(RR_INVALID_PARAMETER, "the sharded estimate serves the systematic scheme (the window steps: rr_pf_shard_step_p2p, rr_pf_shard_step)");
   if (want && !h->est_slot_partials) {
-    RR_HIP_TRY(hipMalloc(&h->est_slot_partials, est_slot_bytes(h)));
+    RR_HIP_TRY(rr::dev_malloc(&h->est_slot_partials, est_slot_bytes(h)));
     RR_HIP_TRY(hipMemsetAsync(est_stamp_slot(h), 0, sizeof(uint64_t), h->stream));  // (no step's sums yet: stamps start at 1)
   }
   h->shard_est = want != 0;  // (want == 0: later steps leave no sums; the last step's stay readable, also after one more step)
@@ -2814,7 +2816,7 @@ rr_status rr_pf_shard_last_estimate_sums(rr_pf* h, double out_sums[4], double* o
 rr_status rr_pf_debug_trace(rr_pf* h, uint32_t cap_steps) {
   rr_status s = bind(h);
   if (s != RR_OK) return s;
-  RR_HIP_TRY(hipMalloc(&h->dbg_trace, (size_t)cap_steps * kDbgWords * sizeof(uint64_t)));
+  RR_HIP_TRY(rr::dev_malloc(&h->dbg_trace, (size_t)cap_steps * kDbgWords * sizeof(uint64_t)));
   RR_HIP_TRY(rr::memset_on(h->stream, h->dbg_trace, 0, (size_t)cap_steps * kDbgWords * sizeof(uint64_t)));
   h->dbg_cap = cap_steps;
   return RR_OK;

@@ -152,7 +152,7 @@ inline uint64_t plan_giveup_ticks() {
 // latter (round 6: the unsharded 2e6-particle reference filter of ONE of eight processes sharing a device came out different, and
 // only when other tests had run before).  With the switch on, the whole GPU suite runs against poisoned allocations
 // (tests/test_gpu_poison.py); a buffer the engine reads before it writes shows as a parity failure, deterministically.
-inline hipError_t dev_malloc_checked(void** p, size_t bytes) {
+inline hipError_t dev_malloc(void** p, size_t bytes) {
   // 1: the byte 0xA5 (a huge integer, a denormal-sized negative double); any other value: that byte (0x3f: doubles of ~5e-4 and
   // integers of ~1e9; 0xff: NaNs and all-ones markers; 0x01: small counters) -- what a stale tenant left looks like SOMETHING
   static const int poison = [] { const char* e = std::getenv("RR_DEBUG_POISON_ALLOC"); return e ? (int)std::strtol(e, nullptr, 0) : 0; }();
@@ -169,7 +169,7 @@ inline hipError_t dev_malloc_checked(void** p, size_t bytes) {
   return e;
 }
 template <class T>
-inline hipError_t dev_malloc_checked(T** p, size_t bytes) { return dev_malloc_checked(reinterpret_cast<void**>(p), bytes); }
+inline hipError_t dev_malloc(T** p, size_t bytes) { return dev_malloc(reinterpret_cast<void**>(p), bytes); }
 
 // ---- fills that are DONE when the call returns ------------------------------------------------------------------------------------
 // hipMemset(device memory) is queued on the NULL stream and may return before it has run (CUDA's rule, and this runtime's: seen in
@@ -364,5 +364,3 @@ __device__ inline u128 wave_sum_u128(u128 v) {
 
 }  // namespace rr
 
-// every hipMalloc of the engine's translation units (this header comes first in all of them) goes through the checked allocator
-#define hipMalloc(p, n) rr::dev_malloc_checked((p), (n))

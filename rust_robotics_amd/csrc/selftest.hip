@@ -43,10 +43,10 @@ extern "C" rr_status rr_selftest_math(int32_t device, int32_t fn, size_t n, cons
   RR_HIP_TRY(hipSetDevice(device));
   double *da = nullptr, *db = nullptr, *d0 = nullptr, *d1 = nullptr;
   const size_t nb = n * sizeof(double);
-  RR_HIP_TRY(hipMalloc(&da, nb));
-  RR_HIP_TRY(hipMalloc(&db, nb));
-  RR_HIP_TRY(hipMalloc(&d0, nb));
-  RR_HIP_TRY(hipMalloc(&d1, nb));
+  RR_HIP_TRY(rr::dev_malloc(&da, nb));
+  RR_HIP_TRY(rr::dev_malloc(&db, nb));
+  RR_HIP_TRY(rr::dev_malloc(&d0, nb));
+  RR_HIP_TRY(rr::dev_malloc(&d1, nb));
   RR_HIP_TRY(hipMemcpy(da, a, nb, hipMemcpyHostToDevice));
   if (b) RR_HIP_TRY(hipMemcpy(db, b, nb, hipMemcpyHostToDevice));
   else RR_HIP_TRY(hipMemset(db, 0, nb));

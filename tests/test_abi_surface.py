@@ -100,6 +100,10 @@ def test_no_plain_hipmemset_in_the_engine():
                 assert "hipDeviceSynchronize()" in code[at:end if end > 0 else len(code)], (f, code[at:at + 80])
         else:
             assert not hits, (f, [code[at:at + 80] for at in hits])
+        # ... and device memory comes from rr::dev_malloc (rr_common.hpp), which is what RR_DEBUG_POISON_ALLOC poisons: an allocation
+        # made with a bare hipMalloc would escape tests/test_gpu_poison.py
+        bare = [m.start() for m in re.finditer(r"(?<![\w:])hipMalloc\(", code)]
+        assert not bare or f == "rr_common.hpp", (f, [code[at:at + 80] for at in bare])
 
 
 def test_mirror_exposes_reference_names():

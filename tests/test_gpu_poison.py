@@ -2,7 +2,7 @@
 A read of something the engine never wrote therefore passes every test on the former and fails somewhere, sometimes, on the latter
 (round 6: the unsharded 2 000 000-particle reference filter of ONE of eight processes sharing a device came out different -- and only
 when other tests had run on the box before).  RR_DEBUG_POISON_ALLOC=1 fills every device allocation of the engine with 0xA5 before
-anybody uses it (rr_common.hpp, dev_malloc_checked); the parity suites then run again, in a fresh interpreter, against poisoned
+anybody uses it (rr_common.hpp, rr::dev_malloc -- the engine allocates through nothing else); the parity suites then run again, in a fresh interpreter, against poisoned
 allocations: a buffer that is read before it is written shows as a parity failure, deterministically.
 
 What the hunt found (round 6): the markers of the lazy systematic resample were cleared at create time with a plain hipMemset --
