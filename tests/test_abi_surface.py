@@ -81,6 +81,28 @@ def test_product_never_imports_the_oracle():
                 assert "ref_literal" not in text and "det_spec" not in text.replace("det_spec.c)", ""), f
 
 
+def test_library_reports_the_hash_of_its_sources(ffi):
+    """rr_version carries the first 16 hex digits of the SHA-256 over the sources the library was built from (csrc/Makefile: cat SRCS
+    HDRS | sha256sum) -- what ties a PMC summary under profiles/ to a build (benchlib.common.library_sha16 / measured_traffic): two
+    builds of the same sources are different bytes, the same kernels.  A library older than its sources fails here: run make."""
+    import hashlib
+    import re
+
+    from benchlib.common import library_sha16
+
+    csrc = os.path.join(ROOT, "rust_robotics_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    files = re.search(r"^SRCS\s*:=\s*(.*)$", mk, flags=re.M).group(1).split() + re.search(r"^HDRS\s*:=\s*(.*)$", mk, flags=re.M).group(1).split()
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    version = ffi.lib().rr_version().decode()
+    m = re.search(r"sources ([0-9a-f]{16})\)", version)
+    assert m, version
+    assert m.group(1) == h.hexdigest()[:16], "librust_robotics_amd.so is older than its sources: make -C rust_robotics_amd/csrc"
+    assert library_sha16() == m.group(1)
+
+
 def test_no_plain_hipmemset_in_the_engine():
     """hipMemset(device memory) returns before it has run (tools/ubench/memset_sync_probe.hip, profiles/r06o_*) and the engine's
     streams are non-blocking ones: a plain hipMemset is a race with the next kernel.  Fills go through rr::memset_on / hipMemsetAsync
