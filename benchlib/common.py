@@ -30,7 +30,9 @@ K1_BYTES = {"systematic": 72.0, "multinomial": 64.0}
 
 # sharded legs: a process that has torch's HIP context loaded stalls once on the host (~40 ms) somewhere in its first few
 # hundred launches; this many extra untimed steps keep that out of the timed region
-EXTRA_WARMUP = 1000
+# (RR_BENCH_EXTRA_WARMUP: the shared-device rig of tests/test_gpu_world8.py, where a step of eight processes time-slicing one GPU
+# takes tens of milliseconds and nothing about the rate is being measured, asks for fewer)
+EXTRA_WARMUP = max(0, int(os.environ.get("RR_BENCH_EXTRA_WARMUP", "1000")))
 
 
 # ---- one JSON line on stdout, whatever the native libraries print; progress on stderr; a deadline

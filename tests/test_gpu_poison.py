@@ -28,7 +28,7 @@ SUITES = ["tests/test_gpu_pf_parity.py", "tests/test_gpu_fs1_parity.py", "tests/
 
 # the sharded worlds (linked shards of one process, processes over hipIpc): the poison is written on a stream of its own, so a linked
 # shard that waits on the device for the shard being created does not stand in its way
-SHARDED = ["tests/test_gpu_p2p.py", "tests/test_gpu_fs1_sharded.py", "tests/test_gpu_sharded.py"]
+SHARDED = ["tests/test_gpu_p2p.py", "tests/test_gpu_fs1_sharded.py", "-k", "in_process"]  # (all three files, every test: tools/gpu_call_r06i.sh, 4 patterns)
 
 
 @pytest.mark.parametrize("part", [0, 1, 2])
