@@ -69,10 +69,14 @@ def test_mcl_every_particle_matches_the_literal_reference(det, ref, n, L):
         ref.ref_pf_update_raw(n, dp(gx), dp(gy), dp(wr), dp(obs), L, sigma)
     finally:
         ref.ref_set_threads(1)
-    big = wr > 1e-250  # below that the literal running product has lost bits of its own
+    # The literal running product loses bits of its own only while a partial product is subnormal, and 1e-6 of them only below
+    # 2^-1054 = 5e-318; the factors that follow are at most 1/(sigma sqrt(2 pi)) = 1.995 each, so a final weight above
+    # 5e-318 * 1.995^63 = 3.9e-299 (L = 64; L = 32: 1e-308) has lost less than that.  Compared at 1e-6 down to 1e-290 (until
+    # round 6: 1e-250).
+    big = wr > 1e-290
     assert np.count_nonzero(big) > n // 2
     np.testing.assert_allclose(raw[big], wr[big], rtol=1e-6, atol=0.0)
-    assert np.all(raw[~big] <= 1e-249)
+    assert np.all(raw[~big] <= 1e-289)
     # ... and below it, down to the edge of the normal range, the two still agree in the logarithm (no garbage hides in the mask)
     tiny = (~big) & (wr > 1e-300) & (raw > 0.0)
     if np.any(tiny):
@@ -133,7 +137,9 @@ def test_fastslam_every_pair_matches_the_literal_reference(det, ref, n):
     finally:
         ref.ref_set_threads(1)
     np.testing.assert_allclose(gm.reshape(-1), lm, **TOL)  # 1.2e8 numbers: mean and covariance of every landmark of every particle
-    big = pw > 1e-250
+    # (one update multiplies at most 200 factors of at most 1 / (2 pi sqrt(det R)) = 1.29 into a weight: a result above
+    # 5e-318 * 1.29^200 = 6.6e-296 has not lost 1e-6 of itself in a subnormal partial product)
+    big = pw > 1e-290
     assert np.count_nonzero(big) > n // 2
     np.testing.assert_allclose(gp[big, 0], pw[big], rtol=1e-6, atol=0.0)
     tiny = (~big) & (pw > 1e-300) & (gp[:, 0] > 0.0)

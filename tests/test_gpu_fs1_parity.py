@@ -142,7 +142,7 @@ def test_observe_ekf_matches_oracles(fs, det, ref, n, L, chunks):
             break
     if n * L <= 60000:
         np.testing.assert_allclose(gm.reshape(-1), rm, **TOL)
-        big = rw > 1e-250
+        big = rw > 1e-290  # (a handful of factors of at most 1.29: tests/test_gpu_baseline_literal.py has the bound)
         np.testing.assert_allclose(gp[big, 0], rw[big], rtol=1e-6)
 
 
@@ -193,7 +193,7 @@ def test_adjacent_duplicate_ids_update_sequentially(fs, det, ref, first_obs_cov)
             ref.ref_fs1_update_landmark(poses[p, 1], poses[p, 2], poses[p, 3], C.byref(wv), z[k, 0], z[k, 1], dp(e), C.byref(mr))
             rw[p] = wv.value
     np.testing.assert_allclose(gm.reshape(-1), rm, **TOL)
-    big = rw > 1e-250
+    big = rw > 1e-290  # (a handful of factors of at most 1.29: tests/test_gpu_baseline_literal.py has the bound)
     np.testing.assert_allclose(gp[big, 0], rw[big], rtol=1e-6)
 
 
