@@ -203,6 +203,40 @@ def test_rust_sys_struct_layouts_match_the_c_headers(tmp_path):
     assert r.returncode != 0
 
 
+def test_rust_examples_call_only_what_the_safe_layer_declares():
+    """bindings/rust/rust_robotics_amd/examples/*.rs cannot be compiled here (no rustc): at least every method they call on a
+    localizer / engine and every item they import from the crate must be declared `pub` in the safe layer, every sys:: symbol the
+    safe layer itself calls must be in the generated -sys crate, and braces / parentheses must balance."""
+    import glob
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    crate = os.path.join(root, "bindings", "rust", "rust_robotics_amd")
+    lib = open(os.path.join(crate, "src", "lib.rs")).read()
+    sys_lib = open(os.path.join(root, "bindings", "rust", "rust_robotics_amd-sys", "src", "lib.rs")).read()
+    declared = set(re.findall(r"pub (?:fn|struct|type|mod|enum|trait) (\w+)", lib))
+    for name in set(re.findall(r"sys::(rr_\w+)", lib)):
+        assert re.search(r"\b%s\b" % name, sys_lib), f"the safe layer calls sys::{name}, which the -sys crate does not declare"
+    examples = sorted(glob.glob(os.path.join(crate, "examples", "*.rs")))
+    assert len(examples) >= 3
+    for path in examples:
+        text = open(path).read()
+        code = "\n".join(l for l in text.splitlines() if not l.lstrip().startswith("//"))
+        code = re.sub(r'"(?:[^"\\]|\\.)*"', '""', code)  # string literals out of the way
+        code = re.sub(r"//.*", "", code)
+        for o, c in ("{}", "()", "[]"):
+            assert code.count(o) == code.count(c), f"{os.path.basename(path)}: unbalanced {o}{c}"
+        for imp in re.findall(r"use rust_robotics_amd::(?:fastslam::)?\{([^}]*)\}", code):
+            for item in (x.strip() for x in imp.split(",")):
+                assert item in declared, f"{os.path.basename(path)} imports {item}, which the safe layer does not declare"
+        for var in ("pf", "mcl", "slam", "engine", "generic"):
+            for meth in set(re.findall(r"\b%s\.(\w+)\(" % var, code)):
+                assert meth in declared, f"{os.path.basename(path)} calls {var}.{meth}(), which the safe layer does not declare"
+        for ty, fn in re.findall(r"\b(ParticleFilterLocalizer|MonteCarloLocalizer|FastSlam1|Engine)::(\w+)\(", code):
+            assert fn in declared, f"{os.path.basename(path)} calls {ty}::{fn}(), which the safe layer does not declare"
+
+
+
 def test_instruction_budget_is_reproducible_from_the_isa():
     """rust_robotics_amd/csrc/INSTRUCTION_BUDGET.json (bench.py's roofline.fp64_valu) cites tools/count_isa.py: the tool must
     exist and read the same per-pair count off the compiler's ISA for the kernel as it is today (hipcc cross-compiles here)."""
