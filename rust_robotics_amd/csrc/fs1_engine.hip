@@ -732,7 +732,7 @@ rr_status rr_fs1_create(uint64_t n_particles, uint64_t n_landmarks, const rr_fs1
   RR_TRY_OR_CLEAN(rr::dev_malloc(&h->ctl, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipHostMalloc(&h->ctl_host, sizeof(Ctl)));
   RR_TRY_OR_CLEAN(hipMemsetAsync(h->ctl, 0, sizeof(Ctl), h->stream));
-  hipLaunchKernelGGL(k_fs1_init, dim3(grid_for(h->n_planes * h->n, kBlock)), dim3(kBlock), 0, h->stream, h->pl, h->pw,
+  hipLaunchKernelGGL(k_fs1_init, dim3(grid_for(h->n, kBlock), (unsigned)std::min<uint64_t>(h->n_planes, 65535)), dim3(kBlock), 0, h->stream, h->pl, h->pw,
                      h->n, h->L, prm.initial_weight, prm.init_cov);
   RR_TRY_OR_CLEAN(hipGetLastError());
   RR_TRY_OR_CLEAN(hipStreamSynchronize(h->stream));

@@ -203,3 +203,30 @@ def test_config5_full_size_on_one_gpu(loc):
     cnt = np.bincount(idx, minlength=n)
     assert np.max(np.abs(cnt - n * before[:, 4])) <= 1.0 + 1e-6
     assert np.all(after[:, 4] == 1.0 / n)
+
+
+def test_a_billion_particles_on_one_gpu(loc):
+    """The largest sizes: 10^9 particles (84 GB of the 288) unsharded on one GPU -- 62.5 x BASELINE configs[4], 488 282 scan tiles, every
+    index beyond 2^24 and the byte offsets beyond 2^32 -- through the asynchronous step with the systematic resampler every step, checked
+    by what needs no N-sized copy to the host: the mean tracks the truth, N_eff lies in (0, N], the covariance is finite with a
+    non-negative diagonal, the counters count.  (tools/max_size_probe.py takes the same run to the ABI's limit, 2^31 - 1 particles =
+    181 GB: profiles/r06z5_max_size_probe.jsonl.)  One particle more than the limit is refused with the reference-style message."""
+    n, steps = 1_000_000_000, 4
+    cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
+    pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=5, resample_scheme=1)
+    assert pf.particle_count() == n
+    rng = np.random.default_rng(6)
+    for t in range(steps):
+        pf.step_async([1.0, 0.1], H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(t + 1), 0.2, rng))
+    est = pf.estimate()
+    truth = H.true_pose(steps)
+    assert np.all(np.isfinite(est)) and np.hypot(est[0] - truth[0], est[1] - truth[1]) < 0.5
+    cov = pf.calc_covariance()
+    assert np.all(np.isfinite(cov)) and np.all(np.diag(cov) >= 0.0)
+    pf.predict_with_control([1.0, 0.1])
+    pf.update_with_observations(H.observations(H.REF_SCENE_LANDMARKS, H.true_pose(steps + 1), 0.2, rng))
+    assert 0.0 < pf.n_eff() <= n
+    assert pf.counters()[0] == steps + 1
+    del pf
+    with pytest.raises(loc.RoboticsError, match="below 2\\^31"):
+        loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], loc.MonteCarloLocalizationConfig(min_particles=2**31, max_particles=2**31), seed=5, resample_scheme=1)

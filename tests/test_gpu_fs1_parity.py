@@ -590,3 +590,46 @@ def test_config4_full_size_on_one_gpu(fs):
     if k < n and idx[k] == probe:
         assert bits_equal(f.landmarks_of(k), lm_before)
     f.close()
+
+
+def test_four_million_particles_times_200_landmarks(fs):
+    """Beyond BASELINE configs[3]: 4 000 000 particles x 200 landmarks -- 77 GB of maps in two buffer sets, (3 + 6 L) N = 4.8e9 plane
+    elements, i.e. past the 2^32 that one dimension of a launch can count (rr_fs1_create's fill was such a launch until round 6 and left
+    most planes of a filter this size unwritten: tools/max_size_probe_fastslam.py found it; the probe takes the same run to
+    14 000 000 particles = 270 GB).  Size-independent properties: a fresh filter's last plane holds the initial covariance, every
+    landmark of the best particle is initialised by the first update and lies near the truth after three, weights are normalised,
+    a forced resample's survivors are exact copies."""
+    n, L = 4_000_000, 200
+    lms = scene(L, 61)
+    prm = fs.default_params()
+    prm.first_obs_cov = 0.5
+    prm.nth = n / 1.5
+    f = fs.FastSlam1(n, L, params=prm, seed=8)
+    for probe in (0, n // 2, n - 1):  # before any update: (0, 0, 1000 I) in every landmark of every particle (fastslam1.rs:34-41)
+        m = f.landmarks_of(probe)
+        assert np.all(m[:, :2] == 0.0) and np.all(m[:, 2] == 1000.0) and np.all(m[:, 5] == 1000.0) and np.all(m[:, 3:5] == 0.0), probe
+    for t in range(3):
+        z = observations_for(fs, H.true_pose(t + 1, v=0.5), lms, seed=8, step=t)
+        assert len(z) == L
+        f.update([0.5, 0.1], z)
+    poses = f.poses()
+    assert poses.shape == (n, 4) and np.all(np.isfinite(poses))
+    assert abs(poses[:, 0].sum() - 1.0) < 1e-9
+    pose, w, i = f.best_particle()
+    assert w == poses[:, 0].max() and i == int(np.nonzero(poses[:, 0] == w)[0][-1])
+    for probe in (i, n - 1):
+        m = f.landmarks_of(probe)
+        assert np.all(m[:, 2] < 100.0) and np.all(np.isfinite(m))
+        assert np.median(np.hypot(m[:, 0] - lms[:, 0], m[:, 1] - lms[:, 1])) < 1.5
+    before = f.poses()
+    probe = n - 12_345
+    lm_before = f.landmarks_of(probe)
+    f.resample_systematic(0.37)
+    idx = f.last_resample_indices()
+    after = f.poses()
+    assert np.all(np.diff(idx.astype(np.int64)) >= 0)
+    assert bits_equal(after[:, 1:], before[idx, 1:]) and np.all(after[:, 0] == 1.0 / n)
+    k = int(np.searchsorted(idx, probe))
+    if k < n and idx[k] == probe:
+        assert bits_equal(f.landmarks_of(k), lm_before)
+    f.close()
