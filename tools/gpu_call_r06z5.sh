@@ -4,7 +4,7 @@ set -u
 export PYTHONPATH=$PWD HSA_ENABLE_IPC_MODE_LEGACY=0
 OUT=gpurun_out/r06z5
 mkdir -p $OUT
-timeout 420 python tools/max_size_probe.py ${1:-1e9} ${2:-0} > $OUT/r06z5_max_size_probe.jsonl 2> $OUT/probe.err; echo "probe rc=$?" | tee -a $OUT/summary.txt
+timeout 420 python tools/max_size_probe.py ${1:-1e9} ${2:-0} ${5:-1} > $OUT/r06z5_max_size_probe.jsonl 2> $OUT/probe.err; echo "probe rc=$?" | tee -a $OUT/summary.txt
 cat $OUT/r06z5_max_size_probe.jsonl | cut -c1-400 | tee -a $OUT/summary.txt
 tail -3 $OUT/probe.err
 rocm-smi --showmeminfo vram 2>/dev/null | grep -i "total\|used" | head -4 | tee -a $OUT/summary.txt

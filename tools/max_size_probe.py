@@ -4,7 +4,7 @@ limit (n_particles < 2^31: 32-bit resample indices and markers), L = 4 landmarks
 every step, checked by what does not need an N-sized copy to the host: the estimate tracks the truth, N_eff lies in (0, N], the
 covariance is finite and its diagonal non-negative, the counters count.  Prints one JSON line per size (stops at the first size
 the device refuses; an allocation failure is an error message, not a crash).
-    python tools/max_size_probe.py [max_particles [min_particles]] > profiles/r06z5_max_size_probe.jsonl"""
+    python tools/max_size_probe.py [max_particles [min_particles [scheme]]] > profiles/r06z5_max_size_probe.jsonl"""
 import json
 import os
 import sys
@@ -22,6 +22,7 @@ import rust_robotics_amd.localization as loc  # noqa: E402
 def main():
     top = int(float(sys.argv[1])) if len(sys.argv) > 1 else 2**31 - 1
     low = int(float(sys.argv[2])) if len(sys.argv) > 2 else 0
+    scheme = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # 1: systematic (fastslam1.rs:205-234), 0: multinomial (monte_carlo_localization.rs:322-365)
     L, steps = 4, 4
     lms = H.REF_SCENE_LANDMARKS
     for n in (16_000_000, 100_000_000, 400_000_000, 1_000_000_000, 1_600_000_000, 2**31 - 1):
@@ -29,11 +30,11 @@ def main():
             break
         if n < low:
             continue
-        row = {"particles": n, "landmarks": L, "bytes_per_particle_resident": None}
+        row = {"particles": n, "landmarks": L, "resample": "systematic" if scheme == 1 else "multinomial"}
         t0 = time.perf_counter()
         try:
             cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n)
-            pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=5, resample_scheme=1)
+            pf = loc.MonteCarloLocalizer.with_initial_state([0.0, 0.0, 0.0, 1.0], cfg, seed=5, resample_scheme=scheme)
         except Exception as e:  # the engine's message (hipMalloc, a limit of the ABI)
             row.update(ok=False, error=str(e)[:300])
             print(json.dumps(row), flush=True)
