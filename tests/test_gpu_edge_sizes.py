@@ -69,6 +69,40 @@ def test_observation_counts_around_the_kernarg_limit(loc, det, L):
     assert np.all(np.isfinite(e))
 
 
+@pytest.mark.parametrize("L", [2730, 2731, 6400])
+def test_observation_counts_up_to_the_lds_limit(loc, det, L):
+    """The observation block of a step is staged in LDS, 24 bytes per observation: 2 730 is the last count below 64 KB, 6 400 the
+    engine's limit (150 KB of the CU's 160); one more is refused.  sigma is chosen so that 1 / (sigma sqrt(2 pi)) = e^0.5, i.e. the
+    fused likelihood's exponent L ln c - sum diff^2 / 2 sigma^2 stays near 0 for particles next to the truth instead of running off
+    to -L/2 (the linear-space product underflows at such counts whatever one does)."""
+    n, sigma = 3000, 1.0 / (math.exp(0.5) * math.sqrt(2.0 * math.pi))
+    lms = H.landmarks_grid(L, 3)
+    pose = H.true_pose(5)
+    rng = np.random.default_rng(4)
+    obs = np.ascontiguousarray(H.observations(lms, pose, sigma, rng))
+    x, y = pose[0] + rng.normal(0, 0.002, n), pose[1] + rng.normal(0, 0.002, n)
+    yaw, v = np.full(n, pose[2]), np.ones(n)
+    cfg = loc.ParticleFilterConfig(n_particles=n, range_noise=sigma)
+    pf = loc.ParticleFilterLocalizer(cfg)
+    pf.set_particles_array(H.aos(x, y, yaw, v, np.full(n, 1.0 / n)))
+    pf.update_with_observations(obs)
+    w = np.empty(n)
+    det.det_pf_weights(n, dp(x), dp(y), dp(w), dp(obs), L, sigma, 0)
+    got = pf.raw_weights()
+    assert bits_eq(got, w)
+    assert np.count_nonzero(np.isfinite(got) & (got > 0.0)) > n // 2, "the comparison must not be one of zeros"
+    pf2 = loc.ParticleFilterLocalizer(cfg, seed=3, resample_scheme=1)
+    for _ in range(3):  # the lazy step kernels stage the same block
+        e = pf2.step([1.0, 0.1], obs)
+    assert np.all(np.isfinite(e))
+    if L == 6400:
+        more = np.vstack([obs, obs[:1]])
+        with pytest.raises(loc.RoboticsError, match="too many observations"):
+            pf.update_with_observations(more)
+        with pytest.raises(loc.RoboticsError, match="too many observations"):
+            pf2.step([1.0, 0.1], more)
+
+
 def test_long_run_stays_locked_and_finite(loc):
     n = 20_000
     cfg = loc.MonteCarloLocalizationConfig(min_particles=n, max_particles=n, range_noise=0.3, velocity_noise=0.5,

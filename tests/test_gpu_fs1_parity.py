@@ -107,7 +107,7 @@ def test_predict_with_noise(fs, det, ref, n):
     assert np.all(np.abs(got[:, 3]) <= math.pi)
 
 
-@pytest.mark.parametrize("n,L,chunks", [(300, 6, 1), (1000, 50, 1), (1000, 50, 4), (2049, 33, 7), (500, 200, 0)])
+@pytest.mark.parametrize("n,L,chunks", [(300, 6, 1), (1000, 50, 1), (1000, 50, 4), (2049, 33, 7), (500, 200, 0), (200, 3000, 0), (100, 5000, 64)])
 def test_observe_ekf_matches_oracles(fs, det, ref, n, L, chunks):
     lms = scene(L, 11)
     poses, maps = make_state(n, L, lms, 12)
