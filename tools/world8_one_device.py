@@ -210,6 +210,10 @@ CASES = {
     # BASELINE configs[4]: 8 x 2 000 000 x 64
     "mcl-config5": lambda: [run_mcl("mcl-config5", WORLD, 2_000_000, 6, peaked=True, L=64)],
     "mcl-config5-heavy": lambda: [run_mcl("mcl-config5-heavy-last-rank", WORLD, 2_000_000, 4, peaked=True, L=64, heavy=[(WORLD - 1) * 2_000_000 + 123])],
+    # beyond the BASELINE sizes: 8 x 12 500 000 = 1e8 particles in one global slot space (positions beyond 2^24, inboxes of 400 MB),
+    # steady state and the worst-case resample
+    "mcl-1e8": lambda: [run_mcl("mcl-1e8", WORLD, 12_500_000, 3, peaked=True, L=4),
+                        run_mcl("mcl-1e8-heavy-last-rank", WORLD, 12_500_000, 3, peaked=True, L=4, heavy=[(WORLD - 1) * 12_500_000 + 123])],
     # BASELINE configs[3]: 8 x 125 000 x 200
     "fs1-small": lambda: [run_fs1("fs1-small", WORLD, 1300, 7, 8, chunks=2), run_fs1("fs2-small", WORLD, 1300, 7, 8, chunks=2, variant=2)],
     "fs1-config4": lambda: [run_fs1("fs1-config4", WORLD, 125_000, 200, 4)],
