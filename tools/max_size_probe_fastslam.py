@@ -3,7 +3,7 @@
 particle and buffer set, two sets), particle counts from configs[3]'s 10^6 upwards, every landmark observed in every update, checked
 by what needs no map-sized copy to the host: the best particle is finite and near the truth, its map lies around the landmarks, N_eff
 in (0, N].  One JSON line per size; stops at the first size the device refuses (an error message, not a crash).
-    python tools/max_size_probe_fastslam.py [max_particles [min_particles]] > profiles/r06z5_max_size_probe_fastslam.jsonl"""
+    python tools/max_size_probe_fastslam.py [max_particles [min_particles [1 | 2]]] > profiles/r06z5_max_size_probe_fastslam.jsonl"""
 import json
 import os
 import sys
@@ -16,11 +16,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import helpers as H  # noqa: E402
 from rust_robotics_amd.slam import fastslam1 as fs  # noqa: E402
+from rust_robotics_amd.slam import fastslam2 as fs2  # noqa: E402
 
 
 def main():
     top = int(float(sys.argv[1])) if len(sys.argv) > 1 else 14_000_000
     low = int(float(sys.argv[2])) if len(sys.argv) > 2 else 0
+    variant = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # 2: FastSLAM 2.0 (fastslam2.rs:173-374) on the same planes
     L, steps = 200, 3
     lms = np.random.default_rng(61).uniform(-13.0, 13.0, size=(L, 2))
     for n in (1_000_000, 4_000_000, 8_000_000, 10_000_000, 12_000_000, 14_000_000):
@@ -28,13 +30,14 @@ def main():
             break
         if n < low:
             continue
-        row = {"particles": n, "landmarks": L, "map_bytes_both_sets_GB": round(2 * (3 + 6 * L) * 8 * n / 1e9, 1)}
-        prm = fs.default_params()
-        prm.first_obs_cov = 0.5
-        prm.nth = n / 1.5
+        row = {"filter": f"FastSLAM {variant}.0", "particles": n, "landmarks": L, "map_bytes_both_sets_GB": round(2 * (3 + 6 * L) * 8 * n / 1e9, 1)}
+        prm = fs2.default_params() if variant == 2 else fs.default_params()
+        base = prm.base if variant == 2 else prm
+        base.first_obs_cov = 0.5
+        base.nth = n / 1.5
         t0 = time.perf_counter()
         try:
-            f = fs.FastSlam1(n, L, params=prm, seed=8)
+            f = (fs2.FastSlam2 if variant == 2 else fs.FastSlam1)(n, L, params=prm, seed=8)
         except Exception as e:
             row.update(ok=False, error=str(e)[:300])
             print(json.dumps(row), flush=True)

@@ -217,6 +217,9 @@ CASES = {
     # BASELINE configs[3]: 8 x 125 000 x 200
     "fs1-small": lambda: [run_fs1("fs1-small", WORLD, 1300, 7, 8, chunks=2), run_fs1("fs2-small", WORLD, 1300, 7, 8, chunks=2, variant=2)],
     "fs1-config4": lambda: [run_fs1("fs1-config4", WORLD, 125_000, 200, 4)],
+    # FastSLAM 2.0 at the same size, and FastSLAM 1.0 at twice it (8 x 250 000 x 200: shards of 4.8 GB per buffer set, a 38 GB unsharded filter)
+    "fs2-config4": lambda: [run_fs1("fs2-config4", WORLD, 125_000, 200, 3, variant=2)],
+    "fs1-2e6": lambda: [run_fs1("fs1-2e6", WORLD, 250_000, 200, 3)],
 }
 
 
