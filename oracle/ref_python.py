@@ -336,3 +336,69 @@ def get_best_particle_index(particles):
         if not (b < a):  # partial_cmp(best, candidate) != Greater: the candidate replaces it
             best = i
     return best
+
+
+# ------------------------------------------------------------------ monte_carlo_localization.rs: the KLD-adaptive resample
+X_BIN_SIZE = 0.5  # monte_carlo_localization.rs:23-25
+Y_BIN_SIZE = 0.5
+YAW_BIN_SIZE = 15.0 * PI / 180.0
+
+
+def _as_i32(v):
+    """Rust's `f64 as i32`: truncation towards zero, saturating at the type's ends, NaN -> 0"""
+    if v != v:
+        return 0
+    if v <= -2147483648.0:
+        return -2147483648
+    if v >= 2147483647.0:
+        return 2147483647
+    return int(v)
+
+
+def _floor(v):
+    """f64::floor: a float back (Python's math.floor makes an int and refuses NaN and the infinities)"""
+    return v if v != v or abs(v) == math.inf else float(math.floor(v))
+
+
+def quantize_particle(x, y, yaw):
+    return (_as_i32(_floor(x / X_BIN_SIZE)), _as_i32(_floor(y / Y_BIN_SIZE)), _as_i32(_floor(yaw / YAW_BIN_SIZE)))
+
+
+def kld_required_particles(k_bins, min_particles, max_particles, kld_epsilon, kld_z):
+    """:367-378; `n.ceil() as usize` saturates (negative and NaN -> 0) before the clamp"""
+    if k_bins <= 1:
+        return min_particles
+    k_minus_one = float(k_bins - 1)
+    term = 1.0 - 2.0 / (9.0 * k_minus_one) + kld_z * math.sqrt(2.0 / (9.0 * k_minus_one))
+    n = (k_minus_one / (2.0 * kld_epsilon)) * (term * term * term)  # term.powi(3)
+    c = math.ceil(n) if n == n and abs(n) != math.inf else n
+    as_usize = 0 if not (c > 0.0) else (2**64 - 1 if c >= 18446744073709551615.0 else int(c))
+    return min(max(as_usize, min_particles), max_particles)
+
+
+def resample_adaptive_indices(xs, ys, yaws, weights, draws, min_particles, max_particles, kld_epsilon, kld_z):
+    """:322-365: the source index of every particle the loop keeps; draws[k] stands for the k-th `rng.random::<f64>()`"""
+    if not weights:
+        return []
+    cumulative = []
+    cum_sum = 0.0
+    for w in weights:
+        cum_sum += w
+        cumulative.append(cum_sum)
+    cumulative[-1] = 1.0
+    bins = set()
+    new = []
+    required = min_particles
+    while len(new) < max_particles:
+        r = draws[len(new)]
+        idx = len(cumulative) - 1
+        for i, w in enumerate(cumulative):  # sample_index :387-392
+            if r <= w:
+                idx = i
+                break
+        bins.add(quantize_particle(xs[idx], ys[idx], yaws[idx]))
+        required = max(required, kld_required_particles(len(bins), min_particles, max_particles, kld_epsilon, kld_z))
+        new.append(idx)
+        if len(new) >= min_particles and len(new) >= required:
+            break
+    return new

@@ -216,3 +216,28 @@ def test_best_particle_ties_go_to_the_last(ref):
     pw = np.array([0.1, 0.9, 0.3, 0.9, 0.2])
     ref.ref_fs1_best_particle.restype = C.c_size_t
     assert ref.ref_fs1_best_particle(5, dp(pw)) == 3
+
+
+@pytest.mark.parametrize("n,lo,hi,spread,seed", [(300, 100, 5000, 0.3, 21), (300, 100, 5000, 6.0, 22), (50, 10, 60, 3.0, 23), (400, 1, 400, 20.0, 24)])
+def test_kld_adaptive_resample(ref, n, lo, hi, spread, seed):
+    """monte_carlo_localization.rs:322-385: the same kept prefix of the draw sequence, the same count -- a tight cloud (few bins: the
+    count stays at min_particles), a wide one (the bound grows with the bins and the loop runs into max_particles), and the formula
+    itself over every bin count that can occur."""
+    rng = np.random.default_rng(seed)
+    x, y, yaw = rng.normal(0, spread, n), rng.normal(0, spread, n), rng.normal(0, 0.5 * spread, n)
+    w = rng.uniform(0, 1, n) ** 3
+    w /= w.sum()
+    r = rng.uniform(0, 1, hi)
+    r[0] = 1.0 - 1e-17  # == 1.0: only the forced last cumulative weight answers it
+    idx = np.empty(hi, np.uint32)
+    ref.ref_mcl_resample_adaptive.restype = C.c_size_t
+    ref.ref_mcl_resample_adaptive.argtypes = [C.c_size_t] + [C.POINTER(C.c_double)] * 5 + [C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.POINTER(C.c_uint32)]
+    cnt = ref.ref_mcl_resample_adaptive(n, dp(x), dp(y), dp(yaw), dp(w), dp(r), lo, hi, 0.05, 2.326, u32p(idx))
+    got = P.resample_adaptive_indices(x.tolist(), y.tolist(), yaw.tolist(), w.tolist(), r.tolist(), lo, hi, 0.05, 2.326)
+    assert cnt == len(got) and list(idx[:cnt]) == got
+    assert lo <= cnt <= hi
+    ref.ref_kld_required.restype = C.c_size_t
+    ref.ref_kld_required.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t, C.c_double, C.c_double]
+    for k in list(range(0, 200)) + [1000, 10**6]:
+        assert ref.ref_kld_required(k, lo, hi, 0.05, 2.326) == P.kld_required_particles(k, lo, hi, 0.05, 2.326), k
+    assert P.quantize_particle(-0.1, 0.5, -1e300) == (-1, 1, -2147483648) and P.quantize_particle(float("nan"), 0.49, 0.0) == (0, 0, 0)
