@@ -1,7 +1,7 @@
 /* rr_detmath.h -- the deterministic arithmetic contract ("D-spec") of the engine.
  *
  * Every transcendental the hot path needs (exp, log, sin/cos, atan2) and the
- * counter-based noise source (Philox4x32-10 -> Box-Muller) are written here as a
+ * counter-based noise source (Philox4x32, RR_PHILOX_ROUNDS = 7 rounds -> Box-Muller) are written here as a
  * fixed sequence of IEEE-754 binary64 operations: +, -, *, /, sqrt, fma,
  * round-to-nearest-even and integer bit manipulation.  Those primitives are
  * correctly rounded on both x86-64 and gfx950, so a translation unit compiled
@@ -363,7 +363,7 @@ RR_HD double rr_atan2(double y, double x) {
   return rr_u2d(rr_d2u(a) | sy);
 }
 
-/* ------------------------------------------------------------------ Philox4x32-10 */
+/* ------------------------------------------------------------------ Philox4x32 (7 rounds in the engine's streams, see below) */
 /* Salmon et al., "Parallel random numbers: as easy as 1, 2, 3" (SC'11);
  * constants are the published ones. */
 #define RR_PHILOX_M0 0xD2511F53u

@@ -177,7 +177,11 @@ rr_status validate_u(const double u[2]) {
   return RR_OK;
 }
 
-// z rows are (d, angle, id); ids must be integral and inside the map; duplicates force one chunk
+int choose_chunks(const rr_fs1* h, size_t n_z, bool dup);
+
+// z rows are (d, angle, id); ids must be integral and inside the map; duplicates force one chunk.  A chunk's observations are staged
+// in LDS (24 bytes each, 150 of the CU's 160 KB): a list whose chunk plan does not fit is refused HERE, before anything of the update
+// has run (until round 6 the observe launch itself failed -- after the predict -- and left HIP's sticky error for the next call)
 rr_status validate_z(const rr_fs1* h, const double* z, size_t n_z, bool* has_duplicates) {
   if (n_z && !z) return fail(RR_INVALID_PARAMETER, "null observations");
   std::vector<char> seen(h->L, 0);
@@ -190,6 +194,14 @@ rr_status validate_z(const rr_fs1* h, const double* z, size_t n_z, bool* has_dup
       return fail(RR_INVALID_PARAMETER, "fastslam observation landmark id out of range");  // the reference would panic on the index
     if (seen[(size_t)id]) *has_duplicates = true;
     seen[(size_t)id] = 1;
+  }
+  if (n_z > 1) {
+    const int chunks = choose_chunks(h, n_z, *has_duplicates);
+    const size_t len = (n_z + (size_t)chunks - 1) / (size_t)chunks;
+    if (3 * len * sizeof(double) > 150 * 1024)
+      return fail(RR_INVALID_PARAMETER, *has_duplicates
+                                            ? "too many fastslam observations for an update with a repeated landmark id (one sequential chunk, max 6400)"
+                                            : "too many fastslam observations per chunk for one LDS block (max 6400 per chunk, 64 chunks)");
   }
   return RR_OK;
 }

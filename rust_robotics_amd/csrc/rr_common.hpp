@@ -27,6 +27,7 @@ inline rr_status fail(rr_status code, const std::string& msg) {
   do {                                                                                    \
     hipError_t _e = (expr);                                                               \
     if (_e != hipSuccess) {                                                               \
+      (void)hipGetLastError(); /* HIP's last error is sticky: reported once, here */        \
       return ::rr::fail(RR_RUNTIME_ERROR, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     }                                                                                     \
   } while (0)

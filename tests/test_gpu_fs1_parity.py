@@ -635,3 +635,29 @@ def test_four_million_particles_times_200_landmarks(fs):
     if k < n and idx[k] == probe:
         assert bits_equal(f.landmarks_of(k), lm_before)
     f.close()
+
+
+def test_an_observation_list_that_does_not_fit_the_lds_staging_is_refused_before_anything_runs(fs):
+    """A chunk's observations are staged in LDS (24 bytes each, 150 KB): 8 000 distinct landmarks in one update are 64 chunks of 125 and
+    fine; the same list with ONE landmark id repeated must run as one sequential chunk (fastslam1.rs:250-256's order for a landmark
+    seen twice) and does not fit -- refused as an invalid parameter with nothing of the update done (until round 6 the observe launch
+    failed after the predict had run, and HIP's sticky error failed the next call too)."""
+    from rust_robotics_amd.core import RoboticsError
+
+    L, n = 8000, 300
+    lms = scene(L, 71)
+    f = fs.FastSlam1(n, L, seed=3)
+    z = observations_for(fs, H.true_pose(1, v=0.5), lms, seed=3, step=0)
+    assert len(z) == L
+    f.update([0.5, 0.1], z)
+    assert f.counters()[2] == 64
+    before, counters = f.poses(), f.counters()
+    with pytest.raises(RoboticsError, match="too many fastslam observations") as ei:
+        f.update([0.5, 0.1], np.vstack([z, z[:1]]))
+    assert ei.value.kind == "InvalidParameter"
+    assert f.counters() == counters and bits_equal(f.poses(), before), "a refused update must not have moved anything"
+    f.update([0.5, 0.1], z)  # the handle is as usable as before
+    assert np.all(np.isfinite(f.best_particle()[0]))
+    f.update([0.5, 0.1], np.vstack([z[:6000], z[:1]]))  # 6 001 in one sequential chunk: 144 KB, fits
+    assert f.counters()[2] == 1
+    f.close()
