@@ -402,3 +402,162 @@ def resample_adaptive_indices(xs, ys, yaws, weights, draws, min_particles, max_p
         if len(new) >= min_particles and len(new) >= required:
             break
     return new
+
+
+# ------------------------------------------------------------------ fastslam2.rs
+# nalgebra 0.33.2 pieces this file needs beyond the 2 x 2 ones above, restated from the crate's published source (none of it is under
+# /root/reference): Matrix3::try_inverse (linalg/inverse.rs, the cofactor form with its three shared minors), Cholesky::new + l()
+# (linalg/cholesky.rs: column by column, col_j -= L[j][k] * col_k as an axpy over rows j.., None on a zero or negative pivot).
+MOTION_COV = [[0.1, 0.0, 0.0], [0.0, 0.1, 0.0], [0.0, 0.0, 0.01]]  # fastslam2.rs:30
+
+
+def try_inverse3(m):
+    (m11, m12, m13), (m21, m22, m23), (m31, m32, m33) = m
+    minor_m12_m23 = m22 * m33 - m32 * m23
+    minor_m11_m23 = m21 * m33 - m31 * m23
+    minor_m11_m22 = m21 * m32 - m31 * m22
+    determinant = m11 * minor_m12_m23 - m12 * minor_m11_m23 + m13 * minor_m11_m22
+    if determinant == 0.0:
+        return None
+    return [[minor_m12_m23 / determinant, (m13 * m32 - m33 * m12) / determinant, (m12 * m23 - m22 * m13) / determinant],
+            [-minor_m11_m23 / determinant, (m11 * m33 - m31 * m13) / determinant, (m13 * m21 - m23 * m11) / determinant],
+            [minor_m11_m22 / determinant, (m12 * m31 - m32 * m11) / determinant, (m11 * m22 - m21 * m12) / determinant]]
+
+
+def cholesky_l(a):
+    """The lower factor, or None where nalgebra's Cholesky::new gives up"""
+    n = len(a)
+    m = [row[:] for row in a]
+    for j in range(n):
+        for k in range(j):
+            factor = -m[j][k]
+            for i in range(j, n):  # col_j[j..] = factor * col_k[j..] + col_j[j..]
+                m[i][j] = factor * m[i][k] + m[i][j]
+        diag = m[j][j]
+        if diag == 0.0 or not (diag >= 0.0):
+            return None
+        denom = math.sqrt(diag)
+        m[j][j] = denom
+        for i in range(j + 1, n):
+            m[i][j] /= denom
+    return [[m[i][j] if j <= i else 0.0 for j in range(n)] for i in range(n)]
+
+
+def motion_jacobian(x, u, dt=DT):
+    yaw, v = x[2], u[0]
+    sin_yaw, cos_yaw = sincos(yaw)
+    return [[1.0, 0.0, -v * dt * sin_yaw], [0.0, 1.0, v * dt * cos_yaw], [0.0, 0.0, 1.0]]
+
+
+def fs2_observation_model(px, py, pyaw, lm_x, lm_y):
+    dx = lm_x - px
+    dy = lm_y - py
+    d = math.sqrt(dx * dx + dy * dy)
+    return [d, normalize_angle(math.atan2(dy, dx) - pyaw)]
+
+
+def obs_jacobian_landmark(px, py, lm_x, lm_y):
+    dx = lm_x - px
+    dy = lm_y - py
+    d2 = dx * dx + dy * dy
+    d = math.sqrt(d2)
+    return [[dx / d, dy / d], [-dy / d2, dx / d2]]
+
+
+def obs_jacobian_pose(px, py, lm_x, lm_y):
+    dx = lm_x - px
+    dy = lm_y - py
+    d2 = dx * dx + dy * dy
+    d = math.sqrt(d2)
+    return [[-dx / d, -dy / d, 0.0], [dy / d2, -dx / d2, -1.0]]
+
+
+def fs2_is_initialized(lm):
+    return lm.cov[0][0] < 100.0
+
+
+def compute_proposal(particle, u, z, lm_id, r):
+    """fastslam2.rs:173-216 -> (mean as a list of 3, covariance 3 x 3)"""
+    lm = particle.landmarks[lm_id]
+    pose = [particle.x, particle.y, particle.yaw]
+    x_pred = motion_model(pose, u)
+    g = motion_jacobian(pose, u)
+    p_pred = mat_mul(mat_mul(g, MOTION_COV), transpose(g))
+    if not fs2_is_initialized(lm):
+        return x_pred, p_pred
+    h_pose = obs_jacobian_pose(x_pred[0], x_pred[1], lm.x, lm.y)
+    h_lm = obs_jacobian_landmark(x_pred[0], x_pred[1], lm.x, lm.y)
+    q_obs = mat_add(mat_mul(mat_mul(h_lm, lm.cov), transpose(h_lm)), r)
+    h_pose_t = transpose(h_pose)
+    q_obs_inv = try_inverse2(q_obs)
+    if q_obs_inv is None:
+        q_obs_inv = identity2()
+    p_pred_inv = try_inverse3(p_pred)
+    if p_pred_inv is None:
+        p_pred_inv = [[1e-6 if i == j else 0.0 * 1e-6 for j in range(3)] for i in range(3)]  # Matrix3::identity() * 1e-6
+    p_post_inv = mat_add(p_pred_inv, mat_mul(mat_mul(h_pose_t, q_obs_inv), h_pose))
+    p_post = try_inverse3(p_post_inv)
+    if p_post is None:
+        p_post = p_pred
+    z_pred = fs2_observation_model(x_pred[0], x_pred[1], x_pred[2], lm.x, lm.y)
+    innovation = [[z[0] - z_pred[0]], [normalize_angle(z[1] - z_pred[1])]]
+    corr = mat_mul(mat_mul(mat_mul(p_post, h_pose_t), q_obs_inv), innovation)
+    return [x_pred[k] + corr[k][0] for k in range(3)], p_post
+
+
+def sample_pose(mean, cov, noise):
+    """:219-239; noise stands for the three standard-normal samples, in the order they are drawn"""
+    l = cholesky_l(cov)
+    if l is None:
+        l = [[math.sqrt(max(cov[i][i], 0.0)) if i == j else 0.0 for j in range(3)] for i in range(3)]
+    ln = mat_mul(l, [[noise[0]], [noise[1]], [noise[2]]])
+    return [mean[k] + ln[k][0] for k in range(3)]
+
+
+def update_landmark_and_weight(particle, z, lm_id, r):
+    """:242-280 -> the weight factor"""
+    lm = particle.landmarks[lm_id]
+    if not fs2_is_initialized(lm):
+        sin_b, cos_b = sincos(particle.yaw + z[1])
+        lm.x = particle.x + z[0] * cos_b
+        lm.y = particle.y + z[0] * sin_b
+        lm.cov = [[10.0, 0.0 * 10.0], [0.0 * 10.0, 10.0]]  # Matrix2::identity() * 10.0
+        return 1.0
+    z_pred = fs2_observation_model(particle.x, particle.y, particle.yaw, lm.x, lm.y)
+    innovation = [[z[0] - z_pred[0]], [normalize_angle(z[1] - z_pred[1])]]
+    h = obs_jacobian_landmark(particle.x, particle.y, lm.x, lm.y)
+    s = mat_add(mat_mul(mat_mul(h, lm.cov), transpose(h)), r)
+    s_inv = try_inverse2(s)
+    if s_inv is None:
+        s_inv = identity2()
+    k = mat_mul(mat_mul(lm.cov, transpose(h)), s_inv)
+    delta = mat_mul(k, innovation)
+    lm.x += delta[0][0]
+    lm.y += delta[1][0]
+    lm.cov = mat_mul(mat_sub(identity2(), mat_mul(k, h)), lm.cov)
+    det_s = determinant2(s)
+    if det_s > 0.0:
+        mahal = mat_mul(mat_mul(transpose(innovation), s_inv), innovation)
+        return math.exp(-0.5 * mahal[0][0]) / (2.0 * PI * math.sqrt(det_s))
+    return 1e-10
+
+
+def fastslam2_update(particles, u, z, noise, draw_r0, nth=100.0 / 1.5, r=R_SIM, q=Q_SIM):
+    """:331-374.  noise[p] = the normals particle p draws (three with an observation, two without); draw_r0() is called only when the
+    gate fires, as the reference draws its uniform inside resample_with_rng.  Returns (particles, fired)."""
+    for particle, nz in zip(particles, noise):
+        if len(z):
+            d, angle, lm_id = z[0]
+            mean, cov = compute_proposal(particle, u, [d, angle], int(lm_id), r)
+            pose = sample_pose(mean, cov, nz)
+        else:
+            u_noisy = [u[0] + nz[0] * math.sqrt(q[0][0]), u[1] + nz[1] * math.sqrt(q[1][1])]
+            pose = motion_model([particle.x, particle.y, particle.yaw], u_noisy)
+        particle.x, particle.y, particle.yaw = pose[0], pose[1], normalize_angle(pose[2])  # set_pose :78-82
+        for d, angle, lm_id in z:
+            particle.weight *= update_landmark_and_weight(particle, [d, angle], int(lm_id), r)
+    normalize_weights(particles)
+    if compute_neff(particles) < nth:
+        particles, _ = resample(particles, draw_r0())
+        return particles, True
+    return particles, False

@@ -121,3 +121,27 @@ def landmark_error(engine, lm_xy):
     else:
         mx, my = maps[init, 0, 0].mean(), maps[init, 0, 1].mean()
     return math.hypot(mx - lm_xy[0], my - lm_xy[1])
+
+
+class PythonEngine:
+    """oracle/ref_python.py's fastslam2_update -- the second, independently written restatement -- behind the same two methods"""
+
+    def __init__(self, n, n_lm):
+        from oracle import ref_python as P
+
+        self.P, self.n, self.L = P, n, n_lm
+        self.parts = [P.Particle(n_lm) for _ in range(n)]
+
+    def update(self, u, z, noise, draw_r0):
+        per = 3 if len(z) else 2
+        self.parts, fired = self.P.fastslam2_update(self.parts, [float(u[0]), float(u[1])], [tuple(float(t) for t in row) for row in z],
+                                                    [[float(t) for t in row[:per]] for row in noise], draw_r0)
+        return fired
+
+    def state(self):
+        w = np.array([p.weight for p in self.parts])
+        maps = np.array([[[m.x, m.y, m.cov[0][0], m.cov[1][0], m.cov[0][1], m.cov[1][1]] for m in p.landmarks] for p in self.parts])
+        return w, maps
+
+    def poses(self):
+        return np.array([[p.x, p.y, p.yaw] for p in self.parts])

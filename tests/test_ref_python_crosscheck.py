@@ -241,3 +241,64 @@ def test_kld_adaptive_resample(ref, n, lo, hi, spread, seed):
     for k in list(range(0, 200)) + [1000, 10**6]:
         assert ref.ref_kld_required(k, lo, hi, 0.05, 2.326) == P.kld_required_particles(k, lo, hi, 0.05, 2.326), k
     assert P.quantize_particle(-0.1, 0.5, -1e300) == (-1, 1, -2147483648) and P.quantize_particle(float("nan"), 0.49, 0.0) == (0, 0, 0)
+
+
+def test_reference_seeded_fastslam2_tests_through_both_restatements():
+    """fastslam2.rs:443-456 (StdRng seed 7) and :491-545 (seed 17, `lm_err < 6.0`) replayed draw for draw (tests/fs2_replay.py) through
+    ref_literal.c AND through ref_python.py: the same gate decisions step for step, the same amount of stream consumed, identical bits in
+    every weight, pose and map entry at the end -- and the reference's own assertion holds on both."""
+    from tests import fs2_replay as RP
+
+    for seed, n, lms, x0, u, steps, moves in ((7, 20, [(10.0, 0.0), (0.0, 10.0), (10.0, 10.0)], np.zeros(3), [1.0, 0.1], 5, False),
+                                             (17, 120, [(5.0, 5.0)], np.array([0.0, 0.0, math.pi / 4]), [0.5, 0.0], 60, True)):
+        a, b = RP.LiteralEngine(n, len(lms)), RP.PythonEngine(n, len(lms))
+        fa, rng_a = RP.replay(a, seed, n, lms, x0.copy(), u, steps, truth_moves=moves)
+        fb, rng_b = RP.replay(b, seed, n, lms, x0.copy(), u, steps, truth_moves=moves)
+        assert fa == fb, "gate decisions differ"
+        assert rng_a.next_u64() == rng_b.next_u64(), "the two replays consumed different amounts of the stream"
+        (wa, ma), (wb, mb) = a.state(), b.state()
+        assert np.array_equal(bits(wa), bits(wb)) and np.array_equal(bits(ma), bits(mb))
+        assert np.array_equal(bits(np.column_stack([a.px, a.py, a.pyaw])), bits(b.poses()))
+        if seed == 17:
+            ea, eb = RP.landmark_error(a, (5.0, 5.0)), RP.landmark_error(b, (5.0, 5.0))
+            assert ea == eb and ea < 6.0
+
+
+def test_fastslam2_proposal_sample_and_update_on_random_inputs(ref):
+    """compute_proposal (fastslam2.rs:173-216), sample_pose (:219-239) and update_landmark_and_weight (:242-280) one call at a time:
+    initialised and uninitialised landmarks, asymmetric covariances, a proposal covariance that is not positive definite (the Cholesky
+    gives up: the diagonal fallback) and one with a zero pivot."""
+    rng = np.random.default_rng(31)
+    r = P.R_SIM
+    for trial in range(300):
+        pose = rng.uniform(-3, 3, 3)
+        cov2 = rng.uniform(-0.2, 0.2, (2, 2)) + np.diag(rng.uniform(0.05, 3.0, 2))
+        if trial % 6 == 0:
+            cov2[0, 0] = 1000.0  # uninitialised (Landmark::is_initialized, :49-51)
+        e = np.array([rng.uniform(-8, 8), rng.uniform(-8, 8), cov2[0, 0], cov2[1, 0], cov2[0, 1], cov2[1, 1]])
+        z = (float(rng.uniform(0.5, 15.0)), float(rng.uniform(-3.5, 3.5)))
+        u = (float(rng.uniform(-1, 2)), float(rng.uniform(-1, 1)))
+        q = P.Particle(1, 0.01)
+        q.x, q.y, q.yaw = (float(t) for t in pose)
+        q.landmarks[0] = P.Landmark(float(e[0]), float(e[1]), [[float(cov2[0, 0]), float(cov2[0, 1])], [float(cov2[1, 0]), float(cov2[1, 1])]])
+        mean, cov = np.empty(3), np.empty(9)
+        ref.ref_fs2_proposal(dp(np.ascontiguousarray(pose)), u[0], u[1], z[0], z[1], dp(e), r[0][0], r[1][1], dp(mean), dp(cov))
+        m_p, c_p = P.compute_proposal(q, list(u), list(z), 0, r)
+        assert np.array_equal(bits(mean), bits(m_p)) and np.array_equal(bits(cov), bits(np.array(c_p).reshape(-1))), trial
+        nz = rng.normal(0, 1, 3)
+        c_use = cov.copy()
+        if trial % 7 == 0:
+            c_use[0] = -abs(c_use[0])  # not positive definite: the fallback of :226-233
+        if trial % 11 == 0:
+            c_use[:] = 0.0
+            c_use[4] = c_use[8] = 0.3  # a zero first pivot
+        out = np.empty(3)
+        ref.ref_fs2_sample(dp(mean), dp(c_use), dp(nz), dp(out))
+        sp = P.sample_pose(list(mean), c_use.reshape(3, 3).tolist(), nz.tolist())
+        sp[2] = P.normalize_angle(sp[2])  # (ref_fs2_sample includes set_pose's wrap, fastslam2.rs:78-82)
+        assert np.array_equal(bits(out), bits(sp)), trial
+        e2 = e.copy()
+        w_c = ref.ref_fs2_update_landmark(pose[0], pose[1], pose[2], z[0], z[1], dp(e2), r[0][0], r[1][1])
+        w_p = P.update_landmark_and_weight(q, list(z), 0, r)
+        m = q.landmarks[0]
+        assert bits(w_c) == bits(w_p) and np.array_equal(bits(e2), bits([m.x, m.y, m.cov[0][0], m.cov[1][0], m.cov[0][1], m.cov[1][1]])), trial
