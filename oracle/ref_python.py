@@ -12,6 +12,9 @@ Followed (relative to /root/reference/crates/):
   rust_robotics_slam/src/fastslam1.rs                         :70-77 motion_model, :80-89 normalize_angle, :92-99 observation_model,
       :102-110 compute_jacobian, :123-137 predict_particle, :140-183 update_landmark, :186-193 compute_neff, :196-203 normalize_weights,
       :205-234 resample, :237-266 fastslam_update, :269-274 get_best_particle
+  rust_robotics_slam/src/fastslam2.rs                         :105-118 motion_jacobian, :122-148 observation model and its two Jacobians,
+      :173-216 compute_proposal, :219-239 sample_pose_with_rng, :242-280 update_landmark_and_weight, :331-374 fastslam2_update_with_rng
+  rust_robotics_localization/src/monte_carlo_localization.rs :322-385 resample_adaptive, kld_required_particles, quantize_particle
 nalgebra 0.33.2 (not under /root/reference; restated from its published source): a product of small static matrices is evaluated
 column by column of the right-hand side, every entry summed over k in ascending order, no fused multiply-add (base/blas.rs gemm ->
 gemv -> axcpy); Matrix2::try_inverse is `det = m11 m22 - m21 m12; None if det == 0; [m22, -m12; -m21, m11] / det` (linalg/inverse.rs);
