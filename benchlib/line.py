@@ -125,6 +125,15 @@ def compact_line(out):
     for k in ("strong_scaling_ceiling", "weak_scaling_ceiling"):
         if k in out:
             line[k] = out[k]
+    # resample indices against the LITERAL float walk on identical weights and draws: [differing slots, slots] per scheme (against
+    # the integer CDF of the D-spec they are identical at every size: tests/)
+    ip = {}
+    for src in (out, out.get("mcl_multinomial")):
+        d = src.get("index_parity") if isinstance(src, dict) else None
+        if isinstance(d, dict) and "differing_slots_vs_literal_float_walk" in d:
+            ip[str(d.get("resample", "?"))] = [d["differing_slots_vs_literal_float_walk"], d.get("slots")]
+    if ip:
+        line["index_parity"] = ip
     if legs:
         line["full"] = "bench_legs.json; every leg also as its own JSON line above this one"
     data = json.dumps(line)

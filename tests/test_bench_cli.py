@@ -114,3 +114,18 @@ def test_an_oversized_record_still_yields_a_parseable_line():
         big[f"leg{i}"] = {"ms_per_step": 0.1 * i, "roofline": {"frac": 0.5}}
     s = bench.compact_line(big)
     assert len(s) <= bench.LINE_LIMIT and json.loads(s)["value"] == 1.0
+
+
+def test_the_line_says_how_the_resample_indices_compare_with_the_literal_walk():
+    """north_star: "bit-exact resample indices".  Against the literal FLOAT walk on identical weights and draws a handful of 10^6 slots
+    pick the neighbouring particle (the walk's own rounding); the line keeps saying how many, per scheme."""
+    import json
+
+    import bench
+
+    legs = [json.loads(l) for l in open(os.path.join(ROOT, "profiles", "r06zzz_bench_default.json")).read().strip().splitlines()]
+    out = {k: v for k, v in next(l for l in legs if l.get("leg") == "headline").items() if k != "leg"}
+    out["mcl_multinomial"] = {k: v for k, v in next(l for l in legs if l.get("leg") == "mcl_multinomial").items() if k != "leg"}
+    line = json.loads(bench.compact_line(out))
+    assert line["index_parity"] == {"systematic": [0, 1000000], "multinomial": [3, 1000000]}
+    assert len(json.dumps(line)) <= bench.LINE_LIMIT
