@@ -214,6 +214,7 @@ CASES = {
     # steady state and the worst-case resample
     "mcl-1e8": lambda: [run_mcl("mcl-1e8", WORLD, 12_500_000, 3, peaked=True, L=4),
                         run_mcl("mcl-1e8-heavy-last-rank", WORLD, 12_500_000, 3, peaked=True, L=4, heavy=[(WORLD - 1) * 12_500_000 + 123])],
+    "mcl-multinomial-1e8": lambda: [run_mcl_multinomial("mcl-multinomial-1e8", WORLD, 12_500_000, 3)],
     # BASELINE configs[3]: 8 x 125 000 x 200
     "fs1-small": lambda: [run_fs1("fs1-small", WORLD, 1300, 7, 8, chunks=2), run_fs1("fs2-small", WORLD, 1300, 7, 8, chunks=2, variant=2)],
     "fs1-config4": lambda: [run_fs1("fs1-config4", WORLD, 125_000, 200, 4)],
